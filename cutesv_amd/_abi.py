@@ -1,0 +1,181 @@
+"""ctypes mirror of include/cutesv_hip.h (structs, constants) and numpy-side batch buffers.
+
+Nothing here computes anything: it only lays out memory for the C ABI.  The same struct
+definitions are used by the tests to drive oracle/liboracle.so, which consumes the same
+csv_batch_in / csv_batch_out layout.
+"""
+import ctypes as C
+
+import numpy as np
+
+ABI_VERSION = 1
+DEL, INS, DUP, INV, TRA = 0, 1, 2, 3, 4
+SVTYPE_CODE = {"DEL": DEL, "INS": INS, "DUP": DUP, "INV": INV, "TRA": TRA}
+SVTYPE_NAME = {v: k for k, v in SVTYPE_CODE.items()}
+
+OK, E_INVALID, E_CAPACITY, E_HIP, E_NOMEM, E_UNSORTED, E_STATE = range(7)
+ERR_NAME = {OK: "CSV_OK", E_INVALID: "CSV_E_INVALID", E_CAPACITY: "CSV_E_CAPACITY", E_HIP: "CSV_E_HIP",
+            E_NOMEM: "CSV_E_NOMEM", E_UNSORTED: "CSV_E_UNSORTED", E_STATE: "CSV_E_STATE"}
+N_STAGES = 8
+GL_TABLE_SIZE = 101 * 101 + 2
+
+# numpy dtype with exactly the C layout of `csv_segment` (all members naturally aligned)
+SEGMENT_DTYPE = np.dtype([
+    ("svtype", "<i4"), ("chrom", "<i4"),
+    ("sig_begin", "<i8"), ("sig_end", "<i8"),
+    ("max_cluster_bias", "<i8"),
+    ("diff_ratio", "<f8"), ("remain_reads_ratio", "<f8"),
+    ("sv_size", "<i8"), ("max_size", "<i8"), ("gt_bias", "<i8"),
+    ("read_count", "<i4"), ("min_support_reads", "<i4"),
+    ("genotype", "<i4"), ("reserved", "<i4"),
+], align=True)
+assert SEGMENT_DTYPE.itemsize == 88
+
+
+class BatchIn(C.Structure):
+    _fields_ = [
+        ("n_seg", C.c_int32), ("n_chrom", C.c_int32),
+        ("seg", C.c_void_p),
+        ("n_sig", C.c_int64),
+        ("a", C.c_void_p), ("b", C.c_void_p), ("read_id", C.c_void_p), ("aux", C.c_void_p),
+        ("reads_off", C.c_void_p),
+        ("n_reads", C.c_int64),
+        ("r_start", C.c_void_p), ("r_end", C.c_void_p), ("r_primary", C.c_void_p), ("r_id", C.c_void_p),
+    ]
+
+
+_OUT_ARRAYS = [  # (name, dtype, which capacity)
+    ("call_seg", np.int32, "calls"), ("call_cluster", np.int32, "calls"), ("call_aux", np.int32, "calls"),
+    ("bp1", np.int64, "calls"), ("bp2", np.int64, "calls"),
+    ("support", np.int32, "calls"), ("cipos", np.int32, "calls"), ("cilen", np.int32, "calls"),
+    ("search_pos", np.int64, "calls"), ("seq_pick", np.int64, "calls"),
+    ("dr", np.int32, "calls"), ("dv", np.int32, "calls"), ("gl_idx", np.int32, "calls"),
+    ("support_off", np.int64, "calls+1"), ("support_sig", np.int64, "support"),
+    ("cluster_id", np.int32, "sig"), ("allele_id", np.int32, "sig"),
+]
+
+
+class BatchOut(C.Structure):
+    _fields_ = ([("cap_calls", C.c_int64), ("cap_support", C.c_int64),
+                 ("n_calls", C.c_int64), ("n_support", C.c_int64), ("n_clusters", C.c_int64)]
+                + [(name, C.c_void_p) for name, _, _ in _OUT_ARRAYS])
+
+
+class RunStats(C.Structure):
+    _fields_ = [("ms_total", C.c_float), ("ms_stage", C.c_float * N_STAGES),
+                ("n_clusters", C.c_int64), ("n_work_wave", C.c_int64), ("n_work_block", C.c_int64),
+                ("n_calls", C.c_int64), ("n_support", C.c_int64)]
+
+
+def _ptr(arr):
+    return None if arr is None else arr.ctypes.data
+
+
+def _col(x, dtype):
+    return np.ascontiguousarray(x, dtype=dtype)
+
+
+class HostBatch:
+    """Host-side buffers of one csv_batch_in.  Keeps the numpy arrays alive for the C call."""
+
+    def __init__(self, segments, a, b, read_id, aux, n_chrom=0, reads_off=None,
+                 r_start=None, r_end=None, r_primary=None, r_id=None):
+        self.segments = np.ascontiguousarray(segments, dtype=SEGMENT_DTYPE)
+        self.a = _col(a, np.int64)
+        self.b = _col(b, np.int64)
+        self.read_id = _col(read_id, np.int32)
+        self.aux = _col(aux, np.int32)
+        n = self.a.shape[0]
+        if not (self.b.shape[0] == n and self.read_id.shape[0] == n and self.aux.shape[0] == n):
+            raise ValueError("signature columns differ in length")
+        self.n_chrom = int(n_chrom)
+        if reads_off is not None:
+            self.reads_off = _col(reads_off, np.int64)
+            self.r_start = _col(r_start, np.int64)
+            self.r_end = _col(r_end, np.int64)
+            self.r_primary = _col(r_primary, np.uint8)
+            self.r_id = _col(r_id, np.int32)
+            if self.reads_off.shape[0] != self.n_chrom + 1:
+                raise ValueError("reads_off must have n_chrom + 1 entries")
+        else:
+            self.reads_off = self.r_start = self.r_end = self.r_primary = self.r_id = None
+        self.c = BatchIn(
+            n_seg=len(self.segments), n_chrom=self.n_chrom, seg=_ptr(self.segments),
+            n_sig=n, a=_ptr(self.a), b=_ptr(self.b), read_id=_ptr(self.read_id), aux=_ptr(self.aux),
+            reads_off=_ptr(self.reads_off),
+            n_reads=0 if self.r_start is None else self.r_start.shape[0],
+            r_start=_ptr(self.r_start), r_end=_ptr(self.r_end), r_primary=_ptr(self.r_primary), r_id=_ptr(self.r_id))
+
+    @property
+    def n_sig(self):
+        return self.a.shape[0]
+
+
+class HostResult:
+    """Caller-allocated csv_batch_out plus numpy views on it."""
+
+    def __init__(self, n_sig, cap_calls, cap_support, per_sig=False):
+        self.cap_calls = int(cap_calls)
+        self.cap_support = int(cap_support)
+        self.arrays = {}
+        kw = {}
+        for name, dt, cap in _OUT_ARRAYS:
+            if cap == "sig":
+                arr = np.empty(n_sig, dtype=dt) if per_sig else None
+            elif cap == "calls":
+                arr = np.empty(self.cap_calls, dtype=dt)
+            elif cap == "calls+1":
+                arr = np.zeros(self.cap_calls + 1, dtype=dt)
+            else:
+                arr = np.empty(self.cap_support, dtype=dt)
+            self.arrays[name] = arr
+            kw[name] = _ptr(arr)
+        self.c = BatchOut(cap_calls=self.cap_calls, cap_support=self.cap_support, **kw)
+
+    @property
+    def n_calls(self):
+        return int(self.c.n_calls)
+
+    @property
+    def n_support(self):
+        return int(self.c.n_support)
+
+    @property
+    def n_clusters(self):
+        return int(self.c.n_clusters)
+
+    def trimmed(self):
+        """dict of arrays cut to the produced sizes (views)."""
+        nc, ns = self.n_calls, self.n_support
+        out = {}
+        for name, _, cap in _OUT_ARRAYS:
+            arr = self.arrays[name]
+            if arr is None:
+                out[name] = None
+            elif cap == "calls":
+                out[name] = arr[:nc]
+            elif cap == "calls+1":
+                out[name] = arr[:nc + 1]
+            elif cap == "support":
+                out[name] = arr[:ns]
+            else:
+                out[name] = arr
+        out["n_clusters"] = self.n_clusters
+        return out
+
+
+def make_segment(svtype, chrom, sig_begin, sig_end, max_cluster_bias, read_count, diff_ratio=0.0,
+                 remain_reads_ratio=1.0, sv_size=0, max_size=-1, gt_bias=0, min_support_reads=None, genotype=False):
+    """One csv_segment record (numpy void) from the reference's run_* scalars."""
+    s = np.zeros((), dtype=SEGMENT_DTYPE)
+    s["svtype"] = SVTYPE_CODE[svtype] if isinstance(svtype, str) else svtype
+    s["chrom"] = chrom
+    s["sig_begin"], s["sig_end"] = sig_begin, sig_end
+    s["max_cluster_bias"] = max_cluster_bias
+    s["diff_ratio"] = diff_ratio
+    s["remain_reads_ratio"] = remain_reads_ratio
+    s["sv_size"], s["max_size"], s["gt_bias"] = sv_size, max_size, gt_bias
+    s["read_count"] = read_count
+    s["min_support_reads"] = min(read_count, 5) if min_support_reads is None else min_support_reads
+    s["genotype"] = 1 if genotype else 0
+    return s

@@ -1,0 +1,343 @@
+"""Flat columnar signature store — the input side of the hot path.
+
+The reference keeps signatures as pickled lists of Python tuples, one list per (SV type,
+chromosome), in `<work_dir>/<TYPE>.pickle` at the byte offsets of `sigindex.pickle`
+(cuteSV main script :817-857, 1092-1093).  This module holds the same information as flat
+little-endian columns, already in the layout of `csv_batch_in` (include/cutesv_hip.h), so a
+whole genome goes to the GPU in one H2D copy:
+
+    a:int64[N]  b:int64[N]  read_id:int32[N]  aux:int32[N]     + segment table (type, chrom, begin, end)
+    reads: r_start:int64[R] r_end:int64[R] r_primary:u8[R] r_id:int32[R] + reads_off[n_chrom+1]
+
+Order contract: inside a segment, rows are in the order the reference's
+rebuild step leaves them (main script :764-802 sort keys, :958-969 adjacent de-duplication);
+read ids are interned so that id order == Python string order of the names, which makes the
+reference's name tie-break an integer comparison.  The reads block of a chromosome is sorted
+by start here (the reference sorts its sweep-line events itself, cuteSV_genotype.py:109).
+"""
+import json
+import os
+import pickle
+from dataclasses import dataclass, field, asdict
+
+import numpy as np
+
+from . import _abi
+
+TYPES = ("DEL", "INS", "INV", "DUP", "TRA")      # the reference's submission order (main script :1116-1189)
+BND_CODE = {"A": 0, "B": 1, "C": 2, "D": 3}
+BND_NAME = "ABCD"
+
+
+@dataclass
+class Params:
+    """The hot-path flags of cuteSV_Description.py:53-263 with their defaults."""
+    min_support: int = 10
+    min_size: int = 30
+    max_size: int = 100000
+    genotype: bool = False
+    gt_round: int = 500
+    max_cluster_bias_INS: int = 100
+    diff_ratio_merging_INS: float = 0.3
+    max_cluster_bias_DEL: int = 200
+    diff_ratio_merging_DEL: float = 0.5
+    max_cluster_bias_INV: int = 500
+    max_cluster_bias_DUP: int = 500
+    max_cluster_bias_TRA: int = 50
+    diff_ratio_filtering_TRA: float = 0.6
+    remain_reads_ratio: float = 1.0
+
+    @classmethod
+    def ont(cls, **kw):          # README preset: INS 100/0.3, DEL 100/0.3
+        return cls(max_cluster_bias_INS=100, diff_ratio_merging_INS=0.3,
+                   max_cluster_bias_DEL=100, diff_ratio_merging_DEL=0.3, **kw)
+
+    @classmethod
+    def hifi(cls, **kw):         # INS 1000/0.9, DEL 1000/0.5
+        return cls(max_cluster_bias_INS=1000, diff_ratio_merging_INS=0.9,
+                   max_cluster_bias_DEL=1000, diff_ratio_merging_DEL=0.5, **kw)
+
+    @classmethod
+    def clr(cls, **kw):          # INS 100/0.3, DEL 200/0.5 (== defaults)
+        return cls(max_cluster_bias_INS=100, diff_ratio_merging_INS=0.3,
+                   max_cluster_bias_DEL=200, diff_ratio_merging_DEL=0.5, **kw)
+
+
+class NameTable:
+    """read_id -> read name.  Either an explicit list (ids index it) or a fixed-width
+    synthetic scheme whose string order equals id order."""
+
+    def __init__(self, names=None, fmt="r%09d"):
+        self.names = None if names is None else list(names)
+        self.fmt = fmt
+
+    def __getitem__(self, i):
+        return self.names[int(i)] if self.names is not None else self.fmt % int(i)
+
+    def take(self, ids):
+        if self.names is not None:
+            n = self.names
+            return [n[int(i)] for i in ids]
+        f = self.fmt
+        return [f % int(i) for i in ids]
+
+    def __len__(self):
+        return len(self.names) if self.names is not None else 0
+
+
+def intern_names(*name_lists):
+    """Rank-preserving interning: returns (sorted unique names, [id arrays...])."""
+    uniq = sorted(set().union(*[set(x) for x in name_lists]))
+    rank = {n: i for i, n in enumerate(uniq)}
+    return uniq, [np.fromiter((rank[n] for n in lst), dtype=np.int32, count=len(lst)) for lst in name_lists]
+
+
+@dataclass
+class SigStore:
+    chroms: list                                  # chromosome names; index = chrom id (also the chr2 rank for TRA)
+    a: np.ndarray
+    b: np.ndarray
+    read_id: np.ndarray
+    aux: np.ndarray
+    seg_index: dict                               # (type name, chrom name) -> (begin, end)
+    names: NameTable = field(default_factory=NameTable)
+    ins_seq: object = None                        # None (synthetic: "ACGT" repeated to aux length) or dict sig index -> str
+    strands: tuple = ("++", "--")                 # INV aux code -> strand string
+    reads_off: np.ndarray = None
+    r_start: np.ndarray = None
+    r_end: np.ndarray = None
+    r_primary: np.ndarray = None
+    r_id: np.ndarray = None
+
+    # ------------------------------------------------------------------ basic access
+    @property
+    def n_sig(self):
+        return int(self.a.shape[0])
+
+    @property
+    def n_reads(self):
+        return 0 if self.r_start is None else int(self.r_start.shape[0])
+
+    def has_reads(self, chrom):
+        if self.reads_off is None:
+            return False
+        c = self.chroms.index(chrom)
+        return bool(self.reads_off[c + 1] > self.reads_off[c])
+
+    def sequence(self, sig):
+        """Inserted sequence of INS signature `sig` (global index)."""
+        if self.ins_seq is None:
+            n = int(self.aux[sig])
+            return ("ACGT" * (n // 4 + 1))[:n]
+        return self.ins_seq[int(sig)]
+
+    # ------------------------------------------------------------------ segments / batches
+    def segment(self, svtype, chrom, p: Params):
+        """csv_segment record for one reference task, scalars as main script :1117-1188 passes them."""
+        beg, end = self.seg_index[(svtype, chrom)]
+        c = self.chroms.index(chrom)
+        if svtype in ("DEL", "INS"):
+            bias = p.max_cluster_bias_DEL if svtype == "DEL" else p.max_cluster_bias_INS
+            ratio = p.diff_ratio_merging_DEL if svtype == "DEL" else p.diff_ratio_merging_INS
+            return _abi.make_segment(svtype, c, beg, end, bias, p.min_support, diff_ratio=ratio,
+                                     remain_reads_ratio=p.remain_reads_ratio,
+                                     gt_bias=bias if svtype == "DEL" else 1000,
+                                     min_support_reads=min(p.min_support, 5), genotype=p.genotype)
+        if svtype == "INV":
+            return _abi.make_segment(svtype, c, beg, end, p.max_cluster_bias_INV, p.min_support,
+                                     sv_size=p.min_size, max_size=p.max_size, gt_bias=p.max_cluster_bias_INV,
+                                     genotype=p.genotype)
+        if svtype == "DUP":
+            return _abi.make_segment(svtype, c, beg, end, p.max_cluster_bias_DUP, p.min_support,
+                                     sv_size=p.min_size, max_size=p.max_size, gt_bias=p.max_cluster_bias_DUP,
+                                     genotype=p.genotype)
+        if svtype == "TRA":
+            # TRA genotyping re-opens the BAM (cuteSV_resolveTRA.py:260-309): not part of this path
+            return _abi.make_segment(svtype, c, beg, end, p.max_cluster_bias_TRA, p.min_support,
+                                     diff_ratio=p.diff_ratio_filtering_TRA, genotype=False)
+        raise ValueError(svtype)
+
+    def tasks(self, types=TYPES, chroms=None):
+        """(type, chrom) pairs in the reference's submission order (main script :1116-1189)."""
+        out = []
+        for t in types:
+            for (tt, ch) in self.seg_index:
+                if tt == t and (chroms is None or ch in chroms):
+                    out.append((t, ch))
+        return out
+
+    def host_batch(self, tasks, p: Params):
+        segs = np.array([self.segment(t, ch, p) for t, ch in tasks], dtype=_abi.SEGMENT_DTYPE)
+        need_reads = bool(segs["genotype"].any()) if len(segs) else False
+        kw = {}
+        if need_reads and self.reads_off is not None:
+            kw = dict(reads_off=self.reads_off, r_start=self.r_start, r_end=self.r_end,
+                      r_primary=self.r_primary, r_id=self.r_id)
+        return _abi.HostBatch(segs, self.a, self.b, self.read_id, self.aux, n_chrom=len(self.chroms), **kw)
+
+    # ------------------------------------------------------------------ persistence (flat .cols directory)
+    def save(self, path):
+        os.makedirs(path, exist_ok=True)
+        cols = dict(a=self.a, b=self.b, read_id=self.read_id, aux=self.aux)
+        if self.reads_off is not None:
+            cols.update(reads_off=self.reads_off, r_start=self.r_start, r_end=self.r_end,
+                        r_primary=self.r_primary, r_id=self.r_id)
+        for k, v in cols.items():
+            np.save(os.path.join(path, k + ".npy"), v)
+        meta = dict(chroms=self.chroms, strands=list(self.strands),
+                    seg_index=[[t, c, int(b), int(e)] for (t, c), (b, e) in self.seg_index.items()],
+                    names=self.names.names, name_fmt=self.names.fmt,
+                    ins_seq=None if self.ins_seq is None else {str(k): v for k, v in self.ins_seq.items()})
+        with open(os.path.join(path, "sigindex.json"), "w") as f:
+            json.dump(meta, f)
+
+    @classmethod
+    def load(cls, path, mmap=True):
+        with open(os.path.join(path, "sigindex.json")) as f:
+            meta = json.load(f)
+        ld = lambda k: np.load(os.path.join(path, k + ".npy"), mmap_mode="r" if mmap else None)
+        kw = {}
+        if os.path.exists(os.path.join(path, "reads_off.npy")):
+            kw = {k: ld(k) for k in ("reads_off", "r_start", "r_end", "r_primary", "r_id")}
+        return cls(chroms=meta["chroms"], a=ld("a"), b=ld("b"), read_id=ld("read_id"), aux=ld("aux"),
+                   seg_index={(t, c): (b, e) for t, c, b, e in meta["seg_index"]},
+                   names=NameTable(meta["names"], meta["name_fmt"]), strands=tuple(meta["strands"]),
+                   ins_seq=None if meta["ins_seq"] is None else {int(k): v for k, v in meta["ins_seq"].items()}, **kw)
+
+    # ------------------------------------------------------------------ conversion from the reference's layout
+    @classmethod
+    def from_tuple_lists(cls, per_type, reads=None, chroms=None):
+        """Build the flat store from the reference's in-memory representation.
+
+        per_type: {"DEL": [(pos, len, read, "DEL", chr), ...], "INS": [(pos, len, read, seq, "INS", chr)],
+                   "DUP": [(p1, p2, read, "DUP", chr)], "INV": [(strand, p1, p2, read, "INV", chr)],
+                   "TRA": [(type, p1, chr2, p2, read, "TRA", chr1)]}   (main script :228-257, 520-575)
+        reads:    [(start, end, is_primary, read, chr)]                  (main script :733)
+        The lists are sorted and adjacent-deduplicated here exactly as the rebuild step does
+        (main script :764-802, 958-969), so unsorted extraction output may be passed in.
+        """
+        keys = {
+            "DEL": lambda x: (x[-1], int(x[0]), x[1], x[2]),
+            "INS": lambda x: (x[-1], int(x[0]), x[1], x[2], x[3]),
+            "DUP": lambda x: (x[-1], int(x[0]), int(x[1]), x[2]),
+            "INV": lambda x: (x[-1], x[0], int(x[1]), x[2], x[3]),
+            "TRA": lambda x: (x[-1], x[2], x[0], int(x[1]), x[3], x[4], x[5]),
+        }
+        lists = {}
+        for t in TYPES:
+            lst = sorted(per_type.get(t, []), key=keys[t])
+            ded = []
+            for x in lst:                      # adjacent exact duplicates only (main script :958-969)
+                if not ded or ded[-1] != x:
+                    ded.append(x)
+            lists[t] = ded
+        reads = list(reads or [])
+        name_pos = {"DEL": 2, "INS": 2, "DUP": 2, "INV": 3, "TRA": 4}
+        all_names = set(r[3] for r in reads)
+        for t in TYPES:
+            all_names.update(x[name_pos[t]] for x in lists[t])
+        uniq = sorted(all_names)
+        rank = {n: i for i, n in enumerate(uniq)}
+        if chroms is None:
+            cs = set(r[4] for r in reads)
+            for t in TYPES:
+                cs.update(x[-1] for x in lists[t])
+            cs.update(x[2] for x in lists["TRA"])
+            chroms = sorted(cs)
+        chrom_rank = {c: i for i, c in enumerate(chroms)}
+        strands = sorted(set(x[0] for x in lists["INV"])) or ["++", "--"]
+        strand_code = {s: i for i, s in enumerate(strands)}
+
+        a, b, rid, aux, seg_index, ins_seq = [], [], [], [], {}, {}
+        n = 0
+        for t in TYPES:
+            cur, beg = None, n
+            for x in lists[t]:
+                ch = x[-1]
+                if ch != cur:
+                    if cur is not None:
+                        seg_index[(t, cur)] = (beg, n)
+                    cur, beg = ch, n
+                if t == "DEL":
+                    a.append(int(x[0])); b.append(int(x[1])); rid.append(rank[x[2]]); aux.append(0)
+                elif t == "INS":
+                    a.append(int(x[0])); b.append(int(x[1])); rid.append(rank[x[2]]); aux.append(len(x[3]))
+                    ins_seq[n] = x[3]
+                elif t == "DUP":
+                    a.append(int(x[0])); b.append(int(x[1])); rid.append(rank[x[2]]); aux.append(0)
+                elif t == "INV":
+                    a.append(int(x[1])); b.append(int(x[2])); rid.append(rank[x[3]]); aux.append(strand_code[x[0]])
+                else:
+                    code = BND_CODE.get(x[0], 4)
+                    a.append(int(x[1])); b.append(int(x[3])); rid.append(rank[x[4]])
+                    aux.append(chrom_rank[x[2]] * 8 + code)
+                n += 1
+            if cur is not None:
+                seg_index[(t, cur)] = (beg, n)
+
+        kw = {}
+        if reads:
+            per = {c: [] for c in chroms}
+            for r in reads:
+                per[r[4]].append(r)
+            off, rs, re_, rp, ri = [0], [], [], [], []
+            for c in chroms:
+                blk = sorted(per[c], key=lambda r: r[0])     # start-sorted block (stable)
+                rs += [int(r[0]) for r in blk]; re_ += [int(r[1]) for r in blk]
+                rp += [int(r[2]) for r in blk]; ri += [rank[r[3]] for r in blk]
+                off.append(len(rs))
+            kw = dict(reads_off=np.array(off, np.int64), r_start=np.array(rs, np.int64), r_end=np.array(re_, np.int64),
+                      r_primary=np.array(rp, np.uint8), r_id=np.array(ri, np.int32))
+        return cls(chroms=list(chroms), a=np.array(a, np.int64), b=np.array(b, np.int64),
+                   read_id=np.array(rid, np.int32), aux=np.array(aux, np.int32), seg_index=seg_index,
+                   names=NameTable(uniq), ins_seq=ins_seq, strands=tuple(strands), **kw)
+
+    @classmethod
+    def from_reference_workdir(cls, work_dir, sigs_index=None):
+        """Read the reference's own `<TYPE>.pickle` / `reads.pickle` / `sigindex.pickle` files
+        (main script :817-857, 1092-1093) into the flat layout.  Needs only `pickle`."""
+        if not work_dir.endswith("/"):
+            work_dir += "/"
+        if sigs_index is None:
+            with open(work_dir + "sigindex.pickle", "rb") as f:
+                sigs_index = pickle.load(f)
+        per_type, reads = {}, []
+        for t in TYPES:
+            per_type[t] = []
+            for ch, off in sigs_index.get(t, {}).items():
+                with open("%s%s.pickle" % (work_dir, t), "rb") as f:
+                    f.seek(off)
+                    per_type[t].extend(pickle.load(f))
+        for ch, off in sigs_index.get("reads", {}).items():
+            with open(work_dir + "reads.pickle", "rb") as f:
+                f.seek(off)
+                reads.extend(pickle.load(f))
+        return cls.from_tuple_lists(per_type, reads)
+
+    # ------------------------------------------------------------------ the inverse (tests / golden generation)
+    def tuple_lists(self):
+        """Reference-format tuple lists per type and the reads list (inverse of from_tuple_lists)."""
+        out = {t: [] for t in TYPES}
+        for (t, ch), (beg, end) in self.seg_index.items():
+            names = self.names.take(self.read_id[beg:end])
+            for k, i in enumerate(range(beg, end)):
+                a, b, nm, ax = int(self.a[i]), int(self.b[i]), names[k], int(self.aux[i])
+                if t == "DEL":
+                    out[t].append((a, b, nm, "DEL", ch))
+                elif t == "INS":
+                    out[t].append((a, b, nm, self.sequence(i), "INS", ch))
+                elif t == "DUP":
+                    out[t].append((a, b, nm, "DUP", ch))
+                elif t == "INV":
+                    out[t].append((self.strands[ax], a, b, nm, "INV", ch))
+                else:
+                    code = ax & 7
+                    out[t].append((BND_NAME[code] if code < 4 else "X", a, self.chroms[ax >> 3], b, nm, "TRA", ch))
+        reads = []
+        if self.reads_off is not None:
+            for c, ch in enumerate(self.chroms):
+                lo, hi = int(self.reads_off[c]), int(self.reads_off[c + 1])
+                names = self.names.take(self.r_id[lo:hi])
+                for k, i in enumerate(range(lo, hi)):
+                    reads.append((int(self.r_start[i]), int(self.r_end[i]), int(self.r_primary[i]), names[k], ch))
+        return out, reads

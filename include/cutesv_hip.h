@@ -1,0 +1,193 @@
+/*
+ * cutesv_hip.h — C ABI of libcutesv_hip.so, the MI355X (gfx950) implementation of
+ * cuteSV's signature clustering-and-refinement stage and its genotyping re-cluster.
+ *
+ * Every entry point replaces one piece of the reference's Python interface for this
+ * path.  Reference citations are into /root/reference/src/cuteSV/ (v2.1.4):
+ *   INDEL = cuteSV_resolveINDEL.py   DUP = cuteSV_resolveDUP.py   INV = cuteSV_resolveINV.py
+ *   TRA   = cuteSV_resolveTRA.py     GT  = cuteSV_genotype.py     MAIN = cuteSV (main script)
+ *
+ * Boundary rules:
+ *   - plain pointers and sizes only; the caller owns every host buffer, the library
+ *     never retains a host pointer after a call returns;
+ *   - device memory belongs to a per-process context (grow-only arena, one HIP stream);
+ *   - a context is not thread-safe; distinct contexts are independent; create it
+ *     AFTER fork (one HIP device per worker process, as MAIN:1113 uses one task per
+ *     pool worker);
+ *   - errors are returned as non-zero ints, never abort(); text via csv_last_error().
+ *
+ * The same structs are consumed by oracle/liboracle.so (csvo_cluster_batch), the CPU
+ * restatement used only by tests/, smoke() and bench.py's cpu_baseline leg.
+ */
+#ifndef CUTESV_HIP_H
+#define CUTESV_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CSV_ABI_VERSION 1
+
+/* SV types: one (chromosome, type) pair is one segment == one reference pool task
+ * (MAIN:1116-1189).  Order of the enum is irrelevant to results. */
+enum { CSV_DEL = 0, CSV_INS = 1, CSV_DUP = 2, CSV_INV = 3, CSV_TRA = 4 };
+
+enum {
+    CSV_OK = 0,
+    CSV_E_INVALID = 1,   /* bad argument / unsupported combination (e.g. TRA + genotype) */
+    CSV_E_CAPACITY = 2,  /* output arrays too small; n_calls / n_support hold the need */
+    CSV_E_HIP = 3,       /* a HIP runtime call failed; see csv_last_error */
+    CSV_E_NOMEM = 4,
+    CSV_E_UNSORTED = 5,  /* reads table of some chromosome is not sorted by start */
+    CSV_E_STATE = 6      /* run/download without a preceding upload */
+};
+
+/*
+ * One (chromosome, SV type) task.  The scalar fields are the positional arguments of the
+ * reference's run_* tuples:
+ *   DEL/INS  INDEL:17-18, 222-223  (read_count, threshold_gloab, max_cluster_bias,
+ *            minimum_support_reads, action, remain_reads_ratio)
+ *   DUP      DUP:17-18   (read_count, max_cluster_bias, sv_size, action, MaxSize)
+ *   INV      INV:6-7     (read_count, max_cluster_bias, sv_size, action, MaxSize)
+ *   TRA      TRA:30      (read_count, overlap_size, max_cluster_bias)
+ */
+typedef struct csv_segment {
+    int32_t svtype;             /* CSV_DEL..CSV_TRA */
+    int32_t chrom;              /* index into reads_off[] (selects the reads block) */
+    int64_t sig_begin;          /* [sig_begin, sig_end) in the signature columns */
+    int64_t sig_end;
+    int64_t max_cluster_bias;   /* INDEL:61, DUP:35, INV:56, TRA:65 */
+    double  diff_ratio;         /* INDEL threshold_gloab (INDEL:138) / TRA overlap_size (TRA:134,211) */
+    double  remain_reads_ratio; /* INDEL:46-47,169 (clamped to <= 1 by the library as well) */
+    int64_t sv_size;            /* DUP:112 / INV:132 minimum size */
+    int64_t max_size;           /* DUP:112 / INV:134 MaxSize, -1 = unlimited */
+    int64_t gt_bias;            /* genotype half window: DEL max_cluster_bias (INDEL:103),
+                                   INS 1000 (INDEL:312), DUP/INV max_cluster_bias (DUP:72, INV:94) */
+    int32_t read_count;         /* min_support */
+    int32_t min_support_reads;  /* min(min_support, 5), MAIN:1124 */
+    int32_t genotype;           /* the reference's `action` flag */
+    int32_t reserved;
+} csv_segment;
+
+/*
+ * Flat signature / reads columns.  Within a segment the rows are in
+ * the reference's sorted, adjacent-deduplicated order (MAIN:764-802, 958-969).
+ *   a        int(pos) (DEL/INS)  | pos1 (DUP/INV/TRA)
+ *   b        length (DEL/INS)    | pos2 (DUP/INV/TRA)
+ *   read_id  interned read name; equal ids <=> equal names
+ *   aux      INS: len(inserted sequence) | INV: strand code | TRA: chr2_rank*8 + BND type code (A..D = 0..3,
+ *            codes 4..7 = any other BND type:
+ *            the library emits nothing for it, TRA:154-155) | DEL/DUP: ignored
+ * Reads table (MAIN:733): one block per chromosome, sorted by r_start inside the block.
+ */
+typedef struct csv_batch_in {
+    int32_t            n_seg;
+    int32_t            n_chrom;
+    const csv_segment* seg;
+    int64_t            n_sig;
+    const int64_t*     a;
+    const int64_t*     b;
+    const int32_t*     read_id;
+    const int32_t*     aux;
+    const int64_t*     reads_off;   /* n_chrom + 1 offsets; NULL when no segment genotypes */
+    int64_t            n_reads;
+    const int64_t*     r_start;
+    const int64_t*     r_end;
+    const uint8_t*     r_primary;
+    const int32_t*     r_id;
+} csv_batch_in;
+
+/*
+ * Caller-allocated structure-of-arrays result.  One entry per candidate SV ("call"), in the
+ * reference's emission order: segments in input order, clusters in file order, alleles /
+ * sub-clusters in the order the reference appends them (INDEL:163-219, DUP:95-131, INV:124-203,
+ * TRA:131-254).  Field meaning per type:
+ *             bp1                  bp2                    support             search_pos
+ *   DEL   int(breakpointStart)  int(signalLen) (>0)   allele read count    search_threshold (INDEL:177)
+ *   INS   int(breakpointStart)  int(signalLen)        allele read count    = bp1 (INDEL:415)
+ *   DUP   breakpoint_1          breakpoint_2          unique reads         -
+ *   INV   breakpoint_1          breakpoint_2          unique reads         -
+ *   TRA   int(sum p1 / n)       int(sum p2 / n)       unique reads         -
+ * cipos / cilen: the integer inside cal_CIPOS's "-%d,%d" (GT:58-60), DEL/INS only.
+ * seq_pick: INS only, global signature index whose sequence is sliced for ALT (INDEL:399-403).
+ * call_aux: aux of the cluster's first signature (INV strand / TRA chr2,type).
+ * dr / dv / gl_idx: genotype read counts (GT:161-173) and the index of cal_GL's result
+ *   (GT:33-56) in the table defined by csv_gl_index(); -1 when the segment is not genotyped.
+ * support_off/support_sig: CSR list of the signatures whose read names form the call's
+ *   read list, in reference order where that order is deterministic.
+ * cluster_id / allele_id: optional per-signature outputs (NULL to skip): dense id of the
+ *   chained cluster a signature belongs to, and the index of the call (0-based, global)
+ *   it supports or -1.
+ */
+typedef struct csv_batch_out {
+    int64_t  cap_calls;
+    int64_t  cap_support;
+    int64_t  n_calls;       /* out */
+    int64_t  n_support;     /* out */
+    int64_t  n_clusters;    /* out: chained clusters over the whole batch */
+    int32_t* call_seg;
+    int32_t* call_cluster;
+    int32_t* call_aux;
+    int64_t* bp1;
+    int64_t* bp2;
+    int32_t* support;
+    int32_t* cipos;
+    int32_t* cilen;
+    int64_t* search_pos;
+    int64_t* seq_pick;
+    int32_t* dr;
+    int32_t* dv;
+    int32_t* gl_idx;
+    int64_t* support_off;   /* cap_calls + 1 */
+    int64_t* support_sig;   /* cap_support */
+    int32_t* cluster_id;    /* n_sig or NULL */
+    int32_t* allele_id;     /* n_sig or NULL */
+} csv_batch_out;
+
+/* Per-stage device timings of one csv_batch_run, measured with HIP events on the
+ * context's stream.  Stage names: csv_stage_name(i). */
+#define CSV_N_STAGES 8
+typedef struct csv_run_stats {
+    float   ms_total;
+    float   ms_stage[CSV_N_STAGES];
+    int64_t n_clusters;
+    int64_t n_work_wave;    /* clusters refined by the one-wavefront-per-cluster tier */
+    int64_t n_work_block;   /* clusters refined by the workgroup (LDS / global scratch) tier */
+    int64_t n_calls;
+    int64_t n_support;
+} csv_run_stats;
+
+typedef struct csv_ctx csv_ctx;
+
+int         csv_abi_version(void);
+int         csv_device_count(int* n);
+int         csv_ctx_create(int device_id, csv_ctx** out);
+void        csv_ctx_destroy(csv_ctx* ctx);
+const char* csv_last_error(const csv_ctx* ctx);
+const char* csv_stage_name(int stage);
+
+/* One-shot: H2D, all kernels, D2H.  Replaces the bodies of resolution_DEL/INS/DUP/INV/TRA
+ * (INDEL:17-108, 222-317; DUP:17-77; INV:6-99; TRA:30-104) and of call_gt -> overlap_cover
+ * -> assign_gt (INDEL:441-479, DUP:137-181, INV:208-252, GT:95-173) for every segment of
+ * the batch at once. */
+int csv_cluster_batch(csv_ctx* ctx, const csv_batch_in* in, csv_batch_out* out);
+
+/* Resident mode: the same work split at the PCIe boundary, so a caller (or bench.py) can
+ * keep the columns in HBM and run the kernels repeatedly. */
+int csv_batch_upload(csv_ctx* ctx, const csv_batch_in* in);
+int csv_batch_run(csv_ctx* ctx, csv_run_stats* stats /* nullable */);
+int csv_batch_download(csv_ctx* ctx, csv_batch_out* out);
+int csv_ctx_sync(csv_ctx* ctx);
+
+/* cal_GL's domain after its special cases and rescale_read_counts (GT:25-37): returns the
+ * table index the device writes into gl_idx for (DR, DV) = (c0, c1).  Host-side helper so
+ * the Python shim and the tests share one definition with the kernels. */
+int32_t csv_gl_index(int64_t c0, int64_t c1);
+#define CSV_GL_TABLE_SIZE (101 * 101 + 2)
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CUTESV_HIP_H */

@@ -1,0 +1,687 @@
+/*
+ * cutesv_oracle.c — CPU restatement of cuteSV's clustering-and-refinement hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load liboracle.so.  The product path (cutesv_amd/) never
+ * imports, links or executes anything in oracle/.
+ *
+ * Parity pin: the reference ships no tests for this path ("parity unpinned by the
+ * reference").  This restatement is pinned instead by golden vectors made in
+ * the build container by importing the reference itself (tests/golden/make_golden.py ->
+ * tests/golden/ (json + npz files); checked by tests/test_oracle_golden.py).
+ *
+ * It follows the reference function by function (citations into /root/reference/src/cuteSV/):
+ *   chain()           resolution_DEL/INS/DUP/INV/TRA outer loops
+ *                     cuteSV_resolveINDEL.py:55-100, 261-310; cuteSV_resolveDUP.py:28-70;
+ *                     cuteSV_resolveINV.py:45-92; cuteSV_resolveTRA.py:39-102
+ *   refine_indel()    generate_del_cluster / generate_ins_cluster  cuteSV_resolveINDEL.py:110-219, 319-432
+ *   refine_dup()      generate_dup_cluster        cuteSV_resolveDUP.py:79-131
+ *   refine_inv()      generate_semi_inv_cluster   cuteSV_resolveINV.py:101-203
+ *   refine_tra()      generate_semi_tra_cluster   cuteSV_resolveTRA.py:106-254
+ *   genotype()        call_gt -> overlap_cover -> assign_gt
+ *                     cuteSV_resolveINDEL.py:441-458, cuteSV_resolveDUP.py:137-165,
+ *                     cuteSV_resolveINV.py:208-235, cuteSV_genotype.py:95-173
+ *   csvo_gl_index()   cal_GL special cases + rescale_read_counts  cuteSV_genotype.py:25-39
+ * numpy arithmetic on the path (np.mean, np.std) is restated bit for bit: np_sum_f64() is
+ * numpy 2.2's pairwise summation (8 strided accumulators per <=128 block, recursive halving,
+ * 8192-element buffer chunks), verified against numpy in tests/test_oracle_golden.py.
+ *
+ * Build: make -C oracle   (gcc -O2 -ffp-contract=off: no FMA contraction, IEEE double)
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/cutesv_hip.h"
+
+/* ------------------------------------------------------------------ numpy arithmetic */
+
+static double pairwise_f64(const double* a, int64_t n)
+{
+    if (n < 8) {
+        double r = 0.0;
+        for (int64_t i = 0; i < n; i++) r += a[i];
+        return r;
+    }
+    if (n <= 128) {
+        double r[8];
+        int64_t i;
+        for (int j = 0; j < 8; j++) r[j] = a[j];
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; j++) r[j] += a[i + j];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; i++) res += a[i];
+        return res;
+    }
+    int64_t n2 = n / 2;
+    n2 -= n2 % 8;
+    return pairwise_f64(a, n2) + pairwise_f64(a + n2, n - n2);
+}
+
+/* np.add.reduce over a contiguous float64 vector (numpy 2.2, default bufsize 8192). */
+double csvo_np_sum_f64(const double* a, int64_t n)
+{
+    double acc = 0.0;
+    for (int64_t i = 0; i < n; i += 8192) {
+        int64_t c = n - i < 8192 ? n - i : 8192;
+        acc += pairwise_f64(a + i, c);
+    }
+    return acc;
+}
+
+/* np.std(list_of_ints): mean = sum/n (exact integer sum), sqrt(sum((x-mean)^2)/n). */
+double csvo_np_std_i64(const int64_t* v, int64_t n, double* scratch)
+{
+    int64_t s = 0;
+    for (int64_t i = 0; i < n; i++) s += v[i];
+    double mean = (double)s / (double)n;
+    for (int64_t i = 0; i < n; i++) {
+        double x = (double)v[i] - mean;
+        scratch[i] = x * x;
+    }
+    return sqrt(csvo_np_sum_f64(scratch, n) / (double)n);
+}
+
+/* cal_CIPOS (cuteSV_genotype.py:58-60): int(1.96 * std / num ** 0.5).  `num ** 0.5` is libm
+ * pow(), which is NOT always equal to sqrt() (first difference at num = 2921). */
+int32_t csvo_cipos(double std, int64_t num)
+{
+    return (int32_t)(1.96 * std / pow((double)num, 0.5));
+}
+
+/* cal_GL's input normalisation (cuteSV_genotype.py:25-39) -> table index. */
+int32_t csvo_gl_index(int64_t c0, int64_t c1)
+{
+    if (c0 == 3 && c1 == 1) return 101 * 101;
+    if (c0 == 6 && c1 == 2) return 101 * 101 + 1;
+    int64_t total = c0 + c1;
+    if (total > 100) {
+        double frac = (double)c0 / (double)total;
+        c0 = (int64_t)(100.0 * frac);
+        c1 = 100 - c0;
+    }
+    return (int32_t)(c0 * 101 + c1);
+}
+
+/* ------------------------------------------------------------------ small helpers */
+
+typedef struct {
+    const csv_batch_in* in;
+    csv_batch_out*      out;
+    int64_t             n_calls;
+    int64_t             n_support;
+    /* per-call pending genotype info is taken from the out arrays themselves */
+    /* grow-only scratch */
+    int64_t  cap;
+    int64_t* idx;       /* working permutation */
+    int64_t* idx2;
+    int64_t* tmp;
+    int64_t* vals;
+    int64_t* vals2;
+    double*  dev;
+    double*  sq;
+    int32_t* ids;
+    int32_t* ids2;
+    /* reads: prefix max of r_end per chromosome block */
+    int64_t* pmax;
+} work_t;
+
+static int ensure(work_t* w, int64_t m)
+{
+    if (m <= w->cap) return 0;
+    int64_t c = w->cap ? w->cap : 1024;
+    while (c < m) c *= 2;
+#define GROW(p, T) do { void* q = realloc(w->p, (size_t)c * sizeof(T)); if (!q) return -1; w->p = (T*)q; } while (0)
+    GROW(idx, int64_t); GROW(idx2, int64_t); GROW(tmp, int64_t); GROW(vals, int64_t); GROW(vals2, int64_t);
+    GROW(dev, double); GROW(sq, double); GROW(ids, int32_t); GROW(ids2, int32_t);
+#undef GROW
+    w->cap = c;
+    return 0;
+}
+
+/* stable merge sort of an index array by an int64 key column */
+static void msort_i64(int64_t* idx, int64_t* tmp, int64_t n, const int64_t* key)
+{
+    if (n < 2) return;
+    if (n <= 16) {
+        for (int64_t i = 1; i < n; i++) {
+            int64_t x = idx[i], k = key[x], j = i;
+            while (j > 0 && key[idx[j - 1]] > k) { idx[j] = idx[j - 1]; j--; }
+            idx[j] = x;
+        }
+        return;
+    }
+    int64_t h = n / 2;
+    msort_i64(idx, tmp, h, key);
+    msort_i64(idx + h, tmp, n - h, key);
+    int64_t i = 0, j = h, o = 0;
+    while (i < h && j < n) tmp[o++] = (key[idx[j]] < key[idx[i]]) ? idx[j++] : idx[i++];
+    while (i < h) tmp[o++] = idx[i++];
+    while (j < n) tmp[o++] = idx[j++];
+    memcpy(idx, tmp, (size_t)n * sizeof(int64_t));
+}
+
+/* stable sort of local indices 0..n-1 by a double key (deviation sort, INDEL:171-173) */
+static void msort_f64(int64_t* idx, int64_t* tmp, int64_t n, const double* key)
+{
+    if (n < 2) return;
+    if (n <= 16) {
+        for (int64_t i = 1; i < n; i++) {
+            int64_t x = idx[i], j = i;
+            double  k = key[x];
+            while (j > 0 && key[idx[j - 1]] > k) { idx[j] = idx[j - 1]; j--; }
+            idx[j] = x;
+        }
+        return;
+    }
+    int64_t h = n / 2;
+    msort_f64(idx, tmp, h, key);
+    msort_f64(idx + h, tmp, n - h, key);
+    int64_t i = 0, j = h, o = 0;
+    while (i < h && j < n) tmp[o++] = (key[idx[j]] < key[idx[i]]) ? idx[j++] : idx[i++];
+    while (i < h) tmp[o++] = idx[i++];
+    while (j < n) tmp[o++] = idx[j++];
+    memcpy(idx, tmp, (size_t)n * sizeof(int64_t));
+}
+
+static int cmp_i32(const void* x, const void* y)
+{
+    int32_t a = *(const int32_t*)x, b = *(const int32_t*)y;
+    return (a > b) - (a < b);
+}
+
+/* number of distinct ids among ids[0..n) (destroys order) */
+static int64_t count_unique(int32_t* ids, int64_t n)
+{
+    if (n == 0) return 0;
+    qsort(ids, (size_t)n, sizeof(int32_t), cmp_i32);
+    int64_t u = 1;
+    for (int64_t i = 1; i < n; i++) u += ids[i] != ids[i - 1];
+    return u;
+}
+
+/* begin a call; returns its slot (may be beyond capacity: then fields are not written) */
+static int64_t call_begin(work_t* w, int32_t seg, int32_t cluster, int32_t aux)
+{
+    int64_t c = w->n_calls++;
+    csv_batch_out* o = w->out;
+    if (c < o->cap_calls) {
+        o->call_seg[c] = seg;
+        o->call_cluster[c] = cluster;
+        o->call_aux[c] = aux;
+        o->bp1[c] = 0; o->bp2[c] = 0; o->support[c] = 0; o->cipos[c] = 0; o->cilen[c] = 0;
+        o->search_pos[c] = 0; o->seq_pick[c] = -1; o->dr[c] = -1; o->dv[c] = -1; o->gl_idx[c] = -1;
+        o->support_off[c] = w->n_support;
+    }
+    return c;
+}
+
+static void call_add_support(work_t* w, int64_t c, int64_t sig)
+{
+    csv_batch_out* o = w->out;
+    int64_t s = w->n_support++;
+    if (s < o->cap_support) o->support_sig[s] = sig;
+    if (o->allele_id && c < o->cap_calls) o->allele_id[sig] = (int32_t)c;
+}
+
+static void call_end(work_t* w, int64_t c)
+{
+    csv_batch_out* o = w->out;
+    if (c < o->cap_calls) o->support_off[c + 1] = w->n_support;
+}
+
+/* ------------------------------------------------------------------ DEL / INS */
+
+/* generate_del_cluster / generate_ins_cluster (INDEL:110-219, 319-432) on the chained
+ * cluster [s, e) of segment sg. */
+static int refine_indel(work_t* w, const csv_segment* sg, int32_t seg_i, int32_t cid, int64_t s, int64_t e)
+{
+    const csv_batch_in* in = w->in;
+    const int64_t m = e - s;
+    if (ensure(w, m + 2)) return CSV_E_NOMEM;
+    const int is_ins = sg->svtype == CSV_INS;
+    double rr = sg->remain_reads_ratio;
+    if (rr > 1) rr = 1;                                    /* INDEL:46-47 */
+
+    /* Remove duplicates (INDEL:125-131): dict keyed by read; first appearance keeps the slot,
+     * a strictly longer later signature of the same read replaces the value. */
+    int64_t* chosen = w->idx2;  /* chosen[u] = global index kept for the u-th distinct read */
+    int64_t  U = 0;
+    for (int64_t j = s; j < e; j++) {
+        int64_t u;
+        for (u = 0; u < U; u++)
+            if (in->read_id[chosen[u]] == in->read_id[j]) break;
+        if (u == U) chosen[U++] = j;
+        else if (in->b[j] > in->b[chosen[u]]) chosen[u] = j;
+    }
+    if (U < sg->read_count) return CSV_OK;                 /* INDEL:133-134 */
+
+    /* sorted(..., key=len) is stable (INDEL:136) */
+    int64_t* ord = w->idx;
+    for (int64_t u = 0; u < U; u++) { ord[u] = u; w->vals[u] = in->b[chosen[u]]; }
+    msort_i64(ord, w->tmp, U, w->vals);
+    int64_t sum_len = 0;
+    for (int64_t u = 0; u < U; u++) sum_len += w->vals[u];
+    const double thr = sg->diff_ratio * ((double)sum_len / (double)U);   /* INDEL:138 */
+
+    /* allele split on consecutive length gaps (INDEL:153-162); alleles are ranges of ord[] */
+    int64_t* astart = w->tmp;            /* reuse: A+1 entries, A <= U */
+    int64_t  A = 0;
+    astart[A++] = 0;
+    for (int64_t r = 1; r < U; r++) {
+        int64_t gap = w->vals[ord[r]] - w->vals[ord[r - 1]];
+        if ((double)gap > thr) astart[A++] = r;
+    }
+    astart[A] = U;
+
+    /* allele_sort = sorted(allele_collect, key=count) — stable ascending (INDEL:163) */
+    int64_t* aord = (int64_t*)malloc((size_t)(A + 1) * 3 * sizeof(int64_t));
+    if (!aord) return CSV_E_NOMEM;
+    int64_t* acnt = aord + A + 1;
+    int64_t* atmp = acnt + A + 1;
+    for (int64_t k = 0; k < A; k++) { aord[k] = k; acnt[k] = astart[k + 1] - astart[k]; }
+    msort_i64(aord, atmp, A, acnt);
+    /* astart lives in w->tmp which msort above did not touch (it used atmp) */
+
+    int64_t* P = w->vals2;   /* positions of the current allele, allele order */
+    int64_t* L = (int64_t*)malloc((size_t)(U + 1) * 3 * sizeof(int64_t));
+    if (!L) { free(aord); return CSV_E_NOMEM; }
+    int64_t* loc = L + U + 1;
+    int64_t* ltmp = loc + U + 1;
+
+    for (int64_t q = 0; q < A; q++) {
+        const int64_t k = aord[q];
+        const int64_t n = acnt[k];
+        if (n < sg->min_support_reads) continue;           /* INDEL:166 */
+        const int64_t r0 = astart[k];
+        int64_t sp = 0, sl = 0;
+        for (int64_t i = 0; i < n; i++) {
+            int64_t g = chosen[ord[r0 + i]];
+            P[i] = in->a[g]; L[i] = in->b[g];
+            sp += P[i]; sl += L[i];
+        }
+        int64_t keep = (int64_t)(rr * (double)n);          /* INDEL:169 */
+        if (keep < 1) keep = 1;
+
+        const double pos_mean = (double)sp / (double)n;
+        for (int64_t i = 0; i < n; i++) { w->dev[i] = fabs((double)P[i] - pos_mean); loc[i] = i; }
+        msort_f64(loc, ltmp, n, w->dev);                   /* INDEL:171-173 */
+        int64_t ks = 0;
+        for (int64_t i = 0; i < keep; i++) ks += P[loc[i]];
+        double  bp = (double)ks / (double)keep;            /* INDEL:176 */
+        int64_t search = P[loc[0]];                        /* INDEL:177 */
+
+        const double len_mean = (double)sl / (double)n;
+        for (int64_t i = 0; i < n; i++) { w->dev[i] = fabs((double)L[i] - len_mean); loc[i] = i; }
+        msort_f64(loc, ltmp, n, w->dev);
+        ks = 0;
+        for (int64_t i = 0; i < keep; i++) ks += L[loc[i]];
+        const double sig_len = (double)ks / (double)keep;  /* INDEL:187 */
+
+        const int32_t cipos = csvo_cipos(csvo_np_std_i64(P, n, w->sq), n);   /* INDEL:191 */
+        const int32_t cilen = csvo_cipos(csvo_np_std_i64(L, n, w->sq), n);   /* INDEL:194 */
+
+        int64_t pick = -1;
+        if (is_ins) {                                      /* INDEL:398-405 */
+            const int64_t want = (int64_t)sig_len;
+            for (int64_t i = 0; i < n; i++) {
+                int64_t g = chosen[ord[r0 + i]];
+                if ((int64_t)in->aux[g] >= want) { pick = g; bp = (double)P[i]; break; }
+            }
+            if (pick < 0) continue;
+            search = (int64_t)bp;                          /* INDEL:415 */
+        }
+
+        int64_t c = call_begin(w, seg_i, cid, in->aux[s]);
+        if (c < w->out->cap_calls) {
+            csv_batch_out* o = w->out;
+            o->bp1[c] = (int64_t)bp;                       /* INDEL:199 / 410 */
+            o->bp2[c] = (int64_t)sig_len;                  /* INDEL:200 (sign applied by the host) / 411 */
+            o->support[c] = (int32_t)n;
+            o->cipos[c] = cipos;
+            o->cilen[c] = cilen;
+            o->search_pos[c] = search;
+            o->seq_pick[c] = pick;
+        }
+        for (int64_t i = 0; i < n; i++) call_add_support(w, c, chosen[ord[r0 + i]]);
+        call_end(w, c);
+    }
+    free(L);
+    free(aord);
+    return CSV_OK;
+}
+
+/* first-seen distinct reads of the signatures ord[r0..r1) -> support list; returns count */
+static int64_t emit_unique_support(work_t* w, int64_t c, const int64_t* ord, int64_t r0, int64_t r1)
+{
+    const csv_batch_in* in = w->in;
+    int64_t u = 0;
+    for (int64_t r = r0; r < r1; r++) {
+        int32_t id = in->read_id[ord[r]];
+        int64_t k;
+        for (k = 0; k < u; k++) if (w->ids2[k] == id) break;
+        if (k == u) { w->ids2[u++] = id; call_add_support(w, c, ord[r]); }
+    }
+    return u;
+}
+
+static int64_t unique_reads(work_t* w, const int64_t* ord, int64_t r0, int64_t r1)
+{
+    for (int64_t r = r0; r < r1; r++) w->ids[r - r0] = w->in->read_id[ord[r]];
+    return count_unique(w->ids, r1 - r0);
+}
+
+/* ------------------------------------------------------------------ DUP */
+
+static int refine_dup(work_t* w, const csv_segment* sg, int32_t seg_i, int32_t cid, int64_t s, int64_t e)
+{
+    const csv_batch_in* in = w->in;
+    const int64_t m = e - s;
+    if (ensure(w, m)) return CSV_E_NOMEM;
+    int64_t* ord = w->idx;
+    for (int64_t i = 0; i < m; i++) ord[i] = s + i;
+    if (unique_reads(w, ord, 0, m) < sg->read_count) return CSV_OK;      /* DUP:82-84 */
+    msort_i64(ord, w->tmp, m, in->b);                                     /* DUP:86 */
+    int64_t r0 = 0;
+    for (int64_t r = 1; r <= m; r++) {
+        if (r < m && !(in->b[ord[r]] - in->b[ord[r - 1]] > sg->max_cluster_bias)) continue;  /* DUP:91 */
+        const int64_t n = r - r0;
+        const int64_t uniq = unique_reads(w, ord, r0, r);
+        if (uniq >= sg->read_count) {                                     /* DUP:96-98 */
+            const int64_t lo = (int64_t)((double)n * 0.4);                /* DUP:99-100 */
+            const int64_t hi = (int64_t)((double)n * 0.6);
+            int64_t bp1, bp2;
+            if (lo == hi) {
+                bp1 = in->a[ord[r0 + lo]];
+                bp2 = in->b[ord[r0 + lo]];
+            } else {
+                int64_t s1 = 0, s2 = 0;
+                for (int64_t i = lo; i < hi; i++) { s1 += in->a[ord[r0 + i]]; s2 += in->b[ord[r0 + i]]; }
+                bp1 = (int64_t)((double)s1 / (double)(hi - lo));          /* DUP:108-109 */
+                bp2 = (int64_t)((double)s2 / (double)(hi - lo));
+            }
+            const int64_t d = bp2 - bp1;
+            if ((sg->sv_size <= d && d <= sg->max_size) || (sg->sv_size <= d && sg->max_size == -1)) {  /* DUP:112 */
+                int64_t c = call_begin(w, seg_i, cid, in->aux[s]);
+                int64_t u = emit_unique_support(w, c, ord, r0, r);
+                if (c < w->out->cap_calls) {
+                    w->out->bp1[c] = bp1; w->out->bp2[c] = bp2; w->out->support[c] = (int32_t)u;
+                }
+                call_end(w, c);
+            }
+        }
+        r0 = r;
+    }
+    return CSV_OK;
+}
+
+/* ------------------------------------------------------------------ INV */
+
+static int refine_inv(work_t* w, const csv_segment* sg, int32_t seg_i, int32_t cid, int64_t s, int64_t e)
+{
+    const csv_batch_in* in = w->in;
+    const int64_t m = e - s;
+    if (ensure(w, m)) return CSV_E_NOMEM;
+    int64_t* ord = w->idx;
+    for (int64_t i = 0; i < m; i++) ord[i] = s + i;
+    if (unique_reads(w, ord, 0, m) < sg->read_count) return CSV_OK;      /* INV:106-109 */
+    msort_i64(ord, w->tmp, m, in->b);                                     /* INV:111 */
+    int64_t r0 = 0;
+    for (int64_t r = 1; r <= m; r++) {
+        if (r < m && !(in->b[ord[r]] - in->b[ord[r - 1]] > sg->max_cluster_bias)) continue;  /* INV:125 */
+        const int64_t n = r - r0;
+        if (n >= sg->read_count) {                                        /* INV:126 / 173 */
+            int64_t s1 = 0, s2 = 0;
+            for (int64_t i = r0; i < r; i++) { s1 += in->a[ord[i]]; s2 += in->b[ord[i]]; }
+            const int64_t uniq = unique_reads(w, ord, r0, r);
+            /* Python round(): float64 quotient rounded half-to-even (INV:129-130) */
+            const int64_t bp1 = (int64_t)rint((double)s1 / (double)n);
+            const int64_t bp2 = (int64_t)rint((double)s2 / (double)n);
+            const int64_t len = bp2 - bp1;
+            if (len >= sg->sv_size && uniq >= sg->read_count &&
+                (len <= sg->max_size || sg->max_size == -1)) {            /* INV:132-134 */
+                int64_t c = call_begin(w, seg_i, cid, in->aux[s]);
+                int64_t u = emit_unique_support(w, c, ord, r0, r);
+                if (c < w->out->cap_calls) {
+                    w->out->bp1[c] = bp1; w->out->bp2[c] = bp2; w->out->support[c] = (int32_t)u;
+                }
+                call_end(w, c);
+            }
+        }
+        r0 = r;
+    }
+    return CSV_OK;
+}
+
+/* ------------------------------------------------------------------ TRA */
+
+static int refine_tra(work_t* w, const csv_segment* sg, int32_t seg_i, int32_t cid, int64_t s, int64_t e)
+{
+    const csv_batch_in* in = w->in;
+    const int64_t m = e - s;
+    if (ensure(w, m + 1)) return CSV_E_NOMEM;
+    int64_t* ord = w->idx;
+    for (int64_t i = 0; i < m; i++) ord[i] = s + i;
+    const int32_t aux0 = in->aux[s];
+    msort_i64(ord, w->tmp, m, in->b);                                     /* TRA:109 */
+    /* sub-clusters over pos2 gaps; the loop at TRA:116-124 revisits element 0, so the first
+     * sub-cluster's sums and its read list contain element 0 twice. */
+    int64_t nsub = 0;
+    int64_t* sub0 = w->vals;      /* start rank of each sub-cluster */
+    sub0[nsub++] = 0;
+    for (int64_t r = 1; r < m; r++)
+        if (in->b[ord[r]] - in->b[ord[r - 1]] > sg->max_cluster_bias) sub0[nsub++] = r;
+    sub0[nsub] = m;
+    if (unique_reads(w, ord, 0, m) < sg->read_count) return CSV_OK;      /* TRA:128-129 */
+
+    /* temp = sorted(temp, key=-len(set(reads))) — stable; only the first two matter */
+    int64_t best = -1, second = -1, ubest = -1, usecond = -1;
+    for (int64_t k = 0; k < nsub; k++) {
+        int64_t u = unique_reads(w, ord, sub0[k], sub0[k + 1]);
+        if (u > ubest) { second = best; usecond = ubest; best = k; ubest = u; }
+        else if (u > usecond) { second = k; usecond = u; }
+    }
+    const int type = aux0 & 7;
+    if (type > 3) return CSV_OK;                                          /* TRA:154-155, 226-227 */
+
+    int64_t emit[2]; int n_emit = 0;
+    if (nsub > 1 && (double)usecond >= 0.5 * (double)sg->read_count) {    /* TRA:133 */
+        if ((double)(ubest + usecond) >= (double)m * sg->diff_ratio) { emit[0] = best; emit[1] = second; n_emit = 2; }  /* TRA:134 */
+    } else {
+        if ((double)ubest >= (double)m * sg->diff_ratio) { emit[0] = best; n_emit = 1; }   /* TRA:211 */
+    }
+    for (int q = 0; q < n_emit; q++) {
+        const int64_t k = emit[q];
+        int64_t s1 = 0, s2 = 0, cnt = sub0[k + 1] - sub0[k];
+        for (int64_t r = sub0[k]; r < sub0[k + 1]; r++) { s1 += in->a[ord[r]]; s2 += in->b[ord[r]]; }
+        if (k == 0) { s1 += in->a[ord[0]]; s2 += in->b[ord[0]]; cnt += 1; }   /* the double count */
+        int64_t c = call_begin(w, seg_i, cid, aux0);
+        int64_t u = emit_unique_support(w, c, ord, sub0[k], sub0[k + 1]);
+        if (c < w->out->cap_calls) {
+            w->out->bp1[c] = (int64_t)((double)s1 / (double)cnt);         /* TRA:173 */
+            w->out->bp2[c] = (int64_t)((double)s2 / (double)cnt);         /* TRA:175 */
+            w->out->support[c] = (int32_t)u;
+        }
+        call_end(w, c);
+    }
+    return CSV_OK;
+}
+
+/* ------------------------------------------------------------------ chaining */
+
+static int seg_break(const csv_batch_in* in, const csv_segment* sg, int64_t i)
+{
+    /* predicate between file-order neighbours i-1 and i */
+    const int64_t da = in->a[i] - in->a[i - 1];
+    switch (sg->svtype) {
+    case CSV_DEL: case CSV_INS: case CSV_DUP:
+        return da > sg->max_cluster_bias;                                  /* INDEL:61,271; DUP:35 */
+    case CSV_INV:
+        return da > sg->max_cluster_bias || (in->b[i] - in->b[i - 1]) > sg->max_cluster_bias ||
+               in->aux[i] != in->aux[i - 1];                               /* INV:56 */
+    default:
+        return da > sg->max_cluster_bias || in->aux[i] != in->aux[i - 1];  /* TRA:41,65 */
+    }
+}
+
+static int refine(work_t* w, const csv_segment* sg, int32_t seg_i, int32_t cid, int64_t s, int64_t e)
+{
+    const csv_batch_in* in = w->in;
+    /* the size gate counts signatures (INDEL:62,86) and a trailing (0,0) element behaves like
+     * the reference's [0,0,''] sentinel: the cluster is skipped (INDEL:63-64) */
+    if (e - s < sg->read_count) return CSV_OK;
+    if (in->a[e - 1] == 0 && in->b[e - 1] == 0) return CSV_OK;
+    switch (sg->svtype) {
+    case CSV_DEL: case CSV_INS: return refine_indel(w, sg, seg_i, cid, s, e);
+    case CSV_DUP: return refine_dup(w, sg, seg_i, cid, s, e);
+    case CSV_INV: return refine_inv(w, sg, seg_i, cid, s, e);
+    default:      return refine_tra(w, sg, seg_i, cid, s, e);
+    }
+}
+
+/* ------------------------------------------------------------------ genotype */
+
+/* cover set of one window in doubled coordinates: primary reads with 2*start <= L2 and
+ * 2*end >= R2 (the net effect of GT:95-159; semantics spelled out by duipai, GT:206-212). */
+static int64_t collect_cover(work_t* w, int64_t r0, int64_t r1, int64_t L2, int64_t R2, int32_t* dst, int64_t n)
+{
+    const csv_batch_in* in = w->in;
+    /* upper bound of start <= L */
+    int64_t lo = r0, hi = r1;
+    while (lo < hi) {
+        int64_t mid = lo + (hi - lo) / 2;
+        if (2 * in->r_start[mid] <= L2) lo = mid + 1; else hi = mid;
+    }
+    for (int64_t i = lo - 1; i >= r0; i--) {
+        if (2 * w->pmax[i] < R2) break;           /* nothing at or before i reaches R */
+        if (in->r_primary[i] == 1 && 2 * in->r_end[i] >= R2) dst[n++] = in->r_id[i];
+    }
+    return n;
+}
+
+static int genotype_all(work_t* w)
+{
+    const csv_batch_in* in = w->in;
+    csv_batch_out* o = w->out;
+    const int64_t nc = w->n_calls < o->cap_calls ? w->n_calls : o->cap_calls;
+    int any = 0;
+    for (int32_t k = 0; k < in->n_seg; k++) any |= in->seg[k].genotype;
+    if (!any || !in->reads_off) return CSV_OK;
+    w->pmax = (int64_t*)malloc((size_t)(in->n_reads + 1) * sizeof(int64_t));
+    if (!w->pmax) return CSV_E_NOMEM;
+    for (int32_t ch = 0; ch < in->n_chrom; ch++) {
+        int64_t mx = INT64_MIN;
+        for (int64_t i = in->reads_off[ch]; i < in->reads_off[ch + 1]; i++) {
+            if (i > in->reads_off[ch] && in->r_start[i] < in->r_start[i - 1]) return CSV_E_UNSORTED;
+            if (in->r_end[i] > mx) mx = in->r_end[i];
+            w->pmax[i] = mx;
+        }
+    }
+    int64_t cap = 1024;
+    int32_t* cov = (int32_t*)malloc((size_t)cap * sizeof(int32_t));
+    int32_t* sup = NULL; int64_t sup_cap = 0;
+    if (!cov) return CSV_E_NOMEM;
+    for (int64_t c = 0; c < nc; c++) {
+        const csv_segment* sg = &in->seg[o->call_seg[c]];
+        if (!sg->genotype) continue;
+        const int64_t r0 = in->reads_off[sg->chrom], r1 = in->reads_off[sg->chrom + 1];
+        if (cap < 2 * (r1 - r0) + 16) {
+            cap = 2 * (r1 - r0) + 16;
+            int32_t* q = (int32_t*)realloc(cov, (size_t)cap * sizeof(int32_t));
+            if (!q) { free(cov); free(sup); return CSV_E_NOMEM; }
+            cov = q;
+        }
+        int64_t n = 0;
+        if (sg->svtype == CSV_DEL || sg->svtype == CSV_INS) {
+            const int64_t p = o->search_pos[c], g = sg->gt_bias;         /* INDEL:450-451 */
+            int64_t L = p - g; if (L < 0) L = 0;
+            n = collect_cover(w, r0, r1, 2 * L, 2 * (p + g), cov, n);
+        } else {
+            int64_t nb = sg->gt_bias;
+            if (sg->svtype == CSV_DUP) { int64_t d = o->bp2[c] - o->bp1[c]; if (d < nb) nb = d; }   /* DUP:147 */
+            /* windows (max(bp - nb/2, 0), bp + nb/2) as doubled integers (DUP:148-151, INV:219-221) */
+            int64_t L2 = 2 * o->bp1[c] - nb; if (L2 < 0) L2 = 0;
+            n = collect_cover(w, r0, r1, L2, 2 * o->bp1[c] + nb, cov, n);
+            L2 = 2 * o->bp2[c] - nb; if (L2 < 0) L2 = 0;
+            n = collect_cover(w, r0, r1, L2, 2 * o->bp2[c] + nb, cov, n);   /* union: DUP:155-157 */
+        }
+        /* distinct names (cover sets hold names, GT:149-152) */
+        int64_t u = 0;
+        if (n) { qsort(cov, (size_t)n, sizeof(int32_t), cmp_i32); u = 1; for (int64_t i = 1; i < n; i++) if (cov[i] != cov[u - 1]) cov[u++] = cov[i]; }
+        const int64_t ns = o->support_off[c + 1] - o->support_off[c];
+        if (ns > sup_cap) { sup_cap = ns * 2; int32_t* q = (int32_t*)realloc(sup, (size_t)sup_cap * sizeof(int32_t)); if (!q) { free(cov); free(sup); return CSV_E_NOMEM; } sup = q; }
+        for (int64_t i = 0; i < ns; i++) sup[i] = in->read_id[o->support_sig[o->support_off[c] + i]];
+        qsort(sup, (size_t)ns, sizeof(int32_t), cmp_i32);
+        int64_t dr = 0;                                                    /* GT:167-170 */
+        for (int64_t i = 0; i < u; i++)
+            if (!bsearch(&cov[i], sup, (size_t)ns, sizeof(int32_t), cmp_i32)) dr++;
+        o->dr[c] = (int32_t)dr;
+        o->dv[c] = (int32_t)ns;                                            /* GT:171-172: len(read_id_dict[idx]) */
+        o->gl_idx[c] = csvo_gl_index(dr, ns);
+    }
+    free(cov); free(sup);
+    return CSV_OK;
+}
+
+/* ------------------------------------------------------------------ entry point */
+
+int csvo_cluster_batch(const csv_batch_in* in, csv_batch_out* out)
+{
+    work_t w;
+    memset(&w, 0, sizeof w);
+    w.in = in; w.out = out;
+    int rc = CSV_OK;
+    int32_t cid = -1;
+    if (out->allele_id) for (int64_t i = 0; i < in->n_sig; i++) out->allele_id[i] = -1;
+    for (int32_t k = 0; k < in->n_seg && rc == CSV_OK; k++) {
+        const csv_segment* sg = &in->seg[k];
+        if (sg->svtype < CSV_DEL || sg->svtype > CSV_TRA || sg->sig_begin > sg->sig_end ||
+            sg->sig_end > in->n_sig || (sg->svtype == CSV_TRA && sg->genotype)) { rc = CSV_E_INVALID; break; }
+        /* a genotyped segment whose chromosome has no reads block yields nothing (INDEL:443-444) */
+        const int drop = sg->genotype && (!in->reads_off || in->reads_off[sg->chrom + 1] == in->reads_off[sg->chrom]);
+        int64_t start = sg->sig_begin;
+        for (int64_t i = sg->sig_begin; i < sg->sig_end; i++) {
+            int brk = (i == sg->sig_begin);
+            if (!brk) {
+                /* a (0,0) element is indistinguishable from the reference's sentinel: whatever
+                 * follows it restarts the cluster and the old one is never processed (INDEL:80-82) */
+                brk = seg_break(in, sg, i) || (in->a[i - 1] == 0 && in->b[i - 1] == 0);
+            }
+            if (brk) {
+                if (i > sg->sig_begin && !drop) { rc = refine(&w, sg, k, cid, start, i); if (rc) break; }
+                cid++;
+                start = i;
+            }
+            if (out->cluster_id) out->cluster_id[i] = cid;
+        }
+        if (rc == CSV_OK && sg->sig_end > sg->sig_begin && !drop) rc = refine(&w, sg, k, cid, start, sg->sig_end);
+    }
+    out->n_clusters = cid + 1;
+    if (rc == CSV_OK) {
+        if (w.n_calls > out->cap_calls || w.n_support > out->cap_support) rc = CSV_E_CAPACITY;
+        else rc = genotype_all(&w);
+    }
+    out->n_calls = w.n_calls;
+    out->n_support = w.n_support;
+    free(w.idx); free(w.idx2); free(w.tmp); free(w.vals); free(w.vals2); free(w.dev); free(w.sq);
+    free(w.ids); free(w.ids2); free(w.pmax);
+    return rc;
+}
+
+/* Stand-alone overlap_cover restatement for the golden tests: for each window (L2, R2 in
+ * doubled coordinates) the number of distinct primary read names covering it. */
+int csvo_cover_count(const int64_t* r_start, const int64_t* r_end, const uint8_t* r_primary, const int32_t* r_id,
+                     int64_t n_reads, const int64_t* L2, const int64_t* R2, int64_t n_win, int32_t* out_count)
+{
+    for (int64_t k = 0; k < n_win; k++) {
+        int32_t* ids = (int32_t*)malloc((size_t)(n_reads + 1) * sizeof(int32_t));
+        if (!ids) return CSV_E_NOMEM;
+        int64_t n = 0;
+        for (int64_t i = 0; i < n_reads; i++)
+            if (r_primary[i] == 1 && 2 * r_start[i] <= L2[k] && 2 * r_end[i] >= R2[k]) ids[n++] = r_id[i];
+        out_count[k] = (int32_t)count_unique(ids, n);
+        free(ids);
+    }
+    return CSV_OK;
+}

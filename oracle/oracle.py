@@ -1,0 +1,76 @@
+"""ctypes driver of oracle/liboracle.so (the C restatement).  TEST INFRASTRUCTURE ONLY."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from cutesv_amd import _abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(path):
+            build()
+        _LIB = C.CDLL(path)
+        _LIB.csvo_cluster_batch.restype = C.c_int
+        _LIB.csvo_cluster_batch.argtypes = [C.POINTER(_abi.BatchIn), C.POINTER(_abi.BatchOut)]
+        _LIB.csvo_gl_index.restype = C.c_int32
+        _LIB.csvo_gl_index.argtypes = [C.c_int64, C.c_int64]
+        _LIB.csvo_np_sum_f64.restype = C.c_double
+        _LIB.csvo_np_sum_f64.argtypes = [C.c_void_p, C.c_int64]
+        _LIB.csvo_np_std_i64.restype = C.c_double
+        _LIB.csvo_np_std_i64.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+        _LIB.csvo_cipos.restype = C.c_int32
+        _LIB.csvo_cipos.argtypes = [C.c_double, C.c_int64]
+        _LIB.csvo_cover_count.restype = C.c_int
+        _LIB.csvo_cover_count.argtypes = [C.c_void_p] * 4 + [C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    return _LIB
+
+
+def cluster_batch(batch, per_sig=True, cap_calls=None, cap_support=None):
+    """Run the C restatement on a HostBatch; returns a HostResult (retries once on capacity)."""
+    n = batch.n_sig
+    cap_calls = cap_calls or max(64, n // 8 + 16)
+    cap_support = cap_support or max(64, n + 16)
+    for _ in range(2):
+        res = _abi.HostResult(n, cap_calls, cap_support, per_sig=per_sig)
+        rc = lib().csvo_cluster_batch(C.byref(batch.c), C.byref(res.c))
+        if rc == _abi.E_CAPACITY:
+            cap_calls, cap_support = res.n_calls + 1, res.n_support + 1
+            continue
+        if rc != _abi.OK:
+            raise RuntimeError("oracle: %s" % _abi.ERR_NAME.get(rc, rc))
+        return res
+    raise RuntimeError("oracle: capacity retry failed")
+
+
+def np_sum(x):
+    x = np.ascontiguousarray(x, np.float64)
+    return lib().csvo_np_sum_f64(x.ctypes.data, len(x))
+
+
+def np_std(v):
+    v = np.ascontiguousarray(v, np.int64)
+    s = np.empty(len(v), np.float64)
+    return lib().csvo_np_std_i64(v.ctypes.data, len(v), s.ctypes.data)
+
+
+def cover_count(r_start, r_end, r_primary, r_id, L2, R2):
+    r_start = np.ascontiguousarray(r_start, np.int64); r_end = np.ascontiguousarray(r_end, np.int64)
+    r_primary = np.ascontiguousarray(r_primary, np.uint8); r_id = np.ascontiguousarray(r_id, np.int32)
+    L2 = np.ascontiguousarray(L2, np.int64); R2 = np.ascontiguousarray(R2, np.int64)
+    out = np.zeros(len(L2), np.int32)
+    rc = lib().csvo_cover_count(r_start.ctypes.data, r_end.ctypes.data, r_primary.ctypes.data, r_id.ctypes.data,
+                                len(r_start), L2.ctypes.data, R2.ctypes.data, len(L2), out.ctypes.data)
+    assert rc == 0
+    return out

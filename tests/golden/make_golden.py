@@ -1,0 +1,388 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE in the build container.
+
+    python tests/golden/make_golden.py            # needs /root/reference (read-only mount)
+
+The reference is imported from /root/reference/src with a stub `pysam` module (its only use on
+this path is the VCF emitter's FastaFile and TRA genotyping, neither of which is called here).
+Nothing of the reference is copied: the outputs are data — the inputs we synthesise (flat arrays)
+and the rows / values the reference returns for them.  The GPU box never runs this script.
+
+Outputs
+    small_cases.json.gz    ~20 small (chr, type) workloads: inputs as flat arrays + every row the reference returns
+    known_answers.json     hand-made edge cases + the reference's rows
+    gl_table.json.gz       cal_GL over its whole rescaled domain + large-count samples, cal_CIPOS samples
+    overlap_cover.json.gz  random overlap_cover instances (ties, x.5 windows, non-primary, repeated names)
+    sim_sites.npz          truth sites of simulation/sim_*.bed.gz as integer arrays (data for cfg-1 / cfg-2)
+    digests.json           sha256 of the reference's canonical rows per (type, chr) for BASELINE configs 1-5
+                           (cfg-3/4/5 at reduced scale so the reference finishes in minutes)
+"""
+import gzip
+import hashlib
+import json
+import os
+import pickle
+import sys
+import tempfile
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+
+sys.modules["pysam"] = types.ModuleType("pysam")          # stub: never called on this path
+sys.path.insert(0, os.path.join(REF, "src"))
+from cuteSV import cuteSV_resolveINDEL as R_INDEL          # noqa: E402
+from cuteSV import cuteSV_resolveDUP as R_DUP              # noqa: E402
+from cuteSV import cuteSV_resolveINV as R_INV              # noqa: E402
+from cuteSV import cuteSV_resolveTRA as R_TRA              # noqa: E402
+from cuteSV import cuteSV_genotype as R_GT                 # noqa: E402
+
+from cutesv_amd import synth                               # noqa: E402
+from cutesv_amd.columns import SigStore, Params, TYPES    # noqa: E402
+
+import logging                                             # noqa: E402
+logging.disable(logging.CRITICAL)
+
+
+# ----------------------------------------------------------------------------- driving the reference
+def write_reference_workdir(store, work_dir):
+    """Lay the store out as the reference's <TYPE>.pickle / reads.pickle + index (one pickled list per chr)."""
+    per_type, reads = store.tuple_lists()
+    index = {}
+    for t in TYPES:
+        index[t] = {}
+        with open(os.path.join(work_dir, t + ".pickle"), "wb") as f:
+            cur, blk = None, []
+            for x in per_type[t]:
+                if x[-1] != cur:
+                    if cur is not None:
+                        index[t][cur] = f.tell(); pickle.dump(blk, f)
+                    cur, blk = x[-1], []
+                blk.append(x)
+            if cur is not None:
+                index[t][cur] = f.tell(); pickle.dump(blk, f)
+    index["reads"] = {}
+    with open(os.path.join(work_dir, "reads.pickle"), "wb") as f:
+        cur, blk = None, []
+        for r in sorted(reads, key=lambda r: r[-1]):
+            if r[-1] != cur:
+                if cur is not None:
+                    index["reads"][cur] = f.tell(); pickle.dump(blk, f)
+                cur, blk = r[-1], []
+            blk.append(r)
+        if cur is not None:
+            index["reads"][cur] = f.tell(); pickle.dump(blk, f)
+    return index
+
+
+def run_reference(store, p, tasks=None):
+    """rows per (type, chr) exactly as phase 3 of main_ctrl would obtain them (main script :1116-1189)."""
+    out = {}
+    with tempfile.TemporaryDirectory() as d:
+        d = d + "/"
+        idx = write_reference_workdir(store, d)
+        for t, ch in (tasks or store.tasks()):
+            if t == "DEL":
+                r = R_INDEL.run_del((d, ch, "DEL", p.min_support, p.diff_ratio_merging_DEL, p.max_cluster_bias_DEL,
+                                     min(p.min_support, 5), "bam", p.genotype, p.gt_round, p.remain_reads_ratio, idx))
+            elif t == "INS":
+                r = R_INDEL.run_ins((d, ch, "INS", p.min_support, p.diff_ratio_merging_INS, p.max_cluster_bias_INS,
+                                     min(p.min_support, 5), "bam", p.genotype, p.gt_round, p.remain_reads_ratio, idx))
+            elif t == "INV":
+                r = R_INV.run_inv((d, ch, "INV", p.min_support, p.max_cluster_bias_INV, p.min_size, "bam", p.genotype,
+                                   p.max_size, p.gt_round, idx))
+            elif t == "DUP":
+                r = R_DUP.run_dup((d, ch, p.min_support, p.max_cluster_bias_DUP, p.min_size, "bam", p.genotype,
+                                   p.max_size, p.gt_round, idx))
+            else:
+                r = R_TRA.run_tra((d, ch, p.min_support, p.diff_ratio_filtering_TRA, p.max_cluster_bias_TRA, "bam",
+                                   False, p.gt_round, idx))
+            assert r[0] == ch
+            out[(t, ch)] = [[str(x) for x in row] for row in r[1]]
+    return out
+
+
+READS_FIELD = {"DEL": 12, "INS": 12, "DUP": 10, "INV": 11, "TRA": 11}
+
+
+def canonical(t, rows):
+    """text form of a row list with the read-name field sorted (set-order fields: DUP:82,96; TRA:182)"""
+    lines = []
+    for row in rows:
+        row = list(row)
+        k = READS_FIELD[t]
+        row[k] = ",".join(sorted(row[k].split(",")))
+        lines.append("\t".join(row))
+    return "\n".join(lines)
+
+
+def digest(t, rows):
+    return hashlib.sha256(canonical(t, rows).encode()).hexdigest()
+
+
+def store_to_json(store):
+    d = dict(chroms=store.chroms, a=store.a.tolist(), b=store.b.tolist(), read_id=store.read_id.tolist(),
+             aux=store.aux.tolist(), seg_index=[[t, c, int(b), int(e)] for (t, c), (b, e) in store.seg_index.items()],
+             strands=list(store.strands), names=store.names.names, name_fmt=store.names.fmt,
+             ins_seq=None if store.ins_seq is None else {str(k): v for k, v in store.ins_seq.items()})
+    if store.reads_off is not None:
+        d.update(reads_off=store.reads_off.tolist(), r_start=store.r_start.tolist(), r_end=store.r_end.tolist(),
+                 r_primary=store.r_primary.tolist(), r_id=store.r_id.tolist())
+    return d
+
+
+def params_to_json(p):
+    return dict(p.__dict__)
+
+
+# ----------------------------------------------------------------------------- small full-row cases
+def small_cases():
+    cases = []
+    specs = [
+        ("default", Params(), dict()),
+        ("default_gt", Params(genotype=True), dict()),
+        ("ont", Params.ont(), dict()),
+        ("ont_gt", Params.ont(genotype=True), dict()),
+        ("hifi_gt", Params.hifi(genotype=True, min_support=3), dict(pos_sigma=2.0, len_sigma=0.005, coverage=24)),
+        ("hifi", Params.hifi(min_support=3), dict(pos_sigma=2.0, len_sigma=0.005, coverage=24)),
+        ("ont_keep07", Params.ont(remain_reads_ratio=0.7), dict()),
+        ("ont_keep07_gt", Params.ont(remain_reads_ratio=0.7, genotype=True), dict()),
+        ("keep_gt1", Params(remain_reads_ratio=1.5), dict()),
+        ("lowsupport", Params.ont(min_support=2), dict(coverage=8)),
+        ("dense_dups", Params.ont(genotype=True), dict(dup_frac=0.5, coverage=40)),
+        ("wide_bias", Params(max_cluster_bias_DEL=2000, max_cluster_bias_INS=2000, max_cluster_bias_DUP=5000,
+                             max_cluster_bias_INV=5000, max_cluster_bias_TRA=2000, genotype=True), dict(n_loci=400)),
+        ("small_sizes", Params.ont(min_size=2000, max_size=8000, genotype=True), dict()),
+        ("unlimited", Params.ont(max_size=-1), dict()),
+    ]
+    for i, (name, p, kw) in enumerate(specs):
+        st = synth.small_mixed(seed=7000 + i, contig_len=1_000_000, genotype=True, **kw)
+        rows = run_reference(st, p)
+        cases.append(dict(name=name, params=params_to_json(p), store=store_to_json(st),
+                          rows=[[t, c, r] for (t, c), r in rows.items()]))
+        print("small case %-14s sigs=%d reads=%d rows=%d" % (name, st.n_sig, st.n_reads, sum(len(r) for r in rows.values())))
+    # one case with realistic read names and real sequences, built through from_tuple_lists (interning path)
+    rng = np.random.default_rng(99)
+    per = {t: [] for t in TYPES}
+    names = ["m54238_180901_011437/%d/ccs" % rng.integers(1, 10**8) for _ in range(400)] + \
+            ["%08x-%04x-4%03x-a%03x-%012x" % tuple(rng.integers(0, 2**15, 5)) for _ in range(400)]
+    names = sorted(set(names))
+    acgt = np.array(list("ACGT"))
+    for s in range(25):
+        ch = "chr%d" % (1 + s % 2)
+        pos = int(rng.integers(10000, 900000)); ln = int(rng.integers(40, 900))
+        for nm in rng.choice(names, int(rng.integers(4, 30)), replace=False):
+            p_ = pos + int(rng.normal(0, 8)) + (0.5 if rng.random() < 0.2 else 0)     # x.5 split-read positions
+            l_ = max(30, int(ln * (1 + rng.normal(0, 0.05))))
+            per["DEL"].append((p_, l_, str(nm), "DEL", ch))
+            sl = l_ if rng.random() < 0.8 else l_ // 2
+            per["INS"].append((p_ + 3, l_, str(nm), "".join(rng.choice(acgt, sl)), "INS", ch))
+            per["DUP"].append((pos + int(rng.normal(0, 20)), pos + 5 * ln + int(rng.normal(0, 20)), str(nm), "DUP", ch))
+            per["INV"].append((("++", "--")[int(rng.integers(0, 2))], pos + int(rng.normal(0, 15)),
+                               pos + 3 * ln + int(rng.normal(0, 15)), str(nm), "INV", ch))
+            per["TRA"].append(("ABCD"[s % 4], pos + int(rng.normal(0, 6)), "chr%d" % (3 + s % 2),
+                               5000 + 37 * s + int(rng.normal(0, 6)), str(nm), "TRA", ch))
+    for t in TYPES:                                   # exact duplicates must be dropped by the rebuild
+        per[t] = per[t] + per[t][:10]
+    reads = []
+    for ch in ("chr1", "chr2", "chr3", "chr4"):
+        for nm in names:
+            s0 = int(rng.integers(0, 950000))
+            reads.append((s0, s0 + int(rng.integers(3000, 60000)), int(rng.random() < 0.9), nm, ch))
+    st = SigStore.from_tuple_lists(per, reads)
+    for name, p in (("realnames", Params.ont(min_support=3)), ("realnames_gt", Params.ont(min_support=3, genotype=True))):
+        rows = run_reference(st, p)
+        cases.append(dict(name=name, params=params_to_json(p), store=store_to_json(st),
+                          rows=[[t, c, r] for (t, c), r in rows.items()]))
+        print("small case %-14s sigs=%d reads=%d rows=%d" % (name, st.n_sig, st.n_reads, sum(len(r) for r in rows.values())))
+    return cases
+
+
+# ----------------------------------------------------------------------------- known answers
+def known_answers():
+    out = []
+
+    def case(name, per, p, reads=None):
+        st = SigStore.from_tuple_lists(per, reads)
+        rows = run_reference(st, p)
+        out.append(dict(name=name, params=params_to_json(p), store=store_to_json(st),
+                        rows=[[t, c, r] for (t, c), r in rows.items()]))
+
+    # TRA counts the first element of a cluster twice (cuteSV_resolveTRA.py:114-124)
+    case("tra_double_count", {"TRA": [("A", p, "5", 100, "r%d" % i, "TRA", "1") for i, p in enumerate((10, 20, 30, 40, 50))]},
+         Params(min_support=3))
+    # INS tie order / sequence pick moves POS (cuteSV_resolveINDEL.py:125-136, 399-403)
+    case("ins_tie_order", {"INS": [(1000, 50, "rb", "A" * 40, "INS", "1"), (1001, 50, "ra", "C" * 50, "INS", "1"),
+                                   (1002, 50, "rc", "G" * 50, "INS", "1"), (1003, 40, "rb", "T" * 40, "INS", "1"),
+                                   (1004, 60, "ra", "ACGTAC" * 10, "INS", "1")]},
+         Params(min_support=3, max_cluster_bias_INS=100, diff_ratio_merging_INS=0.3))
+    # INV banker's rounding on the float quotient (cuteSV_resolveINV.py:129-130)
+    case("inv_bankers", {"INV": [("++", 100, 1000, "a", "INV", "1"), ("++", 101, 1001, "d", "INV", "1"),
+                                 ("++", 101, 1001, "b", "INV", "1"), ("++", 100, 1000, "c", "INV", "1")]},
+         Params(min_support=3, min_size=30))
+    # INV signed pos2 gap (cuteSV_resolveINV.py:56): pos2 falls back by more than the bias without a break
+    case("inv_signed_gap", {"INV": [("++", 100 + i, 9000 - 700 * i, "r%d" % i, "INV", "1") for i in range(6)]},
+         Params(min_support=3, min_size=30, max_cluster_bias_INV=500))
+    # pre-dedupe gate counts signatures, post-dedupe gate counts reads (cuteSV_resolveINDEL.py:62 vs 133)
+    case("del_gate_reads", {"DEL": [(500 + i, 100 + i, "r%d" % (i % 2), "DEL", "1") for i in range(6)]}, Params(min_support=3))
+    # min(min_support, 5): a 5-read allele passes inside a >=10-read cluster (main script :1124)
+    case("del_two_alleles", {"DEL": [(5000 + i, 100, "a%d" % i, "DEL", "1") for i in range(5)] +
+                                    [(5010 + i, 400, "b%d" % i, "DEL", "1") for i in range(7)]}, Params(min_support=10))
+    # INS allele without a long-enough sequence is dropped (cuteSV_resolveINDEL.py:404-405)
+    case("ins_no_seq", {"INS": [(7000 + i, 200, "r%d" % i, "A" * 100, "INS", "1") for i in range(6)]}, Params(min_support=3))
+    # first signature beyond the bias, cluster at position 0, chromosome change
+    case("del_first_far", {"DEL": [(0, 50, "z0", "DEL", "1"), (3, 52, "z1", "DEL", "1"), (5, 51, "z2", "DEL", "1"),
+                                   (90000 + 0, 60, "y0", "DEL", "2"), (90001, 61, "y1", "DEL", "2"), (90002, 62, "y2", "DEL", "2")]},
+         Params(min_support=3))
+    # genotype with no reads block for the chromosome drops every call (cuteSV_resolveINDEL.py:443-444)
+    case("gt_no_reads_block", {"DEL": [(5000 + i, 100, "a%d" % i, "DEL", "1") for i in range(5)] +
+                                      [(5000 + i, 100, "c%d" % i, "DEL", "2") for i in range(5)]},
+         Params(min_support=3, genotype=True), reads=[(100, 9000, 1, "q%d" % i, "2") for i in range(8)])
+    # DUP quantile rule with n = 3 (lo == hi) and n = 10; size filter edges
+    case("dup_quantiles", {"DUP": [(1000 + 3 * i, 5000 + 7 * i, "r%d" % i, "DUP", "1") for i in range(3)] +
+                                  [(20000 + 3 * i, 20030 + 2 * i, "s%d" % i, "DUP", "1") for i in range(10)] +
+                                  [(40000 + 3 * i, 140001 + 2 * i, "t%d" % i, "DUP", "1") for i in range(10)]},
+         Params(min_support=3, min_size=30, max_size=100000))
+    # TRA two-allele rule, unknown BND type, type change splits clusters
+    tra = [("B", 1000 + i, "7", 500 + i, "r%d" % i, "TRA", "1") for i in range(6)] + \
+          [("B", 1003 + i, "7", 9000 + i, "s%d" % i, "TRA", "1") for i in range(5)] + \
+          [("C", 1004 + i, "7", 500 + i, "u%d" % i, "TRA", "1") for i in range(4)] + \
+          [("D", 70000 + i, "9", 100 + i, "v%d" % i, "TRA", "1") for i in range(4)]
+    case("tra_two_alleles", {"TRA": tra}, Params(min_support=4))
+    case("tra_two_alleles_strict", {"TRA": tra}, Params(min_support=4, diff_ratio_filtering_TRA=0.95))
+    return out
+
+
+# ----------------------------------------------------------------------------- scalar tables
+def gl_table():
+    rows = []
+    for c0 in range(0, 101):
+        for c1 in range(0, 101 - c0):
+            if c0 + c1 == 0:
+                continue
+            g = R_GT.cal_GL(c0, c1)
+            rows.append([c0, c1, g[0], g[1], str(g[2]), str(g[3])])
+    rng = np.random.default_rng(5)
+    big = []
+    for _ in range(400):
+        c0, c1 = int(rng.integers(0, 3000)), int(rng.integers(1, 3000))
+        g = R_GT.cal_GL(c0, c1)
+        big.append([c0, c1, g[0], g[1], str(g[2]), str(g[3])])
+    for c0, c1 in ((250, 31), (0, 400), (3, 1), (6, 2), (100, 1), (1, 100), (99, 2), (50, 51)):
+        g = R_GT.cal_GL(c0, c1)
+        big.append([c0, c1, g[0], g[1], str(g[2]), str(g[3])])
+    ci = []       # [values or None, n, seed, cal_CIPOS string, np.std hex, np.mean hex]
+    for _ in range(1500):
+        if rng.random() < 0.9:
+            n = int(rng.integers(1, 65))
+            base = int(rng.integers(0, 2 * 10**8))
+            vals = [int(x) for x in (base + rng.normal(0, rng.choice([1, 10, 100, 3000]), n)).astype(np.int64)]
+            seed = 0
+            stored = vals
+        else:             # long lists are regenerated from a seed instead of being stored
+            n = int(rng.integers(65, 20000))
+            seed = int(rng.integers(1, 2**31))
+            vals = [int(x) for x in np.random.default_rng(seed).integers(10**8, 10**8 + 5000, n)]
+            stored = None
+        ci.append([stored, n, seed, R_GT.cal_CIPOS(np.std(vals), len(vals)), float(np.std(vals)).hex(),
+                   float(np.mean(vals)).hex()])
+    return dict(table=rows, samples=big, cipos=ci)
+
+
+def overlap_cases():
+    rng = np.random.default_rng(11)
+    out = []
+    for k in range(250):
+        nr, ns = int(rng.integers(0, 40)), int(rng.integers(1, 8))
+        span = int(rng.choice([50, 400, 5000]))
+        names = ["n%d" % int(x) for x in rng.integers(0, max(2, nr // 2 + 3), nr)]   # repeated names on purpose
+        reads = []
+        for i in range(nr):
+            s = int(rng.integers(0, span)); e = s + int(rng.integers(0, span))
+            reads.append([s, e, int(rng.random() < 0.8), names[i]])
+        svs = []
+        for i in range(ns):
+            l = int(rng.integers(0, span)); r = l + int(rng.integers(1, span // 2 + 2))   # zero-width windows crash the reference
+            if rng.random() < 0.4:
+                l, r = l + 0.5, r + 0.5
+            svs.append((l, r))
+        it, pn, cov, ov = R_GT.overlap_cover(svs, [tuple(r) for r in reads])
+        out.append(dict(reads=reads, svs=[list(s) for s in svs], cover=[sorted(cov[i]) for i in range(ns)],
+                        overlap=[sorted(ov[i]) for i in range(ns)], iteration=[it[i] for i in range(ns)],
+                        primary=[pn[i] for i in range(ns)]))
+    return out
+
+
+# ----------------------------------------------------------------------------- simulation truth sites
+def sim_sites():
+    idx = {c: i for i, (c, _) in enumerate(synth.CONTIGS)}
+    out = {}
+
+    def rd(name):
+        with gzip.open(os.path.join(REF, "simulation", name), "rt") as f:
+            for line in f:
+                x = line.rstrip("\n").split("\t")
+                if x[0] in idx:
+                    yield x
+    d = [(idx[x[0]], int(x[1]), int(x[2])) for x in rd("sim_del.bed.gz")]
+    out["del_ch"], out["del_start"], out["del_end"] = map(np.array, zip(*d))
+    d = [(idx[x[0]], int(x[1]), len(x[4])) for x in rd("sim_ins.bed.gz")]
+    out["ins_ch"], out["ins_pos"], out["ins_len"] = map(np.array, zip(*d))
+    d = [(idx[x[0]], int(x[1]), int(x[2])) for x in rd("sim_dup.bed.gz")]
+    out["dup_ch"], out["dup_start"], out["dup_end"] = map(np.array, zip(*d))
+    d = [(idx[x[0]], int(x[1]), int(x[2])) for x in rd("sim_inv.bed.gz")]
+    out["inv_ch"], out["inv_start"], out["inv_end"] = map(np.array, zip(*d))
+    d = []
+    for x in rd("sim_tra.bed.gz"):
+        h = x[4].split(":")
+        if h[1] in idx:
+            d.append((idx[x[0]], int(x[1]), idx[h[1]], int(h[2]), 2 * (h[3] == "reverse") + (h[4] == "reverse")))
+    out["tra_ch"], out["tra_pos"], out["tra_ch2"], out["tra_pos2"], out["tra_type"] = map(np.array, zip(*d))
+    return {k: v.astype(np.int32) for k, v in out.items()}
+
+
+def config_digests(sites):
+    out = {}
+
+    def add(name, st, p, note):
+        rows = run_reference(st, p)
+        out[name] = dict(note=note, params=params_to_json(p), n_sig=st.n_sig, n_reads=st.n_reads,
+                         segments={"%s:%s" % k: [len(v), digest(k[0], v)] for k, v in rows.items()})
+        print("digest %-8s sigs=%d reads=%d rows=%d" % (name, st.n_sig, st.n_reads, sum(len(v) for v in rows.values())))
+
+    add("cfg1", synth.sim_all_types(sites, seed=20260101, chroms=["1"]), Params(),
+        "sim_del chr1, default flags: synth.sim_all_types(sites, seed=20260101, chroms=['1'])")
+    add("cfg2", synth.sim_all_types(sites, seed=20260102), Params.ont(),
+        "all five sim beds, ONT preset: synth.sim_all_types(sites, seed=20260102)")
+    add("cfg3_s025", synth.ont30(scale=0.25), Params.ont(), "synth.ont30(scale=0.25), ONT preset")
+    add("cfg4_s002", synth.hifi30_gt(scale=0.02), Params.hifi(genotype=True, min_support=3),
+        "synth.hifi30_gt(scale=0.02), HiFi preset, --genotype, min_support 3")
+    add("cfg5_s002", synth.ont90_all(scale=0.02), Params.ont(genotype=True),
+        "synth.ont90_all(scale=0.02), ONT preset, --genotype (TRA never genotyped here)")
+    return out
+
+
+def main():
+    os.chdir(HERE)
+    sites = sim_sites()
+    np.savez_compressed("sim_sites.npz", **sites)
+    with gzip.open("small_cases.json.gz", "wt") as f:
+        json.dump(small_cases(), f)
+    with open("known_answers.json", "w") as f:
+        json.dump(known_answers(), f)
+    with gzip.open("gl_table.json.gz", "wt") as f:
+        json.dump(gl_table(), f)
+    with gzip.open("overlap_cover.json.gz", "wt") as f:
+        json.dump(overlap_cases(), f)
+    with open("digests.json", "w") as f:
+        json.dump(config_digests(sites), f, indent=1)
+    for fn in sorted(os.listdir(".")):
+        print("%-24s %8d bytes" % (fn, os.path.getsize(fn)))
+
+
+if __name__ == "__main__":
+    main()

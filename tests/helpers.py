@@ -1,0 +1,94 @@
+"""Shared test helpers: golden-fixture loading, row canonicalisation, engine adapters."""
+import gzip
+import hashlib
+import json
+import os
+
+import numpy as np
+
+from cutesv_amd import _abi, rows as rows_mod
+from cutesv_amd.columns import SigStore, Params, NameTable
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+READS_FIELD = {"DEL": 12, "INS": 12, "DUP": 10, "INV": 11, "TRA": 11}
+SET_ORDER_TYPES = ("DUP", "TRA")      # read lists built from Python sets in the reference (DUP:82,96; TRA:182)
+
+
+def load_json(name):
+    path = os.path.join(GOLDEN, name)
+    if name.endswith(".gz"):
+        with gzip.open(path, "rt") as f:
+            return json.load(f)
+    with open(path) as f:
+        return json.load(f)
+
+
+def store_from_json(d):
+    kw = {}
+    if "reads_off" in d:
+        kw = dict(reads_off=np.array(d["reads_off"], np.int64), r_start=np.array(d["r_start"], np.int64),
+                  r_end=np.array(d["r_end"], np.int64), r_primary=np.array(d["r_primary"], np.uint8),
+                  r_id=np.array(d["r_id"], np.int32))
+    return SigStore(chroms=d["chroms"], a=np.array(d["a"], np.int64), b=np.array(d["b"], np.int64),
+                    read_id=np.array(d["read_id"], np.int32), aux=np.array(d["aux"], np.int32),
+                    seg_index={(t, c): (b, e) for t, c, b, e in d["seg_index"]},
+                    names=NameTable(d["names"], d["name_fmt"]), strands=tuple(d["strands"]),
+                    ins_seq=None if d["ins_seq"] is None else {int(k): v for k, v in d["ins_seq"].items()}, **kw)
+
+
+def canonical_row(t, row):
+    row = list(row)
+    k = READS_FIELD[t]
+    row[k] = ",".join(sorted(row[k].split(",")))
+    return row
+
+
+def digest(t, rows):
+    text = "\n".join("\t".join(canonical_row(t, r)) for r in rows)
+    return hashlib.sha256(text.encode()).hexdigest()
+
+
+def rows_by_task(store, params, engine, tasks=None):
+    """engine(HostBatch) -> HostResult; returns {(type, chr): rows} for all tasks in one batch."""
+    tasks = tasks or store.tasks()
+    hb = store.host_batch(tasks, params)
+    res = engine(hb)
+    out = {t: [] for t in tasks}
+    for k, row in rows_mod.materialise(store, hb.segments, res.trimmed()):
+        out[tasks[k]].append(row)
+    return out, res, hb
+
+
+def assert_rows_equal(t, got, want, where=""):
+    assert len(got) == len(want), "%s %s: %d rows, reference has %d" % (where, t, len(got), len(want))
+    for i, (g, w) in enumerate(zip(got, want)):
+        if t in SET_ORDER_TYPES:
+            g, w = canonical_row(t, g), canonical_row(t, w)
+        assert list(g) == list(w), "%s %s row %d:\n got %s\nwant %s" % (where, t, i, g, w)
+
+
+SOA_FIELDS = ("call_seg", "call_cluster", "call_aux", "bp1", "bp2", "support", "cipos", "cilen", "search_pos",
+              "seq_pick", "dr", "dv", "gl_idx", "support_off")
+
+
+def assert_soa_equal(got, want, store=None, set_order_segments=()):
+    """bit-exact comparison of two HostResult.trimmed() dicts"""
+    assert got["n_clusters"] == want["n_clusters"]
+    for f in SOA_FIELDS:
+        assert np.array_equal(got[f], want[f]), "field %s differs (first at %s)" % (
+            f, np.flatnonzero(np.asarray(got[f]) != np.asarray(want[f]))[:5] if len(got[f]) == len(want[f]) else "len")
+    go, wo = got["support_off"], want["support_off"]
+    gs, ws = got["support_sig"], want["support_sig"]
+    if len(set_order_segments) == 0:
+        assert np.array_equal(gs, ws), "support_sig differs"
+    else:
+        seg = got["call_seg"]
+        for c in range(len(seg)):
+            x, y = gs[go[c]:go[c + 1]], ws[wo[c]:wo[c + 1]]
+            if seg[c] in set_order_segments:
+                assert sorted(store.read_id[x].tolist()) == sorted(store.read_id[y].tolist())
+            else:
+                assert np.array_equal(x, y), "support list of call %d differs" % c
+    for f in ("cluster_id", "allele_id"):
+        if got.get(f) is not None and want.get(f) is not None:
+            assert np.array_equal(got[f], want[f]), "%s differs" % f
