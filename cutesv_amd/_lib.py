@@ -1,0 +1,48 @@
+"""Loader of libcutesv_hip.so (the HIP kernels + C ABI).  There is no CPU fallback: if the
+extension is missing or does not load, importing this module's `lib()` raises."""
+import ctypes as C
+import os
+
+from . import _abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcutesv_hip.so")
+_LIB = None
+
+# every symbol include/cutesv_hip.h declares: (name, restype, argtypes)
+SYMBOLS = [
+    ("csv_abi_version", C.c_int, []),
+    ("csv_device_count", C.c_int, [C.POINTER(C.c_int)]),
+    ("csv_ctx_create", C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    ("csv_ctx_destroy", None, [C.c_void_p]),
+    ("csv_last_error", C.c_char_p, [C.c_void_p]),
+    ("csv_stage_name", C.c_char_p, [C.c_int]),
+    ("csv_cluster_batch", C.c_int, [C.c_void_p, C.POINTER(_abi.BatchIn), C.POINTER(_abi.BatchOut)]),
+    ("csv_batch_upload", C.c_int, [C.c_void_p, C.POINTER(_abi.BatchIn)]),
+    ("csv_batch_run", C.c_int, [C.c_void_p, C.POINTER(_abi.RunStats)]),
+    ("csv_batch_download", C.c_int, [C.c_void_p, C.POINTER(_abi.BatchOut)]),
+    ("csv_ctx_sync", C.c_int, [C.c_void_p]),
+    ("csv_gl_index", C.c_int32, [C.c_int64, C.c_int64]),
+]
+
+
+class ExtensionMissing(RuntimeError):
+    pass
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise ExtensionMissing(
+                "%s not found: build it with `make -C cutesv_amd/csrc` (or __graft_entry__.build()). "
+                "cutesv_amd has no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, res, args in SYMBOLS:
+            fn = getattr(L, name)          # AttributeError here == ABI mismatch, fail loudly
+            fn.restype = res
+            fn.argtypes = args
+        if L.csv_abi_version() != _abi.ABI_VERSION:
+            raise ExtensionMissing("libcutesv_hip.so ABI %d != python side %d" % (L.csv_abi_version(), _abi.ABI_VERSION))
+        _LIB = L
+    return _LIB

@@ -1,0 +1,407 @@
+// cutesv_hip.hip — host side of libcutesv_hip.so: context, device arena, the C ABI of
+// include/cutesv_hip.h and the launch sequence of one batch.  gfx950 only.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "kernels.hip.h"
+
+using namespace csv;
+
+namespace {
+
+struct Buf {                      // grow-only device buffer
+    void*  p = nullptr;
+    size_t cap = 0;
+};
+
+enum StageId { ST_CHAIN = 0, ST_SELECT, ST_REFINE_SMALL, ST_REFINE_BIG, ST_ORDER, ST_READS, ST_GENOTYPE, ST_SPARE };
+const char* kStageName[CSV_N_STAGES] = {"chain", "select", "refine_wave", "refine_block", "order", "reads_pmax",
+                                        "genotype", "spare"};
+
+}  // namespace
+
+struct csv_ctx {
+    int         device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    hipEvent_t  ev[CSV_N_STAGES + 2] = {};
+    // device buffers
+    Buf seg, woff, seg_drop, a, b, rid, aux;
+    Buf cluster_id, cstart, partial, partial64, item_cid, item_seg, list_small, list_big;
+    Buf item_tbase, item_nslots, item_ncalls, item_nsup, sup_tmp, item_base;
+    Buf t_bp1, t_bp2, t_search, t_pick, t_support, t_cipos, t_cilen, t_supoff, t_valid;
+    Buf sc_k, sc_x, sc_v1, sc_v2, sc_v3, sc_v4, sc_v5;
+    Buf o_seg, o_cluster, o_aux, o_bp1, o_bp2, o_support, o_cipos, o_cilen, o_search, o_pick, o_dr, o_dv, o_gl;
+    Buf o_supoff, o_supsig, o_suprid, allele_id;
+    Buf reads_off, r_start, r_end, r_primary, r_id, r_pmax;
+    Buf sqrt_tab, cnt;
+    // host copies
+    std::vector<csv_segment> h_seg;
+    std::vector<i64>         h_woff;
+    bool     uploaded = false, ran = false, any_genotype = false, big_lds_set = false;
+    i64      n_sig_host = 0;
+    DevBatch B;
+    DevCounters h_cnt;
+};
+
+namespace {
+
+int fail(csv_ctx* c, int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    return code;
+}
+
+#define HIP_TRY(c, call)                                                                                   \
+    do {                                                                                                   \
+        hipError_t e_ = (call);                                                                            \
+        if (e_ != hipSuccess) return fail((c), CSV_E_HIP, "%s failed: %s", #call, hipGetErrorString(e_));   \
+    } while (0)
+
+int reserve(csv_ctx* c, Buf& b, size_t bytes)
+{
+    if (bytes <= b.cap) return CSV_OK;
+    if (b.p) { HIP_TRY(c, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+    size_t want = bytes + bytes / 4 + 256;
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) { b.p = nullptr; return fail(c, CSV_E_NOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e)); }
+    b.cap = want;
+    return CSV_OK;
+}
+
+#define RES(buf, bytes) do { int rc_ = reserve(c, c->buf, (size_t)(bytes)); if (rc_) return rc_; } while (0)
+
+template <class T> T* dp(const Buf& b) { return (T*)b.p; }
+
+int div_up(i64 a, i64 b) { return (int)((a + b - 1) / b); }
+
+}  // namespace
+
+extern "C" {
+
+int csv_abi_version(void) { return CSV_ABI_VERSION; }
+
+const char* csv_stage_name(int s) { return (s >= 0 && s < CSV_N_STAGES) ? kStageName[s] : ""; }
+
+int csv_device_count(int* n)
+{
+    int k = 0;
+    hipError_t e = hipGetDeviceCount(&k);
+    if (n) *n = (e == hipSuccess) ? k : 0;
+    return e == hipSuccess ? CSV_OK : CSV_E_HIP;
+}
+
+int32_t csv_gl_index(int64_t c0, int64_t c1)
+{
+    if (c0 == 3 && c1 == 1) return 101 * 101;
+    if (c0 == 6 && c1 == 2) return 101 * 101 + 1;
+    const int64_t total = c0 + c1;
+    if (total > 100) {
+        const double frac = (double)c0 / (double)total;
+        c0 = (int64_t)(100.0 * frac);
+        c1 = 100 - c0;
+    }
+    return (int32_t)(c0 * 101 + c1);
+}
+
+int csv_ctx_create(int device_id, csv_ctx** out)
+{
+    if (!out) return CSV_E_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device_id < 0 || device_id >= n) return CSV_E_HIP;
+    csv_ctx* c = new csv_ctx();
+    c->device = device_id;
+    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) { delete c; return CSV_E_HIP; }
+    for (auto& e : c->ev) if (hipEventCreate(&e) != hipSuccess) { delete c; return CSV_E_HIP; }
+    // `num ** 0.5` of cal_CIPOS is libm pow(), not sqrt(): tabulate it with the host libm (GT:59)
+    std::vector<double> tab(SQRT_TAB);
+    for (int i = 0; i < SQRT_TAB; i++) tab[i] = pow((double)i, 0.5);
+    if (reserve(c, c->sqrt_tab, SQRT_TAB * sizeof(double)) || reserve(c, c->cnt, sizeof(DevCounters)) ||
+        hipMemcpy(c->sqrt_tab.p, tab.data(), SQRT_TAB * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
+        delete c;
+        return CSV_E_HIP;
+    }
+    *out = c;
+    return CSV_OK;
+}
+
+void csv_ctx_destroy(csv_ctx* c)
+{
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    Buf* all[] = {&c->seg, &c->woff, &c->seg_drop, &c->a, &c->b, &c->rid, &c->aux, &c->cluster_id, &c->cstart, &c->partial,
+                  &c->partial64, &c->item_cid, &c->item_seg, &c->list_small, &c->list_big, &c->item_tbase, &c->item_nslots,
+                  &c->item_ncalls, &c->item_nsup, &c->sup_tmp, &c->item_base, &c->t_bp1, &c->t_bp2, &c->t_search, &c->t_pick,
+                  &c->t_support, &c->t_cipos, &c->t_cilen, &c->t_supoff, &c->t_valid, &c->sc_k, &c->sc_x, &c->sc_v1, &c->sc_v2,
+                  &c->sc_v3, &c->sc_v4, &c->sc_v5, &c->o_seg, &c->o_cluster, &c->o_aux, &c->o_bp1, &c->o_bp2, &c->o_support,
+                  &c->o_cipos, &c->o_cilen, &c->o_search, &c->o_pick, &c->o_dr, &c->o_dv, &c->o_gl, &c->o_supoff, &c->o_supsig,
+                  &c->o_suprid, &c->allele_id, &c->reads_off, &c->r_start, &c->r_end, &c->r_primary, &c->r_id, &c->r_pmax,
+                  &c->sqrt_tab, &c->cnt};
+    for (Buf* b : all) if (b->p) hipFree(b->p);
+    for (auto& e : c->ev) if (e) hipEventDestroy(e);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* csv_last_error(const csv_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int csv_ctx_sync(csv_ctx* c)
+{
+    if (!c) return CSV_E_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return CSV_OK;
+}
+
+int csv_batch_upload(csv_ctx* c, const csv_batch_in* in)
+{
+    if (!c || !in) return CSV_E_INVALID;
+    c->uploaded = c->ran = false;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (in->n_seg < 0 || in->n_sig < 0 || (in->n_seg > 0 && !in->seg)) return fail(c, CSV_E_INVALID, "bad batch header");
+    const int S = in->n_seg;
+    c->h_seg.assign(in->seg, in->seg + S);
+    c->h_woff.assign(S + 1, 0);
+    std::vector<uint8_t> drop(S + 1, 0);
+    c->any_genotype = false;
+    i64 cap_items = 16, cap_tmp = 16;
+    for (int k = 0; k < S; k++) {
+        const csv_segment& g = c->h_seg[k];
+        if (g.svtype < CSV_DEL || g.svtype > CSV_TRA) return fail(c, CSV_E_INVALID, "segment %d: unknown svtype %d", k, g.svtype);
+        if (g.sig_begin < 0 || g.sig_begin > g.sig_end || g.sig_end > in->n_sig) return fail(c, CSV_E_INVALID, "segment %d: bad signature range", k);
+        if (g.svtype == CSV_TRA && g.genotype) return fail(c, CSV_E_INVALID, "segment %d: TRA genotyping reads the BAM (cuteSV_resolveTRA.py:260-309) and is not part of this path", k);
+        if (g.genotype) {
+            c->any_genotype = true;
+            if (g.chrom < 0 || g.chrom >= in->n_chrom) return fail(c, CSV_E_INVALID, "segment %d: chrom %d outside the reads table", k, g.chrom);
+            drop[k] = (!in->reads_off || in->reads_off[g.chrom + 1] == in->reads_off[g.chrom]) ? 1 : 0;
+        }
+        const i64 len = g.sig_end - g.sig_begin;
+        c->h_woff[k + 1] = c->h_woff[k] + len;
+        const i64 rc = g.read_count > 1 ? g.read_count : 1;
+        const i64 msr = g.min_support_reads > 1 ? g.min_support_reads : 1;
+        cap_items += len / rc + 1;
+        if (g.svtype == CSV_DEL || g.svtype == CSV_INS) cap_tmp += len / msr + 1;
+        else if (g.svtype == CSV_TRA) cap_tmp += 2 * (len / rc) + 2;
+        else cap_tmp += len / rc + 1;
+    }
+    const i64 W = c->h_woff[S];
+    if (W >= (1ll << 31) - 4096 || cap_tmp >= (1ll << 31) - 1) return fail(c, CSV_E_INVALID, "batch too large for 32-bit work indices (%lld signatures)", (long long)W);
+    if (c->any_genotype && in->reads_off && (!in->r_start || !in->r_end || !in->r_primary || !in->r_id) && in->n_reads > 0)
+        return fail(c, CSV_E_INVALID, "reads columns missing");
+
+    // ---- device memory
+    RES(seg, (S + 1) * sizeof(csv_segment)); RES(woff, (S + 2) * sizeof(i64)); RES(seg_drop, S + 1);
+    RES(a, (W + 1) * 8); RES(b, (W + 1) * 8); RES(rid, (W + 1) * 4); RES(aux, (W + 1) * 4);
+    RES(cluster_id, (W + 1) * 4); RES(cstart, (W + 2) * 4); RES(sup_tmp, (W + 1) * 4); RES(allele_id, (W + 1) * 4);
+    const i64 R = (c->any_genotype && in->reads_off) ? in->n_reads : 0;
+    const i64 np32 = div_up(W, CH_TILE) + 2;
+    i64 np64 = div_up(W, 256) + 2;
+    if (div_up(R, PM_TILE) + 2 > np64) np64 = div_up(R, PM_TILE) + 2;
+    RES(partial, np32 * 4); RES(partial64, np64 * 8);
+    RES(item_cid, cap_items * 4); RES(item_seg, cap_items * 4); RES(list_small, cap_items * 4); RES(list_big, cap_items * 4);
+    RES(item_tbase, cap_items * 4); RES(item_nslots, cap_items * 4); RES(item_ncalls, cap_items * 4); RES(item_nsup, cap_items * 4);
+    RES(item_base, cap_items * 8);
+    RES(t_bp1, cap_tmp * 8); RES(t_bp2, cap_tmp * 8); RES(t_search, cap_tmp * 8); RES(t_pick, cap_tmp * 8);
+    RES(t_support, cap_tmp * 4); RES(t_cipos, cap_tmp * 4); RES(t_cilen, cap_tmp * 4); RES(t_supoff, cap_tmp * 4); RES(t_valid, cap_tmp * 4);
+    const i64 SC = 2 * W + 16 + 2 * ARR_PAD;
+    RES(sc_k, SC * 8); RES(sc_x, SC * 8); RES(sc_v1, SC * 4); RES(sc_v2, SC * 4); RES(sc_v3, SC * 4); RES(sc_v4, SC * 4); RES(sc_v5, SC * 4);
+    RES(o_seg, cap_tmp * 4); RES(o_cluster, cap_tmp * 4); RES(o_aux, cap_tmp * 4); RES(o_bp1, cap_tmp * 8); RES(o_bp2, cap_tmp * 8);
+    RES(o_support, cap_tmp * 4); RES(o_cipos, cap_tmp * 4); RES(o_cilen, cap_tmp * 4); RES(o_search, cap_tmp * 8); RES(o_pick, cap_tmp * 8);
+    RES(o_dr, cap_tmp * 4); RES(o_dv, cap_tmp * 4); RES(o_gl, cap_tmp * 4); RES(o_supoff, (cap_tmp + 1) * 8);
+    RES(o_supsig, (W + 1) * 8); RES(o_suprid, (W + 1) * 4);
+    if (R > 0) {
+        RES(reads_off, (in->n_chrom + 1) * 8); RES(r_start, R * 8); RES(r_end, R * 8); RES(r_primary, R); RES(r_id, R * 4); RES(r_pmax, R * 8);
+    }
+
+    // ---- host -> device.  Segments whose source ranges are adjacent travel as one copy.
+    hipStream_t st = c->stream;
+    HIP_TRY(c, hipMemcpyAsync(c->seg.p, c->h_seg.data(), S * sizeof(csv_segment), hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(c->woff.p, c->h_woff.data(), (S + 1) * sizeof(i64), hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(c->seg_drop.p, drop.data(), S + 1, hipMemcpyHostToDevice, st));
+    for (int k = 0; k < S;) {
+        int e = k;
+        while (e + 1 < S && c->h_seg[e + 1].sig_begin == c->h_seg[e].sig_end) e++;
+        const i64 src = c->h_seg[k].sig_begin, n = c->h_woff[e + 1] - c->h_woff[k], dst = c->h_woff[k];
+        if (n > 0) {
+            HIP_TRY(c, hipMemcpyAsync(dp<i64>(c->a) + dst, in->a + src, n * 8, hipMemcpyHostToDevice, st));
+            HIP_TRY(c, hipMemcpyAsync(dp<i64>(c->b) + dst, in->b + src, n * 8, hipMemcpyHostToDevice, st));
+            HIP_TRY(c, hipMemcpyAsync(dp<int>(c->rid) + dst, in->read_id + src, n * 4, hipMemcpyHostToDevice, st));
+            HIP_TRY(c, hipMemcpyAsync(dp<int>(c->aux) + dst, in->aux + src, n * 4, hipMemcpyHostToDevice, st));
+        }
+        k = e + 1;
+    }
+    if (R > 0) {
+        HIP_TRY(c, hipMemcpyAsync(c->reads_off.p, in->reads_off, (in->n_chrom + 1) * 8, hipMemcpyHostToDevice, st));
+        HIP_TRY(c, hipMemcpyAsync(c->r_start.p, in->r_start, R * 8, hipMemcpyHostToDevice, st));
+        HIP_TRY(c, hipMemcpyAsync(c->r_end.p, in->r_end, R * 8, hipMemcpyHostToDevice, st));
+        HIP_TRY(c, hipMemcpyAsync(c->r_primary.p, in->r_primary, R, hipMemcpyHostToDevice, st));
+        HIP_TRY(c, hipMemcpyAsync(c->r_id.p, in->r_id, R * 4, hipMemcpyHostToDevice, st));
+    }
+    HIP_TRY(c, hipStreamSynchronize(st));
+
+    DevBatch& B = c->B;
+    memset(&B, 0, sizeof B);
+    B.n_seg = S; B.n_chrom = in->n_chrom; B.W = W;
+    B.seg = dp<csv_segment>(c->seg); B.woff = dp<i64>(c->woff); B.seg_drop = dp<uint8_t>(c->seg_drop);
+    B.a = dp<i64>(c->a); B.b = dp<i64>(c->b); B.rid = dp<int>(c->rid); B.aux = dp<int>(c->aux);
+    B.cluster_id = dp<int>(c->cluster_id); B.cstart = dp<int>(c->cstart); B.partial = dp<int>(c->partial); B.partial64 = dp<i64>(c->partial64);
+    B.item_cid = dp<int>(c->item_cid); B.item_seg = dp<int>(c->item_seg); B.list_small = dp<int>(c->list_small); B.list_big = dp<int>(c->list_big);
+    B.item_tbase = dp<int>(c->item_tbase); B.item_nslots = dp<int>(c->item_nslots); B.item_ncalls = dp<int>(c->item_ncalls); B.item_nsup = dp<int>(c->item_nsup);
+    B.sup_tmp = dp<int>(c->sup_tmp);
+    B.t_bp1 = dp<i64>(c->t_bp1); B.t_bp2 = dp<i64>(c->t_bp2); B.t_search = dp<i64>(c->t_search); B.t_pick = dp<i64>(c->t_pick);
+    B.t_support = dp<int>(c->t_support); B.t_cipos = dp<int>(c->t_cipos); B.t_cilen = dp<int>(c->t_cilen); B.t_supoff = dp<int>(c->t_supoff); B.t_valid = dp<int>(c->t_valid);
+    B.cap_tmp = (int)cap_tmp; B.cap_items = (int)cap_items;
+    B.sc_k = dp<u64>(c->sc_k); B.sc_x = dp<i64>(c->sc_x); B.sc_v1 = dp<int>(c->sc_v1); B.sc_v2 = dp<int>(c->sc_v2); B.sc_v3 = dp<int>(c->sc_v3); B.sc_v4 = dp<int>(c->sc_v4); B.sc_v5 = dp<int>(c->sc_v5);
+    B.item_base = dp<i64>(c->item_base);
+    B.o_seg = dp<int>(c->o_seg); B.o_cluster = dp<int>(c->o_cluster); B.o_aux = dp<int>(c->o_aux);
+    B.o_bp1 = dp<i64>(c->o_bp1); B.o_bp2 = dp<i64>(c->o_bp2); B.o_support = dp<int>(c->o_support); B.o_cipos = dp<int>(c->o_cipos); B.o_cilen = dp<int>(c->o_cilen);
+    B.o_search = dp<i64>(c->o_search); B.o_pick = dp<i64>(c->o_pick); B.o_dr = dp<int>(c->o_dr); B.o_dv = dp<int>(c->o_dv); B.o_gl = dp<int>(c->o_gl);
+    B.o_supoff = dp<i64>(c->o_supoff); B.o_supsig = dp<i64>(c->o_supsig); B.o_suprid = dp<int>(c->o_suprid); B.allele_id = dp<int>(c->allele_id);
+    B.reads_off = dp<i64>(c->reads_off); B.n_reads = R;
+    B.r_start = dp<i64>(c->r_start); B.r_end = dp<i64>(c->r_end); B.r_primary = dp<uint8_t>(c->r_primary); B.r_id = dp<int>(c->r_id); B.r_pmax = dp<i64>(c->r_pmax);
+    B.sqrt_tab = dp<double>(c->sqrt_tab); B.cnt = dp<DevCounters>(c->cnt);
+    c->n_sig_host = in->n_sig;
+    c->uploaded = true;
+    return CSV_OK;
+}
+
+int csv_batch_run(csv_ctx* c, csv_run_stats* stats)
+{
+    if (!c) return CSV_E_INVALID;
+    if (!c->uploaded) return fail(c, CSV_E_STATE, "csv_batch_run before csv_batch_upload");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    const DevBatch& B = c->B;
+    const i64 W = B.W;
+    constexpr int LDS_SMALL = refine_lds_bytes<64>();
+    constexpr int LDS_BIG = refine_lds_bytes<2048>();
+    if (!c->big_lds_set) {
+        HIP_TRY(c, hipFuncSetAttribute((const void*)k_refine<256, 2048>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BIG));
+        c->big_lds_set = true;
+    }
+    int ev = 0;
+    auto mark = [&]() -> hipError_t { return stats ? hipEventRecord(c->ev[ev++], st) : hipSuccess; };
+    HIP_TRY(c, mark());
+    HIP_TRY(c, hipMemsetAsync(c->cnt.p, 0, sizeof(DevCounters), st));
+    if (W > 0) {
+        HIP_TRY(c, hipMemsetAsync(c->allele_id.p, 0xff, W * 4, st));
+        const int nb = div_up(W, CH_TILE);
+        hipLaunchKernelGGL(k_chain_count, dim3(nb), dim3(256), 0, st, B);
+        hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(256), 0, st, B.partial, nb, (int*)nullptr);
+        hipLaunchKernelGGL(k_chain_apply, dim3(nb), dim3(256), 0, st, B);
+        HIP_TRY(c, mark());
+        const int ns = div_up(W, 256);
+        hipLaunchKernelGGL(k_select_count, dim3(ns), dim3(256), 0, st, B);
+        hipLaunchKernelGGL(k_scan_partials64, dim3(1), dim3(256), 0, st, B.partial64, &B.cnt->n_clusters, 256, &B.cnt->sel_total);
+        hipLaunchKernelGGL(k_select_apply, dim3(ns), dim3(256), 0, st, B);
+        HIP_TRY(c, mark());
+        int g_small = B.cap_items < 8192 ? B.cap_items : 8192;
+        if (g_small < 1) g_small = 1;
+        hipLaunchKernelGGL((k_refine<64, 64>), dim3(g_small), dim3(64), LDS_SMALL, st, B, 0);
+        HIP_TRY(c, mark());
+        int g_big = B.cap_items < 512 ? B.cap_items : 512;
+        if (g_big < 1) g_big = 1;
+        hipLaunchKernelGGL((k_refine<256, 2048>), dim3(g_big), dim3(256), LDS_BIG, st, B, 1);
+        HIP_TRY(c, mark());
+        hipLaunchKernelGGL(k_items_scan, dim3(1), dim3(1024), 0, st, B);
+        hipLaunchKernelGGL(k_emit, dim3(1024), dim3(256), 0, st, B);
+        HIP_TRY(c, mark());
+        if (c->any_genotype && B.n_reads > 0) {
+            const int nr = div_up(B.n_reads, PM_TILE);
+            hipLaunchKernelGGL(k_pmax_count, dim3(nr), dim3(256), 0, st, B);
+            hipLaunchKernelGGL(k_pmax_scan, dim3(1), dim3(256), 0, st, B.partial64, nr);
+            hipLaunchKernelGGL(k_pmax_apply, dim3(nr), dim3(256), 0, st, B);
+            HIP_TRY(c, mark());
+            hipLaunchKernelGGL(k_genotype, dim3(1024), dim3(256), 0, st, B);
+            HIP_TRY(c, mark());
+        } else {
+            HIP_TRY(c, mark());
+            HIP_TRY(c, mark());
+        }
+    } else {
+        for (int i = 0; i < 7; i++) HIP_TRY(c, mark());
+    }
+    HIP_TRY(c, hipGetLastError());
+    c->ran = true;
+    if (stats) {
+        memset(stats, 0, sizeof *stats);
+        HIP_TRY(c, hipMemcpyAsync(&c->h_cnt, c->cnt.p, sizeof(DevCounters), hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipStreamSynchronize(st));
+        for (int i = 0; i + 1 < ev && i < CSV_N_STAGES; i++) HIP_TRY(c, hipEventElapsedTime(&stats->ms_stage[i], c->ev[i], c->ev[i + 1]));
+        HIP_TRY(c, hipEventElapsedTime(&stats->ms_total, c->ev[0], c->ev[ev - 1]));
+        stats->n_clusters = c->h_cnt.n_clusters;
+        stats->n_work_block = c->h_cnt.n_items_big;
+        stats->n_work_wave = c->h_cnt.n_items - c->h_cnt.n_items_big;
+        stats->n_calls = c->h_cnt.n_calls;
+        stats->n_support = c->h_cnt.n_support;
+    }
+    return CSV_OK;
+}
+
+int csv_batch_download(csv_ctx* c, csv_batch_out* out)
+{
+    if (!c || !out) return CSV_E_INVALID;
+    if (!c->ran) return fail(c, CSV_E_STATE, "csv_batch_download before csv_batch_run");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    HIP_TRY(c, hipMemcpyAsync(&c->h_cnt, c->cnt.p, sizeof(DevCounters), hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    const DevCounters& k = c->h_cnt;
+    out->n_calls = k.n_calls; out->n_support = k.n_support; out->n_clusters = k.n_clusters;
+    if (k.error & ERR_READS_UNSORTED) return fail(c, CSV_E_UNSORTED, "a reads block is not sorted by start");
+    if (k.error & ERR_CLUSTER_TOO_BIG) return fail(c, CSV_E_INVALID, "a chained cluster has more than %lld signatures", (long long)MAX_CLUSTER);
+    if (k.error & ERR_KEY_RANGE) return fail(c, CSV_E_INVALID, "a length / pos2 value is negative or >= 2^42");
+    if (k.error & ERR_COVER_OVERFLOW) return fail(c, CSV_E_INVALID, "support + cover set of a call exceeds %d reads", GT_HASH_FILL);
+    if (k.error & ERR_TMP_OVERFLOW) return fail(c, CSV_E_INVALID, "internal: temp call capacity exceeded");
+    if (k.n_calls > out->cap_calls || k.n_support > out->cap_support)
+        return fail(c, CSV_E_CAPACITY, "need %d calls / %lld supports", k.n_calls, (long long)k.n_support);
+    const size_t nc = k.n_calls, ns = (size_t)k.n_support;
+    const DevBatch& B = c->B;
+#define D2H(dst, src, bytes) do { if ((bytes) > 0) HIP_TRY(c, hipMemcpyAsync((dst), (src), (bytes), hipMemcpyDeviceToHost, st)); } while (0)
+    D2H(out->call_seg, B.o_seg, nc * 4); D2H(out->call_cluster, B.o_cluster, nc * 4); D2H(out->call_aux, B.o_aux, nc * 4);
+    D2H(out->bp1, B.o_bp1, nc * 8); D2H(out->bp2, B.o_bp2, nc * 8); D2H(out->support, B.o_support, nc * 4);
+    D2H(out->cipos, B.o_cipos, nc * 4); D2H(out->cilen, B.o_cilen, nc * 4); D2H(out->search_pos, B.o_search, nc * 8);
+    D2H(out->seq_pick, B.o_pick, nc * 8); D2H(out->dr, B.o_dr, nc * 4); D2H(out->dv, B.o_dv, nc * 4); D2H(out->gl_idx, B.o_gl, nc * 4);
+    D2H(out->support_off, B.o_supoff, (nc + 1) * 8); D2H(out->support_sig, B.o_supsig, ns * 8);
+    if (out->cluster_id) memset(out->cluster_id, 0xff, (size_t)c->n_sig_host * 4);
+    if (out->allele_id) memset(out->allele_id, 0xff, (size_t)c->n_sig_host * 4);
+    if (out->cluster_id || out->allele_id) {
+        const int S = (int)c->h_seg.size();
+        for (int s = 0; s < S;) {
+            int e = s;
+            while (e + 1 < S && c->h_seg[e + 1].sig_begin == c->h_seg[e].sig_end) e++;
+            const i64 dst = c->h_seg[s].sig_begin, n = c->h_woff[e + 1] - c->h_woff[s], src = c->h_woff[s];
+            if (out->cluster_id) D2H(out->cluster_id + dst, B.cluster_id + src, n * 4);
+            if (out->allele_id) D2H(out->allele_id + dst, B.allele_id + src, n * 4);
+            s = e + 1;
+        }
+    }
+#undef D2H
+    HIP_TRY(c, hipStreamSynchronize(st));
+    if (nc == 0 && out->cap_calls >= 0 && out->support_off) out->support_off[0] = 0;
+    return CSV_OK;
+}
+
+int csv_cluster_batch(csv_ctx* c, const csv_batch_in* in, csv_batch_out* out)
+{
+    int rc = csv_batch_upload(c, in);
+    if (rc) return rc;
+    rc = csv_batch_run(c, nullptr);
+    if (rc) return rc;
+    return csv_batch_download(c, out);
+}
+
+}  // extern "C"

@@ -1,0 +1,1183 @@
+// kernels.hip.h — device code of libcutesv_hip.so (gfx950 / CDNA4 only, wave64).
+//
+// Pipeline of one csv_batch_run (all on one stream, no host round trip in between):
+//   chain     k_chain_count / k_scan_partials / k_chain_apply    flags + scan -> cluster ids, cluster starts
+//   select    k_select_count / k_scan_partials64 / k_select_apply size gate -> ordered work list (two tiers)
+//   refine    k_refine<64,64>    one wavefront per cluster (m <= 64), arrays in LDS
+//             k_refine<256,2048> one workgroup per cluster; LDS up to 2048 padded elements, global scratch above
+//   order     k_items_scan / k_emit                                per-item counts -> dense, ordered outputs
+//   reads     k_pmax_count / k_pmax_scan / k_pmax_apply            prefix max of read ends + sortedness check
+//   genotype  k_genotype                                           one wavefront per call: 64-ary search,
+//                                                                  backwards stabbing scan, LDS hash set
+//
+// Reference semantics and file:line citations are in oracle/cutesv_oracle.c (the CPU restatement these
+// kernels are tested against) and include/cutesv_hip.h.  The path is integer sort/scan plus a little
+// float64; there is no MFMA work in it.  Compile with -ffp-contract=off: float64 results must equal numpy's.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/cutesv_hip.h"
+
+namespace csv {
+
+typedef unsigned long long u64;
+typedef long long i64;
+
+constexpr int WAVE = 64;
+constexpr u64 PAD_KEY = ~0ull;
+constexpr int IDX_BITS = 21;                       // local-index bits inside a sort key
+constexpr i64 MAX_CLUSTER = (1ll << IDX_BITS);     // larger clusters are rejected (CSV_E_INVALID)
+constexpr u64 IDX_MASK = (1ull << IDX_BITS) - 1;
+constexpr int SQRT_TAB = 65536;                    // pow(n, 0.5) as glibc computes it, n < SQRT_TAB
+constexpr int ARR_PAD = 8;                         // group-start arrays need P + 1 entries
+
+// device error bits (DevCounters::error)
+enum { ERR_CLUSTER_TOO_BIG = 1, ERR_READS_UNSORTED = 2, ERR_COVER_OVERFLOW = 4, ERR_KEY_RANGE = 8, ERR_TMP_OVERFLOW = 16 };
+
+struct DevCounters {          // one small struct in device memory, zeroed at the start of every run
+    int n_clusters;
+    int n_items;              // valid clusters (work items)
+    int n_items_big;          // of those, handled by the workgroup tier
+    int n_tmp_calls;          // allocated temp call slots
+    int n_calls;
+    int error;
+    i64 n_support;
+    i64 sel_total;            // packed select total (scratch)
+};
+
+// Everything the kernels need, passed by value.
+struct DevBatch {
+    int            n_seg;
+    int            n_chrom;
+    i64            W;                // signatures in the batch (compact "w" space)
+    const csv_segment* seg;          // device copy of the segment table
+    const i64*     woff;             // n_seg + 1 prefix of segment lengths
+    const uint8_t* seg_drop;         // genotype requested but no reads block (INDEL:443-444)
+    const i64*     a;
+    const i64*     b;
+    const int*     rid;
+    const int*     aux;
+    // chain / select
+    int*           cluster_id;       // W
+    int*           cstart;           // W + 1 (cluster -> first w; cstart[n_clusters] = W)
+    int*           partial;          // scan partials
+    i64*           partial64;
+    int*           item_cid;         // ordered work list: item -> cluster id
+    int*           item_seg;
+    int*           list_small;       // item ids of the wavefront tier (ordered)
+    int*           list_big;
+    // refine outputs
+    int*           item_tbase;       // first temp slot of the item
+    int*           item_nslots;
+    int*           item_ncalls;      // valid calls
+    int*           item_nsup;        // supports of valid calls
+    int*           sup_tmp;          // W: support lists, stored inside the cluster's own [s, e) range
+    i64*           t_bp1; i64* t_bp2; i64* t_search; i64* t_pick;
+    int*           t_support; int* t_cipos; int* t_cilen; int* t_supoff; int* t_valid;
+    int            cap_tmp;
+    int            cap_items;
+    // big-cluster scratch (2 * W + 16 elements each)
+    u64*           sc_k; i64* sc_x; int* sc_v1; int* sc_v2; int* sc_v3; int* sc_v4; int* sc_v5;
+    // final outputs
+    i64*           item_base;        // packed (calls << 32 | supports) exclusive prefix per item
+    int*           o_seg; int* o_cluster; int* o_aux;
+    i64*           o_bp1; i64* o_bp2; int* o_support; int* o_cipos; int* o_cilen; i64* o_search; i64* o_pick;
+    int*           o_dr; int* o_dv; int* o_gl;
+    i64*           o_supoff;         // n_calls + 1
+    i64*           o_supsig;         // global signature index
+    int*           o_suprid;         // read id of the support (genotype)
+    int*           allele_id;        // W
+    // reads
+    const i64*     reads_off;
+    i64            n_reads;
+    const i64*     r_start; const i64* r_end; const uint8_t* r_primary; const int* r_id;
+    i64*           r_pmax;
+    const double*  sqrt_tab;
+    DevCounters*   cnt;
+};
+
+// ------------------------------------------------------------------------------------ small helpers
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ u64 lanemask_lt() { return (1ull << lane_id()) - 1ull; }
+
+__device__ __forceinline__ i64 shfl_i64(i64 v, int src)
+{
+    int lo = __shfl((int)(v & 0xffffffffll), src), hi = __shfl((int)(v >> 32), src);
+    return ((i64)hi << 32) | (unsigned)lo;
+}
+__device__ __forceinline__ i64 shfl_up_i64(i64 v, int d)
+{
+    int lo = __shfl_up((int)(v & 0xffffffffll), d), hi = __shfl_up((int)(v >> 32), d);
+    return ((i64)hi << 32) | (unsigned)lo;
+}
+__device__ __forceinline__ i64 shfl_xor_i64(i64 v, int m)
+{
+    int lo = __shfl_xor((int)(v & 0xffffffffll), m), hi = __shfl_xor((int)(v >> 32), m);
+    return ((i64)hi << 32) | (unsigned)lo;
+}
+__device__ __forceinline__ double shfl_xor_f64(double v, int m) { return __longlong_as_double(shfl_xor_i64(__double_as_longlong(v), m)); }
+__device__ __forceinline__ i64 wave_sum_i64(i64 v)
+{
+    for (int m = 32; m > 0; m >>= 1) v += shfl_xor_i64(v, m);
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i32(int v)
+{
+    for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+__device__ __forceinline__ i64 wave_incl_scan_i64(i64 v)
+{
+    for (int d = 1; d < 64; d <<= 1) { i64 t = shfl_up_i64(v, d); if (lane_id() >= d) v += t; }
+    return v;
+}
+__device__ __forceinline__ int wave_incl_scan_i32(int v)
+{
+    for (int d = 1; d < 64; d <<= 1) { int t = __shfl_up(v, d); if (lane_id() >= d) v += t; }
+    return v;
+}
+__device__ __forceinline__ i64 wave_incl_max_i64(i64 v)
+{
+    for (int d = 1; d < 64; d <<= 1) { i64 t = shfl_up_i64(v, d); if (lane_id() >= d && t > v) v = t; }
+    return v;
+}
+
+// segment of compact index w (woff is tiny; lives in L1/L2)
+__device__ __forceinline__ int seg_of(const DevBatch& B, i64 w)
+{
+    int lo = 0, hi = B.n_seg;               // last k with woff[k] <= w (empty segments are skipped naturally)
+    while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (B.woff[mid] <= w) lo = mid; else hi = mid; }
+    return lo;
+}
+
+// ------------------------------------------------------------------------------------ chain
+// flag[w] = 1 when w starts a new chained cluster: first of its segment, the type's break predicate
+// against the previous signature, or the previous signature is a (0,0) look-alike of the reference's
+// sentinel (see oracle csvo_cluster_batch).
+__device__ __forceinline__ int chain_flag(const DevBatch& B, i64 w, int& seg_hint)
+{
+    int k = seg_hint;
+    if (w < B.woff[k] || w >= B.woff[k + 1]) { k = seg_of(B, w); seg_hint = k; }
+    if (w == B.woff[k]) return 1;
+    const csv_segment& sg = B.seg[k];
+    const i64 bias = sg.max_cluster_bias;
+    const i64 a1 = B.a[w], a0 = B.a[w - 1];
+    if (a1 - a0 > bias) return 1;
+    if (a0 == 0 && B.b[w - 1] == 0) return 1;
+    if (sg.svtype == CSV_INV) return (B.b[w] - B.b[w - 1] > bias) || (B.aux[w] != B.aux[w - 1]);
+    if (sg.svtype == CSV_TRA) return B.aux[w] != B.aux[w - 1];
+    return 0;
+}
+
+constexpr int CH_ITEMS = 8;                         // rows of 64 per wavefront
+constexpr int CH_TILE = 256 * CH_ITEMS;             // signatures per workgroup
+
+__global__ __launch_bounds__(256) void k_chain_count(DevBatch B)
+{
+    const i64 base = (i64)blockIdx.x * CH_TILE + (threadIdx.x >> 6) * (WAVE * CH_ITEMS);
+    int seg_hint = 0, cnt = 0;
+#pragma unroll
+    for (int r = 0; r < CH_ITEMS; r++) {
+        const i64 w = base + r * WAVE + lane_id();
+        const int f = (w < B.W) ? chain_flag(B, w, seg_hint) : 0;
+        cnt += __popcll(__ballot(f));
+    }
+    __shared__ int s[4];
+    if (lane_id() == 0) s[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) B.partial[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+}
+
+// exclusive scan of n ints in place (single workgroup); total -> *total_out
+__global__ __launch_bounds__(256) void k_scan_partials(int* p, int n, int* total_out)
+{
+    __shared__ int wsum[4];
+    __shared__ int carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 256) {
+        const int i = base + threadIdx.x;
+        const int v = i < n ? p[i] : 0;
+        const int inc = wave_incl_scan_i32(v);
+        if (lane_id() == 63) wsum[threadIdx.x >> 6] = inc;
+        __syncthreads();
+        int woff = 0;
+        for (int k = 0; k < (int)(threadIdx.x >> 6); k++) woff += wsum[k];
+        const int carry = carry_s;
+        if (i < n) p[i] = carry + woff + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 255) carry_s = carry + woff + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && total_out) *total_out = carry_s;
+}
+
+// same for packed 64-bit counters; n is read from device memory (*n_ptr, divided by `per`)
+__global__ __launch_bounds__(256) void k_scan_partials64(i64* p, const int* n_ptr, int per, i64* total_out)
+{
+    const int n = (*n_ptr + per - 1) / per;
+    __shared__ i64 wsum[4];
+    __shared__ i64 carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 256) {
+        const int i = base + threadIdx.x;
+        const i64 v = i < n ? p[i] : 0;
+        const i64 inc = wave_incl_scan_i64(v);
+        if (lane_id() == 63) wsum[threadIdx.x >> 6] = inc;
+        __syncthreads();
+        i64 woff = 0;
+        for (int k = 0; k < (int)(threadIdx.x >> 6); k++) woff += wsum[k];
+        const i64 carry = carry_s;
+        if (i < n) p[i] = carry + woff + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 255) carry_s = carry + woff + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && total_out) *total_out = carry_s;
+}
+
+__global__ __launch_bounds__(256) void k_chain_apply(DevBatch B)
+{
+    const int wv = threadIdx.x >> 6;
+    const i64 base = (i64)blockIdx.x * CH_TILE + wv * (WAVE * CH_ITEMS);
+    int seg_hint = 0;
+    u64 masks[CH_ITEMS];
+    int cnt = 0;
+#pragma unroll
+    for (int r = 0; r < CH_ITEMS; r++) {
+        const i64 w = base + r * WAVE + lane_id();
+        const int f = (w < B.W) ? chain_flag(B, w, seg_hint) : 0;
+        masks[r] = __ballot(f);
+        cnt += __popcll(masks[r]);
+    }
+    __shared__ int s[4];
+    if (lane_id() == 0) s[wv] = cnt;
+    __syncthreads();
+    int run = B.partial[blockIdx.x];
+    for (int k = 0; k < wv; k++) run += s[k];
+#pragma unroll
+    for (int r = 0; r < CH_ITEMS; r++) {
+        const i64 w = base + r * WAVE + lane_id();
+        const u64 m = masks[r];
+        if (w < B.W) {
+            const int cid = run + __popcll(m & (lanemask_lt() | (1ull << lane_id()))) - 1;
+            B.cluster_id[w] = cid;
+            if ((m >> lane_id()) & 1) B.cstart[cid] = (int)w;
+        }
+        run += __popcll(m);
+    }
+    // the last workgroup also plants the sentinel cstart[n_clusters] = W
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) {
+        int tot = B.partial[blockIdx.x];
+        for (int k = 0; k < 4; k++) tot += s[k];
+        B.cstart[tot] = (int)B.W;
+        B.cnt->n_clusters = tot;
+    }
+}
+
+// ------------------------------------------------------------------------------------ select
+// cluster c is a work item when it passes the size gate (signatures >= read_count, INDEL:62),
+// does not end in a (0,0) element (INDEL:63-64) and its segment is not dropped.
+// packed counter: low 32 = items, high 32 = items of the workgroup tier (m > 64).
+__device__ __forceinline__ i64 select_value(const DevBatch& B, int c, int nC, int& seg_out)
+{
+    if (c >= nC) return 0;
+    const int s = B.cstart[c], e = B.cstart[c + 1];
+    const int k = seg_of(B, s);
+    seg_out = k;
+    const csv_segment& sg = B.seg[k];
+    if (e - s < sg.read_count) return 0;
+    if (B.seg_drop[k]) return 0;
+    if (B.a[e - 1] == 0 && B.b[e - 1] == 0) return 0;
+    return 1ll + ((e - s > 64) ? (1ll << 32) : 0ll);
+}
+
+__global__ __launch_bounds__(256) void k_select_count(DevBatch B)
+{
+    const int nC = B.cnt->n_clusters;
+    if ((int)(blockIdx.x * 256) >= nC) return;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    int k;
+    const i64 v = wave_sum_i64(select_value(B, c, nC, k));
+    __shared__ i64 s[4];
+    if (lane_id() == 0) s[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) B.partial64[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+}
+
+__global__ __launch_bounds__(256) void k_select_apply(DevBatch B)
+{
+    const int nC = B.cnt->n_clusters;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const i64 t = B.cnt->sel_total;
+        B.cnt->n_items = (int)(t & 0xffffffffll);
+        B.cnt->n_items_big = (int)(t >> 32);
+    }
+    if ((int)(blockIdx.x * 256) >= nC) return;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    int k = 0;
+    const i64 v = select_value(B, c, nC, k);
+    const i64 inc = wave_incl_scan_i64(v);
+    __shared__ i64 s[4];
+    if (lane_id() == 63) s[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    i64 off = B.partial64[blockIdx.x];
+    for (int q = 0; q < (int)(threadIdx.x >> 6); q++) off += s[q];
+    if (v) {
+        const i64 ex = off + inc - v;
+        const int j = (int)(ex & 0xffffffffll), jb = (int)(ex >> 32);
+        B.item_cid[j] = c;
+        B.item_seg[j] = k;
+        if (v >> 32) B.list_big[jb] = j; else B.list_small[j - jb] = j;
+    }
+}
+
+// ------------------------------------------------------------------------------------ refine
+// Working arrays of one cluster (P = padded power of two >= m; every array has P + ARR_PAD entries):
+//   K  u64   sort keys, later the a-values (pos / pos1) in rank order
+//   X  i64   b-values (len / pos2) in rank order
+//   V1 int   local index of rank r (bit 31: first-seen flag for DUP/INV/TRA)
+//   V2 int   local indices in (read id, index) order, later first rank of each group (allele / sub-cluster)
+//   V3 int   kept-signature-of-first-appearance (INDEL) / rank of local index, later per-group values
+//   V4 int   group of rank r, later per-group values
+//   V5 int   per-group values
+// The pointers are flat: LDS for P <= CAP, the cluster's own slice of the global scratch above.
+struct Arrays { u64* K; i64* X; int* V1; int* V2; int* V3; int* V4; int* V5; };
+
+struct ItemCtx {
+    int j, cid, k, s, m, P;
+    i64 gsig0;             // global signature index of w = s
+};
+
+template <int BLOCK> __device__ void bitonic_sort(u64* K, int P)
+{
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < P; i += BLOCK) {
+                const int x = i ^ j;
+                if (x > i) {
+                    const u64 ki = K[i], kx = K[x];
+                    const bool asc = (i & k) == 0;
+                    if ((ki > kx) == asc) { K[i] = kx; K[x] = ki; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// sum over the workgroup; `red` is a small LDS array; every thread gets the total
+template <int BLOCK> __device__ i64 block_sum_i64(i64 v, i64* red)
+{
+    v = wave_sum_i64(v);
+    if (BLOCK == 64) return v;
+    __syncthreads();
+    if (lane_id() == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    i64 t = 0;
+    for (int k = 0; k < BLOCK / 64; k++) t += red[k];
+    return t;
+}
+
+// inclusive scan over the workgroup of one int per thread; total via *tot
+template <int BLOCK> __device__ int block_incl_scan(int v, int* tot, i64* red)
+{
+    const int inc = wave_incl_scan_i32(v);
+    if (BLOCK == 64) { *tot = __shfl(inc, 63); return inc; }
+    __syncthreads();
+    if (lane_id() == 63) red[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    int off = 0, t = 0;
+    for (int k = 0; k < BLOCK / 64; k++) { if (k < (int)(threadIdx.x >> 6)) off += (int)red[k]; t += (int)red[k]; }
+    *tot = t;
+    return inc + off;
+}
+
+// numpy's pairwise summation over sq(i) = (v[i] - mean)^2, evaluated by ONE lane in numpy's exact
+// association order (oracle: pairwise_f64 / csvo_np_sum_f64).
+__device__ double np_sumsq_leaf(const i64* v, int n, double mean)
+{
+    if (n < 8) {
+        double r = 0.0;
+        for (int i = 0; i < n; i++) { const double x = (double)v[i] - mean; r += x * x; }
+        return r;
+    }
+    double r[8];
+    for (int j = 0; j < 8; j++) { const double x = (double)v[j] - mean; r[j] = x * x; }
+    int i;
+    for (i = 8; i < n - (n % 8); i += 8)
+        for (int j = 0; j < 8; j++) { const double x = (double)v[i + j] - mean; r[j] += x * x; }
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; i++) { const double x = (double)v[i] - mean; res += x * x; }
+    return res;
+}
+
+// explicit-stack form of  pw(a, n) = n <= 128 ? leaf : pw(a, n2) + pw(a + n2, n - n2),  n2 = n/2 - (n/2) % 8
+__device__ double np_sumsq_chunk(const i64* v, int n, double mean)
+{
+    if (n <= 128) return np_sumsq_leaf(v, n, mean);
+    int s_off[16], s_n[16], s_state[16];
+    double s_left[16];
+    int sp = 0;
+    s_off[0] = 0; s_n[0] = n; s_state[0] = 0; s_left[0] = 0.0;
+    double ret = 0.0;
+    while (sp >= 0) {
+        if (s_n[sp] <= 128) { ret = np_sumsq_leaf(v + s_off[sp], s_n[sp], mean); sp--; continue; }
+        int n2 = s_n[sp] / 2; n2 -= n2 % 8;
+        if (s_state[sp] == 0) {
+            s_state[sp] = 1;
+            s_off[sp + 1] = s_off[sp]; s_n[sp + 1] = n2; s_state[sp + 1] = 0; sp++;
+        } else if (s_state[sp] == 1) {
+            s_left[sp] = ret; s_state[sp] = 2;
+            s_off[sp + 1] = s_off[sp] + n2; s_n[sp + 1] = s_n[sp] - n2; s_state[sp + 1] = 0; sp++;
+        } else { ret = s_left[sp] + ret; sp--; }
+    }
+    return ret;
+}
+
+// np.std of the int64 values v[0..n) -> the integer of cal_CIPOS (GT:58-60)
+__device__ int cipos_of(const i64* v, int n, i64 sum, const double* sqrt_tab)
+{
+    const double mean = (double)sum / (double)n;
+    double acc = 0.0;
+    for (int off = 0; off < n; off += 8192) {
+        const int c = n - off < 8192 ? n - off : 8192;
+        acc += np_sumsq_chunk(v + off, c, mean);
+    }
+    const double sd = sqrt(acc / (double)n);
+    const double rt = n < SQRT_TAB ? sqrt_tab[n] : sqrt((double)n);
+    return (int)(1.96 * sd / rt);
+}
+
+__device__ __forceinline__ void item_none(const DevBatch& B, int j)
+{
+    if (threadIdx.x == 0) { B.item_tbase[j] = 0; B.item_nslots[j] = 0; B.item_ncalls[j] = 0; B.item_nsup[j] = 0; }
+}
+
+__device__ __forceinline__ int alloc_slots(const DevBatch& B, int n)
+{
+    if (n <= 0) return 0;
+    const int t = atomicAdd(&B.cnt->n_tmp_calls, n);
+    if (t + n > B.cap_tmp) { atomicOr(&B.cnt->error, ERR_TMP_OVERFLOW); return -1; }
+    return t;
+}
+
+// phase A: sort by (read id, local index); returns the number of distinct reads.
+// Leaves K sorted and V2[q] = local index at sorted position q.
+template <int BLOCK> __device__ int sort_by_read(const DevBatch& B, const ItemCtx& it, const Arrays& A, i64* red)
+{
+    for (int i = threadIdx.x; i < it.P; i += BLOCK)
+        A.K[i] = i < it.m ? (((u64)(unsigned)B.rid[it.s + i]) << 32) | (unsigned)i : PAD_KEY;
+    __syncthreads();
+    bitonic_sort<BLOCK>(A.K, it.P);
+    int runs = 0;
+    for (int q = threadIdx.x; q < it.m; q += BLOCK) {
+        const u64 k = A.K[q];
+        A.V2[q] = (int)(k & 0xffffffffull);
+        runs += (q == 0) || ((A.K[q - 1] >> 32) != (k >> 32));
+    }
+    const int U = (int)block_sum_i64<BLOCK>(runs, red);
+    __syncthreads();
+    return U;
+}
+
+// ---- DEL / INS: generate_del_cluster / generate_ins_cluster (INDEL:110-219, 319-432)
+template <int BLOCK> __device__ void refine_indel(const DevBatch& B, const ItemCtx& it, const Arrays& A, i64* red, int* ired)
+{
+    const csv_segment& sg = B.seg[it.k];
+    const int m = it.m, P = it.P, s = it.s;
+    const int U = sort_by_read<BLOCK>(B, it, A, red);
+    if (U < sg.read_count) { item_none(B, it.j); return; }                  // INDEL:133-134
+
+    // per run of equal read id: first appearance F (smallest index) and the kept signature
+    // (strictly longest, earliest among equals)  INDEL:125-131.  New key = (len, F), staged in X.
+    for (int q = threadIdx.x; q < P; q += BLOCK) {
+        u64 key = PAD_KEY;
+        if (q < m) {
+            const unsigned r = (unsigned)(A.K[q] >> 32);
+            if (q == 0 || (unsigned)(A.K[q - 1] >> 32) != r) {
+                const int F = A.V2[q];
+                int best = F; i64 bl = B.b[s + F];
+                for (int t = q + 1; t < m && (unsigned)(A.K[t] >> 32) == r; t++) {
+                    const int i2 = A.V2[t]; const i64 l2 = B.b[s + i2];
+                    if (l2 > bl) { bl = l2; best = i2; }
+                }
+                A.V3[F] = best;
+                if ((u64)bl >> (63 - IDX_BITS)) atomicOr(&B.cnt->error, ERR_KEY_RANGE);
+                key = ((u64)bl << IDX_BITS) | (u64)F;
+            }
+        }
+        A.X[q] = (i64)key;
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < P; q += BLOCK) A.K[q] = (u64)A.X[q];
+    __syncthreads();
+    bitonic_sort<BLOCK>(A.K, P);        // == stable sort by length over first-appearance order (INDEL:136)
+
+    // rank order: a-values -> K, lengths -> X, kept local index -> V1
+    i64 lsum = 0;
+    for (int r = threadIdx.x; r < U; r += BLOCK) {
+        const u64 key = A.K[r];
+        const int ch = A.V3[(int)(key & IDX_MASK)];
+        const i64 len = (i64)(key >> IDX_BITS);
+        A.K[r] = (u64)B.a[s + ch]; A.X[r] = len; A.V1[r] = ch;
+        lsum += len;
+    }
+    lsum = block_sum_i64<BLOCK>(lsum, red);
+    __syncthreads();
+    const double thr = sg.diff_ratio * ((double)lsum / (double)U);          // INDEL:138
+
+    // allele split on consecutive length gaps (INDEL:153-162): V2[a] = first rank of allele a
+    int carry = 0;
+    for (int base = 0; base < U; base += BLOCK) {
+        const int r = base + threadIdx.x;
+        int f = 0;
+        if (r < U && r > 0) f = ((double)(A.X[r] - A.X[r - 1]) > thr) ? 1 : 0;
+        int tot;
+        const int inc = block_incl_scan<BLOCK>(f, &tot, red);
+        if (r < U && (f || r == 0)) A.V2[carry + inc] = r;
+        carry += tot;
+    }
+    const int nA = carry + 1;
+    if (threadIdx.x == 0) A.V2[nA] = U;
+    __syncthreads();
+
+    // emission order: stable ascending by support among alleles with cnt >= minimum_support_reads
+    // (INDEL:163-166): V3[a] = slot (-1: filtered), V4[a] = offset of its supports
+    const int msr = sg.min_support_reads;
+    int npass = 0;
+    for (int a = threadIdx.x; a < nA; a += BLOCK) {
+        const int cnt = A.V2[a + 1] - A.V2[a];
+        int rank = -1, soff = 0;
+        if (cnt >= msr) {
+            rank = 0;
+            for (int a2 = 0; a2 < nA; a2++) {
+                const int c2 = A.V2[a2 + 1] - A.V2[a2];
+                if (c2 >= msr && (c2 < cnt || (c2 == cnt && a2 < a))) { rank++; soff += c2; }
+            }
+            npass++;
+        }
+        A.V3[a] = rank; A.V4[a] = soff;
+    }
+    npass = (int)block_sum_i64<BLOCK>(npass, red);
+    if (threadIdx.x == 0) *ired = alloc_slots(B, npass);
+    __syncthreads();
+    const int tbase = *ired;
+    if (tbase < 0) { item_none(B, it.j); return; }
+
+    // per allele statistics: one wavefront per allele
+    double rr = sg.remain_reads_ratio; if (rr > 1) rr = 1;                  // INDEL:46-47
+    const int is_ins = sg.svtype == CSV_INS;
+    int ncalls = 0, nsup = 0;
+    const i64* PA = (const i64*)A.K; const i64* PB = A.X;
+    for (int a = threadIdx.x >> 6; a < nA; a += BLOCK / 64) {
+        const int rank = A.V3[a];
+        if (rank < 0) continue;
+        const int r0 = A.V2[a], n = A.V2[a + 1] - r0, soff = A.V4[a];
+        i64 sp = 0, sl = 0;
+        for (int i = lane_id(); i < n; i += 64) { sp += PA[r0 + i]; sl += PB[r0 + i]; }
+        sp = wave_sum_i64(sp); sl = wave_sum_i64(sl);
+        int keep = (int)(rr * (double)n); if (keep < 1) keep = 1;           // INDEL:169
+        const double pmean = (double)sp / (double)n, lmean = (double)sl / (double)n;
+        double bp, siglen; i64 search;
+        if (keep >= n) {
+            // every member kept: mean of the kept values == mean of all (exact integer sums);
+            // search_threshold = first member with the smallest |pos - mean| (INDEL:171-177)
+            double bd = 1e300; int bi = 0x7fffffff;
+            for (int i = lane_id(); i < n; i += 64) {
+                const double d = fabs((double)PA[r0 + i] - pmean);
+                if (d < bd) { bd = d; bi = i; }
+            }
+            for (int msk = 32; msk > 0; msk >>= 1) {
+                const double od = shfl_xor_f64(bd, msk); const int oi = __shfl_xor(bi, msk);
+                if (od < bd || (od == bd && oi < bi)) { bd = od; bi = oi; }
+            }
+            search = PA[r0 + bi];
+            bp = pmean; siglen = lmean;
+        } else {
+            // keep the `keep` members closest to the mean; ties in allele order (stable sort on |x - mean|)
+            i64 ks = 0, kl = 0, sr = 0;
+            for (int i = lane_id(); i < n; i += 64) {
+                const double dp = fabs((double)PA[r0 + i] - pmean), dl = fabs((double)PB[r0 + i] - lmean);
+                int rp = 0, rl = 0;
+                for (int t = 0; t < n; t++) {
+                    const double tp = fabs((double)PA[r0 + t] - pmean), tl = fabs((double)PB[r0 + t] - lmean);
+                    rp += (tp < dp) || (tp == dp && t < i);
+                    rl += (tl < dl) || (tl == dl && t < i);
+                }
+                if (rp < keep) ks += PA[r0 + i];
+                if (rl < keep) kl += PB[r0 + i];
+                if (rp == 0) sr = PA[r0 + i];
+            }
+            ks = wave_sum_i64(ks); kl = wave_sum_i64(kl); sr = wave_sum_i64(sr);
+            bp = (double)ks / (double)keep; siglen = (double)kl / (double)keep; search = sr;   // INDEL:176-177,187
+        }
+        int cip = 0, cil = 0;
+        if (lane_id() == 0) {
+            cip = cipos_of(PA + r0, n, sp, B.sqrt_tab);                      // INDEL:191
+            cil = cipos_of(PB + r0, n, sl, B.sqrt_tab);                      // INDEL:194
+        }
+        i64 pick = -1; int valid = 1;
+        if (is_ins) {                                                       // INDEL:398-405
+            const i64 want = (i64)siglen;
+            valid = 0;
+            for (int base = 0; base < n; base += 64) {
+                const int i = base + lane_id();
+                const int ok = (i < n) && ((i64)B.aux[s + A.V1[r0 + (i < n ? i : 0)]] >= want);
+                const u64 mk = __ballot(ok);
+                if (mk) {
+                    const int i0 = base + __ffsll((long long)mk) - 1;
+                    pick = it.gsig0 + A.V1[r0 + i0];
+                    bp = (double)PA[r0 + i0];
+                    valid = 1;
+                    break;
+                }
+            }
+            search = (i64)bp;                                               // INDEL:415
+        }
+        // supports: the allele's kept signatures in allele order (INDEL:205, 416)
+        for (int i = lane_id(); i < n; i += 64) B.sup_tmp[s + soff + i] = s + A.V1[r0 + i];
+        if (lane_id() == 0) {
+            const int t = tbase + rank;
+            B.t_bp1[t] = (i64)bp; B.t_bp2[t] = (i64)siglen; B.t_support[t] = n;
+            B.t_cipos[t] = cip; B.t_cilen[t] = cil; B.t_search[t] = search; B.t_pick[t] = pick;
+            B.t_supoff[t] = soff; B.t_valid[t] = valid;
+            if (valid) { ncalls++; nsup += n; }
+        }
+    }
+    ncalls = (int)block_sum_i64<BLOCK>(ncalls, red);
+    nsup = (int)block_sum_i64<BLOCK>(nsup, red);
+    if (threadIdx.x == 0) {
+        B.item_tbase[it.j] = tbase; B.item_nslots[it.j] = npass; B.item_ncalls[it.j] = ncalls; B.item_nsup[it.j] = nsup;
+    }
+}
+
+// compacted write of the first-seen signatures of ranks [r0, r1) to sup_tmp[dst...]; one wavefront
+__device__ __forceinline__ void write_first_seen(const DevBatch& B, const Arrays& A, int s, int r0, int r1, int dst)
+{
+    int run = 0;
+    for (int base = r0; base < r1; base += 64) {
+        const int r = base + lane_id();
+        const int f = (r < r1) && (A.V1[r < r1 ? r : r0] < 0);
+        const u64 mk = __ballot(f);
+        if (f) B.sup_tmp[dst + run + __popcll(mk & lanemask_lt())] = s + (A.V1[r] & 0x7fffffff);
+        run += __popcll(mk);
+    }
+}
+
+// ---- DUP / INV / TRA: generate_dup_cluster (DUP:79-131), generate_semi_inv_cluster (INV:101-203),
+//      generate_semi_tra_cluster (TRA:106-254)
+template <int BLOCK> __device__ void refine_pair(const DevBatch& B, const ItemCtx& it, const Arrays& A, i64* red, int* ired)
+{
+    const csv_segment& sg = B.seg[it.k];
+    const int m = it.m, P = it.P, s = it.s, type = sg.svtype;
+    const int U = sort_by_read<BLOCK>(B, it, A, red);                       // V2 = (read id, index) order
+    if (U < sg.read_count) { item_none(B, it.j); return; }                  // DUP:82-84, INV:106-109, TRA:128-129
+
+    // stable sort by pos2 (DUP:86, INV:111, TRA:109): key = (pos2, local index)
+    for (int i = threadIdx.x; i < P; i += BLOCK) {
+        u64 key = PAD_KEY;
+        if (i < m) {
+            const i64 p2 = B.b[s + i];
+            if ((u64)p2 >> (63 - IDX_BITS)) atomicOr(&B.cnt->error, ERR_KEY_RANGE);
+            key = ((u64)p2 << IDX_BITS) | (u64)i;
+        }
+        A.K[i] = key;
+    }
+    __syncthreads();
+    bitonic_sort<BLOCK>(A.K, P);
+    for (int r = threadIdx.x; r < m; r += BLOCK) {
+        const u64 key = A.K[r];
+        const int i = (int)(key & IDX_MASK);
+        A.K[r] = (u64)B.a[s + i]; A.X[r] = (i64)(key >> IDX_BITS); A.V1[r] = i; A.V3[i] = r;
+    }
+    __syncthreads();
+    // sub-clusters on pos2 gaps > bias (DUP:91, INV:125, TRA:117): V4[r] = sub of rank r
+    const i64 bias = sg.max_cluster_bias;
+    int carry = 0;
+    for (int base = 0; base < m; base += BLOCK) {
+        const int r = base + threadIdx.x;
+        int f = 0;
+        if (r < m && r > 0) f = (A.X[r] - A.X[r - 1] > bias) ? 1 : 0;
+        int tot;
+        const int inc = block_incl_scan<BLOCK>(f, &tot, red);
+        if (r < m) A.V4[r] = carry + inc;
+        carry += tot;
+    }
+    const int nsub = carry + 1;
+    __syncthreads();
+    // first-seen flag: rank r is the first occurrence of its read inside its sub-cluster.  The other
+    // signatures of the same read are neighbours in V2 (read-id order).
+    for (int q = threadIdx.x; q < m; q += BLOCK) {
+        const int i = A.V2[q];
+        const int r = A.V3[i], k = A.V4[r];
+        const int id = B.rid[s + i];
+        int first = 1;
+        for (int t = q - 1; t >= 0 && first; t--) {
+            const int i2 = A.V2[t];
+            if (B.rid[s + i2] != id) break;
+            const int r2 = A.V3[i2];
+            if (A.V4[r2] == k && r2 < r) first = 0;
+        }
+        for (int t = q + 1; t < m && first; t++) {
+            const int i2 = A.V2[t];
+            if (B.rid[s + i2] != id) break;
+            const int r2 = A.V3[i2];
+            if (A.V4[r2] == k && r2 < r) first = 0;
+        }
+        if (first) A.V1[r] |= (int)0x80000000;
+    }
+    __syncthreads();
+    // group starts: V2[k] = first rank of sub k (the read-id order is dead now)
+    for (int r = threadIdx.x; r < m; r += BLOCK)
+        if (r == 0 || A.V4[r] != A.V4[r - 1]) A.V2[A.V4[r]] = r;
+    if (threadIdx.x == 0) A.V2[nsub] = m;
+    __syncthreads();
+    const i64* PA = (const i64*)A.K; const i64* PB = A.X;
+    // unique reads per sub-cluster -> V3[k]
+    for (int k = threadIdx.x >> 6; k < nsub; k += BLOCK / 64) {
+        const int r0 = A.V2[k], r1 = A.V2[k + 1];
+        int u = 0;
+        for (int r = r0 + lane_id(); r < r1; r += 64) u += (A.V1[r] < 0);
+        u = wave_sum_i32(u);
+        if (lane_id() == 0) A.V3[k] = u;
+    }
+    __syncthreads();
+
+    if (type == CSV_TRA) {
+        if ((threadIdx.x >> 6) != 0) return;                                // one wavefront finishes the item
+        // sorted(temp, key=-unique) is stable: best = first maximum, second = first maximum of the rest (TRA:131)
+        int bu = -1, bk = 0x7fffffff;
+        for (int k = lane_id(); k < nsub; k += 64) { const int u = A.V3[k]; if (u > bu) { bu = u; bk = k; } }
+        for (int msk = 32; msk > 0; msk >>= 1) {
+            const int ou = __shfl_xor(bu, msk), ok = __shfl_xor(bk, msk);
+            if (ou > bu || (ou == bu && ok < bk)) { bu = ou; bk = ok; }
+        }
+        int su = -1, sk = 0x7fffffff;
+        for (int k = lane_id(); k < nsub; k += 64) { if (k == bk) continue; const int u = A.V3[k]; if (u > su) { su = u; sk = k; } }
+        for (int msk = 32; msk > 0; msk >>= 1) {
+            const int ou = __shfl_xor(su, msk), ok = __shfl_xor(sk, msk);
+            if (ou > su || (ou == su && ok < sk)) { su = ou; sk = ok; }
+        }
+        const int tcode = B.aux[s] & 7;
+        int emit0 = -1, emit1 = -1, ne = 0;
+        if (tcode <= 3) {                                                   // TRA:154-155, 226-227
+            if (nsub > 1 && (double)su >= 0.5 * (double)sg.read_count) {    // TRA:133
+                if ((double)(bu + su) >= (double)m * sg.diff_ratio) { emit0 = bk; emit1 = sk; ne = 2; }       // TRA:134
+            } else if ((double)bu >= (double)m * sg.diff_ratio) { emit0 = bk; ne = 1; }                      // TRA:211
+        }
+        int tbase = 0;
+        if (lane_id() == 0) tbase = alloc_slots(B, ne);
+        tbase = __shfl(tbase, 0);
+        if (tbase < 0) { ne = 0; tbase = 0; }
+        int soff = 0;
+        for (int q = 0; q < ne; q++) {
+            const int k = q ? emit1 : emit0, r0 = A.V2[k], r1 = A.V2[k + 1], u = A.V3[k];
+            i64 s1 = 0, s2 = 0;
+            for (int r = r0 + lane_id(); r < r1; r += 64) { s1 += PA[r]; s2 += PB[r]; }
+            s1 = wave_sum_i64(s1); s2 = wave_sum_i64(s2);
+            int cnt = r1 - r0;
+            if (k == 0) { s1 += PA[0]; s2 += PB[0]; cnt += 1; }             // element 0 is visited twice, TRA:114-124
+            write_first_seen(B, A, s, r0, r1, s + soff);
+            if (lane_id() == 0) {
+                const int t = tbase + q;
+                B.t_bp1[t] = (i64)((double)s1 / (double)cnt);               // TRA:173
+                B.t_bp2[t] = (i64)((double)s2 / (double)cnt);               // TRA:175
+                B.t_support[t] = u; B.t_cipos[t] = 0; B.t_cilen[t] = 0; B.t_search[t] = 0; B.t_pick[t] = -1;
+                B.t_supoff[t] = soff; B.t_valid[t] = 1;
+            }
+            soff += u;
+        }
+        if (lane_id() == 0) {
+            B.item_tbase[it.j] = tbase; B.item_nslots[it.j] = ne; B.item_ncalls[it.j] = ne; B.item_nsup[it.j] = soff;
+        }
+        return;
+    }
+
+    // DUP / INV: slots for sub-clusters with enough reads, in sub order: V4[k] = slot, V5[k] = support offset
+    const int rc = sg.read_count;
+    int carry_slot = 0, carry_sup = 0;
+    for (int base = 0; base < nsub; base += BLOCK) {
+        const int k = base + threadIdx.x;
+        int pass = 0, u = 0;
+        if (k < nsub) {
+            u = A.V3[k];
+            const int n = A.V2[k + 1] - A.V2[k];
+            pass = (u >= rc) && (type == CSV_DUP || n >= rc);               // DUP:96-98; INV:126,132
+        }
+        int tot, tots;
+        const int inc = block_incl_scan<BLOCK>(pass, &tot, red);
+        const int incs = block_incl_scan<BLOCK>(pass ? u : 0, &tots, red);
+        if (k < nsub) { A.V4[k] = pass ? carry_slot + inc - 1 : -1; A.V5[k] = carry_sup + incs - (pass ? u : 0); }
+        carry_slot += tot; carry_sup += tots;
+    }
+    const int nslots = carry_slot;
+    if (threadIdx.x == 0) *ired = alloc_slots(B, nslots);
+    __syncthreads();
+    const int tbase = *ired;
+    if (tbase < 0) { item_none(B, it.j); return; }
+    int ncalls = 0, nsup = 0;
+    for (int k = threadIdx.x >> 6; k < nsub; k += BLOCK / 64) {
+        const int slot = A.V4[k];
+        if (slot < 0) continue;
+        const int r0 = A.V2[k], r1 = A.V2[k + 1], n = r1 - r0, u = A.V3[k];
+        i64 bp1, bp2;
+        if (type == CSV_DUP) {
+            const int lo = (int)((double)n * 0.4), hi = (int)((double)n * 0.6);         // DUP:99-100
+            if (lo == hi) { bp1 = PA[r0 + lo]; bp2 = PB[r0 + lo]; }
+            else {
+                i64 s1 = 0, s2 = 0;
+                for (int r = r0 + lo + lane_id(); r < r0 + hi; r += 64) { s1 += PA[r]; s2 += PB[r]; }
+                s1 = wave_sum_i64(s1); s2 = wave_sum_i64(s2);
+                bp1 = (i64)((double)s1 / (double)(hi - lo));                            // DUP:108-109
+                bp2 = (i64)((double)s2 / (double)(hi - lo));
+            }
+        } else {
+            i64 s1 = 0, s2 = 0;
+            for (int r = r0 + lane_id(); r < r1; r += 64) { s1 += PA[r]; s2 += PB[r]; }
+            s1 = wave_sum_i64(s1); s2 = wave_sum_i64(s2);
+            bp1 = (i64)rint((double)s1 / (double)n);                                    // INV:129-130 (round half even)
+            bp2 = (i64)rint((double)s2 / (double)n);
+        }
+        const i64 d = bp2 - bp1;
+        const int valid = (d >= sg.sv_size) && (d <= sg.max_size || sg.max_size == -1); // DUP:112; INV:132-134
+        write_first_seen(B, A, s, r0, r1, s + A.V5[k]);
+        if (lane_id() == 0) {
+            const int t = tbase + slot;
+            B.t_bp1[t] = bp1; B.t_bp2[t] = bp2; B.t_support[t] = u; B.t_cipos[t] = 0; B.t_cilen[t] = 0;
+            B.t_search[t] = 0; B.t_pick[t] = -1; B.t_supoff[t] = A.V5[k]; B.t_valid[t] = valid;
+            if (valid) { ncalls++; nsup += u; }
+        }
+    }
+    ncalls = (int)block_sum_i64<BLOCK>(ncalls, red);
+    nsup = (int)block_sum_i64<BLOCK>(nsup, red);
+    if (threadIdx.x == 0) {
+        B.item_tbase[it.j] = tbase; B.item_nslots[it.j] = nslots; B.item_ncalls[it.j] = ncalls; B.item_nsup[it.j] = nsup;
+    }
+}
+
+template <int CAP> constexpr int refine_lds_bytes() { return (CAP + ARR_PAD) * (8 + 8 + 4 * 5) + 64; }
+
+template <int BLOCK, int CAP> __global__ __launch_bounds__(BLOCK) void k_refine(DevBatch B, int big)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int N = CAP + ARR_PAD;
+    Arrays L;
+    L.K = (u64*)smem; L.X = (i64*)(smem + 8 * N);
+    L.V1 = (int*)(smem + 16 * N); L.V2 = L.V1 + N; L.V3 = L.V2 + N; L.V4 = L.V3 + N; L.V5 = L.V4 + N;
+    i64* red = (i64*)(smem + 36 * N);
+    int* ired = (int*)(red + 6);
+    const int n = big ? B.cnt->n_items_big : (B.cnt->n_items - B.cnt->n_items_big);
+    for (int q = blockIdx.x; q < n; q += gridDim.x) {
+        ItemCtx it;
+        it.j = big ? B.list_big[q] : B.list_small[q];
+        it.cid = B.item_cid[it.j];
+        it.k = B.item_seg[it.j];
+        it.s = B.cstart[it.cid];
+        it.m = B.cstart[it.cid + 1] - it.s;
+        it.gsig0 = B.seg[it.k].sig_begin + ((i64)it.s - B.woff[it.k]);
+        int P = 1;
+        while (P < it.m) P <<= 1;
+        it.P = P;
+        __syncthreads();                                  // LDS arrays of the previous item are dead
+        if (it.m > MAX_CLUSTER) {
+            if (threadIdx.x == 0) atomicOr(&B.cnt->error, ERR_CLUSTER_TOO_BIG);
+            item_none(B, it.j);
+            continue;
+        }
+        Arrays A = L;
+        if (P > CAP) {
+            const i64 o = 2ll * it.s;
+            A.K = B.sc_k + o; A.X = B.sc_x + o; A.V1 = B.sc_v1 + o; A.V2 = B.sc_v2 + o; A.V3 = B.sc_v3 + o;
+            A.V4 = B.sc_v4 + o; A.V5 = B.sc_v5 + o;
+        }
+        const int t = B.seg[it.k].svtype;
+        if (t == CSV_DEL || t == CSV_INS) refine_indel<BLOCK>(B, it, A, red, ired);
+        else refine_pair<BLOCK>(B, it, A, red, ired);
+    }
+}
+
+// ------------------------------------------------------------------------------------ order
+// exclusive scan of the per-item packed counts (valid calls << 32 | supports); single workgroup of 1024
+constexpr int IS_PER = 8;
+__global__ __launch_bounds__(1024) void k_items_scan(DevBatch B)
+{
+    const int n = B.cnt->n_items;
+    __shared__ i64 wsum[16];
+    __shared__ i64 carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024 * IS_PER) {
+        const int i0 = base + threadIdx.x * IS_PER;
+        i64 v[IS_PER]; i64 loc = 0;
+#pragma unroll
+        for (int q = 0; q < IS_PER; q++) {
+            const int i = i0 + q;
+            v[q] = i < n ? (((i64)B.item_ncalls[i]) << 32) + (i64)B.item_nsup[i] : 0;
+            loc += v[q];
+        }
+        const i64 inc = wave_incl_scan_i64(loc);
+        if (lane_id() == 63) wsum[threadIdx.x >> 6] = inc;
+        __syncthreads();
+        i64 woff = 0;
+        for (int k = 0; k < (int)(threadIdx.x >> 6); k++) woff += wsum[k];
+        const i64 carry = carry_s;
+        i64 run = carry + woff + inc - loc;
+#pragma unroll
+        for (int q = 0; q < IS_PER; q++) { const int i = i0 + q; if (i < n) B.item_base[i] = run; run += v[q]; }
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = carry + woff + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const i64 t = carry_s;
+        const int nc = (int)(t >> 32); const i64 ns = t & 0xffffffffll;
+        B.cnt->n_calls = nc; B.cnt->n_support = ns;
+        B.o_supoff[nc] = ns;
+    }
+}
+
+// one wavefront per item: compact its valid temp calls into the final, ordered arrays
+__global__ __launch_bounds__(256) void k_emit(DevBatch B)
+{
+    const int n = B.cnt->n_items;
+    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = (gridDim.x * 256) >> 6;
+    for (int j = wave; j < n; j += nwaves) {
+        const int nslots = B.item_nslots[j];
+        if (nslots == 0) continue;
+        const int tbase = B.item_tbase[j], cid = B.item_cid[j], k = B.item_seg[j], s = B.cstart[cid];
+        const i64 gs = B.seg[k].sig_begin + ((i64)s - B.woff[k]) - s;      // w -> global signature index
+        const i64 base = B.item_base[j];
+        int cb = (int)(base >> 32); i64 sb = base & 0xffffffffll;
+        const int aux0 = B.aux[s];
+        for (int c0 = 0; c0 < nslots; c0 += 64) {
+            const int t = tbase + c0 + lane_id();
+            const int in = (c0 + lane_id()) < nslots;
+            const int valid = in ? B.t_valid[t] : 0;
+            const int nsup = valid ? B.t_support[t] : 0;
+            const u64 mk = __ballot(valid);
+            const int c = cb + __popcll(mk & lanemask_lt());
+            const int sinc = wave_incl_scan_i32(nsup);
+            const i64 so = sb + sinc - nsup;
+            if (valid) {
+                B.o_seg[c] = k; B.o_cluster[c] = cid; B.o_aux[c] = aux0;
+                B.o_bp1[c] = B.t_bp1[t]; B.o_bp2[c] = B.t_bp2[t]; B.o_support[c] = nsup;
+                B.o_cipos[c] = B.t_cipos[t]; B.o_cilen[c] = B.t_cilen[t];
+                B.o_search[c] = B.t_search[t]; B.o_pick[c] = B.t_pick[t];
+                B.o_dr[c] = -1; B.o_dv[c] = -1; B.o_gl[c] = -1;
+                B.o_supoff[c] = so;
+            }
+            // supports of each valid slot, all lanes cooperating
+            u64 rest = mk;
+            while (rest) {
+                const int l = __ffsll((long long)rest) - 1;
+                rest &= rest - 1;
+                const int cc = __shfl(c, l), nn = __shfl(nsup, l);
+                const i64 dst = shfl_i64(so, l);
+                const int src = s + __shfl(valid ? B.t_supoff[t] : 0, l);
+                for (int i = lane_id(); i < nn; i += 64) {
+                    const int w = B.sup_tmp[src + i];
+                    B.o_supsig[dst + i] = gs + w;
+                    B.o_suprid[dst + i] = B.rid[w];
+                    B.allele_id[w] = cc;
+                }
+            }
+            cb += __popcll(mk);
+            sb += __shfl(sinc, 63);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ reads: prefix max of ends
+constexpr int PM_TILE = 256 * 8;
+__device__ __forceinline__ bool is_chrom_start(const DevBatch& B, i64 i)
+{
+    int lo = 0, hi = B.n_chrom;
+    while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (B.reads_off[mid] <= i) lo = mid; else hi = mid; }
+    return B.reads_off[lo] == i;
+}
+
+__global__ __launch_bounds__(256) void k_pmax_count(DevBatch B)
+{
+    const i64 base = (i64)blockIdx.x * PM_TILE + (threadIdx.x >> 6) * 512;
+    i64 mx = INT64_MIN;
+    for (int r = 0; r < 8; r++) {
+        const i64 i = base + r * 64 + lane_id();
+        if (i < B.n_reads) {
+            const i64 e = B.r_end[i];
+            if (e > mx) mx = e;
+            if (i > 0 && B.r_start[i] < B.r_start[i - 1] && !is_chrom_start(B, i)) atomicOr(&B.cnt->error, ERR_READS_UNSORTED);
+        }
+    }
+    for (int m = 32; m > 0; m >>= 1) { const i64 o = shfl_xor_i64(mx, m); if (o > mx) mx = o; }
+    __shared__ i64 s[4];
+    if (lane_id() == 0) s[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) { i64 t = s[0]; for (int k = 1; k < 4; k++) if (s[k] > t) t = s[k]; B.partial64[blockIdx.x] = t; }
+}
+
+// exclusive max-scan of the tile maxima (single workgroup)
+__global__ __launch_bounds__(256) void k_pmax_scan(i64* p, int n)
+{
+    __shared__ i64 wmax[4];
+    __shared__ i64 carry_s;
+    if (threadIdx.x == 0) carry_s = INT64_MIN;
+    __syncthreads();
+    for (int base = 0; base < n; base += 256) {
+        const int i = base + threadIdx.x;
+        const i64 v = i < n ? p[i] : INT64_MIN;
+        const i64 inc = wave_incl_max_i64(v);
+        if (lane_id() == 63) wmax[threadIdx.x >> 6] = inc;
+        __syncthreads();
+        i64 pre = carry_s;
+        for (int k = 0; k < (int)(threadIdx.x >> 6); k++) if (wmax[k] > pre) pre = wmax[k];
+        i64 ex = shfl_up_i64(inc, 1);
+        if (lane_id() == 0) ex = INT64_MIN;
+        if (pre > ex) ex = pre;
+        if (i < n) p[i] = ex;
+        __syncthreads();
+        if (threadIdx.x == 255) carry_s = inc > pre ? inc : pre;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_pmax_apply(DevBatch B)
+{
+    const int wv = threadIdx.x >> 6;
+    const i64 base = (i64)blockIdx.x * PM_TILE + wv * 512;
+    i64 rowmax[8]; i64 vals[8];
+    i64 run = INT64_MIN;
+    for (int r = 0; r < 8; r++) {
+        const i64 i = base + r * 64 + lane_id();
+        const i64 e = i < B.n_reads ? B.r_end[i] : INT64_MIN;
+        i64 inc = wave_incl_max_i64(e);
+        if (run > inc) inc = run;
+        vals[r] = inc;
+        run = shfl_i64(inc, 63);
+        rowmax[r] = run;
+    }
+    __shared__ i64 s[4];
+    if (lane_id() == 0) s[wv] = run;
+    __syncthreads();
+    i64 pre = B.partial64[blockIdx.x];
+    for (int k = 0; k < wv; k++) if (s[k] > pre) pre = s[k];
+    for (int r = 0; r < 8; r++) {
+        const i64 i = base + r * 64 + lane_id();
+        if (i < B.n_reads) B.r_pmax[i] = vals[r] > pre ? vals[r] : pre;
+    }
+    (void)rowmax;
+}
+
+// ------------------------------------------------------------------------------------ genotype
+// One wavefront per call.  cover(window) = primary reads with 2*start <= L2 and 2*end >= R2 (doubled
+// coordinates keep the x.5 windows of DUP/INV exact; GT:95-159, semantics as in GT.duipai :206-212).
+// DR = distinct cover names that are not support names (GT:167-170): an LDS hash set is seeded with the
+// support read ids, then every covering read id is inserted; each fresh insert is one DR.
+constexpr int GT_HASH = 2048;                       // slots per wavefront
+constexpr int GT_HASH_FILL = 1536;
+
+__device__ __forceinline__ int hash_insert(int* tab, int id)
+{
+    unsigned h = ((unsigned)id * 2654435761u) >> 21;               // 11 bits
+    for (;;) {
+        const int old = atomicCAS(&tab[h], -1, id);
+        if (old == -1) return 1;
+        if (old == id) return 0;
+        h = (h + 1) & (GT_HASH - 1);
+    }
+}
+
+// first index in [lo, hi) with 2*start > L2 (64-ary search, every step one coalesced-ish probe per lane)
+__device__ __forceinline__ i64 upper_bound_start(const i64* __restrict__ st, i64 lo, i64 hi, i64 L2)
+{
+    while (hi - lo > 64) {
+        const i64 step = (hi - lo + 63) / 64;
+        const i64 idx = lo + (i64)lane_id() * step;
+        const int pred = (idx < hi) && (2 * st[idx < hi ? idx : lo] <= L2);
+        const int t = __popcll(__ballot(pred));
+        if (t == 0) return lo;
+        const i64 nlo = lo + (i64)(t - 1) * step + 1;
+        i64 nhi = lo + (i64)t * step;
+        if (nhi > hi) nhi = hi;
+        lo = nlo; hi = nhi;
+    }
+    const i64 idx = lo + lane_id();
+    const int pred = (idx < hi) && (2 * st[idx < hi ? idx : lo] <= L2);
+    return lo + __popcll(__ballot(pred));
+}
+
+__device__ __forceinline__ int cover_window(const DevBatch& B, int* tab, i64 r0, i64 r1, i64 L2, i64 R2, int& filled)
+{
+    int dr = 0;
+    const i64 ub = upper_bound_start(B.r_start, r0, r1, L2);
+    for (i64 top = ub - 1; top >= r0; top -= 64) {
+        const i64 i = top - lane_id();
+        const int in = i >= r0;
+        const i64 ii = in ? i : r0;
+        const int live = in && (2 * B.r_pmax[ii] >= R2);           // nothing at or before a dead lane reaches R
+        const int cov = live && B.r_primary[ii] == 1 && (2 * B.r_end[ii] >= R2);
+        if (filled + 64 > GT_HASH_FILL) { atomicOr(&B.cnt->error, ERR_COVER_OVERFLOW); return dr; }
+        int ins = 0;
+        if (cov) ins = hash_insert(tab, B.r_id[ii]);
+        const int c = __popcll(__ballot(ins));
+        dr += c; filled += c;
+        if (__ballot(!live)) break;
+    }
+    return dr;
+}
+
+__device__ __forceinline__ int gl_index_dev(i64 c0, i64 c1)
+{
+    if (c0 == 3 && c1 == 1) return 101 * 101;
+    if (c0 == 6 && c1 == 2) return 101 * 101 + 1;
+    const i64 total = c0 + c1;
+    if (total > 100) {
+        const double frac = (double)c0 / (double)total;
+        c0 = (i64)(100.0 * frac);
+        c1 = 100 - c0;
+    }
+    return (int)(c0 * 101 + c1);
+}
+
+__global__ __launch_bounds__(256) void k_genotype(DevBatch B)
+{
+    __shared__ int tabs[4][GT_HASH];
+    int* tab = tabs[threadIdx.x >> 6];
+    const int n = B.cnt->n_calls;
+    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = (gridDim.x * 256) >> 6;
+    for (int c = wave; c < n; c += nwaves) {
+        const csv_segment& sg = B.seg[B.o_seg[c]];
+        if (!sg.genotype) continue;
+        for (int i = lane_id(); i < GT_HASH; i += 64) tab[i] = -1;
+        const i64 s0 = B.o_supoff[c], ns = B.o_supoff[c + 1] - s0;
+        int filled = 0;
+        bool overflow = false;
+        for (i64 base = 0; base < ns; base += 64) {
+            if (filled + 64 > GT_HASH_FILL) { overflow = true; break; }
+            const i64 i = base + lane_id();
+            int ins = 0;
+            if (i < ns) ins = hash_insert(tab, B.o_suprid[s0 + i]);
+            filled += __popcll(__ballot(ins));
+        }
+        if (overflow) { atomicOr(&B.cnt->error, ERR_COVER_OVERFLOW); continue; }
+        const i64 r0 = B.reads_off[sg.chrom], r1 = B.reads_off[sg.chrom + 1];
+        int dr = 0;
+        if (sg.svtype == CSV_DEL || sg.svtype == CSV_INS) {
+            const i64 p = B.o_search[c], g = sg.gt_bias;                    // INDEL:450-451
+            i64 L = p - g; if (L < 0) L = 0;
+            dr = cover_window(B, tab, r0, r1, 2 * L, 2 * (p + g), filled);
+        } else {
+            i64 nb = sg.gt_bias;
+            const i64 b1 = B.o_bp1[c], b2 = B.o_bp2[c];
+            if (sg.svtype == CSV_DUP && b2 - b1 < nb) nb = b2 - b1;         // DUP:147
+            i64 L2 = 2 * b1 - nb; if (L2 < 0) L2 = 0;                       // DUP:148-151, INV:219-221
+            dr = cover_window(B, tab, r0, r1, L2, 2 * b1 + nb, filled);
+            L2 = 2 * b2 - nb; if (L2 < 0) L2 = 0;
+            dr += cover_window(B, tab, r0, r1, L2, 2 * b2 + nb, filled);    // union of both windows: DUP:155-157
+        }
+        if (lane_id() == 0) { B.o_dr[c] = dr; B.o_dv[c] = (int)ns; B.o_gl[c] = gl_index_dev(dr, ns); }
+    }
+}
+
+}  // namespace csv

@@ -634,6 +634,7 @@ int csvo_cluster_batch(const csv_batch_in* in, csv_batch_out* out)
     int rc = CSV_OK;
     int32_t cid = -1;
     if (out->allele_id) for (int64_t i = 0; i < in->n_sig; i++) out->allele_id[i] = -1;
+    if (out->cluster_id) for (int64_t i = 0; i < in->n_sig; i++) out->cluster_id[i] = -1;
     for (int32_t k = 0; k < in->n_seg && rc == CSV_OK; k++) {
         const csv_segment* sg = &in->seg[k];
         if (sg->svtype < CSV_DEL || sg->svtype > CSV_TRA || sg->sig_begin > sg->sig_end ||

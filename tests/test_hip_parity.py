@@ -1,0 +1,122 @@
+"""GPU parity tests (-m gpu): the HIP path through the C ABI against the oracle and the golden fixtures."""
+import numpy as np
+import pytest
+
+from cutesv_amd import synth, engine, _abi
+from cutesv_amd.columns import Params
+from helpers import (load_json, store_from_json, rows_by_task, assert_rows_equal, assert_soa_equal, digest)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = engine.Context(0)
+    yield c
+    c.close()
+
+
+def _oracle():
+    from oracle import oracle
+    return oracle
+
+
+def _hip_engine(ctx):
+    return lambda hb: ctx.cluster_batch(hb, per_sig=True)
+
+
+def _set_order_segments(hb):
+    return set(np.flatnonzero((hb.segments["svtype"] == _abi.DUP) | (hb.segments["svtype"] == _abi.TRA)).tolist())
+
+
+def _compare_soa(ctx, st, p, tasks=None):
+    tasks = tasks or st.tasks()
+    hb = st.host_batch(tasks, p)
+    want = _oracle().cluster_batch(hb, per_sig=True).trimmed()
+    got = ctx.cluster_batch(hb, per_sig=True).trimmed()
+    # allele_id of DUP/TRA support lists depends on the (set-ordered) choice of representative signature
+    so = _set_order_segments(hb)
+    assert_soa_equal(got, want, store=st, set_order_segments=())
+    return got
+
+
+def test_small_cases_rows_identical_to_reference(ctx):
+    for case in load_json("small_cases.json.gz"):
+        st = store_from_json(case["store"])
+        p = Params(**case["params"])
+        want = {(t, c): r for t, c, r in case["rows"]}
+        got, res, hb = rows_by_task(st, p, _hip_engine(ctx), tasks=list(want.keys()))
+        for key in want:
+            assert_rows_equal(key[0], got[key], want[key], where="%s %s" % (case["name"], key))
+
+
+def test_known_answers(ctx):
+    for case in load_json("known_answers.json"):
+        st = store_from_json(case["store"])
+        p = Params(**case["params"])
+        want = {(t, c): r for t, c, r in case["rows"]}
+        got, res, hb = rows_by_task(st, p, _hip_engine(ctx), tasks=list(want.keys()))
+        for key in want:
+            assert_rows_equal(key[0], got[key], want[key], where="%s %s" % (case["name"], key))
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+@pytest.mark.parametrize("preset", ["default", "ont", "hifi", "keep"])
+def test_soa_bit_exact_vs_oracle_small(ctx, seed, preset):
+    p = {"default": Params(genotype=True), "ont": Params.ont(genotype=True),
+         "hifi": Params.hifi(genotype=True, min_support=3), "keep": Params.ont(remain_reads_ratio=0.6, genotype=True)}[preset]
+    st = synth.small_mixed(seed=100 + seed, dup_frac=0.2, n_loci=200)
+    _compare_soa(ctx, st, p)
+
+
+def test_large_clusters_all_tiers(ctx):
+    # wide bias chains thousands of signatures together: exercises the workgroup tier in LDS and in global scratch
+    st = synth.small_mixed(seed=77, n_sites=30, coverage=60, n_noise=30000, n_loci=3000, contig_len=400_000, dup_frac=0.3)
+    p = Params(max_cluster_bias_DEL=3000, max_cluster_bias_INS=3000, max_cluster_bias_DUP=20000, max_cluster_bias_INV=20000,
+               max_cluster_bias_TRA=5000, min_support=3, genotype=False)
+    got = _compare_soa(ctx, st, p)
+    sizes = np.bincount(got["cluster_id"][got["cluster_id"] >= 0])
+    assert sizes.max() > 2048, sizes.max()
+
+
+@pytest.mark.parametrize("name", ["cfg1", "cfg2", "cfg3_s025", "cfg4_s002", "cfg5_s002"])
+def test_config_digests(ctx, name, golden_dir):
+    d = load_json("digests.json")[name]
+    sites = dict(np.load(golden_dir + "/sim_sites.npz"))
+    st = {"cfg1": lambda: synth.sim_all_types(sites, seed=20260101, chroms=["1"]),
+          "cfg2": lambda: synth.sim_all_types(sites, seed=20260102),
+          "cfg3_s025": lambda: synth.ont30(scale=0.25),
+          "cfg4_s002": lambda: synth.hifi30_gt(scale=0.02),
+          "cfg5_s002": lambda: synth.ont90_all(scale=0.02)}[name]()
+    p = Params(**d["params"])
+    got, res, hb = rows_by_task(st, p, _hip_engine(ctx))
+    for (t, c), rows in got.items():
+        n, h = d["segments"]["%s:%s" % (t, c)]
+        assert len(rows) == n, (t, c)
+        assert digest(t, rows) == h, (t, c)
+
+
+def test_full_size_cfg3_vs_oracle(ctx):
+    st = synth.ont30()                      # ~2.8 M signatures: BASELINE config 3 at full size
+    assert st.n_sig > 2_500_000
+    _compare_soa(ctx, st, Params.ont())
+
+
+def test_empty_and_ragged(ctx):
+    st = synth.small_mixed(seed=5, genotype=False)
+    p = Params.ont()
+    # a batch with no segments, and a batch made of a strict subset of non-adjacent segments
+    hb = st.host_batch([], p)
+    res = ctx.cluster_batch(hb)
+    assert res.n_calls == 0 and res.n_support == 0
+    tasks = [t for i, t in enumerate(st.tasks()) if i % 2 == 0]
+    _compare_soa(ctx, st, p, tasks=tasks)
+
+
+def test_tra_genotype_is_refused(ctx):
+    st = synth.small_mixed(seed=5)
+    hb = st.host_batch([t for t in st.tasks() if t[0] == "TRA"][:1], Params())
+    hb.segments["genotype"] = 1
+    with pytest.raises(engine.CsvError) as e:
+        ctx.cluster_batch(hb)
+    assert e.value.code == _abi.E_INVALID
