@@ -4,6 +4,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -140,8 +141,8 @@ int csv_ctx_create(int device_id, csv_ctx** out)
 void csv_ctx_destroy(csv_ctx* c)
 {
     if (!c) return;
-    hipSetDevice(c->device);
-    hipStreamSynchronize(c->stream);
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
     Buf* all[] = {&c->seg, &c->woff, &c->seg_drop, &c->a, &c->b, &c->rid, &c->aux, &c->cluster_id, &c->cstart, &c->partial,
                   &c->partial64, &c->item_cid, &c->item_seg, &c->list_small, &c->list_big, &c->item_tbase, &c->item_nslots,
                   &c->item_ncalls, &c->item_nsup, &c->sup_tmp, &c->item_base, &c->t_bp1, &c->t_bp2, &c->t_search, &c->t_pick,
@@ -150,9 +151,9 @@ void csv_ctx_destroy(csv_ctx* c)
                   &c->o_cipos, &c->o_cilen, &c->o_search, &c->o_pick, &c->o_dr, &c->o_dv, &c->o_gl, &c->o_supoff, &c->o_supsig,
                   &c->o_suprid, &c->allele_id, &c->reads_off, &c->r_start, &c->r_end, &c->r_primary, &c->r_id, &c->r_pmax,
                   &c->sqrt_tab, &c->cnt};
-    for (Buf* b : all) if (b->p) hipFree(b->p);
-    for (auto& e : c->ev) if (e) hipEventDestroy(e);
-    if (c->stream) hipStreamDestroy(c->stream);
+    for (Buf* b : all) if (b->p) (void)hipFree(b->p);
+    for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
@@ -294,38 +295,61 @@ int csv_batch_run(csv_ctx* c, csv_run_stats* stats)
     }
     int ev = 0;
     auto mark = [&]() -> hipError_t { return stats ? hipEventRecord(c->ev[ev++], st) : hipSuccess; };
+    const bool dbg = getenv("CSV_DEBUG") != nullptr;
+#define DBG(name)                                                                                          \
+    do {                                                                                                   \
+        if (dbg) {                                                                                         \
+            fprintf(stderr, "[csv] %s ...", name); fflush(stderr);                                         \
+            hipError_t e_ = hipStreamSynchronize(st);                                                      \
+            fprintf(stderr, " %s\n", hipGetErrorString(e_)); fflush(stderr);                               \
+        }                                                                                                  \
+    } while (0)
     HIP_TRY(c, mark());
     HIP_TRY(c, hipMemsetAsync(c->cnt.p, 0, sizeof(DevCounters), st));
     if (W > 0) {
         HIP_TRY(c, hipMemsetAsync(c->allele_id.p, 0xff, W * 4, st));
         const int nb = div_up(W, CH_TILE);
         hipLaunchKernelGGL(k_chain_count, dim3(nb), dim3(256), 0, st, B);
+        DBG("chain_count");
         hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(256), 0, st, B.partial, nb, (int*)nullptr);
+        DBG("scan_partials");
         hipLaunchKernelGGL(k_chain_apply, dim3(nb), dim3(256), 0, st, B);
+        DBG("chain_apply");
         HIP_TRY(c, mark());
         const int ns = div_up(W, 256);
         hipLaunchKernelGGL(k_select_count, dim3(ns), dim3(256), 0, st, B);
+        DBG("select_count");
         hipLaunchKernelGGL(k_scan_partials64, dim3(1), dim3(256), 0, st, B.partial64, &B.cnt->n_clusters, 256, &B.cnt->sel_total);
+        DBG("scan_partials64");
         hipLaunchKernelGGL(k_select_apply, dim3(ns), dim3(256), 0, st, B);
+        DBG("select_apply");
         HIP_TRY(c, mark());
         int g_small = B.cap_items < 8192 ? B.cap_items : 8192;
         if (g_small < 1) g_small = 1;
         hipLaunchKernelGGL((k_refine<64, 64>), dim3(g_small), dim3(64), LDS_SMALL, st, B, 0);
+        DBG("refine_small");
         HIP_TRY(c, mark());
         int g_big = B.cap_items < 512 ? B.cap_items : 512;
         if (g_big < 1) g_big = 1;
         hipLaunchKernelGGL((k_refine<256, 2048>), dim3(g_big), dim3(256), LDS_BIG, st, B, 1);
+        DBG("refine_big");
         HIP_TRY(c, mark());
         hipLaunchKernelGGL(k_items_scan, dim3(1), dim3(1024), 0, st, B);
+        DBG("items_scan");
         hipLaunchKernelGGL(k_emit, dim3(1024), dim3(256), 0, st, B);
+        DBG("emit");
         HIP_TRY(c, mark());
         if (c->any_genotype && B.n_reads > 0) {
             const int nr = div_up(B.n_reads, PM_TILE);
             hipLaunchKernelGGL(k_pmax_count, dim3(nr), dim3(256), 0, st, B);
+        DBG("pmax_count");
             hipLaunchKernelGGL(k_pmax_scan, dim3(1), dim3(256), 0, st, B.partial64, nr);
+        DBG("pmax_scan");
             hipLaunchKernelGGL(k_pmax_apply, dim3(nr), dim3(256), 0, st, B);
+        DBG("pmax_apply");
             HIP_TRY(c, mark());
             hipLaunchKernelGGL(k_genotype, dim3(1024), dim3(256), 0, st, B);
+        DBG("genotype");
             HIP_TRY(c, mark());
         } else {
             HIP_TRY(c, mark());

@@ -857,11 +857,17 @@ template <int BLOCK> __device__ void refine_pair(const DevBatch& B, const ItemCt
     }
 }
 
-template <int CAP> constexpr int refine_lds_bytes() { return (CAP + ARR_PAD) * (8 + 8 + 4 * 5) + 64; }
+// The arrays are reached through FLAT pointers (they may also live in global scratch).  hipcc folds
+// `K[q - 1]`-style neighbour reads into `flat_load ... offset:8` off a pointer to the element BEFORE
+// the one read; the hardware picks the aperture from that base, so an array at LDS offset 0 would send
+// the q = 0 iteration's base below the LDS aperture and fault.  LDS_LEAD keeps every base inside it.
+constexpr int LDS_LEAD = 64;
+template <int CAP> constexpr int refine_lds_bytes() { return LDS_LEAD + (CAP + ARR_PAD) * (8 + 8 + 4 * 5) + 64; }
 
 template <int BLOCK, int CAP> __global__ __launch_bounds__(BLOCK) void k_refine(DevBatch B, int big)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    char* smem = smem_raw + LDS_LEAD;
     constexpr int N = CAP + ARR_PAD;
     Arrays L;
     L.K = (u64*)smem; L.X = (i64*)(smem + 8 * N);
