@@ -16,7 +16,7 @@ SVTYPE_NAME = {v: k for k, v in SVTYPE_CODE.items()}
 OK, E_INVALID, E_CAPACITY, E_HIP, E_NOMEM, E_UNSORTED, E_STATE = range(7)
 ERR_NAME = {OK: "CSV_OK", E_INVALID: "CSV_E_INVALID", E_CAPACITY: "CSV_E_CAPACITY", E_HIP: "CSV_E_HIP",
             E_NOMEM: "CSV_E_NOMEM", E_UNSORTED: "CSV_E_UNSORTED", E_STATE: "CSV_E_STATE"}
-N_STAGES = 8
+N_STAGES = 16
 GL_TABLE_SIZE = 101 * 101 + 2
 
 # numpy dtype with exactly the C layout of `csv_segment` (all members naturally aligned)

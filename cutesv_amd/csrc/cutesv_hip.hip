@@ -21,9 +21,11 @@ struct Buf {                      // grow-only device buffer
     size_t cap = 0;
 };
 
-enum StageId { ST_CHAIN = 0, ST_SELECT, ST_REFINE_SMALL, ST_REFINE_BIG, ST_ORDER, ST_READS, ST_GENOTYPE, ST_SPARE };
-const char* kStageName[CSV_N_STAGES] = {"chain", "select", "refine_wave", "refine_block", "order", "reads_pmax",
-                                        "genotype", "spare"};
+// one timing slot per launch, in launch order
+const char* kStageName[CSV_N_STAGES] = {"init_memset", "k_chain_count", "k_scan_partials", "k_chain_apply", "k_select_count",
+                                        "k_scan_partials64", "k_select_apply", "k_refine_wave", "k_refine_block",
+                                        "k_items_scan", "k_emit", "k_pmax_count", "k_pmax_scan", "k_pmax_apply",
+                                        "k_genotype", ""};
 
 }  // namespace
 
@@ -306,58 +308,40 @@ int csv_batch_run(csv_ctx* c, csv_run_stats* stats)
     } while (0)
     HIP_TRY(c, mark());
     HIP_TRY(c, hipMemsetAsync(c->cnt.p, 0, sizeof(DevCounters), st));
+    if (W > 0) HIP_TRY(c, hipMemsetAsync(c->allele_id.p, 0xff, W * 4, st));
+    HIP_TRY(c, mark());                                                              // slot 0: init_memset
+#define LAUNCH(name, kern, grid, block, lds, ...)                                      \
+    do {                                                                               \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, st, __VA_ARGS__);        \
+        DBG(name);                                                                     \
+        HIP_TRY(c, mark());                                                            \
+    } while (0)
     if (W > 0) {
-        HIP_TRY(c, hipMemsetAsync(c->allele_id.p, 0xff, W * 4, st));
         const int nb = div_up(W, CH_TILE);
-        hipLaunchKernelGGL(k_chain_count, dim3(nb), dim3(256), 0, st, B);
-        DBG("chain_count");
-        hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(256), 0, st, B.partial, nb, (int*)nullptr);
-        DBG("scan_partials");
-        hipLaunchKernelGGL(k_chain_apply, dim3(nb), dim3(256), 0, st, B);
-        DBG("chain_apply");
-        HIP_TRY(c, mark());
+        LAUNCH("chain_count", k_chain_count, nb, 256, 0, B);
+        LAUNCH("scan_partials", k_scan_partials, 1, 256, 0, B.partial, nb, (int*)nullptr);
+        LAUNCH("chain_apply", k_chain_apply, nb, 256, 0, B);
         const int ns = div_up(W, 256);
-        hipLaunchKernelGGL(k_select_count, dim3(ns), dim3(256), 0, st, B);
-        DBG("select_count");
-        hipLaunchKernelGGL(k_scan_partials64, dim3(1), dim3(256), 0, st, B.partial64, &B.cnt->n_clusters, 256, &B.cnt->sel_total);
-        DBG("scan_partials64");
-        hipLaunchKernelGGL(k_select_apply, dim3(ns), dim3(256), 0, st, B);
-        DBG("select_apply");
-        HIP_TRY(c, mark());
+        LAUNCH("select_count", k_select_count, ns, 256, 0, B);
+        LAUNCH("scan_partials64", k_scan_partials64, 1, 256, 0, B.partial64, &B.cnt->n_clusters, 256, &B.cnt->sel_total);
+        LAUNCH("select_apply", k_select_apply, ns, 256, 0, B);
         int g_small = B.cap_items < 8192 ? B.cap_items : 8192;
         if (g_small < 1) g_small = 1;
-        hipLaunchKernelGGL((k_refine<64, 64>), dim3(g_small), dim3(64), LDS_SMALL, st, B, 0);
-        DBG("refine_small");
-        HIP_TRY(c, mark());
+        LAUNCH("refine_wave", (k_refine<64, 64>), g_small, 64, LDS_SMALL, B, 0);
         int g_big = B.cap_items < 512 ? B.cap_items : 512;
         if (g_big < 1) g_big = 1;
-        hipLaunchKernelGGL((k_refine<256, 2048>), dim3(g_big), dim3(256), LDS_BIG, st, B, 1);
-        DBG("refine_big");
-        HIP_TRY(c, mark());
-        hipLaunchKernelGGL(k_items_scan, dim3(1), dim3(1024), 0, st, B);
-        DBG("items_scan");
-        hipLaunchKernelGGL(k_emit, dim3(1024), dim3(256), 0, st, B);
-        DBG("emit");
-        HIP_TRY(c, mark());
+        LAUNCH("refine_block", (k_refine<256, 2048>), g_big, 256, LDS_BIG, B, 1);
+        LAUNCH("items_scan", k_items_scan, 1, 1024, 0, B);
+        LAUNCH("emit", k_emit, 1024, 256, 0, B);
         if (c->any_genotype && B.n_reads > 0) {
             const int nr = div_up(B.n_reads, PM_TILE);
-            hipLaunchKernelGGL(k_pmax_count, dim3(nr), dim3(256), 0, st, B);
-        DBG("pmax_count");
-            hipLaunchKernelGGL(k_pmax_scan, dim3(1), dim3(256), 0, st, B.partial64, nr);
-        DBG("pmax_scan");
-            hipLaunchKernelGGL(k_pmax_apply, dim3(nr), dim3(256), 0, st, B);
-        DBG("pmax_apply");
-            HIP_TRY(c, mark());
-            hipLaunchKernelGGL(k_genotype, dim3(1024), dim3(256), 0, st, B);
-        DBG("genotype");
-            HIP_TRY(c, mark());
-        } else {
-            HIP_TRY(c, mark());
-            HIP_TRY(c, mark());
+            LAUNCH("pmax_count", k_pmax_count, nr, 256, 0, B);
+            LAUNCH("pmax_scan", k_pmax_scan, 1, 256, 0, B.partial64, nr);
+            LAUNCH("pmax_apply", k_pmax_apply, nr, 256, 0, B);
+            LAUNCH("genotype", k_genotype, 1024, 256, 0, B);
         }
-    } else {
-        for (int i = 0; i < 7; i++) HIP_TRY(c, mark());
     }
+#undef LAUNCH
     HIP_TRY(c, hipGetLastError());
     c->ran = true;
     if (stats) {

@@ -146,9 +146,10 @@ typedef struct csv_batch_out {
     int32_t* allele_id;     /* n_sig or NULL */
 } csv_batch_out;
 
-/* Per-stage device timings of one csv_batch_run, measured with HIP events on the
- * context's stream.  Stage names: csv_stage_name(i). */
-#define CSV_N_STAGES 8
+/* Per-kernel device timings of one csv_batch_run, measured with HIP events recorded on the
+ * context's stream around every launch (only when stats != NULL; the plain run records nothing).
+ * Kernel names: csv_stage_name(i); unused slots are 0. */
+#define CSV_N_STAGES 16
 typedef struct csv_run_stats {
     float   ms_total;
     float   ms_stage[CSV_N_STAGES];

@@ -104,3 +104,18 @@ def test_config_digests(name, golden_dir):
         n, h = d["segments"]["%s:%s" % (t, c)]
         assert len(rows) == n, (t, c)
         assert digest(t, rows) == h, (t, c)
+
+
+def test_py_restatement_rows_identical_to_reference():
+    """The Python stand-in that bench.py times as the reference's CPU path returns the reference's rows."""
+    from oracle import py_restatement as pr
+    cases = load_json("small_cases.json.gz") + load_json("known_answers.json")
+    for case in cases:
+        st = store_from_json(case["store"])
+        p = Params(**case["params"])
+        want = {(t, c): r for t, c, r in case["rows"]}
+        tasks = list(want.keys())
+        res = pr.run_pool(pr.tasks_from_store(st, p, tasks), processes=1)
+        for (t, c), (chrom, rows) in zip(tasks, res):
+            assert chrom == c
+            assert_rows_equal(t, [[str(x) for x in r] for r in rows], want[(t, c)], where="py %s %s" % (case["name"], (t, c)))
