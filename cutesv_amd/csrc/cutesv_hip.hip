@@ -23,9 +23,9 @@ struct Buf {                      // grow-only device buffer
 
 // one timing slot per launch, in launch order
 const char* kStageName[CSV_N_STAGES] = {"init_memset", "k_chain_count", "k_scan_partials", "k_chain_apply", "k_select_count",
-                                        "k_scan_partials64", "k_select_apply", "k_refine_wave", "k_refine_block",
-                                        "k_items_scan", "k_emit", "k_pmax_count", "k_pmax_scan", "k_pmax_apply",
-                                        "k_genotype", ""};
+                                        "k_scan_partials64", "k_select_apply", "k_refine_indel_wave", "k_refine_wave",
+                                        "k_refine_block", "k_items_scan", "k_emit", "k_pmax_count", "k_pmax_scan",
+                                        "k_pmax_apply", "k_genotype"};
 
 }  // namespace
 
@@ -217,8 +217,9 @@ int csv_batch_upload(csv_ctx* c, const csv_batch_in* in)
     RES(item_cid, cap_items * 4); RES(item_seg, cap_items * 4); RES(list_small, cap_items * 4); RES(list_big, cap_items * 4);
     RES(item_tbase, cap_items * 4); RES(item_nslots, cap_items * 4); RES(item_ncalls, cap_items * 4); RES(item_nsup, cap_items * 4);
     RES(item_base, cap_items * 8);
-    RES(t_bp1, cap_tmp * 8); RES(t_bp2, cap_tmp * 8); RES(t_search, cap_tmp * 8); RES(t_pick, cap_tmp * 8);
-    RES(t_support, cap_tmp * 4); RES(t_cipos, cap_tmp * 4); RES(t_cilen, cap_tmp * 4); RES(t_supoff, cap_tmp * 4); RES(t_valid, cap_tmp * 4);
+    // temp call records are indexed by w (a cluster's slots live in its own signature range)
+    RES(t_bp1, (W + 1) * 8); RES(t_bp2, (W + 1) * 8); RES(t_search, (W + 1) * 8); RES(t_pick, (W + 1) * 8);
+    RES(t_support, (W + 1) * 4); RES(t_cipos, (W + 1) * 4); RES(t_cilen, (W + 1) * 4); RES(t_supoff, (W + 1) * 4); RES(t_valid, (W + 1) * 4);
     const i64 SC = 2 * W + 16 + 2 * ARR_PAD;
     RES(sc_k, SC * 8); RES(sc_x, SC * 8); RES(sc_v1, SC * 4); RES(sc_v2, SC * 4); RES(sc_v3, SC * 4); RES(sc_v4, SC * 4); RES(sc_v5, SC * 4);
     RES(o_seg, cap_tmp * 4); RES(o_cluster, cap_tmp * 4); RES(o_aux, cap_tmp * 4); RES(o_bp1, cap_tmp * 8); RES(o_bp2, cap_tmp * 8);
@@ -327,6 +328,9 @@ int csv_batch_run(csv_ctx* c, csv_run_stats* stats)
         LAUNCH("select_apply", k_select_apply, ns, 256, 0, B);
         int g_small = B.cap_items < 8192 ? B.cap_items : 8192;
         if (g_small < 1) g_small = 1;
+        int g_iw = div_up(B.cap_items, 4) < 2048 ? div_up(B.cap_items, 4) : 2048;
+        if (g_iw < 1) g_iw = 1;
+        LAUNCH("refine_indel_wave", k_refine_indel_wave, g_iw, 256, 0, B);
         LAUNCH("refine_wave", (k_refine<64, 64>), g_small, 64, LDS_SMALL, B, 0);
         int g_big = B.cap_items < 512 ? B.cap_items : 512;
         if (g_big < 1) g_big = 1;

@@ -3,7 +3,8 @@
 // Pipeline of one csv_batch_run (all on one stream, no host round trip in between):
 //   chain     k_chain_count / k_scan_partials / k_chain_apply    flags + scan -> cluster ids, cluster starts
 //   select    k_select_count / k_scan_partials64 / k_select_apply size gate -> ordered work list (two tiers)
-//   refine    k_refine<64,64>    one wavefront per cluster (m <= 64), arrays in LDS
+//   refine    k_refine_indel_wave one wavefront per DEL/INS cluster (m <= 64), registers + cross-lane ops only
+//             k_refine<64,64>    one wavefront per DUP/INV/TRA cluster (m <= 64), arrays in LDS
 //             k_refine<256,2048> one workgroup per cluster; LDS up to 2048 padded elements, global scratch above
 //   order     k_items_scan / k_emit                                per-item counts -> dense, ordered outputs
 //   reads     k_pmax_count / k_pmax_scan / k_pmax_apply            prefix max of read ends + sortedness check
@@ -455,13 +456,10 @@ __device__ __forceinline__ void item_none(const DevBatch& B, int j)
     if (threadIdx.x == 0) { B.item_tbase[j] = 0; B.item_nslots[j] = 0; B.item_ncalls[j] = 0; B.item_nsup[j] = 0; }
 }
 
-__device__ __forceinline__ int alloc_slots(const DevBatch& B, int n)
-{
-    if (n <= 0) return 0;
-    const int t = atomicAdd(&B.cnt->n_tmp_calls, n);
-    if (t + n > B.cap_tmp) { atomicOr(&B.cnt->error, ERR_TMP_OVERFLOW); return -1; }
-    return t;
-}
+// Temp call slots need no allocation: a cluster of m signatures yields at most m calls (every allele /
+// sub-cluster holds >= 1 signature; TRA's two calls need two sub-clusters), so its records live at
+// t_*[s + slot], inside its own [s, e) range of W-sized arrays.  (A shared atomic bump pointer was
+// measured at ~88 allocations/us on one word and dominated the kernel.)
 
 // phase A: sort by (read id, local index); returns the number of distinct reads.
 // Leaves K sorted and V2[q] = local index at sorted position q.
@@ -561,10 +559,7 @@ template <int BLOCK> __device__ void refine_indel(const DevBatch& B, const ItemC
         A.V3[a] = rank; A.V4[a] = soff;
     }
     npass = (int)block_sum_i64<BLOCK>(npass, red);
-    if (threadIdx.x == 0) *ired = alloc_slots(B, npass);
-    __syncthreads();
-    const int tbase = *ired;
-    if (tbase < 0) { item_none(B, it.j); return; }
+    const int tbase = s;
 
     // per allele statistics: one wavefront per allele
     double rr = sg.remain_reads_ratio; if (rr > 1) rr = 1;                  // INDEL:46-47
@@ -767,10 +762,7 @@ template <int BLOCK> __device__ void refine_pair(const DevBatch& B, const ItemCt
                 if ((double)(bu + su) >= (double)m * sg.diff_ratio) { emit0 = bk; emit1 = sk; ne = 2; }       // TRA:134
             } else if ((double)bu >= (double)m * sg.diff_ratio) { emit0 = bk; ne = 1; }                      // TRA:211
         }
-        int tbase = 0;
-        if (lane_id() == 0) tbase = alloc_slots(B, ne);
-        tbase = __shfl(tbase, 0);
-        if (tbase < 0) { ne = 0; tbase = 0; }
+        const int tbase = s;
         int soff = 0;
         for (int q = 0; q < ne; q++) {
             const int k = q ? emit1 : emit0, r0 = A.V2[k], r1 = A.V2[k + 1], u = A.V3[k];
@@ -813,10 +805,7 @@ template <int BLOCK> __device__ void refine_pair(const DevBatch& B, const ItemCt
         carry_slot += tot; carry_sup += tots;
     }
     const int nslots = carry_slot;
-    if (threadIdx.x == 0) *ired = alloc_slots(B, nslots);
-    __syncthreads();
-    const int tbase = *ired;
-    if (tbase < 0) { item_none(B, it.j); return; }
+    const int tbase = s;
     int ncalls = 0, nsup = 0;
     for (int k = threadIdx.x >> 6; k < nsub; k += BLOCK / 64) {
         const int slot = A.V4[k];
@@ -878,8 +867,9 @@ template <int BLOCK, int CAP> __global__ __launch_bounds__(BLOCK) void k_refine(
     for (int q = blockIdx.x; q < n; q += gridDim.x) {
         ItemCtx it;
         it.j = big ? B.list_big[q] : B.list_small[q];
-        it.cid = B.item_cid[it.j];
         it.k = B.item_seg[it.j];
+        if (!big) { const int ty = B.seg[it.k].svtype; if (ty == CSV_DEL || ty == CSV_INS) continue; }
+        it.cid = B.item_cid[it.j];
         it.s = B.cstart[it.cid];
         it.m = B.cstart[it.cid + 1] - it.s;
         it.gsig0 = B.seg[it.k].sig_begin + ((i64)it.s - B.woff[it.k]);
@@ -901,6 +891,213 @@ template <int BLOCK, int CAP> __global__ __launch_bounds__(BLOCK) void k_refine(
         const int t = B.seg[it.k].svtype;
         if (t == CSV_DEL || t == CSV_INS) refine_indel<BLOCK>(B, it, A, red, ired);
         else refine_pair<BLOCK>(B, it, A, red, ired);
+    }
+}
+
+// ------------------------------------------------------------------------------------ refine: INDEL wavefront tier
+// One wavefront per cluster of m <= 64 DEL/INS signatures, everything in registers: lane i holds
+// signature i, cross-lane traffic is v_readlane (uniform index), ds_permute / ds_bpermute and DPP
+// shuffles; no LDS arrays, no barriers.  Same semantics as refine_indel above (INDEL:110-219, 319-432).
+__device__ __forceinline__ i64 readlane_i64(i64 v, int l)
+{
+    const int lo = __builtin_amdgcn_readlane((int)(v & 0xffffffffll), l);
+    const int hi = __builtin_amdgcn_readlane((int)(v >> 32), l);
+    return ((i64)hi << 32) | (unsigned)lo;
+}
+__device__ __forceinline__ double shfl_f64(double v, int src) { return __longlong_as_double(shfl_i64(__double_as_longlong(v), src)); }
+__device__ __forceinline__ i64 permute_i64(int dest_lane, i64 v)      // lane i sends v to lane dest_lane (a bijection)
+{
+    const int lo = __builtin_amdgcn_ds_permute(dest_lane << 2, (int)(v & 0xffffffffll));
+    const int hi = __builtin_amdgcn_ds_permute(dest_lane << 2, (int)(v >> 32));
+    return ((i64)hi << 32) | (unsigned)lo;
+}
+
+// numpy's pairwise sum of sq over the allele [r0, r0 + n), n <= 64, valid on the lane with i == 0
+// (i = lane - r0).  8 strided accumulators on lanes i < 8, the fixed combine tree, then the tail.
+__device__ __forceinline__ double np_sum_allele(double sq, int r0, int n, int i)
+{
+    const int lane = lane_id();
+    const int nfull = n - (n & 7);
+    double acc = sq;
+#pragma unroll
+    for (int t = 1; t < 8; t++) {
+        const double v = shfl_f64(sq, (lane + 8 * t) & 63);
+        if (i < 8 && i + 8 * t < nfull) acc += v;
+    }
+    const double t1 = acc + shfl_f64(acc, (lane + 1) & 63);
+    const double t2 = t1 + shfl_f64(t1, (lane + 2) & 63);
+    const double t3 = t2 + shfl_f64(t2, (lane + 4) & 63);
+    double res = (n >= 8) ? t3 : 0.0;
+    const int start = (n >= 8) ? nfull : 0;
+#pragma unroll
+    for (int e = 0; e < 7; e++) {
+        const double v = shfl_f64(sq, (r0 + start + e) & 63);
+        if (start + e < n) res += v;
+    }
+    return res;
+}
+
+__global__ __launch_bounds__(256) void k_refine_indel_wave(DevBatch B)
+{
+    const int nsmall = B.cnt->n_items - B.cnt->n_items_big;
+    const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * 256 + threadIdx.x) >> 6), nwaves = (gridDim.x * 256) >> 6;
+    const int lane = lane_id();
+    const u64 lt_mask = lanemask_lt(), le_mask = lt_mask | (1ull << lane);
+    for (int q = wave; q < nsmall; q += nwaves) {
+        const int j = B.list_small[q];
+        const int k = B.item_seg[j];
+        const csv_segment& sg = B.seg[k];
+        const int type = sg.svtype;
+        if (type != CSV_DEL && type != CSV_INS) continue;          // other types: k_refine<64,64>
+        const int cid = B.item_cid[j], s = B.cstart[cid], m = B.cstart[cid + 1] - s;
+        const bool in = lane < m;
+        const i64 a = in ? B.a[s + lane] : 0;
+        const i64 b = in ? B.b[s + lane] : 0;
+        const int rid = in ? B.rid[s + lane] : -1 - lane;
+        const int aux = (in && type == CSV_INS) ? B.aux[s + lane] : 0;
+        if (in && ((u64)b >> (63 - IDX_BITS))) atomicOr(&B.cnt->error, ERR_KEY_RANGE);
+
+        // ---- per-read de-duplication (INDEL:125-131): first appearance F, kept signature = strictly longest
+        int F = lane, ch = lane;
+        i64 bl = b;
+        bool dup_any = false;
+        for (int t = 0; t < m; t++) {
+            const int rt = __builtin_amdgcn_readlane(rid, t);
+            dup_any |= (rt == rid) && (t != lane);
+        }
+        if (__ballot(dup_any)) {
+            F = -1; ch = -1; bl = INT64_MIN;
+            for (int t = 0; t < m; t++) {
+                const int rt = __builtin_amdgcn_readlane(rid, t);
+                const i64 bt = readlane_i64(b, t);
+                if (rt == rid) {
+                    if (F < 0) F = t;
+                    if (bt > bl) { bl = bt; ch = t; }
+                }
+            }
+        }
+        const bool rep = in && (F == lane);
+        const u64 repmask = __ballot(rep);
+        const int U = __popcll(repmask);
+        if (U < sg.read_count) {                                     // INDEL:133-134
+            if (lane == 0) { B.item_tbase[j] = 0; B.item_nslots[j] = 0; B.item_ncalls[j] = 0; B.item_nsup[j] = 0; }
+            continue;
+        }
+        const i64 pa = shfl_i64(a, ch & 63);
+        const int pax = __shfl(aux, ch & 63);
+
+        // ---- stable sort of the kept signatures by length (INDEL:136): rank by (len, first appearance)
+        int rank = 0;
+        for (u64 mk = repmask; mk; mk &= mk - 1) {
+            const int t = __ffsll((long long)mk) - 1;
+            const i64 lt = readlane_i64(bl, t);
+            rank += (lt < bl) || (lt == bl && t < lane);
+        }
+        const int dest = rep ? rank : U + __popcll(~repmask & lt_mask);
+        const i64 pos = permute_i64(dest, pa);
+        const i64 len = permute_i64(dest, bl);
+        const int chp = __builtin_amdgcn_ds_permute(dest << 2, ch);
+        const int axp = __builtin_amdgcn_ds_permute(dest << 2, pax);
+        const int r = lane;
+        const bool live = r < U;
+
+        // ---- allele split on consecutive length gaps (INDEL:138, 153-162)
+        const i64 lsum = wave_sum_i64(live ? len : 0);
+        const double thr = sg.diff_ratio * ((double)lsum / (double)U);
+        const i64 lprev = shfl_up_i64(len, 1);
+        const bool f = live && r > 0 && ((double)(len - lprev) > thr);
+        const u64 S = __ballot(f) | 1ull;                             // allele start ranks
+        const u64 below = S & le_mask, above = S & ~le_mask;
+        const int r0 = 63 - __clzll((long long)below);
+        int r1 = above ? (__ffsll((long long)above) - 1) : U;
+        if (r1 > U) r1 = U;
+        const int n = live ? r1 - r0 : 1, i = r - r0;
+
+        const i64 Ppos = wave_incl_scan_i64(live ? pos : 0), Plen = wave_incl_scan_i64(live ? len : 0);
+        const int e1 = (r1 - 1) & 63, e0 = (r0 - 1) & 63;
+        // NB: every cross-lane op sits in wave-uniform control flow; only the selects are per lane
+        const i64 pp0 = shfl_i64(Ppos, e0), pl0 = shfl_i64(Plen, e0);
+        const i64 sp = shfl_i64(Ppos, e1) - (r0 > 0 ? pp0 : 0);
+        const i64 sl = shfl_i64(Plen, e1) - (r0 > 0 ? pl0 : 0);
+
+        // ---- emission order: stable ascending by support among alleles with n >= minimum_support_reads (INDEL:163-166)
+        const int msr = sg.min_support_reads;
+        const bool pass = live && n >= msr;
+        int erank = 0, soff = 0, npass = 0;
+        for (u64 mk = S; mk; mk &= mk - 1) {
+            const int t = __ffsll((long long)mk) - 1;
+            const int nt = __builtin_amdgcn_readlane(n, t);
+            if (nt >= msr) {
+                npass++;
+                if (nt < n || (nt == n && t < r0)) { erank++; soff += nt; }
+            }
+        }
+        const int tbase = s;
+
+        // ---- statistics, all alleles at once
+        double rr = sg.remain_reads_ratio; if (rr > 1) rr = 1;       // INDEL:46-47
+        int keep = (int)(rr * (double)n); if (keep < 1) keep = 1;     // INDEL:169
+        const double pmean = (double)sp / (double)n, lmean = (double)sl / (double)n;
+        const double dp = fabs((double)pos - pmean), dl = fabs((double)len - lmean);
+        double bp = pmean, siglen = lmean;
+        i64 search;
+        if (!__ballot(pass && keep < n)) {
+            // every member kept: search_threshold = first member with the smallest |pos - mean| (INDEL:171-177)
+            double bd = dp; int bi = r;
+            for (int d = 1; d < 64; d <<= 1) {
+                const double od = shfl_f64(bd, (lane - d) & 63); const int oi = __shfl(bi, (lane - d) & 63);
+                if (r - d >= r0 && (od < bd || (od == bd && oi < bi))) { bd = od; bi = oi; }
+            }
+            search = shfl_i64(pos, __shfl(bi, e1) & 63);
+        } else {
+            // keep the `keep` members closest to the mean, ties in allele order (INDEL:171-176, 182-187)
+            int rp = 0, rl = 0;
+            for (int t = 0; t < U; t++) {
+                const int r0t = __builtin_amdgcn_readlane(r0, t);
+                const double tp = __longlong_as_double(readlane_i64(__double_as_longlong(dp), t));
+                const double tl = __longlong_as_double(readlane_i64(__double_as_longlong(dl), t));
+                if (r0t == r0) {
+                    rp += (tp < dp) || (tp == dp && t < r);
+                    rl += (tl < dl) || (tl == dl && t < r);
+                }
+            }
+            const i64 Kp = wave_incl_scan_i64((live && rp < keep) ? pos : 0), Kl = wave_incl_scan_i64((live && rl < keep) ? len : 0);
+            const i64 Ks = wave_incl_scan_i64((live && rp == 0) ? pos : 0);
+            const i64 kp0 = shfl_i64(Kp, e0), kl0 = shfl_i64(Kl, e0), ks0 = shfl_i64(Ks, e0);
+            const i64 ks = shfl_i64(Kp, e1) - (r0 > 0 ? kp0 : 0);
+            const i64 kl = shfl_i64(Kl, e1) - (r0 > 0 ? kl0 : 0);
+            search = shfl_i64(Ks, e1) - (r0 > 0 ? ks0 : 0);
+            bp = (double)ks / (double)keep; siglen = (double)kl / (double)keep;
+        }
+        const double vsp = np_sum_allele((double)((double)pos - pmean) * ((double)pos - pmean), r0, n, i);
+        const double vsl = np_sum_allele((double)((double)len - lmean) * ((double)len - lmean), r0, n, i);
+        const double rt = B.sqrt_tab[n & (SQRT_TAB - 1)];
+        const int cip = (int)(1.96 * sqrt(vsp / (double)n) / rt);     // INDEL:191, GT:58-60
+        const int cil = (int)(1.96 * sqrt(vsl / (double)n) / rt);     // INDEL:194
+
+        i64 pick = -1; bool valid = true;
+        if (type == CSV_INS) {                                        // INDEL:398-405
+            const i64 want = (i64)siglen;
+            const u64 okm = __ballot(live && (i64)axp >= want);
+            const u64 range = ((n >= 64) ? ~0ull : ((1ull << n) - 1ull)) << r0;
+            const u64 mm = okm & range;
+            valid = mm != 0;
+            const int pr = valid ? (__ffsll((long long)mm) - 1) : r0;
+            pick = B.seg[k].sig_begin + ((i64)s - B.woff[k]) + __shfl(chp, pr);
+            bp = (double)shfl_i64(pos, pr);
+            search = (i64)bp;                                         // INDEL:415
+        }
+        if (pass) B.sup_tmp[s + soff + i] = s + chp;                  // INDEL:205, 416
+        const bool head = pass && i == 0;
+        if (head) {
+            const int t = tbase + erank;
+            B.t_bp1[t] = (i64)bp; B.t_bp2[t] = (i64)siglen; B.t_support[t] = n;
+            B.t_cipos[t] = cip; B.t_cilen[t] = cil; B.t_search[t] = search; B.t_pick[t] = valid ? pick : -1;
+            B.t_supoff[t] = soff; B.t_valid[t] = valid ? 1 : 0;
+        }
+        const int ncalls = __popcll(__ballot(head && valid));
+        const int nsup = wave_sum_i32((head && valid) ? n : 0);
+        if (lane == 0) { B.item_tbase[j] = tbase; B.item_nslots[j] = npass; B.item_ncalls[j] = ncalls; B.item_nsup[j] = nsup; }
     }
 }
 
@@ -948,7 +1145,7 @@ __global__ __launch_bounds__(1024) void k_items_scan(DevBatch B)
 __global__ __launch_bounds__(256) void k_emit(DevBatch B)
 {
     const int n = B.cnt->n_items;
-    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = (gridDim.x * 256) >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * 256 + threadIdx.x) >> 6), nwaves = (gridDim.x * 256) >> 6;
     for (int j = wave; j < n; j += nwaves) {
         const int nslots = B.item_nslots[j];
         if (nslots == 0) continue;
@@ -1151,7 +1348,7 @@ __global__ __launch_bounds__(256) void k_genotype(DevBatch B)
     __shared__ int tabs[4][GT_HASH];
     int* tab = tabs[threadIdx.x >> 6];
     const int n = B.cnt->n_calls;
-    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = (gridDim.x * 256) >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * 256 + threadIdx.x) >> 6), nwaves = (gridDim.x * 256) >> 6;
     for (int c = wave; c < n; c += nwaves) {
         const csv_segment& sg = B.seg[B.o_seg[c]];
         if (!sg.genotype) continue;
