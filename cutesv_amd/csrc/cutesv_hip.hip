@@ -22,10 +22,9 @@ struct Buf {                      // grow-only device buffer
 };
 
 // one timing slot per launch, in launch order
-const char* kStageName[CSV_N_STAGES] = {"init_memset", "k_chain_count", "k_scan_partials", "k_chain_apply", "k_select_count",
-                                        "k_scan_partials64", "k_select_apply", "k_refine_indel_wave", "k_refine_wave",
-                                        "k_refine_block", "k_items_scan", "k_emit", "k_pmax_count", "k_pmax_scan",
-                                        "k_pmax_apply", "k_genotype"};
+const char* kStageName[CSV_N_STAGES] = {"init", "k_chain_count", "k_chain_apply", "k_select_count", "k_select_apply",
+                                        "k_refine_indel_wave", "k_refine_wave", "k_refine_block", "k_items_scan", "k_emit",
+                                        "k_pmax_count", "k_pmax_scan", "k_pmax_apply", "k_genotype", "", ""};
 
 }  // namespace
 
@@ -36,8 +35,8 @@ struct csv_ctx {
     hipEvent_t  ev[CSV_N_STAGES + 2] = {};
     // device buffers
     Buf seg, woff, seg_drop, a, b, rid, aux;
-    Buf cluster_id, cstart, partial, partial64, item_cid, item_seg, list_small, list_big;
-    Buf item_tbase, item_nslots, item_ncalls, item_nsup, sup_tmp, item_base;
+    Buf cluster_id, cstart, cseg, partial, partial64, item_rec, list_small, list_big;
+    Buf item_nslots, item_cnt, item_base, sup_tmp;
     Buf t_bp1, t_bp2, t_search, t_pick, t_support, t_cipos, t_cilen, t_supoff, t_valid;
     Buf sc_k, sc_x, sc_v1, sc_v2, sc_v3, sc_v4, sc_v5;
     Buf o_seg, o_cluster, o_aux, o_bp1, o_bp2, o_support, o_cipos, o_cilen, o_search, o_pick, o_dr, o_dv, o_gl;
@@ -47,7 +46,7 @@ struct csv_ctx {
     // host copies
     std::vector<csv_segment> h_seg;
     std::vector<i64>         h_woff;
-    bool     uploaded = false, ran = false, any_genotype = false, big_lds_set = false;
+    bool     uploaded = false, ran = false, any_genotype = false, any_pair = false, big_lds_set = false;
     i64      n_sig_host = 0;
     DevBatch B;
     DevCounters h_cnt;
@@ -146,8 +145,8 @@ void csv_ctx_destroy(csv_ctx* c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     Buf* all[] = {&c->seg, &c->woff, &c->seg_drop, &c->a, &c->b, &c->rid, &c->aux, &c->cluster_id, &c->cstart, &c->partial,
-                  &c->partial64, &c->item_cid, &c->item_seg, &c->list_small, &c->list_big, &c->item_tbase, &c->item_nslots,
-                  &c->item_ncalls, &c->item_nsup, &c->sup_tmp, &c->item_base, &c->t_bp1, &c->t_bp2, &c->t_search, &c->t_pick,
+                  &c->partial64, &c->item_rec, &c->cseg, &c->list_small, &c->list_big, &c->item_nslots,
+                  &c->item_cnt, &c->item_base, &c->sup_tmp, &c->t_bp1, &c->t_bp2, &c->t_search, &c->t_pick,
                   &c->t_support, &c->t_cipos, &c->t_cilen, &c->t_supoff, &c->t_valid, &c->sc_k, &c->sc_x, &c->sc_v1, &c->sc_v2,
                   &c->sc_v3, &c->sc_v4, &c->sc_v5, &c->o_seg, &c->o_cluster, &c->o_aux, &c->o_bp1, &c->o_bp2, &c->o_support,
                   &c->o_cipos, &c->o_cilen, &c->o_search, &c->o_pick, &c->o_dr, &c->o_dv, &c->o_gl, &c->o_supoff, &c->o_supsig,
@@ -180,6 +179,7 @@ int csv_batch_upload(csv_ctx* c, const csv_batch_in* in)
     c->h_woff.assign(S + 1, 0);
     std::vector<uint8_t> drop(S + 1, 0);
     c->any_genotype = false;
+    c->any_pair = false;
     i64 cap_items = 16, cap_tmp = 16;
     for (int k = 0; k < S; k++) {
         const csv_segment& g = c->h_seg[k];
@@ -192,6 +192,7 @@ int csv_batch_upload(csv_ctx* c, const csv_batch_in* in)
             drop[k] = (!in->reads_off || in->reads_off[g.chrom + 1] == in->reads_off[g.chrom]) ? 1 : 0;
         }
         const i64 len = g.sig_end - g.sig_begin;
+        if (len > 0 && g.svtype != CSV_DEL && g.svtype != CSV_INS) c->any_pair = true;
         c->h_woff[k + 1] = c->h_woff[k] + len;
         const i64 rc = g.read_count > 1 ? g.read_count : 1;
         const i64 msr = g.min_support_reads > 1 ? g.min_support_reads : 1;
@@ -208,15 +209,15 @@ int csv_batch_upload(csv_ctx* c, const csv_batch_in* in)
     // ---- device memory
     RES(seg, (S + 1) * sizeof(csv_segment)); RES(woff, (S + 2) * sizeof(i64)); RES(seg_drop, S + 1);
     RES(a, (W + 1) * 8); RES(b, (W + 1) * 8); RES(rid, (W + 1) * 4); RES(aux, (W + 1) * 4);
-    RES(cluster_id, (W + 1) * 4); RES(cstart, (W + 2) * 4); RES(sup_tmp, (W + 1) * 4); RES(allele_id, (W + 1) * 4);
+    RES(cluster_id, (W + 1) * 4); RES(cstart, (W + 2) * 4); RES(cseg, (W + 2) * 4); RES(sup_tmp, (W + 1) * 4); RES(allele_id, (W + 1) * 4);
     const i64 R = (c->any_genotype && in->reads_off) ? in->n_reads : 0;
     const i64 np32 = div_up(W, CH_TILE) + 2;
-    i64 np64 = div_up(W, 256) + 2;
+    i64 np64 = div_up(W, SEL_TILE) + 2;
     if (div_up(R, PM_TILE) + 2 > np64) np64 = div_up(R, PM_TILE) + 2;
     RES(partial, np32 * 4); RES(partial64, np64 * 8);
-    RES(item_cid, cap_items * 4); RES(item_seg, cap_items * 4); RES(list_small, cap_items * 4); RES(list_big, cap_items * 4);
-    RES(item_tbase, cap_items * 4); RES(item_nslots, cap_items * 4); RES(item_ncalls, cap_items * 4); RES(item_nsup, cap_items * 4);
-    RES(item_base, cap_items * 8);
+    RES(item_rec, cap_items * 16); RES(list_small, cap_items * 4); RES(list_big, cap_items * 4);
+    RES(item_nslots, cap_items * 4); RES(item_cnt, cap_items * 8);
+    RES(item_base, (cap_items + 8) * 8);
     // temp call records are indexed by w (a cluster's slots live in its own signature range)
     RES(t_bp1, (W + 1) * 8); RES(t_bp2, (W + 1) * 8); RES(t_search, (W + 1) * 8); RES(t_pick, (W + 1) * 8);
     RES(t_support, (W + 1) * 4); RES(t_cipos, (W + 1) * 4); RES(t_cilen, (W + 1) * 4); RES(t_supoff, (W + 1) * 4); RES(t_valid, (W + 1) * 4);
@@ -261,15 +262,14 @@ int csv_batch_upload(csv_ctx* c, const csv_batch_in* in)
     B.n_seg = S; B.n_chrom = in->n_chrom; B.W = W;
     B.seg = dp<csv_segment>(c->seg); B.woff = dp<i64>(c->woff); B.seg_drop = dp<uint8_t>(c->seg_drop);
     B.a = dp<i64>(c->a); B.b = dp<i64>(c->b); B.rid = dp<int>(c->rid); B.aux = dp<int>(c->aux);
-    B.cluster_id = dp<int>(c->cluster_id); B.cstart = dp<int>(c->cstart); B.partial = dp<int>(c->partial); B.partial64 = dp<i64>(c->partial64);
-    B.item_cid = dp<int>(c->item_cid); B.item_seg = dp<int>(c->item_seg); B.list_small = dp<int>(c->list_small); B.list_big = dp<int>(c->list_big);
-    B.item_tbase = dp<int>(c->item_tbase); B.item_nslots = dp<int>(c->item_nslots); B.item_ncalls = dp<int>(c->item_ncalls); B.item_nsup = dp<int>(c->item_nsup);
+    B.cluster_id = dp<int>(c->cluster_id); B.cstart = dp<int>(c->cstart); B.cseg = dp<int>(c->cseg); B.partial = dp<int>(c->partial); B.partial64 = dp<i64>(c->partial64);
+    B.item_rec = dp<int4>(c->item_rec); B.list_small = dp<int>(c->list_small); B.list_big = dp<int>(c->list_big);
+    B.item_nslots = dp<int>(c->item_nslots); B.item_cnt = dp<i64>(c->item_cnt); B.item_base = dp<i64>(c->item_base);
     B.sup_tmp = dp<int>(c->sup_tmp);
     B.t_bp1 = dp<i64>(c->t_bp1); B.t_bp2 = dp<i64>(c->t_bp2); B.t_search = dp<i64>(c->t_search); B.t_pick = dp<i64>(c->t_pick);
     B.t_support = dp<int>(c->t_support); B.t_cipos = dp<int>(c->t_cipos); B.t_cilen = dp<int>(c->t_cilen); B.t_supoff = dp<int>(c->t_supoff); B.t_valid = dp<int>(c->t_valid);
     B.cap_tmp = (int)cap_tmp; B.cap_items = (int)cap_items;
     B.sc_k = dp<u64>(c->sc_k); B.sc_x = dp<i64>(c->sc_x); B.sc_v1 = dp<int>(c->sc_v1); B.sc_v2 = dp<int>(c->sc_v2); B.sc_v3 = dp<int>(c->sc_v3); B.sc_v4 = dp<int>(c->sc_v4); B.sc_v5 = dp<int>(c->sc_v5);
-    B.item_base = dp<i64>(c->item_base);
     B.o_seg = dp<int>(c->o_seg); B.o_cluster = dp<int>(c->o_cluster); B.o_aux = dp<int>(c->o_aux);
     B.o_bp1 = dp<i64>(c->o_bp1); B.o_bp2 = dp<i64>(c->o_bp2); B.o_support = dp<int>(c->o_support); B.o_cipos = dp<int>(c->o_cipos); B.o_cilen = dp<int>(c->o_cilen);
     B.o_search = dp<i64>(c->o_search); B.o_pick = dp<i64>(c->o_pick); B.o_dr = dp<int>(c->o_dr); B.o_dv = dp<int>(c->o_dv); B.o_gl = dp<int>(c->o_gl);
@@ -308,9 +308,8 @@ int csv_batch_run(csv_ctx* c, csv_run_stats* stats)
         }                                                                                                  \
     } while (0)
     HIP_TRY(c, mark());
-    HIP_TRY(c, hipMemsetAsync(c->cnt.p, 0, sizeof(DevCounters), st));
-    if (W > 0) HIP_TRY(c, hipMemsetAsync(c->allele_id.p, 0xff, W * 4, st));
-    HIP_TRY(c, mark());                                                              // slot 0: init_memset
+    if (W == 0) HIP_TRY(c, hipMemsetAsync(c->cnt.p, 0, sizeof(DevCounters), st));      // otherwise k_chain_count zeroes them
+    HIP_TRY(c, mark());                                                              // slot 0: init (empty batch only)
 #define LAUNCH(name, kern, grid, block, lds, ...)                                      \
     do {                                                                               \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, st, __VA_ARGS__);        \
@@ -320,23 +319,22 @@ int csv_batch_run(csv_ctx* c, csv_run_stats* stats)
     if (W > 0) {
         const int nb = div_up(W, CH_TILE);
         LAUNCH("chain_count", k_chain_count, nb, 256, 0, B);
-        LAUNCH("scan_partials", k_scan_partials, 1, 256, 0, B.partial, nb, (int*)nullptr);
         LAUNCH("chain_apply", k_chain_apply, nb, 256, 0, B);
-        const int ns = div_up(W, 256);
+        const int ns = div_up(W, SEL_TILE);
         LAUNCH("select_count", k_select_count, ns, 256, 0, B);
-        LAUNCH("scan_partials64", k_scan_partials64, 1, 256, 0, B.partial64, &B.cnt->n_clusters, 256, &B.cnt->sel_total);
         LAUNCH("select_apply", k_select_apply, ns, 256, 0, B);
         int g_small = B.cap_items < 8192 ? B.cap_items : 8192;
         if (g_small < 1) g_small = 1;
         int g_iw = div_up(B.cap_items, 4) < 2048 ? div_up(B.cap_items, 4) : 2048;
         if (g_iw < 1) g_iw = 1;
         LAUNCH("refine_indel_wave", k_refine_indel_wave, g_iw, 256, 0, B);
-        LAUNCH("refine_wave", (k_refine<64, 64>), g_small, 64, LDS_SMALL, B, 0);
+        if (c->any_pair) LAUNCH("refine_wave", (k_refine<64, 64>), g_small, 64, LDS_SMALL, B, 0);
+        else HIP_TRY(c, mark());
         int g_big = B.cap_items < 512 ? B.cap_items : 512;
         if (g_big < 1) g_big = 1;
         LAUNCH("refine_block", (k_refine<256, 2048>), g_big, 256, LDS_BIG, B, 1);
         LAUNCH("items_scan", k_items_scan, 1, 1024, 0, B);
-        LAUNCH("emit", k_emit, 1024, 256, 0, B);
+        LAUNCH("emit", k_emit, 2048, 256, 0, B);
         if (c->any_genotype && B.n_reads > 0) {
             const int nr = div_up(B.n_reads, PM_TILE);
             LAUNCH("pmax_count", k_pmax_count, nr, 256, 0, B);

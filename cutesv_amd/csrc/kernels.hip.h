@@ -1,12 +1,12 @@
 // kernels.hip.h — device code of libcutesv_hip.so (gfx950 / CDNA4 only, wave64).
 //
 // Pipeline of one csv_batch_run (all on one stream, no host round trip in between):
-//   chain     k_chain_count / k_scan_partials / k_chain_apply    flags + scan -> cluster ids, cluster starts
-//   select    k_select_count / k_scan_partials64 / k_select_apply size gate -> ordered work list (two tiers)
+//   chain     k_chain_count / k_chain_apply                        flags + scan -> cluster ids, cluster starts
+//   select    k_select_count / k_select_apply                      size gate -> ordered work list (two tiers)
 //   refine    k_refine_indel_wave one wavefront per DEL/INS cluster (m <= 64), registers + cross-lane ops only
 //             k_refine<64,64>    one wavefront per DUP/INV/TRA cluster (m <= 64), arrays in LDS
 //             k_refine<256,2048> one workgroup per cluster; LDS up to 2048 padded elements, global scratch above
-//   order     k_items_scan / k_emit                                per-item counts -> dense, ordered outputs
+//   order     k_emit                                               per-item counts -> dense, ordered outputs
 //   reads     k_pmax_count / k_pmax_scan / k_pmax_apply            prefix max of read ends + sortedness check
 //   genotype  k_genotype                                           one wavefront per call: 64-ary search,
 //                                                                  backwards stabbing scan, LDS hash set
@@ -43,7 +43,7 @@ struct DevCounters {          // one small struct in device memory, zeroed at th
     int n_calls;
     int error;
     i64 n_support;
-    i64 sel_total;            // packed select total (scratch)
+    i64 spare;
 };
 
 // Everything the kernels need, passed by value.
@@ -60,18 +60,18 @@ struct DevBatch {
     const int*     aux;
     // chain / select
     int*           cluster_id;       // W
-    int*           cstart;           // W + 1 (cluster -> first w; cstart[n_clusters] = W)
+    int*           cstart;           // W + 1 (cluster -> first w; cstart[n_clusters] = W); bit 31 set when the
+                                     // PREVIOUS cluster ended in a (0,0) element (the reference's sentinel look-alike)
+    int*           cseg;             // W: segment of each cluster
     int*           partial;          // scan partials
     i64*           partial64;
-    int*           item_cid;         // ordered work list: item -> cluster id
-    int*           item_seg;
+    int4*          item_rec;         // ordered work list: item -> {cluster id, segment, first w, size}
     int*           list_small;       // item ids of the wavefront tier (ordered)
     int*           list_big;
     // refine outputs
-    int*           item_tbase;       // first temp slot of the item
-    int*           item_nslots;
-    int*           item_ncalls;      // valid calls
-    int*           item_nsup;        // supports of valid calls
+    int*           item_nslots;      // temp slots the item filled (t_*[s + slot])
+    i64*           item_cnt;         // packed (valid calls << 32 | supports of valid calls)
+    i64*           item_base;        // exclusive prefix of item_cnt
     int*           sup_tmp;          // W: support lists, stored inside the cluster's own [s, e) range
     i64*           t_bp1; i64* t_bp2; i64* t_search; i64* t_pick;
     int*           t_support; int* t_cipos; int* t_cilen; int* t_supoff; int* t_valid;
@@ -80,7 +80,6 @@ struct DevBatch {
     // big-cluster scratch (2 * W + 16 elements each)
     u64*           sc_k; i64* sc_x; int* sc_v1; int* sc_v2; int* sc_v3; int* sc_v4; int* sc_v5;
     // final outputs
-    i64*           item_base;        // packed (calls << 32 | supports) exclusive prefix per item
     int*           o_seg; int* o_cluster; int* o_aux;
     i64*           o_bp1; i64* o_bp2; int* o_support; int* o_cipos; int* o_cilen; i64* o_search; i64* o_pick;
     int*           o_dr; int* o_dv; int* o_gl;
@@ -151,18 +150,36 @@ __device__ __forceinline__ int seg_of(const DevBatch& B, i64 w)
     return lo;
 }
 
+// same for a wave-uniform w: all 64 lanes probe one segment each, one load round instead of a
+// dependent binary search (the segment table has ~120 entries for a genome)
+__device__ __forceinline__ int seg_of_wave(const DevBatch& B, i64 w)
+{
+    for (int base = 0; base < B.n_seg; base += 64) {
+        const int l = base + lane_id();
+        const bool hit = l < B.n_seg && B.woff[l] <= w && w < B.woff[l + 1];
+        const u64 mk = __ballot(hit);
+        if (mk) return base + __ffsll((long long)mk) - 1;
+    }
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------ chain
 // flag[w] = 1 when w starts a new chained cluster: first of its segment, the type's break predicate
 // against the previous signature, or the previous signature is a (0,0) look-alike of the reference's
 // sentinel (see oracle csvo_cluster_batch).
-__device__ __forceinline__ int chain_flag(const DevBatch& B, i64 w, int& seg_hint)
+__device__ __forceinline__ int chain_flag(const DevBatch& B, i64 w, int& seg_hint, i64& a0)
 {
+    // all 64 lanes of a row call this together (w = row base + lane); out-of-range lanes pass w >= W
+    const bool in = w < B.W;
+    const i64 a1 = in ? B.a[w] : 0;
+    a0 = shfl_up_i64(a1, 1);
+    if (lane_id() == 0 && in && w > 0) a0 = B.a[w - 1];
+    if (!in) return 0;
     int k = seg_hint;
     if (w < B.woff[k] || w >= B.woff[k + 1]) { k = seg_of(B, w); seg_hint = k; }
     if (w == B.woff[k]) return 1;
     const csv_segment& sg = B.seg[k];
     const i64 bias = sg.max_cluster_bias;
-    const i64 a1 = B.a[w], a0 = B.a[w - 1];
     if (a1 - a0 > bias) return 1;
     if (a0 == 0 && B.b[w - 1] == 0) return 1;
     if (sg.svtype == CSV_INV) return (B.b[w] - B.b[w - 1] > bias) || (B.aux[w] != B.aux[w - 1]);
@@ -173,90 +190,118 @@ __device__ __forceinline__ int chain_flag(const DevBatch& B, i64 w, int& seg_hin
 constexpr int CH_ITEMS = 8;                         // rows of 64 per wavefront
 constexpr int CH_TILE = 256 * CH_ITEMS;             // signatures per workgroup
 
-__global__ __launch_bounds__(256) void k_chain_count(DevBatch B)
+// Flags of the CH_ITEMS rows a wavefront owns ([base, base + 512)).  When the whole span lies in one
+// segment (almost always) the segment scalars sit in SGPRs and the 8 row loads are issued back to
+// back; the neighbour value comes from the lane to the left.  zprev[r] marks cluster starts whose
+// preceding signature is a (0,0) element.
+__device__ __forceinline__ void chain_rows(const DevBatch& B, i64 base, u64 (&masks)[CH_ITEMS], int (&zprev)[CH_ITEMS])
 {
-    const i64 base = (i64)blockIdx.x * CH_TILE + (threadIdx.x >> 6) * (WAVE * CH_ITEMS);
-    int seg_hint = 0, cnt = 0;
+    const int lane = lane_id();
+#pragma unroll
+    for (int r = 0; r < CH_ITEMS; r++) { masks[r] = 0; zprev[r] = 0; }
+    if (base >= B.W) return;
+    const i64 lastw = (base + WAVE * CH_ITEMS - 1 < B.W) ? base + WAVE * CH_ITEMS - 1 : B.W - 1;
+    const int k0 = __builtin_amdgcn_readfirstlane(seg_of_wave(B, base)), k1 = __builtin_amdgcn_readfirstlane(seg_of_wave(B, lastw));
+    if (k0 != k1) {                                   // span crosses a segment boundary: per-row path
+        int seg_hint = k0;
+#pragma unroll
+        for (int r = 0; r < CH_ITEMS; r++) {
+            const i64 w = base + r * WAVE + lane;
+            i64 a0;
+            const int f = chain_flag(B, w, seg_hint, a0);
+            zprev[r] = (f && w > 0 && a0 == 0 && B.b[w - 1] == 0) ? 1 : 0;
+            masks[r] = __ballot(f);
+        }
+        return;
+    }
+    const csv_segment& sg = B.seg[k0];
+    const i64 bias = sg.max_cluster_bias, seg_first = B.woff[k0];
+    const int type = sg.svtype;
+    i64 a[CH_ITEMS];
+#pragma unroll
+    for (int r = 0; r < CH_ITEMS; r++) { const i64 w = base + r * WAVE + lane; a[r] = (w < B.W) ? B.a[w] : 0; }
+    i64 carry = (lane == 0 && base > 0) ? B.a[base - 1] : 0;        // the signature left of the span (lane 0 only)
 #pragma unroll
     for (int r = 0; r < CH_ITEMS; r++) {
-        const i64 w = base + r * WAVE + lane_id();
-        const int f = (w < B.W) ? chain_flag(B, w, seg_hint) : 0;
-        cnt += __popcll(__ballot(f));
+        const i64 w = base + r * WAVE + lane;
+        i64 a0 = shfl_up_i64(a[r], 1);
+        const i64 nxt = shfl_i64(a[r], 63);
+        if (lane == 0) a0 = carry;
+        carry = nxt;
+        const bool in = w < B.W;
+        bool f = in && (w == seg_first || a[r] - a0 > bias);
+        const bool z = in && w > 0 && a0 == 0 && B.b[w - 1] == 0;   // b is read only next to a position-0 signature
+        if (in && !f && w != seg_first) {
+            if (z) f = true;
+            else if (type == CSV_INV) f = (B.b[w] - B.b[w - 1] > bias) || (B.aux[w] != B.aux[w - 1]);
+            else if (type == CSV_TRA) f = B.aux[w] != B.aux[w - 1];
+        }
+        zprev[r] = (f && z) ? 1 : 0;
+        masks[r] = __ballot(f);
     }
+}
+constexpr int EM_TILE = 8;                          // items per emit wavefront
+constexpr int EM_SUPER = 512;                       // items per second-level sum
+
+// sum of p[0 .. n) over the workgroup (256 threads); every thread gets the result
+__device__ __forceinline__ i64 block_prefix_of(const int* p, int n, i64* sh)
+{
+    i64 v = 0;
+    for (int i = threadIdx.x; i < n; i += 256) v += p[i];
+    v = wave_sum_i64(v);
+    if (lane_id() == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const i64 t = sh[0] + sh[1] + sh[2] + sh[3];
+    __syncthreads();
+    return t;
+}
+__device__ __forceinline__ i64 block_prefix_of64(const i64* p, int n, i64* sh)
+{
+    i64 v = 0;
+    for (int i = threadIdx.x; i < n; i += 256) v += p[i];
+    v = wave_sum_i64(v);
+    if (lane_id() == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const i64 t = sh[0] + sh[1] + sh[2] + sh[3];
+    __syncthreads();
+    return t;
+}
+
+__global__ __launch_bounds__(256) void k_chain_count(DevBatch B)
+{
+    // first kernel of a run: nothing in this kernel reads the counters, every later kernel is stream-ordered behind it
+    if (blockIdx.x == 0 && threadIdx.x < (int)(sizeof(DevCounters) / 4)) ((int*)B.cnt)[threadIdx.x] = 0;
+    const i64 base = (i64)blockIdx.x * CH_TILE + (threadIdx.x >> 6) * (WAVE * CH_ITEMS);
+    u64 masks[CH_ITEMS]; int zprev[CH_ITEMS];
+    chain_rows(B, base, masks, zprev);
+    int cnt = 0;
+#pragma unroll
+    for (int r = 0; r < CH_ITEMS; r++) cnt += __popcll(masks[r]);
     __shared__ int s[4];
     if (lane_id() == 0) s[threadIdx.x >> 6] = cnt;
     __syncthreads();
     if (threadIdx.x == 0) B.partial[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
 }
 
-// exclusive scan of n ints in place (single workgroup); total -> *total_out
-__global__ __launch_bounds__(256) void k_scan_partials(int* p, int n, int* total_out)
-{
-    __shared__ int wsum[4];
-    __shared__ int carry_s;
-    if (threadIdx.x == 0) carry_s = 0;
-    __syncthreads();
-    for (int base = 0; base < n; base += 256) {
-        const int i = base + threadIdx.x;
-        const int v = i < n ? p[i] : 0;
-        const int inc = wave_incl_scan_i32(v);
-        if (lane_id() == 63) wsum[threadIdx.x >> 6] = inc;
-        __syncthreads();
-        int woff = 0;
-        for (int k = 0; k < (int)(threadIdx.x >> 6); k++) woff += wsum[k];
-        const int carry = carry_s;
-        if (i < n) p[i] = carry + woff + inc - v;
-        __syncthreads();
-        if (threadIdx.x == 255) carry_s = carry + woff + inc;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0 && total_out) *total_out = carry_s;
-}
-
-// same for packed 64-bit counters; n is read from device memory (*n_ptr, divided by `per`)
-__global__ __launch_bounds__(256) void k_scan_partials64(i64* p, const int* n_ptr, int per, i64* total_out)
-{
-    const int n = (*n_ptr + per - 1) / per;
-    __shared__ i64 wsum[4];
-    __shared__ i64 carry_s;
-    if (threadIdx.x == 0) carry_s = 0;
-    __syncthreads();
-    for (int base = 0; base < n; base += 256) {
-        const int i = base + threadIdx.x;
-        const i64 v = i < n ? p[i] : 0;
-        const i64 inc = wave_incl_scan_i64(v);
-        if (lane_id() == 63) wsum[threadIdx.x >> 6] = inc;
-        __syncthreads();
-        i64 woff = 0;
-        for (int k = 0; k < (int)(threadIdx.x >> 6); k++) woff += wsum[k];
-        const i64 carry = carry_s;
-        if (i < n) p[i] = carry + woff + inc - v;
-        __syncthreads();
-        if (threadIdx.x == 255) carry_s = carry + woff + inc;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0 && total_out) *total_out = carry_s;
-}
-
 __global__ __launch_bounds__(256) void k_chain_apply(DevBatch B)
 {
+    __shared__ i64 sh[4];
     const int wv = threadIdx.x >> 6;
     const i64 base = (i64)blockIdx.x * CH_TILE + wv * (WAVE * CH_ITEMS);
-    int seg_hint = 0;
     u64 masks[CH_ITEMS];
+    int zprev[CH_ITEMS];                // the element before a cluster start is the last element of the previous cluster
+    chain_rows(B, base, masks, zprev);
     int cnt = 0;
 #pragma unroll
-    for (int r = 0; r < CH_ITEMS; r++) {
-        const i64 w = base + r * WAVE + lane_id();
-        const int f = (w < B.W) ? chain_flag(B, w, seg_hint) : 0;
-        masks[r] = __ballot(f);
-        cnt += __popcll(masks[r]);
-    }
+    for (int r = 0; r < CH_ITEMS; r++) cnt += __popcll(masks[r]);
+    // exclusive prefix of this workgroup = sum of the counts of all earlier workgroups (tiny, L2 resident)
+    int run = (int)block_prefix_of(B.partial, blockIdx.x, sh);
     __shared__ int s[4];
     if (lane_id() == 0) s[wv] = cnt;
     __syncthreads();
-    int run = B.partial[blockIdx.x];
     for (int k = 0; k < wv; k++) run += s[k];
+    const int my_total = s[0] + s[1] + s[2] + s[3];
+    int seg_w = 0;                                      // segment of the row element (hint walks forward with w)
 #pragma unroll
     for (int r = 0; r < CH_ITEMS; r++) {
         const i64 w = base + r * WAVE + lane_id();
@@ -264,43 +309,55 @@ __global__ __launch_bounds__(256) void k_chain_apply(DevBatch B)
         if (w < B.W) {
             const int cid = run + __popcll(m & (lanemask_lt() | (1ull << lane_id()))) - 1;
             B.cluster_id[w] = cid;
-            if ((m >> lane_id()) & 1) B.cstart[cid] = (int)w;
+            B.allele_id[w] = -1;
+            if ((m >> lane_id()) & 1) {
+                if (w < B.woff[seg_w] || w >= B.woff[seg_w + 1]) seg_w = seg_of(B, w);
+                B.cstart[cid] = (int)w | (zprev[r] << 31);
+                B.cseg[cid] = seg_w;
+            }
         }
         run += __popcll(m);
     }
-    // the last workgroup also plants the sentinel cstart[n_clusters] = W
+    // the last workgroup also plants the sentinel cstart[n_clusters] = W (bit 31: last element is (0,0))
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) {
-        int tot = B.partial[blockIdx.x];
-        for (int k = 0; k < 4; k++) tot += s[k];
-        B.cstart[tot] = (int)B.W;
-        B.cnt->n_clusters = tot;
+        // thread 255 is in the last wavefront: its `run` now holds prefix + the whole workgroup's count
+        const int z = (B.a[B.W - 1] == 0 && B.b[B.W - 1] == 0) ? 1 : 0;
+        B.cstart[run] = (int)B.W | (z << 31);
+        B.cnt->n_clusters = run;
     }
+    (void)my_total;
 }
 
 // ------------------------------------------------------------------------------------ select
 // cluster c is a work item when it passes the size gate (signatures >= read_count, INDEL:62),
 // does not end in a (0,0) element (INDEL:63-64) and its segment is not dropped.
 // packed counter: low 32 = items, high 32 = items of the workgroup tier (m > 64).
-__device__ __forceinline__ i64 select_value(const DevBatch& B, int c, int nC, int& seg_out)
+__device__ __forceinline__ i64 select_value(const DevBatch& B, int c, int nC, int4& rec)
 {
     if (c >= nC) return 0;
-    const int s = B.cstart[c], e = B.cstart[c + 1];
-    const int k = seg_of(B, s);
-    seg_out = k;
-    const csv_segment& sg = B.seg[k];
-    if (e - s < sg.read_count) return 0;
+    const int s = B.cstart[c] & 0x7fffffff, e1 = B.cstart[c + 1];
+    const int e = e1 & 0x7fffffff;
+    const int k = B.cseg[c];
+    rec = make_int4(c, k, s, e - s);
+    if (e1 < 0) return 0;                                   // the cluster ends in a (0,0) element
+    if (e - s < B.seg[k].read_count) return 0;
     if (B.seg_drop[k]) return 0;
-    if (B.a[e - 1] == 0 && B.b[e - 1] == 0) return 0;
     return 1ll + ((e - s > 64) ? (1ll << 32) : 0ll);
 }
+
+constexpr int SEL_ROWS = 8;
+constexpr int SEL_TILE = 256 * SEL_ROWS;             // clusters per workgroup
 
 __global__ __launch_bounds__(256) void k_select_count(DevBatch B)
 {
     const int nC = B.cnt->n_clusters;
-    if ((int)(blockIdx.x * 256) >= nC) return;
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    int k;
-    const i64 v = wave_sum_i64(select_value(B, c, nC, k));
+    if ((i64)blockIdx.x * SEL_TILE >= nC) return;
+    const int base = blockIdx.x * SEL_TILE + (threadIdx.x >> 6) * (WAVE * SEL_ROWS);
+    i64 v = 0;
+    int4 rec;
+#pragma unroll
+    for (int r = 0; r < SEL_ROWS; r++) v += select_value(B, base + r * WAVE + lane_id(), nC, rec);
+    v = wave_sum_i64(v);
     __shared__ i64 s[4];
     if (lane_id() == 0) s[threadIdx.x >> 6] = v;
     __syncthreads();
@@ -309,28 +366,36 @@ __global__ __launch_bounds__(256) void k_select_count(DevBatch B)
 
 __global__ __launch_bounds__(256) void k_select_apply(DevBatch B)
 {
+    __shared__ i64 sh[4];
     const int nC = B.cnt->n_clusters;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        const i64 t = B.cnt->sel_total;
-        B.cnt->n_items = (int)(t & 0xffffffffll);
-        B.cnt->n_items_big = (int)(t >> 32);
+    const int nblk = (nC + SEL_TILE - 1) / SEL_TILE;
+    if (blockIdx.x == 0) {                                  // publishes the totals for the kernels behind
+        const i64 t = block_prefix_of64(B.partial64, nblk, sh);
+        if (threadIdx.x == 0) { B.cnt->n_items = (int)(t & 0xffffffffll); B.cnt->n_items_big = (int)(t >> 32); }
     }
-    if ((int)(blockIdx.x * 256) >= nC) return;
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    int k = 0;
-    const i64 v = select_value(B, c, nC, k);
-    const i64 inc = wave_incl_scan_i64(v);
+    if ((int)blockIdx.x >= nblk) return;
+    const int wv = threadIdx.x >> 6;
+    const int base = blockIdx.x * SEL_TILE + wv * (WAVE * SEL_ROWS);
+    i64 v[SEL_ROWS]; int4 rec[SEL_ROWS];
+    i64 tot = 0;
+#pragma unroll
+    for (int r = 0; r < SEL_ROWS; r++) { v[r] = select_value(B, base + r * WAVE + lane_id(), nC, rec[r]); tot += v[r]; }
+    tot = wave_sum_i64(tot);
+    i64 run = block_prefix_of64(B.partial64, blockIdx.x, sh);
     __shared__ i64 s[4];
-    if (lane_id() == 63) s[threadIdx.x >> 6] = inc;
+    if (lane_id() == 0) s[wv] = tot;
     __syncthreads();
-    i64 off = B.partial64[blockIdx.x];
-    for (int q = 0; q < (int)(threadIdx.x >> 6); q++) off += s[q];
-    if (v) {
-        const i64 ex = off + inc - v;
-        const int j = (int)(ex & 0xffffffffll), jb = (int)(ex >> 32);
-        B.item_cid[j] = c;
-        B.item_seg[j] = k;
-        if (v >> 32) B.list_big[jb] = j; else B.list_small[j - jb] = j;
+    for (int q = 0; q < wv; q++) run += s[q];
+#pragma unroll
+    for (int r = 0; r < SEL_ROWS; r++) {
+        const i64 inc = wave_incl_scan_i64(v[r]);
+        if (v[r]) {
+            const i64 ex = run + inc - v[r];
+            const int j = (int)(ex & 0xffffffffll), jb = (int)(ex >> 32);
+            B.item_rec[j] = rec[r];
+            if (v[r] >> 32) B.list_big[jb] = j; else B.list_small[j - jb] = j;
+        }
+        run += shfl_i64(inc, 63);
     }
 }
 
@@ -451,9 +516,17 @@ __device__ int cipos_of(const i64* v, int n, i64 sum, const double* sqrt_tab)
     return (int)(1.96 * sd / rt);
 }
 
+// one thread publishes an item's result: slot count and packed (valid calls << 32 | their supports).
+// (Accumulating tile sums here with atomics was tried: even non-returning adds on ~n/8 words doubled
+// the kernel time, so the prefix is a separate, single-workgroup sweep: k_items_scan.)
+__device__ __forceinline__ void item_done(const DevBatch& B, int j, int nslots, int ncalls, int nsup)
+{
+    B.item_nslots[j] = nslots;
+    B.item_cnt[j] = ((i64)ncalls << 32) + (i64)nsup;
+}
 __device__ __forceinline__ void item_none(const DevBatch& B, int j)
 {
-    if (threadIdx.x == 0) { B.item_tbase[j] = 0; B.item_nslots[j] = 0; B.item_ncalls[j] = 0; B.item_nsup[j] = 0; }
+    if (threadIdx.x == 0) item_done(B, j, 0, 0, 0);
 }
 
 // Temp call slots need no allocation: a cluster of m signatures yields at most m calls (every allele /
@@ -643,9 +716,8 @@ template <int BLOCK> __device__ void refine_indel(const DevBatch& B, const ItemC
     }
     ncalls = (int)block_sum_i64<BLOCK>(ncalls, red);
     nsup = (int)block_sum_i64<BLOCK>(nsup, red);
-    if (threadIdx.x == 0) {
-        B.item_tbase[it.j] = tbase; B.item_nslots[it.j] = npass; B.item_ncalls[it.j] = ncalls; B.item_nsup[it.j] = nsup;
-    }
+    (void)tbase;
+    if (threadIdx.x == 0) item_done(B, it.j, npass, ncalls, nsup);
 }
 
 // compacted write of the first-seen signatures of ranks [r0, r1) to sup_tmp[dst...]; one wavefront
@@ -781,9 +853,7 @@ template <int BLOCK> __device__ void refine_pair(const DevBatch& B, const ItemCt
             }
             soff += u;
         }
-        if (lane_id() == 0) {
-            B.item_tbase[it.j] = tbase; B.item_nslots[it.j] = ne; B.item_ncalls[it.j] = ne; B.item_nsup[it.j] = soff;
-        }
+        if (lane_id() == 0) item_done(B, it.j, ne, ne, soff);
         return;
     }
 
@@ -841,9 +911,7 @@ template <int BLOCK> __device__ void refine_pair(const DevBatch& B, const ItemCt
     }
     ncalls = (int)block_sum_i64<BLOCK>(ncalls, red);
     nsup = (int)block_sum_i64<BLOCK>(nsup, red);
-    if (threadIdx.x == 0) {
-        B.item_tbase[it.j] = tbase; B.item_nslots[it.j] = nslots; B.item_ncalls[it.j] = ncalls; B.item_nsup[it.j] = nsup;
-    }
+    if (threadIdx.x == 0) item_done(B, it.j, nslots, ncalls, nsup);
 }
 
 // The arrays are reached through FLAT pointers (they may also live in global scratch).  hipcc folds
@@ -867,11 +935,9 @@ template <int BLOCK, int CAP> __global__ __launch_bounds__(BLOCK) void k_refine(
     for (int q = blockIdx.x; q < n; q += gridDim.x) {
         ItemCtx it;
         it.j = big ? B.list_big[q] : B.list_small[q];
-        it.k = B.item_seg[it.j];
+        const int4 rec = B.item_rec[it.j];
+        it.cid = rec.x; it.k = rec.y; it.s = rec.z; it.m = rec.w;
         if (!big) { const int ty = B.seg[it.k].svtype; if (ty == CSV_DEL || ty == CSV_INS) continue; }
-        it.cid = B.item_cid[it.j];
-        it.s = B.cstart[it.cid];
-        it.m = B.cstart[it.cid + 1] - it.s;
         it.gsig0 = B.seg[it.k].sig_begin + ((i64)it.s - B.woff[it.k]);
         int P = 1;
         while (P < it.m) P <<= 1;
@@ -945,11 +1011,11 @@ __global__ __launch_bounds__(256) void k_refine_indel_wave(DevBatch B)
     const u64 lt_mask = lanemask_lt(), le_mask = lt_mask | (1ull << lane);
     for (int q = wave; q < nsmall; q += nwaves) {
         const int j = B.list_small[q];
-        const int k = B.item_seg[j];
+        const int4 rec = B.item_rec[j];
+        const int k = rec.y, s = rec.z, m = rec.w;
         const csv_segment& sg = B.seg[k];
         const int type = sg.svtype;
         if (type != CSV_DEL && type != CSV_INS) continue;          // other types: k_refine<64,64>
-        const int cid = B.item_cid[j], s = B.cstart[cid], m = B.cstart[cid + 1] - s;
         const bool in = lane < m;
         const i64 a = in ? B.a[s + lane] : 0;
         const i64 b = in ? B.b[s + lane] : 0;
@@ -980,7 +1046,7 @@ __global__ __launch_bounds__(256) void k_refine_indel_wave(DevBatch B)
         const u64 repmask = __ballot(rep);
         const int U = __popcll(repmask);
         if (U < sg.read_count) {                                     // INDEL:133-134
-            if (lane == 0) { B.item_tbase[j] = 0; B.item_nslots[j] = 0; B.item_ncalls[j] = 0; B.item_nsup[j] = 0; }
+            if (lane == 0) item_done(B, j, 0, 0, 0);
             continue;
         }
         const i64 pa = shfl_i64(a, ch & 63);
@@ -1097,40 +1163,47 @@ __global__ __launch_bounds__(256) void k_refine_indel_wave(DevBatch B)
         }
         const int ncalls = __popcll(__ballot(head && valid));
         const int nsup = wave_sum_i32((head && valid) ? n : 0);
-        if (lane == 0) { B.item_tbase[j] = tbase; B.item_nslots[j] = npass; B.item_ncalls[j] = ncalls; B.item_nsup[j] = nsup; }
+        if (lane == 0) item_done(B, j, npass, ncalls, nsup);
     }
 }
 
 // ------------------------------------------------------------------------------------ order
-// exclusive scan of the per-item packed counts (valid calls << 32 | supports); single workgroup of 1024
-constexpr int IS_PER = 8;
+// exclusive prefix of the per-item packed counts; one workgroup of 16 wavefronts, each sweeping
+// IS_ROWS coalesced rows of 64 items (32768 items per sweep: one sweep for a 30x genome)
+constexpr int IS_ROWS = 32;
 __global__ __launch_bounds__(1024) void k_items_scan(DevBatch B)
 {
     const int n = B.cnt->n_items;
+    const int wv = threadIdx.x >> 6;
     __shared__ i64 wsum[16];
     __shared__ i64 carry_s;
     if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
-    for (int base = 0; base < n; base += 1024 * IS_PER) {
-        const int i0 = base + threadIdx.x * IS_PER;
-        i64 v[IS_PER]; i64 loc = 0;
+    for (int base = 0; base < n; base += 1024 * IS_ROWS) {
+        const int w0 = base + wv * (64 * IS_ROWS);
+        i64 v[IS_ROWS]; i64 tot = 0;
 #pragma unroll
-        for (int q = 0; q < IS_PER; q++) {
-            const int i = i0 + q;
-            v[q] = i < n ? (((i64)B.item_ncalls[i]) << 32) + (i64)B.item_nsup[i] : 0;
-            loc += v[q];
+        for (int r = 0; r < IS_ROWS; r++) {
+            const int i = w0 + r * 64 + lane_id();
+            v[r] = i < n ? B.item_cnt[i] : 0;
+            tot += v[r];
         }
-        const i64 inc = wave_incl_scan_i64(loc);
-        if (lane_id() == 63) wsum[threadIdx.x >> 6] = inc;
+        tot = wave_sum_i64(tot);
+        if (lane_id() == 0) wsum[wv] = tot;
         __syncthreads();
-        i64 woff = 0;
-        for (int k = 0; k < (int)(threadIdx.x >> 6); k++) woff += wsum[k];
-        const i64 carry = carry_s;
-        i64 run = carry + woff + inc - loc;
+        i64 run = carry_s;
+        for (int k = 0; k < wv; k++) run += wsum[k];
 #pragma unroll
-        for (int q = 0; q < IS_PER; q++) { const int i = i0 + q; if (i < n) B.item_base[i] = run; run += v[q]; }
+        for (int r = 0; r < IS_ROWS; r++) {
+            const int i = w0 + r * 64 + lane_id();
+            if (w0 + r * 64 < n) {                          // wave-uniform: skip empty rows
+                const i64 inc = wave_incl_scan_i64(v[r]);
+                if (i < n) B.item_base[i] = run + inc - v[r];
+                run += shfl_i64(inc, 63);
+            }
+        }
         __syncthreads();
-        if (threadIdx.x == 1023) carry_s = carry + woff + inc;
+        if (threadIdx.x == 1023) carry_s = run;
         __syncthreads();
     }
     if (threadIdx.x == 0) {
@@ -1141,53 +1214,112 @@ __global__ __launch_bounds__(1024) void k_items_scan(DevBatch B)
     }
 }
 
-// one wavefront per item: compact its valid temp calls into the final, ordered arrays
+// compact one item's valid temp calls into the final arrays (one wavefront, any slot count)
+__device__ __forceinline__ void emit_item_serial(const DevBatch& B, int j, i64 base)
+{
+    const int lane = lane_id();
+    const int nslots = B.item_nslots[j];
+    const int4 rec = B.item_rec[j];
+    const int cid = rec.x, k = rec.y, s = rec.z;
+    const i64 gs = B.seg[k].sig_begin + ((i64)s - B.woff[k]) - s;      // w -> global signature index
+    int cb = (int)(base >> 32); i64 sb = base & 0xffffffffll;
+    const int aux0 = B.aux[s];
+    for (int c0 = 0; c0 < nslots; c0 += 64) {
+        const int t = s + c0 + lane;
+        const int in = (c0 + lane) < nslots;
+        const int valid = in ? B.t_valid[t] : 0;
+        const int nsup = valid ? B.t_support[t] : 0;
+        const int tso = valid ? B.t_supoff[t] : 0;
+        const u64 mk = __ballot(valid);
+        const int c = cb + __popcll(mk & lanemask_lt());
+        const int sinc = wave_incl_scan_i32(nsup);
+        const i64 so = sb + sinc - nsup;
+        if (valid) {
+            B.o_seg[c] = k; B.o_cluster[c] = cid; B.o_aux[c] = aux0;
+            B.o_bp1[c] = B.t_bp1[t]; B.o_bp2[c] = B.t_bp2[t]; B.o_support[c] = nsup;
+            B.o_cipos[c] = B.t_cipos[t]; B.o_cilen[c] = B.t_cilen[t];
+            B.o_search[c] = B.t_search[t]; B.o_pick[c] = B.t_pick[t];
+            B.o_dr[c] = -1; B.o_dv[c] = -1; B.o_gl[c] = -1;
+            B.o_supoff[c] = so;
+        }
+        u64 rest = mk;
+        while (rest) {
+            const int l = __ffsll((long long)rest) - 1;
+            rest &= rest - 1;
+            const int cc = __shfl(c, l), nn = __shfl(nsup, l);
+            const i64 dst = shfl_i64(so, l);
+            const int src = s + __shfl(tso, l);
+            for (int i = lane; i < nn; i += 64) {
+                const int w = B.sup_tmp[src + i];
+                B.o_supsig[dst + i] = gs + w;
+                B.o_suprid[dst + i] = B.rid[w];
+                B.allele_id[w] = cc;
+            }
+        }
+        cb += __popcll(mk);
+        sb += __shfl(sinc, 63);
+    }
+}
+
+// One wavefront per tile of EM_TILE = 8 consecutive items; 8 lanes per item, one lane per temp slot,
+// so the dependent loads of all 8 items are in flight together.  Items with more than 8 slots (rare)
+// send the whole tile down the serial path.
 __global__ __launch_bounds__(256) void k_emit(DevBatch B)
 {
     const int n = B.cnt->n_items;
     const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * 256 + threadIdx.x) >> 6), nwaves = (gridDim.x * 256) >> 6;
-    for (int j = wave; j < n; j += nwaves) {
-        const int nslots = B.item_nslots[j];
-        if (nslots == 0) continue;
-        const int tbase = B.item_tbase[j], cid = B.item_cid[j], k = B.item_seg[j], s = B.cstart[cid];
-        const i64 gs = B.seg[k].sig_begin + ((i64)s - B.woff[k]) - s;      // w -> global signature index
-        const i64 base = B.item_base[j];
-        int cb = (int)(base >> 32); i64 sb = base & 0xffffffffll;
-        const int aux0 = B.aux[s];
-        for (int c0 = 0; c0 < nslots; c0 += 64) {
-            const int t = tbase + c0 + lane_id();
-            const int in = (c0 + lane_id()) < nslots;
-            const int valid = in ? B.t_valid[t] : 0;
-            const int nsup = valid ? B.t_support[t] : 0;
-            const u64 mk = __ballot(valid);
-            const int c = cb + __popcll(mk & lanemask_lt());
-            const int sinc = wave_incl_scan_i32(nsup);
-            const i64 so = sb + sinc - nsup;
-            if (valid) {
-                B.o_seg[c] = k; B.o_cluster[c] = cid; B.o_aux[c] = aux0;
-                B.o_bp1[c] = B.t_bp1[t]; B.o_bp2[c] = B.t_bp2[t]; B.o_support[c] = nsup;
-                B.o_cipos[c] = B.t_cipos[t]; B.o_cilen[c] = B.t_cilen[t];
-                B.o_search[c] = B.t_search[t]; B.o_pick[c] = B.t_pick[t];
-                B.o_dr[c] = -1; B.o_dv[c] = -1; B.o_gl[c] = -1;
-                B.o_supoff[c] = so;
+    const int ntiles = (n + EM_TILE - 1) / EM_TILE;
+    const int lane = lane_id(), g = lane >> 3, l8 = lane & 7;
+    for (int tile = wave; tile < ntiles; tile += nwaves) {
+        const int j = tile * EM_TILE + g;
+        const bool act = j < n;
+        const i64 cnt = act ? B.item_cnt[j] : 0;
+        const i64 base = act ? B.item_base[j] : 0;
+        const int nslots = (act && cnt) ? B.item_nslots[j] : 0;
+        if (__ballot(nslots > 8)) {                         // wave-uniform
+            for (int q = 0; q < EM_TILE; q++) {
+                const i64 cq = shfl_i64(cnt, q * 8), bq = shfl_i64(base, q * 8);
+                if (cq) emit_item_serial(B, tile * EM_TILE + q, bq);
             }
-            // supports of each valid slot, all lanes cooperating
-            u64 rest = mk;
-            while (rest) {
-                const int l = __ffsll((long long)rest) - 1;
-                rest &= rest - 1;
-                const int cc = __shfl(c, l), nn = __shfl(nsup, l);
-                const i64 dst = shfl_i64(so, l);
-                const int src = s + __shfl(valid ? B.t_supoff[t] : 0, l);
-                for (int i = lane_id(); i < nn; i += 64) {
-                    const int w = B.sup_tmp[src + i];
-                    B.o_supsig[dst + i] = gs + w;
-                    B.o_suprid[dst + i] = B.rid[w];
-                    B.allele_id[w] = cc;
-                }
+            continue;
+        }
+        int4 rec = make_int4(0, 0, 0, 0);
+        if (nslots) rec = B.item_rec[j];
+        const int cid = rec.x, k = rec.y, s = rec.z;
+        const bool mine = l8 < nslots;
+        const int t = s + l8;
+        const int valid = mine ? B.t_valid[t] : 0;
+        const int nsup = valid ? B.t_support[t] : 0;
+        const int tso = valid ? B.t_supoff[t] : 0;
+        i64 gs = 0; int aux0 = 0;
+        if (nslots) { gs = B.seg[k].sig_begin + ((i64)s - B.woff[k]) - s; aux0 = B.aux[s]; }
+        const u64 mk = __ballot(valid);
+        const u64 gmask = 0xffull << (g * 8);
+        const int c = (int)(base >> 32) + __popcll(mk & gmask & lanemask_lt());
+        const int sinc = wave_incl_scan_i32(nsup);
+        const int gprev = __shfl(sinc, (g * 8 - 1) & 63);
+        const i64 so = (base & 0xffffffffll) + (sinc - nsup) - (g ? gprev : 0);
+        if (valid) {
+            B.o_seg[c] = k; B.o_cluster[c] = cid; B.o_aux[c] = aux0;
+            B.o_bp1[c] = B.t_bp1[t]; B.o_bp2[c] = B.t_bp2[t]; B.o_support[c] = nsup;
+            B.o_cipos[c] = B.t_cipos[t]; B.o_cilen[c] = B.t_cilen[t];
+            B.o_search[c] = B.t_search[t]; B.o_pick[c] = B.t_pick[t];
+            B.o_dr[c] = -1; B.o_dv[c] = -1; B.o_gl[c] = -1;
+            B.o_supoff[c] = so;
+        }
+        // supports: group g copies the lists of its own slots, 8 lanes at a time
+#pragma unroll
+        for (int sl = 0; sl < 8; sl++) {
+            const int src_lane = g * 8 + sl;
+            const int nn = __shfl(nsup, src_lane), cc = __shfl(c, src_lane), ts = __shfl(tso, src_lane);
+            const i64 dst = shfl_i64(so, src_lane);
+            if (!__ballot(nn > 0)) continue;                // wave-uniform
+            for (int i = l8; i < nn; i += 8) {
+                const int w = B.sup_tmp[s + ts + i];
+                B.o_supsig[dst + i] = gs + w;
+                B.o_suprid[dst + i] = B.rid[w];
+                B.allele_id[w] = cc;
             }
-            cb += __popcll(mk);
-            sb += __shfl(sinc, 63);
         }
     }
 }
