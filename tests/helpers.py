@@ -92,3 +92,28 @@ def assert_soa_equal(got, want, store=None, set_order_segments=()):
     for f in ("cluster_id", "allele_id"):
         if got.get(f) is not None and want.get(f) is not None:
             assert np.array_equal(got[f], want[f]), "%s differs" % f
+
+
+def write_reference_workdir(store, work_dir):
+    """Lay a store out as the reference's <TYPE>.pickle / reads.pickle files + index dict
+    (cuteSV main script :817-857): one pickled list per chromosome at a recorded byte offset."""
+    import pickle
+    from cutesv_amd.columns import TYPES
+    per_type, reads = store.tuple_lists()
+    index = {}
+    for t in TYPES:
+        index[t] = {}
+        with open(os.path.join(work_dir, t + ".pickle"), "wb") as f:
+            for ch in store.chroms:
+                blk = [x for x in per_type[t] if x[-1] == ch]
+                if blk:
+                    index[t][ch] = f.tell()
+                    pickle.dump(blk, f)
+    index["reads"] = {}
+    with open(os.path.join(work_dir, "reads.pickle"), "wb") as f:
+        for ch in store.chroms:
+            blk = [r for r in reads if r[-1] == ch]
+            if blk:
+                index["reads"][ch] = f.tell()
+                pickle.dump(blk, f)
+    return index

@@ -1,4 +1,6 @@
 """GPU parity tests (-m gpu): the HIP path through the C ABI against the oracle and the golden fixtures."""
+import os
+
 import numpy as np
 import pytest
 
@@ -120,3 +122,47 @@ def test_tra_genotype_is_refused(ctx):
     with pytest.raises(engine.CsvError) as e:
         ctx.cluster_batch(hb)
     assert e.value.code == _abi.E_INVALID
+
+
+def test_drop_in_shims_on_a_reference_workdir(ctx, tmp_path, monkeypatch):
+    """run_del/run_ins/run_inv/run_dup/run_tra with the reference's own argument tuples, reading the
+    reference's own pickle layout, return the reference's rows."""
+    from cutesv_amd import resolve
+    from helpers import write_reference_workdir
+    monkeypatch.setattr(resolve, "_ctx", ctx)
+    for case in [c for c in load_json("small_cases.json.gz") if c["name"] in ("realnames_gt", "ont_gt", "hifi")]:
+        st = store_from_json(case["store"])
+        p = Params(**case["params"])
+        d = str(tmp_path / case["name"]) + "/"
+        os.makedirs(d)
+        idx = write_reference_workdir(st, d)
+        resolve._stores.clear()
+        for t, c, want in case["rows"]:
+            if t == "DEL":
+                got = resolve.run_del((d, c, "DEL", p.min_support, p.diff_ratio_merging_DEL, p.max_cluster_bias_DEL,
+                                       min(p.min_support, 5), "bam", p.genotype, p.gt_round, p.remain_reads_ratio, idx))
+            elif t == "INS":
+                got = resolve.run_ins((d, c, "INS", p.min_support, p.diff_ratio_merging_INS, p.max_cluster_bias_INS,
+                                       min(p.min_support, 5), "bam", p.genotype, p.gt_round, p.remain_reads_ratio, idx))
+            elif t == "INV":
+                got = resolve.run_inv((d, c, "INV", p.min_support, p.max_cluster_bias_INV, p.min_size, "bam", p.genotype,
+                                       p.max_size, p.gt_round, idx))
+            elif t == "DUP":
+                got = resolve.run_dup((d, c, p.min_support, p.max_cluster_bias_DUP, p.min_size, "bam", p.genotype,
+                                       p.max_size, p.gt_round, idx))
+            else:
+                got = resolve.run_tra((d, c, p.min_support, p.diff_ratio_filtering_TRA, p.max_cluster_bias_TRA, "bam",
+                                       False, p.gt_round, idx))
+            assert got[0] == c
+            assert_rows_equal(t, got[1], want, where="shim %s %s:%s" % (case["name"], t, c))
+        # and the batched form returns the same rows per chromosome, in main_ctrl's concatenation order
+        merged = resolve.cluster_stage(st, p, ctx=ctx)
+        want_by_chr = {}
+        for t in ("DEL", "INS", "INV", "DUP", "TRA"):
+            for tt, c, rows in case["rows"]:
+                if tt == t:
+                    want_by_chr.setdefault(c, []).extend([(t, r) for r in rows])
+        for c, rows in merged.items():
+            assert len(rows) == len(want_by_chr.get(c, []))
+            for g, (t, w) in zip(rows, want_by_chr[c]):
+                assert_rows_equal(t, [g], [w], where="stage %s" % c)

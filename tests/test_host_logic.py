@@ -1,0 +1,129 @@
+"""CPU tests of the host side: C-ABI surface, column store round trips, sharding, drop-in shims' argument handling."""
+import ctypes as C
+import os
+import pickle
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from cutesv_amd import synth, shard, _abi, _lib
+from cutesv_amd.columns import SigStore, Params, TYPES
+from helpers import load_json, store_from_json
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_c_abi_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "cutesv_hip.h")).read()
+    declared = set(re.findall(r"\b(csv_[a-z_0-9]+)\s*\(", header))
+    declared -= {"csv_ctx"}
+    assert {"csv_cluster_batch", "csv_batch_upload", "csv_batch_run", "csv_batch_download", "csv_ctx_create",
+            "csv_ctx_destroy", "csv_last_error", "csv_gl_index", "csv_abi_version"} <= declared
+    L = _lib.lib()                                      # raises if the .so is missing or a symbol is absent
+    for name in declared:
+        assert hasattr(L, name), name
+    assert {n for n, _, _ in _lib.SYMBOLS} == declared
+    assert L.csv_abi_version() == _abi.ABI_VERSION
+    # the pure host helper needs no GPU
+    from cutesv_amd import genotype
+    for c0, c1 in ((3, 1), (6, 2), (0, 5), (17, 9), (250, 31), (0, 400), (99, 2)):
+        assert L.csv_gl_index(c0, c1) == genotype.gl_index(c0, c1)
+    assert C.sizeof(_abi.BatchIn) == 104 and C.sizeof(_abi.BatchOut) == 176 and C.sizeof(_abi.RunStats) == 112
+    assert _abi.SEGMENT_DTYPE.itemsize == 88      # sizeof(csv_batch_in / _out / csv_run_stats / csv_segment) as gcc lays them out
+
+
+def test_missing_extension_fails_loudly(tmp_path, monkeypatch):
+    monkeypatch.setattr(_lib, "_LIB", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.ExtensionMissing):
+        _lib.lib()
+
+
+def test_store_roundtrips(tmp_path):
+    case = load_json("small_cases.json.gz")[-1]          # real read names, real sequences
+    st = store_from_json(case["store"])
+    per, reads = st.tuple_lists()
+    st2 = SigStore.from_tuple_lists(per, reads)
+    for k in ("a", "b", "read_id", "aux", "reads_off", "r_start", "r_end", "r_primary", "r_id"):
+        assert np.array_equal(getattr(st, k), getattr(st2, k)), k
+    assert st.seg_index == st2.seg_index and st.names.names == st2.names.names
+    st.save(str(tmp_path / "cols"))
+    st3 = SigStore.load(str(tmp_path / "cols"))
+    assert np.array_equal(st3.a, st.a) and st3.seg_index == st.seg_index and st3.sequence(st.seg_index[("INS", "chr1")][0]) == \
+        st.sequence(st.seg_index[("INS", "chr1")][0])
+    # unsorted input with duplicates is sorted / de-duplicated like the reference's rebuild step
+    rng = np.random.default_rng(0)
+    shuffled = {t: [per[t][i] for i in rng.permutation(len(per[t]))] + per[t][:5] for t in TYPES}
+    st4 = SigStore.from_tuple_lists(shuffled, reads)
+    assert np.array_equal(st4.a, st.a) and np.array_equal(st4.read_id, st.read_id)
+
+
+def test_reference_workdir_reader(tmp_path):
+    st = synth.small_mixed(seed=3, n_sites=6, n_noise=50, n_loci=5)
+    per, reads = st.tuple_lists()
+    index = {}
+    d = str(tmp_path) + "/"
+    for t in TYPES:
+        index[t] = {}
+        with open(d + t + ".pickle", "wb") as f:
+            for ch in st.chroms:
+                blk = [x for x in per[t] if x[-1] == ch]
+                if blk:
+                    index[t][ch] = f.tell()
+                    pickle.dump(blk, f)
+    index["reads"] = {}
+    with open(d + "reads.pickle", "wb") as f:
+        for ch in st.chroms:
+            blk = [r for r in reads if r[-1] == ch]
+            if blk:
+                index["reads"][ch] = f.tell()
+                pickle.dump(blk, f)
+    with open(d + "sigindex.pickle", "wb") as f:
+        pickle.dump(index, f)
+    st2 = SigStore.from_reference_workdir(d)
+    assert np.array_equal(st2.a, st.a) and np.array_equal(st2.b, st.b)
+    for (t, ch), (b, e) in st.seg_index.items():         # aux is meaningful for INS / INV / TRA only
+        assert st2.seg_index[(t, ch)] == (b, e)
+        if t in ("INS", "INV", "TRA"):
+            assert np.array_equal(st2.aux[b:e], st.aux[b:e]), (t, ch)
+    assert [st2.names[i] for i in st2.read_id] == [st.names[i] for i in st.read_id]
+
+
+def test_lpt_sharding_is_a_balanced_partition():
+    st = synth.ont30(scale=0.02)
+    for n in (1, 2, 4, 8):
+        parts = shard.assign(st, n)
+        flat = [c for p in parts for c in p]
+        assert sorted(flat) == sorted({c for (_, c) in st.seg_index}) and len(flat) == len(set(flat))
+        loads = [sum(shard.chromosome_cost(st, c) for c in p) for p in parts]
+        assert max(loads) <= sum(loads) / n + max(shard.chromosome_cost(st, c) for c in flat)
+        tasks = [t for r in range(n) for t in shard.tasks_of_rank(st, r, n)]
+        assert sorted(tasks) == sorted(st.tasks())
+
+
+def test_shims_follow_the_reference_argument_contract():
+    from cutesv_amd import resolve
+    idx = {"DEL": {}, "INS": {}, "INV": {}, "DUP": {}, "TRA": {}}
+    # chromosome absent from the index -> (chr, []) without touching any file or GPU (INDEL:44-45 etc.)
+    assert resolve.run_del(("/nonexistent/", "7", "DEL", 10, 0.5, 200, 5, "bam", False, 500, 1.0, idx)) == ("7", [])
+    assert resolve.run_ins(("/nonexistent/", "7", "INS", 10, 0.3, 100, 5, "bam", False, 500, 1.0, idx)) == ("7", [])
+    assert resolve.run_inv(("/nonexistent/", "7", "INV", 10, 500, 30, "bam", False, 100000, 500, idx)) == ("7", [])
+    assert resolve.run_dup(("/nonexistent/", "7", 10, 500, 30, "bam", False, 100000, 500, idx)) == ("7", [])
+    assert resolve.run_tra(("/nonexistent/", "7", 10, 0.6, 50, "bam", False, 500, idx)) == ("7", [])
+    with pytest.raises(NotImplementedError):
+        resolve.run_tra(("/nonexistent/", "7", 10, 0.6, 50, "bam", True, 500, idx))
+
+
+def test_two_rank_gloo_sharded_stage_matches_single_rank():
+    """N > 1 plumbing on CPU: two gloo ranks take their LPT shard, cluster it (oracle engine stands in for
+    the GPU here), exchange per-chromosome digests; rank 0 checks the union equals the unsharded run."""
+    script = os.path.join(ROOT, "tests", "dist_shard_worker.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29613", PYTHONPATH=ROOT)
+    procs = [subprocess.Popen([sys.executable, script, str(r), "2"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(2)]
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert "SHARD-OK" in outs[0]
