@@ -225,6 +225,10 @@ def main():
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()
+    if os.environ.get("CSV_BENCH_EXIT_ALARM"):     # under rocprofv3 the process was seen to hang AFTER the tool had
+        import signal                              # written its output; let teardown run, but not forever
+        sys.stdout.flush()
+        signal.alarm(int(os.environ["CSV_BENCH_EXIT_ALARM"]))
 
 
 if __name__ == "__main__":
