@@ -74,7 +74,7 @@ def kernel_units(store, hb, res, stats):
     b = {
         "k_chain_count": per_sig * W, "k_chain_apply": per_sig * W,
         "k_select_count": per_sig * W, "k_select_apply": per_sig * W,
-        "k_refine_indel_wave": per_sig * n_small + per_call * calls, "k_refine_wave": per_sig * n_small + per_call * calls, "k_refine_block": per_sig * n_big + per_call * calls,
+        "k_refine_indel_wave": per_sig * n_small + per_call * calls, "k_refine_wave": per_sig * n_small + per_call * calls, "k_refine_mid": per_sig * n_big + per_call * calls, "k_refine_block": per_sig * n_big + per_call * calls,
         "k_emit": per_call * calls + 8 * sup, "k_items_scan": 8 * int(stats.n_work_wave + stats.n_work_block),
         "k_pmax_count": 21 * R, "k_pmax_apply": 21 * R, "k_genotype": 21 * R + 32 * gt_calls,
     }

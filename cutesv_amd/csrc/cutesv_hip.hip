@@ -23,8 +23,8 @@ struct Buf {                      // grow-only device buffer
 
 // one timing slot per launch, in launch order
 const char* kStageName[CSV_N_STAGES] = {"init", "k_chain_count", "k_chain_apply", "k_select_count", "k_select_apply",
-                                        "k_refine_indel_wave", "k_refine_wave", "k_refine_block", "k_items_scan", "k_emit",
-                                        "k_pmax_count", "k_pmax_scan", "k_pmax_apply", "k_genotype", "", ""};
+                                        "k_refine_indel_wave", "k_refine_wave", "k_refine_mid", "k_refine_block", "k_items_scan",
+                                        "k_emit", "k_pmax_count", "k_pmax_scan", "k_pmax_apply", "k_genotype", ""};
 
 }  // namespace
 
@@ -291,6 +291,7 @@ int csv_batch_run(csv_ctx* c, csv_run_stats* stats)
     const DevBatch& B = c->B;
     const i64 W = B.W;
     constexpr int LDS_SMALL = refine_lds_bytes<64>();
+    constexpr int LDS_MID = refine_lds_bytes<256>();
     constexpr int LDS_BIG = refine_lds_bytes<2048>();
     if (!c->big_lds_set) {
         HIP_TRY(c, hipFuncSetAttribute((const void*)k_refine<256, 2048>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BIG));
@@ -326,13 +327,17 @@ int csv_batch_run(csv_ctx* c, csv_run_stats* stats)
         int g_small = B.cap_items < 8192 ? B.cap_items : 8192;
         if (g_small < 1) g_small = 1;
         int g_iw = div_up(B.cap_items, 4) < 2048 ? div_up(B.cap_items, 4) : 2048;
+        if (getenv("CSV_IW_GRID")) g_iw = atoi(getenv("CSV_IW_GRID"));       // tuning aid
         if (g_iw < 1) g_iw = 1;
         LAUNCH("refine_indel_wave", k_refine_indel_wave, g_iw, 256, 0, B);
-        if (c->any_pair) LAUNCH("refine_wave", (k_refine<64, 64>), g_small, 64, LDS_SMALL, B, 0);
+        if (c->any_pair) LAUNCH("refine_wave", (k_refine<64, 64>), g_small, 64, LDS_SMALL, B, 0, 0, 64);
         else HIP_TRY(c, mark());
+        int g_mid = B.cap_items < 4096 ? B.cap_items : 4096;
+        if (g_mid < 1) g_mid = 1;
+        LAUNCH("refine_mid", (k_refine<64, 256>), g_mid, 64, LDS_MID, B, 1, 64, 256);
         int g_big = B.cap_items < 512 ? B.cap_items : 512;
         if (g_big < 1) g_big = 1;
-        LAUNCH("refine_block", (k_refine<256, 2048>), g_big, 256, LDS_BIG, B, 1);
+        LAUNCH("refine_block", (k_refine<256, 2048>), g_big, 256, LDS_BIG, B, 1, 256, 0x7fffffff);
         LAUNCH("items_scan", k_items_scan, 1, 1024, 0, B);
         LAUNCH("emit", k_emit, 2048, 256, 0, B);
         if (c->any_genotype && B.n_reads > 0) {

@@ -71,7 +71,7 @@ struct DevBatch {
     // refine outputs
     int*           item_nslots;      // temp slots the item filled (t_*[s + slot])
     i64*           item_cnt;         // packed (valid calls << 32 | supports of valid calls)
-    i64*           item_base;        // exclusive prefix of item_cnt
+    i64*           item_base;        // exclusive prefix of item_cnt per tile of EM_TILE items
     int*           sup_tmp;          // W: support lists, stored inside the cluster's own [s, e) range
     i64*           t_bp1; i64* t_bp2; i64* t_search; i64* t_pick;
     int*           t_support; int* t_cipos; int* t_cilen; int* t_supoff; int* t_valid;
@@ -194,12 +194,12 @@ constexpr int CH_TILE = 256 * CH_ITEMS;             // signatures per workgroup
 // segment (almost always) the segment scalars sit in SGPRs and the 8 row loads are issued back to
 // back; the neighbour value comes from the lane to the left.  zprev[r] marks cluster starts whose
 // preceding signature is a (0,0) element.
-__device__ __forceinline__ void chain_rows(const DevBatch& B, i64 base, u64 (&masks)[CH_ITEMS], int (&zprev)[CH_ITEMS])
+__device__ __forceinline__ int chain_rows(const DevBatch& B, i64 base, u64 (&masks)[CH_ITEMS], int (&zprev)[CH_ITEMS])
 {
     const int lane = lane_id();
 #pragma unroll
     for (int r = 0; r < CH_ITEMS; r++) { masks[r] = 0; zprev[r] = 0; }
-    if (base >= B.W) return;
+    if (base >= B.W) return -1;
     const i64 lastw = (base + WAVE * CH_ITEMS - 1 < B.W) ? base + WAVE * CH_ITEMS - 1 : B.W - 1;
     const int k0 = __builtin_amdgcn_readfirstlane(seg_of_wave(B, base)), k1 = __builtin_amdgcn_readfirstlane(seg_of_wave(B, lastw));
     if (k0 != k1) {                                   // span crosses a segment boundary: per-row path
@@ -212,7 +212,7 @@ __device__ __forceinline__ void chain_rows(const DevBatch& B, i64 base, u64 (&ma
             zprev[r] = (f && w > 0 && a0 == 0 && B.b[w - 1] == 0) ? 1 : 0;
             masks[r] = __ballot(f);
         }
-        return;
+        return -1;
     }
     const csv_segment& sg = B.seg[k0];
     const i64 bias = sg.max_cluster_bias, seg_first = B.woff[k0];
@@ -239,6 +239,7 @@ __device__ __forceinline__ void chain_rows(const DevBatch& B, i64 base, u64 (&ma
         zprev[r] = (f && z) ? 1 : 0;
         masks[r] = __ballot(f);
     }
+    return k0;
 }
 constexpr int EM_TILE = 8;                          // items per emit wavefront
 constexpr int EM_SUPER = 512;                       // items per second-level sum
@@ -290,7 +291,7 @@ __global__ __launch_bounds__(256) void k_chain_apply(DevBatch B)
     const i64 base = (i64)blockIdx.x * CH_TILE + wv * (WAVE * CH_ITEMS);
     u64 masks[CH_ITEMS];
     int zprev[CH_ITEMS];                // the element before a cluster start is the last element of the previous cluster
-    chain_rows(B, base, masks, zprev);
+    const int kuni = chain_rows(B, base, masks, zprev);
     int cnt = 0;
 #pragma unroll
     for (int r = 0; r < CH_ITEMS; r++) cnt += __popcll(masks[r]);
@@ -301,7 +302,7 @@ __global__ __launch_bounds__(256) void k_chain_apply(DevBatch B)
     __syncthreads();
     for (int k = 0; k < wv; k++) run += s[k];
     const int my_total = s[0] + s[1] + s[2] + s[3];
-    int seg_w = 0;                                      // segment of the row element (hint walks forward with w)
+    int seg_w = kuni >= 0 ? kuni : 0;                   // segment of the row element (hint walks forward with w)
 #pragma unroll
     for (int r = 0; r < CH_ITEMS; r++) {
         const i64 w = base + r * WAVE + lane_id();
@@ -503,7 +504,7 @@ __device__ double np_sumsq_chunk(const i64* v, int n, double mean)
 }
 
 // np.std of the int64 values v[0..n) -> the integer of cal_CIPOS (GT:58-60)
-__device__ int cipos_of(const i64* v, int n, i64 sum, const double* sqrt_tab)
+__device__ __noinline__ int cipos_of(const i64* v, int n, i64 sum, const double* sqrt_tab)
 {
     const double mean = (double)sum / (double)n;
     double acc = 0.0;
@@ -921,7 +922,9 @@ template <int BLOCK> __device__ void refine_pair(const DevBatch& B, const ItemCt
 constexpr int LDS_LEAD = 64;
 template <int CAP> constexpr int refine_lds_bytes() { return LDS_LEAD + (CAP + ARR_PAD) * (8 + 8 + 4 * 5) + 64; }
 
-template <int BLOCK, int CAP> __global__ __launch_bounds__(BLOCK) void k_refine(DevBatch B, int big)
+// `big` selects the work list; items whose size is outside (m_lo, m_hi] are left to another launch
+// (small list: DEL/INS go to k_refine_indel_wave; big list: a one-wavefront mid tier and the workgroup tier).
+template <int BLOCK, int CAP> __global__ __launch_bounds__(BLOCK) void k_refine(DevBatch B, int big, int m_lo, int m_hi)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     char* smem = smem_raw + LDS_LEAD;
@@ -937,6 +940,7 @@ template <int BLOCK, int CAP> __global__ __launch_bounds__(BLOCK) void k_refine(
         it.j = big ? B.list_big[q] : B.list_small[q];
         const int4 rec = B.item_rec[it.j];
         it.cid = rec.x; it.k = rec.y; it.s = rec.z; it.m = rec.w;
+        if (it.m <= m_lo || it.m > m_hi) continue;
         if (!big) { const int ty = B.seg[it.k].svtype; if (ty == CSV_DEL || ty == CSV_INS) continue; }
         it.gsig0 = B.seg[it.k].sig_begin + ((i64)it.s - B.woff[it.k]);
         int P = 1;
@@ -1003,7 +1007,10 @@ __device__ __forceinline__ double np_sum_allele(double sq, int r0, int n, int i)
     return res;
 }
 
-__global__ __launch_bounds__(256) void k_refine_indel_wave(DevBatch B)
+#ifndef CSV_IW_WAVES
+#define CSV_IW_WAVES 4
+#endif
+__global__ __launch_bounds__(256, CSV_IW_WAVES) void k_refine_indel_wave(DevBatch B)
 {
     const int nsmall = B.cnt->n_items - B.cnt->n_items_big;
     const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * 256 + threadIdx.x) >> 6), nwaves = (gridDim.x * 256) >> 6;
@@ -1168,42 +1175,43 @@ __global__ __launch_bounds__(256) void k_refine_indel_wave(DevBatch B)
 }
 
 // ------------------------------------------------------------------------------------ order
-// exclusive prefix of the per-item packed counts; one workgroup of 16 wavefronts, each sweeping
-// IS_ROWS coalesced rows of 64 items (32768 items per sweep: one sweep for a 30x genome)
-constexpr int IS_ROWS = 32;
+// exclusive prefix of the packed (calls, supports) counts at the granularity k_emit needs: one value per
+// tile of EM_TILE = 8 items (k_emit finishes the prefix inside its wavefront).  One workgroup; every thread
+// sums IS_TILES consecutive tiles (a contiguous 256-byte run of item_cnt), then one wave scan + one block
+// combine: 4096 tiles = 32768 items per sweep, a single sweep for a 30x genome.
+constexpr int IS_TILES = 4;
 __global__ __launch_bounds__(1024) void k_items_scan(DevBatch B)
 {
     const int n = B.cnt->n_items;
+    const int ntiles = (n + EM_TILE - 1) / EM_TILE;
     const int wv = threadIdx.x >> 6;
     __shared__ i64 wsum[16];
     __shared__ i64 carry_s;
     if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
-    for (int base = 0; base < n; base += 1024 * IS_ROWS) {
-        const int w0 = base + wv * (64 * IS_ROWS);
-        i64 v[IS_ROWS]; i64 tot = 0;
+    for (int base = 0; base < ntiles; base += 1024 * IS_TILES) {
+        const int t0 = base + threadIdx.x * IS_TILES;
+        i64 ts[IS_TILES]; i64 tot = 0;
 #pragma unroll
-        for (int r = 0; r < IS_ROWS; r++) {
-            const int i = w0 + r * 64 + lane_id();
-            v[r] = i < n ? B.item_cnt[i] : 0;
-            tot += v[r];
+        for (int q = 0; q < IS_TILES; q++) {
+            i64 v = 0;
+            const int j0 = (t0 + q) * EM_TILE;
+            if (j0 < n) {
+#pragma unroll
+                for (int e = 0; e < EM_TILE; e++) if (j0 + e < n) v += B.item_cnt[j0 + e];
+            }
+            ts[q] = v; tot += v;
         }
-        tot = wave_sum_i64(tot);
-        if (lane_id() == 0) wsum[wv] = tot;
+        const i64 inc = wave_incl_scan_i64(tot);
+        if (lane_id() == 63) wsum[wv] = inc;
         __syncthreads();
         i64 run = carry_s;
         for (int k = 0; k < wv; k++) run += wsum[k];
+        i64 ex = run + inc - tot;
 #pragma unroll
-        for (int r = 0; r < IS_ROWS; r++) {
-            const int i = w0 + r * 64 + lane_id();
-            if (w0 + r * 64 < n) {                          // wave-uniform: skip empty rows
-                const i64 inc = wave_incl_scan_i64(v[r]);
-                if (i < n) B.item_base[i] = run + inc - v[r];
-                run += shfl_i64(inc, 63);
-            }
-        }
+        for (int q = 0; q < IS_TILES; q++) { if (t0 + q < ntiles) B.item_base[t0 + q] = ex; ex += ts[q]; }
         __syncthreads();
-        if (threadIdx.x == 1023) carry_s = run;
+        if (threadIdx.x == 1023) carry_s = run + inc;
         __syncthreads();
     }
     if (threadIdx.x == 0) {
@@ -1274,7 +1282,8 @@ __global__ __launch_bounds__(256) void k_emit(DevBatch B)
         const int j = tile * EM_TILE + g;
         const bool act = j < n;
         const i64 cnt = act ? B.item_cnt[j] : 0;
-        const i64 base = act ? B.item_base[j] : 0;
+        const i64 ginc = wave_incl_scan_i64(l8 == 0 ? cnt : 0);      // prefix over the tile's 8 items (one lane per group contributes)
+        const i64 base = B.item_base[tile] + ginc - cnt;
         const int nslots = (act && cnt) ? B.item_nslots[j] : 0;
         if (__ballot(nslots > 8)) {                         // wave-uniform
             for (int q = 0; q < EM_TILE; q++) {
@@ -1325,25 +1334,39 @@ __global__ __launch_bounds__(256) void k_emit(DevBatch B)
 }
 
 // ------------------------------------------------------------------------------------ reads: prefix max of ends
+// r_pmax[i] = max end over reads [first read of i's chromosome .. i].  Coordinates restart at every
+// chromosome, so the scan must not leak across blocks: the scanned value is (chromosome << 40 | end) and the
+// operator is plain max — chromosomes are non-decreasing along the table, so a later chromosome always wins.
 constexpr int PM_TILE = 256 * 8;
-__device__ __forceinline__ bool is_chrom_start(const DevBatch& B, i64 i)
+constexpr int PM_SHIFT = 40;
+constexpr i64 PM_MASK = (1ll << PM_SHIFT) - 1;
+
+__device__ __forceinline__ int chrom_of_read(const DevBatch& B, i64 i, int hint)
 {
+    if (B.reads_off[hint] <= i && i < B.reads_off[hint + 1]) return hint;
     int lo = 0, hi = B.n_chrom;
     while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (B.reads_off[mid] <= i) lo = mid; else hi = mid; }
-    return B.reads_off[lo] == i;
+    return lo;
+}
+
+__device__ __forceinline__ i64 pm_value(const DevBatch& B, i64 i, int& hint)
+{
+    if (i >= B.n_reads) return INT64_MIN;
+    hint = chrom_of_read(B, i, hint);
+    const i64 e = B.r_end[i];
+    if (e < 0 || e > PM_MASK) atomicOr(&B.cnt->error, ERR_KEY_RANGE);
+    if (i > B.reads_off[hint] && B.r_start[i] < B.r_start[i - 1]) atomicOr(&B.cnt->error, ERR_READS_UNSORTED);
+    return ((i64)hint << PM_SHIFT) | e;
 }
 
 __global__ __launch_bounds__(256) void k_pmax_count(DevBatch B)
 {
     const i64 base = (i64)blockIdx.x * PM_TILE + (threadIdx.x >> 6) * 512;
     i64 mx = INT64_MIN;
+    int hint = 0;
     for (int r = 0; r < 8; r++) {
-        const i64 i = base + r * 64 + lane_id();
-        if (i < B.n_reads) {
-            const i64 e = B.r_end[i];
-            if (e > mx) mx = e;
-            if (i > 0 && B.r_start[i] < B.r_start[i - 1] && !is_chrom_start(B, i)) atomicOr(&B.cnt->error, ERR_READS_UNSORTED);
-        }
+        const i64 v = pm_value(B, base + r * 64 + lane_id(), hint);
+        if (v > mx) mx = v;
     }
     for (int m = 32; m > 0; m >>= 1) { const i64 o = shfl_xor_i64(mx, m); if (o > mx) mx = o; }
     __shared__ i64 s[4];
@@ -1381,16 +1404,15 @@ __global__ __launch_bounds__(256) void k_pmax_apply(DevBatch B)
 {
     const int wv = threadIdx.x >> 6;
     const i64 base = (i64)blockIdx.x * PM_TILE + wv * 512;
-    i64 rowmax[8]; i64 vals[8];
+    i64 vals[8];
     i64 run = INT64_MIN;
+    int hint = 0;
     for (int r = 0; r < 8; r++) {
-        const i64 i = base + r * 64 + lane_id();
-        const i64 e = i < B.n_reads ? B.r_end[i] : INT64_MIN;
-        i64 inc = wave_incl_max_i64(e);
+        const i64 v = pm_value(B, base + r * 64 + lane_id(), hint);
+        i64 inc = wave_incl_max_i64(v);
         if (run > inc) inc = run;
         vals[r] = inc;
         run = shfl_i64(inc, 63);
-        rowmax[r] = run;
     }
     __shared__ i64 s[4];
     if (lane_id() == 0) s[wv] = run;
@@ -1399,9 +1421,8 @@ __global__ __launch_bounds__(256) void k_pmax_apply(DevBatch B)
     for (int k = 0; k < wv; k++) if (s[k] > pre) pre = s[k];
     for (int r = 0; r < 8; r++) {
         const i64 i = base + r * 64 + lane_id();
-        if (i < B.n_reads) B.r_pmax[i] = vals[r] > pre ? vals[r] : pre;
+        if (i < B.n_reads) B.r_pmax[i] = (vals[r] > pre ? vals[r] : pre) & PM_MASK;
     }
-    (void)rowmax;
 }
 
 // ------------------------------------------------------------------------------------ genotype
