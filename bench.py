@@ -115,8 +115,9 @@ def main():
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         from oracle import oracle, py_restatement as pr
         procs = a.cpu_procs or os.cpu_count() or 1
-        # bounded sample: the DEL and INS segments of every 3rd chromosome of the same workload (same flags)
-        sample = [t for i, t in enumerate(tasks) if (i % 24) % 3 == 0] if len(tasks) > 12 else tasks
+        # bounded sample: all tasks of the workload when it has <= 4 M signatures (a few seconds of pool time),
+        # else the segments of every 3rd chromosome (same flags)
+        sample = tasks if n_sig <= 4_000_000 else [t for i, t in enumerate(tasks) if (i % 24) % 3 == 0]
         tl = pr.tasks_from_store(store, params, sample)
         ns = sum(len(t[2]) for t in tl)
         t0 = time.perf_counter()

@@ -338,7 +338,7 @@ int csv_batch_run(csv_ctx* c, csv_run_stats* stats)
         int g_big = B.cap_items < 512 ? B.cap_items : 512;
         if (g_big < 1) g_big = 1;
         LAUNCH("refine_block", (k_refine<256, 2048>), g_big, 256, LDS_BIG, B, 1, 256, 0x7fffffff);
-        LAUNCH("items_scan", k_items_scan, 1, 1024, 0, B);
+        LAUNCH("items_scan", k_items_scan, 1, 512, 0, B);
         LAUNCH("emit", k_emit, 2048, 256, 0, B);
         if (c->any_genotype && B.n_reads > 0) {
             const int nr = div_up(B.n_reads, PM_TILE);

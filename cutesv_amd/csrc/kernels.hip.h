@@ -984,13 +984,13 @@ __device__ __forceinline__ i64 permute_i64(int dest_lane, i64 v)      // lane i 
 
 // numpy's pairwise sum of sq over the allele [r0, r0 + n), n <= 64, valid on the lane with i == 0
 // (i = lane - r0).  8 strided accumulators on lanes i < 8, the fixed combine tree, then the tail.
-__device__ __forceinline__ double np_sum_allele(double sq, int r0, int n, int i)
+__device__ __forceinline__ double np_sum_allele(double sq, int r0, int n, int i, int rows, int tail)
 {
+    // rows = max over the cluster's alleles of (n / 8), tail = max of the sequential tail length: both wave-uniform
     const int lane = lane_id();
     const int nfull = n - (n & 7);
     double acc = sq;
-#pragma unroll
-    for (int t = 1; t < 8; t++) {
+    for (int t = 1; t < rows; t++) {
         const double v = shfl_f64(sq, (lane + 8 * t) & 63);
         if (i < 8 && i + 8 * t < nfull) acc += v;
     }
@@ -999,8 +999,7 @@ __device__ __forceinline__ double np_sum_allele(double sq, int r0, int n, int i)
     const double t3 = t2 + shfl_f64(t2, (lane + 4) & 63);
     double res = (n >= 8) ? t3 : 0.0;
     const int start = (n >= 8) ? nfull : 0;
-#pragma unroll
-    for (int e = 0; e < 7; e++) {
+    for (int e = 0; e < tail; e++) {
         const double v = shfl_f64(sq, (r0 + start + e) & 63);
         if (start + e < n) res += v;
     }
@@ -1142,8 +1141,14 @@ __global__ __launch_bounds__(256, CSV_IW_WAVES) void k_refine_indel_wave(DevBatc
             search = shfl_i64(Ks, e1) - (r0 > 0 ? ks0 : 0);
             bp = (double)ks / (double)keep; siglen = (double)kl / (double)keep;
         }
-        const double vsp = np_sum_allele((double)((double)pos - pmean) * ((double)pos - pmean), r0, n, i);
-        const double vsl = np_sum_allele((double)((double)len - lmean) * ((double)len - lmean), r0, n, i);
+        int rows_l = pass ? (n >> 3) : 0, tail_l = pass ? (n >= 8 ? (n & 7) : n) : 0;
+        for (int msk = 32; msk > 0; msk >>= 1) {
+            const int orow = __shfl_xor(rows_l, msk), otl = __shfl_xor(tail_l, msk);
+            rows_l = orow > rows_l ? orow : rows_l; tail_l = otl > tail_l ? otl : tail_l;
+        }
+        const int rows_u = __builtin_amdgcn_readfirstlane(rows_l), tail_u = __builtin_amdgcn_readfirstlane(tail_l);
+        const double vsp = np_sum_allele((double)((double)pos - pmean) * ((double)pos - pmean), r0, n, i, rows_u, tail_u);
+        const double vsl = np_sum_allele((double)((double)len - lmean) * ((double)len - lmean), r0, n, i, rows_u, tail_u);
         const double rt = B.sqrt_tab[n & (SQRT_TAB - 1)];
         const int cip = (int)(1.96 * sqrt(vsp / (double)n) / rt);     // INDEL:191, GT:58-60
         const int cil = (int)(1.96 * sqrt(vsl / (double)n) / rt);     // INDEL:194
@@ -1176,42 +1181,55 @@ __global__ __launch_bounds__(256, CSV_IW_WAVES) void k_refine_indel_wave(DevBatc
 
 // ------------------------------------------------------------------------------------ order
 // exclusive prefix of the packed (calls, supports) counts at the granularity k_emit needs: one value per
-// tile of EM_TILE = 8 items (k_emit finishes the prefix inside its wavefront).  One workgroup; every thread
-// sums IS_TILES consecutive tiles (a contiguous 256-byte run of item_cnt), then one wave scan + one block
-// combine: 4096 tiles = 32768 items per sweep, a single sweep for a 30x genome.
-constexpr int IS_TILES = 4;
-__global__ __launch_bounds__(1024) void k_items_scan(DevBatch B)
+// tile of EM_TILE = 8 items (k_emit finishes the prefix inside its wavefront).  One workgroup of 8
+// wavefronts; a wavefront takes IS_CH chunks of 512 items: coalesced row loads, an LDS transpose so that
+// lane t owns tile t of the chunk, one wave scan per chunk.  4096 tiles = 32768 items per sweep.
+constexpr int IS_CH = 8;
+__global__ __launch_bounds__(512) void k_items_scan(DevBatch B)
 {
     const int n = B.cnt->n_items;
     const int ntiles = (n + EM_TILE - 1) / EM_TILE;
-    const int wv = threadIdx.x >> 6;
-    __shared__ i64 wsum[16];
+    const int wv = threadIdx.x >> 6, lane = lane_id();
+    __shared__ i64 buf[8][64 * 9];                      // [tile][8 items], rows padded to 9
+    __shared__ i64 wsum[8];
     __shared__ i64 carry_s;
     if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
-    for (int base = 0; base < ntiles; base += 1024 * IS_TILES) {
-        const int t0 = base + threadIdx.x * IS_TILES;
-        i64 ts[IS_TILES]; i64 tot = 0;
+    for (int base = 0; base < ntiles; base += 8 * IS_CH * 64) {
+        i64 ts[IS_CH];
 #pragma unroll
-        for (int q = 0; q < IS_TILES; q++) {
-            i64 v = 0;
-            const int j0 = (t0 + q) * EM_TILE;
-            if (j0 < n) {
+        for (int c = 0; c < IS_CH; c++) {
+            const int tile0 = base + (wv * IS_CH + c) * 64;
+            i64 v[8];
 #pragma unroll
-                for (int e = 0; e < EM_TILE; e++) if (j0 + e < n) v += B.item_cnt[j0 + e];
+            for (int r = 0; r < 8; r++) {
+                const int i = tile0 * EM_TILE + r * 64 + lane;
+                v[r] = i < n ? B.item_cnt[i] : 0;
             }
-            ts[q] = v; tot += v;
+#pragma unroll
+            for (int r = 0; r < 8; r++) buf[wv][(r * 8 + (lane >> 3)) * 9 + (lane & 7)] = v[r];
+            __syncthreads();
+            i64 t = 0;
+#pragma unroll
+            for (int e = 0; e < 8; e++) t += buf[wv][lane * 9 + e];
+            ts[c] = t;
+            __syncthreads();
         }
-        const i64 inc = wave_incl_scan_i64(tot);
-        if (lane_id() == 63) wsum[wv] = inc;
+        i64 inc[IS_CH]; i64 tot = 0;
+#pragma unroll
+        for (int c = 0; c < IS_CH; c++) { inc[c] = wave_incl_scan_i64(ts[c]); tot += shfl_i64(inc[c], 63); }
+        if (lane == 0) wsum[wv] = tot;
         __syncthreads();
         i64 run = carry_s;
         for (int k = 0; k < wv; k++) run += wsum[k];
-        i64 ex = run + inc - tot;
 #pragma unroll
-        for (int q = 0; q < IS_TILES; q++) { if (t0 + q < ntiles) B.item_base[t0 + q] = ex; ex += ts[q]; }
+        for (int c = 0; c < IS_CH; c++) {
+            const int tile = base + (wv * IS_CH + c) * 64 + lane;
+            if (tile < ntiles) B.item_base[tile] = run + inc[c] - ts[c];
+            run += shfl_i64(inc[c], 63);
+        }
         __syncthreads();
-        if (threadIdx.x == 1023) carry_s = run + inc;
+        if (threadIdx.x == 511) carry_s = run;
         __syncthreads();
     }
     if (threadIdx.x == 0) {
