@@ -116,31 +116,67 @@ __device__ __forceinline__ i64 shfl_xor_i64(i64 v, int m)
     return ((i64)hi << 32) | (unsigned)lo;
 }
 __device__ __forceinline__ double shfl_xor_f64(double v, int m) { return __longlong_as_double(shfl_xor_i64(__double_as_longlong(v), m)); }
-__device__ __forceinline__ i64 wave_sum_i64(i64 v)
+// ---- wave64 scans / reductions on DPP (data-parallel primitives: row_shr inside rows of 16 lanes, then
+// row_bcast:15 / row_bcast:31 across rows): 6 VALU moves per 32-bit word, no LDS round trips, no waitcnt.
+template <int CTRL, int RM> __device__ __forceinline__ int dpp_i32(int old, int v)
 {
-    for (int m = 32; m > 0; m >>= 1) v += shfl_xor_i64(v, m);
-    return v;
+    return __builtin_amdgcn_update_dpp(old, v, CTRL, RM, 0xf, false);       // lanes without a source keep `old`
 }
-__device__ __forceinline__ int wave_sum_i32(int v)
+template <int CTRL, int RM> __device__ __forceinline__ i64 dpp_i64(i64 old, i64 v)
 {
-    for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m);
-    return v;
+    const int lo = dpp_i32<CTRL, RM>((int)(old & 0xffffffffll), (int)(v & 0xffffffffll));
+    const int hi = dpp_i32<CTRL, RM>((int)(old >> 32), (int)(v >> 32));
+    return ((i64)hi << 32) | (unsigned)lo;
 }
 __device__ __forceinline__ i64 wave_incl_scan_i64(i64 v)
 {
-    for (int d = 1; d < 64; d <<= 1) { i64 t = shfl_up_i64(v, d); if (lane_id() >= d) v += t; }
+    v += dpp_i64<0x111, 0xf>(0, v);     // row_shr:1
+    v += dpp_i64<0x112, 0xf>(0, v);     // row_shr:2
+    v += dpp_i64<0x114, 0xf>(0, v);     // row_shr:4
+    v += dpp_i64<0x118, 0xf>(0, v);     // row_shr:8
+    v += dpp_i64<0x142, 0xa>(0, v);     // row_bcast:15 into rows 1 and 3
+    v += dpp_i64<0x143, 0xc>(0, v);     // row_bcast:31 into rows 2 and 3
     return v;
 }
 __device__ __forceinline__ int wave_incl_scan_i32(int v)
 {
-    for (int d = 1; d < 64; d <<= 1) { int t = __shfl_up(v, d); if (lane_id() >= d) v += t; }
+    v += dpp_i32<0x111, 0xf>(0, v);
+    v += dpp_i32<0x112, 0xf>(0, v);
+    v += dpp_i32<0x114, 0xf>(0, v);
+    v += dpp_i32<0x118, 0xf>(0, v);
+    v += dpp_i32<0x142, 0xa>(0, v);
+    v += dpp_i32<0x143, 0xc>(0, v);
     return v;
 }
 __device__ __forceinline__ i64 wave_incl_max_i64(i64 v)
 {
-    for (int d = 1; d < 64; d <<= 1) { i64 t = shfl_up_i64(v, d); if (lane_id() >= d && t > v) v = t; }
+    i64 t;
+    t = dpp_i64<0x111, 0xf>(INT64_MIN, v); v = t > v ? t : v;
+    t = dpp_i64<0x112, 0xf>(INT64_MIN, v); v = t > v ? t : v;
+    t = dpp_i64<0x114, 0xf>(INT64_MIN, v); v = t > v ? t : v;
+    t = dpp_i64<0x118, 0xf>(INT64_MIN, v); v = t > v ? t : v;
+    t = dpp_i64<0x142, 0xa>(INT64_MIN, v); v = t > v ? t : v;
+    t = dpp_i64<0x143, 0xc>(INT64_MIN, v); v = t > v ? t : v;
     return v;
 }
+// totals come back through v_readlane of lane 63: wave-uniform (SGPR) results
+__device__ __forceinline__ i64 wave_sum_i64(i64 v)
+{
+    v = wave_incl_scan_i64(v);
+    const int lo = __builtin_amdgcn_readlane((int)(v & 0xffffffffll), 63), hi = __builtin_amdgcn_readlane((int)(v >> 32), 63);
+    return ((i64)hi << 32) | (unsigned)lo;
+}
+__device__ __forceinline__ int wave_sum_i32(int v)
+{
+    return __builtin_amdgcn_readlane(wave_incl_scan_i32(v), 63);
+}
+__device__ __forceinline__ i64 lane63_i64(i64 v)
+{
+    const int lo = __builtin_amdgcn_readlane((int)(v & 0xffffffffll), 63), hi = __builtin_amdgcn_readlane((int)(v >> 32), 63);
+    return ((i64)hi << 32) | (unsigned)lo;
+}
+// value of the lane to the left (lane 0 gets 0): DPP wave_shr:1
+__device__ __forceinline__ i64 wave_shr1_i64(i64 v) { return dpp_i64<0x138, 0xf>(0, v); }
 
 // segment of compact index w (woff is tiny; lives in L1/L2)
 __device__ __forceinline__ int seg_of(const DevBatch& B, i64 w)
@@ -172,7 +208,7 @@ __device__ __forceinline__ int chain_flag(const DevBatch& B, i64 w, int& seg_hin
     // all 64 lanes of a row call this together (w = row base + lane); out-of-range lanes pass w >= W
     const bool in = w < B.W;
     const i64 a1 = in ? B.a[w] : 0;
-    a0 = shfl_up_i64(a1, 1);
+    a0 = wave_shr1_i64(a1);
     if (lane_id() == 0 && in && w > 0) a0 = B.a[w - 1];
     if (!in) return 0;
     int k = seg_hint;
@@ -224,7 +260,7 @@ __device__ __forceinline__ int chain_rows(const DevBatch& B, i64 base, u64 (&mas
 #pragma unroll
     for (int r = 0; r < CH_ITEMS; r++) {
         const i64 w = base + r * WAVE + lane;
-        i64 a0 = shfl_up_i64(a[r], 1);
+        i64 a0 = wave_shr1_i64(a[r]);
         const i64 nxt = shfl_i64(a[r], 63);
         if (lane == 0) a0 = carry;
         carry = nxt;
@@ -396,7 +432,7 @@ __global__ __launch_bounds__(256) void k_select_apply(DevBatch B)
             B.item_rec[j] = rec[r];
             if (v[r] >> 32) B.list_big[jb] = j; else B.list_small[j - jb] = j;
         }
-        run += shfl_i64(inc, 63);
+        run += lane63_i64(inc);
     }
 }
 
@@ -451,7 +487,7 @@ template <int BLOCK> __device__ i64 block_sum_i64(i64 v, i64* red)
 template <int BLOCK> __device__ int block_incl_scan(int v, int* tot, i64* red)
 {
     const int inc = wave_incl_scan_i32(v);
-    if (BLOCK == 64) { *tot = __shfl(inc, 63); return inc; }
+    if (BLOCK == 64) { *tot = __builtin_amdgcn_readlane(inc, 63); return inc; }
     __syncthreads();
     if (lane_id() == 63) red[threadIdx.x >> 6] = inc;
     __syncthreads();
@@ -1076,7 +1112,7 @@ __global__ __launch_bounds__(256, CSV_IW_WAVES) void k_refine_indel_wave(DevBatc
         // ---- allele split on consecutive length gaps (INDEL:138, 153-162)
         const i64 lsum = wave_sum_i64(live ? len : 0);
         const double thr = sg.diff_ratio * ((double)lsum / (double)U);
-        const i64 lprev = shfl_up_i64(len, 1);
+        const i64 lprev = wave_shr1_i64(len);
         const bool f = live && r > 0 && ((double)(len - lprev) > thr);
         const u64 S = __ballot(f) | 1ull;                             // allele start ranks
         const u64 below = S & le_mask, above = S & ~le_mask;
@@ -1217,7 +1253,7 @@ __global__ __launch_bounds__(512) void k_items_scan(DevBatch B)
         }
         i64 inc[IS_CH]; i64 tot = 0;
 #pragma unroll
-        for (int c = 0; c < IS_CH; c++) { inc[c] = wave_incl_scan_i64(ts[c]); tot += shfl_i64(inc[c], 63); }
+        for (int c = 0; c < IS_CH; c++) { inc[c] = wave_incl_scan_i64(ts[c]); tot += lane63_i64(inc[c]); }
         if (lane == 0) wsum[wv] = tot;
         __syncthreads();
         i64 run = carry_s;
@@ -1226,7 +1262,7 @@ __global__ __launch_bounds__(512) void k_items_scan(DevBatch B)
         for (int c = 0; c < IS_CH; c++) {
             const int tile = base + (wv * IS_CH + c) * 64 + lane;
             if (tile < ntiles) B.item_base[tile] = run + inc[c] - ts[c];
-            run += shfl_i64(inc[c], 63);
+            run += lane63_i64(inc[c]);
         }
         __syncthreads();
         if (threadIdx.x == 511) carry_s = run;
@@ -1283,7 +1319,7 @@ __device__ __forceinline__ void emit_item_serial(const DevBatch& B, int j, i64 b
             }
         }
         cb += __popcll(mk);
-        sb += __shfl(sinc, 63);
+        sb += __builtin_amdgcn_readlane(sinc, 63);
     }
 }
 
@@ -1408,7 +1444,7 @@ __global__ __launch_bounds__(256) void k_pmax_scan(i64* p, int n)
         __syncthreads();
         i64 pre = carry_s;
         for (int k = 0; k < (int)(threadIdx.x >> 6); k++) if (wmax[k] > pre) pre = wmax[k];
-        i64 ex = shfl_up_i64(inc, 1);
+        i64 ex = wave_shr1_i64(inc);
         if (lane_id() == 0) ex = INT64_MIN;
         if (pre > ex) ex = pre;
         if (i < n) p[i] = ex;
@@ -1430,7 +1466,7 @@ __global__ __launch_bounds__(256) void k_pmax_apply(DevBatch B)
         i64 inc = wave_incl_max_i64(v);
         if (run > inc) inc = run;
         vals[r] = inc;
-        run = shfl_i64(inc, 63);
+        run = lane63_i64(inc);
     }
     __shared__ i64 s[4];
     if (lane_id() == 0) s[wv] = run;
