@@ -98,11 +98,6 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
 
     store, params, wl_name = make_workload(a.workload, a.scale, rank)
     tasks = store.tasks()
@@ -135,8 +130,14 @@ def main():
         cpu_c = dict(value=n_sig / dtc, unit="signatures/s", cores=1, kind="port",
                      sample="full workload, oracle/cutesv_oracle.c single thread, %.3f s" % dtc)
 
-    # ---------------- GPU
+    # ---------------- GPU (the library and the HIP runtime it links are loaded before torch is imported)
     ctx = engine.Context(local_rank)
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)     # timing barrier only: no data-path collective
     t0 = time.perf_counter()
     ctx.upload(hb)
     t_upload = time.perf_counter() - t0

@@ -1051,27 +1051,49 @@ __global__ __launch_bounds__(256, CSV_IW_WAVES) void k_refine_indel_wave(DevBatc
     const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * 256 + threadIdx.x) >> 6), nwaves = (gridDim.x * 256) >> 6;
     const int lane = lane_id();
     const u64 lt_mask = lanemask_lt(), le_mask = lt_mask | (1ull << lane);
-    for (int q = wave; q < nsmall; q += nwaves) {
-        const int j = B.list_small[q];
-        const int4 rec = B.item_rec[j];
-        const int k = rec.y, s = rec.z, m = rec.w;
-        const csv_segment& sg = B.seg[k];
-        const int type = sg.svtype;
+    // software pipeline: the columns of the NEXT item are requested before the current one is computed
+    int qn = wave;
+    int j_n = 0, k_n = 0, s_n = 0, m_n = 0, type_n = -1;
+    i64 a_n = 0, b_n = 0; int rid_n = 0, aux_n = 0;
+    auto fetch = [&]() {
+        type_n = -1;
+        if (qn < nsmall) {
+            j_n = B.list_small[qn];
+            const int4 rec = B.item_rec[j_n];
+            k_n = rec.y; s_n = rec.z; m_n = rec.w;
+            type_n = B.seg[k_n].svtype;
+            if (type_n == CSV_DEL || type_n == CSV_INS) {
+                const bool in = lane < m_n;
+                a_n = in ? B.a[s_n + lane] : 0;
+                b_n = in ? B.b[s_n + lane] : 0;
+                rid_n = in ? B.rid[s_n + lane] : -1 - lane;
+                aux_n = (in && type_n == CSV_INS) ? B.aux[s_n + lane] : 0;
+            }
+        }
+    };
+    fetch();
+    for (; qn < nsmall; ) {
+        const int j = j_n, k = k_n, s = s_n, m = m_n, type = type_n;
+        const i64 a = a_n, b = b_n; const int rid = rid_n, aux = aux_n;
+        qn += nwaves;
+        fetch();
         if (type != CSV_DEL && type != CSV_INS) continue;          // other types: k_refine<64,64>
+        const csv_segment& sg = B.seg[k];
         const bool in = lane < m;
-        const i64 a = in ? B.a[s + lane] : 0;
-        const i64 b = in ? B.b[s + lane] : 0;
-        const int rid = in ? B.rid[s + lane] : -1 - lane;
-        const int aux = (in && type == CSV_INS) ? B.aux[s + lane] : 0;
         if (in && ((u64)b >> (63 - IDX_BITS))) atomicOr(&B.cnt->error, ERR_KEY_RANGE);
 
         // ---- per-read de-duplication (INDEL:125-131): first appearance F, kept signature = strictly longest
         int F = lane, ch = lane;
         i64 bl = b;
+        // does any read own two signatures of this cluster?  Rotate the ids around the wavefront (DPP
+        // wave_ror:1, no SGPR round trip): after k steps lane i sees the id of lane i - k.
         bool dup_any = false;
-        for (int t = 0; t < m; t++) {
-            const int rt = __builtin_amdgcn_readlane(rid, t);
-            dup_any |= (rt == rid) && (t != lane);
+        {
+            int rot = rid;
+            for (int t = 1; t < m; t++) {
+                rot = __builtin_amdgcn_update_dpp(rot, rot, 0x13C, 0xf, 0xf, false);      // wave_ror:1
+                dup_any |= (rot == rid);
+            }
         }
         if (__ballot(dup_any)) {
             F = -1; ch = -1; bl = INT64_MIN;
