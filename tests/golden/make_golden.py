@@ -252,6 +252,16 @@ def known_answers():
           [("B", 1003 + i, "7", 9000 + i, "s%d" % i, "TRA", "1") for i in range(5)] + \
           [("C", 1004 + i, "7", 500 + i, "u%d" % i, "TRA", "1") for i in range(4)] + \
           [("D", 70000 + i, "9", 100 + i, "v%d" % i, "TRA", "1") for i in range(4)]
+    # elements equal to the reference's [0, 0, ...] sentinel: the cluster that ends in one is skipped and the
+    # element after one restarts the cluster (cuteSV_resolveDUP.py:37-38, 52-54; same code in every resolver)
+    case("dup_zero_sentinel", {"DUP": [(0, 0, "z%d" % i, "DUP", "1") for i in range(4)] +
+                                      [(3 + i, 900 + i, "y%d" % i, "DUP", "1") for i in range(4)] +
+                                      [(5000 + i, 9000 + i, "x%d" % i, "DUP", "1") for i in range(4)],
+                               "INV": [("++", 0, 0, "p%d" % i, "INV", "1") for i in range(5)] +
+                                      [("++", 2, 700 + i, "q%d" % i, "INV", "1") for i in range(4)],
+                               "TRA": [("A", 0, "2", 0, "t%d" % i, "TRA", "1") for i in range(5)]},
+         Params(min_support=3, min_size=30))
+    case("dup_zero_sentinel_only", {"DUP": [(0, 0, "z%d" % i, "DUP", "1") for i in range(6)]}, Params(min_support=3, min_size=0))
     case("tra_two_alleles", {"TRA": tra}, Params(min_support=4))
     case("tra_two_alleles_strict", {"TRA": tra}, Params(min_support=4, diff_ratio_filtering_TRA=0.95))
     return out

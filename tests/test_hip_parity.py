@@ -166,3 +166,26 @@ def test_drop_in_shims_on_a_reference_workdir(ctx, tmp_path, monkeypatch):
             assert len(rows) == len(want_by_chr.get(c, []))
             for g, (t, w) in zip(rows, want_by_chr[c]):
                 assert_rows_equal(t, [g], [w], where="stage %s" % c)
+
+
+def test_random_parameter_stress_vs_oracle(ctx):
+    """random flags x random workload shapes, every SoA field bit-exact against the oracle"""
+    rng = np.random.default_rng(2026)
+    for it in range(24):
+        p = Params(min_support=int(rng.integers(1, 12)), min_size=int(rng.choice([0, 30, 500])),
+                   max_size=int(rng.choice([-1, 2000, 100000])), genotype=bool(rng.integers(0, 2)),
+                   max_cluster_bias_INS=int(rng.choice([0, 20, 100, 1000, 5000])), diff_ratio_merging_INS=float(rng.choice([0.0, 0.1, 0.3, 0.9, 2.0])),
+                   max_cluster_bias_DEL=int(rng.choice([0, 20, 200, 1000, 5000])), diff_ratio_merging_DEL=float(rng.choice([0.0, 0.2, 0.5, 1.5])),
+                   max_cluster_bias_INV=int(rng.choice([10, 500, 5000])), max_cluster_bias_DUP=int(rng.choice([10, 500, 5000])),
+                   max_cluster_bias_TRA=int(rng.choice([5, 50, 2000])), diff_ratio_filtering_TRA=float(rng.choice([0.2, 0.6, 1.0])),
+                   remain_reads_ratio=float(rng.choice([0.3, 0.7, 1.0, 1.5])))
+        st = synth.small_mixed(seed=9000 + it, n_sites=int(rng.integers(5, 60)), coverage=int(rng.choice([6, 20, 45, 90])),
+                               dup_frac=float(rng.choice([0.0, 0.1, 0.6])), n_noise=int(rng.integers(0, 3000)),
+                               n_loci=int(rng.integers(0, 300)), contig_len=int(rng.choice([300_000, 2_000_000])),
+                               pos_sigma=float(rng.choice([1.0, 12.0, 60.0])), len_sigma=float(rng.choice([0.003, 0.04, 0.2])))
+        _compare_soa(ctx, st, p)
+
+
+def test_scaled_cfg4_and_cfg5_vs_oracle(ctx):
+    _compare_soa(ctx, synth.hifi30_gt(scale=0.05), Params.hifi(genotype=True, min_support=3))
+    _compare_soa(ctx, synth.ont90_all(scale=0.05), Params.ont(genotype=True))        # 90x: mostly mid-tier clusters
