@@ -31,6 +31,8 @@ const char* kStageName[CSV_N_STAGES] = {"init", "k_chain_count", "k_chain_apply"
 struct csv_ctx {
     int         device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t side[3] = {};         // side streams: [0] mid + workgroup tier, [1] DUP/INV/TRA wavefront tier, [2] reads prefix max
+    hipEvent_t  ev_init = nullptr, ev_sel = nullptr, ev_aux[3] = {};
     std::string err;
     hipEvent_t  ev[CSV_N_STAGES + 2] = {};
     // device buffers
@@ -41,7 +43,7 @@ struct csv_ctx {
     Buf sc_k, sc_x, sc_v1, sc_v2, sc_v3, sc_v4, sc_v5;
     Buf o_seg, o_cluster, o_aux, o_bp1, o_bp2, o_support, o_cipos, o_cilen, o_search, o_pick, o_dr, o_dv, o_gl;
     Buf o_supoff, o_supsig, o_suprid, allele_id;
-    Buf reads_off, r_start, r_end, r_primary, r_id, r_pmax;
+    Buf reads_off, r_start, r_end, r_primary, r_id, r_pmax, pm_partial;
     Buf sqrt_tab, cnt;
     // host copies
     std::vector<csv_segment> h_seg;
@@ -127,6 +129,10 @@ int csv_ctx_create(int device_id, csv_ctx** out)
     c->device = device_id;
     if (hipSetDevice(device_id) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) { delete c; return CSV_E_HIP; }
     for (auto& e : c->ev) if (hipEventCreate(&e) != hipSuccess) { delete c; return CSV_E_HIP; }
+    for (auto& s2 : c->side) if (hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) != hipSuccess) { delete c; return CSV_E_HIP; }
+    if (hipEventCreateWithFlags(&c->ev_init, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_sel, hipEventDisableTiming) != hipSuccess) { delete c; return CSV_E_HIP; }
+    for (auto& e : c->ev_aux) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { delete c; return CSV_E_HIP; }
     // `num ** 0.5` of cal_CIPOS is libm pow(), not sqrt(): tabulate it with the host libm (GT:59)
     std::vector<double> tab(SQRT_TAB);
     for (int i = 0; i < SQRT_TAB; i++) tab[i] = pow((double)i, 0.5);
@@ -150,10 +156,14 @@ void csv_ctx_destroy(csv_ctx* c)
                   &c->t_support, &c->t_cipos, &c->t_cilen, &c->t_supoff, &c->t_valid, &c->sc_k, &c->sc_x, &c->sc_v1, &c->sc_v2,
                   &c->sc_v3, &c->sc_v4, &c->sc_v5, &c->o_seg, &c->o_cluster, &c->o_aux, &c->o_bp1, &c->o_bp2, &c->o_support,
                   &c->o_cipos, &c->o_cilen, &c->o_search, &c->o_pick, &c->o_dr, &c->o_dv, &c->o_gl, &c->o_supoff, &c->o_supsig,
-                  &c->o_suprid, &c->allele_id, &c->reads_off, &c->r_start, &c->r_end, &c->r_primary, &c->r_id, &c->r_pmax,
+                  &c->o_suprid, &c->allele_id, &c->reads_off, &c->r_start, &c->r_end, &c->r_primary, &c->r_id, &c->r_pmax, &c->pm_partial,
                   &c->sqrt_tab, &c->cnt};
     for (Buf* b : all) if (b->p) (void)hipFree(b->p);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+    for (auto& e : c->ev_aux) if (e) (void)hipEventDestroy(e);
+    if (c->ev_init) (void)hipEventDestroy(c->ev_init);
+    if (c->ev_sel) (void)hipEventDestroy(c->ev_sel);
+    for (auto& s2 : c->side) if (s2) { (void)hipStreamSynchronize(s2); (void)hipStreamDestroy(s2); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -228,6 +238,7 @@ int csv_batch_upload(csv_ctx* c, const csv_batch_in* in)
     RES(o_dr, cap_tmp * 4); RES(o_dv, cap_tmp * 4); RES(o_gl, cap_tmp * 4); RES(o_supoff, (cap_tmp + 1) * 8);
     RES(o_supsig, (W + 1) * 8); RES(o_suprid, (W + 1) * 4);
     if (R > 0) {
+        RES(pm_partial, (div_up(R, PM_TILE) + 2) * 8);
         RES(reads_off, (in->n_chrom + 1) * 8); RES(r_start, R * 8); RES(r_end, R * 8); RES(r_primary, R); RES(r_id, R * 4); RES(r_pmax, R * 8);
     }
 
@@ -275,7 +286,7 @@ int csv_batch_upload(csv_ctx* c, const csv_batch_in* in)
     B.o_search = dp<i64>(c->o_search); B.o_pick = dp<i64>(c->o_pick); B.o_dr = dp<int>(c->o_dr); B.o_dv = dp<int>(c->o_dv); B.o_gl = dp<int>(c->o_gl);
     B.o_supoff = dp<i64>(c->o_supoff); B.o_supsig = dp<i64>(c->o_supsig); B.o_suprid = dp<int>(c->o_suprid); B.allele_id = dp<int>(c->allele_id);
     B.reads_off = dp<i64>(c->reads_off); B.n_reads = R;
-    B.r_start = dp<i64>(c->r_start); B.r_end = dp<i64>(c->r_end); B.r_primary = dp<uint8_t>(c->r_primary); B.r_id = dp<int>(c->r_id); B.r_pmax = dp<i64>(c->r_pmax);
+    B.r_start = dp<i64>(c->r_start); B.r_end = dp<i64>(c->r_end); B.r_primary = dp<uint8_t>(c->r_primary); B.r_id = dp<int>(c->r_id); B.r_pmax = dp<i64>(c->r_pmax); B.pm_partial = dp<i64>(c->pm_partial);
     B.sqrt_tab = dp<double>(c->sqrt_tab); B.cnt = dp<DevCounters>(c->cnt);
     c->n_sig_host = in->n_sig;
     c->uploaded = true;
@@ -311,15 +322,32 @@ int csv_batch_run(csv_ctx* c, csv_run_stats* stats)
     HIP_TRY(c, mark());
     if (W == 0) HIP_TRY(c, hipMemsetAsync(c->cnt.p, 0, sizeof(DevCounters), st));      // otherwise k_chain_count zeroes them
     HIP_TRY(c, mark());                                                              // slot 0: init (empty batch only)
-#define LAUNCH(name, kern, grid, block, lds, ...)                                      \
+    // Plain runs fork the independent kernels onto side streams (joined again before k_items_scan /
+    // k_genotype); instrumented runs (stats != NULL) and CSV_DEBUG keep everything on the main stream so
+    // that every kernel is timed alone.
+    // (forking costs a few event waits: only worth it when the batch has pair types or genotyping)
+    const bool fork = !stats && !dbg && !getenv("CSV_NO_FORK") && (c->any_pair || (c->any_genotype && B.n_reads > 0));
+    hipStream_t sB = fork ? c->side[0] : st, sC = fork ? c->side[1] : st, sD = fork ? c->side[2] : st;
+#define LAUNCH_ON(strm, name, kern, grid, block, lds, ...)                             \
     do {                                                                               \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, st, __VA_ARGS__);        \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, strm, __VA_ARGS__);      \
         DBG(name);                                                                     \
         HIP_TRY(c, mark());                                                            \
     } while (0)
+#define LAUNCH(name, kern, grid, block, lds, ...) LAUNCH_ON(st, name, kern, grid, block, lds, __VA_ARGS__)
     if (W > 0) {
         const int nb = div_up(W, CH_TILE);
+        const bool do_gt = c->any_genotype && B.n_reads > 0;
+        const int nr = do_gt ? div_up(B.n_reads, PM_TILE) : 0;
         LAUNCH("chain_count", k_chain_count, nb, 256, 0, B);
+        if (fork && do_gt) {                              // reads prefix max: independent of the clustering kernels
+            HIP_TRY(c, hipEventRecord(c->ev_init, st));   // (after the counters were zeroed)
+            HIP_TRY(c, hipStreamWaitEvent(sD, c->ev_init, 0));
+            LAUNCH_ON(sD, "pmax_count", k_pmax_count, nr, 256, 0, B);
+            LAUNCH_ON(sD, "pmax_scan", k_pmax_scan, 1, 256, 0, B.pm_partial, nr);
+            LAUNCH_ON(sD, "pmax_apply", k_pmax_apply, nr, 256, 0, B);
+            HIP_TRY(c, hipEventRecord(c->ev_aux[2], sD));
+        }
         LAUNCH("chain_apply", k_chain_apply, nb, 256, 0, B);
         const int ns = div_up(W, SEL_TILE);
         LAUNCH("select_count", k_select_count, ns, 256, 0, B);
@@ -329,26 +357,39 @@ int csv_batch_run(csv_ctx* c, csv_run_stats* stats)
         int g_iw = div_up(B.cap_items, 4) < 2048 ? div_up(B.cap_items, 4) : 2048;
         if (getenv("CSV_IW_GRID")) g_iw = atoi(getenv("CSV_IW_GRID"));       // tuning aid
         if (g_iw < 1) g_iw = 1;
+        if (fork) {
+            HIP_TRY(c, hipEventRecord(c->ev_sel, st));
+            HIP_TRY(c, hipStreamWaitEvent(sB, c->ev_sel, 0));
+            if (c->any_pair) HIP_TRY(c, hipStreamWaitEvent(sC, c->ev_sel, 0));
+        }
         LAUNCH("refine_indel_wave", k_refine_indel_wave, g_iw, 256, 0, B);
-        if (c->any_pair) LAUNCH("refine_wave", (k_refine<64, 64>), g_small, 64, LDS_SMALL, B, 0, 0, 64);
+        if (c->any_pair) LAUNCH_ON(sC, "refine_wave", (k_refine<64, 64>), g_small, 64, LDS_SMALL, B, 0, 0, 64);
         else HIP_TRY(c, mark());
         int g_mid = B.cap_items < 4096 ? B.cap_items : 4096;
         if (g_mid < 1) g_mid = 1;
-        LAUNCH("refine_mid", (k_refine<64, 256>), g_mid, 64, LDS_MID, B, 1, 64, 256);
+        LAUNCH_ON(sB, "refine_mid", (k_refine<64, 256>), g_mid, 64, LDS_MID, B, 1, 64, 256);
         int g_big = B.cap_items < 512 ? B.cap_items : 512;
         if (g_big < 1) g_big = 1;
-        LAUNCH("refine_block", (k_refine<256, 2048>), g_big, 256, LDS_BIG, B, 1, 256, 0x7fffffff);
+        LAUNCH_ON(sB, "refine_block", (k_refine<256, 2048>), g_big, 256, LDS_BIG, B, 1, 256, 0x7fffffff);
+        if (fork) {                                       // join
+            HIP_TRY(c, hipEventRecord(c->ev_aux[0], sB));
+            HIP_TRY(c, hipStreamWaitEvent(st, c->ev_aux[0], 0));
+            if (c->any_pair) { HIP_TRY(c, hipEventRecord(c->ev_aux[1], sC)); HIP_TRY(c, hipStreamWaitEvent(st, c->ev_aux[1], 0)); }
+        }
         LAUNCH("items_scan", k_items_scan, 1, 512, 0, B);
         LAUNCH("emit", k_emit, 2048, 256, 0, B);
-        if (c->any_genotype && B.n_reads > 0) {
-            const int nr = div_up(B.n_reads, PM_TILE);
-            LAUNCH("pmax_count", k_pmax_count, nr, 256, 0, B);
-            LAUNCH("pmax_scan", k_pmax_scan, 1, 256, 0, B.partial64, nr);
-            LAUNCH("pmax_apply", k_pmax_apply, nr, 256, 0, B);
+        if (do_gt) {
+            if (fork) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_aux[2], 0));
+            else {
+                LAUNCH("pmax_count", k_pmax_count, nr, 256, 0, B);
+                LAUNCH("pmax_scan", k_pmax_scan, 1, 256, 0, B.pm_partial, nr);
+                LAUNCH("pmax_apply", k_pmax_apply, nr, 256, 0, B);
+            }
             LAUNCH("genotype", k_genotype, 1024, 256, 0, B);
         }
     }
 #undef LAUNCH
+#undef LAUNCH_ON
     HIP_TRY(c, hipGetLastError());
     c->ran = true;
     if (stats) {

@@ -92,6 +92,7 @@ struct DevBatch {
     i64            n_reads;
     const i64*     r_start; const i64* r_end; const uint8_t* r_primary; const int* r_id;
     i64*           r_pmax;
+    i64*           pm_partial;       // tile maxima of the reads scan
     const double*  sqrt_tab;
     DevCounters*   cnt;
 };
@@ -1425,13 +1426,15 @@ __device__ __forceinline__ int chrom_of_read(const DevBatch& B, i64 i, int hint)
     return lo;
 }
 
-__device__ __forceinline__ i64 pm_value(const DevBatch& B, i64 i, int& hint)
+template <bool CHECK> __device__ __forceinline__ i64 pm_value(const DevBatch& B, i64 i, int& hint)
 {
     if (i >= B.n_reads) return INT64_MIN;
     hint = chrom_of_read(B, i, hint);
     const i64 e = B.r_end[i];
-    if (e < 0 || e > PM_MASK) atomicOr(&B.cnt->error, ERR_KEY_RANGE);
-    if (i > B.reads_off[hint] && B.r_start[i] < B.r_start[i - 1]) atomicOr(&B.cnt->error, ERR_READS_UNSORTED);
+    if (CHECK) {                                       // input validation happens once, in the counting pass
+        if (e < 0 || e > PM_MASK) atomicOr(&B.cnt->error, ERR_KEY_RANGE);
+        if (i > B.reads_off[hint] && B.r_start[i] < B.r_start[i - 1]) atomicOr(&B.cnt->error, ERR_READS_UNSORTED);
+    }
     return ((i64)hint << PM_SHIFT) | e;
 }
 
@@ -1441,14 +1444,14 @@ __global__ __launch_bounds__(256) void k_pmax_count(DevBatch B)
     i64 mx = INT64_MIN;
     int hint = 0;
     for (int r = 0; r < 8; r++) {
-        const i64 v = pm_value(B, base + r * 64 + lane_id(), hint);
+        const i64 v = pm_value<true>(B, base + r * 64 + lane_id(), hint);
         if (v > mx) mx = v;
     }
     for (int m = 32; m > 0; m >>= 1) { const i64 o = shfl_xor_i64(mx, m); if (o > mx) mx = o; }
     __shared__ i64 s[4];
     if (lane_id() == 0) s[threadIdx.x >> 6] = mx;
     __syncthreads();
-    if (threadIdx.x == 0) { i64 t = s[0]; for (int k = 1; k < 4; k++) if (s[k] > t) t = s[k]; B.partial64[blockIdx.x] = t; }
+    if (threadIdx.x == 0) { i64 t = s[0]; for (int k = 1; k < 4; k++) if (s[k] > t) t = s[k]; B.pm_partial[blockIdx.x] = t; }
 }
 
 // exclusive max-scan of the tile maxima (single workgroup)
@@ -1484,7 +1487,7 @@ __global__ __launch_bounds__(256) void k_pmax_apply(DevBatch B)
     i64 run = INT64_MIN;
     int hint = 0;
     for (int r = 0; r < 8; r++) {
-        const i64 v = pm_value(B, base + r * 64 + lane_id(), hint);
+        const i64 v = pm_value<false>(B, base + r * 64 + lane_id(), hint);
         i64 inc = wave_incl_max_i64(v);
         if (run > inc) inc = run;
         vals[r] = inc;
@@ -1493,7 +1496,7 @@ __global__ __launch_bounds__(256) void k_pmax_apply(DevBatch B)
     __shared__ i64 s[4];
     if (lane_id() == 0) s[wv] = run;
     __syncthreads();
-    i64 pre = B.partial64[blockIdx.x];
+    i64 pre = B.pm_partial[blockIdx.x];
     for (int k = 0; k < wv; k++) if (s[k] > pre) pre = s[k];
     for (int r = 0; r < 8; r++) {
         const i64 i = base + r * 64 + lane_id();
