@@ -3,7 +3,8 @@
 // Pipeline of one csv_batch_run (all on one stream, no host round trip in between):
 //   chain     k_chain_count / k_chain_apply                        flags + scan -> cluster ids, cluster starts
 //   select    k_select_count / k_select_apply                      size gate -> ordered work list (two tiers)
-//   refine    k_refine_indel_wave one wavefront per DEL/INS cluster (m <= 64), registers + cross-lane ops only
+//   refine    k_refine_indel_sub<32> two DEL/INS clusters of m <= 32 per wavefront, <64> one of 32 < m <= 64;
+//                                 registers + cross-lane ops only
 //             k_refine<64,64>    one wavefront per DUP/INV/TRA cluster (m <= 64), arrays in LDS
 //             k_refine<256,2048> one workgroup per cluster; LDS up to 2048 padded elements, global scratch above
 //   order     k_emit                                               per-item counts -> dense, ordered outputs
@@ -1001,10 +1002,14 @@ template <int BLOCK, int CAP> __global__ __launch_bounds__(BLOCK) void k_refine(
     }
 }
 
-// ------------------------------------------------------------------------------------ refine: INDEL wavefront tier
-// One wavefront per cluster of m <= 64 DEL/INS signatures, everything in registers: lane i holds
-// signature i, cross-lane traffic is v_readlane (uniform index), ds_permute / ds_bpermute and DPP
-// shuffles; no LDS arrays, no barriers.  Same semantics as refine_indel above (INDEL:110-219, 319-432).
+// ------------------------------------------------------------------------------------ refine: INDEL wavefront tiers
+// DEL/INS clusters of m <= 64 signatures, everything in registers: one signature per lane, cross-lane traffic
+// is v_readlane (uniform index), ds_permute / ds_bpermute and DPP; no LDS arrays, no barriers.  Same semantics
+// as refine_indel above (INDEL:110-219, 319-432).  The kernel is written for a "sub-wave" of SW lanes:
+//   SW = 32: TWO clusters of m <= 32 per wavefront (lanes 0-31 and 32-63) — the common case, halves the
+//            instruction count per cluster;  SW = 64: one cluster of 32 < m <= 64 per wavefront.
+// Scalars of a cluster (segment flags, sizes) are per-lane values that are uniform inside a sub-wave; every
+// cross-lane operation is executed by all 64 lanes in wave-uniform control flow.
 __device__ __forceinline__ i64 readlane_i64(i64 v, int l)
 {
     const int lo = __builtin_amdgcn_readlane((int)(v & 0xffffffffll), l);
@@ -1018,12 +1023,53 @@ __device__ __forceinline__ i64 permute_i64(int dest_lane, i64 v)      // lane i 
     const int hi = __builtin_amdgcn_ds_permute(dest_lane << 2, (int)(v >> 32));
     return ((i64)hi << 32) | (unsigned)lo;
 }
+// value of sub-lane t of the caller's own sub-wave (t wave-uniform)
+template <int SW> __device__ __forceinline__ int sub_rl(int x, int t, bool hi)
+{
+    if (SW == 64) return __builtin_amdgcn_readlane(x, t);
+    const int lo = __builtin_amdgcn_readlane(x, t), up = __builtin_amdgcn_readlane(x, 32 + t);
+    return hi ? up : lo;
+}
+template <int SW> __device__ __forceinline__ i64 sub_rl64(i64 x, int t, bool hi)
+{
+    if (SW == 64) return readlane_i64(x, t);
+    const i64 lo = readlane_i64(x, t), up = readlane_i64(x, 32 + t);
+    return hi ? up : lo;
+}
+// ballot restricted to the caller's sub-wave, in sub-lane bit positions
+template <int SW> __device__ __forceinline__ u64 sub_ballot(bool p, bool hi)
+{
+    const u64 m = __ballot(p);
+    if (SW == 64) return m;
+    return hi ? (m >> 32) : (m & 0xffffffffull);
+}
+// inclusive scans inside a sub-wave: for 32 lanes the DPP network simply stops before row_bcast:31
+template <int SW> __device__ __forceinline__ i64 sub_scan_i64(i64 v)
+{
+    v += dpp_i64<0x111, 0xf>(0, v);
+    v += dpp_i64<0x112, 0xf>(0, v);
+    v += dpp_i64<0x114, 0xf>(0, v);
+    v += dpp_i64<0x118, 0xf>(0, v);
+    v += dpp_i64<0x142, 0xa>(0, v);
+    if (SW == 64) v += dpp_i64<0x143, 0xc>(0, v);
+    return v;
+}
+template <int SW> __device__ __forceinline__ int sub_scan_i32(int v)
+{
+    v += dpp_i32<0x111, 0xf>(0, v);
+    v += dpp_i32<0x112, 0xf>(0, v);
+    v += dpp_i32<0x114, 0xf>(0, v);
+    v += dpp_i32<0x118, 0xf>(0, v);
+    v += dpp_i32<0x142, 0xa>(0, v);
+    if (SW == 64) v += dpp_i32<0x143, 0xc>(0, v);
+    return v;
+}
 
-// numpy's pairwise sum of sq over the allele [r0, r0 + n), n <= 64, valid on the lane with i == 0
-// (i = lane - r0).  8 strided accumulators on lanes i < 8, the fixed combine tree, then the tail.
+// numpy's pairwise sum of sq over the allele [r0, r0 + n) (absolute lanes), n <= 64, valid on the lane with
+// i == 0 (i = lane - r0).  8 strided accumulators on lanes i < 8, the fixed combine tree, then the tail.
+// rows / tail are wave-uniform upper bounds of n / 8 and of the sequential tail length.
 __device__ __forceinline__ double np_sum_allele(double sq, int r0, int n, int i, int rows, int tail)
 {
-    // rows = max over the cluster's alleles of (n / 8), tail = max of the sequential tail length: both wave-uniform
     const int lane = lane_id();
     const int nfull = n - (n & 7);
     double acc = sq;
@@ -1046,195 +1092,240 @@ __device__ __forceinline__ double np_sum_allele(double sq, int r0, int n, int i,
 #ifndef CSV_IW_WAVES
 #define CSV_IW_WAVES 4
 #endif
-__global__ __launch_bounds__(256, CSV_IW_WAVES) void k_refine_indel_wave(DevBatch B)
+// one unit of work: SW = 32 -> the pair of items (2p, 2p + 1), each handled if m <= 32;
+//                   SW = 64 -> the single item p, handled if 32 < m <= 64.  Returns (SW = 32 only) a 2-bit mask
+//                   of pair members that are DEL/INS clusters of 32 < m <= 64 and still need the wide pass.
+template <int SW> __device__ __forceinline__ int indel_unit(const DevBatch& B, int p, int nsmall)
 {
-    const int nsmall = B.cnt->n_items - B.cnt->n_items_big;
-    const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * 256 + threadIdx.x) >> 6), nwaves = (gridDim.x * 256) >> 6;
-    const int lane = lane_id();
-    const u64 lt_mask = lanemask_lt(), le_mask = lt_mask | (1ull << lane);
-    // software pipeline: the columns of the NEXT item are requested before the current one is computed
-    int qn = wave;
-    int j_n = 0, k_n = 0, s_n = 0, m_n = 0, type_n = -1;
-    i64 a_n = 0, b_n = 0; int rid_n = 0, aux_n = 0;
-    auto fetch = [&]() {
-        type_n = -1;
-        if (qn < nsmall) {
-            j_n = B.list_small[qn];
-            const int4 rec = B.item_rec[j_n];
-            k_n = rec.y; s_n = rec.z; m_n = rec.w;
-            type_n = B.seg[k_n].svtype;
-            if (type_n == CSV_DEL || type_n == CSV_INS) {
-                const bool in = lane < m_n;
-                a_n = in ? B.a[s_n + lane] : 0;
-                b_n = in ? B.b[s_n + lane] : 0;
-                rid_n = in ? B.rid[s_n + lane] : -1 - lane;
-                aux_n = (in && type_n == CSV_INS) ? B.aux[s_n + lane] : 0;
-            }
+    constexpr bool HALF = SW == 32;
+    constexpr int MLO = HALF ? 0 : 32;
+    constexpr u64 SUBMASK = HALF ? 0xffffffffull : ~0ull;
+    const int lane = lane_id(), sl = lane & (SW - 1), hb = lane & ~(SW - 1);
+    const bool hi = HALF && lane >= 32;
+    const u64 sl_lt = (1ull << sl) - 1ull, sl_le = sl_lt | (1ull << sl);        // masks in sub-lane positions
+    int wide = 0;
+    do {
+        const int q = HALF ? 2 * p + (hi ? 1 : 0) : p;
+        int j = 0, k = 0, s = 0, m = 0, type = -1;
+        if (q < nsmall) {
+            j = B.list_small[q];
+            const int4 rec = B.item_rec[j];
+            k = rec.y; s = rec.z; m = rec.w;
+            type = B.seg[k].svtype;
         }
-    };
-    fetch();
-    for (; qn < nsmall; ) {
-        const int j = j_n, k = k_n, s = s_n, m = m_n, type = type_n;
-        const i64 a = a_n, b = b_n; const int rid = rid_n, aux = aux_n;
-        qn += nwaves;
-        fetch();
-        if (type != CSV_DEL && type != CSV_INS) continue;          // other types: k_refine<64,64>
-        const csv_segment& sg = B.seg[k];
-        const bool in = lane < m;
+        // other types go to k_refine<64,64>, the other size class to the other instantiation
+        const bool indel = type == CSV_DEL || type == CSV_INS;
+        const bool act = indel && m > MLO && m <= SW;
+        if (HALF) {
+            const u64 wm = __ballot(indel && m > 32 && sl == 0);
+            wide = (int)(wm & 1) | (int)((wm >> 32) & 1) << 1;
+        }
+        if (!__ballot(act)) break;
+        int rc = 0x7fffffff, msr = 0;
+        double ratio = 0.0, rr = 1.0;
+        i64 gsig0 = 0;
+        if (act) {
+            const csv_segment& sg = B.seg[k];
+            rc = sg.read_count; msr = sg.min_support_reads; ratio = sg.diff_ratio;
+            rr = sg.remain_reads_ratio; if (rr > 1) rr = 1;                       // INDEL:46-47
+            gsig0 = sg.sig_begin + ((i64)s - B.woff[k]);
+        }
+        const bool in = act && sl < m;
+        const i64 a = in ? B.a[s + sl] : 0;
+        const i64 b = in ? B.b[s + sl] : 0;
+        const int rid = in ? B.rid[s + sl] : -1 - lane;
+        const int aux = (in && type == CSV_INS) ? B.aux[s + sl] : 0;
         if (in && ((u64)b >> (63 - IDX_BITS))) atomicOr(&B.cnt->error, ERR_KEY_RANGE);
+        const int mact = act ? m : 0;
+        const int mmax = HALF ? max(__builtin_amdgcn_readlane(mact, 0), __builtin_amdgcn_readlane(mact, 32))
+                              : __builtin_amdgcn_readfirstlane(mact);
 
         // ---- per-read de-duplication (INDEL:125-131): first appearance F, kept signature = strictly longest
-        int F = lane, ch = lane;
+        int F = sl, ch = sl;
         i64 bl = b;
-        // does any read own two signatures of this cluster?  Rotate the ids around the wavefront (DPP
-        // wave_ror:1, no SGPR round trip): after k steps lane i sees the id of lane i - k.
+        // which lanes hold my read id?  One ballot per id bit, AND of the agreeing sides: the whole wavefront
+        // (both sub-waves) in ~6 instructions per bit, independent of m.
         bool dup_any = false;
         {
-            int rot = rid;
-            for (int t = 1; t < m; t++) {
-                rot = __builtin_amdgcn_update_dpp(rot, rot, 0x13C, 0xf, 0xf, false);      // wave_ror:1
-                dup_any |= (rot == rid);
+            const u64 inmask = __ballot(in);
+            int orv = in ? rid : 0;
+            orv |= dpp_i32<0x111, 0xf>(0, orv); orv |= dpp_i32<0x112, 0xf>(0, orv); orv |= dpp_i32<0x114, 0xf>(0, orv);
+            orv |= dpp_i32<0x118, 0xf>(0, orv); orv |= dpp_i32<0x142, 0xa>(0, orv); orv |= dpp_i32<0x143, 0xc>(0, orv);
+            const int nbits = 32 - __builtin_clz((unsigned)__builtin_amdgcn_readlane(orv, 63) | 1u);
+            u64 match = inmask;
+            for (int bit = 0; bit < nbits; bit++) {
+                const bool set = (rid >> bit) & 1;
+                const u64 mk = __ballot(set);
+                match &= set ? mk : ~mk;
             }
+            const u64 mine = HALF ? (hi ? 0xffffffff00000000ull : 0x00000000ffffffffull) : ~0ull;
+            dup_any = in && __popcll(match & mine) > 1;
         }
         if (__ballot(dup_any)) {
             F = -1; ch = -1; bl = INT64_MIN;
-            for (int t = 0; t < m; t++) {
-                const int rt = __builtin_amdgcn_readlane(rid, t);
-                const i64 bt = readlane_i64(b, t);
+            for (int t = 0; t < mmax; t++) {
+                const int rt = sub_rl<SW>(rid, t, hi);
+                const i64 bt = sub_rl64<SW>(b, t, hi);
                 if (rt == rid) {
                     if (F < 0) F = t;
                     if (bt > bl) { bl = bt; ch = t; }
                 }
             }
         }
-        const bool rep = in && (F == lane);
-        const u64 repmask = __ballot(rep);
-        const int U = __popcll(repmask);
-        if (U < sg.read_count) {                                     // INDEL:133-134
-            if (lane == 0) item_done(B, j, 0, 0, 0);
-            continue;
-        }
-        const i64 pa = shfl_i64(a, ch & 63);
-        const int pax = __shfl(aux, ch & 63);
+        const bool rep = in && (F == sl);
+        const u64 rm = sub_ballot<SW>(rep, hi);
+        const int U = __popcll(rm);
+        const bool ok = act && U >= rc;                                          // INDEL:133-134
+        if (act && !ok && sl == 0) item_done(B, j, 0, 0, 0);
+        if (!__ballot(ok)) break;
+        const i64 pa = shfl_i64(a, hb | (ch & (SW - 1)));
+        const int pax = __shfl(aux, hb | (ch & (SW - 1)));
 
         // ---- stable sort of the kept signatures by length (INDEL:136): rank by (len, first appearance)
         int rank = 0;
-        for (u64 mk = repmask; mk; mk &= mk - 1) {
-            const int t = __ffsll((long long)mk) - 1;
-            const i64 lt = readlane_i64(bl, t);
-            rank += (lt < bl) || (lt == bl && t < lane);
+        if (HALF) {
+            if (!__ballot(rep && (bl >> 31) != 0)) {                 // every kept length fits 31 bits: one word per step
+                const int bl32 = rep ? (int)bl : 0x7fffffff;       // non-kept lanes never count as smaller
+                for (int t = 0; t < mmax; t++) {
+                    const int lt = sub_rl<SW>(bl32, t, hi);
+                    rank += (lt < bl32) || (lt == bl32 && t < sl);
+                }
+            } else {
+                for (int t = 0; t < mmax; t++) {
+                    const i64 lt = sub_rl64<SW>(bl, t, hi);
+                    rank += ((rm >> t) & 1) && ((lt < bl) || (lt == bl && t < sl));
+                }
+            }
+        } else {
+            for (u64 mk = __ballot(rep); mk; mk &= mk - 1) {
+                const int t = __ffsll((long long)mk) - 1;
+                const i64 lt = readlane_i64(bl, t);
+                rank += (lt < bl) || (lt == bl && t < sl);
+            }
         }
-        const int dest = rep ? rank : U + __popcll(~repmask & lt_mask);
+        const int dest = hb | (rep ? rank : U + __popcll(~rm & sl_lt & SUBMASK));
         const i64 pos = permute_i64(dest, pa);
         const i64 len = permute_i64(dest, bl);
         const int chp = __builtin_amdgcn_ds_permute(dest << 2, ch);
         const int axp = __builtin_amdgcn_ds_permute(dest << 2, pax);
-        const int r = lane;
-        const bool live = r < U;
+        const int r = sl;
+        const bool live = ok && r < U;
+        const int last = hb | (SW - 1);
 
         // ---- allele split on consecutive length gaps (INDEL:138, 153-162)
-        const i64 lsum = wave_sum_i64(live ? len : 0);
-        const double thr = sg.diff_ratio * ((double)lsum / (double)U);
+        const i64 lsum = shfl_i64(sub_scan_i64<SW>(live ? len : 0), last);
+        const double thr = ratio * ((double)lsum / (double)U);
         const i64 lprev = wave_shr1_i64(len);
         const bool f = live && r > 0 && ((double)(len - lprev) > thr);
-        const u64 S = __ballot(f) | 1ull;                             // allele start ranks
-        const u64 below = S & le_mask, above = S & ~le_mask;
+        const u64 fmask = __ballot(f);
+        const u64 S = (HALF ? (hi ? (fmask >> 32) : (fmask & 0xffffffffull)) : fmask) | 1ull;    // allele start ranks
+        const u64 below = S & sl_le, above = S & ~sl_le & SUBMASK;
         const int r0 = 63 - __clzll((long long)below);
         int r1 = above ? (__ffsll((long long)above) - 1) : U;
         if (r1 > U) r1 = U;
         const int n = live ? r1 - r0 : 1, i = r - r0;
 
-        const i64 Ppos = wave_incl_scan_i64(live ? pos : 0), Plen = wave_incl_scan_i64(live ? len : 0);
-        const int e1 = (r1 - 1) & 63, e0 = (r0 - 1) & 63;
+        const i64 Ppos = sub_scan_i64<SW>(live ? pos : 0), Plen = sub_scan_i64<SW>(live ? len : 0);
+        const int e1 = hb | ((r1 - 1) & (SW - 1)), e0 = hb | ((r0 - 1) & (SW - 1));
         // NB: every cross-lane op sits in wave-uniform control flow; only the selects are per lane
         const i64 pp0 = shfl_i64(Ppos, e0), pl0 = shfl_i64(Plen, e0);
         const i64 sp = shfl_i64(Ppos, e1) - (r0 > 0 ? pp0 : 0);
-        const i64 sl = shfl_i64(Plen, e1) - (r0 > 0 ? pl0 : 0);
+        const i64 sln = shfl_i64(Plen, e1) - (r0 > 0 ? pl0 : 0);
 
         // ---- emission order: stable ascending by support among alleles with n >= minimum_support_reads (INDEL:163-166)
-        const int msr = sg.min_support_reads;
         const bool pass = live && n >= msr;
         int erank = 0, soff = 0, npass = 0;
-        for (u64 mk = S; mk; mk &= mk - 1) {
+        const u64 starts = HALF ? (fmask | 1ull | (1ull << 32)) : S;             // allele starts of every sub-wave, absolute lanes
+        for (u64 mk = starts; mk; mk &= mk - 1) {
             const int t = __ffsll((long long)mk) - 1;
             const int nt = __builtin_amdgcn_readlane(n, t);
-            if (nt >= msr) {
+            const int tl = t & (SW - 1);
+            if ((t & ~(SW - 1)) == hb && nt >= msr) {
                 npass++;
-                if (nt < n || (nt == n && t < r0)) { erank++; soff += nt; }
+                if (nt < n || (nt == n && tl < r0)) { erank++; soff += nt; }
             }
         }
-        const int tbase = s;
 
         // ---- statistics, all alleles at once
-        double rr = sg.remain_reads_ratio; if (rr > 1) rr = 1;       // INDEL:46-47
-        int keep = (int)(rr * (double)n); if (keep < 1) keep = 1;     // INDEL:169
-        const double pmean = (double)sp / (double)n, lmean = (double)sl / (double)n;
+        int keep = (int)(rr * (double)n); if (keep < 1) keep = 1;                 // INDEL:169
+        const double pmean = (double)sp / (double)n, lmean = (double)sln / (double)n;
         const double dp = fabs((double)pos - pmean), dl = fabs((double)len - lmean);
         double bp = pmean, siglen = lmean;
         i64 search;
         if (!__ballot(pass && keep < n)) {
             // every member kept: search_threshold = first member with the smallest |pos - mean| (INDEL:171-177)
             double bd = dp; int bi = r;
-            for (int d = 1; d < 64; d <<= 1) {
+            for (int d = 1; d < SW; d <<= 1) {
                 const double od = shfl_f64(bd, (lane - d) & 63); const int oi = __shfl(bi, (lane - d) & 63);
                 if (r - d >= r0 && (od < bd || (od == bd && oi < bi))) { bd = od; bi = oi; }
             }
-            search = shfl_i64(pos, __shfl(bi, e1) & 63);
+            search = shfl_i64(pos, hb | (__shfl(bi, e1) & (SW - 1)));
         } else {
             // keep the `keep` members closest to the mean, ties in allele order (INDEL:171-176, 182-187)
             int rp = 0, rl = 0;
-            for (int t = 0; t < U; t++) {
-                const int r0t = __builtin_amdgcn_readlane(r0, t);
-                const double tp = __longlong_as_double(readlane_i64(__double_as_longlong(dp), t));
-                const double tl = __longlong_as_double(readlane_i64(__double_as_longlong(dl), t));
-                if (r0t == r0) {
+            for (int t = 0; t < mmax; t++) {
+                const int r0t = sub_rl<SW>(r0, t, hi);
+                const double tp = __longlong_as_double(sub_rl64<SW>(__double_as_longlong(dp), t, hi));
+                const double tl = __longlong_as_double(sub_rl64<SW>(__double_as_longlong(dl), t, hi));
+                if (t < U && r0t == r0) {
                     rp += (tp < dp) || (tp == dp && t < r);
                     rl += (tl < dl) || (tl == dl && t < r);
                 }
             }
-            const i64 Kp = wave_incl_scan_i64((live && rp < keep) ? pos : 0), Kl = wave_incl_scan_i64((live && rl < keep) ? len : 0);
-            const i64 Ks = wave_incl_scan_i64((live && rp == 0) ? pos : 0);
+            const i64 Kp = sub_scan_i64<SW>((live && rp < keep) ? pos : 0), Kl = sub_scan_i64<SW>((live && rl < keep) ? len : 0);
+            const i64 Ks = sub_scan_i64<SW>((live && rp == 0) ? pos : 0);
             const i64 kp0 = shfl_i64(Kp, e0), kl0 = shfl_i64(Kl, e0), ks0 = shfl_i64(Ks, e0);
             const i64 ks = shfl_i64(Kp, e1) - (r0 > 0 ? kp0 : 0);
             const i64 kl = shfl_i64(Kl, e1) - (r0 > 0 ? kl0 : 0);
             search = shfl_i64(Ks, e1) - (r0 > 0 ? ks0 : 0);
-            bp = (double)ks / (double)keep; siglen = (double)kl / (double)keep;
+            bp = (double)ks / (double)keep; siglen = (double)kl / (double)keep;   // INDEL:176-177, 187
         }
-        int rows_l = pass ? (n >> 3) : 0, tail_l = pass ? (n >= 8 ? (n & 7) : n) : 0;
-        for (int msk = 32; msk > 0; msk >>= 1) {
-            const int orow = __shfl_xor(rows_l, msk), otl = __shfl_xor(tail_l, msk);
-            rows_l = orow > rows_l ? orow : rows_l; tail_l = otl > tail_l ? otl : tail_l;
-        }
-        const int rows_u = __builtin_amdgcn_readfirstlane(rows_l), tail_u = __builtin_amdgcn_readfirstlane(tail_l);
-        const double vsp = np_sum_allele((double)((double)pos - pmean) * ((double)pos - pmean), r0, n, i, rows_u, tail_u);
-        const double vsl = np_sum_allele((double)((double)len - lmean) * ((double)len - lmean), r0, n, i, rows_u, tail_u);
+        const int rows_u = (mmax >> 3) + 1, tail_u = mmax < 7 ? mmax : 7;         // wave-uniform bounds (allele size <= m)
+        const int r0a = hb | r0;
+        const double vsp = np_sum_allele(((double)pos - pmean) * ((double)pos - pmean), r0a, n, i, rows_u, tail_u);
+        const double vsl = np_sum_allele(((double)len - lmean) * ((double)len - lmean), r0a, n, i, rows_u, tail_u);
         const double rt = B.sqrt_tab[n & (SQRT_TAB - 1)];
-        const int cip = (int)(1.96 * sqrt(vsp / (double)n) / rt);     // INDEL:191, GT:58-60
-        const int cil = (int)(1.96 * sqrt(vsl / (double)n) / rt);     // INDEL:194
+        const int cip = (int)(1.96 * sqrt(vsp / (double)n) / rt);                 // INDEL:191, GT:58-60
+        const int cil = (int)(1.96 * sqrt(vsl / (double)n) / rt);                 // INDEL:194
 
+        // ---- INS: first member (allele order) whose sequence is long enough gives POS and ALT (INDEL:398-405)
+        const i64 want = (i64)siglen;
+        const u64 okm = sub_ballot<SW>(live && type == CSV_INS && (i64)axp >= want, hi);
+        const u64 range = ((n >= 64) ? ~0ull : ((1ull << n) - 1ull)) << r0;
+        const u64 mm = okm & range;
+        const int pr = mm ? (__ffsll((long long)mm) - 1) : r0;
+        const int pick_ch = __shfl(chp, hb | pr);
+        const i64 pick_pos = shfl_i64(pos, hb | pr);
         i64 pick = -1; bool valid = true;
-        if (type == CSV_INS) {                                        // INDEL:398-405
-            const i64 want = (i64)siglen;
-            const u64 okm = __ballot(live && (i64)axp >= want);
-            const u64 range = ((n >= 64) ? ~0ull : ((1ull << n) - 1ull)) << r0;
-            const u64 mm = okm & range;
+        if (type == CSV_INS) {
             valid = mm != 0;
-            const int pr = valid ? (__ffsll((long long)mm) - 1) : r0;
-            pick = B.seg[k].sig_begin + ((i64)s - B.woff[k]) + __shfl(chp, pr);
-            bp = (double)shfl_i64(pos, pr);
-            search = (i64)bp;                                         // INDEL:415
+            pick = gsig0 + pick_ch;
+            bp = (double)pick_pos;
+            search = (i64)bp;                                                     // INDEL:415
         }
-        if (pass) B.sup_tmp[s + soff + i] = s + chp;                  // INDEL:205, 416
+        if (pass) B.sup_tmp[s + soff + i] = s + chp;                              // INDEL:205, 416
         const bool head = pass && i == 0;
         if (head) {
-            const int t = tbase + erank;
+            const int t = s + erank;
             B.t_bp1[t] = (i64)bp; B.t_bp2[t] = (i64)siglen; B.t_support[t] = n;
             B.t_cipos[t] = cip; B.t_cilen[t] = cil; B.t_search[t] = search; B.t_pick[t] = valid ? pick : -1;
             B.t_supoff[t] = soff; B.t_valid[t] = valid ? 1 : 0;
         }
-        const int ncalls = __popcll(__ballot(head && valid));
-        const int nsup = wave_sum_i32((head && valid) ? n : 0);
-        if (lane == 0) item_done(B, j, npass, ncalls, nsup);
+        const int ncalls = __popcll(sub_ballot<SW>(head && valid, hi));
+        const int nsup = __shfl(sub_scan_i32<SW>((head && valid) ? n : 0), last);
+        if (ok && sl == 0) item_done(B, j, npass, ncalls, nsup);
+    } while (0);
+    return wide;
+}
+
+__global__ __launch_bounds__(256, CSV_IW_WAVES) void k_refine_indel_wave(DevBatch B)
+{
+    const int nsmall = B.cnt->n_items - B.cnt->n_items_big;
+    const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * 256 + threadIdx.x) >> 6), nwaves = (gridDim.x * 256) >> 6;
+    for (int p = wave; p < (nsmall + 1) / 2; p += nwaves) {
+        const int wide = __builtin_amdgcn_readfirstlane(indel_unit<32>(B, p, nsmall));
+        if (wide & 1) indel_unit<64>(B, 2 * p, nsmall);          // rare: a pair member with 32 < m <= 64
+        if (wide & 2) indel_unit<64>(B, 2 * p + 1, nsmall);
     }
 }
 
