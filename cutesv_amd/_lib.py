@@ -23,6 +23,7 @@ SYMBOLS = [
     ("csv_batch_download", C.c_int, [C.c_void_p, C.POINTER(_abi.BatchOut)]),
     ("csv_ctx_sync", C.c_int, [C.c_void_p]),
     ("csv_gl_index", C.c_int32, [C.c_int64, C.c_int64]),
+    ("csv_vcf_emit", C.c_int, None),           # prototype set in cutesv_amd/vcf.py (needs its struct)
 ]
 
 
@@ -41,7 +42,8 @@ def lib():
         for name, res, args in SYMBOLS:
             fn = getattr(L, name)          # AttributeError here == ABI mismatch, fail loudly
             fn.restype = res
-            fn.argtypes = args
+            if args is not None:
+                fn.argtypes = args
         if L.csv_abi_version() != _abi.ABI_VERSION:
             raise ExtensionMissing("libcutesv_hip.so ABI %d != python side %d" % (L.csv_abi_version(), _abi.ABI_VERSION))
         _LIB = L

@@ -359,3 +359,10 @@ def small_mixed(seed, n_sites=40, coverage=30, genotype=True, n_contigs=3, conti
         reads = (r_ch, r_s, r_e, prim, ids.astype(np.int64))
         nr += nR
     return _finish(contigs, per, nr, rng, reads=reads)
+
+
+def reference_sequence(length, seed=0):
+    """deterministic pseudo-reference for the VCF-emit tests: mostly ACGT with a sprinkle of IUPAC codes and N"""
+    rng = np.random.default_rng(seed)
+    alphabet = np.frombuffer(b"ACGT" * 12 + b"RYSWKMBDHVN", dtype=np.uint8)
+    return alphabet[rng.integers(0, len(alphabet), length)].tobytes().decode()

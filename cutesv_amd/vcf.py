@@ -1,0 +1,100 @@
+"""VCF record emit for the clustering stage's calls.
+
+`emit_records` hands the structure-of-arrays result straight to the native emitter (`csv_vcf_emit`,
+cutesv_amd/csrc/vcf_emit.cpp), which restates generate_output (cuteSV_genotype.py:242-467) and main_ctrl's
+SVID numbering (cuteSV main script :1208-1237) — no Python row lists in between.  Only the strings a call
+needs from Python-side objects are gathered here: the sliced INS sequence (cuteSV_resolveINDEL.py:402), the
+read names when --report_readid is on, and the genotype strings of the gl_idx values that occur.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+from ._lib import lib
+from .genotype import gl_fields
+
+
+class VcfIn(C.Structure):
+    _fields_ = [
+        ("res", C.POINTER(_abi.BatchOut)), ("seg", C.c_void_p), ("n_seg", C.c_int32), ("n_chrom", C.c_int32),
+        ("chrom_name", C.POINTER(C.c_char_p)), ("chrom_seq", C.POINTER(C.c_char_p)), ("chrom_len", C.c_void_p),
+        ("chrom_rank", C.c_void_p),
+        ("ins_alt", C.c_char_p), ("ins_alt_off", C.c_void_p), ("rnames", C.c_char_p), ("rnames_off", C.c_void_p),
+        ("strand_name", C.POINTER(C.c_char_p)),
+        ("gl_key", C.c_void_p), ("gl_str", C.POINTER(C.c_char_p)), ("n_gl", C.c_int32),
+        ("min_size", C.c_int64), ("max_size", C.c_int64),
+        ("genotype", C.c_int32), ("report_readid", C.c_int32), ("ignore_sequence", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+def _csr(strings):
+    blob = "".join(strings).encode()
+    off = np.zeros(len(strings) + 1, np.int64)
+    if strings:
+        off[1:] = np.cumsum([len(s) for s in strings])
+    return blob, off
+
+
+def emit_records(store, segments, res, reference, min_size=30, max_size=100000, genotype=False, report_readid=False,
+                 ignore_sequence=False, svid=None):
+    """calls of one batch -> (VCF body text, svid counters).
+
+    segments   the csv_segment records the batch was run with (HostBatch.segments)
+    res        _abi.HostResult of that batch
+    reference  {chromosome name: sequence (str or bytes)}; may miss chromosomes without calls
+    svid       running counters [INS, DEL, BND, DUP, INV] (main script :1209-1213), advanced in place
+    """
+    L = lib()
+    L.csv_vcf_emit.restype = C.c_int
+    L.csv_vcf_emit.argtypes = [C.POINTER(VcfIn), C.c_char_p, C.c_int64, C.POINTER(C.c_int64), C.c_void_p]
+    t = res.trimmed()
+    n = res.n_calls
+    segs = np.ascontiguousarray(segments, dtype=_abi.SEGMENT_DTYPE)
+    call_type = segs["svtype"][t["call_seg"]] if n else np.zeros(0, np.int32)
+    nch = len(store.chroms)
+    names = (C.c_char_p * nch)(*[c.encode() for c in store.chroms])
+    seq_bytes = [None if reference is None or c not in reference else
+                 (reference[c] if isinstance(reference[c], bytes) else reference[c].encode()) for c in store.chroms]
+    seqs = (C.c_char_p * nch)(*seq_bytes)
+    clen = np.array([0 if s is None else len(s) for s in seq_bytes], np.int64)
+    order = sorted(range(nch), key=lambda i: store.chroms[i])
+    rank = np.zeros(nch, np.int32)
+    rank[order] = np.arange(nch, dtype=np.int32)
+    # inserted sequences of INS calls, sliced to SVLEN
+    alt_blob, alt_off = None, None
+    if n and not ignore_sequence and (call_type == _abi.INS).any():
+        pick, ln = t["seq_pick"].tolist(), t["bp2"].tolist()
+        alt = [store.sequence(pick[c])[:ln[c]] if call_type[c] == _abi.INS else "" for c in range(n)]
+        alt_blob, alt_off = _csr(alt)
+    rn_blob, rn_off = None, None
+    if n and report_readid:
+        nm = store.names.take(store.read_id[t["support_sig"]])
+        so = t["support_off"].tolist()
+        rn_blob, rn_off = _csr([",".join(nm[so[c]:so[c + 1]]) for c in range(n)])
+    keys = np.unique(t["gl_idx"][t["gl_idx"] >= 0]).astype(np.int32) if n else np.zeros(0, np.int32)
+    gl_strs = (C.c_char_p * max(1, len(keys)))(*["\t".join(gl_fields(int(k))).encode() for k in keys])
+    strands = (C.c_char_p * len(store.strands))(*[s.encode() for s in store.strands])
+    if svid is None:
+        svid = np.zeros(5, np.int64)
+    vin = VcfIn(res=C.pointer(res.c), seg=segs.ctypes.data, n_seg=len(segs), n_chrom=nch,
+                chrom_name=names, chrom_seq=seqs, chrom_len=clen.ctypes.data, chrom_rank=rank.ctypes.data,
+                ins_alt=alt_blob, ins_alt_off=None if alt_off is None else alt_off.ctypes.data,
+                rnames=rn_blob, rnames_off=None if rn_off is None else rn_off.ctypes.data,
+                strand_name=strands, gl_key=keys.ctypes.data, gl_str=gl_strs, n_gl=len(keys),
+                min_size=min_size, max_size=max_size, genotype=int(bool(genotype)), report_readid=int(bool(report_readid)),
+                ignore_sequence=int(bool(ignore_sequence)))
+    cap = 256 * max(n, 1) + (len(alt_blob) if alt_blob else 0) + (len(rn_blob) if rn_blob else 0) + 4096
+    for _ in range(2):
+        buf = C.create_string_buffer(cap)
+        need = C.c_int64(0)
+        sv = svid.copy()
+        rc = L.csv_vcf_emit(C.byref(vin), buf, cap, C.byref(need), sv.ctypes.data)
+        if rc == _abi.E_CAPACITY:
+            cap = need.value + 16
+            continue
+        if rc != _abi.OK:
+            raise RuntimeError("csv_vcf_emit: %s (a reference sequence is missing or too short?)" % _abi.ERR_NAME.get(rc, rc))
+        svid[:] = sv
+        return buf.raw[:need.value].decode(), svid
+    raise RuntimeError("csv_vcf_emit: capacity retry failed")

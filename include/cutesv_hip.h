@@ -188,6 +188,49 @@ int csv_ctx_sync(csv_ctx* ctx);
 int32_t csv_gl_index(int64_t c0, int64_t c1);
 #define CSV_GL_TABLE_SIZE (101 * 101 + 2)
 
+/* ---------------------------------------------------------------------------------------------
+ * Host-side VCF record emit: the structure-of-arrays result -> the text lines
+ * of cuteSV's VCF body, without materialising Python row lists.  Replaces generate_output
+ * (cuteSV_genotype.py:242-467: per-chromosome stable sort by POS, size filters, INFO/FORMAT
+ * assembly, REF/ALT from the reference sequence, q5 filter, AF) and the SVID numbering of main_ctrl
+ * (cuteSV main script :1208-1237: one counter per SV type over the sorted chromosome names).
+ * No GPU work: plain C++ on the caller's thread.
+ */
+typedef struct csv_vcf_in {
+    /* the calls (csv_batch_out after csv_cluster_batch / csv_batch_download) and their segments */
+    const csv_batch_out* res;
+    const csv_segment*   seg;
+    int32_t              n_seg;
+    int32_t              n_chrom;
+    /* per chromosome (index = csv_segment.chrom): name, reference sequence, emission rank
+     * (chrom_rank[c] = position of chromosome c in sorted(names): the order main_ctrl writes them) */
+    const char* const*   chrom_name;
+    const char* const*   chrom_seq;
+    const int64_t*       chrom_len;
+    const int32_t*       chrom_rank;
+    /* strings attached to calls, as CSR blobs indexed by call (NULL = absent):
+     *   ins_alt  the inserted sequence already sliced to SVLEN (INS calls; INDEL:402)
+     *   rnames   comma-joined supporting read names (only read when report_readid)            */
+    const char*          ins_alt;    const int64_t* ins_alt_off;
+    const char*          rnames;     const int64_t* rnames_off;
+    /* INV strand strings by call_aux code; genotype strings by table row:
+     *   gl_key[n_gl] sorted gl_idx values present, gl_str = per key "GT\tPL\tGQ\tQUAL" (tab separated) */
+    const char* const*   strand_name;
+    const int32_t*       gl_key;     const char* const* gl_str;     int32_t n_gl;
+    /* flags of cuteSV_Description.py: --min_size (:144), --max_size (:148), --genotype (:159), --report_readid (:100), --ignore_sequence (:104) */
+    int64_t              min_size;
+    int64_t              max_size;
+    int32_t              genotype;
+    int32_t              report_readid;
+    int32_t              ignore_sequence;
+    int32_t              reserved;
+} csv_vcf_in;
+
+/* Writes the records into `out` (capacity `cap` bytes) and returns CSV_OK, or CSV_E_CAPACITY with
+ * *n_written = the needed size.  svid[5] = running record counters in the order INS, DEL, BND, DUP, INV
+ * (main script :1209-1213); pass zeros for a fresh file, they are advanced in place. */
+int csv_vcf_emit(const csv_vcf_in* in, char* out, int64_t cap, int64_t* n_written, int64_t* svid);
+
 #ifdef __cplusplus
 }
 #endif

@@ -14,6 +14,7 @@ Outputs
     gl_table.json.gz       cal_GL over its whole rescaled domain + large-count samples, cal_CIPOS samples
     overlap_cover.json.gz  random overlap_cover instances (ties, x.5 windows, non-primary, repeated names)
     sim_sites.npz          truth sites of simulation/sim_*.bed.gz as integer arrays (data for cfg-1 / cfg-2)
+    vcf_lines.json.gz      generate_output lines (+ SVID numbering) for some small cases x report_readid / ignore_sequence
     digests.json           sha256 of the reference's canonical rows per (type, chr) for BASELINE configs 1-5
                            (cfg-3/4/5 at reduced scale so the reference finishes in minutes)
 """
@@ -33,7 +34,23 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 REF = "/root/reference"
 
-sys.modules["pysam"] = types.ModuleType("pysam")          # stub: never called on this path
+_pysam = types.ModuleType("pysam")                         # stub: only FastaFile is ever touched (generate_output)
+_REF_SEQS = {}
+
+
+class _FastaFile:                                          # pysam.FastaFile stand-in backed by _REF_SEQS
+    def __init__(self, path):
+        pass
+
+    def fetch(self, chrom):
+        return _REF_SEQS[chrom]
+
+    def close(self):
+        pass
+
+
+_pysam.FastaFile = _FastaFile
+sys.modules["pysam"] = _pysam
 sys.path.insert(0, os.path.join(REF, "src"))
 from cuteSV import cuteSV_resolveINDEL as R_INDEL          # noqa: E402
 from cuteSV import cuteSV_resolveDUP as R_DUP              # noqa: E402
@@ -376,6 +393,53 @@ def config_digests(sites):
     return out
 
 
+# ----------------------------------------------------------------------------- VCF lines (generate_output + numbering)
+def vcf_lines():
+    """The reference's generate_output (cuteSV_genotype.py:242-467) on the rows of some small cases, then
+    main_ctrl's numbering (main script :1208-1237) restated in three lines: per-type counters over the
+    sorted chromosome names."""
+    import argparse
+    out = []
+    small = json.load(gzip.open(os.path.join(HERE, "small_cases.json.gz"), "rt"))
+    flagsets = [dict(report_readid=False, ignore_sequence=False), dict(report_readid=True, ignore_sequence=False),
+                dict(report_readid=False, ignore_sequence=True)]
+    for case in small:
+        if case["name"] not in ("default_gt", "ont", "hifi_gt", "realnames_gt", "small_sizes", "unlimited", "lowsupport"):
+            continue
+        p = Params(**case["params"])
+        chroms = case["store"]["chroms"]
+        maxpos = max(max(case["store"]["a"]), max(case["store"]["b"])) + 200000
+        _REF_SEQS.clear()
+        for i, c in enumerate(chroms):
+            _REF_SEQS[c] = synth.reference_sequence(min(maxpos, 3_100_000), seed=1000 + i)
+        results = {}
+        for t in TYPES:                                     # main script :1191-1197: extend in submission order
+            for tt, c, rows in case["rows"]:
+                if tt == t:
+                    results.setdefault(c, []).extend([list(r) for r in rows])
+        for fl in flagsets:
+            args = argparse.Namespace(genotype=p.genotype, max_size=p.max_size, min_size=p.min_size, **fl)
+            svid = {"INS": 0, "DEL": 0, "BND": 0, "DUP": 0, "INV": 0}
+            text = []
+            with tempfile.TemporaryDirectory() as d:
+                d += "/"
+                os.mkdir(d + "results")
+                for c in sorted(results):
+                    R_GT.generate_output(args, [list(r) for r in results[c]], "ref.fa", c, d)
+                for c in sorted(results):
+                    with open("%sresults/%s.pickle" % (d, c), "rb") as f:
+                        while True:
+                            try:
+                                for svtype, line in pickle.load(f):
+                                    text.append(line.replace("<SVID>", str(svid[svtype])))
+                                    svid[svtype] += 1
+                            except EOFError:
+                                break
+            out.append(dict(case=case["name"], flags=fl, ref_seed0=1000, ref_len=min(maxpos, 3_100_000), text="".join(text)))
+            print("vcf %-14s %s lines=%d" % (case["name"], fl, len(text)))
+    return out
+
+
 def main():
     os.chdir(HERE)
     sites = sim_sites()
@@ -388,6 +452,8 @@ def main():
         json.dump(gl_table(), f)
     with gzip.open("overlap_cover.json.gz", "wt") as f:
         json.dump(overlap_cases(), f)
+    with gzip.open("vcf_lines.json.gz", "wt") as f:
+        json.dump(vcf_lines(), f)
     with open("digests.json", "w") as f:
         json.dump(config_digests(sites), f, indent=1)
     for fn in sorted(os.listdir(".")):

@@ -189,3 +189,20 @@ def test_random_parameter_stress_vs_oracle(ctx):
 def test_scaled_cfg4_and_cfg5_vs_oracle(ctx):
     _compare_soa(ctx, synth.hifi30_gt(scale=0.05), Params.hifi(genotype=True, min_support=3))
     _compare_soa(ctx, synth.ont90_all(scale=0.05), Params.ont(genotype=True))        # 90x: mostly mid-tier clusters
+
+
+def test_end_to_end_vcf_text_from_the_gpu_path(ctx):
+    """signature columns -> HIP kernels -> native VCF emit == the reference's generate_output text"""
+    from cutesv_amd import vcf
+    from test_vcf_emit import _canon
+    small = {c["name"]: c for c in load_json("small_cases.json.gz")}
+    for g in load_json("vcf_lines.json.gz"):
+        case = small[g["case"]]
+        st = store_from_json(case["store"])
+        p = Params(**case["params"])
+        ref = {c: synth.reference_sequence(g["ref_len"], seed=g["ref_seed0"] + i) for i, c in enumerate(st.chroms)}
+        hb = st.host_batch([(t, c) for t, c, _ in case["rows"]], p)
+        res = ctx.cluster_batch(hb)
+        text, _ = vcf.emit_records(st, hb.segments, res, ref, min_size=p.min_size, max_size=p.max_size,
+                                   genotype=p.genotype, **g["flags"])
+        assert _canon(text) == _canon(g["text"]), (g["case"], g["flags"])

@@ -1,0 +1,70 @@
+"""CPU test: the native VCF record emitter (cutesv_amd/csrc/vcf_emit.cpp, no GPU work) against the lines the
+reference's generate_output + main_ctrl numbering produce for the same calls (tests/golden/vcf_lines.json.gz)."""
+import numpy as np
+
+from cutesv_amd import synth, vcf
+from cutesv_amd.columns import Params
+from oracle import oracle
+from helpers import load_json, store_from_json
+
+
+def _first_diff(a, b):
+    la, lb = a.split("\n"), b.split("\n")
+    for i, (x, y) in enumerate(zip(la, lb)):
+        if x != y:
+            return "line %d:\n got %s\nwant %s" % (i, x[:400], y[:400])
+    return "line counts %d vs %d" % (len(la), len(lb))
+
+
+def _canon(text):
+    """DUP / BND read-name lists come from Python sets in the reference (cuteSV_resolveDUP.py:82,96,
+    cuteSV_resolveTRA.py:182): their order depends on the interpreter's hash seed, so sort them."""
+    out = []
+    for line in text.split("\n"):
+        if ";RNAMES=" in line and ("SVTYPE=DUP" in line or "SVTYPE=BND" in line):
+            head, rest = line.split(";RNAMES=", 1)
+            cut = min([i for i in (rest.find(";"), rest.find("\t")) if i >= 0])
+            line = head + ";RNAMES=" + ",".join(sorted(rest[:cut].split(","))) + rest[cut:]
+        out.append(line)
+    return "\n".join(out)
+
+
+def test_vcf_text_identical_to_reference():
+    small = {c["name"]: c for c in load_json("small_cases.json.gz")}
+    golden = load_json("vcf_lines.json.gz")
+    assert len(golden) >= 21
+    for g in golden:
+        case = small[g["case"]]
+        st = store_from_json(case["store"])
+        p = Params(**case["params"])
+        ref = {c: synth.reference_sequence(g["ref_len"], seed=g["ref_seed0"] + i) for i, c in enumerate(st.chroms)}
+        tasks = [(t, c) for t, c, _ in case["rows"]]
+        # the order main_ctrl concatenates results in: DEL, INS, INV, DUP, TRA (already the fixture's order)
+        hb = st.host_batch(tasks, p)
+        res = oracle.cluster_batch(hb, per_sig=False)          # the emitter only sees the SoA; any engine will do
+        text, svid = vcf.emit_records(st, hb.segments, res, ref, min_size=p.min_size, max_size=p.max_size,
+                                      genotype=p.genotype, **g["flags"])
+        assert _canon(text) == _canon(g["text"]), "%s %s: %s" % (g["case"], g["flags"], _first_diff(_canon(text), _canon(g["text"])))
+        assert int(svid.sum()) == g["text"].count("\n")
+
+
+def test_svid_counters_continue_across_calls():
+    case = load_json("small_cases.json.gz")[0]
+    st = store_from_json(case["store"])
+    p = Params(**case["params"])
+    ref = {c: synth.reference_sequence(1_300_000, seed=7 + i) for i, c in enumerate(st.chroms)}
+    hb = st.host_batch(st.tasks(), p)
+    res = oracle.cluster_batch(hb)
+    t1, sv = vcf.emit_records(st, hb.segments, res, ref, min_size=p.min_size, max_size=p.max_size)
+    t2, sv = vcf.emit_records(st, hb.segments, res, ref, min_size=p.min_size, max_size=p.max_size, svid=sv)
+    n = t1.count("\n")
+    assert t2.count("\n") == n and int(sv.sum()) == 2 * n
+    assert "cuteSV.DEL.0\t" in t1 and "cuteSV.DEL.0\t" not in t2
+
+
+def test_fasta_reader(tmp_path):
+    from cutesv_amd.fasta import read_fasta
+    p = tmp_path / "r.fa"
+    p.write_text(">chr1 desc\nACGT\nNNAC\n>chr2\nGG\n\n>chr3\n")
+    assert read_fasta(str(p)) == {"chr1": "ACGTNNAC", "chr2": "GG", "chr3": ""}
+    assert read_fasta(str(p), only={"chr2"}) == {"chr2": "GG"}
