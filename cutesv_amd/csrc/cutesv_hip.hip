@@ -407,6 +407,25 @@ int csv_batch_run(csv_ctx* c, csv_run_stats* stats)
     return CSV_OK;
 }
 
+int csv_batch_validate(csv_ctx* c)
+{
+    if (!c) return CSV_E_INVALID;
+    if (!c->uploaded) return fail(c, CSV_E_STATE, "csv_batch_validate before csv_batch_upload");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    DevCounters zero;
+    memset(&zero, 0, sizeof zero);
+    HIP_TRY(c, hipMemcpyAsync(c->cnt.p, &zero, sizeof zero, hipMemcpyHostToDevice, st));
+    if (c->B.W > 0) hipLaunchKernelGGL(k_validate_order, dim3(div_up(c->B.W, 256)), dim3(256), 0, st, c->B);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(&c->h_cnt, c->cnt.p, sizeof(DevCounters), hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    c->ran = false;
+    if (c->h_cnt.error & ERR_SIG_ORDER)
+        return fail(c, CSV_E_UNSORTED, "a segment is not in the rebuild order of cuteSV (main script :764-802) or holds adjacent duplicates");
+    return CSV_OK;
+}
+
 int csv_batch_download(csv_ctx* c, csv_batch_out* out)
 {
     if (!c || !out) return CSV_E_INVALID;

@@ -34,7 +34,7 @@ constexpr int SQRT_TAB = 65536;                    // pow(n, 0.5) as glibc compu
 constexpr int ARR_PAD = 8;                         // group-start arrays need P + 1 entries
 
 // device error bits (DevCounters::error)
-enum { ERR_CLUSTER_TOO_BIG = 1, ERR_READS_UNSORTED = 2, ERR_COVER_OVERFLOW = 4, ERR_KEY_RANGE = 8, ERR_TMP_OVERFLOW = 16 };
+enum { ERR_CLUSTER_TOO_BIG = 1, ERR_READS_UNSORTED = 2, ERR_COVER_OVERFLOW = 4, ERR_KEY_RANGE = 8, ERR_TMP_OVERFLOW = 16, ERR_SIG_ORDER = 32 };
 
 struct DevCounters {          // one small struct in device memory, zeroed at the start of every run
     int n_clusters;
@@ -365,6 +365,29 @@ __global__ __launch_bounds__(256) void k_chain_apply(DevBatch B)
         B.cnt->n_clusters = run;
     }
     (void)my_total;
+}
+
+// ------------------------------------------------------------------------------------ input order contract
+// Inside a segment the rows must be in the order the reference's rebuild step leaves them (main script
+// :764-802 sort keys, :958-969 adjacent de-duplication): strictly increasing in (a, b, read_id) for DEL / INS /
+// DUP and in (aux, a, b, read_id) for INV (aux = strand) and TRA (aux = chr2, type).  A violation means the
+// caller's columns are not what phase 3 of cuteSV would see; csv_batch_validate reports it.
+__global__ __launch_bounds__(256) void k_validate_order(DevBatch B)
+{
+    const i64 w = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (w >= B.W || w == 0) return;
+    const int k = seg_of(B, w);
+    if (w == B.woff[k]) return;
+    const int type = B.seg[k].svtype;
+    const i64 a0 = B.a[w - 1], a1 = B.a[w], b0 = B.b[w - 1], b1 = B.b[w];
+    const int r0 = B.rid[w - 1], r1 = B.rid[w];
+    int c = 0;                                          // sign of key(w) - key(w - 1)
+    if (type == CSV_INV || type == CSV_TRA) { const int x0 = B.aux[w - 1], x1 = B.aux[w]; c = (x1 > x0) - (x1 < x0); }
+    if (c == 0) c = (a1 > a0) - (a1 < a0);
+    if (c == 0) c = (b1 > b0) - (b1 < b0);
+    if (c == 0) c = (r1 > r0) - (r1 < r0);
+    if (c == 0 && type == CSV_INS) c = 1;               // equal (pos, len, read): the sequences may still differ
+    if (c <= 0) atomicOr(&B.cnt->error, ERR_SIG_ORDER);
 }
 
 // ------------------------------------------------------------------------------------ select

@@ -61,6 +61,10 @@ class Context:
         self._check(lib().csv_batch_run(self._h, None))
         return None
 
+    def validate(self):
+        """check the uploaded batch against the reference's rebuild order (raises CsvError E_UNSORTED)"""
+        self._check(lib().csv_batch_validate(self._h))
+
     def sync(self):
         self._check(lib().csv_ctx_sync(self._h))
 

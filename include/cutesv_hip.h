@@ -182,6 +182,11 @@ int csv_batch_run(csv_ctx* ctx, csv_run_stats* stats /* nullable */);
 int csv_batch_download(csv_ctx* ctx, csv_batch_out* out);
 int csv_ctx_sync(csv_ctx* ctx);
 
+/* Optional check of the input order contract on the uploaded batch: inside every segment the rows must be
+ * strictly increasing in the reference's rebuild sort key (cuteSV main script :764-802; adjacent duplicates
+ * removed, :958-969).  Returns CSV_E_UNSORTED otherwise.  One pass over the columns; not part of csv_batch_run. */
+int csv_batch_validate(csv_ctx* ctx);
+
 /* cal_GL's domain after its special cases and rescale_read_counts (GT:25-37): returns the
  * table index the device writes into gl_idx for (DR, DV) = (c0, c1).  Host-side helper so
  * the Python shim and the tests share one definition with the kernels. */

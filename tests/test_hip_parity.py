@@ -206,3 +206,21 @@ def test_end_to_end_vcf_text_from_the_gpu_path(ctx):
         text, _ = vcf.emit_records(st, hb.segments, res, ref, min_size=p.min_size, max_size=p.max_size,
                                    genotype=p.genotype, **g["flags"])
         assert _canon(text) == _canon(g["text"]), (g["case"], g["flags"])
+
+
+def test_input_order_contract_is_checked(ctx):
+    st = synth.small_mixed(seed=21, genotype=False)
+    hb = st.host_batch(st.tasks(), Params.ont())
+    ctx.upload(hb)
+    ctx.validate()                                        # generator output honours the rebuild order
+    for col, delta in (("a", -10_000_000), ("read_id", 0)):
+        bad = synth.small_mixed(seed=21, genotype=False)
+        beg, end = bad.seg_index[("DEL", "2")]
+        if col == "a":
+            bad.a[beg + 5] += delta                       # out of position order
+        else:
+            bad.a[beg + 6], bad.b[beg + 6], bad.read_id[beg + 6] = bad.a[beg + 5], bad.b[beg + 5], bad.read_id[beg + 5]   # adjacent duplicate
+        ctx.upload(bad.host_batch(bad.tasks(), Params.ont()))
+        with pytest.raises(engine.CsvError) as e:
+            ctx.validate()
+        assert e.value.code == _abi.E_UNSORTED
