@@ -24,6 +24,7 @@ SYMBOLS = [
     ("csv_ctx_sync", C.c_int, [C.c_void_p]),
     ("csv_batch_validate", C.c_int, [C.c_void_p]),
     ("csv_gl_index", C.c_int32, [C.c_int64, C.c_int64]),
+    ("csv_rebuild_signatures", C.c_int, None),  # prototype set in cutesv_amd/rebuild.py
     ("csv_vcf_emit", C.c_int, None),           # prototype set in cutesv_amd/vcf.py (needs its struct)
 ]
 

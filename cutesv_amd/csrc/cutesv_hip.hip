@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "kernels.hip.h"
+#include "sort.hip.h"
 
 using namespace csv;
 
@@ -45,6 +46,8 @@ struct csv_ctx {
     Buf o_supoff, o_supsig, o_suprid, allele_id;
     Buf reads_off, r_start, r_end, r_primary, r_id, r_pmax, pm_partial;
     Buf sqrt_tab, cnt;
+    Buf rb_seg, rb_a, rb_b, rb_rid, rb_aux, rb_auxk, rb_major, rb_perm0, rb_perm1, rb_hist, rb_tot, rb_partial;
+    Buf rb_oseg, rb_oa, rb_ob, rb_orid, rb_oaux, rb_osrc;
     // host copies
     std::vector<csv_segment> h_seg;
     std::vector<i64>         h_woff;
@@ -157,7 +160,9 @@ void csv_ctx_destroy(csv_ctx* c)
                   &c->sc_v3, &c->sc_v4, &c->sc_v5, &c->o_seg, &c->o_cluster, &c->o_aux, &c->o_bp1, &c->o_bp2, &c->o_support,
                   &c->o_cipos, &c->o_cilen, &c->o_search, &c->o_pick, &c->o_dr, &c->o_dv, &c->o_gl, &c->o_supoff, &c->o_supsig,
                   &c->o_suprid, &c->allele_id, &c->reads_off, &c->r_start, &c->r_end, &c->r_primary, &c->r_id, &c->r_pmax, &c->pm_partial,
-                  &c->sqrt_tab, &c->cnt};
+                  &c->sqrt_tab, &c->cnt, &c->rb_seg, &c->rb_a, &c->rb_b, &c->rb_rid, &c->rb_aux, &c->rb_auxk, &c->rb_major,
+                  &c->rb_perm0, &c->rb_perm1, &c->rb_hist, &c->rb_tot, &c->rb_partial, &c->rb_oseg, &c->rb_oa, &c->rb_ob,
+                  &c->rb_orid, &c->rb_oaux, &c->rb_osrc};
     for (Buf* b : all) if (b->p) (void)hipFree(b->p);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->ev_aux) if (e) (void)hipEventDestroy(e);
@@ -467,6 +472,86 @@ int csv_batch_download(csv_ctx* c, csv_batch_out* out)
 #undef D2H
     HIP_TRY(c, hipStreamSynchronize(st));
     if (nc == 0 && out->cap_calls >= 0 && out->support_off) out->support_off[0] = 0;
+    return CSV_OK;
+}
+
+int csv_rebuild_signatures(csv_ctx* c, const csv_rebuild_in* in, csv_rebuild_out* out)
+{
+    if (!c || !in || !out) return CSV_E_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const i64 n = in->n;
+    out->n_out = 0; out->ms_device = 0; out->n_passes = 0;
+    if (n < 0 || n >= (1ll << 31) - 4096 || in->n_seg <= 0) return fail(c, CSV_E_INVALID, "bad rebuild input");
+    if (n == 0) return CSV_OK;
+    // key widths (bytes that are non-zero somewhere) from one host pass over the columns
+    i64 mx_a = 0, mx_b = 0; int mx_rid = 0, mx_aux = 0, mx_seg = 0;
+    for (i64 i = 0; i < n; i++) {
+        const int sg = in->seg_id[i];
+        if (sg < 0 || sg >= in->n_seg || in->a[i] < 0 || in->b[i] < 0 || in->read_id[i] < 0 || in->aux[i] < 0)
+            return fail(c, CSV_E_INVALID, "row %lld: negative key or segment out of range", (long long)i);
+        if (in->a[i] > mx_a) mx_a = in->a[i];
+        if (in->b[i] > mx_b) mx_b = in->b[i];
+        if (in->read_id[i] > mx_rid) mx_rid = in->read_id[i];
+        if (in->seg_aux_major[sg] && in->aux[i] > mx_aux) mx_aux = in->aux[i];
+        if (sg > mx_seg) mx_seg = sg;
+    }
+    auto nbytes = [](u64 v) { int k = 0; while (v) { k++; v >>= 8; } return k; };
+    const int nunits = div_up(n, SORT_WTILE), nblk = div_up(nunits, 4), ntile = div_up(n, 2048);
+    RES(rb_seg, n * 4); RES(rb_a, n * 8); RES(rb_b, n * 8); RES(rb_rid, n * 4); RES(rb_aux, n * 4); RES(rb_auxk, n * 4);
+    RES(rb_major, in->n_seg); RES(rb_perm0, n * 4); RES(rb_perm1, n * 4); RES(rb_hist, (size_t)256 * nunits * 4);
+    RES(rb_tot, 256 * 4); RES(rb_partial, (ntile + 2) * 4);
+    RES(rb_oseg, n * 4); RES(rb_oa, n * 8); RES(rb_ob, n * 8); RES(rb_orid, n * 4); RES(rb_oaux, n * 4); RES(rb_osrc, n * 4);
+    hipStream_t st = c->stream;
+    HIP_TRY(c, hipMemcpyAsync(c->rb_seg.p, in->seg_id, n * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(c->rb_a.p, in->a, n * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(c->rb_b.p, in->b, n * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(c->rb_rid.p, in->read_id, n * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(c->rb_aux.p, in->aux, n * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(c->rb_major.p, in->seg_aux_major, in->n_seg, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipEventRecord(c->ev[0], st));
+    hipLaunchKernelGGL(k_rebuild_auxkey, dim3(div_up(n, 256)), dim3(256), 0, st, n, dp<int>(c->rb_seg), dp<int>(c->rb_aux),
+                       dp<uint8_t>(c->rb_major), dp<int>(c->rb_auxk));
+    // least significant key first: read_id, b, a, [aux], segment
+    struct Field { const void* col; int elem64; int bytes; };
+    const Field fields[5] = {{c->rb_rid.p, 0, nbytes((u64)mx_rid)}, {c->rb_b.p, 1, nbytes((u64)mx_b)}, {c->rb_a.p, 1, nbytes((u64)mx_a)},
+                             {c->rb_auxk.p, 0, nbytes((u64)mx_aux)}, {c->rb_seg.p, 0, nbytes((u64)mx_seg) > 0 ? nbytes((u64)mx_seg) : 1}};
+    const int* pin = nullptr;
+    int* pout = dp<int>(c->rb_perm0);
+    int npass = 0;
+    for (const Field& f : fields)
+        for (int byte = 0; byte < f.bytes; byte++) {
+            SortPass P{f.col, f.elem64, byte * 8, n, nunits, pin, pout, dp<int>(c->rb_hist)};
+            hipLaunchKernelGGL(k_sort_hist, dim3(nblk), dim3(256), 0, st, P);
+            hipLaunchKernelGGL(k_sort_rowsum, dim3(256), dim3(256), 0, st, dp<int>(c->rb_hist), nunits, dp<int>(c->rb_tot));
+            hipLaunchKernelGGL(k_sort_rowscan, dim3(256), dim3(256), 0, st, dp<int>(c->rb_hist), nunits, dp<int>(c->rb_tot));
+            hipLaunchKernelGGL(k_sort_scatter, dim3(nblk), dim3(256), 0, st, P);
+            pin = pout;
+            pout = (pout == dp<int>(c->rb_perm0)) ? dp<int>(c->rb_perm1) : dp<int>(c->rb_perm0);
+            npass++;
+        }
+    RebuildArgs R{};
+    R.n = n; R.perm = pin;
+    R.seg = dp<int>(c->rb_seg); R.a = dp<i64>(c->rb_a); R.b = dp<i64>(c->rb_b); R.rid = dp<int>(c->rb_rid); R.aux = dp<int>(c->rb_aux);
+    R.auxk = dp<int>(c->rb_auxk); R.keep = nullptr; R.partial = dp<int>(c->rb_partial);
+    R.o_seg = dp<int>(c->rb_oseg); R.o_a = dp<i64>(c->rb_oa); R.o_b = dp<i64>(c->rb_ob); R.o_rid = dp<int>(c->rb_orid);
+    R.o_aux = dp<int>(c->rb_oaux); R.o_src = dp<int>(c->rb_osrc); R.n_out = (int*)c->cnt.p;
+    hipLaunchKernelGGL(k_rebuild_count, dim3(ntile), dim3(256), 0, st, R);
+    hipLaunchKernelGGL(k_rebuild_apply, dim3(ntile), dim3(256), 0, st, R);
+    HIP_TRY(c, hipEventRecord(c->ev[1], st));
+    HIP_TRY(c, hipGetLastError());
+    int n_out = 0;
+    HIP_TRY(c, hipMemcpyAsync(&n_out, c->cnt.p, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    HIP_TRY(c, hipEventElapsedTime(&out->ms_device, c->ev[0], c->ev[1]));
+    out->n_out = n_out; out->n_passes = npass;
+    HIP_TRY(c, hipMemcpyAsync(out->seg_id, c->rb_oseg.p, (size_t)n_out * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(out->a, c->rb_oa.p, (size_t)n_out * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(out->b, c->rb_ob.p, (size_t)n_out * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(out->read_id, c->rb_orid.p, (size_t)n_out * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(out->aux, c->rb_oaux.p, (size_t)n_out * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(out->src_row, c->rb_osrc.p, (size_t)n_out * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    c->uploaded = c->ran = false;          // cnt was used as scratch
     return CSV_OK;
 }
 

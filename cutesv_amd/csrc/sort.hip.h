@@ -1,0 +1,198 @@
+// sort.hip.h — the rebuild step on the GPU: stable LSD radix sort of row
+// permutations on multi-column keys, then gather + adjacent de-duplication.
+//
+// Reproduces the ORDER CONTRACT of cuteSV's process_process_sigs_type (main script :750-857): signatures
+// sorted by (chromosome, [strand | chr2, type], int(pos), len | pos2, read name) (:764-802) with adjacent
+// exact duplicates removed (:958-969).  Read names are interned ids whose order is the names' string order,
+// so the whole key is integer columns.
+//
+// One pass = one 8-bit digit of one key column: k_sort_hist (per-wavefront-tile digit histograms),
+// k_sort_rowsum / k_sort_rowscan (digit-major exclusive scan), k_sort_scatter (stable scatter of the permutation).  The
+// permutation moves, the columns stay in place and are gathered by index; digits whose byte is zero for
+// every row are skipped by the host.  Intra-tile stability uses the bit-sliced ballot trick: eight
+// __ballot()s tell each lane which lanes of its 64-row chunk carry the same digit.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace csv {
+
+constexpr int SORT_CHUNKS = 32;                      // 64-row chunks per wavefront tile
+constexpr int SORT_WTILE = 64 * SORT_CHUNKS;         // rows per wavefront tile (2048)
+
+struct SortPass {
+    const void* col;       // key column (device)
+    int         elem64;    // 1: int64 column, 0: int32
+    int         shift;     // bit offset of the digit
+    i64         n;
+    int         nunits;    // wavefront tiles
+    const int*  perm_in;   // nullptr on the first pass (identity)
+    int*        perm_out;
+    int*        hist;      // [256][nunits]
+};
+
+__device__ __forceinline__ int sort_digit(const SortPass& P, i64 row)
+{
+    const i64 src = P.perm_in ? P.perm_in[row] : row;
+    const u64 v = P.elem64 ? (u64)((const i64*)P.col)[src] : (u64)(unsigned)((const int*)P.col)[src];
+    return (int)((v >> P.shift) & 255);
+}
+
+// one wavefront per tile of 2048 rows: LDS histogram per wavefront, written digit-major
+__global__ __launch_bounds__(256) void k_sort_hist(SortPass P)
+{
+    __shared__ int h[4][256];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int unit = blockIdx.x * 4 + wv;
+    for (int d = lane; d < 256; d += 64) h[wv][d] = 0;
+    __syncthreads();
+    if (unit < P.nunits) {
+        const i64 base = (i64)unit * SORT_WTILE;
+        for (int c = 0; c < SORT_CHUNKS; c++) {
+            const i64 row = base + c * 64 + lane;
+            if (row < P.n) atomicAdd(&h[wv][sort_digit(P, row)], 1);
+        }
+    }
+    __syncthreads();
+    if (unit < P.nunits)
+        for (int d = lane; d < 256; d += 64) P.hist[(i64)d * P.nunits + unit] = h[wv][d];
+}
+
+// exclusive scan of hist in (digit, unit) order, two launches of 256 workgroups (one per digit):
+//   k_sort_rowsum   total of digit d's row -> tot[d]
+//   k_sort_rowscan  base(d) = sum of tot[d' < d]; row-local exclusive scan + base, in place
+__global__ __launch_bounds__(256) void k_sort_rowsum(const int* hist, int nunits, int* tot)
+{
+    const int* row = hist + (i64)blockIdx.x * nunits;
+    i64 v = 0;
+    for (int u = threadIdx.x; u < nunits; u += 256) v += row[u];
+    v = wave_sum_i64(v);
+    __shared__ i64 s[4];
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) tot[blockIdx.x] = (int)(s[0] + s[1] + s[2] + s[3]);
+}
+
+__global__ __launch_bounds__(256) void k_sort_rowscan(int* hist, int nunits, const int* tot)
+{
+    __shared__ i64 sh[4];
+    __shared__ int wsum[4];
+    __shared__ int carry_s;
+    int* row = hist + (i64)blockIdx.x * nunits;
+    const int base = (int)block_prefix_of(tot, blockIdx.x, sh);
+    if (threadIdx.x == 0) carry_s = base;
+    __syncthreads();
+    for (int b0 = 0; b0 < nunits; b0 += 256) {
+        const int u = b0 + threadIdx.x;
+        const int v = u < nunits ? row[u] : 0;
+        const int inc = wave_incl_scan_i32(v);
+        if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = inc;
+        __syncthreads();
+        int off = carry_s;
+        for (int k = 0; k < (int)(threadIdx.x >> 6); k++) off += wsum[k];
+        if (u < nunits) row[u] = off + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 255) carry_s = off + inc;
+        __syncthreads();
+    }
+}
+
+// stable scatter: every wavefront walks its tile chunk by chunk, in row order
+__global__ __launch_bounds__(256) void k_sort_scatter(SortPass P)
+{
+    __shared__ int cnt[4][256];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int unit = blockIdx.x * 4 + wv;
+    if (unit < P.nunits)
+        for (int d = lane; d < 256; d += 64) cnt[wv][d] = P.hist[(i64)d * P.nunits + unit];
+    __syncthreads();
+    if (unit >= P.nunits) return;
+    const i64 base = (i64)unit * SORT_WTILE;
+    const u64 lt = (1ull << lane) - 1ull;
+    for (int c = 0; c < SORT_CHUNKS; c++) {
+        const i64 row = base + c * 64 + lane;
+        const bool in = row < P.n;
+        const int dig = in ? sort_digit(P, row) : 0;
+        const int src = in ? (P.perm_in ? P.perm_in[row] : (int)row) : 0;
+        u64 match = __ballot(in);
+#pragma unroll
+        for (int bit = 0; bit < 8; bit++) {
+            const bool set = (dig >> bit) & 1;
+            const u64 mk = __ballot(set);
+            match &= set ? mk : ~mk;
+        }
+        if (in) {
+            const int before = cnt[wv][dig];                         // same value for the whole match group
+            const int rank = __popcll(match & lt);
+            P.perm_out[before + rank] = src;
+        }
+        // the highest lane of each group advances the group's counter (after everyone read it: LDS ops of a
+        // wavefront execute in order)
+        if (in && (match >> lane) <= 1ull) cnt[wv][dig] += __popcll(match);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ---------------------------------------------------------------------------------------- gather + de-dup
+struct RebuildArgs {
+    i64 n;
+    const int* perm;
+    const int* seg; const i64* a; const i64* b; const int* rid; const int* aux; const int* auxk;
+    int* keep;             // 1 when the sorted row differs from its predecessor
+    int* partial;          // per 2048-row tile counts
+    int* o_seg; i64* o_a; i64* o_b; int* o_rid; int* o_aux; int* o_src;
+    int* n_out;
+};
+
+__device__ __forceinline__ int rebuild_keep(const RebuildArgs& R, i64 i)
+{
+    if (i >= R.n) return 0;
+    if (i == 0) return 1;
+    const int p = R.perm ? R.perm[i] : (int)i, q = R.perm ? R.perm[i - 1] : (int)(i - 1);
+    return !(R.seg[p] == R.seg[q] && R.a[p] == R.a[q] && R.b[p] == R.b[q] && R.rid[p] == R.rid[q] && R.aux[p] == R.aux[q]);
+}
+
+__global__ __launch_bounds__(256) void k_rebuild_count(RebuildArgs R)
+{
+    const i64 base = (i64)blockIdx.x * 2048 + (threadIdx.x >> 6) * 512;
+    int cnt = 0;
+    for (int r = 0; r < 8; r++) cnt += __popcll(__ballot(rebuild_keep(R, base + r * 64 + (threadIdx.x & 63))));
+    __shared__ int s[4];
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) R.partial[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+}
+
+__global__ __launch_bounds__(256) void k_rebuild_apply(RebuildArgs R)
+{
+    __shared__ i64 sh[4];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const i64 base = (i64)blockIdx.x * 2048 + wv * 512;
+    u64 masks[8]; int cnt = 0;
+    for (int r = 0; r < 8; r++) { masks[r] = __ballot(rebuild_keep(R, base + r * 64 + lane)); cnt += __popcll(masks[r]); }
+    int run = (int)block_prefix_of(R.partial, blockIdx.x, sh);
+    __shared__ int s[4];
+    if (lane == 0) s[wv] = cnt;
+    __syncthreads();
+    for (int k = 0; k < wv; k++) run += s[k];
+    for (int r = 0; r < 8; r++) {
+        const i64 i = base + r * 64 + lane;
+        const u64 m = masks[r];
+        if ((m >> lane) & 1) {
+            const int o = run + __popcll(m & ((1ull << lane) - 1ull));
+            const int p = R.perm ? R.perm[i] : (int)i;
+            R.o_seg[o] = R.seg[p]; R.o_a[o] = R.a[p]; R.o_b[o] = R.b[p]; R.o_rid[o] = R.rid[p]; R.o_aux[o] = R.aux[p]; R.o_src[o] = p;
+        }
+        run += __popcll(m);
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) *R.n_out = run;
+}
+
+// effective aux key: aux sorts before pos only for INV (strand) and TRA (chr2, type) segments
+__global__ __launch_bounds__(256) void k_rebuild_auxkey(i64 n, const int* seg, const int* aux, const uint8_t* seg_aux_major, int* auxk)
+{
+    const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) auxk[i] = seg_aux_major[seg[i]] ? aux[i] : 0;
+}
+
+}  // namespace csv

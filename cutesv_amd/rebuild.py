@@ -1,0 +1,88 @@
+"""The rebuild step on the GPU: unsorted signature rows -> a `SigStore` in the order
+contract of cuteSV's process_process_sigs_type (main script :750-857).
+
+`rebuild_columns` is the thin face of `csv_rebuild_signatures` (stable LSD radix sort of a row permutation on
+(segment, [aux], pos, len/pos2, read id) + adjacent de-duplication, cutesv_amd/csrc/sort.hip.h);
+`store_from_unsorted` assembles the flat store from per-type unsorted columns the extraction step produced."""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+from ._lib import lib
+from .columns import SigStore, NameTable, TYPES
+
+
+class RebuildIn(C.Structure):
+    _fields_ = [("n", C.c_int64), ("n_seg", C.c_int32), ("reserved", C.c_int32), ("seg_aux_major", C.c_void_p),
+                ("seg_id", C.c_void_p), ("a", C.c_void_p), ("b", C.c_void_p), ("read_id", C.c_void_p), ("aux", C.c_void_p)]
+
+
+class RebuildOut(C.Structure):
+    _fields_ = [("n_out", C.c_int64), ("seg_id", C.c_void_p), ("a", C.c_void_p), ("b", C.c_void_p), ("read_id", C.c_void_p),
+                ("aux", C.c_void_p), ("src_row", C.c_void_p), ("ms_device", C.c_float), ("n_passes", C.c_int32)]
+
+
+def rebuild_columns(ctx, seg_id, a, b, read_id, aux, seg_aux_major):
+    """-> dict(seg_id, a, b, read_id, aux, src_row, ms_device, n_passes): sorted, de-duplicated rows"""
+    L = lib()
+    L.csv_rebuild_signatures.restype = C.c_int
+    L.csv_rebuild_signatures.argtypes = [C.c_void_p, C.POINTER(RebuildIn), C.POINTER(RebuildOut)]
+    seg_id = np.ascontiguousarray(seg_id, np.int32); a = np.ascontiguousarray(a, np.int64); b = np.ascontiguousarray(b, np.int64)
+    read_id = np.ascontiguousarray(read_id, np.int32); aux = np.ascontiguousarray(aux, np.int32)
+    major = np.ascontiguousarray(seg_aux_major, np.uint8)
+    n = len(a)
+    o = dict(seg_id=np.empty(n, np.int32), a=np.empty(n, np.int64), b=np.empty(n, np.int64), read_id=np.empty(n, np.int32),
+             aux=np.empty(n, np.int32), src_row=np.empty(n, np.int32))
+    rin = RebuildIn(n=n, n_seg=len(major), seg_aux_major=major.ctypes.data, seg_id=seg_id.ctypes.data, a=a.ctypes.data,
+                    b=b.ctypes.data, read_id=read_id.ctypes.data, aux=aux.ctypes.data)
+    rout = RebuildOut(seg_id=o["seg_id"].ctypes.data, a=o["a"].ctypes.data, b=o["b"].ctypes.data, read_id=o["read_id"].ctypes.data,
+                      aux=o["aux"].ctypes.data, src_row=o["src_row"].ctypes.data)
+    ctx._check(L.csv_rebuild_signatures(ctx._h, C.byref(rin), C.byref(rout)))
+    k = int(rout.n_out)
+    out = {key: v[:k] for key, v in o.items()}
+    out["ms_device"] = float(rout.ms_device)
+    out["n_passes"] = int(rout.n_passes)
+    return out
+
+
+def store_from_unsorted(ctx, chroms, per_type, names=None, strands=("++", "--"), reads=None):
+    """per_type: {"DEL": dict(chrom=int[], a=, b=, read_id=, aux=), ...} unsorted rows (chrom = index into `chroms`).
+    Segments come out in the reference's order: types as main_ctrl submits them, chromosomes by name.
+    `reads`: optional dict(chrom, start, end, primary, read_id) -> blocks sorted by start (numpy; the table is small next
+    to the signature sort and already nearly sorted by construction)."""
+    order = sorted(range(len(chroms)), key=lambda i: chroms[i])
+    crank = np.zeros(len(chroms), np.int64)
+    crank[order] = np.arange(len(chroms))
+    segs, cols = [], {k: [] for k in ("seg", "a", "b", "rid", "aux")}
+    for ti, t in enumerate(TYPES):
+        if t not in per_type or len(per_type[t]["a"]) == 0:
+            continue
+        d = per_type[t]
+        ch = np.asarray(d["chrom"], np.int64)
+        cols["seg"].append(ti * len(chroms) + crank[ch])
+        cols["a"].append(np.asarray(d["a"], np.int64)); cols["b"].append(np.asarray(d["b"], np.int64))
+        cols["rid"].append(np.asarray(d["read_id"], np.int64)); cols["aux"].append(np.asarray(d["aux"], np.int64))
+    cat = {k: np.concatenate(v) if v else np.zeros(0, np.int64) for k, v in cols.items()}
+    n_seg = len(TYPES) * len(chroms)
+    major = np.zeros(n_seg, np.uint8)
+    for ti, t in enumerate(TYPES):
+        if t in ("INV", "TRA"):
+            major[ti * len(chroms):(ti + 1) * len(chroms)] = 1
+    r = rebuild_columns(ctx, cat["seg"], cat["a"], cat["b"], cat["rid"], cat["aux"], major)
+    seg_sorted = r["seg_id"]
+    bounds = np.flatnonzero(np.r_[True, seg_sorted[1:] != seg_sorted[:-1], True]) if len(seg_sorted) else np.zeros(1, np.int64)
+    seg_index = {}
+    for i in range(len(bounds) - 1):
+        s = int(seg_sorted[bounds[i]])
+        seg_index[(TYPES[s // len(chroms)], chroms[order[s % len(chroms)]])] = (int(bounds[i]), int(bounds[i + 1]))
+    kw = {}
+    if reads is not None:
+        rc = np.asarray(reads["chrom"], np.int64)
+        o = np.lexsort((np.asarray(reads["start"]), rc))
+        off = np.searchsorted(rc[o], np.arange(len(chroms) + 1)).astype(np.int64)
+        kw = dict(reads_off=off, r_start=np.asarray(reads["start"], np.int64)[o], r_end=np.asarray(reads["end"], np.int64)[o],
+                  r_primary=np.asarray(reads["primary"], np.uint8)[o], r_id=np.asarray(reads["read_id"], np.int32)[o])
+    st = SigStore(chroms=list(chroms), a=r["a"], b=r["b"], read_id=r["read_id"], aux=r["aux"], seg_index=seg_index,
+                  names=names or NameTable(), strands=tuple(strands), **kw)
+    return st, r

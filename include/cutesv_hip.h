@@ -194,6 +194,42 @@ int32_t csv_gl_index(int64_t c0, int64_t c1);
 #define CSV_GL_TABLE_SIZE (101 * 101 + 2)
 
 /* ---------------------------------------------------------------------------------------------
+ * Rebuild step on the GPU: unsorted signature rows -> the order contract of
+ * process_process_sigs_type (cuteSV main script :750-857): rows sorted by
+ *   (segment, [aux for INV / TRA segments], a, b, read_id)           (:764-802 sort keys)
+ * with adjacent exact duplicates removed (:958-969).  `seg_id` is the caller's ordinal of the row's
+ * (SV type, chromosome) pair in the order the segments should come out; seg_aux_major[s] = 1 for INV and
+ * TRA segments (strand / chr2,type sort before the position).  Stable LSD radix sort of a row permutation,
+ * 8 bits per pass, zero bytes skipped; then gather + de-duplication.  Outputs are caller-allocated with
+ * room for n rows; src_row[i] = input row of output row i (to carry payloads such as INS sequences).
+ */
+typedef struct csv_rebuild_in {
+    int64_t        n;
+    int32_t        n_seg;
+    int32_t        reserved;
+    const uint8_t* seg_aux_major;   /* n_seg */
+    const int32_t* seg_id;
+    const int64_t* a;
+    const int64_t* b;
+    const int32_t* read_id;
+    const int32_t* aux;
+} csv_rebuild_in;
+
+typedef struct csv_rebuild_out {
+    int64_t  n_out;                 /* out */
+    int32_t* seg_id;
+    int64_t* a;
+    int64_t* b;
+    int32_t* read_id;
+    int32_t* aux;
+    int32_t* src_row;
+    float    ms_device;             /* out: kernels only (HIP events) */
+    int32_t  n_passes;              /* out: radix passes executed */
+} csv_rebuild_out;
+
+int csv_rebuild_signatures(csv_ctx* ctx, const csv_rebuild_in* in, csv_rebuild_out* out);
+
+/* ---------------------------------------------------------------------------------------------
  * Host-side VCF record emit: the structure-of-arrays result -> the text lines
  * of cuteSV's VCF body, without materialising Python row lists.  Replaces generate_output
  * (cuteSV_genotype.py:242-467: per-chromosome stable sort by POS, size filters, INFO/FORMAT

@@ -224,3 +224,37 @@ def test_input_order_contract_is_checked(ctx):
         with pytest.raises(engine.CsvError) as e:
             ctx.validate()
         assert e.value.code == _abi.E_UNSORTED
+
+
+def test_gpu_rebuild_reproduces_the_reference_order_contract(ctx):
+    """shuffled rows (+ injected exact duplicates) -> csv_rebuild_signatures == the store the tuple-sorting
+    rebuild (main script :764-802, :958-969 restated in SigStore.from_tuple_lists / numpy lexsort) gives"""
+    from cutesv_amd import rebuild
+    rng = np.random.default_rng(5)
+    for seed, kw in ((31, dict()), (32, dict(n_sites=120, coverage=60, n_noise=20000, n_loci=2000, dup_frac=0.3))):
+        st = synth.small_mixed(seed=seed, genotype=False, **kw)
+        per = {}
+        for (t, ch), (b, e) in st.seg_index.items():
+            d = per.setdefault(t, dict(chrom=[], a=[], b=[], read_id=[], aux=[]))
+            d["chrom"].append(np.full(e - b, st.chroms.index(ch))); d["a"].append(st.a[b:e]); d["b"].append(st.b[b:e])
+            d["read_id"].append(st.read_id[b:e])
+            d["aux"].append(st.aux[b:e] if t in ("INS", "INV", "TRA") else np.zeros(e - b, np.int32))
+        for t, d in per.items():
+            cols = {k: np.concatenate(v) for k, v in d.items()}
+            n = len(cols["a"])
+            dup = rng.integers(0, n, max(1, n // 20))                  # exact duplicates, as overlapping extraction windows make
+            perm = rng.permutation(n + len(dup))
+            per[t] = {k: np.concatenate([v, v[dup]])[perm] for k, v in cols.items()}
+        got, info = rebuild.store_from_unsorted(ctx, st.chroms, per)
+        assert info["n_passes"] >= 5
+        assert got.seg_index == st.seg_index
+        assert np.array_equal(got.a, st.a) and np.array_equal(got.b, st.b) and np.array_equal(got.read_id, st.read_id)
+        for (t, ch), (b, e) in st.seg_index.items():
+            if t in ("INS", "INV", "TRA"):
+                assert np.array_equal(got.aux[b:e], st.aux[b:e]), (t, ch)
+        # and the clustering result on the rebuilt store is the same as on the original
+        p = Params.ont()
+        x = ctx.cluster_batch(got.host_batch(got.tasks(), p)).trimmed()
+        y = ctx.cluster_batch(st.host_batch(st.tasks(), p)).trimmed()
+        for k in ("bp1", "bp2", "support", "cipos", "cilen", "support_sig"):
+            assert np.array_equal(x[k], y[k]), k
