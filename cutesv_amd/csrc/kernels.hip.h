@@ -471,14 +471,24 @@ __global__ __launch_bounds__(256) void k_select_apply(DevBatch B)
 //   V4 int   group of rank r, later per-group values
 //   V5 int   per-group values
 // The pointers are flat: LDS for P <= CAP, the cluster's own slice of the global scratch above.
-struct Arrays { u64* K; i64* X; int* V1; int* V2; int* V3; int* V4; int* V5; };
+// LDS = true: real local-address-space pointers (ds_read / ds_write); LDS = false: global scratch.  (A first
+// version reached both through flat pointers: every LDS access then took the slow FLAT path and the mid
+// tier spent ~25 cycles per instruction waiting on ~700 flat LDS round trips per cluster.)
+#define CSV_LDS __attribute__((address_space(3)))
+template <bool LDS> struct MemT;
+template <> struct MemT<true>  { typedef CSV_LDS u64* u64p; typedef CSV_LDS i64* i64p; typedef CSV_LDS const i64* ci64p; typedef CSV_LDS int* intp; };
+template <> struct MemT<false> { typedef u64* u64p; typedef i64* i64p; typedef const i64* ci64p; typedef int* intp; };
+template <bool LDS> struct ArraysT {
+    typename MemT<LDS>::u64p K; typename MemT<LDS>::i64p X;
+    typename MemT<LDS>::intp V1; typename MemT<LDS>::intp V2; typename MemT<LDS>::intp V3; typename MemT<LDS>::intp V4; typename MemT<LDS>::intp V5;
+};
 
 struct ItemCtx {
     int j, cid, k, s, m, P;
     i64 gsig0;             // global signature index of w = s
 };
 
-template <int BLOCK> __device__ void bitonic_sort(u64* K, int P)
+template <int BLOCK, class KP> __device__ void bitonic_sort(KP K, int P)
 {
     for (int k = 2; k <= P; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
@@ -524,7 +534,7 @@ template <int BLOCK> __device__ int block_incl_scan(int v, int* tot, i64* red)
 
 // numpy's pairwise summation over sq(i) = (v[i] - mean)^2, evaluated by ONE lane in numpy's exact
 // association order (oracle: pairwise_f64 / csvo_np_sum_f64).
-__device__ double np_sumsq_leaf(const i64* v, int n, double mean)
+template <class VP> __device__ double np_sumsq_leaf(VP v, int n, double mean)
 {
     if (n < 8) {
         double r = 0.0;
@@ -542,7 +552,7 @@ __device__ double np_sumsq_leaf(const i64* v, int n, double mean)
 }
 
 // explicit-stack form of  pw(a, n) = n <= 128 ? leaf : pw(a, n2) + pw(a + n2, n - n2),  n2 = n/2 - (n/2) % 8
-__device__ double np_sumsq_chunk(const i64* v, int n, double mean)
+template <class VP> __device__ double np_sumsq_chunk(VP v, int n, double mean)
 {
     if (n <= 128) return np_sumsq_leaf(v, n, mean);
     int s_off[16], s_n[16], s_state[16];
@@ -565,7 +575,7 @@ __device__ double np_sumsq_chunk(const i64* v, int n, double mean)
 }
 
 // np.std of the int64 values v[0..n) -> the integer of cal_CIPOS (GT:58-60)
-__device__ __noinline__ int cipos_of(const i64* v, int n, i64 sum, const double* sqrt_tab)
+template <class VP> __device__ __noinline__ int cipos_of(VP v, int n, i64 sum, const double* sqrt_tab)
 {
     const double mean = (double)sum / (double)n;
     double acc = 0.0;
@@ -598,7 +608,7 @@ __device__ __forceinline__ void item_none(const DevBatch& B, int j)
 
 // phase A: sort by (read id, local index); returns the number of distinct reads.
 // Leaves K sorted and V2[q] = local index at sorted position q.
-template <int BLOCK> __device__ int sort_by_read(const DevBatch& B, const ItemCtx& it, const Arrays& A, i64* red)
+template <int BLOCK, bool LDS> __device__ int sort_by_read(const DevBatch& B, const ItemCtx& it, const ArraysT<LDS>& A, i64* red)
 {
     for (int i = threadIdx.x; i < it.P; i += BLOCK)
         A.K[i] = i < it.m ? (((u64)(unsigned)B.rid[it.s + i]) << 32) | (unsigned)i : PAD_KEY;
@@ -616,11 +626,11 @@ template <int BLOCK> __device__ int sort_by_read(const DevBatch& B, const ItemCt
 }
 
 // ---- DEL / INS: generate_del_cluster / generate_ins_cluster (INDEL:110-219, 319-432)
-template <int BLOCK> __device__ void refine_indel(const DevBatch& B, const ItemCtx& it, const Arrays& A, i64* red, int* ired)
+template <int BLOCK, bool LDS> __device__ void refine_indel(const DevBatch& B, const ItemCtx& it, const ArraysT<LDS>& A, i64* red, int* ired)
 {
     const csv_segment& sg = B.seg[it.k];
     const int m = it.m, P = it.P, s = it.s;
-    const int U = sort_by_read<BLOCK>(B, it, A, red);
+    const int U = sort_by_read<BLOCK, LDS>(B, it, A, red);
     if (U < sg.read_count) { item_none(B, it.j); return; }                  // INDEL:133-134
 
     // per run of equal read id: first appearance F (smallest index) and the kept signature
@@ -700,7 +710,7 @@ template <int BLOCK> __device__ void refine_indel(const DevBatch& B, const ItemC
     double rr = sg.remain_reads_ratio; if (rr > 1) rr = 1;                  // INDEL:46-47
     const int is_ins = sg.svtype == CSV_INS;
     int ncalls = 0, nsup = 0;
-    const i64* PA = (const i64*)A.K; const i64* PB = A.X;
+    const typename MemT<LDS>::ci64p PA = (typename MemT<LDS>::ci64p)A.K; const typename MemT<LDS>::ci64p PB = A.X;
     for (int a = threadIdx.x >> 6; a < nA; a += BLOCK / 64) {
         const int rank = A.V3[a];
         if (rank < 0) continue;
@@ -783,7 +793,7 @@ template <int BLOCK> __device__ void refine_indel(const DevBatch& B, const ItemC
 }
 
 // compacted write of the first-seen signatures of ranks [r0, r1) to sup_tmp[dst...]; one wavefront
-__device__ __forceinline__ void write_first_seen(const DevBatch& B, const Arrays& A, int s, int r0, int r1, int dst)
+template <bool LDS> __device__ __forceinline__ void write_first_seen(const DevBatch& B, const ArraysT<LDS>& A, int s, int r0, int r1, int dst)
 {
     int run = 0;
     for (int base = r0; base < r1; base += 64) {
@@ -797,11 +807,11 @@ __device__ __forceinline__ void write_first_seen(const DevBatch& B, const Arrays
 
 // ---- DUP / INV / TRA: generate_dup_cluster (DUP:79-131), generate_semi_inv_cluster (INV:101-203),
 //      generate_semi_tra_cluster (TRA:106-254)
-template <int BLOCK> __device__ void refine_pair(const DevBatch& B, const ItemCtx& it, const Arrays& A, i64* red, int* ired)
+template <int BLOCK, bool LDS> __device__ void refine_pair(const DevBatch& B, const ItemCtx& it, const ArraysT<LDS>& A, i64* red, int* ired)
 {
     const csv_segment& sg = B.seg[it.k];
     const int m = it.m, P = it.P, s = it.s, type = sg.svtype;
-    const int U = sort_by_read<BLOCK>(B, it, A, red);                       // V2 = (read id, index) order
+    const int U = sort_by_read<BLOCK, LDS>(B, it, A, red);                       // V2 = (read id, index) order
     if (U < sg.read_count) { item_none(B, it.j); return; }                  // DUP:82-84, INV:106-109, TRA:128-129
 
     // stable sort by pos2 (DUP:86, INV:111, TRA:109): key = (pos2, local index)
@@ -863,7 +873,7 @@ template <int BLOCK> __device__ void refine_pair(const DevBatch& B, const ItemCt
         if (r == 0 || A.V4[r] != A.V4[r - 1]) A.V2[A.V4[r]] = r;
     if (threadIdx.x == 0) A.V2[nsub] = m;
     __syncthreads();
-    const i64* PA = (const i64*)A.K; const i64* PB = A.X;
+    const typename MemT<LDS>::ci64p PA = (typename MemT<LDS>::ci64p)A.K; const typename MemT<LDS>::ci64p PB = A.X;
     // unique reads per sub-cluster -> V3[k]
     for (int k = threadIdx.x >> 6; k < nsub; k += BLOCK / 64) {
         const int r0 = A.V2[k], r1 = A.V2[k + 1];
@@ -905,7 +915,7 @@ template <int BLOCK> __device__ void refine_pair(const DevBatch& B, const ItemCt
             s1 = wave_sum_i64(s1); s2 = wave_sum_i64(s2);
             int cnt = r1 - r0;
             if (k == 0) { s1 += PA[0]; s2 += PB[0]; cnt += 1; }             // element 0 is visited twice, TRA:114-124
-            write_first_seen(B, A, s, r0, r1, s + soff);
+            write_first_seen<LDS>(B, A, s, r0, r1, s + soff);
             if (lane_id() == 0) {
                 const int t = tbase + q;
                 B.t_bp1[t] = (i64)((double)s1 / (double)cnt);               // TRA:173
@@ -963,7 +973,7 @@ template <int BLOCK> __device__ void refine_pair(const DevBatch& B, const ItemCt
         }
         const i64 d = bp2 - bp1;
         const int valid = (d >= sg.sv_size) && (d <= sg.max_size || sg.max_size == -1); // DUP:112; INV:132-134
-        write_first_seen(B, A, s, r0, r1, s + A.V5[k]);
+        write_first_seen<LDS>(B, A, s, r0, r1, s + A.V5[k]);
         if (lane_id() == 0) {
             const int t = tbase + slot;
             B.t_bp1[t] = bp1; B.t_bp2[t] = bp2; B.t_support[t] = u; B.t_cipos[t] = 0; B.t_cilen[t] = 0;
@@ -988,12 +998,12 @@ template <int CAP> constexpr int refine_lds_bytes() { return LDS_LEAD + (CAP + A
 template <int BLOCK, int CAP> __global__ __launch_bounds__(BLOCK) void k_refine(DevBatch B, int big, int m_lo, int m_hi)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    char* smem = smem_raw + LDS_LEAD;
+    CSV_LDS char* smem = (CSV_LDS char*)smem_raw + LDS_LEAD;
     constexpr int N = CAP + ARR_PAD;
-    Arrays L;
-    L.K = (u64*)smem; L.X = (i64*)(smem + 8 * N);
-    L.V1 = (int*)(smem + 16 * N); L.V2 = L.V1 + N; L.V3 = L.V2 + N; L.V4 = L.V3 + N; L.V5 = L.V4 + N;
-    i64* red = (i64*)(smem + 36 * N);
+    ArraysT<true> L;
+    L.K = (CSV_LDS u64*)smem; L.X = (CSV_LDS i64*)(smem + 8 * N);
+    L.V1 = (CSV_LDS int*)(smem + 16 * N); L.V2 = L.V1 + N; L.V3 = L.V2 + N; L.V4 = L.V3 + N; L.V5 = L.V4 + N;
+    i64* red = (i64*)(smem_raw + LDS_LEAD + 36 * N);
     int* ired = (int*)(red + 6);
     const int n = big ? B.cnt->n_items_big : (B.cnt->n_items - B.cnt->n_items_big);
     for (int q = blockIdx.x; q < n; q += gridDim.x) {
@@ -1013,15 +1023,20 @@ template <int BLOCK, int CAP> __global__ __launch_bounds__(BLOCK) void k_refine(
             item_none(B, it.j);
             continue;
         }
-        Arrays A = L;
-        if (P > CAP) {
-            const i64 o = 2ll * it.s;
-            A.K = B.sc_k + o; A.X = B.sc_x + o; A.V1 = B.sc_v1 + o; A.V2 = B.sc_v2 + o; A.V3 = B.sc_v3 + o;
-            A.V4 = B.sc_v4 + o; A.V5 = B.sc_v5 + o;
-        }
         const int t = B.seg[it.k].svtype;
-        if (t == CSV_DEL || t == CSV_INS) refine_indel<BLOCK>(B, it, A, red, ired);
-        else refine_pair<BLOCK>(B, it, A, red, ired);
+        const bool indel = t == CSV_DEL || t == CSV_INS;
+        if (P <= CAP) {
+            if (indel) refine_indel<BLOCK, true>(B, it, L, red, ired);
+            else refine_pair<BLOCK, true>(B, it, L, red, ired);
+        } else {
+            // cluster larger than the LDS tier: its own [2s, 2s + P) slice of the global scratch
+            ArraysT<false> G;
+            const i64 o = 2ll * it.s;
+            G.K = B.sc_k + o; G.X = B.sc_x + o; G.V1 = B.sc_v1 + o; G.V2 = B.sc_v2 + o; G.V3 = B.sc_v3 + o;
+            G.V4 = B.sc_v4 + o; G.V5 = B.sc_v5 + o;
+            if (indel) refine_indel<BLOCK, false>(B, it, G, red, ired);
+            else refine_pair<BLOCK, false>(B, it, G, red, ired);
+        }
     }
 }
 
