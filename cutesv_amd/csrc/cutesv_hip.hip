@@ -370,7 +370,7 @@ int csv_batch_run(csv_ctx* c, csv_run_stats* stats)
         LAUNCH("refine_indel_wave", k_refine_indel_wave, g_iw, 256, 0, B);
         if (c->any_pair) LAUNCH_ON(sC, "refine_wave", (k_refine<64, 64>), g_small, 64, LDS_SMALL, B, 0, 0, 64);
         else HIP_TRY(c, mark());
-        int g_mid = B.cap_items < 4096 ? B.cap_items : 4096;
+        int g_mid = B.cap_items < 8192 ? B.cap_items : 8192;
         if (g_mid < 1) g_mid = 1;
         LAUNCH_ON(sB, "refine_mid", (k_refine<64, 256>), g_mid, 64, LDS_MID, B, 1, 64, 256);
         int g_big = B.cap_items < 512 ? B.cap_items : 512;

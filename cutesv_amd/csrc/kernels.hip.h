@@ -995,7 +995,10 @@ template <int CAP> constexpr int refine_lds_bytes() { return LDS_LEAD + (CAP + A
 
 // `big` selects the work list; items whose size is outside (m_lo, m_hi] are left to another launch
 // (small list: DEL/INS go to k_refine_indel_wave; big list: a one-wavefront mid tier and the workgroup tier).
-template <int BLOCK, int CAP> __global__ __launch_bounds__(BLOCK) void k_refine(DevBatch B, int big, int m_lo, int m_hi)
+#ifndef CSV_RF_WAVES
+#define CSV_RF_WAVES 4
+#endif
+template <int BLOCK, int CAP> __global__ __launch_bounds__(BLOCK, (BLOCK == 64 ? CSV_RF_WAVES : 1)) void k_refine(DevBatch B, int big, int m_lo, int m_hi)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     CSV_LDS char* smem = (CSV_LDS char*)smem_raw + LDS_LEAD;
