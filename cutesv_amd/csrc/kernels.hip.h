@@ -118,6 +118,12 @@ __device__ __forceinline__ i64 shfl_xor_i64(i64 v, int m)
     return ((i64)hi << 32) | (unsigned)lo;
 }
 __device__ __forceinline__ double shfl_xor_f64(double v, int m) { return __longlong_as_double(shfl_xor_i64(__double_as_longlong(v), m)); }
+__device__ __forceinline__ i64 readlane_i64x(i64 v, int l)
+{
+    const int lo = __builtin_amdgcn_readlane((int)(v & 0xffffffffll), l);
+    const int hi = __builtin_amdgcn_readlane((int)(v >> 32), l);
+    return ((i64)hi << 32) | (unsigned)lo;
+}
 // ---- wave64 scans / reductions on DPP (data-parallel primitives: row_shr inside rows of 16 lanes, then
 // row_bcast:15 / row_bcast:31 across rows): 6 VALU moves per 32-bit word, no LDS round trips, no waitcnt.
 template <int CTRL, int RM> __device__ __forceinline__ int dpp_i32(int old, int v)
@@ -551,37 +557,43 @@ template <class VP> __device__ double np_sumsq_leaf(VP v, int n, double mean)
     return res;
 }
 
-// explicit-stack form of  pw(a, n) = n <= 128 ? leaf : pw(a, n2) + pw(a + n2, n - n2),  n2 = n/2 - (n/2) % 8
-template <class VP> __device__ double np_sumsq_chunk(VP v, int n, double mean)
+// explicit-stack form of  pw(a, n) = n <= 128 ? leaf : pw(a, n2) + pw(a + n2, n - n2),  n2 = n/2 - (n/2) % 8.
+// The stack (5 ints per level: offset, length, state, partial sum lo/hi) lives in the cluster's own working
+// memory (LDS or global scratch), not in private arrays, so the kernel needs no scratch segment.
+template <class VP, class IP> __device__ double np_sumsq_chunk(VP v, int n, double mean, IP stk)
 {
     if (n <= 128) return np_sumsq_leaf(v, n, mean);
-    int s_off[16], s_n[16], s_state[16];
-    double s_left[16];
     int sp = 0;
-    s_off[0] = 0; s_n[0] = n; s_state[0] = 0; s_left[0] = 0.0;
+    stk[0] = 0; stk[1] = n; stk[2] = 0;
     double ret = 0.0;
     while (sp >= 0) {
-        if (s_n[sp] <= 128) { ret = np_sumsq_leaf(v + s_off[sp], s_n[sp], mean); sp--; continue; }
-        int n2 = s_n[sp] / 2; n2 -= n2 % 8;
-        if (s_state[sp] == 0) {
-            s_state[sp] = 1;
-            s_off[sp + 1] = s_off[sp]; s_n[sp + 1] = n2; s_state[sp + 1] = 0; sp++;
-        } else if (s_state[sp] == 1) {
-            s_left[sp] = ret; s_state[sp] = 2;
-            s_off[sp + 1] = s_off[sp] + n2; s_n[sp + 1] = s_n[sp] - n2; s_state[sp + 1] = 0; sp++;
-        } else { ret = s_left[sp] + ret; sp--; }
+        const int off = stk[5 * sp], len = stk[5 * sp + 1], state = stk[5 * sp + 2];
+        if (len <= 128) { ret = np_sumsq_leaf(v + off, len, mean); sp--; continue; }
+        int n2 = len / 2; n2 -= n2 % 8;
+        if (state == 0) {
+            stk[5 * sp + 2] = 1;
+            stk[5 * sp + 5] = off; stk[5 * sp + 6] = n2; stk[5 * sp + 7] = 0; sp++;
+        } else if (state == 1) {
+            const i64 bits = __double_as_longlong(ret);
+            stk[5 * sp + 3] = (int)(bits & 0xffffffffll); stk[5 * sp + 4] = (int)(bits >> 32); stk[5 * sp + 2] = 2;
+            stk[5 * sp + 5] = off + n2; stk[5 * sp + 6] = len - n2; stk[5 * sp + 7] = 0; sp++;
+        } else {
+            const i64 bits = ((i64)stk[5 * sp + 4] << 32) | (unsigned)stk[5 * sp + 3];
+            ret = __longlong_as_double(bits) + ret; sp--;
+        }
     }
     return ret;
 }
 
-// np.std of the int64 values v[0..n) -> the integer of cal_CIPOS (GT:58-60)
-template <class VP> __device__ __noinline__ int cipos_of(VP v, int n, i64 sum, const double* sqrt_tab)
+// np.std of the int64 values v[0..n) -> the integer of cal_CIPOS (GT:58-60); one lane, any n
+constexpr int CIPOS_STACK_INTS = 5 * 16;
+template <class VP, class IP> __device__ int cipos_of(VP v, int n, i64 sum, const double* sqrt_tab, IP stk)
 {
     const double mean = (double)sum / (double)n;
     double acc = 0.0;
     for (int off = 0; off < n; off += 8192) {
         const int c = n - off < 8192 ? n - off : 8192;
-        acc += np_sumsq_chunk(v + off, c, mean);
+        acc += np_sumsq_chunk(v + off, c, mean, stk);
     }
     const double sd = sqrt(acc / (double)n);
     const double rt = n < SQRT_TAB ? sqrt_tab[n] : sqrt((double)n);
@@ -596,6 +608,48 @@ __device__ __forceinline__ void item_done(const DevBatch& B, int j, int nslots, 
     B.item_nslots[j] = nslots;
     B.item_cnt[j] = ((i64)ncalls << 32) + (i64)nsup;
 }
+// The same np.std / cal_CIPOS for n <= 256, computed by a whole wavefront from values held in LDS: numpy's
+// recursion has at most three leaves there (n -> n2 = (n/2) & ~7 and n - n2 <= 135 -> 64 + <= 71); each leaf is
+// summed by an 8-lane group (lane j = accumulator j of numpy's 8-way unrolled loop), then numpy's fixed combine
+// tree and sequential tail.  Every lane returns the result.  No private arrays, no call: the one-wavefront tiers
+// stay free of scratch.
+template <class VP> __device__ __forceinline__ int cipos_wave(VP v, int n, i64 sum, const double* sqrt_tab)
+{
+    const int lane = lane_id(), g = lane >> 3, j = lane & 7;
+    const double mean = (double)sum / (double)n;
+    int off0 = 0, len0 = n, off1 = 0, len1 = 0, off2 = 0, len2 = 0, cnt = 1;
+    if (n > 128) {
+        int n2 = n / 2; n2 -= n2 % 8;
+        len0 = n2; off1 = n2; len1 = n - n2; cnt = 2;
+        if (len1 > 128) { int m2 = len1 / 2; m2 -= m2 % 8; off2 = off1 + m2; len2 = len1 - m2; len1 = m2; cnt = 3; }
+    }
+    const int off = g == 0 ? off0 : (g == 1 ? off1 : off2);
+    const int len = g == 0 ? len0 : (g == 1 ? len1 : (g == 2 ? len2 : 0));
+    const bool act = g < cnt;
+    const int nfull = len - (len & 7);
+    double acc = 0.0;
+    if (act && len >= 8) { const double x = (double)v[off + j] - mean; acc = x * x; }
+    for (int t = 1; t < 16; t++) {                                   // leaves hold <= 128 values
+        if (!__ballot(act && len >= 8 && 8 * t < nfull)) break;
+        if (act && len >= 8 && 8 * t < nfull) { const double x = (double)v[off + 8 * t + j] - mean; acc += x * x; }
+    }
+    const double t1 = acc + shfl_xor_f64(acc, 1);
+    const double t2 = t1 + shfl_xor_f64(t1, 2);
+    const double t3 = t2 + shfl_xor_f64(t2, 4);
+    double res = (len >= 8) ? t3 : 0.0;
+    const int start = (len >= 8) ? nfull : 0;
+    for (int e = 0; e < 7; e++) {
+        if (!__ballot(act && j == 0 && start + e < len)) break;
+        if (act && j == 0 && start + e < len) { const double x = (double)v[off + start + e] - mean; res += x * x; }
+    }
+    const double l0 = __longlong_as_double(readlane_i64x(__double_as_longlong(res), 0));
+    const double l1 = __longlong_as_double(readlane_i64x(__double_as_longlong(res), 8));
+    const double l2 = __longlong_as_double(readlane_i64x(__double_as_longlong(res), 16));
+    const double tot = cnt == 1 ? l0 : (cnt == 2 ? l0 + l1 : l0 + (l1 + l2));
+    const double sd = sqrt(tot / (double)n);
+    return (int)(1.96 * sd / sqrt_tab[n]);
+}
+
 __device__ __forceinline__ void item_none(const DevBatch& B, int j)
 {
     if (threadIdx.x == 0) item_done(B, j, 0, 0, 0);
@@ -626,7 +680,7 @@ template <int BLOCK, bool LDS> __device__ int sort_by_read(const DevBatch& B, co
 }
 
 // ---- DEL / INS: generate_del_cluster / generate_ins_cluster (INDEL:110-219, 319-432)
-template <int BLOCK, bool LDS> __device__ void refine_indel(const DevBatch& B, const ItemCtx& it, const ArraysT<LDS>& A, i64* red, int* ired)
+template <int BLOCK, bool LDS, bool SMALLN> __device__ void refine_indel(const DevBatch& B, const ItemCtx& it, const ArraysT<LDS>& A, i64* red, int* ired)
 {
     const csv_segment& sg = B.seg[it.k];
     const int m = it.m, P = it.P, s = it.s;
@@ -754,9 +808,13 @@ template <int BLOCK, bool LDS> __device__ void refine_indel(const DevBatch& B, c
             bp = (double)ks / (double)keep; siglen = (double)kl / (double)keep; search = sr;   // INDEL:176-177,187
         }
         int cip = 0, cil = 0;
-        if (lane_id() == 0) {
-            cip = cipos_of(PA + r0, n, sp, B.sqrt_tab);                      // INDEL:191
-            cil = cipos_of(PB + r0, n, sl, B.sqrt_tab);                      // INDEL:194
+        if (SMALLN) {                                                       // n <= 256: whole wavefront, no scratch
+            cip = cipos_wave(PA + r0, n, sp, B.sqrt_tab);                    // INDEL:191
+            cil = cipos_wave(PB + r0, n, sl, B.sqrt_tab);                    // INDEL:194
+        } else if (lane_id() == 0) {                                          // V5 is free on the DEL/INS path: per-wavefront stack
+            const typename MemT<LDS>::intp stk = A.V5 + (threadIdx.x >> 6) * CIPOS_STACK_INTS;
+            cip = cipos_of(PA + r0, n, sp, B.sqrt_tab, stk);
+            cil = cipos_of(PB + r0, n, sl, B.sqrt_tab, stk);
         }
         i64 pick = -1; int valid = 1;
         if (is_ins) {                                                       // INDEL:398-405
@@ -1029,15 +1087,20 @@ template <int BLOCK, int CAP> __global__ __launch_bounds__(BLOCK, (BLOCK == 64 ?
         const int t = B.seg[it.k].svtype;
         const bool indel = t == CSV_DEL || t == CSV_INS;
         if (P <= CAP) {
-            if (indel) refine_indel<BLOCK, true>(B, it, L, red, ired);
+            if (indel) refine_indel<BLOCK, true, (CAP <= 256)>(B, it, L, red, ired);
             else refine_pair<BLOCK, true>(B, it, L, red, ired);
+        } else if constexpr (CAP <= 256) {
+            // the one-wavefront tiers are only launched for m <= CAP; keeping the global-scratch path (and its
+            // serial np.std routine with a private stack) out of them keeps these kernels free of scratch
+            if (threadIdx.x == 0) atomicOr(&B.cnt->error, ERR_CLUSTER_TOO_BIG);
+            item_none(B, it.j);
         } else {
             // cluster larger than the LDS tier: its own [2s, 2s + P) slice of the global scratch
             ArraysT<false> G;
             const i64 o = 2ll * it.s;
             G.K = B.sc_k + o; G.X = B.sc_x + o; G.V1 = B.sc_v1 + o; G.V2 = B.sc_v2 + o; G.V3 = B.sc_v3 + o;
             G.V4 = B.sc_v4 + o; G.V5 = B.sc_v5 + o;
-            if (indel) refine_indel<BLOCK, false>(B, it, G, red, ired);
+            if (indel) refine_indel<BLOCK, false, false>(B, it, G, red, ired);
             else refine_pair<BLOCK, false>(B, it, G, red, ired);
         }
     }
