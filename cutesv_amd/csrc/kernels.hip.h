@@ -211,7 +211,7 @@ __device__ __forceinline__ int seg_of_wave(const DevBatch& B, i64 w)
 // flag[w] = 1 when w starts a new chained cluster: first of its segment, the type's break predicate
 // against the previous signature, or the previous signature is a (0,0) look-alike of the reference's
 // sentinel (see oracle csvo_cluster_batch).
-__device__ __forceinline__ int chain_flag(const DevBatch& B, i64 w, int& seg_hint, i64& a0)
+__device__ __forceinline__ int chain_flag(const DevBatch& B, i64 w, int& seg_hint, i64& a0, int k_last)
 {
     // all 64 lanes of a row call this together (w = row base + lane); out-of-range lanes pass w >= W
     const bool in = w < B.W;
@@ -219,8 +219,11 @@ __device__ __forceinline__ int chain_flag(const DevBatch& B, i64 w, int& seg_hin
     a0 = wave_shr1_i64(a1);
     if (lane_id() == 0 && in && w > 0) a0 = B.a[w - 1];
     if (!in) return 0;
+    // a lane's w only grows from row to row, so its segment is found by walking forward from the last one
+    // (bounded by the segment of the span's last signature): no binary search over the segment table
     int k = seg_hint;
-    if (w < B.woff[k] || w >= B.woff[k + 1]) { k = seg_of(B, w); seg_hint = k; }
+    while (k < k_last && w >= B.woff[k + 1]) k++;
+    seg_hint = k;
     if (w == B.woff[k]) return 1;
     const csv_segment& sg = B.seg[k];
     const i64 bias = sg.max_cluster_bias;
@@ -238,11 +241,11 @@ constexpr int CH_TILE = 256 * CH_ITEMS;             // signatures per workgroup
 // segment (almost always) the segment scalars sit in SGPRs and the 8 row loads are issued back to
 // back; the neighbour value comes from the lane to the left.  zprev[r] marks cluster starts whose
 // preceding signature is a (0,0) element.
-__device__ __forceinline__ int chain_rows(const DevBatch& B, i64 base, u64 (&masks)[CH_ITEMS], int (&zprev)[CH_ITEMS])
+__device__ __forceinline__ int chain_rows(const DevBatch& B, i64 base, u64 (&masks)[CH_ITEMS], int (&zprev)[CH_ITEMS], int (&ksg)[CH_ITEMS])
 {
     const int lane = lane_id();
 #pragma unroll
-    for (int r = 0; r < CH_ITEMS; r++) { masks[r] = 0; zprev[r] = 0; }
+    for (int r = 0; r < CH_ITEMS; r++) { masks[r] = 0; zprev[r] = 0; ksg[r] = 0; }
     if (base >= B.W) return -1;
     const i64 lastw = (base + WAVE * CH_ITEMS - 1 < B.W) ? base + WAVE * CH_ITEMS - 1 : B.W - 1;
     const int k0 = __builtin_amdgcn_readfirstlane(seg_of_wave(B, base)), k1 = __builtin_amdgcn_readfirstlane(seg_of_wave(B, lastw));
@@ -252,12 +255,15 @@ __device__ __forceinline__ int chain_rows(const DevBatch& B, i64 base, u64 (&mas
         for (int r = 0; r < CH_ITEMS; r++) {
             const i64 w = base + r * WAVE + lane;
             i64 a0;
-            const int f = chain_flag(B, w, seg_hint, a0);
+            const int f = chain_flag(B, w, seg_hint, a0, k1);
+            ksg[r] = seg_hint;
             zprev[r] = (f && w > 0 && a0 == 0 && B.b[w - 1] == 0) ? 1 : 0;
             masks[r] = __ballot(f);
         }
         return -1;
     }
+#pragma unroll
+    for (int r = 0; r < CH_ITEMS; r++) ksg[r] = k0;
     const csv_segment& sg = B.seg[k0];
     const i64 bias = sg.max_cluster_bias, seg_first = B.woff[k0];
     const int type = sg.svtype;
@@ -317,8 +323,8 @@ __global__ __launch_bounds__(256) void k_chain_count(DevBatch B)
     // first kernel of a run: nothing in this kernel reads the counters, every later kernel is stream-ordered behind it
     if (blockIdx.x == 0 && threadIdx.x < (int)(sizeof(DevCounters) / 4)) ((int*)B.cnt)[threadIdx.x] = 0;
     const i64 base = (i64)blockIdx.x * CH_TILE + (threadIdx.x >> 6) * (WAVE * CH_ITEMS);
-    u64 masks[CH_ITEMS]; int zprev[CH_ITEMS];
-    chain_rows(B, base, masks, zprev);
+    u64 masks[CH_ITEMS]; int zprev[CH_ITEMS], ksg[CH_ITEMS];
+    chain_rows(B, base, masks, zprev, ksg);
     int cnt = 0;
 #pragma unroll
     for (int r = 0; r < CH_ITEMS; r++) cnt += __popcll(masks[r]);
@@ -334,8 +340,8 @@ __global__ __launch_bounds__(256) void k_chain_apply(DevBatch B)
     const int wv = threadIdx.x >> 6;
     const i64 base = (i64)blockIdx.x * CH_TILE + wv * (WAVE * CH_ITEMS);
     u64 masks[CH_ITEMS];
-    int zprev[CH_ITEMS];                // the element before a cluster start is the last element of the previous cluster
-    const int kuni = chain_rows(B, base, masks, zprev);
+    int zprev[CH_ITEMS], ksg[CH_ITEMS]; // the element before a cluster start is the last element of the previous cluster
+    chain_rows(B, base, masks, zprev, ksg);
     int cnt = 0;
 #pragma unroll
     for (int r = 0; r < CH_ITEMS; r++) cnt += __popcll(masks[r]);
@@ -346,7 +352,6 @@ __global__ __launch_bounds__(256) void k_chain_apply(DevBatch B)
     __syncthreads();
     for (int k = 0; k < wv; k++) run += s[k];
     const int my_total = s[0] + s[1] + s[2] + s[3];
-    int seg_w = kuni >= 0 ? kuni : 0;                   // segment of the row element (hint walks forward with w)
 #pragma unroll
     for (int r = 0; r < CH_ITEMS; r++) {
         const i64 w = base + r * WAVE + lane_id();
@@ -355,11 +360,7 @@ __global__ __launch_bounds__(256) void k_chain_apply(DevBatch B)
             const int cid = run + __popcll(m & (lanemask_lt() | (1ull << lane_id()))) - 1;
             B.cluster_id[w] = cid;
             B.allele_id[w] = -1;
-            if ((m >> lane_id()) & 1) {
-                if (w < B.woff[seg_w] || w >= B.woff[seg_w + 1]) seg_w = seg_of(B, w);
-                B.cstart[cid] = (int)w | (zprev[r] << 31);
-                B.cseg[cid] = seg_w;
-            }
+            if ((m >> lane_id()) & 1) { B.cstart[cid] = (int)w | (zprev[r] << 31); B.cseg[cid] = ksg[r]; }
         }
         run += __popcll(m);
     }
