@@ -495,8 +495,74 @@ struct ItemCtx {
     i64 gsig0;             // global signature index of w = s
 };
 
+// One-wavefront tiers: the whole sort runs in registers.  Lane l holds elements l, l + 64, ... (E per lane);
+// partners at distance >= 64 are in the same lane, partners at distance < 64 sit in lane l ^ j and are
+// exchanged with DPP (quad_perm for 1 and 2, row_ror:8 for 8) or ds_bpermute — no LDS arrays, no barriers
+// between the stages.
+template <int J> __device__ __forceinline__ u64 xor_lane_u64(u64 v)
+{
+    int lo = (int)(v & 0xffffffffull), hi = (int)(v >> 32);
+    if (J == 1) { lo = __builtin_amdgcn_update_dpp(lo, lo, 0xB1, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0xB1, 0xf, 0xf, false); }
+    else if (J == 2) { lo = __builtin_amdgcn_update_dpp(lo, lo, 0x4E, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x4E, 0xf, 0xf, false); }
+    else if (J == 8) { lo = __builtin_amdgcn_update_dpp(lo, lo, 0x128, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x128, 0xf, 0xf, false); }
+    else { lo = __shfl_xor(lo, J); hi = __shfl_xor(hi, J); }
+    return ((u64)(unsigned)hi << 32) | (unsigned)lo;
+}
+template <int E, int J> __device__ __forceinline__ void bitonic_step_lanes(u64 (&k)[E], int kk)
+{
+    const int lane = lane_id();
+    const bool lower = (lane & J) == 0;
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const u64 other = xor_lane_u64<J>(k[e]);
+        const bool asc = ((e * 64 + lane) & kk) == 0;
+        const u64 mn = k[e] < other ? k[e] : other, mx = k[e] < other ? other : k[e];
+        k[e] = (lower == asc) ? mn : mx;
+    }
+}
+template <int E> __device__ __forceinline__ void bitonic_wave(u64 (&k)[E])
+{
+    const int lane = lane_id();
+    for (int kk = 2; kk <= 64 * E; kk <<= 1) {
+        for (int j = kk >> 1; j >= 64; j >>= 1) {            // same-lane partners
+            const int de = j >> 6;
+#pragma unroll
+            for (int e = 0; e < E; e++)
+                if ((e & de) == 0 && (e | de) < E) {
+                    const bool asc = ((e * 64 + lane) & kk) == 0;
+                    const u64 x = k[e], y = k[e | de];
+                    if ((x > y) == asc) { k[e] = y; k[e | de] = x; }
+                }
+        }
+        const int j0 = kk >> 1 < 32 ? kk >> 1 : 32;
+        if (j0 >= 32) bitonic_step_lanes<E, 32>(k, kk);
+        if (j0 >= 16) bitonic_step_lanes<E, 16>(k, kk);
+        if (j0 >= 8) bitonic_step_lanes<E, 8>(k, kk);
+        if (j0 >= 4) bitonic_step_lanes<E, 4>(k, kk);
+        if (j0 >= 2) bitonic_step_lanes<E, 2>(k, kk);
+        bitonic_step_lanes<E, 1>(k, kk);
+    }
+}
+template <int E, class KP> __device__ __forceinline__ void bitonic_wave_mem(KP K, int P)
+{
+    const int lane = lane_id();
+    u64 k[E];
+#pragma unroll
+    for (int e = 0; e < E; e++) k[e] = (e * 64 + lane < P) ? K[e * 64 + lane] : PAD_KEY;
+    bitonic_wave<E>(k);
+#pragma unroll
+    for (int e = 0; e < E; e++) if (e * 64 + lane < P) K[e * 64 + lane] = k[e];
+}
+
 template <int BLOCK, class KP> __device__ void bitonic_sort(KP K, int P)
 {
+    if (BLOCK == 64 && P <= 256) {                    // callers synchronised before; the results are visible after this barrier
+        if (P <= 64) bitonic_wave_mem<1>(K, P);
+        else if (P <= 128) bitonic_wave_mem<2>(K, P);
+        else bitonic_wave_mem<4>(K, P);
+        __syncthreads();
+        return;
+    }
     for (int k = 2; k <= P; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
             for (int i = threadIdx.x; i < P; i += BLOCK) {
