@@ -44,7 +44,7 @@ struct csv_ctx {
     Buf sc_k, sc_x, sc_v1, sc_v2, sc_v3, sc_v4, sc_v5;
     Buf o_seg, o_cluster, o_aux, o_bp1, o_bp2, o_support, o_cipos, o_cilen, o_search, o_pick, o_dr, o_dv, o_gl;
     Buf o_supoff, o_supsig, o_suprid, allele_id;
-    Buf reads_off, r_start, r_end, r_primary, r_id, r_pmax, pm_partial;
+    Buf reads_off, r_start, r_end, r_primary, r_id, r_pmax, pm_partial, gt_over;
     Buf sqrt_tab, cnt;
     Buf rb_seg, rb_a, rb_b, rb_rid, rb_aux, rb_auxk, rb_major, rb_perm0, rb_perm1, rb_hist, rb_tot, rb_partial;
     Buf rb_oseg, rb_oa, rb_ob, rb_orid, rb_oaux, rb_osrc;
@@ -159,7 +159,7 @@ void csv_ctx_destroy(csv_ctx* c)
                   &c->t_support, &c->t_cipos, &c->t_cilen, &c->t_supoff, &c->t_valid, &c->sc_k, &c->sc_x, &c->sc_v1, &c->sc_v2,
                   &c->sc_v3, &c->sc_v4, &c->sc_v5, &c->o_seg, &c->o_cluster, &c->o_aux, &c->o_bp1, &c->o_bp2, &c->o_support,
                   &c->o_cipos, &c->o_cilen, &c->o_search, &c->o_pick, &c->o_dr, &c->o_dv, &c->o_gl, &c->o_supoff, &c->o_supsig,
-                  &c->o_suprid, &c->allele_id, &c->reads_off, &c->r_start, &c->r_end, &c->r_primary, &c->r_id, &c->r_pmax, &c->pm_partial,
+                  &c->o_suprid, &c->allele_id, &c->reads_off, &c->r_start, &c->r_end, &c->r_primary, &c->r_id, &c->r_pmax, &c->pm_partial, &c->gt_over,
                   &c->sqrt_tab, &c->cnt, &c->rb_seg, &c->rb_a, &c->rb_b, &c->rb_rid, &c->rb_aux, &c->rb_auxk, &c->rb_major,
                   &c->rb_perm0, &c->rb_perm1, &c->rb_hist, &c->rb_tot, &c->rb_partial, &c->rb_oseg, &c->rb_oa, &c->rb_ob,
                   &c->rb_orid, &c->rb_oaux, &c->rb_osrc};
@@ -243,7 +243,7 @@ int csv_batch_upload(csv_ctx* c, const csv_batch_in* in)
     RES(o_dr, cap_tmp * 4); RES(o_dv, cap_tmp * 4); RES(o_gl, cap_tmp * 4); RES(o_supoff, (cap_tmp + 1) * 8);
     RES(o_supsig, (W + 1) * 8); RES(o_suprid, (W + 1) * 4);
     if (R > 0) {
-        RES(pm_partial, (div_up(R, PM_TILE) + 2) * 8);
+        RES(pm_partial, (div_up(R, PM_TILE) + 2) * 8); RES(gt_over, (cap_tmp + 2) * 4);
         RES(reads_off, (in->n_chrom + 1) * 8); RES(r_start, R * 8); RES(r_end, R * 8); RES(r_primary, R); RES(r_id, R * 4); RES(r_pmax, R * 8);
     }
 
@@ -291,7 +291,7 @@ int csv_batch_upload(csv_ctx* c, const csv_batch_in* in)
     B.o_search = dp<i64>(c->o_search); B.o_pick = dp<i64>(c->o_pick); B.o_dr = dp<int>(c->o_dr); B.o_dv = dp<int>(c->o_dv); B.o_gl = dp<int>(c->o_gl);
     B.o_supoff = dp<i64>(c->o_supoff); B.o_supsig = dp<i64>(c->o_supsig); B.o_suprid = dp<int>(c->o_suprid); B.allele_id = dp<int>(c->allele_id);
     B.reads_off = dp<i64>(c->reads_off); B.n_reads = R;
-    B.r_start = dp<i64>(c->r_start); B.r_end = dp<i64>(c->r_end); B.r_primary = dp<uint8_t>(c->r_primary); B.r_id = dp<int>(c->r_id); B.r_pmax = dp<i64>(c->r_pmax); B.pm_partial = dp<i64>(c->pm_partial);
+    B.r_start = dp<i64>(c->r_start); B.r_end = dp<i64>(c->r_end); B.r_primary = dp<uint8_t>(c->r_primary); B.r_id = dp<int>(c->r_id); B.r_pmax = dp<i64>(c->r_pmax); B.pm_partial = dp<i64>(c->pm_partial); B.gt_over = dp<int>(c->gt_over);
     B.sqrt_tab = dp<double>(c->sqrt_tab); B.cnt = dp<DevCounters>(c->cnt);
     c->n_sig_host = in->n_sig;
     c->uploaded = true;
@@ -390,7 +390,10 @@ int csv_batch_run(csv_ctx* c, csv_run_stats* stats)
                 LAUNCH("pmax_scan", k_pmax_scan, 1, 256, 0, B.pm_partial, nr);
                 LAUNCH("pmax_apply", k_pmax_apply, nr, 256, 0, B);
             }
-            LAUNCH("genotype", k_genotype, 1024, 256, 0, B);
+            hipLaunchKernelGGL((k_genotype<1024, 4>), dim3(2048), dim3(256), 0, st, B, 0);
+            hipLaunchKernelGGL((k_genotype<8192, 1>), dim3(256), dim3(64), 0, st, B, 1);      // overflow list of the first pass
+            DBG("genotype");
+            HIP_TRY(c, mark());
         }
     }
 #undef LAUNCH
@@ -444,7 +447,7 @@ int csv_batch_download(csv_ctx* c, csv_batch_out* out)
     if (k.error & ERR_READS_UNSORTED) return fail(c, CSV_E_UNSORTED, "a reads block is not sorted by start");
     if (k.error & ERR_CLUSTER_TOO_BIG) return fail(c, CSV_E_INVALID, "a chained cluster has more than %lld signatures", (long long)MAX_CLUSTER);
     if (k.error & ERR_KEY_RANGE) return fail(c, CSV_E_INVALID, "a length / pos2 value is negative or >= 2^42");
-    if (k.error & ERR_COVER_OVERFLOW) return fail(c, CSV_E_INVALID, "support + cover set of a call exceeds %d reads", GT_HASH_FILL);
+    if (k.error & ERR_COVER_OVERFLOW) return fail(c, CSV_E_INVALID, "support + cover set of a call exceeds ~6000 reads");
     if (k.error & ERR_TMP_OVERFLOW) return fail(c, CSV_E_INVALID, "internal: temp call capacity exceeded");
     if (k.n_calls > out->cap_calls || k.n_support > out->cap_support)
         return fail(c, CSV_E_CAPACITY, "need %d calls / %lld supports", k.n_calls, (long long)k.n_support);

@@ -44,7 +44,8 @@ struct DevCounters {          // one small struct in device memory, zeroed at th
     int n_calls;
     int error;
     i64 n_support;
-    i64 spare;
+    int n_gt_over;            // calls whose support + cover did not fit the small hash set
+    int spare;
 };
 
 // Everything the kernels need, passed by value.
@@ -94,6 +95,7 @@ struct DevBatch {
     const i64*     r_start; const i64* r_end; const uint8_t* r_primary; const int* r_id;
     i64*           r_pmax;
     i64*           pm_partial;       // tile maxima of the reads scan
+    int*           gt_over;          // overflow list of the first genotype pass
     const double*  sqrt_tab;
     DevCounters*   cnt;
 };
@@ -1771,17 +1773,17 @@ __global__ __launch_bounds__(256) void k_pmax_apply(DevBatch B)
 // coordinates keep the x.5 windows of DUP/INV exact; GT:95-159, semantics as in GT.duipai :206-212).
 // DR = distinct cover names that are not support names (GT:167-170): an LDS hash set is seeded with the
 // support read ids, then every covering read id is inserted; each fresh insert is one DR.
-constexpr int GT_HASH = 2048;                       // slots per wavefront
-constexpr int GT_HASH_FILL = 1536;
-
-__device__ __forceinline__ int hash_insert(int* tab, int id)
+// Two passes: k_genotype<1024, 4> (4 KB of LDS per wavefront, full occupancy) handles every call whose
+// support + cover fits ~700 reads and appends the others to an overflow list; k_genotype<8192, 1> (one
+// wavefront per workgroup, 32 KB) finishes those.  Beyond ~6000 reads the call is reported as an error.
+template <int HASH> __device__ __forceinline__ int hash_insert(int* tab, int id)
 {
-    unsigned h = ((unsigned)id * 2654435761u) >> 21;               // 11 bits
+    unsigned h = ((unsigned)id * 2654435761u) >> (32 - __builtin_ctz(HASH));
     for (;;) {
         const int old = atomicCAS(&tab[h], -1, id);
         if (old == -1) return 1;
         if (old == id) return 0;
-        h = (h + 1) & (GT_HASH - 1);
+        h = (h + 1) & (HASH - 1);
     }
 }
 
@@ -1804,7 +1806,7 @@ __device__ __forceinline__ i64 upper_bound_start(const i64* __restrict__ st, i64
     return lo + __popcll(__ballot(pred));
 }
 
-__device__ __forceinline__ int cover_window(const DevBatch& B, int* tab, i64 r0, i64 r1, i64 L2, i64 R2, int& filled)
+template <int HASH> __device__ __forceinline__ int cover_window(const DevBatch& B, int* tab, i64 r0, i64 r1, i64 L2, i64 R2, int& filled, bool& overflow)
 {
     int dr = 0;
     const i64 ub = upper_bound_start(B.r_start, r0, r1, L2);
@@ -1814,9 +1816,9 @@ __device__ __forceinline__ int cover_window(const DevBatch& B, int* tab, i64 r0,
         const i64 ii = in ? i : r0;
         const int live = in && (2 * B.r_pmax[ii] >= R2);           // nothing at or before a dead lane reaches R
         const int cov = live && B.r_primary[ii] == 1 && (2 * B.r_end[ii] >= R2);
-        if (filled + 64 > GT_HASH_FILL) { atomicOr(&B.cnt->error, ERR_COVER_OVERFLOW); return dr; }
+        if (filled + 64 > HASH * 3 / 4) { overflow = true; return dr; }
         int ins = 0;
-        if (cov) ins = hash_insert(tab, B.r_id[ii]);
+        if (cov) ins = hash_insert<HASH>(tab, B.r_id[ii]);
         const int c = __popcll(__ballot(ins));
         dr += c; filled += c;
         if (__ballot(!live)) break;
@@ -1837,41 +1839,50 @@ __device__ __forceinline__ int gl_index_dev(i64 c0, i64 c1)
     return (int)(c0 * 101 + c1);
 }
 
-__global__ __launch_bounds__(256) void k_genotype(DevBatch B)
+template <int HASH, int WPB> __global__ __launch_bounds__(64 * WPB) void k_genotype(DevBatch B, int second)
 {
-    __shared__ int tabs[4][GT_HASH];
+    __shared__ int tabs[WPB][HASH];
     int* tab = tabs[threadIdx.x >> 6];
-    const int n = B.cnt->n_calls;
-    const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * 256 + threadIdx.x) >> 6), nwaves = (gridDim.x * 256) >> 6;
-    for (int c = wave; c < n; c += nwaves) {
+    const int n = second ? B.cnt->n_gt_over : B.cnt->n_calls;
+    const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * (64 * WPB) + threadIdx.x) >> 6), nwaves = (gridDim.x * (64 * WPB)) >> 6;
+    for (int q = wave; q < n; q += nwaves) {
+        const int c = second ? B.gt_over[q] : q;
         const csv_segment& sg = B.seg[B.o_seg[c]];
         if (!sg.genotype) continue;
-        for (int i = lane_id(); i < GT_HASH; i += 64) tab[i] = -1;
+        for (int i = lane_id(); i < HASH; i += 64) tab[i] = -1;
         const i64 s0 = B.o_supoff[c], ns = B.o_supoff[c + 1] - s0;
         int filled = 0;
         bool overflow = false;
         for (i64 base = 0; base < ns; base += 64) {
-            if (filled + 64 > GT_HASH_FILL) { overflow = true; break; }
+            if (filled + 64 > HASH * 3 / 4) { overflow = true; break; }
             const i64 i = base + lane_id();
             int ins = 0;
-            if (i < ns) ins = hash_insert(tab, B.o_suprid[s0 + i]);
+            if (i < ns) ins = hash_insert<HASH>(tab, B.o_suprid[s0 + i]);
             filled += __popcll(__ballot(ins));
         }
-        if (overflow) { atomicOr(&B.cnt->error, ERR_COVER_OVERFLOW); continue; }
         const i64 r0 = B.reads_off[sg.chrom], r1 = B.reads_off[sg.chrom + 1];
         int dr = 0;
-        if (sg.svtype == CSV_DEL || sg.svtype == CSV_INS) {
-            const i64 p = B.o_search[c], g = sg.gt_bias;                    // INDEL:450-451
-            i64 L = p - g; if (L < 0) L = 0;
-            dr = cover_window(B, tab, r0, r1, 2 * L, 2 * (p + g), filled);
-        } else {
-            i64 nb = sg.gt_bias;
-            const i64 b1 = B.o_bp1[c], b2 = B.o_bp2[c];
-            if (sg.svtype == CSV_DUP && b2 - b1 < nb) nb = b2 - b1;         // DUP:147
-            i64 L2 = 2 * b1 - nb; if (L2 < 0) L2 = 0;                       // DUP:148-151, INV:219-221
-            dr = cover_window(B, tab, r0, r1, L2, 2 * b1 + nb, filled);
-            L2 = 2 * b2 - nb; if (L2 < 0) L2 = 0;
-            dr += cover_window(B, tab, r0, r1, L2, 2 * b2 + nb, filled);    // union of both windows: DUP:155-157
+        if (!overflow) {
+            if (sg.svtype == CSV_DEL || sg.svtype == CSV_INS) {
+                const i64 p = B.o_search[c], g = sg.gt_bias;                    // INDEL:450-451
+                i64 L = p - g; if (L < 0) L = 0;
+                dr = cover_window<HASH>(B, tab, r0, r1, 2 * L, 2 * (p + g), filled, overflow);
+            } else {
+                i64 nb = sg.gt_bias;
+                const i64 b1 = B.o_bp1[c], b2 = B.o_bp2[c];
+                if (sg.svtype == CSV_DUP && b2 - b1 < nb) nb = b2 - b1;         // DUP:147
+                i64 L2 = 2 * b1 - nb; if (L2 < 0) L2 = 0;                       // DUP:148-151, INV:219-221
+                dr = cover_window<HASH>(B, tab, r0, r1, L2, 2 * b1 + nb, filled, overflow);
+                L2 = 2 * b2 - nb; if (L2 < 0) L2 = 0;
+                if (!overflow) dr += cover_window<HASH>(B, tab, r0, r1, L2, 2 * b2 + nb, filled, overflow);   // union: DUP:155-157
+            }
+        }
+        if (overflow) {                                                       // wave-uniform
+            if (lane_id() == 0) {
+                if (second) atomicOr(&B.cnt->error, ERR_COVER_OVERFLOW);
+                else B.gt_over[atomicAdd(&B.cnt->n_gt_over, 1)] = c;
+            }
+            continue;
         }
         if (lane_id() == 0) { B.o_dr[c] = dr; B.o_dv[c] = (int)ns; B.o_gl[c] = gl_index_dev(dr, ns); }
     }
