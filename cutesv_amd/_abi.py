@@ -8,7 +8,7 @@ import ctypes as C
 
 import numpy as np
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 DEL, INS, DUP, INV, TRA = 0, 1, 2, 3, 4
 SVTYPE_CODE = {"DEL": DEL, "INS": INS, "DUP": DUP, "INV": INV, "TRA": TRA}
 SVTYPE_NAME = {v: k for k, v in SVTYPE_CODE.items()}
@@ -27,7 +27,7 @@ SEGMENT_DTYPE = np.dtype([
     ("diff_ratio", "<f8"), ("remain_reads_ratio", "<f8"),
     ("sv_size", "<i8"), ("max_size", "<i8"), ("gt_bias", "<i8"),
     ("read_count", "<i4"), ("min_support_reads", "<i4"),
-    ("genotype", "<i4"), ("reserved", "<i4"),
+    ("genotype", "<i4"), ("gt_round", "<i4"),
 ], align=True)
 assert SEGMENT_DTYPE.itemsize == 88
 
@@ -41,6 +41,7 @@ class BatchIn(C.Structure):
         ("reads_off", C.c_void_p),
         ("n_reads", C.c_int64),
         ("r_start", C.c_void_p), ("r_end", C.c_void_p), ("r_primary", C.c_void_p), ("r_id", C.c_void_p),
+        ("contig_len", C.c_void_p),
     ]
 
 
@@ -79,7 +80,7 @@ class HostBatch:
     """Host-side buffers of one csv_batch_in.  Keeps the numpy arrays alive for the C call."""
 
     def __init__(self, segments, a, b, read_id, aux, n_chrom=0, reads_off=None,
-                 r_start=None, r_end=None, r_primary=None, r_id=None):
+                 r_start=None, r_end=None, r_primary=None, r_id=None, contig_len=None):
         self.segments = np.ascontiguousarray(segments, dtype=SEGMENT_DTYPE)
         self.a = _col(a, np.int64)
         self.b = _col(b, np.int64)
@@ -99,12 +100,16 @@ class HostBatch:
                 raise ValueError("reads_off must have n_chrom + 1 entries")
         else:
             self.reads_off = self.r_start = self.r_end = self.r_primary = self.r_id = None
+        self.contig_len = None if contig_len is None else _col(contig_len, np.int64)
+        if self.contig_len is not None and self.contig_len.shape[0] != self.n_chrom:
+            raise ValueError("contig_len must have n_chrom entries")
         self.c = BatchIn(
             n_seg=len(self.segments), n_chrom=self.n_chrom, seg=_ptr(self.segments),
             n_sig=n, a=_ptr(self.a), b=_ptr(self.b), read_id=_ptr(self.read_id), aux=_ptr(self.aux),
             reads_off=_ptr(self.reads_off),
             n_reads=0 if self.r_start is None else self.r_start.shape[0],
-            r_start=_ptr(self.r_start), r_end=_ptr(self.r_end), r_primary=_ptr(self.r_primary), r_id=_ptr(self.r_id))
+            r_start=_ptr(self.r_start), r_end=_ptr(self.r_end), r_primary=_ptr(self.r_primary), r_id=_ptr(self.r_id),
+            contig_len=_ptr(self.contig_len))
 
     @property
     def n_sig(self):
@@ -165,7 +170,8 @@ class HostResult:
 
 
 def make_segment(svtype, chrom, sig_begin, sig_end, max_cluster_bias, read_count, diff_ratio=0.0,
-                 remain_reads_ratio=1.0, sv_size=0, max_size=-1, gt_bias=0, min_support_reads=None, genotype=False):
+                 remain_reads_ratio=1.0, sv_size=0, max_size=-1, gt_bias=0, min_support_reads=None, genotype=False,
+                 gt_round=0):
     """One csv_segment record (numpy void) from the reference's run_* scalars."""
     s = np.zeros((), dtype=SEGMENT_DTYPE)
     s["svtype"] = SVTYPE_CODE[svtype] if isinstance(svtype, str) else svtype
@@ -178,4 +184,5 @@ def make_segment(svtype, chrom, sig_begin, sig_end, max_cluster_bias, read_count
     s["read_count"] = read_count
     s["min_support_reads"] = min(read_count, 5) if min_support_reads is None else min_support_reads
     s["genotype"] = 1 if genotype else 0
+    s["gt_round"] = gt_round
     return s

@@ -36,6 +36,7 @@ class Params:
     min_size: int = 30
     max_size: int = 100000
     genotype: bool = False
+    genotype_tra: bool = False        # with genotype: TRA calls are genotyped from the reads table
     gt_round: int = 500
     max_cluster_bias_INS: int = 100
     diff_ratio_merging_INS: float = 0.3
@@ -108,6 +109,7 @@ class SigStore:
     r_end: np.ndarray = None
     r_primary: np.ndarray = None
     r_id: np.ndarray = None
+    contig_len: np.ndarray = None                 # reference lengths per chromosome (TRA genotyping windows)
 
     # ------------------------------------------------------------------ basic access
     @property
@@ -152,9 +154,14 @@ class SigStore:
                                      sv_size=p.min_size, max_size=p.max_size, gt_bias=p.max_cluster_bias_DUP,
                                      genotype=p.genotype)
         if svtype == "TRA":
-            # TRA genotyping re-opens the BAM (cuteSV_resolveTRA.py:260-309): not part of this path
+            # TRA genotyping (cuteSV_resolveTRA.py:258-309) runs over the reads table when asked for; the
+            # reference re-fetches the BAM there, see include/cutesv_hip.h
+            gt = bool(p.genotype and p.genotype_tra)
+            if gt and self.contig_len is None:
+                raise ValueError("TRA genotyping needs the reference lengths (SigStore.contig_len)")
             return _abi.make_segment(svtype, c, beg, end, p.max_cluster_bias_TRA, p.min_support,
-                                     diff_ratio=p.diff_ratio_filtering_TRA, genotype=False)
+                                     diff_ratio=p.diff_ratio_filtering_TRA, gt_bias=p.max_cluster_bias_TRA,
+                                     genotype=gt, gt_round=p.gt_round)
         raise ValueError(svtype)
 
     def tasks(self, types=TYPES, chroms=None):
@@ -173,6 +180,8 @@ class SigStore:
         if need_reads and self.reads_off is not None:
             kw = dict(reads_off=self.reads_off, r_start=self.r_start, r_end=self.r_end,
                       r_primary=self.r_primary, r_id=self.r_id)
+            if bool(((segs["svtype"] == _abi.TRA) & (segs["genotype"] != 0)).any()):
+                kw["contig_len"] = self.contig_len
         return _abi.HostBatch(segs, self.a, self.b, self.read_id, self.aux, n_chrom=len(self.chroms), **kw)
 
     # ------------------------------------------------------------------ persistence (flat .cols directory)
@@ -182,6 +191,8 @@ class SigStore:
         if self.reads_off is not None:
             cols.update(reads_off=self.reads_off, r_start=self.r_start, r_end=self.r_end,
                         r_primary=self.r_primary, r_id=self.r_id)
+        if self.contig_len is not None:
+            cols.update(contig_len=self.contig_len)
         for k, v in cols.items():
             np.save(os.path.join(path, k + ".npy"), v)
         meta = dict(chroms=self.chroms, strands=list(self.strands),
@@ -199,6 +210,8 @@ class SigStore:
         kw = {}
         if os.path.exists(os.path.join(path, "reads_off.npy")):
             kw = {k: ld(k) for k in ("reads_off", "r_start", "r_end", "r_primary", "r_id")}
+        if os.path.exists(os.path.join(path, "contig_len.npy")):
+            kw["contig_len"] = ld("contig_len")
         return cls(chroms=meta["chroms"], a=ld("a"), b=ld("b"), read_id=ld("read_id"), aux=ld("aux"),
                    seg_index={(t, c): (b, e) for t, c, b, e in meta["seg_index"]},
                    names=NameTable(meta["names"], meta["name_fmt"]), strands=tuple(meta["strands"]),
@@ -206,7 +219,7 @@ class SigStore:
 
     # ------------------------------------------------------------------ conversion from the reference's layout
     @classmethod
-    def from_tuple_lists(cls, per_type, reads=None, chroms=None):
+    def from_tuple_lists(cls, per_type, reads=None, chroms=None, contig_len=None):
         """Build the flat store from the reference's in-memory representation.
 
         per_type: {"DEL": [(pos, len, read, "DEL", chr), ...], "INS": [(pos, len, read, seq, "INS", chr)],
@@ -215,6 +228,7 @@ class SigStore:
         reads:    [(start, end, is_primary, read, chr)]                  (main script :733)
         The lists are sorted and adjacent-deduplicated here exactly as the rebuild step does
         (main script :764-802, 958-969), so unsorted extraction output may be passed in.
+        contig_len: {chromosome: reference length} (the BAM header), only needed to genotype TRA calls.
         """
         keys = {
             "DEL": lambda x: (x[-1], int(x[0]), x[1], x[2]),
@@ -288,12 +302,14 @@ class SigStore:
                 off.append(len(rs))
             kw = dict(reads_off=np.array(off, np.int64), r_start=np.array(rs, np.int64), r_end=np.array(re_, np.int64),
                       r_primary=np.array(rp, np.uint8), r_id=np.array(ri, np.int32))
+        if contig_len is not None:
+            kw["contig_len"] = np.array([int(contig_len[c]) for c in chroms], np.int64)
         return cls(chroms=list(chroms), a=np.array(a, np.int64), b=np.array(b, np.int64),
                    read_id=np.array(rid, np.int32), aux=np.array(aux, np.int32), seg_index=seg_index,
                    names=NameTable(uniq), ins_seq=ins_seq, strands=tuple(strands), **kw)
 
     @classmethod
-    def from_reference_workdir(cls, work_dir, sigs_index=None):
+    def from_reference_workdir(cls, work_dir, sigs_index=None, contig_len=None):
         """Read the reference's own `<TYPE>.pickle` / `reads.pickle` / `sigindex.pickle` files
         (main script :817-857, 1092-1093) into the flat layout.  Needs only `pickle`."""
         if not work_dir.endswith("/"):
@@ -312,7 +328,7 @@ class SigStore:
             with open(work_dir + "reads.pickle", "rb") as f:
                 f.seek(off)
                 reads.extend(pickle.load(f))
-        return cls.from_tuple_lists(per_type, reads)
+        return cls.from_tuple_lists(per_type, reads, contig_len=contig_len)
 
     # ------------------------------------------------------------------ the inverse (tests / golden generation)
     def tuple_lists(self):

@@ -25,7 +25,7 @@ struct Buf {                      // grow-only device buffer
 // one timing slot per launch, in launch order
 const char* kStageName[CSV_N_STAGES] = {"init", "k_chain_count", "k_chain_apply", "k_select_count", "k_select_apply",
                                         "k_refine_indel_wave", "k_refine_wave", "k_refine_mid", "k_refine_block", "k_items_scan",
-                                        "k_emit", "k_pmax_count", "k_pmax_scan", "k_pmax_apply", "k_genotype", ""};
+                                        "k_emit", "k_pmax_count", "k_pmax_scan", "k_pmax_apply", "k_genotype", "k_genotype_tra"};
 
 }  // namespace
 
@@ -44,14 +44,14 @@ struct csv_ctx {
     Buf sc_k, sc_x, sc_v1, sc_v2, sc_v3, sc_v4, sc_v5;
     Buf o_seg, o_cluster, o_aux, o_bp1, o_bp2, o_support, o_cipos, o_cilen, o_search, o_pick, o_dr, o_dv, o_gl;
     Buf o_supoff, o_supsig, o_suprid, allele_id;
-    Buf reads_off, r_start, r_end, r_primary, r_id, r_pmax, pm_partial, gt_over;
+    Buf reads_off, r_start, r_end, r_primary, r_id, r_pmax, pm_partial, gt_over, contig_len;
     Buf sqrt_tab, cnt;
     Buf rb_seg, rb_a, rb_b, rb_rid, rb_aux, rb_auxk, rb_major, rb_perm0, rb_perm1, rb_hist, rb_tot, rb_partial;
     Buf rb_oseg, rb_oa, rb_ob, rb_orid, rb_oaux, rb_osrc;
     // host copies
     std::vector<csv_segment> h_seg;
     std::vector<i64>         h_woff;
-    bool     uploaded = false, ran = false, any_genotype = false, any_pair = false, big_lds_set = false;
+    bool     uploaded = false, ran = false, any_genotype = false, any_pair = false, any_tra_gt = false, big_lds_set = false;
     i64      n_sig_host = 0;
     DevBatch B;
     DevCounters h_cnt;
@@ -159,7 +159,7 @@ void csv_ctx_destroy(csv_ctx* c)
                   &c->t_support, &c->t_cipos, &c->t_cilen, &c->t_supoff, &c->t_valid, &c->sc_k, &c->sc_x, &c->sc_v1, &c->sc_v2,
                   &c->sc_v3, &c->sc_v4, &c->sc_v5, &c->o_seg, &c->o_cluster, &c->o_aux, &c->o_bp1, &c->o_bp2, &c->o_support,
                   &c->o_cipos, &c->o_cilen, &c->o_search, &c->o_pick, &c->o_dr, &c->o_dv, &c->o_gl, &c->o_supoff, &c->o_supsig,
-                  &c->o_suprid, &c->allele_id, &c->reads_off, &c->r_start, &c->r_end, &c->r_primary, &c->r_id, &c->r_pmax, &c->pm_partial, &c->gt_over,
+                  &c->o_suprid, &c->allele_id, &c->reads_off, &c->r_start, &c->r_end, &c->r_primary, &c->r_id, &c->r_pmax, &c->pm_partial, &c->gt_over, &c->contig_len,
                   &c->sqrt_tab, &c->cnt, &c->rb_seg, &c->rb_a, &c->rb_b, &c->rb_rid, &c->rb_aux, &c->rb_auxk, &c->rb_major,
                   &c->rb_perm0, &c->rb_perm1, &c->rb_hist, &c->rb_tot, &c->rb_partial, &c->rb_oseg, &c->rb_oa, &c->rb_ob,
                   &c->rb_orid, &c->rb_oaux, &c->rb_osrc};
@@ -195,16 +195,22 @@ int csv_batch_upload(csv_ctx* c, const csv_batch_in* in)
     std::vector<uint8_t> drop(S + 1, 0);
     c->any_genotype = false;
     c->any_pair = false;
+    c->any_tra_gt = false;
     i64 cap_items = 16, cap_tmp = 16;
     for (int k = 0; k < S; k++) {
         const csv_segment& g = c->h_seg[k];
         if (g.svtype < CSV_DEL || g.svtype > CSV_TRA) return fail(c, CSV_E_INVALID, "segment %d: unknown svtype %d", k, g.svtype);
         if (g.sig_begin < 0 || g.sig_begin > g.sig_end || g.sig_end > in->n_sig) return fail(c, CSV_E_INVALID, "segment %d: bad signature range", k);
-        if (g.svtype == CSV_TRA && g.genotype) return fail(c, CSV_E_INVALID, "segment %d: TRA genotyping reads the BAM (cuteSV_resolveTRA.py:260-309) and is not part of this path", k);
         if (g.genotype) {
             c->any_genotype = true;
             if (g.chrom < 0 || g.chrom >= in->n_chrom) return fail(c, CSV_E_INVALID, "segment %d: chrom %d outside the reads table", k, g.chrom);
-            drop[k] = (!in->reads_off || in->reads_off[g.chrom + 1] == in->reads_off[g.chrom]) ? 1 : 0;
+            if (g.svtype == CSV_TRA) {
+                // call_gt of cuteSV_resolveTRA.py:258-309 over the reads table; no "no reads block" gate there
+                if (!in->reads_off || !in->contig_len) return fail(c, CSV_E_INVALID, "segment %d: TRA genotyping needs reads_off and contig_len", k);
+                c->any_tra_gt = true;
+            } else {
+                drop[k] = (!in->reads_off || in->reads_off[g.chrom + 1] == in->reads_off[g.chrom]) ? 1 : 0;
+            }
         }
         const i64 len = g.sig_end - g.sig_begin;
         if (len > 0 && g.svtype != CSV_DEL && g.svtype != CSV_INS) c->any_pair = true;
@@ -242,9 +248,11 @@ int csv_batch_upload(csv_ctx* c, const csv_batch_in* in)
     RES(o_support, cap_tmp * 4); RES(o_cipos, cap_tmp * 4); RES(o_cilen, cap_tmp * 4); RES(o_search, cap_tmp * 8); RES(o_pick, cap_tmp * 8);
     RES(o_dr, cap_tmp * 4); RES(o_dv, cap_tmp * 4); RES(o_gl, cap_tmp * 4); RES(o_supoff, (cap_tmp + 1) * 8);
     RES(o_supsig, (W + 1) * 8); RES(o_suprid, (W + 1) * 4);
+    const bool have_tab = c->any_genotype && in->reads_off;
+    if (have_tab) { RES(reads_off, (in->n_chrom + 1) * 8); RES(contig_len, (in->n_chrom + 1) * 8); }
     if (R > 0) {
         RES(pm_partial, (div_up(R, PM_TILE) + 2) * 8); RES(gt_over, (cap_tmp + 2) * 4);
-        RES(reads_off, (in->n_chrom + 1) * 8); RES(r_start, R * 8); RES(r_end, R * 8); RES(r_primary, R); RES(r_id, R * 4); RES(r_pmax, R * 8);
+        RES(r_start, R * 8); RES(r_end, R * 8); RES(r_primary, R); RES(r_id, R * 4); RES(r_pmax, R * 8);
     }
 
     // ---- host -> device.  Segments whose source ranges are adjacent travel as one copy.
@@ -264,8 +272,9 @@ int csv_batch_upload(csv_ctx* c, const csv_batch_in* in)
         }
         k = e + 1;
     }
+    if (have_tab) HIP_TRY(c, hipMemcpyAsync(c->reads_off.p, in->reads_off, (in->n_chrom + 1) * 8, hipMemcpyHostToDevice, st));
+    if (c->any_tra_gt && in->n_chrom > 0) HIP_TRY(c, hipMemcpyAsync(c->contig_len.p, in->contig_len, in->n_chrom * 8, hipMemcpyHostToDevice, st));
     if (R > 0) {
-        HIP_TRY(c, hipMemcpyAsync(c->reads_off.p, in->reads_off, (in->n_chrom + 1) * 8, hipMemcpyHostToDevice, st));
         HIP_TRY(c, hipMemcpyAsync(c->r_start.p, in->r_start, R * 8, hipMemcpyHostToDevice, st));
         HIP_TRY(c, hipMemcpyAsync(c->r_end.p, in->r_end, R * 8, hipMemcpyHostToDevice, st));
         HIP_TRY(c, hipMemcpyAsync(c->r_primary.p, in->r_primary, R, hipMemcpyHostToDevice, st));
@@ -291,7 +300,7 @@ int csv_batch_upload(csv_ctx* c, const csv_batch_in* in)
     B.o_search = dp<i64>(c->o_search); B.o_pick = dp<i64>(c->o_pick); B.o_dr = dp<int>(c->o_dr); B.o_dv = dp<int>(c->o_dv); B.o_gl = dp<int>(c->o_gl);
     B.o_supoff = dp<i64>(c->o_supoff); B.o_supsig = dp<i64>(c->o_supsig); B.o_suprid = dp<int>(c->o_suprid); B.allele_id = dp<int>(c->allele_id);
     B.reads_off = dp<i64>(c->reads_off); B.n_reads = R;
-    B.r_start = dp<i64>(c->r_start); B.r_end = dp<i64>(c->r_end); B.r_primary = dp<uint8_t>(c->r_primary); B.r_id = dp<int>(c->r_id); B.r_pmax = dp<i64>(c->r_pmax); B.pm_partial = dp<i64>(c->pm_partial); B.gt_over = dp<int>(c->gt_over);
+    B.r_start = dp<i64>(c->r_start); B.r_end = dp<i64>(c->r_end); B.r_primary = dp<uint8_t>(c->r_primary); B.r_id = dp<int>(c->r_id); B.r_pmax = dp<i64>(c->r_pmax); B.pm_partial = dp<i64>(c->pm_partial); B.gt_over = dp<int>(c->gt_over); B.contig_len = dp<i64>(c->contig_len);
     B.sqrt_tab = dp<double>(c->sqrt_tab); B.cnt = dp<DevCounters>(c->cnt);
     c->n_sig_host = in->n_sig;
     c->uploaded = true;
@@ -394,6 +403,9 @@ int csv_batch_run(csv_ctx* c, csv_run_stats* stats)
             hipLaunchKernelGGL((k_genotype<8192, 1>), dim3(256), dim3(64), 0, st, B, 1);      // overflow list of the first pass
             DBG("genotype");
             HIP_TRY(c, mark());
+        } else if (stats) { HIP_TRY(c, mark()); HIP_TRY(c, mark()); HIP_TRY(c, mark()); HIP_TRY(c, mark()); }
+        if (c->any_tra_gt) {
+            LAUNCH("genotype_tra", k_genotype_tra, 256, 64, 0, B);
         }
     }
 #undef LAUNCH
@@ -448,6 +460,7 @@ int csv_batch_download(csv_ctx* c, csv_batch_out* out)
     if (k.error & ERR_CLUSTER_TOO_BIG) return fail(c, CSV_E_INVALID, "a chained cluster has more than %lld signatures", (long long)MAX_CLUSTER);
     if (k.error & ERR_KEY_RANGE) return fail(c, CSV_E_INVALID, "a length / pos2 value is negative or >= 2^42");
     if (k.error & ERR_COVER_OVERFLOW) return fail(c, CSV_E_INVALID, "support + cover set of a call exceeds ~6000 reads");
+    if (k.error & ERR_TRA_CHROM) return fail(c, CSV_E_INVALID, "a TRA call names a mate chromosome outside the reads table");
     if (k.error & ERR_TMP_OVERFLOW) return fail(c, CSV_E_INVALID, "internal: temp call capacity exceeded");
     if (k.n_calls > out->cap_calls || k.n_support > out->cap_support)
         return fail(c, CSV_E_CAPACITY, "need %d calls / %lld supports", k.n_calls, (long long)k.n_support);

@@ -34,7 +34,7 @@ constexpr int SQRT_TAB = 65536;                    // pow(n, 0.5) as glibc compu
 constexpr int ARR_PAD = 8;                         // group-start arrays need P + 1 entries
 
 // device error bits (DevCounters::error)
-enum { ERR_CLUSTER_TOO_BIG = 1, ERR_READS_UNSORTED = 2, ERR_COVER_OVERFLOW = 4, ERR_KEY_RANGE = 8, ERR_TMP_OVERFLOW = 16, ERR_SIG_ORDER = 32 };
+enum { ERR_CLUSTER_TOO_BIG = 1, ERR_READS_UNSORTED = 2, ERR_COVER_OVERFLOW = 4, ERR_KEY_RANGE = 8, ERR_TMP_OVERFLOW = 16, ERR_SIG_ORDER = 32, ERR_TRA_CHROM = 64 };
 
 struct DevCounters {          // one small struct in device memory, zeroed at the start of every run
     int n_clusters;
@@ -96,6 +96,7 @@ struct DevBatch {
     i64*           r_pmax;
     i64*           pm_partial;       // tile maxima of the reads scan
     int*           gt_over;          // overflow list of the first genotype pass
+    const i64*     contig_len;       // reference lengths (TRA genotyping windows)
     const double*  sqrt_tab;
     DevCounters*   cnt;
 };
@@ -1848,7 +1849,7 @@ template <int HASH, int WPB> __global__ __launch_bounds__(64 * WPB) void k_genot
     for (int q = wave; q < n; q += nwaves) {
         const int c = second ? B.gt_over[q] : q;
         const csv_segment& sg = B.seg[B.o_seg[c]];
-        if (!sg.genotype) continue;
+        if (!sg.genotype || sg.svtype == CSV_TRA) continue;       // TRA: k_genotype_tra
         for (int i = lane_id(); i < HASH; i += 64) tab[i] = -1;
         const i64 s0 = B.o_supoff[c], ns = B.o_supoff[c + 1] - s0;
         int filled = 0;
@@ -1885,6 +1886,158 @@ template <int HASH, int WPB> __global__ __launch_bounds__(64 * WPB) void k_genot
             continue;
         }
         if (lane_id() == 0) { B.o_dr[c] = dr; B.o_dv[c] = (int)ns; B.o_gl[c] = gl_index_dev(dr, ns); }
+    }
+}
+
+// ---------------------------------------------------------------------------------------- TRA genotyping
+// call_gt / count_coverage of cuteSV_resolveTRA.py:258-309 and cuteSV_genotype.py:62-93 with the reads table
+// as the alignment stream (include/cutesv_hip.h).  One wavefront per TRA call.  The reference's loop is
+// sequential with two early exits (querydata reaches up_bound; iteration reaches gt_round at a primary
+// read); here a chunk of 64 reads is classified at once, the running counters become ballot prefixes and the
+// first lane at which either exit fires ends the scan; only lanes up to it are committed to the set.
+//   table entry flags: 1 = read supports the call (read_id_list), 2 = read is in querydata
+constexpr int TG_HASH = 4096;                        // slots per wavefront (ids + flags: 32 KB of LDS)
+
+// first index in [lo, hi) at which pred turns false (pred is true on a prefix); 64-ary search
+template <class P> __device__ __forceinline__ i64 partition_point_wave(i64 lo, i64 hi, P pred)
+{
+    while (hi - lo > 64) {
+        const i64 step = (hi - lo + 63) / 64;
+        const i64 idx = lo + (i64)lane_id() * step;
+        const int t = __popcll(__ballot(idx < hi && pred(idx < hi ? idx : lo)));
+        if (t == 0) return lo;
+        i64 nhi = lo + (i64)t * step;
+        if (nhi > hi) nhi = hi;
+        lo = lo + (i64)(t - 1) * step + 1; hi = nhi;
+    }
+    const i64 idx = lo + lane_id();
+    return lo + __popcll(__ballot(idx < hi && pred(idx < hi ? idx : lo)));
+}
+
+// slot of id in the table, inserting it (flags 0) when absent; `fresh` = 1 when this call created the entry
+__device__ __forceinline__ int tg_find_or_insert(int* ids, int id, int& fresh)
+{
+    unsigned h = ((unsigned)id * 2654435761u) >> (32 - __builtin_ctz(TG_HASH));
+    for (;;) {
+        const int old = atomicCAS(&ids[h], -1, id);
+        if (old == -1) { fresh = 1; return (int)h; }
+        if (old == id) { fresh = 0; return (int)h; }
+        h = (h + 1) & (TG_HASH - 1);
+    }
+}
+
+__device__ __forceinline__ i64 tra_up_bound(i64 num)     // threshold_ref_count, cuteSV_genotype.py:62-70
+{
+    if (num <= 2) return 20 * num;
+    if (num <= 5) return 9 * num;
+    if (num <= 15) return 7 * num;
+    return 5 * num;
+}
+
+// one count_coverage() call; returns the status (0 / 1 / -1).  nq / dr / filled are wave-uniform running totals.
+__device__ __forceinline__ int tra_window(const DevBatch& B, int* ids, int* fl, int chrom, i64 s, i64 e, i64 up_bound, i64 itround,
+                                          i64& nq, int& dr, int& filled, bool& overflow)
+{
+    if (s >= e) return 0;
+    const i64 r0 = B.reads_off[chrom], r1 = B.reads_off[chrom + 1];
+    const i64 hi = partition_point_wave(r0, r1, [&](i64 i) { return B.r_start[i] < e; });      // fetch(): start < e ...
+    const i64 lo = partition_point_wave(r0, hi, [&](i64 i) { return B.r_pmax[i] <= s; });      // ... and end > s
+    i64 iteration = 0, primary = 0;
+    const u64 le = lanemask_lt() | (1ull << lane_id());
+    for (i64 base = lo; base < hi; base += 64) {
+        if (filled + 64 > TG_HASH * 3 / 4) { overflow = true; return 0; }
+        const i64 i = base + lane_id();
+        const bool in = i < hi;
+        const i64 ii = in ? i : lo;
+        const i64 rs = B.r_start[ii], re = B.r_end[ii];
+        const int id = B.r_id[ii];
+        const bool ov = in && re > s;                                          // GT:76-77
+        const bool prim = ov && B.r_primary[ii] == 1;                          // GT:78-80
+        const bool span = prim && rs < s && re > e;                            // GT:81
+        // a name that occurs twice among the chunk's spanning reads counts at its first occurrence
+        bool dup = false;
+        for (u64 m = __ballot(span); m;) {
+            const int j = __builtin_amdgcn_readfirstlane(__builtin_ctzll(m));
+            m &= m - 1;
+            const int idj = __builtin_amdgcn_readlane(id, j);
+            if (span && lane_id() > j && id == idj) dup = true;
+        }
+        int fresh = 0, slot = 0;
+        if (span && !dup) slot = tg_find_or_insert(ids, id, fresh);
+        filled += __popcll(__ballot(fresh));
+        const int flags = (span && !dup && !fresh) ? fl[slot] : 0;
+        const bool isnew = span && !dup && !(flags & 2);
+        const u64 m_ov = __ballot(ov), m_pr = __ballot(prim), m_new = __ballot(isnew);
+        const i64 it_i = iteration + __popcll(m_ov & le), pn_i = primary + __popcll(m_pr & le), nq_i = nq + __popcll(m_new & le);
+        const bool exitA = span && nq_i >= up_bound;                           // GT:83-85
+        const bool exitB = prim && it_i >= itround;                            // GT:86-91
+        const u64 stop = __ballot(exitA || exitB);
+        const int t = stop ? __builtin_ctzll(stop) : 63;
+        const bool commit = isnew && lane_id() <= t;
+        if (commit) fl[slot] = flags | 2;
+        dr += __popcll(__ballot(commit && !(flags & 1)));
+        if (stop) {
+            nq = __builtin_amdgcn_readlane((int)nq_i, t);
+            const int a_t = __builtin_amdgcn_readlane((int)exitA, t);
+            const i64 it_t = __builtin_amdgcn_readlane((int)it_i, t), pn_t = __builtin_amdgcn_readlane((int)pn_i, t);
+            if (a_t) return 1;
+            return (5 * pn_t <= it_t) ? 1 : -1;                                // float(primary_num / iteration) <= 0.2
+        }
+        nq += __popcll(m_new); iteration += __popcll(m_ov); primary += __popcll(m_pr);
+    }
+    return 0;
+}
+
+__global__ __launch_bounds__(64) void k_genotype_tra(DevBatch B)
+{
+    __shared__ int ids[TG_HASH];
+    __shared__ int fl[TG_HASH];
+    const int n = B.cnt->n_calls;
+    for (int c0 = blockIdx.x * 64; c0 < n; c0 += gridDim.x * 64) {
+        // 64 calls per round: the lanes look for genotyped TRA calls, the wavefront then takes them one by one
+        const int cl = c0 + lane_id();
+        bool mine = false;
+        if (cl < n) { const csv_segment& g = B.seg[B.o_seg[cl]]; mine = g.svtype == CSV_TRA && g.genotype; }
+        for (u64 todo = __ballot(mine); todo;) {
+            const int c = c0 + __builtin_amdgcn_readfirstlane(__builtin_ctzll(todo));
+            todo &= todo - 1;
+            const csv_segment& sg = B.seg[B.o_seg[c]];
+            const int chr1 = sg.chrom, chr2 = B.o_aux[c] >> 3;
+            if (chr2 < 0 || chr2 >= B.n_chrom) { if (lane_id() == 0) atomicOr(&B.cnt->error, ERR_TRA_CHROM); continue; }
+            for (int i = lane_id(); i < TG_HASH; i += 64) { ids[i] = -1; fl[i] = 0; }
+            const i64 s0 = B.o_supoff[c], ns = B.o_supoff[c + 1] - s0;
+            int filled = 0;
+            bool overflow = false;
+            for (i64 base = 0; base < ns && !overflow; base += 64) {           // read_id_list: flag 1
+                if (filled + 64 > TG_HASH * 3 / 4) { overflow = true; break; }
+                const i64 i = base + lane_id();
+                int fresh = 0;
+                if (i < ns) { const int slot = tg_find_or_insert(ids, B.o_suprid[s0 + i], fresh); fl[slot] = 1; }
+                filled += __popcll(__ballot(fresh));
+            }
+            const i64 up_bound = tra_up_bound(ns);                             // TRA:266
+            const i64 bias = sg.gt_bias;
+            i64 nq = 0;
+            int dr = 0, status = 0;
+            if (!overflow) {
+                i64 s = B.o_bp1[c] - bias, e = B.o_bp1[c] + bias;             // TRA:263-264
+                if (s < 0) s = 0;
+                if (e > B.contig_len[chr1]) e = B.contig_len[chr1];
+                status = tra_window(B, ids, fl, chr1, s, e, up_bound, sg.gt_round, nq, dr, filled, overflow);
+                if (status == 0 && !overflow) {                               // TRA:289-299 (status_2 is not looked at)
+                    s = B.o_bp2[c] - bias; e = B.o_bp2[c] + bias;
+                    if (s < 0) s = 0;
+                    if (e > B.contig_len[chr2]) e = B.contig_len[chr2];
+                    tra_window(B, ids, fl, chr2, s, e, up_bound, sg.gt_round, nq, dr, filled, overflow);
+                }
+            }
+            if (overflow) { if (lane_id() == 0) atomicOr(&B.cnt->error, ERR_COVER_OVERFLOW); continue; }
+            if (lane_id() == 0) {
+                B.o_dv[c] = (int)ns;
+                if (status == -1) { B.o_dr[c] = -1; B.o_gl[c] = -1; }          // TRA:276-281
+                else { B.o_dr[c] = dr; B.o_gl[c] = gl_index_dev(dr, ns); }
+            }
+        }
     }
 }
 

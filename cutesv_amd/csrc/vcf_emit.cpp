@@ -104,7 +104,8 @@ extern "C" int csv_vcf_emit(const csv_vcf_in* in, char* out, int64_t cap, int64_
         for (int64_t c : v) {
             const csv_segment& sg = in->seg[R.call_seg[c]];
             const int type = sg.svtype;
-            const bool gt_on = sg.genotype != 0;
+            // TRA calls whose count_coverage gave up carry the '.' fields too (cuteSV_resolveTRA.py:276-281)
+            const bool gt_on = sg.genotype != 0 && R.gl_idx[c] >= 0;
             // genotype strings of the row ('.' fields when the task was not genotyped)
             GlRow g{"./.", 3, ".,.,.", 5, ".", 1, ".", 1};
             if (gt_on) {
@@ -225,7 +226,7 @@ extern "C" int csv_vcf_emit(const csv_vcf_in* in, char* out, int64_t cap, int64_
                 o.put(imprecise ? "IMPRECISE" : "PRECISE");
                 o.put(";SVTYPE=BND;RE="); o.num(re);
                 put_rnames();
-                put_af_field(false);                                                    // DR is '.' for TRA rows -> AF=. (:412-414)
+                put_af_field(gt_on);                                                    // DR '.' -> AF=. (:412-414)
                 put_tail();
             }
         }

@@ -58,6 +58,8 @@ def run_batch(store, segments, tasks, ctx=None):
     if len(segs) and segs["genotype"].any() and store.reads_off is not None:
         kw = dict(reads_off=store.reads_off, r_start=store.r_start, r_end=store.r_end,
                   r_primary=store.r_primary, r_id=store.r_id)
+        if ((segs["svtype"] == _abi.TRA) & (segs["genotype"] != 0)).any():
+            kw["contig_len"] = store.contig_len
     hb = _abi.HostBatch(segs, store.a, store.b, store.read_id, store.aux, n_chrom=len(store.chroms), **kw)
     res = ctx.cluster_batch(hb)
     out = {t: [] for t in tasks}
@@ -133,14 +135,18 @@ def run_dup(args):
 
 
 def run_tra(args):
-    path, chrom, read_count, overlap_size, max_cluster_bias, _bam, action, _gt_round, sigs_index = args
-    if action:
-        # the reference re-opens the BAM per breakpoint here (cuteSV_resolveTRA.py:260-309): that stays on
-        # the pysam host path and is outside this library
-        raise NotImplementedError("TRA genotyping reads the BAM and is not part of the GPU clustering path")
+    path, chrom, read_count, overlap_size, max_cluster_bias, bam, action, gt_round, sigs_index = args
 
     def seg(store):
         beg, end = store.seg_index[("TRA", chrom)]
+        if action and store.contig_len is None:
+            # call_gt only takes the reference lengths from the BAM (cuteSV_resolveTRA.py:264, 291); the
+            # alignments come from the reads table (include/cutesv_hip.h)
+            from .bam_header import reference_lengths
+            import numpy as np
+            lens = reference_lengths(bam)
+            store.contig_len = np.array([lens[c] for c in store.chroms], np.int64)
         return _abi.make_segment("TRA", store.chroms.index(chrom), beg, end, max_cluster_bias, read_count,
-                                 diff_ratio=overlap_size, genotype=False)
+                                 diff_ratio=overlap_size, gt_bias=max_cluster_bias, genotype=bool(action),
+                                 gt_round=gt_round)
     return _one(path, chrom, "TRA", sigs_index, seg)

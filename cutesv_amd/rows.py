@@ -5,7 +5,7 @@ unchanged by the reference's VCF emitter (cuteSV_genotype.py:263-458):
     DEL 13 fields / INS 14   cuteSV_resolveINDEL.py:207-219, 419-432 (no genotype), :464-478 (genotype)
     DUP 11                   cuteSV_resolveDUP.py:121-131, 170-180
     INV 12                   cuteSV_resolveINV.py:145-156, 240-251
-    TRA 12                   cuteSV_resolveTRA.py:171-182
+    TRA 12                   cuteSV_resolveTRA.py:171-182 (genotype fields from call_gt, :258-309)
 All numeric fields are `str`; read names are joined by ','.
 """
 from . import _abi
@@ -45,7 +45,7 @@ def materialise(store, segments, res, chrom_of_seg=None):
         t = seg_type[k]
         chrom = store.chroms[seg_chrom[k]]
         reads = ",".join(names[off[c]:off[c + 1]])
-        if seg_gt[k]:
+        if seg_gt[k] and gl[c] >= 0:          # TRA: count_coverage may give up -> '.' fields (cuteSV_resolveTRA.py:276-281)
             gt, pl, gq, qual = gl_fields(gl[c])
             g = (str(dr[c]), gt, pl, gq, qual)
         else:

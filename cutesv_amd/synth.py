@@ -142,7 +142,8 @@ def _finish(contigs, per_type, n_reads_total, rng, reads=None, shuffle_ids=True)
         kw = dict(reads_off=off, r_start=r_s.astype(np.int64), r_end=r_e.astype(np.int64),
                   r_primary=r_p.astype(np.uint8), r_id=r_i.astype(np.int32))
     return SigStore(chroms=chroms, a=cat(A, np.int64), b=cat(B, np.int64), read_id=cat(R, np.int32),
-                    aux=cat(X, np.int32), seg_index=seg_index, names=NameTable(), **kw)
+                    aux=cat(X, np.int32), seg_index=seg_index, names=NameTable(),
+                    contig_len=np.array([l for _, l in contigs], np.int64), **kw)
 
 
 def ont30(seed=20260103, scale=1.0, contigs=CONTIGS, coverage=30, ins_ratio=1.0):

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CSV_ABI_VERSION 1
+#define CSV_ABI_VERSION 2
 
 /* SV types: one (chromosome, type) pair is one segment == one reference pool task
  * (MAIN:1116-1189).  Order of the enum is irrelevant to results. */
@@ -36,7 +36,7 @@ enum { CSV_DEL = 0, CSV_INS = 1, CSV_DUP = 2, CSV_INV = 3, CSV_TRA = 4 };
 
 enum {
     CSV_OK = 0,
-    CSV_E_INVALID = 1,   /* bad argument / unsupported combination (e.g. TRA + genotype) */
+    CSV_E_INVALID = 1,   /* bad argument / unsupported combination (e.g. TRA + genotype without contig_len) */
     CSV_E_CAPACITY = 2,  /* output arrays too small; n_calls / n_support hold the need */
     CSV_E_HIP = 3,       /* a HIP runtime call failed; see csv_last_error */
     CSV_E_NOMEM = 4,
@@ -51,7 +51,7 @@ enum {
  *            minimum_support_reads, action, remain_reads_ratio)
  *   DUP      DUP:17-18   (read_count, max_cluster_bias, sv_size, action, MaxSize)
  *   INV      INV:6-7     (read_count, max_cluster_bias, sv_size, action, MaxSize)
- *   TRA      TRA:30      (read_count, overlap_size, max_cluster_bias)
+ *   TRA      TRA:30      (read_count, overlap_size, max_cluster_bias, action, gt_round)
  */
 typedef struct csv_segment {
     int32_t svtype;             /* CSV_DEL..CSV_TRA */
@@ -64,11 +64,12 @@ typedef struct csv_segment {
     int64_t sv_size;            /* DUP:112 / INV:132 minimum size */
     int64_t max_size;           /* DUP:112 / INV:134 MaxSize, -1 = unlimited */
     int64_t gt_bias;            /* genotype half window: DEL max_cluster_bias (INDEL:103),
-                                   INS 1000 (INDEL:312), DUP/INV max_cluster_bias (DUP:72, INV:94) */
+                                   INS 1000 (INDEL:312), DUP/INV max_cluster_bias (DUP:72, INV:94),
+                                   TRA max_cluster_bias (TRA:164-166) */
     int32_t read_count;         /* min_support */
     int32_t min_support_reads;  /* min(min_support, 5), MAIN:1124 */
     int32_t genotype;           /* the reference's `action` flag */
-    int32_t reserved;
+    int32_t gt_round;           /* TRA only: --gt_round, the iteration cap of count_coverage (GT:62-93) */
 } csv_segment;
 
 /*
@@ -97,6 +98,8 @@ typedef struct csv_batch_in {
     const int64_t*     r_end;
     const uint8_t*     r_primary;
     const int32_t*     r_id;
+    const int64_t*     contig_len;  /* n_chrom reference lengths (bamfile.get_reference_length, TRA:264,291); NULL unless a
+                                       TRA segment genotypes */
 } csv_batch_in;
 
 /*
@@ -115,6 +118,11 @@ typedef struct csv_batch_in {
  * call_aux: aux of the cluster's first signature (INV strand / TRA chr2,type).
  * dr / dv / gl_idx: genotype read counts (GT:161-173) and the index of cal_GL's result
  *   (GT:33-56) in the table defined by csv_gl_index(); -1 when the segment is not genotyped.
+ *   TRA: call_gt / count_coverage (TRA:258-309, GT:62-93) evaluated over the READS TABLE
+ *   instead of a BAM re-fetch: `fetch(chr, s, e)` = the reads of the chromosome's block with start < e and
+ *   end > s, in block order; flag in [0, 16] = r_primary.  Identical to the reference whenever the BAM holds
+ *   no alignment inside the two windows that the reads table drops (secondary flag 256/272, mapq < min_mapq,
+ *   MAIN:711-733).  count_coverage's give-up status (-1) is dr = -1, gl_idx = -1 ("./.", DR ".").
  * support_off/support_sig: CSR list of the signatures whose read names form the call's
  *   read list, in reference order where that order is deterministic.
  * cluster_id / allele_id: optional per-signature outputs (NULL to skip): dense id of the

@@ -560,6 +560,85 @@ static int64_t collect_cover(work_t* w, int64_t r0, int64_t r1, int64_t L2, int6
     return n;
 }
 
+/* threshold_ref_count (GT:62-70) */
+static int64_t tra_up_bound(int64_t num)
+{
+    if (num <= 2) return 20 * num;
+    if (num <= 5) return 9 * num;
+    if (num <= 15) return 7 * num;
+    return 5 * num;
+}
+
+/* count_coverage (GT:72-93) with `f.fetch(chr, s, e)` restated over the reads block of chromosome ch: the
+ * reads with start < e and end > s, in block (start-sorted) order; `flag in [0, 16]` is r_primary.
+ * q / nq: the querydata set shared by the two windows (TRA:262). */
+static int tra_count_coverage(work_t* w, int32_t ch, int64_t s, int64_t e, int32_t* q, int64_t* nq,
+                              int64_t up_bound, int64_t itround)
+{
+    const csv_batch_in* in = w->in;
+    int status = 0;
+    int64_t iteration = 0, primary_num = 0;
+    if (s >= e) return 0;
+    for (int64_t i = in->reads_off[ch]; i < in->reads_off[ch + 1]; i++) {
+        if (in->r_start[i] >= e) break;
+        if (in->r_end[i] <= s) continue;
+        iteration++;                                                     /* GT:77 */
+        if (in->r_primary[i] != 1) continue;                             /* GT:78-79 */
+        primary_num++;
+        if (in->r_start[i] < s && in->r_end[i] > e) {                    /* GT:81-85 */
+            int64_t j = 0;
+            while (j < *nq && q[j] != in->r_id[i]) j++;
+            if (j == *nq) q[(*nq)++] = in->r_id[i];
+            if (*nq >= up_bound) { status = 1; break; }
+        }
+        if (iteration >= itround) {                                      /* GT:86-91 */
+            status = ((double)primary_num / (double)iteration <= 0.2) ? 1 : -1;
+            break;
+        }
+    }
+    return status;
+}
+
+/* call_gt of cuteSV_resolveTRA.py:258-309 for call c */
+static int tra_genotype(work_t* w, int64_t c, const csv_segment* sg, int32_t** qbuf, int64_t* qcap)
+{
+    const csv_batch_in* in = w->in;
+    csv_batch_out* o = w->out;
+    const int64_t ns = o->support_off[c + 1] - o->support_off[c];      /* len(read_id_list): a set of names */
+    const int64_t up_bound = tra_up_bound(ns);                           /* TRA:266 */
+    const int32_t chr1 = sg->chrom, chr2 = o->call_aux[c] >> 3;
+    if (chr2 < 0 || chr2 >= in->n_chrom) return CSV_E_INVALID;
+    if (*qcap < up_bound + 2) {
+        int32_t* nq_ = (int32_t*)realloc(*qbuf, (size_t)(up_bound + 2) * sizeof(int32_t));
+        if (!nq_) return CSV_E_NOMEM;
+        *qbuf = nq_; *qcap = up_bound + 2;
+    }
+    int32_t* q = *qbuf;
+    int64_t nq = 0;
+    const int64_t bias = sg->gt_bias;
+    int64_t s = o->bp1[c] - bias, e = o->bp1[c] + bias;                 /* TRA:263-264 */
+    if (s < 0) s = 0;
+    if (e > in->contig_len[chr1]) e = in->contig_len[chr1];
+    int status = tra_count_coverage(w, chr1, s, e, q, &nq, up_bound, sg->gt_round);
+    o->dv[c] = (int32_t)ns;
+    if (status == -1) { o->dr[c] = -1; o->gl_idx[c] = -1; return CSV_OK; }   /* TRA:276-281 */
+    if (status == 0) {                                                   /* TRA:290-299: status_2 is not looked at */
+        s = o->bp2[c] - bias; e = o->bp2[c] + bias;
+        if (s < 0) s = 0;
+        if (e > in->contig_len[chr2]) e = in->contig_len[chr2];
+        tra_count_coverage(w, chr2, s, e, q, &nq, up_bound, sg->gt_round);
+    }
+    int64_t dr = 0;                                                      /* TRA:284-287, 301-304 */
+    for (int64_t j = 0; j < nq; j++) {
+        int found = 0;
+        for (int64_t i = 0; i < ns && !found; i++) found = in->read_id[o->support_sig[o->support_off[c] + i]] == q[j];
+        if (!found) dr++;
+    }
+    o->dr[c] = (int32_t)dr;
+    o->gl_idx[c] = csvo_gl_index(dr, ns);
+    return CSV_OK;
+}
+
 static int genotype_all(work_t* w)
 {
     const csv_batch_in* in = w->in;
@@ -581,15 +660,21 @@ static int genotype_all(work_t* w)
     int64_t cap = 1024;
     int32_t* cov = (int32_t*)malloc((size_t)cap * sizeof(int32_t));
     int32_t* sup = NULL; int64_t sup_cap = 0;
+    int32_t* qbuf = NULL; int64_t qcap = 0;
     if (!cov) return CSV_E_NOMEM;
     for (int64_t c = 0; c < nc; c++) {
         const csv_segment* sg = &in->seg[o->call_seg[c]];
         if (!sg->genotype) continue;
+        if (sg->svtype == CSV_TRA) {
+            const int rc = tra_genotype(w, c, sg, &qbuf, &qcap);
+            if (rc) { free(cov); free(sup); free(qbuf); return rc; }
+            continue;
+        }
         const int64_t r0 = in->reads_off[sg->chrom], r1 = in->reads_off[sg->chrom + 1];
         if (cap < 2 * (r1 - r0) + 16) {
             cap = 2 * (r1 - r0) + 16;
             int32_t* q = (int32_t*)realloc(cov, (size_t)cap * sizeof(int32_t));
-            if (!q) { free(cov); free(sup); return CSV_E_NOMEM; }
+            if (!q) { free(cov); free(sup); free(qbuf); return CSV_E_NOMEM; }
             cov = q;
         }
         int64_t n = 0;
@@ -610,7 +695,7 @@ static int genotype_all(work_t* w)
         int64_t u = 0;
         if (n) { qsort(cov, (size_t)n, sizeof(int32_t), cmp_i32); u = 1; for (int64_t i = 1; i < n; i++) if (cov[i] != cov[u - 1]) cov[u++] = cov[i]; }
         const int64_t ns = o->support_off[c + 1] - o->support_off[c];
-        if (ns > sup_cap) { sup_cap = ns * 2; int32_t* q = (int32_t*)realloc(sup, (size_t)sup_cap * sizeof(int32_t)); if (!q) { free(cov); free(sup); return CSV_E_NOMEM; } sup = q; }
+        if (ns > sup_cap) { sup_cap = ns * 2; int32_t* q = (int32_t*)realloc(sup, (size_t)sup_cap * sizeof(int32_t)); if (!q) { free(cov); free(sup); free(qbuf); return CSV_E_NOMEM; } sup = q; }
         for (int64_t i = 0; i < ns; i++) sup[i] = in->read_id[o->support_sig[o->support_off[c] + i]];
         qsort(sup, (size_t)ns, sizeof(int32_t), cmp_i32);
         int64_t dr = 0;                                                    /* GT:167-170 */
@@ -620,7 +705,7 @@ static int genotype_all(work_t* w)
         o->dv[c] = (int32_t)ns;                                            /* GT:171-172: len(read_id_dict[idx]) */
         o->gl_idx[c] = csvo_gl_index(dr, ns);
     }
-    free(cov); free(sup);
+    free(cov); free(sup); free(qbuf);
     return CSV_OK;
 }
 
@@ -638,9 +723,10 @@ int csvo_cluster_batch(const csv_batch_in* in, csv_batch_out* out)
     for (int32_t k = 0; k < in->n_seg && rc == CSV_OK; k++) {
         const csv_segment* sg = &in->seg[k];
         if (sg->svtype < CSV_DEL || sg->svtype > CSV_TRA || sg->sig_begin > sg->sig_end ||
-            sg->sig_end > in->n_sig || (sg->svtype == CSV_TRA && sg->genotype)) { rc = CSV_E_INVALID; break; }
-        /* a genotyped segment whose chromosome has no reads block yields nothing (INDEL:443-444) */
-        const int drop = sg->genotype && (!in->reads_off || in->reads_off[sg->chrom + 1] == in->reads_off[sg->chrom]);
+            sg->sig_end > in->n_sig || (sg->svtype == CSV_TRA && sg->genotype && (!in->contig_len || !in->reads_off))) { rc = CSV_E_INVALID; break; }
+        /* a genotyped segment whose chromosome has no reads block yields nothing (INDEL:443-444, DUP:139-140,
+         * INV:210-211); TRA genotyping has no such gate (TRA:258-309) */
+        const int drop = sg->genotype && sg->svtype != CSV_TRA && (!in->reads_off || in->reads_off[sg->chrom + 1] == in->reads_off[sg->chrom]);
         int64_t start = sg->sig_begin;
         for (int64_t i = sg->sig_begin; i < sg->sig_end; i++) {
             int brk = (i == sg->sig_begin);

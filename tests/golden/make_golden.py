@@ -3,8 +3,9 @@
 
     python tests/golden/make_golden.py            # needs /root/reference (read-only mount)
 
-The reference is imported from /root/reference/src with a stub `pysam` module (its only use on
-this path is the VCF emitter's FastaFile and TRA genotyping, neither of which is called here).
+The reference is imported from /root/reference/src with a stub `pysam` module: FastaFile (the VCF
+emitter) serves synthetic chromosome strings and AlignmentFile (TRA genotyping, cuteSV_resolveTRA.py:258-309)
+serves the store's reads table as the alignment stream.
 Nothing of the reference is copied: the outputs are data — the inputs we synthesise (flat arrays)
 and the rows / values the reference returns for them.  The GPU box never runs this script.
 
@@ -14,6 +15,7 @@ Outputs
     gl_table.json.gz       cal_GL over its whole rescaled domain + large-count samples, cal_CIPOS samples
     overlap_cover.json.gz  random overlap_cover instances (ties, x.5 windows, non-primary, repeated names)
     sim_sites.npz          truth sites of simulation/sim_*.bed.gz as integer arrays (data for cfg-1 / cfg-2)
+    tra_genotype.json.gz   TRA tasks run with action=True (call_gt / count_coverage over the reads table) + their VCF lines
     vcf_lines.json.gz      generate_output lines (+ SVID numbering) for some small cases x report_readid / ignore_sequence
     digests.json           sha256 of the reference's canonical rows per (type, chr) for BASELINE configs 1-5
                            (cfg-3/4/5 at reduced scale so the reference finishes in minutes)
@@ -49,7 +51,41 @@ class _FastaFile:                                          # pysam.FastaFile sta
         pass
 
 
+_BAM = {"store": None}
+
+
+class _Aln:
+    __slots__ = ("flag", "reference_start", "reference_end", "query_name")
+
+
+class _AlignmentFile:                                      # pysam.AlignmentFile stand-in: the store's reads table as the BAM
+    def __init__(self, path):
+        self.st = _BAM["store"]
+
+    def get_reference_length(self, chrom):
+        return int(self.st.contig_len[self.st.chroms.index(chrom)])
+
+    def fetch(self, chrom, s, e):                          # alignments overlapping [s, e), coordinate order
+        st = self.st
+        if s > e:
+            raise ValueError("invalid coordinates: start (%i) > stop (%i)" % (s, e))
+        c = st.chroms.index(chrom)
+        for i in range(int(st.reads_off[c]), int(st.reads_off[c + 1])):
+            if st.r_start[i] >= e:
+                break
+            if st.r_end[i] > s:
+                a = _Aln()
+                a.flag = 0 if st.r_primary[i] == 1 else 2048
+                a.reference_start, a.reference_end = int(st.r_start[i]), int(st.r_end[i])
+                a.query_name = st.names[st.r_id[i]]
+                yield a
+
+    def close(self):
+        pass
+
+
 _pysam.FastaFile = _FastaFile
+_pysam.AlignmentFile = _AlignmentFile
 sys.modules["pysam"] = _pysam
 sys.path.insert(0, os.path.join(REF, "src"))
 from cuteSV import cuteSV_resolveINDEL as R_INDEL          # noqa: E402
@@ -99,6 +135,7 @@ def write_reference_workdir(store, work_dir):
 def run_reference(store, p, tasks=None):
     """rows per (type, chr) exactly as phase 3 of main_ctrl would obtain them (main script :1116-1189)."""
     out = {}
+    _BAM["store"] = store
     with tempfile.TemporaryDirectory() as d:
         d = d + "/"
         idx = write_reference_workdir(store, d)
@@ -117,7 +154,7 @@ def run_reference(store, p, tasks=None):
                                    p.max_size, p.gt_round, idx))
             else:
                 r = R_TRA.run_tra((d, ch, p.min_support, p.diff_ratio_filtering_TRA, p.max_cluster_bias_TRA, "bam",
-                                   False, p.gt_round, idx))
+                                   bool(p.genotype and p.genotype_tra), p.gt_round, idx))
             assert r[0] == ch
             out[(t, ch)] = [[str(x) for x in row] for row in r[1]]
     return out
@@ -149,6 +186,8 @@ def store_to_json(store):
     if store.reads_off is not None:
         d.update(reads_off=store.reads_off.tolist(), r_start=store.r_start.tolist(), r_end=store.r_end.tolist(),
                  r_primary=store.r_primary.tolist(), r_id=store.r_id.tolist())
+    if store.contig_len is not None:
+        d.update(contig_len=store.contig_len.tolist())
     return d
 
 
@@ -440,8 +479,101 @@ def vcf_lines():
     return out
 
 
+# ----------------------------------------------------------------------------- TRA genotyping
+def _tra_store(seed, n_sites, coverage, read_cov, contig_len=300_000, n_contigs=3, nonprimary=0.1, dark_contig=None):
+    """TRA-only store: n_sites breakpoint pairs, `coverage` supporting reads each, a reads table of depth
+    read_cov whose names partly coincide with the supporting reads; `dark_contig` gets 90 % non-primary reads."""
+    rng = np.random.default_rng(seed)
+    chroms = [str(i + 1) for i in range(n_contigs)]
+    names = ["q%06d" % i for i in range(40000)]
+    per = {t: [] for t in TYPES}
+    reads = []
+    nm = 0
+    for ci, ch in enumerate(chroms):
+        n_r = int(read_cov * contig_len / 12000)
+        starts = np.sort(rng.integers(0, contig_len - 2000, n_r))
+        lens = np.clip(rng.normal(12000, 5000, n_r), 1500, 60000).astype(np.int64)
+        for s0, ln in zip(starts.tolist(), lens.tolist()):
+            frac = 0.9 if ch == dark_contig else nonprimary
+            reads.append((int(s0), int(min(s0 + ln, contig_len)), int(rng.random() >= frac), names[nm % len(names)], ch))
+            nm += 1
+    for s in range(n_sites):
+        c1 = int(rng.integers(0, n_contigs)); c2 = int((c1 + 1 + rng.integers(0, n_contigs - 1)) % n_contigs)
+        p1 = int(rng.integers(2000, contig_len - 2000)); p2 = int(rng.integers(2000, contig_len - 2000))
+        if s % 7 == 0:
+            p1 = int(rng.integers(0, 40))                    # window clipped at 0
+        if s % 7 == 1:
+            p2 = contig_len - int(rng.integers(0, 40))        # window clipped at the contig end
+        k = max(2, int(rng.poisson(coverage)))
+        typ = "ABCD"[s % 4]
+        # supporting reads: half of them are reads of the table that span the breakpoint
+        spanning = [r for r in reads if r[4] == chroms[c1] and r[0] < p1 - 60 and r[1] > p1 + 60]
+        for j in range(k):
+            if spanning and rng.random() < 0.5:
+                name = spanning[int(rng.integers(0, len(spanning)))][3]
+            else:
+                name = "s%05d_%03d" % (s, j)
+            per["TRA"].append((typ, max(0, p1 + int(rng.normal(0, 6))), chroms[c2], max(0, p2 + int(rng.normal(0, 6))),
+                               name, "TRA", chroms[c1]))
+    return SigStore.from_tuple_lists(per, reads, chroms=chroms, contig_len={c: contig_len for c in chroms})
+
+
+def tra_genotype_cases():
+    import argparse
+    cases = []
+    specs = [
+        ("tra_default", dict(seed=1, n_sites=40, coverage=12, read_cov=30), Params(genotype=True, genotype_tra=True)),
+        ("tra_lowsup_upbound", dict(seed=2, n_sites=40, coverage=3, read_cov=80), Params(genotype=True, genotype_tra=True, min_support=2)),
+        ("tra_round25", dict(seed=3, n_sites=40, coverage=12, read_cov=40), Params(genotype=True, genotype_tra=True, gt_round=25)),
+        ("tra_round8_dark", dict(seed=4, n_sites=60, coverage=10, read_cov=40, dark_contig="2"),
+         Params(genotype=True, genotype_tra=True, gt_round=8, min_support=3)),
+        ("tra_widebias", dict(seed=5, n_sites=40, coverage=15, read_cov=25),
+         Params(genotype=True, genotype_tra=True, max_cluster_bias_TRA=800, min_support=5)),
+        ("tra_deep", dict(seed=6, n_sites=25, coverage=60, read_cov=150), Params(genotype=True, genotype_tra=True, gt_round=500)),
+    ]
+    for name, kw, p in specs:
+        st = _tra_store(**kw)
+        rows = run_reference(st, p)
+        case = dict(name=name, params=params_to_json(p), store=store_to_json(st),
+                    rows=[[t, c, r] for (t, c), r in rows.items()])
+        allrows = [r for v in rows.values() for r in v]
+        stat = {"dot": sum(r[7] == "./." for r in allrows), "n": len(allrows),
+                "dr0": sum(r[6] == "0" for r in allrows)}
+        # VCF text of the genotyped BND rows (generate_output + numbering), report_readid on
+        _REF_SEQS.clear()
+        for i, c in enumerate(st.chroms):
+            _REF_SEQS[c] = synth.reference_sequence(int(st.contig_len[i]), seed=2000 + i)
+        args = argparse.Namespace(genotype=True, max_size=p.max_size, min_size=p.min_size, report_readid=True, ignore_sequence=False)
+        text, svid = [], {"INS": 0, "DEL": 0, "BND": 0, "DUP": 0, "INV": 0}
+        results = {}
+        for (t, c), r in rows.items():
+            results.setdefault(c, []).extend([list(x) for x in r])
+        with tempfile.TemporaryDirectory() as d:
+            d += "/"
+            os.mkdir(d + "results")
+            for c in sorted(results):
+                R_GT.generate_output(args, [list(r) for r in results[c]], "ref.fa", c, d)
+            for c in sorted(results):
+                with open("%sresults/%s.pickle" % (d, c), "rb") as f:
+                    while True:
+                        try:
+                            for svtype, line in pickle.load(f):
+                                text.append(line.replace("<SVID>", str(svid[svtype])))
+                                svid[svtype] += 1
+                        except EOFError:
+                            break
+        case["vcf"] = dict(ref_seed0=2000, text="".join(text))
+        cases.append(case)
+        print("tra case %-20s sigs=%d reads=%d rows=%s" % (name, st.n_sig, st.n_reads, stat))
+    return cases
+
+
 def main():
     os.chdir(HERE)
+    if len(sys.argv) > 1 and sys.argv[1] == "tra":
+        with gzip.open("tra_genotype.json.gz", "wt") as f:
+            json.dump(tra_genotype_cases(), f)
+        return
     sites = sim_sites()
     np.savez_compressed("sim_sites.npz", **sites)
     with gzip.open("small_cases.json.gz", "wt") as f:
@@ -454,6 +586,8 @@ def main():
         json.dump(overlap_cases(), f)
     with gzip.open("vcf_lines.json.gz", "wt") as f:
         json.dump(vcf_lines(), f)
+    with gzip.open("tra_genotype.json.gz", "wt") as f:
+        json.dump(tra_genotype_cases(), f)
     with open("digests.json", "w") as f:
         json.dump(config_digests(sites), f, indent=1)
     for fn in sorted(os.listdir(".")):

@@ -29,6 +29,8 @@ def store_from_json(d):
         kw = dict(reads_off=np.array(d["reads_off"], np.int64), r_start=np.array(d["r_start"], np.int64),
                   r_end=np.array(d["r_end"], np.int64), r_primary=np.array(d["r_primary"], np.uint8),
                   r_id=np.array(d["r_id"], np.int32))
+    if d.get("contig_len") is not None:
+        kw["contig_len"] = np.array(d["contig_len"], np.int64)
     return SigStore(chroms=d["chroms"], a=np.array(d["a"], np.int64), b=np.array(d["b"], np.int64),
                     read_id=np.array(d["read_id"], np.int32), aux=np.array(d["aux"], np.int32),
                     seg_index={(t, c): (b, e) for t, c, b, e in d["seg_index"]},

@@ -81,6 +81,14 @@ def test_large_clusters_all_tiers(ctx):
     assert sizes.max() > 2048, sizes.max()
 
 
+def test_genotype_cover_overflow_pass(ctx):
+    # ~1000x coverage: support + cover of a call exceeds the 4 KB hash set, so the second (32 KB) pass runs
+    st = synth.small_mixed(seed=78, n_sites=6, coverage=1000, n_noise=100, n_loci=20, contig_len=200_000, n_contigs=2)
+    got = _compare_soa(ctx, st, Params(genotype=True, min_support=10))
+    tot = got["dr"].astype(np.int64) + got["dv"]
+    assert tot.max() > 1500 and tot.max() < 6000, tot.max()
+
+
 @pytest.mark.parametrize("name", ["cfg1", "cfg2", "cfg3_s025", "cfg4_s002", "cfg5_s002"])
 def test_config_digests(ctx, name, golden_dir):
     d = load_json("digests.json")[name]
@@ -115,13 +123,34 @@ def test_empty_and_ragged(ctx):
     _compare_soa(ctx, st, p, tasks=tasks)
 
 
-def test_tra_genotype_is_refused(ctx):
+def test_tra_genotype_needs_the_reference_lengths(ctx):
     st = synth.small_mixed(seed=5)
     hb = st.host_batch([t for t in st.tasks() if t[0] == "TRA"][:1], Params())
-    hb.segments["genotype"] = 1
+    hb.segments["genotype"] = 1                      # no reads table / contig_len in this batch
     with pytest.raises(engine.CsvError) as e:
         ctx.cluster_batch(hb)
     assert e.value.code == _abi.E_INVALID
+
+
+def test_tra_genotyping_rows_identical_to_reference(ctx):
+    # call_gt / count_coverage (cuteSV_resolveTRA.py:258-309) over the reads table: every exit of the loop
+    for case in load_json("tra_genotype.json.gz"):
+        st = store_from_json(case["store"])
+        p = Params(**case["params"])
+        want = {(t, c): r for t, c, r in case["rows"]}
+        got, res, hb = rows_by_task(st, p, _hip_engine(ctx), tasks=list(want.keys()))
+        for key in want:
+            assert_rows_equal(key[0], got[key], want[key], where="%s %s" % (case["name"], key))
+
+
+@pytest.mark.parametrize("gt_round", [500, 30, 6])
+def test_tra_genotyping_in_a_mixed_batch_vs_oracle(ctx, gt_round):
+    st = synth.small_mixed(seed=400 + gt_round, n_sites=60, coverage=25, contig_len=400_000, n_loci=100)
+    got = _compare_soa(ctx, st, Params.ont(genotype=True, genotype_tra=True, gt_round=gt_round, min_support=3))
+    tra = np.flatnonzero(np.isin(got["call_seg"], [k for k, t in enumerate(st.tasks()) if t[0] == "TRA"]))
+    assert len(tra) > 5 and (got["dv"][tra] > 0).all()
+    if gt_round == 6:
+        assert (got["gl_idx"][tra] < 0).any()
 
 
 def test_drop_in_shims_on_a_reference_workdir(ctx, tmp_path, monkeypatch):

@@ -31,7 +31,7 @@ def test_c_abi_exports_every_declared_symbol():
     from cutesv_amd import genotype
     for c0, c1 in ((3, 1), (6, 2), (0, 5), (17, 9), (250, 31), (0, 400), (99, 2)):
         assert L.csv_gl_index(c0, c1) == genotype.gl_index(c0, c1)
-    assert C.sizeof(_abi.BatchIn) == 104 and C.sizeof(_abi.BatchOut) == 176 and C.sizeof(_abi.RunStats) == 112
+    assert C.sizeof(_abi.BatchIn) == 112 and C.sizeof(_abi.BatchOut) == 176 and C.sizeof(_abi.RunStats) == 112
     assert _abi.SEGMENT_DTYPE.itemsize == 88      # sizeof(csv_batch_in / _out / csv_run_stats / csv_segment) as gcc lays them out
 
 
@@ -113,8 +113,25 @@ def test_shims_follow_the_reference_argument_contract():
     assert resolve.run_inv(("/nonexistent/", "7", "INV", 10, 500, 30, "bam", False, 100000, 500, idx)) == ("7", [])
     assert resolve.run_dup(("/nonexistent/", "7", 10, 500, 30, "bam", False, 100000, 500, idx)) == ("7", [])
     assert resolve.run_tra(("/nonexistent/", "7", 10, 0.6, 50, "bam", False, 500, idx)) == ("7", [])
-    with pytest.raises(NotImplementedError):
-        resolve.run_tra(("/nonexistent/", "7", 10, 0.6, 50, "bam", True, 500, idx))
+    assert resolve.run_tra(("/nonexistent/", "7", 10, 0.6, 50, "bam", True, 500, idx)) == ("7", [])
+
+
+def test_bam_header_reference_lengths(tmp_path):
+    # a BAM header is: magic, l_text, text, n_ref, then (l_name, name NUL, l_ref) per reference, in gzip members
+    import gzip, struct
+    from cutesv_amd.bam_header import reference_lengths
+    refs = [("chr1", 248956422), ("chrUn_KI270442v1", 392061), ("MT", 16569)]
+    text = b"@HD\tVN:1.6\tSO:coordinate\n"
+    raw = b"BAM\x01" + struct.pack("<i", len(text)) + text + struct.pack("<i", len(refs))
+    for n, l in refs:
+        raw += struct.pack("<i", len(n) + 1) + n.encode() + b"\0" + struct.pack("<i", l)
+    p = tmp_path / "x.bam"
+    with open(p, "wb") as f:                      # two gzip members, like consecutive BGZF blocks
+        f.write(gzip.compress(raw[:30])); f.write(gzip.compress(raw[30:] + b"alignment records follow"))
+    assert reference_lengths(str(p)) == dict(refs)
+    (tmp_path / "y.bam").write_bytes(gzip.compress(b"CRAM...."))
+    with pytest.raises(ValueError):
+        reference_lengths(str(tmp_path / "y.bam"))
 
 
 def test_two_rank_gloo_sharded_stage_matches_single_rank():

@@ -42,6 +42,18 @@ def test_known_answers():
         _check_case(case)
 
 
+def test_tra_genotyping_rows_identical_to_reference():
+    # call_gt / count_coverage (cuteSV_resolveTRA.py:258-309) with the reads table as the alignment stream
+    cases = load_json("tra_genotype.json.gz")
+    assert len(cases) >= 6
+    seen = set()
+    for case in cases:
+        _check_case(case)
+        for _, _, rows in case["rows"]:
+            seen |= {"dot" if r[7] == "./." else "gt" for r in rows}
+    assert seen == {"dot", "gt"}
+
+
 def test_gl_table_and_index():
     g = load_json("gl_table.json.gz")
     lib = oracle.lib()

@@ -48,6 +48,19 @@ def test_vcf_text_identical_to_reference():
         assert int(svid.sum()) == g["text"].count("\n")
 
 
+def test_vcf_text_of_genotyped_bnd_records():
+    for case in load_json("tra_genotype.json.gz"):
+        st = store_from_json(case["store"])
+        p = Params(**case["params"])
+        ref = {c: synth.reference_sequence(int(st.contig_len[i]), seed=case["vcf"]["ref_seed0"] + i) for i, c in enumerate(st.chroms)}
+        hb = st.host_batch([(t, c) for t, c, _ in case["rows"]], p)
+        res = oracle.cluster_batch(hb, per_sig=False)
+        text, svid = vcf.emit_records(st, hb.segments, res, ref, min_size=p.min_size, max_size=p.max_size,
+                                      genotype=True, report_readid=True)
+        want = case["vcf"]["text"]
+        assert _canon(text) == _canon(want), "%s: %s" % (case["name"], _first_diff(_canon(text), _canon(want)))
+
+
 def test_svid_counters_continue_across_calls():
     case = load_json("small_cases.json.gz")[0]
     st = store_from_json(case["store"])
