@@ -6,7 +6,8 @@ import os
 from . import _abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcutesv_hip.so")
+# CUTESV_AMD_LIB: load another build of the same library (A/B timing of kernel variants); never a CPU fallback
+LIB_PATH = os.environ.get("CUTESV_AMD_LIB") or os.path.join(_HERE, "libcutesv_hip.so")
 _LIB = None
 
 # every symbol include/cutesv_hip.h declares: (name, restype, argtypes)
