@@ -1239,28 +1239,44 @@ template <int SW> __device__ __forceinline__ int sub_scan_i32(int v)
     return v;
 }
 
-// numpy's pairwise sum of sq over the allele [r0, r0 + n) (absolute lanes), n <= 64, valid on the lane with
-// i == 0 (i = lane - r0).  8 strided accumulators on lanes i < 8, the fixed combine tree, then the tail.
-// rows / tail are wave-uniform upper bounds of n / 8 and of the sequential tail length.
-__device__ __forceinline__ double np_sum_allele(double sq, int r0, int n, int i, int rows, int tail)
+// ds_bpermute with a ready byte address (lane << 2): no per-call index arithmetic
+__device__ __forceinline__ double bperm_f64(int addr4, double v)
+{
+    const i64 b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_ds_bpermute(addr4, (int)(b & 0xffffffffll)), hi = __builtin_amdgcn_ds_bpermute(addr4, (int)(b >> 32));
+    return __longlong_as_double(((i64)hi << 32) | (unsigned)lo);
+}
+// value of the lane to the right (lane 63 gets 0): DPP wave_shl:1
+__device__ __forceinline__ double wave_shl1_f64(double v) { return __longlong_as_double(dpp_i64<0x130, 0xf>(0, __double_as_longlong(v))); }
+
+// numpy's pairwise sum of two per-lane series (sq1, sq2) over the allele [r0, r0 + n) (absolute lanes), n <= 64,
+// valid on the lane with i == 0 (i = lane - r0).  8 strided accumulators on lanes i < 8, the fixed combine
+// tree, then the sequential tail (the tail values are fetched once and then walk down to the head lane with
+// wave_shl:1).  rows / tail are wave-uniform upper bounds of n / 8 and of the tail length.  Both series share
+// the cross-lane addresses and predicates.
+__device__ __forceinline__ void np_sum_allele2(double sq1, double sq2, int n, int i, int rows, int tail, double& out1, double& out2)
 {
     const int lane = lane_id();
     const int nfull = n - (n & 7);
-    double acc = sq;
+    double acc1 = sq1, acc2 = sq2;
     for (int t = 1; t < rows; t++) {
-        const double v = shfl_f64(sq, (lane + 8 * t) & 63);
-        if (i < 8 && i + 8 * t < nfull) acc += v;
+        const int addr = ((lane + 8 * t) & 63) << 2;
+        const double v1 = bperm_f64(addr, sq1), v2 = bperm_f64(addr, sq2);
+        if (i < 8 && i + 8 * t < nfull) { acc1 += v1; acc2 += v2; }
     }
-    const double t1 = acc + shfl_f64(acc, (lane + 1) & 63);
-    const double t2 = t1 + shfl_f64(t1, (lane + 2) & 63);
-    const double t3 = t2 + shfl_f64(t2, (lane + 4) & 63);
-    double res = (n >= 8) ? t3 : 0.0;
+    const int ad1 = ((lane + 1) & 63) << 2, ad2 = ((lane + 2) & 63) << 2, ad4 = ((lane + 4) & 63) << 2;
+    const double p1 = acc1 + bperm_f64(ad1, acc1), q1 = acc2 + bperm_f64(ad1, acc2);
+    const double p2 = p1 + bperm_f64(ad2, p1), q2 = q1 + bperm_f64(ad2, q1);
+    const double p3 = p2 + bperm_f64(ad4, p2), q3 = q2 + bperm_f64(ad4, q2);
+    double res1 = (n >= 8) ? p3 : 0.0, res2 = (n >= 8) ? q3 : 0.0;
     const int start = (n >= 8) ? nfull : 0;
+    const int adt = ((lane + start) & 63) << 2;               // lane L now holds element start + (L - r0) of its allele
+    double t1 = bperm_f64(adt, sq1), t2 = bperm_f64(adt, sq2);
     for (int e = 0; e < tail; e++) {
-        const double v = shfl_f64(sq, (r0 + start + e) & 63);
-        if (start + e < n) res += v;
+        if (start + e < n) { res1 += t1; res2 += t2; }
+        t1 = wave_shl1_f64(t1); t2 = wave_shl1_f64(t2);
     }
-    return res;
+    out1 = res1; out2 = res2;
 }
 
 #ifndef CSV_IW_WAVES
@@ -1325,10 +1341,14 @@ template <int SW> __device__ __forceinline__ int indel_unit(const DevBatch& B, i
             int orv = in ? rid : 0;
             orv |= dpp_i32<0x111, 0xf>(0, orv); orv |= dpp_i32<0x112, 0xf>(0, orv); orv |= dpp_i32<0x114, 0xf>(0, orv);
             orv |= dpp_i32<0x118, 0xf>(0, orv); orv |= dpp_i32<0x142, 0xa>(0, orv); orv |= dpp_i32<0x143, 0xc>(0, orv);
-            const int nbits = 32 - __builtin_clz((unsigned)__builtin_amdgcn_readlane(orv, 63) | 1u);
+            int nbits = 32 - __builtin_clz((unsigned)__builtin_amdgcn_readlane(orv, 63) | 1u);
+            // more than 12 id bits: compare a 12-bit fold instead.  Equal ids still always match; a false match only
+            // sends the wavefront through the exact loop below (probability ~m^2 / 8192 per cluster).
+            int hid = rid;
+            if (nbits > 12) { hid = (rid ^ (rid >> 12) ^ (rid >> 24)) & 0xfff; nbits = 12; }
             u64 match = inmask;
             for (int bit = 0; bit < nbits; bit++) {
-                const bool set = (rid >> bit) & 1;
+                const bool set = (hid >> bit) & 1;
                 const u64 mk = __ballot(set);
                 match &= set ? mk : ~mk;
             }
@@ -1358,12 +1378,11 @@ template <int SW> __device__ __forceinline__ int indel_unit(const DevBatch& B, i
         // ---- stable sort of the kept signatures by length (INDEL:136): rank by (len, first appearance)
         int rank = 0;
         if (HALF) {
-            if (!__ballot(rep && (bl >> 31) != 0)) {                 // every kept length fits 31 bits: one word per step
-                const int bl32 = rep ? (int)bl : 0x7fffffff;       // non-kept lanes never count as smaller
-                for (int t = 0; t < mmax; t++) {
-                    const int lt = sub_rl<SW>(bl32, t, hi);
-                    rank += (lt < bl32) || (lt == bl32 && t < sl);
-                }
+            if (!__ballot(rep && (bl >> 26) != 0)) {
+                // every kept length fits 26 bits: (length, first appearance) packs into ONE word, so a step is a
+                // broadcast, a compare and an add.  Lanes that are not kept never count as smaller.
+                const int key = rep ? (((int)bl << 5) | sl) : 0x7fffffff;
+                for (int t = 0; t < mmax; t++) rank += sub_rl<SW>(key, t, hi) < key;
             } else {
                 for (int t = 0; t < mmax; t++) {
                     const i64 lt = sub_rl64<SW>(bl, t, hi);
@@ -1455,9 +1474,8 @@ template <int SW> __device__ __forceinline__ int indel_unit(const DevBatch& B, i
             bp = (double)ks / (double)keep; siglen = (double)kl / (double)keep;   // INDEL:176-177, 187
         }
         const int rows_u = (mmax >> 3) + 1, tail_u = mmax < 7 ? mmax : 7;         // wave-uniform bounds (allele size <= m)
-        const int r0a = hb | r0;
-        const double vsp = np_sum_allele(((double)pos - pmean) * ((double)pos - pmean), r0a, n, i, rows_u, tail_u);
-        const double vsl = np_sum_allele(((double)len - lmean) * ((double)len - lmean), r0a, n, i, rows_u, tail_u);
+        double vsp, vsl;
+        np_sum_allele2(((double)pos - pmean) * ((double)pos - pmean), ((double)len - lmean) * ((double)len - lmean), n, i, rows_u, tail_u, vsp, vsl);
         const double rt = B.sqrt_tab[n & (SQRT_TAB - 1)];
         const int cip = (int)(1.96 * sqrt(vsp / (double)n) / rt);                 // INDEL:191, GT:58-60
         const int cil = (int)(1.96 * sqrt(vsl / (double)n) / rt);                 // INDEL:194
