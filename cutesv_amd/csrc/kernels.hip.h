@@ -1825,23 +1825,43 @@ __device__ __forceinline__ i64 upper_bound_start(const i64* __restrict__ st, i64
     return lo + __popcll(__ballot(pred));
 }
 
+// Backwards stabbing scan from the last read with start <= L.  The scan is a chain of dependent round trips
+// (~28 chunks of 64 reads per window on 90x ultra-long reads, 1-2 on HiFi), so after the first chunk
+// GT_UNROLL chunks are loaded per step (all loads issued before the first one is used) and consumed in order.
+constexpr int GT_UNROLL = 4;
+// one step over U chunks below `top`; returns true when the scan is over (dead lane met, overflow)
+template <int HASH, int U> __device__ __forceinline__ bool cover_step(const DevBatch& B, int* tab, i64 r0, i64 top, i64 R2, int& dr, int& filled, bool& overflow)
+{
+    i64 pm[U], en[U];
+    int id[U], pr[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const i64 i = top - u * 64 - lane_id();
+        const i64 ii = i >= r0 ? i : r0;
+        pm[u] = B.r_pmax[ii]; en[u] = B.r_end[ii]; pr[u] = B.r_primary[ii]; id[u] = B.r_id[ii];
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const i64 i = top - u * 64 - lane_id();
+        const int in = i >= r0;
+        const int live = in && (2 * pm[u] >= R2);                     // nothing at or before a dead lane reaches R
+        const int cov = live && pr[u] == 1 && (2 * en[u] >= R2);
+        if (filled + 64 > HASH * 3 / 4) { overflow = true; return true; }
+        int ins = 0;
+        if (cov) ins = hash_insert<HASH>(tab, id[u]);
+        const int c = __popcll(__ballot(ins));
+        dr += c; filled += c;
+        if (__ballot(!live)) return true;
+    }
+    return false;
+}
 template <int HASH> __device__ __forceinline__ int cover_window(const DevBatch& B, int* tab, i64 r0, i64 r1, i64 L2, i64 R2, int& filled, bool& overflow)
 {
     int dr = 0;
-    const i64 ub = upper_bound_start(B.r_start, r0, r1, L2);
-    for (i64 top = ub - 1; top >= r0; top -= 64) {
-        const i64 i = top - lane_id();
-        const int in = i >= r0;
-        const i64 ii = in ? i : r0;
-        const int live = in && (2 * B.r_pmax[ii] >= R2);           // nothing at or before a dead lane reaches R
-        const int cov = live && B.r_primary[ii] == 1 && (2 * B.r_end[ii] >= R2);
-        if (filled + 64 > HASH * 3 / 4) { overflow = true; return dr; }
-        int ins = 0;
-        if (cov) ins = hash_insert<HASH>(tab, B.r_id[ii]);
-        const int c = __popcll(__ballot(ins));
-        dr += c; filled += c;
-        if (__ballot(!live)) break;
-    }
+    i64 top = upper_bound_start(B.r_start, r0, r1, L2) - 1;
+    if (top < r0 || cover_step<HASH, 1>(B, tab, r0, top, R2, dr, filled, overflow)) return dr;
+    for (top -= 64; top >= r0; top -= 64 * GT_UNROLL)
+        if (cover_step<HASH, GT_UNROLL>(B, tab, r0, top, R2, dr, filled, overflow)) break;
     return dr;
 }
 
