@@ -1683,11 +1683,21 @@ __global__ __launch_bounds__(256) void k_emit(DevBatch B)
             const int nn = __shfl(nsup, src_lane), cc = __shfl(c, src_lane), ts = __shfl(tso, src_lane);
             const i64 dst = shfl_i64(so, src_lane);
             if (!__ballot(nn > 0)) continue;                // wave-uniform
-            for (int i = l8; i < nn; i += 8) {
-                const int w = B.sup_tmp[s + ts + i];
-                B.o_supsig[dst + i] = gs + w;
-                B.o_suprid[dst + i] = B.rid[w];
-                B.allele_id[w] = cc;
+            // 4 strides per step: the index loads, then the read-id gathers, are issued together (two dependent
+            // round trips per step instead of per 8 supports; lists are 15-90 long)
+            for (int i = l8; i < nn; i += 32) {
+                int w[4], rd[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) w[u] = (i + 8 * u < nn) ? B.sup_tmp[s + ts + i + 8 * u] : -1;
+#pragma unroll
+                for (int u = 0; u < 4; u++) rd[u] = (w[u] >= 0) ? B.rid[w[u]] : 0;
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (w[u] >= 0) {
+                        B.o_supsig[dst + i + 8 * u] = gs + w[u];
+                        B.o_suprid[dst + i + 8 * u] = rd[u];
+                        B.allele_id[w[u]] = cc;
+                    }
             }
         }
     }
