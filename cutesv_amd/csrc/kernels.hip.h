@@ -1389,6 +1389,9 @@ template <int SW> __device__ __forceinline__ int indel_unit(const DevBatch& B, i
                     rank += ((rm >> t) & 1) && ((lt < bl) || (lt == bl && t < sl));
                 }
             }
+        } else if (!__ballot(rep && (bl >> 25) != 0)) {                  // same one-word key, 6 bits of first appearance
+            const int key = rep ? (((int)bl << 6) | sl) : 0x7fffffff;
+            for (u64 mk = __ballot(rep); mk; mk &= mk - 1) rank += __builtin_amdgcn_readlane(key, __ffsll((long long)mk) - 1) < key;
         } else {
             for (u64 mk = __ballot(rep); mk; mk &= mk - 1) {
                 const int t = __ffsll((long long)mk) - 1;
