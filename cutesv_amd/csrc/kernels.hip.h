@@ -1279,6 +1279,18 @@ __device__ __forceinline__ void np_sum_allele2(double sq1, double sq2, int n, in
     out1 = res1; out2 = res2;
 }
 
+// rank += #{t < mmax : key[t] < key} with key[t] = the key of sub-lane t of the caller's own half of 32 lanes
+// (ds_swizzle wants its pattern as an immediate: compile-time recursion instead of a loop)
+template <int T, int N> struct RankSwz {
+    static __device__ __forceinline__ void run(int key, int mmax, int& rank)
+    {
+        if (T >= mmax) return;
+        rank += __builtin_amdgcn_ds_swizzle(key, T << 5) < key;
+        RankSwz<T + 1, N>::run(key, mmax, rank);
+    }
+};
+template <int N> struct RankSwz<N, N> { static __device__ __forceinline__ void run(int, int, int&) {} };
+
 #ifndef CSV_IW_WAVES
 #define CSV_IW_WAVES 4
 #endif
@@ -1382,7 +1394,9 @@ template <int SW> __device__ __forceinline__ int indel_unit(const DevBatch& B, i
                 // every kept length fits 26 bits: (length, first appearance) packs into ONE word, so a step is a
                 // broadcast, a compare and an add.  Lanes that are not kept never count as smaller.
                 const int key = rep ? (((int)bl << 5) | sl) : 0x7fffffff;
-                for (int t = 0; t < mmax; t++) rank += sub_rl<SW>(key, t, hi) < key;
+                // ds_swizzle (bit mode: lane' = (lane & and) | or, inside each half of 32) broadcasts sub-lane t of BOTH
+                // sub-waves in one LDS-crossbar instruction; the pattern is an immediate, hence the unrolled loop
+                RankSwz<0, 32>::run(key, mmax, rank);
             } else {
                 for (int t = 0; t < mmax; t++) {
                     const i64 lt = sub_rl64<SW>(bl, t, hi);
