@@ -38,7 +38,7 @@ struct csv_ctx {
     hipEvent_t  ev[CSV_N_STAGES + 2] = {};
     // device buffers
     Buf seg, woff, seg_drop, a, b, rid, aux;
-    Buf cluster_id, cstart, cseg, partial, partial64, item_rec, list_small, list_big;
+    Buf cluster_id, cstart, cseg, partial, partial64, item_rec, list_small, list_big, list_tiny;
     Buf item_nslots, item_cnt, item_base, sup_tmp;
     Buf t_bp1, t_bp2, t_search, t_pick, t_support, t_cipos, t_cilen, t_supoff, t_valid;
     Buf sc_k, sc_x, sc_v1, sc_v2, sc_v3, sc_v4, sc_v5;
@@ -154,7 +154,7 @@ void csv_ctx_destroy(csv_ctx* c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     Buf* all[] = {&c->seg, &c->woff, &c->seg_drop, &c->a, &c->b, &c->rid, &c->aux, &c->cluster_id, &c->cstart, &c->partial,
-                  &c->partial64, &c->item_rec, &c->cseg, &c->list_small, &c->list_big, &c->item_nslots,
+                  &c->partial64, &c->item_rec, &c->cseg, &c->list_small, &c->list_big, &c->list_tiny, &c->item_nslots,
                   &c->item_cnt, &c->item_base, &c->sup_tmp, &c->t_bp1, &c->t_bp2, &c->t_search, &c->t_pick,
                   &c->t_support, &c->t_cipos, &c->t_cilen, &c->t_supoff, &c->t_valid, &c->sc_k, &c->sc_x, &c->sc_v1, &c->sc_v2,
                   &c->sc_v3, &c->sc_v4, &c->sc_v5, &c->o_seg, &c->o_cluster, &c->o_aux, &c->o_bp1, &c->o_bp2, &c->o_support,
@@ -232,11 +232,11 @@ int csv_batch_upload(csv_ctx* c, const csv_batch_in* in)
     RES(a, (W + 1) * 8); RES(b, (W + 1) * 8); RES(rid, (W + 1) * 4); RES(aux, (W + 1) * 4);
     RES(cluster_id, (W + 1) * 4); RES(cstart, (W + 2) * 4); RES(cseg, (W + 2) * 4); RES(sup_tmp, (W + 1) * 4); RES(allele_id, (W + 1) * 4);
     const i64 R = (c->any_genotype && in->reads_off) ? in->n_reads : 0;
-    const i64 np32 = div_up(W, CH_TILE) + 2;
+    const i64 np32 = (div_up(W, CH_TILE) > div_up(W, SEL_TILE) ? div_up(W, CH_TILE) : div_up(W, SEL_TILE)) + 2;   // B.partial serves both tilings
     i64 np64 = div_up(W, SEL_TILE) + 2;
     if (div_up(R, PM_TILE) + 2 > np64) np64 = div_up(R, PM_TILE) + 2;
     RES(partial, np32 * 4); RES(partial64, np64 * 8);
-    RES(item_rec, cap_items * 16); RES(list_small, cap_items * 4); RES(list_big, cap_items * 4);
+    RES(item_rec, cap_items * 16); RES(list_small, cap_items * 4); RES(list_big, cap_items * 4); RES(list_tiny, cap_items * 4);
     RES(item_nslots, cap_items * 4); RES(item_cnt, cap_items * 8);
     RES(item_base, (cap_items + 8) * 8);
     // temp call records are indexed by w (a cluster's slots live in its own signature range)
@@ -288,7 +288,8 @@ int csv_batch_upload(csv_ctx* c, const csv_batch_in* in)
     B.seg = dp<csv_segment>(c->seg); B.woff = dp<i64>(c->woff); B.seg_drop = dp<uint8_t>(c->seg_drop);
     B.a = dp<i64>(c->a); B.b = dp<i64>(c->b); B.rid = dp<int>(c->rid); B.aux = dp<int>(c->aux);
     B.cluster_id = dp<int>(c->cluster_id); B.cstart = dp<int>(c->cstart); B.cseg = dp<int>(c->cseg); B.partial = dp<int>(c->partial); B.partial64 = dp<i64>(c->partial64);
-    B.item_rec = dp<int4>(c->item_rec); B.list_small = dp<int>(c->list_small); B.list_big = dp<int>(c->list_big);
+    B.item_rec = dp<int4>(c->item_rec); B.list_small = dp<int>(c->list_small); B.list_big = dp<int>(c->list_big); B.list_tiny = dp<int>(c->list_tiny);
+    B.tiny_max = getenv("CSV_NO_TINY") ? 0 : 16;               // (timing aid: 0 sends every DEL/INS cluster of m <= 32 through the paired path)
     B.item_nslots = dp<int>(c->item_nslots); B.item_cnt = dp<i64>(c->item_cnt); B.item_base = dp<i64>(c->item_base);
     B.sup_tmp = dp<int>(c->sup_tmp);
     B.t_bp1 = dp<i64>(c->t_bp1); B.t_bp2 = dp<i64>(c->t_bp2); B.t_search = dp<i64>(c->t_search); B.t_pick = dp<i64>(c->t_pick);

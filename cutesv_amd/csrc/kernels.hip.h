@@ -45,7 +45,7 @@ struct DevCounters {          // one small struct in device memory, zeroed at th
     int error;
     i64 n_support;
     int n_gt_over;            // calls whose support + cover did not fit the small hash set
-    int spare;
+    int n_items_tiny;         // DEL/INS work items of at most tiny_max signatures (four per wavefront)
 };
 
 // Everything the kernels need, passed by value.
@@ -70,6 +70,8 @@ struct DevBatch {
     int4*          item_rec;         // ordered work list: item -> {cluster id, segment, first w, size}
     int*           list_small;       // item ids of the wavefront tier (ordered)
     int*           list_big;
+    int*           list_tiny;        // DEL/INS items with m <= tiny_max: k_refine_indel_wave packs four per wavefront
+    int            tiny_max;         // 16 (0 switches the class off)
     // refine outputs
     int*           item_nslots;      // temp slots the item filled (t_*[s + slot])
     i64*           item_cnt;         // packed (valid calls << 32 | supports of valid calls)
@@ -404,8 +406,9 @@ __global__ __launch_bounds__(256) void k_validate_order(DevBatch B)
 // cluster c is a work item when it passes the size gate (signatures >= read_count, INDEL:62),
 // does not end in a (0,0) element (INDEL:63-64) and its segment is not dropped.
 // packed counter: low 32 = items, high 32 = items of the workgroup tier (m > 64).
-__device__ __forceinline__ i64 select_value(const DevBatch& B, int c, int nC, int4& rec)
+__device__ __forceinline__ i64 select_value(const DevBatch& B, int c, int nC, int4& rec, int& tiny)
 {
+    tiny = 0;
     if (c >= nC) return 0;
     const int s = B.cstart[c] & 0x7fffffff, e1 = B.cstart[c + 1];
     const int e = e1 & 0x7fffffff;
@@ -414,10 +417,11 @@ __device__ __forceinline__ i64 select_value(const DevBatch& B, int c, int nC, in
     if (e1 < 0) return 0;                                   // the cluster ends in a (0,0) element
     if (e - s < B.seg[k].read_count) return 0;
     if (B.seg_drop[k]) return 0;
+    tiny = (e - s <= B.tiny_max && B.seg[k].svtype <= CSV_INS) ? 1 : 0;
     return 1ll + ((e - s > 64) ? (1ll << 32) : 0ll);
 }
 
-constexpr int SEL_ROWS = 8;
+constexpr int SEL_ROWS = 4;
 constexpr int SEL_TILE = 256 * SEL_ROWS;             // clusters per workgroup
 
 __global__ __launch_bounds__(256) void k_select_count(DevBatch B)
@@ -426,14 +430,17 @@ __global__ __launch_bounds__(256) void k_select_count(DevBatch B)
     if ((i64)blockIdx.x * SEL_TILE >= nC) return;
     const int base = blockIdx.x * SEL_TILE + (threadIdx.x >> 6) * (WAVE * SEL_ROWS);
     i64 v = 0;
+    int nt = 0;
     int4 rec;
 #pragma unroll
-    for (int r = 0; r < SEL_ROWS; r++) v += select_value(B, base + r * WAVE + lane_id(), nC, rec);
+    for (int r = 0; r < SEL_ROWS; r++) { int t; v += select_value(B, base + r * WAVE + lane_id(), nC, rec, t); nt += t; }
     v = wave_sum_i64(v);
+    nt = wave_sum_i32(nt);
     __shared__ i64 s[4];
-    if (lane_id() == 0) s[threadIdx.x >> 6] = v;
+    __shared__ int st[4];
+    if (lane_id() == 0) { s[threadIdx.x >> 6] = v; st[threadIdx.x >> 6] = nt; }
     __syncthreads();
-    if (threadIdx.x == 0) B.partial64[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+    if (threadIdx.x == 0) { B.partial64[blockIdx.x] = s[0] + s[1] + s[2] + s[3]; B.partial[blockIdx.x] = st[0] + st[1] + st[2] + st[3]; }
 }
 
 __global__ __launch_bounds__(256) void k_select_apply(DevBatch B)
@@ -443,31 +450,49 @@ __global__ __launch_bounds__(256) void k_select_apply(DevBatch B)
     const int nblk = (nC + SEL_TILE - 1) / SEL_TILE;
     if (blockIdx.x == 0) {                                  // publishes the totals for the kernels behind
         const i64 t = block_prefix_of64(B.partial64, nblk, sh);
-        if (threadIdx.x == 0) { B.cnt->n_items = (int)(t & 0xffffffffll); B.cnt->n_items_big = (int)(t >> 32); }
+        const i64 tt = block_prefix_of(B.partial, nblk, sh);
+        if (threadIdx.x == 0) { B.cnt->n_items = (int)(t & 0xffffffffll); B.cnt->n_items_big = (int)(t >> 32); B.cnt->n_items_tiny = (int)tt; }
     }
     if ((int)blockIdx.x >= nblk) return;
     const int wv = threadIdx.x >> 6;
     const int base = blockIdx.x * SEL_TILE + wv * (WAVE * SEL_ROWS);
-    i64 v[SEL_ROWS]; int4 rec[SEL_ROWS];
+    // per row the record is kept as {segment, start, size | tiny << 30} (the cluster id is the row's index): registers
+    // decide whether all ~1400 workgroups of a 30x genome are resident at once
+    i64 v[SEL_ROWS];
+    int rk[SEL_ROWS], rs[SEL_ROWS], rm[SEL_ROWS];
     i64 tot = 0;
+    int tot_t = 0;
 #pragma unroll
-    for (int r = 0; r < SEL_ROWS; r++) { v[r] = select_value(B, base + r * WAVE + lane_id(), nC, rec[r]); tot += v[r]; }
+    for (int r = 0; r < SEL_ROWS; r++) {
+        int4 rec; int t;
+        v[r] = select_value(B, base + r * WAVE + lane_id(), nC, rec, t);
+        rk[r] = rec.y; rs[r] = rec.z; rm[r] = rec.w | (t << 30);
+        tot += v[r]; tot_t += t;
+    }
     tot = wave_sum_i64(tot);
+    tot_t = wave_sum_i32(tot_t);
     i64 run = block_prefix_of64(B.partial64, blockIdx.x, sh);
+    int run_t = (int)block_prefix_of(B.partial, blockIdx.x, sh);
     __shared__ i64 s[4];
-    if (lane_id() == 0) s[wv] = tot;
+    __shared__ int st[4];
+    if (lane_id() == 0) { s[wv] = tot; st[wv] = tot_t; }
     __syncthreads();
-    for (int q = 0; q < wv; q++) run += s[q];
+    for (int q = 0; q < wv; q++) { run += s[q]; run_t += st[q]; }
 #pragma unroll
     for (int r = 0; r < SEL_ROWS; r++) {
         const i64 inc = wave_incl_scan_i64(v[r]);
+        const int tiny = rm[r] >> 30;
+        const int inc_t = wave_incl_scan_i32(tiny);
         if (v[r]) {
             const i64 ex = run + inc - v[r];
-            const int j = (int)(ex & 0xffffffffll), jb = (int)(ex >> 32);
-            B.item_rec[j] = rec[r];
-            if (v[r] >> 32) B.list_big[jb] = j; else B.list_small[j - jb] = j;
+            const int j = (int)(ex & 0xffffffffll), jb = (int)(ex >> 32), jt = run_t + inc_t - tiny;
+            B.item_rec[j] = make_int4(base + r * WAVE + lane_id(), rk[r], rs[r], rm[r] & 0x3fffffff);
+            if (v[r] >> 32) B.list_big[jb] = j;
+            else if (tiny) B.list_tiny[jt] = j;
+            else B.list_small[j - jb - jt] = j;
         }
         run += lane63_i64(inc);
+        run_t += __builtin_amdgcn_readlane(inc_t, 63);
     }
 }
 
@@ -1136,7 +1161,7 @@ template <int BLOCK, int CAP> __global__ __launch_bounds__(BLOCK, (BLOCK == 64 ?
     L.V1 = (CSV_LDS int*)(smem + 16 * N); L.V2 = L.V1 + N; L.V3 = L.V2 + N; L.V4 = L.V3 + N; L.V5 = L.V4 + N;
     i64* red = (i64*)(smem_raw + LDS_LEAD + 36 * N);
     int* ired = (int*)(red + 6);
-    const int n = big ? B.cnt->n_items_big : (B.cnt->n_items - B.cnt->n_items_big);
+    const int n = big ? B.cnt->n_items_big : (B.cnt->n_items - B.cnt->n_items_big - B.cnt->n_items_tiny);
     for (int q = blockIdx.x; q < n; q += gridDim.x) {
         ItemCtx it;
         it.j = big ? B.list_big[q] : B.list_small[q];
@@ -1197,34 +1222,39 @@ __device__ __forceinline__ i64 permute_i64(int dest_lane, i64 v)      // lane i 
     const int hi = __builtin_amdgcn_ds_permute(dest_lane << 2, (int)(v >> 32));
     return ((i64)hi << 32) | (unsigned)lo;
 }
-// value of sub-lane t of the caller's own sub-wave (t wave-uniform)
-template <int SW> __device__ __forceinline__ int sub_rl(int x, int t, bool hi)
+// value of sub-lane t of the caller's own sub-wave (t wave-uniform; g = lane / SW, the caller's sub-wave)
+template <int SW> __device__ __forceinline__ int sub_rl(int x, int t, int g)
 {
     if (SW == 64) return __builtin_amdgcn_readlane(x, t);
-    const int lo = __builtin_amdgcn_readlane(x, t), up = __builtin_amdgcn_readlane(x, 32 + t);
-    return hi ? up : lo;
+    if (SW == 32) {
+        const int lo = __builtin_amdgcn_readlane(x, t), up = __builtin_amdgcn_readlane(x, 32 + t);
+        return g ? up : lo;
+    }
+    const int v0 = __builtin_amdgcn_readlane(x, t), v1 = __builtin_amdgcn_readlane(x, 16 + t);
+    const int v2 = __builtin_amdgcn_readlane(x, 32 + t), v3 = __builtin_amdgcn_readlane(x, 48 + t);
+    return (g & 2) ? ((g & 1) ? v3 : v2) : ((g & 1) ? v1 : v0);
 }
-template <int SW> __device__ __forceinline__ i64 sub_rl64(i64 x, int t, bool hi)
+template <int SW> __device__ __forceinline__ i64 sub_rl64(i64 x, int t, int g)
 {
-    if (SW == 64) return readlane_i64(x, t);
-    const i64 lo = readlane_i64(x, t), up = readlane_i64(x, 32 + t);
-    return hi ? up : lo;
+    const int lo = sub_rl<SW>((int)(x & 0xffffffffll), t, g), up = sub_rl<SW>((int)(x >> 32), t, g);
+    return ((i64)up << 32) | (unsigned)lo;
 }
 // ballot restricted to the caller's sub-wave, in sub-lane bit positions
-template <int SW> __device__ __forceinline__ u64 sub_ballot(bool p, bool hi)
+template <int SW> __device__ __forceinline__ u64 sub_ballot(bool p, int g)
 {
     const u64 m = __ballot(p);
     if (SW == 64) return m;
-    return hi ? (m >> 32) : (m & 0xffffffffull);
+    return (m >> (g * SW)) & ((1ull << SW) - 1ull);
 }
-// inclusive scans inside a sub-wave: for 32 lanes the DPP network simply stops before row_bcast:31
+// inclusive scans inside a sub-wave: the DPP network simply stops early (16 lanes = one DPP row: row_shr only;
+// 32 lanes: before row_bcast:31)
 template <int SW> __device__ __forceinline__ i64 sub_scan_i64(i64 v)
 {
     v += dpp_i64<0x111, 0xf>(0, v);
     v += dpp_i64<0x112, 0xf>(0, v);
     v += dpp_i64<0x114, 0xf>(0, v);
     v += dpp_i64<0x118, 0xf>(0, v);
-    v += dpp_i64<0x142, 0xa>(0, v);
+    if (SW >= 32) v += dpp_i64<0x142, 0xa>(0, v);
     if (SW == 64) v += dpp_i64<0x143, 0xc>(0, v);
     return v;
 }
@@ -1234,7 +1264,7 @@ template <int SW> __device__ __forceinline__ int sub_scan_i32(int v)
     v += dpp_i32<0x112, 0xf>(0, v);
     v += dpp_i32<0x114, 0xf>(0, v);
     v += dpp_i32<0x118, 0xf>(0, v);
-    v += dpp_i32<0x142, 0xa>(0, v);
+    if (SW >= 32) v += dpp_i32<0x142, 0xa>(0, v);
     if (SW == 64) v += dpp_i32<0x143, 0xc>(0, v);
     return v;
 }
@@ -1279,38 +1309,39 @@ __device__ __forceinline__ void np_sum_allele2(double sq1, double sq2, int n, in
     out1 = res1; out2 = res2;
 }
 
-// rank += #{t < mmax : key[t] < key} with key[t] = the key of sub-lane t of the caller's own half of 32 lanes
+// rank += #{t < mmax : key[t] < key} with key[t] = the key of sub-lane t of the caller's own sub-wave of 32 / 16 lanes
 // (ds_swizzle wants its pattern as an immediate: compile-time recursion instead of a loop)
+// (N = sub-wave width: 32 -> and_mask 0, 16 -> and_mask 0x10 keeps the 16-lane row inside the half)
 template <int T, int N> struct RankSwz {
     static __device__ __forceinline__ void run(int key, int mmax, int& rank)
     {
         if (T >= mmax) return;
-        rank += __builtin_amdgcn_ds_swizzle(key, T << 5) < key;
+        rank += __builtin_amdgcn_ds_swizzle(key, (N == 16 ? 0x10 : 0) | (T << 5)) < key;
         RankSwz<T + 1, N>::run(key, mmax, rank);
     }
 };
 template <int N> struct RankSwz<N, N> { static __device__ __forceinline__ void run(int, int, int&) {} };
 
 #ifndef CSV_IW_WAVES
-#define CSV_IW_WAVES 4
+#define CSV_IW_WAVES 5
 #endif
 // one unit of work: SW = 32 -> the pair of items (2p, 2p + 1), each handled if m <= 32;
 //                   SW = 64 -> the single item p, handled if 32 < m <= 64.  Returns (SW = 32 only) a 2-bit mask
 //                   of pair members that are DEL/INS clusters of 32 < m <= 64 and still need the wide pass.
-template <int SW> __device__ __forceinline__ int indel_unit(const DevBatch& B, int p, int nsmall)
+template <int SW> __device__ __forceinline__ int indel_unit(const DevBatch& B, const int* list, int p, int nlist)
 {
     constexpr bool HALF = SW == 32;
-    constexpr int MLO = HALF ? 0 : 32;
-    constexpr u64 SUBMASK = HALF ? 0xffffffffull : ~0ull;
-    const int lane = lane_id(), sl = lane & (SW - 1), hb = lane & ~(SW - 1);
-    const bool hi = HALF && lane >= 32;
+    constexpr int NSUB = 64 / SW;                      // clusters per wavefront
+    constexpr int MLO = SW == 64 ? 32 : 0;
+    constexpr u64 SUBMASK = SW == 64 ? ~0ull : (1ull << SW) - 1ull;
+    const int lane = lane_id(), sl = lane & (SW - 1), hb = lane & ~(SW - 1), g = lane / SW;
     const u64 sl_lt = (1ull << sl) - 1ull, sl_le = sl_lt | (1ull << sl);        // masks in sub-lane positions
     int wide = 0;
     do {
-        const int q = HALF ? 2 * p + (hi ? 1 : 0) : p;
+        const int q = NSUB * p + g;
         int j = 0, k = 0, s = 0, m = 0, type = -1;
-        if (q < nsmall) {
-            j = B.list_small[q];
+        if (q < nlist) {
+            j = list[q];
             const int4 rec = B.item_rec[j];
             k = rec.y; s = rec.z; m = rec.w;
             type = B.seg[k].svtype;
@@ -1339,8 +1370,9 @@ template <int SW> __device__ __forceinline__ int indel_unit(const DevBatch& B, i
         const int aux = (in && type == CSV_INS) ? B.aux[s + sl] : 0;
         if (in && ((u64)b >> (63 - IDX_BITS))) atomicOr(&B.cnt->error, ERR_KEY_RANGE);
         const int mact = act ? m : 0;
-        const int mmax = HALF ? max(__builtin_amdgcn_readlane(mact, 0), __builtin_amdgcn_readlane(mact, 32))
-                              : __builtin_amdgcn_readfirstlane(mact);
+        int mmax = __builtin_amdgcn_readlane(mact, 0);
+        if (NSUB >= 2) mmax = max(mmax, __builtin_amdgcn_readlane(mact, SW));
+        if (NSUB == 4) mmax = max(mmax, max(__builtin_amdgcn_readlane(mact, 32), __builtin_amdgcn_readlane(mact, 48)));
 
         // ---- per-read de-duplication (INDEL:125-131): first appearance F, kept signature = strictly longest
         int F = sl, ch = sl;
@@ -1364,14 +1396,14 @@ template <int SW> __device__ __forceinline__ int indel_unit(const DevBatch& B, i
                 const u64 mk = __ballot(set);
                 match &= set ? mk : ~mk;
             }
-            const u64 mine = HALF ? (hi ? 0xffffffff00000000ull : 0x00000000ffffffffull) : ~0ull;
+            const u64 mine = SUBMASK << hb;
             dup_any = in && __popcll(match & mine) > 1;
         }
         if (__ballot(dup_any)) {
             F = -1; ch = -1; bl = INT64_MIN;
             for (int t = 0; t < mmax; t++) {
-                const int rt = sub_rl<SW>(rid, t, hi);
-                const i64 bt = sub_rl64<SW>(b, t, hi);
+                const int rt = sub_rl<SW>(rid, t, g);
+                const i64 bt = sub_rl64<SW>(b, t, g);
                 if (rt == rid) {
                     if (F < 0) F = t;
                     if (bt > bl) { bl = bt; ch = t; }
@@ -1379,7 +1411,7 @@ template <int SW> __device__ __forceinline__ int indel_unit(const DevBatch& B, i
             }
         }
         const bool rep = in && (F == sl);
-        const u64 rm = sub_ballot<SW>(rep, hi);
+        const u64 rm = sub_ballot<SW>(rep, g);
         const int U = __popcll(rm);
         const bool ok = act && U >= rc;                                          // INDEL:133-134
         if (act && !ok && sl == 0) item_done(B, j, 0, 0, 0);
@@ -1389,17 +1421,17 @@ template <int SW> __device__ __forceinline__ int indel_unit(const DevBatch& B, i
 
         // ---- stable sort of the kept signatures by length (INDEL:136): rank by (len, first appearance)
         int rank = 0;
-        if (HALF) {
+        if (SW < 64) {
             if (!__ballot(rep && (bl >> 26) != 0)) {
                 // every kept length fits 26 bits: (length, first appearance) packs into ONE word, so a step is a
                 // broadcast, a compare and an add.  Lanes that are not kept never count as smaller.
                 const int key = rep ? (((int)bl << 5) | sl) : 0x7fffffff;
                 // ds_swizzle (bit mode: lane' = (lane & and) | or, inside each half of 32) broadcasts sub-lane t of BOTH
                 // sub-waves in one LDS-crossbar instruction; the pattern is an immediate, hence the unrolled loop
-                RankSwz<0, 32>::run(key, mmax, rank);
+                RankSwz<0, SW>::run(key, mmax, rank);
             } else {
                 for (int t = 0; t < mmax; t++) {
-                    const i64 lt = sub_rl64<SW>(bl, t, hi);
+                    const i64 lt = sub_rl64<SW>(bl, t, g);
                     rank += ((rm >> t) & 1) && ((lt < bl) || (lt == bl && t < sl));
                 }
             }
@@ -1428,7 +1460,7 @@ template <int SW> __device__ __forceinline__ int indel_unit(const DevBatch& B, i
         const i64 lprev = wave_shr1_i64(len);
         const bool f = live && r > 0 && ((double)(len - lprev) > thr);
         const u64 fmask = __ballot(f);
-        const u64 S = (HALF ? (hi ? (fmask >> 32) : (fmask & 0xffffffffull)) : fmask) | 1ull;    // allele start ranks
+        const u64 S = ((fmask >> hb) & SUBMASK) | 1ull;                           // allele start ranks (sub-lane positions)
         const u64 below = S & sl_le, above = S & ~sl_le & SUBMASK;
         const int r0 = 63 - __clzll((long long)below);
         int r1 = above ? (__ffsll((long long)above) - 1) : U;
@@ -1445,7 +1477,7 @@ template <int SW> __device__ __forceinline__ int indel_unit(const DevBatch& B, i
         // ---- emission order: stable ascending by support among alleles with n >= minimum_support_reads (INDEL:163-166)
         const bool pass = live && n >= msr;
         int erank = 0, soff = 0, npass = 0;
-        const u64 starts = HALF ? (fmask | 1ull | (1ull << 32)) : S;             // allele starts of every sub-wave, absolute lanes
+        const u64 starts = fmask | (NSUB == 4 ? 0x0001000100010001ull : NSUB == 2 ? 0x0000000100000001ull : 1ull);   // allele starts of every sub-wave, absolute lanes
         for (u64 mk = starts; mk; mk &= mk - 1) {
             const int t = __ffsll((long long)mk) - 1;
             const int nt = __builtin_amdgcn_readlane(n, t);
@@ -1474,9 +1506,9 @@ template <int SW> __device__ __forceinline__ int indel_unit(const DevBatch& B, i
             // keep the `keep` members closest to the mean, ties in allele order (INDEL:171-176, 182-187)
             int rp = 0, rl = 0;
             for (int t = 0; t < mmax; t++) {
-                const int r0t = sub_rl<SW>(r0, t, hi);
-                const double tp = __longlong_as_double(sub_rl64<SW>(__double_as_longlong(dp), t, hi));
-                const double tl = __longlong_as_double(sub_rl64<SW>(__double_as_longlong(dl), t, hi));
+                const int r0t = sub_rl<SW>(r0, t, g);
+                const double tp = __longlong_as_double(sub_rl64<SW>(__double_as_longlong(dp), t, g));
+                const double tl = __longlong_as_double(sub_rl64<SW>(__double_as_longlong(dl), t, g));
                 if (t < U && r0t == r0) {
                     rp += (tp < dp) || (tp == dp && t < r);
                     rl += (tl < dl) || (tl == dl && t < r);
@@ -1499,7 +1531,7 @@ template <int SW> __device__ __forceinline__ int indel_unit(const DevBatch& B, i
 
         // ---- INS: first member (allele order) whose sequence is long enough gives POS and ALT (INDEL:398-405)
         const i64 want = (i64)siglen;
-        const u64 okm = sub_ballot<SW>(live && type == CSV_INS && (i64)axp >= want, hi);
+        const u64 okm = sub_ballot<SW>(live && type == CSV_INS && (i64)axp >= want, g);
         const u64 range = ((n >= 64) ? ~0ull : ((1ull << n) - 1ull)) << r0;
         const u64 mm = okm & range;
         const int pr = mm ? (__ffsll((long long)mm) - 1) : r0;
@@ -1520,7 +1552,7 @@ template <int SW> __device__ __forceinline__ int indel_unit(const DevBatch& B, i
             B.t_cipos[t] = cip; B.t_cilen[t] = cil; B.t_search[t] = search; B.t_pick[t] = valid ? pick : -1;
             B.t_supoff[t] = soff; B.t_valid[t] = valid ? 1 : 0;
         }
-        const int ncalls = __popcll(sub_ballot<SW>(head && valid, hi));
+        const int ncalls = __popcll(sub_ballot<SW>(head && valid, g));
         const int nsup = __shfl(sub_scan_i32<SW>((head && valid) ? n : 0), last);
         if (ok && sl == 0) item_done(B, j, npass, ncalls, nsup);
     } while (0);
@@ -1529,13 +1561,15 @@ template <int SW> __device__ __forceinline__ int indel_unit(const DevBatch& B, i
 
 __global__ __launch_bounds__(256, CSV_IW_WAVES) void k_refine_indel_wave(DevBatch B)
 {
-    const int nsmall = B.cnt->n_items - B.cnt->n_items_big;
+    const int ntiny = B.cnt->n_items_tiny, nsmall = B.cnt->n_items - B.cnt->n_items_big - ntiny;
     const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * 256 + threadIdx.x) >> 6), nwaves = (gridDim.x * 256) >> 6;
     for (int p = wave; p < (nsmall + 1) / 2; p += nwaves) {
-        const int wide = __builtin_amdgcn_readfirstlane(indel_unit<32>(B, p, nsmall));
-        if (wide & 1) indel_unit<64>(B, 2 * p, nsmall);          // rare: a pair member with 32 < m <= 64
-        if (wide & 2) indel_unit<64>(B, 2 * p + 1, nsmall);
+        const int wide = __builtin_amdgcn_readfirstlane(indel_unit<32>(B, B.list_small, p, nsmall));
+        if (wide & 1) indel_unit<64>(B, B.list_small, 2 * p, nsmall);          // a pair member with 32 < m <= 64
+        if (wide & 2) indel_unit<64>(B, B.list_small, 2 * p + 1, nsmall);
     }
+    // clusters of at most 16 signatures: four per wavefront (a sub-wave is one DPP row)
+    for (int p = wave; p < (ntiny + 3) / 4; p += nwaves) indel_unit<16>(B, B.list_tiny, p, ntiny);
 }
 
 // ------------------------------------------------------------------------------------ order
