@@ -81,6 +81,31 @@ def test_large_clusters_all_tiers(ctx):
     assert sizes.max() > 2048, sizes.max()
 
 
+def test_register_tiers_fallback_routes(ctx):
+    # lengths >= 2^26 leave the one-word rank key, repeated read names leave the hashed duplicate filter: the
+    # 64-bit / exact routes of indel_unit<16>, <32> and <64>, next to ordinary clusters in the same wavefronts
+    from cutesv_amd.columns import SigStore
+    rng = np.random.default_rng(123)
+    per = {t: [] for t in ("DEL", "INS", "DUP", "INV", "TRA")}
+    pos = 10_000
+    for site in range(240):
+        m = [12, 25, 50, 9, 16, 17, 32, 33][site % 8]
+        huge = site % 3 == 0
+        base = int(rng.integers(2**27, 2**30)) if huge else int(rng.integers(50, 600))
+        names = ["r%05d" % i for i in rng.choice(20000, m, replace=False)]
+        if site % 5 == 0:
+            names[3] = names[1]; names[m - 1] = names[0]                  # a read with several signatures
+        for nm in names:
+            ln = max(30, int(base * (1 + rng.normal(0, 0.02))))
+            p_ = pos + int(rng.normal(0, 10))
+            per["DEL"].append((p_, ln, nm, "DEL", "1"))
+            per["INS"].append((p_ + 2, ln, nm, "A" * min(ln, 700), "INS", "1"))
+        pos += 3000
+    st = SigStore.from_tuple_lists(per)
+    got = _compare_soa(ctx, st, Params.ont(min_support=5, max_size=-1))
+    assert len(got["bp1"]) > 350 and (got["bp2"] >= 2**26).any()
+
+
 def test_genotype_cover_overflow_pass(ctx):
     # ~1000x coverage: support + cover of a call exceeds the 4 KB hash set, so the second (32 KB) pass runs
     st = synth.small_mixed(seed=78, n_sites=6, coverage=1000, n_noise=100, n_loci=20, contig_len=200_000, n_contigs=2)
