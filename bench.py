@@ -79,7 +79,6 @@ def kernel_units(store, hb, res, stats):
     share = lambda n: per_sig * n + per_call * calls * n // n_ref       # calls attributed in proportion to the signatures refined
     b = {
         "k_chain_count": per_sig * W, "k_chain_apply": per_sig * W,
-        "k_select_count": per_sig * W, "k_select_apply": per_sig * W,
         "k_refine_indel_wave": share(n_iw), "k_refine_wave": share(n_pw), "k_refine_mid": share(n_mid), "k_refine_block": share(n_blk),
         "k_emit": per_call * calls + 8 * sup, "k_items_scan": 8 * int(stats.n_work_wave + stats.n_work_block),
         # genotyping is judged as ONE stage (prefix max over the reads table + the per-call stabbing queries): 21 B per

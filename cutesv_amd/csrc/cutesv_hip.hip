@@ -23,9 +23,9 @@ struct Buf {                      // grow-only device buffer
 };
 
 // one timing slot per launch, in launch order
-const char* kStageName[CSV_N_STAGES] = {"init", "k_chain_count", "k_chain_apply", "k_select_count", "k_select_apply",
+const char* kStageName[CSV_N_STAGES] = {"init", "k_chain_count", "k_chain_apply",
                                         "k_refine_indel_wave", "k_refine_wave", "k_refine_mid", "k_refine_block", "k_items_scan",
-                                        "k_emit", "k_pmax_count", "k_pmax_scan", "k_pmax_apply", "k_genotype", "k_genotype_tra"};
+                                        "k_emit", "k_pmax_count", "k_pmax_scan", "k_pmax_apply", "k_genotype", "k_genotype_tra", "", ""};
 
 }  // namespace
 
@@ -38,7 +38,7 @@ struct csv_ctx {
     hipEvent_t  ev[CSV_N_STAGES + 2] = {};
     // device buffers
     Buf seg, woff, seg_drop, a, b, rid, aux;
-    Buf cluster_id, cstart, cseg, partial, partial64, item_rec, list_small, list_big, list_tiny;
+    Buf cluster_id, partial, partial64, item_rec, list_small, list_big, list_tiny, tile_prev, partial_t, seg_gate;
     Buf item_nslots, item_cnt, item_base, sup_tmp;
     Buf t_bp1, t_bp2, t_search, t_pick, t_support, t_cipos, t_cilen, t_supoff, t_valid;
     Buf sc_k, sc_x, sc_v1, sc_v2, sc_v3, sc_v4, sc_v5;
@@ -51,6 +51,7 @@ struct csv_ctx {
     // host copies
     std::vector<csv_segment> h_seg;
     std::vector<i64>         h_woff;
+    std::vector<int>         h_seg_gate;
     bool     uploaded = false, ran = false, any_genotype = false, any_pair = false, any_tra_gt = false, big_lds_set = false;
     i64      n_sig_host = 0;
     DevBatch B;
@@ -153,8 +154,8 @@ void csv_ctx_destroy(csv_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    Buf* all[] = {&c->seg, &c->woff, &c->seg_drop, &c->a, &c->b, &c->rid, &c->aux, &c->cluster_id, &c->cstart, &c->partial,
-                  &c->partial64, &c->item_rec, &c->cseg, &c->list_small, &c->list_big, &c->list_tiny, &c->item_nslots,
+    Buf* all[] = {&c->seg, &c->woff, &c->seg_drop, &c->a, &c->b, &c->rid, &c->aux, &c->cluster_id, &c->partial,
+                  &c->partial64, &c->item_rec, &c->list_small, &c->list_big, &c->list_tiny, &c->tile_prev, &c->partial_t, &c->seg_gate, &c->item_nslots,
                   &c->item_cnt, &c->item_base, &c->sup_tmp, &c->t_bp1, &c->t_bp2, &c->t_search, &c->t_pick,
                   &c->t_support, &c->t_cipos, &c->t_cilen, &c->t_supoff, &c->t_valid, &c->sc_k, &c->sc_x, &c->sc_v1, &c->sc_v2,
                   &c->sc_v3, &c->sc_v4, &c->sc_v5, &c->o_seg, &c->o_cluster, &c->o_aux, &c->o_bp1, &c->o_bp2, &c->o_support,
@@ -230,12 +231,11 @@ int csv_batch_upload(csv_ctx* c, const csv_batch_in* in)
     // ---- device memory
     RES(seg, (S + 1) * sizeof(csv_segment)); RES(woff, (S + 2) * sizeof(i64)); RES(seg_drop, S + 1);
     RES(a, (W + 1) * 8); RES(b, (W + 1) * 8); RES(rid, (W + 1) * 4); RES(aux, (W + 1) * 4);
-    RES(cluster_id, (W + 1) * 4); RES(cstart, (W + 2) * 4); RES(cseg, (W + 2) * 4); RES(sup_tmp, (W + 1) * 4); RES(allele_id, (W + 1) * 4);
+    RES(cluster_id, (W + 1) * 4); RES(sup_tmp, (W + 1) * 4); RES(allele_id, (W + 1) * 4);
     const i64 R = (c->any_genotype && in->reads_off) ? in->n_reads : 0;
-    const i64 np32 = (div_up(W, CH_TILE) > div_up(W, SEL_TILE) ? div_up(W, CH_TILE) : div_up(W, SEL_TILE)) + 2;   // B.partial serves both tilings
-    i64 np64 = div_up(W, SEL_TILE) + 2;
-    if (div_up(R, PM_TILE) + 2 > np64) np64 = div_up(R, PM_TILE) + 2;
-    RES(partial, np32 * 4); RES(partial64, np64 * 8);
+    const i64 np32 = div_up(W, CH_TILE) + 2;              // per chain tile
+    const i64 np64 = np32;
+    RES(partial, np32 * 4); RES(partial64, np64 * 8); RES(tile_prev, np32 * 8); RES(partial_t, np32 * 4); RES(seg_gate, (S + 1) * 16);
     RES(item_rec, cap_items * 16); RES(list_small, cap_items * 4); RES(list_big, cap_items * 4); RES(list_tiny, cap_items * 4);
     RES(item_nslots, cap_items * 4); RES(item_cnt, cap_items * 8);
     RES(item_base, (cap_items + 8) * 8);
@@ -260,6 +260,9 @@ int csv_batch_upload(csv_ctx* c, const csv_batch_in* in)
     HIP_TRY(c, hipMemcpyAsync(c->seg.p, c->h_seg.data(), S * sizeof(csv_segment), hipMemcpyHostToDevice, st));
     HIP_TRY(c, hipMemcpyAsync(c->woff.p, c->h_woff.data(), (S + 1) * sizeof(i64), hipMemcpyHostToDevice, st));
     HIP_TRY(c, hipMemcpyAsync(c->seg_drop.p, drop.data(), S + 1, hipMemcpyHostToDevice, st));
+    c->h_seg_gate.assign((size_t)(S + 1) * 4, 0);           // {read_count, dropped, svtype, -} per segment
+    for (int k = 0; k < S; k++) { c->h_seg_gate[4 * k] = c->h_seg[k].read_count; c->h_seg_gate[4 * k + 1] = drop[k]; c->h_seg_gate[4 * k + 2] = c->h_seg[k].svtype; }
+    HIP_TRY(c, hipMemcpyAsync(c->seg_gate.p, c->h_seg_gate.data(), (size_t)(S + 1) * 16, hipMemcpyHostToDevice, st));
     for (int k = 0; k < S;) {
         int e = k;
         while (e + 1 < S && c->h_seg[e + 1].sig_begin == c->h_seg[e].sig_end) e++;
@@ -287,8 +290,8 @@ int csv_batch_upload(csv_ctx* c, const csv_batch_in* in)
     B.n_seg = S; B.n_chrom = in->n_chrom; B.W = W;
     B.seg = dp<csv_segment>(c->seg); B.woff = dp<i64>(c->woff); B.seg_drop = dp<uint8_t>(c->seg_drop);
     B.a = dp<i64>(c->a); B.b = dp<i64>(c->b); B.rid = dp<int>(c->rid); B.aux = dp<int>(c->aux);
-    B.cluster_id = dp<int>(c->cluster_id); B.cstart = dp<int>(c->cstart); B.cseg = dp<int>(c->cseg); B.partial = dp<int>(c->partial); B.partial64 = dp<i64>(c->partial64);
-    B.item_rec = dp<int4>(c->item_rec); B.list_small = dp<int>(c->list_small); B.list_big = dp<int>(c->list_big); B.list_tiny = dp<int>(c->list_tiny);
+    B.cluster_id = dp<int>(c->cluster_id); B.partial = dp<int>(c->partial); B.partial64 = dp<i64>(c->partial64);
+    B.item_rec = dp<int4>(c->item_rec); B.list_small = dp<int>(c->list_small); B.list_big = dp<int>(c->list_big); B.list_tiny = dp<int>(c->list_tiny); B.tile_prev = dp<int2>(c->tile_prev); B.partial_t = dp<int>(c->partial_t); B.seg_gate = dp<int4>(c->seg_gate);
     B.tiny_max = getenv("CSV_NO_TINY") ? 0 : 16;               // (timing aid: 0 sends every DEL/INS cluster of m <= 32 through the paired path)
     B.item_nslots = dp<int>(c->item_nslots); B.item_cnt = dp<i64>(c->item_cnt); B.item_base = dp<i64>(c->item_base);
     B.sup_tmp = dp<int>(c->sup_tmp);
@@ -354,7 +357,7 @@ int csv_batch_run(csv_ctx* c, csv_run_stats* stats)
         const int nb = div_up(W, CH_TILE);
         const bool do_gt = c->any_genotype && B.n_reads > 0;
         const int nr = do_gt ? div_up(B.n_reads, PM_TILE) : 0;
-        LAUNCH("chain_count", k_chain_count, nb, 256, 0, B);
+        LAUNCH("chain_count", k_chain_count, nb, 320, 0, B);
         if (fork && do_gt) {                              // reads prefix max: independent of the clustering kernels
             HIP_TRY(c, hipEventRecord(c->ev_init, st));   // (after the counters were zeroed)
             HIP_TRY(c, hipStreamWaitEvent(sD, c->ev_init, 0));
@@ -364,9 +367,6 @@ int csv_batch_run(csv_ctx* c, csv_run_stats* stats)
             HIP_TRY(c, hipEventRecord(c->ev_aux[2], sD));
         }
         LAUNCH("chain_apply", k_chain_apply, nb, 256, 0, B);
-        const int ns = div_up(W, SEL_TILE);
-        LAUNCH("select_count", k_select_count, ns, 256, 0, B);
-        LAUNCH("select_apply", k_select_apply, ns, 256, 0, B);
         int g_small = B.cap_items < 8192 ? B.cap_items : 8192;
         if (g_small < 1) g_small = 1;
         int g_iw = div_up(B.cap_items, 4) < 2048 ? div_up(B.cap_items, 4) : 2048;

@@ -1,8 +1,8 @@
 // kernels.hip.h — device code of libcutesv_hip.so (gfx950 / CDNA4 only, wave64).
 //
 // Pipeline of one csv_batch_run (all on one stream, no host round trip in between):
-//   chain     k_chain_count / k_chain_apply                        flags + scan -> cluster ids, cluster starts
-//   select    k_select_count / k_select_apply                      size gate -> ordered work list (two tiers)
+//   chain     k_chain_count / k_chain_apply                        break flags + scan -> cluster ids; size gate where a
+//                                                                  cluster ends -> ordered work list + three tier lists
 //   refine    k_refine_indel_sub<32> two DEL/INS clusters of m <= 32 per wavefront, <64> one of 32 < m <= 64;
 //                                 registers + cross-lane ops only
 //             k_refine<64,64>    one wavefront per DUP/INV/TRA cluster (m <= 64), arrays in LDS
@@ -62,16 +62,16 @@ struct DevBatch {
     const int*     aux;
     // chain / select
     int*           cluster_id;       // W
-    int*           cstart;           // W + 1 (cluster -> first w; cstart[n_clusters] = W); bit 31 set when the
-                                     // PREVIOUS cluster ended in a (0,0) element (the reference's sentinel look-alike)
-    int*           cseg;             // W: segment of each cluster
-    int*           partial;          // scan partials
-    i64*           partial64;
+    int*           partial;          // cluster starts per chain tile
+    i64*           partial64;        // work items per chain tile (low 32: all, high 32: workgroup tier)
     int4*          item_rec;         // ordered work list: item -> {cluster id, segment, first w, size}
     int*           list_small;       // item ids of the wavefront tier (ordered)
     int*           list_big;
     int*           list_tiny;        // DEL/INS items with m <= tiny_max: k_refine_indel_wave packs four per wavefront
     int            tiny_max;         // 16 (0 switches the class off)
+    int2*          tile_prev;        // {last cluster start before the chain tile, its segment} (k_chain_count -> k_chain_apply)
+    const int4*    seg_gate;         // per segment {read_count, dropped, svtype, -}: one 16-byte load for the size gate
+    int*           partial_t;        // tiny work items per chain tile
     // refine outputs
     int*           item_nslots;      // temp slots the item filled (t_*[s + slot])
     i64*           item_cnt;         // packed (valid calls << 32 | supports of valid calls)
@@ -323,60 +323,226 @@ __device__ __forceinline__ i64 block_prefix_of64(const i64* p, int n, i64* sh)
     return t;
 }
 
-__global__ __launch_bounds__(256) void k_chain_count(DevBatch B)
+// ------------------------------------------------------------------------------------ chain + work list in two kernels
+// Count / apply scan over 2048-signature tiles (apply re-derives its prefix from the per-tile counts; no separate scan
+// kernel).  The size gate (a cluster is a work item when it has >= read_count signatures, does not end in a (0,0)
+// element and its segment is not dropped; INDEL:62-64) is applied where a cluster ENDS, inside the same kernels: every tile lists its cluster starts in LDS (S[1..n]; S[0] = the last start before the tile, found
+// by a fifth wavefront that looks backwards while the other four read their rows), so the clusters that end in the
+// tile are the pairs (S[i], S[i + 1]) and one thread gates one cluster - a handful of integer instructions per
+// cluster instead of lane-mask arithmetic per row (a first version of this fusion did the latter and lost to
+// separate select kernels: DESIGN.md section 6).  No cluster-start / cluster-segment arrays in HBM.
+constexpr int CL_CAP = CH_TILE + 2;
+
+struct TileSeg { int uni, k, rc, drop, type; };                  // workgroup-uniform: the tile lies in one segment
+
+// gate scalars {read_count, dropped, svtype} of segment k: the tile's own when it lies in one segment, else one
+// 16-byte load (rare: a tile that spans segments, or a cluster of the previous one)
+__device__ __forceinline__ int4 gate_scalars(const DevBatch& B, const TileSeg& ts, int k)
 {
-    // first kernel of a run: nothing in this kernel reads the counters, every later kernel is stream-ordered behind it
-    if (blockIdx.x == 0 && threadIdx.x < (int)(sizeof(DevCounters) / 4)) ((int*)B.cnt)[threadIdx.x] = 0;
-    const i64 base = (i64)blockIdx.x * CH_TILE + (threadIdx.x >> 6) * (WAVE * CH_ITEMS);
-    u64 masks[CH_ITEMS]; int zprev[CH_ITEMS], ksg[CH_ITEMS];
-    chain_rows(B, base, masks, zprev, ksg);
+    if (ts.uni && k == ts.k) return make_int4(ts.rc, ts.drop, ts.type, 0);
+    return B.seg_gate[k];
+}
+// gate of the cluster [s, e) (INDEL:62-64 and the drop rule): bit 0 work item, bit 1 workgroup tier, bit 2 tiny
+__device__ __forceinline__ int close_gate(const DevBatch& B, const int4 g, int s, int e, int endz)
+{
+    const int m = e - s;
+    if (endz || m < g.x || g.y) return 0;
+    return 1 | ((m > 64) ? 2 : 0) | ((m <= B.tiny_max && g.z <= CSV_INS) ? 4 : 0);
+}
+constexpr int CL_UNROLL = 4;                         // cluster steps whose loads are issued together
+
+// rows -> flags, the tile's starts into S[1 ..], segment summary; returns the number of starts of the tile.
+// s_cnt / s_ku: per-wavefront scratch in LDS.  All 256 threads of wavefronts 0-3 call this together.
+__device__ __forceinline__ int tile_starts(const DevBatch& B, i64 base, int wv, u64 (&masks)[CH_ITEMS], int* S, int* SK, int* s_cnt, int* s_ku, TileSeg& ts)
+{
+    int zprev[CH_ITEMS], ksg[CH_ITEMS];
+    const int ku = chain_rows(B, base, masks, zprev, ksg);
     int cnt = 0;
 #pragma unroll
     for (int r = 0; r < CH_ITEMS; r++) cnt += __popcll(masks[r]);
-    __shared__ int s[4];
-    if (lane_id() == 0) s[threadIdx.x >> 6] = cnt;
+    if (lane_id() == 0) { s_cnt[wv] = cnt; s_ku[wv] = (base < B.W) ? ku : -2; }     // -2: wavefront beyond the end
     __syncthreads();
-    if (threadIdx.x == 0) B.partial[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+    int off = 1;
+    for (int q = 0; q < wv; q++) off += s_cnt[q];
+#pragma unroll
+    for (int r = 0; r < CH_ITEMS; r++) {
+        const u64 m = masks[r];
+        if ((m >> lane_id()) & 1) {
+            const int idx = off + __popcll(m & lanemask_lt());
+            S[idx] = (int)(base + r * WAVE + lane_id()) | (zprev[r] << 31);
+            SK[idx] = ksg[r];
+        }
+        off += __popcll(m);
+    }
+    int k0 = s_ku[0];
+    bool uni = k0 >= 0;
+    for (int q = 1; q < 4; q++) uni = uni && (s_ku[q] == k0 || s_ku[q] == -2);
+    ts.uni = uni ? 1 : 0; ts.k = 0; ts.rc = 0; ts.drop = 0; ts.type = 0;
+    if (uni) { const int4 g = B.seg_gate[k0]; ts.k = k0; ts.rc = g.x; ts.drop = g.y; ts.type = g.z; }
+    return s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+}
+
+// flags of the 64 signatures [cb, cb + 64), cb >= 0 (used to look backwards from a tile).  Same shape as
+// chain_rows: the row load is issued before the segment probes; one segment -> scalars + neighbour by DPP.
+__device__ __forceinline__ u64 chain_flag_row64(const DevBatch& B, i64 cb, int& kseg)
+{
+    const i64 lastw = cb + 63 < B.W ? cb + 63 : B.W - 1;
+    const i64 w = cb + lane_id();
+    const bool in = w < B.W;
+    const i64 a1 = in ? B.a[w] : 0;
+    const i64 left = (lane_id() == 0 && cb > 0) ? B.a[cb - 1] : 0;
+    const int k0 = __builtin_amdgcn_readfirstlane(seg_of_wave(B, cb)), k1 = __builtin_amdgcn_readfirstlane(seg_of_wave(B, lastw));
+    if (k0 != k1) {
+        int hint = k0;
+        i64 a0;
+        const int f = chain_flag(B, w, hint, a0, k1);
+        kseg = hint;
+        return __ballot(f);
+    }
+    kseg = k0;
+    const csv_segment& sg = B.seg[k0];
+    const i64 bias = sg.max_cluster_bias, seg_first = B.woff[k0];
+    const int type = sg.svtype;
+    i64 a0 = wave_shr1_i64(a1);
+    if (lane_id() == 0) a0 = left;
+    bool f = in && (w == seg_first || a1 - a0 > bias);
+    if (in && !f) {
+        if (w > 0 && a0 == 0 && B.b[w - 1] == 0) f = true;
+        else if (type == CSV_INV) f = (B.b[w] - B.b[w - 1] > bias) || (B.aux[w] != B.aux[w - 1]);
+        else if (type == CSV_TRA) f = B.aux[w] != B.aux[w - 1];
+    }
+    return __ballot(f);
+}
+
+__global__ __launch_bounds__(320) void k_chain_count(DevBatch B)
+{
+    // first kernel of a run: nothing in this kernel reads the counters, every later kernel is stream-ordered behind it
+    if (blockIdx.x == 0 && threadIdx.x < (int)(sizeof(DevCounters) / 4)) ((int*)B.cnt)[threadIdx.x] = 0;
+    __shared__ int S[CL_CAP], SK[CL_CAP];                 // starts of the tile (bit 31: previous signature is (0,0)) and their segments
+    __shared__ int s_cnt[4], s_ku[4], s_t[4];
+    __shared__ i64 s_v[4];
+    const int wv = threadIdx.x >> 6;
+    const i64 tile0 = (i64)blockIdx.x * CH_TILE;
+    const bool last_tile = blockIdx.x == gridDim.x - 1;
+    u64 masks[CH_ITEMS];
+    TileSeg ts;
+    int n = 0;
+    if (wv == 4) {                                         // the look-back wavefront
+        int p = -1, kp = 0;
+        for (i64 hiw = tile0; hiw > 0 && p < 0;) {
+            const i64 cb = hiw > 64 ? hiw - 64 : 0;
+            int kseg;
+            u64 f = chain_flag_row64(B, cb, kseg);
+            if (hiw - cb < 64) f &= (1ull << (hiw - cb)) - 1ull;
+            if (f) { const int l = 63 - __clzll((long long)f); p = (int)cb + l; kp = __builtin_amdgcn_readlane(kseg, l); }
+            hiw = cb;
+        }
+        if (lane_id() == 0) { S[0] = p; SK[0] = kp; B.tile_prev[blockIdx.x] = make_int2(p, kp); }
+        __syncthreads();                                   // (the barrier inside tile_starts)
+    } else {
+        n = tile_starts(B, tile0 + wv * (WAVE * CH_ITEMS), wv, masks, S, SK, s_cnt, s_ku, ts);
+        if (last_tile && threadIdx.x == 0) S[1 + n] = (int)B.W | ((B.a[B.W - 1] == 0 && B.b[B.W - 1] == 0) ? (1 << 31) : 0);
+    }
+    __syncthreads();
+    if (wv < 4) {
+        const int nc = n + (last_tile ? 1 : 0);            // clusters that end in this tile: (S[i], S[i + 1]), i < nc
+        int n_sel = 0, n_big = 0, n_tiny = 0;               // wave-uniform counts: ballots + scalar popcounts, no VALU sums
+        for (int i0 = 0; i0 < nc; i0 += 256 * CL_UNROLL) {
+            int s0[CL_UNROLL], e1[CL_UNROLL];
+            int4 g[CL_UNROLL];
+#pragma unroll
+            for (int u = 0; u < CL_UNROLL; u++) {
+                const int i = i0 + u * 256 + threadIdx.x;
+                s0[u] = -1; e1[u] = 0; g[u] = make_int4(0, 0, 0, 0);
+                if (i < nc) { s0[u] = S[i]; e1[u] = S[i + 1]; g[u] = gate_scalars(B, ts, SK[i]); }
+            }
+#pragma unroll
+            for (int u = 0; u < CL_UNROLL; u++) {
+                const int fl = (s0[u] != -1) ? close_gate(B, g[u], s0[u] & 0x7fffffff, e1[u] & 0x7fffffff, e1[u] < 0) : 0;
+                n_sel += __popcll(__ballot(fl & 1)); n_big += __popcll(__ballot(fl & 2)); n_tiny += __popcll(__ballot(fl & 4));
+            }
+        }
+        if (lane_id() == 0) { s_v[wv] = (i64)n_sel | ((i64)n_big << 32); s_t[wv] = n_tiny; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        B.partial[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        B.partial64[blockIdx.x] = s_v[0] + s_v[1] + s_v[2] + s_v[3];
+        B.partial_t[blockIdx.x] = s_t[0] + s_t[1] + s_t[2] + s_t[3];
+    }
 }
 
 __global__ __launch_bounds__(256) void k_chain_apply(DevBatch B)
 {
-    __shared__ i64 sh[4];
+    __shared__ int S[CL_CAP], SK[CL_CAP];
+    __shared__ int s_cnt[4], s_ku[4], s_t[2][4];
+    __shared__ i64 s_v[2][4], sh[12];
     const int wv = threadIdx.x >> 6;
     const i64 base = (i64)blockIdx.x * CH_TILE + wv * (WAVE * CH_ITEMS);
+    const bool last_tile = blockIdx.x == gridDim.x - 1;
     u64 masks[CH_ITEMS];
-    int zprev[CH_ITEMS], ksg[CH_ITEMS]; // the element before a cluster start is the last element of the previous cluster
-    chain_rows(B, base, masks, zprev, ksg);
-    int cnt = 0;
-#pragma unroll
-    for (int r = 0; r < CH_ITEMS; r++) cnt += __popcll(masks[r]);
-    // exclusive prefix of this workgroup = sum of the counts of all earlier workgroups (tiny, L2 resident)
-    int run = (int)block_prefix_of(B.partial, blockIdx.x, sh);
-    __shared__ int s[4];
-    if (lane_id() == 0) s[wv] = cnt;
-    __syncthreads();
-    for (int k = 0; k < wv; k++) run += s[k];
-    const int my_total = s[0] + s[1] + s[2] + s[3];
+    TileSeg ts;
+    // the three exclusive prefixes of this workgroup (cluster starts, work items | workgroup tier, tiny items):
+    // sums over all earlier workgroups, tiny and L2 resident; one pair of barriers for the three
+    i64 p0 = 0, p1 = 0, p2 = 0;
+    for (int i = threadIdx.x; i < (int)blockIdx.x; i += 256) { p0 += B.partial[i]; p1 += B.partial64[i]; p2 += B.partial_t[i]; }
+    p0 = wave_sum_i64(p0); p1 = wave_sum_i64(p1); p2 = wave_sum_i64(p2);
+    if (lane_id() == 0) { sh[wv] = p0; sh[4 + wv] = p1; sh[8 + wv] = p2; }
+    if (threadIdx.x == 0) { const int2 tp = B.tile_prev[blockIdx.x]; S[0] = tp.x; SK[0] = tp.y; }
+    const int n = tile_starts(B, base, wv, masks, S, SK, s_cnt, s_ku, ts);            // (barrier inside: sh / S[0] are visible after it)
+    int run = (int)(sh[0] + sh[1] + sh[2] + sh[3]);
+    i64 runs = sh[4] + sh[5] + sh[6] + sh[7];
+    int run_t = (int)(sh[8] + sh[9] + sh[10] + sh[11]);
+    const int cid0 = run;                                   // id of the first cluster that STARTS in this tile
+    if (last_tile && threadIdx.x == 0) S[1 + n] = (int)B.W | ((B.a[B.W - 1] == 0 && B.b[B.W - 1] == 0) ? (1 << 31) : 0);
+    for (int q = 0; q < wv; q++) run += s_cnt[q];
 #pragma unroll
     for (int r = 0; r < CH_ITEMS; r++) {
         const i64 w = base + r * WAVE + lane_id();
         const u64 m = masks[r];
-        if (w < B.W) {
-            const int cid = run + __popcll(m & (lanemask_lt() | (1ull << lane_id()))) - 1;
-            B.cluster_id[w] = cid;
-            B.allele_id[w] = -1;
-            if ((m >> lane_id()) & 1) { B.cstart[cid] = (int)w | (zprev[r] << 31); B.cseg[cid] = ksg[r]; }
-        }
+        if (w < B.W) { B.cluster_id[w] = run + __popcll(m & (lanemask_lt() | (1ull << lane_id()))) - 1; B.allele_id[w] = -1; }
         run += __popcll(m);
     }
-    // the last workgroup also plants the sentinel cstart[n_clusters] = W (bit 31: last element is (0,0))
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) {
-        // thread 255 is in the last wavefront: its `run` now holds prefix + the whole workgroup's count
-        const int z = (B.a[B.W - 1] == 0 && B.b[B.W - 1] == 0) ? 1 : 0;
-        B.cstart[run] = (int)B.W | (z << 31);
-        B.cnt->n_clusters = run;
+    __syncthreads();                                        // S complete (sentinel included)
+    const int nc = n + (last_tile ? 1 : 0);
+    int jrun = (int)(runs & 0xffffffffll), jbrun = (int)(runs >> 32);
+    for (int i0 = 0, par = 0; i0 < nc; i0 += 256 * CL_UNROLL) {   // ordered compaction of the tile's work items, 256 clusters per step
+        int s0[CL_UNROLL], e1[CL_UNROLL], kk[CL_UNROLL];
+        int4 g[CL_UNROLL];
+#pragma unroll
+        for (int u = 0; u < CL_UNROLL; u++) {
+            const int i = i0 + u * 256 + threadIdx.x;
+            s0[u] = -1; e1[u] = 0; kk[u] = 0; g[u] = make_int4(0, 0, 0, 0);
+            if (i < nc) { s0[u] = S[i]; e1[u] = S[i + 1]; kk[u] = SK[i]; g[u] = gate_scalars(B, ts, kk[u]); }
+        }
+#pragma unroll
+        for (int u = 0; u < CL_UNROLL; u++) {
+            if (i0 + u * 256 >= nc) break;                    // workgroup-uniform
+            const int i = i0 + u * 256 + threadIdx.x;
+            const int fl = (s0[u] != -1) ? close_gate(B, g[u], s0[u] & 0x7fffffff, e1[u] & 0x7fffffff, e1[u] < 0) : 0;
+            const u64 m_sel = __ballot(fl & 1), m_big = __ballot(fl & 2), m_tiny = __ballot(fl & 4);
+            // (wave totals double-buffered by step parity: one barrier per step)
+            if (lane_id() == 0) { s_v[par][wv] = (i64)__popcll(m_sel) | ((i64)__popcll(m_big) << 32); s_t[par][wv] = __popcll(m_tiny); }
+            __syncthreads();
+            int bj = jrun, bb = jbrun, bt = run_t;          // counts before this wavefront's 64 clusters
+            for (int q = 0; q < wv; q++) { bj += (int)(s_v[par][q] & 0xffffffffll); bb += (int)(s_v[par][q] >> 32); bt += s_t[par][q]; }
+            if (fl & 1) {
+                const int j = bj + __popcll(m_sel & lanemask_lt()), jb = bb + __popcll(m_big & lanemask_lt()), jt = bt + __popcll(m_tiny & lanemask_lt());
+                const int ss = s0[u] & 0x7fffffff;
+                B.item_rec[j] = make_int4(cid0 + i - 1, kk[u], ss, (e1[u] & 0x7fffffff) - ss);
+                if (fl & 2) B.list_big[jb] = j;
+                else if (fl & 4) B.list_tiny[jt] = j;
+                else B.list_small[j - jb - jt] = j;
+            }
+            for (int q = 0; q < 4; q++) { jrun += (int)(s_v[par][q] & 0xffffffffll); jbrun += (int)(s_v[par][q] >> 32); run_t += s_t[par][q]; }
+            par ^= 1;
+        }
     }
-    (void)my_total;
+    runs = (i64)(unsigned)jrun | ((i64)jbrun << 32);
+    if (last_tile && threadIdx.x == 0) {
+        B.cnt->n_clusters = cid0 + n;
+        B.cnt->n_items = (int)(runs & 0xffffffffll); B.cnt->n_items_big = (int)(runs >> 32); B.cnt->n_items_tiny = run_t;
+    }
 }
 
 // ------------------------------------------------------------------------------------ input order contract
@@ -400,100 +566,6 @@ __global__ __launch_bounds__(256) void k_validate_order(DevBatch B)
     if (c == 0) c = (r1 > r0) - (r1 < r0);
     if (c == 0 && type == CSV_INS) c = 1;               // equal (pos, len, read): the sequences may still differ
     if (c <= 0) atomicOr(&B.cnt->error, ERR_SIG_ORDER);
-}
-
-// ------------------------------------------------------------------------------------ select
-// cluster c is a work item when it passes the size gate (signatures >= read_count, INDEL:62),
-// does not end in a (0,0) element (INDEL:63-64) and its segment is not dropped.
-// packed counter: low 32 = items, high 32 = items of the workgroup tier (m > 64).
-__device__ __forceinline__ i64 select_value(const DevBatch& B, int c, int nC, int4& rec, int& tiny)
-{
-    tiny = 0;
-    if (c >= nC) return 0;
-    const int s = B.cstart[c] & 0x7fffffff, e1 = B.cstart[c + 1];
-    const int e = e1 & 0x7fffffff;
-    const int k = B.cseg[c];
-    rec = make_int4(c, k, s, e - s);
-    if (e1 < 0) return 0;                                   // the cluster ends in a (0,0) element
-    if (e - s < B.seg[k].read_count) return 0;
-    if (B.seg_drop[k]) return 0;
-    tiny = (e - s <= B.tiny_max && B.seg[k].svtype <= CSV_INS) ? 1 : 0;
-    return 1ll + ((e - s > 64) ? (1ll << 32) : 0ll);
-}
-
-constexpr int SEL_ROWS = 4;
-constexpr int SEL_TILE = 256 * SEL_ROWS;             // clusters per workgroup
-
-__global__ __launch_bounds__(256) void k_select_count(DevBatch B)
-{
-    const int nC = B.cnt->n_clusters;
-    if ((i64)blockIdx.x * SEL_TILE >= nC) return;
-    const int base = blockIdx.x * SEL_TILE + (threadIdx.x >> 6) * (WAVE * SEL_ROWS);
-    i64 v = 0;
-    int nt = 0;
-    int4 rec;
-#pragma unroll
-    for (int r = 0; r < SEL_ROWS; r++) { int t; v += select_value(B, base + r * WAVE + lane_id(), nC, rec, t); nt += t; }
-    v = wave_sum_i64(v);
-    nt = wave_sum_i32(nt);
-    __shared__ i64 s[4];
-    __shared__ int st[4];
-    if (lane_id() == 0) { s[threadIdx.x >> 6] = v; st[threadIdx.x >> 6] = nt; }
-    __syncthreads();
-    if (threadIdx.x == 0) { B.partial64[blockIdx.x] = s[0] + s[1] + s[2] + s[3]; B.partial[blockIdx.x] = st[0] + st[1] + st[2] + st[3]; }
-}
-
-__global__ __launch_bounds__(256) void k_select_apply(DevBatch B)
-{
-    __shared__ i64 sh[4];
-    const int nC = B.cnt->n_clusters;
-    const int nblk = (nC + SEL_TILE - 1) / SEL_TILE;
-    if (blockIdx.x == 0) {                                  // publishes the totals for the kernels behind
-        const i64 t = block_prefix_of64(B.partial64, nblk, sh);
-        const i64 tt = block_prefix_of(B.partial, nblk, sh);
-        if (threadIdx.x == 0) { B.cnt->n_items = (int)(t & 0xffffffffll); B.cnt->n_items_big = (int)(t >> 32); B.cnt->n_items_tiny = (int)tt; }
-    }
-    if ((int)blockIdx.x >= nblk) return;
-    const int wv = threadIdx.x >> 6;
-    const int base = blockIdx.x * SEL_TILE + wv * (WAVE * SEL_ROWS);
-    // per row the record is kept as {segment, start, size | tiny << 30} (the cluster id is the row's index): registers
-    // decide whether all ~1400 workgroups of a 30x genome are resident at once
-    i64 v[SEL_ROWS];
-    int rk[SEL_ROWS], rs[SEL_ROWS], rm[SEL_ROWS];
-    i64 tot = 0;
-    int tot_t = 0;
-#pragma unroll
-    for (int r = 0; r < SEL_ROWS; r++) {
-        int4 rec; int t;
-        v[r] = select_value(B, base + r * WAVE + lane_id(), nC, rec, t);
-        rk[r] = rec.y; rs[r] = rec.z; rm[r] = rec.w | (t << 30);
-        tot += v[r]; tot_t += t;
-    }
-    tot = wave_sum_i64(tot);
-    tot_t = wave_sum_i32(tot_t);
-    i64 run = block_prefix_of64(B.partial64, blockIdx.x, sh);
-    int run_t = (int)block_prefix_of(B.partial, blockIdx.x, sh);
-    __shared__ i64 s[4];
-    __shared__ int st[4];
-    if (lane_id() == 0) { s[wv] = tot; st[wv] = tot_t; }
-    __syncthreads();
-    for (int q = 0; q < wv; q++) { run += s[q]; run_t += st[q]; }
-#pragma unroll
-    for (int r = 0; r < SEL_ROWS; r++) {
-        const i64 inc = wave_incl_scan_i64(v[r]);
-        const int tiny = rm[r] >> 30;
-        const int inc_t = wave_incl_scan_i32(tiny);
-        if (v[r]) {
-            const i64 ex = run + inc - v[r];
-            const int j = (int)(ex & 0xffffffffll), jb = (int)(ex >> 32), jt = run_t + inc_t - tiny;
-            B.item_rec[j] = make_int4(base + r * WAVE + lane_id(), rk[r], rs[r], rm[r] & 0x3fffffff);
-            if (v[r] >> 32) B.list_big[jb] = j;
-            else if (tiny) B.list_tiny[jt] = j;
-            else B.list_small[j - jb - jt] = j;
-        }
-        run += lane63_i64(inc);
-        run_t += __builtin_amdgcn_readlane(inc_t, 63);
-    }
 }
 
 // ------------------------------------------------------------------------------------ refine
