@@ -1673,12 +1673,14 @@ __global__ __launch_bounds__(512) void k_items_scan(DevBatch B)
             }
 #pragma unroll
             for (int r = 0; r < 8; r++) buf[wv][(r * 8 + (lane >> 3)) * 9 + (lane & 7)] = v[r];
-            __syncthreads();
+            // buf[wv] belongs to this wavefront alone: its LDS operations execute in order, so a wave-level fence
+            // (no instruction, just no reordering by the compiler) is all the transpose needs
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             i64 t = 0;
 #pragma unroll
             for (int e = 0; e < 8; e++) t += buf[wv][lane * 9 + e];
             ts[c] = t;
-            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
         i64 inc[IS_CH]; i64 tot = 0;
 #pragma unroll
