@@ -391,7 +391,7 @@ int csv_batch_run(csv_ctx* c, csv_run_stats* stats)
             HIP_TRY(c, hipStreamWaitEvent(st, c->ev_aux[0], 0));
             if (c->any_pair) { HIP_TRY(c, hipEventRecord(c->ev_aux[1], sC)); HIP_TRY(c, hipStreamWaitEvent(st, c->ev_aux[1], 0)); }
         }
-        LAUNCH("items_scan", k_items_scan, 1, 512, 0, B);
+        LAUNCH("items_scan", k_items_scan, 1, 64 * IS_NW, 0, B);
         LAUNCH("emit", k_emit, 2048, 256, 0, B);
         if (do_gt) {
             if (fork) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_aux[2], 0));

@@ -1646,21 +1646,22 @@ __global__ __launch_bounds__(256, CSV_IW_WAVES) void k_refine_indel_wave(DevBatc
 
 // ------------------------------------------------------------------------------------ order
 // exclusive prefix of the packed (calls, supports) counts at the granularity k_emit needs: one value per
-// tile of EM_TILE = 8 items (k_emit finishes the prefix inside its wavefront).  One workgroup of 8
+// tile of EM_TILE = 8 items (k_emit finishes the prefix inside its wavefront).  One workgroup of IS_NW
 // wavefronts; a wavefront takes IS_CH chunks of 512 items: coalesced row loads, an LDS transpose so that
 // lane t owns tile t of the chunk, one wave scan per chunk.  4096 tiles = 32768 items per sweep.
-constexpr int IS_CH = 8;
-__global__ __launch_bounds__(512) void k_items_scan(DevBatch B)
+constexpr int IS_CH = 4;                             // chunks of 512 items per wavefront and sweep
+constexpr int IS_NW = 16;                            // wavefronts (one workgroup: the scan is a latency chain, so it is spread thin)
+__global__ __launch_bounds__(64 * IS_NW) void k_items_scan(DevBatch B)
 {
     const int n = B.cnt->n_items;
     const int ntiles = (n + EM_TILE - 1) / EM_TILE;
     const int wv = threadIdx.x >> 6, lane = lane_id();
-    __shared__ i64 buf[8][64 * 9];                      // [tile][8 items], rows padded to 9
-    __shared__ i64 wsum[8];
+    __shared__ i64 buf[IS_NW][64 * 9];                      // [tile][8 items], rows padded to 9
+    __shared__ i64 wsum[IS_NW];
     __shared__ i64 carry_s;
     if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
-    for (int base = 0; base < ntiles; base += 8 * IS_CH * 64) {
+    for (int base = 0; base < ntiles; base += IS_NW * IS_CH * 64) {
         i64 ts[IS_CH];
 #pragma unroll
         for (int c = 0; c < IS_CH; c++) {
@@ -1696,7 +1697,7 @@ __global__ __launch_bounds__(512) void k_items_scan(DevBatch B)
             run += lane63_i64(inc[c]);
         }
         __syncthreads();
-        if (threadIdx.x == 511) carry_s = run;
+        if (threadIdx.x == 64 * IS_NW - 1) carry_s = run;
         __syncthreads();
     }
     if (threadIdx.x == 0) {
