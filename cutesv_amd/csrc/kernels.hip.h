@@ -1767,10 +1767,15 @@ __global__ __launch_bounds__(256) void k_emit(DevBatch B)
     for (int tile = wave; tile < ntiles; tile += nwaves) {
         const int j = tile * EM_TILE + g;
         const bool act = j < n;
+        // round 1: everything that only depends on the item index is loaded together ...
         const i64 cnt = act ? B.item_cnt[j] : 0;
+        const int nslots_raw = act ? B.item_nslots[j] : 0;
+        int4 rec = make_int4(0, 0, 0, 0);
+        if (act) rec = B.item_rec[j];
+        const i64 tile_base = B.item_base[tile];
         const i64 ginc = wave_incl_scan_i64(l8 == 0 ? cnt : 0);      // prefix over the tile's 8 items (one lane per group contributes)
-        const i64 base = B.item_base[tile] + ginc - cnt;
-        const int nslots = (act && cnt) ? B.item_nslots[j] : 0;
+        const i64 base = tile_base + ginc - cnt;
+        const int nslots = cnt ? nslots_raw : 0;
         if (__ballot(nslots > 8)) {                         // wave-uniform
             for (int q = 0; q < EM_TILE; q++) {
                 const i64 cq = shfl_i64(cnt, q * 8), bq = shfl_i64(base, q * 8);
@@ -1778,16 +1783,19 @@ __global__ __launch_bounds__(256) void k_emit(DevBatch B)
             }
             continue;
         }
-        int4 rec = make_int4(0, 0, 0, 0);
-        if (nslots) rec = B.item_rec[j];
         const int cid = rec.x, k = rec.y, s = rec.z;
         const bool mine = l8 < nslots;
         const int t = s + l8;
-        const int valid = mine ? B.t_valid[t] : 0;
-        const int nsup = valid ? B.t_support[t] : 0;
-        const int tso = valid ? B.t_supoff[t] : 0;
+        // ... round 2: the slot records of all 8 items (one lane per temp slot), valid or not, and the segment scalars
+        int valid = 0, nsup = 0, tso = 0, ci = 0, cl = 0;
+        i64 bp1 = 0, bp2 = 0, srch = 0, pick = 0;
+        if (mine) {
+            valid = B.t_valid[t]; nsup = B.t_support[t]; tso = B.t_supoff[t];
+            bp1 = B.t_bp1[t]; bp2 = B.t_bp2[t]; ci = B.t_cipos[t]; cl = B.t_cilen[t]; srch = B.t_search[t]; pick = B.t_pick[t];
+        }
         i64 gs = 0; int aux0 = 0;
         if (nslots) { gs = B.seg[k].sig_begin + ((i64)s - B.woff[k]) - s; aux0 = B.aux[s]; }
+        if (!valid) { nsup = 0; tso = 0; }
         const u64 mk = __ballot(valid);
         const u64 gmask = 0xffull << (g * 8);
         const int c = (int)(base >> 32) + __popcll(mk & gmask & lanemask_lt());
@@ -1796,9 +1804,9 @@ __global__ __launch_bounds__(256) void k_emit(DevBatch B)
         const i64 so = (base & 0xffffffffll) + (sinc - nsup) - (g ? gprev : 0);
         if (valid) {
             B.o_seg[c] = k; B.o_cluster[c] = cid; B.o_aux[c] = aux0;
-            B.o_bp1[c] = B.t_bp1[t]; B.o_bp2[c] = B.t_bp2[t]; B.o_support[c] = nsup;
-            B.o_cipos[c] = B.t_cipos[t]; B.o_cilen[c] = B.t_cilen[t];
-            B.o_search[c] = B.t_search[t]; B.o_pick[c] = B.t_pick[t];
+            B.o_bp1[c] = bp1; B.o_bp2[c] = bp2; B.o_support[c] = nsup;
+            B.o_cipos[c] = ci; B.o_cilen[c] = cl;
+            B.o_search[c] = srch; B.o_pick[c] = pick;
             B.o_dr[c] = -1; B.o_dv[c] = -1; B.o_gl[c] = -1;
             B.o_supoff[c] = so;
         }
