@@ -212,7 +212,7 @@ def main():
     if rank == 0:
         kbytes, total_bytes, units = kernel_units(store, hb, res, st)
         per_kernel = {names[i]: round(float(acc[i]) * 1e3, 2) for i in range(_abi.N_STAGES) if names[i]}   # microseconds
-        per_kernel["genotype_stage"] = round(sum(per_kernel.get(k, 0.0) for k in ("k_pmax_count", "k_pmax_scan", "k_pmax_apply", "k_genotype")), 2)
+        per_kernel["genotype_stage"] = round(sum(per_kernel.get(k, 0.0) for k in ("k_pmax_count", "k_pmax_apply", "k_genotype")), 2)
         dom = max((n for n in per_kernel if n in kbytes and kbytes[n] > 0), key=lambda n: per_kernel[n])
         dom_s = per_kernel[dom] * 1e-6
         achieved = kbytes[dom] / dom_s / 1e9
@@ -221,7 +221,7 @@ def main():
         if os.path.exists(tf) and a.scale == 1.0:
             with open(tf) as f:
                 tj = json.load(f)
-                traffic = sum(tj.get(k, 0) for k in ("k_pmax_count", "k_pmax_scan", "k_pmax_apply", "k_genotype")) if dom == "genotype_stage" else tj.get(dom)
+                traffic = sum(tj.get(k, 0) for k in ("k_pmax_count", "k_pmax_apply", "k_genotype")) if dom == "genotype_stage" else tj.get(dom)
         parity = None
         if cpu_c is not None:
             w, g = ores.trimmed(), res.trimmed()

@@ -25,7 +25,7 @@ struct Buf {                      // grow-only device buffer
 // one timing slot per launch, in launch order
 const char* kStageName[CSV_N_STAGES] = {"init", "k_chain_count", "k_chain_apply",
                                         "k_refine_indel_wave", "k_refine_wave", "k_refine_mid", "k_refine_block", "k_items_scan",
-                                        "k_emit", "k_pmax_count", "k_pmax_scan", "k_pmax_apply", "k_genotype", "k_genotype_tra", "", ""};
+                                        "k_emit", "k_pmax_count", "k_pmax_apply", "k_genotype", "k_genotype_tra", "", "", ""};
 
 }  // namespace
 
@@ -362,7 +362,6 @@ int csv_batch_run(csv_ctx* c, csv_run_stats* stats)
             HIP_TRY(c, hipEventRecord(c->ev_init, st));   // (after the counters were zeroed)
             HIP_TRY(c, hipStreamWaitEvent(sD, c->ev_init, 0));
             LAUNCH_ON(sD, "pmax_count", k_pmax_count, nr, 256, 0, B);
-            LAUNCH_ON(sD, "pmax_scan", k_pmax_scan, 1, 256, 0, B.pm_partial, nr);
             LAUNCH_ON(sD, "pmax_apply", k_pmax_apply, nr, 256, 0, B);
             HIP_TRY(c, hipEventRecord(c->ev_aux[2], sD));
         }
@@ -397,14 +396,13 @@ int csv_batch_run(csv_ctx* c, csv_run_stats* stats)
             if (fork) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_aux[2], 0));
             else {
                 LAUNCH("pmax_count", k_pmax_count, nr, 256, 0, B);
-                LAUNCH("pmax_scan", k_pmax_scan, 1, 256, 0, B.pm_partial, nr);
                 LAUNCH("pmax_apply", k_pmax_apply, nr, 256, 0, B);
             }
             hipLaunchKernelGGL((k_genotype<1024, 4>), dim3(2048), dim3(256), 0, st, B, 0);
             hipLaunchKernelGGL((k_genotype<8192, 1>), dim3(256), dim3(64), 0, st, B, 1);      // overflow list of the first pass
             DBG("genotype");
             HIP_TRY(c, mark());
-        } else if (stats) { HIP_TRY(c, mark()); HIP_TRY(c, mark()); HIP_TRY(c, mark()); HIP_TRY(c, mark()); }
+        } else if (stats) { HIP_TRY(c, mark()); HIP_TRY(c, mark()); HIP_TRY(c, mark()); }
         if (c->any_tra_gt) {
             LAUNCH("genotype_tra", k_genotype_tra, 256, 64, 0, B);
         }

@@ -8,7 +8,7 @@
 //             k_refine<64,64>    one wavefront per DUP/INV/TRA cluster (m <= 64), arrays in LDS
 //             k_refine<256,2048> one workgroup per cluster; LDS up to 2048 padded elements, global scratch above
 //   order     k_emit                                               per-item counts -> dense, ordered outputs
-//   reads     k_pmax_count / k_pmax_scan / k_pmax_apply            prefix max of read ends + sortedness check
+//   reads     k_pmax_count / k_pmax_apply                          prefix max of read ends + sortedness check
 //   genotype  k_genotype                                           one wavefront per call: 64-ary search,
 //                                                                  backwards stabbing scan, LDS hash set
 //
@@ -1881,31 +1881,6 @@ __global__ __launch_bounds__(256) void k_pmax_count(DevBatch B)
     if (threadIdx.x == 0) { i64 t = s[0]; for (int k = 1; k < 4; k++) if (s[k] > t) t = s[k]; B.pm_partial[blockIdx.x] = t; }
 }
 
-// exclusive max-scan of the tile maxima (single workgroup)
-__global__ __launch_bounds__(256) void k_pmax_scan(i64* p, int n)
-{
-    __shared__ i64 wmax[4];
-    __shared__ i64 carry_s;
-    if (threadIdx.x == 0) carry_s = INT64_MIN;
-    __syncthreads();
-    for (int base = 0; base < n; base += 256) {
-        const int i = base + threadIdx.x;
-        const i64 v = i < n ? p[i] : INT64_MIN;
-        const i64 inc = wave_incl_max_i64(v);
-        if (lane_id() == 63) wmax[threadIdx.x >> 6] = inc;
-        __syncthreads();
-        i64 pre = carry_s;
-        for (int k = 0; k < (int)(threadIdx.x >> 6); k++) if (wmax[k] > pre) pre = wmax[k];
-        i64 ex = wave_shr1_i64(inc);
-        if (lane_id() == 0) ex = INT64_MIN;
-        if (pre > ex) ex = pre;
-        if (i < n) p[i] = ex;
-        __syncthreads();
-        if (threadIdx.x == 255) carry_s = inc > pre ? inc : pre;
-        __syncthreads();
-    }
-}
-
 __global__ __launch_bounds__(256) void k_pmax_apply(DevBatch B)
 {
     const int wv = threadIdx.x >> 6;
@@ -1920,10 +1895,16 @@ __global__ __launch_bounds__(256) void k_pmax_apply(DevBatch B)
         vals[r] = inc;
         run = lane63_i64(inc);
     }
-    __shared__ i64 s[4];
-    if (lane_id() == 0) s[wv] = run;
+    __shared__ i64 s[4], sp[4];
+    // exclusive prefix max of this tile = max over the maxima of all earlier tiles (self-computed like the chain
+    // prefix: a few thousand L2-resident values; the separate single-workgroup scan kernel cost 8-12 us)
+    i64 pm = INT64_MIN;
+    for (int t = threadIdx.x; t < (int)blockIdx.x; t += 256) { const i64 v = B.pm_partial[t]; if (v > pm) pm = v; }
+    for (int m = 32; m > 0; m >>= 1) { const i64 o = shfl_xor_i64(pm, m); if (o > pm) pm = o; }
+    if (lane_id() == 0) { s[wv] = run; sp[wv] = pm; }
     __syncthreads();
-    i64 pre = B.pm_partial[blockIdx.x];
+    i64 pre = sp[0];
+    for (int k = 1; k < 4; k++) if (sp[k] > pre) pre = sp[k];
     for (int k = 0; k < wv; k++) if (s[k] > pre) pre = s[k];
     for (int r = 0; r < 8; r++) {
         const i64 i = base + r * 64 + lane_id();
