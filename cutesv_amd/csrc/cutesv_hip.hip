@@ -42,7 +42,7 @@ struct csv_ctx {
     Buf item_nslots, item_cnt, item_base, sup_tmp;
     Buf t_bp1, t_bp2, t_search, t_pick, t_support, t_cipos, t_cilen, t_supoff, t_valid;
     Buf sc_k, sc_x, sc_v1, sc_v2, sc_v3, sc_v4, sc_v5;
-    Buf o_seg, o_cluster, o_aux, o_bp1, o_bp2, o_support, o_cipos, o_cilen, o_search, o_pick, o_dr, o_dv, o_gl;
+    Buf o_seg, o_cluster, o_aux, o_bp1, o_bp2, o_support, o_cipos, o_cilen, o_search, o_pick, o_dr, o_dv, o_gl, o_ghdr;
     Buf o_supoff, o_supsig, o_suprid, allele_id;
     Buf reads_off, r_start, r_end, r_primary, r_id, r_pmax, pm_partial, gt_over, contig_len;
     Buf sqrt_tab, cnt;
@@ -246,7 +246,7 @@ int csv_batch_upload(csv_ctx* c, const csv_batch_in* in)
     RES(sc_k, SC * 8); RES(sc_x, SC * 8); RES(sc_v1, SC * 4); RES(sc_v2, SC * 4); RES(sc_v3, SC * 4); RES(sc_v4, SC * 4); RES(sc_v5, SC * 4);
     RES(o_seg, cap_tmp * 4); RES(o_cluster, cap_tmp * 4); RES(o_aux, cap_tmp * 4); RES(o_bp1, cap_tmp * 8); RES(o_bp2, cap_tmp * 8);
     RES(o_support, cap_tmp * 4); RES(o_cipos, cap_tmp * 4); RES(o_cilen, cap_tmp * 4); RES(o_search, cap_tmp * 8); RES(o_pick, cap_tmp * 8);
-    RES(o_dr, cap_tmp * 4); RES(o_dv, cap_tmp * 4); RES(o_gl, cap_tmp * 4); RES(o_supoff, (cap_tmp + 1) * 8);
+    RES(o_dr, cap_tmp * 4); RES(o_dv, cap_tmp * 4); RES(o_gl, cap_tmp * 4); RES(o_ghdr, cap_tmp * 16); RES(o_supoff, (cap_tmp + 1) * 8);
     RES(o_supsig, (W + 1) * 8); RES(o_suprid, (W + 1) * 4);
     const bool have_tab = c->any_genotype && in->reads_off;
     if (have_tab) { RES(reads_off, (in->n_chrom + 1) * 8); RES(contig_len, (in->n_chrom + 1) * 8); }
@@ -301,7 +301,7 @@ int csv_batch_upload(csv_ctx* c, const csv_batch_in* in)
     B.sc_k = dp<u64>(c->sc_k); B.sc_x = dp<i64>(c->sc_x); B.sc_v1 = dp<int>(c->sc_v1); B.sc_v2 = dp<int>(c->sc_v2); B.sc_v3 = dp<int>(c->sc_v3); B.sc_v4 = dp<int>(c->sc_v4); B.sc_v5 = dp<int>(c->sc_v5);
     B.o_seg = dp<int>(c->o_seg); B.o_cluster = dp<int>(c->o_cluster); B.o_aux = dp<int>(c->o_aux);
     B.o_bp1 = dp<i64>(c->o_bp1); B.o_bp2 = dp<i64>(c->o_bp2); B.o_support = dp<int>(c->o_support); B.o_cipos = dp<int>(c->o_cipos); B.o_cilen = dp<int>(c->o_cilen);
-    B.o_search = dp<i64>(c->o_search); B.o_pick = dp<i64>(c->o_pick); B.o_dr = dp<int>(c->o_dr); B.o_dv = dp<int>(c->o_dv); B.o_gl = dp<int>(c->o_gl);
+    B.o_search = dp<i64>(c->o_search); B.o_pick = dp<i64>(c->o_pick); B.o_dr = dp<int>(c->o_dr); B.o_dv = dp<int>(c->o_dv); B.o_gl = dp<int>(c->o_gl); B.o_ghdr = dp<int4>(c->o_ghdr);
     B.o_supoff = dp<i64>(c->o_supoff); B.o_supsig = dp<i64>(c->o_supsig); B.o_suprid = dp<int>(c->o_suprid); B.allele_id = dp<int>(c->allele_id);
     B.reads_off = dp<i64>(c->reads_off); B.n_reads = R;
     B.r_start = dp<i64>(c->r_start); B.r_end = dp<i64>(c->r_end); B.r_primary = dp<uint8_t>(c->r_primary); B.r_id = dp<int>(c->r_id); B.r_pmax = dp<i64>(c->r_pmax); B.pm_partial = dp<i64>(c->pm_partial); B.gt_over = dp<int>(c->gt_over); B.contig_len = dp<i64>(c->contig_len);

@@ -87,6 +87,7 @@ struct DevBatch {
     int*           o_seg; int* o_cluster; int* o_aux;
     i64*           o_bp1; i64* o_bp2; int* o_support; int* o_cipos; int* o_cilen; i64* o_search; i64* o_pick;
     int*           o_dr; int* o_dv; int* o_gl;
+    int4*          o_ghdr;           // per call {chrom, svtype | genotype << 8, gt_bias lo, hi}: k_genotype reads no segment record
     i64*           o_supoff;         // n_calls + 1
     i64*           o_supsig;         // global signature index
     int*           o_suprid;         // read id of the support (genotype)
@@ -1715,7 +1716,9 @@ __device__ __forceinline__ void emit_item_serial(const DevBatch& B, int j, i64 b
     const int nslots = B.item_nslots[j];
     const int4 rec = B.item_rec[j];
     const int cid = rec.x, k = rec.y, s = rec.z;
-    const i64 gs = B.seg[k].sig_begin + ((i64)s - B.woff[k]) - s;      // w -> global signature index
+    const csv_segment& sgk = B.seg[k];
+    const i64 gs = sgk.sig_begin + ((i64)s - B.woff[k]) - s;           // w -> global signature index
+    const int4 ghdr = make_int4(sgk.chrom, sgk.svtype | (sgk.genotype ? 0x100 : 0), (int)(sgk.gt_bias & 0xffffffffll), (int)(sgk.gt_bias >> 32));
     int cb = (int)(base >> 32); i64 sb = base & 0xffffffffll;
     const int aux0 = B.aux[s];
     for (int c0 = 0; c0 < nslots; c0 += 64) {
@@ -1735,6 +1738,7 @@ __device__ __forceinline__ void emit_item_serial(const DevBatch& B, int j, i64 b
             B.o_search[c] = B.t_search[t]; B.o_pick[c] = B.t_pick[t];
             B.o_dr[c] = -1; B.o_dv[c] = -1; B.o_gl[c] = -1;
             B.o_supoff[c] = so;
+            B.o_ghdr[c] = ghdr;
         }
         u64 rest = mk;
         while (rest) {
@@ -1794,7 +1798,12 @@ __global__ __launch_bounds__(256) void k_emit(DevBatch B)
             bp1 = B.t_bp1[t]; bp2 = B.t_bp2[t]; ci = B.t_cipos[t]; cl = B.t_cilen[t]; srch = B.t_search[t]; pick = B.t_pick[t];
         }
         i64 gs = 0; int aux0 = 0;
-        if (nslots) { gs = B.seg[k].sig_begin + ((i64)s - B.woff[k]) - s; aux0 = B.aux[s]; }
+        int4 ghdr = make_int4(0, 0, 0, 0);
+        if (nslots) {
+            const csv_segment& sgk = B.seg[k];
+            gs = sgk.sig_begin + ((i64)s - B.woff[k]) - s; aux0 = B.aux[s];
+            ghdr = make_int4(sgk.chrom, sgk.svtype | (sgk.genotype ? 0x100 : 0), (int)(sgk.gt_bias & 0xffffffffll), (int)(sgk.gt_bias >> 32));
+        }
         if (!valid) { nsup = 0; tso = 0; }
         const u64 mk = __ballot(valid);
         const u64 gmask = 0xffull << (g * 8);
@@ -1809,6 +1818,7 @@ __global__ __launch_bounds__(256) void k_emit(DevBatch B)
             B.o_search[c] = srch; B.o_pick[c] = pick;
             B.o_dr[c] = -1; B.o_dv[c] = -1; B.o_gl[c] = -1;
             B.o_supoff[c] = so;
+            B.o_ghdr[c] = ghdr;
         }
         // supports: group g copies the lists of its own slots, 8 lanes at a time
 #pragma unroll
@@ -2003,18 +2013,32 @@ __device__ __forceinline__ int gl_index_dev(i64 c0, i64 c1)
     return (int)(c0 * 101 + c1);
 }
 
+// what one call needs before it touches the reads table; loaded one call ahead (the per-call work is a chain of
+// dependent round trips, this takes the first ones off it)
+struct GtHead { int c; int4 h; i64 s0, s1, search, b1, b2; };
+__device__ __forceinline__ void gt_load_head(const DevBatch& B, int second, int q, GtHead& H)
+{
+    const int c = second ? B.gt_over[q] : q;
+    H.c = c; H.h = B.o_ghdr[c]; H.s0 = B.o_supoff[c]; H.s1 = B.o_supoff[c + 1];
+    H.search = B.o_search[c]; H.b1 = B.o_bp1[c]; H.b2 = B.o_bp2[c];
+}
+
 template <int HASH, int WPB> __global__ __launch_bounds__(64 * WPB) void k_genotype(DevBatch B, int second)
 {
     __shared__ int tabs[WPB][HASH];
     int* tab = tabs[threadIdx.x >> 6];
     const int n = second ? B.cnt->n_gt_over : B.cnt->n_calls;
     const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * (64 * WPB) + threadIdx.x) >> 6), nwaves = (gridDim.x * (64 * WPB)) >> 6;
-    for (int q = wave; q < n; q += nwaves) {
-        const int c = second ? B.gt_over[q] : q;
-        const csv_segment& sg = B.seg[B.o_seg[c]];
-        if (!sg.genotype || sg.svtype == CSV_TRA) continue;       // TRA: k_genotype_tra
+    GtHead cur, nxt;
+    if (wave < n) gt_load_head(B, second, wave, cur);
+    for (int q = wave; q < n; q += nwaves, cur = nxt) {
+        nxt = cur;
+        if (q + nwaves < n) gt_load_head(B, second, q + nwaves, nxt);
+        const int c = cur.c, svtype = cur.h.y & 0xff, chrom = cur.h.x;
+        if (!(cur.h.y & 0x100) || svtype == CSV_TRA) continue;    // TRA: k_genotype_tra
+        const i64 gt_bias = ((i64)cur.h.w << 32) | (unsigned)cur.h.z;
         for (int i = lane_id(); i < HASH; i += 64) tab[i] = -1;
-        const i64 s0 = B.o_supoff[c], ns = B.o_supoff[c + 1] - s0;
+        const i64 s0 = cur.s0, ns = cur.s1 - s0;
         int filled = 0;
         bool overflow = false;
         for (i64 base = 0; base < ns; base += 64) {
@@ -2024,17 +2048,17 @@ template <int HASH, int WPB> __global__ __launch_bounds__(64 * WPB) void k_genot
             if (i < ns) ins = hash_insert<HASH>(tab, B.o_suprid[s0 + i]);
             filled += __popcll(__ballot(ins));
         }
-        const i64 r0 = B.reads_off[sg.chrom], r1 = B.reads_off[sg.chrom + 1];
+        const i64 r0 = B.reads_off[chrom], r1 = B.reads_off[chrom + 1];
         int dr = 0;
         if (!overflow) {
-            if (sg.svtype == CSV_DEL || sg.svtype == CSV_INS) {
-                const i64 p = B.o_search[c], g = sg.gt_bias;                    // INDEL:450-451
+            if (svtype == CSV_DEL || svtype == CSV_INS) {
+                const i64 p = cur.search, g = gt_bias;                          // INDEL:450-451
                 i64 L = p - g; if (L < 0) L = 0;
                 dr = cover_window<HASH>(B, tab, r0, r1, 2 * L, 2 * (p + g), filled, overflow);
             } else {
-                i64 nb = sg.gt_bias;
-                const i64 b1 = B.o_bp1[c], b2 = B.o_bp2[c];
-                if (sg.svtype == CSV_DUP && b2 - b1 < nb) nb = b2 - b1;         // DUP:147
+                i64 nb = gt_bias;
+                const i64 b1 = cur.b1, b2 = cur.b2;
+                if (svtype == CSV_DUP && b2 - b1 < nb) nb = b2 - b1;            // DUP:147
                 i64 L2 = 2 * b1 - nb; if (L2 < 0) L2 = 0;                       // DUP:148-151, INV:219-221
                 dr = cover_window<HASH>(B, tab, r0, r1, L2, 2 * b1 + nb, filled, overflow);
                 L2 = 2 * b2 - nb; if (L2 < 0) L2 = 0;
