@@ -332,7 +332,6 @@ __device__ __forceinline__ i64 block_prefix_of64(const i64* p, int n, i64* sh)
 // tile are the pairs (S[i], S[i + 1]) and one thread gates one cluster - a handful of integer instructions per
 // cluster instead of lane-mask arithmetic per row (a first version of this fusion did the latter and lost to
 // separate select kernels: DESIGN.md section 6).  No cluster-start / cluster-segment arrays in HBM.
-constexpr int CL_CAP = CH_TILE + 2;
 
 struct TileSeg { int uni, k, rc, drop, type; };                  // workgroup-uniform: the tile lies in one segment
 
@@ -350,37 +349,44 @@ __device__ __forceinline__ int close_gate(const DevBatch& B, const int4 g, int s
     if (endz || m < g.x || g.y) return 0;
     return 1 | ((m > 64) ? 2 : 0) | ((m <= B.tiny_max && g.z <= CSV_INS) ? 4 : 0);
 }
-constexpr int CL_UNROLL = 4;                         // cluster steps whose loads are issued together
 
-// rows -> flags, the tile's starts into S[1 ..], segment summary; returns the number of starts of the tile.
-// s_cnt / s_ku: per-wavefront scratch in LDS.  All 256 threads of wavefronts 0-3 call this together.
-__device__ __forceinline__ int tile_starts(const DevBatch& B, i64 base, int wv, u64 (&masks)[CH_ITEMS], int* S, int* SK, int* s_cnt, int* s_ku, TileSeg& ts)
+// rows -> flags; the wavefront's cluster starts (bit 31: previous signature is (0,0)) and their segments go to its OWN
+// region of the LDS lists, so nothing here waits for another wavefront.  Returns the wavefront's number of starts.
+constexpr int CL_REG = WAVE * CH_ITEMS + 2;          // entries per wavefront region (512 starts + the sentinel)
+__device__ __forceinline__ int wave_starts(const DevBatch& B, i64 base, u64 (&masks)[CH_ITEMS], int* SR, int* SKR, int& ku)
 {
     int zprev[CH_ITEMS], ksg[CH_ITEMS];
-    const int ku = chain_rows(B, base, masks, zprev, ksg);
-    int cnt = 0;
-#pragma unroll
-    for (int r = 0; r < CH_ITEMS; r++) cnt += __popcll(masks[r]);
-    if (lane_id() == 0) { s_cnt[wv] = cnt; s_ku[wv] = (base < B.W) ? ku : -2; }     // -2: wavefront beyond the end
-    __syncthreads();
-    int off = 1;
-    for (int q = 0; q < wv; q++) off += s_cnt[q];
+    ku = chain_rows(B, base, masks, zprev, ksg);
+    if (base >= B.W) ku = -2;                          // wavefront beyond the end
+    int off = 0;
 #pragma unroll
     for (int r = 0; r < CH_ITEMS; r++) {
         const u64 m = masks[r];
         if ((m >> lane_id()) & 1) {
             const int idx = off + __popcll(m & lanemask_lt());
-            S[idx] = (int)(base + r * WAVE + lane_id()) | (zprev[r] << 31);
-            SK[idx] = ksg[r];
+            SR[idx] = (int)(base + r * WAVE + lane_id()) | (zprev[r] << 31);
+            SKR[idx] = ksg[r];
         }
         off += __popcll(m);
     }
-    int k0 = s_ku[0];
+    return off;
+}
+// after the workgroup barrier: is the tile inside one segment?  (s_ku: per-wavefront segment or -1 / -2)
+__device__ __forceinline__ void tile_seg(const DevBatch& B, const int* s_ku, TileSeg& ts)
+{
+    const int k0 = s_ku[0];
     bool uni = k0 >= 0;
     for (int q = 1; q < 4; q++) uni = uni && (s_ku[q] == k0 || s_ku[q] == -2);
     ts.uni = uni ? 1 : 0; ts.k = 0; ts.rc = 0; ts.drop = 0; ts.type = 0;
     if (uni) { const int4 g = B.seg_gate[k0]; ts.k = k0; ts.rc = g.x; ts.drop = g.y; ts.type = g.z; }
-    return s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+}
+// start (and segment) of the cluster that is still open where wavefront wv's span begins: the last entry of the
+// nearest earlier non-empty region, else the tile's look-back result
+__device__ __forceinline__ int2 open_before(const int (*SR)[CL_REG], const int (*SKR)[CL_REG], const int* s_cnt, int wv, int2 tile_prev)
+{
+    for (int q = wv - 1; q >= 0; q--)
+        if (s_cnt[q] > 0) return make_int2(SR[q][s_cnt[q] - 1], SKR[q][s_cnt[q] - 1]);
+    return tile_prev;
 }
 
 // flags of the 64 signatures [cb, cb + 64), cb >= 0 (used to look backwards from a tile).  Same shape as
@@ -419,15 +425,14 @@ __global__ __launch_bounds__(320) void k_chain_count(DevBatch B)
 {
     // first kernel of a run: nothing in this kernel reads the counters, every later kernel is stream-ordered behind it
     if (blockIdx.x == 0 && threadIdx.x < (int)(sizeof(DevCounters) / 4)) ((int*)B.cnt)[threadIdx.x] = 0;
-    __shared__ int S[CL_CAP], SK[CL_CAP];                 // starts of the tile (bit 31: previous signature is (0,0)) and their segments
-    __shared__ int s_cnt[4], s_ku[4], s_t[4];
+    __shared__ int SR[4][CL_REG], SKR[4][CL_REG];         // per wavefront: its cluster starts and their segments
+    __shared__ int s_cnt[4], s_ku[4], s_t[4], s_prev[2];
     __shared__ i64 s_v[4];
     const int wv = threadIdx.x >> 6;
     const i64 tile0 = (i64)blockIdx.x * CH_TILE;
     const bool last_tile = blockIdx.x == gridDim.x - 1;
     u64 masks[CH_ITEMS];
-    TileSeg ts;
-    int n = 0;
+    int cnt = 0;
     if (wv == 4) {                                         // the look-back wavefront
         int p = -1, kp = 0;
         for (i64 hiw = tile0; hiw > 0 && p < 0;) {
@@ -438,30 +443,32 @@ __global__ __launch_bounds__(320) void k_chain_count(DevBatch B)
             if (f) { const int l = 63 - __clzll((long long)f); p = (int)cb + l; kp = __builtin_amdgcn_readlane(kseg, l); }
             hiw = cb;
         }
-        if (lane_id() == 0) { S[0] = p; SK[0] = kp; B.tile_prev[blockIdx.x] = make_int2(p, kp); }
-        __syncthreads();                                   // (the barrier inside tile_starts)
+        if (lane_id() == 0) { s_prev[0] = p; s_prev[1] = kp; B.tile_prev[blockIdx.x] = make_int2(p, kp); }
     } else {
-        n = tile_starts(B, tile0 + wv * (WAVE * CH_ITEMS), wv, masks, S, SK, s_cnt, s_ku, ts);
-        if (last_tile && threadIdx.x == 0) S[1 + n] = (int)B.W | ((B.a[B.W - 1] == 0 && B.b[B.W - 1] == 0) ? (1 << 31) : 0);
+        int ku;
+        cnt = wave_starts(B, tile0 + wv * (WAVE * CH_ITEMS), masks, SR[wv], SKR[wv], ku);
+        if (lane_id() == 0) {
+            s_cnt[wv] = cnt; s_ku[wv] = ku;
+            // the sentinel w = W ends the last cluster: one more "start" in the last wavefront's region
+            if (last_tile && wv == 3) SR[3][cnt] = (int)B.W | ((B.a[B.W - 1] == 0 && B.b[B.W - 1] == 0) ? (1 << 31) : 0);
+        }
     }
     __syncthreads();
     if (wv < 4) {
-        const int nc = n + (last_tile ? 1 : 0);            // clusters that end in this tile: (S[i], S[i + 1]), i < nc
+        TileSeg ts;
+        tile_seg(B, s_ku, ts);
+        const int2 ob = open_before(SR, SKR, s_cnt, wv, make_int2(s_prev[0], s_prev[1]));
+        const int nc = cnt + ((last_tile && wv == 3) ? 1 : 0);   // clusters that end at this wavefront's starts
         int n_sel = 0, n_big = 0, n_tiny = 0;               // wave-uniform counts: ballots + scalar popcounts, no VALU sums
-        for (int i0 = 0; i0 < nc; i0 += 256 * CL_UNROLL) {
-            int s0[CL_UNROLL], e1[CL_UNROLL];
-            int4 g[CL_UNROLL];
-#pragma unroll
-            for (int u = 0; u < CL_UNROLL; u++) {
-                const int i = i0 + u * 256 + threadIdx.x;
-                s0[u] = -1; e1[u] = 0; g[u] = make_int4(0, 0, 0, 0);
-                if (i < nc) { s0[u] = S[i]; e1[u] = S[i + 1]; g[u] = gate_scalars(B, ts, SK[i]); }
+        for (int i0 = 0; i0 < nc; i0 += 64) {
+            const int i = i0 + lane_id();
+            int fl = 0;
+            if (i < nc) {
+                const int e1 = SR[wv][i];
+                const int s0 = i ? SR[wv][i - 1] : ob.x, k = i ? SKR[wv][i - 1] : ob.y;
+                if (s0 != -1) fl = close_gate(B, gate_scalars(B, ts, k), s0 & 0x7fffffff, e1 & 0x7fffffff, e1 < 0);
             }
-#pragma unroll
-            for (int u = 0; u < CL_UNROLL; u++) {
-                const int fl = (s0[u] != -1) ? close_gate(B, g[u], s0[u] & 0x7fffffff, e1[u] & 0x7fffffff, e1[u] < 0) : 0;
-                n_sel += __popcll(__ballot(fl & 1)); n_big += __popcll(__ballot(fl & 2)); n_tiny += __popcll(__ballot(fl & 4));
-            }
+            n_sel += __popcll(__ballot(fl & 1)); n_big += __popcll(__ballot(fl & 2)); n_tiny += __popcll(__ballot(fl & 4));
         }
         if (lane_id() == 0) { s_v[wv] = (i64)n_sel | ((i64)n_big << 32); s_t[wv] = n_tiny; }
     }
@@ -473,30 +480,36 @@ __global__ __launch_bounds__(320) void k_chain_count(DevBatch B)
     }
 }
 
+constexpr int CL_STEPS = CH_ITEMS + 1;              // 64-cluster steps a wavefront can need (512 starts + the sentinel)
 __global__ __launch_bounds__(256) void k_chain_apply(DevBatch B)
 {
-    __shared__ int S[CL_CAP], SK[CL_CAP];
-    __shared__ int s_cnt[4], s_ku[4], s_t[2][4];
-    __shared__ i64 s_v[2][4], sh[12];
+    __shared__ int SR[4][CL_REG], SKR[4][CL_REG];
+    __shared__ int s_cnt[4], s_ku[4], s_t[4];
+    __shared__ i64 s_v[4], sh[12];
     const int wv = threadIdx.x >> 6;
     const i64 base = (i64)blockIdx.x * CH_TILE + wv * (WAVE * CH_ITEMS);
     const bool last_tile = blockIdx.x == gridDim.x - 1;
     u64 masks[CH_ITEMS];
-    TileSeg ts;
     // the three exclusive prefixes of this workgroup (cluster starts, work items | workgroup tier, tiny items):
-    // sums over all earlier workgroups, tiny and L2 resident; one pair of barriers for the three
+    // sums over all earlier workgroups, tiny and L2 resident
     i64 p0 = 0, p1 = 0, p2 = 0;
     for (int i = threadIdx.x; i < (int)blockIdx.x; i += 256) { p0 += B.partial[i]; p1 += B.partial64[i]; p2 += B.partial_t[i]; }
     p0 = wave_sum_i64(p0); p1 = wave_sum_i64(p1); p2 = wave_sum_i64(p2);
     if (lane_id() == 0) { sh[wv] = p0; sh[4 + wv] = p1; sh[8 + wv] = p2; }
-    if (threadIdx.x == 0) { const int2 tp = B.tile_prev[blockIdx.x]; S[0] = tp.x; SK[0] = tp.y; }
-    const int n = tile_starts(B, base, wv, masks, S, SK, s_cnt, s_ku, ts);            // (barrier inside: sh / S[0] are visible after it)
+    int ku;
+    const int cnt = wave_starts(B, base, masks, SR[wv], SKR[wv], ku);
+    if (lane_id() == 0) {
+        s_cnt[wv] = cnt; s_ku[wv] = ku;
+        if (last_tile && wv == 3) SR[3][cnt] = (int)B.W | ((B.a[B.W - 1] == 0 && B.b[B.W - 1] == 0) ? (1 << 31) : 0);
+    }
+    __syncthreads();                                        // ---- barrier 1: every region, count and prefix partial is visible
     int run = (int)(sh[0] + sh[1] + sh[2] + sh[3]);
     i64 runs = sh[4] + sh[5] + sh[6] + sh[7];
     int run_t = (int)(sh[8] + sh[9] + sh[10] + sh[11]);
-    const int cid0 = run;                                   // id of the first cluster that STARTS in this tile
-    if (last_tile && threadIdx.x == 0) S[1 + n] = (int)B.W | ((B.a[B.W - 1] == 0 && B.b[B.W - 1] == 0) ? (1 << 31) : 0);
+    const int n = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    const int cid_tile = run;                               // id of the first cluster that STARTS in this tile
     for (int q = 0; q < wv; q++) run += s_cnt[q];
+    const int cid_wave = run;                               // ... in this wavefront's span
 #pragma unroll
     for (int r = 0; r < CH_ITEMS; r++) {
         const i64 w = base + r * WAVE + lane_id();
@@ -504,45 +517,51 @@ __global__ __launch_bounds__(256) void k_chain_apply(DevBatch B)
         if (w < B.W) { B.cluster_id[w] = run + __popcll(m & (lanemask_lt() | (1ull << lane_id()))) - 1; B.allele_id[w] = -1; }
         run += __popcll(m);
     }
-    __syncthreads();                                        // S complete (sentinel included)
-    const int nc = n + (last_tile ? 1 : 0);
-    int jrun = (int)(runs & 0xffffffffll), jbrun = (int)(runs >> 32);
-    for (int i0 = 0, par = 0; i0 < nc; i0 += 256 * CL_UNROLL) {   // ordered compaction of the tile's work items, 256 clusters per step
-        int s0[CL_UNROLL], e1[CL_UNROLL], kk[CL_UNROLL];
-        int4 g[CL_UNROLL];
+    // gate of the clusters that end at this wavefront's starts; the 3 flag bits of the <= 9 steps of 64 clusters stay
+    // packed in one register, the records are re-read from LDS by the few lanes that write a work item
+    TileSeg ts;
+    tile_seg(B, s_ku, ts);
+    const int2 ob = open_before(SR, SKR, s_cnt, wv, B.tile_prev[blockIdx.x]);
+    const int nc = cnt + ((last_tile && wv == 3) ? 1 : 0);
+    int flags = 0;
+    int n_sel = 0, n_big = 0, n_tiny = 0;
 #pragma unroll
-        for (int u = 0; u < CL_UNROLL; u++) {
-            const int i = i0 + u * 256 + threadIdx.x;
-            s0[u] = -1; e1[u] = 0; kk[u] = 0; g[u] = make_int4(0, 0, 0, 0);
-            if (i < nc) { s0[u] = S[i]; e1[u] = S[i + 1]; kk[u] = SK[i]; g[u] = gate_scalars(B, ts, kk[u]); }
+    for (int st = 0; st < CL_STEPS; st++) {
+        if (st * 64 >= nc) break;                           // wave-uniform
+        const int i = st * 64 + lane_id();
+        int fl = 0;
+        if (i < nc) {
+            const int e1 = SR[wv][i];
+            const int s0 = i ? SR[wv][i - 1] : ob.x, k = i ? SKR[wv][i - 1] : ob.y;
+            if (s0 != -1) fl = close_gate(B, gate_scalars(B, ts, k), s0 & 0x7fffffff, e1 & 0x7fffffff, e1 < 0);
         }
-#pragma unroll
-        for (int u = 0; u < CL_UNROLL; u++) {
-            if (i0 + u * 256 >= nc) break;                    // workgroup-uniform
-            const int i = i0 + u * 256 + threadIdx.x;
-            const int fl = (s0[u] != -1) ? close_gate(B, g[u], s0[u] & 0x7fffffff, e1[u] & 0x7fffffff, e1[u] < 0) : 0;
-            const u64 m_sel = __ballot(fl & 1), m_big = __ballot(fl & 2), m_tiny = __ballot(fl & 4);
-            // (wave totals double-buffered by step parity: one barrier per step)
-            if (lane_id() == 0) { s_v[par][wv] = (i64)__popcll(m_sel) | ((i64)__popcll(m_big) << 32); s_t[par][wv] = __popcll(m_tiny); }
-            __syncthreads();
-            int bj = jrun, bb = jbrun, bt = run_t;          // counts before this wavefront's 64 clusters
-            for (int q = 0; q < wv; q++) { bj += (int)(s_v[par][q] & 0xffffffffll); bb += (int)(s_v[par][q] >> 32); bt += s_t[par][q]; }
-            if (fl & 1) {
-                const int j = bj + __popcll(m_sel & lanemask_lt()), jb = bb + __popcll(m_big & lanemask_lt()), jt = bt + __popcll(m_tiny & lanemask_lt());
-                const int ss = s0[u] & 0x7fffffff;
-                B.item_rec[j] = make_int4(cid0 + i - 1, kk[u], ss, (e1[u] & 0x7fffffff) - ss);
-                if (fl & 2) B.list_big[jb] = j;
-                else if (fl & 4) B.list_tiny[jt] = j;
-                else B.list_small[j - jb - jt] = j;
-            }
-            for (int q = 0; q < 4; q++) { jrun += (int)(s_v[par][q] & 0xffffffffll); jbrun += (int)(s_v[par][q] >> 32); run_t += s_t[par][q]; }
-            par ^= 1;
-        }
+        flags |= fl << (3 * st);
+        n_sel += __popcll(__ballot(fl & 1)); n_big += __popcll(__ballot(fl & 2)); n_tiny += __popcll(__ballot(fl & 4));
     }
-    runs = (i64)(unsigned)jrun | ((i64)jbrun << 32);
-    if (last_tile && threadIdx.x == 0) {
-        B.cnt->n_clusters = cid0 + n;
-        B.cnt->n_items = (int)(runs & 0xffffffffll); B.cnt->n_items_big = (int)(runs >> 32); B.cnt->n_items_tiny = run_t;
+    if (lane_id() == 0) { s_v[wv] = (i64)n_sel | ((i64)n_big << 32); s_t[wv] = n_tiny; }
+    __syncthreads();                                        // ---- barrier 2: per-wavefront work item counts
+    int bj = (int)(runs & 0xffffffffll), bb = (int)(runs >> 32), bt = run_t;
+    for (int q = 0; q < wv; q++) { bj += (int)(s_v[q] & 0xffffffffll); bb += (int)(s_v[q] >> 32); bt += s_t[q]; }
+#pragma unroll
+    for (int st = 0; st < CL_STEPS; st++) {
+        if (st * 64 >= nc) break;                           // wave-uniform
+        const int fl = (flags >> (3 * st)) & 7;
+        const u64 m_sel = __ballot(fl & 1), m_big = __ballot(fl & 2), m_tiny = __ballot(fl & 4);
+        if (fl & 1) {
+            const int j = bj + __popcll(m_sel & lanemask_lt()), jb = bb + __popcll(m_big & lanemask_lt()), jt = bt + __popcll(m_tiny & lanemask_lt());
+            const int i = st * 64 + lane_id();
+            const int e1 = SR[wv][i] & 0x7fffffff;
+            const int s0 = (i ? SR[wv][i - 1] : ob.x) & 0x7fffffff, k = i ? SKR[wv][i - 1] : ob.y;
+            B.item_rec[j] = make_int4(cid_wave + i - 1, k, s0, e1 - s0);
+            if (fl & 2) B.list_big[jb] = j;
+            else if (fl & 4) B.list_tiny[jt] = j;
+            else B.list_small[j - jb - jt] = j;
+        }
+        bj += __popcll(m_sel); bb += __popcll(m_big); bt += __popcll(m_tiny);
+    }
+    if (last_tile && threadIdx.x == 255) {                  // wavefront 3: its running counts now cover the whole batch
+        B.cnt->n_clusters = cid_tile + n;
+        B.cnt->n_items = bj; B.cnt->n_items_big = bb; B.cnt->n_items_tiny = bt;
     }
 }
 
