@@ -176,6 +176,19 @@ def test_full_size_partition_and_rerun_properties(ctx, cfg):
         return out
 
     whole = per_segment(tasks)
+    # consistency of the per-signature outputs with the call lists (whole-genome batch still resident)
+    full = ctx.download(per_sig=True).trimmed()
+    cid = full["cluster_id"]
+    live = cid >= 0
+    assert (np.diff(cid[live]) >= 0).all() and (np.diff(cid[live]) <= 1).all()         # dense, in file order
+    segs = st.host_batch(tasks, p).segments
+    indel_call = np.isin(full["call_seg"], np.flatnonzero(segs["svtype"] <= _abi.INS))
+    so, ss = full["support_off"], full["support_sig"]
+    call_of_support = np.repeat(np.arange(len(full["bp1"])), np.diff(so))
+    pick = indel_call[call_of_support]
+    assert np.array_equal(full["allele_id"][ss[pick]], call_of_support[pick])            # a supporting signature points back at its call
+    assert np.array_equal(np.diff(so)[indel_call], full["support"][indel_call])          # DEL/INS: support = length of the read list
+    assert np.array_equal(cid[ss], full["call_cluster"][call_of_support])               # ... and lies in the call's cluster
     half_a = [t for t in tasks if st.chroms.index(t[1]) % 2 == 0]
     half_b = [t for t in tasks if st.chroms.index(t[1]) % 2 == 1]
     parts = per_segment(half_a)
