@@ -106,6 +106,27 @@ def test_register_tiers_fallback_routes(ctx):
     assert len(got["bp1"]) > 350 and (got["bp2"] >= 2**26).any()
 
 
+@pytest.mark.parametrize("n", [2048, 4096, 4097, 6143, 64, 1])
+def test_chain_tile_edges(ctx, n):
+    # batches whose size sits on / next to the 2048-signature tile boundary of the chain kernels: the sentinel that
+    # ends the last cluster lands in a full last wavefront region, clusters straddle tiles, the last one is long
+    from cutesv_amd.columns import SigStore
+    rng = np.random.default_rng(n)
+    per = {t: [] for t in ("DEL", "INS", "DUP", "INV", "TRA")}
+    pos, i = 1000, 0
+    while i < n:
+        m = int(rng.choice([1, 2, 5, 12, 20, 40, 70, 300])) if n - i > 400 else n - i      # the tail is one cluster
+        m = min(m, n - i)
+        for j in range(m):
+            per["DEL"].append((pos + int(rng.integers(0, 30)), int(rng.integers(40, 60)), "q%06d" % (i + j), "DEL", "1"))
+        pos += 5000
+        i += m
+    st = SigStore.from_tuple_lists(per)
+    assert st.n_sig == n
+    got = _compare_soa(ctx, st, Params.ont(min_support=3))
+    assert got["n_clusters"] >= 1
+
+
 def test_genotype_cover_overflow_pass(ctx):
     # ~1000x coverage: support + cover of a call exceeds the 4 KB hash set, so the second (32 KB) pass runs
     st = synth.small_mixed(seed=78, n_sites=6, coverage=1000, n_noise=100, n_loci=20, contig_len=200_000, n_contigs=2)
