@@ -371,14 +371,17 @@ __device__ __forceinline__ int wave_starts(const DevBatch& B, i64 base, u64 (&ma
     }
     return off;
 }
-// after the workgroup barrier: is the tile inside one segment?  (s_ku: per-wavefront segment or -1 / -2)
-__device__ __forceinline__ void tile_seg(const DevBatch& B, const int* s_ku, TileSeg& ts)
+// after the workgroup barrier: is the tile inside one segment?  (s_ku: per-wavefront segment or -1 / -2; g_own: the
+// gate scalars of the caller's OWN segment, loaded before the barrier so that no global load follows it - when the
+// tile is uniform every wavefront that lies inside the batch has that same segment)
+__device__ __forceinline__ void tile_seg(const int* s_ku, int ku_own, const int4 g_own, TileSeg& ts)
 {
     const int k0 = s_ku[0];
     bool uni = k0 >= 0;
     for (int q = 1; q < 4; q++) uni = uni && (s_ku[q] == k0 || s_ku[q] == -2);
+    uni = uni && ku_own == k0;                         // (a wavefront beyond the end has nothing to gate anyway)
     ts.uni = uni ? 1 : 0; ts.k = 0; ts.rc = 0; ts.drop = 0; ts.type = 0;
-    if (uni) { const int4 g = B.seg_gate[k0]; ts.k = k0; ts.rc = g.x; ts.drop = g.y; ts.type = g.z; }
+    if (uni) { ts.k = k0; ts.rc = g_own.x; ts.drop = g_own.y; ts.type = g_own.z; }
 }
 // start (and segment) of the cluster that is still open where wavefront wv's span begins: the last entry of the
 // nearest earlier non-empty region, else the tile's look-back result
@@ -432,7 +435,8 @@ __global__ __launch_bounds__(320) void k_chain_count(DevBatch B)
     const i64 tile0 = (i64)blockIdx.x * CH_TILE;
     const bool last_tile = blockIdx.x == gridDim.x - 1;
     u64 masks[CH_ITEMS];
-    int cnt = 0;
+    int cnt = 0, ku = -1;
+    int4 g_own = make_int4(0, 0, 0, 0);
     if (wv == 4) {                                         // the look-back wavefront
         int p = -1, kp = 0;
         for (i64 hiw = tile0; hiw > 0 && p < 0;) {
@@ -445,8 +449,8 @@ __global__ __launch_bounds__(320) void k_chain_count(DevBatch B)
         }
         if (lane_id() == 0) { s_prev[0] = p; s_prev[1] = kp; B.tile_prev[blockIdx.x] = make_int2(p, kp); }
     } else {
-        int ku;
         cnt = wave_starts(B, tile0 + wv * (WAVE * CH_ITEMS), masks, SR[wv], SKR[wv], ku);
+        if (ku >= 0) g_own = B.seg_gate[ku];
         if (lane_id() == 0) {
             s_cnt[wv] = cnt; s_ku[wv] = ku;
             // the sentinel w = W ends the last cluster: one more "start" in the last wavefront's region
@@ -456,7 +460,7 @@ __global__ __launch_bounds__(320) void k_chain_count(DevBatch B)
     __syncthreads();
     if (wv < 4) {
         TileSeg ts;
-        tile_seg(B, s_ku, ts);
+        tile_seg(s_ku, ku, g_own, ts);
         const int2 ob = open_before(SR, SKR, s_cnt, wv, make_int2(s_prev[0], s_prev[1]));
         const int nc = cnt + ((last_tile && wv == 3) ? 1 : 0);   // clusters that end at this wavefront's starts
         int n_sel = 0, n_big = 0, n_tiny = 0;               // wave-uniform counts: ballots + scalar popcounts, no VALU sums
@@ -498,6 +502,9 @@ __global__ __launch_bounds__(256) void k_chain_apply(DevBatch B)
     if (lane_id() == 0) { sh[wv] = p0; sh[4 + wv] = p1; sh[8 + wv] = p2; }
     int ku;
     const int cnt = wave_starts(B, base, masks, SR[wv], SKR[wv], ku);
+    int4 g_own = make_int4(0, 0, 0, 0);
+    if (ku >= 0) g_own = B.seg_gate[ku];                    // (before the barrier: no global load on the path after it)
+    const int2 tile_prev = B.tile_prev[blockIdx.x];
     if (lane_id() == 0) {
         s_cnt[wv] = cnt; s_ku[wv] = ku;
         if (last_tile && wv == 3) SR[3][cnt] = (int)B.W | ((B.a[B.W - 1] == 0 && B.b[B.W - 1] == 0) ? (1 << 31) : 0);
@@ -520,8 +527,8 @@ __global__ __launch_bounds__(256) void k_chain_apply(DevBatch B)
     // gate of the clusters that end at this wavefront's starts; the 3 flag bits of the <= 9 steps of 64 clusters stay
     // packed in one register, the records are re-read from LDS by the few lanes that write a work item
     TileSeg ts;
-    tile_seg(B, s_ku, ts);
-    const int2 ob = open_before(SR, SKR, s_cnt, wv, B.tile_prev[blockIdx.x]);
+    tile_seg(s_ku, ku, g_own, ts);
+    const int2 ob = open_before(SR, SKR, s_cnt, wv, tile_prev);
     const int nc = cnt + ((last_tile && wv == 3) ? 1 : 0);
     int flags = 0;
     int n_sel = 0, n_big = 0, n_tiny = 0;
