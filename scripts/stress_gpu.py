@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Long randomized parity campaign on the GPU box (not part of the test suite):
-    python scripts/stress_gpu.py [n_iterations] [first_seed]
+    python scripts/stress_gpu.py [n_iterations] [first_seed] [big]
 random flags x random workload shapes (incl. TRA genotyping), every SoA field of the HIP path bit-exact against the
 oracle.  Prints the failing seeds, exits non-zero if there are any."""
 import os
@@ -19,6 +19,7 @@ from helpers import assert_soa_equal                      # noqa: E402
 
 n_it = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 50000
+BIG = len(sys.argv) > 3 and sys.argv[3] == "big"          # deep coverage / wide bias: the LDS and workgroup tiers
 ctx = engine.Context(0)
 bad = []
 skipped = 0
@@ -34,7 +35,7 @@ for it in range(n_it):
                max_cluster_bias_INV=int(rng.choice([10, 500, 5000])), max_cluster_bias_DUP=int(rng.choice([10, 500, 5000])),
                max_cluster_bias_TRA=int(rng.choice([5, 50, 2000])), diff_ratio_filtering_TRA=float(rng.choice([0.2, 0.6, 1.0])),
                remain_reads_ratio=float(rng.choice([0.3, 0.7, 1.0, 1.5])))
-    st = synth.small_mixed(seed=seed0 + it, n_sites=int(rng.integers(5, 80)), coverage=int(rng.choice([4, 9, 14, 20, 45, 90, 150])),
+    st = synth.small_mixed(seed=seed0 + it, n_sites=int(rng.integers(3, 12) if BIG else rng.integers(5, 80)), coverage=int(rng.choice([200, 400, 900]) if BIG else rng.choice([4, 9, 14, 20, 45, 90, 150])),
                            dup_frac=float(rng.choice([0.0, 0.1, 0.6])), n_noise=int(rng.integers(0, 6000)),
                            n_loci=int(rng.integers(0, 400)), contig_len=int(rng.choice([300_000, 2_000_000])),
                            pos_sigma=float(rng.choice([1.0, 12.0, 60.0])), len_sigma=float(rng.choice([0.003, 0.04, 0.2])),
