@@ -34,7 +34,7 @@ sys.path.insert(0, ROOT)
 from cutesv_amd import synth, engine, _abi, rows as rows_mod     # noqa: E402
 from cutesv_amd.columns import Params                            # noqa: E402
 
-HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); the copy ceiling is measured per run (~5.3 TB/s)
 
 
 def make_workload(name, scale, rank):
@@ -210,6 +210,14 @@ def main():
 
     out = None
     if rank == 0:
+        # measured device-to-device copy ceiling of this box (report the fraction of the vendor peak AND of
+        # the copy ceiling): 512 MiB hipMemcpy device to device, read + write bytes over the best of 10 runs
+        copy_gbs = None
+        try:
+            copy_gbs = ctx.copy_bandwidth(512 << 20, 10)
+        except Exception as e:           # noqa: BLE001  (optional leg)
+            print("copy ceiling not measured: %r" % (e,), file=sys.stderr)
+            copy_gbs = None
         kbytes, total_bytes, units = kernel_units(store, hb, res, st)
         per_kernel = {names[i]: round(float(acc[i]) * 1e3, 2) for i in range(_abi.N_STAGES) if names[i]}   # microseconds
         per_kernel["genotype_stage"] = round(sum(per_kernel.get(k, 0.0) for k in ("k_pmax_count", "k_pmax_apply", "k_genotype")), 2)
@@ -236,7 +244,8 @@ def main():
                        "genotype": bool(params.genotype), "sharding": "one genome per GPU, no collective"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes": kbytes[dom], "kernel_us": per_kernel[dom]},
+                         "algorithmic_bytes": kbytes[dom], "kernel_us": per_kernel[dom],
+                         "copy_ceiling": copy_gbs, "frac_of_copy_ceiling": (achieved / copy_gbs) if copy_gbs else None},
             "roofline_pipeline": {"algorithmic_bytes": total_bytes, "kernel_time_us": round(tot / a.steps * 1e3, 2),
                                   "achieved": total_bytes / (ms_per_step * 1e-3) / 1e9, "unit": "GB/s",
                                   "frac": total_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},

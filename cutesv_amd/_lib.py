@@ -13,6 +13,7 @@ _LIB = None
 # every symbol include/cutesv_hip.h declares: (name, restype, argtypes)
 SYMBOLS = [
     ("csv_abi_version", C.c_int, []),
+    ("csv_measure_copy_bandwidth", C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_double)]),
     ("csv_device_count", C.c_int, [C.POINTER(C.c_int)]),
     ("csv_ctx_create", C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     ("csv_ctx_destroy", None, [C.c_void_p]),

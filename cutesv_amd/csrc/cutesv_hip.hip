@@ -426,6 +426,33 @@ int csv_batch_run(csv_ctx* c, csv_run_stats* stats)
     return CSV_OK;
 }
 
+int csv_measure_copy_bandwidth(csv_ctx* c, int64_t bytes, int reps, double* gb_per_s)
+{
+    if (!c || !gb_per_s || bytes <= 0 || reps <= 0) return CSV_E_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    void *src = nullptr, *dst = nullptr;
+    if (hipMalloc(&src, (size_t)bytes) != hipSuccess || hipMalloc(&dst, (size_t)bytes) != hipSuccess) {
+        if (src) (void)hipFree(src);
+        return fail(c, CSV_E_NOMEM, "copy-bandwidth buffers (%lld bytes each)", (long long)bytes);
+    }
+    (void)hipMemsetAsync(src, 1, (size_t)bytes, c->stream);
+    float best = 1e30f;
+    hipError_t e = hipSuccess;
+    for (int r = 0; r < reps && e == hipSuccess; r++) {
+        e = hipEventRecord(c->ev[0], c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToDevice, c->stream);
+        if (e == hipSuccess) e = hipEventRecord(c->ev[1], c->stream);
+        if (e == hipSuccess) e = hipEventSynchronize(c->ev[1]);
+        float ms = 0;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, c->ev[0], c->ev[1]);
+        if (e == hipSuccess && ms < best) best = ms;
+    }
+    (void)hipFree(src); (void)hipFree(dst);
+    if (e != hipSuccess) return fail(c, CSV_E_HIP, "copy-bandwidth measurement: %s", hipGetErrorString(e));
+    *gb_per_s = 2.0 * (double)bytes / ((double)best * 1e-3) / 1e9;
+    return CSV_OK;
+}
+
 int csv_batch_validate(csv_ctx* c)
 {
     if (!c) return CSV_E_INVALID;

@@ -68,6 +68,12 @@ class Context:
     def sync(self):
         self._check(lib().csv_ctx_sync(self._h))
 
+    def copy_bandwidth(self, nbytes=512 << 20, reps=10):
+        """device-to-device copy ceiling of this GPU in GB/s (read + write bytes); a measurement aid for bench.py"""
+        out = C.c_double(0.0)
+        self._check(lib().csv_measure_copy_bandwidth(self._h, int(nbytes), int(reps), C.byref(out)))
+        return float(out.value)
+
     def download(self, per_sig=False, cap_calls=None, cap_support=None):
         n = self._batch.n_sig
         cap_calls = cap_calls or max(64, n // 16 + 16)

@@ -195,6 +195,10 @@ int csv_ctx_sync(csv_ctx* ctx);
  * removed, :958-969).  Returns CSV_E_UNSORTED otherwise.  One pass over the columns; not part of csv_batch_run. */
 int csv_batch_validate(csv_ctx* ctx);
 
+/* Measurement aid (bench.py's roofline object): device-to-device copy bandwidth of this GPU, read + write bytes
+ * over the best of `reps` hipMemcpyAsync calls of `bytes` bytes, in GB/s.  No counterpart in the reference. */
+int csv_measure_copy_bandwidth(csv_ctx* ctx, int64_t bytes, int reps, double* gb_per_s);
+
 /* cal_GL's domain after its special cases and rescale_read_counts (GT:25-37): returns the
  * table index the device writes into gl_idx for (DR, DV) = (c0, c1).  Host-side helper so
  * the Python shim and the tests share one definition with the kernels. */
