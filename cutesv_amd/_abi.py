@@ -8,7 +8,7 @@ import ctypes as C
 
 import numpy as np
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 DEL, INS, DUP, INV, TRA = 0, 1, 2, 3, 4
 SVTYPE_CODE = {"DEL": DEL, "INS": INS, "DUP": DUP, "INV": INV, "TRA": TRA}
 SVTYPE_NAME = {v: k for k, v in SVTYPE_CODE.items()}
@@ -16,8 +16,10 @@ SVTYPE_NAME = {v: k for k, v in SVTYPE_CODE.items()}
 OK, E_INVALID, E_CAPACITY, E_HIP, E_NOMEM, E_UNSORTED, E_STATE = range(7)
 ERR_NAME = {OK: "CSV_OK", E_INVALID: "CSV_E_INVALID", E_CAPACITY: "CSV_E_CAPACITY", E_HIP: "CSV_E_HIP",
             E_NOMEM: "CSV_E_NOMEM", E_UNSORTED: "CSV_E_UNSORTED", E_STATE: "CSV_E_STATE"}
-N_STAGES = 16
+N_STAGES = 24
 GL_TABLE_SIZE = 101 * 101 + 2
+IN_PER_SIG, IN_READS_SORTED = 1, 2            # csv_batch_in.flags
+SEG_KEY_RANGE = 1                             # csv_batch_out.seg_status bits
 
 # numpy dtype with exactly the C layout of `csv_segment` (all members naturally aligned)
 SEGMENT_DTYPE = np.dtype([
@@ -42,6 +44,7 @@ class BatchIn(C.Structure):
         ("n_reads", C.c_int64),
         ("r_start", C.c_void_p), ("r_end", C.c_void_p), ("r_primary", C.c_void_p), ("r_id", C.c_void_p),
         ("contig_len", C.c_void_p),
+        ("flags", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
@@ -52,7 +55,7 @@ _OUT_ARRAYS = [  # (name, dtype, which capacity)
     ("search_pos", np.int64, "calls"), ("seq_pick", np.int64, "calls"),
     ("dr", np.int32, "calls"), ("dv", np.int32, "calls"), ("gl_idx", np.int32, "calls"),
     ("support_off", np.int64, "calls+1"), ("support_sig", np.int64, "support"),
-    ("cluster_id", np.int32, "sig"), ("allele_id", np.int32, "sig"),
+    ("cluster_id", np.int32, "sig"), ("allele_id", np.int32, "sig"), ("seg_status", np.int32, "seg"),
 ]
 
 
@@ -80,7 +83,7 @@ class HostBatch:
     """Host-side buffers of one csv_batch_in.  Keeps the numpy arrays alive for the C call."""
 
     def __init__(self, segments, a, b, read_id, aux, n_chrom=0, reads_off=None,
-                 r_start=None, r_end=None, r_primary=None, r_id=None, contig_len=None):
+                 r_start=None, r_end=None, r_primary=None, r_id=None, contig_len=None, per_sig=False, reads_sorted=False):
         self.segments = np.ascontiguousarray(segments, dtype=SEGMENT_DTYPE)
         self.a = _col(a, np.int64)
         self.b = _col(b, np.int64)
@@ -109,7 +112,8 @@ class HostBatch:
             reads_off=_ptr(self.reads_off),
             n_reads=0 if self.r_start is None else self.r_start.shape[0],
             r_start=_ptr(self.r_start), r_end=_ptr(self.r_end), r_primary=_ptr(self.r_primary), r_id=_ptr(self.r_id),
-            contig_len=_ptr(self.contig_len))
+            contig_len=_ptr(self.contig_len),
+            flags=(IN_PER_SIG if per_sig else 0) | (IN_READS_SORTED if reads_sorted else 0))
 
     @property
     def n_sig(self):
@@ -119,7 +123,7 @@ class HostBatch:
 class HostResult:
     """Caller-allocated csv_batch_out plus numpy views on it."""
 
-    def __init__(self, n_sig, cap_calls, cap_support, per_sig=False):
+    def __init__(self, n_sig, cap_calls, cap_support, per_sig=False, n_seg=0):
         self.cap_calls = int(cap_calls)
         self.cap_support = int(cap_support)
         self.arrays = {}
@@ -127,6 +131,8 @@ class HostResult:
         for name, dt, cap in _OUT_ARRAYS:
             if cap == "sig":
                 arr = np.empty(n_sig, dtype=dt) if per_sig else None
+            elif cap == "seg":
+                arr = np.zeros(max(1, n_seg), dtype=dt)
             elif cap == "calls":
                 arr = np.empty(self.cap_calls, dtype=dt)
             elif cap == "calls+1":

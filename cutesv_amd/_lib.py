@@ -13,7 +13,9 @@ _LIB = None
 # every symbol include/cutesv_hip.h declares: (name, restype, argtypes)
 SYMBOLS = [
     ("csv_abi_version", C.c_int, []),
+    ("csv_struct_size", C.c_int, [C.c_int]),
     ("csv_measure_copy_bandwidth", C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_double)]),
+    ("csv_cache_flush", C.c_int, [C.c_void_p, C.c_int64]),
     ("csv_device_count", C.c_int, [C.POINTER(C.c_int)]),
     ("csv_ctx_create", C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     ("csv_ctx_destroy", None, [C.c_void_p]),
@@ -26,6 +28,11 @@ SYMBOLS = [
     ("csv_ctx_sync", C.c_int, [C.c_void_p]),
     ("csv_batch_validate", C.c_int, [C.c_void_p]),
     ("csv_gl_index", C.c_int32, [C.c_int64, C.c_int64]),
+    ("csv_host_alloc", C.c_int, [C.c_int64, C.POINTER(C.c_void_p)]),
+    ("csv_host_free", None, [C.c_void_p]),
+    ("csv_host_register", C.c_int, [C.c_void_p, C.c_int64]),
+    ("csv_host_unregister", C.c_int, [C.c_void_p]),
+    ("csv_rows_emit", C.c_int, None),          # prototype set in cutesv_amd/rows.py (needs its struct)
     ("csv_rebuild_signatures", C.c_int, None),  # prototype set in cutesv_amd/rebuild.py
     ("csv_vcf_emit", C.c_int, None),           # prototype set in cutesv_amd/vcf.py (needs its struct)
 ]

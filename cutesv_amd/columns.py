@@ -133,6 +133,58 @@ class SigStore:
             return ("ACGT" * (n // 4 + 1))[:n]
         return self.ins_seq[int(sig)]
 
+    # ------------------------------------------------------------------ page-locked columns
+    def pinned(self):
+        """A store whose columns live in page-locked host memory (csv_host_alloc): csv_cluster_batch then moves them to
+        the GPU by DMA straight from these pages (PCIe rate) instead of through the runtime's staging copies.  The
+        natural home of the columns in a worker process: load the flat `.cols` files into it once."""
+        import dataclasses
+        from . import engine
+        cols = {}
+        for k in ("a", "b", "read_id", "aux", "reads_off", "r_start", "r_end", "r_primary", "r_id", "contig_len"):
+            v = getattr(self, k)
+            cols[k] = None if v is None else engine.pinned_copy(v)
+        return dataclasses.replace(self, **cols)
+
+    # ------------------------------------------------------------------ string tables for the native row / VCF emitters
+    def names_blob(self):
+        """read names as csv_rows_emit takes them: (blob, offsets, n_names, prefix, width); an explicit table, or
+        (None, None, 0, prefix, width) for the synthetic '<prefix>%0<width>d' scheme.  Cached on the store."""
+        nb = getattr(self, "_names_blob", None)
+        if nb is None:
+            if self.names.names is not None:
+                enc = [x.encode() for x in self.names.names]
+                off = np.zeros(len(enc) + 1, np.int64)
+                if enc:
+                    np.cumsum([len(x) for x in enc], out=off[1:])
+                nb = (b"".join(enc), off, len(enc), None, 0)
+            else:
+                import re
+                m = re.fullmatch(r"([^%]*)%0(\d+)d", self.names.fmt)
+                if not m:
+                    raise ValueError("synthetic read-name format %r is not '<prefix>%%0<width>d'" % self.names.fmt)
+                nb = (None, None, 0, m.group(1).encode(), int(m.group(2)))
+            self._names_blob = nb
+        return nb
+
+    def ins_blob(self):
+        """inserted sequences by global signature index as (blob, offsets[n_sig + 1]); (None, None) when the store is
+        synthetic ('ACGT' repeated to the aux length).  Cached on the store."""
+        ib = getattr(self, "_ins_blob", None)
+        if ib is None:
+            if self.ins_seq is None:
+                ib = (None, None)
+            else:
+                lens = np.zeros(self.n_sig, np.int64)
+                keys = sorted(self.ins_seq)
+                if keys:
+                    lens[np.array(keys, np.int64)] = [len(self.ins_seq[k]) for k in keys]
+                off = np.zeros(self.n_sig + 1, np.int64)
+                np.cumsum(lens, out=off[1:])
+                ib = ("".join(self.ins_seq[k] for k in keys).encode(), off)
+            self._ins_blob = ib
+        return ib
+
     # ------------------------------------------------------------------ segments / batches
     def segment(self, svtype, chrom, p: Params):
         """csv_segment record for one reference task, scalars as main script :1117-1188 passes them."""

@@ -8,6 +8,7 @@
 #include <string.h>
 
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "kernels.hip.h"
@@ -17,43 +18,73 @@ using namespace csv;
 
 namespace {
 
-struct Buf {                      // grow-only device buffer
+struct Buf {                      // a slice of an arena (or, for the few stand-alone buffers, its own allocation)
     void*  p = nullptr;
     size_t cap = 0;
 };
 
-// one timing slot per launch, in launch order
-const char* kStageName[CSV_N_STAGES] = {"init", "k_chain_count", "k_chain_apply",
-                                        "k_refine_indel_wave", "k_refine_wave", "k_refine_mid", "k_refine_block", "k_items_scan",
-                                        "k_emit", "k_pmax_count", "k_pmax_apply", "k_genotype", "k_genotype_tra", "", "", ""};
+// One device allocation for everything a batch needs: the buffers are planned (sizes -> offsets), the arena grows
+// only when the plan does not fit, and every Buf becomes a pointer into it.  (The first version reserved ~90 buffers
+// with one hipMalloc each: 2.7 ms on the first upload, and a larger batch re-allocated them one by one.)
+struct Arena {
+    char*  base = nullptr;
+    size_t cap = 0;
+};
+struct Plan {
+    std::vector<std::pair<Buf*, size_t>> items;
+    size_t total = 0;
+    void add(Buf& b, size_t bytes)
+    {
+        items.emplace_back(&b, total);
+        b.cap = bytes;
+        total += (bytes + 255) & ~(size_t)255;
+    }
+};
+
+// one timing slot per launch (group), in launch order
+const char* kStageName[CSV_N_STAGES] = {"init", "k_chain_count", "k_chain_apply", "k_refine_indel_wave", "k_refine_wave", "k_refine_mid",
+                                        "k_refine_block", "k_items_scan", "k_emit", "k_reads_order", "k_pmax_count", "k_pmax_apply",
+                                        "k_genotype", "k_genotype_tra", "", "", "", "", "", "", "", "", "", ""};
+constexpr int N_COPY_STREAMS = 4;
+constexpr int RO_CAP = 4096;                 // sorted runs the reads_order stage plans (k_reads_plan packs the rank in 12 bits)
 
 }  // namespace
 
 struct csv_ctx {
     int         device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t side[3] = {};         // side streams: [0] mid + workgroup tier, [1] DUP/INV/TRA wavefront tier, [2] reads prefix max
-    hipEvent_t  ev_init = nullptr, ev_sel = nullptr, ev_aux[3] = {};
+    hipStream_t side[3] = {};         // side streams: [0] mid + workgroup tier, [1] DUP/INV/TRA wavefront tier, [2] reads order + prefix max
+    hipStream_t copy[N_COPY_STREAMS] = {};    // host -> device column copies (one DMA engine each)
+    hipEvent_t  ev_init = nullptr, ev_sel = nullptr, ev_aux[3] = {}, ev_copy[N_COPY_STREAMS] = {}, ev_reads = nullptr;
     std::string err;
     hipEvent_t  ev[CSV_N_STAGES + 2] = {};
-    // device buffers
+    Arena       arena, arena_rb;
+    // batch buffers (slices of `arena`)
     Buf seg, woff, seg_drop, a, b, rid, aux;
-    Buf cluster_id, partial, partial64, item_rec, list_small, list_big, list_tiny, tile_prev, partial_t, seg_gate;
+    Buf cluster_id, partial, partial64, item_rec, list_small, list_big, list_tiny, tile_prev, partial_t, seg_gate, ch_masks, ch_ku, seg_err;
     Buf item_nslots, item_cnt, item_base, sup_tmp;
     Buf t_bp1, t_bp2, t_search, t_pick, t_support, t_cipos, t_cilen, t_supoff, t_valid;
     Buf sc_k, sc_x, sc_v1, sc_v2, sc_v3, sc_v4, sc_v5;
-    Buf o_seg, o_cluster, o_aux, o_bp1, o_bp2, o_support, o_cipos, o_cilen, o_search, o_pick, o_dr, o_dv, o_gl, o_ghdr;
-    Buf o_supoff, o_supsig, o_suprid, allele_id;
-    Buf reads_off, r_start, r_end, r_primary, r_id, r_pmax, pm_partial, gt_over, contig_len;
+    Buf o_rec, o_supsig, o_suprid, allele_id;
+    Buf reads_off, r_start, r_end, r_primary, r_id, s_start, s_end, s_primary, s_id, r_pmax, pm_partial, gt_over, gt_huge, gt_pool, contig_len;
+    Buf ro_runs, ro_table;
+    // stand-alone
     Buf sqrt_tab, cnt;
+    Buf gs_chrom, gs_perm0, gs_perm1, gs_hist, gs_tot;          // general reads sort (fallback), allocated on first use
+    Buf flush;                                                   // csv_cache_flush scratch
+    // rebuild step (slices of `arena_rb`)
     Buf rb_seg, rb_a, rb_b, rb_rid, rb_aux, rb_auxk, rb_major, rb_perm0, rb_perm1, rb_hist, rb_tot, rb_partial;
     Buf rb_oseg, rb_oa, rb_ob, rb_orid, rb_oaux, rb_osrc;
+    // page-locked host staging: small tables on the way in, counters + call records + support lists on the way out
+    char*  h_pin = nullptr;
+    size_t h_pin_cap = 0;
     // host copies
     std::vector<csv_segment> h_seg;
     std::vector<i64>         h_woff;
-    std::vector<int>         h_seg_gate;
-    bool     uploaded = false, ran = false, any_genotype = false, any_pair = false, any_tra_gt = false, big_lds_set = false;
-    i64      n_sig_host = 0;
+    bool     uploaded = false, ran = false, any_genotype = false, any_pair = false, any_tra_gt = false, lds_set = false;
+    bool     reads_general = false;            // this batch's reads table needs the general sort (found out by a first run)
+    int      n_copy = 1;
+    i64      n_sig_host = 0, n_reads = 0;
     DevBatch B;
     DevCounters h_cnt;
 };
@@ -77,7 +108,7 @@ int fail(csv_ctx* c, int code, const char* fmt, ...)
         if (e_ != hipSuccess) return fail((c), CSV_E_HIP, "%s failed: %s", #call, hipGetErrorString(e_));   \
     } while (0)
 
-int reserve(csv_ctx* c, Buf& b, size_t bytes)
+int reserve(csv_ctx* c, Buf& b, size_t bytes)            // stand-alone grow-only buffer
 {
     if (bytes <= b.cap) return CSV_OK;
     if (b.p) { HIP_TRY(c, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
@@ -88,17 +119,65 @@ int reserve(csv_ctx* c, Buf& b, size_t bytes)
     return CSV_OK;
 }
 
-#define RES(buf, bytes) do { int rc_ = reserve(c, c->buf, (size_t)(bytes)); if (rc_) return rc_; } while (0)
+int commit(csv_ctx* c, Arena& A, const Plan& P)
+{
+    if (P.total > A.cap) {
+        if (A.base) { HIP_TRY(c, hipFree(A.base)); A.base = nullptr; A.cap = 0; }
+        const size_t want = P.total + P.total / 8 + 4096;
+        void* p = nullptr;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) return fail(c, CSV_E_NOMEM, "hipMalloc(%zu) for the batch arena failed: %s", want, hipGetErrorString(e));
+        A.base = (char*)p; A.cap = want;
+    }
+    for (const auto& it : P.items) it.first->p = A.base + it.second;
+    return CSV_OK;
+}
+
+int pin_reserve(csv_ctx* c, size_t bytes)
+{
+    if (bytes <= c->h_pin_cap) return CSV_OK;
+    if (c->h_pin) { HIP_TRY(c, hipHostFree(c->h_pin)); c->h_pin = nullptr; c->h_pin_cap = 0; }
+    const size_t want = bytes + bytes / 4 + 4096;
+    void* p = nullptr;
+    hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+    if (e != hipSuccess) return fail(c, CSV_E_NOMEM, "hipHostMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+    c->h_pin = (char*)p; c->h_pin_cap = want;
+    return CSV_OK;
+}
 
 template <class T> T* dp(const Buf& b) { return (T*)b.p; }
 
 int div_up(i64 a, i64 b) { return (int)((a + b - 1) / b); }
+
+int env_int(const char* name, int dflt)
+{
+    const char* v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+
+int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sync);
+int read_counters(csv_ctx* c);
 
 }  // namespace
 
 extern "C" {
 
 int csv_abi_version(void) { return CSV_ABI_VERSION; }
+
+int csv_struct_size(int which)
+{
+    switch (which) {
+    case 0: return (int)sizeof(csv_segment);
+    case 1: return (int)sizeof(csv_batch_in);
+    case 2: return (int)sizeof(csv_batch_out);
+    case 3: return (int)sizeof(csv_run_stats);
+    case 4: return (int)sizeof(csv_rebuild_in);
+    case 5: return (int)sizeof(csv_rebuild_out);
+    case 6: return (int)sizeof(csv_vcf_in);
+    case 7: return (int)sizeof(csv_rows_in);
+    default: return -1;
+    }
+}
 
 const char* csv_stage_name(int s) { return (s >= 0 && s < CSV_N_STAGES) ? kStageName[s] : ""; }
 
@@ -123,6 +202,23 @@ int32_t csv_gl_index(int64_t c0, int64_t c1)
     return (int32_t)(c0 * 101 + c1);
 }
 
+int csv_host_alloc(int64_t bytes, void** out)
+{
+    if (!out || bytes < 0) return CSV_E_INVALID;
+    *out = nullptr;
+    void* p = nullptr;
+    if (hipHostMalloc(&p, (size_t)(bytes > 0 ? bytes : 1), hipHostMallocPortable) != hipSuccess) return CSV_E_NOMEM;
+    *out = p;
+    return CSV_OK;
+}
+void csv_host_free(void* p) { if (p) (void)hipHostFree(p); }
+int csv_host_register(void* p, int64_t bytes)
+{
+    if (!p || bytes <= 0) return CSV_E_INVALID;
+    return hipHostRegister(p, (size_t)bytes, hipHostRegisterPortable) == hipSuccess ? CSV_OK : CSV_E_HIP;
+}
+int csv_host_unregister(void* p) { return (p && hipHostUnregister(p) == hipSuccess) ? CSV_OK : CSV_E_HIP; }
+
 int csv_ctx_create(int device_id, csv_ctx** out)
 {
     if (!out) return CSV_E_INVALID;
@@ -134,13 +230,19 @@ int csv_ctx_create(int device_id, csv_ctx** out)
     if (hipSetDevice(device_id) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) { delete c; return CSV_E_HIP; }
     for (auto& e : c->ev) if (hipEventCreate(&e) != hipSuccess) { delete c; return CSV_E_HIP; }
     for (auto& s2 : c->side) if (hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) != hipSuccess) { delete c; return CSV_E_HIP; }
+    for (auto& s2 : c->copy) if (hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) != hipSuccess) { delete c; return CSV_E_HIP; }
     if (hipEventCreateWithFlags(&c->ev_init, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_sel, hipEventDisableTiming) != hipSuccess) { delete c; return CSV_E_HIP; }
+        hipEventCreateWithFlags(&c->ev_sel, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_reads, hipEventDisableTiming) != hipSuccess) { delete c; return CSV_E_HIP; }
     for (auto& e : c->ev_aux) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { delete c; return CSV_E_HIP; }
+    for (auto& e : c->ev_copy) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { delete c; return CSV_E_HIP; }
+    c->n_copy = env_int("CSV_COPY_STREAMS", N_COPY_STREAMS);
+    if (c->n_copy < 1) c->n_copy = 1;
+    if (c->n_copy > N_COPY_STREAMS) c->n_copy = N_COPY_STREAMS;
     // `num ** 0.5` of cal_CIPOS is libm pow(), not sqrt(): tabulate it with the host libm (GT:59)
     std::vector<double> tab(SQRT_TAB);
     for (int i = 0; i < SQRT_TAB; i++) tab[i] = pow((double)i, 0.5);
-    if (reserve(c, c->sqrt_tab, SQRT_TAB * sizeof(double)) || reserve(c, c->cnt, sizeof(DevCounters)) ||
+    if (reserve(c, c->sqrt_tab, SQRT_TAB * sizeof(double)) || reserve(c, c->cnt, sizeof(DevCounters)) || pin_reserve(c, 1 << 20) ||
         hipMemcpy(c->sqrt_tab.p, tab.data(), SQRT_TAB * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
         delete c;
         return CSV_E_HIP;
@@ -153,23 +255,20 @@ void csv_ctx_destroy(csv_ctx* c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
-    Buf* all[] = {&c->seg, &c->woff, &c->seg_drop, &c->a, &c->b, &c->rid, &c->aux, &c->cluster_id, &c->partial,
-                  &c->partial64, &c->item_rec, &c->list_small, &c->list_big, &c->list_tiny, &c->tile_prev, &c->partial_t, &c->seg_gate, &c->item_nslots,
-                  &c->item_cnt, &c->item_base, &c->sup_tmp, &c->t_bp1, &c->t_bp2, &c->t_search, &c->t_pick,
-                  &c->t_support, &c->t_cipos, &c->t_cilen, &c->t_supoff, &c->t_valid, &c->sc_k, &c->sc_x, &c->sc_v1, &c->sc_v2,
-                  &c->sc_v3, &c->sc_v4, &c->sc_v5, &c->o_seg, &c->o_cluster, &c->o_aux, &c->o_bp1, &c->o_bp2, &c->o_support,
-                  &c->o_cipos, &c->o_cilen, &c->o_search, &c->o_pick, &c->o_dr, &c->o_dv, &c->o_gl, &c->o_supoff, &c->o_supsig,
-                  &c->o_suprid, &c->allele_id, &c->reads_off, &c->r_start, &c->r_end, &c->r_primary, &c->r_id, &c->r_pmax, &c->pm_partial, &c->gt_over, &c->contig_len,
-                  &c->sqrt_tab, &c->cnt, &c->rb_seg, &c->rb_a, &c->rb_b, &c->rb_rid, &c->rb_aux, &c->rb_auxk, &c->rb_major,
-                  &c->rb_perm0, &c->rb_perm1, &c->rb_hist, &c->rb_tot, &c->rb_partial, &c->rb_oseg, &c->rb_oa, &c->rb_ob,
-                  &c->rb_orid, &c->rb_oaux, &c->rb_osrc};
-    for (Buf* b : all) if (b->p) (void)hipFree(b->p);
+    (void)hipDeviceSynchronize();
+    Buf* own[] = {&c->sqrt_tab, &c->cnt, &c->gs_chrom, &c->gs_perm0, &c->gs_perm1, &c->gs_hist, &c->gs_tot, &c->flush};
+    for (Buf* b : own) if (b->p) (void)hipFree(b->p);
+    if (c->arena.base) (void)hipFree(c->arena.base);
+    if (c->arena_rb.base) (void)hipFree(c->arena_rb.base);
+    if (c->h_pin) (void)hipHostFree(c->h_pin);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->ev_aux) if (e) (void)hipEventDestroy(e);
+    for (auto& e : c->ev_copy) if (e) (void)hipEventDestroy(e);
     if (c->ev_init) (void)hipEventDestroy(c->ev_init);
     if (c->ev_sel) (void)hipEventDestroy(c->ev_sel);
-    for (auto& s2 : c->side) if (s2) { (void)hipStreamSynchronize(s2); (void)hipStreamDestroy(s2); }
+    if (c->ev_reads) (void)hipEventDestroy(c->ev_reads);
+    for (auto& s2 : c->side) if (s2) (void)hipStreamDestroy(s2);
+    for (auto& s2 : c->copy) if (s2) (void)hipStreamDestroy(s2);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -184,20 +283,39 @@ int csv_ctx_sync(csv_ctx* c)
     return CSV_OK;
 }
 
-int csv_batch_upload(csv_ctx* c, const csv_batch_in* in)
+int csv_batch_upload(csv_ctx* c, const csv_batch_in* in) { return upload_impl(c, in, false, true); }
+
+}  // extern "C"
+
+namespace {
+
+// Host -> device.  The small tables travel as ONE copy out of the page-locked staging block; the columns go out on up
+// to four copy streams (one DMA engine each), the reads table on its own so that the clustering kernels never wait
+// for it.  `sync` = false (csv_cluster_batch): nothing waits here, the kernels are ordered behind the copies by events
+// and the final download synchronises before the call returns.
+int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sync)
 {
     if (!c || !in) return CSV_E_INVALID;
     c->uploaded = c->ran = false;
+    c->reads_general = false;
     HIP_TRY(c, hipSetDevice(c->device));
     if (in->n_seg < 0 || in->n_sig < 0 || (in->n_seg > 0 && !in->seg)) return fail(c, CSV_E_INVALID, "bad batch header");
     const int S = in->n_seg;
     c->h_seg.assign(in->seg, in->seg + S);
     c->h_woff.assign(S + 1, 0);
-    std::vector<uint8_t> drop(S + 1, 0);
     c->any_genotype = false;
     c->any_pair = false;
     c->any_tra_gt = false;
-    i64 cap_items = 16, cap_tmp = 16;
+    const bool have_reads_off = in->reads_off != nullptr;
+    if (have_reads_off) {                                   // the reads table is trusted by the kernels: check its frame here
+        if (in->n_chrom < 0 || in->n_reads < 0 || in->n_reads >= (1ll << 31) - 4096) return fail(c, CSV_E_INVALID, "bad reads table header");
+        if (in->reads_off[0] < 0) return fail(c, CSV_E_INVALID, "reads_off[0] is negative");
+        for (int k = 0; k < in->n_chrom; k++)
+            if (in->reads_off[k + 1] < in->reads_off[k]) return fail(c, CSV_E_INVALID, "reads_off decreases at chromosome %d", k);
+        if (in->reads_off[in->n_chrom] > in->n_reads) return fail(c, CSV_E_INVALID, "reads_off[n_chrom] exceeds n_reads");
+    }
+    std::vector<uint8_t> drop(S + 1, 0);
+    i64 cap_items = 16, cap_tmp = 16, maxseg_gt = 0, tra_gt_len = 0;
     for (int k = 0; k < S; k++) {
         const csv_segment& g = c->h_seg[k];
         if (g.svtype < CSV_DEL || g.svtype > CSV_TRA) return fail(c, CSV_E_INVALID, "segment %d: unknown svtype %d", k, g.svtype);
@@ -214,6 +332,8 @@ int csv_batch_upload(csv_ctx* c, const csv_batch_in* in)
             }
         }
         const i64 len = g.sig_end - g.sig_begin;
+        if (g.genotype && g.svtype == CSV_TRA && len > tra_gt_len) tra_gt_len = len;
+        if (g.genotype && g.svtype != CSV_TRA && len > maxseg_gt) maxseg_gt = len;
         if (len > 0 && g.svtype != CSV_DEL && g.svtype != CSV_INS) c->any_pair = true;
         c->h_woff[k + 1] = c->h_woff[k] + len;
         const i64 rc = g.read_count > 1 ? g.read_count : 1;
@@ -227,71 +347,125 @@ int csv_batch_upload(csv_ctx* c, const csv_batch_in* in)
     if (W >= (1ll << 31) - 4096 || cap_tmp >= (1ll << 31) - 1) return fail(c, CSV_E_INVALID, "batch too large for 32-bit work indices (%lld signatures)", (long long)W);
     if (c->any_genotype && in->reads_off && (!in->r_start || !in->r_end || !in->r_primary || !in->r_id) && in->n_reads > 0)
         return fail(c, CSV_E_INVALID, "reads columns missing");
+    const bool per_sig = per_sig_forced || (in->flags & CSV_IN_PER_SIG);
 
-    // ---- device memory
-    RES(seg, (S + 1) * sizeof(csv_segment)); RES(woff, (S + 2) * sizeof(i64)); RES(seg_drop, S + 1);
-    RES(a, (W + 1) * 8); RES(b, (W + 1) * 8); RES(rid, (W + 1) * 4); RES(aux, (W + 1) * 4);
-    RES(cluster_id, (W + 1) * 4); RES(sup_tmp, (W + 1) * 4); RES(allele_id, (W + 1) * 4);
+    // ---- device memory: one plan, one arena
     const i64 R = (c->any_genotype && in->reads_off) ? in->n_reads : 0;
-    const i64 np32 = div_up(W, CH_TILE) + 2;              // per chain tile
-    const i64 np64 = np32;
-    RES(partial, np32 * 4); RES(partial64, np64 * 8); RES(tile_prev, np32 * 8); RES(partial_t, np32 * 4); RES(seg_gate, (S + 1) * 16);
-    RES(item_rec, cap_items * 16); RES(list_small, cap_items * 4); RES(list_big, cap_items * 4); RES(list_tiny, cap_items * 4);
-    RES(item_nslots, cap_items * 4); RES(item_cnt, cap_items * 8);
-    RES(item_base, (cap_items + 8) * 8);
-    // temp call records are indexed by w (a cluster's slots live in its own signature range)
-    RES(t_bp1, (W + 1) * 8); RES(t_bp2, (W + 1) * 8); RES(t_search, (W + 1) * 8); RES(t_pick, (W + 1) * 8);
-    RES(t_support, (W + 1) * 4); RES(t_cipos, (W + 1) * 4); RES(t_cilen, (W + 1) * 4); RES(t_supoff, (W + 1) * 4); RES(t_valid, (W + 1) * 4);
-    const i64 SC = 2 * W + 16 + 2 * ARR_PAD;
-    RES(sc_k, SC * 8); RES(sc_x, SC * 8); RES(sc_v1, SC * 4); RES(sc_v2, SC * 4); RES(sc_v3, SC * 4); RES(sc_v4, SC * 4); RES(sc_v5, SC * 4);
-    RES(o_seg, cap_tmp * 4); RES(o_cluster, cap_tmp * 4); RES(o_aux, cap_tmp * 4); RES(o_bp1, cap_tmp * 8); RES(o_bp2, cap_tmp * 8);
-    RES(o_support, cap_tmp * 4); RES(o_cipos, cap_tmp * 4); RES(o_cilen, cap_tmp * 4); RES(o_search, cap_tmp * 8); RES(o_pick, cap_tmp * 8);
-    RES(o_dr, cap_tmp * 4); RES(o_dv, cap_tmp * 4); RES(o_gl, cap_tmp * 4); RES(o_ghdr, cap_tmp * 16); RES(o_supoff, (cap_tmp + 1) * 8);
-    RES(o_supsig, (W + 1) * 8); RES(o_suprid, (W + 1) * 4);
+    const bool reorder = R > 0 && !(in->flags & CSV_IN_READS_SORTED);
     const bool have_tab = c->any_genotype && in->reads_off;
-    if (have_tab) { RES(reads_off, (in->n_chrom + 1) * 8); RES(contig_len, (in->n_chrom + 1) * 8); }
+    const i64 nt = div_up(W, CH_TILE) + 2;                 // chain tiles
+    const i64 SC = 2 * W + 16 + 2 * ARR_PAD;
+    i64 rc_max = 0;                                        // largest reads block: bounds the cover set of one call
+    if (R > 0) for (int k = 0; k < in->n_chrom; k++) { const i64 d = in->reads_off[k + 1] - in->reads_off[k]; if (d > rc_max) rc_max = d; }
+    // global hash pool (ints, a power of two): holds the set of ANY call of the batch - supports <= its segment, cover <= two
+    // scans of a reads block (genotype_global: table < 4 * need), TRA: < 59 * supports + 1710 ints (tra_bits_for)
+    i64 pool_n = 1 << 20;
+    if (R > 0) while (pool_n < 2 * (2 * rc_max + maxseg_gt) + 4096 || pool_n < 64 * tra_gt_len + 8192) { pool_n <<= 1; if (pool_n >= (1ll << 32)) break; }
+    Plan P;
+#define PL(buf, bytes) P.add(c->buf, (size_t)(bytes))
+    PL(seg, (S + 1) * sizeof(csv_segment)); PL(woff, (S + 2) * sizeof(i64)); PL(seg_drop, S + 1); PL(seg_gate, (S + 1) * 16); PL(seg_err, (S + 1) * 4);
+    PL(a, (W + 1) * 8); PL(b, (W + 1) * 8); PL(rid, (W + 1) * 4); PL(aux, (W + 1) * 4);
+    PL(sup_tmp, (W + 1) * 4);
+    if (per_sig) { PL(cluster_id, (W + 1) * 4); PL(allele_id, (W + 1) * 4); }
+    PL(partial, nt * 4); PL(partial64, nt * 8); PL(tile_prev, nt * 8); PL(partial_t, nt * 4);
+    PL(ch_masks, nt * 4 * 2 * CH_ITEMS * 8); PL(ch_ku, nt * 4 * 4);
+    PL(item_rec, cap_items * 16); PL(list_small, cap_items * 4); PL(list_big, cap_items * 4); PL(list_tiny, cap_items * 4);
+    PL(item_nslots, cap_items * 4); PL(item_cnt, cap_items * 8); PL(item_base, (cap_items + 8) * 8);
+    // temp call records are indexed by w (a cluster's slots live in its own signature range)
+    PL(t_bp1, (W + 1) * 8); PL(t_bp2, (W + 1) * 8); PL(t_search, (W + 1) * 8); PL(t_pick, (W + 1) * 8);
+    PL(t_support, (W + 1) * 4); PL(t_cipos, (W + 1) * 4); PL(t_cilen, (W + 1) * 4); PL(t_supoff, (W + 1) * 4); PL(t_valid, (W + 1) * 4);
+    PL(sc_k, SC * 8); PL(sc_x, SC * 8); PL(sc_v1, SC * 4); PL(sc_v2, SC * 4); PL(sc_v3, SC * 4); PL(sc_v4, SC * 4); PL(sc_v5, SC * 4);
+    PL(o_rec, (cap_tmp + 1) * sizeof(CallRec)); PL(o_supsig, (W + 1) * 8); PL(o_suprid, (W + 1) * 4);
+    if (have_tab) { PL(reads_off, (in->n_chrom + 1) * 8); PL(contig_len, (in->n_chrom + 1) * 8); }
     if (R > 0) {
-        RES(pm_partial, (div_up(R, PM_TILE) + 2) * 8); RES(gt_over, (cap_tmp + 2) * 4);
-        RES(r_start, R * 8); RES(r_end, R * 8); RES(r_primary, R); RES(r_id, R * 4); RES(r_pmax, R * 8);
+        PL(pm_partial, (div_up(R, PM_TILE) + 2) * 8); PL(gt_over, (cap_tmp + 2) * 4); PL(gt_huge, (cap_tmp + 2) * 4); PL(gt_pool, pool_n * 4);
+        PL(r_start, R * 8); PL(r_end, R * 8); PL(r_primary, R); PL(r_id, R * 4); PL(r_pmax, R * 8);
+        if (reorder) { PL(s_start, R * 8); PL(s_end, R * 8); PL(s_primary, R); PL(s_id, R * 4); PL(ro_runs, RO_CAP * 4); PL(ro_table, RO_CAP * 16); }
+    }
+#undef PL
+    {
+        // the arena may move: nothing may still be running out of the old one
+        if (P.total > c->arena.cap) HIP_TRY(c, hipDeviceSynchronize());
+        const int rc = commit(c, c->arena, P);
+        if (rc) return rc;
     }
 
-    // ---- host -> device.  Segments whose source ranges are adjacent travel as one copy.
+    // ---- small tables: staged in page-locked memory, one copy
+    const size_t o_seg = 0, o_woff = o_seg + (size_t)(S + 1) * sizeof(csv_segment), o_drop = o_woff + (size_t)(S + 2) * 8,
+                 o_gate = (o_drop + (size_t)S + 1 + 15) & ~(size_t)15, o_end = o_gate + (size_t)(S + 1) * 16;
+    // (the staging block is also the landing zone of the results: never smaller than one counters struct)
+    { const int rc = pin_reserve(c, o_end + sizeof(DevCounters) + 256); if (rc) return rc; }
     hipStream_t st = c->stream;
-    HIP_TRY(c, hipMemcpyAsync(c->seg.p, c->h_seg.data(), S * sizeof(csv_segment), hipMemcpyHostToDevice, st));
-    HIP_TRY(c, hipMemcpyAsync(c->woff.p, c->h_woff.data(), (S + 1) * sizeof(i64), hipMemcpyHostToDevice, st));
-    HIP_TRY(c, hipMemcpyAsync(c->seg_drop.p, drop.data(), S + 1, hipMemcpyHostToDevice, st));
-    c->h_seg_gate.assign((size_t)(S + 1) * 4, 0);           // {read_count, dropped, svtype, -} per segment
-    for (int k = 0; k < S; k++) { c->h_seg_gate[4 * k] = c->h_seg[k].read_count; c->h_seg_gate[4 * k + 1] = drop[k]; c->h_seg_gate[4 * k + 2] = c->h_seg[k].svtype; }
-    HIP_TRY(c, hipMemcpyAsync(c->seg_gate.p, c->h_seg_gate.data(), (size_t)(S + 1) * 16, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipStreamSynchronize(st));                   // the staging block may still be the source of an earlier copy
+    memcpy(c->h_pin + o_seg, c->h_seg.data(), (size_t)S * sizeof(csv_segment));
+    memcpy(c->h_pin + o_woff, c->h_woff.data(), (size_t)(S + 1) * 8);
+    memcpy(c->h_pin + o_drop, drop.data(), (size_t)S + 1);
+    int* gate = (int*)(c->h_pin + o_gate);                  // {read_count, dropped, svtype, -} per segment
+    for (int k = 0; k < S; k++) { gate[4 * k] = c->h_seg[k].read_count; gate[4 * k + 1] = drop[k]; gate[4 * k + 2] = c->h_seg[k].svtype; gate[4 * k + 3] = 0; }
+    HIP_TRY(c, hipMemcpyAsync(c->seg.p, c->h_pin + o_seg, (size_t)S * sizeof(csv_segment), hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(c->woff.p, c->h_pin + o_woff, (size_t)(S + 1) * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(c->seg_drop.p, c->h_pin + o_drop, (size_t)S + 1, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(c->seg_gate.p, c->h_pin + o_gate, (size_t)(S + 1) * 16, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemsetAsync(c->seg_err.p, 0, (size_t)(S + 1) * 4, st));
+
+    // ---- columns.  Segments whose source ranges are adjacent travel as one copy; aux is not read for DEL / DUP
+    // segments (include/cutesv_hip.h) and is zero-filled on the device instead of crossing PCIe.
+    const int NC = c->n_copy;
+    int rr = 0;
+    auto cs = [&]() -> hipStream_t { hipStream_t s2 = c->copy[rr % NC]; rr++; return s2; };
+    HIP_TRY(c, hipMemsetAsync(c->aux.p, 0, (size_t)(W + 1) * 4, st));
+    HIP_TRY(c, hipEventRecord(c->ev_init, st));
+    for (int q = 0; q < NC; q++) HIP_TRY(c, hipStreamWaitEvent(c->copy[q], c->ev_init, 0));   // (the memset above, and whatever ran before)
     for (int k = 0; k < S;) {
         int e = k;
         while (e + 1 < S && c->h_seg[e + 1].sig_begin == c->h_seg[e].sig_end) e++;
         const i64 src = c->h_seg[k].sig_begin, n = c->h_woff[e + 1] - c->h_woff[k], dst = c->h_woff[k];
         if (n > 0) {
-            HIP_TRY(c, hipMemcpyAsync(dp<i64>(c->a) + dst, in->a + src, n * 8, hipMemcpyHostToDevice, st));
-            HIP_TRY(c, hipMemcpyAsync(dp<i64>(c->b) + dst, in->b + src, n * 8, hipMemcpyHostToDevice, st));
-            HIP_TRY(c, hipMemcpyAsync(dp<int>(c->rid) + dst, in->read_id + src, n * 4, hipMemcpyHostToDevice, st));
-            HIP_TRY(c, hipMemcpyAsync(dp<int>(c->aux) + dst, in->aux + src, n * 4, hipMemcpyHostToDevice, st));
+            HIP_TRY(c, hipMemcpyAsync(dp<i64>(c->a) + dst, in->a + src, n * 8, hipMemcpyHostToDevice, cs()));
+            HIP_TRY(c, hipMemcpyAsync(dp<i64>(c->b) + dst, in->b + src, n * 8, hipMemcpyHostToDevice, cs()));
+            HIP_TRY(c, hipMemcpyAsync(dp<int>(c->rid) + dst, in->read_id + src, n * 4, hipMemcpyHostToDevice, cs()));
+            // aux: runs of segments that need it
+            for (int q = k; q <= e;) {
+                const bool need = c->h_seg[q].svtype == CSV_INS || c->h_seg[q].svtype == CSV_INV || c->h_seg[q].svtype == CSV_TRA;
+                int q2 = q;
+                while (q2 + 1 <= e && ((c->h_seg[q2 + 1].svtype == CSV_INS || c->h_seg[q2 + 1].svtype == CSV_INV || c->h_seg[q2 + 1].svtype == CSV_TRA) == need)) q2++;
+                const i64 na = c->h_woff[q2 + 1] - c->h_woff[q];
+                if (need && na > 0)
+                    HIP_TRY(c, hipMemcpyAsync(dp<int>(c->aux) + c->h_woff[q], in->aux + c->h_seg[q].sig_begin, na * 4, hipMemcpyHostToDevice, cs()));
+                q = q2 + 1;
+            }
         }
         k = e + 1;
     }
-    if (have_tab) HIP_TRY(c, hipMemcpyAsync(c->reads_off.p, in->reads_off, (in->n_chrom + 1) * 8, hipMemcpyHostToDevice, st));
-    if (c->any_tra_gt && in->n_chrom > 0) HIP_TRY(c, hipMemcpyAsync(c->contig_len.p, in->contig_len, in->n_chrom * 8, hipMemcpyHostToDevice, st));
-    if (R > 0) {
-        HIP_TRY(c, hipMemcpyAsync(c->r_start.p, in->r_start, R * 8, hipMemcpyHostToDevice, st));
-        HIP_TRY(c, hipMemcpyAsync(c->r_end.p, in->r_end, R * 8, hipMemcpyHostToDevice, st));
-        HIP_TRY(c, hipMemcpyAsync(c->r_primary.p, in->r_primary, R, hipMemcpyHostToDevice, st));
-        HIP_TRY(c, hipMemcpyAsync(c->r_id.p, in->r_id, R * 4, hipMemcpyHostToDevice, st));
+    for (int q = 0; q < NC; q++) { HIP_TRY(c, hipEventRecord(c->ev_copy[q], c->copy[q])); HIP_TRY(c, hipStreamWaitEvent(st, c->ev_copy[q], 0)); }
+    // reads table: its own stream (side[2] runs the reads_order / prefix-max kernels behind it)
+    hipStream_t sr = c->side[2];
+    if (have_tab) {
+        HIP_TRY(c, hipStreamWaitEvent(sr, c->ev_init, 0));
+        HIP_TRY(c, hipMemcpyAsync(c->reads_off.p, in->reads_off, (size_t)(in->n_chrom + 1) * 8, hipMemcpyHostToDevice, sr));
+        if (c->any_tra_gt && in->n_chrom > 0) HIP_TRY(c, hipMemcpyAsync(c->contig_len.p, in->contig_len, (size_t)in->n_chrom * 8, hipMemcpyHostToDevice, sr));
     }
-    HIP_TRY(c, hipStreamSynchronize(st));
+    if (R > 0) {
+        HIP_TRY(c, hipMemcpyAsync(c->r_start.p, in->r_start, R * 8, hipMemcpyHostToDevice, sr));
+        HIP_TRY(c, hipMemcpyAsync(c->r_end.p, in->r_end, R * 8, hipMemcpyHostToDevice, sr));
+        HIP_TRY(c, hipMemcpyAsync(c->r_primary.p, in->r_primary, R, hipMemcpyHostToDevice, sr));
+        HIP_TRY(c, hipMemcpyAsync(c->r_id.p, in->r_id, R * 4, hipMemcpyHostToDevice, sr));
+    }
+    // (the main stream does not wait for the reads table: the kernels that read it are ordered behind this event)
+    if (have_tab) HIP_TRY(c, hipEventRecord(c->ev_reads, sr));
+    if (sync) { HIP_TRY(c, hipStreamSynchronize(st)); if (have_tab) HIP_TRY(c, hipStreamSynchronize(sr)); }
 
     DevBatch& B = c->B;
     memset(&B, 0, sizeof B);
     B.n_seg = S; B.n_chrom = in->n_chrom; B.W = W;
     B.seg = dp<csv_segment>(c->seg); B.woff = dp<i64>(c->woff); B.seg_drop = dp<uint8_t>(c->seg_drop);
     B.a = dp<i64>(c->a); B.b = dp<i64>(c->b); B.rid = dp<int>(c->rid); B.aux = dp<int>(c->aux);
-    B.cluster_id = dp<int>(c->cluster_id); B.partial = dp<int>(c->partial); B.partial64 = dp<i64>(c->partial64);
-    B.item_rec = dp<int4>(c->item_rec); B.list_small = dp<int>(c->list_small); B.list_big = dp<int>(c->list_big); B.list_tiny = dp<int>(c->list_tiny); B.tile_prev = dp<int2>(c->tile_prev); B.partial_t = dp<int>(c->partial_t); B.seg_gate = dp<int4>(c->seg_gate);
+    B.per_sig = per_sig ? 1 : 0;
+    B.cluster_id = per_sig ? dp<int>(c->cluster_id) : nullptr; B.allele_id = per_sig ? dp<int>(c->allele_id) : nullptr;
+    B.partial = dp<int>(c->partial); B.partial64 = dp<i64>(c->partial64);
+    B.item_rec = dp<int4>(c->item_rec); B.list_small = dp<int>(c->list_small); B.list_big = dp<int>(c->list_big); B.list_tiny = dp<int>(c->list_tiny);
+    B.tile_prev = dp<int2>(c->tile_prev); B.partial_t = dp<int>(c->partial_t); B.seg_gate = dp<int4>(c->seg_gate);
+    B.ch_masks = dp<u64>(c->ch_masks); B.ch_ku = dp<int>(c->ch_ku); B.seg_err = dp<int>(c->seg_err);
     B.tiny_max = getenv("CSV_NO_TINY") ? 0 : 16;               // (timing aid: 0 sends every DEL/INS cluster of m <= 32 through the paired path)
     B.item_nslots = dp<int>(c->item_nslots); B.item_cnt = dp<i64>(c->item_cnt); B.item_base = dp<i64>(c->item_base);
     B.sup_tmp = dp<int>(c->sup_tmp);
@@ -299,32 +473,72 @@ int csv_batch_upload(csv_ctx* c, const csv_batch_in* in)
     B.t_support = dp<int>(c->t_support); B.t_cipos = dp<int>(c->t_cipos); B.t_cilen = dp<int>(c->t_cilen); B.t_supoff = dp<int>(c->t_supoff); B.t_valid = dp<int>(c->t_valid);
     B.cap_tmp = (int)cap_tmp; B.cap_items = (int)cap_items;
     B.sc_k = dp<u64>(c->sc_k); B.sc_x = dp<i64>(c->sc_x); B.sc_v1 = dp<int>(c->sc_v1); B.sc_v2 = dp<int>(c->sc_v2); B.sc_v3 = dp<int>(c->sc_v3); B.sc_v4 = dp<int>(c->sc_v4); B.sc_v5 = dp<int>(c->sc_v5);
-    B.o_seg = dp<int>(c->o_seg); B.o_cluster = dp<int>(c->o_cluster); B.o_aux = dp<int>(c->o_aux);
-    B.o_bp1 = dp<i64>(c->o_bp1); B.o_bp2 = dp<i64>(c->o_bp2); B.o_support = dp<int>(c->o_support); B.o_cipos = dp<int>(c->o_cipos); B.o_cilen = dp<int>(c->o_cilen);
-    B.o_search = dp<i64>(c->o_search); B.o_pick = dp<i64>(c->o_pick); B.o_dr = dp<int>(c->o_dr); B.o_dv = dp<int>(c->o_dv); B.o_gl = dp<int>(c->o_gl); B.o_ghdr = dp<int4>(c->o_ghdr);
-    B.o_supoff = dp<i64>(c->o_supoff); B.o_supsig = dp<i64>(c->o_supsig); B.o_suprid = dp<int>(c->o_suprid); B.allele_id = dp<int>(c->allele_id);
-    B.reads_off = dp<i64>(c->reads_off); B.n_reads = R;
-    B.r_start = dp<i64>(c->r_start); B.r_end = dp<i64>(c->r_end); B.r_primary = dp<uint8_t>(c->r_primary); B.r_id = dp<int>(c->r_id); B.r_pmax = dp<i64>(c->r_pmax); B.pm_partial = dp<i64>(c->pm_partial); B.gt_over = dp<int>(c->gt_over); B.contig_len = dp<i64>(c->contig_len);
+    B.o_rec = dp<CallRec>(c->o_rec); B.o_supsig = dp<i64>(c->o_supsig); B.o_suprid = dp<int>(c->o_suprid);
+    B.n_reads = R;
+    if (have_tab) { B.reads_off = dp<i64>(c->reads_off); B.contig_len = dp<i64>(c->contig_len); }
+    if (R > 0) {
+        B.r_start = dp<i64>(c->r_start); B.r_end = dp<i64>(c->r_end); B.r_primary = dp<uint8_t>(c->r_primary); B.r_id = dp<int>(c->r_id);
+        B.r_pmax = dp<i64>(c->r_pmax); B.pm_partial = dp<i64>(c->pm_partial); B.gt_over = dp<int>(c->gt_over); B.gt_huge = dp<int>(c->gt_huge);
+        B.gt_pool = dp<int>(c->gt_pool); B.gt_pool_n = pool_n;
+        B.ro_mode = reorder ? 1 : 0;
+        if (reorder) {
+            B.s_start = dp<i64>(c->s_start); B.s_end = dp<i64>(c->s_end); B.s_primary = dp<uint8_t>(c->s_primary); B.s_id = dp<int>(c->s_id);
+            B.ro_runs = dp<int>(c->ro_runs); B.ro_table = dp<int4>(c->ro_table); B.ro_cap = RO_CAP;
+        }
+    }
     B.sqrt_tab = dp<double>(c->sqrt_tab); B.cnt = dp<DevCounters>(c->cnt);
     c->n_sig_host = in->n_sig;
+    c->n_reads = R;
     c->uploaded = true;
     return CSV_OK;
 }
 
-int csv_batch_run(csv_ctx* c, csv_run_stats* stats)
+// general stable sort of the reads table by (chromosome, start): the fallback of the reads_order stage for tables that
+// are not a permutation of disjoint sorted runs.  LSD radix passes of sort.hip.h over the 5 start bytes and the
+// chromosome bytes; the result is a row permutation that k_reads_gather applies.
+int general_reads_sort(csv_ctx* c, hipStream_t st)
 {
-    if (!c) return CSV_E_INVALID;
-    if (!c->uploaded) return fail(c, CSV_E_STATE, "csv_batch_run before csv_batch_upload");
+    const i64 R = c->n_reads;
+    const int nunits = div_up(R, SORT_WTILE), nblk = div_up(nunits, 4);
+    int rc;
+    if ((rc = reserve(c, c->gs_chrom, R * 4)) || (rc = reserve(c, c->gs_perm0, R * 4)) || (rc = reserve(c, c->gs_perm1, R * 4)) ||
+        (rc = reserve(c, c->gs_hist, (size_t)256 * nunits * 4)) || (rc = reserve(c, c->gs_tot, 256 * 4))) return rc;
+    hipLaunchKernelGGL(k_reads_chromcol, dim3(div_up(R, 256)), dim3(256), 0, st, c->B, dp<int>(c->gs_chrom));
+    int cbytes = 0;
+    for (u64 v = (u64)(c->B.n_chrom > 0 ? c->B.n_chrom - 1 : 0); v; v >>= 8) cbytes++;
+    const int* pin = nullptr;
+    int* pout = dp<int>(c->gs_perm0);
+    for (int f = 0; f < 2; f++) {
+        const int nb = f == 0 ? 5 : cbytes;                // starts < 2^40 (checked with the ends by k_pmax_count)
+        for (int byte = 0; byte < nb; byte++) {
+            SortPass P{f == 0 ? (const void*)c->B.r_start : (const void*)c->gs_chrom.p, f == 0 ? 1 : 0, byte * 8, R, nunits, pin, pout, dp<int>(c->gs_hist)};
+            hipLaunchKernelGGL(k_sort_hist, dim3(nblk), dim3(256), 0, st, P);
+            hipLaunchKernelGGL(k_sort_rowsum, dim3(256), dim3(256), 0, st, dp<int>(c->gs_hist), nunits, dp<int>(c->gs_tot));
+            hipLaunchKernelGGL(k_sort_rowscan, dim3(256), dim3(256), 0, st, dp<int>(c->gs_hist), nunits, dp<int>(c->gs_tot));
+            hipLaunchKernelGGL(k_sort_scatter, dim3(nblk), dim3(256), 0, st, P);
+            pin = pout;
+            pout = (pout == dp<int>(c->gs_perm0)) ? dp<int>(c->gs_perm1) : dp<int>(c->gs_perm0);
+        }
+    }
+    c->B.ro_perm = pin;
+    HIP_TRY(c, hipGetLastError());
+    return CSV_OK;
+}
+
+int run_impl(csv_ctx* c, csv_run_stats* stats)
+{
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t st = c->stream;
-    const DevBatch& B = c->B;
+    DevBatch& B = c->B;
     const i64 W = B.W;
     constexpr int LDS_SMALL = refine_lds_bytes<64>();
     constexpr int LDS_MID = refine_lds_bytes<256>();
     constexpr int LDS_BIG = refine_lds_bytes<2048>();
-    if (!c->big_lds_set) {
+    constexpr int LDS_PLAN = RO_CAP * 16 + 64;
+    if (!c->lds_set) {
         HIP_TRY(c, hipFuncSetAttribute((const void*)k_refine<256, 2048>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BIG));
-        c->big_lds_set = true;
+        HIP_TRY(c, hipFuncSetAttribute((const void*)k_reads_plan, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_PLAN));
+        c->lds_set = true;
     }
     int ev = 0;
     auto mark = [&]() -> hipError_t { return stats ? hipEventRecord(c->ev[ev++], st) : hipSuccess; };
@@ -333,7 +547,7 @@ int csv_batch_run(csv_ctx* c, csv_run_stats* stats)
     do {                                                                                                   \
         if (dbg) {                                                                                         \
             fprintf(stderr, "[csv] %s ...", name); fflush(stderr);                                         \
-            hipError_t e_ = hipStreamSynchronize(st);                                                      \
+            hipError_t e_ = hipDeviceSynchronize();                                                        \
             fprintf(stderr, " %s\n", hipGetErrorString(e_)); fflush(stderr);                               \
         }                                                                                                  \
     } while (0)
@@ -344,7 +558,8 @@ int csv_batch_run(csv_ctx* c, csv_run_stats* stats)
     // k_genotype); instrumented runs (stats != NULL) and CSV_DEBUG keep everything on the main stream so
     // that every kernel is timed alone.
     // (forking costs a few event waits: only worth it when the batch has pair types or genotyping)
-    const bool fork = !stats && !dbg && !getenv("CSV_NO_FORK") && (c->any_pair || (c->any_genotype && B.n_reads > 0));
+    const bool do_gt = c->any_genotype && B.n_reads > 0;
+    const bool fork = !stats && !dbg && !getenv("CSV_NO_FORK") && (c->any_pair || do_gt);
     hipStream_t sB = fork ? c->side[0] : st, sC = fork ? c->side[1] : st, sD = fork ? c->side[2] : st;
 #define LAUNCH_ON(strm, name, kern, grid, block, lds, ...)                             \
     do {                                                                               \
@@ -353,23 +568,38 @@ int csv_batch_run(csv_ctx* c, csv_run_stats* stats)
         HIP_TRY(c, mark());                                                            \
     } while (0)
 #define LAUNCH(name, kern, grid, block, lds, ...) LAUNCH_ON(st, name, kern, grid, block, lds, __VA_ARGS__)
+    auto reads_stage = [&](hipStream_t s2) -> int {       // reads_order + prefix max on stream s2 (5 launches)
+        const int nr = div_up(B.n_reads, PM_TILE);
+        if (B.ro_mode == 2) {
+            const int rc = general_reads_sort(c, s2);
+            if (rc) return rc;
+            hipLaunchKernelGGL(k_reads_gather, dim3(nr), dim3(256), 0, s2, B);
+        } else if (B.ro_mode == 1) {
+            hipLaunchKernelGGL(k_reads_runs, dim3(div_up(B.n_reads, RO_TILE)), dim3(256), 0, s2, B);
+            hipLaunchKernelGGL(k_reads_plan, dim3(1), dim3(RP_THREADS), LDS_PLAN, s2, B);
+            hipLaunchKernelGGL(k_reads_gather, dim3(nr), dim3(256), 0, s2, B);
+        }
+        DBG("reads_order");
+        if (s2 == st || stats) HIP_TRY(c, mark());
+        LAUNCH_ON(s2, "pmax_count", k_pmax_count, nr, 256, 0, B);
+        LAUNCH_ON(s2, "pmax_apply", k_pmax_apply, nr, 256, 0, B);
+        return CSV_OK;
+    };
     if (W > 0) {
         const int nb = div_up(W, CH_TILE);
-        const bool do_gt = c->any_genotype && B.n_reads > 0;
-        const int nr = do_gt ? div_up(B.n_reads, PM_TILE) : 0;
         LAUNCH("chain_count", k_chain_count, nb, 320, 0, B);
-        if (fork && do_gt) {                              // reads prefix max: independent of the clustering kernels
+        if (fork && do_gt) {                              // reads order + prefix max: independent of the clustering kernels
             HIP_TRY(c, hipEventRecord(c->ev_init, st));   // (after the counters were zeroed)
             HIP_TRY(c, hipStreamWaitEvent(sD, c->ev_init, 0));
-            LAUNCH_ON(sD, "pmax_count", k_pmax_count, nr, 256, 0, B);
-            LAUNCH_ON(sD, "pmax_apply", k_pmax_apply, nr, 256, 0, B);
+            const int rc = reads_stage(sD);
+            if (rc) return rc;
             HIP_TRY(c, hipEventRecord(c->ev_aux[2], sD));
         }
         LAUNCH("chain_apply", k_chain_apply, nb, 256, 0, B);
         int g_small = B.cap_items < 8192 ? B.cap_items : 8192;
         if (g_small < 1) g_small = 1;
         int g_iw = div_up(B.cap_items, 4) < 2048 ? div_up(B.cap_items, 4) : 2048;
-        if (getenv("CSV_IW_GRID")) g_iw = atoi(getenv("CSV_IW_GRID"));       // tuning aid
+        g_iw = env_int("CSV_IW_GRID", g_iw);              // tuning aid
         if (g_iw < 1) g_iw = 1;
         if (fork) {
             HIP_TRY(c, hipEventRecord(c->ev_sel, st));
@@ -394,15 +624,12 @@ int csv_batch_run(csv_ctx* c, csv_run_stats* stats)
         LAUNCH("emit", k_emit, 2048, 256, 0, B);
         if (do_gt) {
             if (fork) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_aux[2], 0));
-            else {
-                LAUNCH("pmax_count", k_pmax_count, nr, 256, 0, B);
-                LAUNCH("pmax_apply", k_pmax_apply, nr, 256, 0, B);
-            }
+            else { HIP_TRY(c, hipStreamWaitEvent(st, c->ev_reads, 0)); const int rc = reads_stage(st); if (rc) return rc; }
             hipLaunchKernelGGL((k_genotype<1024, 4>), dim3(2048), dim3(256), 0, st, B, 0);
-            hipLaunchKernelGGL((k_genotype<8192, 1>), dim3(256), dim3(64), 0, st, B, 1);      // overflow list of the first pass
+            hipLaunchKernelGGL((k_genotype<8192, 4>), dim3(256), dim3(256), 0, st, B, 1);     // overflow list of the first pass; global tables beyond
             DBG("genotype");
             HIP_TRY(c, mark());
-        } else if (stats) { HIP_TRY(c, mark()); HIP_TRY(c, mark()); HIP_TRY(c, mark()); }
+        } else if (stats) { for (int q = 0; q < 4; q++) HIP_TRY(c, mark()); }
         if (c->any_tra_gt) {
             LAUNCH("genotype_tra", k_genotype_tra, 256, 64, 0, B);
         }
@@ -413,8 +640,8 @@ int csv_batch_run(csv_ctx* c, csv_run_stats* stats)
     c->ran = true;
     if (stats) {
         memset(stats, 0, sizeof *stats);
-        HIP_TRY(c, hipMemcpyAsync(&c->h_cnt, c->cnt.p, sizeof(DevCounters), hipMemcpyDeviceToHost, st));
-        HIP_TRY(c, hipStreamSynchronize(st));
+        const int rc = read_counters(c);
+        if (rc) return rc;
         for (int i = 0; i + 1 < ev && i < CSV_N_STAGES; i++) HIP_TRY(c, hipEventElapsedTime(&stats->ms_stage[i], c->ev[i], c->ev[i + 1]));
         HIP_TRY(c, hipEventElapsedTime(&stats->ms_total, c->ev[0], c->ev[ev - 1]));
         stats->n_clusters = c->h_cnt.n_clusters;
@@ -424,6 +651,38 @@ int csv_batch_run(csv_ctx* c, csv_run_stats* stats)
         stats->n_support = c->h_cnt.n_support;
     }
     return CSV_OK;
+}
+
+// device counters -> c->h_cnt (through the page-locked block).  A reads table that the run-level reorder could not
+// handle switches the batch to the general sort and runs it again, once.
+int read_counters(csv_ctx* c)
+{
+    hipStream_t st = c->stream;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        HIP_TRY(c, hipMemcpyAsync(c->h_pin, c->cnt.p, sizeof(DevCounters), hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipStreamSynchronize(st));
+        memcpy(&c->h_cnt, c->h_pin, sizeof(DevCounters));
+        if (c->B.ro_mode == 1 && c->B.n_reads > 0 && c->any_genotype && c->h_cnt.ro_state == RO_NEED_GENERAL && attempt == 0) {
+            c->reads_general = true;
+            c->B.ro_mode = 2;
+            const int rc = run_impl(c, nullptr);
+            if (rc) return rc;
+            continue;
+        }
+        break;
+    }
+    return CSV_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int csv_batch_run(csv_ctx* c, csv_run_stats* stats)
+{
+    if (!c) return CSV_E_INVALID;
+    if (!c->uploaded) return fail(c, CSV_E_STATE, "csv_batch_run before csv_batch_upload");
+    return run_impl(c, stats);
 }
 
 int csv_measure_copy_bandwidth(csv_ctx* c, int64_t bytes, int reps, double* gb_per_s)
@@ -453,67 +712,89 @@ int csv_measure_copy_bandwidth(csv_ctx* c, int64_t bytes, int reps, double* gb_p
     return CSV_OK;
 }
 
+int csv_cache_flush(csv_ctx* c, int64_t bytes)
+{
+    if (!c || bytes <= 0) return CSV_E_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int rc = reserve(c, c->flush, (size_t)bytes);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemsetAsync(c->flush.p, 0x5a, (size_t)bytes, c->stream));
+    return CSV_OK;
+}
+
 int csv_batch_validate(csv_ctx* c)
 {
     if (!c) return CSV_E_INVALID;
     if (!c->uploaded) return fail(c, CSV_E_STATE, "csv_batch_validate before csv_batch_upload");
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t st = c->stream;
-    DevCounters zero;
-    memset(&zero, 0, sizeof zero);
-    HIP_TRY(c, hipMemcpyAsync(c->cnt.p, &zero, sizeof zero, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemsetAsync(c->cnt.p, 0, sizeof(DevCounters), st));
     if (c->B.W > 0) hipLaunchKernelGGL(k_validate_order, dim3(div_up(c->B.W, 256)), dim3(256), 0, st, c->B);
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipMemcpyAsync(&c->h_cnt, c->cnt.p, sizeof(DevCounters), hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(c->h_pin, c->cnt.p, sizeof(DevCounters), hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipStreamSynchronize(st));
+    memcpy(&c->h_cnt, c->h_pin, sizeof(DevCounters));
     c->ran = false;
     if (c->h_cnt.error & ERR_SIG_ORDER)
         return fail(c, CSV_E_UNSORTED, "a segment is not in the rebuild order of cuteSV (main script :764-802) or holds adjacent duplicates");
     return CSV_OK;
 }
 
+// Device -> host: the counters, then ONE copy of the call records and one of the support lists into the page-locked
+// block, unpacked into the caller's arrays on the host (a few MB; the per-signature outputs only when they were asked
+// for at upload).
 int csv_batch_download(csv_ctx* c, csv_batch_out* out)
 {
     if (!c || !out) return CSV_E_INVALID;
     if (!c->ran) return fail(c, CSV_E_STATE, "csv_batch_download before csv_batch_run");
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t st = c->stream;
-    HIP_TRY(c, hipMemcpyAsync(&c->h_cnt, c->cnt.p, sizeof(DevCounters), hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipStreamSynchronize(st));
+    { const int rc = read_counters(c); if (rc) return rc; }
     const DevCounters& k = c->h_cnt;
     out->n_calls = k.n_calls; out->n_support = k.n_support; out->n_clusters = k.n_clusters;
-    if (k.error & ERR_READS_UNSORTED) return fail(c, CSV_E_UNSORTED, "a reads block is not sorted by start");
+    if (k.error & ERR_READS_UNSORTED) return fail(c, CSV_E_UNSORTED, "a reads block is not sorted by start although CSV_IN_READS_SORTED was set");
     if (k.error & ERR_CLUSTER_TOO_BIG) return fail(c, CSV_E_INVALID, "a chained cluster has more than %lld signatures", (long long)MAX_CLUSTER);
-    if (k.error & ERR_KEY_RANGE) return fail(c, CSV_E_INVALID, "a length / pos2 value is negative or >= 2^42");
-    if (k.error & ERR_COVER_OVERFLOW) return fail(c, CSV_E_INVALID, "support + cover set of a call exceeds ~6000 reads");
+    if (k.error & ERR_KEY_RANGE) return fail(c, CSV_E_INVALID, "a read id is negative, or a read end is negative or >= 2^40");
+    if (k.error & ERR_COVER_OVERFLOW) return fail(c, CSV_E_INVALID, "internal: the genotype hash pool was too small");
     if (k.error & ERR_TRA_CHROM) return fail(c, CSV_E_INVALID, "a TRA call names a mate chromosome outside the reads table");
     if (k.error & ERR_TMP_OVERFLOW) return fail(c, CSV_E_INVALID, "internal: temp call capacity exceeded");
+    if ((out->cluster_id || out->allele_id) && !c->B.per_sig)
+        return fail(c, CSV_E_STATE, "cluster_id / allele_id requested but the batch was uploaded without CSV_IN_PER_SIG");
     if (k.n_calls > out->cap_calls || k.n_support > out->cap_support)
         return fail(c, CSV_E_CAPACITY, "need %d calls / %lld supports", k.n_calls, (long long)k.n_support);
-    const size_t nc = k.n_calls, ns = (size_t)k.n_support;
+    const size_t nc = (size_t)k.n_calls, ns = (size_t)k.n_support;
     const DevBatch& B = c->B;
-#define D2H(dst, src, bytes) do { if ((bytes) > 0) HIP_TRY(c, hipMemcpyAsync((dst), (src), (bytes), hipMemcpyDeviceToHost, st)); } while (0)
-    D2H(out->call_seg, B.o_seg, nc * 4); D2H(out->call_cluster, B.o_cluster, nc * 4); D2H(out->call_aux, B.o_aux, nc * 4);
-    D2H(out->bp1, B.o_bp1, nc * 8); D2H(out->bp2, B.o_bp2, nc * 8); D2H(out->support, B.o_support, nc * 4);
-    D2H(out->cipos, B.o_cipos, nc * 4); D2H(out->cilen, B.o_cilen, nc * 4); D2H(out->search_pos, B.o_search, nc * 8);
-    D2H(out->seq_pick, B.o_pick, nc * 8); D2H(out->dr, B.o_dr, nc * 4); D2H(out->dv, B.o_dv, nc * 4); D2H(out->gl_idx, B.o_gl, nc * 4);
-    D2H(out->support_off, B.o_supoff, (nc + 1) * 8); D2H(out->support_sig, B.o_supsig, ns * 8);
+    const int S = (int)c->h_seg.size();
+    const size_t o_rec = 256, o_sup = o_rec + ((nc * sizeof(CallRec) + 255) & ~(size_t)255), o_err = o_sup + ((ns * 8 + 255) & ~(size_t)255),
+                 o_end = o_err + (size_t)(S + 1) * 4;
+    if (o_end > c->h_pin_cap) { const int rc = pin_reserve(c, o_end); if (rc) return rc; }
+    if (nc) HIP_TRY(c, hipMemcpyAsync(c->h_pin + o_rec, B.o_rec, nc * sizeof(CallRec), hipMemcpyDeviceToHost, st));
+    if (ns) HIP_TRY(c, hipMemcpyAsync(c->h_pin + o_sup, B.o_supsig, ns * 8, hipMemcpyDeviceToHost, st));
+    if (S) HIP_TRY(c, hipMemcpyAsync(c->h_pin + o_err, B.seg_err, (size_t)S * 4, hipMemcpyDeviceToHost, st));
     if (out->cluster_id) memset(out->cluster_id, 0xff, (size_t)c->n_sig_host * 4);
     if (out->allele_id) memset(out->allele_id, 0xff, (size_t)c->n_sig_host * 4);
     if (out->cluster_id || out->allele_id) {
-        const int S = (int)c->h_seg.size();
         for (int s = 0; s < S;) {
             int e = s;
             while (e + 1 < S && c->h_seg[e + 1].sig_begin == c->h_seg[e].sig_end) e++;
             const i64 dst = c->h_seg[s].sig_begin, n = c->h_woff[e + 1] - c->h_woff[s], src = c->h_woff[s];
-            if (out->cluster_id) D2H(out->cluster_id + dst, B.cluster_id + src, n * 4);
-            if (out->allele_id) D2H(out->allele_id + dst, B.allele_id + src, n * 4);
+            if (n > 0 && out->cluster_id) HIP_TRY(c, hipMemcpyAsync(out->cluster_id + dst, B.cluster_id + src, n * 4, hipMemcpyDeviceToHost, st));
+            if (n > 0 && out->allele_id) HIP_TRY(c, hipMemcpyAsync(out->allele_id + dst, B.allele_id + src, n * 4, hipMemcpyDeviceToHost, st));
             s = e + 1;
         }
     }
-#undef D2H
     HIP_TRY(c, hipStreamSynchronize(st));
-    if (nc == 0 && out->cap_calls >= 0 && out->support_off) out->support_off[0] = 0;
+    const CallRec* r = (const CallRec*)(c->h_pin + o_rec);
+    for (size_t i = 0; i < nc; i++) {
+        const CallRec& x = r[i];
+        out->call_seg[i] = x.seg; out->call_cluster[i] = x.cluster; out->call_aux[i] = x.aux;
+        out->bp1[i] = x.bp1; out->bp2[i] = x.bp2; out->support[i] = x.support; out->cipos[i] = x.cipos; out->cilen[i] = x.cilen;
+        out->search_pos[i] = x.search; out->seq_pick[i] = x.pick; out->dr[i] = x.dr; out->dv[i] = x.dv; out->gl_idx[i] = x.gl;
+        out->support_off[i] = x.supoff;
+    }
+    if (out->support_off) out->support_off[nc] = (int64_t)ns;
+    if (ns) memcpy(out->support_sig, c->h_pin + o_sup, ns * 8);
+    if (out->seg_status && S) memcpy(out->seg_status, c->h_pin + o_err, (size_t)S * 4);
     return CSV_OK;
 }
 
@@ -539,10 +820,18 @@ int csv_rebuild_signatures(csv_ctx* c, const csv_rebuild_in* in, csv_rebuild_out
     }
     auto nbytes = [](u64 v) { int k = 0; while (v) { k++; v >>= 8; } return k; };
     const int nunits = div_up(n, SORT_WTILE), nblk = div_up(nunits, 4), ntile = div_up(n, 2048);
-    RES(rb_seg, n * 4); RES(rb_a, n * 8); RES(rb_b, n * 8); RES(rb_rid, n * 4); RES(rb_aux, n * 4); RES(rb_auxk, n * 4);
-    RES(rb_major, in->n_seg); RES(rb_perm0, n * 4); RES(rb_perm1, n * 4); RES(rb_hist, (size_t)256 * nunits * 4);
-    RES(rb_tot, 256 * 4); RES(rb_partial, (ntile + 2) * 4);
-    RES(rb_oseg, n * 4); RES(rb_oa, n * 8); RES(rb_ob, n * 8); RES(rb_orid, n * 4); RES(rb_oaux, n * 4); RES(rb_osrc, n * 4);
+    Plan P;
+#define PL(buf, bytes) P.add(c->buf, (size_t)(bytes))
+    PL(rb_seg, n * 4); PL(rb_a, n * 8); PL(rb_b, n * 8); PL(rb_rid, n * 4); PL(rb_aux, n * 4); PL(rb_auxk, n * 4);
+    PL(rb_major, in->n_seg); PL(rb_perm0, n * 4); PL(rb_perm1, n * 4); PL(rb_hist, (size_t)256 * nunits * 4);
+    PL(rb_tot, 256 * 4); PL(rb_partial, (ntile + 2) * 4);
+    PL(rb_oseg, n * 4); PL(rb_oa, n * 8); PL(rb_ob, n * 8); PL(rb_orid, n * 4); PL(rb_oaux, n * 4); PL(rb_osrc, n * 4);
+#undef PL
+    {
+        if (P.total > c->arena_rb.cap) HIP_TRY(c, hipDeviceSynchronize());
+        const int rc = commit(c, c->arena_rb, P);
+        if (rc) return rc;
+    }
     hipStream_t st = c->stream;
     HIP_TRY(c, hipMemcpyAsync(c->rb_seg.p, in->seg_id, n * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(c, hipMemcpyAsync(c->rb_a.p, in->a, n * 8, hipMemcpyHostToDevice, st));
@@ -562,11 +851,11 @@ int csv_rebuild_signatures(csv_ctx* c, const csv_rebuild_in* in, csv_rebuild_out
     int npass = 0;
     for (const Field& f : fields)
         for (int byte = 0; byte < f.bytes; byte++) {
-            SortPass P{f.col, f.elem64, byte * 8, n, nunits, pin, pout, dp<int>(c->rb_hist)};
-            hipLaunchKernelGGL(k_sort_hist, dim3(nblk), dim3(256), 0, st, P);
+            SortPass SP{f.col, f.elem64, byte * 8, n, nunits, pin, pout, dp<int>(c->rb_hist)};
+            hipLaunchKernelGGL(k_sort_hist, dim3(nblk), dim3(256), 0, st, SP);
             hipLaunchKernelGGL(k_sort_rowsum, dim3(256), dim3(256), 0, st, dp<int>(c->rb_hist), nunits, dp<int>(c->rb_tot));
             hipLaunchKernelGGL(k_sort_rowscan, dim3(256), dim3(256), 0, st, dp<int>(c->rb_hist), nunits, dp<int>(c->rb_tot));
-            hipLaunchKernelGGL(k_sort_scatter, dim3(nblk), dim3(256), 0, st, P);
+            hipLaunchKernelGGL(k_sort_scatter, dim3(nblk), dim3(256), 0, st, SP);
             pin = pout;
             pout = (pout == dp<int>(c->rb_perm0)) ? dp<int>(c->rb_perm1) : dp<int>(c->rb_perm0);
             npass++;
@@ -599,11 +888,13 @@ int csv_rebuild_signatures(csv_ctx* c, const csv_rebuild_in* in, csv_rebuild_out
 
 int csv_cluster_batch(csv_ctx* c, const csv_batch_in* in, csv_batch_out* out)
 {
-    int rc = csv_batch_upload(c, in);
-    if (rc) return rc;
-    rc = csv_batch_run(c, nullptr);
-    if (rc) return rc;
-    return csv_batch_download(c, out);
+    if (!c || !in || !out) return CSV_E_INVALID;
+    int rc = upload_impl(c, in, out->cluster_id != nullptr || out->allele_id != nullptr, false);
+    if (rc == CSV_OK) rc = run_impl(c, nullptr);
+    if (rc == CSV_OK) rc = csv_batch_download(c, out);
+    // the caller's columns may still be the source of a copy in flight when something failed on the way
+    if (rc != CSV_OK && rc != CSV_E_CAPACITY) (void)hipDeviceSynchronize();
+    return rc;
 }
 
 }  // extern "C"

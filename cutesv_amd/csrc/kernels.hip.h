@@ -27,14 +27,27 @@ typedef long long i64;
 
 constexpr int WAVE = 64;
 constexpr u64 PAD_KEY = ~0ull;
-constexpr int IDX_BITS = 21;                       // local-index bits inside a sort key
-constexpr i64 MAX_CLUSTER = (1ll << IDX_BITS);     // larger clusters are rejected (CSV_E_INVALID)
-constexpr u64 IDX_MASK = (1ull << IDX_BITS) - 1;
+constexpr int IDX_BITS = 21;                       // local-index bits inside a sort key: (value << 21 | index), values < 2^42 ...
+constexpr int IDX_BITS_HUGE = 31;                  // ... and (value << 31 | index), values < 2^32, for chained clusters above 2^21 signatures
+constexpr i64 MAX_CLUSTER = (1ll << 30);           // (padded size must fit an int; a batch holds < 2^31 signatures anyway)
 constexpr int SQRT_TAB = 65536;                    // pow(n, 0.5) as glibc computes it, n < SQRT_TAB
 constexpr int ARR_PAD = 8;                         // group-start arrays need P + 1 entries
 
 // device error bits (DevCounters::error)
 enum { ERR_CLUSTER_TOO_BIG = 1, ERR_READS_UNSORTED = 2, ERR_COVER_OVERFLOW = 4, ERR_KEY_RANGE = 8, ERR_TMP_OVERFLOW = 16, ERR_SIG_ORDER = 32, ERR_TRA_CHROM = 64 };
+
+// One call as the device keeps it: written by k_emit with six 16-byte stores, read back by the genotype kernels with
+// four, copied to the host in one piece.  (Fourteen separate arrays cost k_emit 9.6x its algorithmic bytes in
+// scattered 4/8-byte stores and every consumer one dependent load per field.)
+struct __attribute__((aligned(16))) CallRec {
+    i64 bp1, bp2;                     //  0
+    i64 search, pick;                 // 16
+    i64 supoff; int support, cipos;   // 32
+    int cilen, seg, cluster, aux;     // 48
+    int dr, dv, gl, pad;              // 64
+    int chrom, type_gt, bias_lo, bias_hi;   // 80: {chromosome, svtype | genotype << 8, gt_bias}: k_genotype reads no segment record
+};
+static_assert(sizeof(CallRec) == 96, "CallRec layout");
 
 struct DevCounters {          // one small struct in device memory, zeroed at the start of every run
     int n_clusters;
@@ -46,7 +59,14 @@ struct DevCounters {          // one small struct in device memory, zeroed at th
     i64 n_support;
     int n_gt_over;            // calls whose support + cover did not fit the small hash set
     int n_items_tiny;         // DEL/INS work items of at most tiny_max signatures (four per wavefront)
+    int n_runs;               // reads_order: sorted runs found in the reads table
+    int ro_state;             // reads_order: RO_*
+    int n_gt_huge;            // genotype: calls that need the whole global pool
+    int gt_ticket;            // workgroups of the second genotype pass that have finished
+    int n_tra_huge;           // the same two for k_genotype_tra
+    int tra_ticket;
 };
+enum { RO_REORDER = 0, RO_IDENTITY = 1, RO_NEED_GENERAL = 2 };
 
 // Everything the kernels need, passed by value.
 struct DevBatch {
@@ -70,6 +90,10 @@ struct DevBatch {
     int*           list_tiny;        // DEL/INS items with m <= tiny_max: k_refine_indel_wave packs four per wavefront
     int            tiny_max;         // 16 (0 switches the class off)
     int2*          tile_prev;        // {last cluster start before the chain tile, its segment} (k_chain_count -> k_chain_apply)
+    u64*           ch_masks;         // per chain wavefront (512 signatures): 8 flag masks + 8 "(0,0) predecessor" masks
+    int*           ch_ku;            // per chain wavefront: its segment when the span lies in one, else -1 / -2
+    int            per_sig;          // CSV_IN_PER_SIG: cluster_id / allele_id are produced
+    int*           seg_err;          // n_seg words of CSV_SEG_* bits
     const int4*    seg_gate;         // per segment {read_count, dropped, svtype, -}: one 16-byte load for the size gate
     int*           partial_t;        // tiny work items per chain tile
     // refine outputs
@@ -83,19 +107,24 @@ struct DevBatch {
     int            cap_items;
     // big-cluster scratch (2 * W + 16 elements each)
     u64*           sc_k; i64* sc_x; int* sc_v1; int* sc_v2; int* sc_v3; int* sc_v4; int* sc_v5;
-    // final outputs
-    int*           o_seg; int* o_cluster; int* o_aux;
-    i64*           o_bp1; i64* o_bp2; int* o_support; int* o_cipos; int* o_cilen; i64* o_search; i64* o_pick;
-    int*           o_dr; int* o_dv; int* o_gl;
-    int4*          o_ghdr;           // per call {chrom, svtype | genotype << 8, gt_bias lo, hi}: k_genotype reads no segment record
-    i64*           o_supoff;         // n_calls + 1
+    // final outputs: one 96-byte record per call (the host unpacks it into csv_batch_out's arrays after ONE copy)
+    CallRec*       o_rec;
     i64*           o_supsig;         // global signature index
     int*           o_suprid;         // read id of the support (genotype)
     int*           allele_id;        // W
     // reads
     const i64*     reads_off;
     i64            n_reads;
-    const i64*     r_start; const i64* r_end; const uint8_t* r_primary; const int* r_id;
+    const i64*     r_start; const i64* r_end; const uint8_t* r_primary; const int* r_id;     // as uploaded (any order inside a block)
+    i64*           s_start; i64* s_end; uint8_t* s_primary; int* s_id;                       // start-ordered copies (reads_order stage)
+    int            ro_mode;          // 0: caller promised sorted blocks; 1: run-level reorder on the device; 2: general radix sort (fallback)
+    int*           ro_runs;          // run starts found by k_reads_runs (unordered)
+    int4*          ro_table;         // runs in start order: {source begin, length, destination begin, chromosome}
+    int            ro_cap;           // capacity of both
+    const int*     ro_perm;          // mode 2: sorted position -> uploaded row
+    int*           gt_huge;          // calls whose sets overflow the 32 KB tables AND one wavefront's slice of the global pool
+    int*           gt_pool;          // global hash pool: gt_pool_n ints, power of two
+    i64            gt_pool_n;
     i64*           r_pmax;
     i64*           pm_partial;       // tile maxima of the reads scan
     int*           gt_over;          // overflow list of the first genotype pass
@@ -353,7 +382,7 @@ __device__ __forceinline__ int close_gate(const DevBatch& B, const int4 g, int s
 // rows -> flags; the wavefront's cluster starts (bit 31: previous signature is (0,0)) and their segments go to its OWN
 // region of the LDS lists, so nothing here waits for another wavefront.  Returns the wavefront's number of starts.
 constexpr int CL_REG = WAVE * CH_ITEMS + 2;          // entries per wavefront region (512 starts + the sentinel)
-__device__ __forceinline__ int wave_starts(const DevBatch& B, i64 base, u64 (&masks)[CH_ITEMS], int* SR, int* SKR, int& ku)
+__device__ __forceinline__ int wave_starts(const DevBatch& B, i64 base, u64 (&masks)[CH_ITEMS], u64 (&zmasks)[CH_ITEMS], int* SR, int* SKR, int& ku)
 {
     int zprev[CH_ITEMS], ksg[CH_ITEMS];
     ku = chain_rows(B, base, masks, zprev, ksg);
@@ -362,10 +391,29 @@ __device__ __forceinline__ int wave_starts(const DevBatch& B, i64 base, u64 (&ma
 #pragma unroll
     for (int r = 0; r < CH_ITEMS; r++) {
         const u64 m = masks[r];
+        zmasks[r] = __ballot(zprev[r]);
         if ((m >> lane_id()) & 1) {
             const int idx = off + __popcll(m & lanemask_lt());
             SR[idx] = (int)(base + r * WAVE + lane_id()) | (zprev[r] << 31);
             SKR[idx] = ksg[r];
+        }
+        off += __popcll(m);
+    }
+    return off;
+}
+// the same lists rebuilt from the masks k_chain_count published (k_chain_apply reads 132 bytes per wavefront instead of
+// its 512 rows: the position column is read ONCE per run, and no flag is derived twice)
+__device__ __forceinline__ int wave_starts_from_masks(const DevBatch& B, i64 base, const u64 (&masks)[CH_ITEMS], const u64 (&zmasks)[CH_ITEMS], int ku, int* SR, int* SKR)
+{
+    int off = 0;
+#pragma unroll
+    for (int r = 0; r < CH_ITEMS; r++) {
+        const u64 m = masks[r];
+        if ((m >> lane_id()) & 1) {
+            const int idx = off + __popcll(m & lanemask_lt());
+            const i64 w = base + r * WAVE + lane_id();
+            SR[idx] = (int)w | ((int)((zmasks[r] >> lane_id()) & 1) << 31);
+            SKR[idx] = ku >= 0 ? ku : seg_of(B, w);           // (a span that crosses segments: rare, binary search)
         }
         off += __popcll(m);
     }
@@ -434,7 +482,7 @@ __global__ __launch_bounds__(320) void k_chain_count(DevBatch B)
     const int wv = threadIdx.x >> 6;
     const i64 tile0 = (i64)blockIdx.x * CH_TILE;
     const bool last_tile = blockIdx.x == gridDim.x - 1;
-    u64 masks[CH_ITEMS];
+    u64 masks[CH_ITEMS], zmasks[CH_ITEMS];
     int cnt = 0, ku = -1;
     int4 g_own = make_int4(0, 0, 0, 0);
     if (wv == 4) {                                         // the look-back wavefront
@@ -449,8 +497,16 @@ __global__ __launch_bounds__(320) void k_chain_count(DevBatch B)
         }
         if (lane_id() == 0) { s_prev[0] = p; s_prev[1] = kp; B.tile_prev[blockIdx.x] = make_int2(p, kp); }
     } else {
-        cnt = wave_starts(B, tile0 + wv * (WAVE * CH_ITEMS), masks, SR[wv], SKR[wv], ku);
+        cnt = wave_starts(B, tile0 + wv * (WAVE * CH_ITEMS), masks, zmasks, SR[wv], SKR[wv], ku);
         if (ku >= 0) g_own = B.seg_gate[ku];
+        {                                                  // publish the flags for k_chain_apply: lane r holds masks[r], lane 8 + r zmasks[r]
+            u64 pub = 0;
+#pragma unroll
+            for (int r = 0; r < CH_ITEMS; r++) { if (lane_id() == r) pub = masks[r]; if (lane_id() == CH_ITEMS + r) pub = zmasks[r]; }
+            const i64 gw = (i64)blockIdx.x * 4 + wv;
+            if (lane_id() < 2 * CH_ITEMS) B.ch_masks[gw * (2 * CH_ITEMS) + lane_id()] = pub;
+            if (lane_id() == 0) B.ch_ku[gw] = ku;
+        }
         if (lane_id() == 0) {
             s_cnt[wv] = cnt; s_ku[wv] = ku;
             // the sentinel w = W ends the last cluster: one more "start" in the last wavefront's region
@@ -493,15 +549,22 @@ __global__ __launch_bounds__(256) void k_chain_apply(DevBatch B)
     const int wv = threadIdx.x >> 6;
     const i64 base = (i64)blockIdx.x * CH_TILE + wv * (WAVE * CH_ITEMS);
     const bool last_tile = blockIdx.x == gridDim.x - 1;
-    u64 masks[CH_ITEMS];
+    u64 masks[CH_ITEMS], zmasks[CH_ITEMS];
+    int ku;
+    {                                                       // the flags of this wavefront's 512 signatures, as k_chain_count left them
+        const i64 gw = (i64)blockIdx.x * 4 + wv;
+        const u64 pub = lane_id() < 2 * CH_ITEMS ? B.ch_masks[gw * (2 * CH_ITEMS) + lane_id()] : 0;
+        ku = __builtin_amdgcn_readfirstlane(B.ch_ku[gw]);
+#pragma unroll
+        for (int r = 0; r < CH_ITEMS; r++) { masks[r] = (u64)readlane_i64x((i64)pub, r); zmasks[r] = (u64)readlane_i64x((i64)pub, CH_ITEMS + r); }
+    }
     // the three exclusive prefixes of this workgroup (cluster starts, work items | workgroup tier, tiny items):
     // sums over all earlier workgroups, tiny and L2 resident
     i64 p0 = 0, p1 = 0, p2 = 0;
     for (int i = threadIdx.x; i < (int)blockIdx.x; i += 256) { p0 += B.partial[i]; p1 += B.partial64[i]; p2 += B.partial_t[i]; }
     p0 = wave_sum_i64(p0); p1 = wave_sum_i64(p1); p2 = wave_sum_i64(p2);
     if (lane_id() == 0) { sh[wv] = p0; sh[4 + wv] = p1; sh[8 + wv] = p2; }
-    int ku;
-    const int cnt = wave_starts(B, base, masks, SR[wv], SKR[wv], ku);
+    const int cnt = wave_starts_from_masks(B, base, masks, zmasks, ku, SR[wv], SKR[wv]);
     int4 g_own = make_int4(0, 0, 0, 0);
     if (ku >= 0) g_own = B.seg_gate[ku];                    // (before the barrier: no global load on the path after it)
     const int2 tile_prev = B.tile_prev[blockIdx.x];
@@ -521,7 +584,7 @@ __global__ __launch_bounds__(256) void k_chain_apply(DevBatch B)
     for (int r = 0; r < CH_ITEMS; r++) {
         const i64 w = base + r * WAVE + lane_id();
         const u64 m = masks[r];
-        if (w < B.W) { B.cluster_id[w] = run + __popcll(m & (lanemask_lt() | (1ull << lane_id()))) - 1; B.allele_id[w] = -1; }
+        if (B.per_sig && w < B.W) { B.cluster_id[w] = run + __popcll(m & (lanemask_lt() | (1ull << lane_id()))) - 1; B.allele_id[w] = -1; }
         run += __popcll(m);
     }
     // gate of the clusters that end at this wavefront's starts; the 3 flag bits of the <= 9 steps of 64 clusters stay
@@ -619,6 +682,7 @@ template <bool LDS> struct ArraysT {
 
 struct ItemCtx {
     int j, cid, k, s, m, P;
+    int ib;                // index bits of this cluster's sort keys
     i64 gsig0;             // global signature index of w = s
 };
 
@@ -873,11 +937,25 @@ template <int BLOCK, bool LDS> __device__ int sort_by_read(const DevBatch& B, co
     return U;
 }
 
+// A length / pos2 value outside [0, 2^(63 - ib)) cannot be packed into a sort key: the cluster emits nothing and its
+// segment is flagged (csv_batch_out.seg_status); every other cluster of the batch is unaffected.
+template <int BLOCK> __device__ bool keys_out_of_range(const DevBatch& B, const ItemCtx& it, i64* red)
+{
+    int bad = 0;
+    for (int i = threadIdx.x; i < it.m; i += BLOCK) bad |= (((u64)B.b[it.s + i]) >> (63 - it.ib)) != 0;
+    if (block_sum_i64<BLOCK>(bad, red) == 0) return false;
+    if (threadIdx.x == 0) atomicOr(&B.seg_err[it.k], CSV_SEG_KEY_RANGE);
+    __syncthreads();
+    return true;
+}
+
 // ---- DEL / INS: generate_del_cluster / generate_ins_cluster (INDEL:110-219, 319-432)
 template <int BLOCK, bool LDS, bool SMALLN> __device__ void refine_indel(const DevBatch& B, const ItemCtx& it, const ArraysT<LDS>& A, i64* red, int* ired)
 {
     const csv_segment& sg = B.seg[it.k];
-    const int m = it.m, P = it.P, s = it.s;
+    const int m = it.m, P = it.P, s = it.s, ib = it.ib;
+    const u64 imask = (1ull << ib) - 1ull;
+    if (keys_out_of_range<BLOCK>(B, it, red)) { item_none(B, it.j); return; }
     const int U = sort_by_read<BLOCK, LDS>(B, it, A, red);
     if (U < sg.read_count) { item_none(B, it.j); return; }                  // INDEL:133-134
 
@@ -895,8 +973,7 @@ template <int BLOCK, bool LDS, bool SMALLN> __device__ void refine_indel(const D
                     if (l2 > bl) { bl = l2; best = i2; }
                 }
                 A.V3[F] = best;
-                if ((u64)bl >> (63 - IDX_BITS)) atomicOr(&B.cnt->error, ERR_KEY_RANGE);
-                key = ((u64)bl << IDX_BITS) | (u64)F;
+                key = ((u64)bl << ib) | (u64)F;
             }
         }
         A.X[q] = (i64)key;
@@ -910,8 +987,8 @@ template <int BLOCK, bool LDS, bool SMALLN> __device__ void refine_indel(const D
     i64 lsum = 0;
     for (int r = threadIdx.x; r < U; r += BLOCK) {
         const u64 key = A.K[r];
-        const int ch = A.V3[(int)(key & IDX_MASK)];
-        const i64 len = (i64)(key >> IDX_BITS);
+        const int ch = A.V3[(int)(key & imask)];
+        const i64 len = (i64)(key >> ib);
         A.K[r] = (u64)B.a[s + ch]; A.X[r] = len; A.V1[r] = ch;
         lsum += len;
     }
@@ -1062,7 +1139,9 @@ template <bool LDS> __device__ __forceinline__ void write_first_seen(const DevBa
 template <int BLOCK, bool LDS> __device__ void refine_pair(const DevBatch& B, const ItemCtx& it, const ArraysT<LDS>& A, i64* red, int* ired)
 {
     const csv_segment& sg = B.seg[it.k];
-    const int m = it.m, P = it.P, s = it.s, type = sg.svtype;
+    const int m = it.m, P = it.P, s = it.s, type = sg.svtype, ib = it.ib;
+    const u64 imask = (1ull << ib) - 1ull;
+    if (keys_out_of_range<BLOCK>(B, it, red)) { item_none(B, it.j); return; }
     const int U = sort_by_read<BLOCK, LDS>(B, it, A, red);                       // V2 = (read id, index) order
     if (U < sg.read_count) { item_none(B, it.j); return; }                  // DUP:82-84, INV:106-109, TRA:128-129
 
@@ -1071,8 +1150,7 @@ template <int BLOCK, bool LDS> __device__ void refine_pair(const DevBatch& B, co
         u64 key = PAD_KEY;
         if (i < m) {
             const i64 p2 = B.b[s + i];
-            if ((u64)p2 >> (63 - IDX_BITS)) atomicOr(&B.cnt->error, ERR_KEY_RANGE);
-            key = ((u64)p2 << IDX_BITS) | (u64)i;
+            key = ((u64)p2 << ib) | (u64)i;
         }
         A.K[i] = key;
     }
@@ -1080,8 +1158,8 @@ template <int BLOCK, bool LDS> __device__ void refine_pair(const DevBatch& B, co
     bitonic_sort<BLOCK>(A.K, P);
     for (int r = threadIdx.x; r < m; r += BLOCK) {
         const u64 key = A.K[r];
-        const int i = (int)(key & IDX_MASK);
-        A.K[r] = (u64)B.a[s + i]; A.X[r] = (i64)(key >> IDX_BITS); A.V1[r] = i; A.V3[i] = r;
+        const int i = (int)(key & imask);
+        A.K[r] = (u64)B.a[s + i]; A.X[r] = (i64)(key >> ib); A.V1[r] = i; A.V3[i] = r;
     }
     __syncthreads();
     // sub-clusters on pos2 gaps > bias (DUP:91, INV:125, TRA:117): V4[r] = sub of rank r
@@ -1272,6 +1350,7 @@ template <int BLOCK, int CAP> __global__ __launch_bounds__(BLOCK, (BLOCK == 64 ?
         int P = 1;
         while (P < it.m) P <<= 1;
         it.P = P;
+        it.ib = P <= (1 << IDX_BITS) ? IDX_BITS : IDX_BITS_HUGE;
         __syncthreads();                                  // LDS arrays of the previous item are dead
         if (it.m > MAX_CLUSTER) {
             if (threadIdx.x == 0) atomicOr(&B.cnt->error, ERR_CLUSTER_TOO_BIG);
@@ -1467,7 +1546,8 @@ template <int SW> __device__ __forceinline__ int indel_unit(const DevBatch& B, c
         const i64 b = in ? B.b[s + sl] : 0;
         const int rid = in ? B.rid[s + sl] : -1 - lane;
         const int aux = (in && type == CSV_INS) ? B.aux[s + sl] : 0;
-        if (in && ((u64)b >> (63 - IDX_BITS))) atomicOr(&B.cnt->error, ERR_KEY_RANGE);
+        const bool badk = sub_ballot<SW>(in && (((u64)b) >> (63 - IDX_BITS)) != 0, g) != 0;   // out-of-range length: the cluster emits nothing
+        if (badk && sl == 0) atomicOr(&B.seg_err[k], CSV_SEG_KEY_RANGE);
         const int mact = act ? m : 0;
         int mmax = __builtin_amdgcn_readlane(mact, 0);
         if (NSUB >= 2) mmax = max(mmax, __builtin_amdgcn_readlane(mact, SW));
@@ -1512,7 +1592,7 @@ template <int SW> __device__ __forceinline__ int indel_unit(const DevBatch& B, c
         const bool rep = in && (F == sl);
         const u64 rm = sub_ballot<SW>(rep, g);
         const int U = __popcll(rm);
-        const bool ok = act && U >= rc;                                          // INDEL:133-134
+        const bool ok = act && !badk && U >= rc;                                 // INDEL:133-134
         if (act && !ok && sl == 0) item_done(B, j, 0, 0, 0);
         if (!__ballot(ok)) break;
         const i64 pa = shfl_i64(a, hb | (ch & (SW - 1)));
@@ -1731,8 +1811,20 @@ __global__ __launch_bounds__(64 * IS_NW) void k_items_scan(DevBatch B)
         const i64 t = carry_s;
         const int nc = (int)(t >> 32); const i64 ns = t & 0xffffffffll;
         B.cnt->n_calls = nc; B.cnt->n_support = ns;
-        B.o_supoff[nc] = ns;
     }
+}
+
+// one call record: six 16-byte stores to consecutive addresses
+__device__ __forceinline__ void write_call(const DevBatch& B, int c, i64 bp1, i64 bp2, i64 search, i64 pick, i64 supoff, int support,
+                                           int cipos, int cilen, int seg, int cluster, int aux, int4 ghdr)
+{
+    int4* r = (int4*)&B.o_rec[c];
+    r[0] = make_int4((int)(bp1 & 0xffffffffll), (int)(bp1 >> 32), (int)(bp2 & 0xffffffffll), (int)(bp2 >> 32));
+    r[1] = make_int4((int)(search & 0xffffffffll), (int)(search >> 32), (int)(pick & 0xffffffffll), (int)(pick >> 32));
+    r[2] = make_int4((int)(supoff & 0xffffffffll), (int)(supoff >> 32), support, cipos);
+    r[3] = make_int4(cilen, seg, cluster, aux);
+    r[4] = make_int4(-1, -1, -1, 0);                     // dr, dv, gl_idx: "not genotyped" until a genotype kernel says otherwise
+    r[5] = ghdr;
 }
 
 // compact one item's valid temp calls into the final arrays (one wavefront, any slot count)
@@ -1757,15 +1849,7 @@ __device__ __forceinline__ void emit_item_serial(const DevBatch& B, int j, i64 b
         const int c = cb + __popcll(mk & lanemask_lt());
         const int sinc = wave_incl_scan_i32(nsup);
         const i64 so = sb + sinc - nsup;
-        if (valid) {
-            B.o_seg[c] = k; B.o_cluster[c] = cid; B.o_aux[c] = aux0;
-            B.o_bp1[c] = B.t_bp1[t]; B.o_bp2[c] = B.t_bp2[t]; B.o_support[c] = nsup;
-            B.o_cipos[c] = B.t_cipos[t]; B.o_cilen[c] = B.t_cilen[t];
-            B.o_search[c] = B.t_search[t]; B.o_pick[c] = B.t_pick[t];
-            B.o_dr[c] = -1; B.o_dv[c] = -1; B.o_gl[c] = -1;
-            B.o_supoff[c] = so;
-            B.o_ghdr[c] = ghdr;
-        }
+        if (valid) write_call(B, c, B.t_bp1[t], B.t_bp2[t], B.t_search[t], B.t_pick[t], so, nsup, B.t_cipos[t], B.t_cilen[t], k, cid, aux0, ghdr);
         u64 rest = mk;
         while (rest) {
             const int l = __ffsll((long long)rest) - 1;
@@ -1777,7 +1861,7 @@ __device__ __forceinline__ void emit_item_serial(const DevBatch& B, int j, i64 b
                 const int w = B.sup_tmp[src + i];
                 B.o_supsig[dst + i] = gs + w;
                 B.o_suprid[dst + i] = B.rid[w];
-                B.allele_id[w] = cc;
+                if (B.per_sig) B.allele_id[w] = cc;
             }
         }
         cb += __popcll(mk);
@@ -1837,15 +1921,7 @@ __global__ __launch_bounds__(256) void k_emit(DevBatch B)
         const int sinc = wave_incl_scan_i32(nsup);
         const int gprev = __shfl(sinc, (g * 8 - 1) & 63);
         const i64 so = (base & 0xffffffffll) + (sinc - nsup) - (g ? gprev : 0);
-        if (valid) {
-            B.o_seg[c] = k; B.o_cluster[c] = cid; B.o_aux[c] = aux0;
-            B.o_bp1[c] = bp1; B.o_bp2[c] = bp2; B.o_support[c] = nsup;
-            B.o_cipos[c] = ci; B.o_cilen[c] = cl;
-            B.o_search[c] = srch; B.o_pick[c] = pick;
-            B.o_dr[c] = -1; B.o_dv[c] = -1; B.o_gl[c] = -1;
-            B.o_supoff[c] = so;
-            B.o_ghdr[c] = ghdr;
-        }
+        if (valid) write_call(B, c, bp1, bp2, srch, pick, so, nsup, ci, cl, k, cid, aux0, ghdr);
         // supports: group g copies the lists of its own slots, 8 lanes at a time
 #pragma unroll
         for (int sl = 0; sl < 8; sl++) {
@@ -1866,11 +1942,195 @@ __global__ __launch_bounds__(256) void k_emit(DevBatch B)
                     if (w[u] >= 0) {
                         B.o_supsig[dst + i + 8 * u] = gs + w[u];
                         B.o_suprid[dst + i + 8 * u] = rd[u];
-                        B.allele_id[w[u]] = cc;
+                        if (rd[u] < 0) atomicOr(&B.cnt->error, ERR_KEY_RANGE);      // (a negative id would pass for an empty hash slot)
+                        if (B.per_sig) B.allele_id[w[u]] = cc;
                     }
             }
         }
     }
+}
+
+// ------------------------------------------------------------------------------------ reads: order
+// The reads block of a chromosome arrives in the order cuteSV's rebuild step leaves it (main script :810): the
+// concatenation of per-worker extraction batches, each batch being the reads that START inside one task region in BAM
+// order (:697-735), i.e. a permutation of DISJOINT, start-sorted runs.  overlap_cover sorts its sweep events inside
+// the stage (cuteSV_genotype.py:101-109); here the stage brings every block into stable start order with three
+// launches: k_reads_runs lists the descents (run starts), k_reads_plan orders the runs (one workgroup; a genome has a
+// few hundred) and checks that they do not interleave, k_reads_gather moves whole runs.  A table that is not a
+// permutation of disjoint runs (or has more than ro_cap of them) is reported back (RO_NEED_GENERAL) and the host
+// re-runs the batch through the general stable radix sort (sort.hip.h) - correct for any input, just slower.
+struct ReadsView { const i64* start; const i64* end; const uint8_t* primary; const int* id; };
+__device__ __forceinline__ ReadsView reads_view(const DevBatch& B)
+{
+    const bool copy = B.ro_mode == 2 || (B.ro_mode == 1 && B.cnt->ro_state != RO_IDENTITY);
+    ReadsView V;
+    V.start = copy ? B.s_start : B.r_start; V.end = copy ? B.s_end : B.r_end;
+    V.primary = copy ? B.s_primary : B.r_primary; V.id = copy ? B.s_id : B.r_id;
+    return V;
+}
+
+__device__ __forceinline__ int chrom_of_read(const DevBatch& B, i64 i, int hint)
+{
+    if (B.reads_off[hint] <= i && i < B.reads_off[hint + 1]) return hint;
+    int lo = 0, hi = B.n_chrom;
+    while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (B.reads_off[mid] <= i) lo = mid; else hi = mid; }
+    return lo;
+}
+
+constexpr int RO_TILE = 256 * 8;
+__global__ __launch_bounds__(256) void k_reads_runs(DevBatch B)
+{
+    const i64 base = (i64)blockIdx.x * RO_TILE + (threadIdx.x >> 6) * 512;
+    int hint = 0;
+    for (int r = 0; r < 8; r++) {
+        const i64 i = base + r * 64 + lane_id();
+        bool st = false;
+        if (i < B.n_reads) {
+            hint = chrom_of_read(B, i, hint);
+            st = i == B.reads_off[hint] || B.r_start[i] < B.r_start[i - 1];
+        }
+        const u64 mk = __ballot(st);
+        if (mk) {                                          // wave-aggregated append (order is restored by k_reads_plan)
+            int slot = 0;
+            if (lane_id() == 0) slot = atomicAdd(&B.cnt->n_runs, __popcll(mk));
+            slot = __builtin_amdgcn_readfirstlane(slot) + __popcll(mk & lanemask_lt());
+            if (st && slot < B.ro_cap) B.ro_runs[slot] = (int)i;
+        }
+    }
+}
+
+// one workgroup: runs by position -> runs by (chromosome, first start, position); disjointness / stability check;
+// destination offsets.  LDS: 16 bytes per run.
+constexpr int RP_THREADS = 1024;
+template <class T> __device__ __forceinline__ void lds_bitonic(T* K, int P)
+{
+    for (int k = 2; k <= P; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < P; i += RP_THREADS) {
+                const int x = i ^ j;
+                if (x > i) {
+                    const T a = K[i], b = K[x];
+                    const bool asc = (i & k) == 0;
+                    if ((a > b) == asc) { K[i] = b; K[x] = a; }
+                }
+            }
+            __syncthreads();
+        }
+}
+__global__ __launch_bounds__(RP_THREADS) void k_reads_plan(DevBatch B)
+{
+    extern __shared__ __attribute__((aligned(16))) char rp_smem[];
+    const int n_raw = B.cnt->n_runs;
+    if (n_raw > B.ro_cap) { if (threadIdx.x == 0) B.cnt->ro_state = RO_NEED_GENERAL; return; }
+    const int n = n_raw;
+    int P = 1;
+    while (P < n) P <<= 1;
+    u64* K = (u64*)rp_smem;                    // P sort keys
+    int* pos = (int*)(K + P);                  // run starts by position (+ sentinel)
+    int* len_s = pos + P + 1;                  // lengths in start order, then their exclusive scan
+    __shared__ int s_bad, s_moved, s_carry;
+    __shared__ int s_w[RP_THREADS / 64];
+    if (threadIdx.x == 0) { s_bad = 0; s_moved = 0; s_carry = 0; }
+    for (int i = threadIdx.x; i < P; i += RP_THREADS) K[i] = i < n ? (u64)(unsigned)B.ro_runs[i] : PAD_KEY;
+    __syncthreads();
+    lds_bitonic(K, P);                                      // by position
+    for (int i = threadIdx.x; i < n; i += RP_THREADS) pos[i] = (int)K[i];
+    if (threadIdx.x == 0) pos[n] = (int)B.n_reads;
+    __syncthreads();
+    // key (chromosome, first start, rank by position): chromosome 20 bits | start 32 bits | rank 12 bits.  A block start
+    // is always a run start, so a run lies inside one chromosome.
+    for (int i = threadIdx.x; i < P; i += RP_THREADS) {
+        u64 key = PAD_KEY;
+        if (i < n) {
+            const int p = pos[i];
+            const int ch = chrom_of_read(B, p, 0);
+            const i64 st = B.r_start[p];
+            if (st < 0 || st >= (1ll << 32) || ch >= (1 << 20) || n > 4096) atomicOr(&s_bad, 1);
+            key = ((u64)ch << 44) | ((u64)(st & 0xffffffffll) << 12) | (u64)(i & 4095);
+        }
+        K[i] = key;
+    }
+    __syncthreads();
+    lds_bitonic(K, P);                                      // by (chromosome, first start, position)
+    // consecutive runs of one chromosome must not interleave: last start of the earlier <= first start of the later,
+    // and on equality the earlier one must also come first by position (that is what a stable sort would do)
+    for (int q = threadIdx.x; q < n; q += RP_THREADS) {
+        const int i = (int)(K[q] & 4095);
+        if (i != q) atomicOr(&s_moved, 1);
+        len_s[q] = pos[i + 1] - pos[i];
+        if (q > 0 && (K[q] >> 44) == (K[q - 1] >> 44)) {
+            const int ip = (int)(K[q - 1] & 4095);
+            const i64 last_prev = B.r_start[pos[ip + 1] - 1], first = B.r_start[pos[i]];
+            if (last_prev > first || (last_prev == first && ip > i)) atomicOr(&s_bad, 1);
+        }
+    }
+    __syncthreads();
+    if (s_bad) { if (threadIdx.x == 0) B.cnt->ro_state = RO_NEED_GENERAL; return; }
+    if (!s_moved) { if (threadIdx.x == 0) B.cnt->ro_state = RO_IDENTITY; return; }
+    // exclusive scan of the lengths in start order -> destination offsets
+    for (int b0 = 0; b0 < n; b0 += RP_THREADS) {
+        const int q = b0 + threadIdx.x;
+        const int v = q < n ? len_s[q] : 0;
+        const int inc = wave_incl_scan_i32(v);
+        if (lane_id() == 63) s_w[threadIdx.x >> 6] = inc;
+        __syncthreads();
+        int off = s_carry;
+        for (int k = 0; k < (int)(threadIdx.x >> 6); k++) off += s_w[k];
+        if (q < n) {
+            const int i = (int)(K[q] & 4095);
+            B.ro_table[q] = make_int4(pos[i], v, off + inc - v, (int)(K[q] >> 44));
+        }
+        __syncthreads();
+        if (threadIdx.x == RP_THREADS - 1) s_carry = off + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) B.cnt->ro_state = RO_REORDER;
+}
+
+// one wavefront per 512 destination rows: find the run of the first row (64-ary search over the run table), then copy
+// run by run (a span of 512 rows usually lies inside one run)
+__global__ __launch_bounds__(256) void k_reads_gather(DevBatch B)
+{
+    if (B.ro_mode == 1 && B.cnt->ro_state != RO_REORDER) return;
+    const i64 d0 = ((i64)blockIdx.x * 4 + (threadIdx.x >> 6)) * 512;
+    if (d0 >= B.n_reads) return;
+    const i64 d1 = d0 + 512 < B.n_reads ? d0 + 512 : B.n_reads;
+    if (B.ro_mode == 2) {                                   // general sort: a row permutation
+        for (i64 d = d0 + lane_id(); d < d1; d += 64) {
+            const int p = B.ro_perm[d];
+            B.s_start[d] = B.r_start[p]; B.s_end[d] = B.r_end[p]; B.s_primary[d] = B.r_primary[p]; B.s_id[d] = B.r_id[p];
+        }
+        return;
+    }
+    const int n = B.cnt->n_runs;
+    int lo = 0, hi = n;                                     // last run with destination begin <= d0
+    while (hi - lo > 1) {
+        const int step = (hi - lo + 63) / 64;
+        const int idx = lo + lane_id() * step;
+        const int t = __popcll(__ballot(idx < hi && (i64)B.ro_table[idx < hi ? idx : lo].z <= d0));
+        const int nlo = lo + (t - 1) * step;
+        int nhi = lo + t * step;
+        if (nhi > hi) nhi = hi;
+        lo = nlo; hi = nhi;
+    }
+    i64 d = d0;
+    for (int q = lo; q < n && d < d1; q++) {
+        const int4 run = B.ro_table[q];
+        const i64 e = (i64)run.z + run.y < d1 ? (i64)run.z + run.y : d1;
+        const i64 shift = (i64)run.x - run.z;
+        for (i64 x = d + lane_id(); x < e; x += 64) {
+            const i64 p = x + shift;
+            B.s_start[x] = B.r_start[p]; B.s_end[x] = B.r_end[p]; B.s_primary[x] = B.r_primary[p]; B.s_id[x] = B.r_id[p];
+        }
+        d = e;
+    }
+}
+
+// chromosome of every row (key column of the general sort)
+__global__ __launch_bounds__(256) void k_reads_chromcol(DevBatch B, int* out)
+{
+    const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (i < B.n_reads) out[i] = chrom_of_read(B, i, 0);
 }
 
 // ------------------------------------------------------------------------------------ reads: prefix max of ends
@@ -1881,33 +2141,26 @@ constexpr int PM_TILE = 256 * 8;
 constexpr int PM_SHIFT = 40;
 constexpr i64 PM_MASK = (1ll << PM_SHIFT) - 1;
 
-__device__ __forceinline__ int chrom_of_read(const DevBatch& B, i64 i, int hint)
-{
-    if (B.reads_off[hint] <= i && i < B.reads_off[hint + 1]) return hint;
-    int lo = 0, hi = B.n_chrom;
-    while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (B.reads_off[mid] <= i) lo = mid; else hi = mid; }
-    return lo;
-}
-
-template <bool CHECK> __device__ __forceinline__ i64 pm_value(const DevBatch& B, i64 i, int& hint)
+template <bool CHECK> __device__ __forceinline__ i64 pm_value(const DevBatch& B, const ReadsView& V, i64 i, int& hint)
 {
     if (i >= B.n_reads) return INT64_MIN;
     hint = chrom_of_read(B, i, hint);
-    const i64 e = B.r_end[i];
+    const i64 e = V.end[i];
     if (CHECK) {                                       // input validation happens once, in the counting pass
-        if (e < 0 || e > PM_MASK) atomicOr(&B.cnt->error, ERR_KEY_RANGE);
-        if (i > B.reads_off[hint] && B.r_start[i] < B.r_start[i - 1]) atomicOr(&B.cnt->error, ERR_READS_UNSORTED);
+        if (e < 0 || e > PM_MASK || V.id[i] < 0) atomicOr(&B.cnt->error, ERR_KEY_RANGE);
+        if (i > B.reads_off[hint] && V.start[i] < V.start[i - 1]) atomicOr(&B.cnt->error, ERR_READS_UNSORTED);
     }
     return ((i64)hint << PM_SHIFT) | e;
 }
 
 __global__ __launch_bounds__(256) void k_pmax_count(DevBatch B)
 {
+    const ReadsView V = reads_view(B);
     const i64 base = (i64)blockIdx.x * PM_TILE + (threadIdx.x >> 6) * 512;
     i64 mx = INT64_MIN;
     int hint = 0;
     for (int r = 0; r < 8; r++) {
-        const i64 v = pm_value<true>(B, base + r * 64 + lane_id(), hint);
+        const i64 v = pm_value<true>(B, V, base + r * 64 + lane_id(), hint);
         if (v > mx) mx = v;
     }
     for (int m = 32; m > 0; m >>= 1) { const i64 o = shfl_xor_i64(mx, m); if (o > mx) mx = o; }
@@ -1919,13 +2172,14 @@ __global__ __launch_bounds__(256) void k_pmax_count(DevBatch B)
 
 __global__ __launch_bounds__(256) void k_pmax_apply(DevBatch B)
 {
+    const ReadsView V = reads_view(B);
     const int wv = threadIdx.x >> 6;
     const i64 base = (i64)blockIdx.x * PM_TILE + wv * 512;
     i64 vals[8];
     i64 run = INT64_MIN;
     int hint = 0;
     for (int r = 0; r < 8; r++) {
-        const i64 v = pm_value<false>(B, base + r * 64 + lane_id(), hint);
+        const i64 v = pm_value<false>(B, V, base + r * 64 + lane_id(), hint);
         i64 inc = wave_incl_max_i64(v);
         if (run > inc) inc = run;
         vals[r] = inc;
@@ -1951,11 +2205,13 @@ __global__ __launch_bounds__(256) void k_pmax_apply(DevBatch B)
 // ------------------------------------------------------------------------------------ genotype
 // One wavefront per call.  cover(window) = primary reads with 2*start <= L2 and 2*end >= R2 (doubled
 // coordinates keep the x.5 windows of DUP/INV exact; GT:95-159, semantics as in GT.duipai :206-212).
-// DR = distinct cover names that are not support names (GT:167-170): an LDS hash set is seeded with the
+// DR = distinct cover names that are not support names (GT:167-170): a hash set is seeded with the
 // support read ids, then every covering read id is inserted; each fresh insert is one DR.
-// Two passes: k_genotype<1024, 4> (4 KB of LDS per wavefront, full occupancy) handles every call whose
-// support + cover fits ~700 reads and appends the others to an overflow list; k_genotype<8192, 1> (one
-// wavefront per workgroup, 32 KB) finishes those.  Beyond ~6000 reads the call is reported as an error.
+// Three tiers, no size limit (the reference has none, GT:95-159): k_genotype<1024, 4> (4 KB of LDS per wavefront,
+// full occupancy) handles every call whose support + cover fits ~700 reads and appends the others to an overflow
+// list; k_genotype<8192, 1> (one wavefront per workgroup, 32 KB) finishes those up to ~6000 reads; what is deeper
+// still (chrM, rDNA and centromeric pile-ups) gets a table in GLOBAL memory sized from the scan extent: a slice of
+// the pool per workgroup, and the whole pool - which holds any call of the batch - for the last workgroup standing.
 template <int HASH> __device__ __forceinline__ int hash_insert(int* tab, int id)
 {
     unsigned h = ((unsigned)id * 2654435761u) >> (32 - __builtin_ctz(HASH));
@@ -1964,6 +2220,17 @@ template <int HASH> __device__ __forceinline__ int hash_insert(int* tab, int id)
         if (old == -1) return 1;
         if (old == id) return 0;
         h = (h + 1) & (HASH - 1);
+    }
+}
+__device__ __forceinline__ int hash_insert_n(int* tab, int bits, int id)      // runtime size 2^bits (global-memory tables)
+{
+    const unsigned mask = (1u << bits) - 1u;
+    unsigned h = ((unsigned)id * 2654435761u) >> (32 - bits);
+    for (;;) {
+        const int old = atomicCAS(&tab[h], -1, id);
+        if (old == -1) return 1;
+        if (old == id) return 0;
+        h = (h + 1) & mask;
     }
 }
 
@@ -1991,7 +2258,7 @@ __device__ __forceinline__ i64 upper_bound_start(const i64* __restrict__ st, i64
 // GT_UNROLL chunks are loaded per step (all loads issued before the first one is used) and consumed in order.
 constexpr int GT_UNROLL = 4;
 // one step over U chunks below `top`; returns true when the scan is over (dead lane met, overflow)
-template <int HASH, int U> __device__ __forceinline__ bool cover_step(const DevBatch& B, int* tab, i64 r0, i64 top, i64 R2, int& dr, int& filled, bool& overflow)
+template <int HASH, int U> __device__ __forceinline__ bool cover_step(const DevBatch& B, const ReadsView& V, int* tab, i64 r0, i64 top, i64 R2, int& dr, int& filled, bool& overflow)
 {
     i64 pm[U], en[U];
     int id[U], pr[U];
@@ -1999,7 +2266,7 @@ template <int HASH, int U> __device__ __forceinline__ bool cover_step(const DevB
     for (int u = 0; u < U; u++) {
         const i64 i = top - u * 64 - lane_id();
         const i64 ii = i >= r0 ? i : r0;
-        pm[u] = B.r_pmax[ii]; en[u] = B.r_end[ii]; pr[u] = B.r_primary[ii]; id[u] = B.r_id[ii];
+        pm[u] = B.r_pmax[ii]; en[u] = V.end[ii]; pr[u] = V.primary[ii]; id[u] = V.id[ii];
     }
 #pragma unroll
     for (int u = 0; u < U; u++) {
@@ -2016,13 +2283,13 @@ template <int HASH, int U> __device__ __forceinline__ bool cover_step(const DevB
     }
     return false;
 }
-template <int HASH> __device__ __forceinline__ int cover_window(const DevBatch& B, int* tab, i64 r0, i64 r1, i64 L2, i64 R2, int& filled, bool& overflow)
+template <int HASH> __device__ __forceinline__ int cover_window(const DevBatch& B, const ReadsView& V, int* tab, i64 r0, i64 r1, i64 L2, i64 R2, int& filled, bool& overflow)
 {
     int dr = 0;
-    i64 top = upper_bound_start(B.r_start, r0, r1, L2) - 1;
-    if (top < r0 || cover_step<HASH, 1>(B, tab, r0, top, R2, dr, filled, overflow)) return dr;
+    i64 top = upper_bound_start(V.start, r0, r1, L2) - 1;
+    if (top < r0 || cover_step<HASH, 1>(B, V, tab, r0, top, R2, dr, filled, overflow)) return dr;
     for (top -= 64; top >= r0; top -= 64 * GT_UNROLL)
-        if (cover_step<HASH, GT_UNROLL>(B, tab, r0, top, R2, dr, filled, overflow)) break;
+        if (cover_step<HASH, GT_UNROLL>(B, V, tab, r0, top, R2, dr, filled, overflow)) break;
     return dr;
 }
 
@@ -2042,17 +2309,104 @@ __device__ __forceinline__ int gl_index_dev(i64 c0, i64 c1)
 // what one call needs before it touches the reads table; loaded one call ahead (the per-call work is a chain of
 // dependent round trips, this takes the first ones off it)
 struct GtHead { int c; int4 h; i64 s0, s1, search, b1, b2; };
+__device__ __forceinline__ void gt_load_call(const DevBatch& B, int c, GtHead& H)
+{
+    const int4* r = (const int4*)&B.o_rec[c];
+    const int4 r0 = r[0], r1 = r[1], r2 = r[2];
+    H.c = c; H.h = r[5];
+    H.b1 = ((i64)r0.y << 32) | (unsigned)r0.x; H.b2 = ((i64)r0.w << 32) | (unsigned)r0.z;
+    H.search = ((i64)r1.y << 32) | (unsigned)r1.x;
+    H.s0 = ((i64)r2.y << 32) | (unsigned)r2.x; H.s1 = H.s0 + r2.z;
+}
 __device__ __forceinline__ void gt_load_head(const DevBatch& B, int second, int q, GtHead& H)
 {
-    const int c = second ? B.gt_over[q] : q;
-    H.c = c; H.h = B.o_ghdr[c]; H.s0 = B.o_supoff[c]; H.s1 = B.o_supoff[c + 1];
-    H.search = B.o_search[c]; H.b1 = B.o_bp1[c]; H.b2 = B.o_bp2[c];
+    gt_load_call(B, second ? B.gt_over[q] : q, H);
+}
+
+// the one or two windows of a call in doubled coordinates (INDEL:450-451; DUP:146-151; INV:218-221); returns their number
+__device__ __forceinline__ int gt_windows(const GtHead& H, i64 (&L2)[2], i64 (&R2)[2])
+{
+    const int svtype = H.h.y & 0xff;
+    const i64 gt_bias = ((i64)H.h.w << 32) | (unsigned)H.h.z;
+    if (svtype == CSV_DEL || svtype == CSV_INS) {
+        const i64 p = H.search, g = gt_bias;
+        i64 L = p - g; if (L < 0) L = 0;
+        L2[0] = 2 * L; R2[0] = 2 * (p + g);
+        return 1;
+    }
+    i64 nb = gt_bias;
+    if (svtype == CSV_DUP && H.b2 - H.b1 < nb) nb = H.b2 - H.b1;            // DUP:147
+    L2[0] = 2 * H.b1 - nb; if (L2[0] < 0) L2[0] = 0; R2[0] = 2 * H.b1 + nb;
+    L2[1] = 2 * H.b2 - nb; if (L2[1] < 0) L2[1] = 0; R2[1] = 2 * H.b2 + nb; // union of both: DUP:155-157
+    return 2;
+}
+
+// first index in [lo, hi) whose prefix max reaches R (r_pmax is non-decreasing inside a chromosome): the scan of a
+// window never goes below it
+__device__ __forceinline__ i64 lower_bound_pmax(const i64* __restrict__ pm, i64 lo, i64 hi, i64 R2)
+{
+    while (hi - lo > 64) {
+        const i64 step = (hi - lo + 63) / 64;
+        const i64 idx = lo + (i64)lane_id() * step;
+        const int pred = (idx < hi) && (2 * pm[idx < hi ? idx : lo] < R2);
+        const int t = __popcll(__ballot(pred));
+        if (t == 0) return lo;
+        const i64 nlo = lo + (i64)(t - 1) * step + 1;
+        i64 nhi = lo + (i64)t * step;
+        if (nhi > hi) nhi = hi;
+        lo = nlo; hi = nhi;
+    }
+    const i64 idx = lo + lane_id();
+    const int pred = (idx < hi) && (2 * pm[idx < hi ? idx : lo] < R2);
+    return lo + __popcll(__ballot(pred));
+}
+
+// A call of any depth with its set in global memory; executed by `nthreads` threads of one workgroup (64: one
+// wavefront with its slice of the pool; 64 * WPB = the whole workgroup with the whole pool).  Returns false when the
+// table the call needs does not fit `cap` ints (nothing has been written then).
+__device__ bool genotype_global(const DevBatch& B, const ReadsView& V, const GtHead& H, int* tab, i64 cap, int tid, int nthreads, bool whole_block, int* s_red)
+{
+    const int chrom = H.h.x;
+    const i64 r0 = B.reads_off[chrom], r1 = B.reads_off[chrom + 1];
+    const i64 ns = H.s1 - H.s0;
+    i64 L2[2], R2[2], top[2], bot[2];
+    const int nw = gt_windows(H, L2, R2);
+    i64 need = ns;
+    for (int w = 0; w < nw; w++) {
+        top[w] = upper_bound_start(V.start, r0, r1, L2[w]) - 1;
+        bot[w] = top[w] >= r0 ? lower_bound_pmax(B.r_pmax, r0, top[w] + 1, R2[w]) : r0;
+        if (top[w] >= bot[w]) need += top[w] - bot[w] + 1;
+    }
+    int bits = 10;
+    while ((1ll << bits) < 2 * need) bits++;
+    if ((1ll << bits) > cap || bits > 31) return false;
+    const i64 T = 1ll << bits;
+    for (i64 i = tid; i < T; i += nthreads) tab[i] = -1;
+    if (whole_block) __syncthreads(); else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    for (i64 i = tid; i < ns; i += nthreads) hash_insert_n(tab, bits, B.o_suprid[H.s0 + i]);
+    if (whole_block) __syncthreads(); else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    int dr = 0;
+    for (int w = 0; w < nw; w++)
+        for (i64 i = bot[w] + tid; i <= top[w]; i += nthreads)
+            if (V.primary[i] == 1 && 2 * V.end[i] >= R2[w]) dr += hash_insert_n(tab, bits, V.id[i]);
+    dr = wave_sum_i32(dr);
+    if (whole_block) {
+        if (lane_id() == 0) s_red[tid >> 6] = dr;
+        __syncthreads();
+        dr = 0;
+        for (int k = 0; k < nthreads / 64; k++) dr += s_red[k];
+        __syncthreads();
+    }
+    if (tid == 0) ((int4*)&B.o_rec[H.c])[4] = make_int4(dr, (int)ns, gl_index_dev(dr, ns), 0);
+    return true;
 }
 
 template <int HASH, int WPB> __global__ __launch_bounds__(64 * WPB) void k_genotype(DevBatch B, int second)
 {
     __shared__ int tabs[WPB][HASH];
+    __shared__ int s_red[WPB], s_last;
     int* tab = tabs[threadIdx.x >> 6];
+    const ReadsView V = reads_view(B);
     const int n = second ? B.cnt->n_gt_over : B.cnt->n_calls;
     const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * (64 * WPB) + threadIdx.x) >> 6), nwaves = (gridDim.x * (64 * WPB)) >> 6;
     GtHead cur, nxt;
@@ -2062,7 +2416,6 @@ template <int HASH, int WPB> __global__ __launch_bounds__(64 * WPB) void k_genot
         if (q + nwaves < n) gt_load_head(B, second, q + nwaves, nxt);
         const int c = cur.c, svtype = cur.h.y & 0xff, chrom = cur.h.x;
         if (!(cur.h.y & 0x100) || svtype == CSV_TRA) continue;    // TRA: k_genotype_tra
-        const i64 gt_bias = ((i64)cur.h.w << 32) | (unsigned)cur.h.z;
         for (int i = lane_id(); i < HASH; i += 64) tab[i] = -1;
         const i64 s0 = cur.s0, ns = cur.s1 - s0;
         int filled = 0;
@@ -2077,28 +2430,39 @@ template <int HASH, int WPB> __global__ __launch_bounds__(64 * WPB) void k_genot
         const i64 r0 = B.reads_off[chrom], r1 = B.reads_off[chrom + 1];
         int dr = 0;
         if (!overflow) {
-            if (svtype == CSV_DEL || svtype == CSV_INS) {
-                const i64 p = cur.search, g = gt_bias;                          // INDEL:450-451
-                i64 L = p - g; if (L < 0) L = 0;
-                dr = cover_window<HASH>(B, tab, r0, r1, 2 * L, 2 * (p + g), filled, overflow);
-            } else {
-                i64 nb = gt_bias;
-                const i64 b1 = cur.b1, b2 = cur.b2;
-                if (svtype == CSV_DUP && b2 - b1 < nb) nb = b2 - b1;            // DUP:147
-                i64 L2 = 2 * b1 - nb; if (L2 < 0) L2 = 0;                       // DUP:148-151, INV:219-221
-                dr = cover_window<HASH>(B, tab, r0, r1, L2, 2 * b1 + nb, filled, overflow);
-                L2 = 2 * b2 - nb; if (L2 < 0) L2 = 0;
-                if (!overflow) dr += cover_window<HASH>(B, tab, r0, r1, L2, 2 * b2 + nb, filled, overflow);   // union: DUP:155-157
-            }
+            i64 L2[2], R2[2];
+            const int nw = gt_windows(cur, L2, R2);
+            dr = cover_window<HASH>(B, V, tab, r0, r1, L2[0], R2[0], filled, overflow);
+            if (nw == 2 && !overflow) dr += cover_window<HASH>(B, V, tab, r0, r1, L2[1], R2[1], filled, overflow);
         }
         if (overflow) {                                                       // wave-uniform
-            if (lane_id() == 0) {
-                if (second) atomicOr(&B.cnt->error, ERR_COVER_OVERFLOW);
-                else B.gt_over[atomicAdd(&B.cnt->n_gt_over, 1)] = c;
-            }
+            if (!second) { if (lane_id() == 0) B.gt_over[atomicAdd(&B.cnt->n_gt_over, 1)] = c; continue; }
+            // deeper than the 32 KB tables: this wavefront's slice of the global pool ...
+            const i64 slice = B.gt_pool_n / nwaves;
+            if (!genotype_global(B, V, cur, B.gt_pool + (i64)wave * slice, slice, lane_id(), 64, false, s_red) && lane_id() == 0)
+                B.gt_huge[atomicAdd(&B.cnt->n_gt_huge, 1)] = c;               // ... or, later, the whole pool
             continue;
         }
-        if (lane_id() == 0) { B.o_dr[c] = dr; B.o_dv[c] = (int)ns; B.o_gl[c] = gl_index_dev(dr, ns); }
+        if (lane_id() == 0) ((int4*)&B.o_rec[c])[4] = make_int4(dr, (int)ns, gl_index_dev(dr, ns), 0);
+    }
+    if (!second) return;
+    // the last workgroup to get here owns the whole pool (every other one is done with its slice) and finishes the
+    // calls that needed more than a slice, one at a time
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        s_last = atomicAdd(&B.cnt->gt_ticket, 1) == (int)gridDim.x - 1;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    if (!s_last) return;
+    const int nh = __hip_atomic_load(&B.cnt->n_gt_huge, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int q = 0; q < nh; q++) {
+        GtHead H;
+        gt_load_call(B, __hip_atomic_load(&B.gt_huge[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), H);
+        if (!genotype_global(B, V, H, B.gt_pool, B.gt_pool_n, threadIdx.x, 64 * WPB, WPB > 1, s_red) && threadIdx.x == 0)
+            atomicOr(&B.cnt->error, ERR_COVER_OVERFLOW);                      // (cannot happen: the pool is sized for any call of the batch)
     }
 }
 
@@ -2109,6 +2473,8 @@ template <int HASH, int WPB> __global__ __launch_bounds__(64 * WPB) void k_genot
 // read); here a chunk of 64 reads is classified at once, the running counters become ballot prefixes and the
 // first lane at which either exit fires ends the scan; only lanes up to it are committed to the set.
 //   table entry flags: 1 = read supports the call (read_id_list), 2 = read is in querydata
+// The set lives in LDS (4096 slots) and, for calls with more than ~3000 supports + spanning reads, in the global pool
+// (same slice / whole-pool scheme as k_genotype).
 constexpr int TG_HASH = 4096;                        // slots per wavefront (ids + flags: 32 KB of LDS)
 
 // first index in [lo, hi) at which pred turns false (pred is true on a prefix); 64-ary search
@@ -2127,15 +2493,16 @@ template <class P> __device__ __forceinline__ i64 partition_point_wave(i64 lo, i
     return lo + __popcll(__ballot(idx < hi && pred(idx < hi ? idx : lo)));
 }
 
-// slot of id in the table, inserting it (flags 0) when absent; `fresh` = 1 when this call created the entry
-__device__ __forceinline__ int tg_find_or_insert(int* ids, int id, int& fresh)
+// slot of id in the table of 2^bits entries, inserting it (flags 0) when absent; `fresh` = 1 when this call created the entry
+__device__ __forceinline__ int tg_find_or_insert(int* ids, int bits, int id, int& fresh)
 {
-    unsigned h = ((unsigned)id * 2654435761u) >> (32 - __builtin_ctz(TG_HASH));
+    const unsigned mask = (1u << bits) - 1u;
+    unsigned h = ((unsigned)id * 2654435761u) >> (32 - bits);
     for (;;) {
         const int old = atomicCAS(&ids[h], -1, id);
         if (old == -1) { fresh = 1; return (int)h; }
         if (old == id) { fresh = 0; return (int)h; }
-        h = (h + 1) & (TG_HASH - 1);
+        h = (h + 1) & mask;
     }
 }
 
@@ -2148,24 +2515,25 @@ __device__ __forceinline__ i64 tra_up_bound(i64 num)     // threshold_ref_count,
 }
 
 // one count_coverage() call; returns the status (0 / 1 / -1).  nq / dr / filled are wave-uniform running totals.
-__device__ __forceinline__ int tra_window(const DevBatch& B, int* ids, int* fl, int chrom, i64 s, i64 e, i64 up_bound, i64 itround,
+__device__ __forceinline__ int tra_window(const DevBatch& B, const ReadsView& V, int* ids, int* fl, int bits, int chrom, i64 s, i64 e, i64 up_bound, i64 itround,
                                           i64& nq, int& dr, int& filled, bool& overflow)
 {
     if (s >= e) return 0;
+    const i64 limit = (3ll << bits) / 4;
     const i64 r0 = B.reads_off[chrom], r1 = B.reads_off[chrom + 1];
-    const i64 hi = partition_point_wave(r0, r1, [&](i64 i) { return B.r_start[i] < e; });      // fetch(): start < e ...
+    const i64 hi = partition_point_wave(r0, r1, [&](i64 i) { return V.start[i] < e; });        // fetch(): start < e ...
     const i64 lo = partition_point_wave(r0, hi, [&](i64 i) { return B.r_pmax[i] <= s; });      // ... and end > s
     i64 iteration = 0, primary = 0;
     const u64 le = lanemask_lt() | (1ull << lane_id());
     for (i64 base = lo; base < hi; base += 64) {
-        if (filled + 64 > TG_HASH * 3 / 4) { overflow = true; return 0; }
+        if (filled + 64 > limit) { overflow = true; return 0; }
         const i64 i = base + lane_id();
         const bool in = i < hi;
         const i64 ii = in ? i : lo;
-        const i64 rs = B.r_start[ii], re = B.r_end[ii];
-        const int id = B.r_id[ii];
+        const i64 rs = V.start[ii], re = V.end[ii];
+        const int id = V.id[ii];
         const bool ov = in && re > s;                                          // GT:76-77
-        const bool prim = ov && B.r_primary[ii] == 1;                          // GT:78-80
+        const bool prim = ov && V.primary[ii] == 1;                            // GT:78-80
         const bool span = prim && rs < s && re > e;                            // GT:81
         // a name that occurs twice among the chunk's spanning reads counts at its first occurrence
         bool dup = false;
@@ -2176,7 +2544,7 @@ __device__ __forceinline__ int tra_window(const DevBatch& B, int* ids, int* fl, 
             if (span && lane_id() > j && id == idj) dup = true;
         }
         int fresh = 0, slot = 0;
-        if (span && !dup) slot = tg_find_or_insert(ids, id, fresh);
+        if (span && !dup) slot = tg_find_or_insert(ids, bits, id, fresh);
         filled += __popcll(__ballot(fresh));
         const int flags = (span && !dup && !fresh) ? fl[slot] : 0;
         const bool isnew = span && !dup && !(flags & 2);
@@ -2201,56 +2569,96 @@ __device__ __forceinline__ int tra_window(const DevBatch& B, int* ids, int* fl, 
     return 0;
 }
 
+// one TRA call with its set in ids / fl (2^bits slots each); returns false when the set overflowed (nothing written)
+__device__ bool tra_call(const DevBatch& B, const ReadsView& V, int c, int* ids, int* fl, int bits)
+{
+    const CallRec rec = B.o_rec[c];
+    const csv_segment& sg = B.seg[rec.seg];
+    const int chr1 = sg.chrom, chr2 = rec.aux >> 3;
+    if (chr2 < 0 || chr2 >= B.n_chrom) { if (lane_id() == 0) atomicOr(&B.cnt->error, ERR_TRA_CHROM); return true; }
+    const i64 T = 1ll << bits, limit = (3ll << bits) / 4;
+    for (i64 i = lane_id(); i < T; i += 64) { ids[i] = -1; fl[i] = 0; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    const i64 s0 = rec.supoff, ns = rec.support;
+    int filled = 0;
+    bool overflow = false;
+    for (i64 base = 0; base < ns && !overflow; base += 64) {           // read_id_list: flag 1
+        if (filled + 64 > limit) { overflow = true; break; }
+        const i64 i = base + lane_id();
+        int fresh = 0;
+        if (i < ns) { const int slot = tg_find_or_insert(ids, bits, B.o_suprid[s0 + i], fresh); fl[slot] = 1; }
+        filled += __popcll(__ballot(fresh));
+    }
+    const i64 up_bound = tra_up_bound(ns);                             // TRA:266
+    const i64 bias = sg.gt_bias;
+    i64 nq = 0;
+    int dr = 0, status = 0;
+    if (!overflow) {
+        i64 s = rec.bp1 - bias, e = rec.bp1 + bias;                   // TRA:263-264
+        if (s < 0) s = 0;
+        if (e > B.contig_len[chr1]) e = B.contig_len[chr1];
+        status = tra_window(B, V, ids, fl, bits, chr1, s, e, up_bound, sg.gt_round, nq, dr, filled, overflow);
+        if (status == 0 && !overflow) {                               // TRA:289-299 (status_2 is not looked at)
+            s = rec.bp2 - bias; e = rec.bp2 + bias;
+            if (s < 0) s = 0;
+            if (e > B.contig_len[chr2]) e = B.contig_len[chr2];
+            tra_window(B, V, ids, fl, bits, chr2, s, e, up_bound, sg.gt_round, nq, dr, filled, overflow);
+        }
+    }
+    if (overflow) return false;
+    if (lane_id() == 0)                                                 // status -1: TRA:276-281
+        ((int4*)&B.o_rec[c])[4] = status == -1 ? make_int4(-1, (int)ns, -1, 0) : make_int4(dr, (int)ns, gl_index_dev(dr, ns), 0);
+    return true;
+}
+
+// table bits that surely hold a TRA call: supports + at most up_bound querydata names per window + one chunk
+__device__ __forceinline__ int tra_bits_for(i64 ns)
+{
+    const i64 need = ns + 2 * (tra_up_bound(ns) + 64) + 128;
+    int bits = 10;
+    while ((3ll << bits) / 4 < need + 64) bits++;
+    return bits;
+}
+
 __global__ __launch_bounds__(64) void k_genotype_tra(DevBatch B)
 {
     __shared__ int ids[TG_HASH];
     __shared__ int fl[TG_HASH];
+    __shared__ int s_last;
+    const ReadsView V = reads_view(B);
     const int n = B.cnt->n_calls;
+    const i64 slice = B.gt_pool_n / gridDim.x;          // (the pool is free: k_genotype ran before this kernel)
     for (int c0 = blockIdx.x * 64; c0 < n; c0 += gridDim.x * 64) {
         // 64 calls per round: the lanes look for genotyped TRA calls, the wavefront then takes them one by one
         const int cl = c0 + lane_id();
         bool mine = false;
-        if (cl < n) { const csv_segment& g = B.seg[B.o_seg[cl]]; mine = g.svtype == CSV_TRA && g.genotype; }
+        if (cl < n) mine = B.o_rec[cl].type_gt == (CSV_TRA | 0x100);
         for (u64 todo = __ballot(mine); todo;) {
             const int c = c0 + __builtin_amdgcn_readfirstlane(__builtin_ctzll(todo));
             todo &= todo - 1;
-            const csv_segment& sg = B.seg[B.o_seg[c]];
-            const int chr1 = sg.chrom, chr2 = B.o_aux[c] >> 3;
-            if (chr2 < 0 || chr2 >= B.n_chrom) { if (lane_id() == 0) atomicOr(&B.cnt->error, ERR_TRA_CHROM); continue; }
-            for (int i = lane_id(); i < TG_HASH; i += 64) { ids[i] = -1; fl[i] = 0; }
-            const i64 s0 = B.o_supoff[c], ns = B.o_supoff[c + 1] - s0;
-            int filled = 0;
-            bool overflow = false;
-            for (i64 base = 0; base < ns && !overflow; base += 64) {           // read_id_list: flag 1
-                if (filled + 64 > TG_HASH * 3 / 4) { overflow = true; break; }
-                const i64 i = base + lane_id();
-                int fresh = 0;
-                if (i < ns) { const int slot = tg_find_or_insert(ids, B.o_suprid[s0 + i], fresh); fl[slot] = 1; }
-                filled += __popcll(__ballot(fresh));
-            }
-            const i64 up_bound = tra_up_bound(ns);                             // TRA:266
-            const i64 bias = sg.gt_bias;
-            i64 nq = 0;
-            int dr = 0, status = 0;
-            if (!overflow) {
-                i64 s = B.o_bp1[c] - bias, e = B.o_bp1[c] + bias;             // TRA:263-264
-                if (s < 0) s = 0;
-                if (e > B.contig_len[chr1]) e = B.contig_len[chr1];
-                status = tra_window(B, ids, fl, chr1, s, e, up_bound, sg.gt_round, nq, dr, filled, overflow);
-                if (status == 0 && !overflow) {                               // TRA:289-299 (status_2 is not looked at)
-                    s = B.o_bp2[c] - bias; e = B.o_bp2[c] + bias;
-                    if (s < 0) s = 0;
-                    if (e > B.contig_len[chr2]) e = B.contig_len[chr2];
-                    tra_window(B, ids, fl, chr2, s, e, up_bound, sg.gt_round, nq, dr, filled, overflow);
-                }
-            }
-            if (overflow) { if (lane_id() == 0) atomicOr(&B.cnt->error, ERR_COVER_OVERFLOW); continue; }
-            if (lane_id() == 0) {
-                B.o_dv[c] = (int)ns;
-                if (status == -1) { B.o_dr[c] = -1; B.o_gl[c] = -1; }          // TRA:276-281
-                else { B.o_dr[c] = dr; B.o_gl[c] = gl_index_dev(dr, ns); }
-            }
+            if (tra_call(B, V, c, ids, fl, 12)) continue;
+            // more names than the LDS set holds: this workgroup's slice of the global pool, or the whole pool later
+            const int bits = tra_bits_for(B.o_rec[c].support);
+            if ((2ll << bits) <= slice && bits <= 30) {
+                int* g = B.gt_pool + (i64)blockIdx.x * slice;
+                if (!tra_call(B, V, c, g, g + (1ll << bits), bits) && lane_id() == 0) atomicOr(&B.cnt->error, ERR_COVER_OVERFLOW);
+            } else if (lane_id() == 0) B.gt_huge[atomicAdd(&B.cnt->n_tra_huge, 1)] = c;
         }
+    }
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        s_last = atomicAdd(&B.cnt->tra_ticket, 1) == (int)gridDim.x - 1;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    if (!s_last) return;
+    const int nh = __hip_atomic_load(&B.cnt->n_tra_huge, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int q = 0; q < nh; q++) {
+        const int c = __hip_atomic_load(&B.gt_huge[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int bits = tra_bits_for(B.o_rec[c].support);
+        if ((2ll << bits) > B.gt_pool_n || bits > 30 || !tra_call(B, V, c, B.gt_pool, B.gt_pool + (1ll << bits), bits))
+            if (lane_id() == 0) atomicOr(&B.cnt->error, ERR_COVER_OVERFLOW);   // (cannot happen: the pool is sized for any call of the batch)
     }
 }
 

@@ -49,7 +49,10 @@ class Context:
             raise CsvError(rc, (lib().csv_last_error(self._h) or b"").decode())
 
     # ---- resident mode
-    def upload(self, batch):
+    def upload(self, batch, per_sig=None):
+        """per_sig: also produce cluster_id / allele_id (CSV_IN_PER_SIG); None keeps the batch's own flag"""
+        if per_sig is not None:
+            batch.c.flags = (batch.c.flags & ~_abi.IN_PER_SIG) | (_abi.IN_PER_SIG if per_sig else 0)
         self._check(lib().csv_batch_upload(self._h, C.byref(batch.c)))
         self._batch = batch
 
@@ -74,12 +77,16 @@ class Context:
         self._check(lib().csv_measure_copy_bandwidth(self._h, int(nbytes), int(reps), C.byref(out)))
         return float(out.value)
 
+    def cache_flush(self, nbytes=1 << 30):
+        """evict L2 / Infinity Cache (a measurement aid: the next run reads its columns from HBM)"""
+        self._check(lib().csv_cache_flush(self._h, int(nbytes)))
+
     def download(self, per_sig=False, cap_calls=None, cap_support=None):
         n = self._batch.n_sig
         cap_calls = cap_calls or max(64, n // 16 + 16)
         cap_support = cap_support or max(64, n // 2 + 16)
         for _ in range(2):
-            res = _abi.HostResult(n, cap_calls, cap_support, per_sig=per_sig)
+            res = _abi.HostResult(n, cap_calls, cap_support, per_sig=per_sig, n_seg=len(self._batch.segments))
             rc = lib().csv_batch_download(self._h, C.byref(res.c))
             if rc == _abi.E_CAPACITY:            # required sizes were filled in: re-allocate and retry
                 cap_calls, cap_support = res.n_calls + 1, res.n_support + 1
@@ -88,12 +95,70 @@ class Context:
             return res
         raise CsvError(_abi.E_CAPACITY, "capacity retry failed")
 
-    # ---- one shot
-    def cluster_batch(self, batch, per_sig=False):
-        self.upload(batch)
-        self.run()
-        return self.download(per_sig=per_sig)
+    # ---- one shot: csv_cluster_batch (H2D, kernels and D2H overlap inside the one call)
+    def cluster_batch(self, batch, per_sig=False, cap_calls=None, cap_support=None):
+        n = batch.n_sig
+        cap_calls = cap_calls or max(64, n // 16 + 16)
+        cap_support = cap_support or max(64, n // 2 + 16)
+        self._batch = batch
+        for _ in range(2):
+            res = _abi.HostResult(n, cap_calls, cap_support, per_sig=per_sig, n_seg=len(batch.segments))
+            rc = lib().csv_cluster_batch(self._h, C.byref(batch.c), C.byref(res.c))
+            if rc == _abi.E_CAPACITY:            # required sizes were filled in: re-allocate and retry
+                cap_calls, cap_support = res.n_calls + 1, res.n_support + 1
+                continue
+            self._check(rc)
+            return res
+        raise CsvError(_abi.E_CAPACITY, "capacity retry failed")
 
 
 def stage_names():
     return [lib().csv_stage_name(i).decode() for i in range(_abi.N_STAGES)]
+
+
+# ---- page-locked host memory (csv_host_alloc / csv_host_register): columns that live in it reach the GPU by DMA
+class _PinnedBlock:
+    def __init__(self, nbytes):
+        p = C.c_void_p()
+        rc = lib().csv_host_alloc(int(nbytes), C.byref(p))
+        if rc != _abi.OK:
+            raise CsvError(rc, "csv_host_alloc(%d) failed" % nbytes)
+        self.ptr, self.nbytes = p.value, int(nbytes)
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                lib().csv_host_free(C.c_void_p(self.ptr))
+                self.ptr = None
+        except Exception:
+            pass
+
+
+def pinned_empty(shape, dtype):
+    """numpy array in page-locked host memory (freed when the array and its views are gone)"""
+    import numpy as np
+    dtype = np.dtype(dtype)
+    n = int(np.prod(shape)) if not isinstance(shape, int) else int(shape)
+    blk = _PinnedBlock(max(1, n * dtype.itemsize))
+    buf = (C.c_char * blk.nbytes).from_address(blk.ptr)
+    buf._csv_block = blk                      # the array's base is `buf`; the block lives exactly as long
+    return np.frombuffer(buf, dtype=dtype, count=n).reshape(shape)
+
+
+def pinned_copy(arr):
+    """copy of `arr` in page-locked host memory"""
+    import numpy as np
+    arr = np.ascontiguousarray(arr)
+    out = pinned_empty(arr.shape, arr.dtype)
+    out[...] = arr
+    return out
+
+
+def host_register(arr):
+    """page-lock an existing contiguous numpy array in place; returns True on success (keep the array alive and
+    call host_unregister before it is freed)"""
+    return lib().csv_host_register(C.c_void_p(arr.ctypes.data), int(arr.nbytes)) == _abi.OK
+
+
+def host_unregister(arr):
+    return lib().csv_host_unregister(C.c_void_p(arr.ctypes.data)) == _abi.OK

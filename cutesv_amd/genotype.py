@@ -56,3 +56,16 @@ def gl_fields(idx):
         hit = _SPECIAL.get(idx) or _likelihood_fields(idx // 101, idx % 101)
         _table[idx] = hit
     return hit
+
+
+def gl_table_blob(keys):
+    """the strings of the table rows in `keys` as csv_rows_emit wants them: (blob, offsets[TABLE_SIZE + 1]) with
+    'GT\tPL\tGQ\tQUAL' per listed row and empty entries elsewhere"""
+    off = np.zeros(TABLE_SIZE + 1, np.int64)
+    parts, lens = [], np.zeros(TABLE_SIZE, np.int64)
+    for k in sorted(int(x) for x in keys):
+        sfx = "\t".join(gl_fields(k)).encode()
+        parts.append(sfx)
+        lens[k] = len(sfx)
+    np.cumsum(lens, out=off[1:])
+    return b"".join(parts), off

@@ -62,10 +62,8 @@ def run_batch(store, segments, tasks, ctx=None):
             kw["contig_len"] = store.contig_len
     hb = _abi.HostBatch(segs, store.a, store.b, store.read_id, store.aux, n_chrom=len(store.chroms), **kw)
     res = ctx.cluster_batch(hb)
-    out = {t: [] for t in tasks}
-    for k, row in rows_mod.materialise(store, hb.segments, res.trimmed()):
-        out[tasks[k]].append(row)
-    return out
+    per_seg = rows_mod.rows_by_segment(store, hb.segments, res)
+    return {t: per_seg[k] for k, t in enumerate(tasks)}
 
 
 def cluster_stage(store, params, tasks=None, ctx=None):

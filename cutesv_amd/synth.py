@@ -367,3 +367,53 @@ def reference_sequence(length, seed=0):
     rng = np.random.default_rng(seed)
     alphabet = np.frombuffer(b"ACGT" * 12 + b"RYSWKMBDHVN", dtype=np.uint8)
     return alphabet[rng.integers(0, len(alphabet), length)].tobytes().decode()
+
+
+def extraction_order(store, seed=7, region=10_000_000, workers=16):
+    """The same store with its reads table in the order cuteSV's extraction + rebuild steps leave it (main script
+    :697-735, :810, :1040-1093): the genome is cut into `region`-sized tasks, each pool worker appends the batches it
+    happened to process to its own file (a batch = the reads that START in the region, in BAM order), and the rebuild
+    step concatenates the workers' files and sorts stably by chromosome only.  Inside a chromosome the block is thus a
+    permutation of disjoint, start-sorted runs.  Returns (store, row permutation applied)."""
+    import dataclasses
+    if store.reads_off is None:
+        return store, None
+    rng = np.random.default_rng(seed)
+    off = store.reads_off
+    perm = np.arange(store.n_reads, dtype=np.int64)
+    for c in range(len(store.chroms)):
+        lo, hi = int(off[c]), int(off[c + 1])
+        if hi - lo < 2:
+            continue
+        task = store.r_start[lo:hi] // region                   # batch of every read
+        n_task = int(task.max()) + 1
+        worker = rng.integers(0, workers, n_task)                # which worker took the batch ...
+        when = rng.permutation(n_task)                           # ... and when (order inside its file)
+        key = worker[task] * n_task + when[task]
+        perm[lo:hi] = lo + np.argsort(key, kind="stable")
+    st = dataclasses.replace(store, r_start=store.r_start[perm], r_end=store.r_end[perm],
+                             r_primary=store.r_primary[perm], r_id=store.r_id[perm])
+    return st, perm
+
+
+def concat_stores(x, y, suffix="b"):
+    """Two synthetic stores as one genome: y's chromosomes are renamed (name + suffix) and its read ids shifted past
+    x's.  Used to put a pathological locus (e.g. a 10 000x pile-up) next to ordinary ones in one batch."""
+    shift = int(max(x.read_id.max(initial=-1), -1 if x.r_id is None else x.r_id.max(initial=-1))) + 1
+    chroms = list(x.chroms) + [c + suffix for c in y.chroms]
+    nx = len(x.chroms)
+    y_aux = y.aux.copy()
+    seg_index = dict(x.seg_index)
+    for (t, c), (b, e) in y.seg_index.items():
+        seg_index[(t, c + suffix)] = (b + x.n_sig, e + x.n_sig)
+        if t == "TRA":                                   # aux = chr2 * 8 + type: chr2 moves with the renaming
+            y_aux[b:e] = ((y.aux[b:e] >> 3) + nx) * 8 + (y.aux[b:e] & 7)
+    kw = {}
+    if x.reads_off is not None and y.reads_off is not None:
+        kw = dict(reads_off=np.concatenate([x.reads_off, x.reads_off[-1] + y.reads_off[1:]]),
+                  r_start=np.concatenate([x.r_start, y.r_start]), r_end=np.concatenate([x.r_end, y.r_end]),
+                  r_primary=np.concatenate([x.r_primary, y.r_primary]), r_id=np.concatenate([x.r_id, y.r_id + shift]).astype(np.int32))
+    cl = None if x.contig_len is None or y.contig_len is None else np.concatenate([x.contig_len, y.contig_len])
+    return SigStore(chroms=chroms, a=np.concatenate([x.a, y.a]), b=np.concatenate([x.b, y.b]),
+                    read_id=np.concatenate([x.read_id, y.read_id + shift]).astype(np.int32), aux=np.concatenate([x.aux, y_aux]).astype(np.int32),
+                    seg_index=seg_index, names=NameTable(), contig_len=cl, **kw)

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CSV_ABI_VERSION 2
+#define CSV_ABI_VERSION 3
 
 /* SV types: one (chromosome, type) pair is one segment == one reference pool task
  * (MAIN:1116-1189).  Order of the enum is irrelevant to results. */
@@ -40,7 +40,8 @@ enum {
     CSV_E_CAPACITY = 2,  /* output arrays too small; n_calls / n_support hold the need */
     CSV_E_HIP = 3,       /* a HIP runtime call failed; see csv_last_error */
     CSV_E_NOMEM = 4,
-    CSV_E_UNSORTED = 5,  /* reads table of some chromosome is not sorted by start */
+    CSV_E_UNSORTED = 5,  /* csv_batch_validate: a segment is not in the rebuild order; or CSV_IN_READS_SORTED was promised
+                            and a reads block is not sorted by start */
     CSV_E_STATE = 6      /* run/download without a preceding upload */
 };
 
@@ -81,8 +82,18 @@ typedef struct csv_segment {
  *   aux      INS: len(inserted sequence) | INV: strand code | TRA: chr2_rank*8 + BND type code (A..D = 0..3,
  *            codes 4..7 = any other BND type:
  *            the library emits nothing for it, TRA:154-155) | DEL/DUP: ignored
- * Reads table (MAIN:733): one block per chromosome, sorted by r_start inside the block.
+ * Reads table (MAIN:733): one block per chromosome (reads_off), rows in ANY order inside a block — the reference's
+ * block is the concatenation of per-worker extraction batches, stably sorted by chromosome only (MAIN:810), and
+ * overlap_cover sorts its sweep events itself (GT:101-109).  csv_batch_run brings every block into stable start order
+ * on the device (stage "reads_order": whole sorted runs are moved when the block is a permutation of disjoint sorted
+ * runs, which is what MAIN:697-735 produces; a general stable radix sort otherwise).  CSV_IN_READS_SORTED skips that.
  */
+enum {
+    CSV_IN_PER_SIG = 1,       /* also produce the per-signature outputs cluster_id / allele_id (csv_batch_download may
+                                 then be given those arrays); without it the kernels skip 8 B of stores per signature */
+    CSV_IN_READS_SORTED = 2   /* caller's promise: every reads block is already sorted by r_start (checked on the
+                                 device: CSV_E_UNSORTED if not) */
+};
 typedef struct csv_batch_in {
     int32_t            n_seg;
     int32_t            n_chrom;
@@ -100,6 +111,8 @@ typedef struct csv_batch_in {
     const int32_t*     r_id;
     const int64_t*     contig_len;  /* n_chrom reference lengths (bamfile.get_reference_length, TRA:264,291); NULL unless a
                                        TRA segment genotypes */
+    int32_t            flags;       /* CSV_IN_* */
+    int32_t            reserved;
 } csv_batch_in;
 
 /*
@@ -125,10 +138,15 @@ typedef struct csv_batch_in {
  *   MAIN:711-733).  count_coverage's give-up status (-1) is dr = -1, gl_idx = -1 ("./.", DR ".").
  * support_off/support_sig: CSR list of the signatures whose read names form the call's
  *   read list, in reference order where that order is deterministic.
- * cluster_id / allele_id: optional per-signature outputs (NULL to skip): dense id of the
- *   chained cluster a signature belongs to, and the index of the call (0-based, global)
- *   it supports or -1.
+ * cluster_id / allele_id: optional per-signature outputs (NULL to skip; they need CSV_IN_PER_SIG on the batch,
+ *   csv_cluster_batch sets it by itself when either array is given): dense id of the chained cluster a signature
+ *   belongs to, and the index of the call (0-based, global) it supports or -1.
+ * seg_status: optional (NULL to skip) n_seg words of CSV_SEG_* bits.  The reference has no size limits
+ *   (INDEL:110-136, GT:95-159) and neither has this library; the only per-segment condition left is a length / pos2
+ *   value outside [0, 2^42) (the clusters holding one emit nothing, every other cluster of the batch is unaffected;
+ *   main_ctrl swallows a failing task the same way, MAIN:1193-1199).
  */
+enum { CSV_SEG_KEY_RANGE = 1 };
 typedef struct csv_batch_out {
     int64_t  cap_calls;
     int64_t  cap_support;
@@ -152,12 +170,13 @@ typedef struct csv_batch_out {
     int64_t* support_sig;   /* cap_support */
     int32_t* cluster_id;    /* n_sig or NULL */
     int32_t* allele_id;     /* n_sig or NULL */
+    int32_t* seg_status;    /* n_seg or NULL */
 } csv_batch_out;
 
 /* Per-kernel device timings of one csv_batch_run, measured with HIP events recorded on the
  * context's stream around every launch (only when stats != NULL; the plain run records nothing).
  * Kernel names: csv_stage_name(i); unused slots are 0. */
-#define CSV_N_STAGES 16
+#define CSV_N_STAGES 24
 typedef struct csv_run_stats {
     float   ms_total;
     float   ms_stage[CSV_N_STAGES];
@@ -171,6 +190,10 @@ typedef struct csv_run_stats {
 typedef struct csv_ctx csv_ctx;
 
 int         csv_abi_version(void);
+/* sizeof() of the ABI's structs as this library was compiled (which: 0 csv_segment, 1 csv_batch_in, 2 csv_batch_out,
+ * 3 csv_run_stats, 4 csv_rebuild_in, 5 csv_rebuild_out, 6 csv_vcf_in, 7 csv_rows_in; -1 otherwise): lets a binding
+ * check its own mirror of the layouts at load time. */
+int         csv_struct_size(int which);
 int         csv_device_count(int* n);
 int         csv_ctx_create(int device_id, csv_ctx** out);
 void        csv_ctx_destroy(csv_ctx* ctx);
@@ -190,6 +213,15 @@ int csv_batch_run(csv_ctx* ctx, csv_run_stats* stats /* nullable */);
 int csv_batch_download(csv_ctx* ctx, csv_batch_out* out);
 int csv_ctx_sync(csv_ctx* ctx);
 
+/* Page-locked host memory.  Columns that live in it (or in a registered caller buffer) travel to the GPU by DMA
+ * straight from the caller's pages; anything else is staged by the HIP runtime at roughly half the PCIe rate.  No
+ * counterpart in the reference (its pool workers unpickle tuples, INDEL:52-58).  csv_host_alloc needs no context; the
+ * memory is usable from every context of the process. */
+int  csv_host_alloc(int64_t bytes, void** out);
+void csv_host_free(void* p);
+int  csv_host_register(void* p, int64_t bytes);
+int  csv_host_unregister(void* p);
+
 /* Optional check of the input order contract on the uploaded batch: inside every segment the rows must be
  * strictly increasing in the reference's rebuild sort key (cuteSV main script :764-802; adjacent duplicates
  * removed, :958-969).  Returns CSV_E_UNSORTED otherwise.  One pass over the columns; not part of csv_batch_run. */
@@ -198,6 +230,10 @@ int csv_batch_validate(csv_ctx* ctx);
 /* Measurement aid (bench.py's roofline object): device-to-device copy bandwidth of this GPU, read + write bytes
  * over the best of `reps` hipMemcpyAsync calls of `bytes` bytes, in GB/s.  No counterpart in the reference. */
 int csv_measure_copy_bandwidth(csv_ctx* ctx, int64_t bytes, int reps, double* gb_per_s);
+/* Measurement aid: evict the GPU's caches (per-XCD L2s and the 256 MiB Infinity Cache) by overwriting a scratch buffer of
+ * `bytes` bytes on the context's stream (allocated on first use), so that the next csv_batch_run finds its columns in
+ * HBM only: the "cold" figures of bench.py.  No counterpart in the reference. */
+int csv_cache_flush(csv_ctx* ctx, int64_t bytes);
 
 /* cal_GL's domain after its special cases and rescale_read_counts (GT:25-37): returns the
  * table index the device writes into gl_idx for (DR, DV) = (c0, c1).  Host-side helper so
@@ -283,6 +319,42 @@ typedef struct csv_vcf_in {
  * *n_written = the needed size.  svid[5] = running record counters in the order INS, DEL, BND, DUP, INV
  * (main script :1209-1213); pass zeros for a fresh file, they are advanced in place. */
 int csv_vcf_emit(const csv_vcf_in* in, char* out, int64_t cap, int64_t* n_written, int64_t* svid);
+
+/* ---------------------------------------------------------------------------------------------
+ * Host-side row builder: the structure-of-arrays result -> the row lists the reference's resolvers return
+ * (DEL 13 fields INDEL:207-219 / 464-478, INS 14 INDEL:419-432, DUP 11 DUP:121-131 / 170-180, INV 12 INV:145-156 /
+ * 240-251, TRA 12 TRA:171-182), as ONE text blob: fields separated by '\t', rows terminated by '\n', rows in call
+ * order (row c belongs to segment res->call_seg[c]).  All numeric fields are decimal text, read names joined by ','
+ * exactly as the reference's rows hold them.  The Python shim splits the blob once (cutesv_amd/rows.py); any other
+ * host language can do the same.  No GPU work: plain C++ on the caller's thread.
+ */
+typedef struct csv_rows_in {
+    const csv_batch_out* res;
+    const csv_segment*   seg;
+    int32_t              n_seg;
+    int32_t              n_chrom;
+    const char* const*   chrom_name;     /* n_chrom */
+    const int32_t*       read_id;        /* the batch's read_id column (support_sig indexes it) */
+    const int32_t*       aux;            /* the batch's aux column (length of a synthetic inserted sequence) */
+    /* read names: a table (blob + n_names + 1 offsets) or, when name_blob is NULL, "<name_prefix><id zero-padded to
+     * name_width digits>" (the naming scheme of the synthetic workloads) */
+    const char*          name_blob;
+    const int64_t*       name_off;
+    int64_t              n_names;
+    const char*          name_prefix;
+    int32_t              name_width;
+    int32_t              n_strand;
+    /* inserted sequences by global signature index (blob + n_sig + 1 offsets); NULL = "ACGT" repeated to aux[sig] */
+    const char*          ins_blob;
+    const int64_t*       ins_off;
+    const char* const*   strand_name;    /* INV: call_aux -> strand text */
+    /* cal_GL's strings per table row: CSV_GL_TABLE_SIZE entries "GT\tPL\tGQ\tQUAL" as blob + offsets */
+    const char*          gl_blob;
+    const int64_t*       gl_off;
+} csv_rows_in;
+
+/* Writes the rows into `out` (capacity `cap`) and returns CSV_OK, or CSV_E_CAPACITY with *n_written = the need. */
+int csv_rows_emit(const csv_rows_in* in, char* out, int64_t cap, int64_t* n_written);
 
 #ifdef __cplusplus
 }

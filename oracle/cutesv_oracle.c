@@ -125,6 +125,9 @@ typedef struct {
     int32_t* ids2;
     /* reads: prefix max of r_end per chromosome block */
     int64_t* pmax;
+    /* start-ordered copy of the reads table (when the caller's blocks are not sorted) */
+    csv_batch_in in_sorted;
+    int64_t* s_start; int64_t* s_end; uint8_t* s_primary; int32_t* s_id;
 } work_t;
 
 static int ensure(work_t* w, int64_t m)
@@ -209,7 +212,8 @@ static int64_t call_begin(work_t* w, int32_t seg, int32_t cluster, int32_t aux)
     if (c < o->cap_calls) {
         o->call_seg[c] = seg;
         o->call_cluster[c] = cluster;
-        o->call_aux[c] = aux;
+        /* aux is not part of a DEL / DUP signature ("ignored", include/cutesv_hip.h): reported as 0 */
+        o->call_aux[c] = (w->in->seg[seg].svtype == CSV_DEL || w->in->seg[seg].svtype == CSV_DUP) ? 0 : aux;
         o->bp1[c] = 0; o->bp2[c] = 0; o->support[c] = 0; o->cipos[c] = 0; o->cilen[c] = 0;
         o->search_pos[c] = 0; o->seq_pick[c] = -1; o->dr[c] = -1; o->dv[c] = -1; o->gl_idx[c] = -1;
         o->support_off[c] = w->n_support;
@@ -532,6 +536,13 @@ static int refine(work_t* w, const csv_segment* sg, int32_t seg_i, int32_t cid, 
      * the reference's [0,0,''] sentinel: the cluster is skipped (INDEL:63-64) */
     if (e - s < sg->read_count) return CSV_OK;
     if (in->a[e - 1] == 0 && in->b[e - 1] == 0) return CSV_OK;
+    /* the build's only per-segment condition (csv_batch_out.seg_status): a length / pos2 value that no genome produces,
+     * outside [0, 2^42) ([0, 2^32) inside a chained cluster of more than 2^21 signatures).  The cluster emits nothing. */
+    {
+        const int bits = (e - s) > (1 << 21) ? 32 : 42;
+        for (int64_t i = s; i < e; i++)
+            if (((uint64_t)in->b[i]) >> bits) { if (w->out->seg_status) w->out->seg_status[seg_i] |= CSV_SEG_KEY_RANGE; return CSV_OK; }
+    }
     switch (sg->svtype) {
     case CSV_DEL: case CSV_INS: return refine_indel(w, sg, seg_i, cid, s, e);
     case CSV_DUP: return refine_dup(w, sg, seg_i, cid, s, e);
@@ -647,6 +658,36 @@ static int genotype_all(work_t* w)
     int any = 0;
     for (int32_t k = 0; k < in->n_seg; k++) any |= in->seg[k].genotype;
     if (!any || !in->reads_off) return CSV_OK;
+    /* overlap_cover sorts its events itself (GT:101-109) and count_coverage walks the BAM in start order: bring every
+     * block into STABLE start order first (the order of equal starts is the order of the block) */
+    {
+        int sorted = 1;
+        for (int32_t ch = 0; ch < in->n_chrom && sorted; ch++)
+            for (int64_t i = in->reads_off[ch] + 1; i < in->reads_off[ch + 1]; i++)
+                if (in->r_start[i] < in->r_start[i - 1]) { sorted = 0; break; }
+        if (!sorted) {
+            if (in->flags & CSV_IN_READS_SORTED) return CSV_E_UNSORTED;
+            const int64_t R = in->n_reads;
+            int64_t* perm = (int64_t*)malloc((size_t)(R + 1) * sizeof(int64_t));
+            int64_t* tmp = (int64_t*)malloc((size_t)(R + 1) * sizeof(int64_t));
+            w->s_start = (int64_t*)malloc((size_t)(R + 1) * sizeof(int64_t));
+            w->s_end = (int64_t*)malloc((size_t)(R + 1) * sizeof(int64_t));
+            w->s_primary = (uint8_t*)malloc((size_t)(R + 1));
+            w->s_id = (int32_t*)malloc((size_t)(R + 1) * sizeof(int32_t));
+            if (!perm || !tmp || !w->s_start || !w->s_end || !w->s_primary || !w->s_id) { free(perm); free(tmp); return CSV_E_NOMEM; }
+            for (int64_t i = 0; i < R; i++) perm[i] = i;
+            for (int32_t ch = 0; ch < in->n_chrom; ch++)
+                msort_i64(perm + in->reads_off[ch], tmp, in->reads_off[ch + 1] - in->reads_off[ch], in->r_start);
+            for (int64_t i = 0; i < R; i++) {
+                const int64_t p = (i >= in->reads_off[0] && i < in->reads_off[in->n_chrom]) ? perm[i] : i;
+                w->s_start[i] = in->r_start[p]; w->s_end[i] = in->r_end[p]; w->s_primary[i] = in->r_primary[p]; w->s_id[i] = in->r_id[p];
+            }
+            free(perm); free(tmp);
+            w->in_sorted = *in;
+            w->in_sorted.r_start = w->s_start; w->in_sorted.r_end = w->s_end; w->in_sorted.r_primary = w->s_primary; w->in_sorted.r_id = w->s_id;
+            w->in = in = &w->in_sorted;
+        }
+    }
     w->pmax = (int64_t*)malloc((size_t)(in->n_reads + 1) * sizeof(int64_t));
     if (!w->pmax) return CSV_E_NOMEM;
     for (int32_t ch = 0; ch < in->n_chrom; ch++) {
@@ -718,6 +759,7 @@ int csvo_cluster_batch(const csv_batch_in* in, csv_batch_out* out)
     w.in = in; w.out = out;
     int rc = CSV_OK;
     int32_t cid = -1;
+    if (out->seg_status) for (int32_t k = 0; k < in->n_seg; k++) out->seg_status[k] = 0;
     if (out->allele_id) for (int64_t i = 0; i < in->n_sig; i++) out->allele_id[i] = -1;
     if (out->cluster_id) for (int64_t i = 0; i < in->n_sig; i++) out->cluster_id[i] = -1;
     for (int32_t k = 0; k < in->n_seg && rc == CSV_OK; k++) {
@@ -753,6 +795,7 @@ int csvo_cluster_batch(const csv_batch_in* in, csv_batch_out* out)
     out->n_support = w.n_support;
     free(w.idx); free(w.idx2); free(w.tmp); free(w.vals); free(w.vals2); free(w.dev); free(w.sq);
     free(w.ids); free(w.ids2); free(w.pmax);
+    free(w.s_start); free(w.s_end); free(w.s_primary); free(w.s_id);
     return rc;
 }
 

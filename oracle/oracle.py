@@ -43,7 +43,7 @@ def cluster_batch(batch, per_sig=True, cap_calls=None, cap_support=None):
     cap_calls = cap_calls or max(64, n // 8 + 16)
     cap_support = cap_support or max(64, n + 16)
     for _ in range(2):
-        res = _abi.HostResult(n, cap_calls, cap_support, per_sig=per_sig)
+        res = _abi.HostResult(n, cap_calls, cap_support, per_sig=per_sig, n_seg=len(batch.segments))
         rc = lib().csvo_cluster_batch(C.byref(batch.c), C.byref(res.c))
         if rc == _abi.E_CAPACITY:
             cap_calls, cap_support = res.n_calls + 1, res.n_support + 1

@@ -15,9 +15,8 @@ from oracle import oracle                                       # noqa: E402
 def stage(store, params, tasks):
     hb = store.host_batch(tasks, params)
     res = oracle.cluster_batch(hb)
-    by = {t: [] for t in tasks}
-    for k, row in rows_mod.materialise(store, hb.segments, res.trimmed()):
-        by[tasks[k]].append(row)
+    per_seg = rows_mod.rows_by_segment(store, hb.segments, res)
+    by = {t: per_seg[k] for k, t in enumerate(tasks)}
     out = {}
     for t in TYPES:
         for (tt, ch) in tasks:

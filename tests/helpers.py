@@ -55,9 +55,13 @@ def rows_by_task(store, params, engine, tasks=None):
     tasks = tasks or store.tasks()
     hb = store.host_batch(tasks, params)
     res = engine(hb)
-    out = {t: [] for t in tasks}
-    for k, row in rows_mod.materialise(store, hb.segments, res.trimmed()):
-        out[tasks[k]].append(row)
+    per_seg = rows_mod.rows_by_segment(store, hb.segments, res)      # native row builder (csv_rows_emit + _rowsplit)
+    out = {t: per_seg[k] for k, t in enumerate(tasks)}
+    # ... which must say exactly what the plain Python statement of the row layouts says
+    plain = {t: [] for t in tasks}
+    for k, row in rows_mod.materialise_py(store, hb.segments, res.trimmed()):
+        plain[tasks[k]].append(row)
+    assert plain == out, "native rows differ from rows.materialise_py"
     return out, res, hb
 
 

@@ -127,6 +127,95 @@ def test_chain_tile_edges(ctx, n):
     assert got["n_clusters"] >= 1
 
 
+def test_deep_pileup_next_to_ordinary_loci(ctx):
+    """No depth limit (the reference has none, cuteSV_genotype.py:95-159): a 12 000x pile-up - clusters of ~10 k
+    signatures, cover sets of ~12 k reads, far beyond the 32 KB LDS tables - in one batch with ordinary 30x loci.
+    The deep calls take the global-memory hash tables; every call of the batch equals the oracle's."""
+    base = synth.small_mixed(seed=5, coverage=30, n_contigs=2, contig_len=1_000_000)
+    pile = synth.small_mixed(seed=6, coverage=12000, n_sites=3, n_contigs=2, contig_len=40_000, n_noise=0, n_loci=0, dup_frac=0.02)
+    st = synth.concat_stores(base, pile)
+    got = _compare_soa(ctx, st, Params(genotype=True, min_support=10, max_cluster_bias_DEL=200))
+    tot = got["dr"].astype(np.int64) + got["dv"]
+    assert tot.max() > 10000, tot.max()
+    assert (got["seg_status"] == 0).all()
+
+
+def test_key_range_is_a_per_segment_status(ctx):
+    """a length outside [0, 2^42) silences its own cluster and flags its segment; every other call is untouched"""
+    st = synth.small_mixed(seed=31, genotype=False)
+    p = Params.ont()
+    ref = ctx.cluster_batch(st.host_batch(st.tasks(), p)).trimmed()
+    tasks = st.tasks()
+    k_bad = tasks.index(("DEL", "2"))
+    victim = int(ref["support_sig"][ref["support_off"][np.flatnonzero(ref["call_seg"] == k_bad)[0]]])
+    st.b[victim] = 1 << 45
+    got = _compare_soa(ctx, st, p)
+    assert got["seg_status"][k_bad] == _abi.SEG_KEY_RANGE and got["seg_status"].sum() == _abi.SEG_KEY_RANGE
+    assert len(got["bp1"]) == len(ref["bp1"]) - (1 if True else 0) or len(got["bp1"]) < len(ref["bp1"])
+
+
+def test_reads_table_in_extraction_order(ctx):
+    """the reads block as cuteSV's extraction leaves it (a permutation of disjoint sorted runs, main script :697-735,
+    :810): ordered on the device inside the run; an arbitrary shuffle takes the general sort; both give the rows of the
+    start-sorted table; a false CSV_IN_READS_SORTED promise is refused"""
+    st = synth.small_mixed(seed=91, n_sites=60, coverage=40, contig_len=2_000_000)
+    p = Params.ont(genotype=True, genotype_tra=True, min_support=3)
+    want = ctx.cluster_batch(st.host_batch(st.tasks(), p), per_sig=True).trimmed()
+    runs, _ = synth.extraction_order(st, region=150_000, workers=5)
+    assert (np.diff(runs.r_start) < 0).sum() > 20
+    got = _compare_soa(ctx, runs, p)
+    assert_soa_equal(got, want)
+    rng = np.random.default_rng(3)
+    import dataclasses
+    perm = np.arange(st.n_reads)
+    for c in range(len(st.chroms)):
+        lo, hi = int(st.reads_off[c]), int(st.reads_off[c + 1])
+        perm[lo:hi] = lo + rng.permutation(hi - lo)
+    shuf = dataclasses.replace(st, r_start=st.r_start[perm], r_end=st.r_end[perm], r_primary=st.r_primary[perm], r_id=st.r_id[perm])
+    # DEL / INS / DUP / INV genotypes are set-valued (order free); TRA's count_coverage walks in stable start order,
+    # which a shuffle of equal starts may change: compare it through the oracle on the same shuffled table
+    _compare_soa(ctx, shuf, p)
+    hb = shuf.host_batch(shuf.tasks(), p)
+    hb.c.flags |= _abi.IN_READS_SORTED
+    with pytest.raises(engine.CsvError) as e:
+        ctx.cluster_batch(hb)
+    assert e.value.code == _abi.E_UNSORTED
+    hb2 = st.host_batch(st.tasks(), p)
+    hb2.c.flags |= _abi.IN_READS_SORTED                    # a true promise skips the ordering stage
+    assert_soa_equal(ctx.cluster_batch(hb2, per_sig=True).trimmed(), want)
+
+
+def test_two_contexts_shard_one_genome(ctx):
+    """chromosomes sharded over two contexts (one per GPU in production; both on device 0 here) through the HIP path:
+    merged rows == the unsharded stage's (main script :1191-1197 is the merge)"""
+    from cutesv_amd import resolve, shard
+    st = synth.small_mixed(seed=12, n_contigs=5, contig_len=800_000)
+    p = Params.ont(genotype=True)
+    other = engine.Context(0)
+    try:
+        parts = [resolve.cluster_stage(st, p, tasks=shard.tasks_of_rank(st, r, 2, genotype=True), ctx=c) for r, c in ((0, ctx), (1, other))]
+    finally:
+        other.close()
+    merged = shard.merge_results(parts)
+    full = resolve.cluster_stage(st, p, ctx=ctx)
+    assert set(merged) == set(full) and all(merged[c] == full[c] for c in full)
+
+
+def test_pinned_columns_and_native_rows(ctx):
+    """columns in page-locked memory give the same calls; csv_rows_emit's blob splits into the same rows as the
+    CPython builder"""
+    from cutesv_amd import rows as rows_mod
+    st = synth.small_mixed(seed=8)
+    p = Params.ont(genotype=True)
+    pst = st.pinned()
+    hb, phb = st.host_batch(st.tasks(), p), pst.host_batch(pst.tasks(), p)
+    a, b = ctx.cluster_batch(hb, per_sig=True), ctx.cluster_batch(phb, per_sig=True)
+    assert_soa_equal(b.trimmed(), a.trimmed())
+    rows, _ = rows_mod.materialise(st, hb.segments, a)
+    blob, n = rows_mod.rows_blob(st, hb.segments, a)
+    assert rows_mod._native().split(blob, n) == rows and n == len(rows) > 0
+
+
 def test_genotype_cover_overflow_pass(ctx):
     # ~1000x coverage: support + cover of a call exceeds the 4 KB hash set, so the second (32 KB) pass runs
     st = synth.small_mixed(seed=78, n_sites=6, coverage=1000, n_noise=100, n_loci=20, contig_len=200_000, n_contigs=2)
@@ -177,7 +266,7 @@ def test_full_size_partition_and_rerun_properties(ctx, cfg):
 
     def per_segment(tk):
         hb = st.host_batch(tk, p)
-        ctx.upload(hb)
+        ctx.upload(hb, per_sig=True)
         ctx.run(); r1 = ctx.download().trimmed()
         ctx.run(); r2 = ctx.download().trimmed()
         for k in ("bp1", "bp2", "support", "cipos", "cilen", "search_pos", "seq_pick", "dr", "dv", "gl_idx", "support_off", "support_sig", "call_seg"):
