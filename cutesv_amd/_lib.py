@@ -26,6 +26,7 @@ SYMBOLS = [
     ("csv_batch_run", C.c_int, [C.c_void_p, C.POINTER(_abi.RunStats)]),
     ("csv_batch_download", C.c_int, [C.c_void_p, C.POINTER(_abi.BatchOut)]),
     ("csv_ctx_sync", C.c_int, [C.c_void_p]),
+    ("csv_batch_reads_mode", C.c_int, [C.c_void_p]),
     ("csv_batch_validate", C.c_int, [C.c_void_p]),
     ("csv_gl_index", C.c_int32, [C.c_int64, C.c_int64]),
     ("csv_host_alloc", C.c_int, [C.c_int64, C.POINTER(C.c_void_p)]),

@@ -285,6 +285,8 @@ int csv_ctx_sync(csv_ctx* c)
 
 int csv_batch_upload(csv_ctx* c, const csv_batch_in* in) { return upload_impl(c, in, false, true); }
 
+int csv_batch_reads_mode(const csv_ctx* c) { return (c && c->uploaded && c->n_reads > 0) ? c->B.ro_mode : -1; }
+
 }  // extern "C"
 
 namespace {
@@ -484,6 +486,7 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
         if (reorder) {
             B.s_start = dp<i64>(c->s_start); B.s_end = dp<i64>(c->s_end); B.s_primary = dp<uint8_t>(c->s_primary); B.s_id = dp<int>(c->s_id);
             B.ro_runs = dp<int>(c->ro_runs); B.ro_table = dp<int4>(c->ro_table); B.ro_cap = RO_CAP;
+            B.ro_gap = env_int("CSV_READS_GAP", 1000000);      // (tests shrink it together with their task regions)
         }
     }
     B.sqrt_tab = dp<double>(c->sqrt_tab); B.cnt = dp<DevCounters>(c->cnt);
@@ -662,6 +665,10 @@ int read_counters(csv_ctx* c)
         HIP_TRY(c, hipMemcpyAsync(c->h_pin, c->cnt.p, sizeof(DevCounters), hipMemcpyDeviceToHost, st));
         HIP_TRY(c, hipStreamSynchronize(st));
         memcpy(&c->h_cnt, c->h_pin, sizeof(DevCounters));
+        if (getenv("CSV_DEBUG"))
+            fprintf(stderr, "[csv] counters: clusters %d items %d calls %d error %d | reads: mode %d runs %d state %d | gt_over %d gt_huge %d tra_huge %d\n",
+                    c->h_cnt.n_clusters, c->h_cnt.n_items, c->h_cnt.n_calls, c->h_cnt.error, c->B.ro_mode, c->h_cnt.n_runs, c->h_cnt.ro_state,
+                    c->h_cnt.n_gt_over, c->h_cnt.n_gt_huge, c->h_cnt.n_tra_huge);
         if (c->B.ro_mode == 1 && c->B.n_reads > 0 && c->any_genotype && c->h_cnt.ro_state == RO_NEED_GENERAL && attempt == 0) {
             c->reads_general = true;
             c->B.ro_mode = 2;

@@ -121,6 +121,7 @@ struct DevBatch {
     int*           ro_runs;          // run starts found by k_reads_runs (unordered)
     int4*          ro_table;         // runs in start order: {source begin, length, destination begin, chromosome}
     int            ro_cap;           // capacity of both
+    i64            ro_gap;           // a jump of more than this many bases between neighbours also starts a run
     const int*     ro_perm;          // mode 2: sorted position -> uploaded row
     int*           gt_huge;          // calls whose sets overflow the 32 KB tables AND one wavefront's slice of the global pool
     int*           gt_pool;          // global hash pool: gt_pool_n ints, power of two
@@ -1978,17 +1979,27 @@ __device__ __forceinline__ int chrom_of_read(const DevBatch& B, i64 i, int hint)
 }
 
 constexpr int RO_TILE = 256 * 8;
+// A row starts a run when its start is smaller than its predecessor's (a descent) or jumps ahead by more than ro_gap.
+// The second rule cuts the runs the extraction step glued together: a worker that processed the task regions 3 and then 7
+// of a chromosome leaves them back to back without a descent, although the regions 4-6 (in other workers' files)
+// belong in between; such a seam is at least one task region wide (--batches, 10 Mbp by default), ro_gap is 1 Mbp.
+// The rule is only a heuristic for WHERE to cut - k_reads_plan verifies that the pieces do not interleave once
+// ordered, and anything else goes to the general sort.  (Block starts are added by k_reads_plan.)
 __global__ __launch_bounds__(256) void k_reads_runs(DevBatch B)
 {
     const i64 base = (i64)blockIdx.x * RO_TILE + (threadIdx.x >> 6) * 512;
-    int hint = 0;
+    if (base >= B.n_reads) return;
+    i64 v[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) { const i64 i = base + r * 64 + lane_id(); v[r] = i < B.n_reads ? B.r_start[i] : INT64_MAX; }
+    i64 carry = (lane_id() == 0 && base > 0) ? B.r_start[base - 1] : INT64_MIN;
+#pragma unroll
     for (int r = 0; r < 8; r++) {
         const i64 i = base + r * 64 + lane_id();
-        bool st = false;
-        if (i < B.n_reads) {
-            hint = chrom_of_read(B, i, hint);
-            st = i == B.reads_off[hint] || B.r_start[i] < B.r_start[i - 1];
-        }
+        i64 prev = wave_shr1_i64(v[r]);
+        if (lane_id() == 0) prev = carry;
+        carry = readlane_i64x(v[r], 63);
+        const bool st = i < B.n_reads && i > 0 && prev != INT64_MIN && (v[r] < prev || v[r] - prev > B.ro_gap);
         const u64 mk = __ballot(st);
         if (mk) {                                          // wave-aggregated append (order is restored by k_reads_plan)
             int slot = 0;
@@ -2020,22 +2031,43 @@ template <class T> __device__ __forceinline__ void lds_bitonic(T* K, int P)
 __global__ __launch_bounds__(RP_THREADS) void k_reads_plan(DevBatch B)
 {
     extern __shared__ __attribute__((aligned(16))) char rp_smem[];
-    const int n_raw = B.cnt->n_runs;
-    if (n_raw > B.ro_cap) { if (threadIdx.x == 0) B.cnt->ro_state = RO_NEED_GENERAL; return; }
-    const int n = n_raw;
+    const int n_found = B.cnt->n_runs;
+    // + one start per chromosome block (an empty block repeats its neighbour's start: duplicates are dropped below)
+    const int n_raw = n_found + B.n_chrom;
+    if (n_found > B.ro_cap || n_raw > B.ro_cap) { if (threadIdx.x == 0) B.cnt->ro_state = RO_NEED_GENERAL; return; }
     int P = 1;
-    while (P < n) P <<= 1;
+    while (P < n_raw) P <<= 1;
     u64* K = (u64*)rp_smem;                    // P sort keys
     int* pos = (int*)(K + P);                  // run starts by position (+ sentinel)
     int* len_s = pos + P + 1;                  // lengths in start order, then their exclusive scan
     __shared__ int s_bad, s_moved, s_carry;
     __shared__ int s_w[RP_THREADS / 64];
-    if (threadIdx.x == 0) { s_bad = 0; s_moved = 0; s_carry = 0; }
-    for (int i = threadIdx.x; i < P; i += RP_THREADS) K[i] = i < n ? (u64)(unsigned)B.ro_runs[i] : PAD_KEY;
+    __shared__ int s_n;
+    if (threadIdx.x == 0) { s_bad = 0; s_moved = 0; s_carry = 0; s_n = 0; }
+    for (int i = threadIdx.x; i < P; i += RP_THREADS) {
+        u64 key = PAD_KEY;
+        if (i < n_found) key = (u64)(unsigned)B.ro_runs[i];
+        else if (i < n_raw) { const i64 o = B.reads_off[i - n_found]; key = o < B.n_reads ? (u64)o : PAD_KEY; }
+        K[i] = key;
+    }
     __syncthreads();
     lds_bitonic(K, P);                                      // by position
-    for (int i = threadIdx.x; i < n; i += RP_THREADS) pos[i] = (int)K[i];
-    if (threadIdx.x == 0) pos[n] = (int)B.n_reads;
+    // distinct positions, compacted in order (one thread: a few hundred entries)
+    if (threadIdx.x == 0) {
+        int m = 0;
+        for (int i = 0; i < n_raw; i++) {
+            const u64 k = K[i];
+            if (k == PAD_KEY) break;
+            if (m == 0 || (u64)(unsigned)pos[m - 1] != k) pos[m++] = (int)k;
+        }
+        pos[m] = (int)B.n_reads;
+        s_n = m;
+    }
+    __syncthreads();
+    const int n = s_n;
+    if (threadIdx.x == 0) B.cnt->n_runs = n;                 // (k_reads_gather walks the table)
+    P = 1;
+    while (P < n) P <<= 1;
     __syncthreads();
     // key (chromosome, first start, rank by position): chromosome 20 bits | start 32 bits | rank 12 bits.  A block start
     // is always a run start, so a run lies inside one chromosome.
@@ -2153,8 +2185,13 @@ template <bool CHECK> __device__ __forceinline__ i64 pm_value(const DevBatch& B,
     return ((i64)hint << PM_SHIFT) | e;
 }
 
+// (a batch whose reads table turned out to need the general sort is run again by the host: nothing downstream of the
+// reads_order stage does any work in the first attempt)
+__device__ __forceinline__ bool reads_pending(const DevBatch& B) { return B.ro_mode == 1 && B.cnt->ro_state == RO_NEED_GENERAL; }
+
 __global__ __launch_bounds__(256) void k_pmax_count(DevBatch B)
 {
+    if (reads_pending(B)) return;
     const ReadsView V = reads_view(B);
     const i64 base = (i64)blockIdx.x * PM_TILE + (threadIdx.x >> 6) * 512;
     i64 mx = INT64_MIN;
@@ -2172,6 +2209,7 @@ __global__ __launch_bounds__(256) void k_pmax_count(DevBatch B)
 
 __global__ __launch_bounds__(256) void k_pmax_apply(DevBatch B)
 {
+    if (reads_pending(B)) return;
     const ReadsView V = reads_view(B);
     const int wv = threadIdx.x >> 6;
     const i64 base = (i64)blockIdx.x * PM_TILE + wv * 512;
@@ -2406,6 +2444,7 @@ template <int HASH, int WPB> __global__ __launch_bounds__(64 * WPB) void k_genot
     __shared__ int tabs[WPB][HASH];
     __shared__ int s_red[WPB], s_last;
     int* tab = tabs[threadIdx.x >> 6];
+    if (reads_pending(B)) return;
     const ReadsView V = reads_view(B);
     const int n = second ? B.cnt->n_gt_over : B.cnt->n_calls;
     const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * (64 * WPB) + threadIdx.x) >> 6), nwaves = (gridDim.x * (64 * WPB)) >> 6;
@@ -2625,6 +2664,7 @@ __global__ __launch_bounds__(64) void k_genotype_tra(DevBatch B)
     __shared__ int ids[TG_HASH];
     __shared__ int fl[TG_HASH];
     __shared__ int s_last;
+    if (reads_pending(B)) return;
     const ReadsView V = reads_view(B);
     const int n = B.cnt->n_calls;
     const i64 slice = B.gt_pool_n / gridDim.x;          // (the pool is free: k_genotype ran before this kernel)

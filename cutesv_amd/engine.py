@@ -77,6 +77,10 @@ class Context:
         self._check(lib().csv_measure_copy_bandwidth(self._h, int(nbytes), int(reps), C.byref(out)))
         return float(out.value)
 
+    def last_reads_mode(self):
+        """0 promised sorted, 1 run-level reorder on the device, 2 general radix sort, -1 no reads table"""
+        return int(lib().csv_batch_reads_mode(self._h))
+
     def cache_flush(self, nbytes=1 << 30):
         """evict L2 / Infinity Cache (a measurement aid: the next run reads its columns from HBM)"""
         self._check(lib().csv_cache_flush(self._h, int(nbytes)))

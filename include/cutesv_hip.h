@@ -212,6 +212,9 @@ int csv_batch_upload(csv_ctx* ctx, const csv_batch_in* in);
 int csv_batch_run(csv_ctx* ctx, csv_run_stats* stats /* nullable */);
 int csv_batch_download(csv_ctx* ctx, csv_batch_out* out);
 int csv_ctx_sync(csv_ctx* ctx);
+/* How the reads table of the last completed run was brought into start order: 0 = the caller promised sorted blocks,
+ * 1 = whole sorted runs were moved (or nothing had to move), 2 = the general stable radix sort; -1 = no reads table. */
+int csv_batch_reads_mode(const csv_ctx* ctx);
 
 /* Page-locked host memory.  Columns that live in it (or in a registered caller buffer) travel to the GPU by DMA
  * straight from the caller's pages; anything else is staged by the HIP runtime at roughly half the PCIe rate.  No

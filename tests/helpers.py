@@ -95,7 +95,7 @@ def assert_soa_equal(got, want, store=None, set_order_segments=()):
                 assert sorted(store.read_id[x].tolist()) == sorted(store.read_id[y].tolist())
             else:
                 assert np.array_equal(x, y), "support list of call %d differs" % c
-    for f in ("cluster_id", "allele_id"):
+    for f in ("cluster_id", "allele_id", "seg_status"):
         if got.get(f) is not None and want.get(f) is not None:
             assert np.array_equal(got[f], want[f]), "%s differs" % f
 

@@ -137,7 +137,9 @@ def test_deep_pileup_next_to_ordinary_loci(ctx):
     got = _compare_soa(ctx, st, Params(genotype=True, min_support=10, max_cluster_bias_DEL=200))
     tot = got["dr"].astype(np.int64) + got["dv"]
     assert tot.max() > 10000, tot.max()
-    assert (got["seg_status"] == 0).all()
+    # (the pile-up generator leaves a few negative pos2 values in its DUP / INV segments: those clusters are silenced and
+    # their segments flagged, exactly as the oracle does - compared inside _compare_soa)
+    assert (got["seg_status"][:8] == 0).all()
 
 
 def test_key_range_is_a_per_segment_status(ctx):
@@ -154,7 +156,7 @@ def test_key_range_is_a_per_segment_status(ctx):
     assert len(got["bp1"]) == len(ref["bp1"]) - (1 if True else 0) or len(got["bp1"]) < len(ref["bp1"])
 
 
-def test_reads_table_in_extraction_order(ctx):
+def test_reads_table_in_extraction_order(ctx, monkeypatch):
     """the reads block as cuteSV's extraction leaves it (a permutation of disjoint sorted runs, main script :697-735,
     :810): ordered on the device inside the run; an arbitrary shuffle takes the general sort; both give the rows of the
     start-sorted table; a false CSV_IN_READS_SORTED promise is refused"""
@@ -163,8 +165,10 @@ def test_reads_table_in_extraction_order(ctx):
     want = ctx.cluster_batch(st.host_batch(st.tasks(), p), per_sig=True).trimmed()
     runs, _ = synth.extraction_order(st, region=150_000, workers=5)
     assert (np.diff(runs.r_start) < 0).sum() > 20
+    monkeypatch.setenv("CSV_READS_GAP", "20000")           # task regions are 150 kbp here (10 Mbp / gap 1 Mbp in production)
     got = _compare_soa(ctx, runs, p)
     assert_soa_equal(got, want)
+    assert ctx.last_reads_mode() == 1                       # ordered by moving whole runs, not by the general sort
     rng = np.random.default_rng(3)
     import dataclasses
     perm = np.arange(st.n_reads)
@@ -175,6 +179,7 @@ def test_reads_table_in_extraction_order(ctx):
     # DEL / INS / DUP / INV genotypes are set-valued (order free); TRA's count_coverage walks in stable start order,
     # which a shuffle of equal starts may change: compare it through the oracle on the same shuffled table
     _compare_soa(ctx, shuf, p)
+    assert ctx.last_reads_mode() == 2                       # the general stable radix sort
     hb = shuf.host_batch(shuf.tasks(), p)
     hb.c.flags |= _abi.IN_READS_SORTED
     with pytest.raises(engine.CsvError) as e:
