@@ -291,8 +291,8 @@ def main():
         warm_plain /= ncold
 
         # ---------------- the boundary as a drop-in sees it
-        t_one = timed(lambda: ctx.cluster_batch(phb), 5)
-        t_one_pageable = timed(lambda: ctx.cluster_batch(hb), 3)
+        t_one = timed(lambda: ctx.cluster_batch(phb, reuse=True), 7)          # (caller-owned result arrays, allocated once)
+        t_one_pageable = timed(lambda: ctx.cluster_batch(hb, reuse=True), 5)
         r2 = ctx.cluster_batch(phb)
         t_rows = timed(lambda: rows_mod.rows_by_segment(pstore, phb.segments, r2), 3)
         t_stage = timed(lambda: resolve.cluster_stage(pstore, params, tasks=tasks, ctx=ctx), 5)

@@ -123,22 +123,27 @@ class HostBatch:
 class HostResult:
     """Caller-allocated csv_batch_out plus numpy views on it."""
 
-    def __init__(self, n_sig, cap_calls, cap_support, per_sig=False, n_seg=0):
+    def __init__(self, n_sig, cap_calls, cap_support, per_sig=False, n_seg=0, alloc=None):
+        """alloc(shape, dtype) -> array: where the result arrays live (default numpy; engine.pinned_empty puts them in
+        page-locked memory, so that the device-to-host copies land in them by DMA)"""
+        empty = alloc or (lambda n, dt: np.empty(n, dtype=dt))
         self.cap_calls = int(cap_calls)
         self.cap_support = int(cap_support)
+        self.n_sig, self.n_seg, self.per_sig = int(n_sig), int(n_seg), bool(per_sig)
         self.arrays = {}
         kw = {}
         for name, dt, cap in _OUT_ARRAYS:
             if cap == "sig":
-                arr = np.empty(n_sig, dtype=dt) if per_sig else None
+                arr = empty(n_sig, dt) if per_sig else None
             elif cap == "seg":
                 arr = np.zeros(max(1, n_seg), dtype=dt)
             elif cap == "calls":
-                arr = np.empty(self.cap_calls, dtype=dt)
+                arr = empty(self.cap_calls, dt)
             elif cap == "calls+1":
-                arr = np.zeros(self.cap_calls + 1, dtype=dt)
+                arr = empty(self.cap_calls + 1, dt)
+                arr[:] = 0
             else:
-                arr = np.empty(self.cap_support, dtype=dt)
+                arr = empty(self.cap_support, dt)
             self.arrays[name] = arr
             kw[name] = _ptr(arr)
         self.c = BatchOut(cap_calls=self.cap_calls, cap_support=self.cap_support, **kw)

@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
 #include <string>
 #include <utility>
 #include <vector>
@@ -45,7 +46,7 @@ struct Plan {
 const char* kStageName[CSV_N_STAGES] = {"init", "k_chain_count", "k_chain_apply", "k_refine_indel_wave", "k_refine_wave", "k_refine_mid",
                                         "k_refine_block", "k_items_scan", "k_emit", "k_reads_order", "k_pmax_count", "k_pmax_apply",
                                         "k_genotype", "k_genotype_tra", "", "", "", "", "", "", "", "", "", ""};
-constexpr int N_COPY_STREAMS = 4;
+constexpr int N_COPY_STREAMS = 2;
 constexpr int RO_CAP = 4096;                 // sorted runs the reads_order stage plans (k_reads_plan packs the rank in 12 bits)
 
 }  // namespace
@@ -83,7 +84,7 @@ struct csv_ctx {
     std::vector<i64>         h_woff;
     bool     uploaded = false, ran = false, any_genotype = false, any_pair = false, any_tra_gt = false, lds_set = false;
     bool     reads_general = false;            // this batch's reads table needs the general sort (found out by a first run)
-    int      n_copy = 1;
+    bool     copies_pending = false;           // csv_cluster_batch: the column copies are still in flight behind ev_copy[0] / [1]
     i64      n_sig_host = 0, n_reads = 0;
     DevBatch B;
     DevCounters h_cnt;
@@ -236,9 +237,6 @@ int csv_ctx_create(int device_id, csv_ctx** out)
         hipEventCreateWithFlags(&c->ev_reads, hipEventDisableTiming) != hipSuccess) { delete c; return CSV_E_HIP; }
     for (auto& e : c->ev_aux) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { delete c; return CSV_E_HIP; }
     for (auto& e : c->ev_copy) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { delete c; return CSV_E_HIP; }
-    c->n_copy = env_int("CSV_COPY_STREAMS", N_COPY_STREAMS);
-    if (c->n_copy < 1) c->n_copy = 1;
-    if (c->n_copy > N_COPY_STREAMS) c->n_copy = N_COPY_STREAMS;
     // `num ** 0.5` of cal_CIPOS is libm pow(), not sqrt(): tabulate it with the host libm (GT:59)
     std::vector<double> tab(SQRT_TAB);
     for (int i = 0; i < SQRT_TAB; i++) tab[i] = pow((double)i, 0.5);
@@ -371,7 +369,7 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
     if (per_sig) { PL(cluster_id, (W + 1) * 4); PL(allele_id, (W + 1) * 4); }
     PL(partial, nt * 4); PL(partial64, nt * 8); PL(tile_prev, nt * 8); PL(partial_t, nt * 4);
     PL(ch_masks, nt * 4 * 2 * CH_ITEMS * 8); PL(ch_ku, nt * 4 * 4);
-    PL(item_rec, cap_items * 16); PL(list_small, cap_items * 4); PL(list_big, cap_items * 4); PL(list_tiny, cap_items * 4);
+    PL(item_rec, cap_items * 16); PL(list_small, cap_items * 16); PL(list_big, cap_items * 4); PL(list_tiny, cap_items * 16);
     PL(item_nslots, cap_items * 4); PL(item_cnt, cap_items * 8); PL(item_base, (cap_items + 8) * 8);
     // temp call records are indexed by w (a cluster's slots live in its own signature range)
     PL(t_bp1, (W + 1) * 8); PL(t_bp2, (W + 1) * 8); PL(t_search, (W + 1) * 8); PL(t_pick, (W + 1) * 8);
@@ -410,36 +408,41 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
     HIP_TRY(c, hipMemcpyAsync(c->seg_gate.p, c->h_pin + o_gate, (size_t)(S + 1) * 16, hipMemcpyHostToDevice, st));
     HIP_TRY(c, hipMemsetAsync(c->seg_err.p, 0, (size_t)(S + 1) * 4, st));
 
-    // ---- columns.  Segments whose source ranges are adjacent travel as one copy; aux is not read for DEL / DUP
-    // segments (include/cutesv_hip.h) and is zero-filled on the device instead of crossing PCIe.
-    const int NC = c->n_copy;
-    int rr = 0;
-    auto cs = [&]() -> hipStream_t { hipStream_t s2 = c->copy[rr % NC]; rr++; return s2; };
+    // ---- columns, on the copy stream, in two groups: what the chain kernels read (positions, lengths / pos2, the strand
+    // and chr2 words of INV / TRA segments), then what only the refine kernels read (read ids, INS sequence lengths).  In a
+    // one-shot call the chain kernels start when the first group has landed and run under the second.  Segments whose
+    // source ranges are adjacent travel as one copy; aux is not read for DEL / DUP segments (include/cutesv_hip.h) and is
+    // zero-filled on the device instead of crossing PCIe.  (One stream: a second DMA engine adds nothing on this link -
+    // scripts/micro/h2d_bw.hip measures 57 GB/s with 1, 2, 4 or 8 streams, from page-locked and pageable memory alike.)
+    hipStream_t cs = c->copy[0];
     HIP_TRY(c, hipMemsetAsync(c->aux.p, 0, (size_t)(W + 1) * 4, st));
     HIP_TRY(c, hipEventRecord(c->ev_init, st));
-    for (int q = 0; q < NC; q++) HIP_TRY(c, hipStreamWaitEvent(c->copy[q], c->ev_init, 0));   // (the memset above, and whatever ran before)
-    for (int k = 0; k < S;) {
-        int e = k;
-        while (e + 1 < S && c->h_seg[e + 1].sig_begin == c->h_seg[e].sig_end) e++;
-        const i64 src = c->h_seg[k].sig_begin, n = c->h_woff[e + 1] - c->h_woff[k], dst = c->h_woff[k];
-        if (n > 0) {
-            HIP_TRY(c, hipMemcpyAsync(dp<i64>(c->a) + dst, in->a + src, n * 8, hipMemcpyHostToDevice, cs()));
-            HIP_TRY(c, hipMemcpyAsync(dp<i64>(c->b) + dst, in->b + src, n * 8, hipMemcpyHostToDevice, cs()));
-            HIP_TRY(c, hipMemcpyAsync(dp<int>(c->rid) + dst, in->read_id + src, n * 4, hipMemcpyHostToDevice, cs()));
-            // aux: runs of segments that need it
-            for (int q = k; q <= e;) {
-                const bool need = c->h_seg[q].svtype == CSV_INS || c->h_seg[q].svtype == CSV_INV || c->h_seg[q].svtype == CSV_TRA;
-                int q2 = q;
-                while (q2 + 1 <= e && ((c->h_seg[q2 + 1].svtype == CSV_INS || c->h_seg[q2 + 1].svtype == CSV_INV || c->h_seg[q2 + 1].svtype == CSV_TRA) == need)) q2++;
-                const i64 na = c->h_woff[q2 + 1] - c->h_woff[q];
-                if (need && na > 0)
-                    HIP_TRY(c, hipMemcpyAsync(dp<int>(c->aux) + c->h_woff[q], in->aux + c->h_seg[q].sig_begin, na * 4, hipMemcpyHostToDevice, cs()));
-                q = q2 + 1;
+    HIP_TRY(c, hipStreamWaitEvent(cs, c->ev_init, 0));      // (the memset above, and whatever ran before)
+    auto aux_kind = [&](int q) { const int t = c->h_seg[q].svtype; return t == CSV_INS ? 2 : (t == CSV_INV || t == CSV_TRA) ? 1 : 0; };
+    for (int group = 1; group <= 2; group++) {
+        for (int k = 0; k < S;) {
+            int e = k;
+            while (e + 1 < S && c->h_seg[e + 1].sig_begin == c->h_seg[e].sig_end) e++;
+            const i64 src = c->h_seg[k].sig_begin, n = c->h_woff[e + 1] - c->h_woff[k], dst = c->h_woff[k];
+            if (n > 0) {
+                if (group == 1) {
+                    HIP_TRY(c, hipMemcpyAsync(dp<i64>(c->a) + dst, in->a + src, n * 8, hipMemcpyHostToDevice, cs));
+                    HIP_TRY(c, hipMemcpyAsync(dp<i64>(c->b) + dst, in->b + src, n * 8, hipMemcpyHostToDevice, cs));
+                } else HIP_TRY(c, hipMemcpyAsync(dp<int>(c->rid) + dst, in->read_id + src, n * 4, hipMemcpyHostToDevice, cs));
+                for (int q = k; q <= e;) {                  // aux: runs of segments of this group's kind
+                    int q2 = q;
+                    while (q2 + 1 <= e && aux_kind(q2 + 1) == aux_kind(q)) q2++;
+                    const i64 na = c->h_woff[q2 + 1] - c->h_woff[q];
+                    if (aux_kind(q) == group && na > 0)
+                        HIP_TRY(c, hipMemcpyAsync(dp<int>(c->aux) + c->h_woff[q], in->aux + c->h_seg[q].sig_begin, na * 4, hipMemcpyHostToDevice, cs));
+                    q = q2 + 1;
+                }
             }
+            k = e + 1;
         }
-        k = e + 1;
+        HIP_TRY(c, hipEventRecord(c->ev_copy[group - 1], cs));
     }
-    for (int q = 0; q < NC; q++) { HIP_TRY(c, hipEventRecord(c->ev_copy[q], c->copy[q])); HIP_TRY(c, hipStreamWaitEvent(st, c->ev_copy[q], 0)); }
+    c->copies_pending = true;                               // run_impl orders the kernels behind the two events
     // reads table: its own stream (side[2] runs the reads_order / prefix-max kernels behind it)
     hipStream_t sr = c->side[2];
     if (have_tab) {
@@ -455,7 +458,11 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
     }
     // (the main stream does not wait for the reads table: the kernels that read it are ordered behind this event)
     if (have_tab) HIP_TRY(c, hipEventRecord(c->ev_reads, sr));
-    if (sync) { HIP_TRY(c, hipStreamSynchronize(st)); if (have_tab) HIP_TRY(c, hipStreamSynchronize(sr)); }
+    if (sync) {
+        HIP_TRY(c, hipStreamSynchronize(st)); HIP_TRY(c, hipStreamSynchronize(cs));
+        if (have_tab) HIP_TRY(c, hipStreamSynchronize(sr));
+        c->copies_pending = false;
+    }
 
     DevBatch& B = c->B;
     memset(&B, 0, sizeof B);
@@ -465,7 +472,7 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
     B.per_sig = per_sig ? 1 : 0;
     B.cluster_id = per_sig ? dp<int>(c->cluster_id) : nullptr; B.allele_id = per_sig ? dp<int>(c->allele_id) : nullptr;
     B.partial = dp<int>(c->partial); B.partial64 = dp<i64>(c->partial64);
-    B.item_rec = dp<int4>(c->item_rec); B.list_small = dp<int>(c->list_small); B.list_big = dp<int>(c->list_big); B.list_tiny = dp<int>(c->list_tiny);
+    B.item_rec = dp<int4>(c->item_rec); B.list_small = dp<int4>(c->list_small); B.list_big = dp<int>(c->list_big); B.list_tiny = dp<int4>(c->list_tiny);
     B.tile_prev = dp<int2>(c->tile_prev); B.partial_t = dp<int>(c->partial_t); B.seg_gate = dp<int4>(c->seg_gate);
     B.ch_masks = dp<u64>(c->ch_masks); B.ch_ku = dp<int>(c->ch_ku); B.seg_err = dp<int>(c->seg_err);
     B.tiny_max = getenv("CSV_NO_TINY") ? 0 : 16;               // (timing aid: 0 sends every DEL/INS cluster of m <= 32 through the paired path)
@@ -562,7 +569,7 @@ int run_impl(csv_ctx* c, csv_run_stats* stats)
     // that every kernel is timed alone.
     // (forking costs a few event waits: only worth it when the batch has pair types or genotyping)
     const bool do_gt = c->any_genotype && B.n_reads > 0;
-    const bool fork = !stats && !dbg && !getenv("CSV_NO_FORK") && (c->any_pair || do_gt);
+    const bool fork = !stats && !dbg && !getenv("CSV_NO_FORK") && (c->any_pair || do_gt || getenv("CSV_FORK_ALWAYS"));
     hipStream_t sB = fork ? c->side[0] : st, sC = fork ? c->side[1] : st, sD = fork ? c->side[2] : st;
 #define LAUNCH_ON(strm, name, kern, grid, block, lds, ...)                             \
     do {                                                                               \
@@ -588,6 +595,7 @@ int run_impl(csv_ctx* c, csv_run_stats* stats)
         LAUNCH_ON(s2, "pmax_apply", k_pmax_apply, nr, 256, 0, B);
         return CSV_OK;
     };
+    if (c->copies_pending) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_copy[0], 0));       // positions, lengths, INV / TRA words
     if (W > 0) {
         const int nb = div_up(W, CH_TILE);
         LAUNCH("chain_count", k_chain_count, nb, 320, 0, B);
@@ -599,9 +607,12 @@ int run_impl(csv_ctx* c, csv_run_stats* stats)
             HIP_TRY(c, hipEventRecord(c->ev_aux[2], sD));
         }
         LAUNCH("chain_apply", k_chain_apply, nb, 256, 0, B);
+        if (c->copies_pending) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_copy[1], 0));   // read ids, INS sequence lengths
         int g_small = B.cap_items < 8192 ? B.cap_items : 8192;
         if (g_small < 1) g_small = 1;
-        int g_iw = div_up(B.cap_items, 4) < 2048 ? div_up(B.cap_items, 4) : 2048;
+        // (3072 workgroups = 12 288 wavefronts: a 30x genome has ~10 k units, and a wavefront with two units is the
+        // kernel's tail - 2048 workgroups measured 42.5 us, 3072 and 4096 38.6 us, 1280 - the resident set - 48 us)
+        int g_iw = div_up(B.cap_items, 4) < 3072 ? div_up(B.cap_items, 4) : 3072;
         g_iw = env_int("CSV_IW_GRID", g_iw);              // tuning aid
         if (g_iw < 1) g_iw = 1;
         if (fork) {
@@ -639,6 +650,7 @@ int run_impl(csv_ctx* c, csv_run_stats* stats)
     }
 #undef LAUNCH
 #undef LAUNCH_ON
+    if (c->copies_pending) { HIP_TRY(c, hipStreamWaitEvent(st, c->ev_copy[1], 0)); c->copies_pending = false; }   // (empty batch)
     HIP_TRY(c, hipGetLastError());
     c->ran = true;
     if (stats) {
@@ -772,11 +784,10 @@ int csv_batch_download(csv_ctx* c, csv_batch_out* out)
     const size_t nc = (size_t)k.n_calls, ns = (size_t)k.n_support;
     const DevBatch& B = c->B;
     const int S = (int)c->h_seg.size();
-    const size_t o_rec = 256, o_sup = o_rec + ((nc * sizeof(CallRec) + 255) & ~(size_t)255), o_err = o_sup + ((ns * 8 + 255) & ~(size_t)255),
-                 o_end = o_err + (size_t)(S + 1) * 4;
+    const size_t o_rec = 256, o_err = o_rec + ((nc * sizeof(CallRec) + 255) & ~(size_t)255), o_end = o_err + (size_t)(S + 1) * 4;
     if (o_end > c->h_pin_cap) { const int rc = pin_reserve(c, o_end); if (rc) return rc; }
     if (nc) HIP_TRY(c, hipMemcpyAsync(c->h_pin + o_rec, B.o_rec, nc * sizeof(CallRec), hipMemcpyDeviceToHost, st));
-    if (ns) HIP_TRY(c, hipMemcpyAsync(c->h_pin + o_sup, B.o_supsig, ns * 8, hipMemcpyDeviceToHost, st));
+    if (ns) HIP_TRY(c, hipMemcpyAsync(out->support_sig, B.o_supsig, ns * 8, hipMemcpyDeviceToHost, st));    // (already in its final layout)
     if (S) HIP_TRY(c, hipMemcpyAsync(c->h_pin + o_err, B.seg_err, (size_t)S * 4, hipMemcpyDeviceToHost, st));
     if (out->cluster_id) memset(out->cluster_id, 0xff, (size_t)c->n_sig_host * 4);
     if (out->allele_id) memset(out->allele_id, 0xff, (size_t)c->n_sig_host * 4);
@@ -800,7 +811,6 @@ int csv_batch_download(csv_ctx* c, csv_batch_out* out)
         out->support_off[i] = x.supoff;
     }
     if (out->support_off) out->support_off[nc] = (int64_t)ns;
-    if (ns) memcpy(out->support_sig, c->h_pin + o_sup, ns * 8);
     if (out->seg_status && S) memcpy(out->seg_status, c->h_pin + o_err, (size_t)S * 4);
     return CSV_OK;
 }
@@ -896,9 +906,18 @@ int csv_rebuild_signatures(csv_ctx* c, const csv_rebuild_in* in, csv_rebuild_out
 int csv_cluster_batch(csv_ctx* c, const csv_batch_in* in, csv_batch_out* out)
 {
     if (!c || !in || !out) return CSV_E_INVALID;
+    const bool tm = getenv("CSV_DEBUG_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = tm ? now() : 0;
     int rc = upload_impl(c, in, out->cluster_id != nullptr || out->allele_id != nullptr, false);
+    const double t1 = tm ? now() : 0;
     if (rc == CSV_OK) rc = run_impl(c, nullptr);
+    const double t2 = tm ? now() : 0;
+    if (tm && rc == CSV_OK) { (void)hipStreamSynchronize(c->stream); }
+    const double t3 = tm ? now() : 0;
     if (rc == CSV_OK) rc = csv_batch_download(c, out);
+    if (tm) fprintf(stderr, "[csv] one shot: upload issue %.3f ms, run issue %.3f ms, wait for the kernels %.3f ms, download %.3f ms, total %.3f ms\n",
+                    t1 - t0, t2 - t1, t3 - t2, now() - t3, now() - t0);
     // the caller's columns may still be the source of a copy in flight when something failed on the way
     if (rc != CSV_OK && rc != CSV_E_CAPACITY) (void)hipDeviceSynchronize();
     return rc;

@@ -85,9 +85,10 @@ struct DevBatch {
     int*           partial;          // cluster starts per chain tile
     i64*           partial64;        // work items per chain tile (low 32: all, high 32: workgroup tier)
     int4*          item_rec;         // ordered work list: item -> {cluster id, segment, first w, size}
-    int*           list_small;       // item ids of the wavefront tier (ordered)
+    int4*          list_small;       // wavefront tier (ordered): {item, segment | svtype << 24, first w, size} - everything the
+                                     // refine kernels need to issue their row loads straight after this ONE load
     int*           list_big;
-    int*           list_tiny;        // DEL/INS items with m <= tiny_max: k_refine_indel_wave packs four per wavefront
+    int4*          list_tiny;        // DEL/INS items with m <= tiny_max (same entries): k_refine_indel_wave packs four per wavefront
     int            tiny_max;         // 16 (0 switches the class off)
     int2*          tile_prev;        // {last cluster start before the chain tile, its segment} (k_chain_count -> k_chain_apply)
     u64*           ch_masks;         // per chain wavefront (512 signatures): 8 flag masks + 8 "(0,0) predecessor" masks
@@ -624,9 +625,10 @@ __global__ __launch_bounds__(256) void k_chain_apply(DevBatch B)
             const int e1 = SR[wv][i] & 0x7fffffff;
             const int s0 = (i ? SR[wv][i - 1] : ob.x) & 0x7fffffff, k = i ? SKR[wv][i - 1] : ob.y;
             B.item_rec[j] = make_int4(cid_wave + i - 1, k, s0, e1 - s0);
+            const int4 ent = make_int4(j, k | (gate_scalars(B, ts, k).z << 24), s0, e1 - s0);
             if (fl & 2) B.list_big[jb] = j;
-            else if (fl & 4) B.list_tiny[jt] = j;
-            else B.list_small[j - jb - jt] = j;
+            else if (fl & 4) B.list_tiny[jt] = ent;
+            else B.list_small[j - jb - jt] = ent;
         }
         bj += __popcll(m_sel); bb += __popcll(m_big); bt += __popcll(m_tiny);
     }
@@ -1342,7 +1344,7 @@ template <int BLOCK, int CAP> __global__ __launch_bounds__(BLOCK, (BLOCK == 64 ?
     const int n = big ? B.cnt->n_items_big : (B.cnt->n_items - B.cnt->n_items_big - B.cnt->n_items_tiny);
     for (int q = blockIdx.x; q < n; q += gridDim.x) {
         ItemCtx it;
-        it.j = big ? B.list_big[q] : B.list_small[q];
+        it.j = big ? B.list_big[q] : B.list_small[q].x;
         const int4 rec = B.item_rec[it.j];
         it.cid = rec.x; it.k = rec.y; it.s = rec.z; it.m = rec.w;
         if (it.m <= m_lo || it.m > m_hi) continue;
@@ -1501,13 +1503,41 @@ template <int T, int N> struct RankSwz {
 };
 template <int N> struct RankSwz<N, N> { static __device__ __forceinline__ void run(int, int, int&) {} };
 
+// What a unit reads from memory, in two rounds: the list entries of its clusters (one per sub-wave), then - addresses
+// known from the entry alone - the rows and the segment scalars together.  (The first version walked list -> item
+// record -> segment -> rows: four dependent round trips per unit, and with ~10 k units on ~5 k resident wavefronts the
+// kernel's time is a small multiple of one unit's latency.)  k_refine_indel_wave loads the inputs of a wavefront's
+// first two units before it computes anything.
+struct UnitIn {
+    int4 e;                       // list entry {item, segment | svtype << 24, first w, size}; svtype -1: no item (per lane, uniform inside a sub-wave)
+    i64  a, b;
+    int  rid, aux;
+};
+// entry of the sub-wave's cluster: unit p of a list whose units hold 64 / sw clusters (sw = 1 << sw_log2, wave-uniform)
+__device__ __forceinline__ int4 unit_entry(const int4* list, int p, int nlist, int sw_log2)
+{
+    const int q = (p << (6 - sw_log2)) + (lane_id() >> sw_log2);
+    return (p >= 0 && q < nlist) ? list[q] : make_int4(0, (int)0xff000000u, 0, 0);
+}
+// rows of the entry's cluster, one signature per lane of the sub-wave; m_lo < size <= sw or the lanes stay empty
+__device__ __forceinline__ void unit_rows(const DevBatch& B, const int4 e, int sw_log2, int m_lo, UnitIn& U)
+{
+    const int sl = lane_id() & ((1 << sw_log2) - 1), type = e.y >> 24, s = e.z, m = e.w;
+    const bool in = (type == CSV_DEL || type == CSV_INS) && m > m_lo && m <= (1 << sw_log2) && sl < m;
+    U.e = e;
+    U.a = in ? B.a[s + sl] : 0;
+    U.b = in ? B.b[s + sl] : 0;
+    U.rid = in ? B.rid[s + sl] : -1 - lane_id();
+    U.aux = (in && type == CSV_INS) ? B.aux[s + sl] : 0;
+}
+
 #ifndef CSV_IW_WAVES
 #define CSV_IW_WAVES 5
 #endif
 // one unit of work: SW = 32 -> the pair of items (2p, 2p + 1), each handled if m <= 32;
 //                   SW = 64 -> the single item p, handled if 32 < m <= 64.  Returns (SW = 32 only) a 2-bit mask
 //                   of pair members that are DEL/INS clusters of 32 < m <= 64 and still need the wide pass.
-template <int SW> __device__ __forceinline__ int indel_unit(const DevBatch& B, const int* list, int p, int nlist)
+template <int SW> __device__ __forceinline__ int indel_unit(const DevBatch& B, const UnitIn& U)
 {
     constexpr bool HALF = SW == 32;
     constexpr int NSUB = 64 / SW;                      // clusters per wavefront
@@ -1517,14 +1547,7 @@ template <int SW> __device__ __forceinline__ int indel_unit(const DevBatch& B, c
     const u64 sl_lt = (1ull << sl) - 1ull, sl_le = sl_lt | (1ull << sl);        // masks in sub-lane positions
     int wide = 0;
     do {
-        const int q = NSUB * p + g;
-        int j = 0, k = 0, s = 0, m = 0, type = -1;
-        if (q < nlist) {
-            j = list[q];
-            const int4 rec = B.item_rec[j];
-            k = rec.y; s = rec.z; m = rec.w;
-            type = B.seg[k].svtype;
-        }
+        const int j = U.e.x, k = U.e.y & 0xffffff, type = U.e.y >> 24, s = U.e.z, m = U.e.w;
         // other types go to k_refine<64,64>, the other size class to the other instantiation
         const bool indel = type == CSV_DEL || type == CSV_INS;
         const bool act = indel && m > MLO && m <= SW;
@@ -1533,6 +1556,7 @@ template <int SW> __device__ __forceinline__ int indel_unit(const DevBatch& B, c
             wide = (int)(wm & 1) | (int)((wm >> 32) & 1) << 1;
         }
         if (!__ballot(act)) break;
+        // segment scalars: issued here, first needed after the de-duplication (the table is a few KB and cache resident)
         int rc = 0x7fffffff, msr = 0;
         double ratio = 0.0, rr = 1.0;
         i64 gsig0 = 0;
@@ -1543,10 +1567,8 @@ template <int SW> __device__ __forceinline__ int indel_unit(const DevBatch& B, c
             gsig0 = sg.sig_begin + ((i64)s - B.woff[k]);
         }
         const bool in = act && sl < m;
-        const i64 a = in ? B.a[s + sl] : 0;
-        const i64 b = in ? B.b[s + sl] : 0;
-        const int rid = in ? B.rid[s + sl] : -1 - lane;
-        const int aux = (in && type == CSV_INS) ? B.aux[s + sl] : 0;
+        const i64 a = U.a, b = U.b;
+        const int rid = U.rid, aux = U.aux;
         const bool badk = sub_ballot<SW>(in && (((u64)b) >> (63 - IDX_BITS)) != 0, g) != 0;   // out-of-range length: the cluster emits nothing
         if (badk && sl == 0) atomicOr(&B.seg_err[k], CSV_SEG_KEY_RANGE);
         const int mact = act ? m : 0;
@@ -1743,13 +1765,29 @@ __global__ __launch_bounds__(256, CSV_IW_WAVES) void k_refine_indel_wave(DevBatc
 {
     const int ntiny = B.cnt->n_items_tiny, nsmall = B.cnt->n_items - B.cnt->n_items_big - ntiny;
     const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * 256 + threadIdx.x) >> 6), nwaves = (gridDim.x * 256) >> 6;
-    for (int p = wave; p < (nsmall + 1) / 2; p += nwaves) {
-        const int wide = __builtin_amdgcn_readfirstlane(indel_unit<32>(B, B.list_small, p, nsmall));
-        if (wide & 1) indel_unit<64>(B, B.list_small, 2 * p, nsmall);          // a pair member with 32 < m <= 64
-        if (wide & 2) indel_unit<64>(B, B.list_small, 2 * p + 1, nsmall);
+    // Units: the pairs of the small list, then the quads of the tiny list (clusters of at most 16 signatures: four per
+    // wavefront, a sub-wave is one DPP row); unit u goes to wavefront u mod nwaves.  A unit costs two dependent round
+    // trips: its list entries, then its rows.
+    const int n_pair = (nsmall + 1) / 2, n_quad = (ntiny + 3) / 4;
+    for (int p = wave; p < n_pair; p += nwaves) {
+        UnitIn U;
+        unit_rows(B, unit_entry(B.list_small, p, nsmall, 5), 5, 0, U);
+        const int wide = __builtin_amdgcn_readfirstlane(indel_unit<32>(B, U));
+        for (int h = 0; h < 2; h++)
+            if (wide & (1 << h)) {                         // a pair member with 32 < m <= 64: the one-cluster-per-wavefront form
+                UnitIn Wd;
+                unit_rows(B, unit_entry(B.list_small, 2 * p + h, nsmall, 6), 6, 32, Wd);
+                indel_unit<64>(B, Wd);
+            }
     }
-    // clusters of at most 16 signatures: four per wavefront (a sub-wave is one DPP row)
-    for (int p = wave; p < (ntiny + 3) / 4; p += nwaves) indel_unit<16>(B, B.list_tiny, p, ntiny);
+    // (the quads continue the round-robin where the pairs stopped, so that every wavefront gets its share of both)
+    int q0 = wave - n_pair % nwaves;
+    if (q0 < 0) q0 += nwaves;
+    for (int p = q0; p < n_quad; p += nwaves) {
+        UnitIn U;
+        unit_rows(B, unit_entry(B.list_tiny, p, ntiny, 4), 4, 0, U);
+        indel_unit<16>(B, U);
+    }
 }
 
 // ------------------------------------------------------------------------------------ order

@@ -26,6 +26,7 @@ class Context:
             raise CsvError(rc, "csv_ctx_create(device=%d) failed (is a GPU visible?)" % device)
         self.device = device
         self._batch = None
+        self._res_cache = None
 
     def close(self):
         if self._h:
@@ -100,13 +101,23 @@ class Context:
         raise CsvError(_abi.E_CAPACITY, "capacity retry failed")
 
     # ---- one shot: csv_cluster_batch (H2D, kernels and D2H overlap inside the one call)
-    def cluster_batch(self, batch, per_sig=False, cap_calls=None, cap_support=None):
+    def cluster_batch(self, batch, per_sig=False, cap_calls=None, cap_support=None, reuse=False):
+        """reuse=True hands the C call the result arrays of this context's previous reuse=True call when they are large
+        enough (a caller that consumes a result before asking for the next one, like resolve.run_batch, saves the
+        page faults of ~20 MB of fresh arrays per call); the previous result is overwritten."""
         n = batch.n_sig
         cap_calls = cap_calls or max(64, n // 16 + 16)
         cap_support = cap_support or max(64, n // 2 + 16)
         self._batch = batch
         for _ in range(2):
-            res = _abi.HostResult(n, cap_calls, cap_support, per_sig=per_sig, n_seg=len(batch.segments))
+            res = self._res_cache if reuse else None
+            if (res is None or res.cap_calls < cap_calls or res.cap_support < cap_support or res.n_seg < len(batch.segments)
+                    or res.per_sig != per_sig or (per_sig and res.n_sig != n)):
+                # (recycled arrays are worth page-locking: the result copies then land in them by DMA)
+                res = _abi.HostResult(n, cap_calls, cap_support, per_sig=per_sig, n_seg=len(batch.segments),
+                                      alloc=pinned_empty if reuse else None)
+                if reuse:
+                    self._res_cache = res
             rc = lib().csv_cluster_batch(self._h, C.byref(batch.c), C.byref(res.c))
             if rc == _abi.E_CAPACITY:            # required sizes were filled in: re-allocate and retry
                 cap_calls, cap_support = res.n_calls + 1, res.n_support + 1

@@ -61,7 +61,7 @@ def run_batch(store, segments, tasks, ctx=None):
         if ((segs["svtype"] == _abi.TRA) & (segs["genotype"] != 0)).any():
             kw["contig_len"] = store.contig_len
     hb = _abi.HostBatch(segs, store.a, store.b, store.read_id, store.aux, n_chrom=len(store.chroms), **kw)
-    res = ctx.cluster_batch(hb)
+    res = ctx.cluster_batch(hb, reuse=True)           # (consumed right here: the arrays may be recycled by the next call)
     per_seg = rows_mod.rows_by_segment(store, hb.segments, res)
     return {t: per_seg[k] for k, t in enumerate(tasks)}
 
