@@ -129,7 +129,10 @@ class SigStore:
     def sequence(self, sig):
         """Inserted sequence of INS signature `sig` (global index)."""
         if self.ins_seq is None:
-            n = int(self.aux[sig])
+            if self.names.names is not None:
+                raise KeyError("this store holds real read names but no inserted sequences: pass them to the builder "
+                               "(SigStore.from_tuple_lists / rebuild.store_from_unsorted(per_type['INS']['seq']))")
+            n = int(self.aux[sig])                           # synthetic workloads: 'ACGT' repeated to the aux length
             return ("ACGT" * (n // 4 + 1))[:n]
         return self.ins_seq[int(sig)]
 

@@ -14,6 +14,7 @@
 
 #include "kernels.hip.h"
 #include "sort.hip.h"
+#include "cigar.hip.h"
 
 using namespace csv;
 
@@ -74,8 +75,10 @@ struct csv_ctx {
     Buf gs_chrom, gs_perm0, gs_perm1, gs_hist, gs_tot;          // general reads sort (fallback), allocated on first use
     Buf flush;                                                   // csv_cache_flush scratch
     // rebuild step (slices of `arena_rb`)
-    Buf rb_seg, rb_a, rb_b, rb_rid, rb_aux, rb_auxk, rb_major, rb_perm0, rb_perm1, rb_hist, rb_tot, rb_partial;
+    Buf rb_seg, rb_a, rb_b, rb_rid, rb_aux, rb_auxk, rb_major, rb_nodedup, rb_perm0, rb_perm1, rb_hist, rb_tot, rb_partial;
     Buf rb_oseg, rb_oa, rb_ob, rb_orid, rb_oaux, rb_osrc;
+    // CIGAR scan (slices of `arena_rb` as well: the two steps never overlap)
+    Buf cg_off, cg_ops, cg_start, cg_use, cg_cnt, cg_tiles, cg_tot, cg_iread, cg_ipos, cg_ilen, cg_ip0, cg_inp, cg_pq, cg_pl, cg_dread, cg_dpos, cg_dlen;
     // page-locked host staging: small tables on the way in, counters + call records + support lists on the way out
     char*  h_pin = nullptr;
     size_t h_pin_cap = 0;
@@ -176,6 +179,8 @@ int csv_struct_size(int which)
     case 5: return (int)sizeof(csv_rebuild_out);
     case 6: return (int)sizeof(csv_vcf_in);
     case 7: return (int)sizeof(csv_rows_in);
+    case 8: return (int)sizeof(csv_cigar_in);
+    case 9: return (int)sizeof(csv_cigar_out);
     default: return -1;
     }
 }
@@ -840,7 +845,7 @@ int csv_rebuild_signatures(csv_ctx* c, const csv_rebuild_in* in, csv_rebuild_out
     Plan P;
 #define PL(buf, bytes) P.add(c->buf, (size_t)(bytes))
     PL(rb_seg, n * 4); PL(rb_a, n * 8); PL(rb_b, n * 8); PL(rb_rid, n * 4); PL(rb_aux, n * 4); PL(rb_auxk, n * 4);
-    PL(rb_major, in->n_seg); PL(rb_perm0, n * 4); PL(rb_perm1, n * 4); PL(rb_hist, (size_t)256 * nunits * 4);
+    PL(rb_major, in->n_seg); PL(rb_nodedup, in->n_seg); PL(rb_perm0, n * 4); PL(rb_perm1, n * 4); PL(rb_hist, (size_t)256 * nunits * 4);
     PL(rb_tot, 256 * 4); PL(rb_partial, (ntile + 2) * 4);
     PL(rb_oseg, n * 4); PL(rb_oa, n * 8); PL(rb_ob, n * 8); PL(rb_orid, n * 4); PL(rb_oaux, n * 4); PL(rb_osrc, n * 4);
 #undef PL
@@ -856,6 +861,7 @@ int csv_rebuild_signatures(csv_ctx* c, const csv_rebuild_in* in, csv_rebuild_out
     HIP_TRY(c, hipMemcpyAsync(c->rb_rid.p, in->read_id, n * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(c, hipMemcpyAsync(c->rb_aux.p, in->aux, n * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(c, hipMemcpyAsync(c->rb_major.p, in->seg_aux_major, in->n_seg, hipMemcpyHostToDevice, st));
+    if (in->seg_nodedup) HIP_TRY(c, hipMemcpyAsync(c->rb_nodedup.p, in->seg_nodedup, in->n_seg, hipMemcpyHostToDevice, st));
     HIP_TRY(c, hipEventRecord(c->ev[0], st));
     hipLaunchKernelGGL(k_rebuild_auxkey, dim3(div_up(n, 256)), dim3(256), 0, st, n, dp<int>(c->rb_seg), dp<int>(c->rb_aux),
                        dp<uint8_t>(c->rb_major), dp<int>(c->rb_auxk));
@@ -881,6 +887,7 @@ int csv_rebuild_signatures(csv_ctx* c, const csv_rebuild_in* in, csv_rebuild_out
     R.n = n; R.perm = pin;
     R.seg = dp<int>(c->rb_seg); R.a = dp<i64>(c->rb_a); R.b = dp<i64>(c->rb_b); R.rid = dp<int>(c->rb_rid); R.aux = dp<int>(c->rb_aux);
     R.auxk = dp<int>(c->rb_auxk); R.keep = nullptr; R.partial = dp<int>(c->rb_partial);
+    R.nodedup = in->seg_nodedup ? dp<uint8_t>(c->rb_nodedup) : nullptr;
     R.o_seg = dp<int>(c->rb_oseg); R.o_a = dp<i64>(c->rb_oa); R.o_b = dp<i64>(c->rb_ob); R.o_rid = dp<int>(c->rb_orid);
     R.o_aux = dp<int>(c->rb_oaux); R.o_src = dp<int>(c->rb_osrc); R.n_out = (int*)c->cnt.p;
     hipLaunchKernelGGL(k_rebuild_count, dim3(ntile), dim3(256), 0, st, R);
@@ -900,6 +907,79 @@ int csv_rebuild_signatures(csv_ctx* c, const csv_rebuild_in* in, csv_rebuild_out
     HIP_TRY(c, hipMemcpyAsync(out->src_row, c->rb_osrc.p, (size_t)n_out * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipStreamSynchronize(st));
     c->uploaded = c->ran = false;          // cnt was used as scratch
+    return CSV_OK;
+}
+
+int csv_cigar_signatures(csv_ctx* c, const csv_cigar_in* in, csv_cigar_out* out)
+{
+    if (!c || !in || !out) return CSV_E_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    out->n_sig_ins = out->n_piece_ins = out->n_sig_del = 0; out->ms_device = 0;
+    const i64 n = in->n_reads;
+    if (n < 0 || (n > 0 && (!in->cig_off || !in->ref_start))) return fail(c, CSV_E_INVALID, "bad CIGAR batch header");
+    if (n == 0) return CSV_OK;
+    const i64 nops = in->cig_off[n] - in->cig_off[0];
+    if (in->cig_off[0] != 0 || nops < 0 || (nops > 0 && !in->cigar)) return fail(c, CSV_E_INVALID, "cig_off must start at 0 and not decrease");
+    if (nops >= (1ll << 31) - 4096) return fail(c, CSV_E_INVALID, "CIGAR batch too large (%lld operations): split it", (long long)nops);
+    const int ntile = div_up(n, CG_TILE);
+    // every op can be a piece and a signature of its own: size the outputs for the worst case the caller allows, but never
+    // more than the operations there are
+    const i64 cap_i = out->cap_sig_ins < nops ? out->cap_sig_ins : nops, cap_p = out->cap_piece_ins < nops ? out->cap_piece_ins : nops,
+              cap_d = out->cap_sig_del < nops ? out->cap_sig_del : nops;
+    Plan P;
+#define PL(buf, bytes) P.add(c->buf, (size_t)(bytes))
+    PL(cg_off, (n + 1) * 8); PL(cg_ops, (nops + 1) * 4); PL(cg_start, n * 8); PL(cg_use, n); PL(cg_cnt, n * 16);
+    PL(cg_tiles, (size_t)ntile * 24); PL(cg_tot, 32);
+    PL(cg_iread, (cap_i + 1) * 4); PL(cg_ipos, (cap_i + 1) * 8); PL(cg_ilen, (cap_i + 1) * 8); PL(cg_ip0, (cap_i + 1) * 8); PL(cg_inp, (cap_i + 1) * 4);
+    PL(cg_pq, (cap_p + 1) * 4); PL(cg_pl, (cap_p + 1) * 4);
+    PL(cg_dread, (cap_d + 1) * 4); PL(cg_dpos, (cap_d + 1) * 8); PL(cg_dlen, (cap_d + 1) * 8);
+#undef PL
+    {
+        if (P.total > c->arena_rb.cap) HIP_TRY(c, hipDeviceSynchronize());
+        const int rc = commit(c, c->arena_rb, P);
+        if (rc) return rc;
+    }
+    hipStream_t st = c->stream;
+    HIP_TRY(c, hipMemcpyAsync(c->cg_off.p, in->cig_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
+    if (nops) HIP_TRY(c, hipMemcpyAsync(c->cg_ops.p, in->cigar, (size_t)nops * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(c->cg_start.p, in->ref_start, (size_t)n * 8, hipMemcpyHostToDevice, st));
+    if (in->use) HIP_TRY(c, hipMemcpyAsync(c->cg_use.p, in->use, (size_t)n, hipMemcpyHostToDevice, st));
+    CigarArgs A{};
+    A.n_reads = n; A.cig_off = dp<i64>(c->cg_off); A.cigar = dp<unsigned>(c->cg_ops); A.ref_start = dp<i64>(c->cg_start);
+    A.use = in->use ? dp<uint8_t>(c->cg_use) : nullptr;
+    A.min_siglength = in->min_siglength; A.merge_ins = in->merge_ins_threshold; A.merge_del = in->merge_del_threshold;
+    A.cnt = dp<int4>(c->cg_cnt); A.tile_sum = dp<i64>(c->cg_tiles); A.totals = dp<i64>(c->cg_tot);
+    A.ins_read = dp<int>(c->cg_iread); A.ins_pos = dp<i64>(c->cg_ipos); A.ins_len = dp<i64>(c->cg_ilen); A.ins_piece0 = dp<i64>(c->cg_ip0);
+    A.ins_npiece = dp<int>(c->cg_inp); A.piece_qoff = dp<int>(c->cg_pq); A.piece_len = dp<int>(c->cg_pl);
+    A.del_read = dp<int>(c->cg_dread); A.del_pos = dp<i64>(c->cg_dpos); A.del_len = dp<i64>(c->cg_dlen);
+    const int grid = div_up(n, 4) < 4096 ? div_up(n, 4) : 4096;
+    HIP_TRY(c, hipEventRecord(c->ev[0], st));
+    hipLaunchKernelGGL(k_cigar_count, dim3(grid), dim3(256), 0, st, A);
+    hipLaunchKernelGGL(k_cigar_tiles, dim3(ntile), dim3(256), 0, st, A);
+    hipLaunchKernelGGL(k_cigar_offsets, dim3(ntile), dim3(256), 0, st, A);
+    HIP_TRY(c, hipEventRecord(c->ev[1], st));
+    HIP_TRY(c, hipGetLastError());
+    i64 tot[3] = {0, 0, 0};
+    HIP_TRY(c, hipMemcpyAsync(tot, c->cg_tot.p, 24, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    out->n_sig_ins = tot[0]; out->n_piece_ins = tot[1]; out->n_sig_del = tot[2];
+    float ms1 = 0, ms2 = 0;
+    HIP_TRY(c, hipEventElapsedTime(&ms1, c->ev[0], c->ev[1]));
+    if (tot[0] > out->cap_sig_ins || tot[1] > out->cap_piece_ins || tot[2] > out->cap_sig_del)
+        return fail(c, CSV_E_CAPACITY, "need %lld INS signatures / %lld INS pieces / %lld DEL signatures", (long long)tot[0], (long long)tot[1], (long long)tot[2]);
+    HIP_TRY(c, hipEventRecord(c->ev[2], st));
+    hipLaunchKernelGGL(k_cigar_emit, dim3(grid), dim3(256), 0, st, A);
+    HIP_TRY(c, hipEventRecord(c->ev[3], st));
+    HIP_TRY(c, hipGetLastError());
+#define D2H(dst, buf, bytes) do { if ((bytes) > 0) HIP_TRY(c, hipMemcpyAsync((dst), c->buf.p, (size_t)(bytes), hipMemcpyDeviceToHost, st)); } while (0)
+    D2H(out->ins_read, cg_iread, tot[0] * 4); D2H(out->ins_pos, cg_ipos, tot[0] * 8); D2H(out->ins_len, cg_ilen, tot[0] * 8);
+    D2H(out->ins_piece0, cg_ip0, tot[0] * 8); D2H(out->ins_npiece, cg_inp, tot[0] * 4);
+    D2H(out->piece_qoff, cg_pq, tot[1] * 4); D2H(out->piece_len, cg_pl, tot[1] * 4);
+    D2H(out->del_read, cg_dread, tot[2] * 4); D2H(out->del_pos, cg_dpos, tot[2] * 8); D2H(out->del_len, cg_dlen, tot[2] * 8);
+#undef D2H
+    HIP_TRY(c, hipStreamSynchronize(st));
+    HIP_TRY(c, hipEventElapsedTime(&ms2, c->ev[2], c->ev[3]));
+    out->ms_device = ms1 + ms2;
     return CSV_OK;
 }
 

@@ -138,6 +138,7 @@ struct RebuildArgs {
     i64 n;
     const int* perm;
     const int* seg; const i64* a; const i64* b; const int* rid; const int* aux; const int* auxk;
+    const uint8_t* nodedup;     // per segment: keep every row (nullable)
     int* keep;             // 1 when the sorted row differs from its predecessor
     int* partial;          // per 2048-row tile counts
     int* o_seg; i64* o_a; i64* o_b; int* o_rid; int* o_aux; int* o_src;
@@ -149,6 +150,7 @@ __device__ __forceinline__ int rebuild_keep(const RebuildArgs& R, i64 i)
     if (i >= R.n) return 0;
     if (i == 0) return 1;
     const int p = R.perm ? R.perm[i] : (int)i, q = R.perm ? R.perm[i - 1] : (int)(i - 1);
+    if (R.nodedup && R.nodedup[R.seg[p]]) return 1;
     return !(R.seg[p] == R.seg[q] && R.a[p] == R.a[q] && R.b[p] == R.b[q] && R.rid[p] == R.rid[q] && R.aux[p] == R.aux[q]);
 }
 

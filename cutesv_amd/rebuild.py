@@ -3,7 +3,13 @@ contract of cuteSV's process_process_sigs_type (main script :750-857).
 
 `rebuild_columns` is the thin face of `csv_rebuild_signatures` (stable LSD radix sort of a row permutation on
 (segment, [aux], pos, len/pos2, read id) + adjacent de-duplication, cutesv_amd/csrc/sort.hip.h);
-`store_from_unsorted` assembles the flat store from per-type unsorted columns the extraction step produced."""
+`store_from_unsorted` assembles the flat store from per-type unsorted columns the extraction step produced.
+
+INS rows are special: the reference sorts them by (chr, int(pos), len, read, sequence) and removes a row only when the
+WHOLE tuple repeats - including the sequence and the x.5 of a split-read position ((a + b) / 2, main script :228,
+:774-775, :958-969).  The GPU sorts on the integer columns (stable, so equal keys stay in input order) and leaves INS
+segments un-deduplicated; the host then finishes the few groups of INS rows that agree in (chr, int(pos), len, read):
+ordered by sequence, exact duplicates dropped.  Everything else is exact on the integer columns alone."""
 import ctypes as C
 
 import numpy as np
@@ -15,7 +21,8 @@ from .columns import SigStore, NameTable, TYPES
 
 class RebuildIn(C.Structure):
     _fields_ = [("n", C.c_int64), ("n_seg", C.c_int32), ("reserved", C.c_int32), ("seg_aux_major", C.c_void_p),
-                ("seg_id", C.c_void_p), ("a", C.c_void_p), ("b", C.c_void_p), ("read_id", C.c_void_p), ("aux", C.c_void_p)]
+                ("seg_id", C.c_void_p), ("a", C.c_void_p), ("b", C.c_void_p), ("read_id", C.c_void_p), ("aux", C.c_void_p),
+                ("seg_nodedup", C.c_void_p)]
 
 
 class RebuildOut(C.Structure):
@@ -23,7 +30,7 @@ class RebuildOut(C.Structure):
                 ("aux", C.c_void_p), ("src_row", C.c_void_p), ("ms_device", C.c_float), ("n_passes", C.c_int32)]
 
 
-def rebuild_columns(ctx, seg_id, a, b, read_id, aux, seg_aux_major):
+def rebuild_columns(ctx, seg_id, a, b, read_id, aux, seg_aux_major, seg_nodedup=None):
     """-> dict(seg_id, a, b, read_id, aux, src_row, ms_device, n_passes): sorted, de-duplicated rows"""
     L = lib()
     L.csv_rebuild_signatures.restype = C.c_int
@@ -31,11 +38,13 @@ def rebuild_columns(ctx, seg_id, a, b, read_id, aux, seg_aux_major):
     seg_id = np.ascontiguousarray(seg_id, np.int32); a = np.ascontiguousarray(a, np.int64); b = np.ascontiguousarray(b, np.int64)
     read_id = np.ascontiguousarray(read_id, np.int32); aux = np.ascontiguousarray(aux, np.int32)
     major = np.ascontiguousarray(seg_aux_major, np.uint8)
+    nodedup = None if seg_nodedup is None else np.ascontiguousarray(seg_nodedup, np.uint8)
     n = len(a)
     o = dict(seg_id=np.empty(n, np.int32), a=np.empty(n, np.int64), b=np.empty(n, np.int64), read_id=np.empty(n, np.int32),
              aux=np.empty(n, np.int32), src_row=np.empty(n, np.int32))
     rin = RebuildIn(n=n, n_seg=len(major), seg_aux_major=major.ctypes.data, seg_id=seg_id.ctypes.data, a=a.ctypes.data,
-                    b=b.ctypes.data, read_id=read_id.ctypes.data, aux=aux.ctypes.data)
+                    b=b.ctypes.data, read_id=read_id.ctypes.data, aux=aux.ctypes.data,
+                    seg_nodedup=None if nodedup is None else nodedup.ctypes.data)
     rout = RebuildOut(seg_id=o["seg_id"].ctypes.data, a=o["a"].ctypes.data, b=o["b"].ctypes.data, read_id=o["read_id"].ctypes.data,
                       aux=o["aux"].ctypes.data, src_row=o["src_row"].ctypes.data)
     ctx._check(L.csv_rebuild_signatures(ctx._h, C.byref(rin), C.byref(rout)))
@@ -46,30 +55,88 @@ def rebuild_columns(ctx, seg_id, a, b, read_id, aux, seg_aux_major):
     return out
 
 
+def finish_ins_ties(r, ins_segs, seq_of_src, half_of_src):
+    """The INS tie groups of a sorted (not de-duplicated) row set `r` (dict of arrays from rebuild_columns): rows that agree
+    in (segment, a, b, read_id).  Each group is ordered by sequence (stable: equal sequences keep the concatenation order
+    of the extraction files, as the reference's stable sort does) and adjacent rows whose sequence and half-position are
+    equal too are dropped (main script :774-775, :958-969).  Returns the index array to apply to r's arrays."""
+    n = len(r["a"])
+    idx = np.arange(n)
+    if n < 2:
+        return idx
+    is_ins = np.isin(r["seg_id"], ins_segs)
+    same = np.zeros(n, bool)
+    same[1:] = (is_ins[1:] & (r["seg_id"][1:] == r["seg_id"][:-1]) & (r["a"][1:] == r["a"][:-1]) &
+                (r["b"][1:] == r["b"][:-1]) & (r["read_id"][1:] == r["read_id"][:-1]))
+    if not same.any():
+        return idx
+    starts = np.flatnonzero(same & ~np.r_[False, same[:-1]]) - 1          # first row of every tie group
+    keep = np.ones(n, bool)
+    order = idx.copy()
+    for g0 in starts.tolist():
+        g1 = g0 + 1
+        while g1 < n and same[g1]:
+            g1 += 1
+        rows = list(range(g0, g1))
+        src = r["src_row"][g0:g1].tolist()
+        rows.sort(key=lambda i: seq_of_src(src[i - g0]))                    # Python's sort is stable
+        order[g0:g1] = rows
+        prev = None
+        for pos, i in enumerate(rows):
+            cur = (seq_of_src(src[i - g0]), int(half_of_src(src[i - g0])))
+            if prev is not None and cur == prev:
+                keep[g0 + pos] = False
+            prev = cur
+    return order[keep]
+
+
 def store_from_unsorted(ctx, chroms, per_type, names=None, strands=("++", "--"), reads=None):
     """per_type: {"DEL": dict(chrom=int[], a=, b=, read_id=, aux=), ...} unsorted rows (chrom = index into `chroms`).
+    An INS entry may carry `seq` (list of str, one per row) and `half` (0/1 per row: the position is x.5): the rows are
+    then ordered and de-duplicated exactly as the reference does and the store holds the sequences; without them INS rows
+    are de-duplicated on their integer columns only.
     Segments come out in the reference's order: types as main_ctrl submits them, chromosomes by name.
-    `reads`: optional dict(chrom, start, end, primary, read_id) -> blocks sorted by start (numpy; the table is small next
-    to the signature sort and already nearly sorted by construction)."""
+    `reads`: optional dict(chrom, start, end, primary, read_id): blocks keep their input order (csv_cluster_batch orders
+    every block by start on the device)."""
     order = sorted(range(len(chroms)), key=lambda i: chroms[i])
     crank = np.zeros(len(chroms), np.int64)
     crank[order] = np.arange(len(chroms))
-    segs, cols = [], {k: [] for k in ("seg", "a", "b", "rid", "aux")}
+    cols = {k: [] for k in ("seg", "a", "b", "rid", "aux")}
+    ins_base, ins_n = 0, 0
+    n_rows = 0
     for ti, t in enumerate(TYPES):
         if t not in per_type or len(per_type[t]["a"]) == 0:
             continue
         d = per_type[t]
         ch = np.asarray(d["chrom"], np.int64)
+        if t == "INS":
+            ins_base, ins_n = n_rows, len(ch)
         cols["seg"].append(ti * len(chroms) + crank[ch])
         cols["a"].append(np.asarray(d["a"], np.int64)); cols["b"].append(np.asarray(d["b"], np.int64))
         cols["rid"].append(np.asarray(d["read_id"], np.int64)); cols["aux"].append(np.asarray(d["aux"], np.int64))
+        n_rows += len(ch)
     cat = {k: np.concatenate(v) if v else np.zeros(0, np.int64) for k, v in cols.items()}
     n_seg = len(TYPES) * len(chroms)
     major = np.zeros(n_seg, np.uint8)
+    nodedup = np.zeros(n_seg, np.uint8)
+    ins_seq_in = per_type.get("INS", {}).get("seq") if "INS" in per_type else None
+    ti_ins = TYPES.index("INS")
     for ti, t in enumerate(TYPES):
         if t in ("INV", "TRA"):
             major[ti * len(chroms):(ti + 1) * len(chroms)] = 1
-    r = rebuild_columns(ctx, cat["seg"], cat["a"], cat["b"], cat["rid"], cat["aux"], major)
+    if ins_seq_in is not None:
+        nodedup[ti_ins * len(chroms):(ti_ins + 1) * len(chroms)] = 1
+    r = rebuild_columns(ctx, cat["seg"], cat["a"], cat["b"], cat["rid"], cat["aux"], major, nodedup)
+    ins_seq = None
+    if ins_seq_in is not None:
+        half = per_type["INS"].get("half")
+        half = np.zeros(ins_n, np.uint8) if half is None else np.asarray(half, np.uint8)
+        sel = finish_ins_ties(r, np.arange(ti_ins * len(chroms), (ti_ins + 1) * len(chroms)),
+                              lambda s: ins_seq_in[s - ins_base], lambda s: half[s - ins_base])
+        for k in ("seg_id", "a", "b", "read_id", "aux", "src_row"):
+            r[k] = r[k][sel]
+        is_ins = (r["seg_id"] // len(chroms)) == ti_ins
+        ins_seq = {int(i): ins_seq_in[int(r["src_row"][i]) - ins_base] for i in np.flatnonzero(is_ins).tolist()}
     seg_sorted = r["seg_id"]
     bounds = np.flatnonzero(np.r_[True, seg_sorted[1:] != seg_sorted[:-1], True]) if len(seg_sorted) else np.zeros(1, np.int64)
     seg_index = {}
@@ -79,10 +146,10 @@ def store_from_unsorted(ctx, chroms, per_type, names=None, strands=("++", "--"),
     kw = {}
     if reads is not None:
         rc = np.asarray(reads["chrom"], np.int64)
-        o = np.lexsort((np.asarray(reads["start"]), rc))
+        o = np.argsort(rc, kind="stable")                       # by chromosome only, as main script :810 leaves the block
         off = np.searchsorted(rc[o], np.arange(len(chroms) + 1)).astype(np.int64)
         kw = dict(reads_off=off, r_start=np.asarray(reads["start"], np.int64)[o], r_end=np.asarray(reads["end"], np.int64)[o],
                   r_primary=np.asarray(reads["primary"], np.uint8)[o], r_id=np.asarray(reads["read_id"], np.int32)[o])
     st = SigStore(chroms=list(chroms), a=r["a"], b=r["b"], read_id=r["read_id"], aux=r["aux"], seg_index=seg_index,
-                  names=names or NameTable(), strands=tuple(strands), **kw)
+                  names=names or NameTable(), strands=tuple(strands), ins_seq=ins_seq, **kw)
     return st, r

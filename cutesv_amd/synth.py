@@ -417,3 +417,10 @@ def concat_stores(x, y, suffix="b"):
     return SigStore(chroms=chroms, a=np.concatenate([x.a, y.a]), b=np.concatenate([x.b, y.b]),
                     read_id=np.concatenate([x.read_id, y.read_id + shift]).astype(np.int32), aux=np.concatenate([x.aux, y_aux]).astype(np.int32),
                     seg_index=seg_index, names=NameTable(), contig_len=cl, **kw)
+
+
+def pseudo_sequence(length, key):
+    """deterministic pseudo-random ACGT string (fixtures store `key` instead of the bases)"""
+    j = np.arange(length, dtype=np.uint64)
+    h = (j * np.uint64(2654435761) + np.uint64(key) * np.uint64(40503) + (j >> np.uint64(3)) * np.uint64(97)) >> np.uint64(7)
+    return np.array(list("ACGT"))[(h & np.uint64(3)).astype(np.int64)].astype("U1").tobytes().decode("utf-32-le") if length else ""

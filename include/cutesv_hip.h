@@ -191,7 +191,7 @@ typedef struct csv_ctx csv_ctx;
 
 int         csv_abi_version(void);
 /* sizeof() of the ABI's structs as this library was compiled (which: 0 csv_segment, 1 csv_batch_in, 2 csv_batch_out,
- * 3 csv_run_stats, 4 csv_rebuild_in, 5 csv_rebuild_out, 6 csv_vcf_in, 7 csv_rows_in; -1 otherwise): lets a binding
+ * 3 csv_run_stats, 4 csv_rebuild_in, 5 csv_rebuild_out, 6 csv_vcf_in, 7 csv_rows_in, 8 csv_cigar_in, 9 csv_cigar_out; -1 otherwise): lets a binding
  * check its own mirror of the layouts at load time. */
 int         csv_struct_size(int which);
 int         csv_device_count(int* n);
@@ -264,6 +264,9 @@ typedef struct csv_rebuild_in {
     const int64_t* b;
     const int32_t* read_id;
     const int32_t* aux;
+    const uint8_t* seg_nodedup;     /* n_seg or NULL: 1 = sort this segment but keep every row.  INS rows are equal only when
+                                       their sequences and the x.5 of a split-read position are equal too (MAIN:228, :774-775):
+                                       the caller finishes those few tie groups on the host (cutesv_amd/rebuild.py) */
 } csv_rebuild_in;
 
 typedef struct csv_rebuild_out {
@@ -279,6 +282,42 @@ typedef struct csv_rebuild_out {
 } csv_rebuild_out;
 
 int csv_rebuild_signatures(csv_ctx* ctx, const csv_rebuild_in* in, csv_rebuild_out* out);
+
+/* ---------------------------------------------------------------------------------------------
+ * The CIGAR scan of the extraction step on the GPU.  Restates the CIGAR part of parse_read
+ * (cuteSV main script :606-655: every I / D operation of at least min_siglength bases is a piece at the reference position
+ * it is reached, :629-643) and generate_combine_sigs (:515-575: pieces of one type within merge_ins_threshold /
+ * merge_del_threshold of each other inside a read become one signature; the distance rule of :535 / :558 / :569 is
+ * reproduced as written).  BAM decode, the SA-tag split-read analysis (:190-464) and the bases stay in the Python driver
+ * with pysam: the input is the flat BAM-encoded CIGAR array of a batch of reads (pysam: read.cigartuples), the output the
+ * INS / DEL signatures in read order plus, for INS, the query slices the inserted sequence is made of
+ * (query_sequence[qoff : qoff + len] per piece, concatenated: :639-640, :537).
+ *   use[r] = 0 skips read r (mapq < min_mapq, :614; the query_length < min_read_len gate of :607 is the caller's too).
+ * Outputs are caller-allocated; CSV_E_CAPACITY fills n_sig_ins / n_piece_ins / n_sig_del with the need.
+ */
+typedef struct csv_cigar_in {
+    int64_t         n_reads;
+    const int64_t*  cig_off;        /* n_reads + 1 offsets into cigar */
+    const uint32_t* cigar;          /* oplen << 4 | op, op = 0..9 for M I D N S H P = X B (the BAM encoding) */
+    const int64_t*  ref_start;      /* read.reference_start, 0-based */
+    const uint8_t*  use;            /* n_reads or NULL */
+    int32_t         min_siglength;  /* --min_siglength (cuteSV_Description.py:152) */
+    int32_t         reserved;
+    int64_t         merge_ins_threshold;   /* --merge_ins_threshold (:127) */
+    int64_t         merge_del_threshold;   /* --merge_del_threshold (:123) */
+} csv_cigar_in;
+
+typedef struct csv_cigar_out {
+    int64_t  cap_sig_ins, cap_piece_ins, cap_sig_del;
+    int64_t  n_sig_ins, n_piece_ins, n_sig_del;          /* out */
+    int32_t* ins_read;  int64_t* ins_pos;  int64_t* ins_len;  int64_t* ins_piece0;  int32_t* ins_npiece;     /* cap_sig_ins */
+    int32_t* piece_qoff;  int32_t* piece_len;                                                               /* cap_piece_ins */
+    int32_t* del_read;  int64_t* del_pos;  int64_t* del_len;                                                /* cap_sig_del */
+    float    ms_device;                                  /* out: kernels only (HIP events) */
+    int32_t  reserved;
+} csv_cigar_out;
+
+int csv_cigar_signatures(csv_ctx* ctx, const csv_cigar_in* in, csv_cigar_out* out);
 
 /* ---------------------------------------------------------------------------------------------
  * Host-side VCF record emit: the structure-of-arrays result -> the text lines

@@ -815,3 +815,58 @@ int csvo_cover_count(const int64_t* r_start, const int64_t* r_end, const uint8_t
     }
     return CSV_OK;
 }
+
+/* ------------------------------------------------------------------ CIGAR scan */
+
+/* The CIGAR part of parse_read (main script :606-655) + generate_combine_sigs (:515-575), one read after the other.
+ * Same structs as csv_cigar_signatures (include/cutesv_hip.h). */
+int csvo_cigar_signatures(const csv_cigar_in* in, csv_cigar_out* out)
+{
+    int64_t n_i = 0, n_p = 0, n_d = 0;
+    for (int64_t r = 0; r < in->n_reads; r++) {
+        const int64_t c0 = in->cig_off[r], c1 = in->cig_off[r + 1];
+        if (c1 <= c0 || (in->use && !in->use[r])) continue;
+        int64_t sig_start = in->ref_start[r];                                  /* :616 */
+        int64_t shift = ((in->cigar[c0] & 15u) == 5u) ? -(int64_t)(in->cigar[c0] >> 4) : 0;   /* :621-627 */
+        int i_open = 0, d_open = 0;
+        int64_t i_last = 0, i_k = 0, d_last = 0, d_k = 0;
+        for (int64_t k = c0; k < c1; k++) {
+            const int op = (int)(in->cigar[k] & 15u);
+            const int64_t oplen = (int64_t)(in->cigar[k] >> 4);
+            if (op != 2) shift += oplen;                                       /* :630-631 */
+            if (oplen >= in->min_siglength && (op == 1 || op == 2)) {          /* :632 */
+                if (op == 2) {
+                    /* generate_combine_sigs, DEL branch (:553-575) */
+                    if (d_open && sig_start - d_last <= in->merge_del_threshold) {
+                        if (d_k < out->cap_sig_del) out->del_len[d_k] += oplen;
+                        d_last = sig_start + oplen;
+                    } else {
+                        const int was_open = d_open;
+                        d_k = n_d++;
+                        if (d_k < out->cap_sig_del) { out->del_read[d_k] = (int32_t)r; out->del_pos[d_k] = sig_start; out->del_len[d_k] = oplen; }
+                        d_open = 1;
+                        d_last = was_open ? sig_start : sig_start + oplen;     /* :555 sum(sigs[0]) / :569 append(i[0]) */
+                    }
+                    sig_start += oplen;                                        /* :635 */
+                } else {
+                    /* INS branch (:530-552) */
+                    const int64_t p = n_p++;
+                    if (p < out->cap_piece_ins) { out->piece_qoff[p] = (int32_t)(shift - oplen); out->piece_len[p] = (int32_t)oplen; }
+                    if (i_open && sig_start - i_last <= in->merge_ins_threshold) {
+                        if (i_k < out->cap_sig_ins) { out->ins_len[i_k] += oplen; out->ins_npiece[i_k] += 1; }
+                    } else {
+                        i_k = n_i++;
+                        if (i_k < out->cap_sig_ins) { out->ins_read[i_k] = (int32_t)r; out->ins_pos[i_k] = sig_start; out->ins_len[i_k] = oplen; out->ins_piece0[i_k] = p; out->ins_npiece[i_k] = 1; }
+                        i_open = 1;
+                    }
+                    i_last = sig_start;
+                }
+            } else if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) {  /* REFCHANGEOP (:589-602) */
+                sig_start += oplen;
+            }
+        }
+    }
+    out->n_sig_ins = n_i; out->n_piece_ins = n_p; out->n_sig_del = n_d;
+    out->ms_device = 0;
+    return (n_i > out->cap_sig_ins || n_p > out->cap_piece_ins || n_d > out->cap_sig_del) ? CSV_E_CAPACITY : CSV_OK;
+}

@@ -74,3 +74,16 @@ def cover_count(r_start, r_end, r_primary, r_id, L2, R2):
                                 len(r_start), L2.ctypes.data, R2.ctypes.data, len(L2), out.ctypes.data)
     assert rc == 0
     return out
+
+
+def cigar_signatures(cig_off, cigar, ref_start, use=None, min_siglength=10, merge_ins_threshold=100, merge_del_threshold=0):
+    """the C restatement of the CIGAR scan (csvo_cigar_signatures); same result dict as cutesv_amd.extract.cigar_signatures"""
+    from cutesv_amd import extract
+    L = lib()
+    L.csvo_cigar_signatures.restype = C.c_int
+    L.csvo_cigar_signatures.argtypes = [C.POINTER(extract.CigarIn), C.POINTER(extract.CigarOut)]
+
+    def check(rc):
+        if rc != _abi.OK:
+            raise RuntimeError("oracle: %s" % _abi.ERR_NAME.get(rc, rc))
+    return extract._run(L.csvo_cigar_signatures, None, cig_off, cigar, ref_start, use, min_siglength, merge_ins_threshold, merge_del_threshold, check)

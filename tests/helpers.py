@@ -123,3 +123,56 @@ def write_reference_workdir(store, work_dir):
                 index["reads"][ch] = f.tell()
                 pickle.dump(blk, f)
     return index
+
+
+# ------------------------------------------------------------------------------------------------ rebuild golden (8f row 2)
+def rebuild_case_inputs(case):
+    """the candidates of a rebuild_order.json.gz case in the order process_process_sigs_type reads them (main script
+    :753-761: worker files in pid order, batches in file order) -> ({type: [tuple]}, reads list)"""
+    per = {t: [] for t in ("DEL", "INS", "DUP", "INV", "TRA")}
+    reads = []
+    for f in case["files"]:
+        for t in per:
+            for batch in f[t]:
+                per[t].extend(tuple(x) for x in batch)
+        for batch in f["reads"]:
+            reads.extend(tuple(x) for x in batch)
+    return per, reads
+
+
+def rebuild_expected(case):
+    """the reference's per-(type, chromosome) lists with int(pos) in place of the INS float position (the columns hold
+    int(pos): every consumer takes int(), cuteSV_resolveINDEL.py:271)"""
+    out = {}
+    for t in ("DEL", "INS", "DUP", "INV", "TRA"):
+        for ch, rows in case["out"][t]:
+            out[(t, ch)] = [tuple([int(r[0])] + r[1:]) if t in ("DEL", "INS", "DUP") else tuple(r) for r in rows]
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ CIGAR scan golden (8f row 4)
+def cigar_case_inputs(case):
+    """a cigar_sigs.json.gz case -> (cig_off, cigar, ref_start, use, names, seqs, kwargs of the scan)"""
+    from cutesv_amd import extract
+    p = case["params"]
+    from cutesv_amd import synth
+    reads = case["reads"]
+    for r in reads:
+        r["seq"] = synth.pseudo_sequence(r["seq_len"], r["seq_key"])
+    off, flat = extract.encode_cigars([r["cigar"] for r in reads])
+    start = np.array([r["start"] for r in reads], np.int64)
+    # the gates of parse_read that are the caller's: query_length >= min_read_len (:607), mapq >= min_mapq (:614)
+    use = np.array([1 if (len(r["seq"]) >= p["min_read_len"] and r["mapq"] >= p["min_mapq"]) else 0 for r in reads], np.uint8)
+    kw = dict(min_siglength=p["min_siglength"], merge_ins_threshold=p["mi"], merge_del_threshold=p["md"])
+    return off, flat, start, use, [r["name"] for r in reads], [r["seq"] for r in reads], kw
+
+
+def assert_cigar_case(case, scan):
+    """scan(cig_off, cigar, ref_start, use, **kw) -> signature arrays; compared with the reference's candidate lists"""
+    from cutesv_amd import extract
+    off, flat, start, use, names, seqs, kw = cigar_case_inputs(case)
+    sig = scan(off, flat, start, use, **kw)
+    ins, dele = extract.candidates(sig, names, seqs, "chr7")
+    assert [list(x) for x in ins] == case["INS"], case["name"]
+    assert [list(x) for x in dele] == case["DEL"], case["name"]
+    return sig

@@ -489,3 +489,70 @@ def test_gpu_rebuild_reproduces_the_reference_order_contract(ctx):
         y = ctx.cluster_batch(st.host_batch(st.tasks(), p)).trimmed()
         for k in ("bp1", "bp2", "support", "cipos", "cilen", "support_sig"):
             assert np.array_equal(x[k], y[k]), k
+
+
+def test_gpu_rebuild_identical_to_reference_rebuild(ctx):
+    """csv_rebuild_signatures (+ the host finish of INS tie groups) on the raw, concatenated per-worker candidates ==
+    the per-chromosome lists the reference's process_process_sigs_type wrote (rebuild_order.json.gz)"""
+    from cutesv_amd import rebuild
+    from cutesv_amd.columns import intern_names, BND_CODE
+    from helpers import rebuild_case_inputs, rebuild_expected
+    for case in load_json("rebuild_order.json.gz"):
+        per, reads = rebuild_case_inputs(case)
+        chroms = sorted({x[-1] for t in per for x in per[t]} | {x[2] for x in per["TRA"]} | {r[-1] for r in reads})
+        cidx = {c: i for i, c in enumerate(chroms)}
+        npos = {"DEL": 2, "INS": 2, "DUP": 2, "INV": 3, "TRA": 4}
+        uniq, _ = intern_names([x[npos[t]] for t in per for x in per[t]] + [r[3] for r in reads])
+        rank = {n: i for i, n in enumerate(uniq)}
+        strands = sorted({x[0] for x in per["INV"]})
+        cols = {}
+        for t, lst in per.items():
+            d = dict(chrom=[cidx[x[-1]] for x in lst], read_id=[rank[x[npos[t]]] for x in lst])
+            if t in ("DEL", "DUP"):
+                d.update(a=[int(x[0]) for x in lst], b=[int(x[1]) for x in lst], aux=[0] * len(lst))
+            elif t == "INS":
+                d.update(a=[int(x[0]) for x in lst], b=[int(x[1]) for x in lst], aux=[len(x[3]) for x in lst],
+                         seq=[x[3] for x in lst], half=[int(x[0] != int(x[0])) for x in lst])
+            elif t == "INV":
+                d.update(a=[int(x[1]) for x in lst], b=[int(x[2]) for x in lst], aux=[strands.index(x[0]) for x in lst])
+            else:
+                d.update(a=[int(x[1]) for x in lst], b=[int(x[3]) for x in lst], aux=[cidx[x[2]] * 8 + BND_CODE[x[0]] for x in lst])
+            cols[t] = d
+        from cutesv_amd.columns import NameTable
+        st, _ = rebuild.store_from_unsorted(ctx, chroms, cols, names=NameTable(uniq), strands=tuple(strands))
+        got, _ = st.tuple_lists()
+        want = rebuild_expected(case)
+        assert set(want) == set(st.seg_index), case["name"]
+        for (t, ch), rows in want.items():
+            assert [x for x in got[t] if x[-1] == ch] == rows, (case["name"], t, ch)
+
+
+def test_cigar_scan_identical_to_reference_and_oracle(ctx):
+    """csv_cigar_signatures (8f row 4): the reference's candidate lists on the golden reads, and the oracle's arrays bit for
+    bit on a large random batch (reads of 1 .. 5000 operations, so that the 64-operation steps, the carried merge state
+    and the two-pass offsets are all exercised), plus the empty shapes"""
+    from cutesv_amd import extract
+    from helpers import assert_cigar_case
+    for case in load_json("cigar_sigs.json.gz"):
+        assert_cigar_case(case, lambda *a, **k: extract.cigar_signatures(ctx, *a, **k))
+    rng = np.random.default_rng(77)
+    n = 20000
+    nops = np.minimum(rng.geometric(1 / 60.0, n), 5000).astype(np.int64)
+    nops[rng.integers(0, n, 50)] = 0                                    # reads without a CIGAR
+    off = np.zeros(n + 1, np.int64); np.cumsum(nops, out=off[1:])
+    tot = int(off[-1])
+    op = rng.choice(np.array([0, 1, 2, 3, 4, 5, 6, 7, 8], np.uint32), tot, p=[0.4, 0.2, 0.2, 0.02, 0.02, 0.02, 0.02, 0.06, 0.06])
+    ln = np.where(rng.random(tot) < 0.2, rng.integers(10, 3000, tot), rng.integers(1, 10, tot)).astype(np.uint32)
+    cigar = (ln << np.uint32(4)) | op
+    start = rng.integers(0, 200_000_000, n).astype(np.int64)
+    use = (rng.random(n) < 0.9).astype(np.uint8)
+    for kw in (dict(min_siglength=10, merge_ins_threshold=100, merge_del_threshold=0), dict(min_siglength=1, merge_ins_threshold=5000, merge_del_threshold=5000),
+               dict(min_siglength=30, merge_ins_threshold=0, merge_del_threshold=300)):
+        want = _oracle().cigar_signatures(off, cigar, start, use, **kw)
+        got = extract.cigar_signatures(ctx, off, cigar, start, use, **kw)
+        for k in want:
+            if k != "ms_device":
+                assert np.array_equal(got[k], want[k]), (k, kw)
+        assert len(got["del_pos"]) > 1000 and len(got["ins_pos"]) > 1000
+    empty = extract.cigar_signatures(ctx, np.zeros(1, np.int64), np.zeros(0, np.uint32), np.zeros(0, np.int64))
+    assert len(empty["ins_pos"]) == 0 and len(empty["del_pos"]) == 0

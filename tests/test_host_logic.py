@@ -32,11 +32,12 @@ def test_c_abi_exports_every_declared_symbol():
     for c0, c1 in ((3, 1), (6, 2), (0, 5), (17, 9), (250, 31), (0, 400), (99, 2)):
         assert L.csv_gl_index(c0, c1) == genotype.gl_index(c0, c1)
     # the ctypes / numpy mirrors have exactly the layouts the library was compiled with
-    from cutesv_amd import rebuild, vcf, rows
+    from cutesv_amd import rebuild, vcf, rows, extract
     mirrors = [_abi.SEGMENT_DTYPE.itemsize, C.sizeof(_abi.BatchIn), C.sizeof(_abi.BatchOut), C.sizeof(_abi.RunStats),
-               C.sizeof(rebuild.RebuildIn), C.sizeof(rebuild.RebuildOut), C.sizeof(vcf.VcfIn), C.sizeof(rows.RowsIn)]
-    assert [L.csv_struct_size(i) for i in range(8)] == mirrors
-    assert L.csv_struct_size(8) == -1
+               C.sizeof(rebuild.RebuildIn), C.sizeof(rebuild.RebuildOut), C.sizeof(vcf.VcfIn), C.sizeof(rows.RowsIn),
+               C.sizeof(extract.CigarIn), C.sizeof(extract.CigarOut)]
+    assert [L.csv_struct_size(i) for i in range(10)] == mirrors
+    assert L.csv_struct_size(10) == -1
 
 
 def test_missing_extension_fails_loudly(tmp_path, monkeypatch):

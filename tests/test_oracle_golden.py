@@ -131,3 +131,38 @@ def test_py_restatement_rows_identical_to_reference():
         for (t, c), (chrom, rows) in zip(tasks, res):
             assert chrom == c
             assert_rows_equal(t, [[str(x) for x in r] for r in rows], want[(t, c)], where="py %s %s" % (case["name"], (t, c)))
+
+
+def test_rebuild_order_identical_to_reference():
+    """SigStore.from_tuple_lists (the host statement of the rebuild order) against the lists the reference's own
+    process_process_sigs_type + remove_duplicates_sorted wrote for the same per-worker pickles (main script :750-857,
+    :958-969): duplicates across workers, adversarial read-name orders, x.5 INS positions, INS rows that differ only in
+    their sequence."""
+    from helpers import rebuild_case_inputs, rebuild_expected
+    from cutesv_amd.columns import SigStore
+    for case in load_json("rebuild_order.json.gz"):
+        per, reads = rebuild_case_inputs(case)
+        st = SigStore.from_tuple_lists(per, reads)
+        got, got_reads = st.tuple_lists()
+        want = rebuild_expected(case)
+        assert set(want) == set(st.seg_index), case["name"]
+        for (t, ch), rows in want.items():
+            mine = [x for x in got[t] if x[-1] == ch]
+            assert mine == rows, (case["name"], t, ch)
+        # reads: the reference keeps the concatenation order per chromosome (:810); the store holds the same rows
+        # start-sorted, ties in that order
+        for ch, rows in case["out"]["reads"]:
+            ref_sorted = sorted((tuple(r) for r in rows), key=lambda r: r[0])
+            assert [r for r in got_reads if r[-1] == ch] == ref_sorted, (case["name"], ch)
+
+
+def test_cigar_scan_identical_to_reference():
+    """oracle (csvo_cigar_signatures) == the candidate lists the reference's parse_read + generate_combine_sigs produced
+    for the same reads (main script :606-655, :515-575): merging distances incl. the DEL quirk of :569, hard / soft clips,
+    N and P operations, min_siglength 1"""
+    from helpers import assert_cigar_case
+    n = 0
+    for case in load_json("cigar_sigs.json.gz"):
+        sig = assert_cigar_case(case, oracle.cigar_signatures)
+        n += len(sig["ins_pos"]) + len(sig["del_pos"])
+    assert n > 3000
