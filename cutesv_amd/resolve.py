@@ -38,15 +38,30 @@ def context():
     return _ctx
 
 
-def _store_for(work_dir, sigs_index):
-    """Signatures of a work dir as flat columns: `<work_dir>cutesv_amd.cols/` if our rebuild step wrote
-    it, otherwise converted once per process from the reference's pickles (main script :817-857)."""
-    st = _stores.get(work_dir)
-    if st is None:
-        cols = os.path.join(work_dir, "cutesv_amd.cols")
-        st = SigStore.load(cols) if os.path.isdir(cols) else SigStore.from_reference_workdir(work_dir, sigs_index)
-        _stores[work_dir] = st
-    return st
+def _store_for(work_dir, sigs_index, svtype, chrom, need_reads):
+    """Signatures of ONE task as flat columns: the mmap'ed `<work_dir>cutesv_amd.cols/` if our rebuild step wrote it
+    (shared by every task of the process), otherwise just this task's pickled list - and, when it genotypes, its
+    chromosome's reads block - converted from the reference's files (main script :817-857).  A pool worker therefore
+    pays for the tasks it runs, not for the genome (the reference's workers do the same, INDEL:52-58)."""
+    cols = os.path.join(work_dir, "cutesv_amd.cols")
+    if os.path.isdir(cols):
+        st = _stores.get(work_dir)
+        if st is None:
+            st = _stores[work_dir] = SigStore.load(cols)
+        return st
+    import pickle
+    with open("%s%s.pickle" % (work_dir, svtype), "rb") as f:
+        f.seek(sigs_index[svtype][chrom])
+        sigs = pickle.load(f)
+    reads = []
+    if need_reads and chrom in sigs_index.get("reads", {}):
+        with open("%sreads.pickle" % work_dir, "rb") as f:
+            f.seek(sigs_index["reads"][chrom])
+            reads = pickle.load(f)
+    chroms = None
+    if svtype == "TRA":                               # chr2 ranks must cover every mate chromosome of the list
+        chroms = sorted({chrom} | {x[2] for x in sigs})
+    return SigStore.from_tuple_lists({svtype: sigs}, reads, chroms=chroms)
 
 
 def run_batch(store, segments, tasks, ctx=None):
@@ -79,10 +94,12 @@ def cluster_stage(store, params, tasks=None, ctx=None):
     return results
 
 
-def _one(work_dir, chrom, svtype, sigs_index, seg_of_store):
+def _one(work_dir, chrom, svtype, sigs_index, seg_of_store, need_reads=False):
     if chrom not in sigs_index.get(svtype, {}):       # INDEL:44-45, DUP:19-20, INV:33-34, TRA:31-32
         return (chrom, [])
-    store = _store_for(work_dir, sigs_index)
+    if not work_dir.endswith("/"):
+        work_dir += "/"                               # (main_ctrl normalises it, main script :993-996)
+    store = _store_for(work_dir, sigs_index, svtype, chrom, need_reads)
     if (svtype, chrom) not in store.seg_index:
         return (chrom, [])
     seg = seg_of_store(store)
@@ -101,7 +118,7 @@ def _indel(args, svtype):
                                  diff_ratio=threshold_gloab, remain_reads_ratio=remain_reads_ratio,
                                  gt_bias=max_cluster_bias if svtype == "DEL" else 1000,       # INDEL:103 / :312
                                  min_support_reads=minimum_support_reads, genotype=bool(action))
-    return _one(path, chrom, svtype, sigs_index, seg)
+    return _one(path, chrom, svtype, sigs_index, seg, need_reads=bool(action))
 
 
 def run_del(args):
@@ -119,7 +136,7 @@ def run_inv(args):
         beg, end = store.seg_index[("INV", chrom)]
         return _abi.make_segment("INV", store.chroms.index(chrom), beg, end, max_cluster_bias, read_count,
                                  sv_size=sv_size, max_size=MaxSize, gt_bias=max_cluster_bias, genotype=bool(action))
-    return _one(path, chrom, "INV", sigs_index, seg)
+    return _one(path, chrom, "INV", sigs_index, seg, need_reads=bool(action))
 
 
 def run_dup(args):
@@ -129,15 +146,34 @@ def run_dup(args):
         beg, end = store.seg_index[("DUP", chrom)]
         return _abi.make_segment("DUP", store.chroms.index(chrom), beg, end, max_cluster_bias, read_count,
                                  sv_size=sv_size, max_size=MaxSize, gt_bias=max_cluster_bias, genotype=bool(action))
-    return _one(path, chrom, "DUP", sigs_index, seg)
+    return _one(path, chrom, "DUP", sigs_index, seg, need_reads=bool(action))
+
+
+_warned_tra = False
 
 
 def run_tra(args):
+    """TRA task.  With --genotype the reference re-opens the BAM per call (call_gt, cuteSV_resolveTRA.py:258-309).
+    CUTESV_AMD_TRA_GT selects how that is reproduced:
+      bam          (default) cluster on the GPU, then the reference's own loop over pysam on the host (tra_bam.py):
+                   identical to the reference on any BAM;
+      reads_table  genotype on the GPU from the reads table (k_genotype_tra): identical only when the windows hold no
+                   secondary / low-mapq alignments (main script :711-733) - a warning is logged once;
+      off          leave the '.' fields."""
+    global _warned_tra
     path, chrom, read_count, overlap_size, max_cluster_bias, bam, action, gt_round, sigs_index = args
+    mode = os.environ.get("CUTESV_AMD_TRA_GT", "bam") if action else "off"
+    if mode not in ("bam", "reads_table", "off"):
+        raise ValueError("CUTESV_AMD_TRA_GT must be bam, reads_table or off")
+    on_gpu = mode == "reads_table"
+    if on_gpu and not _warned_tra:
+        logging.warning("TRA calls are genotyped from the reads table (CUTESV_AMD_TRA_GT=reads_table): DR / GT / PL can differ "
+                        "from cuteSV's BAM-based call_gt where secondary or low-mapq alignments overlap a breakpoint window")
+        _warned_tra = True
 
     def seg(store):
         beg, end = store.seg_index[("TRA", chrom)]
-        if action and store.contig_len is None:
+        if on_gpu and store.contig_len is None:
             # call_gt only takes the reference lengths from the BAM (cuteSV_resolveTRA.py:264, 291); the
             # alignments come from the reads table (include/cutesv_hip.h, SURVEY.md 8f row 3)
             from .bam_header import reference_lengths
@@ -145,6 +181,36 @@ def run_tra(args):
             lens = reference_lengths(bam)
             store.contig_len = np.array([lens[c] for c in store.chroms], np.int64)
         return _abi.make_segment("TRA", store.chroms.index(chrom), beg, end, max_cluster_bias, read_count,
-                                 diff_ratio=overlap_size, gt_bias=max_cluster_bias, genotype=bool(action),
+                                 diff_ratio=overlap_size, gt_bias=max_cluster_bias, genotype=on_gpu,
                                  gt_round=gt_round)
-    return _one(path, chrom, "TRA", sigs_index, seg)
+    if on_gpu and not os.path.isdir(os.path.join(path, "cutesv_amd.cols")):
+        # the reads table must hold BOTH chromosomes of every pair: load every reads block for this task
+        res = _one_tra_reads_table(path, chrom, sigs_index, seg)
+    else:
+        res = _one(path, chrom, "TRA", sigs_index, seg)
+    if mode == "bam" and res[1]:
+        from .tra_bam import genotype_rows
+        res = (res[0], genotype_rows(res[1], bam, max_cluster_bias, gt_round))
+    return res
+
+
+def _one_tra_reads_table(work_dir, chrom, sigs_index, seg_of_store):
+    import pickle
+    if chrom not in sigs_index.get("TRA", {}):
+        return (chrom, [])
+    if not work_dir.endswith("/"):
+        work_dir += "/"
+    with open("%sTRA.pickle" % work_dir, "rb") as f:
+        f.seek(sigs_index["TRA"][chrom])
+        sigs = pickle.load(f)
+    chroms = sorted({chrom} | {x[2] for x in sigs})
+    reads = []
+    for c in chroms:
+        if c in sigs_index.get("reads", {}):
+            with open("%sreads.pickle" % work_dir, "rb") as f:
+                f.seek(sigs_index["reads"][c])
+                reads.extend(pickle.load(f))
+    store = SigStore.from_tuple_lists({"TRA": sigs}, reads, chroms=chroms)
+    rows = run_batch(store, [seg_of_store(store)], [("TRA", chrom)])[("TRA", chrom)]
+    logging.info("Finished %s:TRA." % chrom)
+    return (chrom, rows)

@@ -556,3 +556,37 @@ def test_cigar_scan_identical_to_reference_and_oracle(ctx):
         assert len(got["del_pos"]) > 1000 and len(got["ins_pos"]) > 1000
     empty = extract.cigar_signatures(ctx, np.zeros(1, np.int64), np.zeros(0, np.uint32), np.zeros(0, np.int64))
     assert len(empty["ins_pos"]) == 0 and len(empty["del_pos"]) == 0
+
+
+def test_run_tra_shim_genotypes_like_the_reference(ctx, tmp_path, monkeypatch):
+    """run_tra(action=True): clustering on the GPU + the reference's call_gt loop over the BAM (default), or everything on
+    the GPU from the reads table (CUTESV_AMD_TRA_GT=reads_table); both give the reference's rows on the golden cases
+    (whose BAM stand-in IS the reads table)"""
+    import sys
+    import types
+    from cutesv_amd import resolve
+    from helpers import write_reference_workdir
+    from test_host_logic import _StubBam
+    stub = types.ModuleType("pysam")
+    stub.AlignmentFile = _StubBam
+    monkeypatch.setitem(sys.modules, "pysam", stub)
+    monkeypatch.setattr(resolve, "_ctx", ctx)
+    for case in load_json("tra_genotype.json.gz")[:4]:
+        st = store_from_json(case["store"])
+        _StubBam.store = st
+        p = Params(**case["params"])
+        d = str(tmp_path / case["name"]) + "/"
+        os.makedirs(d)
+        idx = write_reference_workdir(st, d)
+        for mode in ("bam", "reads_table"):
+            monkeypatch.setenv("CUTESV_AMD_TRA_GT", mode)
+            if mode == "reads_table":
+                from cutesv_amd import bam_header
+                monkeypatch.setattr(bam_header, "reference_lengths", lambda path: {c: int(l) for c, l in zip(st.chroms, st.contig_len)})
+            for t, c, want in case["rows"]:
+                if t != "TRA":
+                    continue
+                got = resolve.run_tra((d, c, p.min_support, p.diff_ratio_filtering_TRA, p.max_cluster_bias_TRA, "stub.bam",
+                                       True, p.gt_round, idx))
+                assert got[0] == c
+                assert_rows_equal("TRA", got[1], want, where="run_tra %s %s %s" % (mode, case["name"], c))

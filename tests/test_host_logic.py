@@ -149,3 +149,53 @@ def test_two_rank_gloo_sharded_stage_matches_single_rank():
     outs = [p.communicate(timeout=600)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
     assert "SHARD-OK" in outs[0]
+
+
+class _StubBam:
+    """pysam.AlignmentFile stand-in over a store's reads table (the same stand-in the golden generator used)"""
+    store = None
+
+    def __init__(self, path):
+        self.st = _StubBam.store
+
+    def get_reference_length(self, chrom):
+        return int(self.st.contig_len[self.st.chroms.index(chrom)])
+
+    def fetch(self, chrom, s, e):
+        import types
+        st = self.st
+        c = st.chroms.index(chrom)
+        for i in range(int(st.reads_off[c]), int(st.reads_off[c + 1])):
+            if st.r_start[i] >= e:
+                break
+            if st.r_end[i] > s:
+                yield types.SimpleNamespace(flag=0 if st.r_primary[i] == 1 else 2048, reference_start=int(st.r_start[i]),
+                                            reference_end=int(st.r_end[i]), query_name=st.names[st.r_id[i]])
+
+    def close(self):
+        pass
+
+
+def test_bam_faithful_tra_genotyping_matches_reference(monkeypatch):
+    """tra_bam.genotype_rows (the default of the run_tra drop-in under --genotype) reproduces the genotype fields the
+    reference's call_gt computed for the same calls (tra_genotype.json.gz; pysam stubbed over the reads table)"""
+    import sys
+    import types
+    from helpers import load_json, store_from_json
+    from cutesv_amd import tra_bam
+    stub = types.ModuleType("pysam")
+    stub.AlignmentFile = _StubBam
+    monkeypatch.setitem(sys.modules, "pysam", stub)
+    n = 0
+    for case in load_json("tra_genotype.json.gz"):
+        st = store_from_json(case["store"])
+        _StubBam.store = st
+        p = case["params"]
+        for t, c, rows in case["rows"]:
+            if t != "TRA" or not rows:
+                continue
+            bare = [r[:6] + [".", "./.", ".,.,.", ".", ".", r[11]] for r in rows]
+            got = tra_bam.genotype_rows(bare, "stub.bam", p["max_cluster_bias_TRA"], p["gt_round"])
+            assert got == rows, (case["name"], c)
+            n += len(rows)
+    assert n > 20
