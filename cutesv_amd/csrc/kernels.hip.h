@@ -1537,6 +1537,13 @@ __device__ __forceinline__ void unit_rows(const DevBatch& B, const int4 e, int s
 // one unit of work: SW = 32 -> the pair of items (2p, 2p + 1), each handled if m <= 32;
 //                   SW = 64 -> the single item p, handled if 32 < m <= 64.  Returns (SW = 32 only) a 2-bit mask
 //                   of pair members that are DEL/INS clusters of 32 < m <= 64 and still need the wide pass.
+// Measurement aid (scripts/ablate.sh): -DCSV_ABLATE=<bit mask> drops a section of indel_unit so that its share of the
+// kernel time can be read off a same-box A/B run.  The results are wrong then; never defined in a product build.
+#ifdef CSV_ABLATE
+#define CSV_ABL(bit) (((CSV_ABLATE) >> (bit)) & 1)
+#else
+#define CSV_ABL(bit) 0
+#endif
 template <int SW> __device__ __forceinline__ int indel_unit(const DevBatch& B, const UnitIn& U)
 {
     constexpr bool HALF = SW == 32;
@@ -1556,6 +1563,7 @@ template <int SW> __device__ __forceinline__ int indel_unit(const DevBatch& B, c
             wide = (int)(wm & 1) | (int)((wm >> 32) & 1) << 1;
         }
         if (!__ballot(act)) break;
+        if (CSV_ABL(6)) { if (act && sl == 0) item_done(B, j, 0, 0, (int)(U.a + U.b + U.rid + U.aux)); break; }      // loads only
         // segment scalars: issued here, first needed after the de-duplication (the table is a few KB and cache resident)
         int rc = 0x7fffffff, msr = 0;
         double ratio = 0.0, rr = 1.0;
@@ -1600,15 +1608,20 @@ template <int SW> __device__ __forceinline__ int indel_unit(const DevBatch& B, c
             }
             const u64 mine = SUBMASK << hb;
             dup_any = in && __popcll(match & mine) > 1;
+            if (CSV_ABL(0)) dup_any = false;
         }
-        if (__ballot(dup_any)) {
-            F = -1; ch = -1; bl = INT64_MIN;
-            for (int t = 0; t < mmax; t++) {
-                const int rt = sub_rl<SW>(rid, t, g);
-                const i64 bt = sub_rl64<SW>(b, t, g);
-                if (rt == rid) {
-                    if (F < 0) F = t;
-                    if (bt > bl) { bl = bt; ch = t; }
+        // Reads with more than one signature in a cluster are common (a 30x cluster has one in ~40 % of the cases), so this is
+        // not a rare path: walk only the lanes that have a partner (two to four per wavefront, in lane order = order of
+        // appearance), each broadcast with plain v_readlane, instead of all mmax sub-lanes through the 4-way select.
+        if (const u64 dm0 = __ballot(dup_any)) {
+            if (dup_any) { F = -1; ch = -1; bl = INT64_MIN; }
+            for (u64 dm = dm0; dm; dm &= dm - 1) {
+                const int t = __ffsll((long long)dm) - 1;
+                const int rt = __builtin_amdgcn_readlane(rid, t);
+                const i64 bt = readlane_i64(b, t);
+                if (dup_any && (t & ~(SW - 1)) == hb && rt == rid) {          // same cluster, same read (a folded-id false match fails here)
+                    if (F < 0) F = t & (SW - 1);
+                    if (bt > bl) { bl = bt; ch = t & (SW - 1); }
                 }
             }
         }
@@ -1623,7 +1636,8 @@ template <int SW> __device__ __forceinline__ int indel_unit(const DevBatch& B, c
 
         // ---- stable sort of the kept signatures by length (INDEL:136): rank by (len, first appearance)
         int rank = 0;
-        if (SW < 64) {
+        if (CSV_ABL(1)) rank = sl;
+        else if (SW < 64) {
             if (!__ballot(rep && (bl >> 26) != 0)) {
                 // every kept length fits 26 bits: (length, first appearance) packs into ONE word, so a step is a
                 // broadcast, a compare and an add.  Lanes that are not kept never count as smaller.
@@ -1680,7 +1694,7 @@ template <int SW> __device__ __forceinline__ int indel_unit(const DevBatch& B, c
         const bool pass = live && n >= msr;
         int erank = 0, soff = 0, npass = 0;
         const u64 starts = fmask | (NSUB == 4 ? 0x0001000100010001ull : NSUB == 2 ? 0x0000000100000001ull : 1ull);   // allele starts of every sub-wave, absolute lanes
-        for (u64 mk = starts; mk; mk &= mk - 1) {
+        for (u64 mk = CSV_ABL(5) ? 0ull : starts; mk; mk &= mk - 1) {
             const int t = __ffsll((long long)mk) - 1;
             const int nt = __builtin_amdgcn_readlane(n, t);
             const int tl = t & (SW - 1);
@@ -1696,7 +1710,8 @@ template <int SW> __device__ __forceinline__ int indel_unit(const DevBatch& B, c
         const double dp = fabs((double)pos - pmean), dl = fabs((double)len - lmean);
         double bp = pmean, siglen = lmean;
         i64 search;
-        if (!__ballot(pass && keep < n)) {
+        if (CSV_ABL(3)) search = pos;
+        else if (!__ballot(pass && keep < n)) {
             // every member kept: search_threshold = first member with the smallest |pos - mean| (INDEL:171-177)
             double bd = dp; int bi = r;
             for (int d = 1; d < SW; d <<= 1) {
@@ -1725,11 +1740,14 @@ template <int SW> __device__ __forceinline__ int indel_unit(const DevBatch& B, c
             bp = (double)ks / (double)keep; siglen = (double)kl / (double)keep;   // INDEL:176-177, 187
         }
         const int rows_u = (mmax >> 3) + 1, tail_u = mmax < 7 ? mmax : 7;         // wave-uniform bounds (allele size <= m)
-        double vsp, vsl;
-        np_sum_allele2(((double)pos - pmean) * ((double)pos - pmean), ((double)len - lmean) * ((double)len - lmean), n, i, rows_u, tail_u, vsp, vsl);
-        const double rt = B.sqrt_tab[n & (SQRT_TAB - 1)];
-        const int cip = (int)(1.96 * sqrt(vsp / (double)n) / rt);                 // INDEL:191, GT:58-60
-        const int cil = (int)(1.96 * sqrt(vsl / (double)n) / rt);                 // INDEL:194
+        double vsp = 0.0, vsl = 0.0;
+        int cip = 0, cil = 0;
+        if (!CSV_ABL(2)) {
+            np_sum_allele2(((double)pos - pmean) * ((double)pos - pmean), ((double)len - lmean) * ((double)len - lmean), n, i, rows_u, tail_u, vsp, vsl);
+            const double rt = B.sqrt_tab[n & (SQRT_TAB - 1)];
+            cip = (int)(1.96 * sqrt(vsp / (double)n) / rt);                       // INDEL:191, GT:58-60
+            cil = (int)(1.96 * sqrt(vsl / (double)n) / rt);                       // INDEL:194
+        }
 
         // ---- INS: first member (allele order) whose sequence is long enough gives POS and ALT (INDEL:398-405)
         const i64 want = (i64)siglen;
@@ -1746,9 +1764,9 @@ template <int SW> __device__ __forceinline__ int indel_unit(const DevBatch& B, c
             bp = (double)pick_pos;
             search = (i64)bp;                                                     // INDEL:415
         }
-        if (pass) B.sup_tmp[s + soff + i] = s + chp;                              // INDEL:205, 416
+        if (pass && !CSV_ABL(4)) B.sup_tmp[s + soff + i] = s + chp;               // INDEL:205, 416
         const bool head = pass && i == 0;
-        if (head) {
+        if (head && !CSV_ABL(4)) {
             const int t = s + erank;
             B.t_bp1[t] = (i64)bp; B.t_bp2[t] = (i64)siglen; B.t_support[t] = n;
             B.t_cipos[t] = cip; B.t_cilen[t] = cil; B.t_search[t] = search; B.t_pick[t] = valid ? pick : -1;
