@@ -63,7 +63,7 @@ struct csv_ctx {
     Arena       arena, arena_rb;
     // batch buffers (slices of `arena`)
     Buf seg, woff, seg_drop, a, b, rid, aux;
-    Buf cluster_id, partial, partial64, item_rec, list_small, list_big, list_tiny, tile_prev, partial_t, seg_gate, ch_masks, ch_ku, seg_err;
+    Buf cluster_id, partial, partial64, item_rec, list_small, list_big, list_tiny, partial_t, seg_gate, ch_masks, wave_items, wave_cnt, seg_err;
     Buf item_nslots, item_cnt, item_base, sup_tmp;
     Buf t_bp1, t_bp2, t_search, t_pick, t_support, t_cipos, t_cilen, t_supoff, t_valid;
     Buf sc_k, sc_x, sc_v1, sc_v2, sc_v3, sc_v4, sc_v5;
@@ -372,8 +372,9 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
     PL(a, (W + 1) * 8); PL(b, (W + 1) * 8); PL(rid, (W + 1) * 4); PL(aux, (W + 1) * 4);
     PL(sup_tmp, (W + 1) * 4);
     if (per_sig) { PL(cluster_id, (W + 1) * 4); PL(allele_id, (W + 1) * 4); }
-    PL(partial, nt * 4); PL(partial64, nt * 8); PL(tile_prev, nt * 8); PL(partial_t, nt * 4);
-    PL(ch_masks, nt * 4 * 2 * CH_ITEMS * 8); PL(ch_ku, nt * 4 * 4);
+    PL(partial, nt * 4); PL(partial64, nt * 8); PL(partial_t, nt * 4);
+    if (per_sig) PL(ch_masks, nt * 4 * CH_ITEMS * 8);
+    PL(wave_items, nt * 4 * (size_t)WI_STRIDE * 16); PL(wave_cnt, nt * 4 * 16);
     PL(item_rec, cap_items * 16); PL(list_small, cap_items * 16); PL(list_big, cap_items * 4); PL(list_tiny, cap_items * 16);
     PL(item_nslots, cap_items * 4); PL(item_cnt, cap_items * 8); PL(item_base, (cap_items + 8) * 8);
     // temp call records are indexed by w (a cluster's slots live in its own signature range)
@@ -478,8 +479,9 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
     B.cluster_id = per_sig ? dp<int>(c->cluster_id) : nullptr; B.allele_id = per_sig ? dp<int>(c->allele_id) : nullptr;
     B.partial = dp<int>(c->partial); B.partial64 = dp<i64>(c->partial64);
     B.item_rec = dp<int4>(c->item_rec); B.list_small = dp<int4>(c->list_small); B.list_big = dp<int>(c->list_big); B.list_tiny = dp<int4>(c->list_tiny);
-    B.tile_prev = dp<int2>(c->tile_prev); B.partial_t = dp<int>(c->partial_t); B.seg_gate = dp<int4>(c->seg_gate);
-    B.ch_masks = dp<u64>(c->ch_masks); B.ch_ku = dp<int>(c->ch_ku); B.seg_err = dp<int>(c->seg_err);
+    B.partial_t = dp<int>(c->partial_t); B.seg_gate = dp<int4>(c->seg_gate);
+    B.ch_masks = per_sig ? dp<u64>(c->ch_masks) : nullptr; B.wave_items = dp<int4>(c->wave_items); B.wave_cnt = dp<int4>(c->wave_cnt);
+    B.seg_err = dp<int>(c->seg_err);
     B.tiny_max = getenv("CSV_NO_TINY") ? 0 : 16;               // (timing aid: 0 sends every DEL/INS cluster of m <= 32 through the paired path)
     B.item_nslots = dp<int>(c->item_nslots); B.item_cnt = dp<i64>(c->item_cnt); B.item_base = dp<i64>(c->item_base);
     B.sup_tmp = dp<int>(c->sup_tmp);
@@ -612,6 +614,7 @@ int run_impl(csv_ctx* c, csv_run_stats* stats)
             HIP_TRY(c, hipEventRecord(c->ev_aux[2], sD));
         }
         LAUNCH("chain_apply", k_chain_apply, nb, 256, 0, B);
+        if (B.per_sig) hipLaunchKernelGGL(k_chain_ids, dim3(nb), dim3(256), 0, st, B);      // (optional outputs; timed with whatever follows)
         if (c->copies_pending) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_copy[1], 0));   // read ids, INS sequence lengths
         int g_small = B.cap_items < 8192 ? B.cap_items : 8192;
         if (g_small < 1) g_small = 1;

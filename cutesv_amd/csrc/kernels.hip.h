@@ -90,9 +90,10 @@ struct DevBatch {
     int*           list_big;
     int4*          list_tiny;        // DEL/INS items with m <= tiny_max (same entries): k_refine_indel_wave packs four per wavefront
     int            tiny_max;         // 16 (0 switches the class off)
-    int2*          tile_prev;        // {last cluster start before the chain tile, its segment} (k_chain_count -> k_chain_apply)
-    u64*           ch_masks;         // per chain wavefront (512 signatures): 8 flag masks + 8 "(0,0) predecessor" masks
-    int*           ch_ku;            // per chain wavefront: its segment when the span lies in one, else -1 / -2
+    u64*           ch_masks;         // per chain wavefront (512 signatures): its 8 flag masks (written only for CSV_IN_PER_SIG: k_chain_ids)
+    int4*          wave_items;       // per chain wavefront, WI_STRIDE slots: the clusters that passed the size gate, in order:
+                                     // {first w, size, segment | svtype << 24 | tier << 28, cluster index relative to the wavefront}
+    int4*          wave_cnt;         // per chain wavefront {cluster starts, work items, workgroup-tier items, tiny items}
     int            per_sig;          // CSV_IN_PER_SIG: cluster_id / allele_id are produced
     int*           seg_err;          // n_seg words of CSV_SEG_* bits
     const int4*    seg_gate;         // per segment {read_count, dropped, svtype, -}: one 16-byte load for the size gate
@@ -384,6 +385,7 @@ __device__ __forceinline__ int close_gate(const DevBatch& B, const int4 g, int s
 // rows -> flags; the wavefront's cluster starts (bit 31: previous signature is (0,0)) and their segments go to its OWN
 // region of the LDS lists, so nothing here waits for another wavefront.  Returns the wavefront's number of starts.
 constexpr int CL_REG = WAVE * CH_ITEMS + 2;          // entries per wavefront region (512 starts + the sentinel)
+constexpr int WI_STRIDE = WAVE * CH_ITEMS + 8;       // item slots per wavefront (at most 513 clusters end in its span)
 __device__ __forceinline__ int wave_starts(const DevBatch& B, i64 base, u64 (&masks)[CH_ITEMS], u64 (&zmasks)[CH_ITEMS], int* SR, int* SKR, int& ku)
 {
     int zprev[CH_ITEMS], ksg[CH_ITEMS];
@@ -398,24 +400,6 @@ __device__ __forceinline__ int wave_starts(const DevBatch& B, i64 base, u64 (&ma
             const int idx = off + __popcll(m & lanemask_lt());
             SR[idx] = (int)(base + r * WAVE + lane_id()) | (zprev[r] << 31);
             SKR[idx] = ksg[r];
-        }
-        off += __popcll(m);
-    }
-    return off;
-}
-// the same lists rebuilt from the masks k_chain_count published (k_chain_apply reads 132 bytes per wavefront instead of
-// its 512 rows: the position column is read ONCE per run, and no flag is derived twice)
-__device__ __forceinline__ int wave_starts_from_masks(const DevBatch& B, i64 base, const u64 (&masks)[CH_ITEMS], const u64 (&zmasks)[CH_ITEMS], int ku, int* SR, int* SKR)
-{
-    int off = 0;
-#pragma unroll
-    for (int r = 0; r < CH_ITEMS; r++) {
-        const u64 m = masks[r];
-        if ((m >> lane_id()) & 1) {
-            const int idx = off + __popcll(m & lanemask_lt());
-            const i64 w = base + r * WAVE + lane_id();
-            SR[idx] = (int)w | ((int)((zmasks[r] >> lane_id()) & 1) << 31);
-            SKR[idx] = ku >= 0 ? ku : seg_of(B, w);           // (a span that crosses segments: rare, binary search)
         }
         off += __popcll(m);
     }
@@ -497,17 +481,15 @@ __global__ __launch_bounds__(320) void k_chain_count(DevBatch B)
             if (f) { const int l = 63 - __clzll((long long)f); p = (int)cb + l; kp = __builtin_amdgcn_readlane(kseg, l); }
             hiw = cb;
         }
-        if (lane_id() == 0) { s_prev[0] = p; s_prev[1] = kp; B.tile_prev[blockIdx.x] = make_int2(p, kp); }
+        if (lane_id() == 0) { s_prev[0] = p; s_prev[1] = kp; }
     } else {
         cnt = wave_starts(B, tile0 + wv * (WAVE * CH_ITEMS), masks, zmasks, SR[wv], SKR[wv], ku);
         if (ku >= 0) g_own = B.seg_gate[ku];
-        {                                                  // publish the flags for k_chain_apply: lane r holds masks[r], lane 8 + r zmasks[r]
+        if (B.per_sig) {                                   // the flags, for k_chain_ids: lane r stores masks[r]
             u64 pub = 0;
 #pragma unroll
-            for (int r = 0; r < CH_ITEMS; r++) { if (lane_id() == r) pub = masks[r]; if (lane_id() == CH_ITEMS + r) pub = zmasks[r]; }
-            const i64 gw = (i64)blockIdx.x * 4 + wv;
-            if (lane_id() < 2 * CH_ITEMS) B.ch_masks[gw * (2 * CH_ITEMS) + lane_id()] = pub;
-            if (lane_id() == 0) B.ch_ku[gw] = ku;
+            for (int r = 0; r < CH_ITEMS; r++) if (lane_id() == r) pub = masks[r];
+            if (lane_id() < CH_ITEMS) B.ch_masks[((i64)blockIdx.x * 4 + wv) * CH_ITEMS + lane_id()] = pub;
         }
         if (lane_id() == 0) {
             s_cnt[wv] = cnt; s_ku[wv] = ku;
@@ -521,18 +503,28 @@ __global__ __launch_bounds__(320) void k_chain_count(DevBatch B)
         tile_seg(s_ku, ku, g_own, ts);
         const int2 ob = open_before(SR, SKR, s_cnt, wv, make_int2(s_prev[0], s_prev[1]));
         const int nc = cnt + ((last_tile && wv == 3) ? 1 : 0);   // clusters that end at this wavefront's starts
+        // The size gate is evaluated HERE only: the clusters that pass (a few per cent) leave a record in the wavefront's
+        // own item region, in order, and k_chain_apply is a plain compaction of those records (it used to rebuild the start
+        // lists from the masks and evaluate every gate a second time: 16 us of a 100 us step).
+        const i64 gw = (i64)blockIdx.x * 4 + wv;
         int n_sel = 0, n_big = 0, n_tiny = 0;               // wave-uniform counts: ballots + scalar popcounts, no VALU sums
         for (int i0 = 0; i0 < nc; i0 += 64) {
             const int i = i0 + lane_id();
-            int fl = 0;
+            int fl = 0, s0c = 0, mc = 0, kt = 0;
             if (i < nc) {
                 const int e1 = SR[wv][i];
                 const int s0 = i ? SR[wv][i - 1] : ob.x, k = i ? SKR[wv][i - 1] : ob.y;
-                if (s0 != -1) fl = close_gate(B, gate_scalars(B, ts, k), s0 & 0x7fffffff, e1 & 0x7fffffff, e1 < 0);
+                if (s0 != -1) {
+                    const int4 g = gate_scalars(B, ts, k);
+                    fl = close_gate(B, g, s0 & 0x7fffffff, e1 & 0x7fffffff, e1 < 0);
+                    s0c = s0 & 0x7fffffff; mc = (e1 & 0x7fffffff) - s0c; kt = k | (g.z << 24) | ((fl >> 1) << 28);
+                }
             }
-            n_sel += __popcll(__ballot(fl & 1)); n_big += __popcll(__ballot(fl & 2)); n_tiny += __popcll(__ballot(fl & 4));
+            const u64 m_sel = __ballot(fl & 1);
+            if (fl & 1) B.wave_items[gw * WI_STRIDE + n_sel + __popcll(m_sel & lanemask_lt())] = make_int4(s0c, mc, kt, i - 1);
+            n_sel += __popcll(m_sel); n_big += __popcll(__ballot(fl & 2)); n_tiny += __popcll(__ballot(fl & 4));
         }
-        if (lane_id() == 0) { s_v[wv] = (i64)n_sel | ((i64)n_big << 32); s_t[wv] = n_tiny; }
+        if (lane_id() == 0) { s_v[wv] = (i64)n_sel | ((i64)n_big << 32); s_t[wv] = n_tiny; B.wave_cnt[gw] = make_int4(cnt, n_sel, n_big, n_tiny); }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -542,99 +534,74 @@ __global__ __launch_bounds__(320) void k_chain_count(DevBatch B)
     }
 }
 
-constexpr int CL_STEPS = CH_ITEMS + 1;              // 64-cluster steps a wavefront can need (512 starts + the sentinel)
+// Compaction of the wavefronts' item records into the ordered work list and the three tier lists.  One workgroup per
+// chain tile (the prefix over the earlier tiles is recomputed from the per-tile counts: a few thousand L2-resident
+// values), one wavefront per chain wavefront.  Reads ~16 bytes per work item; no signature column, no flag, no gate.
 __global__ __launch_bounds__(256) void k_chain_apply(DevBatch B)
 {
-    __shared__ int SR[4][CL_REG], SKR[4][CL_REG];
-    __shared__ int s_cnt[4], s_ku[4], s_t[4];
-    __shared__ i64 s_v[4], sh[12];
+    __shared__ i64 sh[12];
     const int wv = threadIdx.x >> 6;
-    const i64 base = (i64)blockIdx.x * CH_TILE + wv * (WAVE * CH_ITEMS);
+    const i64 gw = (i64)blockIdx.x * 4 + wv;
     const bool last_tile = blockIdx.x == gridDim.x - 1;
-    u64 masks[CH_ITEMS], zmasks[CH_ITEMS];
-    int ku;
-    {                                                       // the flags of this wavefront's 512 signatures, as k_chain_count left them
-        const i64 gw = (i64)blockIdx.x * 4 + wv;
-        const u64 pub = lane_id() < 2 * CH_ITEMS ? B.ch_masks[gw * (2 * CH_ITEMS) + lane_id()] : 0;
-        ku = __builtin_amdgcn_readfirstlane(B.ch_ku[gw]);
-#pragma unroll
-        for (int r = 0; r < CH_ITEMS; r++) { masks[r] = (u64)readlane_i64x((i64)pub, r); zmasks[r] = (u64)readlane_i64x((i64)pub, CH_ITEMS + r); }
-    }
-    // the three exclusive prefixes of this workgroup (cluster starts, work items | workgroup tier, tiny items):
-    // sums over all earlier workgroups, tiny and L2 resident
     i64 p0 = 0, p1 = 0, p2 = 0;
     for (int i = threadIdx.x; i < (int)blockIdx.x; i += 256) { p0 += B.partial[i]; p1 += B.partial64[i]; p2 += B.partial_t[i]; }
     p0 = wave_sum_i64(p0); p1 = wave_sum_i64(p1); p2 = wave_sum_i64(p2);
     if (lane_id() == 0) { sh[wv] = p0; sh[4 + wv] = p1; sh[8 + wv] = p2; }
-    const int cnt = wave_starts_from_masks(B, base, masks, zmasks, ku, SR[wv], SKR[wv]);
-    int4 g_own = make_int4(0, 0, 0, 0);
-    if (ku >= 0) g_own = B.seg_gate[ku];                    // (before the barrier: no global load on the path after it)
-    const int2 tile_prev = B.tile_prev[blockIdx.x];
-    if (lane_id() == 0) {
-        s_cnt[wv] = cnt; s_ku[wv] = ku;
-        if (last_tile && wv == 3) SR[3][cnt] = (int)B.W | ((B.a[B.W - 1] == 0 && B.b[B.W - 1] == 0) ? (1 << 31) : 0);
-    }
-    __syncthreads();                                        // ---- barrier 1: every region, count and prefix partial is visible
-    int run = (int)(sh[0] + sh[1] + sh[2] + sh[3]);
-    i64 runs = sh[4] + sh[5] + sh[6] + sh[7];
-    int run_t = (int)(sh[8] + sh[9] + sh[10] + sh[11]);
-    const int n = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
-    const int cid_tile = run;                               // id of the first cluster that STARTS in this tile
-    for (int q = 0; q < wv; q++) run += s_cnt[q];
-    const int cid_wave = run;                               // ... in this wavefront's span
-#pragma unroll
-    for (int r = 0; r < CH_ITEMS; r++) {
-        const i64 w = base + r * WAVE + lane_id();
-        const u64 m = masks[r];
-        if (B.per_sig && w < B.W) { B.cluster_id[w] = run + __popcll(m & (lanemask_lt() | (1ull << lane_id()))) - 1; B.allele_id[w] = -1; }
-        run += __popcll(m);
-    }
-    // gate of the clusters that end at this wavefront's starts; the 3 flag bits of the <= 9 steps of 64 clusters stay
-    // packed in one register, the records are re-read from LDS by the few lanes that write a work item
-    TileSeg ts;
-    tile_seg(s_ku, ku, g_own, ts);
-    const int2 ob = open_before(SR, SKR, s_cnt, wv, tile_prev);
-    const int nc = cnt + ((last_tile && wv == 3) ? 1 : 0);
-    int flags = 0;
-    int n_sel = 0, n_big = 0, n_tiny = 0;
-#pragma unroll
-    for (int st = 0; st < CL_STEPS; st++) {
-        if (st * 64 >= nc) break;                           // wave-uniform
-        const int i = st * 64 + lane_id();
-        int fl = 0;
-        if (i < nc) {
-            const int e1 = SR[wv][i];
-            const int s0 = i ? SR[wv][i - 1] : ob.x, k = i ? SKR[wv][i - 1] : ob.y;
-            if (s0 != -1) fl = close_gate(B, gate_scalars(B, ts, k), s0 & 0x7fffffff, e1 & 0x7fffffff, e1 < 0);
-        }
-        flags |= fl << (3 * st);
-        n_sel += __popcll(__ballot(fl & 1)); n_big += __popcll(__ballot(fl & 2)); n_tiny += __popcll(__ballot(fl & 4));
-    }
-    if (lane_id() == 0) { s_v[wv] = (i64)n_sel | ((i64)n_big << 32); s_t[wv] = n_tiny; }
-    __syncthreads();                                        // ---- barrier 2: per-wavefront work item counts
-    int bj = (int)(runs & 0xffffffffll), bb = (int)(runs >> 32), bt = run_t;
-    for (int q = 0; q < wv; q++) { bj += (int)(s_v[q] & 0xffffffffll); bb += (int)(s_v[q] >> 32); bt += s_t[q]; }
-#pragma unroll
-    for (int st = 0; st < CL_STEPS; st++) {
-        if (st * 64 >= nc) break;                           // wave-uniform
-        const int fl = (flags >> (3 * st)) & 7;
-        const u64 m_sel = __ballot(fl & 1), m_big = __ballot(fl & 2), m_tiny = __ballot(fl & 4);
-        if (fl & 1) {
-            const int j = bj + __popcll(m_sel & lanemask_lt()), jb = bb + __popcll(m_big & lanemask_lt()), jt = bt + __popcll(m_tiny & lanemask_lt());
-            const int i = st * 64 + lane_id();
-            const int e1 = SR[wv][i] & 0x7fffffff;
-            const int s0 = (i ? SR[wv][i - 1] : ob.x) & 0x7fffffff, k = i ? SKR[wv][i - 1] : ob.y;
-            B.item_rec[j] = make_int4(cid_wave + i - 1, k, s0, e1 - s0);
-            const int4 ent = make_int4(j, k | (gate_scalars(B, ts, k).z << 24), s0, e1 - s0);
-            if (fl & 2) B.list_big[jb] = j;
-            else if (fl & 4) B.list_tiny[jt] = ent;
+    const int4 wc = B.wave_cnt[gw];                          // {cluster starts, work items, workgroup tier, tiny}
+    int4 before = make_int4(0, 0, 0, 0);                    // ... of the tile's earlier wavefronts
+    for (int q = 0; q < wv; q++) { const int4 c = B.wave_cnt[gw - wv + q]; before.x += c.x; before.y += c.y; before.z += c.z; before.w += c.w; }
+    __syncthreads();
+    const i64 runs = sh[4] + sh[5] + sh[6] + sh[7];
+    const int run = (int)(sh[0] + sh[1] + sh[2] + sh[3]) + before.x;          // id of the first cluster that STARTS in this wavefront's span
+    const int bj = (int)(runs & 0xffffffffll) + before.y;
+    int bb = (int)(runs >> 32) + before.z, bt = (int)(sh[8] + sh[9] + sh[10] + sh[11]) + before.w;
+    const int n_it = __builtin_amdgcn_readfirstlane(wc.y);
+    for (int base = 0; base < n_it; base += 64) {
+        const int idx = base + lane_id();
+        const bool act = idx < n_it;
+        int4 rec = make_int4(0, 0, 0, 0);
+        if (act) rec = B.wave_items[gw * WI_STRIDE + idx];
+        const int tier = (rec.z >> 28) & 3;
+        const u64 m_big = __ballot(act && (tier & 1)), m_tiny = __ballot(act && (tier & 2));
+        if (act) {
+            const int j = bj + idx, jb = bb + __popcll(m_big & lanemask_lt()), jt = bt + __popcll(m_tiny & lanemask_lt());
+            B.item_rec[j] = make_int4(run + rec.w, rec.z & 0xffffff, rec.x, rec.y);
+            const int4 ent = make_int4(j, rec.z & 0x0fffffff, rec.x, rec.y);
+            if (tier & 1) B.list_big[jb] = j;
+            else if (tier & 2) B.list_tiny[jt] = ent;
             else B.list_small[j - jb - jt] = ent;
         }
-        bj += __popcll(m_sel); bb += __popcll(m_big); bt += __popcll(m_tiny);
+        bb += __popcll(m_big); bt += __popcll(m_tiny);
     }
     if (last_tile && threadIdx.x == 255) {                  // wavefront 3: its running counts now cover the whole batch
-        B.cnt->n_clusters = cid_tile + n;
-        B.cnt->n_items = bj; B.cnt->n_items_big = bb; B.cnt->n_items_tiny = bt;
+        B.cnt->n_clusters = run + wc.x;
+        B.cnt->n_items = bj + wc.y; B.cnt->n_items_big = bb; B.cnt->n_items_tiny = bt;
+    }
+}
+
+// CSV_IN_PER_SIG only: dense cluster id of every signature (and allele_id = -1 until k_emit says otherwise), from the
+// flag masks k_chain_count published
+__global__ __launch_bounds__(256) void k_chain_ids(DevBatch B)
+{
+    __shared__ i64 sh[4];
+    const int wv = threadIdx.x >> 6;
+    const i64 gw = (i64)blockIdx.x * 4 + wv;
+    const i64 base = (i64)blockIdx.x * CH_TILE + wv * (WAVE * CH_ITEMS);
+    i64 p0 = 0;
+    for (int i = threadIdx.x; i < (int)blockIdx.x; i += 256) p0 += B.partial[i];
+    p0 = wave_sum_i64(p0);
+    if (lane_id() == 0) sh[wv] = p0;
+    const u64 pub = lane_id() < CH_ITEMS ? B.ch_masks[gw * CH_ITEMS + lane_id()] : 0;
+    int run = 0;
+    for (int q = 0; q < wv; q++) run += B.wave_cnt[gw - wv + q].x;
+    __syncthreads();
+    run += (int)(sh[0] + sh[1] + sh[2] + sh[3]);
+#pragma unroll
+    for (int r = 0; r < CH_ITEMS; r++) {
+        const u64 m = (u64)readlane_i64x((i64)pub, r);
+        const i64 w = base + r * WAVE + lane_id();
+        if (w < B.W) { B.cluster_id[w] = run + __popcll(m & (lanemask_lt() | (1ull << lane_id()))) - 1; B.allele_id[w] = -1; }
+        run += __popcll(m);
     }
 }
 
