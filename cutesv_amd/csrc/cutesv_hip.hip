@@ -685,7 +685,7 @@ int read_counters(csv_ctx* c)
         HIP_TRY(c, hipMemcpyAsync(c->h_pin, c->cnt.p, sizeof(DevCounters), hipMemcpyDeviceToHost, st));
         HIP_TRY(c, hipStreamSynchronize(st));
         memcpy(&c->h_cnt, c->h_pin, sizeof(DevCounters));
-        if (getenv("CSV_DEBUG"))
+        if (getenv("CSV_DEBUG") || getenv("CSV_DEBUG_COUNTERS"))
             fprintf(stderr, "[csv] counters: clusters %d items %d calls %d error %d | reads: mode %d runs %d state %d | gt_over %d gt_huge %d tra_huge %d\n",
                     c->h_cnt.n_clusters, c->h_cnt.n_items, c->h_cnt.n_calls, c->h_cnt.error, c->B.ro_mode, c->h_cnt.n_runs, c->h_cnt.ro_state,
                     c->h_cnt.n_gt_over, c->h_cnt.n_gt_huge, c->h_cnt.n_tra_huge);
@@ -794,7 +794,9 @@ int csv_batch_download(csv_ctx* c, csv_batch_out* out)
     const int S = (int)c->h_seg.size();
     const size_t o_rec = 256, o_err = o_rec + ((nc * sizeof(CallRec) + 255) & ~(size_t)255), o_end = o_err + (size_t)(S + 1) * 4;
     if (o_end > c->h_pin_cap) { const int rc = pin_reserve(c, o_end); if (rc) return rc; }
+    // the call records first: they are unpacked on the host while the (larger) support list is still on its way
     if (nc) HIP_TRY(c, hipMemcpyAsync(c->h_pin + o_rec, B.o_rec, nc * sizeof(CallRec), hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipEventRecord(c->ev_sel, st));
     if (ns) HIP_TRY(c, hipMemcpyAsync(out->support_sig, B.o_supsig, ns * 8, hipMemcpyDeviceToHost, st));    // (already in its final layout)
     if (S) HIP_TRY(c, hipMemcpyAsync(c->h_pin + o_err, B.seg_err, (size_t)S * 4, hipMemcpyDeviceToHost, st));
     if (out->cluster_id) memset(out->cluster_id, 0xff, (size_t)c->n_sig_host * 4);
@@ -809,7 +811,7 @@ int csv_batch_download(csv_ctx* c, csv_batch_out* out)
             s = e + 1;
         }
     }
-    HIP_TRY(c, hipStreamSynchronize(st));
+    HIP_TRY(c, hipEventSynchronize(c->ev_sel));
     const CallRec* r = (const CallRec*)(c->h_pin + o_rec);
     for (size_t i = 0; i < nc; i++) {
         const CallRec& x = r[i];
@@ -819,6 +821,7 @@ int csv_batch_download(csv_ctx* c, csv_batch_out* out)
         out->support_off[i] = x.supoff;
     }
     if (out->support_off) out->support_off[nc] = (int64_t)ns;
+    HIP_TRY(c, hipStreamSynchronize(st));
     if (out->seg_status && S) memcpy(out->seg_status, c->h_pin + o_err, (size_t)S * 4);
     return CSV_OK;
 }

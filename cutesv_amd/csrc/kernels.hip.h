@@ -279,12 +279,18 @@ constexpr int CH_TILE = 256 * CH_ITEMS;             // signatures per workgroup
 // segment (almost always) the segment scalars sit in SGPRs and the 8 row loads are issued back to
 // back; the neighbour value comes from the lane to the left.  zprev[r] marks cluster starts whose
 // preceding signature is a (0,0) element.
-__device__ __forceinline__ int chain_rows(const DevBatch& B, i64 base, u64 (&masks)[CH_ITEMS], int (&zprev)[CH_ITEMS], int (&ksg)[CH_ITEMS])
+__device__ __forceinline__ int chain_rows(const DevBatch& B, i64 base, u64 (&masks)[CH_ITEMS], u64 (&zmasks)[CH_ITEMS], int (&ksg)[CH_ITEMS])
 {
     const int lane = lane_id();
 #pragma unroll
-    for (int r = 0; r < CH_ITEMS; r++) { masks[r] = 0; zprev[r] = 0; ksg[r] = 0; }
+    for (int r = 0; r < CH_ITEMS; r++) { masks[r] = 0; zmasks[r] = 0; ksg[r] = 0; }
     if (base >= B.W) return -1;
+    // the rows first: their addresses depend on nothing, the segment probes below ride on the same round trip
+    const int w0 = (int)base, nW = (int)B.W;            // (a batch holds < 2^31 signatures)
+    i64 a[CH_ITEMS];
+#pragma unroll
+    for (int r = 0; r < CH_ITEMS; r++) { const int w = w0 + r * WAVE + lane; a[r] = (w < nW) ? B.a[w] : 0; }
+    i64 left = (lane == 0 && base > 0) ? B.a[base - 1] : 0;         // the signature left of the span (lane 0 only)
     const i64 lastw = (base + WAVE * CH_ITEMS - 1 < B.W) ? base + WAVE * CH_ITEMS - 1 : B.W - 1;
     const int k0 = __builtin_amdgcn_readfirstlane(seg_of_wave(B, base)), k1 = __builtin_amdgcn_readfirstlane(seg_of_wave(B, lastw));
     if (k0 != k1) {                                   // span crosses a segment boundary: per-row path
@@ -295,7 +301,7 @@ __device__ __forceinline__ int chain_rows(const DevBatch& B, i64 base, u64 (&mas
             i64 a0;
             const int f = chain_flag(B, w, seg_hint, a0, k1);
             ksg[r] = seg_hint;
-            zprev[r] = (f && w > 0 && a0 == 0 && B.b[w - 1] == 0) ? 1 : 0;
+            zmasks[r] = __ballot(f && w > 0 && w < B.W && a0 == 0 && B.b[w > 0 ? w - 1 : 0] == 0);
             masks[r] = __ballot(f);
         }
         return -1;
@@ -303,28 +309,26 @@ __device__ __forceinline__ int chain_rows(const DevBatch& B, i64 base, u64 (&mas
 #pragma unroll
     for (int r = 0; r < CH_ITEMS; r++) ksg[r] = k0;
     const csv_segment& sg = B.seg[k0];
-    const i64 bias = sg.max_cluster_bias, seg_first = B.woff[k0];
-    const int type = sg.svtype;
-    i64 a[CH_ITEMS];
-#pragma unroll
-    for (int r = 0; r < CH_ITEMS; r++) { const i64 w = base + r * WAVE + lane; a[r] = (w < B.W) ? B.a[w] : 0; }
-    i64 carry = (lane == 0 && base > 0) ? B.a[base - 1] : 0;        // the signature left of the span (lane 0 only)
+    // segment scalars are wave-uniform: say so, and the type tests below become scalar branches
+    const i64 bias = readlane_i64x(sg.max_cluster_bias, 0);
+    const int sf = __builtin_amdgcn_readfirstlane((int)B.woff[k0]), type = __builtin_amdgcn_readfirstlane(sg.svtype);
 #pragma unroll
     for (int r = 0; r < CH_ITEMS; r++) {
-        const i64 w = base + r * WAVE + lane;
+        const int w = w0 + r * WAVE + lane;
         i64 a0 = wave_shr1_i64(a[r]);
-        const i64 nxt = shfl_i64(a[r], 63);
-        if (lane == 0) a0 = carry;
-        carry = nxt;
-        const bool in = w < B.W;
-        bool f = in && (w == seg_first || a[r] - a0 > bias);
-        const bool z = in && w > 0 && a0 == 0 && B.b[w - 1] == 0;   // b is read only next to a position-0 signature
-        if (in && !f && w != seg_first) {
-            if (z) f = true;
-            else if (type == CSV_INV) f = (B.b[w] - B.b[w - 1] > bias) || (B.aux[w] != B.aux[w - 1]);
-            else if (type == CSV_TRA) f = B.aux[w] != B.aux[w - 1];
-        }
-        zprev[r] = (f && z) ? 1 : 0;
+        if (lane == 0) a0 = left;
+        left = readlane_i64x(a[r], 63);                 // (v_readlane: the next row's lane 0 reads it back as a scalar)
+        const bool in = w < nW;
+        bool f = in && (w == sf || a[r] - a0 > bias);
+        // a (0,0) predecessor looks like the reference's sentinel: only a signature at position 0 can be one, so the
+        // length column is touched behind a wave-uniform test that almost never fires
+        bool z = false;
+        const bool zc = in && w > 0 && a0 == 0;
+        if (__ballot(zc)) z = zc && B.b[w - 1] == 0;
+        if (type == CSV_INV) { if (in && !f && !z && w != sf) f = (B.b[w] - B.b[w - 1] > bias) || (B.aux[w] != B.aux[w - 1]); }
+        else if (type == CSV_TRA) { if (in && !f && !z && w != sf) f = B.aux[w] != B.aux[w - 1]; }
+        if (z && w != sf) f = true;
+        zmasks[r] = __ballot(f && z);
         masks[r] = __ballot(f);
     }
     return k0;
@@ -388,17 +392,18 @@ constexpr int CL_REG = WAVE * CH_ITEMS + 2;          // entries per wavefront re
 constexpr int WI_STRIDE = WAVE * CH_ITEMS + 8;       // item slots per wavefront (at most 513 clusters end in its span)
 __device__ __forceinline__ int wave_starts(const DevBatch& B, i64 base, u64 (&masks)[CH_ITEMS], u64 (&zmasks)[CH_ITEMS], int* SR, int* SKR, int& ku)
 {
-    int zprev[CH_ITEMS], ksg[CH_ITEMS];
-    ku = chain_rows(B, base, masks, zprev, ksg);
+    int ksg[CH_ITEMS];
+    ku = chain_rows(B, base, masks, zmasks, ksg);
     if (base >= B.W) ku = -2;                          // wavefront beyond the end
     int off = 0;
 #pragma unroll
     for (int r = 0; r < CH_ITEMS; r++) {
         const u64 m = masks[r];
-        zmasks[r] = __ballot(zprev[r]);
         if ((m >> lane_id()) & 1) {
             const int idx = off + __popcll(m & lanemask_lt());
-            SR[idx] = (int)(base + r * WAVE + lane_id()) | (zprev[r] << 31);
+            int v = (int)base + r * WAVE + lane_id();
+            if (zmasks[r]) v |= (int)((zmasks[r] >> lane_id()) & 1) << 31;       // (wave-uniform test: the mask is almost always 0)
+            SR[idx] = v;
             SKR[idx] = ksg[r];
         }
         off += __popcll(m);
@@ -2075,17 +2080,22 @@ __global__ __launch_bounds__(RP_THREADS) void k_reads_plan(DevBatch B)
     }
     __syncthreads();
     lds_bitonic(K, P);                                      // by position
-    // distinct positions, compacted in order (one thread: a few hundred entries)
-    if (threadIdx.x == 0) {
-        int m = 0;
-        for (int i = 0; i < n_raw; i++) {
-            const u64 k = K[i];
-            if (k == PAD_KEY) break;
-            if (m == 0 || (u64)(unsigned)pos[m - 1] != k) pos[m++] = (int)k;
-        }
-        pos[m] = (int)B.n_reads;
-        s_n = m;
+    // distinct positions, compacted in order (flag + block scan; the entries are already sorted)
+    for (int b0 = 0; b0 < P; b0 += RP_THREADS) {
+        const int i = b0 + threadIdx.x;
+        const u64 k = i < P ? K[i] : PAD_KEY;
+        const int f = (i < n_raw && k != PAD_KEY && (i == 0 || K[i - 1] != k)) ? 1 : 0;
+        const int inc = wave_incl_scan_i32(f);
+        if (lane_id() == 63) s_w[threadIdx.x >> 6] = inc;
+        __syncthreads();
+        int off = s_n;
+        for (int q = 0; q < (int)(threadIdx.x >> 6); q++) off += s_w[q];
+        if (f) pos[off + inc - 1] = (int)k;
+        __syncthreads();
+        if (threadIdx.x == RP_THREADS - 1) s_n = off + inc;
+        __syncthreads();
     }
+    if (threadIdx.x == 0) pos[s_n] = (int)B.n_reads;
     __syncthreads();
     const int n = s_n;
     if (threadIdx.x == 0) B.cnt->n_runs = n;                 // (k_reads_gather walks the table)
@@ -2143,42 +2153,64 @@ __global__ __launch_bounds__(RP_THREADS) void k_reads_plan(DevBatch B)
 }
 
 // one wavefront per 512 destination rows: find the run of the first row (64-ary search over the run table), then copy
-// run by run (a span of 512 rows usually lies inside one run)
+// run by run (a span of 512 rows usually lies inside one run).  The workgroup's 2048 rows are one tile of the prefix-max
+// scan: the copy also leaves the tile's maximum of (chromosome << 40 | end) and checks the ends, so k_pmax_count has
+// nothing left to do when the table was moved (it still runs for tables that were already in order).
 __global__ __launch_bounds__(256) void k_reads_gather(DevBatch B)
 {
     if (B.ro_mode == 1 && B.cnt->ro_state != RO_REORDER) return;
-    const i64 d0 = ((i64)blockIdx.x * 4 + (threadIdx.x >> 6)) * 512;
-    if (d0 >= B.n_reads) return;
-    const i64 d1 = d0 + 512 < B.n_reads ? d0 + 512 : B.n_reads;
-    if (B.ro_mode == 2) {                                   // general sort: a row permutation
-        for (i64 d = d0 + lane_id(); d < d1; d += 64) {
-            const int p = B.ro_perm[d];
-            B.s_start[d] = B.r_start[p]; B.s_end[d] = B.r_end[p]; B.s_primary[d] = B.r_primary[p]; B.s_id[d] = B.r_id[p];
+    __shared__ i64 s_mx[4];
+    const int wv = threadIdx.x >> 6;
+    const i64 d0 = ((i64)blockIdx.x * 4 + wv) * 512;
+    i64 mx = INT64_MIN;
+    if (d0 < B.n_reads) {
+        const i64 d1 = d0 + 512 < B.n_reads ? d0 + 512 : B.n_reads;
+        int hint = 0;
+        if (B.ro_mode == 2) {                               // general sort: a row permutation
+            for (i64 d = d0 + lane_id(); d < d1; d += 64) {
+                const int p = B.ro_perm[d];
+                const i64 e = B.r_end[p];
+                const int id = B.r_id[p];
+                B.s_start[d] = B.r_start[p]; B.s_end[d] = e; B.s_primary[d] = B.r_primary[p]; B.s_id[d] = id;
+                hint = chrom_of_read(B, d, hint);
+                if (e < 0 || e > ((1ll << 40) - 1) || id < 0) atomicOr(&B.cnt->error, ERR_KEY_RANGE);
+                const i64 v = ((i64)hint << 40) | e;
+                if (v > mx) mx = v;
+            }
+        } else {
+            const int n = B.cnt->n_runs;
+            int lo = 0, hi = n;                             // last run with destination begin <= d0
+            while (hi - lo > 1) {
+                const int step = (hi - lo + 63) / 64;
+                const int idx = lo + lane_id() * step;
+                const int t = __popcll(__ballot(idx < hi && (i64)B.ro_table[idx < hi ? idx : lo].z <= d0));
+                const int nlo = lo + (t - 1) * step;
+                int nhi = lo + t * step;
+                if (nhi > hi) nhi = hi;
+                lo = nlo; hi = nhi;
+            }
+            i64 d = d0;
+            for (int q = lo; q < n && d < d1; q++) {
+                const int4 run = B.ro_table[q];
+                const i64 e1 = (i64)run.z + run.y < d1 ? (i64)run.z + run.y : d1;
+                const i64 shift = (i64)run.x - run.z;
+                for (i64 x = d + lane_id(); x < e1; x += 64) {
+                    const i64 p = x + shift;
+                    const i64 e = B.r_end[p];
+                    const int id = B.r_id[p];
+                    B.s_start[x] = B.r_start[p]; B.s_end[x] = e; B.s_primary[x] = B.r_primary[p]; B.s_id[x] = id;
+                    if (e < 0 || e > ((1ll << 40) - 1) || id < 0) atomicOr(&B.cnt->error, ERR_KEY_RANGE);
+                    const i64 v = ((i64)run.w << 40) | e;   // (the run's chromosome)
+                    if (v > mx) mx = v;
+                }
+                d = e1;
+            }
         }
-        return;
     }
-    const int n = B.cnt->n_runs;
-    int lo = 0, hi = n;                                     // last run with destination begin <= d0
-    while (hi - lo > 1) {
-        const int step = (hi - lo + 63) / 64;
-        const int idx = lo + lane_id() * step;
-        const int t = __popcll(__ballot(idx < hi && (i64)B.ro_table[idx < hi ? idx : lo].z <= d0));
-        const int nlo = lo + (t - 1) * step;
-        int nhi = lo + t * step;
-        if (nhi > hi) nhi = hi;
-        lo = nlo; hi = nhi;
-    }
-    i64 d = d0;
-    for (int q = lo; q < n && d < d1; q++) {
-        const int4 run = B.ro_table[q];
-        const i64 e = (i64)run.z + run.y < d1 ? (i64)run.z + run.y : d1;
-        const i64 shift = (i64)run.x - run.z;
-        for (i64 x = d + lane_id(); x < e; x += 64) {
-            const i64 p = x + shift;
-            B.s_start[x] = B.r_start[p]; B.s_end[x] = B.r_end[p]; B.s_primary[x] = B.r_primary[p]; B.s_id[x] = B.r_id[p];
-        }
-        d = e;
-    }
+    for (int m = 32; m > 0; m >>= 1) { const i64 o = shfl_xor_i64(mx, m); if (o > mx) mx = o; }
+    if (lane_id() == 0) s_mx[wv] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) { i64 t = s_mx[0]; for (int k = 1; k < 4; k++) if (s_mx[k] > t) t = s_mx[k]; B.pm_partial[blockIdx.x] = t; }
 }
 
 // chromosome of every row (key column of the general sort)
@@ -2215,6 +2247,9 @@ __device__ __forceinline__ bool reads_pending(const DevBatch& B) { return B.ro_m
 __global__ __launch_bounds__(256) void k_pmax_count(DevBatch B)
 {
     if (reads_pending(B)) return;
+    // a table that k_reads_gather moved already has its tile maxima (and checked ends); an ordered table - promised, or
+    // found to be in order - is scanned here
+    if (B.ro_mode == 2 || (B.ro_mode == 1 && B.cnt->ro_state == RO_REORDER)) return;
     const ReadsView V = reads_view(B);
     const i64 base = (i64)blockIdx.x * PM_TILE + (threadIdx.x >> 6) * 512;
     i64 mx = INT64_MIN;

@@ -89,7 +89,7 @@ class Context:
     def download(self, per_sig=False, cap_calls=None, cap_support=None):
         n = self._batch.n_sig
         cap_calls = cap_calls or max(64, n // 16 + 16)
-        cap_support = cap_support or max(64, n // 2 + 16)
+        cap_support = cap_support or max(64, n + 16)
         for _ in range(2):
             res = _abi.HostResult(n, cap_calls, cap_support, per_sig=per_sig, n_seg=len(self._batch.segments))
             rc = lib().csv_batch_download(self._h, C.byref(res.c))
@@ -107,7 +107,7 @@ class Context:
         page faults of ~20 MB of fresh arrays per call); the previous result is overwritten."""
         n = batch.n_sig
         cap_calls = cap_calls or max(64, n // 16 + 16)
-        cap_support = cap_support or max(64, n // 2 + 16)
+        cap_support = cap_support or max(64, n + 16)         # (a signature supports at most one call)
         self._batch = batch
         for _ in range(2):
             res = self._res_cache if reuse else None
@@ -119,8 +119,8 @@ class Context:
                 if reuse:
                     self._res_cache = res
             rc = lib().csv_cluster_batch(self._h, C.byref(batch.c), C.byref(res.c))
-            if rc == _abi.E_CAPACITY:            # required sizes were filled in: re-allocate and retry
-                cap_calls, cap_support = res.n_calls + 1, res.n_support + 1
+            if rc == _abi.E_CAPACITY:            # required sizes were filled in: re-allocate (never smaller) and retry
+                cap_calls, cap_support = max(cap_calls, res.n_calls + 1), max(cap_support, res.n_support + 1)
                 continue
             self._check(rc)
             return res
