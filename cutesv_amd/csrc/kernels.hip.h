@@ -2419,22 +2419,25 @@ __device__ __forceinline__ void gt_load_head(const DevBatch& B, int second, int 
     gt_load_call(B, second ? B.gt_over[q] : q, H);
 }
 
-// the one or two windows of a call in doubled coordinates (INDEL:450-451; DUP:146-151; INV:218-221); returns their number
-__device__ __forceinline__ int gt_windows(const GtHead& H, i64 (&L2)[2], i64 (&R2)[2])
+// the one or two windows of a call in doubled coordinates (INDEL:450-451; DUP:146-151; INV:218-221)
+struct GtWin { int n; i64 La, Ra, Lb, Rb; };              // (scalars, not arrays: a dynamically indexed private array is scratch memory)
+__device__ __forceinline__ GtWin gt_windows(const GtHead& H)
 {
+    GtWin W;
     const int svtype = H.h.y & 0xff;
     const i64 gt_bias = ((i64)H.h.w << 32) | (unsigned)H.h.z;
     if (svtype == CSV_DEL || svtype == CSV_INS) {
         const i64 p = H.search, g = gt_bias;
         i64 L = p - g; if (L < 0) L = 0;
-        L2[0] = 2 * L; R2[0] = 2 * (p + g);
-        return 1;
+        W.n = 1; W.La = 2 * L; W.Ra = 2 * (p + g); W.Lb = 0; W.Rb = 0;
+        return W;
     }
     i64 nb = gt_bias;
     if (svtype == CSV_DUP && H.b2 - H.b1 < nb) nb = H.b2 - H.b1;            // DUP:147
-    L2[0] = 2 * H.b1 - nb; if (L2[0] < 0) L2[0] = 0; R2[0] = 2 * H.b1 + nb;
-    L2[1] = 2 * H.b2 - nb; if (L2[1] < 0) L2[1] = 0; R2[1] = 2 * H.b2 + nb; // union of both: DUP:155-157
-    return 2;
+    W.n = 2;
+    W.La = 2 * H.b1 - nb; if (W.La < 0) W.La = 0; W.Ra = 2 * H.b1 + nb;
+    W.Lb = 2 * H.b2 - nb; if (W.Lb < 0) W.Lb = 0; W.Rb = 2 * H.b2 + nb;     // union of both: DUP:155-157
+    return W;
 }
 
 // first index in [lo, hi) whose prefix max reaches R (r_pmax is non-decreasing inside a chromosome): the scan of a
@@ -2465,13 +2468,16 @@ __device__ bool genotype_global(const DevBatch& B, const ReadsView& V, const GtH
     const int chrom = H.h.x;
     const i64 r0 = B.reads_off[chrom], r1 = B.reads_off[chrom + 1];
     const i64 ns = H.s1 - H.s0;
-    i64 L2[2], R2[2], top[2], bot[2];
-    const int nw = gt_windows(H, L2, R2);
+    const GtWin W = gt_windows(H);
     i64 need = ns;
-    for (int w = 0; w < nw; w++) {
-        top[w] = upper_bound_start(V.start, r0, r1, L2[w]) - 1;
-        bot[w] = top[w] >= r0 ? lower_bound_pmax(B.r_pmax, r0, top[w] + 1, R2[w]) : r0;
-        if (top[w] >= bot[w]) need += top[w] - bot[w] + 1;
+    const i64 topa = upper_bound_start(V.start, r0, r1, W.La) - 1;
+    const i64 bota = topa >= r0 ? lower_bound_pmax(B.r_pmax, r0, topa + 1, W.Ra) : r0;
+    if (topa >= bota) need += topa - bota + 1;
+    i64 topb = r0 - 1, botb = r0;
+    if (W.n == 2) {
+        topb = upper_bound_start(V.start, r0, r1, W.Lb) - 1;
+        botb = topb >= r0 ? lower_bound_pmax(B.r_pmax, r0, topb + 1, W.Rb) : r0;
+        if (topb >= botb) need += topb - botb + 1;
     }
     int bits = 10;
     while ((1ll << bits) < 2 * need) bits++;
@@ -2482,9 +2488,10 @@ __device__ bool genotype_global(const DevBatch& B, const ReadsView& V, const GtH
     for (i64 i = tid; i < ns; i += nthreads) hash_insert_n(tab, bits, B.o_suprid[H.s0 + i]);
     if (whole_block) __syncthreads(); else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     int dr = 0;
-    for (int w = 0; w < nw; w++)
-        for (i64 i = bot[w] + tid; i <= top[w]; i += nthreads)
-            if (V.primary[i] == 1 && 2 * V.end[i] >= R2[w]) dr += hash_insert_n(tab, bits, V.id[i]);
+    for (i64 i = bota + tid; i <= topa; i += nthreads)
+        if (V.primary[i] == 1 && 2 * V.end[i] >= W.Ra) dr += hash_insert_n(tab, bits, V.id[i]);
+    for (i64 i = botb + tid; i <= topb; i += nthreads)
+        if (V.primary[i] == 1 && 2 * V.end[i] >= W.Rb) dr += hash_insert_n(tab, bits, V.id[i]);
     dr = wave_sum_i32(dr);
     if (whole_block) {
         if (lane_id() == 0) s_red[tid >> 6] = dr;
@@ -2505,6 +2512,7 @@ template <int HASH, int WPB> __global__ __launch_bounds__(64 * WPB) void k_genot
     if (reads_pending(B)) return;
     const ReadsView V = reads_view(B);
     const int n = second ? B.cnt->n_gt_over : B.cnt->n_calls;
+    if (second && n == 0) return;                                   // (nothing overflowed the first pass: no list, no hand-over)
     const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * (64 * WPB) + threadIdx.x) >> 6), nwaves = (gridDim.x * (64 * WPB)) >> 6;
     GtHead cur, nxt;
     if (wave < n) gt_load_head(B, second, wave, cur);
@@ -2527,10 +2535,9 @@ template <int HASH, int WPB> __global__ __launch_bounds__(64 * WPB) void k_genot
         const i64 r0 = B.reads_off[chrom], r1 = B.reads_off[chrom + 1];
         int dr = 0;
         if (!overflow) {
-            i64 L2[2], R2[2];
-            const int nw = gt_windows(cur, L2, R2);
-            dr = cover_window<HASH>(B, V, tab, r0, r1, L2[0], R2[0], filled, overflow);
-            if (nw == 2 && !overflow) dr += cover_window<HASH>(B, V, tab, r0, r1, L2[1], R2[1], filled, overflow);
+            const GtWin W = gt_windows(cur);
+            dr = cover_window<HASH>(B, V, tab, r0, r1, W.La, W.Ra, filled, overflow);
+            if (W.n == 2 && !overflow) dr += cover_window<HASH>(B, V, tab, r0, r1, W.Lb, W.Rb, filled, overflow);
         }
         if (overflow) {                                                       // wave-uniform
             if (!second) { if (lane_id() == 0) B.gt_over[atomicAdd(&B.cnt->n_gt_over, 1)] = c; continue; }

@@ -16,9 +16,9 @@ import sys
 
 
 def short(name):
-    m = re.search(r"k_refine<(\d+)", name)
+    m = re.search(r"k_refine<(\d+), (\d+)", name)
     if m:
-        return "k_refine_block" if m.group(1) == "256" else "k_refine_wave"
+        return "k_refine_block" if m.group(1) == "256" else ("k_refine_mid" if m.group(2) == "256" else "k_refine_wave")
     m = re.search(r"csv::(k_[a-z_0-9]+)", name)
     return m.group(1) if m else name
 
@@ -28,7 +28,8 @@ def per_kernel(db, counter):
     out = {}
     for name, n, avg in cur.execute("select kernel_name, count(*), avg(value) from counters_collection where counter_name=? "
                                     "group by kernel_name", (counter,)):
-        out[short(name)] = (n, avg)
+        k = short(name)                                    # (the two k_genotype instantiations run once per step each: summed)
+        out[k] = (max(n, out[k][0]), avg + out[k][1]) if k in out else (n, avg)
     return out
 
 
