@@ -65,7 +65,7 @@ struct csv_ctx {
     Buf seg, woff, seg_drop, a, b, rid, aux;
     Buf cluster_id, partial, partial64, item_rec, list_small, list_big, list_tiny, partial_t, seg_gate, ch_masks, wave_items, wave_cnt, seg_err;
     Buf item_nslots, item_cnt, item_base, sup_tmp;
-    Buf t_bp1, t_bp2, t_search, t_pick, t_support, t_cipos, t_cilen, t_supoff, t_valid;
+    Buf t_rec;
     Buf sc_k, sc_x, sc_v1, sc_v2, sc_v3, sc_v4, sc_v5;
     Buf o_rec, o_supsig, o_suprid, allele_id;
     Buf reads_off, r_start, r_end, r_primary, r_id, s_start, s_end, s_primary, s_id, r_pmax, pm_partial, gt_over, gt_huge, gt_pool, contig_len;
@@ -378,8 +378,7 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
     PL(item_rec, cap_items * 16); PL(list_small, cap_items * 16); PL(list_big, cap_items * 4); PL(list_tiny, cap_items * 16);
     PL(item_nslots, cap_items * 4); PL(item_cnt, cap_items * 8); PL(item_base, (cap_items + 8) * 8);
     // temp call records are indexed by w (a cluster's slots live in its own signature range)
-    PL(t_bp1, (W + 1) * 8); PL(t_bp2, (W + 1) * 8); PL(t_search, (W + 1) * 8); PL(t_pick, (W + 1) * 8);
-    PL(t_support, (W + 1) * 4); PL(t_cipos, (W + 1) * 4); PL(t_cilen, (W + 1) * 4); PL(t_supoff, (W + 1) * 4); PL(t_valid, (W + 1) * 4);
+    PL(t_rec, (W + 1) * sizeof(TmpRec));
     PL(sc_k, SC * 8); PL(sc_x, SC * 8); PL(sc_v1, SC * 4); PL(sc_v2, SC * 4); PL(sc_v3, SC * 4); PL(sc_v4, SC * 4); PL(sc_v5, SC * 4);
     PL(o_rec, (cap_tmp + 1) * sizeof(CallRec)); PL(o_supsig, (W + 1) * 8); PL(o_suprid, (W + 1) * 4);
     if (have_tab) { PL(reads_off, (in->n_chrom + 1) * 8); PL(contig_len, (in->n_chrom + 1) * 8); }
@@ -485,8 +484,7 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
     B.tiny_max = getenv("CSV_NO_TINY") ? 0 : 16;               // (timing aid: 0 sends every DEL/INS cluster of m <= 32 through the paired path)
     B.item_nslots = dp<int>(c->item_nslots); B.item_cnt = dp<i64>(c->item_cnt); B.item_base = dp<i64>(c->item_base);
     B.sup_tmp = dp<int>(c->sup_tmp);
-    B.t_bp1 = dp<i64>(c->t_bp1); B.t_bp2 = dp<i64>(c->t_bp2); B.t_search = dp<i64>(c->t_search); B.t_pick = dp<i64>(c->t_pick);
-    B.t_support = dp<int>(c->t_support); B.t_cipos = dp<int>(c->t_cipos); B.t_cilen = dp<int>(c->t_cilen); B.t_supoff = dp<int>(c->t_supoff); B.t_valid = dp<int>(c->t_valid);
+    B.t_rec = dp<TmpRec>(c->t_rec);
     B.cap_tmp = (int)cap_tmp; B.cap_items = (int)cap_items;
     B.sc_k = dp<u64>(c->sc_k); B.sc_x = dp<i64>(c->sc_x); B.sc_v1 = dp<int>(c->sc_v1); B.sc_v2 = dp<int>(c->sc_v2); B.sc_v3 = dp<int>(c->sc_v3); B.sc_v4 = dp<int>(c->sc_v4); B.sc_v5 = dp<int>(c->sc_v5);
     B.o_rec = dp<CallRec>(c->o_rec); B.o_supsig = dp<i64>(c->o_supsig); B.o_suprid = dp<int>(c->o_suprid);

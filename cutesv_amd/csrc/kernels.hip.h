@@ -49,6 +49,25 @@ struct __attribute__((aligned(16))) CallRec {
 };
 static_assert(sizeof(CallRec) == 96, "CallRec layout");
 
+// A temp call record (one per allele / sub-cluster, at t_rec[first w of the cluster + slot]): written by the refine
+// kernels with three 16-byte stores and a 4-byte one, read by k_emit as one 64-byte line.  (Nine separate arrays made k_emit
+// fetch nine lines per slot: 9.6x its algorithmic bytes.)
+struct __attribute__((aligned(16))) TmpRec {
+    i64 bp1, bp2;                     //  0
+    i64 search, pick;                 // 16
+    int support, cipos, cilen, supoff;   // 32
+    int valid, pad0, pad1, pad2;      // 48
+};
+static_assert(sizeof(TmpRec) == 64, "TmpRec layout");
+__device__ __forceinline__ void tmp_write(TmpRec* t, i64 bp1, i64 bp2, i64 search, i64 pick, int support, int cipos, int cilen, int supoff, int valid)
+{
+    int4* r = (int4*)t;
+    r[0] = make_int4((int)(bp1 & 0xffffffffll), (int)(bp1 >> 32), (int)(bp2 & 0xffffffffll), (int)(bp2 >> 32));
+    r[1] = make_int4((int)(search & 0xffffffffll), (int)(search >> 32), (int)(pick & 0xffffffffll), (int)(pick >> 32));
+    r[2] = make_int4(support, cipos, cilen, supoff);
+    ((int*)t)[12] = valid;
+}
+
 struct DevCounters {          // one small struct in device memory, zeroed at the start of every run
     int n_clusters;
     int n_items;              // valid clusters (work items)
@@ -103,8 +122,7 @@ struct DevBatch {
     i64*           item_cnt;         // packed (valid calls << 32 | supports of valid calls)
     i64*           item_base;        // exclusive prefix of item_cnt per tile of EM_TILE items
     int*           sup_tmp;          // W: support lists, stored inside the cluster's own [s, e) range
-    i64*           t_bp1; i64* t_bp2; i64* t_search; i64* t_pick;
-    int*           t_support; int* t_cipos; int* t_cilen; int* t_supoff; int* t_valid;
+    TmpRec*        t_rec;            // W temp call records (a cluster's slots live in its own signature range)
     int            cap_tmp;
     int            cap_items;
     // big-cluster scratch (2 * W + 16 elements each)
@@ -1084,9 +1102,7 @@ template <int BLOCK, bool LDS, bool SMALLN> __device__ void refine_indel(const D
         for (int i = lane_id(); i < n; i += 64) B.sup_tmp[s + soff + i] = s + A.V1[r0 + i];
         if (lane_id() == 0) {
             const int t = tbase + rank;
-            B.t_bp1[t] = (i64)bp; B.t_bp2[t] = (i64)siglen; B.t_support[t] = n;
-            B.t_cipos[t] = cip; B.t_cilen[t] = cil; B.t_search[t] = search; B.t_pick[t] = pick;
-            B.t_supoff[t] = soff; B.t_valid[t] = valid;
+            tmp_write(&B.t_rec[t], (i64)bp, (i64)siglen, search, pick, n, cip, cil, soff, valid);
             if (valid) { ncalls++; nsup += n; }
         }
     }
@@ -1223,10 +1239,7 @@ template <int BLOCK, bool LDS> __device__ void refine_pair(const DevBatch& B, co
             write_first_seen<LDS>(B, A, s, r0, r1, s + soff);
             if (lane_id() == 0) {
                 const int t = tbase + q;
-                B.t_bp1[t] = (i64)((double)s1 / (double)cnt);               // TRA:173
-                B.t_bp2[t] = (i64)((double)s2 / (double)cnt);               // TRA:175
-                B.t_support[t] = u; B.t_cipos[t] = 0; B.t_cilen[t] = 0; B.t_search[t] = 0; B.t_pick[t] = -1;
-                B.t_supoff[t] = soff; B.t_valid[t] = 1;
+                tmp_write(&B.t_rec[t], (i64)((double)s1 / (double)cnt), (i64)((double)s2 / (double)cnt), 0, -1, u, 0, 0, soff, 1);   // TRA:173, 175
             }
             soff += u;
         }
@@ -1281,8 +1294,7 @@ template <int BLOCK, bool LDS> __device__ void refine_pair(const DevBatch& B, co
         write_first_seen<LDS>(B, A, s, r0, r1, s + A.V5[k]);
         if (lane_id() == 0) {
             const int t = tbase + slot;
-            B.t_bp1[t] = bp1; B.t_bp2[t] = bp2; B.t_support[t] = u; B.t_cipos[t] = 0; B.t_cilen[t] = 0;
-            B.t_search[t] = 0; B.t_pick[t] = -1; B.t_supoff[t] = A.V5[k]; B.t_valid[t] = valid;
+            tmp_write(&B.t_rec[t], bp1, bp2, 0, -1, u, 0, 0, A.V5[k], valid);
             if (valid) { ncalls++; nsup += u; }
         }
     }
@@ -1686,9 +1698,20 @@ template <int SW> __device__ __forceinline__ int indel_unit(const DevBatch& B, c
         else if (!__ballot(pass && keep < n)) {
             // every member kept: search_threshold = first member with the smallest |pos - mean| (INDEL:171-177)
             double bd = dp; int bi = r;
-            for (int d = 1; d < SW; d <<= 1) {
-                const double od = shfl_f64(bd, (lane - d) & 63); const int oi = __shfl(bi, (lane - d) & 63);
-                if (r - d >= r0 && (od < bd || (od == bd && oi < bi))) { bd = od; bi = oi; }
+            if (SW == 16) {                                  // a sub-wave is one DPP row: row_shr moves, no LDS round trips
+#define CSV_MINSTEP(CTRL, D)                                                                                              \
+                {                                                                                                         \
+                    const double od = __longlong_as_double(dpp_i64<CTRL, 0xf>(__double_as_longlong(bd), __double_as_longlong(bd))); \
+                    const int oi = dpp_i32<CTRL, 0xf>(bi, bi);                                                            \
+                    if (r - D >= r0 && (od < bd || (od == bd && oi < bi))) { bd = od; bi = oi; }                          \
+                }
+                CSV_MINSTEP(0x111, 1) CSV_MINSTEP(0x112, 2) CSV_MINSTEP(0x114, 4) CSV_MINSTEP(0x118, 8)
+#undef CSV_MINSTEP
+            } else {
+                for (int d = 1; d < SW; d <<= 1) {
+                    const double od = shfl_f64(bd, (lane - d) & 63); const int oi = __shfl(bi, (lane - d) & 63);
+                    if (r - d >= r0 && (od < bd || (od == bd && oi < bi))) { bd = od; bi = oi; }
+                }
             }
             search = shfl_i64(pos, hb | (__shfl(bi, e1) & (SW - 1)));
         } else {
@@ -1740,9 +1763,7 @@ template <int SW> __device__ __forceinline__ int indel_unit(const DevBatch& B, c
         const bool head = pass && i == 0;
         if (head && !CSV_ABL(4)) {
             const int t = s + erank;
-            B.t_bp1[t] = (i64)bp; B.t_bp2[t] = (i64)siglen; B.t_support[t] = n;
-            B.t_cipos[t] = cip; B.t_cilen[t] = cil; B.t_search[t] = search; B.t_pick[t] = valid ? pick : -1;
-            B.t_supoff[t] = soff; B.t_valid[t] = valid ? 1 : 0;
+            tmp_write(&B.t_rec[t], (i64)bp, (i64)siglen, search, valid ? pick : -1, n, cip, cil, soff, valid ? 1 : 0);
         }
         const int ncalls = __popcll(sub_ballot<SW>(head && valid, g));
         const int nsup = __shfl(sub_scan_i32<SW>((head && valid) ? n : 0), last);
@@ -1871,14 +1892,17 @@ __device__ __forceinline__ void emit_item_serial(const DevBatch& B, int j, i64 b
     for (int c0 = 0; c0 < nslots; c0 += 64) {
         const int t = s + c0 + lane;
         const int in = (c0 + lane) < nslots;
-        const int valid = in ? B.t_valid[t] : 0;
-        const int nsup = valid ? B.t_support[t] : 0;
-        const int tso = valid ? B.t_supoff[t] : 0;
+        TmpRec tr;
+        tr.valid = 0;
+        if (in) tr = B.t_rec[t];
+        const int valid = in ? tr.valid : 0;
+        const int nsup = valid ? tr.support : 0;
+        const int tso = valid ? tr.supoff : 0;
         const u64 mk = __ballot(valid);
         const int c = cb + __popcll(mk & lanemask_lt());
         const int sinc = wave_incl_scan_i32(nsup);
         const i64 so = sb + sinc - nsup;
-        if (valid) write_call(B, c, B.t_bp1[t], B.t_bp2[t], B.t_search[t], B.t_pick[t], so, nsup, B.t_cipos[t], B.t_cilen[t], k, cid, aux0, ghdr);
+        if (valid) write_call(B, c, tr.bp1, tr.bp2, tr.search, tr.pick, so, nsup, tr.cipos, tr.cilen, k, cid, aux0, ghdr);
         u64 rest = mk;
         while (rest) {
             const int l = __ffsll((long long)rest) - 1;
@@ -1933,8 +1957,9 @@ __global__ __launch_bounds__(256) void k_emit(DevBatch B)
         int valid = 0, nsup = 0, tso = 0, ci = 0, cl = 0;
         i64 bp1 = 0, bp2 = 0, srch = 0, pick = 0;
         if (mine) {
-            valid = B.t_valid[t]; nsup = B.t_support[t]; tso = B.t_supoff[t];
-            bp1 = B.t_bp1[t]; bp2 = B.t_bp2[t]; ci = B.t_cipos[t]; cl = B.t_cilen[t]; srch = B.t_search[t]; pick = B.t_pick[t];
+            const TmpRec tr = B.t_rec[t];
+            valid = tr.valid; nsup = tr.support; tso = tr.supoff;
+            bp1 = tr.bp1; bp2 = tr.bp2; ci = tr.cipos; cl = tr.cilen; srch = tr.search; pick = tr.pick;
         }
         i64 gs = 0; int aux0 = 0;
         int4 ghdr = make_int4(0, 0, 0, 0);
