@@ -82,6 +82,10 @@ struct csv_ctx {
     // page-locked host staging: small tables on the way in, counters + call records + support lists on the way out
     char*  h_pin = nullptr;
     size_t h_pin_cap = 0;
+    // two page-locked words the device writes and the host peeks at during a run (which big tiers have work)
+    volatile int* h_flag = nullptr;
+    int*          d_flag = nullptr;
+    int           run_seq = 0;
     // host copies
     std::vector<csv_segment> h_seg;
     std::vector<i64>         h_woff;
@@ -245,6 +249,14 @@ int csv_ctx_create(int device_id, csv_ctx** out)
     // `num ** 0.5` of cal_CIPOS is libm pow(), not sqrt(): tabulate it with the host libm (GT:59)
     std::vector<double> tab(SQRT_TAB);
     for (int i = 0; i < SQRT_TAB; i++) tab[i] = pow((double)i, 0.5);
+    {
+        void* hf = nullptr;
+        if (hipHostMalloc(&hf, 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
+            void* df = nullptr;
+            if (hipHostGetDevicePointer(&df, hf, 0) == hipSuccess) { c->h_flag = (volatile int*)hf; c->d_flag = (int*)df; memset(hf, 0, 64); }
+            else (void)hipHostFree(hf);
+        }
+    }
     if (reserve(c, c->sqrt_tab, SQRT_TAB * sizeof(double)) || reserve(c, c->cnt, sizeof(DevCounters)) || pin_reserve(c, 1 << 20) ||
         hipMemcpy(c->sqrt_tab.p, tab.data(), SQRT_TAB * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
         delete c;
@@ -264,6 +276,7 @@ void csv_ctx_destroy(csv_ctx* c)
     if (c->arena.base) (void)hipFree(c->arena.base);
     if (c->arena_rb.base) (void)hipFree(c->arena_rb.base);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
+    if (c->h_flag) (void)hipHostFree((void*)c->h_flag);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->ev_aux) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->ev_copy) if (e) (void)hipEventDestroy(e);
@@ -601,6 +614,10 @@ int run_impl(csv_ctx* c, csv_run_stats* stats)
         return CSV_OK;
     };
     if (c->copies_pending) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_copy[0], 0));       // positions, lengths, INV / TRA words
+    // (not in a one-shot call: the kernels then queue behind a millisecond of column copies, the answer would come too late)
+    const bool peek = c->h_flag && !c->copies_pending && !getenv("CSV_NO_PEEK");
+    B.host_flag = peek ? c->d_flag : nullptr;
+    B.run_seq = ++c->run_seq;
     if (W > 0) {
         const int nb = div_up(W, CH_TILE);
         LAUNCH("chain_count", k_chain_count, nb, 320, 0, B);
@@ -629,12 +646,27 @@ int run_impl(csv_ctx* c, csv_run_stats* stats)
         LAUNCH("refine_indel_wave", k_refine_indel_wave, g_iw, 256, 0, B);
         if (c->any_pair) LAUNCH_ON(sC, "refine_wave", (k_refine<64, 64>), g_small, 64, LDS_SMALL, B, 0, 0, 64);
         else HIP_TRY(c, mark());
+        // The tiers above 64 signatures usually have nothing to do (a 30x genome has no such cluster) and an empty launch
+        // still costs ~4 us of the stream: while the wavefront tier runs, peek at the two page-locked words k_chain_apply
+        // wrote.  The GPU never waits for this (the peek ends long before k_refine_indel_wave does); no answer within
+        // the bound -> launch both, as if there were no peek.
+        bool need_big = true;
+        if (peek) {
+            const auto t0 = std::chrono::steady_clock::now();
+            for (int spin = 0;; spin++) {
+                if (c->h_flag[0] == B.run_seq) { need_big = c->h_flag[1] > 0; break; }
+                if ((spin & 63) == 63 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(400)) break;
+                __builtin_ia32_pause();
+            }
+        }
         int g_mid = B.cap_items < 8192 ? B.cap_items : 8192;
         if (g_mid < 1) g_mid = 1;
-        LAUNCH_ON(sB, "refine_mid", (k_refine<64, 256>), g_mid, 64, LDS_MID, B, 1, 64, 256);
         int g_big = B.cap_items < 512 ? B.cap_items : 512;
         if (g_big < 1) g_big = 1;
-        LAUNCH_ON(sB, "refine_block", (k_refine<256, 2048>), g_big, 256, LDS_BIG, B, 1, 256, 0x7fffffff);
+        if (need_big) {
+            LAUNCH_ON(sB, "refine_mid", (k_refine<64, 256>), g_mid, 64, LDS_MID, B, 1, 64, 256);
+            LAUNCH_ON(sB, "refine_block", (k_refine<256, 2048>), g_big, 256, LDS_BIG, B, 1, 256, 0x7fffffff);
+        } else { HIP_TRY(c, mark()); HIP_TRY(c, mark()); }
         if (fork) {                                       // join
             HIP_TRY(c, hipEventRecord(c->ev_aux[0], sB));
             HIP_TRY(c, hipStreamWaitEvent(st, c->ev_aux[0], 0));

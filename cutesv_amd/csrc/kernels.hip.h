@@ -20,6 +20,14 @@
 #include <stdint.h>
 #include "../../include/cutesv_hip.h"
 
+// Measurement aid (scripts/ablate.sh): -DCSV_ABLATE=<bit mask> drops a section of a kernel so that its share of the
+// kernel time can be read off a same-box A/B run.  The results are wrong then; never defined in a product build.
+#ifdef CSV_ABLATE
+#define CSV_ABL(bit) (((CSV_ABLATE) >> (bit)) & 1)
+#else
+#define CSV_ABL(bit) 0
+#endif
+
 namespace csv {
 
 typedef unsigned long long u64;
@@ -114,6 +122,8 @@ struct DevBatch {
                                      // {first w, size, segment | svtype << 24 | tier << 28, cluster index relative to the wavefront}
     int4*          wave_cnt;         // per chain wavefront {cluster starts, work items, workgroup-tier items, tiny items}
     int            per_sig;          // CSV_IN_PER_SIG: cluster_id / allele_id are produced
+    int*           host_flag;        // page-locked host words {run sequence, work items above 64 signatures}: the host peeks
+    int            run_seq;          // at them while k_refine_indel_wave runs and launches only the tiers that have work
     int*           seg_err;          // n_seg words of CSV_SEG_* bits
     const int4*    seg_gate;         // per segment {read_count, dropped, svtype, -}: one 16-byte load for the size gate
     int*           partial_t;        // tiny work items per chain tile
@@ -417,7 +427,7 @@ __device__ __forceinline__ int wave_starts(const DevBatch& B, i64 base, u64 (&ma
 #pragma unroll
     for (int r = 0; r < CH_ITEMS; r++) {
         const u64 m = masks[r];
-        if ((m >> lane_id()) & 1) {
+        if (!CSV_ABL(8) && ((m >> lane_id()) & 1)) {
             const int idx = off + __popcll(m & lanemask_lt());
             int v = (int)base + r * WAVE + lane_id();
             if (zmasks[r]) v |= (int)((zmasks[r] >> lane_id()) & 1) << 31;       // (wave-uniform test: the mask is almost always 0)
@@ -496,7 +506,7 @@ __global__ __launch_bounds__(320) void k_chain_count(DevBatch B)
     int4 g_own = make_int4(0, 0, 0, 0);
     if (wv == 4) {                                         // the look-back wavefront
         int p = -1, kp = 0;
-        for (i64 hiw = tile0; hiw > 0 && p < 0;) {
+        for (i64 hiw = CSV_ABL(9) ? 0 : tile0; hiw > 0 && p < 0;) {
             const i64 cb = hiw > 64 ? hiw - 64 : 0;
             int kseg;
             u64 f = chain_flag_row64(B, cb, kseg);
@@ -531,12 +541,16 @@ __global__ __launch_bounds__(320) void k_chain_count(DevBatch B)
         // lists from the masks and evaluate every gate a second time: 16 us of a 100 us step).
         const i64 gw = (i64)blockIdx.x * 4 + wv;
         int n_sel = 0, n_big = 0, n_tiny = 0;               // wave-uniform counts: ballots + scalar popcounts, no VALU sums
-        for (int i0 = 0; i0 < nc; i0 += 64) {
+        for (int i0 = 0; i0 < (CSV_ABL(7) ? 0 : nc); i0 += 64) {
             const int i = i0 + lane_id();
             int fl = 0, s0c = 0, mc = 0, kt = 0;
+            // one LDS read per cluster: its end; the start is the neighbour lane's end (DPP), the segment the tile's own
+            // unless the tile spans segments
+            const int e1 = i < nc ? SR[wv][i] : 0;
+            int s0 = dpp_i32<0x138, 0xf>(0, e1);              // wave_shr:1
+            if (lane_id() == 0) s0 = i0 ? SR[wv][i0 - 1] : ob.x;
             if (i < nc) {
-                const int e1 = SR[wv][i];
-                const int s0 = i ? SR[wv][i - 1] : ob.x, k = i ? SKR[wv][i - 1] : ob.y;
+                const int k = ts.uni ? ((i || ob.y == ts.k) ? ts.k : ob.y) : (i ? SKR[wv][i - 1] : ob.y);
                 if (s0 != -1) {
                     const int4 g = gate_scalars(B, ts, k);
                     fl = close_gate(B, g, s0 & 0x7fffffff, e1 & 0x7fffffff, e1 < 0);
@@ -599,6 +613,13 @@ __global__ __launch_bounds__(256) void k_chain_apply(DevBatch B)
     if (last_tile && threadIdx.x == 255) {                  // wavefront 3: its running counts now cover the whole batch
         B.cnt->n_clusters = run + wc.x;
         B.cnt->n_items = bj + wc.y; B.cnt->n_items_big = bb; B.cnt->n_items_tiny = bt;
+        // tell the host whether the tiers above 64 signatures have any work: it peeks at these page-locked words while
+        // the wavefront tier runs and launches k_refine<64,256> / k_refine<256,2048> only then (a missing or late answer
+        // just means that they are launched as before)
+        if (B.host_flag) {
+            __hip_atomic_store(&B.host_flag[1], bb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&B.host_flag[0], B.run_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
@@ -1521,13 +1542,6 @@ __device__ __forceinline__ void unit_rows(const DevBatch& B, const int4 e, int s
 // one unit of work: SW = 32 -> the pair of items (2p, 2p + 1), each handled if m <= 32;
 //                   SW = 64 -> the single item p, handled if 32 < m <= 64.  Returns (SW = 32 only) a 2-bit mask
 //                   of pair members that are DEL/INS clusters of 32 < m <= 64 and still need the wide pass.
-// Measurement aid (scripts/ablate.sh): -DCSV_ABLATE=<bit mask> drops a section of indel_unit so that its share of the
-// kernel time can be read off a same-box A/B run.  The results are wrong then; never defined in a product build.
-#ifdef CSV_ABLATE
-#define CSV_ABL(bit) (((CSV_ABLATE) >> (bit)) & 1)
-#else
-#define CSV_ABL(bit) 0
-#endif
 template <int SW> __device__ __forceinline__ int indel_unit(const DevBatch& B, const UnitIn& U)
 {
     constexpr bool HALF = SW == 32;
