@@ -165,8 +165,13 @@ PyObject* build(PyObject*, PyObject* arg)
     const csv_rows_in* in = (const csv_rows_in*)PyLong_AsVoidPtr(arg);
     if (!in) { if (!PyErr_Occurred()) PyErr_SetString(PyExc_ValueError, "null csv_rows_in"); return nullptr; }
     if (!in->res) { PyErr_SetString(PyExc_ValueError, "csv_rows_in.res is null"); return nullptr; }
+    // Rows are lists of str: they cannot be part of a reference cycle, yet every PyList_New counts towards the collector's
+    // thresholds and 25 k of them trigger dozens of young-generation passes (~15 % of the call).  Collection is paused
+    // for the duration of the build.
+    const int gc_was_on = PyGC_Disable();
     PySink S(in->res->n_calls);
     const int rc = S.ok ? csv_rows::layout(in, S) : CSV_E_NOMEM;
+    if (gc_was_on) PyGC_Enable();
     if (rc != CSV_OK || !S.ok) {
         Py_XDECREF(S.rows);
         if (!PyErr_Occurred()) PyErr_Format(PyExc_RuntimeError, "row builder failed (code %d)", rc ? rc : CSV_E_NOMEM);

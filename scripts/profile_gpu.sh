@@ -10,7 +10,7 @@ OUT=$R/gpurun_out/prof
 mkdir -p $OUT
 cd $R
 export CSV_BENCH_EXIT_ALARM=15
-ARGS="bench.py --workload $WL --steps 10 --warmup 2 --no-cpu-baseline"
+ARGS="bench.py --workload $WL --steps 50 --warmup 5 --no-cpu-baseline"
 timeout -k 5 150 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_${WL}_kt -o kt -- python $ARGS > $OUT/${TAG}_${WL}_kt.log 2>&1
 echo "kt rc=$?"
 timeout -k 5 150 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/${TAG}_${WL}_fetch -o pmc -- python $ARGS > $OUT/${TAG}_${WL}_fetch.log 2>&1

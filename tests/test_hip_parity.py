@@ -590,3 +590,23 @@ def test_run_tra_shim_genotypes_like_the_reference(ctx, tmp_path, monkeypatch):
                                        True, p.gt_round, idx))
                 assert got[0] == c
                 assert_rows_equal("TRA", got[1], want, where="run_tra %s %s %s" % (mode, case["name"], c))
+
+
+def test_resident_runs_with_and_without_the_tier_peek(ctx, monkeypatch):
+    """upload / run / download: the host's peek at the big-tier counts (which skips empty k_refine<64,256> /
+    k_refine<256,2048> launches) must not change a byte, with clusters above 64 signatures present or not"""
+    for st, p in ((synth.small_mixed(seed=3), Params.ont(genotype=True)),
+                  (synth.small_mixed(seed=4, coverage=150, n_sites=20), Params.ont(genotype=True, min_support=3))):
+        hb = st.host_batch(st.tasks(), p)
+        want = _oracle().cluster_batch(hb, per_sig=True).trimmed()
+        for env in (None, "1"):
+            if env:
+                monkeypatch.setenv("CSV_NO_PEEK", env)
+            else:
+                monkeypatch.delenv("CSV_NO_PEEK", raising=False)
+            ctx.upload(hb, per_sig=True)
+            for _ in range(3):
+                ctx.run()
+            assert_soa_equal(ctx.download(per_sig=True).trimmed(), want)
+    sizes = np.bincount(want["cluster_id"][want["cluster_id"] >= 0])
+    assert sizes.max() > 64                                   # the second workload does exercise the big tiers
