@@ -45,7 +45,7 @@ struct Plan {
 
 // one timing slot per launch (group), in launch order
 const char* kStageName[CSV_N_STAGES] = {"init", "k_chain_count", "k_chain_apply", "k_refine_indel_wave", "k_refine_wave", "k_refine_mid",
-                                        "k_refine_block", "k_items_scan", "k_emit", "k_reads_order", "k_pmax_count", "k_pmax_apply",
+                                        "k_refine_block", "k_items_scan", "k_emit", "k_reads_order", "k_pmax_count", "k_pmax_scan",
                                         "k_genotype", "k_genotype_tra", "", "", "", "", "", "", "", "", "", ""};
 constexpr int N_COPY_STREAMS = 2;
 constexpr int RO_CAP = 4096;                 // sorted runs the reads_order stage plans (k_reads_plan packs the rank in 12 bits)
@@ -68,7 +68,7 @@ struct csv_ctx {
     Buf t_rec;
     Buf sc_k, sc_x, sc_v1, sc_v2, sc_v3, sc_v4, sc_v5;
     Buf o_rec, o_supsig, o_suprid, allele_id;
-    Buf reads_off, r_start, r_end, r_primary, r_id, s_start, s_end, s_primary, s_id, r_pmax, pm_partial, gt_over, gt_huge, gt_pool, contig_len;
+    Buf reads_off, r_start, r_end, r_primary, r_id, s_start, s_end, s_primary, s_id, r_pmax, pm_partial, pm_pre, gt_over, gt_huge, gt_pool, contig_len;
     Buf ro_runs, ro_table;
     // stand-alone
     Buf sqrt_tab, cnt;
@@ -239,7 +239,18 @@ int csv_ctx_create(int device_id, csv_ctx** out)
     c->device = device_id;
     if (hipSetDevice(device_id) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) { delete c; return CSV_E_HIP; }
     for (auto& e : c->ev) if (hipEventCreate(&e) != hipSuccess) { delete c; return CSV_E_HIP; }
-    for (auto& s2 : c->side) if (hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) != hipSuccess) { delete c; return CSV_E_HIP; }
+    {
+        // side[2] carries the reads stage, whose critical path runs through two single-workgroup kernels (k_reads_plan,
+        // k_pmax_scan): at default priority they wait for a free CU behind the clustering kernels of the main stream
+        // (27 and 15 us in the trace for a few microseconds of work), so that stream gets the highest priority
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        for (int q = 0; q < 3; q++) {
+            const hipError_t e = (q == 2 && !getenv("CSV_NO_PRIORITY")) ? hipStreamCreateWithPriority(&c->side[q], hipStreamNonBlocking, greatest)
+                                                                          : hipStreamCreateWithFlags(&c->side[q], hipStreamNonBlocking);
+            if (e != hipSuccess) { delete c; return CSV_E_HIP; }
+        }
+    }
     for (auto& s2 : c->copy) if (hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) != hipSuccess) { delete c; return CSV_E_HIP; }
     if (hipEventCreateWithFlags(&c->ev_init, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_sel, hipEventDisableTiming) != hipSuccess ||
@@ -396,7 +407,7 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
     PL(o_rec, (cap_tmp + 1) * sizeof(CallRec)); PL(o_supsig, (W + 1) * 8); PL(o_suprid, (W + 1) * 4);
     if (have_tab) { PL(reads_off, (in->n_chrom + 1) * 8); PL(contig_len, (in->n_chrom + 1) * 8); }
     if (R > 0) {
-        PL(pm_partial, (div_up(R, PM_TILE) + 2) * 8); PL(gt_over, (cap_tmp + 2) * 4); PL(gt_huge, (cap_tmp + 2) * 4); PL(gt_pool, pool_n * 4);
+        PL(pm_partial, (div_up(R, 512) + 8) * 8); PL(pm_pre, (div_up(R, 512) + 8) * 8); PL(gt_over, (cap_tmp + 2) * 4); PL(gt_huge, (cap_tmp + 2) * 4); PL(gt_pool, pool_n * 4);
         PL(r_start, R * 8); PL(r_end, R * 8); PL(r_primary, R); PL(r_id, R * 4); PL(r_pmax, R * 8);
         if (reorder) { PL(s_start, R * 8); PL(s_end, R * 8); PL(s_primary, R); PL(s_id, R * 4); PL(ro_runs, RO_CAP * 4); PL(ro_table, RO_CAP * 16); }
     }
@@ -505,7 +516,7 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
     if (have_tab) { B.reads_off = dp<i64>(c->reads_off); B.contig_len = dp<i64>(c->contig_len); }
     if (R > 0) {
         B.r_start = dp<i64>(c->r_start); B.r_end = dp<i64>(c->r_end); B.r_primary = dp<uint8_t>(c->r_primary); B.r_id = dp<int>(c->r_id);
-        B.r_pmax = dp<i64>(c->r_pmax); B.pm_partial = dp<i64>(c->pm_partial); B.gt_over = dp<int>(c->gt_over); B.gt_huge = dp<int>(c->gt_huge);
+        B.r_pmax = dp<i64>(c->r_pmax); B.pm_partial = dp<i64>(c->pm_partial); B.pm_pre = dp<i64>(c->pm_pre); B.gt_over = dp<int>(c->gt_over); B.gt_huge = dp<int>(c->gt_huge);
         B.gt_pool = dp<int>(c->gt_pool); B.gt_pool_n = pool_n;
         B.ro_mode = reorder ? 1 : 0;
         if (reorder) {
@@ -610,7 +621,7 @@ int run_impl(csv_ctx* c, csv_run_stats* stats)
         DBG("reads_order");
         if (s2 == st || stats) HIP_TRY(c, mark());
         LAUNCH_ON(s2, "pmax_count", k_pmax_count, nr, 256, 0, B);
-        LAUNCH_ON(s2, "pmax_apply", k_pmax_apply, nr, 256, 0, B);
+        LAUNCH_ON(s2, "pmax_scan", k_pmax_scan, 1, PS_THREADS, 0, B);
         return CSV_OK;
     };
     if (c->copies_pending) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_copy[0], 0));       // positions, lengths, INV / TRA words
@@ -719,6 +730,17 @@ int read_counters(csv_ctx* c)
             fprintf(stderr, "[csv] counters: clusters %d items %d calls %d error %d | reads: mode %d runs %d state %d | gt_over %d gt_huge %d tra_huge %d\n",
                     c->h_cnt.n_clusters, c->h_cnt.n_items, c->h_cnt.n_calls, c->h_cnt.error, c->B.ro_mode, c->h_cnt.n_runs, c->h_cnt.ro_state,
                     c->h_cnt.n_gt_over, c->h_cnt.n_gt_huge, c->h_cnt.n_tra_huge);
+        if (const char* dump = getenv("CSV_DUMP_ITEMS")) {                    // debug aid: the work-item tables of the last run
+            const int n = c->h_cnt.n_items;
+            std::vector<char> buf((size_t)n * (16 + 8 + 4 + 16 + 4 + 16) + 64);
+            char* q = buf.data();
+            int hdr[4] = {n, c->h_cnt.n_items_big, c->h_cnt.n_items_tiny, c->h_cnt.n_calls};
+            memcpy(q, hdr, 16); q += 16;
+            const void* src[6] = {c->item_rec.p, c->item_cnt.p, c->item_nslots.p, c->list_small.p, c->list_big.p, c->list_tiny.p};
+            const size_t w[6] = {16, 8, 4, 16, 4, 16};
+            for (int k = 0; k < 6; k++) { if (n) (void)hipMemcpy(q, src[k], (size_t)n * w[k], hipMemcpyDeviceToHost); q += (size_t)n * w[k]; }
+            if (FILE* f = fopen(dump, "wb")) { fwrite(buf.data(), 1, (size_t)(q - buf.data()), f); fclose(f); }
+        }
         if (c->B.ro_mode == 1 && c->B.n_reads > 0 && c->any_genotype && c->h_cnt.ro_state == RO_NEED_GENERAL && attempt == 0) {
             c->reads_general = true;
             c->B.ro_mode = 2;

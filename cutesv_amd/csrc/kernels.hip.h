@@ -8,7 +8,7 @@
 //             k_refine<64,64>    one wavefront per DUP/INV/TRA cluster (m <= 64), arrays in LDS
 //             k_refine<256,2048> one workgroup per cluster; LDS up to 2048 padded elements, global scratch above
 //   order     k_emit                                               per-item counts -> dense, ordered outputs
-//   reads     k_pmax_count / k_pmax_apply                          prefix max of read ends + sortedness check
+//   reads     k_reads_runs / _plan / _gather, k_pmax_count / _scan start order of every block; prefix max of read ends
 //   genotype  k_genotype                                           one wavefront per call: 64-ary search,
 //                                                                  backwards stabbing scan, LDS hash set
 //
@@ -156,8 +156,9 @@ struct DevBatch {
     int*           gt_huge;          // calls whose sets overflow the 32 KB tables AND one wavefront's slice of the global pool
     int*           gt_pool;          // global hash pool: gt_pool_n ints, power of two
     i64            gt_pool_n;
-    i64*           r_pmax;
-    i64*           pm_partial;       // tile maxima of the reads scan
+    i64*           r_pmax;           // per read: max of (chromosome << 40 | end) over the reads of its 512-row span up to it
+    i64*           pm_partial;       // per 512-row span: its maximum ...
+    i64*           pm_pre;           // ... and the maximum of all earlier spans (k_pmax_scan); see pmax_at()
     int*           gt_over;          // overflow list of the first genotype pass
     const i64*     contig_len;       // reference lengths (TRA genotyping windows)
     const double*  sqrt_tab;
@@ -1288,6 +1289,7 @@ template <int BLOCK, bool LDS> __device__ void refine_pair(const DevBatch& B, co
     const int nslots = carry_slot;
     const int tbase = s;
     int ncalls = 0, nsup = 0;
+    __syncthreads();                                                        // V4 / V5 of sub k were written by thread k
     for (int k = threadIdx.x >> 6; k < nsub; k += BLOCK / 64) {
         const int slot = A.V4[k];
         if (slot < 0) continue;
@@ -2191,65 +2193,85 @@ __global__ __launch_bounds__(RP_THREADS) void k_reads_plan(DevBatch B)
     if (threadIdx.x == 0) B.cnt->ro_state = RO_REORDER;
 }
 
+// Prefix max of read ends, in three cheap pieces instead of a second pass over the table: every 512-row span keeps the
+// running maximum of (chromosome << 40 | end) inside the span (r_pmax, written by whoever touches the rows anyway: the
+// gather below, or k_pmax_count for a table that was already in order) and its total (pm_partial); k_pmax_scan turns the
+// totals into the maximum of all EARLIER spans (pm_pre, a few thousand values); a reader combines the two.  Coordinates
+// restart at every chromosome, so the scanned value carries the chromosome in its high bits: a later chromosome wins.
+constexpr int PM_SHIFT = 40;
+constexpr i64 PM_MASK = (1ll << PM_SHIFT) - 1;
+__device__ __forceinline__ i64 pmax_at(const DevBatch& B, i64 i)
+{
+    const i64 a = B.r_pmax[i], b = B.pm_pre[i >> 9];
+    return (a > b ? a : b) & PM_MASK;
+}
+
 // one wavefront per 512 destination rows: find the run of the first row (64-ary search over the run table), then copy
-// run by run (a span of 512 rows usually lies inside one run).  The workgroup's 2048 rows are one tile of the prefix-max
-// scan: the copy also leaves the tile's maximum of (chromosome << 40 | end) and checks the ends, so k_pmax_count has
-// nothing left to do when the table was moved (it still runs for tables that were already in order).
+// run by run (a span of 512 rows usually lies inside one run), leaving the span's running maximum behind.
 __global__ __launch_bounds__(256) void k_reads_gather(DevBatch B)
 {
     if (B.ro_mode == 1 && B.cnt->ro_state != RO_REORDER) return;
-    __shared__ i64 s_mx[4];
     const int wv = threadIdx.x >> 6;
-    const i64 d0 = ((i64)blockIdx.x * 4 + wv) * 512;
-    i64 mx = INT64_MIN;
-    if (d0 < B.n_reads) {
-        const i64 d1 = d0 + 512 < B.n_reads ? d0 + 512 : B.n_reads;
+    const i64 span = (i64)blockIdx.x * 4 + wv, d0 = span * 512;
+    if (d0 >= B.n_reads) return;
+    const i64 d1 = d0 + 512 < B.n_reads ? d0 + 512 : B.n_reads;
+    i64 run = INT64_MIN;                                    // maximum of the span so far (wave-uniform)
+    if (B.ro_mode == 2) {                                   // general sort: a row permutation
         int hint = 0;
-        if (B.ro_mode == 2) {                               // general sort: a row permutation
-            for (i64 d = d0 + lane_id(); d < d1; d += 64) {
-                const int p = B.ro_perm[d];
+        for (i64 d = d0; d < d1; d += 64) {
+            const i64 x = d + lane_id();
+            i64 v = INT64_MIN;
+            if (x < d1) {
+                const int p = B.ro_perm[x];
                 const i64 e = B.r_end[p];
                 const int id = B.r_id[p];
-                B.s_start[d] = B.r_start[p]; B.s_end[d] = e; B.s_primary[d] = B.r_primary[p]; B.s_id[d] = id;
-                hint = chrom_of_read(B, d, hint);
-                if (e < 0 || e > ((1ll << 40) - 1) || id < 0) atomicOr(&B.cnt->error, ERR_KEY_RANGE);
-                const i64 v = ((i64)hint << 40) | e;
-                if (v > mx) mx = v;
+                B.s_start[x] = B.r_start[p]; B.s_end[x] = e; B.s_primary[x] = B.r_primary[p]; B.s_id[x] = id;
+                hint = chrom_of_read(B, x, hint);
+                if (e < 0 || e > PM_MASK || id < 0) atomicOr(&B.cnt->error, ERR_KEY_RANGE);
+                v = ((i64)hint << PM_SHIFT) | e;
             }
-        } else {
-            const int n = B.cnt->n_runs;
-            int lo = 0, hi = n;                             // last run with destination begin <= d0
-            while (hi - lo > 1) {
-                const int step = (hi - lo + 63) / 64;
-                const int idx = lo + lane_id() * step;
-                const int t = __popcll(__ballot(idx < hi && (i64)B.ro_table[idx < hi ? idx : lo].z <= d0));
-                const int nlo = lo + (t - 1) * step;
-                int nhi = lo + t * step;
-                if (nhi > hi) nhi = hi;
-                lo = nlo; hi = nhi;
-            }
-            i64 d = d0;
-            for (int q = lo; q < n && d < d1; q++) {
-                const int4 run = B.ro_table[q];
-                const i64 e1 = (i64)run.z + run.y < d1 ? (i64)run.z + run.y : d1;
-                const i64 shift = (i64)run.x - run.z;
-                for (i64 x = d + lane_id(); x < e1; x += 64) {
+            i64 inc = wave_incl_max_i64(v);
+            if (run > inc) inc = run;
+            if (x < d1) B.r_pmax[x] = inc;
+            run = lane63_i64(inc);
+        }
+    } else {
+        const int n = B.cnt->n_runs;
+        int lo = 0, hi = n;                                 // last run with destination begin <= d0
+        while (hi - lo > 1) {
+            const int step = (hi - lo + 63) / 64;
+            const int idx = lo + lane_id() * step;
+            const int t = __popcll(__ballot(idx < hi && (i64)B.ro_table[idx < hi ? idx : lo].z <= d0));
+            const int nlo = lo + (t - 1) * step;
+            int nhi = lo + t * step;
+            if (nhi > hi) nhi = hi;
+            lo = nlo; hi = nhi;
+        }
+        i64 d = d0;
+        for (int q = lo; q < n && d < d1; q++) {
+            const int4 rn = B.ro_table[q];
+            const i64 e1 = (i64)rn.z + rn.y < d1 ? (i64)rn.z + rn.y : d1;
+            const i64 shift = (i64)rn.x - rn.z;
+            for (i64 c0 = d; c0 < e1; c0 += 64) {           // consecutive rows, 64 at a time, in order
+                const i64 x = c0 + lane_id();
+                i64 v = INT64_MIN;
+                if (x < e1) {
                     const i64 p = x + shift;
                     const i64 e = B.r_end[p];
                     const int id = B.r_id[p];
                     B.s_start[x] = B.r_start[p]; B.s_end[x] = e; B.s_primary[x] = B.r_primary[p]; B.s_id[x] = id;
-                    if (e < 0 || e > ((1ll << 40) - 1) || id < 0) atomicOr(&B.cnt->error, ERR_KEY_RANGE);
-                    const i64 v = ((i64)run.w << 40) | e;   // (the run's chromosome)
-                    if (v > mx) mx = v;
+                    if (e < 0 || e > PM_MASK || id < 0) atomicOr(&B.cnt->error, ERR_KEY_RANGE);
+                    v = ((i64)rn.w << PM_SHIFT) | e;        // (the run's chromosome)
                 }
-                d = e1;
+                i64 inc = wave_incl_max_i64(v);
+                if (run > inc) inc = run;
+                if (x < e1) B.r_pmax[x] = inc;
+                run = lane63_i64(inc);
             }
+            d = e1;
         }
     }
-    for (int m = 32; m > 0; m >>= 1) { const i64 o = shfl_xor_i64(mx, m); if (o > mx) mx = o; }
-    if (lane_id() == 0) s_mx[wv] = mx;
-    __syncthreads();
-    if (threadIdx.x == 0) { i64 t = s_mx[0]; for (int k = 1; k < 4; k++) if (s_mx[k] > t) t = s_mx[k]; B.pm_partial[blockIdx.x] = t; }
+    if (lane_id() == 0) B.pm_partial[span] = run;
 }
 
 // chromosome of every row (key column of the general sort)
@@ -2260,80 +2282,71 @@ __global__ __launch_bounds__(256) void k_reads_chromcol(DevBatch B, int* out)
 }
 
 // ------------------------------------------------------------------------------------ reads: prefix max of ends
-// r_pmax[i] = max end over reads [first read of i's chromosome .. i].  Coordinates restart at every
-// chromosome, so the scan must not leak across blocks: the scanned value is (chromosome << 40 | end) and the
-// operator is plain max — chromosomes are non-decreasing along the table, so a later chromosome always wins.
 constexpr int PM_TILE = 256 * 8;
-constexpr int PM_SHIFT = 40;
-constexpr i64 PM_MASK = (1ll << PM_SHIFT) - 1;
-
-template <bool CHECK> __device__ __forceinline__ i64 pm_value(const DevBatch& B, const ReadsView& V, i64 i, int& hint)
-{
-    if (i >= B.n_reads) return INT64_MIN;
-    hint = chrom_of_read(B, i, hint);
-    const i64 e = V.end[i];
-    if (CHECK) {                                       // input validation happens once, in the counting pass
-        if (e < 0 || e > PM_MASK || V.id[i] < 0) atomicOr(&B.cnt->error, ERR_KEY_RANGE);
-        if (i > B.reads_off[hint] && V.start[i] < V.start[i - 1]) atomicOr(&B.cnt->error, ERR_READS_UNSORTED);
-    }
-    return ((i64)hint << PM_SHIFT) | e;
-}
 
 // (a batch whose reads table turned out to need the general sort is run again by the host: nothing downstream of the
 // reads_order stage does any work in the first attempt)
 __device__ __forceinline__ bool reads_pending(const DevBatch& B) { return B.ro_mode == 1 && B.cnt->ro_state == RO_NEED_GENERAL; }
 
+// the span pass for a table that was NOT moved (promised sorted, or found to be in order): running maxima per 512-row
+// span + input validation (ends, ids, and - for the promise - the order of the starts)
 __global__ __launch_bounds__(256) void k_pmax_count(DevBatch B)
 {
     if (reads_pending(B)) return;
-    // a table that k_reads_gather moved already has its tile maxima (and checked ends); an ordered table - promised, or
-    // found to be in order - is scanned here
-    if (B.ro_mode == 2 || (B.ro_mode == 1 && B.cnt->ro_state == RO_REORDER)) return;
+    if (B.ro_mode == 2 || (B.ro_mode == 1 && B.cnt->ro_state == RO_REORDER)) return;      // k_reads_gather did it
     const ReadsView V = reads_view(B);
-    const i64 base = (i64)blockIdx.x * PM_TILE + (threadIdx.x >> 6) * 512;
-    i64 mx = INT64_MIN;
-    int hint = 0;
-    for (int r = 0; r < 8; r++) {
-        const i64 v = pm_value<true>(B, V, base + r * 64 + lane_id(), hint);
-        if (v > mx) mx = v;
-    }
-    for (int m = 32; m > 0; m >>= 1) { const i64 o = shfl_xor_i64(mx, m); if (o > mx) mx = o; }
-    __shared__ i64 s[4];
-    if (lane_id() == 0) s[threadIdx.x >> 6] = mx;
-    __syncthreads();
-    if (threadIdx.x == 0) { i64 t = s[0]; for (int k = 1; k < 4; k++) if (s[k] > t) t = s[k]; B.pm_partial[blockIdx.x] = t; }
-}
-
-__global__ __launch_bounds__(256) void k_pmax_apply(DevBatch B)
-{
-    if (reads_pending(B)) return;
-    const ReadsView V = reads_view(B);
-    const int wv = threadIdx.x >> 6;
-    const i64 base = (i64)blockIdx.x * PM_TILE + wv * 512;
-    i64 vals[8];
+    const i64 span = (i64)blockIdx.x * 4 + (threadIdx.x >> 6), base = span * 512;
+    if (base >= B.n_reads) return;
     i64 run = INT64_MIN;
     int hint = 0;
     for (int r = 0; r < 8; r++) {
-        const i64 v = pm_value<false>(B, V, base + r * 64 + lane_id(), hint);
+        const i64 i = base + r * 64 + lane_id();
+        i64 v = INT64_MIN;
+        if (i < B.n_reads) {
+            hint = chrom_of_read(B, i, hint);
+            const i64 e = V.end[i];
+            if (e < 0 || e > PM_MASK || V.id[i] < 0) atomicOr(&B.cnt->error, ERR_KEY_RANGE);
+            if (i > B.reads_off[hint] && V.start[i] < V.start[i - 1]) atomicOr(&B.cnt->error, ERR_READS_UNSORTED);
+            v = ((i64)hint << PM_SHIFT) | e;
+        }
         i64 inc = wave_incl_max_i64(v);
         if (run > inc) inc = run;
-        vals[r] = inc;
+        if (i < B.n_reads) B.r_pmax[i] = inc;
         run = lane63_i64(inc);
     }
-    __shared__ i64 s[4], sp[4];
-    // exclusive prefix max of this tile = max over the maxima of all earlier tiles (self-computed like the chain
-    // prefix: a few thousand L2-resident values; the separate single-workgroup scan kernel cost 8-12 us)
-    i64 pm = INT64_MIN;
-    for (int t = threadIdx.x; t < (int)blockIdx.x; t += 256) { const i64 v = B.pm_partial[t]; if (v > pm) pm = v; }
-    for (int m = 32; m > 0; m >>= 1) { const i64 o = shfl_xor_i64(pm, m); if (o > pm) pm = o; }
-    if (lane_id() == 0) { s[wv] = run; sp[wv] = pm; }
+    if (lane_id() == 0) B.pm_partial[span] = run;
+}
+
+// exclusive prefix max over the span maxima: one workgroup, a few thousand values.  Every thread takes PS_PER consecutive
+// spans (a serial max in registers), one block scan combines the threads: a 30x genome (12 k spans) is one sweep.
+constexpr int PS_THREADS = 1024;
+constexpr int PS_PER = 16;
+__global__ __launch_bounds__(PS_THREADS) void k_pmax_scan(DevBatch B)
+{
+    if (reads_pending(B)) return;
+    __shared__ i64 s_w[PS_THREADS / 64];
+    __shared__ i64 s_carry;
+    const i64 nspan = (B.n_reads + 511) >> 9;
+    if (threadIdx.x == 0) s_carry = INT64_MIN;
     __syncthreads();
-    i64 pre = sp[0];
-    for (int k = 1; k < 4; k++) if (sp[k] > pre) pre = sp[k];
-    for (int k = 0; k < wv; k++) if (s[k] > pre) pre = s[k];
-    for (int r = 0; r < 8; r++) {
-        const i64 i = base + r * 64 + lane_id();
-        if (i < B.n_reads) B.r_pmax[i] = (vals[r] > pre ? vals[r] : pre) & PM_MASK;
+    for (i64 b0 = 0; b0 < nspan; b0 += (i64)PS_THREADS * PS_PER) {
+        const i64 i0 = b0 + (i64)threadIdx.x * PS_PER;
+        i64 v[PS_PER];
+        i64 mine = INT64_MIN;
+#pragma unroll
+        for (int k = 0; k < PS_PER; k++) { v[k] = i0 + k < nspan ? B.pm_partial[i0 + k] : INT64_MIN; if (v[k] > mine) mine = v[k]; }
+        const i64 inc = wave_incl_max_i64(mine);
+        if (lane_id() == 63) s_w[threadIdx.x >> 6] = inc;
+        __syncthreads();
+        i64 pre = s_carry;
+        for (int q = 0; q < (int)(threadIdx.x >> 6); q++) if (s_w[q] > pre) pre = s_w[q];
+        i64 run = dpp_i64<0x138, 0xf>(INT64_MIN, inc);       // wave_shr:1: everything left of this thread in its wavefront
+        if (run < pre) run = pre;
+#pragma unroll
+        for (int k = 0; k < PS_PER; k++) { if (i0 + k < nspan) B.pm_pre[i0 + k] = run; if (v[k] > run) run = v[k]; }
+        __syncthreads();
+        if (threadIdx.x == PS_THREADS - 1) s_carry = run;
+        __syncthreads();
     }
 }
 
@@ -2401,7 +2414,7 @@ template <int HASH, int U> __device__ __forceinline__ bool cover_step(const DevB
     for (int u = 0; u < U; u++) {
         const i64 i = top - u * 64 - lane_id();
         const i64 ii = i >= r0 ? i : r0;
-        pm[u] = B.r_pmax[ii]; en[u] = V.end[ii]; pr[u] = V.primary[ii]; id[u] = V.id[ii];
+        pm[u] = pmax_at(B, ii); en[u] = V.end[ii]; pr[u] = V.primary[ii]; id[u] = V.id[ii];
     }
 #pragma unroll
     for (int u = 0; u < U; u++) {
@@ -2481,12 +2494,12 @@ __device__ __forceinline__ GtWin gt_windows(const GtHead& H)
 
 // first index in [lo, hi) whose prefix max reaches R (r_pmax is non-decreasing inside a chromosome): the scan of a
 // window never goes below it
-__device__ __forceinline__ i64 lower_bound_pmax(const i64* __restrict__ pm, i64 lo, i64 hi, i64 R2)
+__device__ __forceinline__ i64 lower_bound_pmax(const DevBatch& B, i64 lo, i64 hi, i64 R2)
 {
     while (hi - lo > 64) {
         const i64 step = (hi - lo + 63) / 64;
         const i64 idx = lo + (i64)lane_id() * step;
-        const int pred = (idx < hi) && (2 * pm[idx < hi ? idx : lo] < R2);
+        const int pred = (idx < hi) && (2 * pmax_at(B, idx < hi ? idx : lo) < R2);
         const int t = __popcll(__ballot(pred));
         if (t == 0) return lo;
         const i64 nlo = lo + (i64)(t - 1) * step + 1;
@@ -2495,7 +2508,7 @@ __device__ __forceinline__ i64 lower_bound_pmax(const i64* __restrict__ pm, i64 
         lo = nlo; hi = nhi;
     }
     const i64 idx = lo + lane_id();
-    const int pred = (idx < hi) && (2 * pm[idx < hi ? idx : lo] < R2);
+    const int pred = (idx < hi) && (2 * pmax_at(B, idx < hi ? idx : lo) < R2);
     return lo + __popcll(__ballot(pred));
 }
 
@@ -2510,12 +2523,12 @@ __device__ bool genotype_global(const DevBatch& B, const ReadsView& V, const GtH
     const GtWin W = gt_windows(H);
     i64 need = ns;
     const i64 topa = upper_bound_start(V.start, r0, r1, W.La) - 1;
-    const i64 bota = topa >= r0 ? lower_bound_pmax(B.r_pmax, r0, topa + 1, W.Ra) : r0;
+    const i64 bota = topa >= r0 ? lower_bound_pmax(B, r0, topa + 1, W.Ra) : r0;
     if (topa >= bota) need += topa - bota + 1;
     i64 topb = r0 - 1, botb = r0;
     if (W.n == 2) {
         topb = upper_bound_start(V.start, r0, r1, W.Lb) - 1;
-        botb = topb >= r0 ? lower_bound_pmax(B.r_pmax, r0, topb + 1, W.Rb) : r0;
+        botb = topb >= r0 ? lower_bound_pmax(B, r0, topb + 1, W.Rb) : r0;
         if (topb >= botb) need += topb - botb + 1;
     }
     int bits = 10;
@@ -2665,7 +2678,7 @@ __device__ __forceinline__ int tra_window(const DevBatch& B, const ReadsView& V,
     const i64 limit = (3ll << bits) / 4;
     const i64 r0 = B.reads_off[chrom], r1 = B.reads_off[chrom + 1];
     const i64 hi = partition_point_wave(r0, r1, [&](i64 i) { return V.start[i] < e; });        // fetch(): start < e ...
-    const i64 lo = partition_point_wave(r0, hi, [&](i64 i) { return B.r_pmax[i] <= s; });      // ... and end > s
+    const i64 lo = partition_point_wave(r0, hi, [&](i64 i) { return pmax_at(B, i) <= s; });    // ... and end > s
     i64 iteration = 0, primary = 0;
     const u64 le = lanemask_lt() | (1ull << lane_id());
     for (i64 base = lo; base < hi; base += 64) {
