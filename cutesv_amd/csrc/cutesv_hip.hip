@@ -63,8 +63,8 @@ struct csv_ctx {
     Arena       arena, arena_rb;
     // batch buffers (slices of `arena`)
     Buf seg, woff, seg_drop, a, b, rid, aux;
-    Buf cluster_id, partial, partial64, item_rec, list_small, list_big, list_tiny, partial_t, seg_gate, ch_masks, wave_items, wave_cnt, seg_err;
-    Buf item_nslots, item_cnt, item_base, sup_tmp;
+    Buf cluster_id, partial, partial64, item_rec, list_small, list_big, list_tiny, partial_t, seg_gate, tile_info, ch_masks, wave_items, wave_cnt, seg_err;
+    Buf item_nslots, item_cnt, item_base, item_chunk, sup_tmp;
     Buf t_rec;
     Buf sc_k, sc_x, sc_v1, sc_v2, sc_v3, sc_v4, sc_v5;
     Buf o_rec, o_supsig, o_suprid, allele_id;
@@ -393,6 +393,7 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
     Plan P;
 #define PL(buf, bytes) P.add(c->buf, (size_t)(bytes))
     PL(seg, (S + 1) * sizeof(csv_segment)); PL(woff, (S + 2) * sizeof(i64)); PL(seg_drop, S + 1); PL(seg_gate, (S + 1) * 16); PL(seg_err, (S + 1) * 4);
+    PL(tile_info, nt * 32);
     PL(a, (W + 1) * 8); PL(b, (W + 1) * 8); PL(rid, (W + 1) * 4); PL(aux, (W + 1) * 4);
     PL(sup_tmp, (W + 1) * 4);
     if (per_sig) { PL(cluster_id, (W + 1) * 4); PL(allele_id, (W + 1) * 4); }
@@ -400,7 +401,7 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
     if (per_sig) PL(ch_masks, nt * 4 * CH_ITEMS * 8);
     PL(wave_items, nt * 4 * (size_t)WI_STRIDE * 16); PL(wave_cnt, nt * 4 * 16);
     PL(item_rec, cap_items * 16); PL(list_small, cap_items * 16); PL(list_big, cap_items * 4); PL(list_tiny, cap_items * 16);
-    PL(item_nslots, cap_items * 4); PL(item_cnt, cap_items * 8); PL(item_base, (cap_items + 8) * 8);
+    PL(item_nslots, cap_items * 4); PL(item_cnt, cap_items * 8); PL(item_base, (cap_items + 8) * 8); PL(item_chunk, (cap_items / IS_CHUNK + 2) * 8);
     // temp call records are indexed by w (a cluster's slots live in its own signature range)
     PL(t_rec, (W + 1) * sizeof(TmpRec));
     PL(sc_k, SC * 8); PL(sc_x, SC * 8); PL(sc_v1, SC * 4); PL(sc_v2, SC * 4); PL(sc_v3, SC * 4); PL(sc_v4, SC * 4); PL(sc_v5, SC * 4);
@@ -421,7 +422,7 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
 
     // ---- small tables: staged in page-locked memory, one copy
     const size_t o_seg = 0, o_woff = o_seg + (size_t)(S + 1) * sizeof(csv_segment), o_drop = o_woff + (size_t)(S + 2) * 8,
-                 o_gate = (o_drop + (size_t)S + 1 + 15) & ~(size_t)15, o_end = o_gate + (size_t)(S + 1) * 16;
+                 o_gate = (o_drop + (size_t)S + 1 + 15) & ~(size_t)15, o_tiles = o_gate + (size_t)(S + 1) * 16, o_end = o_tiles + (size_t)nt * 32;
     // (the staging block is also the landing zone of the results: never smaller than one counters struct)
     { const int rc = pin_reserve(c, o_end + sizeof(DevCounters) + 256); if (rc) return rc; }
     hipStream_t st = c->stream;
@@ -431,6 +432,24 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
     memcpy(c->h_pin + o_drop, drop.data(), (size_t)S + 1);
     int* gate = (int*)(c->h_pin + o_gate);                  // {read_count, dropped, svtype, -} per segment
     for (int k = 0; k < S; k++) { gate[4 * k] = c->h_seg[k].read_count; gate[4 * k + 1] = drop[k]; gate[4 * k + 2] = c->h_seg[k].svtype; gate[4 * k + 3] = 0; }
+    {
+        // per chain tile: first / last segment and, for the tiles that lie inside one segment, its chain scalars (kernels.hip.h
+        // TileInfo).  Empty segments own no row and are skipped, as seg_of_wave does on the device.
+        int* ti = (int*)(c->h_pin + o_tiles);
+        int k = 0;
+        for (i64 t = 0; t < nt; t++) {
+            int* r = ti + 8 * t;
+            const i64 w0 = t * (i64)CH_TILE, w1 = (w0 + CH_TILE < W ? w0 + CH_TILE : W) - 1;
+            if (w0 >= W) { for (int q = 0; q < 8; q++) r[q] = 0; r[1] = -1; continue; }      // (k0 != k1: never trusted)
+            while (k + 1 < S && c->h_woff[k + 1] <= w0) k++;
+            int k1 = k;
+            while (k1 + 1 < S && c->h_woff[k1 + 1] <= w1) k1++;
+            const csv_segment& g = c->h_seg[k];
+            r[0] = k; r[1] = k1; r[2] = g.svtype; r[3] = (int)c->h_woff[k];
+            r[4] = (int)(g.max_cluster_bias & 0xffffffffll); r[5] = (int)(g.max_cluster_bias >> 32); r[6] = g.read_count; r[7] = drop[k];
+        }
+        HIP_TRY(c, hipMemcpyAsync(c->tile_info.p, ti, (size_t)nt * 32, hipMemcpyHostToDevice, st));
+    }
     HIP_TRY(c, hipMemcpyAsync(c->seg.p, c->h_pin + o_seg, (size_t)S * sizeof(csv_segment), hipMemcpyHostToDevice, st));
     HIP_TRY(c, hipMemcpyAsync(c->woff.p, c->h_pin + o_woff, (size_t)(S + 1) * 8, hipMemcpyHostToDevice, st));
     HIP_TRY(c, hipMemcpyAsync(c->seg_drop.p, c->h_pin + o_drop, (size_t)S + 1, hipMemcpyHostToDevice, st));
@@ -502,11 +521,11 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
     B.cluster_id = per_sig ? dp<int>(c->cluster_id) : nullptr; B.allele_id = per_sig ? dp<int>(c->allele_id) : nullptr;
     B.partial = dp<int>(c->partial); B.partial64 = dp<i64>(c->partial64);
     B.item_rec = dp<int4>(c->item_rec); B.list_small = dp<int4>(c->list_small); B.list_big = dp<int>(c->list_big); B.list_tiny = dp<int4>(c->list_tiny);
-    B.partial_t = dp<int>(c->partial_t); B.seg_gate = dp<int4>(c->seg_gate);
+    B.partial_t = dp<int>(c->partial_t); B.seg_gate = dp<int4>(c->seg_gate); B.tile_info = dp<int4>(c->tile_info);
     B.ch_masks = per_sig ? dp<u64>(c->ch_masks) : nullptr; B.wave_items = dp<int4>(c->wave_items); B.wave_cnt = dp<int4>(c->wave_cnt);
     B.seg_err = dp<int>(c->seg_err);
     B.tiny_max = getenv("CSV_NO_TINY") ? 0 : 16;               // (timing aid: 0 sends every DEL/INS cluster of m <= 32 through the paired path)
-    B.item_nslots = dp<int>(c->item_nslots); B.item_cnt = dp<i64>(c->item_cnt); B.item_base = dp<i64>(c->item_base);
+    B.item_nslots = dp<int>(c->item_nslots); B.item_cnt = dp<i64>(c->item_cnt); B.item_base = dp<i64>(c->item_base); B.item_chunk = dp<i64>(c->item_chunk);
     B.sup_tmp = dp<int>(c->sup_tmp);
     B.t_rec = dp<TmpRec>(c->t_rec);
     B.cap_tmp = (int)cap_tmp; B.cap_items = (int)cap_items;
@@ -683,7 +702,7 @@ int run_impl(csv_ctx* c, csv_run_stats* stats)
             HIP_TRY(c, hipStreamWaitEvent(st, c->ev_aux[0], 0));
             if (c->any_pair) { HIP_TRY(c, hipEventRecord(c->ev_aux[1], sC)); HIP_TRY(c, hipStreamWaitEvent(st, c->ev_aux[1], 0)); }
         }
-        LAUNCH("items_scan", k_items_scan, 1, 64 * IS_NW, 0, B);
+        LAUNCH("items_scan", k_items_scan, B.cap_items / IS_CHUNK + 1, 64 * IS_NW, 0, B);
         LAUNCH("emit", k_emit, 2048, 256, 0, B);
         if (do_gt) {
             if (fork) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_aux[2], 0));

@@ -126,11 +126,14 @@ struct DevBatch {
     int            run_seq;          // at them while k_refine_indel_wave runs and launches only the tiers that have work
     int*           seg_err;          // n_seg words of CSV_SEG_* bits
     const int4*    seg_gate;         // per segment {read_count, dropped, svtype, -}: one 16-byte load for the size gate
+    const int4*    tile_info;        // per chain tile, built by the host: {k_first, k_last, svtype, segment start} and
+                                     // {max_cluster_bias lo, hi, read_count, dropped} of k_first (TileInfo below)
     int*           partial_t;        // tiny work items per chain tile
     // refine outputs
     int*           item_nslots;      // temp slots the item filled (t_*[s + slot])
     i64*           item_cnt;         // packed (valid calls << 32 | supports of valid calls)
-    i64*           item_base;        // exclusive prefix of item_cnt per tile of EM_TILE items
+    i64*           item_base;        // exclusive prefix of item_cnt per tile of EM_TILE items, inside the tile's chunk of IS_CHUNK items
+    i64*           item_chunk;       // total of item_cnt per chunk
     int*           sup_tmp;          // W: support lists, stored inside the cluster's own [s, e) range
     TmpRec*        t_rec;            // W temp call records (a cluster's slots live in its own signature range)
     int            cap_tmp;
@@ -304,43 +307,59 @@ __device__ __forceinline__ int chain_flag(const DevBatch& B, i64 w, int& seg_hin
 constexpr int CH_ITEMS = 8;                         // rows of 64 per wavefront
 constexpr int CH_TILE = 256 * CH_ITEMS;             // signatures per workgroup
 
-// Flags of the CH_ITEMS rows a wavefront owns ([base, base + 512)).  When the whole span lies in one
-// segment (almost always) the segment scalars sit in SGPRs and the 8 row loads are issued back to
-// back; the neighbour value comes from the lane to the left.  zprev[r] marks cluster starts whose
-// preceding signature is a (0,0) element.
-__device__ __forceinline__ int chain_rows(const DevBatch& B, i64 base, u64 (&masks)[CH_ITEMS], u64 (&zmasks)[CH_ITEMS], int (&ksg)[CH_ITEMS])
+// Flags of the CH_ITEMS rows a wavefront owns ([base, base + 512)), handed row by row to `sink(r, mask, zmask, segment)`
+// (the masks are wave-uniform 64-bit values: keeping all 16 of them alive cost 32 SGPRs and, through the SGPR file, two
+// wavefronts per SIMD of occupancy).  When the whole span lies in one segment (almost always) the segment scalars sit
+// in SGPRs and the 8 row loads are issued back to back; the neighbour value comes from the lane to the left.
+// zmask marks cluster starts whose preceding signature is a (0,0) element.
+// What the chain kernels need to know about a tile's segment(s).  The host knows the segment table when it uploads a
+// batch, so it leaves one 32-byte record per tile: a tile that lies inside one segment (almost all do) gets its scalars
+// with the same round trip as its rows instead of three dependent ones (segment search -> segment record -> rows).
+struct TileInfo { int k0, k1, type, sf; i64 bias; int rc, drop; };
+__device__ __forceinline__ TileInfo tile_info_of(const DevBatch& B, int tile)
+{
+    const int4 t0 = B.tile_info[2 * tile], t1 = B.tile_info[2 * tile + 1];
+    TileInfo T;
+    T.k0 = __builtin_amdgcn_readfirstlane(t0.x); T.k1 = __builtin_amdgcn_readfirstlane(t0.y);
+    T.type = __builtin_amdgcn_readfirstlane(t0.z); T.sf = __builtin_amdgcn_readfirstlane(t0.w);
+    T.bias = ((i64)__builtin_amdgcn_readfirstlane(t1.y) << 32) | (i64)(unsigned)__builtin_amdgcn_readfirstlane(t1.x);
+    T.rc = __builtin_amdgcn_readfirstlane(t1.z); T.drop = __builtin_amdgcn_readfirstlane(t1.w);
+    return T;
+}
+
+template <class Sink> __device__ __forceinline__ void chain_rows(const DevBatch& B, i64 base, const TileInfo& T, Sink&& sink)
 {
     const int lane = lane_id();
-#pragma unroll
-    for (int r = 0; r < CH_ITEMS; r++) { masks[r] = 0; zmasks[r] = 0; ksg[r] = 0; }
-    if (base >= B.W) return -1;
+    if (base >= B.W) return;
     // the rows first: their addresses depend on nothing, the segment probes below ride on the same round trip
     const int w0 = (int)base, nW = (int)B.W;            // (a batch holds < 2^31 signatures)
     i64 a[CH_ITEMS];
 #pragma unroll
     for (int r = 0; r < CH_ITEMS; r++) { const int w = w0 + r * WAVE + lane; a[r] = (w < nW) ? B.a[w] : 0; }
     i64 left = (lane == 0 && base > 0) ? B.a[base - 1] : 0;         // the signature left of the span (lane 0 only)
-    const i64 lastw = (base + WAVE * CH_ITEMS - 1 < B.W) ? base + WAVE * CH_ITEMS - 1 : B.W - 1;
-    const int k0 = __builtin_amdgcn_readfirstlane(seg_of_wave(B, base)), k1 = __builtin_amdgcn_readfirstlane(seg_of_wave(B, lastw));
-    if (k0 != k1) {                                   // span crosses a segment boundary: per-row path
-        int seg_hint = k0;
-#pragma unroll
-        for (int r = 0; r < CH_ITEMS; r++) {
-            const i64 w = base + r * WAVE + lane;
-            i64 a0;
-            const int f = chain_flag(B, w, seg_hint, a0, k1);
-            ksg[r] = seg_hint;
-            zmasks[r] = __ballot(f && w > 0 && w < B.W && a0 == 0 && B.b[w > 0 ? w - 1 : 0] == 0);
-            masks[r] = __ballot(f);
+    int k0 = T.k0, sf = T.sf, type = T.type;
+    i64 bias = T.bias;
+    if (T.k0 != T.k1) {                               // the tile spans segments: does this wavefront's span?
+        const i64 lastw = (base + WAVE * CH_ITEMS - 1 < B.W) ? base + WAVE * CH_ITEMS - 1 : B.W - 1;
+        k0 = __builtin_amdgcn_readfirstlane(seg_of_wave(B, base));
+        const int k1 = __builtin_amdgcn_readfirstlane(seg_of_wave(B, lastw));
+        if (k0 != k1) {                               // it does: per-row path
+            int seg_hint = k0;
+#pragma unroll 1
+            for (int r = 0; r < CH_ITEMS; r++) {
+                const i64 w = base + r * WAVE + lane;
+                i64 a0;
+                const int f = chain_flag(B, w, seg_hint, a0, k1);
+                const u64 zm = __ballot(f && w > 0 && w < B.W && a0 == 0 && B.b[w > 0 ? w - 1 : 0] == 0);
+                sink(r, __ballot(f), zm, seg_hint);
+            }
+            return;
         }
-        return -1;
+        const csv_segment& sg = B.seg[k0];
+        // segment scalars are wave-uniform: say so, and the type tests below become scalar branches
+        bias = readlane_i64x(sg.max_cluster_bias, 0);
+        sf = __builtin_amdgcn_readfirstlane((int)B.woff[k0]); type = __builtin_amdgcn_readfirstlane(sg.svtype);
     }
-#pragma unroll
-    for (int r = 0; r < CH_ITEMS; r++) ksg[r] = k0;
-    const csv_segment& sg = B.seg[k0];
-    // segment scalars are wave-uniform: say so, and the type tests below become scalar branches
-    const i64 bias = readlane_i64x(sg.max_cluster_bias, 0);
-    const int sf = __builtin_amdgcn_readfirstlane((int)B.woff[k0]), type = __builtin_amdgcn_readfirstlane(sg.svtype);
 #pragma unroll
     for (int r = 0; r < CH_ITEMS; r++) {
         const int w = w0 + r * WAVE + lane;
@@ -357,10 +376,9 @@ __device__ __forceinline__ int chain_rows(const DevBatch& B, i64 base, u64 (&mas
         if (type == CSV_INV) { if (in && !f && !z && w != sf) f = (B.b[w] - B.b[w - 1] > bias) || (B.aux[w] != B.aux[w - 1]); }
         else if (type == CSV_TRA) { if (in && !f && !z && w != sf) f = B.aux[w] != B.aux[w - 1]; }
         if (z && w != sf) f = true;
-        zmasks[r] = __ballot(f && z);
-        masks[r] = __ballot(f);
+        const u64 zm = __ballot(f && z);
+        sink(r, __ballot(f), zm, k0);
     }
-    return k0;
 }
 constexpr int EM_TILE = 8;                          // items per emit wavefront
 constexpr int EM_SUPER = 512;                       // items per second-level sum
@@ -416,40 +434,27 @@ __device__ __forceinline__ int close_gate(const DevBatch& B, const int4 g, int s
 }
 
 // rows -> flags; the wavefront's cluster starts (bit 31: previous signature is (0,0)) and their segments go to its OWN
-// region of the LDS lists, so nothing here waits for another wavefront.  Returns the wavefront's number of starts.
+// region of the LDS lists, so nothing here waits for another wavefront.  Returns the wavefront's number of starts;
+// `pub` = lane r's copy of row r's flag mask (for k_chain_ids).
 constexpr int CL_REG = WAVE * CH_ITEMS + 2;          // entries per wavefront region (512 starts + the sentinel)
 constexpr int WI_STRIDE = WAVE * CH_ITEMS + 8;       // item slots per wavefront (at most 513 clusters end in its span)
-__device__ __forceinline__ int wave_starts(const DevBatch& B, i64 base, u64 (&masks)[CH_ITEMS], u64 (&zmasks)[CH_ITEMS], int* SR, int* SKR, int& ku)
+__device__ __forceinline__ int wave_starts(const DevBatch& B, i64 base, const TileInfo& T, int* SR, int* SKR, u64& pub)
 {
-    int ksg[CH_ITEMS];
-    ku = chain_rows(B, base, masks, zmasks, ksg);
-    if (base >= B.W) ku = -2;                          // wavefront beyond the end
     int off = 0;
-#pragma unroll
-    for (int r = 0; r < CH_ITEMS; r++) {
-        const u64 m = masks[r];
+    u64 pb = 0;
+    chain_rows(B, base, T, [&](int r, u64 m, u64 zm, int kseg) {
         if (!CSV_ABL(8) && ((m >> lane_id()) & 1)) {
             const int idx = off + __popcll(m & lanemask_lt());
             int v = (int)base + r * WAVE + lane_id();
-            if (zmasks[r]) v |= (int)((zmasks[r] >> lane_id()) & 1) << 31;       // (wave-uniform test: the mask is almost always 0)
+            if (zm) v |= (int)((zm >> lane_id()) & 1) << 31;               // (wave-uniform test: the mask is almost always 0)
             SR[idx] = v;
-            SKR[idx] = ksg[r];
+            SKR[idx] = kseg;
         }
         off += __popcll(m);
-    }
+        if (lane_id() == r) pb = m;
+    });
+    pub = pb;
     return off;
-}
-// after the workgroup barrier: is the tile inside one segment?  (s_ku: per-wavefront segment or -1 / -2; g_own: the
-// gate scalars of the caller's OWN segment, loaded before the barrier so that no global load follows it - when the
-// tile is uniform every wavefront that lies inside the batch has that same segment)
-__device__ __forceinline__ void tile_seg(const int* s_ku, int ku_own, const int4 g_own, TileSeg& ts)
-{
-    const int k0 = s_ku[0];
-    bool uni = k0 >= 0;
-    for (int q = 1; q < 4; q++) uni = uni && (s_ku[q] == k0 || s_ku[q] == -2);
-    uni = uni && ku_own == k0;                         // (a wavefront beyond the end has nothing to gate anyway)
-    ts.uni = uni ? 1 : 0; ts.k = 0; ts.rc = 0; ts.drop = 0; ts.type = 0;
-    if (uni) { ts.k = k0; ts.rc = g_own.x; ts.drop = g_own.y; ts.type = g_own.z; }
 }
 // start (and segment) of the cluster that is still open where wavefront wv's span begins: the last entry of the
 // nearest earlier non-empty region, else the tile's look-back result
@@ -462,25 +467,29 @@ __device__ __forceinline__ int2 open_before(const int (*SR)[CL_REG], const int (
 
 // flags of the 64 signatures [cb, cb + 64), cb >= 0 (used to look backwards from a tile).  Same shape as
 // chain_rows: the row load is issued before the segment probes; one segment -> scalars + neighbour by DPP.
-__device__ __forceinline__ u64 chain_flag_row64(const DevBatch& B, i64 cb, int& kseg)
+__device__ __forceinline__ u64 chain_flag_row64(const DevBatch& B, i64 cb, int& kseg, const TileInfo& T)
 {
     const i64 lastw = cb + 63 < B.W ? cb + 63 : B.W - 1;
     const i64 w = cb + lane_id();
     const bool in = w < B.W;
     const i64 a1 = in ? B.a[w] : 0;
     const i64 left = (lane_id() == 0 && cb > 0) ? B.a[cb - 1] : 0;
-    const int k0 = __builtin_amdgcn_readfirstlane(seg_of_wave(B, cb)), k1 = __builtin_amdgcn_readfirstlane(seg_of_wave(B, lastw));
-    if (k0 != k1) {
-        int hint = k0;
-        i64 a0;
-        const int f = chain_flag(B, w, hint, a0, k1);
-        kseg = hint;
-        return __ballot(f);
+    i64 bias = T.bias, seg_first = T.sf;
+    int type = T.type, k0 = T.k0;
+    if (T.k0 != T.k1 || cb < T.sf) {                   // not (known to be) inside the tile's own segment
+        k0 = __builtin_amdgcn_readfirstlane(seg_of_wave(B, cb));
+        const int k1 = __builtin_amdgcn_readfirstlane(seg_of_wave(B, lastw));
+        if (k0 != k1) {
+            int hint = k0;
+            i64 a0;
+            const int f = chain_flag(B, w, hint, a0, k1);
+            kseg = hint;
+            return __ballot(f);
+        }
+        const csv_segment& sg = B.seg[k0];
+        bias = sg.max_cluster_bias; seg_first = B.woff[k0]; type = sg.svtype;
     }
     kseg = k0;
-    const csv_segment& sg = B.seg[k0];
-    const i64 bias = sg.max_cluster_bias, seg_first = B.woff[k0];
-    const int type = sg.svtype;
     i64 a0 = wave_shr1_i64(a1);
     if (lane_id() == 0) a0 = left;
     bool f = in && (w == seg_first || a1 - a0 > bias);
@@ -492,41 +501,50 @@ __device__ __forceinline__ u64 chain_flag_row64(const DevBatch& B, i64 cb, int& 
     return __ballot(f);
 }
 
-__global__ __launch_bounds__(320) void k_chain_count(DevBatch B)
+#ifdef CSV_CC_SGPR
+#define CSV_CC_ATTR __attribute__((amdgpu_num_sgpr(CSV_CC_SGPR), amdgpu_num_vgpr(64)))
+#else
+#define CSV_CC_ATTR
+#endif
+#ifdef CSV_CC_EXIT              // timing experiments only: leave the kernel at stage n, keeping `val` alive
+#define CC_EXIT(n, val) if (CSV_CC_EXIT == (n)) { \
+    if (lane_id() == 0) B.wave_cnt[(i64)blockIdx.x * 4 + wv] = make_int4(cnt, 0, 0, 0); \
+    if (threadIdx.x == 0) { B.partial[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3] + ((val) == 0x7fedcba9); B.partial64[blockIdx.x] = 0; B.partial_t[blockIdx.x] = 0; } \
+    return; }
+#else
+#define CC_EXIT(n, val)
+#endif
+__global__ __launch_bounds__(320) CSV_CC_ATTR void k_chain_count(DevBatch B)
 {
     // first kernel of a run: nothing in this kernel reads the counters, every later kernel is stream-ordered behind it
     if (blockIdx.x == 0 && threadIdx.x < (int)(sizeof(DevCounters) / 4)) ((int*)B.cnt)[threadIdx.x] = 0;
     __shared__ int SR[4][CL_REG], SKR[4][CL_REG];         // per wavefront: its cluster starts and their segments
-    __shared__ int s_cnt[4], s_ku[4], s_t[4], s_prev[2];
+    __shared__ int s_cnt[4], s_t[4], s_prev[2];
     __shared__ i64 s_v[4];
     const int wv = threadIdx.x >> 6;
     const i64 tile0 = (i64)blockIdx.x * CH_TILE;
     const bool last_tile = blockIdx.x == gridDim.x - 1;
-    u64 masks[CH_ITEMS], zmasks[CH_ITEMS];
-    int cnt = 0, ku = -1;
-    int4 g_own = make_int4(0, 0, 0, 0);
+    int cnt = 0;
+    const TileInfo T = tile_info_of(B, blockIdx.x);
     if (wv == 4) {                                         // the look-back wavefront
         int p = -1, kp = 0;
         for (i64 hiw = CSV_ABL(9) ? 0 : tile0; hiw > 0 && p < 0;) {
             const i64 cb = hiw > 64 ? hiw - 64 : 0;
             int kseg;
-            u64 f = chain_flag_row64(B, cb, kseg);
+            u64 f = chain_flag_row64(B, cb, kseg, T);
             if (hiw - cb < 64) f &= (1ull << (hiw - cb)) - 1ull;
             if (f) { const int l = 63 - __clzll((long long)f); p = (int)cb + l; kp = __builtin_amdgcn_readlane(kseg, l); }
             hiw = cb;
         }
         if (lane_id() == 0) { s_prev[0] = p; s_prev[1] = kp; }
     } else {
-        cnt = wave_starts(B, tile0 + wv * (WAVE * CH_ITEMS), masks, zmasks, SR[wv], SKR[wv], ku);
-        if (ku >= 0) g_own = B.seg_gate[ku];
-        if (B.per_sig) {                                   // the flags, for k_chain_ids: lane r stores masks[r]
-            u64 pub = 0;
-#pragma unroll
-            for (int r = 0; r < CH_ITEMS; r++) if (lane_id() == r) pub = masks[r];
-            if (lane_id() < CH_ITEMS) B.ch_masks[((i64)blockIdx.x * 4 + wv) * CH_ITEMS + lane_id()] = pub;
-        }
+        u64 pub;
+        cnt = wave_starts(B, tile0 + wv * (WAVE * CH_ITEMS), T, SR[wv], SKR[wv], pub);
+        CC_EXIT(3, cnt + SR[wv][(cnt - 1) & 511] + SKR[wv][(cnt - 1) & 511]);
+        // the flags, for k_chain_ids: lane r stores the mask of row r
+        if (B.per_sig && lane_id() < CH_ITEMS) B.ch_masks[((i64)blockIdx.x * 4 + wv) * CH_ITEMS + lane_id()] = pub;
         if (lane_id() == 0) {
-            s_cnt[wv] = cnt; s_ku[wv] = ku;
+            s_cnt[wv] = cnt;
             // the sentinel w = W ends the last cluster: one more "start" in the last wavefront's region
             if (last_tile && wv == 3) SR[3][cnt] = (int)B.W | ((B.a[B.W - 1] == 0 && B.b[B.W - 1] == 0) ? (1 << 31) : 0);
         }
@@ -534,9 +552,10 @@ __global__ __launch_bounds__(320) void k_chain_count(DevBatch B)
     __syncthreads();
     if (wv < 4) {
         TileSeg ts;
-        tile_seg(s_ku, ku, g_own, ts);
+        ts.uni = T.k0 == T.k1; ts.k = T.k0; ts.rc = T.rc; ts.drop = T.drop; ts.type = T.type;
         const int2 ob = open_before(SR, SKR, s_cnt, wv, make_int2(s_prev[0], s_prev[1]));
         const int nc = cnt + ((last_tile && wv == 3) ? 1 : 0);   // clusters that end at this wavefront's starts
+        CC_EXIT(4, nc + ob.x + ob.y);
         // The size gate is evaluated HERE only: the clusters that pass (a few per cent) leave a record in the wavefront's
         // own item region, in order, and k_chain_apply is a plain compaction of those records (it used to rebuild the start
         // lists from the masks and evaluate every gate a second time: 16 us of a 100 us step).
@@ -562,6 +581,7 @@ __global__ __launch_bounds__(320) void k_chain_count(DevBatch B)
             if (fl & 1) B.wave_items[gw * WI_STRIDE + n_sel + __popcll(m_sel & lanemask_lt())] = make_int4(s0c, mc, kt, i - 1);
             n_sel += __popcll(m_sel); n_big += __popcll(__ballot(fl & 2)); n_tiny += __popcll(__ballot(fl & 4));
         }
+        CC_EXIT(5, n_sel + n_big + n_tiny);
         if (lane_id() == 0) { s_v[wv] = (i64)n_sel | ((i64)n_big << 32); s_t[wv] = n_tiny; B.wave_cnt[gw] = make_int4(cnt, n_sel, n_big, n_tiny); }
     }
     __syncthreads();
@@ -1788,7 +1808,12 @@ template <int SW> __device__ __forceinline__ int indel_unit(const DevBatch& B, c
     return wide;
 }
 
-__global__ __launch_bounds__(256, CSV_IW_WAVES) void k_refine_indel_wave(DevBatch B)
+#ifdef CSV_IW_SGPR
+#define CSV_IW_ATTR __attribute__((amdgpu_num_sgpr(CSV_IW_SGPR)))
+#else
+#define CSV_IW_ATTR
+#endif
+__global__ __launch_bounds__(256, CSV_IW_WAVES) CSV_IW_ATTR void k_refine_indel_wave(DevBatch B)
 {
     const int ntiny = B.cnt->n_items_tiny, nsmall = B.cnt->n_items - B.cnt->n_items_big - ntiny;
     const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * 256 + threadIdx.x) >> 6), nwaves = (gridDim.x * 256) >> 6;
@@ -1818,66 +1843,66 @@ __global__ __launch_bounds__(256, CSV_IW_WAVES) void k_refine_indel_wave(DevBatc
 }
 
 // ------------------------------------------------------------------------------------ order
-// exclusive prefix of the packed (calls, supports) counts at the granularity k_emit needs: one value per
-// tile of EM_TILE = 8 items (k_emit finishes the prefix inside its wavefront).  One workgroup of IS_NW
-// wavefronts; a wavefront takes IS_CH chunks of 512 items: coalesced row loads, an LDS transpose so that
-// lane t owns tile t of the chunk, one wave scan per chunk.  4096 tiles = 32768 items per sweep.
-constexpr int IS_CH = 4;                             // chunks of 512 items per wavefront and sweep
-constexpr int IS_NW = 16;                            // wavefronts (one workgroup: the scan is a latency chain, so it is spread thin)
+// exclusive prefix of the packed (calls, supports) counts, in two levels: k_items_scan leaves, per tile of
+// EM_TILE = 8 items, the prefix INSIDE its chunk of IS_CHUNK items plus one total per chunk; k_emit adds the totals
+// of the earlier chunks (a few dozen L2-resident words, one wave reduction) and finishes the prefix inside its
+// wavefront.  One workgroup per chunk; a wavefront takes IS_CH pieces of 512 items: coalesced row loads, an LDS
+// transpose so that lane t owns tile t of the piece, one wave scan per piece.  (One workgroup sweeping the whole
+// list - the first version - was a 6 us latency chain through a single CU.)
+constexpr int IS_CH = 2;                             // pieces of 512 items per wavefront
+constexpr int IS_NW = 4;                             // wavefronts per workgroup
+constexpr int IS_CHUNK = IS_NW * IS_CH * 512;        // items per workgroup (4096)
 __global__ __launch_bounds__(64 * IS_NW) void k_items_scan(DevBatch B)
 {
     const int n = B.cnt->n_items;
     const int ntiles = (n + EM_TILE - 1) / EM_TILE;
     const int wv = threadIdx.x >> 6, lane = lane_id();
+    const int base = blockIdx.x * (IS_CHUNK / EM_TILE);     // first tile of the chunk
+    if (base >= ntiles) return;
     __shared__ i64 buf[IS_NW][64 * 9];                      // [tile][8 items], rows padded to 9
     __shared__ i64 wsum[IS_NW];
-    __shared__ i64 carry_s;
-    if (threadIdx.x == 0) carry_s = 0;
+    i64 ts[IS_CH];
+#pragma unroll
+    for (int c = 0; c < IS_CH; c++) {
+        const int tile0 = base + (wv * IS_CH + c) * 64;
+        i64 v[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int i = tile0 * EM_TILE + r * 64 + lane;
+            v[r] = i < n ? B.item_cnt[i] : 0;
+        }
+#pragma unroll
+        for (int r = 0; r < 8; r++) buf[wv][(r * 8 + (lane >> 3)) * 9 + (lane & 7)] = v[r];
+        // buf[wv] belongs to this wavefront alone: its LDS operations execute in order, so a wave-level fence
+        // (no instruction, just no reordering by the compiler) is all the transpose needs
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        i64 t = 0;
+#pragma unroll
+        for (int e = 0; e < 8; e++) t += buf[wv][lane * 9 + e];
+        ts[c] = t;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    i64 inc[IS_CH]; i64 tot = 0;
+#pragma unroll
+    for (int c = 0; c < IS_CH; c++) { inc[c] = wave_incl_scan_i64(ts[c]); tot += lane63_i64(inc[c]); }
+    if (lane == 0) wsum[wv] = tot;
     __syncthreads();
-    for (int base = 0; base < ntiles; base += IS_NW * IS_CH * 64) {
-        i64 ts[IS_CH];
+    i64 run = 0;
+    for (int k = 0; k < wv; k++) run += wsum[k];
 #pragma unroll
-        for (int c = 0; c < IS_CH; c++) {
-            const int tile0 = base + (wv * IS_CH + c) * 64;
-            i64 v[8];
-#pragma unroll
-            for (int r = 0; r < 8; r++) {
-                const int i = tile0 * EM_TILE + r * 64 + lane;
-                v[r] = i < n ? B.item_cnt[i] : 0;
-            }
-#pragma unroll
-            for (int r = 0; r < 8; r++) buf[wv][(r * 8 + (lane >> 3)) * 9 + (lane & 7)] = v[r];
-            // buf[wv] belongs to this wavefront alone: its LDS operations execute in order, so a wave-level fence
-            // (no instruction, just no reordering by the compiler) is all the transpose needs
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            i64 t = 0;
-#pragma unroll
-            for (int e = 0; e < 8; e++) t += buf[wv][lane * 9 + e];
-            ts[c] = t;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        }
-        i64 inc[IS_CH]; i64 tot = 0;
-#pragma unroll
-        for (int c = 0; c < IS_CH; c++) { inc[c] = wave_incl_scan_i64(ts[c]); tot += lane63_i64(inc[c]); }
-        if (lane == 0) wsum[wv] = tot;
-        __syncthreads();
-        i64 run = carry_s;
-        for (int k = 0; k < wv; k++) run += wsum[k];
-#pragma unroll
-        for (int c = 0; c < IS_CH; c++) {
-            const int tile = base + (wv * IS_CH + c) * 64 + lane;
-            if (tile < ntiles) B.item_base[tile] = run + inc[c] - ts[c];
-            run += lane63_i64(inc[c]);
-        }
-        __syncthreads();
-        if (threadIdx.x == 64 * IS_NW - 1) carry_s = run;
-        __syncthreads();
+    for (int c = 0; c < IS_CH; c++) {
+        const int tile = base + (wv * IS_CH + c) * 64 + lane;
+        if (tile < ntiles) B.item_base[tile] = run + inc[c] - ts[c];
+        run += lane63_i64(inc[c]);
     }
-    if (threadIdx.x == 0) {
-        const i64 t = carry_s;
-        const int nc = (int)(t >> 32); const i64 ns = t & 0xffffffffll;
-        B.cnt->n_calls = nc; B.cnt->n_support = ns;
-    }
+    if (threadIdx.x == 64 * IS_NW - 1) B.item_chunk[blockIdx.x] = run;
+}
+// packed (calls, supports) of the chunks before chunk c (every lane gets the sum)
+__device__ __forceinline__ i64 chunks_before(const DevBatch& B, int c)
+{
+    i64 v = 0;
+    for (int i = lane_id(); i < c; i += 64) v += B.item_chunk[i];
+    return wave_sum_i64(v);
 }
 
 // one call record: six 16-byte stores to consecutive addresses
@@ -1955,9 +1980,13 @@ __global__ __launch_bounds__(256) void k_emit(DevBatch B)
         const int nslots_raw = act ? B.item_nslots[j] : 0;
         int4 rec = make_int4(0, 0, 0, 0);
         if (act) rec = B.item_rec[j];
-        const i64 tile_base = B.item_base[tile];
+        const i64 tile_base = B.item_base[tile] + chunks_before(B, tile / (IS_CHUNK / EM_TILE));
         const i64 ginc = wave_incl_scan_i64(l8 == 0 ? cnt : 0);      // prefix over the tile's 8 items (one lane per group contributes)
         const i64 base = tile_base + ginc - cnt;
+        if (tile == ntiles - 1 && lane == 63) {             // the last tile closes the prefix: totals of the batch
+            const i64 t = tile_base + ginc;
+            B.cnt->n_calls = (int)(t >> 32); B.cnt->n_support = t & 0xffffffffll;
+        }
         const int nslots = cnt ? nslots_raw : 0;
         if (__ballot(nslots > 8)) {                         // wave-uniform
             for (int q = 0; q < EM_TILE; q++) {

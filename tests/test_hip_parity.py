@@ -142,6 +142,19 @@ def test_deep_pileup_next_to_ordinary_loci(ctx):
     assert (got["seg_status"][:8] == 0).all()
 
 
+def test_deep_pileup_is_repeatable(ctx):
+    """the workgroup tier (clusters of thousands of signatures in global scratch) gives the same answer every time:
+    300 runs of the pile-up batch, call count and supports against the oracle (a missing barrier between the DUP slot
+    assignment and its readers once showed up as one extra call in ~1 % of runs)"""
+    pile = synth.small_mixed(seed=6, coverage=12000, n_sites=3, n_contigs=2, contig_len=40_000, n_noise=0, n_loci=0, dup_frac=0.02)
+    hb = pile.host_batch(pile.tasks(), Params(genotype=False, min_support=10, max_cluster_bias_DEL=200))
+    want = _oracle().cluster_batch(hb).trimmed()
+    for it in range(300):
+        got = ctx.cluster_batch(hb).trimmed()
+        assert len(got["bp1"]) == len(want["bp1"]), it
+        assert np.array_equal(got["support_off"], want["support_off"]) and np.array_equal(got["bp1"], want["bp1"]), it
+
+
 def test_key_range_is_a_per_segment_status(ctx):
     """a length outside [0, 2^42) silences its own cluster and flags its segment; every other call is untouched"""
     st = synth.small_mixed(seed=31, genotype=False)
