@@ -448,7 +448,7 @@ __device__ __forceinline__ int wave_starts(const DevBatch& B, i64 base, const Ti
             int v = (int)base + r * WAVE + lane_id();
             if (zm) v |= (int)((zm >> lane_id()) & 1) << 31;               // (wave-uniform test: the mask is almost always 0)
             SR[idx] = v;
-            SKR[idx] = kseg;
+            if (T.k0 != T.k1) SKR[idx] = kseg;                              // (a tile inside one segment never reads them)
         }
         off += __popcll(m);
         if (lane_id() == r) pb = m;
@@ -458,10 +458,10 @@ __device__ __forceinline__ int wave_starts(const DevBatch& B, i64 base, const Ti
 }
 // start (and segment) of the cluster that is still open where wavefront wv's span begins: the last entry of the
 // nearest earlier non-empty region, else the tile's look-back result
-__device__ __forceinline__ int2 open_before(const int (*SR)[CL_REG], const int (*SKR)[CL_REG], const int* s_cnt, int wv, int2 tile_prev)
+__device__ __forceinline__ int2 open_before(const int (*SR)[CL_REG], const int (*SKR)[CL_REG], const int* s_cnt, int wv, int2 tile_prev, const TileInfo& T)
 {
     for (int q = wv - 1; q >= 0; q--)
-        if (s_cnt[q] > 0) return make_int2(SR[q][s_cnt[q] - 1], SKR[q][s_cnt[q] - 1]);
+        if (s_cnt[q] > 0) return make_int2(SR[q][s_cnt[q] - 1], T.k0 == T.k1 ? T.k0 : SKR[q][s_cnt[q] - 1]);
     return tile_prev;
 }
 
@@ -501,20 +501,7 @@ __device__ __forceinline__ u64 chain_flag_row64(const DevBatch& B, i64 cb, int& 
     return __ballot(f);
 }
 
-#ifdef CSV_CC_SGPR
-#define CSV_CC_ATTR __attribute__((amdgpu_num_sgpr(CSV_CC_SGPR), amdgpu_num_vgpr(64)))
-#else
-#define CSV_CC_ATTR
-#endif
-#ifdef CSV_CC_EXIT              // timing experiments only: leave the kernel at stage n, keeping `val` alive
-#define CC_EXIT(n, val) if (CSV_CC_EXIT == (n)) { \
-    if (lane_id() == 0) B.wave_cnt[(i64)blockIdx.x * 4 + wv] = make_int4(cnt, 0, 0, 0); \
-    if (threadIdx.x == 0) { B.partial[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3] + ((val) == 0x7fedcba9); B.partial64[blockIdx.x] = 0; B.partial_t[blockIdx.x] = 0; } \
-    return; }
-#else
-#define CC_EXIT(n, val)
-#endif
-__global__ __launch_bounds__(320) CSV_CC_ATTR void k_chain_count(DevBatch B)
+__global__ __launch_bounds__(320) void k_chain_count(DevBatch B)
 {
     // first kernel of a run: nothing in this kernel reads the counters, every later kernel is stream-ordered behind it
     if (blockIdx.x == 0 && threadIdx.x < (int)(sizeof(DevCounters) / 4)) ((int*)B.cnt)[threadIdx.x] = 0;
@@ -540,7 +527,6 @@ __global__ __launch_bounds__(320) CSV_CC_ATTR void k_chain_count(DevBatch B)
     } else {
         u64 pub;
         cnt = wave_starts(B, tile0 + wv * (WAVE * CH_ITEMS), T, SR[wv], SKR[wv], pub);
-        CC_EXIT(3, cnt + SR[wv][(cnt - 1) & 511] + SKR[wv][(cnt - 1) & 511]);
         // the flags, for k_chain_ids: lane r stores the mask of row r
         if (B.per_sig && lane_id() < CH_ITEMS) B.ch_masks[((i64)blockIdx.x * 4 + wv) * CH_ITEMS + lane_id()] = pub;
         if (lane_id() == 0) {
@@ -553,9 +539,8 @@ __global__ __launch_bounds__(320) CSV_CC_ATTR void k_chain_count(DevBatch B)
     if (wv < 4) {
         TileSeg ts;
         ts.uni = T.k0 == T.k1; ts.k = T.k0; ts.rc = T.rc; ts.drop = T.drop; ts.type = T.type;
-        const int2 ob = open_before(SR, SKR, s_cnt, wv, make_int2(s_prev[0], s_prev[1]));
+        const int2 ob = open_before(SR, SKR, s_cnt, wv, make_int2(s_prev[0], s_prev[1]), T);
         const int nc = cnt + ((last_tile && wv == 3) ? 1 : 0);   // clusters that end at this wavefront's starts
-        CC_EXIT(4, nc + ob.x + ob.y);
         // The size gate is evaluated HERE only: the clusters that pass (a few per cent) leave a record in the wavefront's
         // own item region, in order, and k_chain_apply is a plain compaction of those records (it used to rebuild the start
         // lists from the masks and evaluate every gate a second time: 16 us of a 100 us step).
@@ -581,7 +566,6 @@ __global__ __launch_bounds__(320) CSV_CC_ATTR void k_chain_count(DevBatch B)
             if (fl & 1) B.wave_items[gw * WI_STRIDE + n_sel + __popcll(m_sel & lanemask_lt())] = make_int4(s0c, mc, kt, i - 1);
             n_sel += __popcll(m_sel); n_big += __popcll(__ballot(fl & 2)); n_tiny += __popcll(__ballot(fl & 4));
         }
-        CC_EXIT(5, n_sel + n_big + n_tiny);
         if (lane_id() == 0) { s_v[wv] = (i64)n_sel | ((i64)n_big << 32); s_t[wv] = n_tiny; B.wave_cnt[gw] = make_int4(cnt, n_sel, n_big, n_tiny); }
     }
     __syncthreads();
@@ -1808,12 +1792,7 @@ template <int SW> __device__ __forceinline__ int indel_unit(const DevBatch& B, c
     return wide;
 }
 
-#ifdef CSV_IW_SGPR
-#define CSV_IW_ATTR __attribute__((amdgpu_num_sgpr(CSV_IW_SGPR)))
-#else
-#define CSV_IW_ATTR
-#endif
-__global__ __launch_bounds__(256, CSV_IW_WAVES) CSV_IW_ATTR void k_refine_indel_wave(DevBatch B)
+__global__ __launch_bounds__(256, CSV_IW_WAVES) void k_refine_indel_wave(DevBatch B)
 {
     const int ntiny = B.cnt->n_items_tiny, nsmall = B.cnt->n_items - B.cnt->n_items_big - ntiny;
     const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * 256 + threadIdx.x) >> 6), nwaves = (gridDim.x * 256) >> 6;
