@@ -1507,7 +1507,7 @@ __device__ __forceinline__ void np_sum_allele2(double sq1, double sq2, int n, in
 template <int T, int N> struct RankSwz {
     static __device__ __forceinline__ void run(int key, int mmax, int& rank)
     {
-        if (T >= mmax) return;
+        if ((T & 3) == 0 && T >= mmax) return;             // (sub-lanes past the cluster hold the largest key: harmless, so the test runs every 4th step)
         rank += __builtin_amdgcn_ds_swizzle(key, (N == 16 ? 0x10 : 0) | (T << 5)) < key;
         RankSwz<T + 1, N>::run(key, mmax, rank);
     }
@@ -1599,13 +1599,14 @@ template <int SW> __device__ __forceinline__ int indel_unit(const DevBatch& B, c
             int orv = in ? rid : 0;
             orv |= dpp_i32<0x111, 0xf>(0, orv); orv |= dpp_i32<0x112, 0xf>(0, orv); orv |= dpp_i32<0x114, 0xf>(0, orv);
             orv |= dpp_i32<0x118, 0xf>(0, orv); orv |= dpp_i32<0x142, 0xa>(0, orv); orv |= dpp_i32<0x143, 0xc>(0, orv);
-            int nbits = 32 - __builtin_clz((unsigned)__builtin_amdgcn_readlane(orv, 63) | 1u);
             // more than 12 id bits: compare a 12-bit fold instead.  Equal ids still always match; a false match only
-            // sends the wavefront through the exact loop below (probability ~m^2 / 8192 per cluster).
-            int hid = rid;
-            if (nbits > 12) { hid = (rid ^ (rid >> 12) ^ (rid >> 24)) & 0xfff; nbits = 12; }
+            // sends the wavefront through the exact loop below (probability ~m^2 / 8192 per cluster).  Always 12 steps,
+            // straight-line: a bit that no id has set costs one ballot and changes nothing.
+            const bool wide_ids = ((unsigned)__builtin_amdgcn_readlane(orv, 63) >> 12) != 0;
+            const int hid = wide_ids ? ((rid ^ (rid >> 12) ^ (rid >> 24)) & 0xfff) : rid;
             u64 match = inmask;
-            for (int bit = 0; bit < nbits; bit++) {
+#pragma unroll
+            for (int bit = 0; bit < 12; bit++) {
                 const bool set = (hid >> bit) & 1;
                 const u64 mk = __ballot(set);
                 match &= set ? mk : ~mk;
