@@ -8,6 +8,8 @@
 #include <string.h>
 
 #include <chrono>
+#include <map>
+#include <mutex>
 #include <string>
 #include <utility>
 #include <vector>
@@ -19,6 +21,41 @@
 using namespace csv;
 
 namespace {
+
+// Page-locked host ranges handed out (or registered) through this library, process wide: {base -> bytes, device address}.
+// csv_batch_download writes results straight into such memory from a kernel; a range leaves the table before it is freed,
+// so a table hit is always live memory (addresses pinned by other means are asked about through the HIP runtime each time).
+struct PinnedRange { size_t bytes; char* dev; };
+std::mutex g_pinned_mu;
+std::map<uintptr_t, PinnedRange> g_pinned;
+void pinned_note(void* p, size_t bytes)
+{
+    void* d = nullptr;
+    if (hipHostGetDevicePointer(&d, p, 0) != hipSuccess) { (void)hipGetLastError(); return; }
+    std::lock_guard<std::mutex> lk(g_pinned_mu);
+    g_pinned[(uintptr_t)p] = PinnedRange{bytes, (char*)d};
+}
+void pinned_forget(void* p)
+{
+    std::lock_guard<std::mutex> lk(g_pinned_mu);
+    g_pinned.erase((uintptr_t)p);
+}
+// device address of host pointer p (with `bytes` behind it) if it is page-locked, else nullptr
+void* pinned_device_address(const void* p, size_t bytes)
+{
+    {
+        std::lock_guard<std::mutex> lk(g_pinned_mu);
+        auto it = g_pinned.upper_bound((uintptr_t)p);
+        if (it != g_pinned.begin()) {
+            --it;
+            const uintptr_t off = (uintptr_t)p - it->first;
+            if (off < it->second.bytes) return off + bytes <= it->second.bytes ? it->second.dev + off : nullptr;
+        }
+    }
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return (at.type == hipMemoryTypeHost) ? at.devicePointer : nullptr;
+}
 
 struct Buf {                      // a slice of an arena (or, for the few stand-alone buffers, its own allocation)
     void*  p = nullptr;
@@ -217,17 +254,21 @@ int csv_host_alloc(int64_t bytes, void** out)
     if (!out || bytes < 0) return CSV_E_INVALID;
     *out = nullptr;
     void* p = nullptr;
-    if (hipHostMalloc(&p, (size_t)(bytes > 0 ? bytes : 1), hipHostMallocPortable) != hipSuccess) return CSV_E_NOMEM;
+    const size_t n = (size_t)(bytes > 0 ? bytes : 1);
+    if (hipHostMalloc(&p, n, hipHostMallocPortable) != hipSuccess) return CSV_E_NOMEM;
+    pinned_note(p, n);
     *out = p;
     return CSV_OK;
 }
-void csv_host_free(void* p) { if (p) (void)hipHostFree(p); }
+void csv_host_free(void* p) { if (p) { pinned_forget(p); (void)hipHostFree(p); } }
 int csv_host_register(void* p, int64_t bytes)
 {
     if (!p || bytes <= 0) return CSV_E_INVALID;
-    return hipHostRegister(p, (size_t)bytes, hipHostRegisterPortable) == hipSuccess ? CSV_OK : CSV_E_HIP;
+    if (hipHostRegister(p, (size_t)bytes, hipHostRegisterPortable) != hipSuccess) return CSV_E_HIP;
+    pinned_note(p, (size_t)bytes);
+    return CSV_OK;
 }
-int csv_host_unregister(void* p) { return (p && hipHostUnregister(p) == hipSuccess) ? CSV_OK : CSV_E_HIP; }
+int csv_host_unregister(void* p) { if (p) pinned_forget(p); return (p && hipHostUnregister(p) == hipSuccess) ? CSV_OK : CSV_E_HIP; }
 
 int csv_ctx_create(int device_id, csv_ctx** out)
 {
@@ -841,13 +882,67 @@ int csv_batch_validate(csv_ctx* c)
 // Device -> host: the counters, then ONE copy of the call records and one of the support lists into the page-locked
 // block, unpacked into the caller's arrays on the host (a few MB; the per-signature outputs only when they were asked
 // for at upload).
+// Are all of the caller's call arrays page-locked (device addressable)?  Then fill `P` with their device addresses.
+bool publish_targets(csv_ctx* c, const csv_batch_out* out, PublishArgs& P)
+{
+    (void)c;
+    if (getenv("CSV_NO_PUBLISH") || out->cap_calls < 0 || out->cap_support < 0) return false;
+    const size_t nc = (size_t)out->cap_calls, ns = (size_t)out->cap_support;
+    const void* host[15] = {out->call_seg, out->call_cluster, out->call_aux, out->support, out->cipos, out->cilen, out->dr, out->dv, out->gl_idx,
+                            out->bp1, out->bp2, out->search_pos, out->seq_pick, out->support_off, out->support_sig};
+    const size_t bytes[15] = {nc * 4, nc * 4, nc * 4, nc * 4, nc * 4, nc * 4, nc * 4, nc * 4, nc * 4, nc * 8, nc * 8, nc * 8, nc * 8, (nc + 1) * 8, ns * 8};
+    void* dev[15];
+    for (int i = 0; i < 15; i++) {
+        if (!host[i]) return false;
+        dev[i] = pinned_device_address(host[i], bytes[i]);
+        if (!dev[i]) return false;
+    }
+    P.call_seg = (int*)dev[0]; P.call_cluster = (int*)dev[1]; P.call_aux = (int*)dev[2]; P.support = (int*)dev[3]; P.cipos = (int*)dev[4];
+    P.cilen = (int*)dev[5]; P.dr = (int*)dev[6]; P.dv = (int*)dev[7]; P.gl_idx = (int*)dev[8];
+    P.bp1 = (i64*)dev[9]; P.bp2 = (i64*)dev[10]; P.search_pos = (i64*)dev[11]; P.seq_pick = (i64*)dev[12]; P.support_off = (i64*)dev[13];
+    P.support_sig = (i64*)dev[14];
+    return true;
+}
+
 int csv_batch_download(csv_ctx* c, csv_batch_out* out)
 {
     if (!c || !out) return CSV_E_INVALID;
     if (!c->ran) return fail(c, CSV_E_STATE, "csv_batch_download before csv_batch_run");
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t st = c->stream;
-    { const int rc = read_counters(c); if (rc) return rc; }
+    const int S0 = (int)c->h_seg.size();
+    PublishArgs P{};
+    bool published = false;
+    if (publish_targets(c, out, P)) {
+        // page-locked result arrays: k_publish writes everything in place; the download is one synchronisation
+        const size_t o_cnt = 0, o_err = 256, need = o_err + (size_t)(S0 + 1) * 4;
+        static_assert(sizeof(DevCounters) <= 256, "counters landing zone");
+        if (need > c->h_pin_cap) { HIP_TRY(c, hipStreamSynchronize(st)); const int rc = pin_reserve(c, need); if (rc) return rc; }
+        void* dpin = nullptr;
+        HIP_TRY(c, hipHostGetDevicePointer(&dpin, c->h_pin, 0));
+        P.cap_calls = out->cap_calls; P.cap_support = out->cap_support; P.n_seg = S0;
+        P.h_cnt = (DevCounters*)((char*)dpin + o_cnt); P.h_seg_err = (int*)((char*)dpin + o_err);
+        for (int attempt = 0; attempt < 2; attempt++) {
+            hipLaunchKernelGGL(k_publish, dim3(512), dim3(256), 0, st, c->B, P);
+            HIP_TRY(c, hipStreamSynchronize(st));
+            memcpy(&c->h_cnt, c->h_pin + o_cnt, sizeof(DevCounters));
+            if (getenv("CSV_DEBUG") || getenv("CSV_DEBUG_COUNTERS"))
+                fprintf(stderr, "[csv] counters (published): clusters %d items %d calls %d error %d | reads: mode %d runs %d state %d\n",
+                        c->h_cnt.n_clusters, c->h_cnt.n_items, c->h_cnt.n_calls, c->h_cnt.error, c->B.ro_mode, c->h_cnt.n_runs, c->h_cnt.ro_state);
+            if (c->B.ro_mode == 1 && c->B.n_reads > 0 && c->any_genotype && c->h_cnt.ro_state == RO_NEED_GENERAL && attempt == 0) {
+                c->reads_general = true;             // (as read_counters does: the batch again, through the general sort)
+                c->B.ro_mode = 2;
+                const int rc = run_impl(c, nullptr);
+                if (rc) return rc;
+                continue;
+            }
+            break;
+        }
+        published = true;
+    } else {
+        const int rc = read_counters(c);
+        if (rc) return rc;
+    }
     const DevCounters& k = c->h_cnt;
     out->n_calls = k.n_calls; out->n_support = k.n_support; out->n_clusters = k.n_clusters;
     if (k.error & ERR_READS_UNSORTED) return fail(c, CSV_E_UNSORTED, "a reads block is not sorted by start although CSV_IN_READS_SORTED was set");
@@ -863,13 +958,15 @@ int csv_batch_download(csv_ctx* c, csv_batch_out* out)
     const size_t nc = (size_t)k.n_calls, ns = (size_t)k.n_support;
     const DevBatch& B = c->B;
     const int S = (int)c->h_seg.size();
-    const size_t o_rec = 256, o_err = o_rec + ((nc * sizeof(CallRec) + 255) & ~(size_t)255), o_end = o_err + (size_t)(S + 1) * 4;
+    const size_t o_rec = 256, o_err = published ? 256 : o_rec + ((nc * sizeof(CallRec) + 255) & ~(size_t)255), o_end = o_err + (size_t)(S + 1) * 4;
+    if (!published) {
     if (o_end > c->h_pin_cap) { const int rc = pin_reserve(c, o_end); if (rc) return rc; }
     // the call records first: they are unpacked on the host while the (larger) support list is still on its way
     if (nc) HIP_TRY(c, hipMemcpyAsync(c->h_pin + o_rec, B.o_rec, nc * sizeof(CallRec), hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipEventRecord(c->ev_sel, st));
     if (ns) HIP_TRY(c, hipMemcpyAsync(out->support_sig, B.o_supsig, ns * 8, hipMemcpyDeviceToHost, st));    // (already in its final layout)
     if (S) HIP_TRY(c, hipMemcpyAsync(c->h_pin + o_err, B.seg_err, (size_t)S * 4, hipMemcpyDeviceToHost, st));
+    }
     if (out->cluster_id) memset(out->cluster_id, 0xff, (size_t)c->n_sig_host * 4);
     if (out->allele_id) memset(out->allele_id, 0xff, (size_t)c->n_sig_host * 4);
     if (out->cluster_id || out->allele_id) {
@@ -882,17 +979,19 @@ int csv_batch_download(csv_ctx* c, csv_batch_out* out)
             s = e + 1;
         }
     }
-    HIP_TRY(c, hipEventSynchronize(c->ev_sel));
-    const CallRec* r = (const CallRec*)(c->h_pin + o_rec);
-    for (size_t i = 0; i < nc; i++) {
-        const CallRec& x = r[i];
-        out->call_seg[i] = x.seg; out->call_cluster[i] = x.cluster; out->call_aux[i] = x.aux;
-        out->bp1[i] = x.bp1; out->bp2[i] = x.bp2; out->support[i] = x.support; out->cipos[i] = x.cipos; out->cilen[i] = x.cilen;
-        out->search_pos[i] = x.search; out->seq_pick[i] = x.pick; out->dr[i] = x.dr; out->dv[i] = x.dv; out->gl_idx[i] = x.gl;
-        out->support_off[i] = x.supoff;
+    if (!published) {
+        HIP_TRY(c, hipEventSynchronize(c->ev_sel));
+        const CallRec* r = (const CallRec*)(c->h_pin + o_rec);
+        for (size_t i = 0; i < nc; i++) {
+            const CallRec& x = r[i];
+            out->call_seg[i] = x.seg; out->call_cluster[i] = x.cluster; out->call_aux[i] = x.aux;
+            out->bp1[i] = x.bp1; out->bp2[i] = x.bp2; out->support[i] = x.support; out->cipos[i] = x.cipos; out->cilen[i] = x.cilen;
+            out->search_pos[i] = x.search; out->seq_pick[i] = x.pick; out->dr[i] = x.dr; out->dv[i] = x.dv; out->gl_idx[i] = x.gl;
+            out->support_off[i] = x.supoff;
+        }
+        if (out->support_off) out->support_off[nc] = (int64_t)ns;
     }
-    if (out->support_off) out->support_off[nc] = (int64_t)ns;
-    HIP_TRY(c, hipStreamSynchronize(st));
+    if (!published || out->cluster_id || out->allele_id) HIP_TRY(c, hipStreamSynchronize(st));
     if (out->seg_status && S) memcpy(out->seg_status, c->h_pin + o_err, (size_t)S * 4);
     return CSV_OK;
 }

@@ -2029,6 +2029,40 @@ __global__ __launch_bounds__(256) void k_emit(DevBatch B)
     }
 }
 
+// ------------------------------------------------------------------------------------ publish
+// The results straight into the caller's arrays, when those live in page-locked host memory (csv_host_alloc /
+// csv_host_register): the device knows the counts, so one kernel writes the calls in their final structure-of-arrays
+// layout, the support list, the segment status words and the counters across the link, and the host's whole download
+// is one stream synchronisation - no counter round trip before the copies can be sized, no staging copy, no unpack
+// loop.  Nothing is written when the caller's capacities are too small (the counters still are: CSV_E_CAPACITY).
+struct PublishArgs {
+    i64 cap_calls, cap_support;
+    DevCounters* h_cnt;      // page-locked landing zone of the counters
+    int* h_seg_err;          // n_seg words (staging block)
+    int n_seg;
+    int *call_seg, *call_cluster, *call_aux, *support, *cipos, *cilen, *dr, *dv, *gl_idx;
+    i64 *bp1, *bp2, *search_pos, *seq_pick, *support_off, *support_sig;
+};
+__global__ __launch_bounds__(256) void k_publish(DevBatch B, PublishArgs P)
+{
+    const i64 tid = (i64)blockIdx.x * 256 + threadIdx.x, nth = (i64)gridDim.x * 256;
+    const i64 nc = B.cnt->n_calls, ns = B.cnt->n_support;
+    if (tid < (i64)(sizeof(DevCounters) / 4)) ((int*)P.h_cnt)[tid] = ((const int*)B.cnt)[tid];
+    for (i64 k = tid; k < P.n_seg; k += nth) P.h_seg_err[k] = B.seg_err[k];
+    if (nc > P.cap_calls || ns > P.cap_support) return;
+    for (i64 i = tid; i < nc; i += nth) {
+        const int4* r = (const int4*)&B.o_rec[i];
+        const int4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4];
+        P.bp1[i] = ((i64)r0.y << 32) | (unsigned)r0.x; P.bp2[i] = ((i64)r0.w << 32) | (unsigned)r0.z;
+        P.search_pos[i] = ((i64)r1.y << 32) | (unsigned)r1.x; P.seq_pick[i] = ((i64)r1.w << 32) | (unsigned)r1.z;
+        P.support_off[i] = ((i64)r2.y << 32) | (unsigned)r2.x; P.support[i] = r2.z; P.cipos[i] = r2.w;
+        P.cilen[i] = r3.x; P.call_seg[i] = r3.y; P.call_cluster[i] = r3.z; P.call_aux[i] = r3.w;
+        P.dr[i] = r4.x; P.dv[i] = r4.y; P.gl_idx[i] = r4.z;
+    }
+    if (tid == 0) P.support_off[nc] = ns;
+    for (i64 i = tid; i < ns; i += nth) P.support_sig[i] = B.o_supsig[i];
+}
+
 // ------------------------------------------------------------------------------------ reads: order
 // The reads block of a chromosome arrives in the order cuteSV's rebuild step leaves it (main script :810): the
 // concatenation of per-worker extraction batches, each batch being the reads that START inside one task region in BAM

@@ -234,6 +234,35 @@ def test_pinned_columns_and_native_rows(ctx):
     assert rows_mod._native().split(blob, n) == rows and n == len(rows) > 0
 
 
+@pytest.mark.parametrize("seed,genotype,order", [(3, False, "sorted"), (4, True, "sorted"), (5, True, "extraction"), (6, True, "shuffled")])
+def test_published_results_equal_copied_results(ctx, seed, genotype, order):
+    """result arrays in page-locked memory are filled in place by k_publish (one synchronisation, no staging copy, no
+    unpack loop); pageable ones through the copy path.  Same bytes either way, including the capacity retry, the per-
+    signature outputs and a reads table that sends the batch through the general sort."""
+    st = synth.small_mixed(seed=seed, genotype=genotype)
+    if genotype and order == "extraction":
+        st, _ = synth.extraction_order(st, seed=seed, region=20_000, workers=4)
+    elif genotype and order == "shuffled":
+        rng = np.random.default_rng(seed)
+        for c in range(len(st.reads_off) - 1):
+            lo, hi = int(st.reads_off[c]), int(st.reads_off[c + 1])
+            perm = lo + rng.permutation(hi - lo)
+            for name in ("r_start", "r_end", "r_primary", "r_id"):
+                col = getattr(st, name)
+                col[lo:hi] = col[perm].copy()
+    hb = st.host_batch(st.tasks(), Params.ont(genotype=genotype))
+    for per_sig in (False, True):
+        copied = ctx.cluster_batch(hb, per_sig=per_sig).trimmed()
+        ctx._res_cache = None
+        published = ctx.cluster_batch(hb, per_sig=per_sig, cap_calls=8, cap_support=8, reuse=True)      # (forces the capacity retry)
+        assert published.cap_calls >= len(copied["bp1"]) > 8
+        assert_soa_equal(published.trimmed(), copied)
+        again = ctx.cluster_batch(hb, per_sig=per_sig, reuse=True).trimmed()                            # the recycled arrays
+        assert_soa_equal(again, copied)
+    want = _oracle().cluster_batch(hb, per_sig=True).trimmed()
+    assert_soa_equal(again, want, st)
+
+
 def test_genotype_cover_overflow_pass(ctx):
     # ~1000x coverage: support + cover of a call exceeds the 4 KB hash set, so the second (32 KB) pass runs
     st = synth.small_mixed(seed=78, n_sites=6, coverage=1000, n_noise=100, n_loci=20, contig_len=200_000, n_contigs=2)
