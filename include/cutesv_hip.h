@@ -216,8 +216,11 @@ int csv_ctx_sync(csv_ctx* ctx);
  * 1 = whole sorted runs were moved (or nothing had to move), 2 = the general stable radix sort; -1 = no reads table. */
 int csv_batch_reads_mode(const csv_ctx* ctx);
 
-/* Page-locked host memory.  Columns that live in it (or in a registered caller buffer) travel to the GPU by DMA
- * straight from the caller's pages; anything else is staged by the HIP runtime at roughly half the PCIe rate.  No
+/* Page-locked host memory.  Columns that live in it (or in a registered caller buffer) are copied asynchronously, so the
+ * kernels start while the later columns are still on the link; RESULT arrays that live in it are filled in place by the
+ * device (csv_batch_download / csv_cluster_batch then cost one synchronisation: no staging copy, no host-side unpack) -
+ * all of bp1 ... support_sig must be page-locked for that, seg_status and the per-signature arrays may be anywhere.
+ * Memory from csv_host_alloc / csv_host_register must be released through csv_host_free / csv_host_unregister.  No
  * counterpart in the reference (its pool workers unpickle tuples, INDEL:52-58).  csv_host_alloc needs no context; the
  * memory is usable from every context of the process. */
 int  csv_host_alloc(int64_t bytes, void** out);

@@ -59,8 +59,8 @@ for it in range(n_it):
     hb = st.host_batch(tasks, p)
     try:
         want = oracle.cluster_batch(hb, per_sig=True).trimmed()
-        if rng.integers(0, 2):                            # the one-shot call ...
-            got = ctx.cluster_batch(hb, per_sig=True).trimmed()
+        if rng.integers(0, 2):                            # the one-shot call, results copied out or published in place ...
+            got = ctx.cluster_batch(hb, per_sig=True, reuse=bool(rng.integers(0, 2))).trimmed()
         else:                                             # ... or upload / run (twice: the tier peek, idempotence) / download
             ctx.upload(hb, per_sig=True)
             ctx.run(); ctx.run()
