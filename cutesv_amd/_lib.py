@@ -35,6 +35,7 @@ SYMBOLS = [
     ("csv_host_unregister", C.c_int, [C.c_void_p]),
     ("csv_rows_emit", C.c_int, None),          # prototype set in cutesv_amd/rows.py (needs its struct)
     ("csv_cigar_signatures", C.c_int, None),   # prototype set in cutesv_amd/extract.py
+    ("csv_split_signatures", C.c_int, None),   # prototype set in cutesv_amd/extract.py
     ("csv_rebuild_signatures", C.c_int, None),  # prototype set in cutesv_amd/rebuild.py
     ("csv_vcf_emit", C.c_int, None),           # prototype set in cutesv_amd/vcf.py (needs its struct)
 ]

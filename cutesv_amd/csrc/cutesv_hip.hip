@@ -17,6 +17,7 @@
 #include "kernels.hip.h"
 #include "sort.hip.h"
 #include "cigar.hip.h"
+#include "split.hip.h"
 
 using namespace csv;
 
@@ -115,6 +116,8 @@ struct csv_ctx {
     Buf rb_seg, rb_a, rb_b, rb_rid, rb_aux, rb_auxk, rb_major, rb_nodedup, rb_perm0, rb_perm1, rb_hist, rb_tot, rb_partial;
     Buf rb_oseg, rb_oa, rb_ob, rb_orid, rb_oaux, rb_osrc;
     // CIGAR scan (slices of `arena_rb` as well: the two steps never overlap)
+    Buf sp_off, sp_len, sp_c0, sp_c1, sp_f0, sp_f1, sp_chr, sp_mapq, sp_strand, sp_primary, sp_seg, sp_cnt, sp_tiles, sp_tot,
+        sp_kind, sp_read, sp_ochr, sp_aux, sp_a, sp_b, sp_c, sp_d;
     Buf cg_off, cg_ops, cg_start, cg_use, cg_cnt, cg_tiles, cg_tot, cg_iread, cg_ipos, cg_ilen, cg_ip0, cg_inp, cg_pq, cg_pl, cg_dread, cg_dpos, cg_dlen;
     // page-locked host staging: small tables on the way in, counters + call records + support lists on the way out
     char*  h_pin = nullptr;
@@ -222,6 +225,8 @@ int csv_struct_size(int which)
     case 7: return (int)sizeof(csv_rows_in);
     case 8: return (int)sizeof(csv_cigar_in);
     case 9: return (int)sizeof(csv_cigar_out);
+    case 10: return (int)sizeof(csv_split_in);
+    case 11: return (int)sizeof(csv_split_out);
     default: return -1;
     }
 }
@@ -1154,6 +1159,80 @@ int csv_cigar_signatures(csv_ctx* c, const csv_cigar_in* in, csv_cigar_out* out)
     D2H(out->del_read, cg_dread, tot[2] * 4); D2H(out->del_pos, cg_dpos, tot[2] * 8); D2H(out->del_len, cg_dlen, tot[2] * 8);
 #undef D2H
     HIP_TRY(c, hipStreamSynchronize(st));
+    HIP_TRY(c, hipEventElapsedTime(&ms2, c->ev[2], c->ev[3]));
+    out->ms_device = ms1 + ms2;
+    return CSV_OK;
+}
+
+int csv_split_signatures(csv_ctx* c, const csv_split_in* in, csv_split_out* out)
+{
+    if (!c || !in || !out) return CSV_E_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    out->n = 0; out->ms_device = 0;
+    const i64 n = in->n_reads;
+    if (n < 0 || (n > 0 && (!in->ent_off || !in->read_len))) return fail(c, CSV_E_INVALID, "bad split-read batch header");
+    if (n == 0) return CSV_OK;
+    const i64 ne = in->ent_off[n] - in->ent_off[0];
+    if (in->ent_off[0] != 0 || ne < 0) return fail(c, CSV_E_INVALID, "ent_off must start at 0 and not decrease");
+    if (ne > 0 && (!in->c0 || !in->c1 || !in->f0 || !in->f1 || !in->chr || !in->mapq || !in->strand || !in->primary))
+        return fail(c, CSV_E_INVALID, "split-read entry columns missing");
+    if (ne >= (1ll << 31) - 4096 || n >= (1ll << 31) - 4096) return fail(c, CSV_E_INVALID, "split-read batch too large: split it");
+    for (i64 r = 0; r < n; r++)
+        if (in->ent_off[r + 1] < in->ent_off[r]) return fail(c, CSV_E_INVALID, "ent_off decreases at read %lld", (long long)r);
+    const int ntile = div_up(n, CG_TILE);
+    const i64 cap = out->cap < 0 ? 0 : out->cap;
+    Plan P;
+#define PL(buf, bytes) P.add(c->buf, (size_t)(bytes))
+    PL(sp_off, (n + 1) * 8); PL(sp_len, n * 8); PL(sp_c0, (ne + 1) * 8); PL(sp_c1, (ne + 1) * 8); PL(sp_f0, (ne + 1) * 8); PL(sp_f1, (ne + 1) * 8);
+    PL(sp_chr, (ne + 1) * 4); PL(sp_mapq, (ne + 1) * 4); PL(sp_strand, ne + 1); PL(sp_primary, ne + 1); PL(sp_seg, (ne + 1) * sizeof(SpSeg));
+    PL(sp_cnt, n * 16); PL(sp_tiles, (size_t)ntile * 24); PL(sp_tot, 32);
+    PL(sp_kind, cap + 1); PL(sp_read, (cap + 1) * 4); PL(sp_ochr, (cap + 1) * 4); PL(sp_aux, (cap + 1) * 4);
+    PL(sp_a, (cap + 1) * 8); PL(sp_b, (cap + 1) * 8); PL(sp_c, (cap + 1) * 8); PL(sp_d, (cap + 1) * 8);
+#undef PL
+    {
+        if (P.total > c->arena_rb.cap) HIP_TRY(c, hipDeviceSynchronize());
+        const int rc = commit(c, c->arena_rb, P);
+        if (rc) return rc;
+    }
+    hipStream_t st = c->stream;
+#define H2D(buf, src, bytes) do { if ((bytes) > 0) HIP_TRY(c, hipMemcpyAsync(c->buf.p, (src), (size_t)(bytes), hipMemcpyHostToDevice, st)); } while (0)
+    H2D(sp_off, in->ent_off, (n + 1) * 8); H2D(sp_len, in->read_len, n * 8);
+    H2D(sp_c0, in->c0, ne * 8); H2D(sp_c1, in->c1, ne * 8); H2D(sp_f0, in->f0, ne * 8); H2D(sp_f1, in->f1, ne * 8);
+    H2D(sp_chr, in->chr, ne * 4); H2D(sp_mapq, in->mapq, ne * 4); H2D(sp_strand, in->strand, ne); H2D(sp_primary, in->primary, ne);
+#undef H2D
+    SplitArgs A{};
+    A.n_reads = n; A.ent_off = dp<i64>(c->sp_off); A.read_len = dp<i64>(c->sp_len);
+    A.c0 = dp<i64>(c->sp_c0); A.c1 = dp<i64>(c->sp_c1); A.f0 = dp<i64>(c->sp_f0); A.f1 = dp<i64>(c->sp_f1);
+    A.chr = dp<int>(c->sp_chr); A.mapq = dp<int>(c->sp_mapq); A.strand = dp<uint8_t>(c->sp_strand); A.primary = dp<uint8_t>(c->sp_primary);
+    A.sv = in->sv_size; A.max_size = in->max_size; A.min_mapq = in->min_mapq; A.parts = in->max_split_parts;
+    A.seg = dp<SpSeg>(c->sp_seg); A.cnt = dp<int4>(c->sp_cnt); A.cap = cap;
+    A.kind = dp<uint8_t>(c->sp_kind); A.read = dp<int>(c->sp_read); A.o_chr = dp<int>(c->sp_ochr); A.aux = dp<int>(c->sp_aux);
+    A.a = dp<i64>(c->sp_a); A.b = dp<i64>(c->sp_b); A.c = dp<i64>(c->sp_c); A.d = dp<i64>(c->sp_d);
+    CigarArgs SC{};                                         // the per-read prefix is the CIGAR scan's (k_cigar_tiles / k_cigar_offsets)
+    SC.n_reads = n; SC.cnt = A.cnt; SC.tile_sum = dp<i64>(c->sp_tiles); SC.totals = dp<i64>(c->sp_tot);
+    const int grid = div_up(n, 256);
+    HIP_TRY(c, hipEventRecord(c->ev[0], st));
+    hipLaunchKernelGGL(k_split_count, dim3(grid), dim3(256), 0, st, A);
+    hipLaunchKernelGGL(k_cigar_tiles, dim3(ntile), dim3(256), 0, st, SC);
+    hipLaunchKernelGGL(k_cigar_offsets, dim3(ntile), dim3(256), 0, st, SC);
+    HIP_TRY(c, hipEventRecord(c->ev[1], st));
+    HIP_TRY(c, hipGetLastError());
+    i64 tot[3] = {0, 0, 0};
+    HIP_TRY(c, hipMemcpyAsync(tot, c->sp_tot.p, 24, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    out->n = tot[0];
+    if (tot[0] > out->cap) return fail(c, CSV_E_CAPACITY, "need %lld candidates", (long long)tot[0]);
+    HIP_TRY(c, hipEventRecord(c->ev[2], st));
+    hipLaunchKernelGGL(k_split_emit, dim3(grid), dim3(256), 0, st, A);
+    HIP_TRY(c, hipEventRecord(c->ev[3], st));
+    HIP_TRY(c, hipGetLastError());
+#define D2H(dst, buf, bytes) do { if ((bytes) > 0) HIP_TRY(c, hipMemcpyAsync((dst), c->buf.p, (size_t)(bytes), hipMemcpyDeviceToHost, st)); } while (0)
+    D2H(out->kind, sp_kind, tot[0]); D2H(out->read, sp_read, tot[0] * 4); D2H(out->chr, sp_ochr, tot[0] * 4); D2H(out->aux, sp_aux, tot[0] * 4);
+    D2H(out->a, sp_a, tot[0] * 8); D2H(out->b, sp_b, tot[0] * 8); D2H(out->c, sp_c, tot[0] * 8); D2H(out->d, sp_d, tot[0] * 8);
+#undef D2H
+    HIP_TRY(c, hipStreamSynchronize(st));
+    float ms1 = 0, ms2 = 0;
+    HIP_TRY(c, hipEventElapsedTime(&ms1, c->ev[0], c->ev[1]));
     HIP_TRY(c, hipEventElapsedTime(&ms2, c->ev[2], c->ev[3]));
     out->ms_device = ms1 + ms2;
     return CSV_OK;

@@ -91,3 +91,121 @@ def candidates(sig, read_names, query_sequences, chrom):
     for r, pos, ln in zip(sig["del_read"].tolist(), sig["del_pos"].tolist(), sig["del_len"].tolist()):
         dele.append((pos, ln, read_names[r], "DEL", chrom))
     return ins, dele
+
+
+# ------------------------------------------------------------------------------------ split reads (SA tag)
+class SplitIn(C.Structure):
+    _fields_ = [("n_reads", C.c_int64), ("ent_off", C.c_void_p), ("read_len", C.c_void_p), ("c0", C.c_void_p), ("c1", C.c_void_p),
+                ("f0", C.c_void_p), ("f1", C.c_void_p), ("chr", C.c_void_p), ("mapq", C.c_void_p), ("strand", C.c_void_p), ("primary", C.c_void_p),
+                ("sv_size", C.c_int64), ("max_size", C.c_int64), ("min_mapq", C.c_int32), ("max_split_parts", C.c_int32)]
+
+
+_SPLIT_OUT = [("kind", np.uint8), ("read", np.int32), ("chr", np.int32), ("aux", np.int32), ("a", np.int64), ("b", np.int64), ("c", np.int64), ("d", np.int64)]
+
+
+class SplitOut(C.Structure):
+    _fields_ = [("cap", C.c_int64), ("n", C.c_int64)] + [(n, C.c_void_p) for n, _ in _SPLIT_OUT] + [("ms_device", C.c_float), ("reserved", C.c_int32)]
+
+
+_CIGAR_RE = None
+
+
+def clip_and_span(cigar_string):
+    """acquire_clip_pos (main script :466-481) on the CIGAR text of an SA entry: [leading soft clip, trailing soft clip,
+    reference span over M / D / = / X]"""
+    global _CIGAR_RE
+    if _CIGAR_RE is None:
+        import re
+        _CIGAR_RE = re.compile(r"(\d+)([MIDNSHP=XB])")
+    ops = _CIGAR_RE.findall(cigar_string)
+    first = int(ops[0][0]) if ops and ops[0][1] == "S" else 0
+    last = int(ops[-1][0]) if ops and ops[-1][1] == "S" else 0
+    return first, last, sum(int(n) for n, o in ops if o in "MD=X")
+
+
+def encode_split_reads(reads, chrom_rank):
+    """reads: [(primary_info or [], "chr,pos,strand,CIGAR,mapq,NM;..." SA tag value, query_length)] per read, as parse_read
+    (main script :657-679) hands them to organize_split_signal; chrom_rank: {name: rank in Python string order}.
+    -> dict of the flat csv_split_in arrays.  This is the text side of the step (the SA tag is a string): it stays here."""
+    ent_off = [0]
+    cols = {k: [] for k in ("c0", "c1", "f0", "f1", "chr", "mapq", "strand", "primary")}
+    read_len = []
+    for primary, sa, qlen in reads:
+        read_len.append(int(qlen))
+        if len(primary) > 0:
+            for k, v in zip(("c0", "c1", "f0", "f1"), primary[:4]):
+                cols[k].append(int(v))
+            cols["chr"].append(chrom_rank[primary[4]]); cols["strand"].append(0 if primary[5] == "+" else 1)
+            cols["mapq"].append(0); cols["primary"].append(1)
+        for entry in sa.split(";")[:-1]:                       # (:676)
+            seq = entry.split(",")
+            first, last, span = clip_and_span(seq[3])
+            cols["c0"].append(first); cols["c1"].append(last); cols["f0"].append(int(seq[1]) - 1); cols["f1"].append(span)      # (:497)
+            cols["chr"].append(chrom_rank[seq[0]]); cols["strand"].append(0 if seq[2] == "+" else 1)
+            cols["mapq"].append(int(seq[4])); cols["primary"].append(0)
+        ent_off.append(len(cols["c0"]))
+    dt = dict(c0=np.int64, c1=np.int64, f0=np.int64, f1=np.int64, chr=np.int32, mapq=np.int32, strand=np.uint8, primary=np.uint8)
+    out = {k: np.asarray(v, dt[k]) for k, v in cols.items()}
+    out["ent_off"] = np.asarray(ent_off, np.int64); out["read_len"] = np.asarray(read_len, np.int64)
+    return out
+
+
+def _run_split(fn, handle, enc, sv_size, min_mapq, max_split_parts, max_size, check):
+    a = {k: np.ascontiguousarray(v) for k, v in enc.items()}
+    n = len(a["read_len"])
+    ptr = lambda x: x.ctypes.data if len(x) else None                      # noqa: E731
+    sin = SplitIn(n_reads=n, ent_off=a["ent_off"].ctypes.data, read_len=ptr(a["read_len"]), c0=ptr(a["c0"]), c1=ptr(a["c1"]), f0=ptr(a["f0"]),
+                  f1=ptr(a["f1"]), chr=ptr(a["chr"]), mapq=ptr(a["mapq"]), strand=ptr(a["strand"]), primary=ptr(a["primary"]),
+                  sv_size=int(sv_size), max_size=int(max_size), min_mapq=int(min_mapq), max_split_parts=int(max_split_parts))
+    cap = max(16, 2 * n)
+    for _ in range(2):
+        arrs = {name: np.zeros(cap, dt) for name, dt in _SPLIT_OUT}
+        sout = SplitOut(cap=cap, **{k: v.ctypes.data for k, v in arrs.items()})
+        rc = fn(handle, C.byref(sin), C.byref(sout)) if handle is not None else fn(C.byref(sin), C.byref(sout))
+        if rc == _abi.E_CAPACITY:
+            cap = int(sout.n) + 1
+            continue
+        check(rc)
+        out = {name: arrs[name][:int(sout.n)] for name, _ in _SPLIT_OUT}
+        out["ms_device"] = float(sout.ms_device)
+        return out
+    raise RuntimeError("csv_split_signatures: capacity retry failed")
+
+
+def split_signatures(ctx, enc, sv_size=30, min_mapq=20, max_split_parts=7, max_size=100000):
+    """flat split-read entries of a batch of reads (encode_split_reads) -> dict of the candidate arrays of csv_split_out
+    (defaults: cuteSV_Description.py: --min_size 30, --min_mapq 20, --max_split_parts 7, --max_size 100000)"""
+    L = lib()
+    L.csv_split_signatures.restype = C.c_int
+    L.csv_split_signatures.argtypes = [C.c_void_p, C.POINTER(SplitIn), C.POINTER(SplitOut)]
+    return _run_split(L.csv_split_signatures, ctx._h, enc, sv_size, min_mapq, max_split_parts, max_size, ctx._check)
+
+
+_COMP = str.maketrans("ACGTNacgtn", "TGCANtgcan")
+
+
+def split_candidates(sig, read_names, queries, chrom_names):
+    """candidate arrays -> the reference's candidate tuples per SV type (main script :50-464), in the order of its five lists.
+    queries[r] = the query string parse_read passes for read r (already reverse-complemented for reverse-strand reads, :673);
+    the inserted sequences are cut out of it here."""
+    cand = {t: [] for t in ("DEL", "INS", "DUP", "INV", "TRA")}
+    rc_cache = {}
+    for kind, r, ch, aux, a, b, c, d in zip(sig["kind"].tolist(), sig["read"].tolist(), sig["chr"].tolist(), sig["aux"].tolist(),
+                                            sig["a"].tolist(), sig["b"].tolist(), sig["c"].tolist(), sig["d"].tolist()):
+        name, chrom = read_names[r], chrom_names[ch]
+        if kind == 0:
+            cand["DEL"].append((a, b, name, "DEL", chrom))
+        elif kind == 1:
+            q = queries[r]
+            if aux & 1:
+                if r not in rc_cache:
+                    rc_cache[r] = str(q).translate(_COMP)[::-1]
+                q = rc_cache[r]
+            cand["INS"].append((a / 2 if aux & 2 else a, b, name, str(q[c:d]), "INS", chrom))
+        elif kind == 2:
+            cand["DUP"].append((a, b, name, "DUP", chrom))
+        elif kind == 3:
+            cand["INV"].append(("--" if aux else "++", a, b, name, "INV", chrom))
+        else:
+            cand["TRA"].append(("ABCD"[aux], a, chrom_names[c], b, name, "TRA", chrom))
+    return cand

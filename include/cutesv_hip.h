@@ -323,6 +323,51 @@ typedef struct csv_cigar_out {
 int csv_cigar_signatures(csv_ctx* ctx, const csv_cigar_in* in, csv_cigar_out* out);
 
 /* ---------------------------------------------------------------------------------------------
+ * The split-read analysis of the extraction step on the GPU (second half).  Restates
+ * organize_split_signal (cuteSV main script :483-513: the primary alignment plus the SA-tag entries that pass min_mapq
+ * become [read_start, read_end, ref_start, ref_end, chr, strand] segments; reads with more than max_split_parts segments
+ * are skipped) and analysis_split_read with analysis_inv / analysis_bnd (:50-464: segments sorted by read_start, then
+ * the two-segment and sliding three-segment rules that emit INV / TRA / DUP / INS / DEL candidates).  BAM decode and
+ * the text of the SA tag stay in the Python driver with pysam (north_star): per entry the caller passes what
+ * acquire_clip_pos (:466-481) takes out of the SA entry's CIGAR and the numbers of the entry itself.
+ *
+ * Entries of read r: [ent_off[r], ent_off[r + 1]), the primary alignment first when the read has one (parse_read
+ * :660-668, primary = 1: c0/c1 = read_start/read_end, f0/f1 = ref_start/ref_end as parse_read computes them), then the
+ * SA entries in tag order (primary = 0: c0/c1 = leading / trailing soft-clip lengths, f0 = 0-based start, f1 = reference
+ * span, mapq).  chr is an integer whose order is the Python string order of the chromosome names (analysis_bnd compares
+ * names with <, :110).  strand: 0 '+', 1 '-'.
+ *
+ * Output: one record per candidate, reads in order, inside a read in the order the reference appends them (per SV type
+ * that is exactly the order of the reference's five lists).  kind: 0 DEL (a = pos, b = length), 1 INS (a = position
+ * numerator, b = length, c / d = the Python slice bounds query[c:d] of the inserted sequence, aux bit 0: the slice is
+ * taken from the reverse complement of the query analysis_split_read was given, aux bit 1: the position is the float
+ * a / 2 (:228, :244) rather than the integer a (:452)), 2 DUP (a, b = the two positions), 3 INV (aux: 0 "++", 1 "--";
+ * a, b), 4 TRA (aux: 0..3 = 'A'..'D'; a = pos1, c = mate chromosome, b = pos2).  chr = the tuple's last element.
+ */
+typedef struct csv_split_in {
+    int64_t         n_reads;
+    const int64_t*  ent_off;        /* n_reads + 1 */
+    const int64_t*  read_len;       /* read.query_length (total_L / RLength) */
+    const int64_t*  c0;  const int64_t* c1;  const int64_t* f0;  const int64_t* f1;      /* per entry */
+    const int32_t*  chr; const int32_t* mapq;
+    const uint8_t*  strand;  const uint8_t* primary;
+    int64_t         sv_size;        /* --min_size (parse_read's SV_size) */
+    int64_t         max_size;       /* --max_size, -1: no limit */
+    int32_t         min_mapq;
+    int32_t         max_split_parts;   /* -1: no limit */
+} csv_split_in;
+
+typedef struct csv_split_out {
+    int64_t  cap;
+    int64_t  n;                     /* out */
+    uint8_t* kind;  int32_t* read;  int32_t* chr;  int32_t* aux;  int64_t* a;  int64_t* b;  int64_t* c;  int64_t* d;   /* cap */
+    float    ms_device;             /* out: kernels only */
+    int32_t  reserved;
+} csv_split_out;
+
+int csv_split_signatures(csv_ctx* ctx, const csv_split_in* in, csv_split_out* out);
+
+/* ---------------------------------------------------------------------------------------------
  * Host-side VCF record emit: the structure-of-arrays result -> the text lines
  * of cuteSV's VCF body, without materialising Python row lists.  Replaces generate_output
  * (cuteSV_genotype.py:242-467: per-chromosome stable sort by POS, size filters, INFO/FORMAT

@@ -870,3 +870,156 @@ int csvo_cigar_signatures(const csv_cigar_in* in, csv_cigar_out* out)
     out->ms_device = 0;
     return (n_i > out->cap_sig_ins || n_p > out->cap_piece_ins || n_d > out->cap_sig_del) ? CSV_E_CAPACITY : CSV_OK;
 }
+
+/* ------------------------------------------------------------------ split-read analysis */
+
+/* organize_split_signal (main script :483-513) + analysis_split_read / analysis_inv / analysis_bnd (:50-464), one read
+ * after the other, written as the reference is: element [0..5] = read_start, read_end, ref_start, ref_end, chr, strand.
+ * Same structs as csv_split_signatures (include/cutesv_hip.h). */
+typedef struct { int64_t rs, re, fs, fe; int32_t chr; int32_t st; } sp_seg;     /* st: 0 '+', 1 '-' */
+typedef struct { const csv_split_in* in; csv_split_out* out; int64_t n; int32_t read; } sp_sink;
+
+static void sp_put(sp_sink* S, int kind, int32_t chr, int32_t aux, int64_t a, int64_t b, int64_t c, int64_t d)
+{
+    const int64_t k = S->n++;
+    if (k >= S->out->cap) return;
+    S->out->kind[k] = (uint8_t)kind; S->out->read[k] = S->read; S->out->chr[k] = chr; S->out->aux[k] = aux;
+    S->out->a[k] = a; S->out->b[k] = b; S->out->c[k] = c; S->out->d[k] = d;
+}
+static sp_seg sp_flip(sp_seg x, int64_t L) { sp_seg y = x; y.rs = L - x.re; y.re = L - x.rs; return y; }    /* [RLength-x[1], RLength-x[0]] + x[2:] */
+static double sp_max(int64_t a, int64_t delta) { const double q = (double)delta / 5.0; return (double)a > q ? (double)a : ((double)a == q ? (double)a : q); }
+
+static void sp_inv(sp_sink* S, sp_seg e1, sp_seg e2, int64_t SV)                 /* analysis_inv :50-95 */
+{
+    if (e1.st == 0) {
+        if (e1.fe - e2.fe >= SV && 2 * e2.rs + (e1.fe - e2.fe) >= 2 * e1.re) sp_put(S, 3, e1.chr, 0, e2.fe, e1.fe, 0, 0);
+        if (e2.fe - e1.fe >= SV && 2 * e2.rs + (e2.fe - e1.fe) >= 2 * e1.re) sp_put(S, 3, e1.chr, 0, e1.fe, e2.fe, 0, 0);
+    } else {
+        if (e2.fs - e1.fs >= SV && 2 * e2.rs + (e2.fs - e1.fs) >= 2 * e1.re) sp_put(S, 3, e1.chr, 1, e1.fs, e2.fs, 0, 0);
+        if (e1.fs - e2.fs >= SV && 2 * e2.rs + (e1.fs - e2.fs) >= 2 * e1.re) sp_put(S, 3, e1.chr, 1, e2.fs, e1.fs, 0, 0);
+    }
+}
+static void sp_bnd(sp_sink* S, sp_seg e1, sp_seg e2)                            /* analysis_bnd :97-188 */
+{
+    if (e2.rs - e1.re > 100) return;
+    const int lt = e1.chr < e2.chr;
+    if (e1.st == 0 && e2.st == 0) { if (lt) sp_put(S, 4, e1.chr, 0, e1.fe, e2.fs, e2.chr, 0); else sp_put(S, 4, e2.chr, 3, e2.fs, e1.fe, e1.chr, 0); }
+    else if (e1.st == 0)          { if (lt) sp_put(S, 4, e1.chr, 1, e1.fe, e2.fe, e2.chr, 0); else sp_put(S, 4, e2.chr, 1, e2.fe, e1.fe, e1.chr, 0); }
+    else if (e2.st == 0)          { if (lt) sp_put(S, 4, e1.chr, 2, e1.fs, e2.fs, e2.chr, 0); else sp_put(S, 4, e2.chr, 2, e2.fs, e1.fs, e1.chr, 0); }
+    else                          { if (lt) sp_put(S, 4, e1.chr, 3, e1.fs, e2.fe, e2.chr, 0); else sp_put(S, 4, e2.chr, 0, e2.fe, e1.fs, e1.chr, 0); }
+}
+/* the INS / DEL pair of rules on two consecutive same-strand segments (:241-259, :358-376, :382-399, :411-428);
+ * need3: the extra `ele_3[2] >= ele_2[3]` test of :361 / :371 */
+static void sp_indel(sp_sink* S, sp_seg e1, sp_seg e2, int64_t SV, int64_t Max, int rc, int need3, int ok3)
+{
+    int64_t delta = e2.rs + e1.fe - e2.fs - e1.re;
+    if ((double)(e1.fe - e2.fs) < sp_max(SV, delta) && delta >= SV)
+        if ((double)(e2.fs - e1.fe) <= sp_max(100, delta) && (delta <= Max || Max == -1))
+            if (!need3 || ok3) sp_put(S, 1, e2.chr, 2 | rc, e2.fs + e1.fe, delta, e1.re + (e2.fs - e1.fe) / 2, e2.rs - (e2.fs - e1.fe) / 2);
+    delta = e2.fs - e2.rs + e1.re - e1.fe;
+    if ((double)(e1.fe - e2.fs) < sp_max(SV, delta) && delta >= SV)
+        if ((double)(e2.rs - e1.re) <= sp_max(100, delta) && (delta <= Max || Max == -1))
+            if (!need3 || ok3) sp_put(S, 0, e2.chr, 0, e1.fe, delta, 0, 0);
+}
+
+int csvo_split_signatures(const csv_split_in* in, csv_split_out* out)
+{
+    sp_sink S = {in, out, 0, 0};
+    const int64_t SV = in->sv_size, Max = in->max_size;
+    int64_t cap_seg = 16;
+    sp_seg* SP = (sp_seg*)malloc((size_t)cap_seg * sizeof(sp_seg));
+    for (int64_t r = 0; r < in->n_reads; r++) {
+        const int64_t e0 = in->ent_off[r], e1o = in->ent_off[r + 1], L = in->read_len[r];
+        if (e1o - e0 > cap_seg) { cap_seg = e1o - e0; SP = (sp_seg*)realloc(SP, (size_t)cap_seg * sizeof(sp_seg)); }
+        S.read = (int32_t)r;
+        /* organize_split_signal */
+        int n = 0;
+        int min_mapq = in->min_mapq;
+        for (int64_t k = e0; k < e1o; k++) {
+            sp_seg x; x.chr = in->chr[k]; x.st = in->strand[k];
+            if (in->primary[k]) { x.rs = in->c0[k]; x.re = in->c1[k]; x.fs = in->f0[k]; x.fe = in->f1[k]; min_mapq = 0; }      /* :486-488 */
+            else {
+                if (in->mapq[k] < min_mapq) continue;                                                                             /* :501 */
+                if (x.st == 0) { x.rs = in->c0[k]; x.re = L - in->c1[k]; } else { x.rs = in->c1[k]; x.re = L - in->c0[k]; }       /* :503-510 */
+                x.fs = in->f0[k]; x.fe = in->f0[k] + in->f1[k];
+            }
+            /* stable insertion by read_start (sorted(..., key = x[0]), :195) */
+            int p = n++;
+            while (p > 0 && SP[p - 1].rs > x.rs) { SP[p] = SP[p - 1]; p--; }
+            SP[p] = x;
+        }
+        if (!(n <= in->max_split_parts || in->max_split_parts == -1)) continue;                                                    /* :512 */
+        /* analysis_split_read */
+        int trigger = 0;
+        if (n == 2) {
+            sp_seg a1 = SP[0], a2 = SP[1];
+            if (a1.chr == a2.chr) {
+                if (a1.st != a2.st) sp_inv(&S, a1, a2, SV);
+                else {
+                    int rc = 0;
+                    if (a1.st == 1) { a1 = sp_flip(SP[1], L); a2 = sp_flip(SP[0], L); rc = 1; }
+                    if (a1.fe - a2.fs >= SV) {                                                                                     /* :225 */
+                        if (a2.rs - a1.re >= a1.fe - a2.fs)
+                            sp_put(&S, 1, a2.chr, 2 | rc, a1.fe + a2.fs, a2.rs + a1.fe - a2.fs - a1.re, a1.re + (a2.fs - a1.fe) / 2, a2.rs - (a2.fs - a1.fe) / 2);
+                        else sp_put(&S, 2, a2.chr, 0, a2.fs, a1.fe, 0, 0);
+                    }
+                    sp_indel(&S, a1, a2, SV, Max, rc, 0, 0);
+                }
+            } else sp_bnd(&S, a1, a2);
+        } else {
+            for (int a = 0; a + 2 < n; a++) {
+                sp_seg a1 = SP[a], a2 = SP[a + 1], a3 = SP[a + 2];
+                int a3_none = 0;
+                const int last = (n - 3 == a);
+                if (a1.chr == a2.chr) {
+                    if (a2.chr == a3.chr) {
+                        if (a1.st == a3.st && a1.st != a2.st) {                                                                    /* :270 */
+                            if (a2.st == 1) {
+                                const int64_t d = a3.fs - a1.fe;
+                                if (2 * a2.rs + d >= 2 * a1.re && 2 * a3.rs + d >= 2 * a2.re)
+                                    if (a2.fs >= a1.fe && a3.fs >= a2.fe) { sp_put(&S, 3, a1.chr, 0, a1.fe, a2.fe, 0, 0); sp_put(&S, 3, a1.chr, 1, a2.fs, a3.fs, 0, 0); }
+                            } else {
+                                const int64_t d = a1.fs - a3.fe;
+                                if (2 * a1.re <= 2 * a2.rs + d && 2 * a3.rs + d >= 2 * a2.re)
+                                    if (a2.fs - a3.fe >= -50 && a1.fs - a2.fe >= -50) { sp_put(&S, 3, a1.chr, 0, a3.fe, a2.fe, 0, 0); sp_put(&S, 3, a1.chr, 1, a2.fs, a1.fs, 0, 0); }
+                            }
+                        }
+                        if (last && a1.st != a3.st) {                                                                              /* :316 */
+                            if (a2.st == a1.st) sp_inv(&S, a2, a3, SV); else sp_inv(&S, a1, a2, SV);
+                        }
+                        if (a1.st == a3.st && a1.st == a2.st) {                                                                    /* :333 */
+                            int rc = 0;
+                            if (a1.st == 1) { a1 = sp_flip(SP[a + 2], L); a2 = sp_flip(SP[a + 1], L); a3 = sp_flip(SP[a], L); rc = 1; }
+                            if (a2.fe - a3.fs >= SV && a2.fs < a3.fe) sp_put(&S, 2, a2.chr, 0, a3.fs, a2.fe, 0, 0);
+                            if (a == 0 && a1.fe - a2.fs >= SV) sp_put(&S, 2, a2.chr, 0, a2.fs, a1.fe, 0, 0);
+                            sp_indel(&S, a1, a2, SV, Max, rc, 1, a3.fs >= a2.fe);
+                            if (last) { a1 = a2; a2 = a3; sp_indel(&S, a1, a2, SV, Max, rc, 0, 0); }
+                        }
+                        if (last && a1.st != a2.st && a2.st == a3.st) { a1 = a2; a2 = a3; a3_none = 1; }                          /* :401 */
+                        if (a3_none || (a1.st == a2.st && a2.st != a3.st)) {                                                       /* :405 */
+                            int rc = 0;
+                            if (a1.st == 1) { a1 = sp_flip(SP[a + 1], L); a2 = sp_flip(SP[a], L); rc = 1; }
+                            sp_indel(&S, a1, a2, SV, Max, rc, 0, 0);
+                        }
+                    }
+                } else {
+                    trigger = 1;
+                    sp_bnd(&S, a1, a2);
+                    if (last && a2.chr != a3.chr) sp_bnd(&S, a2, a3);
+                }
+            }
+        }
+        if (n >= 3 && trigger && SP[0].chr == SP[n - 1].chr && SP[0].st == SP[n - 1].st) {                                         /* :439 */
+            sp_seg a1, a2; int rc = 0;
+            if (SP[0].st == 0) { a1 = SP[0]; a2 = SP[n - 1]; } else { a1 = sp_flip(SP[n - 1], L); a2 = sp_flip(SP[0], L); rc = 1; }
+            const int64_t dis_ref = a2.fs - a1.fe, dis_read = a2.rs - a1.re, dl = dis_read - dis_ref;
+            const int64_t ad = dis_ref < 0 ? -dis_ref : dis_ref;
+            if ((double)ad < sp_max(SV, dl) && dl >= SV && (dl <= Max || Max == -1))
+                sp_put(&S, 1, a2.chr, rc, a2.fs < a1.fe ? a2.fs : a1.fe, dl, a1.re + dis_ref / 2, a2.rs - dis_ref / 2);
+            if (dis_ref <= -SV) sp_put(&S, 2, a2.chr, 0, a2.fs, a1.fe, 0, 0);
+        }
+    }
+    free(SP);
+    out->n = S.n; out->ms_device = 0;
+    return S.n > out->cap ? CSV_E_CAPACITY : CSV_OK;
+}

@@ -87,3 +87,16 @@ def cigar_signatures(cig_off, cigar, ref_start, use=None, min_siglength=10, merg
         if rc != _abi.OK:
             raise RuntimeError("oracle: %s" % _abi.ERR_NAME.get(rc, rc))
     return extract._run(L.csvo_cigar_signatures, None, cig_off, cigar, ref_start, use, min_siglength, merge_ins_threshold, merge_del_threshold, check)
+
+
+def split_signatures(enc, sv_size=30, min_mapq=20, max_split_parts=7, max_size=100000):
+    """the C restatement of the split-read analysis (csvo_split_signatures); same result dict as cutesv_amd.extract.split_signatures"""
+    from cutesv_amd import extract
+    L = lib()
+    L.csvo_split_signatures.restype = C.c_int
+    L.csvo_split_signatures.argtypes = [C.POINTER(extract.SplitIn), C.POINTER(extract.SplitOut)]
+
+    def check(rc):
+        if rc != _abi.OK:
+            raise RuntimeError("oracle: %s" % _abi.ERR_NAME.get(rc, rc))
+    return extract._run_split(L.csvo_split_signatures, None, enc, sv_size, min_mapq, max_split_parts, max_size, check)

@@ -14,6 +14,8 @@ Outputs
                             lists the rebuild step writes, in its order
     cigar_sigs.json.gz      parse_read (main script :606-681) / generate_combine_sigs (:515-575) driven with stub read
                             objects carrying BAM-encoded CIGARs: the INS / DEL signatures each read yields (8f row 4)
+    split_sigs.json.gz      organize_split_signal / analysis_split_read (main script :50-513) driven with synthetic primary
+                            alignments and SA-tag texts: the candidates of all five SV types each read yields (8f row 4)
 """
 import gzip
 import importlib.machinery
@@ -44,6 +46,15 @@ def load_main():
             return Seq(self[::-1].translate(str.maketrans("ACGTacgt", "TGCAtgca")))
     sys.modules["Bio.Seq"].Seq = Seq
     sys.modules["Bio"].Seq = sys.modules["Bio.Seq"]
+
+    class Cigar:                                             # cigar.Cigar stand-in: items() -> (length, operation) of a CIGAR text
+        def __init__(self, text):
+            self.text = text
+
+        def items(self):
+            import re
+            return ((int(n), op) for n, op in re.findall(r"(\d+)([MIDNSHP=XB])", self.text))
+    sys.modules["cigar"].Cigar = Cigar
     sys.path.insert(0, os.path.join(REF, "src"))
     loader = importlib.machinery.SourceFileLoader("cutesv_main", os.path.join(REF, "src", "cuteSV", "cuteSV"))
     spec = importlib.util.spec_from_loader("cutesv_main", loader)
@@ -141,6 +152,8 @@ def main_():
         try:
             from make_golden_cigar import cigar_golden
             cigar_golden(main)
+            from make_golden_split import split_golden
+            split_golden(main)
         except ImportError:
             pass
 

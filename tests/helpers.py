@@ -176,3 +176,33 @@ def assert_cigar_case(case, scan):
     assert [list(x) for x in ins] == case["INS"], case["name"]
     assert [list(x) for x in dele] == case["DEL"], case["name"]
     return sig
+
+
+# ------------------------------------------------------------------------------------------------ split-read golden (8f row 4)
+SPLIT_CHROMS = ["1", "10", "2", "X"]                         # in Python string order, as the generator used them
+
+
+def split_case_inputs(case):
+    """a split_sigs.json.gz case -> (flat csv_split_in arrays, read names, queries, chromosome names by rank, kwargs)"""
+    from cutesv_amd import extract, synth
+    names = sorted(SPLIT_CHROMS)
+    rank = {c: i for i, c in enumerate(names)}
+    reads, p = case["reads"], case["params"]
+    enc = extract.encode_split_reads([(r["primary"], r["sa"], r["qlen"]) for r in reads], rank)
+    queries = [synth.pseudo_sequence(r["qlen"], r["key"]) for r in reads]
+    kw = dict(sv_size=p["sv"], min_mapq=p["min_mapq"], max_split_parts=p["parts"], max_size=p["max_size"])
+    return enc, [r["name"] for r in reads], queries, names, kw
+
+
+def assert_split_case(case, scan):
+    """scan(enc, **kw) -> candidate arrays; compared with the reference's five candidate lists (values AND the int / float
+    type of the INS position, which the reference produces both ways)"""
+    from cutesv_amd import extract
+    enc, names, queries, chroms, kw = split_case_inputs(case)
+    sig = scan(enc, **kw)
+    cand = extract.split_candidates(sig, names, queries, chroms)
+    for t in ("DEL", "INS", "DUP", "INV", "TRA"):
+        got = [list(x) for x in cand[t]]
+        assert got == case[t], (case["name"], t, len(got), len(case[t]))
+        assert all(type(g[0]) is type(w[0]) for g, w in zip(got, case[t])), (case["name"], t)
+    return sig

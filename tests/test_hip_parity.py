@@ -652,3 +652,54 @@ def test_resident_runs_with_and_without_the_tier_peek(ctx, monkeypatch):
             assert_soa_equal(ctx.download(per_sig=True).trimmed(), want)
     sizes = np.bincount(want["cluster_id"][want["cluster_id"] >= 0])
     assert sizes.max() > 64                                   # the second workload does exercise the big tiers
+
+
+def _random_split_batch(rng, n_reads, n_chrom=6):
+    """flat csv_split_in arrays of random reads: 0 .. 12 entries each, with or without a primary, segments that tile the
+    read loosely and wander over a few chromosomes / both strands (every rule of the analysis fires somewhere)"""
+    n_ent = rng.choice(np.array([0, 1, 2, 2, 2, 3, 3, 3, 4, 4, 5, 6, 8, 12]), n_reads)
+    ent_off = np.zeros(n_reads + 1, np.int64); np.cumsum(n_ent, out=ent_off[1:])
+    ne = int(ent_off[-1])
+    read = np.repeat(np.arange(n_reads), n_ent)
+    first = np.zeros(ne, bool); first[ent_off[:-1][n_ent > 0]] = True
+    L = rng.integers(500, 30000, n_reads).astype(np.int64)
+    primary = (first & (rng.random(ne) < 0.8)).astype(np.uint8)
+    strand = (rng.random(ne) < 0.35).astype(np.uint8)
+    # reads mostly keep their strand and chromosome
+    base_st = np.repeat((rng.random(n_reads) < 0.5).astype(np.uint8), n_ent); strand = np.where(rng.random(ne) < 0.7, base_st, strand).astype(np.uint8)
+    base_ch = np.repeat(rng.integers(0, n_chrom, n_reads), n_ent)
+    chrom = np.where(rng.random(ne) < 0.8, base_ch, rng.integers(0, n_chrom, ne)).astype(np.int32)
+    Lr = L[read]
+    lo = (rng.random(ne) * Lr).astype(np.int64); hi = np.minimum(Lr, lo + 1 + (rng.random(ne) * Lr * 0.5).astype(np.int64))
+    base_ref = np.repeat(rng.integers(100_000, 3_000_000, n_reads), n_ent)
+    ref = np.maximum(0, base_ref + np.where(rng.random(ne) < 0.7, lo + rng.integers(-3000, 3000, ne), rng.integers(-2_000_000, 2_000_000, ne))).astype(np.int64)
+    span = np.maximum(1, hi - lo + rng.integers(-50, 50, ne)).astype(np.int64)
+    # primary: c0/c1 = read_start/read_end, f0/f1 = ref_start/ref_end; SA entry: clips (as the strand has them), start, span
+    c0 = np.where(primary == 1, lo, np.where(strand == 0, lo, Lr - hi)); c1 = np.where(primary == 1, hi, np.where(strand == 0, Lr - hi, lo))
+    f1 = np.where(primary == 1, ref + span, span)
+    mapq = rng.choice(np.array([0, 3, 20, 30, 60], np.int32), ne)
+    return dict(ent_off=ent_off, read_len=L, c0=c0.astype(np.int64), c1=c1.astype(np.int64), f0=ref, f1=f1.astype(np.int64), chr=chrom, mapq=mapq,
+                strand=strand, primary=primary)
+
+
+def test_split_read_analysis_identical_to_reference_and_oracle(ctx):
+    """csv_split_signatures (8f row 4): the reference's five candidate lists on the golden reads, and the oracle's arrays
+    bit for bit on large random batches under several parameter sets, plus the empty shapes"""
+    from cutesv_amd import extract
+    from helpers import assert_split_case
+    for case in load_json("split_sigs.json.gz"):
+        assert_split_case(case, lambda enc, **k: extract.split_signatures(ctx, enc, **k))
+    rng = np.random.default_rng(91)
+    enc = _random_split_batch(rng, 60000)
+    seen = set()
+    for kw in (dict(sv_size=30, min_mapq=20, max_split_parts=7, max_size=100000), dict(sv_size=1, min_mapq=0, max_split_parts=-1, max_size=-1),
+               dict(sv_size=200, min_mapq=30, max_split_parts=3, max_size=5000), dict(sv_size=0, min_mapq=61, max_split_parts=12, max_size=100)):
+        got, want = extract.split_signatures(ctx, enc, **kw), _oracle().split_signatures(enc, **kw)
+        for k in ("kind", "read", "chr", "aux", "a", "b", "c", "d"):
+            assert np.array_equal(got[k], want[k]), (kw, k, len(got[k]), len(want[k]))
+        seen |= set(np.unique(got["kind"]).tolist())
+        assert len(got["kind"]) > 0 or kw["min_mapq"] > 60
+    assert seen == {0, 1, 2, 3, 4}
+    empty = {k: v[:0] for k, v in enc.items() if k not in ("ent_off", "read_len")}
+    assert len(extract.split_signatures(ctx, dict(empty, ent_off=np.zeros(1, np.int64), read_len=np.zeros(0, np.int64)))["kind"]) == 0
+    assert len(extract.split_signatures(ctx, dict(empty, ent_off=np.zeros(4, np.int64), read_len=np.full(3, 1000, np.int64)))["kind"]) == 0

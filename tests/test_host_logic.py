@@ -35,9 +35,9 @@ def test_c_abi_exports_every_declared_symbol():
     from cutesv_amd import rebuild, vcf, rows, extract
     mirrors = [_abi.SEGMENT_DTYPE.itemsize, C.sizeof(_abi.BatchIn), C.sizeof(_abi.BatchOut), C.sizeof(_abi.RunStats),
                C.sizeof(rebuild.RebuildIn), C.sizeof(rebuild.RebuildOut), C.sizeof(vcf.VcfIn), C.sizeof(rows.RowsIn),
-               C.sizeof(extract.CigarIn), C.sizeof(extract.CigarOut)]
-    assert [L.csv_struct_size(i) for i in range(10)] == mirrors
-    assert L.csv_struct_size(10) == -1
+               C.sizeof(extract.CigarIn), C.sizeof(extract.CigarOut), C.sizeof(extract.SplitIn), C.sizeof(extract.SplitOut)]
+    assert [L.csv_struct_size(i) for i in range(12)] == mirrors
+    assert L.csv_struct_size(12) == -1
 
 
 def test_missing_extension_fails_loudly(tmp_path, monkeypatch):

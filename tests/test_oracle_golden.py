@@ -166,3 +166,19 @@ def test_cigar_scan_identical_to_reference():
         sig = assert_cigar_case(case, oracle.cigar_signatures)
         n += len(sig["ins_pos"]) + len(sig["del_pos"])
     assert n > 3000
+
+
+def test_split_read_analysis_identical_to_reference():
+    """oracle (csvo_split_signatures) == the candidate lists the reference's organize_split_signal / analysis_split_read
+    produced for synthetic primary + SA-tag inputs (tests/golden/make_golden_split.py): all five SV types, every rule of
+    the two-segment and sliding three-segment analysis, the insertion-inside-a-translocation rule, both strands, mapq and
+    segment-count gates"""
+    from helpers import assert_split_case
+    from oracle import oracle
+    kinds = set()
+    for case in load_json("split_sigs.json.gz"):
+        sig = assert_split_case(case, oracle.split_signatures)
+        kinds |= set(np.unique(sig["kind"]).tolist())
+        if case["name"] == "ins_inside_tra":
+            assert ((sig["kind"] == 1) & ((sig["aux"] & 2) == 0)).any()        # the integer-position form (:452)
+    assert kinds == {0, 1, 2, 3, 4}
