@@ -2,8 +2,8 @@
 //
 // Restates the CIGAR part of parse_read (cuteSV main script :606-655) and generate_combine_sigs (:515-575): every
 // insertion / deletion operation of at least min_siglength bases is a piece; pieces of one type that lie within
-// merge_ins_threshold / merge_del_threshold of each other inside a read are merged into one signature.  BAM decode, the
-// SA-tag split-read analysis (:190-464) and the sequences stay with pysam in the Python driver (north_star): the input
+// merge_ins_threshold / merge_del_threshold of each other inside a read are merged into one signature.  BAM decode and
+// the sequences stay with pysam in the Python driver (north_star; the split-read analysis is split.hip.h): the input
 // is the flat, BAM-encoded CIGAR array of a batch of reads, the output the INS / DEL signatures (+ the query slices an
 // INS sequence is made of), in read order.
 //

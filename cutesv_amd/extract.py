@@ -3,8 +3,10 @@
 `cigar_signatures` is the face of `csv_cigar_signatures` (cutesv_amd/csrc/cigar.hip.h): the flat BAM-encoded CIGAR array
 of a batch of reads -> the INS / DEL signatures parse_read + generate_combine_sigs (main script :606-655, :515-575) make
 of them.  `candidates` turns the flat result into the reference's candidate tuples (the inserted sequence is cut out of
-the reads' query sequences here: the bases never travel to the GPU).  BAM decode, the SA-tag split-read analysis and
-everything else of the extraction stay in the Python driver with pysam, as north_star has it: a driver would collect
+the reads' query sequences here: the bases never travel to the GPU).  `split_signatures` is the face of
+`csv_split_signatures` (split.hip.h): organize_split_signal + analysis_split_read (:50-513) on the numbers of a batch of
+primary alignments and SA-tag entries.  BAM decode, the SA text and everything else of the extraction stay in the Python
+driver with pysam, as north_star has it: a driver would collect
 `read.cigartuples`, `read.reference_start`, `read.mapq >= min_mapq and read.query_length >= min_read_len` for a task's
 reads, make one call here, and extend candidate["INS"] / candidate["DEL"] with the result.
 """

@@ -291,8 +291,8 @@ int csv_rebuild_signatures(csv_ctx* ctx, const csv_rebuild_in* in, csv_rebuild_o
  * (cuteSV main script :606-655: every I / D operation of at least min_siglength bases is a piece at the reference position
  * it is reached, :629-643) and generate_combine_sigs (:515-575: pieces of one type within merge_ins_threshold /
  * merge_del_threshold of each other inside a read become one signature; the distance rule of :535 / :558 / :569 is
- * reproduced as written).  BAM decode, the SA-tag split-read analysis (:190-464) and the bases stay in the Python driver
- * with pysam: the input is the flat BAM-encoded CIGAR array of a batch of reads (pysam: read.cigartuples), the output the
+ * reproduced as written).  BAM decode and the bases stay in the Python driver with pysam (the SA-tag split-read analysis
+ * is csv_split_signatures below): the input is the flat BAM-encoded CIGAR array of a batch of reads (pysam: read.cigartuples), the output the
  * INS / DEL signatures in read order plus, for INS, the query slices the inserted sequence is made of
  * (query_sequence[qoff : qoff + len] per piece, concatenated: :639-640, :537).
  *   use[r] = 0 skips read r (mapq < min_mapq, :614; the query_length < min_read_len gate of :607 is the caller's too).
