@@ -211,3 +211,68 @@ def split_candidates(sig, read_names, queries, chrom_names):
         else:
             cand["TRA"].append(("ABCD"[aux], a, chrom_names[c], b, name, "TRA", chrom))
     return cand
+
+
+# ------------------------------------------------------------------------------------ parse_read for a batch of reads
+def parse_reads(reads, chrom, chrom_rank, sv_size, min_mapq, max_split_parts, min_read_len, min_siglength, merge_del_threshold,
+                merge_ins_threshold, max_size, cigar_fn, split_fn):
+    """What calling the reference's parse_read (main script :606-681) on every read of `reads`, in order, appends to
+    candidate["DEL" | "INS" | "DUP" | "INV" | "TRA"] - with the CIGAR scan and the split-read analysis done per BATCH by
+    `cigar_fn(cig_off, cigar, ref_start, use, **kw)` / `split_fn(enc, **kw)` (a context's cigar_signatures /
+    split_signatures; the tests also pass the oracle's).  reads: pysam.AlignedSegment-like objects (query_length, flag,
+    mapq, reference_start, reference_end, cigartuples, query_sequence, query_name, get_tags()); chrom_rank: {chromosome
+    name: rank in Python string order} over every name an SA tag can mention.
+
+    Everything that is text or per-read bookkeeping stays here, as the reference has it: the read-length gate (:607), the
+    flag classes (:613), the clip lengths that make primary_info (:619-668), the SA tag (:671-679)."""
+    cand = {t: [] for t in ("DEL", "INS", "DUP", "INV", "TRA")}
+    keep = [r for r in reads if r.query_length >= min_read_len]                                    # (:607)
+    if not keep:
+        return cand
+    cig_off, cigar = encode_cigars([r.cigartuples for r in keep])
+    ref_start = np.fromiter((r.reference_start for r in keep), np.int64, len(keep))
+    use = np.fromiter((1 if r.mapq >= min_mapq else 0 for r in keep), np.uint8, len(keep))          # (:614)
+    sig = cigar_fn(cig_off, cigar, ref_start, use, min_siglength=min_siglength, merge_ins_threshold=merge_ins_threshold,
+                   merge_del_threshold=merge_del_threshold)
+    names = [r.query_name for r in keep]
+    c_ins, c_del = candidates(sig, names, [r.query_sequence for r in keep], chrom)
+    # reads with an SA tag on a primary record (flag 0 / 16, :657): their segments go through the split-read analysis
+    sp_reads, sp_idx, sp_query = [], [], []
+    for i, r in enumerate(keep):
+        if r.flag not in (0, 16):
+            continue
+        sa = [v for k, v in r.get_tags() if k == "SA"]
+        if not sa:
+            continue
+        primary = []
+        if r.mapq >= min_mapq:
+            ct = r.cigartuples
+            left = ct[0][1] if ct[0][0] in (4, 5) else 0                                            # soft clip, or the hard clip that replaces it (:619-652)
+            right = ct[-1][1] if ct[-1][0] in (4, 5) else 0
+            primary = ([left, r.query_length - right, r.reference_start, r.reference_end, chrom, "+"] if r.flag == 0 else
+                       [right, r.query_length - left, r.reference_start, r.reference_end, chrom, "-"])
+        q = r.query_sequence if r.flag == 0 else str(r.query_sequence).translate(_COMP)[::-1]       # (:673-675)
+        for tag in sa:                                                                              # (one call per SA tag, :671)
+            sp_reads.append((primary, tag, r.query_length)); sp_idx.append(i); sp_query.append(q)
+    s_cand = {t: [] for t in cand}
+    s_read = {t: [] for t in cand}
+    if sp_reads:
+        enc = encode_split_reads(sp_reads, chrom_rank)
+        ssig = split_fn(enc, sv_size=sv_size, min_mapq=min_mapq, max_split_parts=max_split_parts, max_size=max_size)
+        s_cand = split_candidates(ssig, [names[i] for i in sp_idx], sp_query, sorted(chrom_rank, key=chrom_rank.get))
+        kind_name = ("DEL", "INS", "DUP", "INV", "TRA")
+        for k, rd in zip(ssig["kind"].tolist(), ssig["read"].tolist()):
+            s_read[kind_name[k]].append(sp_idx[rd])
+    # per type: read order; inside a read the CIGAR signatures come first (:656-657 before :671-679)
+    for t, c_list, c_reads in (("INS", c_ins, sig["ins_read"].tolist()), ("DEL", c_del, sig["del_read"].tolist())):
+        out, j = [], 0
+        sl, sr = s_cand[t], s_read[t]
+        for x, rd in zip(c_list, c_reads):
+            while j < len(sl) and sr[j] < rd:
+                out.append(sl[j]); j += 1
+            out.append(x)
+        out.extend(sl[j:])
+        cand[t] = out
+    for t in ("DUP", "INV", "TRA"):
+        cand[t] = s_cand[t]
+    return cand

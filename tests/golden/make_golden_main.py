@@ -14,6 +14,8 @@ Outputs
                             lists the rebuild step writes, in its order
     cigar_sigs.json.gz      parse_read (main script :606-681) / generate_combine_sigs (:515-575) driven with stub read
                             objects carrying BAM-encoded CIGARs: the INS / DEL signatures each read yields (8f row 4)
+    parse_reads.json.gz     parse_read (main script :606-681) called read after read on stub records with CIGARs and SA tags:
+                            what a whole task's extraction appends to the five candidate lists (8f row 4)
     split_sigs.json.gz      organize_split_signal / analysis_split_read (main script :50-513) driven with synthetic primary
                             alignments and SA-tag texts: the candidates of all five SV types each read yields (8f row 4)
 """
@@ -154,6 +156,8 @@ def main_():
             cigar_golden(main)
             from make_golden_split import split_golden
             split_golden(main)
+            from make_golden_parse import parse_golden
+            parse_golden(main)
         except ImportError:
             pass
 

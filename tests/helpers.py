@@ -206,3 +206,32 @@ def assert_split_case(case, scan):
         assert got == case[t], (case["name"], t, len(got), len(case[t]))
         assert all(type(g[0]) is type(w[0]) for g, w in zip(got, case[t])), (case["name"], t)
     return sig
+
+
+# ------------------------------------------------------------------------------------------------ whole parse_read golden (8f row 4)
+class StubRecord:
+    """what parse_read touches of a pysam.AlignedSegment, rebuilt from a parse_reads.json.gz record"""
+
+    def __init__(self, d):
+        from cutesv_amd import synth
+        self.query_name, self.flag, self.mapq, self.reference_start = d["name"], d["flag"], d["mapq"], d["start"]
+        self.cigartuples = [tuple(x) for x in d["cigar"]]
+        self.query_sequence = synth.pseudo_sequence(d["seq_len"], d["seq_key"])
+        self.query_length = d["seq_len"]
+        self.reference_end = d["start"] + sum(ln for op, ln in self.cigartuples if op in (0, 2, 3, 7, 8))
+        self._tags = [tuple(t) for t in d["tags"]]
+
+    def get_tags(self):
+        return self._tags
+
+
+def assert_parse_case(case, cigar_fn, split_fn):
+    from cutesv_amd import extract
+    p = case["params"]
+    rank = {c: i for i, c in enumerate(case["chroms"])}
+    cand = extract.parse_reads([StubRecord(d) for d in case["reads"]], case["chrom"], rank, p["sv"], p["min_mapq"], p["parts"], p["min_read_len"],
+                               p["min_siglength"], p["md"], p["mi"], p["max_size"], cigar_fn, split_fn)
+    for t in ("DEL", "INS", "DUP", "INV", "TRA"):
+        got = [list(x) for x in cand[t]]
+        assert got == case[t], (case["name"], t, len(got), len(case[t]), next(((i, g, w) for i, (g, w) in enumerate(zip(got, case[t])) if g != w), None))
+        assert all(type(g[0]) is type(w[0]) for g, w in zip(got, case[t])), (case["name"], t)

@@ -703,3 +703,11 @@ def test_split_read_analysis_identical_to_reference_and_oracle(ctx):
     empty = {k: v[:0] for k, v in enc.items() if k not in ("ent_off", "read_len")}
     assert len(extract.split_signatures(ctx, dict(empty, ent_off=np.zeros(1, np.int64), read_len=np.zeros(0, np.int64)))["kind"]) == 0
     assert len(extract.split_signatures(ctx, dict(empty, ent_off=np.zeros(4, np.int64), read_len=np.full(3, 1000, np.int64)))["kind"]) == 0
+
+
+def test_whole_parse_read_on_the_gpu(ctx):
+    """the same golden through csv_cigar_signatures + csv_split_signatures"""
+    from cutesv_amd import extract
+    from helpers import assert_parse_case
+    for case in load_json("parse_reads.json.gz"):
+        assert_parse_case(case, lambda *a, **k: extract.cigar_signatures(ctx, *a, **k), lambda enc, **k: extract.split_signatures(ctx, enc, **k))

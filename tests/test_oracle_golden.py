@@ -182,3 +182,13 @@ def test_split_read_analysis_identical_to_reference():
         if case["name"] == "ins_inside_tra":
             assert ((sig["kind"] == 1) & ((sig["aux"] & 2) == 0)).any()        # the integer-position form (:452)
     assert kinds == {0, 1, 2, 3, 4}
+
+
+def test_whole_parse_read_identical_to_reference():
+    """extract.parse_reads (the per-batch form of the extraction: CIGAR scan + split-read analysis + the text-side glue)
+    with the oracle as the engine == what the reference's parse_read, called read after read on records with CIGARs, clips,
+    flags and SA tags, appended to its five candidate lists (tests/golden/make_golden_parse.py)"""
+    from helpers import assert_parse_case
+    from oracle import oracle
+    for case in load_json("parse_reads.json.gz"):
+        assert_parse_case(case, oracle.cigar_signatures, oracle.split_signatures)
