@@ -1,16 +1,21 @@
 // kernels.hip.h — device code of libcutesv_hip.so (gfx950 / CDNA4 only, wave64).
 //
-// Pipeline of one csv_batch_run (all on one stream, no host round trip in between):
-//   chain     k_chain_count / k_chain_apply                        break flags + scan -> cluster ids; size gate where a
-//                                                                  cluster ends -> ordered work list + three tier lists
-//   refine    k_refine_indel_sub<32> two DEL/INS clusters of m <= 32 per wavefront, <64> one of 32 < m <= 64;
-//                                 registers + cross-lane ops only
-//             k_refine<64,64>    one wavefront per DUP/INV/TRA cluster (m <= 64), arrays in LDS
-//             k_refine<256,2048> one workgroup per cluster; LDS up to 2048 padded elements, global scratch above
-//   order     k_emit                                               per-item counts -> dense, ordered outputs
-//   reads     k_reads_runs / _plan / _gather, k_pmax_count / _scan start order of every block; prefix max of read ends
-//   genotype  k_genotype                                           one wavefront per call: 64-ary search,
-//                                                                  backwards stabbing scan, LDS hash set
+// Pipeline of one csv_batch_run (no host round trip in between; side streams for the pair tier, the big tiers and the reads):
+//   chain     k_chain_count                    break flags, cluster starts per wavefront in LDS, the size gate (once) ->
+//                                              item records per wavefront
+//             k_chain_apply                    compaction: ordered work list + three tier lists; tier counts to the host
+//             k_chain_ids                      per-signature cluster ids (CSV_IN_PER_SIG batches only)
+//   refine    k_refine_indel_wave              DEL/INS clusters of m <= 64 in registers: four (m <= 16), two (m <= 32) or
+//                                              one per wavefront; cross-lane ops only
+//             k_refine<64,64>                  one wavefront per DUP/INV/TRA cluster (m <= 64), arrays in LDS
+//             k_refine<64,256>                 one wavefront per cluster of 64 < m <= 256, arrays in LDS
+//             k_refine<256,2048>               one workgroup per cluster; LDS up to 2048 padded elements, global scratch above
+//   order     k_items_scan, k_emit             per-item counts -> two-level prefix -> dense, ordered call records + supports
+//   reads     k_reads_runs / _plan / _gather   start order of every reads block (whole sorted runs move)
+//             k_pmax_count / _scan             prefix max of read ends, span-local + one scan over the span maxima
+//   genotype  k_genotype<1024,4>, <8192,4>     one wavefront per call: 64-ary search, backwards stabbing scan, LDS hash
+//                                              set (4 KB, then 32 KB, then a global pool); k_genotype_tra for TRA calls
+//   results   k_publish                        calls + supports straight into page-locked caller arrays
 //
 // Reference semantics and file:line citations are in oracle/cutesv_oracle.c (the CPU restatement these
 // kernels are tested against) and include/cutesv_hip.h.  The path is integer sort/scan plus a little
