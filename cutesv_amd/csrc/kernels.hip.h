@@ -271,15 +271,18 @@ __device__ __forceinline__ int seg_of(const DevBatch& B, i64 w)
 
 // same for a wave-uniform w: all 64 lanes probe one segment each, one load round instead of a
 // dependent binary search (the segment table has ~120 entries for a genome)
-__device__ __forceinline__ int seg_of_wave(const DevBatch& B, i64 w)
+// segment of signature w, searched by the whole wavefront among the segments [klo, khi] (the range of w's chain tile, from
+// the host-built tile table: a reference with thousands of small contigs has thousands of segments, and a probe of the
+// whole table from every wavefront that crosses a boundary made k_chain_count 8x slower on an 8000-segment batch)
+__device__ __forceinline__ int seg_of_wave(const DevBatch& B, i64 w, int klo, int khi)
 {
-    for (int base = 0; base < B.n_seg; base += 64) {
+    for (int base = klo; base <= khi; base += 64) {
         const int l = base + lane_id();
-        const bool hit = l < B.n_seg && B.woff[l] <= w && w < B.woff[l + 1];
+        const bool hit = l <= khi && B.woff[l] <= w && w < B.woff[l + 1];
         const u64 mk = __ballot(hit);
         if (mk) return base + __ffsll((long long)mk) - 1;
     }
-    return 0;
+    return klo;
 }
 
 // ------------------------------------------------------------------------------------ chain
@@ -346,8 +349,8 @@ template <class Sink> __device__ __forceinline__ void chain_rows(const DevBatch&
     i64 bias = T.bias;
     if (T.k0 != T.k1) {                               // the tile spans segments: does this wavefront's span?
         const i64 lastw = (base + WAVE * CH_ITEMS - 1 < B.W) ? base + WAVE * CH_ITEMS - 1 : B.W - 1;
-        k0 = __builtin_amdgcn_readfirstlane(seg_of_wave(B, base));
-        const int k1 = __builtin_amdgcn_readfirstlane(seg_of_wave(B, lastw));
+        k0 = __builtin_amdgcn_readfirstlane(seg_of_wave(B, base, T.k0, T.k1));
+        const int k1 = __builtin_amdgcn_readfirstlane(seg_of_wave(B, lastw, T.k0, T.k1));
         if (k0 != k1) {                               // it does: per-row path
             int seg_hint = k0;
 #pragma unroll 1
@@ -482,8 +485,11 @@ __device__ __forceinline__ u64 chain_flag_row64(const DevBatch& B, i64 cb, int& 
     i64 bias = T.bias, seg_first = T.sf;
     int type = T.type, k0 = T.k0;
     if (T.k0 != T.k1 || cb < T.sf) {                   // not (known to be) inside the tile's own segment
-        k0 = __builtin_amdgcn_readfirstlane(seg_of_wave(B, cb));
-        const int k1 = __builtin_amdgcn_readfirstlane(seg_of_wave(B, lastw));
+        // (the 64 signatures lie in one chain tile - tiles are multiples of 64 - whose segment range bounds the search)
+        const int4 tr = B.tile_info[2 * (int)(cb / CH_TILE)];
+        const int rlo = __builtin_amdgcn_readfirstlane(tr.x), rhi = __builtin_amdgcn_readfirstlane(tr.y);
+        k0 = __builtin_amdgcn_readfirstlane(seg_of_wave(B, cb, rlo, rhi));
+        const int k1 = __builtin_amdgcn_readfirstlane(seg_of_wave(B, lastw, rlo, rhi));
         if (k0 != k1) {
             int hint = k0;
             i64 a0;

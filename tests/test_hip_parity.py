@@ -711,3 +711,22 @@ def test_whole_parse_read_on_the_gpu(ctx):
     from helpers import assert_parse_case
     for case in load_json("parse_reads.json.gz"):
         assert_parse_case(case, lambda *a, **k: extract.cigar_signatures(ctx, *a, **k), lambda enc, **k: extract.split_signatures(ctx, enc, **k))
+
+
+def test_thousands_of_small_segments(ctx):
+    """a reference with thousands of small contigs: 3000 (contig, type) segments of a few dozen signatures each, so that
+    every chain tile spans dozens of segments (the per-row path, the segment search bounded by the tile's range, the
+    look-back across segment boundaries); every field against the oracle"""
+    from cutesv_amd.columns import SigStore
+    rng = np.random.default_rng(12)
+    per = {"DEL": [], "INS": []}
+    for c in range(1500):
+        ch = "ctg%05d" % c
+        for site in range(int(rng.integers(1, 4))):
+            pos = 1000 + site * 5000
+            for r in range(int(rng.integers(3, 14))):
+                per["DEL"].append((pos + int(rng.integers(-5, 5)), 300 + int(rng.integers(-3, 3)), "d%d_%d_%d" % (c, site, r), "DEL", ch))
+                per["INS"].append((pos + 2000 + int(rng.integers(-5, 5)), 200 + int(rng.integers(-3, 3)), "i%d_%d_%d" % (c, site, r), "ACGT" * 50, "INS", ch))
+    st = SigStore.from_tuple_lists(per, [])
+    got = _compare_soa(ctx, st, Params.ont(min_support=3))
+    assert len(st.tasks()) == 3000 and len(got["bp1"]) > 1500
