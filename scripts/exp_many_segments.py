@@ -19,8 +19,13 @@ p = Params.ont()
 hb = st.host_batch(st.tasks(), p)
 print("segments %d signatures %d" % (len(hb.segments), hb.n_sig), flush=True)
 ctx = engine.Context(0)
-res = ctx.cluster_batch(hb)
-print("calls", res.n_calls)
+import time
+res = ctx.cluster_batch(hb, reuse=True)
+for name, b in (("pageable", hb), ("pinned", st.pinned().host_batch(st.tasks(), p))):
+    ts = []
+    for _ in range(5):
+        t0 = time.perf_counter(); res = ctx.cluster_batch(b, reuse=True); ts.append((time.perf_counter() - t0) * 1e3)
+    print("calls", res.n_calls, "one-shot ms (%s)" % name, ["%.2f" % t for t in ts])
 ctx.upload(hb, per_sig=False)
 for _ in range(5): ctx.run()
 ctx.sync()
