@@ -101,7 +101,7 @@ struct csv_ctx {
     Arena       arena, arena_rb;
     // batch buffers (slices of `arena`)
     Buf seg, woff, seg_drop, a, b, rid, aux;
-    Buf cluster_id, partial, partial64, item_rec, list_small, list_big, list_tiny, partial_t, seg_gate, tile_info, ch_masks, wave_items, wave_cnt, seg_err;
+    Buf cluster_id, partial, partial64, item_rec, list_small, list_big, list_tiny, list_wide, partial_t, seg_gate, tile_info, ch_masks, wave_items, wave_cnt, seg_err;
     Buf item_nslots, item_cnt, item_base, item_chunk, sup_tmp;
     Buf t_rec;
     Buf sc_k, sc_x, sc_v1, sc_v2, sc_v3, sc_v4, sc_v5;
@@ -446,7 +446,7 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
     PL(partial, nt * 4); PL(partial64, nt * 8); PL(partial_t, nt * 4);
     if (per_sig) PL(ch_masks, nt * 4 * CH_ITEMS * 8);
     PL(wave_items, nt * 4 * (size_t)WI_STRIDE * 16); PL(wave_cnt, nt * 4 * 16);
-    PL(item_rec, cap_items * 16); PL(list_small, cap_items * 16); PL(list_big, cap_items * 4); PL(list_tiny, cap_items * 16);
+    PL(item_rec, cap_items * 16); PL(list_small, cap_items * 16); PL(list_big, cap_items * 4); PL(list_tiny, cap_items * 16); PL(list_wide, cap_items * 16);
     PL(item_nslots, cap_items * 4); PL(item_cnt, cap_items * 8); PL(item_base, (cap_items + 8) * 8); PL(item_chunk, (cap_items / IS_CHUNK + 2) * 8);
     // temp call records are indexed by w (a cluster's slots live in its own signature range)
     PL(t_rec, (W + 1) * sizeof(TmpRec));
@@ -566,7 +566,7 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
     B.per_sig = per_sig ? 1 : 0;
     B.cluster_id = per_sig ? dp<int>(c->cluster_id) : nullptr; B.allele_id = per_sig ? dp<int>(c->allele_id) : nullptr;
     B.partial = dp<int>(c->partial); B.partial64 = dp<i64>(c->partial64);
-    B.item_rec = dp<int4>(c->item_rec); B.list_small = dp<int4>(c->list_small); B.list_big = dp<int>(c->list_big); B.list_tiny = dp<int4>(c->list_tiny);
+    B.item_rec = dp<int4>(c->item_rec); B.list_small = dp<int4>(c->list_small); B.list_big = dp<int>(c->list_big); B.list_tiny = dp<int4>(c->list_tiny); B.list_wide = dp<int4>(c->list_wide);
     B.partial_t = dp<int>(c->partial_t); B.seg_gate = dp<int4>(c->seg_gate); B.tile_info = dp<int4>(c->tile_info);
     B.ch_masks = per_sig ? dp<u64>(c->ch_masks) : nullptr; B.wave_items = dp<int4>(c->wave_items); B.wave_cnt = dp<int4>(c->wave_cnt);
     B.seg_err = dp<int>(c->seg_err);

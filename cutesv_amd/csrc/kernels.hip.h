@@ -91,6 +91,7 @@ struct DevCounters {          // one small struct in device memory, zeroed at th
     i64 n_support;
     int n_gt_over;            // calls whose support + cover did not fit the small hash set
     int n_items_tiny;         // DEL/INS work items of at most tiny_max signatures (four per wavefront)
+    int n_items_wide;         // DEL/INS work items of 33 .. 64 signatures (they are in the small list too): one per wavefront
     int n_runs;               // reads_order: sorted runs found in the reads table
     int ro_state;             // reads_order: RO_*
     int n_gt_huge;            // genotype: calls that need the whole global pool
@@ -121,6 +122,8 @@ struct DevBatch {
                                      // refine kernels need to issue their row loads straight after this ONE load
     int*           list_big;
     int4*          list_tiny;        // DEL/INS items with m <= tiny_max (same entries): k_refine_indel_wave packs four per wavefront
+    int4*          list_wide;        // DEL/INS items with 32 < m <= 64 (same entries, any order): their own units, so that no
+                                     // wavefront runs a pair and then its wide members one after the other
     int            tiny_max;         // 16 (0 switches the class off)
     u64*           ch_masks;         // per chain wavefront (512 signatures): its 8 flag masks (written only for CSV_IN_PER_SIG: k_chain_ids)
     int4*          wave_items;       // per chain wavefront, WI_STRIDE slots: the clusters that passed the size gate, in order:
@@ -433,12 +436,13 @@ __device__ __forceinline__ int4 gate_scalars(const DevBatch& B, const TileSeg& t
     if (ts.uni && k == ts.k) return make_int4(ts.rc, ts.drop, ts.type, 0);
     return B.seg_gate[k];
 }
-// gate of the cluster [s, e) (INDEL:62-64 and the drop rule): bit 0 work item, bit 1 workgroup tier, bit 2 tiny
+// gate of the cluster [s, e) (INDEL:62-64 and the drop rule): bit 0 work item, bit 1 workgroup tier, bit 2 tiny, bit 3 wide
+// (a DEL/INS cluster of 33 .. 64 signatures)
 __device__ __forceinline__ int close_gate(const DevBatch& B, const int4 g, int s, int e, int endz)
 {
     const int m = e - s;
     if (endz || m < g.x || g.y) return 0;
-    return 1 | ((m > 64) ? 2 : 0) | ((m <= B.tiny_max && g.z <= CSV_INS) ? 4 : 0);
+    return 1 | ((m > 64) ? 2 : 0) | ((m <= B.tiny_max && g.z <= CSV_INS) ? 4 : 0) | ((m > 32 && m <= 64 && m > B.tiny_max && g.z <= CSV_INS) ? 8 : 0);
 }
 
 // rows -> flags; the wavefront's cluster starts (bit 31: previous signature is (0,0)) and their segments go to its OWN
@@ -556,7 +560,7 @@ __global__ __launch_bounds__(320) void k_chain_count(DevBatch B)
         // own item region, in order, and k_chain_apply is a plain compaction of those records (it used to rebuild the start
         // lists from the masks and evaluate every gate a second time: 16 us of a 100 us step).
         const i64 gw = (i64)blockIdx.x * 4 + wv;
-        int n_sel = 0, n_big = 0, n_tiny = 0;               // wave-uniform counts: ballots + scalar popcounts, no VALU sums
+        int n_sel = 0, n_big = 0, n_tiny = 0, n_wide = 0;   // wave-uniform counts: ballots + scalar popcounts, no VALU sums
         for (int i0 = 0; i0 < (CSV_ABL(7) ? 0 : nc); i0 += 64) {
             const int i = i0 + lane_id();
             int fl = 0, s0c = 0, mc = 0, kt = 0;
@@ -575,9 +579,10 @@ __global__ __launch_bounds__(320) void k_chain_count(DevBatch B)
             }
             const u64 m_sel = __ballot(fl & 1);
             if (fl & 1) B.wave_items[gw * WI_STRIDE + n_sel + __popcll(m_sel & lanemask_lt())] = make_int4(s0c, mc, kt, i - 1);
-            n_sel += __popcll(m_sel); n_big += __popcll(__ballot(fl & 2)); n_tiny += __popcll(__ballot(fl & 4));
+            n_sel += __popcll(m_sel); n_big += __popcll(__ballot(fl & 2)); n_tiny += __popcll(__ballot(fl & 4)); n_wide += __popcll(__ballot(fl & 8));
         }
-        if (lane_id() == 0) { s_v[wv] = (i64)n_sel | ((i64)n_big << 32); s_t[wv] = n_tiny; B.wave_cnt[gw] = make_int4(cnt, n_sel, n_big, n_tiny); }
+        // (tiny and wide counts share a word: a wavefront has at most 513 items, a tile 2052)
+        if (lane_id() == 0) { s_v[wv] = (i64)n_sel | ((i64)n_big << 32); s_t[wv] = n_tiny | (n_wide << 16); B.wave_cnt[gw] = make_int4(cnt, n_sel, n_big, n_tiny | (n_wide << 16)); }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -597,17 +602,21 @@ __global__ __launch_bounds__(256) void k_chain_apply(DevBatch B)
     const i64 gw = (i64)blockIdx.x * 4 + wv;
     const bool last_tile = blockIdx.x == gridDim.x - 1;
     i64 p0 = 0, p1 = 0, p2 = 0;
-    for (int i = threadIdx.x; i < (int)blockIdx.x; i += 256) { p0 += B.partial[i]; p1 += B.partial64[i]; p2 += B.partial_t[i]; }
+    for (int i = threadIdx.x; i < (int)blockIdx.x; i += 256) {
+        const int tw = B.partial_t[i];                       // tiny | wide << 16 of tile i
+        p0 += B.partial[i]; p1 += B.partial64[i]; p2 += (i64)(tw & 0xffff) | ((i64)(tw >> 16) << 32);
+    }
     p0 = wave_sum_i64(p0); p1 = wave_sum_i64(p1); p2 = wave_sum_i64(p2);
     if (lane_id() == 0) { sh[wv] = p0; sh[4 + wv] = p1; sh[8 + wv] = p2; }
-    const int4 wc = B.wave_cnt[gw];                          // {cluster starts, work items, workgroup tier, tiny}
+    const int4 wc = B.wave_cnt[gw];                          // {cluster starts, work items, workgroup tier, tiny | wide << 16}
     int4 before = make_int4(0, 0, 0, 0);                    // ... of the tile's earlier wavefronts
-    for (int q = 0; q < wv; q++) { const int4 c = B.wave_cnt[gw - wv + q]; before.x += c.x; before.y += c.y; before.z += c.z; before.w += c.w; }
+    for (int q = 0; q < wv; q++) { const int4 c = B.wave_cnt[gw - wv + q]; before.x += c.x; before.y += c.y; before.z += c.z; before.w += c.w; }   // (.w: no carry between the halves, see above)
     __syncthreads();
     const i64 runs = sh[4] + sh[5] + sh[6] + sh[7];
     const int run = (int)(sh[0] + sh[1] + sh[2] + sh[3]) + before.x;          // id of the first cluster that STARTS in this wavefront's span
     const int bj = (int)(runs & 0xffffffffll) + before.y;
-    int bb = (int)(runs >> 32) + before.z, bt = (int)(sh[8] + sh[9] + sh[10] + sh[11]) + before.w;
+    const i64 tws = sh[8] + sh[9] + sh[10] + sh[11];
+    int bb = (int)(runs >> 32) + before.z, bt = (int)(tws & 0xffffffffll) + (before.w & 0xffff), bw = (int)(tws >> 32) + (before.w >> 16);
     const int n_it = __builtin_amdgcn_readfirstlane(wc.y);
     for (int base = 0; base < n_it; base += 64) {
         const int idx = base + lane_id();
@@ -615,7 +624,8 @@ __global__ __launch_bounds__(256) void k_chain_apply(DevBatch B)
         int4 rec = make_int4(0, 0, 0, 0);
         if (act) rec = B.wave_items[gw * WI_STRIDE + idx];
         const int tier = (rec.z >> 28) & 3;
-        const u64 m_big = __ballot(act && (tier & 1)), m_tiny = __ballot(act && (tier & 2));
+        const bool wide = act && ((rec.z >> 30) & 1);
+        const u64 m_big = __ballot(act && (tier & 1)), m_tiny = __ballot(act && (tier & 2)), m_wide = __ballot(wide);
         if (act) {
             const int j = bj + idx, jb = bb + __popcll(m_big & lanemask_lt()), jt = bt + __popcll(m_tiny & lanemask_lt());
             B.item_rec[j] = make_int4(run + rec.w, rec.z & 0xffffff, rec.x, rec.y);
@@ -623,12 +633,15 @@ __global__ __launch_bounds__(256) void k_chain_apply(DevBatch B)
             if (tier & 1) B.list_big[jb] = j;
             else if (tier & 2) B.list_tiny[jt] = ent;
             else B.list_small[j - jb - jt] = ent;
+            // DEL/INS items of 33 .. 64 signatures are ALSO listed on their own: k_refine_indel_wave gives each a wavefront
+            // instead of running them after the pair they sit in
+            if (wide) B.list_wide[bw + __popcll(m_wide & lanemask_lt())] = ent;
         }
-        bb += __popcll(m_big); bt += __popcll(m_tiny);
+        bb += __popcll(m_big); bt += __popcll(m_tiny); bw += __popcll(m_wide);
     }
     if (last_tile && threadIdx.x == 255) {                  // wavefront 3: its running counts now cover the whole batch
         B.cnt->n_clusters = run + wc.x;
-        B.cnt->n_items = bj + wc.y; B.cnt->n_items_big = bb; B.cnt->n_items_tiny = bt;
+        B.cnt->n_items = bj + wc.y; B.cnt->n_items_big = bb; B.cnt->n_items_tiny = bt; B.cnt->n_items_wide = bw;
         // tell the host whether the tiers above 64 signatures have any work: it peeks at these page-locked words while
         // the wavefront tier runs and launches k_refine<64,256> / k_refine<256,2048> only then (a missing or late answer
         // just means that they are launched as before)
@@ -1811,25 +1824,27 @@ __global__ __launch_bounds__(256, CSV_IW_WAVES) void k_refine_indel_wave(DevBatc
     // Units: the pairs of the small list, then the quads of the tiny list (clusters of at most 16 signatures: four per
     // wavefront, a sub-wave is one DPP row); unit u goes to wavefront u mod nwaves.  A unit costs two dependent round
     // trips: its list entries, then its rows.
-    const int n_pair = (nsmall + 1) / 2, n_quad = (ntiny + 3) / 4;
+    const int n_pair = (nsmall + 1) / 2, n_quad = (ntiny + 3) / 4, n_wide = B.cnt->n_items_wide;
     for (int p = wave; p < n_pair; p += nwaves) {
         UnitIn U;
         unit_rows(B, unit_entry(B.list_small, p, nsmall, 5), 5, 0, U);
-        const int wide = __builtin_amdgcn_readfirstlane(indel_unit<32>(B, U));
-        for (int h = 0; h < 2; h++)
-            if (wide & (1 << h)) {                         // a pair member with 32 < m <= 64: the one-cluster-per-wavefront form
-                UnitIn Wd;
-                unit_rows(B, unit_entry(B.list_small, 2 * p + h, nsmall, 6), 6, 32, Wd);
-                indel_unit<64>(B, Wd);
-            }
+        indel_unit<32>(B, U);                              // (members with 32 < m <= 64 are skipped here: they are units of their own)
     }
-    // (the quads continue the round-robin where the pairs stopped, so that every wavefront gets its share of both)
+    // (the quads, then the wide items, continue the round-robin where the previous kind stopped, so that every wavefront
+    // gets its share of each - with fewer units than wavefronts, the usual case, nobody gets two)
     int q0 = wave - n_pair % nwaves;
     if (q0 < 0) q0 += nwaves;
     for (int p = q0; p < n_quad; p += nwaves) {
         UnitIn U;
         unit_rows(B, unit_entry(B.list_tiny, p, ntiny, 4), 4, 0, U);
         indel_unit<16>(B, U);
+    }
+    int w0 = wave - (int)(((i64)n_pair + n_quad) % nwaves);
+    if (w0 < 0) w0 += nwaves;
+    for (int p = w0; p < n_wide; p += nwaves) {            // 32 < m <= 64: the one-cluster-per-wavefront form
+        UnitIn U;
+        unit_rows(B, unit_entry(B.list_wide, p, n_wide, 6), 6, 32, U);
+        indel_unit<64>(B, U);
     }
 }
 
