@@ -1821,30 +1821,31 @@ __global__ __launch_bounds__(256, CSV_IW_WAVES) void k_refine_indel_wave(DevBatc
 {
     const int ntiny = B.cnt->n_items_tiny, nsmall = B.cnt->n_items - B.cnt->n_items_big - ntiny;
     const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * 256 + threadIdx.x) >> 6), nwaves = (gridDim.x * 256) >> 6;
-    // Units: the pairs of the small list, then the quads of the tiny list (clusters of at most 16 signatures: four per
-    // wavefront, a sub-wave is one DPP row); unit u goes to wavefront u mod nwaves.  A unit costs two dependent round
-    // trips: its list entries, then its rows.
+    // Units: the wide items (one cluster of 33 .. 64 signatures per wavefront), the pairs of the small list, the quads of the
+    // tiny list (clusters of at most 16 signatures: four per wavefront, a sub-wave is one DPP row); unit u goes to wavefront
+    // u mod nwaves.  A unit costs two dependent round trips: its list entries, then its rows.
     const int n_pair = (nsmall + 1) / 2, n_quad = (ntiny + 3) / 4, n_wide = B.cnt->n_items_wide;
-    for (int p = wave; p < n_pair; p += nwaves) {
+    // Longest first: the wide items (32 < m <= 64, the one-cluster-per-wavefront form, about twice a pair's latency) go to
+    // the wavefronts that are dispatched first, then the pairs, then the quads; each kind continues the round-robin where
+    // the previous one stopped, so with fewer units than wavefronts - the usual case - nobody gets two.
+    for (int p = wave; p < n_wide; p += nwaves) {
+        UnitIn U;
+        unit_rows(B, unit_entry(B.list_wide, p, n_wide, 6), 6, 32, U);
+        indel_unit<64>(B, U);
+    }
+    int p0 = wave - n_wide % nwaves;
+    if (p0 < 0) p0 += nwaves;
+    for (int p = p0; p < n_pair; p += nwaves) {
         UnitIn U;
         unit_rows(B, unit_entry(B.list_small, p, nsmall, 5), 5, 0, U);
         indel_unit<32>(B, U);                              // (members with 32 < m <= 64 are skipped here: they are units of their own)
     }
-    // (the quads, then the wide items, continue the round-robin where the previous kind stopped, so that every wavefront
-    // gets its share of each - with fewer units than wavefronts, the usual case, nobody gets two)
-    int q0 = wave - n_pair % nwaves;
+    int q0 = wave - (int)(((i64)n_wide + n_pair) % nwaves);
     if (q0 < 0) q0 += nwaves;
     for (int p = q0; p < n_quad; p += nwaves) {
         UnitIn U;
         unit_rows(B, unit_entry(B.list_tiny, p, ntiny, 4), 4, 0, U);
         indel_unit<16>(B, U);
-    }
-    int w0 = wave - (int)(((i64)n_pair + n_quad) % nwaves);
-    if (w0 < 0) w0 += nwaves;
-    for (int p = w0; p < n_wide; p += nwaves) {            // 32 < m <= 64: the one-cluster-per-wavefront form
-        UnitIn U;
-        unit_rows(B, unit_entry(B.list_wide, p, n_wide, 6), 6, 32, U);
-        indel_unit<64>(B, U);
     }
 }
 
