@@ -126,6 +126,7 @@ struct csv_ctx {
     volatile int* h_flag = nullptr;
     int*          d_flag = nullptr;
     int           run_seq = 0;
+    int           n_cu = 256;              // compute units of the device
     // host copies
     std::vector<csv_segment> h_seg;
     std::vector<i64>         h_woff;
@@ -284,6 +285,7 @@ int csv_ctx_create(int device_id, csv_ctx** out)
     csv_ctx* c = new csv_ctx();
     c->device = device_id;
     if (hipSetDevice(device_id) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) { delete c; return CSV_E_HIP; }
+    if (hipDeviceGetAttribute(&c->n_cu, hipDeviceAttributeMultiprocessorCount, device_id) != hipSuccess || c->n_cu < 1) c->n_cu = 256;
     for (auto& e : c->ev) if (hipEventCreate(&e) != hipSuccess) { delete c; return CSV_E_HIP; }
     {
         // side[2] carries the reads stage, whose critical path runs through two single-workgroup kernels (k_reads_plan,
@@ -709,9 +711,11 @@ int run_impl(csv_ctx* c, csv_run_stats* stats)
         if (c->copies_pending) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_copy[1], 0));   // read ids, INS sequence lengths
         int g_small = B.cap_items < 8192 ? B.cap_items : 8192;
         if (g_small < 1) g_small = 1;
-        // (3072 workgroups = 12 288 wavefronts: a 30x genome has ~10 k units, and a wavefront with two units is the
-        // kernel's tail - 2048 workgroups measured 42.5 us, 3072 and 4096 38.6 us, 1280 - the resident set - 48 us)
-        int g_iw = div_up(B.cap_items, 4) < 3072 ? div_up(B.cap_items, 4) : 3072;
+        // (the resident set: CSV_IW_WAVES wavefronts per SIMD on every CU.  The units are dealt longest first, so a grid
+        // that is resident at once finishes sooner than one whose last workgroups wait for a slot: 23.1 vs 23.5 us on cfg3
+        // with 1536 vs 3072 workgroups)
+        const int g_res = c->n_cu * CSV_IW_WAVES;
+        int g_iw = div_up(B.cap_items, 4) < g_res ? div_up(B.cap_items, 4) : g_res;
         g_iw = env_int("CSV_IW_GRID", g_iw);              // tuning aid
         if (g_iw < 1) g_iw = 1;
         if (fork) {

@@ -1567,7 +1567,7 @@ __device__ __forceinline__ void unit_rows(const DevBatch& B, const int4 e, int s
 }
 
 #ifndef CSV_IW_WAVES
-#define CSV_IW_WAVES 5
+#define CSV_IW_WAVES 6
 #endif
 // one unit of work: SW = 32 -> the pair of items (2p, 2p + 1), each handled if m <= 32;
 //                   SW = 64 -> the single item p, handled if 32 < m <= 64.  Returns (SW = 32 only) a 2-bit mask
@@ -1826,23 +1826,25 @@ __global__ __launch_bounds__(256, CSV_IW_WAVES) void k_refine_indel_wave(DevBatc
     // u mod nwaves.  A unit costs two dependent round trips: its list entries, then its rows.
     const int n_pair = (nsmall + 1) / 2, n_quad = (ntiny + 3) / 4, n_wide = B.cnt->n_items_wide;
     // Longest first: the wide items (32 < m <= 64, the one-cluster-per-wavefront form, about twice a pair's latency) go to
-    // the wavefronts that are dispatched first, then the pairs, then the quads; each kind continues the round-robin where
-    // the previous one stopped, so with fewer units than wavefronts - the usual case - nobody gets two.
+    // the wavefronts that are dispatched first; the pairs and then the quads are dealt round-robin over the OTHER
+    // wavefronts, so that a wavefront that already has a wide item is not also the one that gets a second unit when there
+    // are more units than wavefronts.  (More wide items than wavefronts - deep coverage - : everything over all of them.)
     for (int p = wave; p < n_wide; p += nwaves) {
         UnitIn U;
         unit_rows(B, unit_entry(B.list_wide, p, n_wide, 6), 6, 32, U);
         indel_unit<64>(B, U);
     }
-    int p0 = wave - n_wide % nwaves;
-    if (p0 < 0) p0 += nwaves;
-    for (int p = p0; p < n_pair; p += nwaves) {
+    const int skip = n_wide < nwaves ? n_wide : 0, M = nwaves - skip;
+    if (wave < skip) return;
+    const int slot = wave - skip;
+    for (int p = slot; p < n_pair; p += M) {
         UnitIn U;
         unit_rows(B, unit_entry(B.list_small, p, nsmall, 5), 5, 0, U);
         indel_unit<32>(B, U);                              // (members with 32 < m <= 64 are skipped here: they are units of their own)
     }
-    int q0 = wave - (int)(((i64)n_wide + n_pair) % nwaves);
-    if (q0 < 0) q0 += nwaves;
-    for (int p = q0; p < n_quad; p += nwaves) {
+    int q0 = slot - n_pair % M;                            // the quads continue the round-robin where the pairs stopped
+    if (q0 < 0) q0 += M;
+    for (int p = q0; p < n_quad; p += M) {
         UnitIn U;
         unit_rows(B, unit_entry(B.list_tiny, p, ntiny, 4), 4, 0, U);
         indel_unit<16>(B, U);
