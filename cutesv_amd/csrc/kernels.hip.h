@@ -23,6 +23,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "../../include/cutesv_hip.h"
 
 // Measurement aid (scripts/ablate.sh): -DCSV_ABLATE=<bit mask> drops a section of a kernel so that its share of the
@@ -362,7 +363,7 @@ template <class Sink> __device__ __forceinline__ void chain_rows(const DevBatch&
                 i64 a0;
                 const int f = chain_flag(B, w, seg_hint, a0, k1);
                 const u64 zm = __ballot(f && w > 0 && w < B.W && a0 == 0 && B.b[w > 0 ? w - 1 : 0] == 0);
-                sink(r, __ballot(f), zm, seg_hint);
+                sink(r, f != 0, __ballot(f), zm, seg_hint);
             }
             return;
         }
@@ -371,25 +372,30 @@ template <class Sink> __device__ __forceinline__ void chain_rows(const DevBatch&
         bias = readlane_i64x(sg.max_cluster_bias, 0);
         sf = __builtin_amdgcn_readfirstlane((int)B.woff[k0]); type = __builtin_amdgcn_readfirstlane(sg.svtype);
     }
+    // INNER: the span lies wholly inside the batch and does not begin it (every wavefront but a handful): no range tests
+    auto rows = [&](auto inner_tag) {
+        constexpr bool INNER = decltype(inner_tag)::value;
 #pragma unroll
-    for (int r = 0; r < CH_ITEMS; r++) {
-        const int w = w0 + r * WAVE + lane;
-        i64 a0 = wave_shr1_i64(a[r]);
-        if (lane == 0) a0 = left;
-        left = readlane_i64x(a[r], 63);                 // (v_readlane: the next row's lane 0 reads it back as a scalar)
-        const bool in = w < nW;
-        bool f = in && (w == sf || a[r] - a0 > bias);
-        // a (0,0) predecessor looks like the reference's sentinel: only a signature at position 0 can be one, so the
-        // length column is touched behind a wave-uniform test that almost never fires
-        bool z = false;
-        const bool zc = in && w > 0 && a0 == 0;
-        if (__ballot(zc)) z = zc && B.b[w - 1] == 0;
-        if (type == CSV_INV) { if (in && !f && !z && w != sf) f = (B.b[w] - B.b[w - 1] > bias) || (B.aux[w] != B.aux[w - 1]); }
-        else if (type == CSV_TRA) { if (in && !f && !z && w != sf) f = B.aux[w] != B.aux[w - 1]; }
-        if (z && w != sf) f = true;
-        const u64 zm = __ballot(f && z);
-        sink(r, __ballot(f), zm, k0);
-    }
+        for (int r = 0; r < CH_ITEMS; r++) {
+            const int w = w0 + r * WAVE + lane;
+            i64 a0 = wave_shr1_i64(a[r]);
+            if (lane == 0) a0 = left;
+            left = readlane_i64x(a[r], 63);             // (v_readlane: the next row's lane 0 reads it back as a scalar)
+            const bool in = INNER || w < nW;
+            bool f = in && (w == sf || a[r] - a0 > bias);
+            // a (0,0) predecessor looks like the reference's sentinel: only a signature at position 0 can be one, so the
+            // length column is touched behind a wave-uniform test that almost never fires
+            bool z = false;
+            const bool zc = in && (INNER || w > 0) && a0 == 0;
+            if (__ballot(zc)) z = zc && B.b[w - 1] == 0;
+            if (type == CSV_INV) { if (in && !f && !z && w != sf) f = (B.b[w] - B.b[w - 1] > bias) || (B.aux[w] != B.aux[w - 1]); }
+            else if (type == CSV_TRA) { if (in && !f && !z && w != sf) f = B.aux[w] != B.aux[w - 1]; }
+            if (z && w != sf) f = true;
+            const u64 zm = __ballot(f && z);
+            sink(r, f, __ballot(f), zm, k0);
+        }
+    };
+    if (base > 0 && base + WAVE * CH_ITEMS <= B.W) rows(std::true_type{}); else rows(std::false_type{});
 }
 constexpr int EM_TILE = 8;                          // items per emit wavefront
 constexpr int EM_SUPER = 512;                       // items per second-level sum
@@ -454,8 +460,8 @@ __device__ __forceinline__ int wave_starts(const DevBatch& B, i64 base, const Ti
 {
     int off = 0;
     u64 pb = 0;
-    chain_rows(B, base, T, [&](int r, u64 m, u64 zm, int kseg) {
-        if (!CSV_ABL(8) && ((m >> lane_id()) & 1)) {
+    chain_rows(B, base, T, [&](int r, bool f, u64 m, u64 zm, int kseg) {
+        if (!CSV_ABL(8) && f) {
             const int idx = off + __popcll(m & lanemask_lt());
             int v = (int)base + r * WAVE + lane_id();
             if (zm) v |= (int)((zm >> lane_id()) & 1) << 31;               // (wave-uniform test: the mask is almost always 0)
