@@ -757,8 +757,8 @@ int run_impl(csv_ctx* c, csv_run_stats* stats)
         if (do_gt) {
             if (fork) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_aux[2], 0));
             else { HIP_TRY(c, hipStreamWaitEvent(st, c->ev_reads, 0)); const int rc = reads_stage(st); if (rc) return rc; }
-            hipLaunchKernelGGL((k_genotype<1024, 4>), dim3(2048), dim3(256), 0, st, B, 0);
-            hipLaunchKernelGGL((k_genotype<8192, 4>), dim3(256), dim3(256), 0, st, B, 1);     // overflow list of the first pass; global tables beyond
+            hipLaunchKernelGGL((k_genotype<1024, 4, false>), dim3(2048), dim3(256), 0, st, B);
+            hipLaunchKernelGGL((k_genotype<8192, 4, true>), dim3(256), dim3(256), 0, st, B);     // overflow list of the first pass; global tables beyond
             DBG("genotype");
             HIP_TRY(c, mark());
         } else if (stats) { for (int q = 0; q < 4; q++) HIP_TRY(c, mark()); }

@@ -2635,8 +2635,12 @@ __device__ bool genotype_global(const DevBatch& B, const ReadsView& V, const GtH
     return true;
 }
 
-template <int HASH, int WPB> __global__ __launch_bounds__(64 * WPB) void k_genotype(DevBatch B, int second)
+// SECOND is a template parameter so that the first pass - the one every call goes through - does not carry the code and the
+// registers of the global-pool path (as a run-time argument: 28 scalar spills and 16 bytes of scratch per lane in the hot
+// kernel; cfg-4 56.7 -> 40.6 us, cfg-5 136 -> 116 us)
+template <int HASH, int WPB, bool SECOND> __global__ __launch_bounds__(64 * WPB) void k_genotype(DevBatch B)
 {
+    constexpr int second = SECOND ? 1 : 0;
     __shared__ int tabs[WPB][HASH];
     __shared__ int s_red[WPB], s_last;
     int* tab = tabs[threadIdx.x >> 6];
@@ -2671,16 +2675,18 @@ template <int HASH, int WPB> __global__ __launch_bounds__(64 * WPB) void k_genot
             if (W.n == 2 && !overflow) dr += cover_window<HASH>(B, V, tab, r0, r1, W.Lb, W.Rb, filled, overflow);
         }
         if (overflow) {                                                       // wave-uniform
-            if (!second) { if (lane_id() == 0) B.gt_over[atomicAdd(&B.cnt->n_gt_over, 1)] = c; continue; }
-            // deeper than the 32 KB tables: this wavefront's slice of the global pool ...
-            const i64 slice = B.gt_pool_n / nwaves;
-            if (!genotype_global(B, V, cur, B.gt_pool + (i64)wave * slice, slice, lane_id(), 64, false, s_red) && lane_id() == 0)
-                B.gt_huge[atomicAdd(&B.cnt->n_gt_huge, 1)] = c;               // ... or, later, the whole pool
-            continue;
+            if constexpr (!SECOND) { if (lane_id() == 0) B.gt_over[atomicAdd(&B.cnt->n_gt_over, 1)] = c; continue; }
+            else {
+                // deeper than the 32 KB tables: this wavefront's slice of the global pool ...
+                const i64 slice = B.gt_pool_n / nwaves;
+                if (!genotype_global(B, V, cur, B.gt_pool + (i64)wave * slice, slice, lane_id(), 64, false, s_red) && lane_id() == 0)
+                    B.gt_huge[atomicAdd(&B.cnt->n_gt_huge, 1)] = c;           // ... or, later, the whole pool
+                continue;
+            }
         }
         if (lane_id() == 0) ((int4*)&B.o_rec[c])[4] = make_int4(dr, (int)ns, gl_index_dev(dr, ns), 0);
     }
-    if (!second) return;
+    if constexpr (!SECOND) return;
     // the last workgroup to get here owns the whole pool (every other one is done with its slice) and finishes the
     // calls that needed more than a slice, one at a time
     __syncthreads();
