@@ -642,7 +642,7 @@ int run_impl(csv_ctx* c, csv_run_stats* stats)
     constexpr int LDS_BIG = refine_lds_bytes<2048>();
     constexpr int LDS_PLAN = RO_CAP * 16 + 64;
     if (!c->lds_set) {
-        HIP_TRY(c, hipFuncSetAttribute((const void*)k_refine<256, 2048>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BIG));
+        HIP_TRY(c, hipFuncSetAttribute((const void*)k_refine<256, 2048, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BIG));
         HIP_TRY(c, hipFuncSetAttribute((const void*)k_reads_plan, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_PLAN));
         c->lds_set = true;
     }
@@ -724,7 +724,7 @@ int run_impl(csv_ctx* c, csv_run_stats* stats)
             if (c->any_pair) HIP_TRY(c, hipStreamWaitEvent(sC, c->ev_sel, 0));
         }
         LAUNCH("refine_indel_wave", k_refine_indel_wave, g_iw, 256, 0, B);
-        if (c->any_pair) LAUNCH_ON(sC, "refine_wave", (k_refine<64, 64>), g_small, 64, LDS_SMALL, B, 0, 0, 64);
+        if (c->any_pair) LAUNCH_ON(sC, "refine_wave", (k_refine<64, 64, false>), g_small, 64, LDS_SMALL, B, 0, 64);
         else HIP_TRY(c, mark());
         // The tiers above 64 signatures usually have nothing to do (a 30x genome has no such cluster) and an empty launch
         // still costs ~4 us of the stream: while the wavefront tier runs, peek at the two page-locked words k_chain_apply
@@ -744,8 +744,8 @@ int run_impl(csv_ctx* c, csv_run_stats* stats)
         int g_big = B.cap_items < 512 ? B.cap_items : 512;
         if (g_big < 1) g_big = 1;
         if (need_big) {
-            LAUNCH_ON(sB, "refine_mid", (k_refine<64, 256>), g_mid, 64, LDS_MID, B, 1, 64, 256);
-            LAUNCH_ON(sB, "refine_block", (k_refine<256, 2048>), g_big, 256, LDS_BIG, B, 1, 256, 0x7fffffff);
+            LAUNCH_ON(sB, "refine_mid", (k_refine<64, 256, true>), g_mid, 64, LDS_MID, B, 64, 256);
+            LAUNCH_ON(sB, "refine_block", (k_refine<256, 2048, true>), g_big, 256, LDS_BIG, B, 256, 0x7fffffff);
         } else { HIP_TRY(c, mark()); HIP_TRY(c, mark()); }
         if (fork) {                                       // join
             HIP_TRY(c, hipEventRecord(c->ev_aux[0], sB));

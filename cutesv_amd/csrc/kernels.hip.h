@@ -1373,8 +1373,11 @@ template <int CAP> constexpr int refine_lds_bytes() { return LDS_LEAD + (CAP + A
 #ifndef CSV_RF_WAVES
 #define CSV_RF_WAVES 4
 #endif
-template <int BLOCK, int CAP> __global__ __launch_bounds__(BLOCK, (BLOCK == 64 ? CSV_RF_WAVES : 1)) void k_refine(DevBatch B, int big, int m_lo, int m_hi)
+// BIG (which list) is a template parameter: the small-list instantiation handles DUP / INV / TRA only (DEL / INS of up to 64
+// signatures belong to k_refine_indel_wave) and so carries neither the code nor the registers of refine_indel
+template <int BLOCK, int CAP, bool BIG> __global__ __launch_bounds__(BLOCK, (BLOCK == 64 ? CSV_RF_WAVES : 1)) void k_refine(DevBatch B, int m_lo, int m_hi)
 {
+    constexpr int big = BIG ? 1 : 0;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     CSV_LDS char* smem = (CSV_LDS char*)smem_raw + LDS_LEAD;
     constexpr int N = CAP + ARR_PAD;
@@ -1405,8 +1408,8 @@ template <int BLOCK, int CAP> __global__ __launch_bounds__(BLOCK, (BLOCK == 64 ?
         const int t = B.seg[it.k].svtype;
         const bool indel = t == CSV_DEL || t == CSV_INS;
         if (P <= CAP) {
-            if (indel) refine_indel<BLOCK, true, (CAP <= 256)>(B, it, L, red, ired);
-            else refine_pair<BLOCK, true>(B, it, L, red, ired);
+            if constexpr (BIG) { if (indel) { refine_indel<BLOCK, true, (CAP <= 256)>(B, it, L, red, ired); continue; } }
+            refine_pair<BLOCK, true>(B, it, L, red, ired);
         } else if constexpr (CAP <= 256) {
             // the one-wavefront tiers are only launched for m <= CAP; keeping the global-scratch path (and its
             // serial np.std routine with a private stack) out of them keeps these kernels free of scratch
