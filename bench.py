@@ -297,7 +297,9 @@ def main():
         t_rows = timed(lambda: rows_mod.rows_by_segment(pstore, phb.segments, r2), 3)
         t_stage = timed(lambda: resolve.cluster_stage(pstore, params, tasks=tasks, ctx=ctx), 5)
         n_rows = sum(len(v) for v in resolve.cluster_stage(pstore, params, tasks=tasks, ctx=ctx).values())
-        h2d_bytes = 24 * n_sig + (21 * int(phb.r_start.shape[0]) if phb.r_start is not None else 0)
+        # (bytes per signature / read as the ABI defines the columns; positions and lengths travel as int32 when the store
+        # keeps narrow twins - CSV_IN_SIG_I32 / CSV_IN_READS_I32)
+        h2d_bytes = (2 * phb.a.dtype.itemsize + 8) * n_sig + ((2 * phb.r_start.dtype.itemsize + 5) * int(phb.r_start.shape[0]) if phb.r_start is not None else 0)
         # native VCF record emit straight from the SoA (no Python rows).  ignore_sequence: a 3.1 Gbp synthetic reference is
         # not materialised for the benchmark, so REF/ALT are 'N' / '<TYPE>' as with cuteSV's --ignore_sequence; pair types
         # (which always look up one base) are left out of this timing

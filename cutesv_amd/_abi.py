@@ -18,7 +18,7 @@ ERR_NAME = {OK: "CSV_OK", E_INVALID: "CSV_E_INVALID", E_CAPACITY: "CSV_E_CAPACIT
             E_NOMEM: "CSV_E_NOMEM", E_UNSORTED: "CSV_E_UNSORTED", E_STATE: "CSV_E_STATE"}
 N_STAGES = 24
 GL_TABLE_SIZE = 101 * 101 + 2
-IN_PER_SIG, IN_READS_SORTED = 1, 2            # csv_batch_in.flags
+IN_PER_SIG, IN_READS_SORTED, IN_SIG_I32, IN_READS_I32 = 1, 2, 4, 8            # csv_batch_in.flags
 SEG_KEY_RANGE = 1                             # csv_batch_out.seg_status bits
 
 # numpy dtype with exactly the C layout of `csv_segment` (all members naturally aligned)
@@ -85,8 +85,10 @@ class HostBatch:
     def __init__(self, segments, a, b, read_id, aux, n_chrom=0, reads_off=None,
                  r_start=None, r_end=None, r_primary=None, r_id=None, contig_len=None, per_sig=False, reads_sorted=False):
         self.segments = np.ascontiguousarray(segments, dtype=SEGMENT_DTYPE)
-        self.a = _col(a, np.int64)
-        self.b = _col(b, np.int64)
+        # positions / lengths may come as int32 columns (CSV_IN_SIG_I32: a third less data on the link); both alike
+        sig32 = getattr(a, "dtype", None) == np.int32 and getattr(b, "dtype", None) == np.int32
+        self.a = _col(a, np.int32 if sig32 else np.int64)
+        self.b = _col(b, np.int32 if sig32 else np.int64)
         self.read_id = _col(read_id, np.int32)
         self.aux = _col(aux, np.int32)
         n = self.a.shape[0]
@@ -95,8 +97,9 @@ class HostBatch:
         self.n_chrom = int(n_chrom)
         if reads_off is not None:
             self.reads_off = _col(reads_off, np.int64)
-            self.r_start = _col(r_start, np.int64)
-            self.r_end = _col(r_end, np.int64)
+            rd32 = getattr(r_start, "dtype", None) == np.int32 and getattr(r_end, "dtype", None) == np.int32
+            self.r_start = _col(r_start, np.int32 if rd32 else np.int64)
+            self.r_end = _col(r_end, np.int32 if rd32 else np.int64)
             self.r_primary = _col(r_primary, np.uint8)
             self.r_id = _col(r_id, np.int32)
             if self.reads_off.shape[0] != self.n_chrom + 1:
@@ -113,7 +116,20 @@ class HostBatch:
             n_reads=0 if self.r_start is None else self.r_start.shape[0],
             r_start=_ptr(self.r_start), r_end=_ptr(self.r_end), r_primary=_ptr(self.r_primary), r_id=_ptr(self.r_id),
             contig_len=_ptr(self.contig_len),
-            flags=(IN_PER_SIG if per_sig else 0) | (IN_READS_SORTED if reads_sorted else 0))
+            flags=(IN_PER_SIG if per_sig else 0) | (IN_READS_SORTED if reads_sorted else 0) | (IN_SIG_I32 if self.a.dtype == np.int32 else 0)
+            | (IN_READS_I32 if self.r_start is not None and self.r_start.dtype == np.int32 else 0))
+
+    def widened(self):
+        """the same batch with int64 position columns (what the oracle takes)"""
+        if self.a.dtype != np.int32 and (self.r_start is None or self.r_start.dtype != np.int32):
+            return self
+        kw = {}
+        if self.reads_off is not None:
+            kw = dict(reads_off=self.reads_off, r_start=self.r_start.astype(np.int64), r_end=self.r_end.astype(np.int64),
+                      r_primary=self.r_primary, r_id=self.r_id)
+        flags = self.c.flags
+        return HostBatch(self.segments, self.a.astype(np.int64), self.b.astype(np.int64), self.read_id, self.aux, n_chrom=self.n_chrom,
+                         contig_len=self.contig_len, per_sig=bool(flags & IN_PER_SIG), reads_sorted=bool(flags & IN_READS_SORTED), **kw)
 
     @property
     def n_sig(self):

@@ -110,6 +110,7 @@ class SigStore:
     r_primary: np.ndarray = None
     r_id: np.ndarray = None
     contig_len: np.ndarray = None                 # reference lengths per chromosome (TRA genotyping windows)
+    narrow: dict = None                           # pinned(): int32 twins of a / b / r_start / r_end (what travels to the GPU)
 
     # ------------------------------------------------------------------ basic access
     @property
@@ -144,10 +145,23 @@ class SigStore:
         import dataclasses
         from . import engine
         cols = {}
-        for k in ("a", "b", "read_id", "aux", "reads_off", "r_start", "r_end", "r_primary", "r_id", "contig_len"):
+        for k in ("read_id", "aux", "reads_off", "r_primary", "r_id", "contig_len"):
             v = getattr(self, k)
             cols[k] = None if v is None else engine.pinned_copy(v)
-        return dataclasses.replace(self, **cols)
+        # positions and lengths: int32 twins when they fit (a genome's coordinates do) - a third less data on the link
+        # (CSV_IN_SIG_I32 / CSV_IN_READS_I32); the int64 columns stay what every host-side consumer reads
+        narrow = {}
+        for pair in (("a", "b"), ("r_start", "r_end")):
+            vs = [getattr(self, k) for k in pair]
+            if vs[0] is None:
+                continue
+            fits = all(len(v) == 0 or (int(v.min()) >= -(1 << 31) and int(v.max()) < (1 << 31)) for v in vs)
+            for k, v in zip(pair, vs):
+                if fits:
+                    narrow[k] = engine.pinned_copy(v.astype(np.int32))
+                else:
+                    cols[k] = engine.pinned_copy(v)
+        return dataclasses.replace(self, narrow=narrow or None, **cols)
 
     # ------------------------------------------------------------------ string tables for the native row / VCF emitters
     def names_blob(self):
@@ -232,12 +246,13 @@ class SigStore:
         segs = np.array([self.segment(t, ch, p) for t, ch in tasks], dtype=_abi.SEGMENT_DTYPE)
         need_reads = bool(segs["genotype"].any()) if len(segs) else False
         kw = {}
+        nw = self.narrow or {}
         if need_reads and self.reads_off is not None:
-            kw = dict(reads_off=self.reads_off, r_start=self.r_start, r_end=self.r_end,
+            kw = dict(reads_off=self.reads_off, r_start=nw.get("r_start", self.r_start), r_end=nw.get("r_end", self.r_end),
                       r_primary=self.r_primary, r_id=self.r_id)
             if bool(((segs["svtype"] == _abi.TRA) & (segs["genotype"] != 0)).any()):
                 kw["contig_len"] = self.contig_len
-        return _abi.HostBatch(segs, self.a, self.b, self.read_id, self.aux, n_chrom=len(self.chroms), **kw)
+        return _abi.HostBatch(segs, nw.get("a", self.a), nw.get("b", self.b), self.read_id, self.aux, n_chrom=len(self.chroms), **kw)
 
     # ------------------------------------------------------------------ persistence (flat .cols directory)
     def save(self, path):

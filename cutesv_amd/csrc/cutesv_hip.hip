@@ -100,7 +100,7 @@ struct csv_ctx {
     hipEvent_t  ev[CSV_N_STAGES + 2] = {};
     Arena       arena, arena_rb;
     // batch buffers (slices of `arena`)
-    Buf seg, woff, seg_drop, a, b, rid, aux;
+    Buf seg, woff, seg_drop, a, b, rid, aux, a32, b32, rs32, re32;
     Buf cluster_id, partial, partial64, item_rec, list_small, list_big, list_tiny, list_wide, partial_t, seg_gate, tile_info, ch_masks, wave_items, wave_cnt, seg_err;
     Buf item_nslots, item_cnt, item_base, item_chunk, sup_tmp;
     Buf t_rec;
@@ -443,6 +443,8 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
     PL(seg, (S + 1) * sizeof(csv_segment)); PL(woff, (S + 2) * sizeof(i64)); PL(seg_drop, S + 1); PL(seg_gate, (S + 1) * 16); PL(seg_err, (S + 1) * 4);
     PL(tile_info, nt * 32);
     PL(a, (W + 1) * 8); PL(b, (W + 1) * 8); PL(rid, (W + 1) * 4); PL(aux, (W + 1) * 4);
+    const bool sig32 = (in->flags & CSV_IN_SIG_I32) != 0, rd32 = (in->flags & CSV_IN_READS_I32) != 0;
+    if (sig32) { PL(a32, (W + 1) * 4); PL(b32, (W + 1) * 4); }
     PL(sup_tmp, (W + 1) * 4);
     if (per_sig) { PL(cluster_id, (W + 1) * 4); PL(allele_id, (W + 1) * 4); }
     PL(partial, nt * 4); PL(partial64, nt * 8); PL(partial_t, nt * 4);
@@ -458,6 +460,7 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
     if (R > 0) {
         PL(pm_partial, (div_up(R, 512) + 8) * 8); PL(pm_pre, (div_up(R, 512) + 8) * 8); PL(gt_over, (cap_tmp + 2) * 4); PL(gt_huge, (cap_tmp + 2) * 4); PL(gt_pool, pool_n * 4);
         PL(r_start, R * 8); PL(r_end, R * 8); PL(r_primary, R); PL(r_id, R * 4); PL(r_pmax, R * 8);
+        if (rd32) { PL(rs32, R * 4); PL(re32, R * 4); }
         if (reorder) { PL(s_start, R * 8); PL(s_end, R * 8); PL(s_primary, R); PL(s_id, R * 4); PL(ro_runs, RO_CAP * 4); PL(ro_table, RO_CAP * 16); }
     }
 #undef PL
@@ -521,7 +524,10 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
             while (e + 1 < S && c->h_seg[e + 1].sig_begin == c->h_seg[e].sig_end) e++;
             const i64 src = c->h_seg[k].sig_begin, n = c->h_woff[e + 1] - c->h_woff[k], dst = c->h_woff[k];
             if (n > 0) {
-                if (group == 1) {
+                if (group == 1 && sig32) {
+                    HIP_TRY(c, hipMemcpyAsync(dp<int>(c->a32) + dst, (const int32_t*)in->a + src, n * 4, hipMemcpyHostToDevice, cs));
+                    HIP_TRY(c, hipMemcpyAsync(dp<int>(c->b32) + dst, (const int32_t*)in->b + src, n * 4, hipMemcpyHostToDevice, cs));
+                } else if (group == 1) {
                     HIP_TRY(c, hipMemcpyAsync(dp<i64>(c->a) + dst, in->a + src, n * 8, hipMemcpyHostToDevice, cs));
                     HIP_TRY(c, hipMemcpyAsync(dp<i64>(c->b) + dst, in->b + src, n * 8, hipMemcpyHostToDevice, cs));
                 } else HIP_TRY(c, hipMemcpyAsync(dp<int>(c->rid) + dst, in->read_id + src, n * 4, hipMemcpyHostToDevice, cs));
@@ -536,6 +542,9 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
             }
             k = e + 1;
         }
+        if (group == 1 && sig32 && W > 0)                     // (the compacted w space is contiguous: one launch widens everything)
+            hipLaunchKernelGGL(k_widen2, dim3(div_up(W, 256 * 8) < 2048 ? div_up(W, 256 * 8) : 2048), dim3(256), 0, cs,
+                               dp<int>(c->a32), dp<i64>(c->a), dp<int>(c->b32), dp<i64>(c->b), W);
         HIP_TRY(c, hipEventRecord(c->ev_copy[group - 1], cs));
     }
     c->copies_pending = true;                               // run_impl orders the kernels behind the two events
@@ -547,8 +556,15 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
         if (c->any_tra_gt && in->n_chrom > 0) HIP_TRY(c, hipMemcpyAsync(c->contig_len.p, in->contig_len, (size_t)in->n_chrom * 8, hipMemcpyHostToDevice, sr));
     }
     if (R > 0) {
-        HIP_TRY(c, hipMemcpyAsync(c->r_start.p, in->r_start, R * 8, hipMemcpyHostToDevice, sr));
-        HIP_TRY(c, hipMemcpyAsync(c->r_end.p, in->r_end, R * 8, hipMemcpyHostToDevice, sr));
+        if (rd32) {
+            HIP_TRY(c, hipMemcpyAsync(c->rs32.p, in->r_start, R * 4, hipMemcpyHostToDevice, sr));
+            HIP_TRY(c, hipMemcpyAsync(c->re32.p, in->r_end, R * 4, hipMemcpyHostToDevice, sr));
+            hipLaunchKernelGGL(k_widen2, dim3(div_up(R, 256 * 8) < 2048 ? div_up(R, 256 * 8) : 2048), dim3(256), 0, sr,
+                               dp<int>(c->rs32), dp<i64>(c->r_start), dp<int>(c->re32), dp<i64>(c->r_end), R);
+        } else {
+            HIP_TRY(c, hipMemcpyAsync(c->r_start.p, in->r_start, R * 8, hipMemcpyHostToDevice, sr));
+            HIP_TRY(c, hipMemcpyAsync(c->r_end.p, in->r_end, R * 8, hipMemcpyHostToDevice, sr));
+        }
         HIP_TRY(c, hipMemcpyAsync(c->r_primary.p, in->r_primary, R, hipMemcpyHostToDevice, sr));
         HIP_TRY(c, hipMemcpyAsync(c->r_id.p, in->r_id, R * 4, hipMemcpyHostToDevice, sr));
     }

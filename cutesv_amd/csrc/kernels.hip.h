@@ -2068,6 +2068,13 @@ __global__ __launch_bounds__(256) void k_emit(DevBatch B)
     }
 }
 
+// ------------------------------------------------------------------------------------ narrow input columns
+// CSV_IN_SIG_I32 / CSV_IN_READS_I32: two int32 columns -> the int64 columns the kernels read (sign-extended)
+__global__ __launch_bounds__(256) void k_widen2(const int* __restrict__ s0, i64* __restrict__ d0, const int* __restrict__ s1, i64* __restrict__ d1, i64 n)
+{
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) { d0[i] = s0[i]; d1[i] = s1[i]; }
+}
+
 // ------------------------------------------------------------------------------------ publish
 // The results straight into the caller's arrays, when those live in page-locked host memory (csv_host_alloc /
 // csv_host_register): the device knows the counts, so one kernel writes the calls in their final structure-of-arrays

@@ -91,8 +91,11 @@ typedef struct csv_segment {
 enum {
     CSV_IN_PER_SIG = 1,       /* also produce the per-signature outputs cluster_id / allele_id (csv_batch_download may
                                  then be given those arrays); without it the kernels skip 8 B of stores per signature */
-    CSV_IN_READS_SORTED = 2   /* caller's promise: every reads block is already sorted by r_start (checked on the
+    CSV_IN_READS_SORTED = 2,  /* caller's promise: every reads block is already sorted by r_start (checked on the
                                  device: CSV_E_UNSORTED if not) */
+    CSV_IN_SIG_I32 = 4,       /* a and b point to int32_t columns (positions and lengths of a genome fit 31 bits; a third
+                                 less data on the link: 67 -> 45 MB for a 30x genome); widened on the device */
+    CSV_IN_READS_I32 = 8      /* r_start and r_end point to int32_t columns */
 };
 typedef struct csv_batch_in {
     int32_t            n_seg;

@@ -39,6 +39,7 @@ def lib():
 
 def cluster_batch(batch, per_sig=True, cap_calls=None, cap_support=None):
     """Run the C restatement on a HostBatch; returns a HostResult (retries once on capacity)."""
+    batch = batch.widened()                    # (the oracle reads int64 columns only)
     n = batch.n_sig
     cap_calls = cap_calls or max(64, n // 8 + 16)
     cap_support = cap_support or max(64, n + 16)

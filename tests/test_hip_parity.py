@@ -730,3 +730,29 @@ def test_thousands_of_small_segments(ctx):
     st = SigStore.from_tuple_lists(per, [])
     got = _compare_soa(ctx, st, Params.ont(min_support=3))
     assert len(st.tasks()) == 3000 and len(got["bp1"]) > 1500
+
+
+def test_narrow_input_columns(ctx):
+    """CSV_IN_SIG_I32 / CSV_IN_READS_I32: a page-locked store keeps int32 twins of the position / length columns (a third
+    less data on the link) and the library widens them on the device: same calls as the int64 columns; a store whose
+    values do not fit keeps its int64 columns"""
+    st = synth.small_mixed(seed=21, genotype=True)
+    p = Params.ont(genotype=True)
+    wide = st.host_batch(st.tasks(), p)
+    pst = st.pinned()
+    narrow = pst.host_batch(pst.tasks(), p)
+    assert narrow.a.dtype == np.int32 and narrow.r_start.dtype == np.int32
+    assert narrow.c.flags & _abi.IN_SIG_I32 and narrow.c.flags & _abi.IN_READS_I32 and not (wide.c.flags & (_abi.IN_SIG_I32 | _abi.IN_READS_I32))
+    for per_sig in (False, True):
+        a, b = ctx.cluster_batch(wide, per_sig=per_sig).trimmed(), ctx.cluster_batch(narrow, per_sig=per_sig, reuse=True).trimmed()
+        assert_soa_equal(b, a)
+    ctx.upload(narrow); ctx.run(); ctx.run()
+    assert_soa_equal(ctx.download().trimmed(), ctx.cluster_batch(wide).trimmed())
+    assert_soa_equal(ctx.cluster_batch(narrow, per_sig=True).trimmed(), _oracle().cluster_batch(narrow, per_sig=True).trimmed(), st)
+    # a length beyond 31 bits: no narrow twins for the signature columns (the reads keep theirs)
+    big = synth.small_mixed(seed=21, genotype=True)
+    big.b[5] = 1 << 33
+    pbig = big.pinned()
+    hb = pbig.host_batch(pbig.tasks(), p)
+    assert hb.a.dtype == np.int64 and hb.r_start.dtype == np.int32
+    assert_soa_equal(ctx.cluster_batch(hb, per_sig=True).trimmed(), _oracle().cluster_batch(hb, per_sig=True).trimmed(), big)
