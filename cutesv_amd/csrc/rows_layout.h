@@ -50,15 +50,16 @@ inline char* put_padded_u32(char* d, uint32_t u, int width)
     return d + n;
 }
 
-template <class Sink> int layout(const csv_rows_in* in, Sink& S)
+// rows of the calls [c_begin, c_end) (c_end < 0: all)
+template <class Sink> int layout(const csv_rows_in* in, Sink& S, int64_t c_begin = 0, int64_t c_end = -1)
 {
     if (!in || !in->res || (in->n_seg > 0 && !in->seg) || !in->chrom_name) return CSV_E_INVALID;
     const csv_batch_out& R = *in->res;
-    const int64_t nc = R.n_calls;
+    const int64_t nc = (c_end < 0 || c_end > R.n_calls) ? R.n_calls : c_end;
     static const char* kTraAlt[4][2] = {{"N[", "["}, {"N]", "]"}, {"[", "[N"}, {"]", "]N"}};     // cuteSV_resolveTRA.py:142-153
     static const char* kType[4] = {"DEL", "INS", "DUP", "INV"};
     const int name_prefix_len = in->name_prefix ? (int)strlen(in->name_prefix) : 0;
-    for (int64_t c = 0; c < nc; c++) {
+    for (int64_t c = c_begin < 0 ? 0 : c_begin; c < nc; c++) {
         const int k = R.call_seg[c];
         if (k < 0 || k >= in->n_seg) return CSV_E_INVALID;
         const csv_segment& sg = in->seg[k];

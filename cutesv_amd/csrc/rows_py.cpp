@@ -5,10 +5,17 @@
 // statement of the row layouts (rows_layout.h, shared with the C ABI's csv_rows_emit) against a sink that creates the
 // str objects directly: the ~350 k strings of a 30x genome are built in one pass over the structure of arrays, the
 // short repeated fields ("DEL", "19", "-3,3", "./.", chromosome names ...) shared through a small direct-mapped cache.
-// (Round 1 built them in a per-call Python loop: 92 ms; blob + str.split: ~35 ms; this: a few ms.)
+// (Round 1 built them in a per-call Python loop: 92 ms; blob + str.split: ~35 ms; one pass of this sink: 19 ms; with the
+// text formatted by worker threads beside the object creation - build_parallel below -: 8-10 ms for a 30x genome.)
 //   build(addr_of_csv_rows_in) -> list[list[str]]       split(blob, n_rows) -> the same from csv_rows_emit's text
 #define PY_SSIZE_T_CLEAN
 #include <Python.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <thread>
+#include <vector>
 
 #include "rows_layout.h"
 
@@ -160,6 +167,131 @@ struct PySink {
     }
 };
 
+// The text of a slice of the rows, produced WITHOUT the interpreter (so that slices can be made by several threads while
+// the GIL is released): the bytes of all fields back to back, the length of every field, the field count of every row.
+inline double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+struct SpanSink {
+    char*                 p = nullptr;       // raw bytes (malloc: no value initialisation of 20 MB of text)
+    size_t                n = 0, cap = 0;
+    std::vector<uint32_t> flen;
+    std::vector<uint8_t>  nf;
+    size_t                fstart = 0;
+    bool                  ok = true;
+    ~SpanSink() { free(p); }
+    inline bool need(size_t len)
+    {
+        if (n + len <= cap) return true;
+        size_t c = cap ? cap * 2 : (1u << 20);
+        while (c < n + len) c *= 2;
+        char* q = (char*)realloc(p, c);
+        if (!q) { ok = false; return false; }
+        p = q; cap = c;
+        return true;
+    }
+    inline void raw(const char* s, int64_t len) { if (len > 0 && need((size_t)len)) { memcpy(p + n, s, (size_t)len); n += (size_t)len; } }
+    inline void ch(char c) { if (need(1)) p[n++] = c; }
+    inline void num(int64_t v) { char b[24]; const int k = csv_rows::fmt_i64(v, b); raw(b + k, 24 - k); }
+    inline char* reserve(int64_t len) { return need((size_t)len) ? p + n : nullptr; }
+    inline void commit(int64_t len) { if (ok) n += (size_t)len; }
+    inline void acgt(int64_t len)
+    {
+        if (len <= 0 || !need((size_t)len)) return;
+        char* d = p + n;
+        const int64_t first = len < 4 ? len : 4;
+        memcpy(d, "ACGT", (size_t)first);
+        for (int64_t have = first; have < len;) { const int64_t k = have < len - have ? have : len - have; memcpy(d + have, d, (size_t)k); have += k; }
+        n += (size_t)len;
+    }
+    inline void row_begin(int k) { nf.push_back((uint8_t)k); }
+    inline bool row_end() { return ok; }
+    inline void field_begin(int64_t) { fstart = n; }
+    inline void field_end() { flen.push_back((uint32_t)(n - fstart)); }
+};
+
+// Large batches, two kinds of work side by side: worker threads (no interpreter: pure C++) format the text of one slice
+// of the calls after the other - gathers of read ids, name joins, number formatting, the inserted sequences: 70 % of the
+// single-pass time - while this thread, which holds the GIL, turns every finished slice into list and str objects, in
+// order.  The object creation (one thread, ~20 ns per object) is what remains on the critical path.
+PyObject* build_parallel(const csv_rows_in* in, int n_threads)
+{
+    const csv_batch_out& R = *in->res;
+    const int64_t nc = R.n_calls;
+    const bool dbg = getenv("CSV_ROWS_DEBUG") != nullptr;
+    const double t_begin = dbg ? now_ms() : 0;
+    // slices of about equal support counts (the read lists are the bulk of the text), several per worker so that the first
+    // ones are ready early
+    const int n_slices = n_threads * 4;
+    std::vector<int64_t> cut(n_slices + 1, 0);
+    const int64_t ns = R.support_off[nc];
+    for (int t = 1; t < n_slices; t++) {
+        const int64_t want = ns * t / n_slices;
+        cut[t] = std::lower_bound(R.support_off, R.support_off + nc, want) - R.support_off;
+        if (cut[t] < cut[t - 1]) cut[t] = cut[t - 1];
+    }
+    cut[n_slices] = nc;
+    std::vector<SpanSink> part(n_slices);
+    std::vector<int> rc(n_slices, CSV_OK);
+    std::vector<std::atomic<int>> ready(n_slices);
+    for (auto& x : ready) x.store(0, std::memory_order_relaxed);
+    std::atomic<int> next{0};
+    std::vector<std::thread> th;
+    auto work = [&] {
+        for (;;) {
+            const int t = next.fetch_add(1, std::memory_order_relaxed);
+            if (t >= n_slices) return;
+            try {
+                part[t].need((size_t)((cut[t + 1] - cut[t]) * 900 + 4096)); part[t].flen.reserve((size_t)(cut[t + 1] - cut[t]) * 14);
+                rc[t] = csv_rows::layout(in, part[t], cut[t], cut[t + 1]);
+                if (!part[t].ok) rc[t] = CSV_E_NOMEM;
+            } catch (...) { rc[t] = CSV_E_NOMEM; }
+            ready[t].store(1, std::memory_order_release);
+        }
+    };
+    try { for (int t = 0; t < n_threads; t++) th.emplace_back(work); }
+    catch (...) { }                                        // (fewer threads than asked for: the ones that started drain the queue)
+    if (th.empty()) work();
+    PyObject* rows = PyList_New(nc);
+    Cache C;
+    bool ok = rows && C.s;
+    int err = CSV_OK;
+    int64_t r = 0;
+    double t_wait = 0;
+    for (int t = 0; t < n_slices; t++) {
+        const double w0 = dbg ? now_ms() : 0;
+        while (!ready[t].load(std::memory_order_acquire)) std::this_thread::yield();
+        if (dbg) t_wait += now_ms() - w0;
+        if (rc[t] != CSV_OK) { err = rc[t]; ok = false; }
+        if (!ok) continue;                                 // (keep draining: the workers hold references to this frame)
+        const SpanSink& P = part[t];
+        const char* p = P.p;
+        size_t fi = 0;
+        for (size_t q = 0; q < P.nf.size() && ok; q++, r++) {
+            const int nf = P.nf[q];
+            PyObject* row = PyList_New(nf);
+            if (!row) { ok = false; break; }
+            PyList_SET_ITEM(rows, r, row);
+            for (int f = 0; f < nf; f++) {
+                const Py_ssize_t n = P.flen[fi++];
+                PyObject* u = n <= 8 ? short_str(C, p, n) : make_str(p, n);
+                if (!u) { ok = false; break; }
+                PyList_SET_ITEM(row, f, u);
+                p += n;
+            }
+        }
+        free(part[t].p); part[t].p = nullptr;              // (give the text back as soon as it is objects)
+    }
+    for (auto& x : th) x.join();
+    if (ok && r != nc) { ok = false; err = CSV_E_INVALID; }
+    if (!ok) {
+        Py_XDECREF(rows);
+        if (!PyErr_Occurred()) { if (err) PyErr_Format(PyExc_RuntimeError, "row builder failed (code %d)", err); else PyErr_NoMemory(); }
+        return nullptr;
+    }
+    if (dbg) fprintf(stderr, "[rows] %d threads, %d slices: %.2f ms, of which %.2f waiting for text\n", n_threads, n_slices, now_ms() - t_begin, t_wait);
+    return rows;
+}
+
 PyObject* build(PyObject*, PyObject* arg)
 {
     const csv_rows_in* in = (const csv_rows_in*)PyLong_AsVoidPtr(arg);
@@ -169,6 +301,21 @@ PyObject* build(PyObject*, PyObject* arg)
     // thresholds and 25 k of them trigger dozens of young-generation passes (~15 % of the call).  Collection is paused
     // for the duration of the build.
     const int gc_was_on = PyGC_Disable();
+    // large batches: text in parallel, objects afterwards (CSV_ROWS_THREADS overrides the thread count; 1 = single pass)
+    const int64_t nc = in->res->n_calls;
+    int n_threads = 1;
+    if (nc >= 4096 && in->res->support_off) {
+        const unsigned hw = std::thread::hardware_concurrency();
+        n_threads = (int)(hw ? (hw < 16 ? hw : 16) : 4);
+        if (const char* e = getenv("CSV_ROWS_THREADS")) n_threads = atoi(e) > 0 ? atoi(e) : 1;
+        if (n_threads > 64) n_threads = 64;
+        if ((int64_t)n_threads > nc / 1024) n_threads = (int)(nc / 1024 > 0 ? nc / 1024 : 1);
+    }
+    if (n_threads > 1) {
+        PyObject* rows = build_parallel(in, n_threads);
+        if (gc_was_on) PyGC_Enable();
+        return rows;
+    }
     PySink S(in->res->n_calls);
     const int rc = S.ok ? csv_rows::layout(in, S) : CSV_E_NOMEM;
     if (gc_was_on) PyGC_Enable();
