@@ -69,8 +69,17 @@ def make_workload(name, scale, rank):
     raise SystemExit("unknown workload " + name)
 
 
-def kernel_units(store, hb, res, stats):
-    """signatures / reads / calls each kernel processes in one launch -> algorithmic bytes"""
+def kernel_units(store, hb, res, stats, per_sig_step):
+    """Algorithmic bytes per launch of every kernel: SURVEY.md 8(d)'s per-unit figures PARTITIONED over the kernels, every byte
+    charged once, to the kernel that first needs it:
+      clustering 32 B per signature = a 8 -> the chain kernel; b 8 + read_id 4 + aux 4 -> the refine kernel that handles the
+      signature's cluster (only clusters that pass the size gate are ever refined: signatures of the others are never charged
+      to a refine kernel, and aux only counts for INS); cluster_id 4 + allele_id 4 -> k_chain_ids, which only runs for
+      CSV_IN_PER_SIG batches; INV chain rows also read b and aux (12 B), TRA rows aux (4 B);
+      64 B per emitted call + 8 B per support entry -> k_emit;
+      genotype: 21 B per read + 32 B per genotyped call -> the genotype stage (reads order + prefix max + stabbing queries).
+    The whole-step figure is the contract's: 24 B per signature in (+ 8 B out when the per-signature outputs are produced in
+    the timed loop) + 64 B per call + the genotype bytes."""
     t = res.trimmed()
     cid = t["cluster_id"]
     cid = cid[cid >= 0]
@@ -78,32 +87,39 @@ def kernel_units(store, hb, res, stats):
     sizes = np.bincount(cid, minlength=t["n_clusters"])
     first = np.flatnonzero(np.r_[True, cid[1:] != cid[:-1]])
     segs = hb.segments
-    woff = np.r_[0, np.cumsum(segs["sig_end"] - segs["sig_begin"])]
+    seglen = segs["sig_end"] - segs["sig_begin"]
+    woff = np.r_[0, np.cumsum(seglen)]
     seg_of_cluster = np.searchsorted(woff, first, side="right") - 1
     valid = sizes >= segs["read_count"][seg_of_cluster]
-    indel = segs["svtype"][seg_of_cluster] <= _abi.INS
+    ctype = segs["svtype"][seg_of_cluster]
+    indel = ctype <= _abi.INS
+    ins = ctype == _abi.INS
+
+    def refine_bytes(mask):
+        return int(16 * sizes[valid & mask].sum() + 4 * sizes[valid & mask & ins].sum())
     n_iw = int(sizes[valid & (sizes <= 64) & indel].sum())             # k_refine_indel_wave
     n_pw = int(sizes[valid & (sizes <= 64) & ~indel].sum())            # k_refine<64,64>
     n_mid = int(sizes[valid & (sizes > 64) & (sizes <= 256)].sum())    # k_refine<64,256>
     n_blk = int(sizes[valid & (sizes > 256)].sum())                    # k_refine<256,2048>
-    n_small, n_big = n_iw + n_pw, n_mid + n_blk
     calls, sup = res.n_calls, res.n_support
     R = 0 if hb.r_start is None else int(hb.r_start.shape[0])
     gt_calls = int((t["gl_idx"] >= 0).sum())
-    per_sig, per_call = 32, 64
-    n_ref = max(1, n_small + n_big)
-    share = lambda n: per_sig * n + per_call * calls * n // n_ref       # calls attributed in proportion to the signatures refined
+    w_inv = int(seglen[segs["svtype"] == _abi.INV].sum())
+    w_tra = int(seglen[segs["svtype"] == _abi.TRA].sum())
     b = {
-        "k_chain_count": per_sig * W, "k_chain_apply": per_sig * W,
-        "k_refine_indel_wave": share(n_iw), "k_refine_wave": share(n_pw), "k_refine_mid": share(n_mid), "k_refine_block": share(n_blk),
-        "k_emit": per_call * calls + 8 * sup, "k_items_scan": 8 * int(stats.n_work_wave + stats.n_work_block),
+        "k_chain_count": 8 * W + 12 * w_inv + 4 * w_tra,
+        "k_chain_apply": 16 * int(stats.n_work_wave + stats.n_work_block),       # one item record per gated cluster (bookkeeping, not in the contract)
+        "k_refine_indel_wave": refine_bytes((sizes <= 64) & indel), "k_refine_wave": refine_bytes((sizes <= 64) & ~indel),
+        "k_refine_mid": refine_bytes((sizes > 64) & (sizes <= 256)), "k_refine_block": refine_bytes(sizes > 256),
+        "k_emit": 64 * calls + 8 * sup, "k_items_scan": 8 * int(stats.n_work_wave + stats.n_work_block),
         # genotyping is judged as ONE stage (reads ordering + prefix max over the reads table + the per-call stabbing
         # queries): 21 B per read + 32 B per genotyped call over the summed duration of its kernels (see main())
         "genotype_stage": 21 * R + 32 * gt_calls,
     }
-    total = per_sig * W + per_call * calls + (21 * R + 32 * gt_calls if R else 0)
-    return b, total, dict(signatures=W, sig_in_wave_items=n_small, sig_in_block_items=n_big, calls=calls, supports=sup,
-                          reads=R, clusters=int(t["n_clusters"]))
+    total = (32 if per_sig_step else 24) * W + 64 * calls + (21 * R + 32 * gt_calls if R else 0)
+    return b, total, dict(signatures=W, sig_in_gated_clusters=n_iw + n_pw + n_mid + n_blk, sig_refined_indel_wave=n_iw, sig_refined_pair_wave=n_pw,
+                          sig_refined_mid=n_mid, sig_refined_block=n_blk, calls=calls, supports=sup,
+                          reads=R, genotyped_calls=gt_calls, clusters=int(t["n_clusters"]), gated_clusters=int(valid.sum()))
 
 
 def spawn_ranks(a):
@@ -156,6 +172,7 @@ def main():
     # ---------------- CPU baseline first (fork pool before any HIP state exists in this process)
     cpu = None
     cpu_c = None
+    cpu_c_mt = None
     ores = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         from oracle import oracle, py_restatement as pr
@@ -179,6 +196,17 @@ def main():
         dtc = time.perf_counter() - t0
         cpu_c = dict(value=n_sig / dtc, unit="signatures/s", cores=1, kind="port",
                      sample="full workload, oracle/cutesv_oracle.c single thread, %.3f s" % dtc)
+        # the same C restatement over the (chr, type) tasks on all host cores, one task per call like the reference's pool:
+        # the parallelism a task pool can reach is bounded by the task count and by the largest task (chr1 INS)
+        nthr = min(len(tasks), procs)
+        dtm, mt_calls = min((oracle.cluster_tasks_mt(store, tasks, params, nthr) for _ in range(3)), key=lambda x: x[0])
+        cpu_c_mt = dict(value=n_sig / dtm, unit="signatures/s", cores=nthr, kind="port", wall_s=dtm, calls=mt_calls,
+                        sample="full workload, oracle/cutesv_oracle.c, one (chr,type) task per call on %d threads (host has %d cores; "
+                               "%d tasks), largest first, best of 3: %.4f s" % (nthr, os.cpu_count() or 1, len(tasks), dtm))
+        cal = os.path.join(ROOT, "profiles", "calibration_py_restatement.json")
+        if os.path.exists(cal):
+            with open(cal) as f:
+                cpu["calibration_vs_reference"] = json.load(f)
 
     # ---------------- GPU (the library and the HIP runtime it links are loaded before torch is imported)
     ndev = max(1, engine.device_count())
@@ -327,28 +355,39 @@ def main():
         except Exception as e:           # noqa: BLE001  (optional leg)
             print("copy ceiling not measured: %r" % (e,), file=sys.stderr)
         try:
-            kbytes, total_bytes, units = kernel_units(store, hb, res, st)
+            kbytes, total_bytes, units = kernel_units(store, hb, res, st, per_sig_step=False)
         except Exception:                # noqa: BLE001  (timing experiments with ablated kernels: CSV_BENCH_LENIENT=1)
             if not os.environ.get("CSV_BENCH_LENIENT"):
                 raise
             kbytes, total_bytes, units = {n: 1 for n in names if n}, 1, {}
-        gt_parts = ("k_reads_order", "k_pmax_count", "k_pmax_apply", "k_genotype")
+        gt_parts = ("k_reads_order", "k_pmax_count", "k_pmax_scan", "k_genotype")        # stage slots (HIP events)
+        gt_kernels = ("k_reads_runs", "k_reads_plan", "k_reads_gather", "k_pmax_count", "k_pmax_scan", "k_genotype", "k_widen2")   # kernel names (PMC)
 
         def per_kernel_us(v):
             d = {names[i]: round(float(v[i]) * 1e3, 2) for i in range(_abi.N_STAGES) if names[i]}   # microseconds
             d["genotype_stage"] = round(sum(d.get(k, 0.0) for k in gt_parts), 2)
             return d
         per_kernel, per_kernel_cold, per_kernel_nps = per_kernel_us(acc), per_kernel_us(cold_acc), per_kernel_us(warm_plain)
-        dom = max((n for n in per_kernel_nps if n in kbytes and kbytes[n] > 0), key=lambda n: per_kernel_nps[n])
+        # dominant kernel = the longest of the plain pass; kernels within 5 % of the longest count as tied and the one that
+        # moves the most algorithmic bytes is named (so that the choice does not flip between runs on a 0.1 us difference)
+        cand = [n for n in per_kernel_nps if n in kbytes and kbytes[n] > 0 and n not in ("k_chain_apply", "k_items_scan")]
+        longest = max(per_kernel_nps[n] for n in cand)
+        dom = max((n for n in cand if per_kernel_nps[n] >= 0.95 * longest), key=lambda n: kbytes[n])
         dom_s = per_kernel_nps[dom] * 1e-6
         achieved = kbytes[dom] / dom_s / 1e9
         cold_achieved = kbytes[dom] / (per_kernel_cold[dom] * 1e-6) / 1e9
-        traffic = None
+        # HBM traffic per launch from the rocprofv3 PMC passes of the SAME command (scripts/refresh_profiles.sh writes
+        # profiles/traffic_<workload>.json from the FETCH_SIZE / WRITE_SIZE databases next to the kernel trace)
+        traffic, traffic_all = None, None
         tf = os.path.join(ROOT, "profiles", "traffic_%s.json" % a.workload)
         if os.path.exists(tf) and a.scale == 1.0:
             with open(tf) as f:
                 tj = json.load(f)
-                traffic = sum(tj.get(k, 0) for k in gt_parts) if dom == "genotype_stage" else tj.get(dom)
+            traffic_all = {k: v for k, v in tj.items() if k.startswith("k_")}
+            traffic = sum(tj.get(k, 0) for k in gt_kernels) if dom == "genotype_stage" else tj.get(dom)
+        roof_all = {n: {"us": per_kernel_nps[n], "algorithmic_bytes": kbytes[n], "gbs": round(kbytes[n] / (per_kernel_nps[n] * 1e-6) / 1e9, 1),
+                        "frac": round(kbytes[n] / (per_kernel_nps[n] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+                    for n in per_kernel_nps if n in kbytes and kbytes[n] > 0 and per_kernel_nps[n] > 0}
         parity = None
         if ores is not None:
             w, g = ores.trimmed(), res.trimmed()
@@ -376,8 +415,9 @@ def main():
             "roofline_pipeline": {"algorithmic_bytes": total_bytes, "kernel_time_us": round(tot / a.steps * 1e3, 2),
                                   "achieved": total_bytes / (ms_per_step * 1e-3) / 1e9 if not shard_mode else None, "unit": "GB/s",
                                   "frac": total_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS if not shard_mode else None},
+            "roofline_per_kernel": roof_all, "traffic_per_kernel": traffic_all,
             "kernel_us": per_kernel_nps, "kernel_us_per_sig_outputs": per_kernel, "kernel_us_cold": per_kernel_cold, "units": units,
-            "cpu_baseline": cpu, "cpu_baseline_c": cpu_c,
+            "cpu_baseline": cpu, "cpu_baseline_c": cpu_c, "cpu_baseline_c_mt": cpu_c_mt,
             "speedup_vs_cpu_baseline": (value / world / cpu["value"]) if cpu else None,
             "boundary": {"pin_ms": t_pin * 1e3,
                          "one_shot_call_ms": one_ms, "one_shot_call_ms_all": [round(x * 1e3, 3) for x in t_one],

@@ -132,6 +132,7 @@ struct csv_ctx {
     std::vector<i64>         h_woff;
     bool     uploaded = false, ran = false, any_genotype = false, any_pair = false, any_tra_gt = false, lds_set = false;
     bool     reads_general = false;            // this batch's reads table needs the general sort (found out by a first run)
+    i64      sqrt_n = 0;                       // entries of sqrt_tab (grown to the longest segment seen: an allele is never larger)
     bool     copies_pending = false;           // csv_cluster_batch: the column copies are still in flight behind ev_copy[0] / [1]
     i64      n_sig_host = 0, n_reads = 0;
     DevBatch B;
@@ -206,6 +207,24 @@ int env_int(const char* name, int dflt)
 
 int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sync);
 int read_counters(csv_ctx* c);
+
+// `num ** 0.5` of cal_CIPOS is libm pow(), not sqrt() (GT:59; the two differ for 271 integers below 300 000): the device reads
+// a table built with the host libm that covers every n an allele of the batch can have (n <= its segment's length).  Grown,
+// never shrunk; a batch whose longest segment fits the table costs nothing here.
+int sqrt_table(csv_ctx* c, i64 n)
+{
+    if (n <= c->sqrt_n) return CSV_OK;
+    const i64 want = n + n / 4;
+    std::vector<double> tab((size_t)want);
+    for (i64 i = 0; i < want; i++) tab[(size_t)i] = pow((double)i, 0.5);
+    HIP_TRY(c, hipDeviceSynchronize());                       // (a kernel of an earlier batch may still read the old table)
+    if (c->sqrt_tab.p) { HIP_TRY(c, hipFree(c->sqrt_tab.p)); c->sqrt_tab.p = nullptr; c->sqrt_tab.cap = 0; }
+    const int rc = reserve(c, c->sqrt_tab, (size_t)want * sizeof(double));
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpy(c->sqrt_tab.p, tab.data(), (size_t)want * sizeof(double), hipMemcpyHostToDevice));
+    c->sqrt_n = want;
+    return CSV_OK;
+}
 
 }  // namespace
 
@@ -305,9 +324,6 @@ int csv_ctx_create(int device_id, csv_ctx** out)
         hipEventCreateWithFlags(&c->ev_reads, hipEventDisableTiming) != hipSuccess) { delete c; return CSV_E_HIP; }
     for (auto& e : c->ev_aux) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { delete c; return CSV_E_HIP; }
     for (auto& e : c->ev_copy) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { delete c; return CSV_E_HIP; }
-    // `num ** 0.5` of cal_CIPOS is libm pow(), not sqrt(): tabulate it with the host libm (GT:59)
-    std::vector<double> tab(SQRT_TAB);
-    for (int i = 0; i < SQRT_TAB; i++) tab[i] = pow((double)i, 0.5);
     {
         void* hf = nullptr;
         if (hipHostMalloc(&hf, 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
@@ -316,8 +332,7 @@ int csv_ctx_create(int device_id, csv_ctx** out)
             else (void)hipHostFree(hf);
         }
     }
-    if (reserve(c, c->sqrt_tab, SQRT_TAB * sizeof(double)) || reserve(c, c->cnt, sizeof(DevCounters)) || pin_reserve(c, 1 << 20) ||
-        hipMemcpy(c->sqrt_tab.p, tab.data(), SQRT_TAB * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
+    if (reserve(c, c->cnt, sizeof(DevCounters)) || pin_reserve(c, 1 << 20) || sqrt_table(c, SQRT_TAB)) {
         delete c;
         return CSV_E_HIP;
     }
@@ -421,6 +436,12 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
         else cap_tmp += len / rc + 1;
     }
     const i64 W = c->h_woff[S];
+    {
+        i64 longest = 0;
+        for (int k = 0; k < S; k++) if (c->h_woff[k + 1] - c->h_woff[k] > longest) longest = c->h_woff[k + 1] - c->h_woff[k];
+        const int rc = sqrt_table(c, longest + 2);
+        if (rc) return rc;
+    }
     if (W >= (1ll << 31) - 4096 || cap_tmp >= (1ll << 31) - 1) return fail(c, CSV_E_INVALID, "batch too large for 32-bit work indices (%lld signatures)", (long long)W);
     if (c->any_genotype && in->reads_off && (!in->r_start || !in->r_end || !in->r_primary || !in->r_id) && in->n_reads > 0)
         return fail(c, CSV_E_INVALID, "reads columns missing");

@@ -44,7 +44,8 @@ constexpr u64 PAD_KEY = ~0ull;
 constexpr int IDX_BITS = 21;                       // local-index bits inside a sort key: (value << 21 | index), values < 2^42 ...
 constexpr int IDX_BITS_HUGE = 31;                  // ... and (value << 31 | index), values < 2^32, for chained clusters above 2^21 signatures
 constexpr i64 MAX_CLUSTER = (1ll << 30);           // (padded size must fit an int; a batch holds < 2^31 signatures anyway)
-constexpr int SQRT_TAB = 65536;                    // pow(n, 0.5) as glibc computes it, n < SQRT_TAB
+constexpr int SQRT_TAB = 65536;                    // pow(n, 0.5) as glibc computes it: the table holds at least n < SQRT_TAB and always every
+                                                   // n up to the longest segment of the batch (an allele cannot be larger): no sqrt() stand-in
 constexpr int ARR_PAD = 8;                         // group-start arrays need P + 1 entries
 
 // device error bits (DevCounters::error)
@@ -904,8 +905,7 @@ template <class VP, class IP> __device__ int cipos_of(VP v, int n, i64 sum, cons
         acc += np_sumsq_chunk(v + off, c, mean, stk);
     }
     const double sd = sqrt(acc / (double)n);
-    const double rt = n < SQRT_TAB ? sqrt_tab[n] : sqrt((double)n);
-    return (int)(1.96 * sd / rt);
+    return (int)(1.96 * sd / sqrt_tab[n]);            // (n <= the segment's length < the table's size, see SQRT_TAB)
 }
 
 // one thread publishes an item's result: slot count and packed (valid calls << 32 | their supports).

@@ -55,6 +55,34 @@ def cluster_batch(batch, per_sig=True, cap_calls=None, cap_support=None):
     raise RuntimeError("oracle: capacity retry failed")
 
 
+def cluster_tasks_mt(store, tasks, params, threads):
+    """The C restatement over the (chr, type) tasks of a workload, one task per call like the reference's pool
+    (main script :1116-1189), on `threads` threads (ctypes drops the GIL inside the C call); largest tasks first.
+    Returns (wall seconds of the parallel region, total calls).  Batches and result arrays are built outside the clock."""
+    import time
+    from concurrent.futures import ThreadPoolExecutor
+    lib()
+    jobs = []
+    for t in tasks:
+        hb = store.host_batch([t], params).widened()
+        n = hb.n_sig
+        res = _abi.HostResult(n, max(64, n // 4 + 16), max(64, n + 16), per_sig=False, n_seg=1)
+        jobs.append((hb, res))
+    jobs.sort(key=lambda j: -j[0].n_sig)
+
+    def run(j):
+        rc = _LIB.csvo_cluster_batch(C.byref(j[0].c), C.byref(j[1].c))
+        if rc != _abi.OK:
+            raise RuntimeError("oracle: %s" % _abi.ERR_NAME.get(rc, rc))
+        return j[1].n_calls
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        list(ex.map(lambda i: time.sleep(0.002), range(threads)))       # (the threads exist before the clock starts)
+        t0 = time.perf_counter()
+        calls = sum(ex.map(run, jobs))
+        dt = time.perf_counter() - t0
+    return dt, calls
+
+
 def np_sum(x):
     x = np.ascontiguousarray(x, np.float64)
     return lib().csvo_np_sum_f64(x.ctypes.data, len(x))

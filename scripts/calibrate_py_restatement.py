@@ -13,6 +13,7 @@ from cutesv_amd.columns import Params
 from oracle import py_restatement as pr
 
 scale = float(sys.argv[1]) if len(sys.argv) > 1 else 0.25
+record = {"where": "build container (the reference cannot travel to the GPU box)", "scale": scale, "processes": 1, "cases": []}
 for name, st, p in (("cfg3 ONT INS+DEL", synth.ont30(scale=scale), Params.ont()),
                     ("cfg4 HiFi --genotype", synth.hifi30_gt(scale=scale * 0.2), Params.hifi(genotype=True, min_support=3))):
     with tempfile.TemporaryDirectory() as d:
@@ -34,3 +35,10 @@ for name, st, p in (("cfg3 ONT INS+DEL", synth.ont30(scale=scale), Params.ont())
     n_py = sum(len(r[1]) for r in res)
     print("%-22s sigs=%d reads=%d | reference %.2f s (%d rows, incl. its pickle.load) | py_restatement %.2f s (%d rows) | ratio restatement/reference = %.2f"
           % (name, st.n_sig, st.n_reads, t_ref, n_ref, t_py, n_py, t_py / t_ref))
+    record["cases"].append({"workload": name, "signatures": int(st.n_sig), "reads": int(st.n_reads), "reference_s": round(t_ref, 3), "reference_rows": n_ref,
+                            "py_restatement_s": round(t_py, 3), "py_restatement_rows": n_py, "ratio_restatement_over_reference": round(t_py / t_ref, 3)})
+import json
+record["note"] = ("ratio < 1: oracle/py_restatement.py is FASTER than the reference on the same input, so a speedup quoted against it "
+                  "understates the speedup against cuteSV itself")
+with open(os.path.join(ROOT, "profiles", "calibration_py_restatement.json"), "w") as f:
+    json.dump(record, f, indent=1)

@@ -81,6 +81,23 @@ def test_large_clusters_all_tiers(ctx):
     assert sizes.max() > 2048, sizes.max()
 
 
+@pytest.mark.parametrize("n", [65733, 70789])
+def test_allele_larger_than_the_static_pow_table(ctx, n):
+    # cal_CIPOS divides by `num ** 0.5` = libm pow(), which is not sqrt() for these n (and 269 more below 300 000); the
+    # device's pow table is sized to the batch's longest segment, so an allele of any size divides by the reference's value
+    import math
+    from cutesv_amd.columns import SigStore
+    assert math.pow(n, 0.5) != math.sqrt(n)
+    rng = np.random.default_rng(n)
+    pos = np.sort(rng.integers(100_000, 100_000 + 40 * n, n))            # gaps ~40 < bias: one chained cluster
+    ln = rng.integers(980, 1020, n)                                       # one allele at ratio 0.3
+    per = {t: [] for t in ("DEL", "INS", "DUP", "INV", "TRA")}
+    per["DEL"] = [(int(pos[i]), int(ln[i]), "p%06d" % i, "DEL", "1") for i in range(n)]
+    st = SigStore.from_tuple_lists(per)
+    got = _compare_soa(ctx, st, Params(min_support=5, max_size=-1, max_cluster_bias_DEL=5000, diff_ratio_merging_DEL=0.3))
+    assert got["support"].max() == n and got["cipos"].max() > 0
+
+
 def test_register_tiers_fallback_routes(ctx):
     # lengths >= 2^26 leave the one-word rank key, repeated read names leave the hashed duplicate filter: the
     # 64-bit / exact routes of indel_unit<16>, <32> and <64>, next to ordinary clusters in the same wavefronts
@@ -292,6 +309,24 @@ def test_full_size_cfg3_vs_oracle(ctx):
     st = synth.ont30()                      # ~2.8 M signatures: BASELINE config 3 at full size
     assert st.n_sig > 2_500_000
     _compare_soa(ctx, st, Params.ont())
+
+
+@pytest.mark.parametrize("cfg", ["cfg4", "cfg5"])
+@pytest.mark.parametrize("order", ["extraction", "sorted"])
+def test_full_size_cfg4_cfg5_vs_oracle(ctx, cfg, order):
+    """BASELINE configs 4 and 5 at FULL size, bit for bit against the C oracle (which needs < 1 s for either): every SoA
+    field, the support lists and the per-signature outputs; the reads table once as the extraction step leaves it (the
+    device reorders it) and once start-sorted."""
+    if cfg == "cfg5":
+        st, p, min_sig, min_calls = synth.ont90_all(), Params.ont(genotype=True), 10_000_000, 50_000
+    else:
+        st, p, min_sig, min_calls = synth.hifi30_gt(), Params.hifi(genotype=True, min_support=3), 400_000, 20_000
+    if order == "extraction":
+        st, _ = synth.extraction_order(st)
+    assert st.n_sig > min_sig
+    got = _compare_soa(ctx, st, p)
+    assert len(got["bp1"]) > min_calls
+    assert (got["gl_idx"] >= 0).sum() > min_calls // 2
 
 
 @pytest.mark.parametrize("cfg", ["cfg4", "cfg5"])
