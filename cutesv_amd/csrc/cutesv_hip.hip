@@ -26,22 +26,26 @@ namespace {
 // Page-locked host ranges handed out (or registered) through this library, process wide: {base -> bytes, device address}.
 // csv_batch_download writes results straight into such memory from a kernel; a range leaves the table before it is freed,
 // so a table hit is always live memory (addresses pinned by other means are asked about through the HIP runtime each time).
-struct PinnedRange { size_t bytes; char* dev; };
+struct PinnedRange { size_t bytes; char* dev; bool owned; };
 std::mutex g_pinned_mu;
 std::map<uintptr_t, PinnedRange> g_pinned;
-void pinned_note(void* p, size_t bytes)
+void pinned_note(void* p, size_t bytes, bool owned)
 {
     void* d = nullptr;
     if (hipHostGetDevicePointer(&d, p, 0) != hipSuccess) { (void)hipGetLastError(); return; }
     std::lock_guard<std::mutex> lk(g_pinned_mu);
-    g_pinned[(uintptr_t)p] = PinnedRange{bytes, (char*)d};
+    g_pinned[(uintptr_t)p] = PinnedRange{bytes, (char*)d, owned};
 }
 void pinned_forget(void* p)
 {
     std::lock_guard<std::mutex> lk(g_pinned_mu);
     g_pinned.erase((uintptr_t)p);
 }
-// device address of host pointer p (with `bytes` behind it) if it is page-locked, else nullptr
+// device address of host pointer p (with `bytes` behind it) if it is page-locked, else nullptr.  Memory from csv_host_alloc
+// is owned by this library (it leaves the table in csv_host_free, before it is released): a hit there is live memory.  A
+// range the CALLER registered (csv_host_register) may have been freed or re-used without csv_host_unregister - a kernel
+// writing through such a stale mapping would fault the GPU - so those hits, like unknown addresses, are confirmed with
+// the HIP runtime on every use.
 void* pinned_device_address(const void* p, size_t bytes)
 {
     {
@@ -50,12 +54,21 @@ void* pinned_device_address(const void* p, size_t bytes)
         if (it != g_pinned.begin()) {
             --it;
             const uintptr_t off = (uintptr_t)p - it->first;
-            if (off < it->second.bytes) return off + bytes <= it->second.bytes ? it->second.dev + off : nullptr;
+            if (off < it->second.bytes) {
+                if (off + bytes > it->second.bytes) return nullptr;
+                if (it->second.owned) return it->second.dev + off;
+            }
         }
     }
     hipPointerAttribute_t at;
     if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-    return (at.type == hipMemoryTypeHost) ? at.devicePointer : nullptr;
+    if (at.type != hipMemoryTypeHost || !at.devicePointer) return nullptr;
+    if (bytes > 1) {                                            // the last byte must belong to the same page-locked range
+        hipPointerAttribute_t a2;
+        if (hipPointerGetAttributes(&a2, (const char*)p + bytes - 1) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        if (a2.type != hipMemoryTypeHost || (char*)a2.devicePointer != (char*)at.devicePointer + bytes - 1) return nullptr;
+    }
+    return at.devicePointer;
 }
 
 struct Buf {                      // a slice of an arena (or, for the few stand-alone buffers, its own allocation)
@@ -131,6 +144,7 @@ struct csv_ctx {
     std::vector<csv_segment> h_seg;
     std::vector<i64>         h_woff;
     bool     uploaded = false, ran = false, any_genotype = false, any_pair = false, any_tra_gt = false, lds_set = false;
+    bool     have_tab = false;                 // this upload issued copies of the reads table frame (reads_off, contig_len, columns) on side[2]
     bool     reads_general = false;            // this batch's reads table needs the general sort (found out by a first run)
     i64      sqrt_n = 0;                       // entries of sqrt_tab (grown to the longest segment seen: an allele is never larger)
     bool     copies_pending = false;           // csv_cluster_batch: the column copies are still in flight behind ev_copy[0] / [1]
@@ -281,7 +295,7 @@ int csv_host_alloc(int64_t bytes, void** out)
     void* p = nullptr;
     const size_t n = (size_t)(bytes > 0 ? bytes : 1);
     if (hipHostMalloc(&p, n, hipHostMallocPortable) != hipSuccess) return CSV_E_NOMEM;
-    pinned_note(p, n);
+    pinned_note(p, n, true);
     *out = p;
     return CSV_OK;
 }
@@ -290,7 +304,7 @@ int csv_host_register(void* p, int64_t bytes)
 {
     if (!p || bytes <= 0) return CSV_E_INVALID;
     if (hipHostRegister(p, (size_t)bytes, hipHostRegisterPortable) != hipSuccess) return CSV_E_HIP;
-    pinned_note(p, (size_t)bytes);
+    pinned_note(p, (size_t)bytes, false);
     return CSV_OK;
 }
 int csv_host_unregister(void* p) { if (p) pinned_forget(p); return (p && hipHostUnregister(p) == hipSuccess) ? CSV_OK : CSV_E_HIP; }
@@ -591,6 +605,7 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
     }
     // (the main stream does not wait for the reads table: the kernels that read it are ordered behind this event)
     if (have_tab) HIP_TRY(c, hipEventRecord(c->ev_reads, sr));
+    c->have_tab = have_tab;
     if (sync) {
         HIP_TRY(c, hipStreamSynchronize(st)); HIP_TRY(c, hipStreamSynchronize(cs));
         if (have_tab) HIP_TRY(c, hipStreamSynchronize(sr));
@@ -800,12 +815,22 @@ int run_impl(csv_ctx* c, csv_run_stats* stats)
             HIP_TRY(c, mark());
         } else if (stats) { for (int q = 0; q < 4; q++) HIP_TRY(c, mark()); }
         if (c->any_tra_gt) {
+            // (reads_off / contig_len / the reads columns travel on side[2]: a batch whose only genotyped segments are TRA
+            // segments, or one without reads, has not waited for them yet)
+            if (c->copies_pending && c->have_tab) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_reads, 0));
             LAUNCH("genotype_tra", k_genotype_tra, 256, 64, 0, B);
         }
     }
 #undef LAUNCH
 #undef LAUNCH_ON
-    if (c->copies_pending) { HIP_TRY(c, hipStreamWaitEvent(st, c->ev_copy[1], 0)); c->copies_pending = false; }   // (empty batch)
+    if (c->copies_pending) {
+        // whatever this run did not consume is still waited for before the call returns (an empty batch; a reads table next
+        // to zero signatures): the caller's page-locked columns must not be the source of a copy in flight after the call,
+        // and the next upload re-plans the arena
+        HIP_TRY(c, hipStreamWaitEvent(st, c->ev_copy[1], 0));
+        if (c->have_tab) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_reads, 0));
+        c->copies_pending = false;
+    }
     HIP_TRY(c, hipGetLastError());
     c->ran = true;
     if (stats) {
@@ -1143,6 +1168,9 @@ int csv_cigar_signatures(csv_ctx* c, const csv_cigar_in* in, csv_cigar_out* out)
     const i64 nops = in->cig_off[n] - in->cig_off[0];
     if (in->cig_off[0] != 0 || nops < 0 || (nops > 0 && !in->cigar)) return fail(c, CSV_E_INVALID, "cig_off must start at 0 and not decrease");
     if (nops >= (1ll << 31) - 4096) return fail(c, CSV_E_INVALID, "CIGAR batch too large (%lld operations): split it", (long long)nops);
+    for (i64 r = 0; r < n; r++)                                 // the kernels index `cigar` with these: every offset is checked here
+        if (in->cig_off[r] < 0 || in->cig_off[r + 1] < in->cig_off[r] || in->cig_off[r + 1] > nops)
+            return fail(c, CSV_E_INVALID, "cig_off decreases or leaves the CIGAR array at read %lld", (long long)r);
     const int ntile = div_up(n, CG_TILE);
     // every op can be a piece and a signature of its own: size the outputs for the worst case the caller allows, but never
     // more than the operations there are

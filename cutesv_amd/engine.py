@@ -169,11 +169,40 @@ def pinned_copy(arr):
     return out
 
 
+class Registered:
+    """An existing contiguous numpy array page-locked in place (csv_host_register).  Keeps the array alive and
+    unregisters it when this object is released (or on close()): the library never holds a mapping of memory that has
+    been freed."""
+
+    def __init__(self, arr):
+        self.arr = arr
+        self.ok = lib().csv_host_register(C.c_void_p(arr.ctypes.data), int(arr.nbytes)) == _abi.OK
+
+    def close(self):
+        if self.ok:
+            self.ok = False
+            lib().csv_host_unregister(C.c_void_p(self.arr.ctypes.data))
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __bool__(self):
+        return self.ok
+
+
 def host_register(arr):
-    """page-lock an existing contiguous numpy array in place; returns True on success (keep the array alive and
-    call host_unregister before it is freed)"""
-    return lib().csv_host_register(C.c_void_p(arr.ctypes.data), int(arr.nbytes)) == _abi.OK
+    """page-lock an existing contiguous numpy array in place; returns a `Registered` handle (truthy on success) that owns
+    the registration: drop it, or call .close(), before the array's memory is released"""
+    return Registered(arr)
 
 
 def host_unregister(arr):
+    """`arr`: the handle host_register returned, or (legacy) the array itself"""
+    if isinstance(arr, Registered):
+        ok = arr.ok
+        arr.close()
+        return ok
     return lib().csv_host_unregister(C.c_void_p(arr.ctypes.data)) == _abi.OK

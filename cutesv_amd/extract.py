@@ -36,6 +36,9 @@ class CigarOut(C.Structure):
 def encode_cigars(cigartuples_per_read):
     """[[(op, oplen), ...] per read] (pysam's read.cigartuples) -> (cig_off int64[n + 1], cigar uint32[n_ops]) in the BAM
     encoding oplen << 4 | op"""
+    # (pysam returns None for a record without a CIGAR - an unmapped mate that fetch() still yields; the reference skips
+    # such a read through its mapq gate, main script :614, and carries on)
+    cigartuples_per_read = [c if c is not None else () for c in cigartuples_per_read]
     lens = np.fromiter((len(c) for c in cigartuples_per_read), np.int64, len(cigartuples_per_read))
     off = np.zeros(len(lens) + 1, np.int64)
     np.cumsum(lens, out=off[1:])
@@ -246,7 +249,7 @@ def parse_reads(reads, chrom, chrom_rank, sv_size, min_mapq, max_split_parts, mi
             continue
         primary = []
         if r.mapq >= min_mapq:
-            ct = r.cigartuples
+            ct = r.cigartuples or ((0, 0),)                                                         # (no CIGAR: no clips)
             left = ct[0][1] if ct[0][0] in (4, 5) else 0                                            # soft clip, or the hard clip that replaces it (:619-652)
             right = ct[-1][1] if ct[-1][0] in (4, 5) else 0
             primary = ([left, r.query_length - right, r.reference_start, r.reference_end, chrom, "+"] if r.flag == 0 else

@@ -8,9 +8,10 @@ unchanged by the reference's VCF emitter (cuteSV_genotype.py:263-458):
     TRA 12                   cuteSV_resolveTRA.py:171-182 (genotype fields from call_gt, :258-309)
 All numeric fields are `str`; read names are joined by ','.
 
-`materialise` is the product path: `csv_rows_emit` (cutesv_amd/csrc/rows_emit.cpp, C ABI) writes every row of the
-batch into one text blob and the CPython helper `_rowsplit` (cutesv_amd/csrc/rowsplit_py.cpp) turns the blob into
-the list objects — ~6 ms for the 25 k calls of a 30x genome.  `materialise_py` is the per-call Python loop it
+`materialise` is the product path: the CPython extension `_rows_native` (cutesv_amd/csrc/rows_py.cpp over rows_layout.h)
+formats the calls on worker threads and creates the list / str objects on the calling thread - ~10 ms for the 25 k calls
+of a 30x genome; `csv_rows_emit` (cutesv_amd/csrc/rows_emit.cpp, C ABI) writes the same rows as one text blob for hosts
+that are not CPython.  `materialise_py` is the per-call Python loop it
 replaced (round 1: ~90 ms); it is kept as the readable statement of the layouts and the tests compare the two.
 """
 import ctypes as C

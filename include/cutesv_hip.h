@@ -194,7 +194,8 @@ typedef struct csv_ctx csv_ctx;
 
 int         csv_abi_version(void);
 /* sizeof() of the ABI's structs as this library was compiled (which: 0 csv_segment, 1 csv_batch_in, 2 csv_batch_out,
- * 3 csv_run_stats, 4 csv_rebuild_in, 5 csv_rebuild_out, 6 csv_vcf_in, 7 csv_rows_in, 8 csv_cigar_in, 9 csv_cigar_out; -1 otherwise): lets a binding
+ * 3 csv_run_stats, 4 csv_rebuild_in, 5 csv_rebuild_out, 6 csv_vcf_in, 7 csv_rows_in, 8 csv_cigar_in, 9 csv_cigar_out, 10 csv_split_in,
+ * 11 csv_split_out; -1 otherwise): lets a binding
  * check its own mirror of the layouts at load time. */
 int         csv_struct_size(int which);
 int         csv_device_count(int* n);
@@ -212,6 +213,10 @@ int csv_cluster_batch(csv_ctx* ctx, const csv_batch_in* in, csv_batch_out* out);
 /* Resident mode: the same work split at the PCIe boundary, so a caller (or bench.py) can
  * keep the columns in HBM and run the kernels repeatedly. */
 int csv_batch_upload(csv_ctx* ctx, const csv_batch_in* in);
+/* csv_batch_run only enqueues work (it returns before the kernels finish; csv_batch_download / csv_ctx_sync wait) - with one
+ * exception: in a resident re-run it may busy-wait on the calling thread for up to 400 microseconds for two words the device
+ * publishes (whether any cluster has more than 64 signatures), to skip two empty kernel launches; CSV_NO_PEEK=1 in the
+ * environment disables that.  csv_cluster_batch never waits this way. */
 int csv_batch_run(csv_ctx* ctx, csv_run_stats* stats /* nullable */);
 int csv_batch_download(csv_ctx* ctx, csv_batch_out* out);
 int csv_ctx_sync(csv_ctx* ctx);
