@@ -114,7 +114,7 @@ struct csv_ctx {
     Arena       arena, arena_rb;
     // batch buffers (slices of `arena`)
     Buf seg, woff, seg_drop, a, b, rid, aux, a32, b32, rs32, re32;
-    Buf cluster_id, partial, partial64, item_rec, list_small, list_big, list_tiny, list_wide, partial_t, seg_gate, tile_info, ch_masks, wave_items, wave_cnt, seg_err;
+    Buf cluster_id, partial, partial64, item_rec, list_small, list_big, list_tiny, list_wide, partial_t, seg_gate, tile_info, ch_masks, tile_items, seg_err;
     Buf item_nslots, item_cnt, item_base, item_chunk, sup_tmp;
     Buf t_rec;
     Buf sc_k, sc_x, sc_v1, sc_v2, sc_v3, sc_v4, sc_v5;
@@ -476,15 +476,17 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
     Plan P;
 #define PL(buf, bytes) P.add(c->buf, (size_t)(bytes))
     PL(seg, (S + 1) * sizeof(csv_segment)); PL(woff, (S + 2) * sizeof(i64)); PL(seg_drop, S + 1); PL(seg_gate, (S + 1) * 16); PL(seg_err, (S + 1) * 4);
-    PL(tile_info, nt * 32);
-    PL(a, (W + 1) * 8); PL(b, (W + 1) * 8); PL(rid, (W + 1) * 4); PL(aux, (W + 1) * 4);
+    PL(tile_info, nt * TILE_REC * 16);
+    // positions and lengths stay in the width they arrive in: the kernels read int32 columns as they are (kernels.hip.h Col)
     const bool sig32 = (in->flags & CSV_IN_SIG_I32) != 0, rd32 = (in->flags & CSV_IN_READS_I32) != 0;
-    if (sig32) { PL(a32, (W + 1) * 4); PL(b32, (W + 1) * 4); }
+    // (the position column is followed by a tile of padding, so that the chain kernel can read any span that begins inside the batch)
+    if (sig32) { PL(a32, (W + CH_TILE + 64) * 4); PL(b32, (W + 1) * 4); } else { PL(a, (W + CH_TILE + 64) * 8); PL(b, (W + 1) * 8); }
+    PL(rid, (W + 1) * 4); PL(aux, (W + 1) * 4);
     PL(sup_tmp, (W + 1) * 4);
     if (per_sig) { PL(cluster_id, (W + 1) * 4); PL(allele_id, (W + 1) * 4); }
     PL(partial, nt * 4); PL(partial64, nt * 8); PL(partial_t, nt * 4);
-    if (per_sig) PL(ch_masks, nt * 4 * CH_ITEMS * 8);
-    PL(wave_items, nt * 4 * (size_t)WI_STRIDE * 16); PL(wave_cnt, nt * 4 * 16);
+    if (per_sig) PL(ch_masks, nt * CT_WORDS * 8);
+    PL(tile_items, nt * (size_t)TI_STRIDE * 16);
     PL(item_rec, cap_items * 16); PL(list_small, cap_items * 16); PL(list_big, cap_items * 4); PL(list_tiny, cap_items * 16); PL(list_wide, cap_items * 16);
     PL(item_nslots, cap_items * 4); PL(item_cnt, cap_items * 8); PL(item_base, (cap_items + 8) * 8); PL(item_chunk, (cap_items / IS_CHUNK + 2) * 8);
     // temp call records are indexed by w (a cluster's slots live in its own signature range)
@@ -508,7 +510,7 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
 
     // ---- small tables: staged in page-locked memory, one copy
     const size_t o_seg = 0, o_woff = o_seg + (size_t)(S + 1) * sizeof(csv_segment), o_drop = o_woff + (size_t)(S + 2) * 8,
-                 o_gate = (o_drop + (size_t)S + 1 + 15) & ~(size_t)15, o_tiles = o_gate + (size_t)(S + 1) * 16, o_end = o_tiles + (size_t)nt * 32;
+                 o_gate = (o_drop + (size_t)S + 1 + 15) & ~(size_t)15, o_tiles = o_gate + (size_t)(S + 1) * 16, o_end = o_tiles + (size_t)nt * TILE_REC * 16;
     // (the staging block is also the landing zone of the results: never smaller than one counters struct)
     { const int rc = pin_reserve(c, o_end + sizeof(DevCounters) + 256); if (rc) return rc; }
     hipStream_t st = c->stream;
@@ -519,22 +521,34 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
     int* gate = (int*)(c->h_pin + o_gate);                  // {read_count, dropped, svtype, -} per segment
     for (int k = 0; k < S; k++) { gate[4 * k] = c->h_seg[k].read_count; gate[4 * k + 1] = drop[k]; gate[4 * k + 2] = c->h_seg[k].svtype; gate[4 * k + 3] = 0; }
     {
-        // per chain tile: first / last segment and, for the tiles that lie inside one segment, its chain scalars (kernels.hip.h
-        // TileInfo).  Empty segments own no row and are skipped, as seg_of_wave does on the device.
+        // per chain tile: first / last segment and the chain / gate scalars of up to three non-empty segments inline
+        // (kernels.hip.h TILE_REC).  Empty segments own no row and are skipped.
         int* ti = (int*)(c->h_pin + o_tiles);
+        memset(ti, 0, (size_t)nt * TILE_REC * 16);
         int k = 0;
         for (i64 t = 0; t < nt; t++) {
-            int* r = ti + 8 * t;
+            int* r = ti + 4 * TILE_REC * t;
             const i64 w0 = t * (i64)CH_TILE, w1 = (w0 + CH_TILE < W ? w0 + CH_TILE : W) - 1;
-            if (w0 >= W) { for (int q = 0; q < 8; q++) r[q] = 0; r[1] = -1; continue; }      // (k0 != k1: never trusted)
+            if (w0 >= W) { r[1] = -1; continue; }
             while (k + 1 < S && c->h_woff[k + 1] <= w0) k++;
             int k1 = k;
             while (k1 + 1 < S && c->h_woff[k1 + 1] <= w1) k1++;
-            const csv_segment& g = c->h_seg[k];
-            r[0] = k; r[1] = k1; r[2] = g.svtype; r[3] = (int)c->h_woff[k];
-            r[4] = (int)(g.max_cluster_bias & 0xffffffffll); r[5] = (int)(g.max_cluster_bias >> 32); r[6] = g.read_count; r[7] = drop[k];
+            r[0] = k; r[1] = k1;
+            int nin = 0;
+            for (int q = k; q <= k1; q++) {
+                if (c->h_woff[q + 1] == c->h_woff[q]) continue;
+                if (nin < 3) {
+                    const csv_segment& g = c->h_seg[q];
+                    int* a = r + 4 + 8 * nin;
+                    a[0] = (int)c->h_woff[q]; a[1] = g.svtype | (drop[q] ? 0x100 : 0); a[2] = g.read_count; a[3] = q;
+                    a[4] = (int)(g.max_cluster_bias & 0xffffffffll); a[5] = (int)(g.max_cluster_bias >> 32);
+                    a[6] = g.max_cluster_bias > 0x7fffffffll ? 0x7fffffff : (g.max_cluster_bias < -0x80000000ll ? (int)0x80000000 : (int)g.max_cluster_bias);
+                }
+                nin++;
+            }
+            r[2] = nin <= 3 ? nin : 0;
         }
-        HIP_TRY(c, hipMemcpyAsync(c->tile_info.p, ti, (size_t)nt * 32, hipMemcpyHostToDevice, st));
+        HIP_TRY(c, hipMemcpyAsync(c->tile_info.p, ti, (size_t)nt * TILE_REC * 16, hipMemcpyHostToDevice, st));
     }
     HIP_TRY(c, hipMemcpyAsync(c->seg.p, c->h_pin + o_seg, (size_t)S * sizeof(csv_segment), hipMemcpyHostToDevice, st));
     HIP_TRY(c, hipMemcpyAsync(c->woff.p, c->h_pin + o_woff, (size_t)(S + 1) * 8, hipMemcpyHostToDevice, st));
@@ -577,9 +591,10 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
             }
             k = e + 1;
         }
-        if (group == 1 && sig32 && W > 0)                     // (the compacted w space is contiguous: one launch widens everything)
-            hipLaunchKernelGGL(k_widen2, dim3(div_up(W, 256 * 8) < 2048 ? div_up(W, 256 * 8) : 2048), dim3(256), 0, cs,
-                               dp<int>(c->a32), dp<i64>(c->a), dp<int>(c->b32), dp<i64>(c->b), W);
+        if (group == 1) {                                   // the padding behind the position column: positive values
+            if (sig32) HIP_TRY(c, hipMemsetD32Async((hipDeviceptr_t)(dp<int>(c->a32) + W), 1, CH_TILE + 64, cs));
+            else HIP_TRY(c, hipMemsetD32Async((hipDeviceptr_t)(dp<i64>(c->a) + W), 1, 2 * (size_t)(CH_TILE + 64), cs));
+        }
         HIP_TRY(c, hipEventRecord(c->ev_copy[group - 1], cs));
     }
     c->copies_pending = true;                               // run_impl orders the kernels behind the two events
@@ -616,13 +631,22 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
     memset(&B, 0, sizeof B);
     B.n_seg = S; B.n_chrom = in->n_chrom; B.W = W;
     B.seg = dp<csv_segment>(c->seg); B.woff = dp<i64>(c->woff); B.seg_drop = dp<uint8_t>(c->seg_drop);
-    B.a = dp<i64>(c->a); B.b = dp<i64>(c->b); B.rid = dp<int>(c->rid); B.aux = dp<int>(c->aux);
+    if (sig32) { B.a = Col{nullptr, dp<int>(c->a32)}; B.b = Col{nullptr, dp<int>(c->b32)}; }
+    else { B.a = Col{dp<i64>(c->a), nullptr}; B.b = Col{dp<i64>(c->b), nullptr}; }
+    B.rid = dp<int>(c->rid); B.aux = dp<int>(c->aux);
     B.per_sig = per_sig ? 1 : 0;
+    B.end_z = 0;                                            // is the batch's last signature a (0,0) element?  (the reference's sentinel rule, INDEL:62-64)
+    for (int k = S - 1; k >= 0; k--)
+        if (c->h_seg[k].sig_end > c->h_seg[k].sig_begin) {
+            const i64 last = c->h_seg[k].sig_end - 1;
+            B.end_z = sig32 ? (((const int32_t*)in->a)[last] == 0 && ((const int32_t*)in->b)[last] == 0) : (in->a[last] == 0 && in->b[last] == 0);
+            break;
+        }
     B.cluster_id = per_sig ? dp<int>(c->cluster_id) : nullptr; B.allele_id = per_sig ? dp<int>(c->allele_id) : nullptr;
     B.partial = dp<int>(c->partial); B.partial64 = dp<i64>(c->partial64);
     B.item_rec = dp<int4>(c->item_rec); B.list_small = dp<int4>(c->list_small); B.list_big = dp<int>(c->list_big); B.list_tiny = dp<int4>(c->list_tiny); B.list_wide = dp<int4>(c->list_wide);
     B.partial_t = dp<int>(c->partial_t); B.seg_gate = dp<int4>(c->seg_gate); B.tile_info = dp<int4>(c->tile_info);
-    B.ch_masks = per_sig ? dp<u64>(c->ch_masks) : nullptr; B.wave_items = dp<int4>(c->wave_items); B.wave_cnt = dp<int4>(c->wave_cnt);
+    B.ch_masks = per_sig ? dp<u64>(c->ch_masks) : nullptr; B.tile_items = dp<int4>(c->tile_items);
     B.seg_err = dp<int>(c->seg_err);
     B.tiny_max = getenv("CSV_NO_TINY") ? 0 : 16;               // (timing aid: 0 sends every DEL/INS cluster of m <= 32 through the paired path)
     B.item_nslots = dp<int>(c->item_nslots); B.item_cnt = dp<i64>(c->item_cnt); B.item_base = dp<i64>(c->item_base); B.item_chunk = dp<i64>(c->item_chunk);
@@ -750,7 +774,8 @@ int run_impl(csv_ctx* c, csv_run_stats* stats)
     B.run_seq = ++c->run_seq;
     if (W > 0) {
         const int nb = div_up(W, CH_TILE);
-        LAUNCH("chain_count", k_chain_count, nb, 320, 0, B);
+        if (B.a.p32) LAUNCH("chain_count", k_chain_count<true>, nb, 256, 0, B);
+        else LAUNCH("chain_count", k_chain_count<false>, nb, 256, 0, B);
         if (fork && do_gt) {                              // reads order + prefix max: independent of the clustering kernels
             HIP_TRY(c, hipEventRecord(c->ev_init, st));   // (after the counters were zeroed)
             HIP_TRY(c, hipStreamWaitEvent(sD, c->ev_init, 0));
@@ -758,7 +783,7 @@ int run_impl(csv_ctx* c, csv_run_stats* stats)
             if (rc) return rc;
             HIP_TRY(c, hipEventRecord(c->ev_aux[2], sD));
         }
-        LAUNCH("chain_apply", k_chain_apply, nb, 256, 0, B);
+        LAUNCH("chain_apply", k_chain_apply, div_up(nb, 4), 256, 0, B);
         if (B.per_sig) hipLaunchKernelGGL(k_chain_ids, dim3(nb), dim3(256), 0, st, B);      // (optional outputs; timed with whatever follows)
         if (c->copies_pending) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_copy[1], 0));   // read ids, INS sequence lengths
         int g_small = B.cap_items < 8192 ? B.cap_items : 8192;
@@ -775,7 +800,8 @@ int run_impl(csv_ctx* c, csv_run_stats* stats)
             HIP_TRY(c, hipStreamWaitEvent(sB, c->ev_sel, 0));
             if (c->any_pair) HIP_TRY(c, hipStreamWaitEvent(sC, c->ev_sel, 0));
         }
-        LAUNCH("refine_indel_wave", k_refine_indel_wave, g_iw, 256, 0, B);
+        if (B.a.p32) LAUNCH("refine_indel_wave", k_refine_indel_wave<true>, g_iw, 256, 0, B);
+        else LAUNCH("refine_indel_wave", k_refine_indel_wave<false>, g_iw, 256, 0, B);
         if (c->any_pair) LAUNCH_ON(sC, "refine_wave", (k_refine<64, 64, false>), g_small, 64, LDS_SMALL, B, 0, 64);
         else HIP_TRY(c, mark());
         // The tiers above 64 signatures usually have nothing to do (a 30x genome has no such cluster) and an empty launch

@@ -33,6 +33,8 @@
 #else
 #define CSV_ABL(bit) 0
 #endif
+#define CSV_LIKELY(x) __builtin_expect(!!(x), 1)
+#define CSV_UNLIKELY(x) __builtin_expect(!!(x), 0)
 
 namespace csv {
 
@@ -103,6 +105,16 @@ struct DevCounters {          // one small struct in device memory, zeroed at th
 };
 enum { RO_REORDER = 0, RO_IDENTITY = 1, RO_NEED_GENERAL = 2 };
 
+// A position / length column as the caller sent it: int64, or int32 (CSV_IN_SIG_I32 / CSV_IN_READS_I32: a genome's coordinates
+// fit 31 bits) - consumed as it is, never widened into a second copy.  The pointer test is wave-uniform (kernel argument).
+// The hot kernels are instantiated per width (NARROW) and go through col_at<> instead.
+struct Col {
+    const i64* p64;
+    const int* p32;
+    __device__ __forceinline__ i64 operator[](i64 i) const { return p32 ? (i64)p32[i] : p64[i]; }
+};
+template <bool NARROW> __device__ __forceinline__ i64 col_at(const Col& c, i64 i) { if constexpr (NARROW) return (i64)c.p32[i]; else return c.p64[i]; }
+
 // Everything the kernels need, passed by value.
 struct DevBatch {
     int            n_seg;
@@ -111,8 +123,8 @@ struct DevBatch {
     const csv_segment* seg;          // device copy of the segment table
     const i64*     woff;             // n_seg + 1 prefix of segment lengths
     const uint8_t* seg_drop;         // genotype requested but no reads block (INDEL:443-444)
-    const i64*     a;
-    const i64*     b;
+    Col            a;                // int(pos) / pos1
+    Col            b;                // length / pos2
     const int*     rid;
     const int*     aux;
     // chain / select
@@ -127,17 +139,16 @@ struct DevBatch {
     int4*          list_wide;        // DEL/INS items with 32 < m <= 64 (same entries, any order): their own units, so that no
                                      // wavefront runs a pair and then its wide members one after the other
     int            tiny_max;         // 16 (0 switches the class off)
-    u64*           ch_masks;         // per chain wavefront (512 signatures): its 8 flag masks (written only for CSV_IN_PER_SIG: k_chain_ids)
-    int4*          wave_items;       // per chain wavefront, WI_STRIDE slots: the clusters that passed the size gate, in order:
-                                     // {first w, size, segment | svtype << 24 | tier << 28, cluster index relative to the wavefront}
-    int4*          wave_cnt;         // per chain wavefront {cluster starts, work items, workgroup-tier items, tiny items}
+    u64*           ch_masks;         // per chain tile: its 32 flag words (written only for CSV_IN_PER_SIG: k_chain_ids)
+    int4*          tile_items;       // per chain tile, TI_STRIDE slots: the clusters that passed the size gate, in order:
+                                     // {first w, size, segment | svtype << 24 | tier << 28, cluster index inside the tile}
     int            per_sig;          // CSV_IN_PER_SIG: cluster_id / allele_id are produced
+    int            end_z;            // the batch's last signature is a (0,0) element (looked up by the host at upload)
     int*           host_flag;        // page-locked host words {run sequence, work items above 64 signatures}: the host peeks
     int            run_seq;          // at them while k_refine_indel_wave runs and launches only the tiers that have work
     int*           seg_err;          // n_seg words of CSV_SEG_* bits
     const int4*    seg_gate;         // per segment {read_count, dropped, svtype, -}: one 16-byte load for the size gate
-    const int4*    tile_info;        // per chain tile, built by the host: {k_first, k_last, svtype, segment start} and
-                                     // {max_cluster_bias lo, hi, read_count, dropped} of k_first (TileInfo below)
+    const int4*    tile_info;        // per chain tile, built by the host: TILE_REC int4 words (see TILE_REC below)
     int*           partial_t;        // tiny work items per chain tile
     // refine outputs
     int*           item_nslots;      // temp slots the item filled (t_*[s + slot])
@@ -274,129 +285,88 @@ __device__ __forceinline__ int seg_of(const DevBatch& B, i64 w)
     return lo;
 }
 
-// same for a wave-uniform w: all 64 lanes probe one segment each, one load round instead of a
-// dependent binary search (the segment table has ~120 entries for a genome)
-// segment of signature w, searched by the whole wavefront among the segments [klo, khi] (the range of w's chain tile, from
-// the host-built tile table: a reference with thousands of small contigs has thousands of segments, and a probe of the
-// whole table from every wavefront that crosses a boundary made k_chain_count 8x slower on an 8000-segment batch)
-__device__ __forceinline__ int seg_of_wave(const DevBatch& B, i64 w, int klo, int khi)
-{
-    for (int base = klo; base <= khi; base += 64) {
-        const int l = base + lane_id();
-        const bool hit = l <= khi && B.woff[l] <= w && w < B.woff[l + 1];
-        const u64 mk = __ballot(hit);
-        if (mk) return base + __ffsll((long long)mk) - 1;
-    }
-    return klo;
-}
-
 // ------------------------------------------------------------------------------------ chain
 // flag[w] = 1 when w starts a new chained cluster: first of its segment, the type's break predicate
 // against the previous signature, or the previous signature is a (0,0) look-alike of the reference's
 // sentinel (see oracle csvo_cluster_batch).
-__device__ __forceinline__ int chain_flag(const DevBatch& B, i64 w, int& seg_hint, i64& a0, int k_last)
-{
-    // all 64 lanes of a row call this together (w = row base + lane); out-of-range lanes pass w >= W
-    const bool in = w < B.W;
-    const i64 a1 = in ? B.a[w] : 0;
-    a0 = wave_shr1_i64(a1);
-    if (lane_id() == 0 && in && w > 0) a0 = B.a[w - 1];
-    if (!in) return 0;
-    // a lane's w only grows from row to row, so its segment is found by walking forward from the last one
-    // (bounded by the segment of the span's last signature): no binary search over the segment table
-    int k = seg_hint;
-    while (k < k_last && w >= B.woff[k + 1]) k++;
-    seg_hint = k;
-    if (w == B.woff[k]) return 1;
-    const csv_segment& sg = B.seg[k];
-    const i64 bias = sg.max_cluster_bias;
-    if (a1 - a0 > bias) return 1;
-    if (a0 == 0 && B.b[w - 1] == 0) return 1;
-    if (sg.svtype == CSV_INV) return (B.b[w] - B.b[w - 1] > bias) || (B.aux[w] != B.aux[w - 1]);
-    if (sg.svtype == CSV_TRA) return B.aux[w] != B.aux[w - 1];
-    return 0;
-}
-
 constexpr int CH_ITEMS = 8;                         // rows of 64 per wavefront
 constexpr int CH_TILE = 256 * CH_ITEMS;             // signatures per workgroup
+constexpr int CT_WORDS = CH_TILE / WAVE;            // flag words (64 signatures each) per tile
+constexpr int TI_STRIDE = CH_TILE + 8;              // work-item slots per tile (at most one per signature)
 
-// Flags of the CH_ITEMS rows a wavefront owns ([base, base + 512)), handed row by row to `sink(r, mask, zmask, segment)`
-// (the masks are wave-uniform 64-bit values: keeping all 16 of them alive cost 32 SGPRs and, through the SGPR file, two
-// wavefronts per SIMD of occupancy).  When the whole span lies in one segment (almost always) the segment scalars sit
-// in SGPRs and the 8 row loads are issued back to back; the neighbour value comes from the lane to the left.
-// zmask marks cluster starts whose preceding signature is a (0,0) element.
 // What the chain kernels need to know about a tile's segment(s).  The host knows the segment table when it uploads a
-// batch, so it leaves one 32-byte record per tile: a tile that lies inside one segment (almost all do) gets its scalars
-// with the same round trip as its rows instead of three dependent ones (segment search -> segment record -> rows).
-struct TileInfo { int k0, k1, type, sf; i64 bias; int rc, drop; };
-__device__ __forceinline__ TileInfo tile_info_of(const DevBatch& B, int tile)
+// batch, so it leaves one 128-byte record per tile (TILE_REC int4 words) that holds the chain / gate scalars of up to
+// three NON-EMPTY segments overlapping the tile INLINE.  With it a tile's flags need no dependent look-up (segment search
+// -> segment record -> rows) at all: record and rows are loaded together, ONE round trip.  (A kernel lasts as long as its
+// slowest wavefront: in the first forms of this kernel the ~50 spans of a 30x genome that cross a segment boundary walked a
+// chain of 4-5 dependent loads, and that chain - not the 5 400 fast wavefronts - was 6.5 us of the kernel's 12.)
+//   [0]          {first segment k0, last segment k1 (overlapping the tile), inline count nin (0: more than three), -}
+//   [1 + 2 i]    segment i: {first w, svtype | dropped << 8, read_count, segment index}
+//   [2 + 2 i]    segment i: {max_cluster_bias lo, hi, the bias clamped to int32, -}
+constexpr int TILE_REC = 8;
+struct TileSegI { int sf, type, drop, rc, k, bias32; i64 bias; };
+__device__ __forceinline__ TileSegI tile_seg(const int4 a, const int4 b)
 {
-    const int4 t0 = B.tile_info[2 * tile], t1 = B.tile_info[2 * tile + 1];
-    TileInfo T;
-    T.k0 = __builtin_amdgcn_readfirstlane(t0.x); T.k1 = __builtin_amdgcn_readfirstlane(t0.y);
-    T.type = __builtin_amdgcn_readfirstlane(t0.z); T.sf = __builtin_amdgcn_readfirstlane(t0.w);
-    T.bias = ((i64)__builtin_amdgcn_readfirstlane(t1.y) << 32) | (i64)(unsigned)__builtin_amdgcn_readfirstlane(t1.x);
-    T.rc = __builtin_amdgcn_readfirstlane(t1.z); T.drop = __builtin_amdgcn_readfirstlane(t1.w);
-    return T;
+    TileSegI g;
+    g.sf = a.x; g.type = a.y & 0xff; g.drop = (a.y >> 8) & 1; g.rc = a.z; g.k = a.w;
+    g.bias = ((i64)b.y << 32) | (i64)(unsigned)b.x; g.bias32 = b.z;
+    return g;
 }
+__device__ __forceinline__ bool pair_type(int t) { return t == CSV_INV || t == CSV_TRA; }
 
-template <class Sink> __device__ __forceinline__ void chain_rows(const DevBatch& B, i64 base, const TileInfo& T, Sink&& sink)
+// The general form of the break flags, one signature at a time, every lane on its own: any type, any number of segment
+// boundaries, the batch's first and last spans.  What a lane needs of its segment: the chain scalars and where the segment
+// and its successor begin.  All loads of a lane are independent of each other except segment search -> segment scalars, so a
+// span that crosses a boundary costs a few dependent round trips, not a few per row (the first form of this path walked the
+// rows one after the other and, with 47 boundary spans in a 30x genome, its latency chain WAS the kernel's duration).
+struct SegScal { i64 bias, sf, next; int type; };
+__device__ __forceinline__ void seg_scal_load(const DevBatch& B, int k, SegScal& S)
 {
-    const int lane = lane_id();
-    if (base >= B.W) return;
-    // the rows first: their addresses depend on nothing, the segment probes below ride on the same round trip
-    const int w0 = (int)base, nW = (int)B.W;            // (a batch holds < 2^31 signatures)
-    i64 a[CH_ITEMS];
-#pragma unroll
-    for (int r = 0; r < CH_ITEMS; r++) { const int w = w0 + r * WAVE + lane; a[r] = (w < nW) ? B.a[w] : 0; }
-    i64 left = (lane == 0 && base > 0) ? B.a[base - 1] : 0;         // the signature left of the span (lane 0 only)
-    int k0 = T.k0, sf = T.sf, type = T.type;
-    i64 bias = T.bias;
-    if (T.k0 != T.k1) {                               // the tile spans segments: does this wavefront's span?
-        const i64 lastw = (base + WAVE * CH_ITEMS - 1 < B.W) ? base + WAVE * CH_ITEMS - 1 : B.W - 1;
-        k0 = __builtin_amdgcn_readfirstlane(seg_of_wave(B, base, T.k0, T.k1));
-        const int k1 = __builtin_amdgcn_readfirstlane(seg_of_wave(B, lastw, T.k0, T.k1));
-        if (k0 != k1) {                               // it does: per-row path
-            int seg_hint = k0;
-#pragma unroll 1
-            for (int r = 0; r < CH_ITEMS; r++) {
-                const i64 w = base + r * WAVE + lane;
-                i64 a0;
-                const int f = chain_flag(B, w, seg_hint, a0, k1);
-                const u64 zm = __ballot(f && w > 0 && w < B.W && a0 == 0 && B.b[w > 0 ? w - 1 : 0] == 0);
-                sink(r, f != 0, __ballot(f), zm, seg_hint);
-            }
-            return;
-        }
-        const csv_segment& sg = B.seg[k0];
-        // segment scalars are wave-uniform: say so, and the type tests below become scalar branches
-        bias = readlane_i64x(sg.max_cluster_bias, 0);
-        sf = __builtin_amdgcn_readfirstlane((int)B.woff[k0]); type = __builtin_amdgcn_readfirstlane(sg.svtype);
+    S.sf = B.woff[k]; S.next = B.woff[k + 1];
+    S.bias = B.seg[k].max_cluster_bias; S.type = B.seg[k].svtype;
+}
+// last segment of [k0, k1] that begins at or before w (binary search; empty segments are skipped naturally)
+__device__ __forceinline__ int seg_in_tile(const DevBatch& B, i64 w, int k0, int k1)
+{
+    int lo = k0, hi = k1 + 1;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (B.woff[mid] <= w) lo = mid; else hi = mid; }
+    return lo;
+}
+// break flag f and (0,0) mark z of signature w > 0's pair (left neighbour values *0, own values *1)
+__device__ __forceinline__ void sig_flag(i64 w, const SegScal& S, i64 a1, i64 a0, i64 b1, i64 b0, int x1, int x0, bool& f, bool& z)
+{
+    z = w > 0 && a0 == 0 && b0 == 0;
+    f = w == S.sf || a1 - a0 > S.bias || z;
+    if (!f) {
+        if (S.type == CSV_INV) f = (b1 - b0 > S.bias) || (x1 != x0);
+        else if (S.type == CSV_TRA) f = x1 != x0;
     }
-    // INNER: the span lies wholly inside the batch and does not begin it (every wavefront but a handful): no range tests
-    auto rows = [&](auto inner_tag) {
-        constexpr bool INNER = decltype(inner_tag)::value;
+}
+// the 8 signatures [w0, w0 + 8) of one lane (those below W): flag byte and mark byte
+__device__ __forceinline__ void chain_bytes_general(const DevBatch& B, i64 w0, int k0, int k1, unsigned& byte_out, unsigned& zbyte_out)
+{
+    unsigned byte = 0, zb = 0;
+    if (w0 < B.W) {
+        i64 a[9], b[9]; int x[9];
+        const i64 wl = w0 > 0 ? w0 - 1 : 0;
+        a[0] = B.a[wl]; b[0] = B.b[wl]; x[0] = B.aux[wl];
 #pragma unroll
-        for (int r = 0; r < CH_ITEMS; r++) {
-            const int w = w0 + r * WAVE + lane;
-            i64 a0 = wave_shr1_i64(a[r]);
-            if (lane == 0) a0 = left;
-            left = readlane_i64x(a[r], 63);             // (v_readlane: the next row's lane 0 reads it back as a scalar)
-            const bool in = INNER || w < nW;
-            bool f = in && (w == sf || a[r] - a0 > bias);
-            // a (0,0) predecessor looks like the reference's sentinel: only a signature at position 0 can be one, so the
-            // length column is touched behind a wave-uniform test that almost never fires
-            bool z = false;
-            const bool zc = in && (INNER || w > 0) && a0 == 0;
-            if (__ballot(zc)) z = zc && B.b[w - 1] == 0;
-            if (type == CSV_INV) { if (in && !f && !z && w != sf) f = (B.b[w] - B.b[w - 1] > bias) || (B.aux[w] != B.aux[w - 1]); }
-            else if (type == CSV_TRA) { if (in && !f && !z && w != sf) f = B.aux[w] != B.aux[w - 1]; }
-            if (z && w != sf) f = true;
-            const u64 zm = __ballot(f && z);
-            sink(r, f, __ballot(f), zm, k0);
+        for (int j = 0; j < 8; j++) { const i64 w = w0 + j < B.W ? w0 + j : B.W - 1; a[j + 1] = B.a[w]; b[j + 1] = B.b[w]; x[j + 1] = B.aux[w]; }
+        int k = seg_in_tile(B, w0, k0, k1);
+        SegScal S;
+        seg_scal_load(B, k, S);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const i64 w = w0 + j;
+            if (w < B.W) {
+                while (k < k1 && w >= S.next) { k++; seg_scal_load(B, k, S); }
+                bool f, z;
+                sig_flag(w, S, a[j + 1], a[j], b[j + 1], b[j], x[j + 1], x[j], f, z);
+                byte |= (unsigned)f << j; zb |= (unsigned)(f && z) << j;
+            }
         }
-    };
-    if (base > 0 && base + WAVE * CH_ITEMS <= B.W) rows(std::true_type{}); else rows(std::false_type{});
+    }
+    byte_out = byte; zbyte_out = zb;
 }
 constexpr int EM_TILE = 8;                          // items per emit wavefront
 constexpr int EM_SUPER = 512;                       // items per second-level sum
@@ -426,211 +396,360 @@ __device__ __forceinline__ i64 block_prefix_of64(const i64* p, int n, i64* sh)
 }
 
 // ------------------------------------------------------------------------------------ chain + work list in two kernels
-// Count / apply scan over 2048-signature tiles (apply re-derives its prefix from the per-tile counts; no separate scan
-// kernel).  The size gate (a cluster is a work item when it has >= read_count signatures, does not end in a (0,0)
-// element and its segment is not dropped; INDEL:62-64) is applied where a cluster ENDS, inside the same kernels: every tile lists its cluster starts in LDS (S[1..n]; S[0] = the last start before the tile, found
-// by a fifth wavefront that looks backwards while the other four read their rows), so the clusters that end in the
-// tile are the pairs (S[i], S[i + 1]) and one thread gates one cluster - a handful of integer instructions per
-// cluster instead of lane-mask arithmetic per row (a first version of this fusion did the latter and lost to
-// separate select kernels: DESIGN.md section 6).  No cluster-start / cluster-segment arrays in HBM.
+// k_chain_count: one workgroup per tile of 2048 signatures.  A chained cluster belongs to the tile it STARTS in.
+//   1. rows -> break flags, kept as bit masks only: 32 words of 64 flags in LDS (+ one word for the 64 signatures after the
+//      tile, so that the tile's last cluster finds its end; the end of the batch counts as one more start).  No list of
+//      cluster starts is ever written: half of all signatures of a 30x genome start a cluster (singletons), and the first
+//      version of this kernel spent most of its ~146 instructions per row of 64 on listing them and on a gate per start.
+//   2. every thread owns 8 flags: the next start after its byte (a find-first-set over the rest of its word, the following
+//      words only when that is empty), then its own starts from the top down: size = next start - this start.  The size gate
+//      (a cluster is a work item when it has >= read_count signatures, does not end in a (0,0) element and its segment is not
+//      dropped; INDEL:62-64) is a compare per start; the few per cent that pass are counted.
+//   3. one packed wave scan (starts | work items << 16) + four wave totals order the tile's work items; their 16-byte
+//      records {first w, size, segment | svtype << 24 | tier << 28, cluster index inside the tile} go to the tile's region.
+// k_chain_apply turns the per-tile counts into global bases and compacts the records into the ordered work list and the
+// tier lists.  (Fusing the two through a look-back costs an agent-scope release + acquire per tile, ~3.5 us against the
+// ~1.7 us of a kernel boundary - MI355X_MICROARCH.md price list - and was measured slower in round 1.)
 
-struct TileSeg { int uni, k, rc, drop, type; };                  // workgroup-uniform: the tile lies in one segment
-
-// gate scalars {read_count, dropped, svtype} of segment k: the tile's own when it lies in one segment, else one
-// 16-byte load (rare: a tile that spans segments, or a cluster of the previous one)
-__device__ __forceinline__ int4 gate_scalars(const DevBatch& B, const TileSeg& ts, int k)
+// gate of the cluster of m signatures in a segment with gate scalars g = {read_count, dropped, svtype}: bit 0 work item,
+// bit 1 workgroup tier, bit 2 tiny, bit 3 wide (a DEL/INS cluster of 33 .. 64 signatures)
+__device__ __forceinline__ int close_gate(int tiny_max, const int4 g, int m, int endz)
 {
-    if (ts.uni && k == ts.k) return make_int4(ts.rc, ts.drop, ts.type, 0);
-    return B.seg_gate[k];
-}
-// gate of the cluster [s, e) (INDEL:62-64 and the drop rule): bit 0 work item, bit 1 workgroup tier, bit 2 tiny, bit 3 wide
-// (a DEL/INS cluster of 33 .. 64 signatures)
-__device__ __forceinline__ int close_gate(const DevBatch& B, const int4 g, int s, int e, int endz)
-{
-    const int m = e - s;
     if (endz || m < g.x || g.y) return 0;
-    return 1 | ((m > 64) ? 2 : 0) | ((m <= B.tiny_max && g.z <= CSV_INS) ? 4 : 0) | ((m > 32 && m <= 64 && m > B.tiny_max && g.z <= CSV_INS) ? 8 : 0);
+    return 1 | ((m > 64) ? 2 : 0) | ((m <= tiny_max && g.z <= CSV_INS) ? 4 : 0) | ((m > 32 && m <= 64 && m > tiny_max && g.z <= CSV_INS) ? 8 : 0);
 }
 
-// rows -> flags; the wavefront's cluster starts (bit 31: previous signature is (0,0)) and their segments go to its OWN
-// region of the LDS lists, so nothing here waits for another wavefront.  Returns the wavefront's number of starts;
-// `pub` = lane r's copy of row r's flag mask (for k_chain_ids).
-constexpr int CL_REG = WAVE * CH_ITEMS + 2;          // entries per wavefront region (512 starts + the sentinel)
-constexpr int WI_STRIDE = WAVE * CH_ITEMS + 8;       // item slots per wavefront (at most 513 clusters end in its span)
-__device__ __forceinline__ int wave_starts(const DevBatch& B, i64 base, const TileInfo& T, int* SR, int* SKR, u64& pub)
+// starts among the 64 signatures [cb, cb + 64), cb <= W (bit i = signature cb + i), the end of the batch counting as one
+// more start (bit W - cb when it falls inside the row); *zm = which of them follow a (0,0) element.  Used to look ahead
+// from a tile; one signature per lane, the general form.
+__device__ __forceinline__ u64 chain_flag_row64(const DevBatch& B, i64 cb, u64* zm)
 {
-    int off = 0;
-    u64 pb = 0;
-    chain_rows(B, base, T, [&](int r, bool f, u64 m, u64 zm, int kseg) {
-        if (!CSV_ABL(8) && f) {
-            const int idx = off + __popcll(m & lanemask_lt());
-            int v = (int)base + r * WAVE + lane_id();
-            if (zm) v |= (int)((zm >> lane_id()) & 1) << 31;               // (wave-uniform test: the mask is almost always 0)
-            SR[idx] = v;
-            if (T.k0 != T.k1) SKR[idx] = kseg;                              // (a tile inside one segment never reads them)
-        }
-        off += __popcll(m);
-        if (lane_id() == r) pb = m;
-    });
-    pub = pb;
-    return off;
-}
-// start (and segment) of the cluster that is still open where wavefront wv's span begins: the last entry of the
-// nearest earlier non-empty region, else the tile's look-back result
-__device__ __forceinline__ int2 open_before(const int (*SR)[CL_REG], const int (*SKR)[CL_REG], const int* s_cnt, int wv, int2 tile_prev, const TileInfo& T)
-{
-    for (int q = wv - 1; q >= 0; q--)
-        if (s_cnt[q] > 0) return make_int2(SR[q][s_cnt[q] - 1], T.k0 == T.k1 ? T.k0 : SKR[q][s_cnt[q] - 1]);
-    return tile_prev;
-}
-
-// flags of the 64 signatures [cb, cb + 64), cb >= 0 (used to look backwards from a tile).  Same shape as
-// chain_rows: the row load is issued before the segment probes; one segment -> scalars + neighbour by DPP.
-__device__ __forceinline__ u64 chain_flag_row64(const DevBatch& B, i64 cb, int& kseg, const TileInfo& T)
-{
-    const i64 lastw = cb + 63 < B.W ? cb + 63 : B.W - 1;
     const i64 w = cb + lane_id();
-    const bool in = w < B.W;
-    const i64 a1 = in ? B.a[w] : 0;
-    const i64 left = (lane_id() == 0 && cb > 0) ? B.a[cb - 1] : 0;
-    i64 bias = T.bias, seg_first = T.sf;
-    int type = T.type, k0 = T.k0;
-    if (T.k0 != T.k1 || cb < T.sf) {                   // not (known to be) inside the tile's own segment
+    u64 f_end = 0, z_end = 0;                          // the batch's end
+    if (B.W - cb < 64) {
+        f_end = 1ull << (B.W - cb);
+        if (B.end_z) z_end = f_end;
+    }
+    if (cb >= B.W) { *zm = z_end; return f_end; }
+    bool f = false, z = false;
+    if (w < B.W) {
         // (the 64 signatures lie in one chain tile - tiles are multiples of 64 - whose segment range bounds the search)
-        const int4 tr = B.tile_info[2 * (int)(cb / CH_TILE)];
-        const int rlo = __builtin_amdgcn_readfirstlane(tr.x), rhi = __builtin_amdgcn_readfirstlane(tr.y);
-        k0 = __builtin_amdgcn_readfirstlane(seg_of_wave(B, cb, rlo, rhi));
-        const int k1 = __builtin_amdgcn_readfirstlane(seg_of_wave(B, lastw, rlo, rhi));
-        if (k0 != k1) {
-            int hint = k0;
-            i64 a0;
-            const int f = chain_flag(B, w, hint, a0, k1);
-            kseg = hint;
-            return __ballot(f);
-        }
-        const csv_segment& sg = B.seg[k0];
-        bias = sg.max_cluster_bias; seg_first = B.woff[k0]; type = sg.svtype;
+        const int4 tr = B.tile_info[TILE_REC * (int)(cb / CH_TILE)];
+        const i64 wl = w > 0 ? w - 1 : 0;
+        const i64 a1 = B.a[w], a0 = B.a[wl], b1 = B.b[w], b0 = B.b[wl];
+        const int x1 = B.aux[w], x0 = B.aux[wl];
+        SegScal S;
+        seg_scal_load(B, seg_in_tile(B, w, tr.x, tr.y), S);
+        sig_flag(w, S, a1, a0, b1, b0, x1, x0, f, z);
     }
-    kseg = k0;
-    i64 a0 = wave_shr1_i64(a1);
-    if (lane_id() == 0) a0 = left;
-    bool f = in && (w == seg_first || a1 - a0 > bias);
-    if (in && !f) {
-        if (w > 0 && a0 == 0 && B.b[w - 1] == 0) f = true;
-        else if (type == CSV_INV) f = (B.b[w] - B.b[w - 1] > bias) || (B.aux[w] != B.aux[w - 1]);
-        else if (type == CSV_TRA) f = B.aux[w] != B.aux[w - 1];
-    }
-    return __ballot(f);
+    *zm = __ballot(f && z) | z_end;
+    return __ballot(f) | f_end;
 }
 
-// (96 SGPRs: 7 wavefronts per SIMD instead of 6 by the SGPR file, for ten scalar spills - measured 20.4 vs 21.0 us)
-__global__ __launch_bounds__(320) __attribute__((amdgpu_num_sgpr(96))) void k_chain_count(DevBatch B)
+// The fast form of a wavefront's 512 flags: the tile's segments (at most three, none of them INV / TRA) are inline in its
+// record.  Lane l owns the 8 consecutive signatures [base + 8 l, base + 8 l + 8): 32 (int32 columns) or 64 contiguous bytes per
+// lane, loaded 16 bytes at a time; seven of its eight neighbour differences are in-lane, the eighth comes from the lane to the
+// left with one DPP move, and the lane's 8 flags are a byte in a register - no ballots, no masks in SGPRs.
+// The loads depend on nothing but the block index, so they are issued BEFORE the tile record is known (SpanRows; the position
+// column is padded by a tile of positive values, so any span that begins inside the batch can be read), together with the
+// tile record and the row after the tile: the kernel's common path is ONE memory round trip.
+template <bool NARROW> struct SpanRows;
+template <> struct SpanRows<true>  { int4 v0, v1; int left; };
+template <> struct SpanRows<false> { longlong2 v0, v1, v2, v3; i64 left; };
+template <bool NARROW> __device__ __forceinline__ void span_rows_load(const DevBatch& B, i64 base, SpanRows<NARROW>& R)
+{
+    const i64 lw = base > 0 ? base - 1 : 0;                     // (every lane, one address: no divergent block around a load)
+    if constexpr (NARROW) {
+        const int4* p = (const int4*)(B.a.p32 + base) + 2 * lane_id();
+        R.v0 = p[0]; R.v1 = p[1];
+        R.left = B.a.p32[lw];
+    } else {
+        const longlong2* p = (const longlong2*)(B.a.p64 + base) + 4 * lane_id();
+        R.v0 = p[0]; R.v1 = p[1]; R.v2 = p[2]; R.v3 = p[3];
+        R.left = B.a.p64[lw];
+    }
+}
+// Returns false (wave-uniform) when a value of the span is 0 or negative: position 0 may be a (0,0) look-alike of the
+// reference's sentinel and negative values would overflow the 32-bit differences; the caller then takes the general form.
+// s0 .. s2: the tile's inline segments (nin of them, wave-uniform).
+template <bool NARROW> __device__ __forceinline__ bool chain_bytes_fast(const SpanRows<NARROW>& R, i64 base, int nin, const TileSegI& s0, const TileSegI& s1,
+                                                                        const TileSegI& s2, unsigned& byte_out)
+{
+    const int lane = lane_id();
+    const int w0 = (int)base + 8 * lane;
+    unsigned byte = 0;
+    if constexpr (NARROW) {
+        const int4 v0 = R.v0, v1 = R.v1;
+        int prev = dpp_i32<0x138, 0xf>(0, v1.w);               // wave_shr:1
+        if (lane == 0) prev = R.left;
+        // all values (and the neighbour) positive?  unsigned minimum / maximum of the nine
+        const unsigned mn = min(min(min((unsigned)v0.x, (unsigned)v0.y), min((unsigned)v0.z, (unsigned)v0.w)),
+                                min(min((unsigned)v1.x, (unsigned)v1.y), min(min((unsigned)v1.z, (unsigned)v1.w), (unsigned)prev)));
+        const unsigned mx = max(max(max((unsigned)v0.x, (unsigned)v0.y), max((unsigned)v0.z, (unsigned)v0.w)),
+                                max(max((unsigned)v1.x, (unsigned)v1.y), max(max((unsigned)v1.z, (unsigned)v1.w), (unsigned)prev)));
+        if (CSV_UNLIKELY(__ballot(mn == 0 || mx > 0x7fffffffu) != 0)) return false;
+        // differences of non-negative 31-bit values cannot overflow; a bias beyond 31 bits can never be exceeded (bias32)
+        const int d0 = v0.x - prev, d1 = v0.y - v0.x, d2 = v0.z - v0.y, d3 = v0.w - v0.z, d4 = v1.x - v0.w, d5 = v1.y - v1.x, d6 = v1.z - v1.y, d7 = v1.w - v1.z;
+        if (CSV_LIKELY(nin == 1)) {
+            const int bias = s0.bias32;
+            byte = (unsigned)(d0 > bias) | ((unsigned)(d1 > bias) << 1) | ((unsigned)(d2 > bias) << 2) | ((unsigned)(d3 > bias) << 3) |
+                   ((unsigned)(d4 > bias) << 4) | ((unsigned)(d5 > bias) << 5) | ((unsigned)(d6 > bias) << 6) | ((unsigned)(d7 > bias) << 7);
+        } else {
+            // a tile on a segment boundary: the bias of the signature's own segment
+            const int sf1 = s1.sf, sf2 = nin > 2 ? s2.sf : 0x7fffffff, b0 = s0.bias32, b1 = s1.bias32, b2 = s2.bias32;
+            const int d[8] = {d0, d1, d2, d3, d4, d5, d6, d7};
+#pragma unroll
+            for (int j = 0; j < 8; j++) { const int w = w0 + j, bias = w >= sf2 ? b2 : (w >= sf1 ? b1 : b0); byte |= (unsigned)(d[j] > bias) << j; }
+        }
+    } else {
+        const longlong2 v0 = R.v0, v1 = R.v1, v2 = R.v2, v3 = R.v3;
+        i64 prev = wave_shr1_i64(v3.y);
+        if (lane == 0) prev = R.left;
+        const bool zero = v0.x == 0 || v0.y == 0 || v1.x == 0 || v1.y == 0 || v2.x == 0 || v2.y == 0 || v3.x == 0 || v3.y == 0 || prev == 0;
+        if (CSV_UNLIKELY(__ballot(zero) != 0)) return false;
+        const i64 d[8] = {v0.x - prev, v0.y - v0.x, v1.x - v0.y, v1.y - v1.x, v2.x - v1.y, v2.y - v2.x, v3.x - v2.y, v3.y - v3.x};
+        const int sf1 = nin > 1 ? s1.sf : 0x7fffffff, sf2 = nin > 2 ? s2.sf : 0x7fffffff;
+#pragma unroll
+        for (int j = 0; j < 8; j++) { const int w = w0 + j; const i64 bias = w >= sf2 ? s2.bias : (w >= sf1 ? s1.bias : s0.bias); byte |= (unsigned)(d[j] > bias) << j; }
+    }
+    // the first signature of a segment is a start
+    { const int rel = s0.sf - w0; if (rel >= 0 && rel < 8) byte |= 1u << rel; }
+    if (nin > 1) { const int rel = s1.sf - w0; if (rel >= 0 && rel < 8) byte |= 1u << rel; }
+    if (nin > 2) { const int rel = s2.sf - w0; if (rel >= 0 && rel < 8) byte |= 1u << rel; }
+    byte_out = byte;
+    return true;
+}
+
+// first start after bit i of the 64-flag window `win` that begins at tile-relative position p0 (word wi, bit offset sh8); the
+// look-ahead word and the far end included
+__device__ __forceinline__ int chain_next_start(const u64* s_F, u64 win, u64 w1, int wi, int sh8, int p0, int i, int far)
+{
+    const u64 above = (i < 63) ? (win & ~((2ull << i) - 1ull)) : 0ull;
+    if (above) return p0 + __ffsll((long long)above) - 1;
+    const u64 rest = sh8 ? (w1 >> sh8) : w1;                // what the window did not cover of word wi + 1
+    if (rest) return p0 + 64 + __ffsll((long long)rest) - 1;
+    for (int wj = wi + 2; wj <= CT_WORDS; wj++) { const u64 f2 = s_F[wj]; if (f2) return wj * 64 + __ffsll((long long)f2) - 1; }
+    return far;
+}
+// gate scalars {read_count, dropped, svtype} and segment of the cluster that starts at signature w
+__device__ __forceinline__ int4 chain_gate_of(const i64* woff, const int4* seg_gate, int w, int nin, int k0, int k1, const TileSegI& g0, const TileSegI& g1,
+                                              const TileSegI& g2, int& kseg)
+{
+    if (CSV_LIKELY(nin >= 1)) {
+        const bool i2 = nin > 2 && w >= g2.sf, i1 = nin > 1 && w >= g1.sf;
+        kseg = i2 ? g2.k : (i1 ? g1.k : g0.k);
+        return make_int4(i2 ? g2.rc : (i1 ? g1.rc : g0.rc), i2 ? g2.drop : (i1 ? g1.drop : g0.drop), i2 ? g2.type : (i1 ? g1.type : g0.type), 0);
+    }
+    int lo = k0, hi = k1 + 1;                               // more than three segments in the tile: the segment table
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (woff[mid] <= w) lo = mid; else hi = mid; }
+    kseg = lo;
+    return seg_gate[lo];
+}
+
+template <bool NARROW> __global__ __launch_bounds__(256) void k_chain_count(DevBatch B)
 {
     // first kernel of a run: nothing in this kernel reads the counters, every later kernel is stream-ordered behind it
     if (blockIdx.x == 0 && threadIdx.x < (int)(sizeof(DevCounters) / 4)) ((int*)B.cnt)[threadIdx.x] = 0;
-    __shared__ int SR[4][CL_REG], SKR[4][CL_REG];         // per wavefront: its cluster starts and their segments
-    __shared__ int s_cnt[4], s_t[4], s_prev[2];
-    __shared__ i64 s_v[4];
-    const int wv = threadIdx.x >> 6;
+    // flags / (0,0)-predecessor marks of the tile, one bit per signature (word w = signatures 64 w .. 64 w + 63, also addressed
+    // as bytes of 8 signatures); [32] = the row after the tile
+    __shared__ __attribute__((aligned(16))) u64 s_F[CT_WORDS + 2], s_Z[CT_WORDS + 2];
+    __shared__ int s_far[2], s_w[4], s_t[4], s_rc[4];
+    const int wv = threadIdx.x >> 6, lane = lane_id();
     const i64 tile0 = (i64)blockIdx.x * CH_TILE;
-    const bool last_tile = blockIdx.x == gridDim.x - 1;
-    int cnt = 0;
-    const TileInfo T = tile_info_of(B, blockIdx.x);
-    if (wv == 4) {                                         // the look-back wavefront
-        int p = -1, kp = 0;
-        for (i64 hiw = CSV_ABL(9) ? 0 : tile0; hiw > 0 && p < 0;) {
-            const i64 cb = hiw > 64 ? hiw - 64 : 0;
-            int kseg;
-            u64 f = chain_flag_row64(B, cb, kseg, T);
-            if (hiw - cb < 64) f &= (1ull << (hiw - cb)) - 1ull;
-            if (f) { const int l = 63 - __clzll((long long)f); p = (int)cb + l; kp = __builtin_amdgcn_readlane(kseg, l); }
-            hiw = cb;
-        }
-        if (lane_id() == 0) { s_prev[0] = p; s_prev[1] = kp; }
-    } else {
-        u64 pub;
-        cnt = wave_starts(B, tile0 + wv * (WAVE * CH_ITEMS), T, SR[wv], SKR[wv], pub);
-        // the flags, for k_chain_ids: lane r stores the mask of row r
-        if (B.per_sig && lane_id() < CH_ITEMS) B.ch_masks[((i64)blockIdx.x * 4 + wv) * CH_ITEMS + lane_id()] = pub;
-        if (lane_id() == 0) {
-            s_cnt[wv] = cnt;
-            // the sentinel w = W ends the last cluster: one more "start" in the last wavefront's region
-            if (last_tile && wv == 3) SR[3][cnt] = (int)B.W | ((B.a[B.W - 1] == 0 && B.b[B.W - 1] == 0) ? (1 << 31) : 0);
-        }
+    const int nvalid = (int)(B.W - tile0 < CH_TILE ? B.W - tile0 : CH_TILE);     // signatures of this tile
+    // ---- everything the common path reads, issued at once: the tile's record, this wavefront's rows, and (wavefront 0) the
+    // next tile's record and the row after the tile.  (Raw values: nothing is converted or compared before every load of
+    // this block has been issued.)
+    const i64 base = tile0 + wv * (WAVE * CH_ITEMS);
+    const bool in_batch = base < B.W;                                      // (wave-uniform, known without any load)
+    const bool halo_in = wv == 0 && tile0 + CH_TILE < B.W;                 // a row after the tile exists (padded: always readable)
+    typedef typename std::conditional<NARROW, int, i64>::type raw_t;
+    const int4* trp = B.tile_info + (i64)TILE_REC * blockIdx.x;
+    const int4 t0 = trp[0], t1 = trp[1], t2 = trp[2], t3 = trp[3], t4 = trp[4], t5 = trp[5], t6 = trp[6];
+    SpanRows<NARROW> R;
+    if (in_batch) span_rows_load<NARROW>(B, base, R);
+    raw_t h_raw = 0, h_lraw = 0;
+    int4 n0 = make_int4(0, 0, 0, 0), n1 = n0, n2 = n0, n3 = n0, n4 = n0, n5 = n0, n6 = n0;
+    if (halo_in) {
+        if constexpr (NARROW) { h_raw = B.a.p32[tile0 + CH_TILE + lane]; h_lraw = B.a.p32[tile0 + CH_TILE - 1]; }
+        else { h_raw = B.a.p64[tile0 + CH_TILE + lane]; h_lraw = B.a.p64[tile0 + CH_TILE - 1]; }
+        n0 = trp[TILE_REC]; n1 = trp[TILE_REC + 1]; n2 = trp[TILE_REC + 2]; n3 = trp[TILE_REC + 3]; n4 = trp[TILE_REC + 4]; n5 = trp[TILE_REC + 5]; n6 = trp[TILE_REC + 6];
     }
-    __syncthreads();
-    if (wv < 4) {
-        TileSeg ts;
-        ts.uni = T.k0 == T.k1; ts.k = T.k0; ts.rc = T.rc; ts.drop = T.drop; ts.type = T.type;
-        const int2 ob = open_before(SR, SKR, s_cnt, wv, make_int2(s_prev[0], s_prev[1]), T);
-        const int nc = cnt + ((last_tile && wv == 3) ? 1 : 0);   // clusters that end at this wavefront's starts
-        // The size gate is evaluated HERE only: the clusters that pass (a few per cent) leave a record in the wavefront's
-        // own item region, in order, and k_chain_apply is a plain compaction of those records (it used to rebuild the start
-        // lists from the masks and evaluate every gate a second time: 16 us of a 100 us step).
-        const i64 gw = (i64)blockIdx.x * 4 + wv;
-        int n_sel = 0, n_big = 0, n_tiny = 0, n_wide = 0;   // wave-uniform counts: ballots + scalar popcounts, no VALU sums
-        for (int i0 = 0; i0 < (CSV_ABL(7) ? 0 : nc); i0 += 64) {
-            const int i = i0 + lane_id();
-            int fl = 0, s0c = 0, mc = 0, kt = 0;
-            // one LDS read per cluster: its end; the start is the neighbour lane's end (DPP), the segment the tile's own
-            // unless the tile spans segments
-            const int e1 = i < nc ? SR[wv][i] : 0;
-            int s0 = dpp_i32<0x138, 0xf>(0, e1);              // wave_shr:1
-            if (lane_id() == 0) s0 = i0 ? SR[wv][i0 - 1] : ob.x;
-            if (i < nc) {
-                const int k = ts.uni ? ((i || ob.y == ts.k) ? ts.k : ob.y) : (i ? SKR[wv][i - 1] : ob.y);
-                if (s0 != -1) {
-                    const int4 g = gate_scalars(B, ts, k);
-                    fl = close_gate(B, g, s0 & 0x7fffffff, e1 & 0x7fffffff, e1 < 0);
-                    s0c = s0 & 0x7fffffff; mc = (e1 & 0x7fffffff) - s0c; kt = k | (g.z << 24) | ((fl >> 1) << 28);
+    const int k0 = __builtin_amdgcn_readfirstlane(t0.x), k1 = __builtin_amdgcn_readfirstlane(t0.y), nin = __builtin_amdgcn_readfirstlane(t0.z);
+    const TileSegI g0 = tile_seg(t1, t2), g1 = tile_seg(t3, t4), g2 = tile_seg(t5, t6);
+    const bool pairs = pair_type(g0.type) || (nin > 1 && pair_type(g1.type)) || (nin > 2 && pair_type(g2.type));     // (uniform values in VGPRs)
+    const bool fastable = nin >= 1 && !__ballot(pairs);
+    if (CSV_ABL(8)) {                                                                   // loads only (every loaded value consumed)
+        i64 acc = (i64)h_raw + g0.rc;
+        if (in_batch) { if constexpr (NARROW) acc += R.left + R.v0.x + R.v0.y + R.v0.z + R.v0.w + R.v1.x + R.v1.y + R.v1.z + R.v1.w; else acc += R.left + R.v0.x + R.v0.y + R.v1.x + R.v1.y + R.v2.x + R.v2.y + R.v3.x + R.v3.y; }
+        if (acc == 12345) B.partial[blockIdx.x] = 1;
+        return;
+    }
+    unsigned bits = 0;                                      // this thread's 8 flags (signatures tile0 + 8 t ...)
+    const int p0 = 8 * (int)threadIdx.x;
+    {
+        bool have_bits = false;
+        if (CSV_LIKELY(in_batch && fastable)) have_bits = chain_bytes_fast<NARROW>(R, base, nin, g0, g1, g2, bits);
+        unsigned zb = 0;
+        if (CSV_UNLIKELY(!have_bits) && !CSV_ABL(14)) chain_bytes_general(B, base + 8 * lane, k0, k1, bits, zb);
+        // real signatures only (the padding behind the batch is not data) ...
+        bits = (p0 + 8 <= nvalid) ? bits : (p0 >= nvalid ? 0u : (bits & ((1u << (nvalid - p0)) - 1u)));
+        // ... and, in the tile that ends the batch, the end of the batch closes the last cluster: a virtual start at position
+        // nvalid (position 2048 lives in the look-ahead word)
+        if (nvalid < CH_TILE && p0 <= nvalid && nvalid < p0 + 8) {
+            bits |= 1u << (nvalid - p0);
+            if (B.end_z) zb |= 1u << (nvalid - p0);
+        }
+        ((unsigned char*)s_F)[threadIdx.x] = (unsigned char)bits;
+        ((unsigned char*)s_Z)[threadIdx.x] = (unsigned char)zb;
+    }
+    if (wv == 0 && !CSV_ABL(12)) {
+        // the row after the tile (the tile's last cluster ends at the first start in it); should it hold none - a cluster of
+        // more than 64 signatures crossing the tile's end - walk on, 64 signatures at a time
+        u64 zm = 0, fm = 0;
+        bool done = nvalid < CH_TILE;                       // (the batch ends inside the tile: the virtual start is in its own words)
+        if (CSV_LIKELY(!done && halo_in)) {
+            // common case: the row's segments are inline in the next tile's record, none INV / TRA, all positions positive
+            const int nn = __builtin_amdgcn_readfirstlane(n0.z);
+            const TileSegI h0 = tile_seg(n1, n2), h1 = tile_seg(n3, n4), h2 = tile_seg(n5, n6);
+            const bool hp = pair_type(h0.type) || (nn > 1 && pair_type(h1.type)) || (nn > 2 && pair_type(h2.type));
+            const i64 h_a = (i64)h_raw;
+            i64 a0 = wave_shr1_i64(h_a);
+            if (lane == 0) a0 = (i64)h_lraw;
+            const int w = (int)tile0 + CH_TILE + lane;
+            const bool in = w < (int)B.W;
+            if (CSV_LIKELY(nn >= 1 && !__ballot(hp || (in && (a0 <= 0 || h_a <= 0))))) {
+                const i64 bias = (nn > 2 && w >= h2.sf) ? h2.bias : ((nn > 1 && w >= h1.sf) ? h1.bias : h0.bias);
+                fm = __ballot(in && (w == h0.sf || (nn > 1 && w == h1.sf) || (nn > 2 && w == h2.sf) || h_a - a0 > bias));
+                if (B.W - (tile0 + CH_TILE) < 64) {         // the batch ends inside the row
+                    fm |= 1ull << (B.W - (tile0 + CH_TILE));
+                    if (B.end_z) zm = 1ull << (B.W - (tile0 + CH_TILE));
                 }
+                done = true;
             }
-            const u64 m_sel = __ballot(fl & 1);
-            if (fl & 1) B.wave_items[gw * WI_STRIDE + n_sel + __popcll(m_sel & lanemask_lt())] = make_int4(s0c, mc, kt, i - 1);
-            n_sel += __popcll(m_sel); n_big += __popcll(__ballot(fl & 2)); n_tiny += __popcll(__ballot(fl & 4)); n_wide += __popcll(__ballot(fl & 8));
         }
-        // (tiny and wide counts share a word: a wavefront has at most 513 items, a tile 2052)
-        if (lane_id() == 0) { s_v[wv] = (i64)n_sel | ((i64)n_big << 32); s_t[wv] = n_tiny | (n_wide << 16); B.wave_cnt[gw] = make_int4(cnt, n_sel, n_big, n_tiny | (n_wide << 16)); }
+        if (CSV_UNLIKELY(!done)) fm = chain_flag_row64(B, tile0 + CH_TILE, &zm);
+        int far = -1, farz = 0;
+        if (CSV_UNLIKELY(nvalid == CH_TILE && fm == 0)) {
+            for (i64 cb = tile0 + CH_TILE + 64;; cb += 64) {
+                u64 z2;
+                const u64 f2 = chain_flag_row64(B, cb, &z2);
+                if (f2) { const int l = __ffsll((long long)f2) - 1; far = (int)(cb - tile0) + l; farz = (int)((z2 >> l) & 1); break; }
+            }
+        }
+        if (lane == 0) { s_F[CT_WORDS] = fm; s_Z[CT_WORDS] = zm; s_F[CT_WORDS + 1] = 0; s_far[0] = far; s_far[1] = farz; }
+    }
+    if (CSV_ABL(11)) { if (bits == 0x1234567u) B.partial[blockIdx.x] = 1; return; }                     // + LDS writes and the look-ahead row
+    // the smallest read_count among the tile's segments bounds the candidate filter below
+    int rcmin = g0.rc;
+    if (nin > 1) rcmin = min(rcmin, g1.rc);
+    if (nin > 2) rcmin = min(rcmin, g2.rc);
+    rcmin = __builtin_amdgcn_readfirstlane(rcmin);
+    if (CSV_UNLIKELY(nin == 0)) {                           // more than three segments in the tile: from the segment table
+        int v = 0x7fffffff;
+        for (int k = k0 + (int)threadIdx.x; k <= k1; k += 256) { const int x = B.seg_gate[k].x; v = x < v ? x : v; }
+        for (int d = 32; d > 0; d >>= 1) { const int o = __shfl_xor(v, d); v = o < v ? o : v; }
+        if (lane == 0) s_rc[wv] = v;
     }
     __syncthreads();
+    if (CSV_UNLIKELY(nin == 0)) rcmin = min(min(s_rc[0], s_rc[1]), min(s_rc[2], s_rc[3]));
+    if (CSV_ABL(9)) { if (threadIdx.x == 0) B.partial[blockIdx.x] = (int)s_F[3]; return; }       // flags + barrier only
+    // ---- every thread: the 8 flags [8 t, 8 t + 8) of the tile and the 64-flag window that begins with them
+    const int t = threadIdx.x, wi = t >> 3, sh8 = (t & 7) * 8;
+    const u64 w0 = s_F[wi], w1 = s_F[wi + 1];
+    if (B.per_sig && t < CT_WORDS) B.ch_masks[(i64)blockIdx.x * CT_WORDS + t] = s_F[t];      // the flags, for k_chain_ids
+    const u64 win = sh8 ? ((w0 >> sh8) | (w1 << (64 - sh8))) : w0;
+    // own starts: real signatures only (the virtual start at nvalid only ENDS a cluster)
+    const unsigned own = (p0 + 8 <= nvalid) ? bits : (p0 >= nvalid ? 0u : (bits & ((1u << (nvalid - p0)) - 1u)));
+    // candidates: a start followed by at least read_count - 1 signatures that do not start a cluster (half of all signatures
+    // of a 30x genome start one, a few per cent of those pass): runs of zeros by shift-and-AND over the window
+    unsigned cand = own;
+    {
+        int kk = rcmin - 1;
+        if (kk > 56) kk = 56;                               // (the window holds 56 flags behind a byte's last one: a longer demand is verified below)
+        if (kk > 0) {
+            u64 r = ~win;
+            for (int have = 1; have < kk;) { const int s = have < kk - have ? have : kk - have; r &= r >> s; have += s; }
+            cand &= (unsigned)(r >> 1);
+        }
+    }
+    const int far_pos = s_far[0];
+    // pass 1: the exact gate for the candidates (sizes are recomputed in pass 2 for those that pass: no per-bit arrays)
+    unsigned passbits = 0;
+    int n_big = 0, n_tiny = 0, n_wide = 0;
+    if (!CSV_ABL(7) && __ballot(cand != 0)) {
+        for (unsigned b = cand; b;) {
+            const int lb = __ffs((int)b) - 1;
+            b &= b - 1;
+            const int pos = p0 + lb, nxt = chain_next_start(s_F, win, w1, wi, sh8, p0, lb, far_pos), m = nxt - pos;
+            // (0,0) look-alike before the cluster's end: marks are kept for the tile and the row after it; a far end carries its own
+            const int endz = nxt <= CT_WORDS * 64 + 63 ? (int)((s_Z[nxt >> 6] >> (nxt & 63)) & 1) : s_far[1];
+            int kseg;
+            const int fl = close_gate(B.tiny_max, chain_gate_of(B.woff, B.seg_gate, (int)tile0 + pos, nin, k0, k1, g0, g1, g2, kseg), m, endz);
+            if (fl & 1) { passbits |= 1u << lb; n_big += (fl >> 1) & 1; n_tiny += (fl >> 2) & 1; n_wide += (fl >> 3) & 1; }
+        }
+    }
+    // ---- order: starts | work items << 16, one wave scan + the wave totals
+    const int v = __popc(own) | (__popc(passbits) << 16);
+    const int inc = wave_incl_scan_i32(v);
+    const int tiers = wave_sum_i32(n_tiny | (n_wide << 12) | (n_big << 20));
+    if (lane == 63) { s_w[wv] = inc; s_t[wv] = tiers; }
+    __syncthreads();
+    int before = inc - v;
+    for (int q = 0; q < wv; q++) before += s_w[q];
+    if (passbits) {                                      // pass 2: the records of the starts that passed, in order
+        const int c_before = (before & 0xffff), j_before = before >> 16;
+        for (unsigned b = passbits; b;) {
+            const int lb = __ffs((int)b) - 1;
+            b &= b - 1;
+            const int pos = p0 + lb, m = chain_next_start(s_F, win, w1, wi, sh8, p0, lb, far_pos) - pos;
+            int kseg;
+            const int4 g = chain_gate_of(B.woff, B.seg_gate, (int)tile0 + pos, nin, k0, k1, g0, g1, g2, kseg);
+            const int fl = close_gate(B.tiny_max, g, m, 0);
+            const int ci = c_before + __popc(own & ((1u << lb) - 1u)), ji = j_before + __popc(passbits & ((1u << lb) - 1u));
+            B.tile_items[(i64)blockIdx.x * TI_STRIDE + ji] = make_int4((int)tile0 + pos, m, kseg | (g.z << 24) | ((fl >> 1) << 28), ci);
+        }
+    }
     if (threadIdx.x == 0) {
-        B.partial[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
-        B.partial64[blockIdx.x] = s_v[0] + s_v[1] + s_v[2] + s_v[3];
-        B.partial_t[blockIdx.x] = s_t[0] + s_t[1] + s_t[2] + s_t[3];
+        const int tot = s_w[0] + s_w[1] + s_w[2] + s_w[3], tt = s_t[0] + s_t[1] + s_t[2] + s_t[3];
+        B.partial[blockIdx.x] = tot & 0xffff;
+        B.partial64[blockIdx.x] = (i64)(tot >> 16) | ((i64)(tt >> 20) << 32);
+        B.partial_t[blockIdx.x] = (tt & 0xfff) | (((tt >> 12) & 0xff) << 16);
     }
 }
 
-// Compaction of the wavefronts' item records into the ordered work list and the three tier lists.  One workgroup per
-// chain tile (the prefix over the earlier tiles is recomputed from the per-tile counts: a few thousand L2-resident
-// values), one wavefront per chain wavefront.  Reads ~16 bytes per work item; no signature column, no flag, no gate.
+// Compaction of the tiles' item records into the ordered work list and the three tier lists.  One wavefront per chain
+// tile, four tiles per workgroup (the prefix over the earlier tiles is recomputed from the per-tile counts: a few thousand
+// L2-resident values).  Reads ~16 bytes per work item; no signature column, no flag, no gate.
 __global__ __launch_bounds__(256) void k_chain_apply(DevBatch B)
 {
     __shared__ i64 sh[12];
     const int wv = threadIdx.x >> 6;
-    const i64 gw = (i64)blockIdx.x * 4 + wv;
-    const bool last_tile = blockIdx.x == gridDim.x - 1;
+    const int tile_b = blockIdx.x * 4, tile = tile_b + wv, ntile = (int)((B.W + CH_TILE - 1) / CH_TILE);
     i64 p0 = 0, p1 = 0, p2 = 0;
-    for (int i = threadIdx.x; i < (int)blockIdx.x; i += 256) {
+    for (int i = threadIdx.x; i < tile_b; i += 256) {
         const int tw = B.partial_t[i];                       // tiny | wide << 16 of tile i
         p0 += B.partial[i]; p1 += B.partial64[i]; p2 += (i64)(tw & 0xffff) | ((i64)(tw >> 16) << 32);
     }
     p0 = wave_sum_i64(p0); p1 = wave_sum_i64(p1); p2 = wave_sum_i64(p2);
     if (lane_id() == 0) { sh[wv] = p0; sh[4 + wv] = p1; sh[8 + wv] = p2; }
-    const int4 wc = B.wave_cnt[gw];                          // {cluster starts, work items, workgroup tier, tiny | wide << 16}
-    int4 before = make_int4(0, 0, 0, 0);                    // ... of the tile's earlier wavefronts
-    for (int q = 0; q < wv; q++) { const int4 c = B.wave_cnt[gw - wv + q]; before.x += c.x; before.y += c.y; before.z += c.z; before.w += c.w; }   // (.w: no carry between the halves, see above)
+    i64 b0 = 0, b1 = 0, b2 = 0;                              // ... of the workgroup's earlier tiles
+    for (int q = tile_b; q < tile && q < ntile; q++) { const int tw = B.partial_t[q]; b0 += B.partial[q]; b1 += B.partial64[q]; b2 += (i64)(tw & 0xffff) | ((i64)(tw >> 16) << 32); }
+    i64 own0 = 0, own1 = 0;
+    if (tile < ntile) { own0 = B.partial[tile]; own1 = B.partial64[tile]; }
     __syncthreads();
-    const i64 runs = sh[4] + sh[5] + sh[6] + sh[7];
-    const int run = (int)(sh[0] + sh[1] + sh[2] + sh[3]) + before.x;          // id of the first cluster that STARTS in this wavefront's span
-    const int bj = (int)(runs & 0xffffffffll) + before.y;
-    const i64 tws = sh[8] + sh[9] + sh[10] + sh[11];
-    int bb = (int)(runs >> 32) + before.z, bt = (int)(tws & 0xffffffffll) + (before.w & 0xffff), bw = (int)(tws >> 32) + (before.w >> 16);
-    const int n_it = __builtin_amdgcn_readfirstlane(wc.y);
+    if (tile >= ntile) return;
+    const i64 runs = sh[4] + sh[5] + sh[6] + sh[7] + b1;
+    const int run = (int)(sh[0] + sh[1] + sh[2] + sh[3] + b0);          // id of the first cluster that STARTS in this tile
+    const int bj = (int)(runs & 0xffffffffll);
+    const i64 tws = sh[8] + sh[9] + sh[10] + sh[11] + b2;
+    int bb = (int)(runs >> 32), bt = (int)(tws & 0xffffffffll), bw = (int)(tws >> 32);
+    const int n_it = __builtin_amdgcn_readfirstlane((int)(own1 & 0xffffffffll));
     for (int base = 0; base < n_it; base += 64) {
         const int idx = base + lane_id();
         const bool act = idx < n_it;
         int4 rec = make_int4(0, 0, 0, 0);
-        if (act) rec = B.wave_items[gw * WI_STRIDE + idx];
+        if (act) rec = B.tile_items[(i64)tile * TI_STRIDE + idx];
         const int tier = (rec.z >> 28) & 3;
         const bool wide = act && ((rec.z >> 30) & 1);
         const u64 m_big = __ballot(act && (tier & 1)), m_tiny = __ballot(act && (tier & 2)), m_wide = __ballot(wide);
@@ -647,9 +766,9 @@ __global__ __launch_bounds__(256) void k_chain_apply(DevBatch B)
         }
         bb += __popcll(m_big); bt += __popcll(m_tiny); bw += __popcll(m_wide);
     }
-    if (last_tile && threadIdx.x == 255) {                  // wavefront 3: its running counts now cover the whole batch
-        B.cnt->n_clusters = run + wc.x;
-        B.cnt->n_items = bj + wc.y; B.cnt->n_items_big = bb; B.cnt->n_items_tiny = bt; B.cnt->n_items_wide = bw;
+    if (tile == ntile - 1 && lane_id() == 63) {             // its running counts now cover the whole batch
+        B.cnt->n_clusters = run + (int)own0;
+        B.cnt->n_items = bj + n_it; B.cnt->n_items_big = bb; B.cnt->n_items_tiny = bt; B.cnt->n_items_wide = bw;
         // tell the host whether the tiers above 64 signatures have any work: it peeks at these page-locked words while
         // the wavefront tier runs and launches k_refine<64,256> / k_refine<256,2048> only then (a missing or late answer
         // just means that they are launched as before)
@@ -666,20 +785,20 @@ __global__ __launch_bounds__(256) void k_chain_ids(DevBatch B)
 {
     __shared__ i64 sh[4];
     const int wv = threadIdx.x >> 6;
-    const i64 gw = (i64)blockIdx.x * 4 + wv;
     const i64 base = (i64)blockIdx.x * CH_TILE + wv * (WAVE * CH_ITEMS);
     i64 p0 = 0;
     for (int i = threadIdx.x; i < (int)blockIdx.x; i += 256) p0 += B.partial[i];
     p0 = wave_sum_i64(p0);
     if (lane_id() == 0) sh[wv] = p0;
-    const u64 pub = lane_id() < CH_ITEMS ? B.ch_masks[gw * CH_ITEMS + lane_id()] : 0;
-    int run = 0;
-    for (int q = 0; q < wv; q++) run += B.wave_cnt[gw - wv + q].x;
+    // the tile's 32 flag words: lane l holds word l; this wavefront's rows are words 8 wv .. 8 wv + 7
+    const u64 mw = lane_id() < CT_WORDS ? B.ch_masks[(i64)blockIdx.x * CT_WORDS + lane_id()] : 0;
+    const int pc_inc = wave_incl_scan_i32(__popcll(mw));
+    int run = wv ? __builtin_amdgcn_readlane(pc_inc, (wv * CH_ITEMS - 1) & 63) : 0;      // starts in the tile's earlier wavefronts
     __syncthreads();
     run += (int)(sh[0] + sh[1] + sh[2] + sh[3]);
 #pragma unroll
     for (int r = 0; r < CH_ITEMS; r++) {
-        const u64 m = (u64)readlane_i64x((i64)pub, r);
+        const u64 m = (u64)readlane_i64x((i64)mw, wv * CH_ITEMS + r);
         const i64 w = base + r * WAVE + lane_id();
         if (w < B.W) { B.cluster_id[w] = run + __popcll(m & (lanemask_lt() | (1ull << lane_id()))) - 1; B.allele_id[w] = -1; }
         run += __popcll(m);
@@ -1565,13 +1684,13 @@ __device__ __forceinline__ int4 unit_entry(const int4* list, int p, int nlist, i
     return (p >= 0 && q < nlist) ? list[q] : make_int4(0, (int)0xff000000u, 0, 0);
 }
 // rows of the entry's cluster, one signature per lane of the sub-wave; m_lo < size <= sw or the lanes stay empty
-__device__ __forceinline__ void unit_rows(const DevBatch& B, const int4 e, int sw_log2, int m_lo, UnitIn& U)
+template <bool NARROW> __device__ __forceinline__ void unit_rows(const DevBatch& B, const int4 e, int sw_log2, int m_lo, UnitIn& U)
 {
     const int sl = lane_id() & ((1 << sw_log2) - 1), type = e.y >> 24, s = e.z, m = e.w;
     const bool in = (type == CSV_DEL || type == CSV_INS) && m > m_lo && m <= (1 << sw_log2) && sl < m;
     U.e = e;
-    U.a = in ? B.a[s + sl] : 0;
-    U.b = in ? B.b[s + sl] : 0;
+    U.a = in ? col_at<NARROW>(B.a, s + sl) : 0;
+    U.b = in ? col_at<NARROW>(B.b, s + sl) : 0;
     U.rid = in ? B.rid[s + sl] : -1 - lane_id();
     U.aux = (in && type == CSV_INS) ? B.aux[s + sl] : 0;
 }
@@ -1827,7 +1946,7 @@ template <int SW> __device__ __forceinline__ int indel_unit(const DevBatch& B, c
     return wide;
 }
 
-__global__ __launch_bounds__(256, CSV_IW_WAVES) void k_refine_indel_wave(DevBatch B)
+template <bool NARROW> __global__ __launch_bounds__(256, CSV_IW_WAVES) void k_refine_indel_wave(DevBatch B)
 {
     const int ntiny = B.cnt->n_items_tiny, nsmall = B.cnt->n_items - B.cnt->n_items_big - ntiny;
     const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * 256 + threadIdx.x) >> 6), nwaves = (gridDim.x * 256) >> 6;
@@ -1841,7 +1960,7 @@ __global__ __launch_bounds__(256, CSV_IW_WAVES) void k_refine_indel_wave(DevBatc
     // are more units than wavefronts.  (More wide items than wavefronts - deep coverage - : everything over all of them.)
     for (int p = wave; p < n_wide; p += nwaves) {
         UnitIn U;
-        unit_rows(B, unit_entry(B.list_wide, p, n_wide, 6), 6, 32, U);
+        unit_rows<NARROW>(B, unit_entry(B.list_wide, p, n_wide, 6), 6, 32, U);
         indel_unit<64>(B, U);
     }
     const int skip = n_wide < nwaves ? n_wide : 0, M = nwaves - skip;
@@ -1849,14 +1968,14 @@ __global__ __launch_bounds__(256, CSV_IW_WAVES) void k_refine_indel_wave(DevBatc
     const int slot = wave - skip;
     for (int p = slot; p < n_pair; p += M) {
         UnitIn U;
-        unit_rows(B, unit_entry(B.list_small, p, nsmall, 5), 5, 0, U);
+        unit_rows<NARROW>(B, unit_entry(B.list_small, p, nsmall, 5), 5, 0, U);
         indel_unit<32>(B, U);                              // (members with 32 < m <= 64 are skipped here: they are units of their own)
     }
     int q0 = slot - n_pair % M;                            // the quads continue the round-robin where the pairs stopped
     if (q0 < 0) q0 += M;
     for (int p = q0; p < n_quad; p += M) {
         UnitIn U;
-        unit_rows(B, unit_entry(B.list_tiny, p, ntiny, 4), 4, 0, U);
+        unit_rows<NARROW>(B, unit_entry(B.list_tiny, p, ntiny, 4), 4, 0, U);
         indel_unit<16>(B, U);
     }
 }
