@@ -482,7 +482,7 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
     // (the position column is followed by a tile of padding, so that the chain kernel can read any span that begins inside the batch)
     if (sig32) { PL(a32, (W + CH_TILE + 64) * 4); PL(b32, (W + 1) * 4); } else { PL(a, (W + CH_TILE + 64) * 8); PL(b, (W + 1) * 8); }
     PL(rid, (W + 1) * 4); PL(aux, (W + 1) * 4);
-    PL(sup_tmp, (W + 1) * 4);
+    PL(sup_tmp, (W + 1) * 8);
     if (per_sig) { PL(cluster_id, (W + 1) * 4); PL(allele_id, (W + 1) * 4); }
     PL(partial, nt * 4); PL(partial64, nt * 8); PL(partial_t, nt * 4);
     if (per_sig) PL(ch_masks, nt * CT_WORDS * 8);
@@ -535,18 +535,18 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
             while (k1 + 1 < S && c->h_woff[k1 + 1] <= w1) k1++;
             r[0] = k; r[1] = k1;
             int nin = 0;
+            bool wide_bias = false;
             for (int q = k; q <= k1; q++) {
                 if (c->h_woff[q + 1] == c->h_woff[q]) continue;
                 if (nin < 3) {
                     const csv_segment& g = c->h_seg[q];
-                    int* a = r + 4 + 8 * nin;
-                    a[0] = (int)c->h_woff[q]; a[1] = g.svtype | (drop[q] ? 0x100 : 0); a[2] = g.read_count; a[3] = q;
-                    a[4] = (int)(g.max_cluster_bias & 0xffffffffll); a[5] = (int)(g.max_cluster_bias >> 32);
-                    a[6] = g.max_cluster_bias > 0x7fffffffll ? 0x7fffffff : (g.max_cluster_bias < -0x80000000ll ? (int)0x80000000 : (int)g.max_cluster_bias);
+                    int* a = r + 4 + 4 * nin;
+                    a[0] = (int)c->h_woff[q]; a[1] = g.read_count; a[2] = q | (g.svtype << 24) | (drop[q] ? (1 << 28) : 0); a[3] = (int)g.max_cluster_bias;
+                    if (g.max_cluster_bias != (i64)(int)g.max_cluster_bias || q >= (1 << 24)) wide_bias = true;
                 }
                 nin++;
             }
-            r[2] = nin <= 3 ? nin : 0;
+            r[2] = (nin <= 3 && !wide_bias) ? nin : 0;
         }
         HIP_TRY(c, hipMemcpyAsync(c->tile_info.p, ti, (size_t)nt * TILE_REC * 16, hipMemcpyHostToDevice, st));
     }
@@ -650,7 +650,7 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
     B.seg_err = dp<int>(c->seg_err);
     B.tiny_max = getenv("CSV_NO_TINY") ? 0 : 16;               // (timing aid: 0 sends every DEL/INS cluster of m <= 32 through the paired path)
     B.item_nslots = dp<int>(c->item_nslots); B.item_cnt = dp<i64>(c->item_cnt); B.item_base = dp<i64>(c->item_base); B.item_chunk = dp<i64>(c->item_chunk);
-    B.sup_tmp = dp<int>(c->sup_tmp);
+    B.sup_tmp = dp<int2>(c->sup_tmp);
     B.t_rec = dp<TmpRec>(c->t_rec);
     B.cap_tmp = (int)cap_tmp; B.cap_items = (int)cap_items;
     B.sc_k = dp<u64>(c->sc_k); B.sc_x = dp<i64>(c->sc_x); B.sc_v1 = dp<int>(c->sc_v1); B.sc_v2 = dp<int>(c->sc_v2); B.sc_v3 = dp<int>(c->sc_v3); B.sc_v4 = dp<int>(c->sc_v4); B.sc_v5 = dp<int>(c->sc_v5);

@@ -155,7 +155,8 @@ struct DevBatch {
     i64*           item_cnt;         // packed (valid calls << 32 | supports of valid calls)
     i64*           item_base;        // exclusive prefix of item_cnt per tile of EM_TILE items, inside the tile's chunk of IS_CHUNK items
     i64*           item_chunk;       // total of item_cnt per chunk
-    int*           sup_tmp;          // W: support lists, stored inside the cluster's own [s, e) range
+    int2*          sup_tmp;          // W: support lists {signature w, its read id}, stored inside the cluster's own [s, e) range (the read id
+                                     // rides along so that k_emit needs no dependent gather for it)
     TmpRec*        t_rec;            // W temp call records (a cluster's slots live in its own signature range)
     int            cap_tmp;
     int            cap_items;
@@ -300,16 +301,16 @@ constexpr int TI_STRIDE = CH_TILE + 8;              // work-item slots per tile 
 // -> segment record -> rows) at all: record and rows are loaded together, ONE round trip.  (A kernel lasts as long as its
 // slowest wavefront: in the first forms of this kernel the ~50 spans of a 30x genome that cross a segment boundary walked a
 // chain of 4-5 dependent loads, and that chain - not the 5 400 fast wavefronts - was 6.5 us of the kernel's 12.)
-//   [0]          {first segment k0, last segment k1 (overlapping the tile), inline count nin (0: more than three), -}
-//   [1 + 2 i]    segment i: {first w, svtype | dropped << 8, read_count, segment index}
-//   [2 + 2 i]    segment i: {max_cluster_bias lo, hi, the bias clamped to int32, -}
-constexpr int TILE_REC = 8;
+//   [0]          {first segment k0, last segment k1 (overlapping the tile), inline count nin (0: more than three, or a bias that
+//                does not fit 32 bits: the general form reads the segment table), -}
+//   [1 + i]      segment i: {first w, read_count, segment index | svtype << 24 | dropped << 28, max_cluster_bias}
+constexpr int TILE_REC = 4;
 struct TileSegI { int sf, type, drop, rc, k, bias32; i64 bias; };
-__device__ __forceinline__ TileSegI tile_seg(const int4 a, const int4 b)
+__device__ __forceinline__ TileSegI tile_seg(const int4 a)
 {
     TileSegI g;
-    g.sf = a.x; g.type = a.y & 0xff; g.drop = (a.y >> 8) & 1; g.rc = a.z; g.k = a.w;
-    g.bias = ((i64)b.y << 32) | (i64)(unsigned)b.x; g.bias32 = b.z;
+    g.sf = a.x; g.rc = a.y; g.k = a.z & 0xffffff; g.type = (a.z >> 24) & 7; g.drop = (a.z >> 28) & 1;
+    g.bias32 = a.w; g.bias = (i64)a.w;
     return g;
 }
 __device__ __forceinline__ bool pair_type(int t) { return t == CSV_INV || t == CSV_TRA; }
@@ -343,15 +344,21 @@ __device__ __forceinline__ void sig_flag(i64 w, const SegScal& S, i64 a1, i64 a0
     }
 }
 // the 8 signatures [w0, w0 + 8) of one lane (those below W): flag byte and mark byte
-__device__ __forceinline__ void chain_bytes_general(const DevBatch& B, i64 w0, int k0, int k1, unsigned& byte_out, unsigned& zbyte_out)
+template <bool NARROW> __device__ __forceinline__ void chain_bytes_general(const DevBatch& B, i64 w0, int k0, int k1, unsigned& byte_out, unsigned& zbyte_out)
 {
+    typedef typename std::conditional<NARROW, int, i64>::type raw_t;      // (values stay in the column's width: 27 instead of 45 registers)
     unsigned byte = 0, zb = 0;
     if (w0 < B.W) {
-        i64 a[9], b[9]; int x[9];
+        raw_t a[9], b[9]; int x[9];
         const i64 wl = w0 > 0 ? w0 - 1 : 0;
-        a[0] = B.a[wl]; b[0] = B.b[wl]; x[0] = B.aux[wl];
+        if constexpr (NARROW) { a[0] = B.a.p32[wl]; b[0] = B.b.p32[wl]; } else { a[0] = B.a.p64[wl]; b[0] = B.b.p64[wl]; }
+        x[0] = B.aux[wl];
 #pragma unroll
-        for (int j = 0; j < 8; j++) { const i64 w = w0 + j < B.W ? w0 + j : B.W - 1; a[j + 1] = B.a[w]; b[j + 1] = B.b[w]; x[j + 1] = B.aux[w]; }
+        for (int j = 0; j < 8; j++) {
+            const i64 w = w0 + j < B.W ? w0 + j : B.W - 1;
+            if constexpr (NARROW) { a[j + 1] = B.a.p32[w]; b[j + 1] = B.b.p32[w]; } else { a[j + 1] = B.a.p64[w]; b[j + 1] = B.b.p64[w]; }
+            x[j + 1] = B.aux[w];
+        }
         int k = seg_in_tile(B, w0, k0, k1);
         SegScal S;
         seg_scal_load(B, k, S);
@@ -361,7 +368,7 @@ __device__ __forceinline__ void chain_bytes_general(const DevBatch& B, i64 w0, i
             if (w < B.W) {
                 while (k < k1 && w >= S.next) { k++; seg_scal_load(B, k, S); }
                 bool f, z;
-                sig_flag(w, S, a[j + 1], a[j], b[j + 1], b[j], x[j + 1], x[j], f, z);
+                sig_flag(w, S, (i64)a[j + 1], (i64)a[j], (i64)b[j + 1], (i64)b[j], x[j + 1], x[j], f, z);
                 byte |= (unsigned)f << j; zb |= (unsigned)(f && z) << j;
             }
         }
@@ -546,7 +553,7 @@ __device__ __forceinline__ int4 chain_gate_of(const i64* woff, const int4* seg_g
     return seg_gate[lo];
 }
 
-template <bool NARROW> __global__ __launch_bounds__(256) void k_chain_count(DevBatch B)
+template <bool NARROW> __global__ __launch_bounds__(256, 6) void k_chain_count(DevBatch B)
 {
     // first kernel of a run: nothing in this kernel reads the counters, every later kernel is stream-ordered behind it
     if (blockIdx.x == 0 && threadIdx.x < (int)(sizeof(DevCounters) / 4)) ((int*)B.cnt)[threadIdx.x] = 0;
@@ -565,18 +572,18 @@ template <bool NARROW> __global__ __launch_bounds__(256) void k_chain_count(DevB
     const bool halo_in = wv == 0 && tile0 + CH_TILE < B.W;                 // a row after the tile exists (padded: always readable)
     typedef typename std::conditional<NARROW, int, i64>::type raw_t;
     const int4* trp = B.tile_info + (i64)TILE_REC * blockIdx.x;
-    const int4 t0 = trp[0], t1 = trp[1], t2 = trp[2], t3 = trp[3], t4 = trp[4], t5 = trp[5], t6 = trp[6];
+    const int4 t0 = trp[0], t1 = trp[1], t2 = trp[2], t3 = trp[3];
     SpanRows<NARROW> R;
     if (in_batch) span_rows_load<NARROW>(B, base, R);
     raw_t h_raw = 0, h_lraw = 0;
-    int4 n0 = make_int4(0, 0, 0, 0), n1 = n0, n2 = n0, n3 = n0, n4 = n0, n5 = n0, n6 = n0;
+    int4 n0 = make_int4(0, 0, 0, 0), n1 = n0, n2 = n0, n3 = n0;
     if (halo_in) {
         if constexpr (NARROW) { h_raw = B.a.p32[tile0 + CH_TILE + lane]; h_lraw = B.a.p32[tile0 + CH_TILE - 1]; }
         else { h_raw = B.a.p64[tile0 + CH_TILE + lane]; h_lraw = B.a.p64[tile0 + CH_TILE - 1]; }
-        n0 = trp[TILE_REC]; n1 = trp[TILE_REC + 1]; n2 = trp[TILE_REC + 2]; n3 = trp[TILE_REC + 3]; n4 = trp[TILE_REC + 4]; n5 = trp[TILE_REC + 5]; n6 = trp[TILE_REC + 6];
+        n0 = trp[TILE_REC]; n1 = trp[TILE_REC + 1]; n2 = trp[TILE_REC + 2]; n3 = trp[TILE_REC + 3];
     }
     const int k0 = __builtin_amdgcn_readfirstlane(t0.x), k1 = __builtin_amdgcn_readfirstlane(t0.y), nin = __builtin_amdgcn_readfirstlane(t0.z);
-    const TileSegI g0 = tile_seg(t1, t2), g1 = tile_seg(t3, t4), g2 = tile_seg(t5, t6);
+    const TileSegI g0 = tile_seg(t1), g1 = tile_seg(t2), g2 = tile_seg(t3);
     const bool pairs = pair_type(g0.type) || (nin > 1 && pair_type(g1.type)) || (nin > 2 && pair_type(g2.type));     // (uniform values in VGPRs)
     const bool fastable = nin >= 1 && !__ballot(pairs);
     if (CSV_ABL(8)) {                                                                   // loads only (every loaded value consumed)
@@ -591,7 +598,7 @@ template <bool NARROW> __global__ __launch_bounds__(256) void k_chain_count(DevB
         bool have_bits = false;
         if (CSV_LIKELY(in_batch && fastable)) have_bits = chain_bytes_fast<NARROW>(R, base, nin, g0, g1, g2, bits);
         unsigned zb = 0;
-        if (CSV_UNLIKELY(!have_bits) && !CSV_ABL(14)) chain_bytes_general(B, base + 8 * lane, k0, k1, bits, zb);
+        if (CSV_UNLIKELY(!have_bits) && !CSV_ABL(14)) chain_bytes_general<NARROW>(B, base + 8 * lane, k0, k1, bits, zb);
         // real signatures only (the padding behind the batch is not data) ...
         bits = (p0 + 8 <= nvalid) ? bits : (p0 >= nvalid ? 0u : (bits & ((1u << (nvalid - p0)) - 1u)));
         // ... and, in the tile that ends the batch, the end of the batch closes the last cluster: a virtual start at position
@@ -611,7 +618,7 @@ template <bool NARROW> __global__ __launch_bounds__(256) void k_chain_count(DevB
         if (CSV_LIKELY(!done && halo_in)) {
             // common case: the row's segments are inline in the next tile's record, none INV / TRA, all positions positive
             const int nn = __builtin_amdgcn_readfirstlane(n0.z);
-            const TileSegI h0 = tile_seg(n1, n2), h1 = tile_seg(n3, n4), h2 = tile_seg(n5, n6);
+            const TileSegI h0 = tile_seg(n1), h1 = tile_seg(n2), h2 = tile_seg(n3);
             const bool hp = pair_type(h0.type) || (nn > 1 && pair_type(h1.type)) || (nn > 2 && pair_type(h2.type));
             const i64 h_a = (i64)h_raw;
             i64 a0 = wave_shr1_i64(h_a);
@@ -1275,7 +1282,7 @@ template <int BLOCK, bool LDS, bool SMALLN> __device__ void refine_indel(const D
             search = (i64)bp;                                               // INDEL:415
         }
         // supports: the allele's kept signatures in allele order (INDEL:205, 416)
-        for (int i = lane_id(); i < n; i += 64) B.sup_tmp[s + soff + i] = s + A.V1[r0 + i];
+        for (int i = lane_id(); i < n; i += 64) { const int w = s + A.V1[r0 + i]; B.sup_tmp[s + soff + i] = make_int2(w, B.rid[w]); }
         if (lane_id() == 0) {
             const int t = tbase + rank;
             tmp_write(&B.t_rec[t], (i64)bp, (i64)siglen, search, pick, n, cip, cil, soff, valid);
@@ -1296,7 +1303,7 @@ template <bool LDS> __device__ __forceinline__ void write_first_seen(const DevBa
         const int r = base + lane_id();
         const int f = (r < r1) && (A.V1[r < r1 ? r : r0] < 0);
         const u64 mk = __ballot(f);
-        if (f) B.sup_tmp[dst + run + __popcll(mk & lanemask_lt())] = s + (A.V1[r] & 0x7fffffff);
+        if (f) { const int w = s + (A.V1[r] & 0x7fffffff); B.sup_tmp[dst + run + __popcll(mk & lanemask_lt())] = make_int2(w, B.rid[w]); }
         run += __popcll(mk);
     }
 }
@@ -1824,6 +1831,7 @@ template <int SW> __device__ __forceinline__ int indel_unit(const DevBatch& B, c
         const i64 len = permute_i64(dest, bl);
         const int chp = __builtin_amdgcn_ds_permute(dest << 2, ch);
         const int axp = __builtin_amdgcn_ds_permute(dest << 2, pax);
+        const int ridp = __builtin_amdgcn_ds_permute(dest << 2, rid);      // (every signature of a read's group carries the group's read id)
         const int r = sl;
         const bool live = ok && r < U;
         const int last = hb | (SW - 1);
@@ -1933,7 +1941,7 @@ template <int SW> __device__ __forceinline__ int indel_unit(const DevBatch& B, c
             bp = (double)pick_pos;
             search = (i64)bp;                                                     // INDEL:415
         }
-        if (pass && !CSV_ABL(4)) B.sup_tmp[s + soff + i] = s + chp;               // INDEL:205, 416
+        if (pass && !CSV_ABL(4)) B.sup_tmp[s + soff + i] = make_int2(s + chp, ridp);   // INDEL:205, 416
         const bool head = pass && i == 0;
         if (head && !CSV_ABL(4)) {
             const int t = s + erank;
@@ -1993,12 +2001,20 @@ constexpr int IS_CHUNK = IS_NW * IS_CH * 512;        // items per workgroup (409
 __global__ __launch_bounds__(64 * IS_NW) void k_items_scan(DevBatch B)
 {
     const int n = B.cnt->n_items;
-    const int ntiles = (n + EM_TILE - 1) / EM_TILE;
     const int wv = threadIdx.x >> 6, lane = lane_id();
     const int base = blockIdx.x * (IS_CHUNK / EM_TILE);     // first tile of the chunk
-    if (base >= ntiles) return;
     __shared__ i64 buf[IS_NW][64 * 9];                      // [tile][8 items], rows padded to 9
     __shared__ i64 wsum[IS_NW];
+    // (the counts are loaded before the item count `n` is looked at - indices clamped to the table, stale entries masked -:
+    // one round trip instead of two)
+    const int imax = B.cap_items - 1;
+    i64 raw[IS_CH][8];
+#pragma unroll
+    for (int c = 0; c < IS_CH; c++)
+#pragma unroll
+        for (int r = 0; r < 8; r++) { const int i = (base + (wv * IS_CH + c) * 64) * EM_TILE + r * 64 + lane; raw[c][r] = B.item_cnt[i < imax ? i : imax]; }
+    const int ntiles = (n + EM_TILE - 1) / EM_TILE;
+    if (base >= ntiles) return;
     i64 ts[IS_CH];
 #pragma unroll
     for (int c = 0; c < IS_CH; c++) {
@@ -2007,7 +2023,7 @@ __global__ __launch_bounds__(64 * IS_NW) void k_items_scan(DevBatch B)
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             const int i = tile0 * EM_TILE + r * 64 + lane;
-            v[r] = i < n ? B.item_cnt[i] : 0;
+            v[r] = i < n ? raw[c][r] : 0;
         }
 #pragma unroll
         for (int r = 0; r < 8; r++) buf[wv][(r * 8 + (lane >> 3)) * 9 + (lane & 7)] = v[r];
@@ -2090,10 +2106,11 @@ __device__ __forceinline__ void emit_item_serial(const DevBatch& B, int j, i64 b
             const i64 dst = shfl_i64(so, l);
             const int src = s + __shfl(tso, l);
             for (int i = lane; i < nn; i += 64) {
-                const int w = B.sup_tmp[src + i];
-                B.o_supsig[dst + i] = gs + w;
-                B.o_suprid[dst + i] = B.rid[w];
-                if (B.per_sig) B.allele_id[w] = cc;
+                const int2 sr = B.sup_tmp[src + i];
+                B.o_supsig[dst + i] = gs + sr.x;
+                B.o_suprid[dst + i] = sr.y;
+                if (sr.y < 0) atomicOr(&B.cnt->error, ERR_KEY_RANGE);
+                if (B.per_sig) B.allele_id[sr.x] = cc;
             }
         }
         cb += __popcll(mk);
@@ -2106,19 +2123,32 @@ __device__ __forceinline__ void emit_item_serial(const DevBatch& B, int j, i64 b
 // send the whole tile down the serial path.
 __global__ __launch_bounds__(256) void k_emit(DevBatch B)
 {
-    const int n = B.cnt->n_items;
     const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * 256 + threadIdx.x) >> 6), nwaves = (gridDim.x * 256) >> 6;
-    const int ntiles = (n + EM_TILE - 1) / EM_TILE;
     const int lane = lane_id(), g = lane >> 3, l8 = lane & 7;
-    for (int tile = wave; tile < ntiles; tile += nwaves) {
+    const int jmax = B.cap_items - 1;
+    int n = -1;
+    for (int tile = wave;; tile += nwaves) {
         const int j = tile * EM_TILE + g;
+        // round 1: everything that only depends on the item index is loaded together - and together with the item count
+        // itself: the loads of a tile do not wait for `n` (indices are clamped to the tables' capacity; what lies beyond n is
+        // stale and masked below), so a wavefront's first tile costs one round trip less.  (n through a vector load issued
+        // AFTER the others: a scalar load of it is hoisted to the top of the kernel and waited for there.)
+        const int jj = j < jmax ? j : jmax, tt = tile < jmax / EM_TILE ? tile : jmax / EM_TILE;
+        const i64 cnt_raw = B.item_cnt[jj];
+        const int nslots_raw = B.item_nslots[jj];
+        const int4 rec_raw = B.item_rec[jj];
+        const int nchunk = tt / (IS_CHUNK / EM_TILE);
+        i64 cb_raw = B.item_chunk[lane < nchunk ? lane : 0];
+        i64 tile_base = B.item_base[tt];
+        if (n < 0) n = __hip_atomic_load(&B.cnt->n_items, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int ntiles = (n + EM_TILE - 1) / EM_TILE;
+        if (tile >= ntiles) break;
+        if (lane >= nchunk) cb_raw = 0;
+        for (int i = 64 + lane; i < nchunk; i += 64) cb_raw += B.item_chunk[i];      // (more than 64 chunks: a quarter of a million items)
+        tile_base += wave_sum_i64(cb_raw);
         const bool act = j < n;
-        // round 1: everything that only depends on the item index is loaded together ...
-        const i64 cnt = act ? B.item_cnt[j] : 0;
-        const int nslots_raw = act ? B.item_nslots[j] : 0;
-        int4 rec = make_int4(0, 0, 0, 0);
-        if (act) rec = B.item_rec[j];
-        const i64 tile_base = B.item_base[tile] + chunks_before(B, tile / (IS_CHUNK / EM_TILE));
+        const i64 cnt = act ? cnt_raw : 0;
+        const int4 rec = act ? rec_raw : make_int4(0, 0, 0, 0);
         const i64 ginc = wave_incl_scan_i64(l8 == 0 ? cnt : 0);      // prefix over the tile's 8 items (one lane per group contributes)
         const i64 base = tile_base + ginc - cnt;
         if (tile == ntiles - 1 && lane == 63) {             // the last tile closes the prefix: totals of the batch
@@ -2166,21 +2196,18 @@ __global__ __launch_bounds__(256) void k_emit(DevBatch B)
             const int nn = __shfl(nsup, src_lane), cc = __shfl(c, src_lane), ts = __shfl(tso, src_lane);
             const i64 dst = shfl_i64(so, src_lane);
             if (!__ballot(nn > 0)) continue;                // wave-uniform
-            // 4 strides per step: the index loads, then the read-id gathers, are issued together (two dependent
-            // round trips per step instead of per 8 supports; lists are 15-90 long)
+            // 4 strides per step, loads issued together (lists are 15-90 long)
             for (int i = l8; i < nn; i += 32) {
-                int w[4], rd[4];
+                int2 sr[4];
 #pragma unroll
-                for (int u = 0; u < 4; u++) w[u] = (i + 8 * u < nn) ? B.sup_tmp[s + ts + i + 8 * u] : -1;
-#pragma unroll
-                for (int u = 0; u < 4; u++) rd[u] = (w[u] >= 0) ? B.rid[w[u]] : 0;
+                for (int u = 0; u < 4; u++) sr[u] = (i + 8 * u < nn) ? B.sup_tmp[s + ts + i + 8 * u] : make_int2(-1, 0);
 #pragma unroll
                 for (int u = 0; u < 4; u++)
-                    if (w[u] >= 0) {
-                        B.o_supsig[dst + i + 8 * u] = gs + w[u];
-                        B.o_suprid[dst + i + 8 * u] = rd[u];
-                        if (rd[u] < 0) atomicOr(&B.cnt->error, ERR_KEY_RANGE);      // (a negative id would pass for an empty hash slot)
-                        if (B.per_sig) B.allele_id[w[u]] = cc;
+                    if (sr[u].x >= 0) {
+                        B.o_supsig[dst + i + 8 * u] = gs + sr[u].x;
+                        B.o_suprid[dst + i + 8 * u] = sr[u].y;
+                        if (sr[u].y < 0) atomicOr(&B.cnt->error, ERR_KEY_RANGE);      // (a negative id would pass for an empty hash slot)
+                        if (B.per_sig) B.allele_id[sr[u].x] = cc;
                     }
             }
         }
