@@ -122,7 +122,7 @@ struct csv_ctx {
     Buf reads_off, r_start, r_end, r_primary, r_id, s_start, s_end, s_primary, s_id, r_pmax, pm_partial, pm_pre, gt_over, gt_huge, gt_pool, contig_len;
     Buf ro_runs, ro_table;
     // stand-alone
-    Buf sqrt_tab, cnt;
+    Buf sqrt_tab, rcp_tab, cipk_tab, cnt;
     Buf gs_chrom, gs_perm0, gs_perm1, gs_hist, gs_tot;          // general reads sort (fallback), allocated on first use
     Buf flush;                                                   // csv_cache_flush scratch
     // rebuild step (slices of `arena_rb`)
@@ -229,13 +229,23 @@ int sqrt_table(csv_ctx* c, i64 n)
 {
     if (n <= c->sqrt_n) return CSV_OK;
     const i64 want = n + n / 4;
-    std::vector<double> tab((size_t)want);
-    for (i64 i = 0; i < want; i++) tab[(size_t)i] = pow((double)i, 0.5);
-    HIP_TRY(c, hipDeviceSynchronize());                       // (a kernel of an earlier batch may still read the old table)
-    if (c->sqrt_tab.p) { HIP_TRY(c, hipFree(c->sqrt_tab.p)); c->sqrt_tab.p = nullptr; c->sqrt_tab.cap = 0; }
-    const int rc = reserve(c, c->sqrt_tab, (size_t)want * sizeof(double));
-    if (rc) return rc;
-    HIP_TRY(c, hipMemcpy(c->sqrt_tab.p, tab.data(), (size_t)want * sizeof(double), hipMemcpyHostToDevice));
+    std::vector<double> tab((size_t)want), rcp((size_t)want);
+    std::vector<float> cipk((size_t)want);
+    for (i64 i = 0; i < want; i++) {
+        tab[(size_t)i] = pow((double)i, 0.5);
+        rcp[(size_t)i] = i ? 1.0 / (double)i : 0.0;                                   // IEEE division: correctly rounded
+        cipk[(size_t)i] = i ? (float)(1.96 / ((double)i * tab[(size_t)i])) : 0.0f;
+    }
+    HIP_TRY(c, hipDeviceSynchronize());                       // (a kernel of an earlier batch may still read the old tables)
+    Buf* tb[3] = {&c->sqrt_tab, &c->rcp_tab, &c->cipk_tab};
+    const void* src[3] = {tab.data(), rcp.data(), cipk.data()};
+    const size_t esz[3] = {sizeof(double), sizeof(double), sizeof(float)};
+    for (int q = 0; q < 3; q++) {
+        if (tb[q]->p) { HIP_TRY(c, hipFree(tb[q]->p)); tb[q]->p = nullptr; tb[q]->cap = 0; }
+        const int rc = reserve(c, *tb[q], (size_t)want * esz[q]);
+        if (rc) return rc;
+        HIP_TRY(c, hipMemcpy(tb[q]->p, src[q], (size_t)want * esz[q], hipMemcpyHostToDevice));
+    }
     c->sqrt_n = want;
     return CSV_OK;
 }
@@ -359,7 +369,7 @@ void csv_ctx_destroy(csv_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    Buf* own[] = {&c->sqrt_tab, &c->cnt, &c->gs_chrom, &c->gs_perm0, &c->gs_perm1, &c->gs_hist, &c->gs_tot, &c->flush};
+    Buf* own[] = {&c->sqrt_tab, &c->rcp_tab, &c->cipk_tab, &c->cnt, &c->gs_chrom, &c->gs_perm0, &c->gs_perm1, &c->gs_hist, &c->gs_tot, &c->flush};
     for (Buf* b : own) if (b->p) (void)hipFree(b->p);
     if (c->arena.base) (void)hipFree(c->arena.base);
     if (c->arena_rb.base) (void)hipFree(c->arena_rb.base);
@@ -668,7 +678,7 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
             B.ro_gap = env_int("CSV_READS_GAP", 1000000);      // (tests shrink it together with their task regions)
         }
     }
-    B.sqrt_tab = dp<double>(c->sqrt_tab); B.cnt = dp<DevCounters>(c->cnt);
+    B.sqrt_tab = dp<double>(c->sqrt_tab); B.rcp_tab = dp<double>(c->rcp_tab); B.cipk_tab = dp<float>(c->cipk_tab); B.cnt = dp<DevCounters>(c->cnt);
     c->n_sig_host = in->n_sig;
     c->n_reads = R;
     c->uploaded = true;

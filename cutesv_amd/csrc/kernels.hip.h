@@ -186,7 +186,9 @@ struct DevBatch {
     i64*           pm_pre;           // ... and the maximum of all earlier spans (k_pmax_scan); see pmax_at()
     int*           gt_over;          // overflow list of the first genotype pass
     const i64*     contig_len;       // reference lengths (TRA genotyping windows)
-    const double*  sqrt_tab;
+    const double*  sqrt_tab;         // pow(n, 0.5) by the host's libm, n < the longest segment + 2
+    const double*  rcp_tab;          // 1.0 / n, correctly rounded (same range): exact division by small integers through div_by (below)
+    const float*   cipk_tab;         // 1.96 / (n * pow(n, 0.5)) as float: the approximate cal_CIPOS of the register tier
     DevCounters*   cnt;
 };
 
@@ -215,6 +217,17 @@ __device__ __forceinline__ i64 readlane_i64x(i64 v, int l)
     const int lo = __builtin_amdgcn_readlane((int)(v & 0xffffffffll), l);
     const int hi = __builtin_amdgcn_readlane((int)(v >> 32), l);
     return ((i64)hi << 32) | (unsigned)lo;
+}
+// a / b for a double a and a divisor b whose correctly rounded reciprocal y = RN(1 / b) is at hand (rcp_tab): q = a y is
+// within an ulp or two of the quotient, the residual r = a - b q is exact in one FMA, and RN(q + r y) is the correctly rounded
+// quotient - bit for bit what the float64 division of numpy / CPython returns (Markstein's theorem: it only fails for a
+// divisor whose significand is all ones; checked against hardware division on 8.6e8 cases incl. quotients next to rounding
+// midpoints).  Three instructions instead of the ~35 of v_div_scale / v_rcp / Newton / v_div_fmas / v_div_fixup.
+__device__ __forceinline__ double div_by(double a, double b, double y)
+{
+    const double q = a * y;
+    const double r = __builtin_fma(-b, q, a);
+    return __builtin_fma(r, y, q);
 }
 // ---- wave64 scans / reductions on DPP (data-parallel primitives: row_shr inside rows of 16 lanes, then
 // row_bcast:15 / row_bcast:31 across rows): 6 VALU moves per 32-bit word, no LDS round trips, no waitcnt.
@@ -1838,7 +1851,7 @@ template <int SW> __device__ __forceinline__ int indel_unit(const DevBatch& B, c
 
         // ---- allele split on consecutive length gaps (INDEL:138, 153-162)
         const i64 lsum = shfl_i64(sub_scan_i64<SW>(live ? len : 0), last);
-        const double thr = ratio * ((double)lsum / (double)U);
+        const double thr = ratio * div_by((double)lsum, (double)U, B.rcp_tab[U & (SQRT_TAB - 1)]);
         const i64 lprev = wave_shr1_i64(len);
         const bool f = live && r > 0 && ((double)(len - lprev) > thr);
         const u64 fmask = __ballot(f);
@@ -1872,7 +1885,8 @@ template <int SW> __device__ __forceinline__ int indel_unit(const DevBatch& B, c
 
         // ---- statistics, all alleles at once
         int keep = (int)(rr * (double)n); if (keep < 1) keep = 1;                 // INDEL:169
-        const double pmean = (double)sp / (double)n, lmean = (double)sln / (double)n;
+        const double rcp_n = B.rcp_tab[n & (SQRT_TAB - 1)];
+        const double pmean = div_by((double)sp, (double)n, rcp_n), lmean = div_by((double)sln, (double)n, rcp_n);
         const double dp = fabs((double)pos - pmean), dl = fabs((double)len - lmean);
         double bp = pmean, siglen = lmean;
         i64 search;
@@ -1914,16 +1928,45 @@ template <int SW> __device__ __forceinline__ int indel_unit(const DevBatch& B, c
             const i64 ks = shfl_i64(Kp, e1) - (r0 > 0 ? kp0 : 0);
             const i64 kl = shfl_i64(Kl, e1) - (r0 > 0 ? kl0 : 0);
             search = shfl_i64(Ks, e1) - (r0 > 0 ? ks0 : 0);
-            bp = (double)ks / (double)keep; siglen = (double)kl / (double)keep;   // INDEL:176-177, 187
+            const double rcp_k = B.rcp_tab[keep & (SQRT_TAB - 1)];
+            bp = div_by((double)ks, (double)keep, rcp_k); siglen = div_by((double)kl, (double)keep, rcp_k);   // INDEL:176-177, 187
         }
-        const int rows_u = (mmax >> 3) + 1, tail_u = mmax < 7 ? mmax : 7;         // wave-uniform bounds (allele size <= m)
-        double vsp = 0.0, vsl = 0.0;
+        // ---- cal_CIPOS of np.std over positions and lengths (INDEL:191-194, GT:58-60).  The reference's float64 result is
+        // replayed exactly further down (numpy's pairwise summation order, IEEE division and square root); but only the INTEGER
+        // int(1.96 * std / n ** 0.5) leaves the stage.  numpy's sum of (x - mean)^2 differs from the exact variance
+        // (n * sum(d^2) - sum(d)^2) / n^2 (integers, d = x - x0) by a relative error below 4e-12 for coordinates under 2^31 (the
+        // mean's rounding error e enters only as n e^2: the first-order term 2 e sum(x - mean) vanishes).  So: the exact integer
+        // variance through two more scans, the value 1.96 * sqrt(N) / (n * n ** 0.5) in float32 (one v_sqrt_f32, a table factor;
+        // relative error < 5e-7), and the replay only for a wavefront in which some allele's value lies within 2e-6 (relative)
+        // of an integer: about one unit in a thousand.  (Replay, four float64 divisions and two square roots per unit were 28 %
+        // of this kernel's instructions.)
         int cip = 0, cil = 0;
         if (!CSV_ABL(2)) {
-            np_sum_allele2(((double)pos - pmean) * ((double)pos - pmean), ((double)len - lmean) * ((double)len - lmean), n, i, rows_u, tail_u, vsp, vsl);
-            const double rt = B.sqrt_tab[n & (SQRT_TAB - 1)];
-            cip = (int)(1.96 * sqrt(vsp / (double)n) / rt);                       // INDEL:191, GT:58-60
-            cil = (int)(1.96 * sqrt(vsl / (double)n) / rt);                       // INDEL:194
+            const i64 bpos = shfl_i64(pos, hb), blen = shfl_i64(len, hb);             // rank 0 of the sub-wave: the origin of the deltas
+            const i64 dpi = pos - bpos, dli = len - blen;
+            const bool small = !live || ((u64)pos < (1ull << 31) && (u64)len < (1ull << 31) && dpi > -(1 << 20) && dpi < (1 << 20) && dli > -(1 << 20) && dli < (1 << 20));
+            bool exact_ok = !__ballot(!small) && !CSV_ABL(15);
+            if (exact_ok) {
+                const int dp32 = live ? (int)dpi : 0, dl32 = live ? (int)dli : 0;
+                const i64 Q2p = sub_scan_i64<SW>((i64)dp32 * dp32), Q2l = sub_scan_i64<SW>((i64)dl32 * dl32);      // squares < 2^40, sums < 2^46
+                const i64 qp0 = shfl_i64(Q2p, e0), ql0 = shfl_i64(Q2l, e0);
+                const i64 s2p = shfl_i64(Q2p, e1) - (r0 > 0 ? qp0 : 0), s2l = shfl_i64(Q2l, e1) - (r0 > 0 ? ql0 : 0);
+                const i64 s1p = sp - (i64)n * bpos, s1l = sln - (i64)n * blen;        // |s1| < 2^26
+                const i64 np_ = (i64)n * s2p - s1p * s1p, nl_ = (i64)n * s2l - s1l * s1l;          // n^2 * variance, exact, < 2^52
+                const float ck = B.cipk_tab[n & (SQRT_TAB - 1)];                     // 1.96 / (n * n ** 0.5)
+                const float vp = __builtin_amdgcn_sqrtf((float)(double)np_) * ck, vl = __builtin_amdgcn_sqrtf((float)(double)nl_) * ck;
+                cip = (int)vp; cil = (int)vl;
+                const bool near_p = vp > 0.5f && fabsf(vp - rintf(vp)) <= 2e-6f * vp, near_l = vl > 0.5f && fabsf(vl - rintf(vl)) <= 2e-6f * vl;
+                if (__ballot(live && (near_p || near_l || np_ < 0 || nl_ < 0))) exact_ok = false;        // too close to call: the replay decides
+            }
+            if (!exact_ok) {
+                const int rows_u = (mmax >> 3) + 1, tail_u = mmax < 7 ? mmax : 7;     // wave-uniform bounds (allele size <= m)
+                double vsp = 0.0, vsl = 0.0;
+                np_sum_allele2(((double)pos - pmean) * ((double)pos - pmean), ((double)len - lmean) * ((double)len - lmean), n, i, rows_u, tail_u, vsp, vsl);
+                const double rt = B.sqrt_tab[n & (SQRT_TAB - 1)];
+                cip = (int)(1.96 * sqrt(vsp / (double)n) / rt);                       // INDEL:191, GT:58-60
+                cil = (int)(1.96 * sqrt(vsl / (double)n) / rt);                       // INDEL:194
+            }
         }
 
         // ---- INS: first member (allele order) whose sequence is long enough gives POS and ALT (INDEL:398-405)

@@ -98,6 +98,28 @@ def test_allele_larger_than_the_static_pow_table(ctx, n):
     assert got["support"].max() == n and got["cipos"].max() > 0
 
 
+def test_cipos_on_integer_boundaries(ctx):
+    # cal_CIPOS = int(1.96 * std / n ** 0.5).  The register tier computes the variance exactly in integers and replays
+    # numpy's float64 summation only when the value is too close to an integer to call; here every allele sits ON such a
+    # boundary in exact arithmetic (half the reads at p, half at p + 2 k: std = k; n = 4, 16, 64 make 1.96 k / sqrt(n) an
+    # integer for k = 50 j, 100 j, 200 j), where float64 lands a hair above or below: the replay must decide, as numpy does
+    from cutesv_amd.columns import SigStore
+    per = {t: [] for t in ("DEL", "INS", "DUP", "INV", "TRA")}
+    pos, rid = 100_000, 0
+    for n, step in ((4, 50), (16, 100), (64, 200)):
+        for j in range(1, 13):
+            k = step * j
+            for i in range(n):
+                p_ = pos + (2 * k if i >= n // 2 else 0)
+                ln = 500 + (2 * k if i % 2 else 0)                    # the lengths sit on a boundary too (two alleles would need ratio < ...: one allele at 0.9)
+                per["DEL"].append((p_, ln, "b%06d" % rid, "DEL", "1"))
+                rid += 1
+            pos += 100_000
+    st = SigStore.from_tuple_lists(per)
+    got = _compare_soa(ctx, st, Params(min_support=3, max_size=-1, max_cluster_bias_DEL=20000, diff_ratio_merging_DEL=50.0))
+    assert len(got["bp1"]) == 36 and (got["cipos"] > 0).all()
+
+
 def test_register_tiers_fallback_routes(ctx):
     # lengths >= 2^26 leave the one-word rank key, repeated read names leave the hashed duplicate filter: the
     # 64-bit / exact routes of indel_unit<16>, <32> and <64>, next to ordinary clusters in the same wavefronts
