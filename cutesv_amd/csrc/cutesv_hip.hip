@@ -96,7 +96,7 @@ struct Plan {
 
 // one timing slot per launch (group), in launch order
 const char* kStageName[CSV_N_STAGES] = {"init", "k_chain_count", "k_chain_apply", "k_refine_indel_wave", "k_refine_wave", "k_refine_mid",
-                                        "k_refine_block", "k_items_scan", "k_emit", "k_reads_order", "k_pmax_count", "k_pmax_scan",
+                                        "k_refine_block", "k_items_scan", "k_emit", "k_reads_order", "k_reads_gather", "k_reads_maxlen",
                                         "k_genotype", "k_genotype_tra", "", "", "", "", "", "", "", "", "", ""};
 constexpr int N_COPY_STREAMS = 2;
 constexpr int RO_CAP = 4096;                 // sorted runs the reads_order stage plans (k_reads_plan packs the rank in 12 bits)
@@ -113,13 +113,13 @@ struct csv_ctx {
     hipEvent_t  ev[CSV_N_STAGES + 2] = {};
     Arena       arena, arena_rb;
     // batch buffers (slices of `arena`)
-    Buf seg, woff, seg_drop, a, b, rid, aux, a32, b32, rs32, re32;
+    Buf seg, woff, seg_drop, a, b, rid, aux, a32, b32;
     Buf cluster_id, partial, partial64, item_rec, list_small, list_big, list_tiny, list_wide, partial_t, seg_gate, tile_info, ch_masks, tile_items, seg_err;
     Buf item_nslots, item_cnt, item_base, item_chunk, sup_tmp;
     Buf t_rec;
     Buf sc_k, sc_x, sc_v1, sc_v2, sc_v3, sc_v4, sc_v5;
     Buf o_rec, o_supsig, o_suprid, allele_id;
-    Buf reads_off, r_start, r_end, r_primary, r_id, s_start, s_end, s_primary, s_id, r_pmax, pm_partial, pm_pre, gt_over, gt_huge, gt_pool, contig_len;
+    Buf reads_off, r_start, r_end, r_primary, r_id, s_start, s_end, s_idp, cmax, clen, cfirst, bfirst, maxlen, gt_over, gt_huge, gt_pool, contig_len;
     Buf ro_runs, ro_table;
     // stand-alone
     Buf sqrt_tab, rcp_tab, cipk_tab, cnt;
@@ -144,6 +144,8 @@ struct csv_ctx {
     std::vector<csv_segment> h_seg;
     std::vector<i64>         h_woff;
     bool     uploaded = false, ran = false, any_genotype = false, any_pair = false, any_tra_gt = false, lds_set = false;
+    bool     reads_ready = false;              // the packed start-ordered reads table of this upload exists (a completed reads stage)
+    bool     reuse_reads = true;               // ... and resident re-runs keep it (csv_batch_option CSV_OPT_REUSE_READS_ORDER)
     bool     have_tab = false;                 // this upload issued copies of the reads table frame (reads_off, contig_len, columns) on side[2]
     bool     reads_general = false;            // this batch's reads table needs the general sort (found out by a first run)
     i64      sqrt_n = 0;                       // entries of sqrt_tab (grown to the longest segment seen: an allele is never larger)
@@ -401,6 +403,13 @@ int csv_batch_upload(csv_ctx* c, const csv_batch_in* in) { return upload_impl(c,
 
 int csv_batch_reads_mode(const csv_ctx* c) { return (c && c->uploaded && c->n_reads > 0) ? c->B.ro_mode : -1; }
 
+int csv_batch_option(csv_ctx* c, int option, int value)
+{
+    if (!c) return CSV_E_INVALID;
+    if (option == CSV_OPT_REUSE_READS_ORDER) { c->reuse_reads = value != 0; return CSV_OK; }
+    return fail(c, CSV_E_INVALID, "unknown option %d", option);
+}
+
 }  // extern "C"
 
 namespace {
@@ -414,6 +423,7 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
     if (!c || !in) return CSV_E_INVALID;
     c->uploaded = c->ran = false;
     c->reads_general = false;
+    c->reads_ready = false;
     HIP_TRY(c, hipSetDevice(c->device));
     if (in->n_seg < 0 || in->n_sig < 0 || (in->n_seg > 0 && !in->seg)) return fail(c, CSV_E_INVALID, "bad batch header");
     const int S = in->n_seg;
@@ -505,10 +515,13 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
     PL(o_rec, (cap_tmp + 1) * sizeof(CallRec)); PL(o_supsig, (W + 1) * 8); PL(o_suprid, (W + 1) * 4);
     if (have_tab) { PL(reads_off, (in->n_chrom + 1) * 8); PL(contig_len, (in->n_chrom + 1) * 8); }
     if (R > 0) {
-        PL(pm_partial, (div_up(R, 512) + 8) * 8); PL(pm_pre, (div_up(R, 512) + 8) * 8); PL(gt_over, (cap_tmp + 2) * 4); PL(gt_huge, (cap_tmp + 2) * 4); PL(gt_pool, pool_n * 4);
-        PL(r_start, R * 8); PL(r_end, R * 8); PL(r_primary, R); PL(r_id, R * 4); PL(r_pmax, R * 8);
-        if (rd32) { PL(rs32, R * 4); PL(re32, R * 4); }
-        if (reorder) { PL(s_start, R * 8); PL(s_end, R * 8); PL(s_primary, R); PL(s_id, R * 4); PL(ro_runs, RO_CAP * 4); PL(ro_table, RO_CAP * 16); }
+        PL(gt_over, (cap_tmp + 2) * 4); PL(gt_huge, (cap_tmp + 2) * 4); PL(gt_pool, pool_n * 4);
+        // the table as uploaded and its packed start-ordered form, both in the caller's width (int32: 13 + 12 bytes per read)
+        const size_t cw = rd32 ? 4 : 8;
+        PL(r_start, R * cw); PL(r_end, R * cw); PL(r_primary, R); PL(r_id, R * 4);
+        PL(s_start, R * cw); PL(s_end, R * cw); PL(s_idp, R * 4); PL(cmax, (div_up(R, 64) + 8) * 8); PL(clen, (div_up(R, 64) + 8) * 8); PL(cfirst, (div_up(R, 64) + 8) * 8); PL(bfirst, (div_up(R, 4096) + 8) * 8);
+        PL(maxlen, (in->n_chrom + 1) * 8);
+        if (reorder) { PL(ro_runs, RO_CAP * 4); PL(ro_table, RO_CAP * 16); }
     }
 #undef PL
     {
@@ -616,15 +629,9 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
         if (c->any_tra_gt && in->n_chrom > 0) HIP_TRY(c, hipMemcpyAsync(c->contig_len.p, in->contig_len, (size_t)in->n_chrom * 8, hipMemcpyHostToDevice, sr));
     }
     if (R > 0) {
-        if (rd32) {
-            HIP_TRY(c, hipMemcpyAsync(c->rs32.p, in->r_start, R * 4, hipMemcpyHostToDevice, sr));
-            HIP_TRY(c, hipMemcpyAsync(c->re32.p, in->r_end, R * 4, hipMemcpyHostToDevice, sr));
-            hipLaunchKernelGGL(k_widen2, dim3(div_up(R, 256 * 8) < 2048 ? div_up(R, 256 * 8) : 2048), dim3(256), 0, sr,
-                               dp<int>(c->rs32), dp<i64>(c->r_start), dp<int>(c->re32), dp<i64>(c->r_end), R);
-        } else {
-            HIP_TRY(c, hipMemcpyAsync(c->r_start.p, in->r_start, R * 8, hipMemcpyHostToDevice, sr));
-            HIP_TRY(c, hipMemcpyAsync(c->r_end.p, in->r_end, R * 8, hipMemcpyHostToDevice, sr));
-        }
+        const size_t cw = rd32 ? 4 : 8;
+        HIP_TRY(c, hipMemcpyAsync(c->r_start.p, in->r_start, R * cw, hipMemcpyHostToDevice, sr));
+        HIP_TRY(c, hipMemcpyAsync(c->r_end.p, in->r_end, R * cw, hipMemcpyHostToDevice, sr));
         HIP_TRY(c, hipMemcpyAsync(c->r_primary.p, in->r_primary, R, hipMemcpyHostToDevice, sr));
         HIP_TRY(c, hipMemcpyAsync(c->r_id.p, in->r_id, R * 4, hipMemcpyHostToDevice, sr));
     }
@@ -668,12 +675,14 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
     B.n_reads = R;
     if (have_tab) { B.reads_off = dp<i64>(c->reads_off); B.contig_len = dp<i64>(c->contig_len); }
     if (R > 0) {
-        B.r_start = dp<i64>(c->r_start); B.r_end = dp<i64>(c->r_end); B.r_primary = dp<uint8_t>(c->r_primary); B.r_id = dp<int>(c->r_id);
-        B.r_pmax = dp<i64>(c->r_pmax); B.pm_partial = dp<i64>(c->pm_partial); B.pm_pre = dp<i64>(c->pm_pre); B.gt_over = dp<int>(c->gt_over); B.gt_huge = dp<int>(c->gt_huge);
+        if (rd32) { B.r_start = Col{nullptr, dp<int>(c->r_start)}; B.r_end = Col{nullptr, dp<int>(c->r_end)}; B.s_start32 = dp<int>(c->s_start); B.s_end32 = dp<int>(c->s_end); }
+        else { B.r_start = Col{dp<i64>(c->r_start), nullptr}; B.r_end = Col{dp<i64>(c->r_end), nullptr}; B.s_start64 = dp<i64>(c->s_start); B.s_end64 = dp<i64>(c->s_end); }
+        B.r_primary = dp<uint8_t>(c->r_primary); B.r_id = dp<int>(c->r_id);
+        B.s_idp = dp<int>(c->s_idp); B.cmax = dp<i64>(c->cmax); B.clen = dp<i64>(c->clen); B.cfirst = dp<i64>(c->cfirst); B.bfirst = dp<i64>(c->bfirst); B.maxlen = dp<i64>(c->maxlen);
+        B.gt_over = dp<int>(c->gt_over); B.gt_huge = dp<int>(c->gt_huge);
         B.gt_pool = dp<int>(c->gt_pool); B.gt_pool_n = pool_n;
         B.ro_mode = reorder ? 1 : 0;
         if (reorder) {
-            B.s_start = dp<i64>(c->s_start); B.s_end = dp<i64>(c->s_end); B.s_primary = dp<uint8_t>(c->s_primary); B.s_id = dp<int>(c->s_id);
             B.ro_runs = dp<int>(c->ro_runs); B.ro_table = dp<int4>(c->ro_table); B.ro_cap = RO_CAP;
             B.ro_gap = env_int("CSV_READS_GAP", 1000000);      // (tests shrink it together with their task regions)
         }
@@ -701,9 +710,11 @@ int general_reads_sort(csv_ctx* c, hipStream_t st)
     const int* pin = nullptr;
     int* pout = dp<int>(c->gs_perm0);
     for (int f = 0; f < 2; f++) {
-        const int nb = f == 0 ? 5 : cbytes;                // starts < 2^40 (checked with the ends by k_pmax_count)
+        const int nb = f == 0 ? 5 : cbytes;                // starts < 2^40 (checked with the ends by k_reads_gather)
         for (int byte = 0; byte < nb; byte++) {
-            SortPass P{f == 0 ? (const void*)c->B.r_start : (const void*)c->gs_chrom.p, f == 0 ? 1 : 0, byte * 8, R, nunits, pin, pout, dp<int>(c->gs_hist)};
+            const bool rn = c->B.r_start.p32 != nullptr;
+            if (f == 0 && rn && byte >= 4) continue;         // (int32 starts have four key bytes)
+            SortPass P{f == 0 ? (rn ? (const void*)c->B.r_start.p32 : (const void*)c->B.r_start.p64) : (const void*)c->gs_chrom.p, (f == 0 && !rn) ? 1 : 0, byte * 8, R, nunits, pin, pout, dp<int>(c->gs_hist)};
             hipLaunchKernelGGL(k_sort_hist, dim3(nblk), dim3(256), 0, st, P);
             hipLaunchKernelGGL(k_sort_rowsum, dim3(256), dim3(256), 0, st, dp<int>(c->gs_hist), nunits, dp<int>(c->gs_tot));
             hipLaunchKernelGGL(k_sort_rowscan, dim3(256), dim3(256), 0, st, dp<int>(c->gs_hist), nunits, dp<int>(c->gs_tot));
@@ -760,21 +771,32 @@ int run_impl(csv_ctx* c, csv_run_stats* stats)
         HIP_TRY(c, mark());                                                            \
     } while (0)
 #define LAUNCH(name, kern, grid, block, lds, ...) LAUNCH_ON(st, name, kern, grid, block, lds, __VA_ARGS__)
-    auto reads_stage = [&](hipStream_t s2) -> int {       // reads_order + prefix max on stream s2 (5 launches)
-        const int nr = div_up(B.n_reads, PM_TILE);
-        if (B.ro_mode == 2) {
-            const int rc = general_reads_sort(c, s2);
-            if (rc) return rc;
-            hipLaunchKernelGGL(k_reads_gather, dim3(nr), dim3(256), 0, s2, B);
-        } else if (B.ro_mode == 1) {
-            hipLaunchKernelGGL(k_reads_runs, dim3(div_up(B.n_reads, RO_TILE)), dim3(256), 0, s2, B);
-            hipLaunchKernelGGL(k_reads_plan, dim3(1), dim3(RP_THREADS), LDS_PLAN, s2, B);
-            hipLaunchKernelGGL(k_reads_gather, dim3(nr), dim3(256), 0, s2, B);
+    auto reads_stage = [&](hipStream_t s2) -> int {       // reads order + pack + longest read per chromosome on stream s2
+        const int nr = div_up(B.n_reads, 2048);
+        const bool rn = B.r_start.p32 != nullptr;
+        // the packed table of an upload does not change between runs: a resident re-run keeps it (csv_batch_option)
+        const bool keep = c->reads_ready && c->reuse_reads && !stats;
+        if (!keep) {
+            if (B.ro_mode == 2) {
+                const int rc = general_reads_sort(c, s2);
+                if (rc) return rc;
+            } else if (B.ro_mode == 1) {
+                hipLaunchKernelGGL(k_reads_runs, dim3(div_up(B.n_reads, RO_TILE)), dim3(256), 0, s2, B);
+                hipLaunchKernelGGL(k_reads_plan, dim3(1), dim3(RP_THREADS), LDS_PLAN, s2, B);
+            }
         }
         DBG("reads_order");
         if (s2 == st || stats) HIP_TRY(c, mark());
-        LAUNCH_ON(s2, "pmax_count", k_pmax_count, nr, 256, 0, B);
-        LAUNCH_ON(s2, "pmax_scan", k_pmax_scan, 1, PS_THREADS, 0, B);
+        if (!keep) {
+            if (rn) hipLaunchKernelGGL(k_reads_gather<true>, dim3(nr), dim3(256), 0, s2, B);
+            else hipLaunchKernelGGL(k_reads_gather<false>, dim3(nr), dim3(256), 0, s2, B);
+        }
+        DBG("reads_gather");
+        if (s2 == st || stats) HIP_TRY(c, mark());
+        if (!keep) hipLaunchKernelGGL(k_reads_maxlen, dim3(B.n_chrom < 1024 ? (B.n_chrom > 0 ? B.n_chrom : 1) : 1024), dim3(256), 0, s2, B);
+        DBG("reads_maxlen");
+        if (s2 == st || stats) HIP_TRY(c, mark());
+        c->reads_ready = true;
         return CSV_OK;
     };
     if (c->copies_pending) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_copy[0], 0));       // positions, lengths, INV / TRA words
@@ -845,8 +867,13 @@ int run_impl(csv_ctx* c, csv_run_stats* stats)
         if (do_gt) {
             if (fork) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_aux[2], 0));
             else { HIP_TRY(c, hipStreamWaitEvent(st, c->ev_reads, 0)); const int rc = reads_stage(st); if (rc) return rc; }
-            hipLaunchKernelGGL((k_genotype<1024, 4, false>), dim3(2048), dim3(256), 0, st, B);
-            hipLaunchKernelGGL((k_genotype<8192, 4, true>), dim3(256), dim3(256), 0, st, B);     // overflow list of the first pass; global tables beyond
+            if (B.r_start.p32) {
+                hipLaunchKernelGGL((k_genotype<1024, 4, false, true>), dim3(2048), dim3(256), 0, st, B);
+                hipLaunchKernelGGL((k_genotype<8192, 4, true, true>), dim3(256), dim3(256), 0, st, B);     // overflow list of the first pass; global tables beyond
+            } else {
+                hipLaunchKernelGGL((k_genotype<1024, 4, false, false>), dim3(2048), dim3(256), 0, st, B);
+                hipLaunchKernelGGL((k_genotype<8192, 4, true, false>), dim3(256), dim3(256), 0, st, B);
+            }
             DBG("genotype");
             HIP_TRY(c, mark());
         } else if (stats) { for (int q = 0; q < 4; q++) HIP_TRY(c, mark()); }
@@ -854,7 +881,8 @@ int run_impl(csv_ctx* c, csv_run_stats* stats)
             // (reads_off / contig_len / the reads columns travel on side[2]: a batch whose only genotyped segments are TRA
             // segments, or one without reads, has not waited for them yet)
             if (c->copies_pending && c->have_tab) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_reads, 0));
-            LAUNCH("genotype_tra", k_genotype_tra, 256, 64, 0, B);
+            if (B.r_start.p32) LAUNCH("genotype_tra", k_genotype_tra<true>, 256, 64, 0, B);
+            else LAUNCH("genotype_tra", k_genotype_tra<false>, 256, 64, 0, B);
         }
     }
 #undef LAUNCH
@@ -911,6 +939,7 @@ int read_counters(csv_ctx* c)
         if (c->B.ro_mode == 1 && c->B.n_reads > 0 && c->any_genotype && c->h_cnt.ro_state == RO_NEED_GENERAL && attempt == 0) {
             c->reads_general = true;
             c->B.ro_mode = 2;
+            c->reads_ready = false;
             const int rc = run_impl(c, nullptr);
             if (rc) return rc;
             continue;
@@ -1039,6 +1068,7 @@ int csv_batch_download(csv_ctx* c, csv_batch_out* out)
             if (c->B.ro_mode == 1 && c->B.n_reads > 0 && c->any_genotype && c->h_cnt.ro_state == RO_NEED_GENERAL && attempt == 0) {
                 c->reads_general = true;             // (as read_counters does: the batch again, through the general sort)
                 c->B.ro_mode = 2;
+                c->reads_ready = false;
                 const int rc = run_impl(c, nullptr);
                 if (rc) return rc;
                 continue;

@@ -170,8 +170,15 @@ struct DevBatch {
     // reads
     const i64*     reads_off;
     i64            n_reads;
-    const i64*     r_start; const i64* r_end; const uint8_t* r_primary; const int* r_id;     // as uploaded (any order inside a block)
-    i64*           s_start; i64* s_end; uint8_t* s_primary; int* s_id;                       // start-ordered copies (reads_order stage)
+    Col            r_start; Col r_end; const uint8_t* r_primary; const int* r_id;            // as uploaded (any order inside a block; int32 or int64)
+    // the packed, start-ordered table k_reads_gather writes (columns in the caller's width): what the genotype kernels read
+    i64*           s_start64; i64* s_end64; int* s_start32; int* s_end32;
+    int*           s_idp;            // read id | primary << 31
+    i64*           cmax;             // per chunk of 64 reads: the largest end
+    i64*           cfirst;           // per chunk: the start of its first read; bfirst[k] = cfirst[64 k] (per block of 4096 reads)
+    i64*           bfirst;
+    i64*           clen;             // per chunk: the longest read ...
+    i64*           maxlen;           // ... and per chromosome (k_reads_maxlen): bounds how far before a window a covering read can start
     int            ro_mode;          // 0: caller promised sorted blocks; 1: run-level reorder on the device; 2: general radix sort (fallback)
     int*           ro_runs;          // run starts found by k_reads_runs (unordered)
     int4*          ro_table;         // runs in start order: {source begin, length, destination begin, chromosome}
@@ -181,9 +188,6 @@ struct DevBatch {
     int*           gt_huge;          // calls whose sets overflow the 32 KB tables AND one wavefront's slice of the global pool
     int*           gt_pool;          // global hash pool: gt_pool_n ints, power of two
     i64            gt_pool_n;
-    i64*           r_pmax;           // per read: max of (chromosome << 40 | end) over the reads of its 512-row span up to it
-    i64*           pm_partial;       // per 512-row span: its maximum ...
-    i64*           pm_pre;           // ... and the maximum of all earlier spans (k_pmax_scan); see pmax_at()
     int*           gt_over;          // overflow list of the first genotype pass
     const i64*     contig_len;       // reference lengths (TRA genotyping windows)
     const double*  sqrt_tab;         // pow(n, 0.5) by the host's libm, n < the longest segment + 2
@@ -2298,25 +2302,25 @@ __global__ __launch_bounds__(256) void k_publish(DevBatch B, PublishArgs P)
     for (i64 i = tid; i < ns; i += nth) P.support_sig[i] = B.o_supsig[i];
 }
 
-// ------------------------------------------------------------------------------------ reads: order
+// ------------------------------------------------------------------------------------ reads: order + pack
 // The reads block of a chromosome arrives in the order cuteSV's rebuild step leaves it (main script :810): the
 // concatenation of per-worker extraction batches, each batch being the reads that START inside one task region in BAM
 // order (:697-735), i.e. a permutation of DISJOINT, start-sorted runs.  overlap_cover sorts its sweep events inside
-// the stage (cuteSV_genotype.py:101-109); here the stage brings every block into stable start order with three
-// launches: k_reads_runs lists the descents (run starts), k_reads_plan orders the runs (one workgroup; a genome has a
-// few hundred) and checks that they do not interleave, k_reads_gather moves whole runs.  A table that is not a
-// permutation of disjoint runs (or has more than ro_cap of them) is reported back (RO_NEED_GENERAL) and the host
-// re-runs the batch through the general stable radix sort (sort.hip.h) - correct for any input, just slower.
-struct ReadsView { const i64* start; const i64* end; const uint8_t* primary; const int* id; };
-__device__ __forceinline__ ReadsView reads_view(const DevBatch& B)
-{
-    const bool copy = B.ro_mode == 2 || (B.ro_mode == 1 && B.cnt->ro_state != RO_IDENTITY);
-    ReadsView V;
-    V.start = copy ? B.s_start : B.r_start; V.end = copy ? B.s_end : B.r_end;
-    V.primary = copy ? B.s_primary : B.r_primary; V.id = copy ? B.s_id : B.r_id;
-    return V;
-}
-
+// the stage (cuteSV_genotype.py:101-109); here the stage brings every block into stable start order: k_reads_runs lists
+// the descents (run starts), k_reads_plan orders the runs (one workgroup; a genome has a few hundred) and checks that
+// they do not interleave, k_reads_gather moves whole runs.  A table that is not a permutation of disjoint runs (or has
+// more than ro_cap of them) is reported back (RO_NEED_GENERAL) and the host re-runs the batch through the general stable
+// radix sort (sort.hip.h) - correct for any input, just slower.
+//
+// What the genotype kernels read is the PACKED, start-ordered form k_reads_gather writes (in every mode - a table that was
+// promised or found sorted is packed in place order): s_start / s_end in the width the caller sent (int32 when the
+// coordinates fit: CSV_IN_READS_I32), s_idp = read id | primary << 31, and per chunk of 64 reads the largest end (cmax) and
+// the longest read (clen, reduced to one value per chromosome by k_reads_maxlen).  A stabbing query for the window [L, R]
+// looks at the chunks between the first read that could still reach R (start >= R - longest read of the chromosome) and the
+// last read with start <= L, and only at those whose cmax reaches R: 8 bytes per read actually scanned.  (The first form
+// kept a per-read prefix maximum of the ends - 8 more bytes per read written and read - and scanned backwards while it
+// stayed >= R: a prefix maximum is monotone, so ONE ultra-long read kept every later call scanning ~900 reads of which ~90
+// covered: 6.7x the algorithmic traffic on the 90x ultra-long workload.)
 __device__ __forceinline__ int chrom_of_read(const DevBatch& B, i64 i, int hint)
 {
     if (B.reads_off[hint] <= i && i < B.reads_off[hint + 1]) return hint;
@@ -2324,6 +2328,7 @@ __device__ __forceinline__ int chrom_of_read(const DevBatch& B, i64 i, int hint)
     while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (B.reads_off[mid] <= i) lo = mid; else hi = mid; }
     return lo;
 }
+constexpr i64 READ_END_MAX = 1ll << 40;             // ends are doubled in window arithmetic: anything beyond is a broken table
 
 constexpr int RO_TILE = 256 * 8;
 // A row starts a run when its start is smaller than its predecessor's (a descent) or jumps ahead by more than ro_gap.
@@ -2471,85 +2476,96 @@ __global__ __launch_bounds__(RP_THREADS) void k_reads_plan(DevBatch B)
     if (threadIdx.x == 0) B.cnt->ro_state = RO_REORDER;
 }
 
-// Prefix max of read ends, in three cheap pieces instead of a second pass over the table: every 512-row span keeps the
-// running maximum of (chromosome << 40 | end) inside the span (r_pmax, written by whoever touches the rows anyway: the
-// gather below, or k_pmax_count for a table that was already in order) and its total (pm_partial); k_pmax_scan turns the
-// totals into the maximum of all EARLIER spans (pm_pre, a few thousand values); a reader combines the two.  Coordinates
-// restart at every chromosome, so the scanned value carries the chromosome in its high bits: a later chromosome wins.
-constexpr int PM_SHIFT = 40;
-constexpr i64 PM_MASK = (1ll << PM_SHIFT) - 1;
-__device__ __forceinline__ i64 pmax_at(const DevBatch& B, i64 i)
-{
-    const i64 a = B.r_pmax[i], b = B.pm_pre[i >> 9];
-    return (a > b ? a : b) & PM_MASK;
-}
+// (a batch whose reads table turned out to need the general sort is run again by the host: nothing downstream of the
+// reads_order stage does any work in the first attempt)
+__device__ __forceinline__ bool reads_pending(const DevBatch& B) { return B.ro_mode == 1 && B.cnt->ro_state == RO_NEED_GENERAL; }
 
-// one wavefront per 512 destination rows: find the run of the first row (64-ary search over the run table), then copy
-// run by run (a span of 512 rows usually lies inside one run), leaving the span's running maximum behind.
-__global__ __launch_bounds__(256) void k_reads_gather(DevBatch B)
+// stores of one packed row (RN: the caller's columns are int32)
+template <bool RN> __device__ __forceinline__ void sread_store(const DevBatch& B, i64 x, i64 st, i64 en, int idp)
 {
-    if (B.ro_mode == 1 && B.cnt->ro_state != RO_REORDER) return;
-    const int wv = threadIdx.x >> 6;
+    if constexpr (RN) { B.s_start32[x] = (int)st; B.s_end32[x] = (int)en; } else { B.s_start64[x] = st; B.s_end64[x] = en; }
+    B.s_idp[x] = idp;
+}
+template <bool RN> __device__ __forceinline__ i64 sread_start(const DevBatch& B, i64 x) { if constexpr (RN) return B.s_start32[x]; else return B.s_start64[x]; }
+template <bool RN> __device__ __forceinline__ i64 sread_end(const DevBatch& B, i64 x) { if constexpr (RN) return B.s_end32[x]; else return B.s_end64[x]; }
+
+// One wavefront per 512 destination rows (8 chunks of 64): source row of every destination row - the row itself (table in
+// order), the run table (whole sorted runs move; a chunk usually lies inside one run) or the permutation of the general
+// sort - then copy + pack, and the chunk's largest end / longest read.  Validates ends and ids, and for a table that was
+// promised sorted the order of the starts.
+template <bool RN> __global__ __launch_bounds__(256) void k_reads_gather(DevBatch B)
+{
+    if (reads_pending(B)) return;
+    const int wv = threadIdx.x >> 6, lane = lane_id();
     const i64 span = (i64)blockIdx.x * 4 + wv, d0 = span * 512;
     if (d0 >= B.n_reads) return;
     const i64 d1 = d0 + 512 < B.n_reads ? d0 + 512 : B.n_reads;
-    i64 run = INT64_MIN;                                    // maximum of the span so far (wave-uniform)
-    if (B.ro_mode == 2) {                                   // general sort: a row permutation
-        int hint = 0;
-        for (i64 d = d0; d < d1; d += 64) {
-            const i64 x = d + lane_id();
-            i64 v = INT64_MIN;
-            if (x < d1) {
-                const int p = B.ro_perm[x];
-                const i64 e = B.r_end[p];
-                const int id = B.r_id[p];
-                B.s_start[x] = B.r_start[p]; B.s_end[x] = e; B.s_primary[x] = B.r_primary[p]; B.s_id[x] = id;
-                hint = chrom_of_read(B, x, hint);
-                if (e < 0 || e > PM_MASK || id < 0) atomicOr(&B.cnt->error, ERR_KEY_RANGE);
-                v = ((i64)hint << PM_SHIFT) | e;
-            }
-            i64 inc = wave_incl_max_i64(v);
-            if (run > inc) inc = run;
-            if (x < d1) B.r_pmax[x] = inc;
-            run = lane63_i64(inc);
-        }
-    } else {
-        const int n = B.cnt->n_runs;
+    const bool by_perm = B.ro_mode == 2, by_runs = B.ro_mode == 1 && B.cnt->ro_state == RO_REORDER;
+    int q = 0, n = 0;
+    if (by_runs) {
+        n = B.cnt->n_runs;
         int lo = 0, hi = n;                                 // last run with destination begin <= d0
         while (hi - lo > 1) {
             const int step = (hi - lo + 63) / 64;
-            const int idx = lo + lane_id() * step;
+            const int idx = lo + lane * step;
             const int t = __popcll(__ballot(idx < hi && (i64)B.ro_table[idx < hi ? idx : lo].z <= d0));
             const int nlo = lo + (t - 1) * step;
             int nhi = lo + t * step;
             if (nhi > hi) nhi = hi;
             lo = nlo; hi = nhi;
         }
-        i64 d = d0;
-        for (int q = lo; q < n && d < d1; q++) {
-            const int4 rn = B.ro_table[q];
-            const i64 e1 = (i64)rn.z + rn.y < d1 ? (i64)rn.z + rn.y : d1;
-            const i64 shift = (i64)rn.x - rn.z;
-            for (i64 c0 = d; c0 < e1; c0 += 64) {           // consecutive rows, 64 at a time, in order
-                const i64 x = c0 + lane_id();
-                i64 v = INT64_MIN;
-                if (x < e1) {
-                    const i64 p = x + shift;
-                    const i64 e = B.r_end[p];
-                    const int id = B.r_id[p];
-                    B.s_start[x] = B.r_start[p]; B.s_end[x] = e; B.s_primary[x] = B.r_primary[p]; B.s_id[x] = id;
-                    if (e < 0 || e > PM_MASK || id < 0) atomicOr(&B.cnt->error, ERR_KEY_RANGE);
-                    v = ((i64)rn.w << PM_SHIFT) | e;        // (the run's chromosome)
-                }
-                i64 inc = wave_incl_max_i64(v);
-                if (run > inc) inc = run;
-                if (x < e1) B.r_pmax[x] = inc;
-                run = lane63_i64(inc);
-            }
-            d = e1;
-        }
+        q = lo;
     }
-    if (lane_id() == 0) B.pm_partial[span] = run;
+    int hint = 0;
+    for (i64 c0 = d0; c0 < d1; c0 += 64) {
+        const i64 x = c0 + lane;
+        const bool in = x < d1;
+        i64 p = x;
+        if (by_perm) p = in ? B.ro_perm[x] : 0;
+        else if (by_runs) {
+            // the runs that intersect this chunk (wave-uniform walk; a lane takes the run its row lies in)
+            const i64 last = (c0 + 63 < d1 ? c0 + 63 : d1 - 1);
+            for (int qq = q; qq < n; qq++) {
+                const int4 rn = B.ro_table[qq];
+                if ((i64)rn.z > last) break;
+                if (x >= rn.z && x < (i64)rn.z + rn.y) p = x + ((i64)rn.x - rn.z);
+                if ((i64)rn.z + rn.y <= last + 1) q = qq + 1;     // the run ends inside the chunk: the next chunk starts with its successor
+            }
+        }
+        i64 vmax = INT64_MIN, vlen = 0, st_own = 0;
+        if (in) {
+            const i64 st = B.r_start[p], en = B.r_end[p];
+            st_own = st;
+            const int id = B.r_id[p], pr = B.r_primary[p];
+            if (en < 0 || en >= READ_END_MAX || st < 0 || id < 0) atomicOr(&B.cnt->error, ERR_KEY_RANGE);
+            sread_store<RN>(B, x, st, en, id | (pr == 1 ? (int)0x80000000 : 0));
+            vmax = en; vlen = en - st;
+            if (B.ro_mode == 0) {                           // the caller's promise: every block sorted by start
+                hint = chrom_of_read(B, x, hint);
+                if (x > B.reads_off[hint] && st < (i64)B.r_start[x - 1]) atomicOr(&B.cnt->error, ERR_READS_UNSORTED);
+            }
+        }
+        const i64 cm = lane63_i64(wave_incl_max_i64(vmax)), cl = lane63_i64(wave_incl_max_i64(vlen));
+        const i64 f0 = readlane_i64x(st_own, 0);                               // (lane 0 of a chunk is always a row of the table)
+        if (lane == 0) { B.cmax[c0 >> 6] = cm; B.clen[c0 >> 6] = cl; B.cfirst[c0 >> 6] = f0; if (((c0 >> 6) & 63) == 0) B.bfirst[c0 >> 12] = f0; }
+    }
+}
+
+// longest read per chromosome (a chunk that straddles two blocks counts for both: the bound may only be too generous)
+__global__ __launch_bounds__(256) void k_reads_maxlen(DevBatch B)
+{
+    if (reads_pending(B)) return;
+    __shared__ i64 sh[4];
+    for (int c = blockIdx.x; c < B.n_chrom; c += gridDim.x) {
+        const i64 r0 = B.reads_off[c], r1 = B.reads_off[c + 1];
+        i64 v = 0;
+        if (r1 > r0) for (i64 k = (r0 >> 6) + threadIdx.x; k <= ((r1 - 1) >> 6); k += 256) { const i64 x = B.clen[k]; v = x > v ? x : v; }
+        v = lane63_i64(wave_incl_max_i64(v));
+        __syncthreads();
+        if (lane_id() == 0) sh[threadIdx.x >> 6] = v;
+        __syncthreads();
+        if (threadIdx.x == 0) { i64 m = sh[0]; for (int k = 1; k < 4; k++) m = sh[k] > m ? sh[k] : m; B.maxlen[c] = m; }
+    }
 }
 
 // chromosome of every row (key column of the general sort)
@@ -2557,75 +2573,6 @@ __global__ __launch_bounds__(256) void k_reads_chromcol(DevBatch B, int* out)
 {
     const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
     if (i < B.n_reads) out[i] = chrom_of_read(B, i, 0);
-}
-
-// ------------------------------------------------------------------------------------ reads: prefix max of ends
-constexpr int PM_TILE = 256 * 8;
-
-// (a batch whose reads table turned out to need the general sort is run again by the host: nothing downstream of the
-// reads_order stage does any work in the first attempt)
-__device__ __forceinline__ bool reads_pending(const DevBatch& B) { return B.ro_mode == 1 && B.cnt->ro_state == RO_NEED_GENERAL; }
-
-// the span pass for a table that was NOT moved (promised sorted, or found to be in order): running maxima per 512-row
-// span + input validation (ends, ids, and - for the promise - the order of the starts)
-__global__ __launch_bounds__(256) void k_pmax_count(DevBatch B)
-{
-    if (reads_pending(B)) return;
-    if (B.ro_mode == 2 || (B.ro_mode == 1 && B.cnt->ro_state == RO_REORDER)) return;      // k_reads_gather did it
-    const ReadsView V = reads_view(B);
-    const i64 span = (i64)blockIdx.x * 4 + (threadIdx.x >> 6), base = span * 512;
-    if (base >= B.n_reads) return;
-    i64 run = INT64_MIN;
-    int hint = 0;
-    for (int r = 0; r < 8; r++) {
-        const i64 i = base + r * 64 + lane_id();
-        i64 v = INT64_MIN;
-        if (i < B.n_reads) {
-            hint = chrom_of_read(B, i, hint);
-            const i64 e = V.end[i];
-            if (e < 0 || e > PM_MASK || V.id[i] < 0) atomicOr(&B.cnt->error, ERR_KEY_RANGE);
-            if (i > B.reads_off[hint] && V.start[i] < V.start[i - 1]) atomicOr(&B.cnt->error, ERR_READS_UNSORTED);
-            v = ((i64)hint << PM_SHIFT) | e;
-        }
-        i64 inc = wave_incl_max_i64(v);
-        if (run > inc) inc = run;
-        if (i < B.n_reads) B.r_pmax[i] = inc;
-        run = lane63_i64(inc);
-    }
-    if (lane_id() == 0) B.pm_partial[span] = run;
-}
-
-// exclusive prefix max over the span maxima: one workgroup, a few thousand values.  Every thread takes PS_PER consecutive
-// spans (a serial max in registers), one block scan combines the threads: a 30x genome (12 k spans) is one sweep.
-constexpr int PS_THREADS = 1024;
-constexpr int PS_PER = 16;
-__global__ __launch_bounds__(PS_THREADS) void k_pmax_scan(DevBatch B)
-{
-    if (reads_pending(B)) return;
-    __shared__ i64 s_w[PS_THREADS / 64];
-    __shared__ i64 s_carry;
-    const i64 nspan = (B.n_reads + 511) >> 9;
-    if (threadIdx.x == 0) s_carry = INT64_MIN;
-    __syncthreads();
-    for (i64 b0 = 0; b0 < nspan; b0 += (i64)PS_THREADS * PS_PER) {
-        const i64 i0 = b0 + (i64)threadIdx.x * PS_PER;
-        i64 v[PS_PER];
-        i64 mine = INT64_MIN;
-#pragma unroll
-        for (int k = 0; k < PS_PER; k++) { v[k] = i0 + k < nspan ? B.pm_partial[i0 + k] : INT64_MIN; if (v[k] > mine) mine = v[k]; }
-        const i64 inc = wave_incl_max_i64(mine);
-        if (lane_id() == 63) s_w[threadIdx.x >> 6] = inc;
-        __syncthreads();
-        i64 pre = s_carry;
-        for (int q = 0; q < (int)(threadIdx.x >> 6); q++) if (s_w[q] > pre) pre = s_w[q];
-        i64 run = dpp_i64<0x138, 0xf>(INT64_MIN, inc);       // wave_shr:1: everything left of this thread in its wavefront
-        if (run < pre) run = pre;
-#pragma unroll
-        for (int k = 0; k < PS_PER; k++) { if (i0 + k < nspan) B.pm_pre[i0 + k] = run; if (v[k] > run) run = v[k]; }
-        __syncthreads();
-        if (threadIdx.x == PS_THREADS - 1) s_carry = run;
-        __syncthreads();
-    }
 }
 
 // ------------------------------------------------------------------------------------ genotype
@@ -2660,62 +2607,111 @@ __device__ __forceinline__ int hash_insert_n(int* tab, int bits, int id)      //
     }
 }
 
-// first index in [lo, hi) with 2*start > L2 (64-ary search, every step one coalesced-ish probe per lane)
-__device__ __forceinline__ i64 upper_bound_start(const i64* __restrict__ st, i64 lo, i64 hi, i64 L2)
+// The scan range of a window in the block [r0, r1) of start-ordered reads: top = last read with 2*start <= L2 (r0 - 1: none),
+// bot = first read with 2*start >= R2 - 2*maxlen (no earlier read is long enough to reach R).  Both 64-ary searches advance
+// together, one probe of each per round trip.
+template <bool RN> __device__ __forceinline__ void window_range(const DevBatch& B, i64 r0, i64 r1, i64 L2, i64 R2, i64 maxlen, i64& bot, i64& top)
 {
-    while (hi - lo > 64) {
-        const i64 step = (hi - lo + 63) / 64;
-        const i64 idx = lo + (i64)lane_id() * step;
-        const int pred = (idx < hi) && (2 * st[idx < hi ? idx : lo] <= L2);
-        const int t = __popcll(__ballot(pred));
-        if (t == 0) return lo;
-        const i64 nlo = lo + (i64)(t - 1) * step + 1;
-        i64 nhi = lo + (i64)t * step;
-        if (nhi > hi) nhi = hi;
-        lo = nlo; hi = nhi;
+    const i64 F2 = R2 - 2 * maxlen;                       // a covering read starts at or after F2 / 2
+    i64 lo_u = r0, hi_u = r1, lo_l = r0, hi_l = r1;        // upper bound of start <= L; lower bound of start >= F
+    while (hi_u - lo_u > 64 || hi_l - lo_l > 64) {
+        const i64 su = (hi_u - lo_u + 63) / 64, sl = (hi_l - lo_l + 63) / 64;
+        const i64 iu = lo_u + (i64)lane_id() * su, il = lo_l + (i64)lane_id() * sl;
+        const i64 vu = sread_start<RN>(B, iu < hi_u ? iu : lo_u), vl = sread_start<RN>(B, il < hi_l ? il : lo_l);
+        if (hi_u - lo_u > 64) {
+            const int t = __popcll(__ballot(iu < hi_u && 2 * vu <= L2));
+            if (t == 0) hi_u = lo_u;
+            else { const i64 nlo = lo_u + (i64)(t - 1) * su + 1; i64 nhi = lo_u + (i64)t * su; if (nhi > hi_u) nhi = hi_u; lo_u = nlo; hi_u = nhi; }
+        }
+        if (hi_l - lo_l > 64) {
+            const int t = __popcll(__ballot(il < hi_l && 2 * vl < F2));
+            if (t == 0) hi_l = lo_l;
+            else { const i64 nlo = lo_l + (i64)(t - 1) * sl + 1; i64 nhi = lo_l + (i64)t * sl; if (nhi > hi_l) nhi = hi_l; lo_l = nlo; hi_l = nhi; }
+        }
     }
-    const i64 idx = lo + lane_id();
-    const int pred = (idx < hi) && (2 * st[idx < hi ? idx : lo] <= L2);
-    return lo + __popcll(__ballot(pred));
+    const i64 iu = lo_u + lane_id(), il = lo_l + lane_id();
+    const i64 safe = B.n_reads - 1;                        // (an exhausted range may sit at the end of the table)
+    const i64 vu = sread_start<RN>(B, iu < hi_u ? iu : (lo_u < safe ? lo_u : safe)), vl = sread_start<RN>(B, il < hi_l ? il : (lo_l < safe ? lo_l : safe));
+    top = lo_u + __popcll(__ballot(iu < hi_u && 2 * vu <= L2)) - 1;
+    bot = lo_l + __popcll(__ballot(il < hi_l && 2 * vl < F2));
 }
 
-// Backwards stabbing scan from the last read with start <= L.  The scan is a chain of dependent round trips
-// (~28 chunks of 64 reads per window on 90x ultra-long reads, 1-2 on HiFi), so after the first chunk
-// GT_UNROLL chunks are loaded per step (all loads issued before the first one is used) and consumed in order.
+// Cover of one window into the LDS set, in three round trips.  The packed table carries two small indices written by
+// k_reads_gather: cfirst[c] = start of the first read of chunk c (64 reads) and bfirst[k] = cfirst[64 k] (a block of 4096
+// reads).  (1) every lane probes bfirst: the block that holds the last read with start <= L; (2) the 128 chunks of that
+// block and its predecessor, cfirst and cmax together: the chunks between the first read that could still reach R
+// (start >= R - longest read) and the last with start <= L whose largest end reaches R; (3) the reads of those chunks,
+// four chunks per step, tested exactly (primary, 2 start <= L2, 2 end >= R2).  The first form searched the exact row
+// bounds with two 64-ary searches over the start column (four dependent probes of 64 scattered cache lines each) before it
+// looked at any chunk: six round trips per window, and with 3-8 calls per wavefront the kernel is a chain of such trips.
 constexpr int GT_UNROLL = 4;
-// one step over U chunks below `top`; returns true when the scan is over (dead lane met, overflow)
-template <int HASH, int U> __device__ __forceinline__ bool cover_step(const DevBatch& B, const ReadsView& V, int* tab, i64 r0, i64 top, i64 R2, int& dr, int& filled, bool& overflow)
-{
-    i64 pm[U], en[U];
-    int id[U], pr[U];
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-        const i64 i = top - u * 64 - lane_id();
-        const i64 ii = i >= r0 ? i : r0;
-        pm[u] = pmax_at(B, ii); en[u] = V.end[ii]; pr[u] = V.primary[ii]; id[u] = V.id[ii];
-    }
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-        const i64 i = top - u * 64 - lane_id();
-        const int in = i >= r0;
-        const int live = in && (2 * pm[u] >= R2);                     // nothing at or before a dead lane reaches R
-        const int cov = live && pr[u] == 1 && (2 * en[u] >= R2);
-        if (filled + 64 > HASH * 3 / 4) { overflow = true; return true; }
-        int ins = 0;
-        if (cov) ins = hash_insert<HASH>(tab, id[u]);
-        const int c = __popcll(__ballot(ins));
-        dr += c; filled += c;
-        if (__ballot(!live)) return true;
-    }
-    return false;
-}
-template <int HASH> __device__ __forceinline__ int cover_window(const DevBatch& B, const ReadsView& V, int* tab, i64 r0, i64 r1, i64 L2, i64 R2, int& filled, bool& overflow)
+template <int HASH, bool RN> __device__ __forceinline__ int cover_window(const DevBatch& B, int* tab, i64 r0, i64 r1, i64 L2, i64 R2, i64 maxlen, int& filled, bool& overflow)
 {
     int dr = 0;
-    i64 top = upper_bound_start(V.start, r0, r1, L2) - 1;
-    if (top < r0 || cover_step<HASH, 1>(B, V, tab, r0, top, R2, dr, filled, overflow)) return dr;
-    for (top -= 64; top >= r0; top -= 64 * GT_UNROLL)
-        if (cover_step<HASH, GT_UNROLL>(B, V, tab, r0, top, R2, dr, filled, overflow)) break;
+    const int lane = lane_id();
+    const i64 F2 = R2 - 2 * maxlen;                       // a covering read starts at or after F2 / 2
+    const i64 c0 = r0 >> 6, c1 = (r1 - 1) >> 6, k0 = c0 >> 6, k1 = c1 >> 6;
+    // (1) last block whose first start is <= L (the block that holds the chromosome's first read counts as such: its own
+    // first read may belong to the previous chromosome)
+    i64 ktop = k0;
+    for (i64 kb = k0; kb <= k1; kb += 128) {
+        const i64 ka = kb + lane, kc = kb + 64 + lane;
+        const i64 fa = B.bfirst[ka <= k1 ? ka : k1], fc = B.bfirst[kc <= k1 ? kc : k1];
+        const int na = __popcll(__ballot(ka <= k1 && (ka == k0 || 2 * fa <= L2))), nc = __popcll(__ballot(kc <= k1 && (kc == k0 || 2 * fc <= L2)));
+        if (na + nc > 0) ktop = kb + na + nc - 1;           // (the predicate is true on a prefix: starts ascend inside a chromosome)
+        if (na + nc < 128) break;
+    }
+    // (2) chunks, two blocks per step, walking towards the chromosome's first chunk until the scan range is closed
+    bool first_step = true;
+    i64 top_chunk = -1;
+    for (i64 kk = ktop; kk >= k0; kk -= 2) {
+        const i64 cb = (kk > k0 ? kk - 1 : kk) << 6;        // first chunk of the step
+        const i64 ca = cb + lane, cc = cb + 64 + lane;
+        const bool ina = ca >= c0 && ca <= c1, inc = cc >= c0 && cc <= c1 && (kk > k0);
+        const i64 fa = B.cfirst[ina ? ca : c0], fc = B.cfirst[inc ? cc : c0];
+        const i64 ma = B.cmax[ina ? ca : c0], mc = B.cmax[inc ? cc : c0];
+        if (first_step) {                                   // the chunk of the last read with start <= L lies in this step
+            const int na = __popcll(__ballot(ina && (ca == c0 || 2 * fa <= L2))), nc = __popcll(__ballot(inc && (cc == c0 || 2 * fc <= L2)));
+            const i64 lo_c = cb > c0 ? cb : c0;
+            top_chunk = lo_c + na + nc - 1;
+            first_step = false;
+            if (top_chunk < lo_c) return 0;                 // no read of the chromosome starts at or before L
+        }
+        // chunks of this step that lie at or before top_chunk, may hold a read with start >= F (their successor's first read
+        // starts at or after F, or they are the last such) and hold a read that reaches R
+        const u64 before_a = __ballot(ina && ca != c0 && 2 * fa < F2), before_c = __ballot(inc && cc != c0 && 2 * fc < F2);   // chunk begins before F
+        // the scan's first chunk is the LAST chunk that begins before F (it may still hold later reads); every chunk after it qualifies
+        const int nb_a = __popcll(before_a), nb_c = __popcll(before_c);
+        const i64 lo_c = cb > c0 ? cb : c0;
+        const bool closed = (nb_a + nb_c > 0) || lo_c == c0;
+        const i64 bot_chunk = (nb_a + nb_c > 0) ? (nb_c ? cb + 64 + (63 - __clzll((long long)before_c)) : cb + (63 - __clzll((long long)before_a))) : lo_c;
+        u64 todo_a = __ballot(ina && ca >= bot_chunk && ca <= top_chunk && 2 * ma >= R2);
+        u64 todo_c = __ballot(inc && cc >= bot_chunk && cc <= top_chunk && 2 * mc >= R2);
+        // (3) the reads of the flagged chunks
+        while (todo_a | todo_c) {
+            i64 st[GT_UNROLL], en[GT_UNROLL]; int idp[GT_UNROLL]; bool ok[GT_UNROLL];
+#pragma unroll
+            for (int u = 0; u < GT_UNROLL; u++) {
+                i64 chunk = -1;
+                if (todo_a) { chunk = cb + __ffsll((long long)todo_a) - 1; todo_a &= todo_a - 1; }
+                else if (todo_c) { chunk = cb + 64 + __ffsll((long long)todo_c) - 1; todo_c &= todo_c - 1; }
+                const i64 row = chunk >= 0 ? (chunk << 6) + lane : -1;
+                ok[u] = row >= r0 && row < r1;
+                const i64 rr = ok[u] ? row : r0;
+                st[u] = sread_start<RN>(B, rr); en[u] = sread_end<RN>(B, rr); idp[u] = B.s_idp[rr];
+            }
+#pragma unroll
+            for (int u = 0; u < GT_UNROLL; u++) {
+                if (filled + 64 > HASH * 3 / 4) { overflow = true; return dr; }
+                const bool cov = ok[u] && idp[u] < 0 && 2 * st[u] <= L2 && 2 * en[u] >= R2;          // primary (bit 31), starts at or before L, reaches R
+                int ins = 0;
+                if (cov) ins = hash_insert<HASH>(tab, idp[u] & 0x7fffffff);
+                const int k = __popcll(__ballot(ins));
+                dr += k; filled += k;
+            }
+        }
+        if (closed) break;
+    }
     return dr;
 }
 
@@ -2770,43 +2766,21 @@ __device__ __forceinline__ GtWin gt_windows(const GtHead& H)
     return W;
 }
 
-// first index in [lo, hi) whose prefix max reaches R (r_pmax is non-decreasing inside a chromosome): the scan of a
-// window never goes below it
-__device__ __forceinline__ i64 lower_bound_pmax(const DevBatch& B, i64 lo, i64 hi, i64 R2)
-{
-    while (hi - lo > 64) {
-        const i64 step = (hi - lo + 63) / 64;
-        const i64 idx = lo + (i64)lane_id() * step;
-        const int pred = (idx < hi) && (2 * pmax_at(B, idx < hi ? idx : lo) < R2);
-        const int t = __popcll(__ballot(pred));
-        if (t == 0) return lo;
-        const i64 nlo = lo + (i64)(t - 1) * step + 1;
-        i64 nhi = lo + (i64)t * step;
-        if (nhi > hi) nhi = hi;
-        lo = nlo; hi = nhi;
-    }
-    const i64 idx = lo + lane_id();
-    const int pred = (idx < hi) && (2 * pmax_at(B, idx < hi ? idx : lo) < R2);
-    return lo + __popcll(__ballot(pred));
-}
-
 // A call of any depth with its set in global memory; executed by `nthreads` threads of one workgroup (64: one
 // wavefront with its slice of the pool; 64 * WPB = the whole workgroup with the whole pool).  Returns false when the
 // table the call needs does not fit `cap` ints (nothing has been written then).
-__device__ bool genotype_global(const DevBatch& B, const ReadsView& V, const GtHead& H, int* tab, i64 cap, int tid, int nthreads, bool whole_block, int* s_red)
+template <bool RN> __device__ bool genotype_global(const DevBatch& B, const GtHead& H, int* tab, i64 cap, int tid, int nthreads, bool whole_block, int* s_red)
 {
     const int chrom = H.h.x;
-    const i64 r0 = B.reads_off[chrom], r1 = B.reads_off[chrom + 1];
+    const i64 r0 = B.reads_off[chrom], r1 = B.reads_off[chrom + 1], maxlen = B.maxlen[chrom];
     const i64 ns = H.s1 - H.s0;
     const GtWin W = gt_windows(H);
     i64 need = ns;
-    const i64 topa = upper_bound_start(V.start, r0, r1, W.La) - 1;
-    const i64 bota = topa >= r0 ? lower_bound_pmax(B, r0, topa + 1, W.Ra) : r0;
+    i64 bota, topa, botb = r0, topb = r0 - 1;
+    window_range<RN>(B, r0, r1, W.La, W.Ra, maxlen, bota, topa);
     if (topa >= bota) need += topa - bota + 1;
-    i64 topb = r0 - 1, botb = r0;
     if (W.n == 2) {
-        topb = upper_bound_start(V.start, r0, r1, W.Lb) - 1;
-        botb = topb >= r0 ? lower_bound_pmax(B, r0, topb + 1, W.Rb) : r0;
+        window_range<RN>(B, r0, r1, W.Lb, W.Rb, maxlen, botb, topb);
         if (topb >= botb) need += topb - botb + 1;
     }
     int bits = 10;
@@ -2818,10 +2792,8 @@ __device__ bool genotype_global(const DevBatch& B, const ReadsView& V, const GtH
     for (i64 i = tid; i < ns; i += nthreads) hash_insert_n(tab, bits, B.o_suprid[H.s0 + i]);
     if (whole_block) __syncthreads(); else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     int dr = 0;
-    for (i64 i = bota + tid; i <= topa; i += nthreads)
-        if (V.primary[i] == 1 && 2 * V.end[i] >= W.Ra) dr += hash_insert_n(tab, bits, V.id[i]);
-    for (i64 i = botb + tid; i <= topb; i += nthreads)
-        if (V.primary[i] == 1 && 2 * V.end[i] >= W.Rb) dr += hash_insert_n(tab, bits, V.id[i]);
+    for (i64 i = bota + tid; i <= topa; i += nthreads) { const int idp = B.s_idp[i]; if (idp < 0 && 2 * sread_end<RN>(B, i) >= W.Ra) dr += hash_insert_n(tab, bits, idp & 0x7fffffff); }
+    for (i64 i = botb + tid; i <= topb; i += nthreads) { const int idp = B.s_idp[i]; if (idp < 0 && 2 * sread_end<RN>(B, i) >= W.Rb) dr += hash_insert_n(tab, bits, idp & 0x7fffffff); }
     dr = wave_sum_i32(dr);
     if (whole_block) {
         if (lane_id() == 0) s_red[tid >> 6] = dr;
@@ -2837,14 +2809,13 @@ __device__ bool genotype_global(const DevBatch& B, const ReadsView& V, const GtH
 // SECOND is a template parameter so that the first pass - the one every call goes through - does not carry the code and the
 // registers of the global-pool path (as a run-time argument: 28 scalar spills and 16 bytes of scratch per lane in the hot
 // kernel; cfg-4 56.7 -> 40.6 us, cfg-5 136 -> 116 us)
-template <int HASH, int WPB, bool SECOND> __global__ __launch_bounds__(64 * WPB) void k_genotype(DevBatch B)
+template <int HASH, int WPB, bool SECOND, bool RN> __global__ __launch_bounds__(64 * WPB) void k_genotype(DevBatch B)
 {
     constexpr int second = SECOND ? 1 : 0;
     __shared__ int tabs[WPB][HASH];
     __shared__ int s_red[WPB], s_last;
     int* tab = tabs[threadIdx.x >> 6];
     if (reads_pending(B)) return;
-    const ReadsView V = reads_view(B);
     const int n = second ? B.cnt->n_gt_over : B.cnt->n_calls;
     if (second && n == 0) return;                                   // (nothing overflowed the first pass: no list, no hand-over)
     const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * (64 * WPB) + threadIdx.x) >> 6), nwaves = (gridDim.x * (64 * WPB)) >> 6;
@@ -2855,6 +2826,7 @@ template <int HASH, int WPB, bool SECOND> __global__ __launch_bounds__(64 * WPB)
         if (q + nwaves < n) gt_load_head(B, second, q + nwaves, nxt);
         const int c = cur.c, svtype = cur.h.y & 0xff, chrom = cur.h.x;
         if (!(cur.h.y & 0x100) || svtype == CSV_TRA) continue;    // TRA: k_genotype_tra
+        const i64 r0 = B.reads_off[chrom], r1 = B.reads_off[chrom + 1], maxlen = B.maxlen[chrom];
         for (int i = lane_id(); i < HASH; i += 64) tab[i] = -1;
         const i64 s0 = cur.s0, ns = cur.s1 - s0;
         int filled = 0;
@@ -2866,19 +2838,18 @@ template <int HASH, int WPB, bool SECOND> __global__ __launch_bounds__(64 * WPB)
             if (i < ns) ins = hash_insert<HASH>(tab, B.o_suprid[s0 + i]);
             filled += __popcll(__ballot(ins));
         }
-        const i64 r0 = B.reads_off[chrom], r1 = B.reads_off[chrom + 1];
         int dr = 0;
         if (!overflow) {
             const GtWin W = gt_windows(cur);
-            dr = cover_window<HASH>(B, V, tab, r0, r1, W.La, W.Ra, filled, overflow);
-            if (W.n == 2 && !overflow) dr += cover_window<HASH>(B, V, tab, r0, r1, W.Lb, W.Rb, filled, overflow);
+            dr = cover_window<HASH, RN>(B, tab, r0, r1, W.La, W.Ra, maxlen, filled, overflow);
+            if (W.n == 2 && !overflow) dr += cover_window<HASH, RN>(B, tab, r0, r1, W.Lb, W.Rb, maxlen, filled, overflow);
         }
         if (overflow) {                                                       // wave-uniform
             if constexpr (!SECOND) { if (lane_id() == 0) B.gt_over[atomicAdd(&B.cnt->n_gt_over, 1)] = c; continue; }
             else {
                 // deeper than the 32 KB tables: this wavefront's slice of the global pool ...
                 const i64 slice = B.gt_pool_n / nwaves;
-                if (!genotype_global(B, V, cur, B.gt_pool + (i64)wave * slice, slice, lane_id(), 64, false, s_red) && lane_id() == 0)
+                if (!genotype_global<RN>(B, cur, B.gt_pool + (i64)wave * slice, slice, lane_id(), 64, false, s_red) && lane_id() == 0)
                     B.gt_huge[atomicAdd(&B.cnt->n_gt_huge, 1)] = c;           // ... or, later, the whole pool
                 continue;
             }
@@ -2901,7 +2872,7 @@ template <int HASH, int WPB, bool SECOND> __global__ __launch_bounds__(64 * WPB)
     for (int q = 0; q < nh; q++) {
         GtHead H;
         gt_load_call(B, __hip_atomic_load(&B.gt_huge[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), H);
-        if (!genotype_global(B, V, H, B.gt_pool, B.gt_pool_n, threadIdx.x, 64 * WPB, WPB > 1, s_red) && threadIdx.x == 0)
+        if (!genotype_global<RN>(B, H, B.gt_pool, B.gt_pool_n, threadIdx.x, 64 * WPB, WPB > 1, s_red) && threadIdx.x == 0)
             atomicOr(&B.cnt->error, ERR_COVER_OVERFLOW);                      // (cannot happen: the pool is sized for any call of the batch)
     }
 }
@@ -2955,14 +2926,15 @@ __device__ __forceinline__ i64 tra_up_bound(i64 num)     // threshold_ref_count,
 }
 
 // one count_coverage() call; returns the status (0 / 1 / -1).  nq / dr / filled are wave-uniform running totals.
-__device__ __forceinline__ int tra_window(const DevBatch& B, const ReadsView& V, int* ids, int* fl, int bits, int chrom, i64 s, i64 e, i64 up_bound, i64 itround,
-                                          i64& nq, int& dr, int& filled, bool& overflow)
+template <bool RN> __device__ __forceinline__ int tra_window(const DevBatch& B, int* ids, int* fl, int bits, int chrom, i64 s, i64 e, i64 up_bound, i64 itround,
+                                                             i64& nq, int& dr, int& filled, bool& overflow)
 {
     if (s >= e) return 0;
     const i64 limit = (3ll << bits) / 4;
-    const i64 r0 = B.reads_off[chrom], r1 = B.reads_off[chrom + 1];
-    const i64 hi = partition_point_wave(r0, r1, [&](i64 i) { return V.start[i] < e; });        // fetch(): start < e ...
-    const i64 lo = partition_point_wave(r0, hi, [&](i64 i) { return pmax_at(B, i) <= s; });    // ... and end > s
+    const i64 r0 = B.reads_off[chrom], r1 = B.reads_off[chrom + 1], maxlen = B.maxlen[chrom];
+    if (r1 <= r0) return 0;
+    const i64 hi = partition_point_wave(r0, r1, [&](i64 i) { return sread_start<RN>(B, i) < e; });          // fetch(): start < e ...
+    const i64 lo = partition_point_wave(r0, hi, [&](i64 i) { return sread_start<RN>(B, i) + maxlen <= s; }); // ... and end > s (no earlier read is long enough)
     i64 iteration = 0, primary = 0;
     const u64 le = lanemask_lt() | (1ull << lane_id());
     for (i64 base = lo; base < hi; base += 64) {
@@ -2970,10 +2942,10 @@ __device__ __forceinline__ int tra_window(const DevBatch& B, const ReadsView& V,
         const i64 i = base + lane_id();
         const bool in = i < hi;
         const i64 ii = in ? i : lo;
-        const i64 rs = V.start[ii], re = V.end[ii];
-        const int id = V.id[ii];
+        const i64 rs = sread_start<RN>(B, ii), re = sread_end<RN>(B, ii);
+        const int idp = B.s_idp[ii], id = idp & 0x7fffffff;
         const bool ov = in && re > s;                                          // GT:76-77
-        const bool prim = ov && V.primary[ii] == 1;                            // GT:78-80
+        const bool prim = ov && idp < 0;                                       // GT:78-80
         const bool span = prim && rs < s && re > e;                            // GT:81
         // a name that occurs twice among the chunk's spanning reads counts at its first occurrence
         bool dup = false;
@@ -3010,7 +2982,7 @@ __device__ __forceinline__ int tra_window(const DevBatch& B, const ReadsView& V,
 }
 
 // one TRA call with its set in ids / fl (2^bits slots each); returns false when the set overflowed (nothing written)
-__device__ bool tra_call(const DevBatch& B, const ReadsView& V, int c, int* ids, int* fl, int bits)
+template <bool RN> __device__ bool tra_call(const DevBatch& B, int c, int* ids, int* fl, int bits)
 {
     const CallRec rec = B.o_rec[c];
     const csv_segment& sg = B.seg[rec.seg];
@@ -3037,12 +3009,12 @@ __device__ bool tra_call(const DevBatch& B, const ReadsView& V, int c, int* ids,
         i64 s = rec.bp1 - bias, e = rec.bp1 + bias;                   // TRA:263-264
         if (s < 0) s = 0;
         if (e > B.contig_len[chr1]) e = B.contig_len[chr1];
-        status = tra_window(B, V, ids, fl, bits, chr1, s, e, up_bound, sg.gt_round, nq, dr, filled, overflow);
+        status = tra_window<RN>(B, ids, fl, bits, chr1, s, e, up_bound, sg.gt_round, nq, dr, filled, overflow);
         if (status == 0 && !overflow) {                               // TRA:289-299 (status_2 is not looked at)
             s = rec.bp2 - bias; e = rec.bp2 + bias;
             if (s < 0) s = 0;
             if (e > B.contig_len[chr2]) e = B.contig_len[chr2];
-            tra_window(B, V, ids, fl, bits, chr2, s, e, up_bound, sg.gt_round, nq, dr, filled, overflow);
+            tra_window<RN>(B, ids, fl, bits, chr2, s, e, up_bound, sg.gt_round, nq, dr, filled, overflow);
         }
     }
     if (overflow) return false;
@@ -3060,13 +3032,12 @@ __device__ __forceinline__ int tra_bits_for(i64 ns)
     return bits;
 }
 
-__global__ __launch_bounds__(64) void k_genotype_tra(DevBatch B)
+template <bool RN> __global__ __launch_bounds__(64) void k_genotype_tra(DevBatch B)
 {
     __shared__ int ids[TG_HASH];
     __shared__ int fl[TG_HASH];
     __shared__ int s_last;
     if (reads_pending(B)) return;
-    const ReadsView V = reads_view(B);
     const int n = B.cnt->n_calls;
     const i64 slice = B.gt_pool_n / gridDim.x;          // (the pool is free: k_genotype ran before this kernel)
     for (int c0 = blockIdx.x * 64; c0 < n; c0 += gridDim.x * 64) {
@@ -3077,12 +3048,12 @@ __global__ __launch_bounds__(64) void k_genotype_tra(DevBatch B)
         for (u64 todo = __ballot(mine); todo;) {
             const int c = c0 + __builtin_amdgcn_readfirstlane(__builtin_ctzll(todo));
             todo &= todo - 1;
-            if (tra_call(B, V, c, ids, fl, 12)) continue;
+            if (tra_call<RN>(B, c, ids, fl, 12)) continue;
             // more names than the LDS set holds: this workgroup's slice of the global pool, or the whole pool later
             const int bits = tra_bits_for(B.o_rec[c].support);
             if ((2ll << bits) <= slice && bits <= 30) {
                 int* g = B.gt_pool + (i64)blockIdx.x * slice;
-                if (!tra_call(B, V, c, g, g + (1ll << bits), bits) && lane_id() == 0) atomicOr(&B.cnt->error, ERR_COVER_OVERFLOW);
+                if (!tra_call<RN>(B, c, g, g + (1ll << bits), bits) && lane_id() == 0) atomicOr(&B.cnt->error, ERR_COVER_OVERFLOW);
             } else if (lane_id() == 0) B.gt_huge[atomicAdd(&B.cnt->n_tra_huge, 1)] = c;
         }
     }
@@ -3098,7 +3069,7 @@ __global__ __launch_bounds__(64) void k_genotype_tra(DevBatch B)
     for (int q = 0; q < nh; q++) {
         const int c = __hip_atomic_load(&B.gt_huge[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int bits = tra_bits_for(B.o_rec[c].support);
-        if ((2ll << bits) > B.gt_pool_n || bits > 30 || !tra_call(B, V, c, B.gt_pool, B.gt_pool + (1ll << bits), bits))
+        if ((2ll << bits) > B.gt_pool_n || bits > 30 || !tra_call<RN>(B, c, B.gt_pool, B.gt_pool + (1ll << bits), bits))
             if (lane_id() == 0) atomicOr(&B.cnt->error, ERR_COVER_OVERFLOW);   // (cannot happen: the pool is sized for any call of the batch)
     }
 }

@@ -78,6 +78,10 @@ class Context:
         self._check(lib().csv_measure_copy_bandwidth(self._h, int(nbytes), int(reps), C.byref(out)))
         return float(out.value)
 
+    def option(self, option, value):
+        """context options (include/cutesv_hip.h CSV_OPT_*): 1 = keep the ordered reads table across runs of one upload"""
+        self._check(lib().csv_batch_option(self._h, int(option), int(value)))
+
     def last_reads_mode(self):
         """0 promised sorted, 1 run-level reorder on the device, 2 general radix sort, -1 no reads table"""
         return int(lib().csv_batch_reads_mode(self._h))

@@ -223,6 +223,12 @@ int csv_ctx_sync(csv_ctx* ctx);
 /* How the reads table of the last completed run was brought into start order: 0 = the caller promised sorted blocks,
  * 1 = whole sorted runs were moved (or nothing had to move), 2 = the general stable radix sort; -1 = no reads table. */
 int csv_batch_reads_mode(const csv_ctx* ctx);
+/* Context options.  CSV_OPT_REUSE_READS_ORDER (default 1): the start-ordered, packed copy of the reads table that the first
+ * csv_batch_run after an upload builds is kept for later runs of the SAME upload (a resident caller that re-runs a batch,
+ * e.g. with other segment scalars, does not re-order millions of reads every time); 0 rebuilds it in every run.
+ * csv_cluster_batch always builds it (every call is a new upload). */
+enum { CSV_OPT_REUSE_READS_ORDER = 1 };
+int csv_batch_option(csv_ctx* ctx, int option, int value);
 
 /* Page-locked host memory.  Columns that live in it (or in a registered caller buffer) are copied asynchronously, so the
  * kernels start while the later columns are still on the link; RESULT arrays that live in it are filled in place by the

@@ -11,6 +11,7 @@ store, params, _ = bench.make_workload(wl, 1.0, 0)
 hb = store.pinned().host_batch(store.tasks(), params)
 ctx = engine.Context(0)
 ctx.upload(hb, per_sig=False)
+ctx.option(1, int(os.environ.get('REUSE_READS', '0')))
 for _ in range(10):
     ctx.run()
 ctx.sync()
