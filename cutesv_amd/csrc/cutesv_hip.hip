@@ -119,7 +119,7 @@ struct csv_ctx {
     Buf t_rec;
     Buf sc_k, sc_x, sc_v1, sc_v2, sc_v3, sc_v4, sc_v5;
     Buf o_rec, o_supsig, o_suprid, allele_id;
-    Buf reads_off, r_start, r_end, r_primary, r_id, s_start, s_end, s_idp, cmax, clen, cfirst, bfirst, maxlen, gt_over, gt_huge, gt_pool, contig_len;
+    Buf reads_off, r_start, r_end, r_primary, r_id, s_start, s_end, s_idp, cmax, cfirst, bfirst, span_len, maxlen, gt_over, gt_huge, gt_pool, contig_len;
     Buf ro_runs, ro_table;
     // stand-alone
     Buf sqrt_tab, rcp_tab, cipk_tab, cnt;
@@ -519,7 +519,7 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
         // the table as uploaded and its packed start-ordered form, both in the caller's width (int32: 13 + 12 bytes per read)
         const size_t cw = rd32 ? 4 : 8;
         PL(r_start, R * cw); PL(r_end, R * cw); PL(r_primary, R); PL(r_id, R * 4);
-        PL(s_start, R * cw); PL(s_end, R * cw); PL(s_idp, R * 4); PL(cmax, (div_up(R, 64) + 8) * 8); PL(clen, (div_up(R, 64) + 8) * 8); PL(cfirst, (div_up(R, 64) + 8) * 8); PL(bfirst, (div_up(R, 4096) + 8) * 8);
+        PL(s_start, R * cw); PL(s_end, R * cw); PL(s_idp, R * 4); PL(cmax, (div_up(R, 64) + 8) * 8); PL(span_len, (div_up(R, 512) + 8) * 8); PL(cfirst, (div_up(R, 64) + 8) * 8); PL(bfirst, (div_up(R, 4096) + 8) * 8);
         PL(maxlen, (in->n_chrom + 1) * 8);
         if (reorder) { PL(ro_runs, RO_CAP * 4); PL(ro_table, RO_CAP * 16); }
     }
@@ -678,7 +678,7 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
         if (rd32) { B.r_start = Col{nullptr, dp<int>(c->r_start)}; B.r_end = Col{nullptr, dp<int>(c->r_end)}; B.s_start32 = dp<int>(c->s_start); B.s_end32 = dp<int>(c->s_end); }
         else { B.r_start = Col{dp<i64>(c->r_start), nullptr}; B.r_end = Col{dp<i64>(c->r_end), nullptr}; B.s_start64 = dp<i64>(c->s_start); B.s_end64 = dp<i64>(c->s_end); }
         B.r_primary = dp<uint8_t>(c->r_primary); B.r_id = dp<int>(c->r_id);
-        B.s_idp = dp<int>(c->s_idp); B.cmax = dp<i64>(c->cmax); B.clen = dp<i64>(c->clen); B.cfirst = dp<i64>(c->cfirst); B.bfirst = dp<i64>(c->bfirst); B.maxlen = dp<i64>(c->maxlen);
+        B.s_idp = dp<int>(c->s_idp); B.cmax = dp<i64>(c->cmax); B.span_len = dp<i64>(c->span_len); B.cfirst = dp<i64>(c->cfirst); B.bfirst = dp<i64>(c->bfirst); B.maxlen = dp<i64>(c->maxlen);
         B.gt_over = dp<int>(c->gt_over); B.gt_huge = dp<int>(c->gt_huge);
         B.gt_pool = dp<int>(c->gt_pool); B.gt_pool_n = pool_n;
         B.ro_mode = reorder ? 1 : 0;
@@ -737,7 +737,7 @@ int run_impl(csv_ctx* c, csv_run_stats* stats)
     constexpr int LDS_SMALL = refine_lds_bytes<64>();
     constexpr int LDS_MID = refine_lds_bytes<256>();
     constexpr int LDS_BIG = refine_lds_bytes<2048>();
-    constexpr int LDS_PLAN = RO_CAP * 16 + 64;
+    constexpr int LDS_PLAN = RO_CAP * 24 + 64;
     if (!c->lds_set) {
         HIP_TRY(c, hipFuncSetAttribute((const void*)k_refine<256, 2048, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BIG));
         HIP_TRY(c, hipFuncSetAttribute((const void*)k_reads_plan, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_PLAN));

@@ -177,7 +177,7 @@ struct DevBatch {
     i64*           cmax;             // per chunk of 64 reads: the largest end
     i64*           cfirst;           // per chunk: the start of its first read; bfirst[k] = cfirst[64 k] (per block of 4096 reads)
     i64*           bfirst;
-    i64*           clen;             // per chunk: the longest read ...
+    i64*           span_len;         // per span of 512 reads: the longest read ...
     i64*           maxlen;           // ... and per chromosome (k_reads_maxlen): bounds how far before a window a covering read can start
     int            ro_mode;          // 0: caller promised sorted blocks; 1: run-level reorder on the device; 2: general radix sort (fallback)
     int*           ro_runs;          // run starts found by k_reads_runs (unordered)
@@ -2315,7 +2315,7 @@ __global__ __launch_bounds__(256) void k_publish(DevBatch B, PublishArgs P)
 // What the genotype kernels read is the PACKED, start-ordered form k_reads_gather writes (in every mode - a table that was
 // promised or found sorted is packed in place order): s_start / s_end in the width the caller sent (int32 when the
 // coordinates fit: CSV_IN_READS_I32), s_idp = read id | primary << 31, and per chunk of 64 reads the largest end (cmax) and
-// the longest read (clen, reduced to one value per chromosome by k_reads_maxlen).  A stabbing query for the window [L, R]
+// the chromosome's longest read (maxlen).  A stabbing query for the window [L, R]
 // looks at the chunks between the first read that could still reach R (start >= R - longest read of the chromosome) and the
 // last read with start <= L, and only at those whose cmax reaches R: 8 bytes per read actually scanned.  (The first form
 // kept a per-read prefix maximum of the ends - 8 more bytes per read written and read - and scanned backwards while it
@@ -2380,6 +2380,20 @@ template <class T> __device__ __forceinline__ void lds_bitonic(T* K, int P)
             __syncthreads();
         }
 }
+// sort of n <= RP_THREADS keys by counting: every thread ranks one key against all others (LDS broadcast reads, no barrier
+// inside) - two barriers instead of the 45 of a 512-key bitonic network, which were 22 of this kernel's 25 us.  T: scratch.
+template <class T> __device__ __forceinline__ void lds_ranksort(T* K, T* Tmp, int n, int P)
+{
+    const int i = threadIdx.x;
+    T mine = i < n ? K[i] : (T)0;
+    int r = 0;
+    if (i < n) for (int j = 0; j < n; j++) { const T o = K[j]; r += (o < mine) || (o == mine && j < i); }
+    __syncthreads();
+    if (i < n) Tmp[r] = mine;
+    __syncthreads();
+    for (int q = threadIdx.x; q < P; q += RP_THREADS) K[q] = q < n ? Tmp[q] : (T)PAD_KEY;
+    __syncthreads();
+}
 __global__ __launch_bounds__(RP_THREADS) void k_reads_plan(DevBatch B)
 {
     extern __shared__ __attribute__((aligned(16))) char rp_smem[];
@@ -2390,7 +2404,8 @@ __global__ __launch_bounds__(RP_THREADS) void k_reads_plan(DevBatch B)
     int P = 1;
     while (P < n_raw) P <<= 1;
     u64* K = (u64*)rp_smem;                    // P sort keys
-    int* pos = (int*)(K + P);                  // run starts by position (+ sentinel)
+    u64* Tmp = K + P;                          // rank-sort scratch
+    int* pos = (int*)(Tmp + P);                // run starts by position (+ sentinel)
     int* len_s = pos + P + 1;                  // lengths in start order, then their exclusive scan
     __shared__ int s_bad, s_moved, s_carry;
     __shared__ int s_w[RP_THREADS / 64];
@@ -2403,7 +2418,7 @@ __global__ __launch_bounds__(RP_THREADS) void k_reads_plan(DevBatch B)
         K[i] = key;
     }
     __syncthreads();
-    lds_bitonic(K, P);                                      // by position
+    if (n_raw <= RP_THREADS) lds_ranksort(K, Tmp, n_raw, P); else lds_bitonic(K, P);      // by position
     // distinct positions, compacted in order (flag + block scan; the entries are already sorted)
     for (int b0 = 0; b0 < P; b0 += RP_THREADS) {
         const int i = b0 + threadIdx.x;
@@ -2440,7 +2455,7 @@ __global__ __launch_bounds__(RP_THREADS) void k_reads_plan(DevBatch B)
         K[i] = key;
     }
     __syncthreads();
-    lds_bitonic(K, P);                                      // by (chromosome, first start, position)
+    if (n <= RP_THREADS) lds_ranksort(K, Tmp, n, P); else lds_bitonic(K, P);              // by (chromosome, first start, position)
     // consecutive runs of one chromosome must not interleave: last start of the earlier <= first start of the later,
     // and on equality the earlier one must also come first by position (that is what a stable sort would do)
     for (int q = threadIdx.x; q < n; q += RP_THREADS) {
@@ -2517,6 +2532,7 @@ template <bool RN> __global__ __launch_bounds__(256) void k_reads_gather(DevBatc
         q = lo;
     }
     int hint = 0;
+    i64 span_len = 0;
     for (i64 c0 = d0; c0 < d1; c0 += 64) {
         const i64 x = c0 + lane;
         const bool in = x < d1;
@@ -2539,7 +2555,7 @@ template <bool RN> __global__ __launch_bounds__(256) void k_reads_gather(DevBatc
             const int id = B.r_id[p], pr = B.r_primary[p];
             if (en < 0 || en >= READ_END_MAX || st < 0 || id < 0) atomicOr(&B.cnt->error, ERR_KEY_RANGE);
             sread_store<RN>(B, x, st, en, id | (pr == 1 ? (int)0x80000000 : 0));
-            vmax = en; vlen = en - st;
+            vmax = en; vlen = en > st ? en - st : 0;
             if (B.ro_mode == 0) {                           // the caller's promise: every block sorted by start
                 hint = chrom_of_read(B, x, hint);
                 if (x > B.reads_off[hint] && st < (i64)B.r_start[x - 1]) atomicOr(&B.cnt->error, ERR_READS_UNSORTED);
@@ -2547,11 +2563,15 @@ template <bool RN> __global__ __launch_bounds__(256) void k_reads_gather(DevBatc
         }
         const i64 cm = lane63_i64(wave_incl_max_i64(vmax)), cl = lane63_i64(wave_incl_max_i64(vlen));
         const i64 f0 = readlane_i64x(st_own, 0);                               // (lane 0 of a chunk is always a row of the table)
-        if (lane == 0) { B.cmax[c0 >> 6] = cm; B.clen[c0 >> 6] = cl; B.cfirst[c0 >> 6] = f0; if (((c0 >> 6) & 63) == 0) B.bfirst[c0 >> 12] = f0; }
+        if (lane == 0) { B.cmax[c0 >> 6] = cm; B.cfirst[c0 >> 6] = f0; if (((c0 >> 6) & 63) == 0) B.bfirst[c0 >> 12] = f0; }
+        span_len = cl > span_len ? cl : span_len;
     }
+    if (lane == 0) B.span_len[span] = span_len;             // longest read of the span (k_reads_maxlen reduces them per chromosome)
 }
 
-// longest read per chromosome (a chunk that straddles two blocks counts for both: the bound may only be too generous)
+// longest read per chromosome from the spans' maxima (a span of 512 rows that straddles two blocks counts for both: the bound
+// may only be too generous).  (One atomic maximum per span from the gather itself was tried: 12 000 atomics on two dozen
+// addresses took the gather from 48 to 137 us.)
 __global__ __launch_bounds__(256) void k_reads_maxlen(DevBatch B)
 {
     if (reads_pending(B)) return;
@@ -2559,7 +2579,7 @@ __global__ __launch_bounds__(256) void k_reads_maxlen(DevBatch B)
     for (int c = blockIdx.x; c < B.n_chrom; c += gridDim.x) {
         const i64 r0 = B.reads_off[c], r1 = B.reads_off[c + 1];
         i64 v = 0;
-        if (r1 > r0) for (i64 k = (r0 >> 6) + threadIdx.x; k <= ((r1 - 1) >> 6); k += 256) { const i64 x = B.clen[k]; v = x > v ? x : v; }
+        if (r1 > r0) for (i64 k = (r0 >> 9) + threadIdx.x; k <= ((r1 - 1) >> 9); k += 256) { const i64 x = B.span_len[k]; v = x > v ? x : v; }
         v = lane63_i64(wave_incl_max_i64(v));
         __syncthreads();
         if (lane_id() == 0) sh[threadIdx.x >> 6] = v;
@@ -2705,8 +2725,8 @@ template <int HASH, bool RN> __device__ __forceinline__ int cover_window(const D
                 if (filled + 64 > HASH * 3 / 4) { overflow = true; return dr; }
                 const bool cov = ok[u] && idp[u] < 0 && 2 * st[u] <= L2 && 2 * en[u] >= R2;          // primary (bit 31), starts at or before L, reaches R
                 int ins = 0;
-                if (cov) ins = hash_insert<HASH>(tab, idp[u] & 0x7fffffff);
-                const int k = __popcll(__ballot(ins));
+                if (cov && !CSV_ABL(17)) ins = hash_insert<HASH>(tab, idp[u] & 0x7fffffff);
+                const int k = __popcll(__ballot(CSV_ABL(17) ? cov : ins));
                 dr += k; filled += k;
             }
         }
@@ -2835,11 +2855,11 @@ template <int HASH, int WPB, bool SECOND, bool RN> __global__ __launch_bounds__(
             if (filled + 64 > HASH * 3 / 4) { overflow = true; break; }
             const i64 i = base + lane_id();
             int ins = 0;
-            if (i < ns) ins = hash_insert<HASH>(tab, B.o_suprid[s0 + i]);
+            if (i < ns && !CSV_ABL(18)) ins = hash_insert<HASH>(tab, B.o_suprid[s0 + i]);
             filled += __popcll(__ballot(ins));
         }
         int dr = 0;
-        if (!overflow) {
+        if (!overflow && !CSV_ABL(16)) {
             const GtWin W = gt_windows(cur);
             dr = cover_window<HASH, RN>(B, tab, r0, r1, W.La, W.Ra, maxlen, filled, overflow);
             if (W.n == 2 && !overflow) dr += cover_window<HASH, RN>(B, tab, r0, r1, W.Lb, W.Rb, maxlen, filled, overflow);
