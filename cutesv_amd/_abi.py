@@ -8,7 +8,7 @@ import ctypes as C
 
 import numpy as np
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 DEL, INS, DUP, INV, TRA = 0, 1, 2, 3, 4
 SVTYPE_CODE = {"DEL": DEL, "INS": INS, "DUP": DUP, "INV": INV, "TRA": TRA}
 SVTYPE_NAME = {v: k for k, v in SVTYPE_CODE.items()}
@@ -18,7 +18,8 @@ ERR_NAME = {OK: "CSV_OK", E_INVALID: "CSV_E_INVALID", E_CAPACITY: "CSV_E_CAPACIT
             E_NOMEM: "CSV_E_NOMEM", E_UNSORTED: "CSV_E_UNSORTED", E_STATE: "CSV_E_STATE"}
 N_STAGES = 24
 GL_TABLE_SIZE = 101 * 101 + 2
-IN_PER_SIG, IN_READS_SORTED, IN_SIG_I32, IN_READS_I32 = 1, 2, 4, 8            # csv_batch_in.flags
+IN_PER_SIG, IN_READS_SORTED, IN_SIG_I32, IN_READS_I32, IN_DEVICE_COLUMNS = 1, 2, 4, 8, 16            # csv_batch_in.flags
+RB_KEEP_ON_DEVICE = 1                         # csv_rebuild_in.flags
 SEG_KEY_RANGE = 1                             # csv_batch_out.seg_status bits
 
 # numpy dtype with exactly the C layout of `csv_segment` (all members naturally aligned)
@@ -119,6 +120,33 @@ class HostBatch:
             flags=(IN_PER_SIG if per_sig else 0) | (IN_READS_SORTED if reads_sorted else 0) | (IN_SIG_I32 if self.a.dtype == np.int32 else 0)
             | (IN_READS_I32 if self.r_start is not None and self.r_start.dtype == np.int32 else 0))
 
+    @classmethod
+    def on_device(cls, segments, dev, n_sig, n_chrom=0, keep=None, **reads):
+        """A batch whose signature columns already live in device memory (CSV_IN_DEVICE_COLUMNS): `dev` = dict(a=, b=, read_id=,
+        aux=) of device addresses (int64 a / b, int32 read_id / aux: what csv_rebuild_signatures leaves with
+        CSV_RB_KEEP_ON_DEVICE); `keep`: objects that own that memory.  The reads table, if any, comes from the host as usual."""
+        self = cls.__new__(cls)
+        self.segments = np.ascontiguousarray(segments, dtype=SEGMENT_DTYPE)
+        self.a = self.b = self.read_id = self.aux = None
+        self._n_sig, self._keep = int(n_sig), keep
+        self.n_chrom = int(n_chrom)
+        self.reads_off = self.r_start = self.r_end = self.r_primary = self.r_id = self.contig_len = None
+        if reads.get("reads_off") is not None:
+            self.reads_off = _col(reads["reads_off"], np.int64)
+            rd32 = getattr(reads["r_start"], "dtype", None) == np.int32 and getattr(reads["r_end"], "dtype", None) == np.int32
+            self.r_start = _col(reads["r_start"], np.int32 if rd32 else np.int64); self.r_end = _col(reads["r_end"], np.int32 if rd32 else np.int64)
+            self.r_primary = _col(reads["r_primary"], np.uint8); self.r_id = _col(reads["r_id"], np.int32)
+        if reads.get("contig_len") is not None:
+            self.contig_len = _col(reads["contig_len"], np.int64)
+        self.c = BatchIn(
+            n_seg=len(self.segments), n_chrom=self.n_chrom, seg=_ptr(self.segments), n_sig=self._n_sig,
+            a=dev["a"], b=dev["b"], read_id=dev["read_id"], aux=dev["aux"], reads_off=_ptr(self.reads_off),
+            n_reads=0 if self.r_start is None else self.r_start.shape[0],
+            r_start=_ptr(self.r_start), r_end=_ptr(self.r_end), r_primary=_ptr(self.r_primary), r_id=_ptr(self.r_id),
+            contig_len=_ptr(self.contig_len),
+            flags=IN_DEVICE_COLUMNS | (IN_READS_I32 if self.r_start is not None and self.r_start.dtype == np.int32 else 0))
+        return self
+
     def widened(self):
         """the same batch with int64 position columns (what the oracle takes)"""
         if self.a.dtype != np.int32 and (self.r_start is None or self.r_start.dtype != np.int32):
@@ -133,7 +161,7 @@ class HostBatch:
 
     @property
     def n_sig(self):
-        return self.a.shape[0]
+        return self.a.shape[0] if self.a is not None else self._n_sig
 
 
 class HostResult:

@@ -127,7 +127,7 @@ struct csv_ctx {
     Buf flush;                                                   // csv_cache_flush scratch
     // rebuild step (slices of `arena_rb`)
     Buf rb_seg, rb_a, rb_b, rb_rid, rb_aux, rb_auxk, rb_major, rb_nodedup, rb_perm0, rb_perm1, rb_hist, rb_tot, rb_partial;
-    Buf rb_oseg, rb_oa, rb_ob, rb_orid, rb_oaux, rb_osrc;
+    Buf rb_oseg, rb_oa, rb_ob, rb_orid, rb_oaux, rb_osrc, rb_segcnt;
     // CIGAR scan (slices of `arena_rb` as well: the two steps never overlap)
     Buf sp_off, sp_len, sp_c0, sp_c1, sp_f0, sp_f1, sp_chr, sp_mapq, sp_strand, sp_primary, sp_seg, sp_cnt, sp_tiles, sp_tot,
         sp_kind, sp_read, sp_ochr, sp_aux, sp_a, sp_b, sp_c, sp_d;
@@ -480,6 +480,8 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
     if (c->any_genotype && in->reads_off && (!in->r_start || !in->r_end || !in->r_primary || !in->r_id) && in->n_reads > 0)
         return fail(c, CSV_E_INVALID, "reads columns missing");
     const bool per_sig = per_sig_forced || (in->flags & CSV_IN_PER_SIG);
+    const bool dev_cols = (in->flags & CSV_IN_DEVICE_COLUMNS) != 0;       // a / b / read_id / aux are device pointers: device-to-device copies
+    const hipMemcpyKind col_kind = dev_cols ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
 
     // ---- device memory: one plan, one arena
     const i64 R = (c->any_genotype && in->reads_off) ? in->n_reads : 0;
@@ -597,18 +599,18 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
             const i64 src = c->h_seg[k].sig_begin, n = c->h_woff[e + 1] - c->h_woff[k], dst = c->h_woff[k];
             if (n > 0) {
                 if (group == 1 && sig32) {
-                    HIP_TRY(c, hipMemcpyAsync(dp<int>(c->a32) + dst, (const int32_t*)in->a + src, n * 4, hipMemcpyHostToDevice, cs));
-                    HIP_TRY(c, hipMemcpyAsync(dp<int>(c->b32) + dst, (const int32_t*)in->b + src, n * 4, hipMemcpyHostToDevice, cs));
+                    HIP_TRY(c, hipMemcpyAsync(dp<int>(c->a32) + dst, (const int32_t*)in->a + src, n * 4, col_kind, cs));
+                    HIP_TRY(c, hipMemcpyAsync(dp<int>(c->b32) + dst, (const int32_t*)in->b + src, n * 4, col_kind, cs));
                 } else if (group == 1) {
-                    HIP_TRY(c, hipMemcpyAsync(dp<i64>(c->a) + dst, in->a + src, n * 8, hipMemcpyHostToDevice, cs));
-                    HIP_TRY(c, hipMemcpyAsync(dp<i64>(c->b) + dst, in->b + src, n * 8, hipMemcpyHostToDevice, cs));
-                } else HIP_TRY(c, hipMemcpyAsync(dp<int>(c->rid) + dst, in->read_id + src, n * 4, hipMemcpyHostToDevice, cs));
+                    HIP_TRY(c, hipMemcpyAsync(dp<i64>(c->a) + dst, in->a + src, n * 8, col_kind, cs));
+                    HIP_TRY(c, hipMemcpyAsync(dp<i64>(c->b) + dst, in->b + src, n * 8, col_kind, cs));
+                } else HIP_TRY(c, hipMemcpyAsync(dp<int>(c->rid) + dst, in->read_id + src, n * 4, col_kind, cs));
                 for (int q = k; q <= e;) {                  // aux: runs of segments of this group's kind
                     int q2 = q;
                     while (q2 + 1 <= e && aux_kind(q2 + 1) == aux_kind(q)) q2++;
                     const i64 na = c->h_woff[q2 + 1] - c->h_woff[q];
                     if (aux_kind(q) == group && na > 0)
-                        HIP_TRY(c, hipMemcpyAsync(dp<int>(c->aux) + c->h_woff[q], in->aux + c->h_seg[q].sig_begin, na * 4, hipMemcpyHostToDevice, cs));
+                        HIP_TRY(c, hipMemcpyAsync(dp<int>(c->aux) + c->h_woff[q], in->aux + c->h_seg[q].sig_begin, na * 4, col_kind, cs));
                     q = q2 + 1;
                 }
             }
@@ -656,7 +658,13 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
     for (int k = S - 1; k >= 0; k--)
         if (c->h_seg[k].sig_end > c->h_seg[k].sig_begin) {
             const i64 last = c->h_seg[k].sig_end - 1;
-            B.end_z = sig32 ? (((const int32_t*)in->a)[last] == 0 && ((const int32_t*)in->b)[last] == 0) : (in->a[last] == 0 && in->b[last] == 0);
+            if (dev_cols) {                                 // (columns in device memory: the two values are fetched)
+                i64 va = 0, vb = 0; int32_t wa = 0, wb = 0;
+                if (sig32) { HIP_TRY(c, hipMemcpy(&wa, (const int32_t*)in->a + last, 4, hipMemcpyDeviceToHost)); HIP_TRY(c, hipMemcpy(&wb, (const int32_t*)in->b + last, 4, hipMemcpyDeviceToHost)); va = wa; vb = wb; }
+                else { HIP_TRY(c, hipMemcpy(&va, in->a + last, 8, hipMemcpyDeviceToHost)); HIP_TRY(c, hipMemcpy(&vb, in->b + last, 8, hipMemcpyDeviceToHost)); }
+                B.end_z = va == 0 && vb == 0;
+            } else
+                B.end_z = sig32 ? (((const int32_t*)in->a)[last] == 0 && ((const int32_t*)in->b)[last] == 0) : (in->a[last] == 0 && in->b[last] == 0);
             break;
         }
     B.cluster_id = per_sig ? dp<int>(c->cluster_id) : nullptr; B.allele_id = per_sig ? dp<int>(c->allele_id) : nullptr;
@@ -1160,7 +1168,7 @@ int csv_rebuild_signatures(csv_ctx* c, const csv_rebuild_in* in, csv_rebuild_out
     PL(rb_seg, n * 4); PL(rb_a, n * 8); PL(rb_b, n * 8); PL(rb_rid, n * 4); PL(rb_aux, n * 4); PL(rb_auxk, n * 4);
     PL(rb_major, in->n_seg); PL(rb_nodedup, in->n_seg); PL(rb_perm0, n * 4); PL(rb_perm1, n * 4); PL(rb_hist, (size_t)256 * nunits * 4);
     PL(rb_tot, 256 * 4); PL(rb_partial, (ntile + 2) * 4);
-    PL(rb_oseg, n * 4); PL(rb_oa, n * 8); PL(rb_ob, n * 8); PL(rb_orid, n * 4); PL(rb_oaux, n * 4); PL(rb_osrc, n * 4);
+    PL(rb_oseg, n * 4); PL(rb_oa, n * 8); PL(rb_ob, n * 8); PL(rb_orid, n * 4); PL(rb_oaux, n * 4); PL(rb_osrc, n * 4); PL(rb_segcnt, ((size_t)in->n_seg + 2) * 8);
 #undef PL
     {
         if (P.total > c->arena_rb.cap) HIP_TRY(c, hipDeviceSynchronize());
@@ -1205,19 +1213,32 @@ int csv_rebuild_signatures(csv_ctx* c, const csv_rebuild_in* in, csv_rebuild_out
     R.o_aux = dp<int>(c->rb_oaux); R.o_src = dp<int>(c->rb_osrc); R.n_out = (int*)c->cnt.p;
     hipLaunchKernelGGL(k_rebuild_count, dim3(ntile), dim3(256), 0, st, R);
     hipLaunchKernelGGL(k_rebuild_apply, dim3(ntile), dim3(256), 0, st, R);
+    // rows per segment and the INS tie count ([n_seg] = ties), from the sorted output
+    HIP_TRY(c, hipMemsetAsync(dp<i64>(c->rb_segcnt) + in->n_seg, 0, 8, st));
+    hipLaunchKernelGGL(k_rebuild_segcount, dim3(div_up(in->n_seg, 256) > 64 ? div_up(in->n_seg, 256) : 64), dim3(256), 0, st, R, in->n_seg,
+                       dp<i64>(c->rb_segcnt), dp<i64>(c->rb_segcnt) + in->n_seg);
     HIP_TRY(c, hipEventRecord(c->ev[1], st));
     HIP_TRY(c, hipGetLastError());
     int n_out = 0;
+    std::vector<i64> segcnt((size_t)in->n_seg + 1);
     HIP_TRY(c, hipMemcpyAsync(&n_out, c->cnt.p, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(segcnt.data(), c->rb_segcnt.p, ((size_t)in->n_seg + 1) * 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipStreamSynchronize(st));
     HIP_TRY(c, hipEventElapsedTime(&out->ms_device, c->ev[0], c->ev[1]));
     out->n_out = n_out; out->n_passes = npass;
-    HIP_TRY(c, hipMemcpyAsync(out->seg_id, c->rb_oseg.p, (size_t)n_out * 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipMemcpyAsync(out->a, c->rb_oa.p, (size_t)n_out * 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipMemcpyAsync(out->b, c->rb_ob.p, (size_t)n_out * 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipMemcpyAsync(out->read_id, c->rb_orid.p, (size_t)n_out * 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipMemcpyAsync(out->aux, c->rb_oaux.p, (size_t)n_out * 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipMemcpyAsync(out->src_row, c->rb_osrc.p, (size_t)n_out * 4, hipMemcpyDeviceToHost, st));
+    out->n_ins_ties = segcnt[(size_t)in->n_seg];
+    if (out->seg_count) memcpy(out->seg_count, segcnt.data(), (size_t)in->n_seg * 8);
+    const bool keep_dev = (in->flags & CSV_RB_KEEP_ON_DEVICE) != 0;
+    out->dev_seg_id = out->dev_a = out->dev_b = out->dev_read_id = out->dev_aux = out->dev_src_row = nullptr;
+    if (keep_dev) {
+        out->dev_seg_id = c->rb_oseg.p; out->dev_a = c->rb_oa.p; out->dev_b = c->rb_ob.p; out->dev_read_id = c->rb_orid.p;
+        out->dev_aux = c->rb_oaux.p; out->dev_src_row = c->rb_osrc.p;
+    }
+    // (with CSV_RB_KEEP_ON_DEVICE a NULL host array is simply not filled; without the flag all six are required, as before)
+#define RB_D2H(dst, buf, bytes) do { if ((dst) || !keep_dev) HIP_TRY(c, hipMemcpyAsync((dst), c->buf.p, (bytes), hipMemcpyDeviceToHost, st)); } while (0)
+    RB_D2H(out->seg_id, rb_oseg, (size_t)n_out * 4); RB_D2H(out->a, rb_oa, (size_t)n_out * 8); RB_D2H(out->b, rb_ob, (size_t)n_out * 8);
+    RB_D2H(out->read_id, rb_orid, (size_t)n_out * 4); RB_D2H(out->aux, rb_oaux, (size_t)n_out * 4); RB_D2H(out->src_row, rb_osrc, (size_t)n_out * 4);
+#undef RB_D2H
     HIP_TRY(c, hipStreamSynchronize(st));
     c->uploaded = c->ran = false;          // cnt was used as scratch
     return CSV_OK;

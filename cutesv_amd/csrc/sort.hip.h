@@ -190,6 +190,30 @@ __global__ __launch_bounds__(256) void k_rebuild_apply(RebuildArgs R)
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) *R.n_out = run;
 }
 
+// rows per segment of the sorted, de-duplicated output (o_seg ascends): one thread per segment, two binary searches; and the
+// number of rows in keep-every-row segments that agree with their predecessor in (segment, a, b, read id) - the INS tie
+// groups whose order depends on the inserted sequences, which only the host has
+__global__ __launch_bounds__(256) void k_rebuild_segcount(RebuildArgs R, int n_seg, i64* seg_count, i64* n_ties)
+{
+    const int n = *R.n_out;
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s < n_seg) {
+        int lo = 0, hi = n;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (R.o_seg[mid] < s) lo = mid + 1; else hi = mid; }
+        const int first = lo;
+        hi = n;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (R.o_seg[mid] <= s) lo = mid + 1; else hi = mid; }
+        seg_count[s] = lo - first;
+    }
+    if (R.nodedup) {
+        int ties = 0;
+        for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x + 1; i < n; i += (i64)gridDim.x * 256)
+            ties += R.nodedup[R.o_seg[i]] && R.o_seg[i] == R.o_seg[i - 1] && R.o_a[i] == R.o_a[i - 1] && R.o_b[i] == R.o_b[i - 1] && R.o_rid[i] == R.o_rid[i - 1];
+        ties = wave_sum_i32(ties);
+        if ((threadIdx.x & 63) == 0 && ties) atomicAdd((unsigned long long*)n_ties, (unsigned long long)ties);
+    }
+}
+
 // effective aux key: aux sorts before pos only for INV (strand) and TRA (chr2, type) segments
 __global__ __launch_bounds__(256) void k_rebuild_auxkey(i64 n, const int* seg, const int* aux, const uint8_t* seg_aux_major, int* auxk)
 {

@@ -20,18 +20,23 @@ from .columns import SigStore, NameTable, TYPES
 
 
 class RebuildIn(C.Structure):
-    _fields_ = [("n", C.c_int64), ("n_seg", C.c_int32), ("reserved", C.c_int32), ("seg_aux_major", C.c_void_p),
+    _fields_ = [("n", C.c_int64), ("n_seg", C.c_int32), ("flags", C.c_int32), ("seg_aux_major", C.c_void_p),
                 ("seg_id", C.c_void_p), ("a", C.c_void_p), ("b", C.c_void_p), ("read_id", C.c_void_p), ("aux", C.c_void_p),
                 ("seg_nodedup", C.c_void_p)]
 
 
 class RebuildOut(C.Structure):
     _fields_ = [("n_out", C.c_int64), ("seg_id", C.c_void_p), ("a", C.c_void_p), ("b", C.c_void_p), ("read_id", C.c_void_p),
-                ("aux", C.c_void_p), ("src_row", C.c_void_p), ("ms_device", C.c_float), ("n_passes", C.c_int32)]
+                ("aux", C.c_void_p), ("src_row", C.c_void_p), ("ms_device", C.c_float), ("n_passes", C.c_int32),
+                ("seg_count", C.c_void_p), ("n_ins_ties", C.c_int64), ("dev_seg_id", C.c_void_p), ("dev_a", C.c_void_p), ("dev_b", C.c_void_p),
+                ("dev_read_id", C.c_void_p), ("dev_aux", C.c_void_p), ("dev_src_row", C.c_void_p)]
 
 
-def rebuild_columns(ctx, seg_id, a, b, read_id, aux, seg_aux_major, seg_nodedup=None):
-    """-> dict(seg_id, a, b, read_id, aux, src_row, ms_device, n_passes): sorted, de-duplicated rows"""
+def rebuild_columns(ctx, seg_id, a, b, read_id, aux, seg_aux_major, seg_nodedup=None, keep_on_device=False):
+    """-> dict(seg_id, a, b, read_id, aux, src_row, ms_device, n_passes, seg_count, n_ins_ties): sorted, de-duplicated rows.
+    keep_on_device: the sorted columns stay in device memory (CSV_RB_KEEP_ON_DEVICE): the dict then holds `dev` (device
+    addresses of a / b / read_id / aux, valid until the context's next rebuild / extraction call) and, from the host side,
+    only src_row and seg_count - 4 instead of 28 bytes per row cross PCIe."""
     L = lib()
     L.csv_rebuild_signatures.restype = C.c_int
     L.csv_rebuild_signatures.argtypes = [C.c_void_p, C.POINTER(RebuildIn), C.POINTER(RebuildOut)]
@@ -42,17 +47,76 @@ def rebuild_columns(ctx, seg_id, a, b, read_id, aux, seg_aux_major, seg_nodedup=
     n = len(a)
     o = dict(seg_id=np.empty(n, np.int32), a=np.empty(n, np.int64), b=np.empty(n, np.int64), read_id=np.empty(n, np.int32),
              aux=np.empty(n, np.int32), src_row=np.empty(n, np.int32))
-    rin = RebuildIn(n=n, n_seg=len(major), seg_aux_major=major.ctypes.data, seg_id=seg_id.ctypes.data, a=a.ctypes.data,
-                    b=b.ctypes.data, read_id=read_id.ctypes.data, aux=aux.ctypes.data,
+    seg_count = np.zeros(len(major), np.int64)
+    rin = RebuildIn(n=n, n_seg=len(major), flags=_abi.RB_KEEP_ON_DEVICE if keep_on_device else 0, seg_aux_major=major.ctypes.data,
+                    seg_id=seg_id.ctypes.data, a=a.ctypes.data, b=b.ctypes.data, read_id=read_id.ctypes.data, aux=aux.ctypes.data,
                     seg_nodedup=None if nodedup is None else nodedup.ctypes.data)
-    rout = RebuildOut(seg_id=o["seg_id"].ctypes.data, a=o["a"].ctypes.data, b=o["b"].ctypes.data, read_id=o["read_id"].ctypes.data,
-                      aux=o["aux"].ctypes.data, src_row=o["src_row"].ctypes.data)
+    if keep_on_device:
+        rout = RebuildOut(src_row=o["src_row"].ctypes.data, seg_count=seg_count.ctypes.data)
+    else:
+        rout = RebuildOut(seg_id=o["seg_id"].ctypes.data, a=o["a"].ctypes.data, b=o["b"].ctypes.data, read_id=o["read_id"].ctypes.data,
+                          aux=o["aux"].ctypes.data, src_row=o["src_row"].ctypes.data, seg_count=seg_count.ctypes.data)
     ctx._check(L.csv_rebuild_signatures(ctx._h, C.byref(rin), C.byref(rout)))
     k = int(rout.n_out)
-    out = {key: v[:k] for key, v in o.items()}
+    out = {key: v[:k] for key, v in o.items()} if not keep_on_device else {"src_row": o["src_row"][:k]}
     out["ms_device"] = float(rout.ms_device)
     out["n_passes"] = int(rout.n_passes)
+    out["seg_count"] = seg_count
+    out["n_ins_ties"] = int(rout.n_ins_ties)
+    out["n_out"] = k
+    if keep_on_device:
+        out["dev"] = dict(a=rout.dev_a, b=rout.dev_b, read_id=rout.dev_read_id, aux=rout.dev_aux, seg_id=rout.dev_seg_id, src_row=rout.dev_src_row)
     return out
+
+
+def rebuild_to_device_batch(ctx, chroms, per_type, params_segment, reads=None):
+    """The rebuild -> cluster hand-off without a host round trip (the reference's dataflow main script :750-857 -> :1113-1199):
+    unsorted per-type rows (as store_from_unsorted takes them; no INS sequences: the integer columns decide) are sorted and
+    de-duplicated on the device and STAY there; returns (batch, tasks, src_row) where `batch` is an `_abi.HostBatch.on_device`
+    whose columns are the rebuild's device buffers, `tasks` the (type, chromosome) pairs of its segments in the reference's
+    order and `src_row` the input row of every sorted row (to carry read names / sequences on the host).
+    params_segment(svtype, chrom_index, begin, end) -> csv_segment record.
+    Raises when INS rows tie on their integer columns (their order depends on the sequences: use store_from_unsorted)."""
+    order = sorted(range(len(chroms)), key=lambda i: chroms[i])
+    crank = np.zeros(len(chroms), np.int64)
+    crank[order] = np.arange(len(chroms))
+    cols = {k: [] for k in ("seg", "a", "b", "rid", "aux")}
+    for ti, t in enumerate(TYPES):
+        if t not in per_type or len(per_type[t]["a"]) == 0:
+            continue
+        d = per_type[t]
+        cols["seg"].append(ti * len(chroms) + crank[np.asarray(d["chrom"], np.int64)])
+        cols["a"].append(np.asarray(d["a"], np.int64)); cols["b"].append(np.asarray(d["b"], np.int64))
+        cols["rid"].append(np.asarray(d["read_id"], np.int64)); cols["aux"].append(np.asarray(d["aux"], np.int64))
+    cat = {k: np.concatenate(v) if v else np.zeros(0, np.int64) for k, v in cols.items()}
+    n_seg = len(TYPES) * len(chroms)
+    major = np.zeros(n_seg, np.uint8)
+    nodedup = np.zeros(n_seg, np.uint8)
+    for ti, t in enumerate(TYPES):
+        if t in ("INV", "TRA"):
+            major[ti * len(chroms):(ti + 1) * len(chroms)] = 1
+    ti_ins = TYPES.index("INS")
+    nodedup[ti_ins * len(chroms):(ti_ins + 1) * len(chroms)] = 1
+    r = rebuild_columns(ctx, cat["seg"], cat["a"], cat["b"], cat["rid"], cat["aux"], major, nodedup, keep_on_device=True)
+    if r["n_ins_ties"]:
+        raise ValueError("%d INS rows tie on (chromosome, position, length, read): their order depends on the inserted sequences; "
+                         "finish them on the host (rebuild.store_from_unsorted)" % r["n_ins_ties"])
+    off = np.r_[0, np.cumsum(r["seg_count"])]
+    segs, tasks = [], []
+    for s in range(n_seg):
+        if r["seg_count"][s] == 0:
+            continue
+        t, ci = TYPES[s // len(chroms)], order[s % len(chroms)]
+        segs.append(params_segment(t, ci, int(off[s]), int(off[s + 1])))
+        tasks.append((t, chroms[ci]))
+    kw = {}
+    if reads is not None:
+        rc = np.asarray(reads["chrom"], np.int64)
+        o = np.argsort(rc, kind="stable")
+        kw = dict(reads_off=np.searchsorted(rc[o], np.arange(len(chroms) + 1)).astype(np.int64), r_start=np.asarray(reads["start"], np.int64)[o],
+                  r_end=np.asarray(reads["end"], np.int64)[o], r_primary=np.asarray(reads["primary"], np.uint8)[o], r_id=np.asarray(reads["read_id"], np.int32)[o])
+    batch = _abi.HostBatch.on_device(np.array(segs, dtype=_abi.SEGMENT_DTYPE), r["dev"], r["n_out"], n_chrom=len(chroms), keep=ctx, **kw)
+    return batch, tasks, r["src_row"]
 
 
 def finish_ins_ties(r, ins_segs, seq_of_src, half_of_src):

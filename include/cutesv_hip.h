@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CSV_ABI_VERSION 3
+#define CSV_ABI_VERSION 4
 
 /* SV types: one (chromosome, type) pair is one segment == one reference pool task
  * (MAIN:1116-1189).  Order of the enum is irrelevant to results. */
@@ -95,7 +95,11 @@ enum {
                                  device: CSV_E_UNSORTED if not) */
     CSV_IN_SIG_I32 = 4,       /* a and b point to int32_t columns (positions and lengths of a genome fit 31 bits; a third
                                  less data on the link: 67 -> 45 MB for a 30x genome); widened on the device */
-    CSV_IN_READS_I32 = 8      /* r_start and r_end point to int32_t columns */
+    CSV_IN_READS_I32 = 8,     /* r_start and r_end point to int32_t columns */
+    CSV_IN_DEVICE_COLUMNS = 16 /* a, b, read_id and aux are DEVICE pointers (memory of this context's GPU, e.g. csv_rebuild_out.dev_* of
+                                 a csv_rebuild_signatures call with CSV_RB_KEEP_ON_DEVICE): the columns move device to device
+                                 (HBM rate) instead of crossing PCIe twice; the reference's dataflow rebuild -> cluster
+                                 (MAIN:750-857 -> 1113-1199) without a host round trip */
 };
 typedef struct csv_batch_in {
     int32_t            n_seg;
@@ -271,10 +275,13 @@ int32_t csv_gl_index(int64_t c0, int64_t c1);
  * 8 bits per pass, zero bytes skipped; then gather + de-duplication.  Outputs are caller-allocated with
  * room for n rows; src_row[i] = input row of output row i (to carry payloads such as INS sequences).
  */
+enum { CSV_RB_KEEP_ON_DEVICE = 1 };  /* csv_rebuild_in.flags: the sorted columns stay in device memory (csv_rebuild_out.dev_*, valid
+                                        until the context's next csv_rebuild_signatures / csv_cigar_signatures / csv_split_signatures
+                                        call); host output arrays that are NULL are not written */
 typedef struct csv_rebuild_in {
     int64_t        n;
     int32_t        n_seg;
-    int32_t        reserved;
+    int32_t        flags;           /* CSV_RB_* */
     const uint8_t* seg_aux_major;   /* n_seg */
     const int32_t* seg_id;
     const int64_t* a;
@@ -296,6 +303,16 @@ typedef struct csv_rebuild_out {
     int32_t* src_row;
     float    ms_device;             /* out: kernels only (HIP events) */
     int32_t  n_passes;              /* out: radix passes executed */
+    int64_t* seg_count;             /* n_seg or NULL: rows of every segment after the de-duplication (the csv_segment ranges of the
+                                       sorted columns follow from these by a prefix sum) */
+    int64_t  n_ins_ties;            /* out: rows of seg_nodedup segments that agree with their predecessor in (segment, a, b, read_id):
+                                       0 means the device order is final, otherwise the caller finishes those groups on the host */
+    void*    dev_seg_id;            /* out (CSV_RB_KEEP_ON_DEVICE): device addresses of the sorted columns, n_out rows each: */
+    void*    dev_a;                 /*   int32 seg_id, int64 a, int64 b, int32 read_id, int32 aux, int32 src_row */
+    void*    dev_b;
+    void*    dev_read_id;
+    void*    dev_aux;
+    void*    dev_src_row;
 } csv_rebuild_out;
 
 int csv_rebuild_signatures(csv_ctx* ctx, const csv_rebuild_in* in, csv_rebuild_out* out);

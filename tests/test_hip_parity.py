@@ -590,6 +590,51 @@ def test_gpu_rebuild_reproduces_the_reference_order_contract(ctx):
             assert np.array_equal(x[k], y[k]), k
 
 
+def test_rebuild_hands_its_columns_to_the_cluster_stage_on_the_device(ctx):
+    """main script :750-857 -> :1113-1199 without a host round trip: the rebuild's sorted columns stay in device memory
+    (CSV_RB_KEEP_ON_DEVICE) and csv_cluster_batch reads them there (CSV_IN_DEVICE_COLUMNS); only src_row and the rows per
+    segment come back.  Same calls as rebuilding to the host and uploading again - and as clustering the original store."""
+    from cutesv_amd import rebuild
+    rng = np.random.default_rng(7)
+    for seed, kw, p in ((41, dict(), Params.ont()),
+                        (42, dict(n_sites=120, coverage=40, n_noise=20000, n_loci=2000, dup_frac=0.0), Params.ont(genotype=True))):
+        st = synth.small_mixed(seed=seed, **kw)
+        per = {}
+        for (t, ch), (b, e) in st.seg_index.items():
+            d = per.setdefault(t, dict(chrom=[], a=[], b=[], read_id=[], aux=[]))
+            d["chrom"].append(np.full(e - b, st.chroms.index(ch))); d["a"].append(st.a[b:e]); d["b"].append(st.b[b:e])
+            d["read_id"].append(st.read_id[b:e])
+            d["aux"].append(st.aux[b:e] if t in ("INS", "INV", "TRA") else np.zeros(e - b, np.int32))
+        for t, d in per.items():
+            cols = {k: np.concatenate(v) for k, v in d.items()}
+            n = len(cols["a"])
+            if t == "INS":                                               # (INS duplicates would be tie groups: the host's business)
+                perm = rng.permutation(n)
+                per[t] = {k: v[perm] for k, v in cols.items()}
+            else:
+                dup = rng.integers(0, n, max(1, n // 20))
+                perm = rng.permutation(n + len(dup))
+                per[t] = {k: np.concatenate([v, v[dup]])[perm] for k, v in cols.items()}
+        reads = None
+        if st.reads_off is not None and p.genotype:
+            ch_of = np.repeat(np.arange(len(st.chroms)), np.diff(st.reads_off))
+            reads = dict(chrom=ch_of, start=st.r_start, end=st.r_end, primary=st.r_primary, read_id=st.r_id)
+
+        def seg_of(t, ci, beg, end):
+            rec = st.segment(t, st.chroms[ci], p).copy()
+            rec["sig_begin"], rec["sig_end"] = beg, end
+            return rec
+        batch, tasks, src_row = rebuild.rebuild_to_device_batch(ctx, st.chroms, per, seg_of, reads=reads)
+        got = ctx.cluster_batch(batch).trimmed()
+        assert batch.n_sig == st.n_sig and len(src_row) == st.n_sig
+        want = ctx.cluster_batch(st.host_batch(tasks, p)).trimmed()
+        # (the segments of `tasks` are in the reference's order in both batches; signature indices are positions in the sorted
+        # columns, which are the store's columns segment by segment)
+        for k in ("call_seg", "bp1", "bp2", "support", "cipos", "cilen", "search_pos", "dr", "dv", "gl_idx", "support_off"):
+            assert np.array_equal(got[k], want[k]), k
+        assert got["n_clusters"] == want["n_clusters"] and len(got["bp1"]) > 20
+
+
 def test_gpu_rebuild_identical_to_reference_rebuild(ctx):
     """csv_rebuild_signatures (+ the host finish of INS tie groups) on the raw, concatenated per-worker candidates ==
     the per-chromosome lists the reference's process_process_sigs_type wrote (rebuild_order.json.gz)"""
