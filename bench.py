@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — signatures clustered per second on MI355X (BASELINE.json's metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg2|cfg4|cfg5] [--scale S] [--mode replica|shard]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg2|cfg4|cfg5|rebuild|extract] [--scale S] [--mode replica|shard]
 
 A "step" is one pass of the whole hot path (chain -> refine -> order [-> reads order -> genotype]) over one synthetic
 signature batch that is already resident in HBM when the timed region starts.  At N = 1 the workload is BASELINE
@@ -122,6 +122,101 @@ def kernel_units(store, hb, res, stats, per_sig_step):
                           reads=R, genotyped_calls=gt_calls, clusters=int(t["n_clusters"]), gated_clusters=int(valid.sum()))
 
 
+def bench_rebuild(a):
+    """--workload rebuild: SURVEY.md 8f row 2 (main script :750-857): the cfg3 genome's rows in random order + 5 % duplicates
+    -> the order contract, on the device.  Roofline: one radix pass reads a key byte column entry and moves a 4-byte
+    permutation entry twice (histogram + scatter: ~24 B per row and pass incl. the gathers), the final gather 56 B per row."""
+    from cutesv_amd import rebuild
+    store, params, _ = make_workload("cfg3", a.scale, 0)
+    per = synth.unsorted_rows(store, seed=1, dup_frac=0.05)
+    n_in = sum(len(d["a"]) for d in per.values())
+    ctx = engine.Context(0)
+    dev_ms, wall_host, wall_dev, info = [], [], [], None
+    for _ in range(a.warmup + min(a.steps, 10)):
+        t0 = time.perf_counter()
+        got, info = rebuild.store_from_unsorted(ctx, store.chroms, per)
+        hb = got.host_batch(got.tasks(), params)
+        r1 = ctx.cluster_batch(hb)
+        wall_host.append(time.perf_counter() - t0)
+        dev_ms.append(info["ms_device"])
+
+        def seg_of(t, ci, beg, end):
+            rec = store.segment(t, store.chroms[ci], params).copy()
+            rec["sig_begin"], rec["sig_end"] = beg, end
+            return rec
+        t0 = time.perf_counter()
+        batch, tasks, src_row = rebuild.rebuild_to_device_batch(ctx, store.chroms, per, seg_of)
+        r2 = ctx.cluster_batch(batch)
+        wall_dev.append(time.perf_counter() - t0)
+    same = all(np.array_equal(r1.trimmed()[k], r2.trimmed()[k]) for k in ("bp1", "bp2", "support", "cipos", "cilen", "call_seg"))
+    ms = float(np.median(dev_ms[a.warmup:]))
+    t0 = time.perf_counter()
+    for t, d in per.items():
+        np.lexsort((d["read_id"], d["b"], d["a"], d["chrom"]))
+    t_np = time.perf_counter() - t0
+    # the reference's own sort is Python's list.sort with a tuple key (main script :764-802): timed on a bounded sample
+    smp = 200_000
+    d = per["DEL"]
+    tl = list(zip(d["chrom"][:smp].tolist(), d["a"][:smp].tolist(), d["b"][:smp].tolist(), d["read_id"][:smp].tolist()))
+    t0 = time.perf_counter()
+    tl.sort(key=lambda x: (x[0], x[1], x[2], x[3]))
+    t_py = time.perf_counter() - t0
+    bytes_alg = n_in * (24 * info["n_passes"] + 56)
+    out = {"metric": "signature rows rebuilt/sec (sort + de-duplication, main script :750-857)", "value": n_in / (ms * 1e-3), "unit": "rows/s", "n_gpus": 1,
+           "steps": min(a.steps, 10), "warmup": a.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "int64 keys", "data": "synthetic",
+           "config": {"workload": "rebuild: cfg3 rows in random order + 5 % exact duplicates (%d rows in, %d out, %d radix passes)" % (n_in, got.n_sig, info["n_passes"])},
+           "roofline": {"bound": "hbm", "kernel": "k_sort_* + k_rebuild_*", "achieved": bytes_alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": bytes_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": bytes_alg},
+           "cpu_baseline": {"value": smp / t_py, "unit": "rows/s", "cores": 1, "kind": "port",
+                            "sample": "Python list.sort with the reference's tuple key on %d DEL rows (%.2f s): the reference's rebuild is this per type" % (smp, t_py)},
+           "cpu_baseline_numpy": {"value": n_in / t_np, "unit": "rows/s", "cores": 1, "sample": "numpy lexsort of all rows, %.3f s" % t_np},
+           "chain": {"rebuild_to_host_then_cluster_ms": float(np.median(wall_host[a.warmup:])) * 1e3,
+                     "rebuild_on_device_then_cluster_ms": float(np.median(wall_dev[a.warmup:])) * 1e3,
+                     "same_calls": bool(same),
+                     "note": "wall clock of rebuild + csv_cluster_batch from unsorted host rows; second form: CSV_RB_KEEP_ON_DEVICE + CSV_IN_DEVICE_COLUMNS"}}
+    print(json.dumps(out))
+    ctx.close()
+
+
+def bench_extract(a):
+    """--workload extract: SURVEY.md 8f row 4 (main script :606-681, :50-513): the CIGAR scan of 10^5 long reads and the
+    split-read analysis of 10^5 reads with SA entries.  Roofline of the CIGAR scan: 4 B per CIGAR operation, read twice
+    (count + emit)."""
+    from cutesv_amd import extract
+    from oracle import oracle
+    n = int(100_000 * a.scale)
+    off, cigar, start, use = synth.cigar_reads(n)
+    enc = synth.split_reads(n)
+    ctx = engine.Context(0)
+    cg, sp = [], []
+    for _ in range(a.warmup + min(a.steps, 10)):
+        cg.append(extract.cigar_signatures(ctx, off, cigar, start, use)["ms_device"])
+        sp.append(extract.split_signatures(ctx, enc)["ms_device"])
+    ms_c, ms_s = float(np.median(cg[a.warmup:])), float(np.median(sp[a.warmup:]))
+    got = extract.cigar_signatures(ctx, off, cigar, start, use)
+    t0 = time.perf_counter(); want = oracle.cigar_signatures(off, cigar, start, use); t_c = time.perf_counter() - t0
+    t0 = time.perf_counter(); want_s = oracle.split_signatures(enc); t_s = time.perf_counter() - t0
+    got_s = extract.split_signatures(ctx, enc)
+    parity = all(np.array_equal(got[k], want[k]) for k in ("ins_read", "ins_pos", "ins_len", "del_read", "del_pos", "del_len")) and \
+        all(np.array_equal(got_s[k], want_s[k]) for k in ("kind", "read", "a", "b"))
+    nops = int(off[-1])
+    out = {"metric": "reads scanned/sec (CIGAR scan of parse_read, main script :606-655)", "value": n / (ms_c * 1e-3), "unit": "reads/s", "n_gpus": 1,
+           "steps": min(a.steps, 10), "warmup": a.warmup, "ms_per_step": ms_c, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "u32 CIGAR words", "data": "synthetic",
+           "config": {"workload": "extract: %d long reads, %d CIGAR operations (synth.cigar_reads); %d reads with %d alignments for the split-read analysis" %
+                                  (n, nops, n, int(enc["ent_off"][-1]))},
+           "roofline": {"bound": "hbm", "kernel": "k_cigar_count + k_cigar_emit", "achieved": 8.0 * nops / (ms_c * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": 8.0 * nops / (ms_c * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": 8 * nops},
+           "cpu_baseline": {"value": n / t_c, "unit": "reads/s", "cores": 1, "kind": "port", "sample": "oracle/cutesv_oracle.c csvo_cigar_signatures, all %d reads, %.3f s" % (n, t_c)},
+           "split_reads": {"ms_device": ms_s, "reads_per_s": n / (ms_s * 1e-3), "alignments": int(enc["ent_off"][-1]), "candidates": int(len(got_s["kind"])),
+                           "us_per_read_vs_cigar_scan": ms_s / ms_c,
+                           "cpu_c_oracle_reads_per_s": n / t_s},
+           "signatures": {"ins": int(len(got["ins_pos"])), "del": int(len(got["del_pos"]))}, "parity_vs_oracle": bool(parity)}
+    print(json.dumps(out))
+    ctx.close()
+
+
 def spawn_ranks(a):
     """`python bench.py --gpus N` without a launcher: start the N ranks and relay rank 0's line"""
     port = 29500 + (os.getpid() % 2000)
@@ -155,6 +250,10 @@ def main():
     ap.add_argument("--cpu-procs", type=int, default=0)
     a = ap.parse_args()
 
+    if a.workload == "rebuild":
+        return bench_rebuild(a)
+    if a.workload == "extract":
+        return bench_extract(a)
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         spawn_ranks(a)
     rank = int(os.environ.get("RANK", "0"))
@@ -355,10 +454,17 @@ def main():
             keep = [i for i, (t, c) in enumerate(tasks) if t in ("DEL", "INS")]
             hb2 = pstore.host_batch([tasks[i] for i in keep], params)
             r3 = ctx.cluster_batch(hb2)
-            t0 = time.perf_counter()
-            text, _ = vcf_mod.emit_records(pstore, hb2.segments, r3, None, min_size=params.min_size, max_size=params.max_size,
-                                           genotype=params.genotype, ignore_sequence=True)
-            t_vcf = dict(ms=(time.perf_counter() - t0) * 1e3, records=text.count("\n"), bytes=len(text))
+            tv = []
+            for _ in range(5):
+                t0 = time.perf_counter()
+                text, _ = vcf_mod.emit_records(pstore, hb2.segments, r3, None, min_size=params.min_size, max_size=params.max_size,
+                                               genotype=params.genotype, ignore_sequence=True, as_bytes=True)
+                tv.append(time.perf_counter() - t0)
+            # pinned columns -> VCF text: the boundary call + the native emitter, no Python rows in between
+            ts = timed(lambda: vcf_mod.emit_records(pstore, hb2.segments, ctx.cluster_batch(hb2, reuse=True), None, min_size=params.min_size,
+                                                     max_size=params.max_size, genotype=params.genotype, ignore_sequence=True, as_bytes=True), 5)
+            t_vcf = dict(ms=float(np.median(tv)) * 1e3, records=text.count(b"\n"), bytes=len(text), threads=min(32, os.cpu_count() or 1),
+                         stage_wall_vcf_ms=float(np.median(ts)) * 1e3)
         except Exception as e:          # never let the optional leg break the benchmark line
             t_vcf = dict(error=str(e))
 

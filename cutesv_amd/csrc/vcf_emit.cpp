@@ -8,29 +8,30 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/cutesv_hip.h"
 
 namespace {
 
+// text of one slice of records: a growable buffer owned by the worker thread that formats the slice
 struct Sink {
-    char*   out;
-    int64_t cap, n;
-    void put(const char* s, size_t len)
+    std::string buf;
+    void put(const char* s, size_t len) { buf.append(s, len); }
+    void put(const char* s) { buf.append(s); }
+    void put(const std::string& s) { buf.append(s); }
+    void put(char c) { buf.push_back(c); }
+    void num(long long v)                                  // decimal text (snprintf was a third of the emitter's time)
     {
-        if (n + (int64_t)len <= cap) memcpy(out + n, s, len);
-        n += (int64_t)len;
-    }
-    void put(const char* s) { put(s, strlen(s)); }
-    void put(const std::string& s) { put(s.data(), s.size()); }
-    void put(char c) { put(&c, 1); }
-    void num(long long v)
-    {
-        char b[32];
-        const int k = snprintf(b, sizeof b, "%lld", v);
-        put(b, (size_t)k);
+        char b[24];
+        int k = 24;
+        unsigned long long u = v < 0 ? 0ull - (unsigned long long)v : (unsigned long long)v;
+        do { b[--k] = (char)('0' + u % 10); u /= 10; } while (u);
+        if (v < 0) b[--k] = '-';
+        buf.append(b + k, (size_t)(24 - k));
     }
 };
 
@@ -70,38 +71,124 @@ bool split_gl(const char* s, GlRow& r)
 
 }  // namespace
 
+// Records are formatted by worker threads, one slice of a chromosome's sorted calls at a time; the SVID counters a slice
+// starts with are the numbers of records of each type EMITTED before it (generate_output's size filters decide that), found
+// by a first pass over the slices.  Order of the text: chromosomes by name rank, records by position, as the reference writes.
+namespace {
+constexpr int64_t VCF_SLICE = 1024;                    // calls per work item
+enum { ID_INS = 0, ID_DEL = 1, ID_BND = 2, ID_DUP = 3, ID_INV = 4 };
+
+// size filters of generate_output (cuteSV_genotype.py:265-268, 315-316, 351-352): is the call written, and under which counter
+inline int emitted_id(const csv_vcf_in* in, const csv_batch_out& R, int64_t c)
+{
+    const int type = in->seg[R.call_seg[c]].svtype;
+    if (type == CSV_DEL || type == CSV_INS) {
+        const long long len = R.bp2[c];
+        if ((len > in->max_size && in->max_size != -1) || len < in->min_size) return -1;
+        return type == CSV_INS ? ID_INS : ID_DEL;
+    }
+    if (type == CSV_DUP || type == CSV_INV) {
+        const long long len = R.bp2[c] - R.bp1[c];
+        if (llabs(len) > in->max_size && in->max_size != -1) return -1;
+        return type == CSV_DUP ? ID_DUP : ID_INV;
+    }
+    return ID_BND;
+}
+
+int emit_slice(const csv_vcf_in* in, const int64_t* v, int64_t nv, int ch, int64_t* svid, Sink& o);
+
+template <class F> void parallel_for(int64_t n, int nthreads, F&& f)
+{
+    if (n <= 0) return;
+    if (nthreads > n) nthreads = (int)n;
+    if (nthreads <= 1) { for (int64_t i = 0; i < n; i++) f(i); return; }
+    std::atomic<int64_t> next{0};
+    std::vector<std::thread> th;
+    auto work = [&]() { for (int64_t i; (i = next.fetch_add(1)) < n;) f(i); };
+    for (int t = 1; t < nthreads; t++) th.emplace_back(work);
+    work();
+    for (auto& t : th) t.join();
+}
+}  // namespace
+
 extern "C" int csv_vcf_emit(const csv_vcf_in* in, char* out, int64_t cap, int64_t* n_written, int64_t* svid)
 {
     if (!in || !in->res || !n_written || !svid) return CSV_E_INVALID;
     const csv_batch_out& R = *in->res;
     const int64_t nc = R.n_calls;
-    Sink o{out, out ? cap : 0, 0};
-    enum { ID_INS = 0, ID_DEL = 1, ID_BND = 2, ID_DUP = 3, ID_INV = 4 };
+    int nthreads = (int)std::thread::hardware_concurrency();
+    if (const char* e = getenv("CSV_VCF_THREADS")) nthreads = atoi(e);
+    if (nthreads > 32) nthreads = 32;
+    if (nthreads < 1 || nc < 2 * VCF_SLICE) nthreads = 1;
 
-    // calls per chromosome in the order main_ctrl concatenates task results (the call order of the batch),
-    // then generate_output's stable sort by int(row[2])  (cuteSV_genotype.py:252)
-    std::vector<std::vector<int64_t>> per(in->n_chrom);
+    // calls per chromosome in the order main_ctrl concatenates task results (the call order of the batch): counting sort
+    std::vector<int64_t> coff((size_t)in->n_chrom + 1, 0), idx((size_t)nc);
     for (int64_t c = 0; c < nc; c++) {
         const int k = R.call_seg[c];
         if (k < 0 || k >= in->n_seg) return CSV_E_INVALID;
         const int ch = in->seg[k].chrom;
         if (ch < 0 || ch >= in->n_chrom) return CSV_E_INVALID;
-        per[ch].push_back(c);
+        coff[(size_t)ch + 1]++;
+    }
+    for (int i = 0; i < in->n_chrom; i++) coff[(size_t)i + 1] += coff[(size_t)i];
+    {
+        std::vector<int64_t> fill(coff.begin(), coff.end() - 1);
+        for (int64_t c = 0; c < nc; c++) idx[(size_t)fill[(size_t)in->seg[R.call_seg[c]].chrom]++] = c;
     }
     std::vector<int> order(in->n_chrom);
     for (int i = 0; i < in->n_chrom; i++) order[i] = i;
     std::sort(order.begin(), order.end(), [&](int x, int y) { return in->chrom_rank[x] < in->chrom_rank[y]; });
+    // generate_output's stable sort by int(row[2]) per chromosome (cuteSV_genotype.py:252)
+    parallel_for(in->n_chrom, nthreads, [&](int64_t ch) {
+        std::stable_sort(idx.begin() + coff[(size_t)ch], idx.begin() + coff[(size_t)ch + 1], [&](int64_t x, int64_t y) { return R.bp1[x] < R.bp1[y]; });
+    });
+    // slices in emission order
+    struct Slice { int ch; int64_t lo, hi; int64_t cnt[5]; int64_t start[5]; int rc; Sink text; };
+    std::vector<Slice> sl;
+    for (int ch : order)
+        for (int64_t lo = coff[(size_t)ch]; lo < coff[(size_t)ch + 1]; lo += VCF_SLICE) {
+            Slice x{};
+            x.ch = ch; x.lo = lo; x.hi = lo + VCF_SLICE < coff[(size_t)ch + 1] ? lo + VCF_SLICE : coff[(size_t)ch + 1];
+            sl.push_back(std::move(x));
+        }
+    // records per type every slice emits -> the counters it starts with (main script :1208-1237: one counter per type over the
+    // whole file)
+    parallel_for((int64_t)sl.size(), nthreads, [&](int64_t i) {
+        Slice& x = sl[(size_t)i];
+        for (int64_t q = x.lo; q < x.hi; q++) { const int id = emitted_id(in, R, idx[(size_t)q]); if (id >= 0) x.cnt[id]++; }
+    });
+    int64_t run[5] = {svid[0], svid[1], svid[2], svid[3], svid[4]};
+    for (Slice& x : sl) for (int t = 0; t < 5; t++) { x.start[t] = run[t]; run[t] += x.cnt[t]; }
+    parallel_for((int64_t)sl.size(), nthreads, [&](int64_t i) {
+        Slice& x = sl[(size_t)i];
+        x.text.buf.reserve((size_t)(x.hi - x.lo) * 192);
+        int64_t sv[5] = {x.start[0], x.start[1], x.start[2], x.start[3], x.start[4]};
+        x.rc = emit_slice(in, idx.data() + x.lo, x.hi - x.lo, x.ch, sv, x.text);
+    });
+    int64_t total = 0;
+    for (Slice& x : sl) { if (x.rc != CSV_OK) return x.rc; total += (int64_t)x.text.buf.size(); }
+    *n_written = total;
+    if (!out || total > cap) return CSV_E_CAPACITY;
+    std::vector<int64_t> toff(sl.size() + 1, 0);
+    for (size_t i = 0; i < sl.size(); i++) toff[i + 1] = toff[i] + (int64_t)sl[i].text.buf.size();
+    parallel_for((int64_t)sl.size(), nthreads, [&](int64_t i) { memcpy(out + toff[(size_t)i], sl[(size_t)i].text.buf.data(), sl[(size_t)i].text.buf.size()); });
+    for (int t = 0; t < 5; t++) svid[t] = run[t];
+    return CSV_OK;
+}
 
+namespace {
+// the records of the calls v[0 .. nv) of chromosome ch, in that order; svid: the counters to start with
+int emit_slice(const csv_vcf_in* in, const int64_t* v, int64_t nv, int ch, int64_t* svid, Sink& o)
+{
+    const csv_batch_out& R = *in->res;
     static const char* kFormat = "GT:DR:DV:PL:GQ";
-    for (int ch : order) {
-        std::vector<int64_t>& v = per[ch];
-        if (v.empty()) continue;
-        std::stable_sort(v.begin(), v.end(), [&](int64_t x, int64_t y) { return R.bp1[x] < R.bp1[y]; });
+    {
         const char* seq = in->chrom_seq ? in->chrom_seq[ch] : nullptr;
         const int64_t slen = in->chrom_len ? in->chrom_len[ch] : 0;
         const char* cname = in->chrom_name[ch];
         auto base = [&](int64_t i, char& c) -> bool { if (!seq || i < 0 || i >= slen) return false; c = seq[i]; return true; };
-        for (int64_t c : v) {
+        for (int64_t qi = 0; qi < nv; qi++) {
+            const int64_t c = v[qi];
             const csv_segment& sg = in->seg[R.call_seg[c]];
             const int type = sg.svtype;
             // TRA calls whose count_coverage gave up carry the '.' fields too (cuteSV_resolveTRA.py:276-281)
@@ -231,6 +318,6 @@ extern "C" int csv_vcf_emit(const csv_vcf_in* in, char* out, int64_t cap, int64_
             }
         }
     }
-    *n_written = o.n;
-    return (out && o.n <= cap) ? CSV_OK : CSV_E_CAPACITY;
+    return CSV_OK;
 }
+}  // namespace

@@ -424,3 +424,73 @@ def pseudo_sequence(length, key):
     j = np.arange(length, dtype=np.uint64)
     h = (j * np.uint64(2654435761) + np.uint64(key) * np.uint64(40503) + (j >> np.uint64(3)) * np.uint64(97)) >> np.uint64(7)
     return np.array(list("ACGT"))[(h & np.uint64(3)).astype(np.int64)].astype("U1").tobytes().decode("utf-32-le") if length else ""
+
+
+# ------------------------------------------------------------------------------------ inputs of the neighbouring steps (bench.py)
+def unsorted_rows(store, seed=1, dup_frac=0.05):
+    """The signatures of `store` as the extraction step leaves them for the rebuild step (main script :750-857): per type,
+    rows in random order with `dup_frac` exact duplicates (overlapping extraction windows make them; INS rows are not
+    duplicated: their tie groups are the host's business).  -> per_type dict for rebuild.store_from_unsorted"""
+    rng = np.random.default_rng(seed)
+    per = {}
+    for (t, ch), (b, e) in store.seg_index.items():
+        d = per.setdefault(t, dict(chrom=[], a=[], b=[], read_id=[], aux=[]))
+        d["chrom"].append(np.full(e - b, store.chroms.index(ch))); d["a"].append(store.a[b:e]); d["b"].append(store.b[b:e])
+        d["read_id"].append(store.read_id[b:e])
+        d["aux"].append(store.aux[b:e] if t in ("INS", "INV", "TRA") else np.zeros(e - b, np.int32))
+    for t, d in per.items():
+        cols = {k: np.concatenate(v) for k, v in d.items()}
+        n = len(cols["a"])
+        if t == "INS" or dup_frac <= 0:
+            perm = rng.permutation(n)
+            per[t] = {k: v[perm] for k, v in cols.items()}
+        else:
+            dup = rng.integers(0, n, max(1, int(n * dup_frac)))
+            perm = rng.permutation(n + len(dup))
+            per[t] = {k: np.concatenate([v, v[dup]])[perm] for k, v in cols.items()}
+    return per
+
+
+def cigar_reads(n, seed=77, mean_ops=180):
+    """BAM-encoded CIGARs of n long reads with ONT-like statistics: ~mean_ops operations per read (a 15-20 kb read at ~90 %
+    identity has a few hundred), mostly matches and 1-9 base indels, a few per cent of indels of 30 bases or more, clips at
+    the ends.  -> (cig_off, cigar, ref_start, use)"""
+    rng = np.random.default_rng(seed)
+    nops = np.minimum(rng.geometric(1.0 / mean_ops, n), 5000).astype(np.int64) + 2
+    off = np.zeros(n + 1, np.int64); np.cumsum(nops, out=off[1:])
+    tot = int(off[-1])
+    op = rng.choice(np.array([0, 1, 2, 7, 8], np.uint32), tot, p=[0.50, 0.17, 0.17, 0.10, 0.06])
+    ln = np.where(op == 0, rng.integers(5, 200, tot), np.where(rng.random(tot) < 0.03, rng.integers(30, 400, tot), rng.integers(1, 10, tot))).astype(np.uint32)
+    first, last = off[:-1], off[1:] - 1
+    op[first] = 4; ln[first] = rng.integers(0, 500, n); op[last] = 4; ln[last] = rng.integers(0, 500, n)      # soft clips
+    cigar = ((ln << 4) | op).astype(np.uint32)
+    start = rng.integers(0, 200_000_000, n).astype(np.int64)
+    use = (rng.random(n) < 0.95).astype(np.uint8)
+    return off, cigar, start, use
+
+
+def split_reads(n, seed=78, n_chrom=6):
+    """flat csv_split_in arrays of n reads with 0 .. 12 alignments each (a primary and SA entries that tile the read loosely,
+    mostly on one chromosome and strand): every rule of analysis_split_read fires somewhere"""
+    rng = np.random.default_rng(seed)
+    n_ent = rng.choice(np.array([0, 1, 2, 2, 2, 3, 3, 3, 4, 4, 5, 6, 8, 12]), n)
+    ent_off = np.zeros(n + 1, np.int64); np.cumsum(n_ent, out=ent_off[1:])
+    ne = int(ent_off[-1])
+    read = np.repeat(np.arange(n), n_ent)
+    first = np.zeros(ne, bool); first[ent_off[:-1][n_ent > 0]] = True
+    L = rng.integers(500, 30000, n).astype(np.int64)
+    primary = (first & (rng.random(ne) < 0.8)).astype(np.uint8)
+    base_st = np.repeat((rng.random(n) < 0.5).astype(np.uint8), n_ent)
+    strand = np.where(rng.random(ne) < 0.7, base_st, (rng.random(ne) < 0.35).astype(np.uint8)).astype(np.uint8)
+    base_ch = np.repeat(rng.integers(0, n_chrom, n), n_ent)
+    chrom = np.where(rng.random(ne) < 0.8, base_ch, rng.integers(0, n_chrom, ne)).astype(np.int32)
+    Lr = L[read]
+    lo = (rng.random(ne) * Lr).astype(np.int64); hi = np.minimum(Lr, lo + 1 + (rng.random(ne) * Lr * 0.5).astype(np.int64))
+    base_ref = np.repeat(rng.integers(100_000, 3_000_000, n), n_ent)
+    ref = np.maximum(0, base_ref + np.where(rng.random(ne) < 0.7, lo + rng.integers(-3000, 3000, ne), rng.integers(-2_000_000, 2_000_000, ne))).astype(np.int64)
+    span = np.maximum(1, hi - lo + rng.integers(-50, 50, ne)).astype(np.int64)
+    c0 = np.where(primary == 1, lo, np.where(strand == 0, lo, Lr - hi)); c1 = np.where(primary == 1, hi, np.where(strand == 0, Lr - hi, lo))
+    f1 = np.where(primary == 1, ref + span, span)
+    mapq = rng.choice(np.array([0, 3, 20, 30, 60], np.int32), ne)
+    return dict(ent_off=ent_off, read_len=L, c0=c0.astype(np.int64), c1=c1.astype(np.int64), f0=ref, f1=f1.astype(np.int64), chr=chrom, mapq=mapq,
+                strand=strand, primary=primary)

@@ -36,15 +36,20 @@ def _csr(strings):
     return blob, off
 
 
+_OUT_BUF = None
+
+
 def emit_records(store, segments, res, reference, min_size=30, max_size=100000, genotype=False, report_readid=False,
-                 ignore_sequence=False, svid=None):
+                 ignore_sequence=False, svid=None, as_bytes=False):
     """calls of one batch -> (VCF body text, svid counters).
 
     segments   the csv_segment records the batch was run with (HostBatch.segments)
     res        _abi.HostResult of that batch
     reference  {chromosome name: sequence (str or bytes)}; may miss chromosomes without calls
     svid       running counters [INS, DEL, BND, DUP, INV] (main script :1209-1213), advanced in place
+    as_bytes   return the text as `bytes` (what a file is written from) instead of decoding it to `str`
     """
+    global _OUT_BUF
     L = lib()
     L.csv_vcf_emit.restype = C.c_int
     L.csv_vcf_emit.argtypes = [C.POINTER(VcfIn), C.c_char_p, C.c_int64, C.POINTER(C.c_int64), C.c_void_p]
@@ -86,15 +91,17 @@ def emit_records(store, segments, res, reference, min_size=30, max_size=100000, 
                 ignore_sequence=int(bool(ignore_sequence)))
     cap = 256 * max(n, 1) + (len(alt_blob) if alt_blob else 0) + (len(rn_blob) if rn_blob else 0) + 4096
     for _ in range(2):
-        buf = C.create_string_buffer(cap)
+        if _OUT_BUF is None or len(_OUT_BUF) < cap:       # (recycled: a fresh zero-filled buffer per call costs as much as the emitter)
+            _OUT_BUF = np.empty(cap, np.uint8)
         need = C.c_int64(0)
         sv = svid.copy()
-        rc = L.csv_vcf_emit(C.byref(vin), buf, cap, C.byref(need), sv.ctypes.data)
+        rc = L.csv_vcf_emit(C.byref(vin), C.cast(_OUT_BUF.ctypes.data, C.c_char_p), len(_OUT_BUF), C.byref(need), sv.ctypes.data)
         if rc == _abi.E_CAPACITY:
             cap = need.value + 16
             continue
         if rc != _abi.OK:
             raise RuntimeError("csv_vcf_emit: %s (a reference sequence is missing or too short?)" % _abi.ERR_NAME.get(rc, rc))
         svid[:] = sv
-        return buf.raw[:need.value].decode(), svid
+        raw = _OUT_BUF[:need.value].tobytes()
+        return (raw if as_bytes else raw.decode()), svid
     raise RuntimeError("csv_vcf_emit: capacity retry failed")
