@@ -165,7 +165,7 @@ def bench_rebuild(a):
     out = {"metric": "signature rows rebuilt/sec (sort + de-duplication, main script :750-857)", "value": n_in / (ms * 1e-3), "unit": "rows/s", "n_gpus": 1,
            "steps": min(a.steps, 10), "warmup": a.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "int64 keys", "data": "synthetic",
-           "config": {"workload": "rebuild: cfg3 rows in random order + 5 % exact duplicates (%d rows in, %d out, %d radix passes)" % (n_in, got.n_sig, info["n_passes"])},
+           "config": {"workload": "rebuild: cfg3 rows in random order + 5 %% exact duplicates (%d rows in, %d out, %d radix passes)" % (n_in, got.n_sig, info["n_passes"])},
            "roofline": {"bound": "hbm", "kernel": "k_sort_* + k_rebuild_*", "achieved": bytes_alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": bytes_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": bytes_alg},
            "cpu_baseline": {"value": smp / t_py, "unit": "rows/s", "cores": 1, "kind": "port",
@@ -245,7 +245,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="cfg3")
     ap.add_argument("--scale", type=float, default=1.0)
-    ap.add_argument("--mode", default="replica", choices=["replica", "shard"])
+    ap.add_argument("--mode", default="auto", choices=["auto", "replica", "shard"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-procs", type=int, default=0)
     a = ap.parse_args()
@@ -260,12 +260,51 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
-    shard_mode = a.mode == "shard"
-
-    store, params, wl_name = make_workload(a.workload, a.scale, 0 if shard_mode else rank)
+    # BASELINE.json: configs 4 and 5 are ONE genome "sharded over 8 MI355X"; config 3 names one GPU (more GPUs = more genomes)
+    shard_mode = a.mode == "shard" or (a.mode == "auto" and world > 1 and a.workload in ("cfg4", "cfg5"))
+    if world > 1:
+        # one rank per GPU: keep the rank's host threads (page-locked copies, the row builder, the VCF emitter) on its own
+        # share of the cores - on an 8-GPU node that is also the socket its GPU hangs off
+        try:
+            cores = sorted(os.sched_getaffinity(0))
+            per = max(1, len(cores) // world)
+            os.sched_setaffinity(0, cores[(local_rank % world) * per:(local_rank % world + 1) * per] or cores)
+        except (AttributeError, OSError):
+            pass
+    ctx = None
+    if world > 1:
+        # (the library and the HIP runtime it links are loaded before torch is imported)
+        ndev = max(1, engine.device_count())
+        ctx = engine.Context(local_rank % ndev)    # (more ranks than devices: they share; used to rehearse N > 1 on one GPU)
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)     # timing barrier only: no data-path collective
+    if shard_mode and world > 1:
+        # one genome for all ranks: rank 0 generates it, the others map the flat column files
+        from cutesv_amd.columns import SigStore
+        shared = "/dev/shm/cutesv_amd_bench_%s_%s" % (os.environ.get("MASTER_PORT", "0"), a.workload)
+        if rank == 0:
+            store, params, wl_name = make_workload(a.workload, a.scale, 0)
+            store.save(shared)
+        dist.barrier()
+        if rank != 0:
+            _, params, wl_name = make_workload(a.workload, 0.001, 0)
+            store = SigStore.load(shared)
+        dist.barrier()
+        if rank == 0:
+            import shutil
+            shutil.rmtree(shared, ignore_errors=True)          # (the mappings stay valid)
+    else:
+        store, params, wl_name = make_workload(a.workload, a.scale, 0 if shard_mode else rank)
     all_tasks = store.tasks()
-    tasks = shard.tasks_of_rank(store, rank, world, genotype=params.genotype) if shard_mode else all_tasks
-    hb = store.host_batch(tasks, params)
+    tasks = all_tasks
+    units = shard.plan(store, world, params, genotype=params.genotype)[rank] if shard_mode else None
+    if shard_mode:
+        hb, unit_keys = shard.host_batch(store, params, units)
+    else:
+        hb = store.host_batch(tasks, params)
     n_sig = int((hb.segments["sig_end"] - hb.segments["sig_begin"]).sum())
 
     # ---------------- CPU baseline first (fork pool before any HIP state exists in this process)
@@ -307,20 +346,17 @@ def main():
             with open(cal) as f:
                 cpu["calibration_vs_reference"] = json.load(f)
 
-    # ---------------- GPU (the library and the HIP runtime it links are loaded before torch is imported)
-    ndev = max(1, engine.device_count())
-    ctx = engine.Context(local_rank % ndev)        # (more ranks than devices: they share; used to rehearse N > 1 on one GPU)
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)     # timing barrier only: no data-path collective
+    # ---------------- GPU
+    if ctx is None:
+        ctx = engine.Context(local_rank % max(1, engine.device_count()))
     # the columns as a worker process holds them: in page-locked host memory
     t0 = time.perf_counter()
     pstore = store.pinned()
     t_pin = time.perf_counter() - t0
-    phb = pstore.host_batch(tasks, params)
+    if shard_mode:
+        phb, unit_keys = shard.host_batch(pstore, params, units, pin=engine.pinned_copy)
+    else:
+        phb = pstore.host_batch(tasks, params)
 
     def timed(fn, reps):
         """wall time of fn() to the moment its result exists (the result is released after the clock stops: tearing down
@@ -390,18 +426,21 @@ def main():
 
     shard_check = None
     if shard_mode:
-        # merge the ranks' rows exactly as main_ctrl concatenates task results and compare with the unsharded run
-        mine = resolve.cluster_stage(pstore, params, tasks=tasks, ctx=ctx)
-        dg = digest_rows(mine)
-        gathered = [dg]
+        # merge the ranks' rows exactly as main_ctrl concatenates task results (pieces of a chromosome in coordinate order)
+        # and compare with the unsharded run
+        per_seg = rows_mod.rows_by_segment(pstore, phb.segments, ctx.cluster_batch(phb))
+        mine = {k: per_seg[i] for i, k in enumerate(unit_keys)}
+        gathered = [mine]
         if dist is not None:
             gathered = [None] * world
-            dist.all_gather_object(gathered, dg)
+            dist.all_gather_object(gathered, mine)
         if rank == 0:
-            merged = shard.merge_results(gathered)
+            merged = digest_rows(shard.merge_rows(gathered))
             full = digest_rows(resolve.cluster_stage(pstore, params, tasks=all_tasks, ctx=ctx))
             shard_check = merged == full
             assert shard_check, "sharded rows differ from the unsharded run"
+            # the shards rank 0 measured below are its own: the per-kernel pass describes one rank's share
+        tasks = list(dict.fromkeys((t, c) for (t, c, _) in unit_keys))
 
     out = None
     if rank == 0:
@@ -463,7 +502,7 @@ def main():
             # pinned columns -> VCF text: the boundary call + the native emitter, no Python rows in between
             ts = timed(lambda: vcf_mod.emit_records(pstore, hb2.segments, ctx.cluster_batch(hb2, reuse=True), None, min_size=params.min_size,
                                                      max_size=params.max_size, genotype=params.genotype, ignore_sequence=True, as_bytes=True), 5)
-            t_vcf = dict(ms=float(np.median(tv)) * 1e3, records=text.count(b"\n"), bytes=len(text), threads=min(32, os.cpu_count() or 1),
+            t_vcf = dict(ms=float(np.median(tv)) * 1e3, records=text.count(b"\n"), bytes=len(text), threads=min(16, os.cpu_count() or 1),
                          stage_wall_vcf_ms=float(np.median(ts)) * 1e3)
         except Exception as e:          # never let the optional leg break the benchmark line
             t_vcf = dict(error=str(e))
@@ -484,14 +523,21 @@ def main():
         gt_parts = ("k_reads_order", "k_reads_gather", "k_reads_maxlen", "k_genotype")        # stage slots (HIP events)
         gt_kernels = ("k_reads_runs", "k_reads_plan", "k_reads_gather", "k_reads_maxlen", "k_genotype")   # kernel names (PMC)
 
+        # A stage slot is the time between two hipEventRecord calls on the library's stream; the records themselves occupy the
+        # stream (slots that launch nothing - a tier without work, the reads stage of a batch without reads - still read
+        # 4-5 us).  That floor, taken as the smallest slot of the pass, is subtracted, so that kernel_us is the kernel's own
+        # duration (it then agrees with rocprofv3's begin-to-end average: profiles/); the raw slots are kept in *_raw.
         def per_kernel_us(v):
-            d = {names[i]: round(float(v[i]) * 1e3, 2) for i in range(_abi.N_STAGES) if names[i]}   # microseconds
+            raw = {names[i]: float(v[i]) * 1e3 for i in range(_abi.N_STAGES) if names[i]}
+            gap = min(raw.values())
+            d = {k: round(max(0.0, x - gap), 2) for k, x in raw.items()}
             d["genotype_stage"] = round(sum(d.get(k, 0.0) for k in gt_parts), 2)
+            d["_event_gap"] = round(gap, 2)
             return d
         per_kernel, per_kernel_cold, per_kernel_nps = per_kernel_us(acc), per_kernel_us(cold_acc), per_kernel_us(warm_plain)
         # dominant kernel = the longest of the plain pass; kernels within 5 % of the longest count as tied and the one that
         # moves the most algorithmic bytes is named (so that the choice does not flip between runs on a 0.1 us difference)
-        cand = [n for n in per_kernel_nps if n in kbytes and kbytes[n] > 0 and n not in ("k_chain_apply", "k_items_scan")]
+        cand = [n for n in per_kernel_nps if n in kbytes and kbytes[n] > 0 and per_kernel_nps[n] > 0 and n not in ("k_chain_apply", "k_items_scan")]
         longest = max(per_kernel_nps[n] for n in cand)
         dom = max((n for n in cand if per_kernel_nps[n] >= 0.95 * longest), key=lambda n: kbytes[n])
         dom_s = per_kernel_nps[dom] * 1e-6
@@ -525,7 +571,8 @@ def main():
             "config": {"workload": wl_name, "signatures_per_gpu": n_sig, "signatures_total": total_sig, "segments": len(tasks),
                        "preset": "ONT" if a.workload in ("cfg2", "cfg3", "cfg5") else "HiFi",
                        "genotype": bool(params.genotype), "mode": a.mode,
-                       "sharding": ("one genome split over the GPUs by chromosome (LPT), no collective; a step is the rank's H2D + kernels + D2H"
+                       "sharding": ("one genome split over the GPUs: chromosomes longest-first, the largest cut at gaps wider than max_cluster_bias until the "
+                                    "heaviest rank is within 3 % of the mean; no collective; a step is the rank's H2D + kernels + D2H"
                                     if shard_mode else "one genome per GPU, no collective")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

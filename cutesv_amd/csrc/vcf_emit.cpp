@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <functional>
 #include <string>
 #include <thread>
 #include <vector>
@@ -97,18 +98,49 @@ inline int emitted_id(const csv_vcf_in* in, const csv_batch_out& R, int64_t c)
 
 int emit_slice(const csv_vcf_in* in, const int64_t* v, int64_t nv, int ch, int64_t* svid, Sink& o);
 
-template <class F> void parallel_for(int64_t n, int nthreads, F&& f)
-{
-    if (n <= 0) return;
-    if (nthreads > n) nthreads = (int)n;
-    if (nthreads <= 1) { for (int64_t i = 0; i < n; i++) f(i); return; }
-    std::atomic<int64_t> next{0};
-    std::vector<std::thread> th;
-    auto work = [&]() { for (int64_t i; (i = next.fetch_add(1)) < n;) f(i); };
-    for (int t = 1; t < nthreads; t++) th.emplace_back(work);
-    work();
-    for (auto& t : th) t.join();
-}
+// A team of worker threads started once per call (thread creation is ~30 us: three parallel loops over 32 fresh threads each
+// cost more than the formatting).  run(n, f): f(i) for i in [0, n) dealt dynamically; returns when all are done.
+class Team {
+public:
+    explicit Team(int nthreads) : n_(nthreads < 1 ? 1 : nthreads)
+    {
+        for (int t = 1; t < n_; t++) th_.emplace_back([this] { loop(); });
+    }
+    ~Team()
+    {
+        quit_.store(true);
+        gen_.fetch_add(1);
+        for (auto& t : th_) t.join();
+    }
+    template <class F> void run(int64_t n, F&& f)
+    {
+        if (n <= 0) return;
+        std::function<void(int64_t)> fn = f;
+        fn_ = &fn; total_ = n; next_.store(0); done_.store(0);
+        gen_.fetch_add(1);                                  // release the workers
+        work();
+        while (done_.load() < n_) std::this_thread::yield();
+    }
+private:
+    void work() { for (int64_t i; (i = next_.fetch_add(1)) < total_;) (*fn_)(i); done_.fetch_add(1); }
+    void loop()
+    {
+        for (int seen = 0;;) {
+            int g;
+            while ((g = gen_.load()) == seen) std::this_thread::yield();
+            seen = g;
+            if (quit_.load()) return;
+            work();
+        }
+    }
+    int n_;
+    std::vector<std::thread> th_;
+    std::atomic<int> gen_{0}, done_{0};
+    std::atomic<bool> quit_{false};
+    std::atomic<int64_t> next_{0};
+    int64_t total_ = 0;
+    std::function<void(int64_t)>* fn_ = nullptr;
+};
 }  // namespace
 
 extern "C" int csv_vcf_emit(const csv_vcf_in* in, char* out, int64_t cap, int64_t* n_written, int64_t* svid)
@@ -118,8 +150,9 @@ extern "C" int csv_vcf_emit(const csv_vcf_in* in, char* out, int64_t cap, int64_
     const int64_t nc = R.n_calls;
     int nthreads = (int)std::thread::hardware_concurrency();
     if (const char* e = getenv("CSV_VCF_THREADS")) nthreads = atoi(e);
-    if (nthreads > 32) nthreads = 32;
+    if (nthreads > 16) nthreads = 16;
     if (nthreads < 1 || nc < 2 * VCF_SLICE) nthreads = 1;
+    Team team(nthreads);
 
     // calls per chromosome in the order main_ctrl concatenates task results (the call order of the batch): counting sort
     std::vector<int64_t> coff((size_t)in->n_chrom + 1, 0), idx((size_t)nc);
@@ -139,7 +172,7 @@ extern "C" int csv_vcf_emit(const csv_vcf_in* in, char* out, int64_t cap, int64_
     for (int i = 0; i < in->n_chrom; i++) order[i] = i;
     std::sort(order.begin(), order.end(), [&](int x, int y) { return in->chrom_rank[x] < in->chrom_rank[y]; });
     // generate_output's stable sort by int(row[2]) per chromosome (cuteSV_genotype.py:252)
-    parallel_for(in->n_chrom, nthreads, [&](int64_t ch) {
+    team.run(in->n_chrom, [&](int64_t ch) {
         std::stable_sort(idx.begin() + coff[(size_t)ch], idx.begin() + coff[(size_t)ch + 1], [&](int64_t x, int64_t y) { return R.bp1[x] < R.bp1[y]; });
     });
     // slices in emission order
@@ -153,13 +186,13 @@ extern "C" int csv_vcf_emit(const csv_vcf_in* in, char* out, int64_t cap, int64_
         }
     // records per type every slice emits -> the counters it starts with (main script :1208-1237: one counter per type over the
     // whole file)
-    parallel_for((int64_t)sl.size(), nthreads, [&](int64_t i) {
+    team.run((int64_t)sl.size(), [&](int64_t i) {
         Slice& x = sl[(size_t)i];
         for (int64_t q = x.lo; q < x.hi; q++) { const int id = emitted_id(in, R, idx[(size_t)q]); if (id >= 0) x.cnt[id]++; }
     });
     int64_t run[5] = {svid[0], svid[1], svid[2], svid[3], svid[4]};
     for (Slice& x : sl) for (int t = 0; t < 5; t++) { x.start[t] = run[t]; run[t] += x.cnt[t]; }
-    parallel_for((int64_t)sl.size(), nthreads, [&](int64_t i) {
+    team.run((int64_t)sl.size(), [&](int64_t i) {
         Slice& x = sl[(size_t)i];
         x.text.buf.reserve((size_t)(x.hi - x.lo) * 192);
         int64_t sv[5] = {x.start[0], x.start[1], x.start[2], x.start[3], x.start[4]};
@@ -171,7 +204,7 @@ extern "C" int csv_vcf_emit(const csv_vcf_in* in, char* out, int64_t cap, int64_
     if (!out || total > cap) return CSV_E_CAPACITY;
     std::vector<int64_t> toff(sl.size() + 1, 0);
     for (size_t i = 0; i < sl.size(); i++) toff[i + 1] = toff[i] + (int64_t)sl[i].text.buf.size();
-    parallel_for((int64_t)sl.size(), nthreads, [&](int64_t i) { memcpy(out + toff[(size_t)i], sl[(size_t)i].text.buf.data(), sl[(size_t)i].text.buf.size()); });
+    team.run((int64_t)sl.size(), [&](int64_t i) { memcpy(out + toff[(size_t)i], sl[(size_t)i].text.buf.data(), sl[(size_t)i].text.buf.size()); });
     for (int t = 0; t < 5; t++) svid[t] = run[t];
     return CSV_OK;
 }

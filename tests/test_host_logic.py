@@ -107,6 +107,19 @@ def test_lpt_sharding_is_a_balanced_partition():
         assert max(loads) <= sum(loads) / n + max(shard.chromosome_cost(st, c) for c in flat)
         tasks = [t for r in range(n) for t in shard.tasks_of_rank(st, r, n)]
         assert sorted(tasks) == sorted(st.tasks())
+    # chromosomes cut at gaps wider than max_cluster_bias: every signature in exactly one unit, and the
+    # heaviest of 8 ranks within 3 % of the mean although chr1 alone is two thirds of a rank's share
+    from cutesv_amd.columns import Params
+    st = synth.ont30(scale=0.2)
+    p = Params.ont()
+    for n in (2, 4, 8):
+        loads, seen = [], 0
+        for units in shard.plan(st, n, p):
+            segs, keys, _ = shard.rank_batch(st, p, units)
+            assert len(set(keys)) == len(keys)
+            loads.append(int((segs["sig_end"] - segs["sig_begin"]).sum()))
+        assert sum(loads) == st.n_sig
+        assert max(loads) <= 1.03 * sum(loads) / n, (n, loads)
 
 
 def test_shims_follow_the_reference_argument_contract():
