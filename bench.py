@@ -507,6 +507,41 @@ def main():
         except Exception as e:          # never let the optional leg break the benchmark line
             t_vcf = dict(error=str(e))
 
+        # INTEGRATION.md mode 1: the reference's own task interface, one (chromosome, type) task per call from ITS files
+        # (<TYPE>.pickle at sigs_index offsets): unpickle + columnar conversion + the boundary call + rows, for the largest task
+        t_task = None
+        try:
+            import pickle, tempfile
+            ins_tasks = [(t, c) for (t, c) in tasks if t == "INS"] or tasks
+            tt, tc = max(ins_tasks, key=lambda k: store.seg_index[k][1] - store.seg_index[k][0])
+            b0, e0 = store.seg_index[(tt, tc)]
+            nm = store.names.take(store.read_id[b0:e0])
+            if tt == "INS":
+                lst = [(int(store.a[i]), int(store.b[i]), nm[i - b0], store.sequence(i), "INS", tc) for i in range(b0, e0)]
+            else:
+                lst = [(int(store.a[i]), int(store.b[i]), nm[i - b0], tt, tc) for i in range(b0, e0)]
+            with tempfile.TemporaryDirectory() as wd:
+                wd += "/"
+                with open(wd + tt + ".pickle", "wb") as f:
+                    pickle.dump(lst, f)
+                idx = {t_: {} for t_ in ("DEL", "INS", "INV", "DUP", "TRA")}
+                idx[tt][tc] = 0
+                bias = params.max_cluster_bias_INS if tt == "INS" else params.max_cluster_bias_DEL
+                ratio = params.diff_ratio_merging_INS if tt == "INS" else params.diff_ratio_merging_DEL
+                args = (wd, tc, tt, params.min_support, ratio, bias, min(params.min_support, 5), "bam", False, params.gt_round, params.remain_reads_ratio, idx)
+                fn = resolve.run_ins if tt == "INS" else resolve.run_del
+                resolve._ctx = ctx
+                ts_ = timed(lambda: fn(args), 4)
+                t0 = time.perf_counter()
+                with open(wd + tt + ".pickle", "rb") as f:
+                    pickle.load(f)
+                t_unpickle = time.perf_counter() - t0
+            t_task = dict(task="%s chr%s" % (tt, tc), signatures=e0 - b0, ms=float(np.median(ts_)) * 1e3, unpickle_ms=t_unpickle * 1e3,
+                          signatures_per_s=(e0 - b0) / float(np.median(ts_)),
+                          note="resolve.run_ins(args) with the reference's argument tuple on its pickle layout: pickle.load + SigStore.from_task_lists + csv_cluster_batch + rows")
+        except Exception as e:           # noqa: BLE001  (optional leg)
+            t_task = dict(error=repr(e))
+
         # measured device-to-device copy ceiling of this box (report the fraction of the vendor peak AND of
         # the copy ceiling): 512 MiB hipMemcpy device to device, read + write bytes over the best of 10 runs
         copy_gbs = None
@@ -595,7 +630,7 @@ def main():
                          "rows_ms": float(np.median(t_rows)) * 1e3, "rows": n_rows,
                          "stage_wall_ms": stage_ms, "stage_wall_ms_all": [round(x * 1e3, 3) for x in t_stage],
                          "stage_speedup_vs_cpu_baseline": (cpu["wall_s"] * 1e3 / stage_ms) if (cpu and cpu.get("full_workload")) else None,
-                         "vcf_emit_native": t_vcf,
+                         "vcf_emit_native": t_vcf, "per_task_drop_in": t_task,
                          "pcie_inclusive_signatures_per_s": n_sig / (one_ms * 1e-3),
                          "stage_signatures_per_s": n_sig / (stage_ms * 1e-3)},
             "parity_vs_oracle": parity, "shard_merge_equals_unsharded": shard_check,

@@ -379,6 +379,57 @@ class SigStore:
                    names=NameTable(uniq), ins_seq=ins_seq, strands=tuple(strands), **kw)
 
     @classmethod
+    def from_task_lists(cls, svtype, chrom, sigs, reads=None, chroms=None):
+        """One reference task - the list `pickle.load` returns at sigs_index[svtype][chrom] (already in the rebuild order
+        and de-duplicated: main script :764-802, :958-969 wrote it) and, when the task genotypes, its chromosome's reads list
+        - as a flat store, column by column (list comprehensions + numpy; `from_tuple_lists` re-sorts and walks tuple by
+        tuple: ~3x the time for a chr1-sized task).  What a pool worker pays per task in the drop-in (resolve.run_*)."""
+        n = len(sigs)
+        reads = reads or []
+        name_col = {"DEL": 2, "INS": 2, "DUP": 2, "INV": 3, "TRA": 4}[svtype]
+        names = [x[name_col] for x in sigs]
+        rnames = [r[3] for r in reads]
+        uniq = sorted(set(names).union(rnames))
+        rank = dict(zip(uniq, range(len(uniq))))
+        rid = np.fromiter((rank[q] for q in names), np.int32, n)
+        if chroms is None:
+            cs = {chrom}
+            if svtype == "TRA":
+                cs.update(x[2] for x in sigs)
+            cs.update(r[4] for r in reads)
+            chroms = sorted(cs)
+        crank = {c: i for i, c in enumerate(chroms)}
+        aux = np.zeros(n, np.int32)
+        ins_seq, strands = {}, ("++", "--")
+        if svtype in ("DEL", "INS", "DUP"):
+            a = np.fromiter((int(x[0]) for x in sigs), np.int64, n)
+            b = np.fromiter((int(x[1]) for x in sigs), np.int64, n)
+            if svtype == "INS":
+                aux = np.fromiter((len(x[3]) for x in sigs), np.int32, n)
+                ins_seq = {i: x[3] for i, x in enumerate(sigs)}
+        elif svtype == "INV":
+            strands = tuple(sorted(set(x[0] for x in sigs))) or ("++", "--")
+            code = {s_: i for i, s_ in enumerate(strands)}
+            a = np.fromiter((int(x[1]) for x in sigs), np.int64, n)
+            b = np.fromiter((int(x[2]) for x in sigs), np.int64, n)
+            aux = np.fromiter((code[x[0]] for x in sigs), np.int32, n)
+        else:
+            a = np.fromiter((int(x[1]) for x in sigs), np.int64, n)
+            b = np.fromiter((int(x[3]) for x in sigs), np.int64, n)
+            aux = np.fromiter((crank[x[2]] * 8 + BND_CODE.get(x[0], 4) for x in sigs), np.int32, n)
+        kw = {}
+        if reads:
+            rc = np.fromiter((crank[r[4]] for r in reads), np.int64, len(reads))
+            o = np.argsort(rc, kind="stable")                # blocks by chromosome; the device orders every block by start
+            kw = dict(reads_off=np.searchsorted(rc[o], np.arange(len(chroms) + 1)).astype(np.int64),
+                      r_start=np.fromiter((int(r[0]) for r in reads), np.int64, len(reads))[o],
+                      r_end=np.fromiter((int(r[1]) for r in reads), np.int64, len(reads))[o],
+                      r_primary=np.fromiter((int(r[2]) for r in reads), np.uint8, len(reads))[o],
+                      r_id=np.fromiter((rank[q] for q in rnames), np.int32, len(reads))[o])
+        return cls(chroms=list(chroms), a=a, b=b, read_id=rid, aux=aux, seg_index={(svtype, chrom): (0, n)} if n else {},
+                   names=NameTable(uniq), ins_seq=ins_seq if svtype == "INS" else {}, strands=strands, **kw)
+
+    @classmethod
     def from_reference_workdir(cls, work_dir, sigs_index=None, contig_len=None):
         """Read the reference's own `<TYPE>.pickle` / `reads.pickle` / `sigindex.pickle` files
         (main script :817-857, 1092-1093) into the flat layout.  Needs only `pickle`."""

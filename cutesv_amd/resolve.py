@@ -61,7 +61,7 @@ def _store_for(work_dir, sigs_index, svtype, chrom, need_reads):
     chroms = None
     if svtype == "TRA":                               # chr2 ranks must cover every mate chromosome of the list
         chroms = sorted({chrom} | {x[2] for x in sigs})
-    return SigStore.from_tuple_lists({svtype: sigs}, reads, chroms=chroms)
+    return SigStore.from_task_lists(svtype, chrom, sigs, reads, chroms=chroms)
 
 
 def run_batch(store, segments, tasks, ctx=None):

@@ -5,37 +5,72 @@ cuteSV_genotype.py:72-93): every alignment `fetch` returns counts towards `itera
 low-mapq ones that never reach the reads table (main script :711-733).  The GPU variant (k_genotype_tra) walks the reads
 table instead and is therefore only identical when the windows hold no such alignment; it stays an explicit opt-in
 (CUTESV_AMD_TRA_GT=reads_table, or Params.genotype_tra in the batched stage).  This module is the faithful path: the
-same loop as the reference, over pysam, for the few hundred BND calls of a genome.  It needs pysam, like cuteSV itself.
+same decision as the reference's loop, taken over chunks of `fetch`'s alignments with array gates (window_status), for the few
+hundred BND calls of a genome.  It needs pysam, like cuteSV itself.
 """
 from .genotype import gl_fields, gl_index
 
 
-def threshold_ref_count(num):                       # cuteSV_genotype.py:62-70
-    if num <= 2:
-        return 20 * num
-    if num <= 5:
-        return 9 * num
-    if num <= 15:
-        return 7 * num
+import itertools
+
+import numpy as np
+
+_UP_BOUND_STEPS = ((2, 20), (5, 9), (15, 7))          # support <= 2 / 5 / 15 -> x20 / x9 / x7, beyond x5 (cuteSV_genotype.py:62-70)
+
+
+def threshold_ref_count(num):
+    for limit, factor in _UP_BOUND_STEPS:
+        if num <= limit:
+            return factor * num
     return 5 * num
 
 
-def count_coverage(chrom, s, e, bam, names, up_bound, itround):
-    """cuteSV_genotype.py:72-93; returns the status 0 / 1 / -1"""
-    iteration = 0
-    primary_num = 0
-    for aln in bam.fetch(chrom, s, e):
-        iteration += 1
-        if aln.flag not in (0, 16):
-            continue
-        primary_num += 1
-        if aln.reference_start < s and aln.reference_end > e:
-            names.add(aln.query_name)
-            if len(names) >= up_bound:
+def window_status(alignments, s, e, names, up_bound, itround, chunk=2048):
+    """What count_coverage (cuteSV_genotype.py:72-93) decides for one window, evaluated a chunk of alignments at a time with
+    array gates instead of a per-alignment loop.  `alignments` yields pysam-like records in fetch order; `names` (a set) is
+    extended with the spanning primary names up to the alignment at which the reference stops.  Returns 0 / 1 / -1.
+
+    Per alignment i (1-based position k in the stream): primary = flag is 0 or 16; spanning = primary, starts before s and
+    ends after e.  The walk stops at the first alignment where either (A) it is spanning and the number of distinct
+    spanning names seen so far reaches up_bound -> 1, or (B) it is primary and k >= itround -> 1 when at most a fifth of
+    the k alignments were primary, else -1.  (A is tested before B on the same alignment.)"""
+    seen = primary_seen = 0
+    it = iter(alignments)
+    while True:
+        block = list(itertools.islice(it, chunk))
+        if not block:
+            return 0
+        flag = np.fromiter((a.flag for a in block), np.int64, len(block))
+        start = np.fromiter((a.reference_start for a in block), np.int64, len(block))
+        end = np.fromiter((a.reference_end for a in block), np.int64, len(block))
+        primary = (flag == 0) | (flag == 16)
+        spanning = primary & (start < s) & (end > e)
+        k = seen + 1 + np.arange(len(block))                                # position in the stream
+        n_primary = primary_seen + np.cumsum(primary)
+        # distinct spanning names so far: a name counts where it first appears (and was not in `names` before the window)
+        fresh = np.zeros(len(block), bool)
+        local = set()
+        for i in np.flatnonzero(spanning).tolist():                         # (only the spanning records: a handful to a few dozen)
+            q = block[i].query_name
+            if q not in names and q not in local:
+                local.add(q)
+                fresh[i] = True
+        n_names = len(names) + np.cumsum(fresh)
+        stop_a = spanning & (n_names >= up_bound)
+        stop_b = primary & (k >= itround)
+        stops = np.flatnonzero(stop_a | stop_b)
+        last = int(stops[0]) if len(stops) else len(block) - 1
+        names.update(block[i].query_name for i in np.flatnonzero(spanning[:last + 1]).tolist())
+        if len(stops):
+            if stop_a[last]:
                 return 1
-        if iteration >= itround:
-            return 1 if float(primary_num / iteration) <= 0.2 else -1
-    return 0
+            return 1 if float(n_primary[last] / k[last]) <= 0.2 else -1
+        seen += len(block)
+        primary_seen = int(n_primary[-1])
+
+
+def count_coverage(chrom, s, e, bam, names, up_bound, itround):
+    return window_status(bam.fetch(chrom, s, e), s, e, names, up_bound, itround)
 
 
 def call_gt(bam, pos_1, pos_2, chr_1, chr_2, read_ids, max_cluster_bias, gt_round):
