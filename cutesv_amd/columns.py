@@ -451,6 +451,38 @@ class SigStore:
                 reads.extend(pickle.load(f))
         return cls.from_tuple_lists(per_type, reads, contig_len=contig_len)
 
+    @classmethod
+    def from_sigs_dir(cls, work_dir, contig_len=None):
+        """Read the legacy text signature files the reference writes under --write_old_sigs (main script :766-816,
+        cuteSV_Description.py:96-98): `<TYPE>.sigs` with the tab-separated columns
+            DEL / DUP   TYPE chr pos|pos1 len|pos2 read          INS   TYPE chr pos len read seq
+            INV         TYPE chr strand pos1 pos2 read           TRA   TYPE chr1 bnd_type pos1 chr2 pos2 read
+        and `reads.sigs` (chr start end is_primary read).  Positions were written with %d, so a split-read INS position
+        x.5 arrives truncated - which is what every consumer of the tuple does with it anyway (int(pos), INDEL:271)."""
+        per_type, reads = {t: [] for t in TYPES}, []
+        for t in TYPES:
+            path = os.path.join(work_dir, t + ".sigs")
+            if not os.path.exists(path):
+                continue
+            with open(path) as f:
+                for line in f:
+                    x = line.rstrip("\n").split("\t")
+                    if t in ("DEL", "DUP"):
+                        per_type[t].append((int(x[2]), int(x[3]), x[4], t, x[1]))
+                    elif t == "INS":
+                        per_type[t].append((int(x[2]), int(x[3]), x[4], x[5], t, x[1]))
+                    elif t == "INV":
+                        per_type[t].append((x[2], int(x[3]), int(x[4]), x[5], t, x[1]))
+                    else:
+                        per_type[t].append((x[2], int(x[3]), x[4], int(x[5]), x[6], t, x[1]))
+        path = os.path.join(work_dir, "reads.sigs")
+        if os.path.exists(path):
+            with open(path) as f:
+                for line in f:
+                    x = line.rstrip("\n").split("\t")
+                    reads.append((int(x[1]), int(x[2]), int(x[3]), x[4], x[0]))
+        return cls.from_tuple_lists(per_type, reads, contig_len=contig_len)
+
     # ------------------------------------------------------------------ the inverse (tests / golden generation)
     def tuple_lists(self):
         """Reference-format tuple lists per type and the reads list (inverse of from_tuple_lists)."""

@@ -279,3 +279,31 @@ def parse_reads(reads, chrom, chrom_rank, sv_size, min_mapq, max_split_parts, mi
     for t in ("DUP", "INV", "TRA"):
         cand[t] = s_cand[t]
     return cand
+
+
+# ------------------------------------------------------------------------------------ single_pipe: one extraction task
+def single_pipe(alignments, chrom, task_start, chrom_rank, sv_size, min_mapq, max_split_parts, min_read_len, min_siglength, merge_del_threshold,
+                merge_ins_threshold, max_size, cigar_fn, split_fn, bed_regions=None):
+    """What the reference's single_pipe (main script :697-743) pickles for one task region: the five candidate lists of the
+    reads that pass its gates and the reads table rows `(start, end, is_primary, name, chr)` (:709-733).
+
+    alignments: what `samfile.fetch(chr, task[1], task[2])` yields, in that order.  Gates, as the reference applies them:
+    secondary records (flag 256 / 272) are skipped (:711); a read belongs to the task in which it STARTS
+    (`reference_start >= task[1]`, :725) and, with --include_bed, must overlap one of the chromosome's regions (:715-723);
+    such a read goes through parse_read (here: one batched call, `parse_reads`), and enters the reads table when its mapq
+    passes (:729-733) - whatever parse_read did with it (a read shorter than min_read_len still counts as coverage)."""
+    recs = [r for r in alignments if r.flag != 256 and r.flag != 272]
+    if recs:
+        start = np.fromiter((r.reference_start for r in recs), np.int64, len(recs))
+        keep = start >= task_start
+        if bed_regions is not None:
+            end = np.fromiter((r.reference_end for r in recs), np.int64, len(recs))
+            in_bed = np.zeros(len(recs), bool)
+            for b0, b1 in bed_regions:                       # not (pos_end <= b0 or pos_start >= b1)
+                in_bed |= (end > b0) & (start < b1)
+            keep &= in_bed
+        recs = [r for r, k in zip(recs, keep.tolist()) if k]
+    cand = parse_reads(recs, chrom, chrom_rank, sv_size, min_mapq, max_split_parts, min_read_len, min_siglength, merge_del_threshold,
+                       merge_ins_threshold, max_size, cigar_fn, split_fn)
+    reads_info = [(r.reference_start, r.reference_end, 1 if r.flag in (0, 16) else 0, r.query_name, chrom) for r in recs if r.mapq >= min_mapq]
+    return cand, reads_info

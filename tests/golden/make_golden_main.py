@@ -156,8 +156,9 @@ def main_():
             cigar_golden(main)
             from make_golden_split import split_golden
             split_golden(main)
-            from make_golden_parse import parse_golden
+            from make_golden_parse import parse_golden, single_pipe_golden
             parse_golden(main)
+            single_pipe_golden(main)
         except ImportError:
             pass
 

@@ -78,3 +78,43 @@ def parse_golden(main):
     with gzip.open(os.path.join(HERE, "parse_reads.json.gz"), "wt") as f:
         json.dump(cases, f)
     print("parse_reads.json.gz: %d cases; candidates %s" % (len(cases), {t: sum(len(c[t]) for c in cases) for t in ("DEL", "INS", "DUP", "INV", "TRA")}))
+
+
+def single_pipe_golden(main):
+    """single_pipe.json.gz: the reference's single_pipe (main script :697-743) on a stub alignment file - the gates of the task
+    loop (secondary records, the task's start coordinate, --include_bed regions) and the reads table rows next to the
+    candidates.  The function pickles into <temp>/signatures/<pid><TYPE>.pickle: read back here."""
+    import pickle
+    import tempfile
+
+    class _Sam:
+        def __init__(self, reads):
+            self.reads = reads
+
+        def fetch(self, chrom, s, e):
+            return iter(self.reads)
+
+    cases = []
+    for name, seed, n, task, bed, params in (("plain", 41, 300, ["7", 1_000_000, 2_000_000], None, dict(sv=30, min_mapq=20, parts=7, min_read_len=500, min_siglength=10, md=0, mi=100, max_size=100000)),
+                                             ("bed", 42, 300, ["7", 500_000, 3_000_000], [[600_000, 900_000], [1_500_000, 2_200_000]],
+                                              dict(sv=30, min_mapq=10, parts=-1, min_read_len=0, min_siglength=10, md=50, mi=50, max_size=-1))):
+        rng = np.random.default_rng(seed)
+        recs = sorted((random_record(rng, "sp%05d" % i, seed * 100000 + i) for i in range(n)), key=lambda d: d["start"])
+        main.samfile = _Sam([_Read(d) for d in recs])
+        with tempfile.TemporaryDirectory() as tmp:
+            tmp += "/"
+            os.mkdir(tmp + "signatures")
+            main.single_pipe("stub.bam", params["sv"], params["min_mapq"], params["parts"], params["min_read_len"], tmp, task, params["min_siglength"],
+                             params["md"], params["mi"], params["max_size"], bed)
+            out = {}
+            for fn in os.listdir(tmp + "signatures"):
+                for t in ("DEL", "INS", "DUP", "INV", "TRA", "reads"):
+                    if fn.endswith(t + ".pickle"):
+                        with open(tmp + "signatures/" + fn, "rb") as f:
+                            out["reads_table" if t == "reads" else t] = [list(x) for x in pickle.load(f)]
+        main.samfile = None
+        cases.append(dict(name=name, params=params, task=task, bed=bed, chroms=sorted(set(CHROMS) | {"7"}), reads=recs, **out))
+    with gzip.open(os.path.join(HERE, "single_pipe.json.gz"), "wt") as f:
+        json.dump(cases, f)
+    print("single_pipe.json.gz: %d cases; reads rows %s, candidates %s" % (len(cases), [len(c["reads_table"]) if "reads_table" in c else len(c["reads"]) for c in cases],
+                                                                            {t: sum(len(c[t]) for c in cases) for t in ("DEL", "INS", "DUP", "INV", "TRA")}))

@@ -235,3 +235,18 @@ def assert_parse_case(case, cigar_fn, split_fn):
         got = [list(x) for x in cand[t]]
         assert got == case[t], (case["name"], t, len(got), len(case[t]), next(((i, g, w) for i, (g, w) in enumerate(zip(got, case[t])) if g != w), None))
         assert all(type(g[0]) is type(w[0]) for g, w in zip(got, case[t])), (case["name"], t)
+
+
+def assert_single_pipe_case(case, cigar_fn, split_fn):
+    """extract.single_pipe == the reference's single_pipe (single_pipe.json.gz): candidates per type and the reads table rows"""
+    from cutesv_amd import extract
+    p = case["params"]
+    rank = {c: i for i, c in enumerate(case["chroms"])}
+    chrom, task_start = case["task"][0], case["task"][1]
+    cand, reads_info = extract.single_pipe([StubRecord(d) for d in case["reads"]], chrom, task_start, rank, p["sv"], p["min_mapq"], p["parts"], p["min_read_len"],
+                                           p["min_siglength"], p["md"], p["mi"], p["max_size"], cigar_fn, split_fn, bed_regions=case["bed"])
+    for t in ("DEL", "INS", "DUP", "INV", "TRA"):
+        got = [list(x) for x in cand[t]]
+        assert got == case[t], (case["name"], t, len(got), len(case[t]))
+    assert [list(x) for x in reads_info] == case["reads_table"], (case["name"], len(reads_info), len(case["reads_table"]))
+    assert len(reads_info) > 20

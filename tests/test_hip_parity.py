@@ -815,6 +815,15 @@ def test_whole_parse_read_on_the_gpu(ctx):
         assert_parse_case(case, lambda *a, **k: extract.cigar_signatures(ctx, *a, **k), lambda enc, **k: extract.split_signatures(ctx, enc, **k))
 
 
+def test_single_pipe_on_the_gpu(ctx):
+    """one extraction task (main script :697-743) with the HIP CIGAR scan and split-read analysis: candidates and reads table
+    rows equal the reference's single_pipe"""
+    from cutesv_amd import extract
+    from helpers import assert_single_pipe_case
+    for case in load_json("single_pipe.json.gz"):
+        assert_single_pipe_case(case, lambda *a, **k: extract.cigar_signatures(ctx, *a, **k), lambda enc, **k: extract.split_signatures(ctx, enc, **k))
+
+
 def test_thousands_of_small_segments(ctx):
     """a reference with thousands of small contigs: 3000 (contig, type) segments of a few dozen signatures each, so that
     every chain tile spans dozens of segments (the per-row path, the segment search bounded by the tile's range, the

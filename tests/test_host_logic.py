@@ -212,3 +212,26 @@ def test_bam_faithful_tra_genotyping_matches_reference(monkeypatch):
             assert got == rows, (case["name"], c)
             n += len(rows)
     assert n > 20
+
+
+def test_legacy_sigs_text_files_round_trip(tmp_path):
+    """--write_old_sigs (main script :766-816): the text lines the reference prints per type, read back into the flat store"""
+    from cutesv_amd.columns import SigStore
+    st = synth.small_mixed(seed=21, genotype=True)
+    per, reads = st.tuple_lists()
+    fmt = {"DEL": lambda e: "%s\t%s\t%d\t%d\t%s\n" % (e[-2], e[-1], e[0], e[1], e[2]),
+           "INS": lambda e: "%s\t%s\t%d\t%d\t%s\t%s\n" % (e[-2], e[-1], e[0], e[1], e[2], e[3]),
+           "DUP": lambda e: "%s\t%s\t%d\t%d\t%s\n" % (e[-2], e[-1], e[0], e[1], e[2]),
+           "INV": lambda e: "%s\t%s\t%s\t%d\t%d\t%s\n" % (e[-2], e[-1], e[0], e[1], e[2], e[3]),
+           "TRA": lambda e: "%s\t%s\t%s\t%d\t%s\t%d\t%s\n" % (e[-2], e[-1], e[0], e[1], e[2], e[3], e[4])}
+    for t, lst in per.items():
+        with open(tmp_path / (t + ".sigs"), "w") as f:
+            f.writelines(fmt[t](e) for e in lst)
+    with open(tmp_path / "reads.sigs", "w") as f:
+        f.writelines("%s\t%d\t%d\t%d\t%s\n" % (e[-1], e[0], e[1], e[2], e[3]) for e in reads)
+    got = SigStore.from_sigs_dir(str(tmp_path))
+    want = SigStore.from_tuple_lists(per, reads)
+    assert got.seg_index == want.seg_index and got.chroms == want.chroms
+    for k in ("a", "b", "read_id", "aux", "reads_off", "r_start", "r_end", "r_primary", "r_id"):
+        assert np.array_equal(getattr(got, k), getattr(want, k)), k
+    assert got.ins_seq == want.ins_seq and got.names.names == want.names.names

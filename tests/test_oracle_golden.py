@@ -192,3 +192,11 @@ def test_whole_parse_read_identical_to_reference():
     from oracle import oracle
     for case in load_json("parse_reads.json.gz"):
         assert_parse_case(case, oracle.cigar_signatures, oracle.split_signatures)
+
+
+def test_single_pipe_task_gates_and_reads_table_vs_reference():
+    """the extraction task loop (main script :697-743): gates + candidates + reads table rows, with the oracle's CIGAR / split engines"""
+    from helpers import assert_single_pipe_case
+    from oracle import oracle
+    for case in load_json("single_pipe.json.gz"):
+        assert_single_pipe_case(case, oracle.cigar_signatures, oracle.split_signatures)
