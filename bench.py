@@ -564,8 +564,8 @@ def main():
         # duration (it then agrees with rocprofv3's begin-to-end average: profiles/); the raw slots are kept in *_raw.
         def per_kernel_us(v):
             raw = {names[i]: float(v[i]) * 1e3 for i in range(_abi.N_STAGES) if names[i]}
-            gap = min(raw.values())
-            d = {k: round(max(0.0, x - gap), 2) for k, x in raw.items()}
+            gap = min([x for x in raw.values() if x > 0.5] or [0.0])        # (slots that were never recorded read 0)
+            d = {k: round(max(0.0, x - gap), 2) if x > 0.5 else 0.0 for k, x in raw.items()}
             d["genotype_stage"] = round(sum(d.get(k, 0.0) for k in gt_parts), 2)
             d["_event_gap"] = round(gap, 2)
             return d

@@ -2,7 +2,7 @@
 # Round-end evidence refresh on the GPU box (run through gpurun):  scripts/refresh_profiles.sh r01 "cfg3 cfg4 cfg5"
 # rocprofv3 kernel trace + separate FETCH_SIZE / WRITE_SIZE passes per workload -> text summaries and traffic JSON,
 # then the bench lines (which pick the fresh traffic up).  Everything lands in gpurun_out/final/ (copy to profiles/).
-TAG=${1:-r02}; WLS=${2:-cfg3 cfg4 cfg5}
+TAG=${1:-r03}; WLS=${2:-cfg3 cfg4 cfg5}
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
 F=$R/gpurun_out/final; mkdir -p $F
 for wl in $WLS; do
