@@ -122,7 +122,7 @@ struct csv_ctx {
     Buf reads_off, r_start, r_end, r_primary, r_id, s_start, s_end, s_idp, cmax, cfirst, bfirst, span_len, maxlen, gt_over, gt_huge, gt_pool, contig_len;
     Buf ro_runs, ro_table;
     // stand-alone
-    Buf sqrt_tab, rcp_tab, cipk_tab, cnt;
+    Buf sqrt_tab, rcp_tab, cipk_tab, cnt, rstate;
     Buf gs_chrom, gs_perm0, gs_perm1, gs_hist, gs_tot;          // general reads sort (fallback), allocated on first use
     Buf flush;                                                   // csv_cache_flush scratch
     // rebuild step (slices of `arena_rb`)
@@ -358,7 +358,7 @@ int csv_ctx_create(int device_id, csv_ctx** out)
             else (void)hipHostFree(hf);
         }
     }
-    if (reserve(c, c->cnt, sizeof(DevCounters)) || pin_reserve(c, 1 << 20) || sqrt_table(c, SQRT_TAB)) {
+    if (reserve(c, c->cnt, sizeof(DevCounters)) || reserve(c, c->rstate, sizeof(ReadsState)) || pin_reserve(c, 1 << 20) || sqrt_table(c, SQRT_TAB)) {
         delete c;
         return CSV_E_HIP;
     }
@@ -371,7 +371,7 @@ void csv_ctx_destroy(csv_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    Buf* own[] = {&c->sqrt_tab, &c->rcp_tab, &c->cipk_tab, &c->cnt, &c->gs_chrom, &c->gs_perm0, &c->gs_perm1, &c->gs_hist, &c->gs_tot, &c->flush};
+    Buf* own[] = {&c->sqrt_tab, &c->rcp_tab, &c->cipk_tab, &c->cnt, &c->rstate, &c->gs_chrom, &c->gs_perm0, &c->gs_perm1, &c->gs_hist, &c->gs_tot, &c->flush};
     for (Buf* b : own) if (b->p) (void)hipFree(b->p);
     if (c->arena.base) (void)hipFree(c->arena.base);
     if (c->arena_rb.base) (void)hipFree(c->arena_rb.base);
@@ -625,6 +625,7 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
     c->copies_pending = true;                               // run_impl orders the kernels behind the two events
     // reads table: its own stream (side[2] runs the reads_order / prefix-max kernels behind it)
     hipStream_t sr = c->side[2];
+    HIP_TRY(c, hipMemsetAsync(c->rstate.p, 0, sizeof(ReadsState), st));
     if (have_tab) {
         HIP_TRY(c, hipStreamWaitEvent(sr, c->ev_init, 0));
         HIP_TRY(c, hipMemcpyAsync(c->reads_off.p, in->reads_off, (size_t)(in->n_chrom + 1) * 8, hipMemcpyHostToDevice, sr));
@@ -695,7 +696,7 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
             B.ro_gap = env_int("CSV_READS_GAP", 1000000);      // (tests shrink it together with their task regions)
         }
     }
-    B.sqrt_tab = dp<double>(c->sqrt_tab); B.rcp_tab = dp<double>(c->rcp_tab); B.cipk_tab = dp<float>(c->cipk_tab); B.cnt = dp<DevCounters>(c->cnt);
+    B.sqrt_tab = dp<double>(c->sqrt_tab); B.rcp_tab = dp<double>(c->rcp_tab); B.cipk_tab = dp<float>(c->cipk_tab); B.cnt = dp<DevCounters>(c->cnt); B.rs = dp<ReadsState>(c->rstate);
     c->n_sig_host = in->n_sig;
     c->n_reads = R;
     c->uploaded = true;
@@ -785,6 +786,7 @@ int run_impl(csv_ctx* c, csv_run_stats* stats)
         // the packed table of an upload does not change between runs: a resident re-run keeps it (csv_batch_option)
         const bool keep = c->reads_ready && c->reuse_reads && !stats;
         if (!keep) {
+            HIP_TRY(c, hipMemsetAsync(c->rstate.p, 0, sizeof(ReadsState), s2));       // (the stage starts over)
             if (B.ro_mode == 2) {
                 const int rc = general_reads_sort(c, s2);
                 if (rc) return rc;
@@ -929,6 +931,11 @@ int read_counters(csv_ctx* c)
         HIP_TRY(c, hipMemcpyAsync(c->h_pin, c->cnt.p, sizeof(DevCounters), hipMemcpyDeviceToHost, st));
         HIP_TRY(c, hipStreamSynchronize(st));
         memcpy(&c->h_cnt, c->h_pin, sizeof(DevCounters));
+        {   // the reads-order state of the upload lives outside the per-run counters
+            ReadsState rs{};
+            HIP_TRY(c, hipMemcpy(&rs, c->rstate.p, sizeof rs, hipMemcpyDeviceToHost));
+            c->h_cnt.n_runs = rs.n_runs; c->h_cnt.ro_state = rs.ro_state;
+        }
         if (getenv("CSV_DEBUG") || getenv("CSV_DEBUG_COUNTERS"))
             fprintf(stderr, "[csv] counters: clusters %d items %d calls %d error %d | reads: mode %d runs %d state %d | gt_over %d gt_huge %d tra_huge %d\n",
                     c->h_cnt.n_clusters, c->h_cnt.n_items, c->h_cnt.n_calls, c->h_cnt.error, c->B.ro_mode, c->h_cnt.n_runs, c->h_cnt.ro_state,

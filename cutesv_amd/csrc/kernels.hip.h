@@ -104,6 +104,10 @@ struct DevCounters {          // one small struct in device memory, zeroed at th
     int tra_ticket;
 };
 enum { RO_REORDER = 0, RO_IDENTITY = 1, RO_NEED_GENERAL = 2 };
+// What the reads-order stage found out about the reads table of the UPLOAD: unlike DevCounters it is not zeroed by every run (a
+// resident re-run that keeps the packed table - CSV_OPT_REUSE_READS_ORDER - must still see that the table needed the general
+// sort); zeroed at upload and whenever the stage is run again.
+struct ReadsState { int n_runs; int ro_state; };
 
 // A position / length column as the caller sent it: int64, or int32 (CSV_IN_SIG_I32 / CSV_IN_READS_I32: a genome's coordinates
 // fit 31 bits) - consumed as it is, never widened into a second copy.  The pointer test is wave-uniform (kernel argument).
@@ -194,6 +198,7 @@ struct DevBatch {
     const double*  rcp_tab;          // 1.0 / n, correctly rounded (same range): exact division by small integers through div_by (below)
     const float*   cipk_tab;         // 1.96 / (n * pow(n, 0.5)) as float: the approximate cal_CIPOS of the register tier
     DevCounters*   cnt;
+    ReadsState*    rs;
 };
 
 // ------------------------------------------------------------------------------------ small helpers
@@ -2286,7 +2291,12 @@ __global__ __launch_bounds__(256) void k_publish(DevBatch B, PublishArgs P)
 {
     const i64 tid = (i64)blockIdx.x * 256 + threadIdx.x, nth = (i64)gridDim.x * 256;
     const i64 nc = B.cnt->n_calls, ns = B.cnt->n_support;
-    if (tid < (i64)(sizeof(DevCounters) / 4)) ((int*)P.h_cnt)[tid] = ((const int*)B.cnt)[tid];
+    if (tid < (i64)(sizeof(DevCounters) / 4)) {            // (the reads-order state of the upload travels in the counters' slots)
+        int v = ((const int*)B.cnt)[tid];
+        if (B.rs && tid == (i64)(offsetof(DevCounters, n_runs) / 4)) v = B.rs->n_runs;
+        if (B.rs && tid == (i64)(offsetof(DevCounters, ro_state) / 4)) v = B.rs->ro_state;
+        ((int*)P.h_cnt)[tid] = v;
+    }
     for (i64 k = tid; k < P.n_seg; k += nth) P.h_seg_err[k] = B.seg_err[k];
     if (nc > P.cap_calls || ns > P.cap_support) return;
     for (i64 i = tid; i < nc; i += nth) {
@@ -2355,7 +2365,7 @@ __global__ __launch_bounds__(256) void k_reads_runs(DevBatch B)
         const u64 mk = __ballot(st);
         if (mk) {                                          // wave-aggregated append (order is restored by k_reads_plan)
             int slot = 0;
-            if (lane_id() == 0) slot = atomicAdd(&B.cnt->n_runs, __popcll(mk));
+            if (lane_id() == 0) slot = atomicAdd(&B.rs->n_runs, __popcll(mk));
             slot = __builtin_amdgcn_readfirstlane(slot) + __popcll(mk & lanemask_lt());
             if (st && slot < B.ro_cap) B.ro_runs[slot] = (int)i;
         }
@@ -2397,10 +2407,10 @@ template <class T> __device__ __forceinline__ void lds_ranksort(T* K, T* Tmp, in
 __global__ __launch_bounds__(RP_THREADS) void k_reads_plan(DevBatch B)
 {
     extern __shared__ __attribute__((aligned(16))) char rp_smem[];
-    const int n_found = B.cnt->n_runs;
+    const int n_found = B.rs->n_runs;
     // + one start per chromosome block (an empty block repeats its neighbour's start: duplicates are dropped below)
     const int n_raw = n_found + B.n_chrom;
-    if (n_found > B.ro_cap || n_raw > B.ro_cap) { if (threadIdx.x == 0) B.cnt->ro_state = RO_NEED_GENERAL; return; }
+    if (n_found > B.ro_cap || n_raw > B.ro_cap) { if (threadIdx.x == 0) B.rs->ro_state = RO_NEED_GENERAL; return; }
     int P = 1;
     while (P < n_raw) P <<= 1;
     u64* K = (u64*)rp_smem;                    // P sort keys
@@ -2437,7 +2447,7 @@ __global__ __launch_bounds__(RP_THREADS) void k_reads_plan(DevBatch B)
     if (threadIdx.x == 0) pos[s_n] = (int)B.n_reads;
     __syncthreads();
     const int n = s_n;
-    if (threadIdx.x == 0) B.cnt->n_runs = n;                 // (k_reads_gather walks the table)
+    if (threadIdx.x == 0) B.rs->n_runs = n;                 // (k_reads_gather walks the table)
     P = 1;
     while (P < n) P <<= 1;
     __syncthreads();
@@ -2469,8 +2479,8 @@ __global__ __launch_bounds__(RP_THREADS) void k_reads_plan(DevBatch B)
         }
     }
     __syncthreads();
-    if (s_bad) { if (threadIdx.x == 0) B.cnt->ro_state = RO_NEED_GENERAL; return; }
-    if (!s_moved) { if (threadIdx.x == 0) B.cnt->ro_state = RO_IDENTITY; return; }
+    if (s_bad) { if (threadIdx.x == 0) B.rs->ro_state = RO_NEED_GENERAL; return; }
+    if (!s_moved) { if (threadIdx.x == 0) B.rs->ro_state = RO_IDENTITY; return; }
     // exclusive scan of the lengths in start order -> destination offsets
     for (int b0 = 0; b0 < n; b0 += RP_THREADS) {
         const int q = b0 + threadIdx.x;
@@ -2488,12 +2498,12 @@ __global__ __launch_bounds__(RP_THREADS) void k_reads_plan(DevBatch B)
         if (threadIdx.x == RP_THREADS - 1) s_carry = off + inc;
         __syncthreads();
     }
-    if (threadIdx.x == 0) B.cnt->ro_state = RO_REORDER;
+    if (threadIdx.x == 0) B.rs->ro_state = RO_REORDER;
 }
 
 // (a batch whose reads table turned out to need the general sort is run again by the host: nothing downstream of the
 // reads_order stage does any work in the first attempt)
-__device__ __forceinline__ bool reads_pending(const DevBatch& B) { return B.ro_mode == 1 && B.cnt->ro_state == RO_NEED_GENERAL; }
+__device__ __forceinline__ bool reads_pending(const DevBatch& B) { return B.ro_mode == 1 && B.rs->ro_state == RO_NEED_GENERAL; }
 
 // stores of one packed row (RN: the caller's columns are int32)
 template <bool RN> __device__ __forceinline__ void sread_store(const DevBatch& B, i64 x, i64 st, i64 en, int idp)
@@ -2515,10 +2525,10 @@ template <bool RN> __global__ __launch_bounds__(256) void k_reads_gather(DevBatc
     const i64 span = (i64)blockIdx.x * 4 + wv, d0 = span * 512;
     if (d0 >= B.n_reads) return;
     const i64 d1 = d0 + 512 < B.n_reads ? d0 + 512 : B.n_reads;
-    const bool by_perm = B.ro_mode == 2, by_runs = B.ro_mode == 1 && B.cnt->ro_state == RO_REORDER;
+    const bool by_perm = B.ro_mode == 2, by_runs = B.ro_mode == 1 && B.rs->ro_state == RO_REORDER;
     int q = 0, n = 0;
     if (by_runs) {
-        n = B.cnt->n_runs;
+        n = B.rs->n_runs;
         int lo = 0, hi = n;                                 // last run with destination begin <= d0
         while (hi - lo > 1) {
             const int step = (hi - lo + 63) / 64;

@@ -815,6 +815,34 @@ def test_whole_parse_read_on_the_gpu(ctx):
         assert_parse_case(case, lambda *a, **k: extract.cigar_signatures(ctx, *a, **k), lambda enc, **k: extract.split_signatures(ctx, enc, **k))
 
 
+def test_resident_reruns_keep_the_reads_order_state(ctx):
+    """upload / run / run / download on a reads table in RANDOM order inside every block: the first run finds out that the
+    table needs the general sort; a re-run that keeps the packed table of the upload (CSV_OPT_REUSE_READS_ORDER) must still
+    know, and the download must still take the fallback - found by scripts/stress_gpu.py, where the second run genotyped
+    from a table that had never been written"""
+    import dataclasses
+    rng = np.random.default_rng(3)
+    st = synth.small_mixed(seed=70115, n_sites=40, coverage=20, genotype=True)
+    perm = np.arange(st.n_reads)
+    for c in range(len(st.chroms)):
+        lo, hi = int(st.reads_off[c]), int(st.reads_off[c + 1])
+        perm[lo:hi] = lo + rng.permutation(hi - lo)
+    st = dataclasses.replace(st, r_start=st.r_start[perm], r_end=st.r_end[perm], r_primary=st.r_primary[perm], r_id=st.r_id[perm])
+    p = Params.ont(genotype=True)
+    hb = st.host_batch(st.tasks(), p)
+    want = _oracle().cluster_batch(hb, per_sig=True).trimmed()
+    for reuse in (1, 0):
+        ctx.option(1, reuse)
+        ctx.upload(hb, per_sig=True)
+        ctx.run(); ctx.run(); ctx.run()
+        got = ctx.download(per_sig=True).trimmed()
+        assert ctx.last_reads_mode() == 2
+        assert_soa_equal(got, want, store=st, set_order_segments=())
+        ctx.run()                                              # and after the fallback: the general sort's table is kept
+        assert_soa_equal(ctx.download(per_sig=True).trimmed(), want, store=st, set_order_segments=())
+    ctx.option(1, 1)
+
+
 def test_single_pipe_on_the_gpu(ctx):
     """one extraction task (main script :697-743) with the HIP CIGAR scan and split-read analysis: candidates and reads table
     rows equal the reference's single_pipe"""
