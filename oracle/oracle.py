@@ -64,7 +64,17 @@ def cluster_tasks_mt(store, tasks, params, threads):
     lib()
     jobs = []
     for t in tasks:
-        hb = store.host_batch([t], params).widened()
+        hb = store.host_batch([t], params)
+        if hb.r_start is not None and t[0] != "TRA":
+            # a task reads its own chromosome's block of the reads table and nothing else (INDEL:52-58)
+            ci = store.chroms.index(t[1])
+            lo, hi = int(store.reads_off[ci]), int(store.reads_off[ci + 1])
+            off = np.zeros(len(store.chroms) + 1, np.int64)
+            off[ci + 1:] = hi - lo
+            hb = _abi.HostBatch(hb.segments, hb.a, hb.b, hb.read_id, hb.aux, n_chrom=len(store.chroms), reads_off=off,
+                                r_start=hb.r_start[lo:hi], r_end=hb.r_end[lo:hi], r_primary=hb.r_primary[lo:hi],
+                                r_id=hb.r_id[lo:hi])
+        hb = hb.widened()
         n = hb.n_sig
         res = _abi.HostResult(n, max(64, n // 4 + 16), max(64, n + 16), per_sig=False, n_seg=1)
         jobs.append((hb, res))
