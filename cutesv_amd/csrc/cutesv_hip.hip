@@ -120,7 +120,7 @@ struct csv_ctx {
     Buf sc_k, sc_x, sc_v1, sc_v2, sc_v3, sc_v4, sc_v5;
     Buf o_rec, o_supsig, o_suprid, allele_id;
     Buf reads_off, r_start, r_end, r_primary, r_id, s_start, s_end, s_idp, cmax, cfirst, bfirst, span_len, maxlen, gt_over, gt_huge, gt_pool, contig_len;
-    Buf ro_runs, ro_table;
+    Buf ro_tcnt, ro_ent, ro_table;
     // stand-alone
     Buf sqrt_tab, rcp_tab, cipk_tab, cnt, rstate;
     Buf gs_chrom, gs_perm0, gs_perm1, gs_hist, gs_tot;          // general reads sort (fallback), allocated on first use
@@ -139,6 +139,7 @@ struct csv_ctx {
     volatile int* h_flag = nullptr;
     int*          d_flag = nullptr;
     int           run_seq = 0;
+    int           upload_seq0 = 0;          // run_seq when the resident batch was uploaded: later sequence numbers are runs of it
     int           n_cu = 256;              // compute units of the device
     // host copies
     std::vector<csv_segment> h_seg;
@@ -424,6 +425,7 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
     c->uploaded = c->ran = false;
     c->reads_general = false;
     c->reads_ready = false;
+    c->upload_seq0 = c->run_seq;                      // (tier answers of earlier sequence numbers belong to other columns)
     HIP_TRY(c, hipSetDevice(c->device));
     if (in->n_seg < 0 || in->n_sig < 0 || (in->n_seg > 0 && !in->seg)) return fail(c, CSV_E_INVALID, "bad batch header");
     const int S = in->n_seg;
@@ -523,7 +525,7 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
         PL(r_start, R * cw); PL(r_end, R * cw); PL(r_primary, R); PL(r_id, R * 4);
         PL(s_start, R * cw); PL(s_end, R * cw); PL(s_idp, R * 4); PL(cmax, (div_up(R, 64) + 8) * 8); PL(span_len, (div_up(R, 512) + 8) * 8); PL(cfirst, (div_up(R, 64) + 8) * 8); PL(bfirst, (div_up(R, 4096) + 8) * 8);
         PL(maxlen, (in->n_chrom + 1) * 8);
-        if (reorder) { PL(ro_runs, RO_CAP * 4); PL(ro_table, RO_CAP * 16); }
+        if (reorder) { PL(ro_tcnt, (div_up(R, RO_TILE) + 1) * 4); PL(ro_ent, (div_up(R, RO_TILE) + 1) * (size_t)RO_TCAP * 16); PL(ro_table, RO_CAP * 16); }
     }
 #undef PL
     {
@@ -692,7 +694,7 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
         B.gt_pool = dp<int>(c->gt_pool); B.gt_pool_n = pool_n;
         B.ro_mode = reorder ? 1 : 0;
         if (reorder) {
-            B.ro_runs = dp<int>(c->ro_runs); B.ro_table = dp<int4>(c->ro_table); B.ro_cap = RO_CAP;
+            B.ro_tcnt = dp<int>(c->ro_tcnt); B.ro_ent = dp<int4>(c->ro_ent); B.ro_table = dp<int4>(c->ro_table); B.ro_cap = RO_CAP;
             B.ro_gap = env_int("CSV_READS_GAP", 1000000);      // (tests shrink it together with their task regions)
         }
     }
@@ -746,10 +748,11 @@ int run_impl(csv_ctx* c, csv_run_stats* stats)
     constexpr int LDS_SMALL = refine_lds_bytes<64>();
     constexpr int LDS_MID = refine_lds_bytes<256>();
     constexpr int LDS_BIG = refine_lds_bytes<2048>();
-    constexpr int LDS_PLAN = RO_CAP * 24 + 64;
+    constexpr int LDS_PLAN = rp_lds_bytes(RO_CAP);
     if (!c->lds_set) {
         HIP_TRY(c, hipFuncSetAttribute((const void*)k_refine<256, 2048, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BIG));
-        HIP_TRY(c, hipFuncSetAttribute((const void*)k_reads_plan, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_PLAN));
+        HIP_TRY(c, hipFuncSetAttribute((const void*)k_reads_plan<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_PLAN));
+        HIP_TRY(c, hipFuncSetAttribute((const void*)k_reads_plan<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_PLAN));
         c->lds_set = true;
     }
     int ev = 0;
@@ -772,7 +775,15 @@ int run_impl(csv_ctx* c, csv_run_stats* stats)
     // (forking costs a few event waits: only worth it when the batch has pair types or genotyping)
     const bool do_gt = c->any_genotype && B.n_reads > 0;
     const bool fork = !stats && !dbg && !getenv("CSV_NO_FORK") && (c->any_pair || do_gt || getenv("CSV_FORK_ALWAYS"));
-    hipStream_t sB = fork ? c->side[0] : st, sC = fork ? c->side[1] : st, sD = fork ? c->side[2] : st;
+    // A genotyping batch has two producer chains - clustering (k_chain_count .. k_emit) and the reads stage - that meet in
+    // k_genotype.  A wait across queues costs 6-11 us when the event fires late and next to nothing when it fired long ago,
+    // so the LONGER chain stays on the main stream together with the genotype kernels and the shorter one is forked off:
+    // its completion event has long fired when the main stream gets there.  (Reads dominate a 30x HiFi genome, clustering a
+    // 90x all-types one.)  `st` is the stream of the clustering chain from here on, `sM` the main stream.
+    hipStream_t sM = c->stream;
+    const bool swap = fork && do_gt && !c->copies_pending && B.n_reads > 4 * W && W > 0 && !getenv("CSV_NO_SWAP");
+    if (swap) st = c->side[2];
+    hipStream_t sB = fork ? c->side[0] : st, sC = fork ? c->side[1] : st, sD = swap ? sM : (fork ? c->side[2] : st);
 #define LAUNCH_ON(strm, name, kern, grid, block, lds, ...)                             \
     do {                                                                               \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, strm, __VA_ARGS__);      \
@@ -785,14 +796,18 @@ int run_impl(csv_ctx* c, csv_run_stats* stats)
         const bool rn = B.r_start.p32 != nullptr;
         // the packed table of an upload does not change between runs: a resident re-run keeps it (csv_batch_option)
         const bool keep = c->reads_ready && c->reuse_reads && !stats;
-        if (!keep) {
-            HIP_TRY(c, hipMemsetAsync(c->rstate.p, 0, sizeof(ReadsState), s2));       // (the stage starts over)
+        if (!keep) {                                      // (k_reads_plan leaves a state on every path; nothing to reset)
             if (B.ro_mode == 2) {
                 const int rc = general_reads_sort(c, s2);
                 if (rc) return rc;
             } else if (B.ro_mode == 1) {
-                hipLaunchKernelGGL(k_reads_runs, dim3(div_up(B.n_reads, RO_TILE)), dim3(256), 0, s2, B);
-                hipLaunchKernelGGL(k_reads_plan, dim3(1), dim3(RP_THREADS), LDS_PLAN, s2, B);
+                if (rn) {
+                    hipLaunchKernelGGL(k_reads_runs<true>, dim3(div_up(B.n_reads, RO_TILE)), dim3(256), 0, s2, B);
+                    hipLaunchKernelGGL(k_reads_plan<true>, dim3(1), dim3(RP_THREADS), LDS_PLAN, s2, B);
+                } else {
+                    hipLaunchKernelGGL(k_reads_runs<false>, dim3(div_up(B.n_reads, RO_TILE)), dim3(256), 0, s2, B);
+                    hipLaunchKernelGGL(k_reads_plan<false>, dim3(1), dim3(RP_THREADS), LDS_PLAN, s2, B);
+                }
             }
         }
         DBG("reads_order");
@@ -810,21 +825,22 @@ int run_impl(csv_ctx* c, csv_run_stats* stats)
         return CSV_OK;
     };
     if (c->copies_pending) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_copy[0], 0));       // positions, lengths, INV / TRA words
-    // (not in a one-shot call: the kernels then queue behind a millisecond of column copies, the answer would come too late)
-    const bool peek = c->h_flag && !c->copies_pending && !getenv("CSV_NO_PEEK");
-    B.host_flag = peek ? c->d_flag : nullptr;
+    B.host_flag = (c->h_flag && !getenv("CSV_NO_PEEK")) ? c->d_flag : nullptr;
     B.run_seq = ++c->run_seq;
     if (W > 0) {
         const int nb = div_up(W, CH_TILE);
-        if (B.a.p32) LAUNCH("chain_count", k_chain_count<true>, nb, 256, 0, B);
-        else LAUNCH("chain_count", k_chain_count<false>, nb, 256, 0, B);
-        if (fork && do_gt) {                              // reads order + prefix max: independent of the clustering kernels
-            HIP_TRY(c, hipEventRecord(c->ev_init, st));   // (after the counters were zeroed)
-            HIP_TRY(c, hipStreamWaitEvent(sD, c->ev_init, 0));
+        if (fork && do_gt) {
+            // reads order + pack: independent of the clustering kernels.  Either chain waits only for whatever ran before on
+            // the main stream (the previous run's genotype / publish kernels read what this run rewrites).  The stage's
+            // verdict on the table goes to the upload's state, not to the run's counters (which k_chain_count zeroes).
+            HIP_TRY(c, hipEventRecord(c->ev_init, sM));
+            HIP_TRY(c, hipStreamWaitEvent(swap ? st : sD, c->ev_init, 0));
             const int rc = reads_stage(sD);
             if (rc) return rc;
-            HIP_TRY(c, hipEventRecord(c->ev_aux[2], sD));
+            if (!swap) HIP_TRY(c, hipEventRecord(c->ev_aux[2], sD));
         }
+        if (B.a.p32) LAUNCH("chain_count", k_chain_count<true>, nb, 256, 0, B);
+        else LAUNCH("chain_count", k_chain_count<false>, nb, 256, 0, B);
         LAUNCH("chain_apply", k_chain_apply, div_up(nb, 4), 256, 0, B);
         if (B.per_sig) hipLaunchKernelGGL(k_chain_ids, dim3(nb), dim3(256), 0, st, B);      // (optional outputs; timed with whatever follows)
         if (c->copies_pending) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_copy[1], 0));   // read ids, INS sequence lengths
@@ -837,28 +853,26 @@ int run_impl(csv_ctx* c, csv_run_stats* stats)
         int g_iw = div_up(B.cap_items, 4) < g_res ? div_up(B.cap_items, 4) : g_res;
         g_iw = env_int("CSV_IW_GRID", g_iw);              // tuning aid
         if (g_iw < 1) g_iw = 1;
-        if (fork) {
+        // The tiers above 64 signatures usually have nothing to do (a 30x genome has no such cluster) and an empty launch
+        // still costs ~4 us of the stream.  k_chain_apply leaves {run sequence, items above 64} in a page-locked word; a
+        // run whose upload has already been through it reads the answer of that earlier run (same columns, same parameters:
+        // same tiers) and launches only what has work.  The first run of an upload, and every one-shot call, launches all.
+        bool need_big = true;
+        if (B.host_flag) {
+            const unsigned long long w = *(volatile unsigned long long*)c->h_flag;
+            if ((int)((unsigned)(w >> 32) - (unsigned)c->upload_seq0) > 0 && (int)((unsigned)(w >> 32) - (unsigned)B.run_seq) < 0) need_big = (unsigned)w > 0;
+        }
+        if (getenv("CSV_FORCE_TIERS")) need_big = true;
+        const bool side_b = fork && need_big, side_c = fork && c->any_pair;
+        if (side_b || side_c) {
             HIP_TRY(c, hipEventRecord(c->ev_sel, st));
-            HIP_TRY(c, hipStreamWaitEvent(sB, c->ev_sel, 0));
-            if (c->any_pair) HIP_TRY(c, hipStreamWaitEvent(sC, c->ev_sel, 0));
+            if (side_b) HIP_TRY(c, hipStreamWaitEvent(sB, c->ev_sel, 0));
+            if (side_c) HIP_TRY(c, hipStreamWaitEvent(sC, c->ev_sel, 0));
         }
         if (B.a.p32) LAUNCH("refine_indel_wave", k_refine_indel_wave<true>, g_iw, 256, 0, B);
         else LAUNCH("refine_indel_wave", k_refine_indel_wave<false>, g_iw, 256, 0, B);
         if (c->any_pair) LAUNCH_ON(sC, "refine_wave", (k_refine<64, 64, false>), g_small, 64, LDS_SMALL, B, 0, 64);
         else HIP_TRY(c, mark());
-        // The tiers above 64 signatures usually have nothing to do (a 30x genome has no such cluster) and an empty launch
-        // still costs ~4 us of the stream: while the wavefront tier runs, peek at the two page-locked words k_chain_apply
-        // wrote.  The GPU never waits for this (the peek ends long before k_refine_indel_wave does); no answer within
-        // the bound -> launch both, as if there were no peek.
-        bool need_big = true;
-        if (peek) {
-            const auto t0 = std::chrono::steady_clock::now();
-            for (int spin = 0;; spin++) {
-                if (c->h_flag[0] == B.run_seq) { need_big = c->h_flag[1] > 0; break; }
-                if ((spin & 63) == 63 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(400)) break;
-                __builtin_ia32_pause();
-            }
-        }
         int g_mid = B.cap_items < 8192 ? B.cap_items : 8192;
         if (g_mid < 1) g_mid = 1;
         int g_big = B.cap_items < 512 ? B.cap_items : 512;
@@ -867,15 +881,18 @@ int run_impl(csv_ctx* c, csv_run_stats* stats)
             LAUNCH_ON(sB, "refine_mid", (k_refine<64, 256, true>), g_mid, 64, LDS_MID, B, 64, 256);
             LAUNCH_ON(sB, "refine_block", (k_refine<256, 2048, true>), g_big, 256, LDS_BIG, B, 256, 0x7fffffff);
         } else { HIP_TRY(c, mark()); HIP_TRY(c, mark()); }
-        if (fork) {                                       // join
-            HIP_TRY(c, hipEventRecord(c->ev_aux[0], sB));
-            HIP_TRY(c, hipStreamWaitEvent(st, c->ev_aux[0], 0));
-            if (c->any_pair) { HIP_TRY(c, hipEventRecord(c->ev_aux[1], sC)); HIP_TRY(c, hipStreamWaitEvent(st, c->ev_aux[1], 0)); }
-        }
+        if (side_b) { HIP_TRY(c, hipEventRecord(c->ev_aux[0], sB)); HIP_TRY(c, hipStreamWaitEvent(st, c->ev_aux[0], 0)); }
+        if (side_c) { HIP_TRY(c, hipEventRecord(c->ev_aux[1], sC)); HIP_TRY(c, hipStreamWaitEvent(st, c->ev_aux[1], 0)); }
         LAUNCH("items_scan", k_items_scan, B.cap_items / IS_CHUNK + 1, 64 * IS_NW, 0, B);
         LAUNCH("emit", k_emit, 2048, 256, 0, B);
+        if (swap) {                                       // the clustering chain joins the main stream
+            HIP_TRY(c, hipEventRecord(c->ev_aux[2], st));
+            HIP_TRY(c, hipStreamWaitEvent(sM, c->ev_aux[2], 0));
+            st = sM;
+        }
         if (do_gt) {
-            if (fork) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_aux[2], 0));
+            if (swap) {}
+            else if (fork) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_aux[2], 0));
             else { HIP_TRY(c, hipStreamWaitEvent(st, c->ev_reads, 0)); const int rc = reads_stage(st); if (rc) return rc; }
             if (B.r_start.p32) {
                 hipLaunchKernelGGL((k_genotype<1024, 4, false, true>), dim3(2048), dim3(256), 0, st, B);
@@ -934,7 +951,7 @@ int read_counters(csv_ctx* c)
         {   // the reads-order state of the upload lives outside the per-run counters
             ReadsState rs{};
             HIP_TRY(c, hipMemcpy(&rs, c->rstate.p, sizeof rs, hipMemcpyDeviceToHost));
-            c->h_cnt.n_runs = rs.n_runs; c->h_cnt.ro_state = rs.ro_state;
+            c->h_cnt.n_runs = rs.n_runs; c->h_cnt.ro_state = rs.ro_state; c->h_cnt.error |= rs.error;
         }
         if (getenv("CSV_DEBUG") || getenv("CSV_DEBUG_COUNTERS"))
             fprintf(stderr, "[csv] counters: clusters %d items %d calls %d error %d | reads: mode %d runs %d state %d | gt_over %d gt_huge %d tra_huge %d\n",

@@ -107,7 +107,7 @@ enum { RO_REORDER = 0, RO_IDENTITY = 1, RO_NEED_GENERAL = 2 };
 // What the reads-order stage found out about the reads table of the UPLOAD: unlike DevCounters it is not zeroed by every run (a
 // resident re-run that keeps the packed table - CSV_OPT_REUSE_READS_ORDER - must still see that the table needed the general
 // sort); zeroed at upload and whenever the stage is run again.
-struct ReadsState { int n_runs; int ro_state; };
+struct ReadsState { int n_runs; int ro_state; int error; int pad; };      // error: ERR_* bits of the table's validation
 
 // A position / length column as the caller sent it: int64, or int32 (CSV_IN_SIG_I32 / CSV_IN_READS_I32: a genome's coordinates
 // fit 31 bits) - consumed as it is, never widened into a second copy.  The pointer test is wave-uniform (kernel argument).
@@ -148,8 +148,8 @@ struct DevBatch {
                                      // {first w, size, segment | svtype << 24 | tier << 28, cluster index inside the tile}
     int            per_sig;          // CSV_IN_PER_SIG: cluster_id / allele_id are produced
     int            end_z;            // the batch's last signature is a (0,0) element (looked up by the host at upload)
-    int*           host_flag;        // page-locked host words {run sequence, work items above 64 signatures}: the host peeks
-    int            run_seq;          // at them while k_refine_indel_wave runs and launches only the tiers that have work
+    int*           host_flag;        // page-locked host word {run sequence << 32 | work items above 64 signatures}: later runs of
+    int            run_seq;          // the same upload launch only the tiers that have work
     int*           seg_err;          // n_seg words of CSV_SEG_* bits
     const int4*    seg_gate;         // per segment {read_count, dropped, svtype, -}: one 16-byte load for the size gate
     const int4*    tile_info;        // per chain tile, built by the host: TILE_REC int4 words (see TILE_REC below)
@@ -184,7 +184,8 @@ struct DevBatch {
     i64*           span_len;         // per span of 512 reads: the longest read ...
     i64*           maxlen;           // ... and per chromosome (k_reads_maxlen): bounds how far before a window a covering read can start
     int            ro_mode;          // 0: caller promised sorted blocks; 1: run-level reorder on the device; 2: general radix sort (fallback)
-    int*           ro_runs;          // run starts found by k_reads_runs (unordered)
+    int*           ro_tcnt;          // per tile of RO_TILE rows: run starts found by k_reads_runs ...
+    int4*          ro_ent;           // ... and their records {row, its start, the start of the row before, out of range}, RO_TCAP per tile
     int4*          ro_table;         // runs in start order: {source begin, length, destination begin, chromosome}
     int            ro_cap;           // capacity of both
     i64            ro_gap;           // a jump of more than this many bases between neighbours also starts a run
@@ -798,13 +799,11 @@ __global__ __launch_bounds__(256) void k_chain_apply(DevBatch B)
     if (tile == ntile - 1 && lane_id() == 63) {             // its running counts now cover the whole batch
         B.cnt->n_clusters = run + (int)own0;
         B.cnt->n_items = bj + n_it; B.cnt->n_items_big = bb; B.cnt->n_items_tiny = bt; B.cnt->n_items_wide = bw;
-        // tell the host whether the tiers above 64 signatures have any work: it peeks at these page-locked words while
-        // the wavefront tier runs and launches k_refine<64,256> / k_refine<256,2048> only then (a missing or late answer
-        // just means that they are launched as before)
-        if (B.host_flag) {
-            __hip_atomic_store(&B.host_flag[1], bb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(&B.host_flag[0], B.run_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
+        // tell the host whether the tiers above 64 signatures have any work - one page-locked word {run sequence, items}: a
+        // later run of the SAME upload (same columns, same parameters: same tiers) launches k_refine<64,256> /
+        // k_refine<256,2048> only then (no answer yet just means that they are launched)
+        if (B.host_flag)
+            __hip_atomic_store((unsigned long long*)B.host_flag, ((unsigned long long)(unsigned)B.run_seq << 32) | (unsigned)bb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -2295,6 +2294,7 @@ __global__ __launch_bounds__(256) void k_publish(DevBatch B, PublishArgs P)
         int v = ((const int*)B.cnt)[tid];
         if (B.rs && tid == (i64)(offsetof(DevCounters, n_runs) / 4)) v = B.rs->n_runs;
         if (B.rs && tid == (i64)(offsetof(DevCounters, ro_state) / 4)) v = B.rs->ro_state;
+        if (B.rs && tid == (i64)(offsetof(DevCounters, error) / 4)) v |= B.rs->error;
         ((int*)P.h_cnt)[tid] = v;
     }
     for (i64 k = tid; k < P.n_seg; k += nth) P.h_seg_err[k] = B.seg_err[k];
@@ -2341,164 +2341,224 @@ __device__ __forceinline__ int chrom_of_read(const DevBatch& B, i64 i, int hint)
 constexpr i64 READ_END_MAX = 1ll << 40;             // ends are doubled in window arithmetic: anything beyond is a broken table
 
 constexpr int RO_TILE = 256 * 8;
+constexpr int RO_TCAP = 8;                          // run starts a tile of RO_TILE rows may hold (more: the general sort)
 // A row starts a run when its start is smaller than its predecessor's (a descent) or jumps ahead by more than ro_gap.
 // The second rule cuts the runs the extraction step glued together: a worker that processed the task regions 3 and then 7
 // of a chromosome leaves them back to back without a descent, although the regions 4-6 (in other workers' files)
 // belong in between; such a seam is at least one task region wide (--batches, 10 Mbp by default), ro_gap is 1 Mbp.
 // The rule is only a heuristic for WHERE to cut - k_reads_plan verifies that the pieces do not interleave once
 // ordered, and anything else goes to the general sort.  (Block starts are added by k_reads_plan.)
-__global__ __launch_bounds__(256) void k_reads_runs(DevBatch B)
+// Every tile keeps its own short list {row, its start, the start of the row before, out of range} + a count: no device
+// atomics (a few hundred appends to ONE counter were a third of this kernel), and k_reads_plan needs no look-up of the
+// starts - its critical path is two round trips.
+template <bool RN> __global__ __launch_bounds__(256) void k_reads_runs(DevBatch B)
 {
-    const i64 base = (i64)blockIdx.x * RO_TILE + (threadIdx.x >> 6) * 512;
-    if (base >= B.n_reads) return;
-    i64 v[8];
+    __shared__ int s_cnt;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    // a lane owns 8 consecutive rows (16-byte loads); the start before its first row comes from the lane to the left
+    const i64 base = (i64)blockIdx.x * RO_TILE + (threadIdx.x >> 6) * 512, i0 = base + lane_id() * 8;
+    if (base < B.n_reads) {
+        i64 v[8];
+        if (i0 + 8 <= B.n_reads) {
+            if constexpr (RN) {
+                const int4 x0 = *(const int4*)(B.r_start.p32 + i0), x1 = *(const int4*)(B.r_start.p32 + i0 + 4);
+                v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+            } else {
 #pragma unroll
-    for (int r = 0; r < 8; r++) { const i64 i = base + r * 64 + lane_id(); v[r] = i < B.n_reads ? B.r_start[i] : INT64_MAX; }
-    i64 carry = (lane_id() == 0 && base > 0) ? B.r_start[base - 1] : INT64_MIN;
+                for (int r = 0; r < 8; r += 2) { const longlong2 x = *(const longlong2*)(B.r_start.p64 + i0 + r); v[r] = x.x; v[r + 1] = x.y; }
+            }
+        } else {
 #pragma unroll
-    for (int r = 0; r < 8; r++) {
-        const i64 i = base + r * 64 + lane_id();
-        i64 prev = wave_shr1_i64(v[r]);
-        if (lane_id() == 0) prev = carry;
-        carry = readlane_i64x(v[r], 63);
-        const bool st = i < B.n_reads && i > 0 && prev != INT64_MIN && (v[r] < prev || v[r] - prev > B.ro_gap);
-        const u64 mk = __ballot(st);
-        if (mk) {                                          // wave-aggregated append (order is restored by k_reads_plan)
-            int slot = 0;
-            if (lane_id() == 0) slot = atomicAdd(&B.rs->n_runs, __popcll(mk));
-            slot = __builtin_amdgcn_readfirstlane(slot) + __popcll(mk & lanemask_lt());
-            if (st && slot < B.ro_cap) B.ro_runs[slot] = (int)i;
+            for (int r = 0; r < 8; r++) v[r] = i0 + r < B.n_reads ? col_at<RN>(B.r_start, i0 + r) : INT64_MAX;
+        }
+        i64 prev = (lane_id() == 0 && base > 0) ? col_at<RN>(B.r_start, base - 1) : INT64_MIN;
+        const i64 left = wave_shr1_i64(v[7]);
+        if (lane_id() != 0) prev = left;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const i64 i = i0 + r;
+            const bool st = i < B.n_reads && i > 0 && prev != INT64_MIN && (v[r] < prev || v[r] - prev > B.ro_gap);
+            if (st) {
+                const int slot = atomicAdd(&s_cnt, 1);
+                const int bad = (v[r] < 0 || v[r] >= (1ll << 32) || prev < 0 || prev >= (1ll << 32)) ? 1 : 0;
+                if (slot < RO_TCAP) B.ro_ent[(i64)blockIdx.x * RO_TCAP + slot] = make_int4((int)i, (int)(unsigned)v[r], (int)(unsigned)prev, bad);
+            }
+            prev = v[r];
         }
     }
+    __syncthreads();
+    if (threadIdx.x == 0) B.ro_tcnt[blockIdx.x] = s_cnt;
 }
 
-// one workgroup: runs by position -> runs by (chromosome, first start, position); disjointness / stability check;
-// destination offsets.  LDS: 16 bytes per run.
+// one workgroup: the tiles' run starts + one start per chromosome block -> runs by (chromosome, first start, position);
+// disjointness / stability check; destination offsets.  Two global round trips (counts + offsets, then the records); everything else is binary searches and
+// short scans over LDS: the tiles' lists arrive in position order and are MERGED with the block starts by rank, and a run is
+// ranked only against the runs of its own chromosome.  (Two 64-bit rank sorts of all runs against all runs were 20 of
+// this kernel's 34 us for the 330 runs of a 30x genome.)  LDS: 36 bytes per run.
 constexpr int RP_THREADS = 1024;
-template <class T> __device__ __forceinline__ void lds_bitonic(T* K, int P)
+// exclusive block scan of one int per thread (RP_THREADS threads); returns the thread's offset, *total = the sum
+__device__ __forceinline__ int rp_block_excl(int v, int* s_w, int* total)
 {
-    for (int k = 2; k <= P; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < P; i += RP_THREADS) {
-                const int x = i ^ j;
-                if (x > i) {
-                    const T a = K[i], b = K[x];
-                    const bool asc = (i & k) == 0;
-                    if ((a > b) == asc) { K[i] = b; K[x] = a; }
-                }
-            }
-            __syncthreads();
-        }
+    const int inc = wave_incl_scan_i32(v);
+    __syncthreads();
+    if (lane_id() == 63) s_w[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    int off = 0, tot = 0;
+    for (int q = 0; q < RP_THREADS / 64; q++) { const int x = s_w[q]; if (q < (int)(threadIdx.x >> 6)) off += x; tot += x; }
+    *total = tot;
+    return off + inc - v;
 }
-// sort of n <= RP_THREADS keys by counting: every thread ranks one key against all others (LDS broadcast reads, no barrier
-// inside) - two barriers instead of the 45 of a 512-key bitonic network, which were 22 of this kernel's 25 us.  T: scratch.
-template <class T> __device__ __forceinline__ void lds_ranksort(T* K, T* Tmp, int n, int P)
-{
-    const int i = threadIdx.x;
-    T mine = i < n ? K[i] : (T)0;
-    int r = 0;
-    if (i < n) for (int j = 0; j < n; j++) { const T o = K[j]; r += (o < mine) || (o == mine && j < i); }
-    __syncthreads();
-    if (i < n) Tmp[r] = mine;
-    __syncthreads();
-    for (int q = threadIdx.x; q < P; q += RP_THREADS) K[q] = q < n ? Tmp[q] : (T)PAD_KEY;
-    __syncthreads();
-}
-__global__ __launch_bounds__(RP_THREADS) void k_reads_plan(DevBatch B)
+// first index in [0, n) with a[i] >= x / > x (a sorted ascending)
+__device__ __forceinline__ int rp_lower(const int* a, int n, int x) { int lo = 0, hi = n; while (lo < hi) { const int mid = (lo + hi) >> 1; if (a[mid] < x) lo = mid + 1; else hi = mid; } return lo; }
+__device__ __forceinline__ int rp_upper(const int* a, int n, int x) { int lo = 0, hi = n; while (lo < hi) { const int mid = (lo + hi) >> 1; if (a[mid] <= x) lo = mid + 1; else hi = mid; } return lo; }
+constexpr int rp_lds_bytes(int cap) { return 9 * (cap + 2) * 4 + 64; }
+template <bool RN> __global__ __launch_bounds__(RP_THREADS) void k_reads_plan(DevBatch B)
 {
     extern __shared__ __attribute__((aligned(16))) char rp_smem[];
-    const int n_found = B.rs->n_runs;
-    // + one start per chromosome block (an empty block repeats its neighbour's start: duplicates are dropped below)
-    const int n_raw = n_found + B.n_chrom;
-    if (n_found > B.ro_cap || n_raw > B.ro_cap) { if (threadIdx.x == 0) B.rs->ro_state = RO_NEED_GENERAL; return; }
-    int P = 1;
-    while (P < n_raw) P <<= 1;
-    u64* K = (u64*)rp_smem;                    // P sort keys
-    u64* Tmp = K + P;                          // rank-sort scratch
-    int* pos = (int*)(Tmp + P);                // run starts by position (+ sentinel)
-    int* len_s = pos + P + 1;                  // lengths in start order, then their exclusive scan
-    __shared__ int s_bad, s_moved, s_carry;
+    const int cap = B.ro_cap, nc = B.n_chrom, tid = threadIdx.x, A = cap + 2;
+    int* fpos = (int*)rp_smem;                 // found run starts: row (ascending), ...
+    unsigned* ffv = (unsigned*)(fpos + A);     // ... its start, the start of the row before it
+    unsigned* fpv = ffv + A;
+    int* off = (int*)(fpv + A);                // reads_off
+    int* kb = off + A;                         // blocks listed on their own (non-empty, not already a found start) before block c
+    int* pos = kb + A;                         // merged, by position (+ sentinel): row, first start, preceding start, chromosome
+    unsigned* fv = (unsigned*)(pos + A);
+    unsigned* pv = fv + A;
+    int* chv = (int*)(pv + A);
+    int* ord = fpos;                           // (after the merge) start order -> merged index
+    int* len_s = (int*)ffv;                    //                   lengths in start order
+    __shared__ int s_bad, s_moved;
     __shared__ int s_w[RP_THREADS / 64];
-    __shared__ int s_n;
-    if (threadIdx.x == 0) { s_bad = 0; s_moved = 0; s_carry = 0; s_n = 0; }
-    for (int i = threadIdx.x; i < P; i += RP_THREADS) {
-        u64 key = PAD_KEY;
-        if (i < n_found) key = (u64)(unsigned)B.ro_runs[i];
-        else if (i < n_raw) { const i64 o = B.reads_off[i - n_found]; key = o < B.n_reads ? (u64)o : PAD_KEY; }
-        K[i] = key;
+    __shared__ unsigned s_last;
+    if (tid == 0) { s_bad = 0; s_moved = 0; }
+    if (nc + 1 > cap) { if (tid == 0) B.rs->ro_state = RO_NEED_GENERAL; return; }
+    // round trip 1: the tiles' counts (eight per thread at a time, issued together), the block offsets, the last start
+    const int n_tiles = (int)((B.n_reads + RO_TILE - 1) / RO_TILE);
+    const int per = (n_tiles + RP_THREADS - 1) / RP_THREADS;
+    const int t0 = tid * per < n_tiles ? tid * per : n_tiles, t1 = t0 + per < n_tiles ? t0 + per : n_tiles;
+    int mine = 0, over = 0;
+    int cnt8[8];                                                // the first eight counts stay in registers for the second pass
+#pragma unroll
+    for (int r = 0; r < 8; r++) cnt8[r] = t0 + r < t1 ? B.ro_tcnt[t0 + r] : 0;
+    for (int c = tid; c <= nc; c += RP_THREADS) off[c] = (int)B.reads_off[c];
+    if (tid == 0) {
+        const i64 l = col_at<RN>(B.r_start, B.n_reads - 1);
+        if (l < 0 || l >= (1ll << 32)) over = 1;
+        s_last = (unsigned)l;
     }
-    __syncthreads();
-    if (n_raw <= RP_THREADS) lds_ranksort(K, Tmp, n_raw, P); else lds_bitonic(K, P);      // by position
-    // distinct positions, compacted in order (flag + block scan; the entries are already sorted)
-    for (int b0 = 0; b0 < P; b0 += RP_THREADS) {
-        const int i = b0 + threadIdx.x;
-        const u64 k = i < P ? K[i] : PAD_KEY;
-        const int f = (i < n_raw && k != PAD_KEY && (i == 0 || K[i - 1] != k)) ? 1 : 0;
-        const int inc = wave_incl_scan_i32(f);
-        if (lane_id() == 63) s_w[threadIdx.x >> 6] = inc;
-        __syncthreads();
-        int off = s_n;
-        for (int q = 0; q < (int)(threadIdx.x >> 6); q++) off += s_w[q];
-        if (f) pos[off + inc - 1] = (int)k;
-        __syncthreads();
-        if (threadIdx.x == RP_THREADS - 1) s_n = off + inc;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) pos[s_n] = (int)B.n_reads;
-    __syncthreads();
-    const int n = s_n;
-    if (threadIdx.x == 0) B.rs->n_runs = n;                 // (k_reads_gather walks the table)
-    P = 1;
-    while (P < n) P <<= 1;
-    __syncthreads();
-    // key (chromosome, first start, rank by position): chromosome 20 bits | start 32 bits | rank 12 bits.  A block start
-    // is always a run start, so a run lies inside one chromosome.
-    for (int i = threadIdx.x; i < P; i += RP_THREADS) {
-        u64 key = PAD_KEY;
-        if (i < n) {
-            const int p = pos[i];
-            const int ch = chrom_of_read(B, p, 0);
-            const i64 st = B.r_start[p];
-            if (st < 0 || st >= (1ll << 32) || ch >= (1 << 20) || n > 4096) atomicOr(&s_bad, 1);
-            key = ((u64)ch << 44) | ((u64)(st & 0xffffffffll) << 12) | (u64)(i & 4095);
+#pragma unroll
+    for (int r = 0; r < 8; r++) { mine += cnt8[r]; over |= cnt8[r] > RO_TCAP; }
+    for (int t = t0 + 8; t < t1; t++) { const int k = B.ro_tcnt[t]; mine += k; over |= k > RO_TCAP; }
+    int n_found;
+    int at = rp_block_excl(mine, s_w, &n_found);               // (its barriers also publish off[], s_bad, s_last)
+    if (over) atomicOr(&s_bad, 1);
+    if (n_found + nc > cap) { if (tid == 0) B.rs->ro_state = RO_NEED_GENERAL; return; }
+    if (CSV_ABL(20)) { if (tid == 0) B.rs->ro_state = RO_IDENTITY; return; }
+    // round trip 2: the run records (a tile's few records in row order; the first record of each of the eight tiles is
+    // fetched up front), and the first / preceding start of this thread's block
+    i64 bf0 = 0, bp0 = 0;
+    if (tid < nc && off[tid] < off[tid + 1]) { bf0 = col_at<RN>(B.r_start, off[tid]); bp0 = off[tid] > 0 ? col_at<RN>(B.r_start, off[tid] - 1) : 0; }
+    int4 e8[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) e8[r] = (cnt8[r] > 0 && !over) ? B.ro_ent[(i64)(t0 + r) * RO_TCAP] : make_int4(0, 0, 0, 0);
+    auto tile_records = [&](int t, int k) {                     // (a tile with several records: ranked among themselves)
+        const int4* E = B.ro_ent + (i64)t * RO_TCAP;
+        for (int j = 0; j < k; j++) {
+            const int4 e = E[j];
+            int r = 0;
+            for (int jj = 0; jj < k; jj++) r += E[jj].x < e.x;
+            fpos[at + r] = e.x; ffv[at + r] = (unsigned)e.y; fpv[at + r] = (unsigned)e.z;
+            if (e.w) atomicOr(&s_bad, 1);
         }
-        K[i] = key;
+    };
+    if (!over) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int k = cnt8[r];
+            if (k == 1) { fpos[at] = e8[r].x; ffv[at] = (unsigned)e8[r].y; fpv[at] = (unsigned)e8[r].z; if (e8[r].w) atomicOr(&s_bad, 1); }
+            else if (k > 1) tile_records(t0 + r, k);
+            at += k;
+        }
+        for (int t = t0 + 8; t < t1; t++) { const int k = B.ro_tcnt[t]; if (k) tile_records(t, k); at += k; }
     }
     __syncthreads();
-    if (n <= RP_THREADS) lds_ranksort(K, Tmp, n, P); else lds_bitonic(K, P);              // by (chromosome, first start, position)
+    if (s_bad) { if (tid == 0) B.rs->ro_state = RO_NEED_GENERAL; return; }
+    // blocks that are not already a found start get an entry of their own
+    if (CSV_ABL(21)) { if (tid == 0) B.rs->ro_state = RO_IDENTITY; return; }
+    int n_kept = 0;
+    for (int c0 = 0; c0 < nc; c0 += RP_THREADS) {
+        const int c = c0 + tid;
+        int keep = 0;
+        if (c < nc && off[c] < off[c + 1]) { const int f = rp_lower(fpos, n_found, off[c]); keep = !(f < n_found && fpos[f] == off[c]); }
+        int tot;
+        const int x = n_kept + rp_block_excl(keep, s_w, &tot);
+        if (c < nc) kb[c] = x;
+        n_kept += tot;
+    }
+    if (tid == 0) kb[nc] = n_kept;
+    const int n = n_found + n_kept;
+    __syncthreads();
+    // merge by rank
+    for (int i = tid; i < n_found; i += RP_THREADS) {
+        const int p = fpos[i], ch = rp_upper(off, nc, p) - 1;  // last block with off <= p: the non-empty one among equals
+        const int m = i + kb[ch + 1];
+        pos[m] = p; fv[m] = ffv[i]; pv[m] = fpv[i]; chv[m] = ch;
+    }
+    for (int c = tid; c < nc; c += RP_THREADS) {
+        const int o = off[c];
+        if (o < off[c + 1] && kb[c + 1] > kb[c]) {
+            i64 f = bf0, pr = bp0;
+            if (c >= RP_THREADS) { f = col_at<RN>(B.r_start, o); pr = o > 0 ? col_at<RN>(B.r_start, o - 1) : 0; }
+            if (f < 0 || f >= (1ll << 32) || pr < 0 || pr >= (1ll << 32)) atomicOr(&s_bad, 1);
+            const int m = kb[c] + rp_lower(fpos, n_found, o);
+            pos[m] = o; fv[m] = (unsigned)f; pv[m] = (unsigned)pr; chv[m] = c;
+        }
+    }
+    if (tid == 0) { pos[n] = (int)B.n_reads; pv[n] = s_last; B.rs->n_runs = n; }
+    __syncthreads();
+    if (CSV_ABL(22)) { if (tid == 0) B.rs->ro_state = RO_IDENTITY; return; }
+    // start order inside every chromosome: a run's rank among the runs of its chromosome by (first start, position)
+    for (int m = tid; m < n; m += RP_THREADS) {
+        const int ch = chv[m], lo = rp_lower(chv, n, ch), hi = rp_upper(chv, n, ch);
+        const unsigned f = fv[m];
+        int r = lo;
+        for (int j = lo; j < hi; j++) { const unsigned o = fv[j]; r += (o < f) || (o == f && j < m); }
+        ord[r] = m;
+    }
+    __syncthreads();
+    if (CSV_ABL(23)) { if (tid == 0) B.rs->ro_state = RO_IDENTITY; return; }
     // consecutive runs of one chromosome must not interleave: last start of the earlier <= first start of the later,
     // and on equality the earlier one must also come first by position (that is what a stable sort would do)
-    for (int q = threadIdx.x; q < n; q += RP_THREADS) {
-        const int i = (int)(K[q] & 4095);
+    for (int q = tid; q < n; q += RP_THREADS) {
+        const int i = ord[q];
         if (i != q) atomicOr(&s_moved, 1);
         len_s[q] = pos[i + 1] - pos[i];
-        if (q > 0 && (K[q] >> 44) == (K[q - 1] >> 44)) {
-            const int ip = (int)(K[q - 1] & 4095);
-            const i64 last_prev = B.r_start[pos[ip + 1] - 1], first = B.r_start[pos[i]];
-            if (last_prev > first || (last_prev == first && ip > i)) atomicOr(&s_bad, 1);
+        if (q > 0) {
+            const int ip = ord[q - 1];
+            if (chv[ip] == chv[i]) {
+                const unsigned last_prev = pv[ip + 1], first = fv[i];      // (the row before the run after ip ends run ip)
+                if (last_prev > first || (last_prev == first && ip > i)) atomicOr(&s_bad, 1);
+            }
         }
     }
     __syncthreads();
-    if (s_bad) { if (threadIdx.x == 0) B.rs->ro_state = RO_NEED_GENERAL; return; }
-    if (!s_moved) { if (threadIdx.x == 0) B.rs->ro_state = RO_IDENTITY; return; }
+    if (s_bad) { if (tid == 0) B.rs->ro_state = RO_NEED_GENERAL; return; }
+    if (!s_moved) { if (tid == 0) B.rs->ro_state = RO_IDENTITY; return; }
     // exclusive scan of the lengths in start order -> destination offsets
+    int carry = 0;
     for (int b0 = 0; b0 < n; b0 += RP_THREADS) {
-        const int q = b0 + threadIdx.x;
+        const int q = b0 + tid;
         const int v = q < n ? len_s[q] : 0;
-        const int inc = wave_incl_scan_i32(v);
-        if (lane_id() == 63) s_w[threadIdx.x >> 6] = inc;
-        __syncthreads();
-        int off = s_carry;
-        for (int k = 0; k < (int)(threadIdx.x >> 6); k++) off += s_w[k];
+        int tot;
+        const int d = carry + rp_block_excl(v, s_w, &tot);
         if (q < n) {
-            const int i = (int)(K[q] & 4095);
-            B.ro_table[q] = make_int4(pos[i], v, off + inc - v, (int)(K[q] >> 44));
+            const int i = ord[q];
+            B.ro_table[q] = make_int4(pos[i], v, d, chv[i]);
         }
-        __syncthreads();
-        if (threadIdx.x == RP_THREADS - 1) s_carry = off + inc;
-        __syncthreads();
+        carry += tot;
     }
-    if (threadIdx.x == 0) B.rs->ro_state = RO_REORDER;
+    if (tid == 0) B.rs->ro_state = RO_REORDER;
 }
 
 // (a batch whose reads table turned out to need the general sort is run again by the host: nothing downstream of the
@@ -2515,67 +2575,102 @@ template <bool RN> __device__ __forceinline__ i64 sread_start(const DevBatch& B,
 template <bool RN> __device__ __forceinline__ i64 sread_end(const DevBatch& B, i64 x) { if constexpr (RN) return B.s_end32[x]; else return B.s_end64[x]; }
 
 // One wavefront per 512 destination rows (8 chunks of 64): source row of every destination row - the row itself (table in
-// order), the run table (whole sorted runs move; a chunk usually lies inside one run) or the permutation of the general
-// sort - then copy + pack, and the chunk's largest end / longest read.  Validates ends and ids, and for a table that was
-// promised sorted the order of the starts.
+// order), the run table (whole sorted runs move; a span usually lies inside one run; k_reads_plan left the span's first run)
+// or the permutation of the general sort - then copy + pack, and the chunk's largest end / longest read.  The 32 loads of
+// a span are issued before the first is consumed (one chunk at a time, the kernel was a chain of eight dependent round
+// trips per wavefront: 3.2 TB/s).  Validates ends and ids, and for a table that was promised sorted the order of the starts.
+constexpr int GA_TAB = 512;                         // runs of the table k_reads_gather keeps in LDS (more: it searches global memory)
 template <bool RN> __global__ __launch_bounds__(256) void k_reads_gather(DevBatch B)
 {
-    if (reads_pending(B)) return;
+    // the run table of a genome (a few hundred runs) is fetched into LDS by every workgroup before it knows whether it is
+    // needed (the buffer exists whenever the mode is 1): one round trip for state + table, then the rows
+    __shared__ int4 s_tab[GA_TAB];
+    int state = RO_IDENTITY, n = 0;
+    if (B.ro_mode == 1) {
+        for (int i = threadIdx.x; i < GA_TAB; i += 256) s_tab[i] = B.ro_table[i];
+        state = B.rs->ro_state; n = B.rs->n_runs;
+        __syncthreads();
+    }
     const int wv = threadIdx.x >> 6, lane = lane_id();
     const i64 span = (i64)blockIdx.x * 4 + wv, d0 = span * 512;
     if (d0 >= B.n_reads) return;
     const i64 d1 = d0 + 512 < B.n_reads ? d0 + 512 : B.n_reads;
-    const bool by_perm = B.ro_mode == 2, by_runs = B.ro_mode == 1 && B.rs->ro_state == RO_REORDER;
-    int q = 0, n = 0;
-    if (by_runs) {
-        n = B.rs->n_runs;
-        int lo = 0, hi = n;                                 // last run with destination begin <= d0
-        while (hi - lo > 1) {
-            const int step = (hi - lo + 63) / 64;
-            const int idx = lo + lane * step;
-            const int t = __popcll(__ballot(idx < hi && (i64)B.ro_table[idx < hi ? idx : lo].z <= d0));
-            const int nlo = lo + (t - 1) * step;
-            int nhi = lo + t * step;
-            if (nhi > hi) nhi = hi;
-            lo = nlo; hi = nhi;
-        }
-        q = lo;
+    if (state == RO_NEED_GENERAL) return;                   // (the host runs the batch again through the general sort)
+    const bool by_perm = B.ro_mode == 2, by_runs = state == RO_REORDER;
+    i64 p[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) p[r] = d0 + r * 64 + lane;
+    if (by_perm) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) { const i64 x = d0 + r * 64 + lane; p[r] = x < d1 ? B.ro_perm[x] : 0; }
+    } else if (by_runs) {
+        // last run with destination begin <= d0 (64 probes per step), then the runs that reach into this span
+        auto walk = [&](auto tab) {
+            int lo = 0, hi = n;
+            while (hi - lo > 1) {
+                const int step = (hi - lo + 63) / 64;
+                const int idx = lo + lane * step;
+                const int t = __popcll(__ballot(idx < hi && (i64)tab[idx < hi ? idx : lo].z <= d0));
+                const int nlo = lo + (t - 1) * step;
+                int nhi = lo + t * step;
+                if (nhi > hi) nhi = hi;
+                lo = nlo; hi = nhi;
+            }
+            for (int qq = lo; qq < n; qq++) {
+                const int4 rn = tab[qq];
+                if ((i64)rn.z >= d1) break;
+#pragma unroll
+                for (int r = 0; r < 8; r++) { const i64 x = d0 + r * 64 + lane; if (x >= rn.z && x < (i64)rn.z + rn.y) p[r] = x + ((i64)rn.x - rn.z); }
+            }
+        };
+        if (n <= GA_TAB) walk((const int4*)s_tab); else walk((const int4*)B.ro_table);
+    }
+    i64 st[8], en[8]; int id[8], pr[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const i64 x = d0 + r * 64 + lane;
+        const i64 pp = x < d1 ? p[r] : p[0];                // (lane 0 of chunk 0 is always a row of the table)
+        st[r] = col_at<RN>(B.r_start, pp); en[r] = col_at<RN>(B.r_end, pp); id[r] = B.r_id[pp]; pr[r] = B.r_primary[pp];
     }
     int hint = 0;
     i64 span_len = 0;
-    for (i64 c0 = d0; c0 < d1; c0 += 64) {
-        const i64 x = c0 + lane;
+    bool bad = false, unsorted = false;
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const i64 c0 = d0 + r * 64, x = c0 + lane;
+        if (c0 >= d1) break;
         const bool in = x < d1;
-        i64 p = x;
-        if (by_perm) p = in ? B.ro_perm[x] : 0;
-        else if (by_runs) {
-            // the runs that intersect this chunk (wave-uniform walk; a lane takes the run its row lies in)
-            const i64 last = (c0 + 63 < d1 ? c0 + 63 : d1 - 1);
-            for (int qq = q; qq < n; qq++) {
-                const int4 rn = B.ro_table[qq];
-                if ((i64)rn.z > last) break;
-                if (x >= rn.z && x < (i64)rn.z + rn.y) p = x + ((i64)rn.x - rn.z);
-                if ((i64)rn.z + rn.y <= last + 1) q = qq + 1;     // the run ends inside the chunk: the next chunk starts with its successor
-            }
-        }
-        i64 vmax = INT64_MIN, vlen = 0, st_own = 0;
+        i64 vmax = INT64_MIN, vlen = 0;
         if (in) {
-            const i64 st = B.r_start[p], en = B.r_end[p];
-            st_own = st;
-            const int id = B.r_id[p], pr = B.r_primary[p];
-            if (en < 0 || en >= READ_END_MAX || st < 0 || id < 0) atomicOr(&B.cnt->error, ERR_KEY_RANGE);
-            sread_store<RN>(B, x, st, en, id | (pr == 1 ? (int)0x80000000 : 0));
-            vmax = en; vlen = en > st ? en - st : 0;
+            bad |= en[r] < 0 || en[r] >= READ_END_MAX || st[r] < 0 || id[r] < 0;
+            sread_store<RN>(B, x, st[r], en[r], id[r] | (pr[r] == 1 ? (int)0x80000000 : 0));
+            vmax = en[r]; vlen = en[r] > st[r] ? en[r] - st[r] : 0;
             if (B.ro_mode == 0) {                           // the caller's promise: every block sorted by start
                 hint = chrom_of_read(B, x, hint);
-                if (x > B.reads_off[hint] && st < (i64)B.r_start[x - 1]) atomicOr(&B.cnt->error, ERR_READS_UNSORTED);
+                if (x > B.reads_off[hint] && st[r] < (i64)B.r_start[x - 1]) unsorted = true;
             }
         }
-        const i64 cm = lane63_i64(wave_incl_max_i64(vmax)), cl = lane63_i64(wave_incl_max_i64(vlen));
-        const i64 f0 = readlane_i64x(st_own, 0);                               // (lane 0 of a chunk is always a row of the table)
+        i64 cm, cl;
+        if constexpr (RN) {                                 // (coordinates of an int32 table: 32-bit reductions)
+            int a = (int)(vmax < 0 ? -1 : vmax), l = (int)vlen, t;
+            t = dpp_i32<0x111, 0xf>(-1, a); a = t > a ? t : a;  t = dpp_i32<0x111, 0xf>(0, l); l = t > l ? t : l;
+            t = dpp_i32<0x112, 0xf>(-1, a); a = t > a ? t : a;  t = dpp_i32<0x112, 0xf>(0, l); l = t > l ? t : l;
+            t = dpp_i32<0x114, 0xf>(-1, a); a = t > a ? t : a;  t = dpp_i32<0x114, 0xf>(0, l); l = t > l ? t : l;
+            t = dpp_i32<0x118, 0xf>(-1, a); a = t > a ? t : a;  t = dpp_i32<0x118, 0xf>(0, l); l = t > l ? t : l;
+            t = dpp_i32<0x142, 0xa>(-1, a); a = t > a ? t : a;  t = dpp_i32<0x142, 0xa>(0, l); l = t > l ? t : l;
+            t = dpp_i32<0x143, 0xc>(-1, a); a = t > a ? t : a;  t = dpp_i32<0x143, 0xc>(0, l); l = t > l ? t : l;
+            cm = __builtin_amdgcn_readlane(a, 63); cl = __builtin_amdgcn_readlane(l, 63);
+            if (cm < 0) cm = INT64_MIN;
+        } else {
+            cm = lane63_i64(wave_incl_max_i64(vmax)); cl = lane63_i64(wave_incl_max_i64(vlen));
+        }
+        const i64 f0 = readlane_i64x(st[r], 0);                                // (lane 0 of a chunk is always a row of the table)
         if (lane == 0) { B.cmax[c0 >> 6] = cm; B.cfirst[c0 >> 6] = f0; if (((c0 >> 6) & 63) == 0) B.bfirst[c0 >> 12] = f0; }
         span_len = cl > span_len ? cl : span_len;
     }
+    // (the verdict on the table belongs to the upload, like the table: the stage may run before the counters of a run are zeroed)
+    if (bad) atomicOr(&B.rs->error, ERR_KEY_RANGE);
+    if (unsorted) atomicOr(&B.rs->error, ERR_READS_UNSORTED);
     if (lane == 0) B.span_len[span] = span_len;             // longest read of the span (k_reads_maxlen reduces them per chromosome)
 }
 

@@ -217,10 +217,10 @@ int csv_cluster_batch(csv_ctx* ctx, const csv_batch_in* in, csv_batch_out* out);
 /* Resident mode: the same work split at the PCIe boundary, so a caller (or bench.py) can
  * keep the columns in HBM and run the kernels repeatedly. */
 int csv_batch_upload(csv_ctx* ctx, const csv_batch_in* in);
-/* csv_batch_run only enqueues work (it returns before the kernels finish; csv_batch_download / csv_ctx_sync wait) - with one
- * exception: in a resident re-run it may busy-wait on the calling thread for up to 400 microseconds for two words the device
- * publishes (whether any cluster has more than 64 signatures), to skip two empty kernel launches; CSV_NO_PEEK=1 in the
- * environment disables that.  csv_cluster_batch never waits this way. */
+/* csv_batch_run only enqueues work (it returns before the kernels finish; csv_batch_download / csv_ctx_sync wait) and never
+ * waits for the device.  A run of an upload that has been run before launches the refine tiers above 64 signatures only if
+ * that earlier run reported clusters of that size (one page-locked word the device writes; same columns and parameters
+ * give the same tiers); CSV_NO_PEEK=1 in the environment launches every tier always. */
 int csv_batch_run(csv_ctx* ctx, csv_run_stats* stats /* nullable */);
 int csv_batch_download(csv_ctx* ctx, csv_batch_out* out);
 int csv_ctx_sync(csv_ctx* ctx);

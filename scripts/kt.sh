@@ -10,3 +10,4 @@ export CSV_BENCH_EXIT_ALARM=15
 echo "kt $WL rc=$?"
 python $R/scripts/rocprof_summary.py $(ls /tmp/kt_$WL/*.db /tmp/kt_$WL/*/*.db 2>/dev/null | head -1) > $O/kt_$WL.txt 2>> $O/kt_$WL.log
 head -45 $O/kt_$WL.txt
+python $R/scripts/rocprof_timeline.py $(ls /tmp/kt_$WL/*.db /tmp/kt_$WL/*/*.db 2>/dev/null | head -1) k_chain_count ${TL_STEP:-8} 2 > $O/tl_$WL.txt 2>&1
