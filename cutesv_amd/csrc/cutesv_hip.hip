@@ -99,6 +99,9 @@ const char* kStageName[CSV_N_STAGES] = {"init", "k_chain_count", "k_chain_apply"
                                         "k_refine_block", "k_items_scan", "k_emit", "k_reads_order", "k_reads_gather", "k_reads_maxlen",
                                         "k_genotype", "k_genotype_tra", "", "", "", "", "", "", "", "", "", ""};
 constexpr int N_COPY_STREAMS = 2;
+// workgroups of k_genotype<1024,4>: about two resident sets - calls differ a lot in cost, and workgroups that start as others
+// finish even the tail out (measured on the 90x workload: 1536..2048 -> 82-86 us, 4096..8192 -> 76 us, 16384 -> 80 us)
+constexpr int GT_GRID = 4096;
 constexpr int RO_CAP = 4096;                 // sorted runs the reads_order stage plans (k_reads_plan packs the rank in 12 bits)
 
 }  // namespace
@@ -895,10 +898,10 @@ int run_impl(csv_ctx* c, csv_run_stats* stats)
             else if (fork) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_aux[2], 0));
             else { HIP_TRY(c, hipStreamWaitEvent(st, c->ev_reads, 0)); const int rc = reads_stage(st); if (rc) return rc; }
             if (B.r_start.p32) {
-                hipLaunchKernelGGL((k_genotype<1024, 4, false, true>), dim3(2048), dim3(256), 0, st, B);
+                hipLaunchKernelGGL((k_genotype<1024, 4, false, true>), dim3(env_int("CSV_GT_GRID", GT_GRID)), dim3(256), 0, st, B);
                 hipLaunchKernelGGL((k_genotype<8192, 4, true, true>), dim3(256), dim3(256), 0, st, B);     // overflow list of the first pass; global tables beyond
             } else {
-                hipLaunchKernelGGL((k_genotype<1024, 4, false, false>), dim3(2048), dim3(256), 0, st, B);
+                hipLaunchKernelGGL((k_genotype<1024, 4, false, false>), dim3(env_int("CSV_GT_GRID", GT_GRID)), dim3(256), 0, st, B);
                 hipLaunchKernelGGL((k_genotype<8192, 4, true, false>), dim3(256), dim3(256), 0, st, B);
             }
             DBG("genotype");

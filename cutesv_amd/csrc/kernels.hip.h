@@ -2265,13 +2265,6 @@ __global__ __launch_bounds__(256) void k_emit(DevBatch B)
     }
 }
 
-// ------------------------------------------------------------------------------------ narrow input columns
-// CSV_IN_SIG_I32 / CSV_IN_READS_I32: two int32 columns -> the int64 columns the kernels read (sign-extended)
-__global__ __launch_bounds__(256) void k_widen2(const int* __restrict__ s0, i64* __restrict__ d0, const int* __restrict__ s1, i64* __restrict__ d1, i64 n)
-{
-    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) { d0[i] = s0[i]; d1[i] = s1[i]; }
-}
-
 // ------------------------------------------------------------------------------------ publish
 // The results straight into the caller's arrays, when those live in page-locked host memory (csv_host_alloc /
 // csv_host_register): the device knows the counts, so one kernel writes the calls in their final structure-of-arrays
@@ -2770,7 +2763,15 @@ template <bool RN> __device__ __forceinline__ void window_range(const DevBatch& 
 // bounds with two 64-ary searches over the start column (four dependent probes of 64 scattered cache lines each) before it
 // looked at any chunk: six round trips per window, and with 3-8 calls per wavefront the kernel is a chain of such trips.
 constexpr int GT_UNROLL = 4;
-template <int HASH, bool RN> __device__ __forceinline__ int cover_window(const DevBatch& B, int* tab, i64 r0, i64 r1, i64 L2, i64 R2, i64 maxlen, int& filled, bool& overflow)
+constexpr int GT_NC = 256;                          // chromosomes whose block offsets / longest reads k_genotype keeps in LDS
+// the first step of (1) below, issued by the caller together with the call's other loads: first starts of the first 128 blocks
+__device__ __forceinline__ void bfirst_probe(const DevBatch& B, i64 r0, i64 r1, i64& fa, i64& fc)
+{
+    const i64 k0 = r0 >> 12, k1 = (r1 - 1) >> 12, ka = k0 + lane_id(), kc = k0 + 64 + lane_id();
+    fa = B.bfirst[ka <= k1 ? ka : k1]; fc = B.bfirst[kc <= k1 ? kc : k1];
+}
+template <int HASH, bool RN> __device__ __forceinline__ int cover_window(const DevBatch& B, int* tab, i64 r0, i64 r1, i64 L2, i64 R2, i64 maxlen, int& filled, bool& overflow,
+                                                                         i64 fa0, i64 fc0)
 {
     int dr = 0;
     const int lane = lane_id();
@@ -2781,7 +2782,8 @@ template <int HASH, bool RN> __device__ __forceinline__ int cover_window(const D
     i64 ktop = k0;
     for (i64 kb = k0; kb <= k1; kb += 128) {
         const i64 ka = kb + lane, kc = kb + 64 + lane;
-        const i64 fa = B.bfirst[ka <= k1 ? ka : k1], fc = B.bfirst[kc <= k1 ? kc : k1];
+        i64 fa = fa0, fc = fc0;
+        if (kb != k0) { fa = B.bfirst[ka <= k1 ? ka : k1]; fc = B.bfirst[kc <= k1 ? kc : k1]; }
         const int na = __popcll(__ballot(ka <= k1 && (ka == k0 || 2 * fa <= L2))), nc = __popcll(__ballot(kc <= k1 && (kc == k0 || 2 * fc <= L2)));
         if (na + nc > 0) ktop = kb + na + nc - 1;           // (the predicate is true on a prefix: starts ascend inside a chromosome)
         if (na + nc < 128) break;
@@ -2939,35 +2941,54 @@ template <int HASH, int WPB, bool SECOND, bool RN> __global__ __launch_bounds__(
     constexpr int second = SECOND ? 1 : 0;
     __shared__ int tabs[WPB][HASH];
     __shared__ int s_red[WPB], s_last;
+    // the chromosomes' blocks of the reads table and their longest reads, once per workgroup (a dependent look-up per call otherwise)
+    __shared__ int s_off[GT_NC + 1];
+    __shared__ i64 s_ml[GT_NC];
     int* tab = tabs[threadIdx.x >> 6];
-    if (reads_pending(B)) return;
-    const int n = second ? B.cnt->n_gt_over : B.cnt->n_calls;
-    if (second && n == 0) return;                                   // (nothing overflowed the first pass: no list, no hand-over)
+    const bool in_lds = B.n_chrom <= GT_NC;
+    if (in_lds) {
+        for (int i = threadIdx.x; i <= B.n_chrom; i += 64 * WPB) s_off[i] = (int)B.reads_off[i];
+        for (int i = threadIdx.x; i < B.n_chrom; i += 64 * WPB) s_ml[i] = B.maxlen[i];
+    }
     const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * (64 * WPB) + threadIdx.x) >> 6), nwaves = (gridDim.x * (64 * WPB)) >> 6;
     GtHead cur, nxt;
-    if (wave < n) gt_load_head(B, second, wave, cur);
+    // (the first call's record is fetched before the number of calls is known - the index is clamped to the table -: one round
+    // trip less at the head of every wavefront)
+    if constexpr (!SECOND) gt_load_call(B, wave < B.cap_tmp ? wave : B.cap_tmp, cur);
+    const bool pending = reads_pending(B);
+    const int n = second ? B.cnt->n_gt_over : B.cnt->n_calls;
+    __syncthreads();
+    if (pending) return;
+    if (second && n == 0) return;                                   // (nothing overflowed the first pass: no list, no hand-over)
+    if constexpr (SECOND) { if (wave < n) gt_load_head(B, second, wave, cur); }
     for (int q = wave; q < n; q += nwaves, cur = nxt) {
         nxt = cur;
         if (q + nwaves < n) gt_load_head(B, second, q + nwaves, nxt);
         const int c = cur.c, svtype = cur.h.y & 0xff, chrom = cur.h.x;
         if (!(cur.h.y & 0x100) || svtype == CSV_TRA) continue;    // TRA: k_genotype_tra
-        const i64 r0 = B.reads_off[chrom], r1 = B.reads_off[chrom + 1], maxlen = B.maxlen[chrom];
-        for (int i = lane_id(); i < HASH; i += 64) tab[i] = -1;
+        i64 r0, r1, maxlen;
+        if (in_lds) { r0 = s_off[chrom]; r1 = s_off[chrom + 1]; maxlen = s_ml[chrom]; }
+        else { r0 = B.reads_off[chrom]; r1 = B.reads_off[chrom + 1]; maxlen = B.maxlen[chrom]; }
+        // one round trip: the first supports and the block probes of the window(s)
+        const GtWin W = gt_windows(cur);
         const i64 s0 = cur.s0, ns = cur.s1 - s0;
+        i64 fa = 0, fc = 0;
+        if (r1 > r0) bfirst_probe(B, r0, r1, fa, fc);
+        const int sup0 = lane_id() < ns ? B.o_suprid[s0 + lane_id()] : -1;
+        for (int i = lane_id(); i < HASH; i += 64) tab[i] = -1;
         int filled = 0;
         bool overflow = false;
         for (i64 base = 0; base < ns; base += 64) {
             if (filled + 64 > HASH * 3 / 4) { overflow = true; break; }
             const i64 i = base + lane_id();
             int ins = 0;
-            if (i < ns && !CSV_ABL(18)) ins = hash_insert<HASH>(tab, B.o_suprid[s0 + i]);
+            if (i < ns && !CSV_ABL(18)) ins = hash_insert<HASH>(tab, base == 0 ? sup0 : B.o_suprid[s0 + i]);
             filled += __popcll(__ballot(ins));
         }
         int dr = 0;
-        if (!overflow && !CSV_ABL(16)) {
-            const GtWin W = gt_windows(cur);
-            dr = cover_window<HASH, RN>(B, tab, r0, r1, W.La, W.Ra, maxlen, filled, overflow);
-            if (W.n == 2 && !overflow) dr += cover_window<HASH, RN>(B, tab, r0, r1, W.Lb, W.Rb, maxlen, filled, overflow);
+        if (!overflow && !CSV_ABL(16) && r1 > r0) {
+            dr = cover_window<HASH, RN>(B, tab, r0, r1, W.La, W.Ra, maxlen, filled, overflow, fa, fc);
+            if (W.n == 2 && !overflow) dr += cover_window<HASH, RN>(B, tab, r0, r1, W.Lb, W.Rb, maxlen, filled, overflow, fa, fc);      // (same chromosome: same probes)
         }
         if (overflow) {                                                       // wave-uniform
             if constexpr (!SECOND) { if (lane_id() == 0) B.gt_over[atomicAdd(&B.cnt->n_gt_over, 1)] = c; continue; }
