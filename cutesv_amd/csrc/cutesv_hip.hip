@@ -526,7 +526,8 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
         // the table as uploaded and its packed start-ordered form, both in the caller's width (int32: 13 + 12 bytes per read)
         const size_t cw = rd32 ? 4 : 8;
         PL(r_start, R * cw); PL(r_end, R * cw); PL(r_primary, R); PL(r_id, R * 4);
-        PL(s_start, R * cw); PL(s_end, R * cw); PL(s_idp, R * 4); PL(cmax, (div_up(R, 64) + 8) * 8); PL(span_len, (div_up(R, 512) + 8) * 8); PL(cfirst, (div_up(R, 64) + 8) * 8); PL(bfirst, (div_up(R, 4096) + 8) * 8);
+        PL(s_start, (R + 64) * cw); PL(s_end, (R + 64) * cw); PL(s_idp, (R + 64) * 4);      // (whole chunks of 64 rows are read)
+        PL(cmax, (div_up(R, 64) + 136) * 8); PL(span_len, (div_up(R, 512) + 8) * 8); PL(cfirst, (div_up(R, 64) + 136) * 8); PL(bfirst, (div_up(R, 4096) + 136) * 8);      // (+ two steps of padding: k_genotype reads 128 entries from any valid one)
         PL(maxlen, (in->n_chrom + 1) * 8);
         if (reorder) { PL(ro_tcnt, (div_up(R, RO_TILE) + 1) * 4); PL(ro_ent, (div_up(R, RO_TILE) + 1) * (size_t)RO_TCAP * 16); PL(ro_table, RO_CAP * 16); }
     }
@@ -692,7 +693,7 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
         if (rd32) { B.r_start = Col{nullptr, dp<int>(c->r_start)}; B.r_end = Col{nullptr, dp<int>(c->r_end)}; B.s_start32 = dp<int>(c->s_start); B.s_end32 = dp<int>(c->s_end); }
         else { B.r_start = Col{dp<i64>(c->r_start), nullptr}; B.r_end = Col{dp<i64>(c->r_end), nullptr}; B.s_start64 = dp<i64>(c->s_start); B.s_end64 = dp<i64>(c->s_end); }
         B.r_primary = dp<uint8_t>(c->r_primary); B.r_id = dp<int>(c->r_id);
-        B.s_idp = dp<int>(c->s_idp); B.cmax = dp<i64>(c->cmax); B.span_len = dp<i64>(c->span_len); B.cfirst = dp<i64>(c->cfirst); B.bfirst = dp<i64>(c->bfirst); B.maxlen = dp<i64>(c->maxlen);
+        B.s_idp = dp<int>(c->s_idp); B.cmax = dp<void>(c->cmax); B.span_len = dp<i64>(c->span_len); B.cfirst = dp<void>(c->cfirst); B.bfirst = dp<void>(c->bfirst); B.maxlen = dp<i64>(c->maxlen);
         B.gt_over = dp<int>(c->gt_over); B.gt_huge = dp<int>(c->gt_huge);
         B.gt_pool = dp<int>(c->gt_pool); B.gt_pool_n = pool_n;
         B.ro_mode = reorder ? 1 : 0;

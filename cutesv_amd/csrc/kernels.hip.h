@@ -117,6 +117,8 @@ struct Col {
     const int* p32;
     __device__ __forceinline__ i64 operator[](i64 i) const { return p32 ? (i64)p32[i] : p64[i]; }
 };
+// coordinates of the packed reads table and its indices: the caller's width
+template <bool RN> using rd_t = typename std::conditional<RN, int, i64>::type;
 template <bool NARROW> __device__ __forceinline__ i64 col_at(const Col& c, i64 i) { if constexpr (NARROW) return (i64)c.p32[i]; else return c.p64[i]; }
 
 // Everything the kernels need, passed by value.
@@ -178,9 +180,9 @@ struct DevBatch {
     // the packed, start-ordered table k_reads_gather writes (columns in the caller's width): what the genotype kernels read
     i64*           s_start64; i64* s_end64; int* s_start32; int* s_end32;
     int*           s_idp;            // read id | primary << 31
-    i64*           cmax;             // per chunk of 64 reads: the largest end
-    i64*           cfirst;           // per chunk: the start of its first read; bfirst[k] = cfirst[64 k] (per block of 4096 reads)
-    i64*           bfirst;
+    void*          cmax;             // per chunk of 64 reads: the largest end                                   } in the table's own
+    void*          cfirst;           // per chunk: the start of its first read; bfirst[k] = cfirst[64 k] (per block of 4096 reads)  } width (rd_t)
+    void*          bfirst;
     i64*           span_len;         // per span of 512 reads: the longest read ...
     i64*           maxlen;           // ... and per chromosome (k_reads_maxlen): bounds how far before a window a covering read can start
     int            ro_mode;          // 0: caller promised sorted blocks; 1: run-level reorder on the device; 2: general radix sort (fallback)
@@ -2658,7 +2660,7 @@ template <bool RN> __global__ __launch_bounds__(256) void k_reads_gather(DevBatc
             cm = lane63_i64(wave_incl_max_i64(vmax)); cl = lane63_i64(wave_incl_max_i64(vlen));
         }
         const i64 f0 = readlane_i64x(st[r], 0);                                // (lane 0 of a chunk is always a row of the table)
-        if (lane == 0) { B.cmax[c0 >> 6] = cm; B.cfirst[c0 >> 6] = f0; if (((c0 >> 6) & 63) == 0) B.bfirst[c0 >> 12] = f0; }
+        if (lane == 0) { ((rd_t<RN>*)B.cmax)[c0 >> 6] = (rd_t<RN>)cm; ((rd_t<RN>*)B.cfirst)[c0 >> 6] = (rd_t<RN>)f0; if (((c0 >> 6) & 63) == 0) ((rd_t<RN>*)B.bfirst)[c0 >> 12] = (rd_t<RN>)f0; }
         span_len = cl > span_len ? cl : span_len;
     }
     // (the verdict on the table belongs to the upload, like the table: the stage may run before the counters of a run are zeroed)
@@ -2762,78 +2764,94 @@ template <bool RN> __device__ __forceinline__ void window_range(const DevBatch& 
 // four chunks per step, tested exactly (primary, 2 start <= L2, 2 end >= R2).  The first form searched the exact row
 // bounds with two 64-ary searches over the start column (four dependent probes of 64 scattered cache lines each) before it
 // looked at any chunk: six round trips per window, and with 3-8 calls per wavefront the kernel is a chain of such trips.
-constexpr int GT_UNROLL = 4;
+constexpr int GT_UNROLL = 4;                         // (2: 5 % faster on 30x HiFi, 2 % slower on 90x ONT; 6 and 8: slower on both)
 constexpr int GT_NC = 256;                          // chromosomes whose block offsets / longest reads k_genotype keeps in LDS
 // the first step of (1) below, issued by the caller together with the call's other loads: first starts of the first 128 blocks
-__device__ __forceinline__ void bfirst_probe(const DevBatch& B, i64 r0, i64 r1, i64& fa, i64& fc)
+template <bool RN> __device__ __forceinline__ void bfirst_probe(const DevBatch& B, int r0, int r1, rd_t<RN>& fa, rd_t<RN>& fc)
 {
-    const i64 k0 = r0 >> 12, k1 = (r1 - 1) >> 12, ka = k0 + lane_id(), kc = k0 + 64 + lane_id();
-    fa = B.bfirst[ka <= k1 ? ka : k1]; fc = B.bfirst[kc <= k1 ? kc : k1];
+    // (indices past the block are masked by the caller, not clamped: the index arrays are padded by two steps, and a uniform base
+    // plus the lane number needs no address arithmetic)
+    const rd_t<RN>* bf = (const rd_t<RN>*)B.bfirst + (r0 >> 12);
+    fa = bf[lane_id()]; fc = bf[64 + lane_id()];
 }
-template <int HASH, bool RN> __device__ __forceinline__ int cover_window(const DevBatch& B, int* tab, i64 r0, i64 r1, i64 L2, i64 R2, i64 maxlen, int& filled, bool& overflow,
-                                                                         i64 fa0, i64 fc0)
+// Rows, chunks and blocks are 32-bit numbers (a table has fewer than 2^31 reads), and the window tests run on HALVED bounds
+// in the table's own width: 2 start <= L2 <=> start <= L2 >> 1, 2 end >= R2 <=> end >= (R2 + 1) >> 1 - the kernel was
+// bound by the issue of 64-bit compares and address arithmetic, not by memory (0.4 k vector instructions per call).
+template <int HASH, bool RN> __device__ __forceinline__ int cover_window(const DevBatch& B, int* tab, int r0, int r1, i64 L2, i64 R2, i64 maxlen, int& filled, bool& overflow,
+                                                                         rd_t<RN> fa0, rd_t<RN> fc0)
 {
+    using CT = rd_t<RN>;
+    const CT* bf = (const CT*)B.bfirst; const CT* cf = (const CT*)B.cfirst; const CT* cx = (const CT*)B.cmax;
     int dr = 0;
     const int lane = lane_id();
-    const i64 F2 = R2 - 2 * maxlen;                       // a covering read starts at or after F2 / 2
-    const i64 c0 = r0 >> 6, c1 = (r1 - 1) >> 6, k0 = c0 >> 6, k1 = c1 >> 6;
+    const i64 Lh64 = L2 >> 1, Rh64 = (R2 + 1) >> 1, Fh64 = (R2 - 2 * maxlen + 1) >> 1;      // a covering read starts at or after Fh
+    CT Lh, Rh, Fh;
+    if constexpr (RN) {
+        if (Rh64 > INT32_MAX) return 0;                     // (no int32 end reaches it)
+        Lh = (int)(Lh64 > INT32_MAX ? INT32_MAX : Lh64);
+        Rh = (int)(Rh64 < INT32_MIN ? INT32_MIN : Rh64);
+        Fh = (int)(Fh64 < INT32_MIN ? INT32_MIN : Fh64);   // (Fh <= Rh)
+    } else { Lh = Lh64; Rh = Rh64; Fh = Fh64; }
+    const int c0 = r0 >> 6, c1 = (r1 - 1) >> 6, k0 = c0 >> 6, k1 = c1 >> 6;
     // (1) last block whose first start is <= L (the block that holds the chromosome's first read counts as such: its own
     // first read may belong to the previous chromosome)
-    i64 ktop = k0;
-    for (i64 kb = k0; kb <= k1; kb += 128) {
-        const i64 ka = kb + lane, kc = kb + 64 + lane;
-        i64 fa = fa0, fc = fc0;
-        if (kb != k0) { fa = B.bfirst[ka <= k1 ? ka : k1]; fc = B.bfirst[kc <= k1 ? kc : k1]; }
-        const int na = __popcll(__ballot(ka <= k1 && (ka == k0 || 2 * fa <= L2))), nc = __popcll(__ballot(kc <= k1 && (kc == k0 || 2 * fc <= L2)));
+    int ktop = k0;
+    for (int kb = k0; kb <= k1; kb += 128) {
+        const int ka = kb + lane, kc = kb + 64 + lane;
+        CT fa = fa0, fc = fc0;
+        if (kb != k0) { fa = (bf + kb)[lane]; fc = (bf + kb)[64 + lane]; }
+        const int na = __popcll(__ballot(ka <= k1 && (ka == k0 || fa <= Lh))), nc = __popcll(__ballot(kc <= k1 && (kc == k0 || fc <= Lh)));
         if (na + nc > 0) ktop = kb + na + nc - 1;           // (the predicate is true on a prefix: starts ascend inside a chromosome)
         if (na + nc < 128) break;
     }
     // (2) chunks, two blocks per step, walking towards the chromosome's first chunk until the scan range is closed
     bool first_step = true;
-    i64 top_chunk = -1;
-    for (i64 kk = ktop; kk >= k0; kk -= 2) {
-        const i64 cb = (kk > k0 ? kk - 1 : kk) << 6;        // first chunk of the step
-        const i64 ca = cb + lane, cc = cb + 64 + lane;
+    int top_chunk = -1;
+    for (int kk = ktop; kk >= k0; kk -= 2) {
+        const int cb = (kk > k0 ? kk - 1 : kk) << 6;        // first chunk of the step
+        const int ca = cb + lane, cc = cb + 64 + lane;
         const bool ina = ca >= c0 && ca <= c1, inc = cc >= c0 && cc <= c1 && (kk > k0);
-        const i64 fa = B.cfirst[ina ? ca : c0], fc = B.cfirst[inc ? cc : c0];
-        const i64 ma = B.cmax[ina ? ca : c0], mc = B.cmax[inc ? cc : c0];
+        const CT fa = (cf + cb)[lane], fc = (cf + cb)[64 + lane];
+        const CT ma = (cx + cb)[lane], mc = (cx + cb)[64 + lane];
         if (first_step) {                                   // the chunk of the last read with start <= L lies in this step
-            const int na = __popcll(__ballot(ina && (ca == c0 || 2 * fa <= L2))), nc = __popcll(__ballot(inc && (cc == c0 || 2 * fc <= L2)));
-            const i64 lo_c = cb > c0 ? cb : c0;
+            const int na = __popcll(__ballot(ina && (ca == c0 || fa <= Lh))), nc = __popcll(__ballot(inc && (cc == c0 || fc <= Lh)));
+            const int lo_c = cb > c0 ? cb : c0;
             top_chunk = lo_c + na + nc - 1;
             first_step = false;
             if (top_chunk < lo_c) return 0;                 // no read of the chromosome starts at or before L
         }
         // chunks of this step that lie at or before top_chunk, may hold a read with start >= F (their successor's first read
         // starts at or after F, or they are the last such) and hold a read that reaches R
-        const u64 before_a = __ballot(ina && ca != c0 && 2 * fa < F2), before_c = __ballot(inc && cc != c0 && 2 * fc < F2);   // chunk begins before F
+        const u64 before_a = __ballot(ina && ca != c0 && fa < Fh), before_c = __ballot(inc && cc != c0 && fc < Fh);   // chunk begins before F
         // the scan's first chunk is the LAST chunk that begins before F (it may still hold later reads); every chunk after it qualifies
         const int nb_a = __popcll(before_a), nb_c = __popcll(before_c);
-        const i64 lo_c = cb > c0 ? cb : c0;
+        const int lo_c = cb > c0 ? cb : c0;
         const bool closed = (nb_a + nb_c > 0) || lo_c == c0;
-        const i64 bot_chunk = (nb_a + nb_c > 0) ? (nb_c ? cb + 64 + (63 - __clzll((long long)before_c)) : cb + (63 - __clzll((long long)before_a))) : lo_c;
-        u64 todo_a = __ballot(ina && ca >= bot_chunk && ca <= top_chunk && 2 * ma >= R2);
-        u64 todo_c = __ballot(inc && cc >= bot_chunk && cc <= top_chunk && 2 * mc >= R2);
+        const int bot_chunk = (nb_a + nb_c > 0) ? (nb_c ? cb + 64 + (63 - __clzll((long long)before_c)) : cb + (63 - __clzll((long long)before_a))) : lo_c;
+        u64 todo_a = __ballot(ina && ca >= bot_chunk && ca <= top_chunk && ma >= Rh);
+        u64 todo_c = __ballot(inc && cc >= bot_chunk && cc <= top_chunk && mc >= Rh);
         // (3) the reads of the flagged chunks
         while (todo_a | todo_c) {
-            i64 st[GT_UNROLL], en[GT_UNROLL]; int idp[GT_UNROLL]; bool ok[GT_UNROLL];
+            CT st[GT_UNROLL], en[GT_UNROLL]; int idp[GT_UNROLL]; bool ok[GT_UNROLL];
 #pragma unroll
             for (int u = 0; u < GT_UNROLL; u++) {
-                i64 chunk = -1;
+                int chunk = -1;
                 if (todo_a) { chunk = cb + __ffsll((long long)todo_a) - 1; todo_a &= todo_a - 1; }
                 else if (todo_c) { chunk = cb + 64 + __ffsll((long long)todo_c) - 1; todo_c &= todo_c - 1; }
-                const i64 row = chunk >= 0 ? (chunk << 6) + lane : -1;
-                ok[u] = row >= r0 && row < r1;
-                const i64 rr = ok[u] ? row : r0;
-                st[u] = sread_start<RN>(B, rr); en[u] = sread_end<RN>(B, rr); idp[u] = B.s_idp[rr];
+                const int row = (chunk << 6) + lane;
+                ok[u] = chunk >= 0 && row >= r0 && row < r1;
+                const i64 cbase = (i64)(chunk >= 0 ? chunk : c0) << 6;      // wave-uniform: base + lane (rows past the table are padding)
+                if constexpr (RN) { st[u] = (B.s_start32 + cbase)[lane]; en[u] = (B.s_end32 + cbase)[lane]; } else { st[u] = (B.s_start64 + cbase)[lane]; en[u] = (B.s_end64 + cbase)[lane]; }
+                idp[u] = (B.s_idp + cbase)[lane];
             }
 #pragma unroll
             for (int u = 0; u < GT_UNROLL; u++) {
                 if (filled + 64 > HASH * 3 / 4) { overflow = true; return dr; }
-                const bool cov = ok[u] && idp[u] < 0 && 2 * st[u] <= L2 && 2 * en[u] >= R2;          // primary (bit 31), starts at or before L, reaches R
+                const bool cov = ok[u] && idp[u] < 0 && st[u] <= Lh && en[u] >= Rh;          // primary (bit 31), starts at or before L, reaches R
                 int ins = 0;
                 if (cov && !CSV_ABL(17)) ins = hash_insert<HASH>(tab, idp[u] & 0x7fffffff);
-                const int k = __popcll(__ballot(CSV_ABL(17) ? cov : ins));
+                if (CSV_ABL(17)) ins = cov;
+                const int k = __popcll(__ballot(ins));
                 dr += k; filled += k;
             }
         }
@@ -2966,16 +2984,22 @@ template <int HASH, int WPB, bool SECOND, bool RN> __global__ __launch_bounds__(
         if (q + nwaves < n) gt_load_head(B, second, q + nwaves, nxt);
         const int c = cur.c, svtype = cur.h.y & 0xff, chrom = cur.h.x;
         if (!(cur.h.y & 0x100) || svtype == CSV_TRA) continue;    // TRA: k_genotype_tra
-        i64 r0, r1, maxlen;
+        int r0, r1; i64 maxlen;
         if (in_lds) { r0 = s_off[chrom]; r1 = s_off[chrom + 1]; maxlen = s_ml[chrom]; }
-        else { r0 = B.reads_off[chrom]; r1 = B.reads_off[chrom + 1]; maxlen = B.maxlen[chrom]; }
-        // one round trip: the first supports and the block probes of the window(s)
+        else { r0 = (int)B.reads_off[chrom]; r1 = (int)B.reads_off[chrom + 1]; maxlen = B.maxlen[chrom]; }
+        // one round trip: the first supports and the block probes of the window(s); the table is cleared while they fly
         const GtWin W = gt_windows(cur);
         const i64 s0 = cur.s0, ns = cur.s1 - s0;
-        i64 fa = 0, fc = 0;
-        if (r1 > r0) bfirst_probe(B, r0, r1, fa, fc);
-        const int sup0 = lane_id() < ns ? B.o_suprid[s0 + lane_id()] : -1;
-        for (int i = lane_id(); i < HASH; i += 64) tab[i] = -1;
+        rd_t<RN> fa = 0, fc = 0;
+        if (r1 > r0) bfirst_probe<RN>(B, r0, r1, fa, fc);
+        int sup0 = lane_id() < ns ? B.o_suprid[s0 + lane_id()] : -1;
+        {
+            int4* t4 = (int4*)tab;
+#pragma unroll
+            for (int k = 0; k < HASH / 256; k++) t4[k * 64 + lane_id()] = make_int4(-1, -1, -1, -1);
+        }
+        // (the loaded values are first looked at here: without this the compiler waits for each load right where it is issued)
+        if constexpr (RN) asm volatile("" : "+v"(fa), "+v"(fc), "+v"(sup0)); else asm volatile("" : "+v"(fa), "+v"(fc), "+v"(sup0));
         int filled = 0;
         bool overflow = false;
         for (i64 base = 0; base < ns; base += 64) {
