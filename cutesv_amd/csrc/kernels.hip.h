@@ -1859,8 +1859,26 @@ template <int SW> __device__ __forceinline__ int indel_unit(const DevBatch& B, c
         const bool live = ok && r < U;
         const int last = hb | (SW - 1);
 
+        // ---- sums.  A cluster whose positions and lengths all lie within 2^18 of its first member's (every ordinary one)
+        // takes the FAST form: both deltas, biased to be non-negative, share ONE 64-bit scan (sums < 2^25 per half), and what
+        // follows - allele sums, the member closest to the mean, the variances - works on these small exact integers.
+        constexpr int DB = 18;
+        const i64 bpos = shfl_i64(pos, hb), blen = shfl_i64(len, hb);             // rank 0 of the sub-wave: the origin of the deltas
+        int dp32, dl32;                                                           // the deltas (meaningful when `fast`)
+        bool small;
+        {
+            const i64 dpi = pos - bpos, dli = len - blen;
+            small = !live || ((u64)pos < (1ull << 31) && (u64)len < (1ull << 31) && dpi > -(1 << DB) && dpi < (1 << DB) && dli > -(1 << DB) && dli < (1 << DB));
+            dp32 = live ? (int)dpi : 0; dl32 = live ? (int)dli : 0;
+        }
+        const bool fast = !__ballot(!small) && !CSV_ABL(15);
+        i64 PK = 0, lsum;
+        if (fast) {
+            const unsigned dpb = live ? (unsigned)(dp32 + (1 << DB)) : 0u, dlb = live ? (unsigned)(dl32 + (1 << DB)) : 0u;
+            PK = sub_scan_i64<SW>((i64)(((u64)dlb << 32) | dpb));
+            lsum = (i64)U * (blen - (1 << DB)) + (i64)((u64)shfl_i64(PK, last) >> 32);
+        } else lsum = shfl_i64(sub_scan_i64<SW>(live ? len : 0), last);
         // ---- allele split on consecutive length gaps (INDEL:138, 153-162)
-        const i64 lsum = shfl_i64(sub_scan_i64<SW>(live ? len : 0), last);
         const double thr = ratio * div_by((double)lsum, (double)U, B.rcp_tab[U & (SQRT_TAB - 1)]);
         const i64 lprev = wave_shr1_i64(len);
         const bool f = live && r > 0 && ((double)(len - lprev) > thr);
@@ -1872,12 +1890,22 @@ template <int SW> __device__ __forceinline__ int indel_unit(const DevBatch& B, c
         if (r1 > U) r1 = U;
         const int n = live ? r1 - r0 : 1, i = r - r0;
 
-        const i64 Ppos = sub_scan_i64<SW>(live ? pos : 0), Plen = sub_scan_i64<SW>(live ? len : 0);
         const int e1 = hb | ((r1 - 1) & (SW - 1)), e0 = hb | ((r0 - 1) & (SW - 1));
         // NB: every cross-lane op sits in wave-uniform control flow; only the selects are per lane
-        const i64 pp0 = shfl_i64(Ppos, e0), pl0 = shfl_i64(Plen, e0);
-        const i64 sp = shfl_i64(Ppos, e1) - (r0 > 0 ? pp0 : 0);
-        const i64 sln = shfl_i64(Plen, e1) - (r0 > 0 ? pl0 : 0);
+        i64 sp, sln;
+        int s1p = 0, s1l = 0;                                                     // fast: sums of the deltas over the allele
+        if (fast) {
+            const i64 k1 = shfl_i64(PK, e1), k0 = shfl_i64(PK, e0);
+            const u64 seg = (u64)(k1 - (r0 > 0 ? k0 : 0));                        // (both halves ascend: no borrow across them)
+            s1p = (int)(unsigned)(seg & 0xffffffffull) - n * (1 << DB);
+            s1l = (int)(unsigned)(seg >> 32) - n * (1 << DB);
+            sp = (i64)n * bpos + s1p; sln = (i64)n * blen + s1l;
+        } else {
+            const i64 Ppos = sub_scan_i64<SW>(live ? pos : 0), Plen = sub_scan_i64<SW>(live ? len : 0);
+            const i64 pp0 = shfl_i64(Ppos, e0), pl0 = shfl_i64(Plen, e0);
+            sp = shfl_i64(Ppos, e1) - (r0 > 0 ? pp0 : 0);
+            sln = shfl_i64(Plen, e1) - (r0 > 0 ? pl0 : 0);
+        }
 
         // ---- emission order: stable ascending by support among alleles with n >= minimum_support_reads (INDEL:163-166)
         const bool pass = live && n >= msr;
@@ -1897,31 +1925,39 @@ template <int SW> __device__ __forceinline__ int indel_unit(const DevBatch& B, c
         int keep = (int)(rr * (double)n); if (keep < 1) keep = 1;                 // INDEL:169
         const double rcp_n = B.rcp_tab[n & (SQRT_TAB - 1)];
         const double pmean = div_by((double)sp, (double)n, rcp_n), lmean = div_by((double)sln, (double)n, rcp_n);
-        const double dp = fabs((double)pos - pmean), dl = fabs((double)len - lmean);
         double bp = pmean, siglen = lmean;
         i64 search;
         if (CSV_ABL(3)) search = pos;
-        else if (!__ballot(pass && keep < n)) {
-            // every member kept: search_threshold = first member with the smallest |pos - mean| (INDEL:171-177)
-            double bd = dp; int bi = r;
+        else if (!__ballot(pass && keep < n) && fast) {
+            // every member kept: search_threshold = first member with the smallest |pos - mean| (INDEL:171-177), in integers:
+            // n pos - sum = n d - s1 exactly, and the reference's doubles |pos - fl(sum / n)| are exact differences too (both
+            // operands are multiples of 2^-22 below 2^31, less than 2^19 apart), so they order like |n d - s1| except when two
+            // members on OPPOSITE sides of the mean are exactly equidistant: then the side towards which the quotient was
+            // rounded is the nearer one - the sign of the division's residual, which one fma gives exactly.
+            const int nd = n * dp32 - s1p;                                      // |nd| < 2^25
+            const unsigned an = (unsigned)(nd < 0 ? -nd : nd);
+            const double resid = fma(-(double)n, pmean, (double)sp);              // sum - n * fl(sum / n): < 0 <=> the mean was rounded up
+            const unsigned t = resid < 0.0 ? (nd < 0) : (resid > 0.0 ? (nd > 0) : 0);
+            unsigned bk = ((2u * an + t) << 6) | (unsigned)r;                    // (distance, side, rank): one 32-bit minimum
             if (SW == 16) {                                  // a sub-wave is one DPP row: row_shr moves, no LDS round trips
-#define CSV_MINSTEP(CTRL, D)                                                                                              \
-                {                                                                                                         \
-                    const double od = __longlong_as_double(dpp_i64<CTRL, 0xf>(__double_as_longlong(bd), __double_as_longlong(bd))); \
-                    const int oi = dpp_i32<CTRL, 0xf>(bi, bi);                                                            \
-                    if (r - D >= r0 && (od < bd || (od == bd && oi < bi))) { bd = od; bi = oi; }                          \
-                }
+#define CSV_MINSTEP(CTRL, D) { const unsigned o = (unsigned)dpp_i32<CTRL, 0xf>((int)bk, (int)bk); if (i >= D && o < bk) bk = o; }
                 CSV_MINSTEP(0x111, 1) CSV_MINSTEP(0x112, 2) CSV_MINSTEP(0x114, 4) CSV_MINSTEP(0x118, 8)
 #undef CSV_MINSTEP
             } else {
-                for (int d = 1; d < SW; d <<= 1) {
-                    const double od = shfl_f64(bd, (lane - d) & 63); const int oi = __shfl(bi, (lane - d) & 63);
-                    if (r - d >= r0 && (od < bd || (od == bd && oi < bi))) { bd = od; bi = oi; }
-                }
+                for (int d = 1; d < SW; d <<= 1) { const unsigned o = (unsigned)__shfl((int)bk, (lane - d) & 63); if (i >= d && o < bk) bk = o; }
+            }
+            search = shfl_i64(pos, hb | (__shfl((int)bk, e1) & (SW - 1)));
+        } else if (!__ballot(pass && keep < n)) {
+            // the same on the doubles themselves (clusters that span more than 2^18 bases)
+            double bd = fabs((double)pos - pmean); int bi = r;
+            for (int d = 1; d < SW; d <<= 1) {
+                const double od = shfl_f64(bd, (lane - d) & 63); const int oi = __shfl(bi, (lane - d) & 63);
+                if (r - d >= r0 && (od < bd || (od == bd && oi < bi))) { bd = od; bi = oi; }
             }
             search = shfl_i64(pos, hb | (__shfl(bi, e1) & (SW - 1)));
         } else {
             // keep the `keep` members closest to the mean, ties in allele order (INDEL:171-176, 182-187)
+            const double dp = fabs((double)pos - pmean), dl = fabs((double)len - lmean);
             int rp = 0, rl = 0;
             for (int t = 0; t < mmax; t++) {
                 const int r0t = sub_rl<SW>(r0, t, g);
@@ -1952,17 +1988,12 @@ template <int SW> __device__ __forceinline__ int indel_unit(const DevBatch& B, c
         // of this kernel's instructions.)
         int cip = 0, cil = 0;
         if (!CSV_ABL(2)) {
-            const i64 bpos = shfl_i64(pos, hb), blen = shfl_i64(len, hb);             // rank 0 of the sub-wave: the origin of the deltas
-            const i64 dpi = pos - bpos, dli = len - blen;
-            const bool small = !live || ((u64)pos < (1ull << 31) && (u64)len < (1ull << 31) && dpi > -(1 << 20) && dpi < (1 << 20) && dli > -(1 << 20) && dli < (1 << 20));
-            bool exact_ok = !__ballot(!small) && !CSV_ABL(15);
+            bool exact_ok = fast;
             if (exact_ok) {
-                const int dp32 = live ? (int)dpi : 0, dl32 = live ? (int)dli : 0;
-                const i64 Q2p = sub_scan_i64<SW>((i64)dp32 * dp32), Q2l = sub_scan_i64<SW>((i64)dl32 * dl32);      // squares < 2^40, sums < 2^46
+                const i64 Q2p = sub_scan_i64<SW>((i64)dp32 * dp32), Q2l = sub_scan_i64<SW>((i64)dl32 * dl32);      // squares < 2^36, sums < 2^42
                 const i64 qp0 = shfl_i64(Q2p, e0), ql0 = shfl_i64(Q2l, e0);
                 const i64 s2p = shfl_i64(Q2p, e1) - (r0 > 0 ? qp0 : 0), s2l = shfl_i64(Q2l, e1) - (r0 > 0 ? ql0 : 0);
-                const i64 s1p = sp - (i64)n * bpos, s1l = sln - (i64)n * blen;        // |s1| < 2^26
-                const i64 np_ = (i64)n * s2p - s1p * s1p, nl_ = (i64)n * s2l - s1l * s1l;          // n^2 * variance, exact, < 2^52
+                const i64 np_ = (i64)n * s2p - (i64)s1p * s1p, nl_ = (i64)n * s2l - (i64)s1l * s1l;          // n^2 * variance, exact, < 2^48
                 const float ck = B.cipk_tab[n & (SQRT_TAB - 1)];                     // 1.96 / (n * n ** 0.5)
                 const float vp = __builtin_amdgcn_sqrtf((float)(double)np_) * ck, vl = __builtin_amdgcn_sqrtf((float)(double)nl_) * ck;
                 cip = (int)vp; cil = (int)vl;
