@@ -117,7 +117,7 @@ struct csv_ctx {
     Arena       arena, arena_rb;
     // batch buffers (slices of `arena`)
     Buf seg, woff, seg_drop, a, b, rid, aux, a32, b32;
-    Buf cluster_id, partial, partial64, item_rec, list_small, list_big, list_tiny, list_wide, partial_t, seg_gate, tile_info, ch_masks, tile_items, seg_err;
+    Buf cluster_id, partial, tile_cnt, item_rec, list_small, list_big, list_tiny, list_wide, seg_gate, tile_info, ch_masks, tile_items, seg_err;
     Buf item_nslots, item_cnt, item_base, item_chunk, sup_tmp;
     Buf t_rec;
     Buf sc_k, sc_x, sc_v1, sc_v2, sc_v3, sc_v4, sc_v5;
@@ -511,7 +511,7 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
     PL(rid, (W + 1) * 4); PL(aux, (W + 1) * 4);
     PL(sup_tmp, (W + 1) * 8);
     if (per_sig) { PL(cluster_id, (W + 1) * 4); PL(allele_id, (W + 1) * 4); }
-    PL(partial, nt * 4); PL(partial64, nt * 8); PL(partial_t, nt * 4);
+    PL(partial, nt * 4); PL(tile_cnt, nt * 16);
     if (per_sig) PL(ch_masks, nt * CT_WORDS * 8);
     PL(tile_items, nt * (size_t)TI_STRIDE * 16);
     PL(item_rec, cap_items * 16); PL(list_small, cap_items * 16); PL(list_big, cap_items * 4); PL(list_tiny, cap_items * 16); PL(list_wide, cap_items * 16);
@@ -675,9 +675,9 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
             break;
         }
     B.cluster_id = per_sig ? dp<int>(c->cluster_id) : nullptr; B.allele_id = per_sig ? dp<int>(c->allele_id) : nullptr;
-    B.partial = dp<int>(c->partial); B.partial64 = dp<i64>(c->partial64);
+    B.partial = dp<int>(c->partial); B.tile_cnt = dp<int4>(c->tile_cnt);
     B.item_rec = dp<int4>(c->item_rec); B.list_small = dp<int4>(c->list_small); B.list_big = dp<int>(c->list_big); B.list_tiny = dp<int4>(c->list_tiny); B.list_wide = dp<int4>(c->list_wide);
-    B.partial_t = dp<int>(c->partial_t); B.seg_gate = dp<int4>(c->seg_gate); B.tile_info = dp<int4>(c->tile_info);
+    B.seg_gate = dp<int4>(c->seg_gate); B.tile_info = dp<int4>(c->tile_info);
     B.ch_masks = per_sig ? dp<u64>(c->ch_masks) : nullptr; B.tile_items = dp<int4>(c->tile_items);
     B.seg_err = dp<int>(c->seg_err);
     B.tiny_max = getenv("CSV_NO_TINY") ? 0 : 16;               // (timing aid: 0 sends every DEL/INS cluster of m <= 32 through the paired path)

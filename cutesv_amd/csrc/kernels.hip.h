@@ -136,7 +136,7 @@ struct DevBatch {
     // chain / select
     int*           cluster_id;       // W
     int*           partial;          // cluster starts per chain tile
-    i64*           partial64;        // work items per chain tile (low 32: all, high 32: workgroup tier)
+    int4*          tile_cnt;         // per chain tile: {cluster starts, work items, items above 64 signatures, tiny | wide << 16}
     int4*          item_rec;         // ordered work list: item -> {cluster id, segment, first w, size}
     int4*          list_small;       // wavefront tier (ordered): {item, segment | svtype << 24, first w, size} - everything the
                                      // refine kernels need to issue their row loads straight after this ONE load
@@ -155,7 +155,6 @@ struct DevBatch {
     int*           seg_err;          // n_seg words of CSV_SEG_* bits
     const int4*    seg_gate;         // per segment {read_count, dropped, svtype, -}: one 16-byte load for the size gate
     const int4*    tile_info;        // per chain tile, built by the host: TILE_REC int4 words (see TILE_REC below)
-    int*           partial_t;        // tiny work items per chain tile
     // refine outputs
     int*           item_nslots;      // temp slots the item filled (t_*[s + slot])
     i64*           item_cnt;         // packed (valid calls << 32 | supports of valid calls)
@@ -744,9 +743,8 @@ template <bool NARROW> __global__ __launch_bounds__(256, 6) void k_chain_count(D
     }
     if (threadIdx.x == 0) {
         const int tot = s_w[0] + s_w[1] + s_w[2] + s_w[3], tt = s_t[0] + s_t[1] + s_t[2] + s_t[3];
-        B.partial[blockIdx.x] = tot & 0xffff;
-        B.partial64[blockIdx.x] = (i64)(tot >> 16) | ((i64)(tt >> 20) << 32);
-        B.partial_t[blockIdx.x] = (tt & 0xfff) | (((tt >> 12) & 0xff) << 16);
+        B.partial[blockIdx.x] = tot & 0xffff;                 // (k_chain_ids reads the starts alone)
+        B.tile_cnt[blockIdx.x] = make_int4(tot & 0xffff, tot >> 16, tt >> 20, (tt & 0xfff) | (((tt >> 12) & 0xff) << 16));   // starts, items, above 64, tiny | wide << 16
     }
 }
 
@@ -755,33 +753,42 @@ template <bool NARROW> __global__ __launch_bounds__(256, 6) void k_chain_count(D
 // L2-resident values).  Reads ~16 bytes per work item; no signature column, no flag, no gate.
 __global__ __launch_bounds__(256) void k_chain_apply(DevBatch B)
 {
-    __shared__ i64 sh[12];
+    __shared__ int sh[4][5];
     const int wv = threadIdx.x >> 6;
     const int tile_b = blockIdx.x * 4, tile = tile_b + wv, ntile = (int)((B.W + CH_TILE - 1) / CH_TILE);
-    i64 p0 = 0, p1 = 0, p2 = 0;
-    for (int i = threadIdx.x; i < tile_b; i += 256) {
-        const int tw = B.partial_t[i];                       // tiny | wide << 16 of tile i
-        p0 += B.partial[i]; p1 += B.partial64[i]; p2 += (i64)(tw & 0xffff) | ((i64)(tw >> 16) << 32);
-    }
-    p0 = wave_sum_i64(p0); p1 = wave_sum_i64(p1); p2 = wave_sum_i64(p2);
-    if (lane_id() == 0) { sh[wv] = p0; sh[4 + wv] = p1; sh[8 + wv] = p2; }
-    i64 b0 = 0, b1 = 0, b2 = 0;                              // ... of the workgroup's earlier tiles
-    for (int q = tile_b; q < tile && q < ntile; q++) { const int tw = B.partial_t[q]; b0 += B.partial[q]; b1 += B.partial64[q]; b2 += (i64)(tw & 0xffff) | ((i64)(tw >> 16) << 32); }
-    i64 own0 = 0, own1 = 0;
-    if (tile < ntile) { own0 = B.partial[tile]; own1 = B.partial64[tile]; }
+    // ONE round trip: the counts of the earlier tiles (one 16-byte record per tile, eight per thread issued together), the
+    // workgroup's own four, and - before its count is known - the tile's first 64 item records
+    int4 c8[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) { const int i = threadIdx.x + 256 * u; c8[u] = i < tile_b ? B.tile_cnt[i] : make_int4(0, 0, 0, 0); }
+    int4 w4[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) w4[q] = tile_b + q < ntile ? B.tile_cnt[tile_b + q] : make_int4(0, 0, 0, 0);
+    const int4 rec0 = B.tile_items[(i64)(tile < ntile ? tile : 0) * TI_STRIDE + lane_id()];
+    int p0 = 0, p1 = 0, p2 = 0, p3 = 0, p4 = 0;              // cluster starts, items, items above 64, tiny, wide
+#pragma unroll
+    for (int u = 0; u < 8; u++) { p0 += c8[u].x; p1 += c8[u].y; p2 += c8[u].z; p3 += c8[u].w & 0xffff; p4 += c8[u].w >> 16; }
+    for (int i = threadIdx.x + 2048; i < tile_b; i += 256) { const int4 c = B.tile_cnt[i]; p0 += c.x; p1 += c.y; p2 += c.z; p3 += c.w & 0xffff; p4 += c.w >> 16; }
+    p0 = wave_sum_i32(p0); p1 = wave_sum_i32(p1); p2 = wave_sum_i32(p2); p3 = wave_sum_i32(p3); p4 = wave_sum_i32(p4);
+    if (lane_id() == 0) { sh[wv][0] = p0; sh[wv][1] = p1; sh[wv][2] = p2; sh[wv][3] = p3; sh[wv][4] = p4; }
+    int b0 = 0, b1 = 0, b2 = 0, b3 = 0, b4 = 0;               // ... of the workgroup's earlier tiles
+#pragma unroll
+    for (int q = 0; q < 4; q++) if (q < wv) { b0 += w4[q].x; b1 += w4[q].y; b2 += w4[q].z; b3 += w4[q].w & 0xffff; b4 += w4[q].w >> 16; }
+    int4 own = make_int4(0, 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 4; q++) if (q == wv) own = w4[q];
     __syncthreads();
     if (tile >= ntile) return;
-    const i64 runs = sh[4] + sh[5] + sh[6] + sh[7] + b1;
-    const int run = (int)(sh[0] + sh[1] + sh[2] + sh[3] + b0);          // id of the first cluster that STARTS in this tile
-    const int bj = (int)(runs & 0xffffffffll);
-    const i64 tws = sh[8] + sh[9] + sh[10] + sh[11] + b2;
-    int bb = (int)(runs >> 32), bt = (int)(tws & 0xffffffffll), bw = (int)(tws >> 32);
-    const int n_it = __builtin_amdgcn_readfirstlane((int)(own1 & 0xffffffffll));
+    const int run = sh[0][0] + sh[1][0] + sh[2][0] + sh[3][0] + b0;          // id of the first cluster that STARTS in this tile
+    const int bj = sh[0][1] + sh[1][1] + sh[2][1] + sh[3][1] + b1;
+    int bb = sh[0][2] + sh[1][2] + sh[2][2] + sh[3][2] + b2, bt = sh[0][3] + sh[1][3] + sh[2][3] + sh[3][3] + b3, bw = sh[0][4] + sh[1][4] + sh[2][4] + sh[3][4] + b4;
+    const i64 own0 = own.x;
+    const int n_it = __builtin_amdgcn_readfirstlane(own.y);
     for (int base = 0; base < n_it; base += 64) {
         const int idx = base + lane_id();
         const bool act = idx < n_it;
         int4 rec = make_int4(0, 0, 0, 0);
-        if (act) rec = B.tile_items[(i64)tile * TI_STRIDE + idx];
+        if (act) rec = base == 0 ? rec0 : B.tile_items[(i64)tile * TI_STRIDE + idx];
         const int tier = (rec.z >> 28) & 3;
         const bool wide = act && ((rec.z >> 30) & 1);
         const u64 m_big = __ballot(act && (tier & 1)), m_tiny = __ballot(act && (tier & 2)), m_wide = __ballot(wide);
@@ -2258,6 +2265,12 @@ __global__ __launch_bounds__(256) void k_emit(DevBatch B)
             valid = tr.valid; nsup = tr.support; tso = tr.supoff;
             bp1 = tr.bp1; bp2 = tr.bp2; ci = tr.cipos; cl = tr.cilen; srch = tr.search; pick = tr.pick;
         }
+        // (... and, before the slot records say how long the lists are, the first 32 supports of the item's first slot, whose list
+        // always begins at the cluster's own first row: most items have one call with fewer supports than that, and their third
+        // round trip disappears)
+        int2 pre[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const i64 x = (i64)s + l8 + 8 * u; pre[u] = B.sup_tmp[x < B.W ? x : B.W]; }
         i64 gs = 0; int aux0 = 0;
         int4 ghdr = make_int4(0, 0, 0, 0);
         if (nslots) {
@@ -2284,7 +2297,10 @@ __global__ __launch_bounds__(256) void k_emit(DevBatch B)
             for (int i = l8; i < nn; i += 32) {
                 int2 sr[4];
 #pragma unroll
-                for (int u = 0; u < 4; u++) sr[u] = (i + 8 * u < nn) ? B.sup_tmp[s + ts + i + 8 * u] : make_int2(-1, 0);
+                for (int u = 0; u < 4; u++) {
+                    if (sl == 0 && i == l8 && ts == 0) sr[u] = (i + 8 * u < nn) ? pre[u] : make_int2(-1, 0);
+                    else sr[u] = (i + 8 * u < nn) ? B.sup_tmp[s + ts + i + 8 * u] : make_int2(-1, 0);
+                }
 #pragma unroll
                 for (int u = 0; u < 4; u++)
                     if (sr[u].x >= 0) {
