@@ -778,14 +778,16 @@ int run_impl(csv_ctx* c, csv_run_stats* stats)
     // that every kernel is timed alone.
     // (forking costs a few event waits: only worth it when the batch has pair types or genotyping)
     const bool do_gt = c->any_genotype && B.n_reads > 0;
-    const bool fork = !stats && !dbg && !getenv("CSV_NO_FORK") && (c->any_pair || do_gt || getenv("CSV_FORK_ALWAYS"));
+    // the packed table of an upload does not change between runs: a resident re-run keeps it (csv_batch_option) and has no reads stage
+    const bool keep_reads = c->reads_ready && c->reuse_reads && !stats;
+    const bool fork = !stats && !dbg && !getenv("CSV_NO_FORK") && (c->any_pair || (do_gt && !keep_reads) || getenv("CSV_FORK_ALWAYS"));
     // A genotyping batch has two producer chains - clustering (k_chain_count .. k_emit) and the reads stage - that meet in
     // k_genotype.  A wait across queues costs 6-11 us when the event fires late and next to nothing when it fired long ago,
     // so the LONGER chain stays on the main stream together with the genotype kernels and the shorter one is forked off:
     // its completion event has long fired when the main stream gets there.  (Reads dominate a 30x HiFi genome, clustering a
     // 90x all-types one.)  `st` is the stream of the clustering chain from here on, `sM` the main stream.
     hipStream_t sM = c->stream;
-    const bool swap = fork && do_gt && !c->copies_pending && B.n_reads > 4 * W && W > 0 && !getenv("CSV_NO_SWAP");
+    const bool swap = fork && do_gt && !keep_reads && !c->copies_pending && B.n_reads > 4 * W && W > 0 && !getenv("CSV_NO_SWAP");
     if (swap) st = c->side[2];
     hipStream_t sB = fork ? c->side[0] : st, sC = fork ? c->side[1] : st, sD = swap ? sM : (fork ? c->side[2] : st);
 #define LAUNCH_ON(strm, name, kern, grid, block, lds, ...)                             \
@@ -798,8 +800,7 @@ int run_impl(csv_ctx* c, csv_run_stats* stats)
     auto reads_stage = [&](hipStream_t s2) -> int {       // reads order + pack + longest read per chromosome on stream s2
         const int nr = div_up(B.n_reads, 2048);
         const bool rn = B.r_start.p32 != nullptr;
-        // the packed table of an upload does not change between runs: a resident re-run keeps it (csv_batch_option)
-        const bool keep = c->reads_ready && c->reuse_reads && !stats;
+        const bool keep = keep_reads;
         if (!keep) {                                      // (k_reads_plan leaves a state on every path; nothing to reset)
             if (B.ro_mode == 2) {
                 const int rc = general_reads_sort(c, s2);
@@ -833,7 +834,7 @@ int run_impl(csv_ctx* c, csv_run_stats* stats)
     B.run_seq = ++c->run_seq;
     if (W > 0) {
         const int nb = div_up(W, CH_TILE);
-        if (fork && do_gt) {
+        if (fork && do_gt && !keep_reads) {
             // reads order + pack: independent of the clustering kernels.  Either chain waits only for whatever ran before on
             // the main stream (the previous run's genotype / publish kernels read what this run rewrites).  The stage's
             // verdict on the table goes to the upload's state, not to the run's counters (which k_chain_count zeroes).
@@ -896,14 +897,22 @@ int run_impl(csv_ctx* c, csv_run_stats* stats)
         }
         if (do_gt) {
             if (swap) {}
-            else if (fork) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_aux[2], 0));
+            else if (fork && !keep_reads) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_aux[2], 0));
             else { HIP_TRY(c, hipStreamWaitEvent(st, c->ev_reads, 0)); const int rc = reads_stage(st); if (rc) return rc; }
+            // the second pass (overflow list of the first; global tables beyond) has usually nothing to do: skipped when an
+            // earlier run of this upload said so (same word scheme as the refine tiers above)
+            bool need_second = true;
+            if (B.host_flag) {
+                const unsigned long long w = ((volatile unsigned long long*)c->h_flag)[1];
+                if ((int)((unsigned)(w >> 32) - (unsigned)c->upload_seq0) > 0 && (int)((unsigned)(w >> 32) - (unsigned)B.run_seq) < 0) need_second = (unsigned)w > 0;
+            }
+            if (getenv("CSV_FORCE_TIERS")) need_second = true;
             if (B.r_start.p32) {
                 hipLaunchKernelGGL((k_genotype<1024, 4, false, true>), dim3(env_int("CSV_GT_GRID", GT_GRID)), dim3(256), 0, st, B);
-                hipLaunchKernelGGL((k_genotype<8192, 4, true, true>), dim3(256), dim3(256), 0, st, B);     // overflow list of the first pass; global tables beyond
+                if (need_second) hipLaunchKernelGGL((k_genotype<8192, 4, true, true>), dim3(256), dim3(256), 0, st, B);
             } else {
                 hipLaunchKernelGGL((k_genotype<1024, 4, false, false>), dim3(env_int("CSV_GT_GRID", GT_GRID)), dim3(256), 0, st, B);
-                hipLaunchKernelGGL((k_genotype<8192, 4, true, false>), dim3(256), dim3(256), 0, st, B);
+                if (need_second) hipLaunchKernelGGL((k_genotype<8192, 4, true, false>), dim3(256), dim3(256), 0, st, B);
             }
             DBG("genotype");
             HIP_TRY(c, mark());

@@ -2219,6 +2219,7 @@ __global__ __launch_bounds__(256) void k_emit(DevBatch B)
     const int jmax = B.cap_items - 1;
     int n = -1;
     for (int tile = wave;; tile += nwaves) {
+        if (n >= 0 && tile >= (n + EM_TILE - 1) / EM_TILE) break;        // (after the first tile the count is known: no loads for nothing)
         const int j = tile * EM_TILE + g;
         // round 1: everything that only depends on the item index is loaded together - and together with the item count
         // itself: the loads of a tile do not wait for `n` (indices are clamped to the tables' capacity; what lies beyond n is
@@ -3024,6 +3025,12 @@ template <int HASH, int WPB, bool SECOND, bool RN> __global__ __launch_bounds__(
     const int n = second ? B.cnt->n_gt_over : B.cnt->n_calls;
     __syncthreads();
     if (pending) return;
+    if constexpr (SECOND) {
+        // tell the host how many calls overflowed the first pass: a later run of the same upload (same calls, same table) skips
+        // this launch when the answer is none (second page-locked word, as k_chain_apply's for the refine tiers)
+        if (B.host_flag && blockIdx.x == 0 && threadIdx.x == 0)
+            __hip_atomic_store((unsigned long long*)B.host_flag + 1, ((unsigned long long)(unsigned)B.run_seq << 32) | (unsigned)n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     if (second && n == 0) return;                                   // (nothing overflowed the first pass: no list, no hand-over)
     if constexpr (SECOND) { if (wave < n) gt_load_head(B, second, wave, cur); }
     for (int q = wave; q < n; q += nwaves, cur = nxt) {

@@ -13,11 +13,15 @@ print("# %-62s %8s %14s %12s %8s" % ("kernel", "calls", "total_us", "avg_us", "p
 for name, calls, total, avg, pct in cur.execute("select name, total_calls, total_duration, average, percentage from top_kernels"):
     print("%-64s %8d %14.3f %12.3f %8.2f" % (name[:64], calls, total, avg, pct))
 try:
-    rows = list(cur.execute("select name, grid_x, workgroup_x, lds_size, scratch_size, vgpr_count, accum_vgpr_count, sgpr_count, "
-                            "count(*), avg(duration)/1000.0, min(duration)/1000.0, max(duration)/1000.0 from kernels group by name, grid_x order by avg(duration) desc"))
-    print("\n# per launch shape: kernel grid wg lds scratch vgpr agpr sgpr calls avg_us min_us max_us")
-    for r in rows:
-        print("%-64s %9d %5d %7d %7d %4d %4d %4d %6d %10.3f %10.3f %10.3f" % ((r[0][:64],) + tuple(r[1:])))
+    import statistics
+    groups = {}
+    for r in cur.execute("select name, grid_x, workgroup_x, lds_size, scratch_size, vgpr_count, accum_vgpr_count, sgpr_count, duration from kernels"):
+        groups.setdefault(tuple(r[:8]), []).append(r[8] / 1000.0)
+    rows = sorted(groups.items(), key=lambda kv: -sum(kv[1]) / len(kv[1]))
+    # (median: the bench command also runs a few steps with the caches flushed, whose launches sit in the average)
+    print("\n# per launch shape: kernel grid wg lds scratch vgpr agpr sgpr calls avg_us median_us min_us max_us")
+    for k, d in rows:
+        print("%-64s %9d %5d %7d %7d %4d %4d %4d %6d %10.3f %10.3f %10.3f %10.3f" % ((k[0][:64],) + tuple(k[1:]) + (len(d), sum(d) / len(d), statistics.median(d), min(d), max(d))))
 except Exception as e:          # view layout differs between versions
     print("# (per-launch view unavailable: %s)" % e)
 try:

@@ -843,6 +843,29 @@ def test_resident_reruns_keep_the_reads_order_state(ctx):
     ctx.option(1, 1)
 
 
+def test_resident_reruns_launch_what_an_earlier_run_asked_for(ctx):
+    """the refine tiers above 64 signatures and the genotype overflow pass are launched in a re-run only if an earlier run of the
+    same upload reported work for them: a deep batch (every tier, cover sets beyond the small hash tables) and a shallow one,
+    uploaded alternately and run several times each, must give the oracle's result every time"""
+    p = Params.ont(genotype=True, min_support=3)
+    deep = synth.small_mixed(seed=4711, n_sites=6, coverage=900, genotype=True)
+    shallow = synth.small_mixed(seed=4712, n_sites=40, coverage=12, genotype=True)
+    cases = []
+    for st in (deep, shallow):
+        hb = st.host_batch(st.tasks(), p)
+        cases.append((st, hb, _oracle().cluster_batch(hb, per_sig=True).trimmed()))
+    for rep in range(2):
+        for st, hb, want in cases:
+            ctx.upload(hb, per_sig=True)
+            for _ in range(4):
+                ctx.run()
+                ctx.sync()                                     # (the answers of the run are on the host before the next one is planned)
+                assert_soa_equal(ctx.download(per_sig=True).trimmed(), want, store=st)
+            for _ in range(3):
+                ctx.run()                                      # ... and with the host running ahead of the device
+            assert_soa_equal(ctx.download(per_sig=True).trimmed(), want, store=st)
+
+
 def test_single_pipe_on_the_gpu(ctx):
     """one extraction task (main script :697-743) with the HIP CIGAR scan and split-read analysis: candidates and reads table
     rows equal the reference's single_pipe"""
