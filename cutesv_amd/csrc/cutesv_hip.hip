@@ -868,7 +868,11 @@ int run_impl(csv_ctx* c, csv_run_stats* stats)
             if ((int)((unsigned)(w >> 32) - (unsigned)c->upload_seq0) > 0 && (int)((unsigned)(w >> 32) - (unsigned)B.run_seq) < 0) need_big = (unsigned)w > 0;
         }
         if (getenv("CSV_FORCE_TIERS")) need_big = true;
-        const bool side_b = fork && need_big, side_c = fork && c->any_pair;
+        // the tiers run side by side only in a large batch: a fork and a join cost 6-10 us each, more than the overlap of short
+        // kernels is worth (five simulation beds, 0.56 M signatures: 110 us in a row, 115-133 us forked; 90x ONT, 11 M: 367 vs 335)
+        const bool tier_fork = fork && W >= (i64)env_int("CSV_TIER_FORK_MIN", 4 << 20);
+        const bool side_b = tier_fork && need_big, side_c = tier_fork && c->any_pair;
+        if (!tier_fork) { sB = st; sC = st; }
         if (side_b || side_c) {
             HIP_TRY(c, hipEventRecord(c->ev_sel, st));
             if (side_b) HIP_TRY(c, hipStreamWaitEvent(sB, c->ev_sel, 0));
