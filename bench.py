@@ -201,6 +201,35 @@ def bench_extract(a):
     parity = all(np.array_equal(got[k], want[k]) for k in ("ins_read", "ins_pos", "ins_len", "del_read", "del_pos", "del_len")) and \
         all(np.array_equal(got_s[k], want_s[k]) for k in ("kind", "read", "a", "b"))
     nops = int(off[-1])
+    # the hand-off extraction -> rebuild: the signatures of 10 tasks through host memory (D2H of the scan's result, rows built
+    # there, H2D into the rebuild, D2H of the sorted columns) and through the context's pool (nothing but src_row comes back)
+    from cutesv_amd import rebuild
+    n_task = 10
+    rank = np.random.default_rng(5).permutation(n * n_task).astype(np.int32)
+    major = np.zeros(2, np.uint8); nodedup = np.array([0, 1], np.uint8)
+
+    def via_host():
+        rows = {k: [] for k in ("seg", "a", "b", "read", "aux")}
+        for k in range(n_task):
+            g = extract.cigar_signatures(ctx, off, cigar, start, use)
+            rows["seg"] += [np.ones(len(g["ins_pos"]), np.int32), np.zeros(len(g["del_pos"]), np.int32)]
+            rows["a"] += [g["ins_pos"] + k, g["del_pos"] + k]; rows["b"] += [g["ins_len"], g["del_len"]]
+            rows["read"] += [k * n + g["ins_read"], k * n + g["del_read"]]; rows["aux"] += [g["ins_len"], np.zeros(len(g["del_pos"]), np.int64)]
+        cat = {k: np.concatenate(v) for k, v in rows.items()}
+        return rebuild.rebuild_columns(ctx, cat["seg"], cat["a"], cat["b"], rank[cat["read"]], cat["aux"], major, nodedup)
+
+    def via_pool():
+        rebuild.pool_reset(ctx)
+        for k in range(n_task):
+            extract.cigar_signatures(ctx, off, cigar, start + k, use, pool=dict(seg_ins=1, seg_del=0, read_base=k * n), host_outputs=False)
+        return rebuild.rebuild_pool(ctx, rank, major, nodedup, keep_on_device=True)
+    chain = {}
+    for name, fn in (("through_host_ms", via_host), ("on_device_ms", via_pool)):
+        fn()
+        t0 = time.perf_counter(); r = fn(); chain[name] = (time.perf_counter() - t0) * 1e3
+        chain[name.replace("_ms", "_rows")] = int(r["n_out"])
+    chain["note"] = "%d tasks of %d reads each: CIGAR scan -> rows -> rebuild (sort + de-duplication); second form: CSV_CG_TO_POOL + CSV_RB_FROM_POOL + CSV_RB_KEEP_ON_DEVICE" % (n_task, n)
+    rebuild.pool_reset(ctx)
     out = {"metric": "reads scanned/sec (CIGAR scan of parse_read, main script :606-655)", "value": n / (ms_c * 1e-3), "unit": "reads/s", "n_gpus": 1,
            "steps": min(a.steps, 10), "warmup": a.warmup, "ms_per_step": ms_c, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "u32 CIGAR words", "data": "synthetic",
@@ -212,7 +241,7 @@ def bench_extract(a):
            "split_reads": {"ms_device": ms_s, "reads_per_s": n / (ms_s * 1e-3), "alignments": int(enc["ent_off"][-1]), "candidates": int(len(got_s["kind"])),
                            "us_per_read_vs_cigar_scan": ms_s / ms_c,
                            "cpu_c_oracle_reads_per_s": n / t_s},
-           "signatures": {"ins": int(len(got["ins_pos"])), "del": int(len(got["del_pos"]))}, "parity_vs_oracle": bool(parity)}
+           "signatures": {"ins": int(len(got["ins_pos"])), "del": int(len(got["del_pos"]))}, "chain_extract_rebuild": chain, "parity_vs_oracle": bool(parity)}
     print(json.dumps(out))
     ctx.close()
 

@@ -8,7 +8,7 @@ import ctypes as C
 
 import numpy as np
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 DEL, INS, DUP, INV, TRA = 0, 1, 2, 3, 4
 SVTYPE_CODE = {"DEL": DEL, "INS": INS, "DUP": DUP, "INV": INV, "TRA": TRA}
 SVTYPE_NAME = {v: k for k, v in SVTYPE_CODE.items()}
@@ -19,7 +19,9 @@ ERR_NAME = {OK: "CSV_OK", E_INVALID: "CSV_E_INVALID", E_CAPACITY: "CSV_E_CAPACIT
 N_STAGES = 24
 GL_TABLE_SIZE = 101 * 101 + 2
 IN_PER_SIG, IN_READS_SORTED, IN_SIG_I32, IN_READS_I32, IN_DEVICE_COLUMNS = 1, 2, 4, 8, 16            # csv_batch_in.flags
-RB_KEEP_ON_DEVICE = 1                         # csv_rebuild_in.flags
+RB_KEEP_ON_DEVICE = 1
+RB_FROM_POOL = 2                        # ... the rows are the context's device-resident signature pool
+CG_TO_POOL = 1                         # csv_cigar_in.flags: the signatures also become pool rows                         # csv_rebuild_in.flags
 SEG_KEY_RANGE = 1                             # csv_batch_out.seg_status bits
 
 # numpy dtype with exactly the C layout of `csv_segment` (all members naturally aligned)

@@ -38,6 +38,9 @@ SYMBOLS = [
     ("csv_cigar_signatures", C.c_int, None),   # prototype set in cutesv_amd/extract.py
     ("csv_split_signatures", C.c_int, None),   # prototype set in cutesv_amd/extract.py
     ("csv_rebuild_signatures", C.c_int, None),  # prototype set in cutesv_amd/rebuild.py
+    ("csv_pool_reset", C.c_int, [C.c_void_p]),
+    ("csv_pool_rows", C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    ("csv_pool_append", C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("csv_vcf_emit", C.c_int, None),           # prototype set in cutesv_amd/vcf.py (needs its struct)
 ]
 

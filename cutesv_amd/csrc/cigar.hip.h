@@ -182,4 +182,33 @@ __global__ __launch_bounds__(256) void k_cigar_emit(CigarArgs A)
     }
 }
 
+// ------------------------------------------------------------------------------------ device-resident signature pool
+// CSV_CG_TO_POOL: the INS / DEL signatures of the batch become rows of the context's pool (segment, position, length, global
+// read index, aux) - what the rebuild step sorts (main script :750-857) - without a trip through host memory.  aux of an
+// INS row is the length of the inserted sequence the caller would cut out of the read (candidates(): the pieces, each
+// clipped to the query sequence like a Python slice).
+struct PoolCols { int* seg; i64* a; i64* b; int* read; int* aux; };
+__global__ __launch_bounds__(256) void k_pool_from_cigar(PoolCols P, i64 base, CigarArgs A, i64 n_ins, i64 n_del, int seg_ins, int seg_del, i64 read_base,
+                                                         const int* query_len)
+{
+    const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (i < n_ins) {
+        const int r = A.ins_read[i];
+        i64 seq = 0;
+        if (query_len) {
+            const i64 ql = query_len[r], p0 = A.ins_piece0[i];
+            for (int k = 0; k < A.ins_npiece[i]; k++) {
+                const i64 q = A.piece_qoff[p0 + k], l = A.piece_len[p0 + k];
+                const i64 lo = q < ql ? q : ql, hi = q + l < ql ? q + l : ql;     // query_sequence[q : q + l]
+                seq += hi > lo ? hi - lo : 0;
+            }
+        } else seq = A.ins_len[i];
+        const i64 o = base + i;
+        P.seg[o] = seg_ins; P.a[o] = A.ins_pos[i]; P.b[o] = A.ins_len[i]; P.read[o] = (int)(read_base + r); P.aux[o] = (int)seq;
+    } else if (i < n_ins + n_del) {
+        const i64 j = i - n_ins, o = base + i;
+        P.seg[o] = seg_del; P.a[o] = A.del_pos[j]; P.b[o] = A.del_len[j]; P.read[o] = (int)(read_base + A.del_read[j]); P.aux[o] = 0;
+    }
+}
+
 }  // namespace csv

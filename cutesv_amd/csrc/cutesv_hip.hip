@@ -130,11 +130,14 @@ struct csv_ctx {
     Buf flush;                                                   // csv_cache_flush scratch
     // rebuild step (slices of `arena_rb`)
     Buf rb_seg, rb_a, rb_b, rb_rid, rb_aux, rb_auxk, rb_major, rb_nodedup, rb_perm0, rb_perm1, rb_hist, rb_tot, rb_partial;
-    Buf rb_oseg, rb_oa, rb_ob, rb_orid, rb_oaux, rb_osrc, rb_segcnt;
+    Buf rb_oseg, rb_oa, rb_ob, rb_orid, rb_oaux, rb_osrc, rb_segcnt, rb_rank, rb_mx;
+    // the device-resident signature pool (stand-alone allocations: it outlives the per-call arenas)
+    Buf pool_seg, pool_a, pool_b, pool_read, pool_aux;
+    i64 pool_n = 0, pool_cap = 0;
     // CIGAR scan (slices of `arena_rb` as well: the two steps never overlap)
     Buf sp_off, sp_len, sp_c0, sp_c1, sp_f0, sp_f1, sp_chr, sp_mapq, sp_strand, sp_primary, sp_seg, sp_cnt, sp_tiles, sp_tot,
         sp_kind, sp_read, sp_ochr, sp_aux, sp_a, sp_b, sp_c, sp_d;
-    Buf cg_off, cg_ops, cg_start, cg_use, cg_cnt, cg_tiles, cg_tot, cg_iread, cg_ipos, cg_ilen, cg_ip0, cg_inp, cg_pq, cg_pl, cg_dread, cg_dpos, cg_dlen;
+    Buf cg_qlen, cg_off, cg_ops, cg_start, cg_use, cg_cnt, cg_tiles, cg_tot, cg_iread, cg_ipos, cg_ilen, cg_ip0, cg_inp, cg_pq, cg_pl, cg_dread, cg_dpos, cg_dlen;
     // page-locked host staging: small tables on the way in, counters + call records + support lists on the way out
     char*  h_pin = nullptr;
     size_t h_pin_cap = 0;
@@ -375,7 +378,7 @@ void csv_ctx_destroy(csv_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    Buf* own[] = {&c->sqrt_tab, &c->rcp_tab, &c->cipk_tab, &c->cnt, &c->rstate, &c->gs_chrom, &c->gs_perm0, &c->gs_perm1, &c->gs_hist, &c->gs_tot, &c->flush};
+    Buf* own[] = {&c->pool_seg, &c->pool_a, &c->pool_b, &c->pool_read, &c->pool_aux, &c->sqrt_tab, &c->rcp_tab, &c->cipk_tab, &c->cnt, &c->rstate, &c->gs_chrom, &c->gs_perm0, &c->gs_perm1, &c->gs_hist, &c->gs_tot, &c->flush};
     for (Buf* b : own) if (b->p) (void)hipFree(b->p);
     if (c->arena.base) (void)hipFree(c->arena.base);
     if (c->arena_rb.base) (void)hipFree(c->arena_rb.base);
@@ -1182,17 +1185,73 @@ int csv_batch_download(csv_ctx* c, csv_batch_out* out)
     return CSV_OK;
 }
 
+// room for `extra` more rows in the pool (grows by copying: the pool is not in an arena)
+static int pool_reserve(csv_ctx* c, i64 extra)
+{
+    const i64 need = c->pool_n + extra;
+    if (need <= c->pool_cap) return CSV_OK;
+    if (need >= (1ll << 31) - 4096) return fail(c, CSV_E_INVALID, "signature pool too large (%lld rows)", (long long)need);
+    const i64 cap = need + need / 2 + 4096;
+    Buf* cols[5] = {&c->pool_seg, &c->pool_a, &c->pool_b, &c->pool_read, &c->pool_aux};
+    const size_t w[5] = {4, 8, 8, 4, 4};
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (int k = 0; k < 5; k++) {
+        void* p = nullptr;
+        hipError_t e = hipMalloc(&p, (size_t)cap * w[k]);
+        if (e != hipSuccess) return fail(c, CSV_E_NOMEM, "hipMalloc(%zu) for the signature pool failed: %s", (size_t)cap * w[k], hipGetErrorString(e));
+        if (c->pool_n > 0) HIP_TRY(c, hipMemcpy(p, cols[k]->p, (size_t)c->pool_n * w[k], hipMemcpyDeviceToDevice));
+        if (cols[k]->p) HIP_TRY(c, hipFree(cols[k]->p));
+        cols[k]->p = p; cols[k]->cap = (size_t)cap * w[k];
+    }
+    c->pool_cap = cap;
+    return CSV_OK;
+}
+
+int csv_pool_reset(csv_ctx* c)
+{
+    if (!c) return CSV_E_INVALID;
+    c->pool_n = 0;
+    return CSV_OK;
+}
+
+int csv_pool_rows(const csv_ctx* c, int64_t* n_rows)
+{
+    if (!c || !n_rows) return CSV_E_INVALID;
+    *n_rows = c->pool_n;
+    return CSV_OK;
+}
+
+int csv_pool_append(csv_ctx* c, int64_t n, const int32_t* seg_id, const int64_t* a, const int64_t* b, const int32_t* read, const int32_t* aux)
+{
+    if (!c || n < 0 || (n > 0 && (!seg_id || !a || !b || !read || !aux))) return CSV_E_INVALID;
+    if (n == 0) return CSV_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    { const int rc = pool_reserve(c, n); if (rc) return rc; }
+    hipStream_t st = c->stream;
+    const i64 o = c->pool_n;
+    HIP_TRY(c, hipMemcpyAsync(dp<int>(c->pool_seg) + o, seg_id, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(dp<i64>(c->pool_a) + o, a, (size_t)n * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(dp<i64>(c->pool_b) + o, b, (size_t)n * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(dp<int>(c->pool_read) + o, read, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(dp<int>(c->pool_aux) + o, aux, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipStreamSynchronize(st));                   // (the caller's arrays may be pageable and are free again on return)
+    c->pool_n += n;
+    return CSV_OK;
+}
+
 int csv_rebuild_signatures(csv_ctx* c, const csv_rebuild_in* in, csv_rebuild_out* out)
 {
     if (!c || !in || !out) return CSV_E_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
-    const i64 n = in->n;
+    const bool from_pool = (in->flags & CSV_RB_FROM_POOL) != 0;
+    const i64 n = from_pool ? c->pool_n : in->n;
     out->n_out = 0; out->ms_device = 0; out->n_passes = 0;
     if (n < 0 || n >= (1ll << 31) - 4096 || in->n_seg <= 0) return fail(c, CSV_E_INVALID, "bad rebuild input");
+    if (from_pool && (!in->read_rank || in->n_rank <= 0 || !in->seg_aux_major)) return fail(c, CSV_E_INVALID, "CSV_RB_FROM_POOL needs read_rank");
     if (n == 0) return CSV_OK;
-    // key widths (bytes that are non-zero somewhere) from one host pass over the columns
+    // key widths (bytes that are non-zero somewhere) from one host pass over the columns (pool rows: from the device, below)
     i64 mx_a = 0, mx_b = 0; int mx_rid = 0, mx_aux = 0, mx_seg = 0;
-    for (i64 i = 0; i < n; i++) {
+    for (i64 i = 0; i < n && !from_pool; i++) {
         const int sg = in->seg_id[i];
         if (sg < 0 || sg >= in->n_seg || in->a[i] < 0 || in->b[i] < 0 || in->read_id[i] < 0 || in->aux[i] < 0)
             return fail(c, CSV_E_INVALID, "row %lld: negative key or segment out of range", (long long)i);
@@ -1210,6 +1269,7 @@ int csv_rebuild_signatures(csv_ctx* c, const csv_rebuild_in* in, csv_rebuild_out
     PL(rb_major, in->n_seg); PL(rb_nodedup, in->n_seg); PL(rb_perm0, n * 4); PL(rb_perm1, n * 4); PL(rb_hist, (size_t)256 * nunits * 4);
     PL(rb_tot, 256 * 4); PL(rb_partial, (ntile + 2) * 4);
     PL(rb_oseg, n * 4); PL(rb_oa, n * 8); PL(rb_ob, n * 8); PL(rb_orid, n * 4); PL(rb_oaux, n * 4); PL(rb_osrc, n * 4); PL(rb_segcnt, ((size_t)in->n_seg + 2) * 8);
+    if (from_pool) { PL(rb_rank, (size_t)in->n_rank * 4); PL(rb_mx, 64); }
 #undef PL
     {
         if (P.total > c->arena_rb.cap) HIP_TRY(c, hipDeviceSynchronize());
@@ -1217,13 +1277,27 @@ int csv_rebuild_signatures(csv_ctx* c, const csv_rebuild_in* in, csv_rebuild_out
         if (rc) return rc;
     }
     hipStream_t st = c->stream;
-    HIP_TRY(c, hipMemcpyAsync(c->rb_seg.p, in->seg_id, n * 4, hipMemcpyHostToDevice, st));
-    HIP_TRY(c, hipMemcpyAsync(c->rb_a.p, in->a, n * 8, hipMemcpyHostToDevice, st));
-    HIP_TRY(c, hipMemcpyAsync(c->rb_b.p, in->b, n * 8, hipMemcpyHostToDevice, st));
-    HIP_TRY(c, hipMemcpyAsync(c->rb_rid.p, in->read_id, n * 4, hipMemcpyHostToDevice, st));
-    HIP_TRY(c, hipMemcpyAsync(c->rb_aux.p, in->aux, n * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(c, hipMemcpyAsync(c->rb_major.p, in->seg_aux_major, in->n_seg, hipMemcpyHostToDevice, st));
     if (in->seg_nodedup) HIP_TRY(c, hipMemcpyAsync(c->rb_nodedup.p, in->seg_nodedup, in->n_seg, hipMemcpyHostToDevice, st));
+    if (!from_pool) {
+        HIP_TRY(c, hipMemcpyAsync(c->rb_seg.p, in->seg_id, n * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(c, hipMemcpyAsync(c->rb_a.p, in->a, n * 8, hipMemcpyHostToDevice, st));
+        HIP_TRY(c, hipMemcpyAsync(c->rb_b.p, in->b, n * 8, hipMemcpyHostToDevice, st));
+        HIP_TRY(c, hipMemcpyAsync(c->rb_rid.p, in->read_id, n * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(c, hipMemcpyAsync(c->rb_aux.p, in->aux, n * 4, hipMemcpyHostToDevice, st));
+    } else {
+        // the pool's rows -> the input columns (read index -> name rank), the key widths from the device
+        HIP_TRY(c, hipMemcpyAsync(c->rb_rank.p, in->read_rank, (size_t)in->n_rank * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(c, hipMemsetAsync(c->rb_mx.p, 0, 64, st));
+        hipLaunchKernelGGL(k_pool_to_rows, dim3(div_up(n, 2048)), dim3(256), 0, st, dp<int>(c->pool_seg), dp<i64>(c->pool_a), dp<i64>(c->pool_b),
+                           dp<int>(c->pool_read), dp<int>(c->pool_aux), n, dp<int>(c->rb_rank), (i64)in->n_rank, in->n_seg, dp<uint8_t>(c->rb_major),
+                           dp<int>(c->rb_seg), dp<i64>(c->rb_a), dp<i64>(c->rb_b), dp<int>(c->rb_rid), dp<int>(c->rb_aux), dp<unsigned long long>(c->rb_mx));
+        unsigned long long mx[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        HIP_TRY(c, hipMemcpyAsync(mx, c->rb_mx.p, 48, hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipStreamSynchronize(st));
+        if (mx[5]) return fail(c, CSV_E_INVALID, "a pool row has a negative key, a segment out of range or a read without a rank");
+        mx_a = (i64)mx[0]; mx_b = (i64)mx[1]; mx_rid = (int)mx[2]; mx_aux = (int)mx[3]; mx_seg = (int)mx[4];
+    }
     HIP_TRY(c, hipEventRecord(c->ev[0], st));
     hipLaunchKernelGGL(k_rebuild_auxkey, dim3(div_up(n, 256)), dim3(256), 0, st, n, dp<int>(c->rb_seg), dp<int>(c->rb_aux),
                        dp<uint8_t>(c->rb_major), dp<int>(c->rb_auxk));
@@ -1306,7 +1380,9 @@ int csv_cigar_signatures(csv_ctx* c, const csv_cigar_in* in, csv_cigar_out* out)
               cap_d = out->cap_sig_del < nops ? out->cap_sig_del : nops;
     Plan P;
 #define PL(buf, bytes) P.add(c->buf, (size_t)(bytes))
+    const bool to_pool = (in->flags & CSV_CG_TO_POOL) != 0;
     PL(cg_off, (n + 1) * 8); PL(cg_ops, (nops + 1) * 4); PL(cg_start, n * 8); PL(cg_use, n); PL(cg_cnt, n * 16);
+    if (to_pool && in->query_len) PL(cg_qlen, n * 4);
     PL(cg_tiles, (size_t)ntile * 24); PL(cg_tot, 32);
     PL(cg_iread, (cap_i + 1) * 4); PL(cg_ipos, (cap_i + 1) * 8); PL(cg_ilen, (cap_i + 1) * 8); PL(cg_ip0, (cap_i + 1) * 8); PL(cg_inp, (cap_i + 1) * 4);
     PL(cg_pq, (cap_p + 1) * 4); PL(cg_pl, (cap_p + 1) * 4);
@@ -1349,7 +1425,18 @@ int csv_cigar_signatures(csv_ctx* c, const csv_cigar_in* in, csv_cigar_out* out)
     hipLaunchKernelGGL(k_cigar_emit, dim3(grid), dim3(256), 0, st, A);
     HIP_TRY(c, hipEventRecord(c->ev[3], st));
     HIP_TRY(c, hipGetLastError());
-#define D2H(dst, buf, bytes) do { if ((bytes) > 0) HIP_TRY(c, hipMemcpyAsync((dst), c->buf.p, (size_t)(bytes), hipMemcpyDeviceToHost, st)); } while (0)
+    if (to_pool && tot[0] + tot[2] > 0) {
+        if (in->read_base < 0 || in->read_base + n >= (1ll << 31)) return fail(c, CSV_E_INVALID, "read_base out of range");
+        { const int rc = pool_reserve(c, tot[0] + tot[2]); if (rc) return rc; }
+        if (in->query_len) HIP_TRY(c, hipMemcpyAsync(c->cg_qlen.p, in->query_len, (size_t)n * 4, hipMemcpyHostToDevice, st));
+        PoolCols PC{dp<int>(c->pool_seg), dp<i64>(c->pool_a), dp<i64>(c->pool_b), dp<int>(c->pool_read), dp<int>(c->pool_aux)};
+        hipLaunchKernelGGL(k_pool_from_cigar, dim3(div_up(tot[0] + tot[2], 256)), dim3(256), 0, st, PC, c->pool_n, A, tot[0], tot[2], in->seg_ins, in->seg_del,
+                           in->read_base, in->query_len ? dp<int>(c->cg_qlen) : nullptr);
+        HIP_TRY(c, hipGetLastError());
+        c->pool_n += tot[0] + tot[2];
+    }
+    // (with CSV_CG_TO_POOL an output array that is NULL is not written)
+#define D2H(dst, buf, bytes) do { if ((bytes) > 0 && ((dst) || !to_pool)) HIP_TRY(c, hipMemcpyAsync((dst), c->buf.p, (size_t)(bytes), hipMemcpyDeviceToHost, st)); } while (0)
     D2H(out->ins_read, cg_iread, tot[0] * 4); D2H(out->ins_pos, cg_ipos, tot[0] * 8); D2H(out->ins_len, cg_ilen, tot[0] * 8);
     D2H(out->ins_piece0, cg_ip0, tot[0] * 8); D2H(out->ins_npiece, cg_inp, tot[0] * 4);
     D2H(out->piece_qoff, cg_pq, tot[1] * 4); D2H(out->piece_len, cg_pl, tot[1] * 4);

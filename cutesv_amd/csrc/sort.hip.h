@@ -221,4 +221,47 @@ __global__ __launch_bounds__(256) void k_rebuild_auxkey(i64 n, const int* seg, c
     if (i < n) auxk[i] = seg_aux_major[seg[i]] ? aux[i] : 0;
 }
 
+// CSV_RB_FROM_POOL: the pool's rows become the rebuild's input columns; the read index of a row is replaced by the rank of the
+// read's NAME (read_rank, the caller's: string order is the host's business), and the largest value of every key column is
+// collected for the radix passes (mx: a, b, read id, aux of aux-major segments, segment; [5] != 0: a row the sort cannot take).
+struct PoolCols;
+__global__ __launch_bounds__(256) void k_pool_to_rows(const int* p_seg, const i64* p_a, const i64* p_b, const int* p_read, const int* p_aux, i64 n,
+                                                      const int* rank, i64 n_rank, int n_seg, const uint8_t* seg_aux_major,
+                                                      int* o_seg, i64* o_a, i64* o_b, int* o_rid, int* o_aux, unsigned long long* mx)
+{
+    __shared__ unsigned long long sh[4][6];
+    unsigned long long m[6] = {0, 0, 0, 0, 0, 0};
+    for (i64 i = (i64)blockIdx.x * 2048 + threadIdx.x; i < n && i < (i64)(blockIdx.x + 1) * 2048; i += 256) {
+        const int sg = p_seg[i], rd = p_read[i], ax = p_aux[i];
+        const i64 a = p_a[i], b = p_b[i];
+        int rk = -1;
+        if (rd >= 0 && rd < n_rank) rk = rank[rd];
+        const bool bad = sg < 0 || sg >= n_seg || a < 0 || b < 0 || rk < 0 || ax < 0;
+        o_seg[i] = bad ? 0 : sg; o_a[i] = a; o_b[i] = b; o_rid[i] = rk; o_aux[i] = ax;
+        if (bad) m[5] = 1;
+        else {
+            m[0] = (unsigned long long)a > m[0] ? (unsigned long long)a : m[0];
+            m[1] = (unsigned long long)b > m[1] ? (unsigned long long)b : m[1];
+            m[2] = (unsigned long long)rk > m[2] ? (unsigned long long)rk : m[2];
+            if (seg_aux_major[sg]) m[3] = (unsigned long long)ax > m[3] ? (unsigned long long)ax : m[3];
+            m[4] = (unsigned long long)sg > m[4] ? (unsigned long long)sg : m[4];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        for (int d = 32; d > 0; d >>= 1) {
+            const unsigned lo = __shfl_xor((unsigned)(m[k] & 0xffffffffull), d), hi = __shfl_xor((unsigned)(m[k] >> 32), d);
+            const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+            m[k] = o > m[k] ? o : m[k];
+        }
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6][k] = m[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        unsigned long long v = sh[0][threadIdx.x];
+        for (int w = 1; w < 4; w++) v = sh[w][threadIdx.x] > v ? sh[w][threadIdx.x] : v;
+        if (v) atomicMax(&mx[threadIdx.x], v);
+    }
+}
+
 }  // namespace csv

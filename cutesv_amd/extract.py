@@ -20,7 +20,8 @@ from ._lib import lib
 
 class CigarIn(C.Structure):
     _fields_ = [("n_reads", C.c_int64), ("cig_off", C.c_void_p), ("cigar", C.c_void_p), ("ref_start", C.c_void_p), ("use", C.c_void_p),
-                ("min_siglength", C.c_int32), ("reserved", C.c_int32), ("merge_ins_threshold", C.c_int64), ("merge_del_threshold", C.c_int64)]
+                ("min_siglength", C.c_int32), ("flags", C.c_int32), ("merge_ins_threshold", C.c_int64), ("merge_del_threshold", C.c_int64),
+                ("seg_ins", C.c_int32), ("seg_del", C.c_int32), ("read_base", C.c_int64), ("query_len", C.c_void_p)]
 
 
 _OUT = [("ins_read", np.int32, "i"), ("ins_pos", np.int64, "i"), ("ins_len", np.int64, "i"), ("ins_piece0", np.int64, "i"), ("ins_npiece", np.int32, "i"),
@@ -51,7 +52,7 @@ def encode_cigars(cigartuples_per_read):
     return off, flat
 
 
-def _run(fn, handle, cig_off, cigar, ref_start, use, min_siglength, merge_ins_threshold, merge_del_threshold, check):
+def _run(fn, handle, cig_off, cigar, ref_start, use, min_siglength, merge_ins_threshold, merge_del_threshold, check, pool=None, host_outputs=True):
     cig_off = np.ascontiguousarray(cig_off, np.int64); cigar = np.ascontiguousarray(cigar, np.uint32)
     ref_start = np.ascontiguousarray(ref_start, np.int64)
     use = None if use is None else np.ascontiguousarray(use, np.uint8)
@@ -59,10 +60,21 @@ def _run(fn, handle, cig_off, cigar, ref_start, use, min_siglength, merge_ins_th
     cin = CigarIn(n_reads=n, cig_off=cig_off.ctypes.data, cigar=cigar.ctypes.data if len(cigar) else None, ref_start=ref_start.ctypes.data,
                   use=None if use is None else use.ctypes.data, min_siglength=int(min_siglength),
                   merge_ins_threshold=int(merge_ins_threshold), merge_del_threshold=int(merge_del_threshold))
+    qlen = None
+    if pool is not None:                                  # CSV_CG_TO_POOL: the signatures also become rows of the context's pool
+        qlen = None if pool.get("query_len") is None else np.ascontiguousarray(pool["query_len"], np.int32)
+        cin.flags = _abi.CG_TO_POOL
+        cin.seg_ins = int(pool["seg_ins"]); cin.seg_del = int(pool["seg_del"]); cin.read_base = int(pool["read_base"])
+        cin.query_len = None if qlen is None else qlen.ctypes.data
     caps = dict(i=max(16, n // 4), p=max(16, n // 4), d=max(16, n // 4))
     for _ in range(2):
-        arrs = {name: np.zeros(caps[k], dt) for name, dt, k in _OUT}
-        cout = CigarOut(cap_sig_ins=caps["i"], cap_piece_ins=caps["p"], cap_sig_del=caps["d"], **{k: v.ctypes.data for k, v in arrs.items()})
+        if host_outputs or pool is None:
+            arrs = {name: np.zeros(caps[k], dt) for name, dt, k in _OUT}
+            cout = CigarOut(cap_sig_ins=caps["i"], cap_piece_ins=caps["p"], cap_sig_del=caps["d"], **{k: v.ctypes.data for k, v in arrs.items()})
+        else:                                             # pool only: nothing but the counts comes back
+            arrs = {name: np.zeros(0, dt) for name, dt, k in _OUT}
+            big = int(cig_off[-1]) + 1
+            cout = CigarOut(cap_sig_ins=big, cap_piece_ins=big, cap_sig_del=big)
         rc = fn(handle, C.byref(cin), C.byref(cout)) if handle is not None else fn(C.byref(cin), C.byref(cout))
         if rc == _abi.E_CAPACITY:
             caps = dict(i=int(cout.n_sig_ins) + 1, p=int(cout.n_piece_ins) + 1, d=int(cout.n_sig_del) + 1)
@@ -70,17 +82,23 @@ def _run(fn, handle, cig_off, cigar, ref_start, use, min_siglength, merge_ins_th
         check(rc)
         cut = dict(i=int(cout.n_sig_ins), p=int(cout.n_piece_ins), d=int(cout.n_sig_del))
         out = {name: arrs[name][:cut[k]] for name, _, k in _OUT}
+        out["n_sig_ins"], out["n_sig_del"] = cut["i"], cut["d"]
         out["ms_device"] = float(cout.ms_device)
         return out
     raise RuntimeError("csv_cigar_signatures: capacity retry failed")
 
 
-def cigar_signatures(ctx, cig_off, cigar, ref_start, use=None, min_siglength=10, merge_ins_threshold=100, merge_del_threshold=0):
-    """flat CIGARs of a batch of reads -> dict of the signature arrays of csv_cigar_out (defaults: cuteSV_Description.py:123-152)"""
+def cigar_signatures(ctx, cig_off, cigar, ref_start, use=None, min_siglength=10, merge_ins_threshold=100, merge_del_threshold=0, pool=None, host_outputs=True):
+    """flat CIGARs of a batch of reads -> dict of the signature arrays of csv_cigar_out (defaults: cuteSV_Description.py:123-152).
+    pool = dict(seg_ins, seg_del, read_base, query_len=None): the signatures ALSO become rows of the context's device-resident
+    pool (CSV_CG_TO_POOL; INS rows in segment seg_ins, DEL rows in seg_del, read index = read_base + index in this batch), in the
+    order INS then DEL - what `rebuild.rebuild_pool` sorts without the rows ever crossing PCIe; host_outputs=False (with a pool):
+    the arrays of the result stay empty, only the counts come back."""
     L = lib()
     L.csv_cigar_signatures.restype = C.c_int
     L.csv_cigar_signatures.argtypes = [C.c_void_p, C.POINTER(CigarIn), C.POINTER(CigarOut)]
-    return _run(L.csv_cigar_signatures, ctx._h, cig_off, cigar, ref_start, use, min_siglength, merge_ins_threshold, merge_del_threshold, ctx._check)
+    return _run(L.csv_cigar_signatures, ctx._h, cig_off, cigar, ref_start, use, min_siglength, merge_ins_threshold, merge_del_threshold, ctx._check, pool=pool,
+                host_outputs=host_outputs)
 
 
 def candidates(sig, read_names, query_sequences, chrom):

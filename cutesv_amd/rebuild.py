@@ -22,7 +22,7 @@ from .columns import SigStore, NameTable, TYPES
 class RebuildIn(C.Structure):
     _fields_ = [("n", C.c_int64), ("n_seg", C.c_int32), ("flags", C.c_int32), ("seg_aux_major", C.c_void_p),
                 ("seg_id", C.c_void_p), ("a", C.c_void_p), ("b", C.c_void_p), ("read_id", C.c_void_p), ("aux", C.c_void_p),
-                ("seg_nodedup", C.c_void_p)]
+                ("seg_nodedup", C.c_void_p), ("read_rank", C.c_void_p), ("n_rank", C.c_int64)]
 
 
 class RebuildOut(C.Structure):
@@ -117,6 +117,52 @@ def rebuild_to_device_batch(ctx, chroms, per_type, params_segment, reads=None):
                   r_end=np.asarray(reads["end"], np.int64)[o], r_primary=np.asarray(reads["primary"], np.uint8)[o], r_id=np.asarray(reads["read_id"], np.int32)[o])
     batch = _abi.HostBatch.on_device(np.array(segs, dtype=_abi.SEGMENT_DTYPE), r["dev"], r["n_out"], n_chrom=len(chroms), keep=ctx, **kw)
     return batch, tasks, r["src_row"]
+
+
+# ------------------------------------------------------------------------------------ the device-resident signature pool
+def pool_reset(ctx):
+    ctx._check(lib().csv_pool_reset(ctx._h))
+
+
+def pool_rows(ctx):
+    n = C.c_int64(0)
+    ctx._check(lib().csv_pool_rows(ctx._h, C.byref(n)))
+    return int(n.value)
+
+
+def pool_append(ctx, seg_id, a, b, read, aux):
+    """rows made on the host (the split-read candidates: they are built from text) -> the context's pool"""
+    seg_id = np.ascontiguousarray(seg_id, np.int32); a = np.ascontiguousarray(a, np.int64); b = np.ascontiguousarray(b, np.int64)
+    read = np.ascontiguousarray(read, np.int32); aux = np.ascontiguousarray(aux, np.int32)
+    ctx._check(lib().csv_pool_append(ctx._h, len(a), seg_id.ctypes.data, a.ctypes.data, b.ctypes.data, read.ctypes.data, aux.ctypes.data))
+
+
+def rebuild_pool(ctx, read_rank, seg_aux_major, seg_nodedup=None, keep_on_device=True):
+    """csv_rebuild_signatures over the context's pool (CSV_RB_FROM_POOL): the rows the extraction kernels left on the device
+    (extract.cigar_signatures(pool=...)) and those appended with pool_append, sorted and de-duplicated; a row's read index is
+    replaced by read_rank[index] (rank of the read's name in Python string order).  Same result dict as rebuild_columns;
+    src_row numbers the pool's rows (extraction order)."""
+    L = lib()
+    L.csv_rebuild_signatures.restype = C.c_int
+    L.csv_rebuild_signatures.argtypes = [C.c_void_p, C.POINTER(RebuildIn), C.POINTER(RebuildOut)]
+    rank = np.ascontiguousarray(read_rank, np.int32)
+    major = np.ascontiguousarray(seg_aux_major, np.uint8)
+    nodedup = None if seg_nodedup is None else np.ascontiguousarray(seg_nodedup, np.uint8)
+    n = pool_rows(ctx)
+    o = dict(src_row=np.empty(n, np.int32))
+    if not keep_on_device:
+        o.update(seg_id=np.empty(n, np.int32), a=np.empty(n, np.int64), b=np.empty(n, np.int64), read_id=np.empty(n, np.int32), aux=np.empty(n, np.int32))
+    seg_count = np.zeros(len(major), np.int64)
+    rin = RebuildIn(n=0, n_seg=len(major), flags=_abi.RB_FROM_POOL | (_abi.RB_KEEP_ON_DEVICE if keep_on_device else 0), seg_aux_major=major.ctypes.data,
+                    seg_nodedup=None if nodedup is None else nodedup.ctypes.data, read_rank=rank.ctypes.data, n_rank=len(rank))
+    rout = RebuildOut(seg_count=seg_count.ctypes.data, **{k: v.ctypes.data for k, v in o.items()})
+    ctx._check(L.csv_rebuild_signatures(ctx._h, C.byref(rin), C.byref(rout)))
+    k = int(rout.n_out)
+    r = {name: v[:k] for name, v in o.items()}
+    r.update(ms_device=float(rout.ms_device), n_passes=int(rout.n_passes), seg_count=seg_count, n_ins_ties=int(rout.n_ins_ties), n_out=k)
+    if keep_on_device:
+        r["dev"] = dict(a=rout.dev_a, b=rout.dev_b, read_id=rout.dev_read_id, aux=rout.dev_aux, seg_id=rout.dev_seg_id, src_row=rout.dev_src_row)
+    return r
 
 
 def finish_ins_ties(r, ins_segs, seq_of_src, half_of_src):

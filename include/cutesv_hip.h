@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CSV_ABI_VERSION 4
+#define CSV_ABI_VERSION 5
 
 /* SV types: one (chromosome, type) pair is one segment == one reference pool task
  * (MAIN:1116-1189).  Order of the enum is irrelevant to results. */
@@ -275,9 +275,14 @@ int32_t csv_gl_index(int64_t c0, int64_t c1);
  * 8 bits per pass, zero bytes skipped; then gather + de-duplication.  Outputs are caller-allocated with
  * room for n rows; src_row[i] = input row of output row i (to carry payloads such as INS sequences).
  */
-enum { CSV_RB_KEEP_ON_DEVICE = 1 };  /* csv_rebuild_in.flags: the sorted columns stay in device memory (csv_rebuild_out.dev_*, valid
+enum {
+    CSV_RB_KEEP_ON_DEVICE = 1,       /* csv_rebuild_in.flags: the sorted columns stay in device memory (csv_rebuild_out.dev_*, valid
                                         until the context's next csv_rebuild_signatures / csv_cigar_signatures / csv_split_signatures
                                         call); host output arrays that are NULL are not written */
+    CSV_RB_FROM_POOL = 2             /* the rows are the context's device-resident signature pool (below): n, seg_id, a, b, read_id and
+                                        aux of csv_rebuild_in are ignored; a row's read index is replaced by read_rank[index] (the
+                                        rank of the read's NAME: string order is the caller's business); src_row numbers pool rows */
+};
 typedef struct csv_rebuild_in {
     int64_t        n;
     int32_t        n_seg;
@@ -291,6 +296,8 @@ typedef struct csv_rebuild_in {
     const uint8_t* seg_nodedup;     /* n_seg or NULL: 1 = sort this segment but keep every row.  INS rows are equal only when
                                        their sequences and the x.5 of a split-read position are equal too (MAIN:228, :774-775):
                                        the caller finishes those few tie groups on the host (cutesv_amd/rebuild.py) */
+    const int32_t* read_rank;       /* CSV_RB_FROM_POOL: n_rank ranks, indexed by the pool rows' read index */
+    int64_t        n_rank;
 } csv_rebuild_in;
 
 typedef struct csv_rebuild_out {
@@ -317,6 +324,15 @@ typedef struct csv_rebuild_out {
 
 int csv_rebuild_signatures(csv_ctx* ctx, const csv_rebuild_in* in, csv_rebuild_out* out);
 
+/* The device-resident signature pool: the reference's dataflow extraction -> rebuild (MAIN:697-743 -> 750-857) without a trip
+ * through host memory.  csv_cigar_signatures with CSV_CG_TO_POOL appends the signatures it finds as rows (segment, position,
+ * length, global read index, aux); csv_pool_append adds rows the host made (the split-read candidates, which are built from
+ * text); csv_rebuild_signatures with CSV_RB_FROM_POOL sorts and de-duplicates the pool.  The pool belongs to the context and
+ * lives until csv_pool_reset / csv_ctx_destroy. */
+int csv_pool_reset(csv_ctx* ctx);
+int csv_pool_rows(const csv_ctx* ctx, int64_t* n_rows);
+int csv_pool_append(csv_ctx* ctx, int64_t n, const int32_t* seg_id, const int64_t* a, const int64_t* b, const int32_t* read, const int32_t* aux);
+
 /* ---------------------------------------------------------------------------------------------
  * The CIGAR scan of the extraction step on the GPU.  Restates the CIGAR part of parse_read
  * (cuteSV main script :606-655: every I / D operation of at least min_siglength bases is a piece at the reference position
@@ -336,10 +352,19 @@ typedef struct csv_cigar_in {
     const int64_t*  ref_start;      /* read.reference_start, 0-based */
     const uint8_t*  use;            /* n_reads or NULL */
     int32_t         min_siglength;  /* --min_siglength (cuteSV_Description.py:152) */
-    int32_t         reserved;
+    int32_t         flags;          /* CSV_CG_* */
     int64_t         merge_ins_threshold;   /* --merge_ins_threshold (:127) */
     int64_t         merge_del_threshold;   /* --merge_del_threshold (:123) */
+    /* CSV_CG_TO_POOL: the signatures also become rows of the context's pool - INS rows in segment seg_ins, DEL rows in seg_del
+     * (the caller's numbering of (chromosome, type)), read index = read_base + the read's index in this batch, aux of an INS
+     * row = length of the sequence the caller would cut out of the read (the pieces clipped to query_len[read] like Python
+     * slices; query_len NULL: the signature's length).  Output arrays of csv_cigar_out that are NULL are then not written
+     * (their capacities still bound the counts). */
+    int32_t         seg_ins, seg_del;
+    int64_t         read_base;
+    const int32_t*  query_len;      /* n_reads or NULL */
 } csv_cigar_in;
+enum { CSV_CG_TO_POOL = 1 };
 
 typedef struct csv_cigar_out {
     int64_t  cap_sig_ins, cap_piece_ins, cap_sig_del;

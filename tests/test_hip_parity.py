@@ -635,6 +635,87 @@ def test_rebuild_hands_its_columns_to_the_cluster_stage_on_the_device(ctx):
         assert got["n_clusters"] == want["n_clusters"] and len(got["bp1"]) > 20
 
 
+def test_extraction_rows_stay_on_the_device_until_they_are_clustered(ctx):
+    """main script :697-743 -> :750-857 -> :1113-1199 with the signature rows never in host memory: the CIGAR scan appends what it
+    finds to the context's pool (CSV_CG_TO_POOL), rows made on the host join it (csv_pool_append), the rebuild sorts the pool
+    (CSV_RB_FROM_POOL; read index -> rank of the read's name) and leaves the columns on the device (CSV_RB_KEEP_ON_DEVICE) for
+    csv_cluster_batch (CSV_IN_DEVICE_COLUMNS).  Same rows and same calls as the chain through host memory."""
+    from cutesv_amd import extract, rebuild
+    from cutesv_amd.columns import TYPES
+    rng = np.random.default_rng(11)
+    n_chrom, tasks = 3, []
+    base = 0
+    for k in range(5):
+        n = int(rng.integers(1500, 4000))
+        off, cigar, start, use = synth.cigar_reads(n, seed=900 + k, mean_ops=60)
+        start = rng.integers(0, 60_000, n).astype(np.int64)                    # (dense enough for clusters to form)
+        qlen = rng.integers(200, 30_000, n).astype(np.int32)                   # some reads shorter than their insertions reach: clipped sequences
+        tasks.append(dict(off=off, cigar=cigar, start=start, use=use, qlen=qlen, chrom=k % n_chrom, base=base))
+        base += n
+    n_reads = base
+    names = ["read%07d" % x for x in rng.permutation(n_reads * 3)[:n_reads]]   # string order != extraction order
+    rank = np.empty(n_reads, np.int32)
+    rank[np.argsort(np.array(names), kind="stable")] = np.arange(n_reads, dtype=np.int32)
+    seg_of = lambda t, ci: TYPES.index(t) * n_chrom + ci
+    n_seg = len(TYPES) * n_chrom
+    major = np.zeros(n_seg, np.uint8); nodedup = np.zeros(n_seg, np.uint8)
+    for t in ("INV", "TRA"):
+        major[TYPES.index(t) * n_chrom:(TYPES.index(t) + 1) * n_chrom] = 1
+    nodedup[TYPES.index("INS") * n_chrom:(TYPES.index("INS") + 1) * n_chrom] = 1
+    # a few rows the host made (stand-ins for split-read candidates), joined at the end
+    extra = dict(seg=np.full(40, seg_of("DUP", 1), np.int32), a=rng.integers(0, 60_000, 40).astype(np.int64), b=rng.integers(1000, 90_000, 40).astype(np.int64),
+                 read=rng.integers(0, n_reads, 40).astype(np.int32), aux=np.zeros(40, np.int32))
+    extra = {k: np.concatenate([v, v[:7]]) for k, v in extra.items()}        # with duplicates: the rebuild drops them
+
+    # ---- through host memory
+    rows = {k: [] for k in ("seg", "a", "b", "read", "aux")}
+    for t in tasks:
+        sig = extract.cigar_signatures(ctx, t["off"], t["cigar"], t["start"], t["use"])
+        ql = t["qlen"][sig["ins_read"]].astype(np.int64)
+        seq = np.zeros(len(sig["ins_read"]), np.int64)
+        for i, (p0, npc) in enumerate(zip(sig["ins_piece0"].tolist(), sig["ins_npiece"].tolist())):
+            for q, l in zip(sig["piece_qoff"][p0:p0 + npc].tolist(), sig["piece_len"][p0:p0 + npc].tolist()):
+                seq[i] += max(0, min(q + l, int(ql[i])) - min(q, int(ql[i])))                     # len(query_sequence[q : q + l])
+        rows["seg"] += [np.full(len(seq), seg_of("INS", t["chrom"])), np.full(len(sig["del_read"]), seg_of("DEL", t["chrom"]))]
+        rows["a"] += [sig["ins_pos"], sig["del_pos"]]; rows["b"] += [sig["ins_len"], sig["del_len"]]
+        rows["read"] += [t["base"] + sig["ins_read"], t["base"] + sig["del_read"]]; rows["aux"] += [seq, np.zeros(len(sig["del_read"]), np.int64)]
+    for k in rows:
+        rows[k].append(extra[k])
+    cat = {k: np.concatenate(v) for k, v in rows.items()}
+    assert (cat["aux"][: len(cat["aux"]) - 47] != cat["b"][: len(cat["b"]) - 47]).sum() > 10        # clipped sequences exist
+    want = rebuild.rebuild_columns(ctx, cat["seg"], cat["a"], cat["b"], rank[cat["read"]], cat["aux"], major, nodedup)
+
+    # ---- on the device
+    rebuild.pool_reset(ctx)
+    for t in tasks:
+        extract.cigar_signatures(ctx, t["off"], t["cigar"], t["start"], t["use"],
+                                 pool=dict(seg_ins=seg_of("INS", t["chrom"]), seg_del=seg_of("DEL", t["chrom"]), read_base=t["base"], query_len=t["qlen"]))
+    rebuild.pool_append(ctx, extra["seg"], extra["a"], extra["b"], extra["read"], extra["aux"])
+    assert rebuild.pool_rows(ctx) == len(cat["a"])
+    got = rebuild.rebuild_pool(ctx, rank, major, nodedup, keep_on_device=False)
+    for k in ("seg_id", "a", "b", "read_id", "aux", "src_row"):
+        assert np.array_equal(got[k], want[k]), k
+    assert np.array_equal(got["seg_count"], want["seg_count"]) and got["n_ins_ties"] == want["n_ins_ties"] and len(got["a"]) < len(cat["a"])
+
+    # ---- ... and on into the clustering stage
+    dev = rebuild.rebuild_pool(ctx, rank, major, nodedup, keep_on_device=True)
+    off = np.r_[0, np.cumsum(dev["seg_count"])]
+    segs = []
+    for sgi in range(n_seg):
+        if dev["seg_count"][sgi]:
+            t = TYPES[sgi // n_chrom]
+            segs.append(_abi.make_segment(t, sgi % n_chrom, int(off[sgi]), int(off[sgi + 1]), 200 if t == "DEL" else 100, 3, diff_ratio=0.3,
+                                          sv_size=30, max_size=100000, min_support_reads=3))
+    segs = np.array(segs, dtype=_abi.SEGMENT_DTYPE)
+    batch = _abi.HostBatch.on_device(segs, dev["dev"], len(dev["src_row"]), n_chrom=n_chrom, keep=ctx)
+    res_dev = ctx.cluster_batch(batch).trimmed()
+    res_host = ctx.cluster_batch(_abi.HostBatch(segs, want["a"], want["b"], want["read_id"], want["aux"], n_chrom=n_chrom)).trimmed()
+    for k in ("call_seg", "bp1", "bp2", "support", "cipos", "cilen", "search_pos", "seq_pick", "support_off", "support_sig"):
+        assert np.array_equal(res_dev[k], res_host[k]), k
+    assert len(res_dev["bp1"]) > 20
+    rebuild.pool_reset(ctx)
+
+
 def test_gpu_rebuild_identical_to_reference_rebuild(ctx):
     """csv_rebuild_signatures (+ the host finish of INS tie groups) on the raw, concatenated per-worker candidates ==
     the per-chromosome lists the reference's process_process_sigs_type wrote (rebuild_order.json.gz)"""
