@@ -132,7 +132,7 @@ struct csv_ctx {
     Buf rb_seg, rb_a, rb_b, rb_rid, rb_aux, rb_auxk, rb_major, rb_nodedup, rb_perm0, rb_perm1, rb_hist, rb_tot, rb_partial;
     Buf rb_oseg, rb_oa, rb_ob, rb_orid, rb_oaux, rb_osrc, rb_segcnt, rb_rank, rb_mx;
     // the device-resident signature pool (stand-alone allocations: it outlives the per-call arenas)
-    Buf pool_seg, pool_a, pool_b, pool_read, pool_aux;
+    Buf pool_seg, pool_a, pool_b, pool_read, pool_aux, sp_qlen;
     i64 pool_n = 0, pool_cap = 0;
     // CIGAR scan (slices of `arena_rb` as well: the two steps never overlap)
     Buf sp_off, sp_len, sp_c0, sp_c1, sp_f0, sp_f1, sp_chr, sp_mapq, sp_strand, sp_primary, sp_seg, sp_cnt, sp_tiles, sp_tot,
@@ -378,7 +378,7 @@ void csv_ctx_destroy(csv_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    Buf* own[] = {&c->pool_seg, &c->pool_a, &c->pool_b, &c->pool_read, &c->pool_aux, &c->sqrt_tab, &c->rcp_tab, &c->cipk_tab, &c->cnt, &c->rstate, &c->gs_chrom, &c->gs_perm0, &c->gs_perm1, &c->gs_hist, &c->gs_tot, &c->flush};
+    Buf* own[] = {&c->pool_seg, &c->pool_a, &c->pool_b, &c->pool_read, &c->pool_aux, &c->sp_qlen, &c->sqrt_tab, &c->rcp_tab, &c->cipk_tab, &c->cnt, &c->rstate, &c->gs_chrom, &c->gs_perm0, &c->gs_perm1, &c->gs_hist, &c->gs_tot, &c->flush};
     for (Buf* b : own) if (b->p) (void)hipFree(b->p);
     if (c->arena.base) (void)hipFree(c->arena.base);
     if (c->arena_rb.base) (void)hipFree(c->arena_rb.base);
@@ -1510,7 +1510,20 @@ int csv_split_signatures(csv_ctx* c, const csv_split_in* in, csv_split_out* out)
     hipLaunchKernelGGL(k_split_emit, dim3(grid), dim3(256), 0, st, A);
     HIP_TRY(c, hipEventRecord(c->ev[3], st));
     HIP_TRY(c, hipGetLastError());
-#define D2H(dst, buf, bytes) do { if ((bytes) > 0) HIP_TRY(c, hipMemcpyAsync((dst), c->buf.p, (size_t)(bytes), hipMemcpyDeviceToHost, st)); } while (0)
+    const bool to_pool = (in->flags & CSV_CG_TO_POOL) != 0;
+    if (to_pool && tot[0] > 0) {
+        if (in->read_base < 0 || in->read_base + n >= (1ll << 31)) return fail(c, CSV_E_INVALID, "read_base out of range");
+        { const int rc = pool_reserve(c, tot[0]); if (rc) return rc; }
+        if (in->query_len) { const int rc = reserve(c, c->sp_qlen, (size_t)n * 4); if (rc) return rc; HIP_TRY(c, hipMemcpyAsync(c->sp_qlen.p, in->query_len, (size_t)n * 4, hipMemcpyHostToDevice, st)); }
+        PoolCols PC{dp<int>(c->pool_seg), dp<i64>(c->pool_a), dp<i64>(c->pool_b), dp<int>(c->pool_read), dp<int>(c->pool_aux)};
+        PoolSegBase SB{};
+        for (int k = 0; k < 5; k++) SB.b[k] = in->pool_seg_base[k];
+        hipLaunchKernelGGL(k_pool_from_split, dim3(div_up(tot[0], 256)), dim3(256), 0, st, PC, c->pool_n, A, tot[0], SB, in->read_base,
+                           in->query_len ? dp<int>(c->sp_qlen) : nullptr);
+        HIP_TRY(c, hipGetLastError());
+        c->pool_n += tot[0];
+    }
+#define D2H(dst, buf, bytes) do { if ((bytes) > 0 && ((dst) || !to_pool)) HIP_TRY(c, hipMemcpyAsync((dst), c->buf.p, (size_t)(bytes), hipMemcpyDeviceToHost, st)); } while (0)
     D2H(out->kind, sp_kind, tot[0]); D2H(out->read, sp_read, tot[0] * 4); D2H(out->chr, sp_ochr, tot[0] * 4); D2H(out->aux, sp_aux, tot[0] * 4);
     D2H(out->a, sp_a, tot[0] * 8); D2H(out->b, sp_b, tot[0] * 8); D2H(out->c, sp_c, tot[0] * 8); D2H(out->d, sp_d, tot[0] * 8);
 #undef D2H

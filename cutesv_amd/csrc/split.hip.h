@@ -187,4 +187,25 @@ __global__ __launch_bounds__(256) void k_split_emit(SplitArgs A)
     if (r < A.n_reads) split_read<true>(A, r, A.cnt[r].x);
 }
 
+// CSV_CG_TO_POOL: the candidates as rows of the device-resident signature pool (cigar.hip.h PoolCols), in the columns the rebuild
+// sorts on (cutesv_amd/columns.py from_tuple_lists has the same encoding: INV aux = strand code, TRA aux = chr2 * 8 + type)
+struct PoolSegBase { int b[5]; };
+__global__ __launch_bounds__(256) void k_pool_from_split(PoolCols P, i64 base, SplitArgs A, i64 n, PoolSegBase sb, i64 read_base, const int* query_len)
+{
+    const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int kind = A.kind[i], r = A.read[i], aux = A.aux[i];
+    i64 a = A.a[i], b = A.b[i];
+    int ax = 0;
+    if (kind == 1) {
+        if (aux & 2) a >>= 1;                               // an x.5 position travels doubled: its integer part sorts
+        const i64 ql = query_len ? (i64)query_len[r] : A.read_len[r], c = A.c[i], d = A.d[i];
+        const i64 lo = c < ql ? c : ql, hi = d < ql ? d : ql;
+        ax = (int)(hi > lo ? hi - lo : 0);
+    } else if (kind == 3) ax = aux;
+    else if (kind == 4) ax = (int)(A.c[i] * 8 + aux);
+    const i64 o = base + i;
+    P.seg[o] = sb.b[kind] + A.o_chr[i]; P.a[o] = a; P.b[o] = b; P.read[o] = (int)(read_base + r); P.aux[o] = ax;
+}
+
 }  // namespace csv

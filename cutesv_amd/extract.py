@@ -120,7 +120,8 @@ def candidates(sig, read_names, query_sequences, chrom):
 class SplitIn(C.Structure):
     _fields_ = [("n_reads", C.c_int64), ("ent_off", C.c_void_p), ("read_len", C.c_void_p), ("c0", C.c_void_p), ("c1", C.c_void_p),
                 ("f0", C.c_void_p), ("f1", C.c_void_p), ("chr", C.c_void_p), ("mapq", C.c_void_p), ("strand", C.c_void_p), ("primary", C.c_void_p),
-                ("sv_size", C.c_int64), ("max_size", C.c_int64), ("min_mapq", C.c_int32), ("max_split_parts", C.c_int32)]
+                ("sv_size", C.c_int64), ("max_size", C.c_int64), ("min_mapq", C.c_int32), ("max_split_parts", C.c_int32),
+                ("flags", C.c_int32), ("pool_seg_base", C.c_int32 * 5), ("read_base", C.c_int64), ("query_len", C.c_void_p)]
 
 
 _SPLIT_OUT = [("kind", np.uint8), ("read", np.int32), ("chr", np.int32), ("aux", np.int32), ("a", np.int64), ("b", np.int64), ("c", np.int64), ("d", np.int64)]
@@ -173,13 +174,20 @@ def encode_split_reads(reads, chrom_rank):
     return out
 
 
-def _run_split(fn, handle, enc, sv_size, min_mapq, max_split_parts, max_size, check):
+def _run_split(fn, handle, enc, sv_size, min_mapq, max_split_parts, max_size, check, pool=None):
     a = {k: np.ascontiguousarray(v) for k, v in enc.items()}
     n = len(a["read_len"])
     ptr = lambda x: x.ctypes.data if len(x) else None                      # noqa: E731
     sin = SplitIn(n_reads=n, ent_off=a["ent_off"].ctypes.data, read_len=ptr(a["read_len"]), c0=ptr(a["c0"]), c1=ptr(a["c1"]), f0=ptr(a["f0"]),
                   f1=ptr(a["f1"]), chr=ptr(a["chr"]), mapq=ptr(a["mapq"]), strand=ptr(a["strand"]), primary=ptr(a["primary"]),
                   sv_size=int(sv_size), max_size=int(max_size), min_mapq=int(min_mapq), max_split_parts=int(max_split_parts))
+    qlen = None
+    if pool is not None:                                  # CSV_CG_TO_POOL: the candidates also become rows of the context's pool
+        qlen = None if pool.get("query_len") is None else np.ascontiguousarray(pool["query_len"], np.int32)
+        sin.flags = _abi.CG_TO_POOL
+        sin.pool_seg_base = (C.c_int32 * 5)(*[int(x) for x in pool["seg_base"]])
+        sin.read_base = int(pool["read_base"])
+        sin.query_len = None if qlen is None else qlen.ctypes.data
     cap = max(16, 2 * n)
     for _ in range(2):
         arrs = {name: np.zeros(cap, dt) for name, dt in _SPLIT_OUT}
@@ -195,13 +203,27 @@ def _run_split(fn, handle, enc, sv_size, min_mapq, max_split_parts, max_size, ch
     raise RuntimeError("csv_split_signatures: capacity retry failed")
 
 
-def split_signatures(ctx, enc, sv_size=30, min_mapq=20, max_split_parts=7, max_size=100000):
+def split_signatures(ctx, enc, sv_size=30, min_mapq=20, max_split_parts=7, max_size=100000, pool=None):
     """flat split-read entries of a batch of reads (encode_split_reads) -> dict of the candidate arrays of csv_split_out
-    (defaults: cuteSV_Description.py: --min_size 30, --min_mapq 20, --max_split_parts 7, --max_size 100000)"""
+    (defaults: cuteSV_Description.py: --min_size 30, --min_mapq 20, --max_split_parts 7, --max_size 100000).
+    pool = dict(seg_base=[segment of chromosome rank 0 for kind DEL, INS, DUP, INV, TRA], read_base, query_len=None): the
+    candidates ALSO become rows of the context's device-resident pool (`pool_rows_of_split` is the same mapping on the host)."""
     L = lib()
     L.csv_split_signatures.restype = C.c_int
     L.csv_split_signatures.argtypes = [C.c_void_p, C.POINTER(SplitIn), C.POINTER(SplitOut)]
-    return _run_split(L.csv_split_signatures, ctx._h, enc, sv_size, min_mapq, max_split_parts, max_size, ctx._check)
+    return _run_split(L.csv_split_signatures, ctx._h, enc, sv_size, min_mapq, max_split_parts, max_size, ctx._check, pool=pool)
+
+
+def pool_rows_of_split(sig, seg_base, read_base, query_len):
+    """the rows csv_split_signatures appends to the pool for the candidates `sig` (host restatement, for tests and for callers
+    that build the rows themselves): dict(seg, a, b, read, aux) in candidate order"""
+    kind = sig["kind"].astype(np.int64); aux = sig["aux"].astype(np.int64)
+    a = np.where((kind == 1) & ((aux & 2) != 0), sig["a"] >> 1, sig["a"])
+    ql = np.asarray(query_len, np.int64)[sig["read"]]
+    lo, hi = np.minimum(sig["c"], ql), np.minimum(sig["d"], ql)
+    ax = np.where(kind == 1, np.maximum(hi - lo, 0), np.where(kind == 3, aux, np.where(kind == 4, sig["c"] * 8 + aux, 0)))
+    return dict(seg=(np.asarray(seg_base, np.int64)[kind] + sig["chr"]).astype(np.int32), a=a.astype(np.int64), b=sig["b"].astype(np.int64),
+                read=(read_base + sig["read"]).astype(np.int32), aux=ax.astype(np.int32))
 
 
 _COMP = str.maketrans("ACGTNacgtn", "TGCANtgcan")

@@ -326,8 +326,8 @@ int csv_rebuild_signatures(csv_ctx* ctx, const csv_rebuild_in* in, csv_rebuild_o
 
 /* The device-resident signature pool: the reference's dataflow extraction -> rebuild (MAIN:697-743 -> 750-857) without a trip
  * through host memory.  csv_cigar_signatures with CSV_CG_TO_POOL appends the signatures it finds as rows (segment, position,
- * length, global read index, aux); csv_pool_append adds rows the host made (the split-read candidates, which are built from
- * text); csv_rebuild_signatures with CSV_RB_FROM_POOL sorts and de-duplicates the pool.  The pool belongs to the context and
+ * length, global read index, aux), csv_split_signatures its candidates; csv_pool_append adds rows the host made;
+ * csv_rebuild_signatures with CSV_RB_FROM_POOL sorts and de-duplicates the pool.  The pool belongs to the context and
  * lives until csv_pool_reset / csv_ctx_destroy. */
 int csv_pool_reset(csv_ctx* ctx);
 int csv_pool_rows(const csv_ctx* ctx, int64_t* n_rows);
@@ -411,6 +411,16 @@ typedef struct csv_split_in {
     int64_t         max_size;       /* --max_size, -1: no limit */
     int32_t         min_mapq;
     int32_t         max_split_parts;   /* -1: no limit */
+    /* CSV_CG_TO_POOL in `flags`: the candidates also become rows of the context's pool (csv_pool_* above).  A candidate of kind k
+     * (0 DEL, 1 INS, 2 DUP, 3 INV, 4 TRA) on chromosome rank ch goes to segment pool_seg_base[k] + ch with the columns the rebuild
+     * sorts on: (pos, len) for DEL / INS (an x.5 INS position as its integer part; aux = length of query[c:d], clipped to
+     * query_len[read] - NULL: read_len - like a Python slice), (pos1, pos2) for DUP, aux = strand code for INV, aux = chr2 * 8 +
+     * type for TRA; read index = read_base + the read's index in this batch.  Output arrays of csv_split_out that are NULL are
+     * then not written. */
+    int32_t         flags;
+    int32_t         pool_seg_base[5];
+    int64_t         read_base;
+    const int32_t*  query_len;      /* n_reads or NULL */
 } csv_split_in;
 
 typedef struct csv_split_out {

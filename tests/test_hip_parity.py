@@ -650,7 +650,7 @@ def test_extraction_rows_stay_on_the_device_until_they_are_clustered(ctx):
         off, cigar, start, use = synth.cigar_reads(n, seed=900 + k, mean_ops=60)
         start = rng.integers(0, 60_000, n).astype(np.int64)                    # (dense enough for clusters to form)
         qlen = rng.integers(200, 30_000, n).astype(np.int32)                   # some reads shorter than their insertions reach: clipped sequences
-        tasks.append(dict(off=off, cigar=cigar, start=start, use=use, qlen=qlen, chrom=k % n_chrom, base=base))
+        tasks.append(dict(off=off, cigar=cigar, start=start, use=use, qlen=qlen, chrom=k % n_chrom, base=base, enc=synth.split_reads(n, seed=950 + k, n_chrom=n_chrom)))
         base += n
     n_reads = base
     names = ["read%07d" % x for x in rng.permutation(n_reads * 3)[:n_reads]]   # string order != extraction order
@@ -667,8 +667,10 @@ def test_extraction_rows_stay_on_the_device_until_they_are_clustered(ctx):
                  read=rng.integers(0, n_reads, 40).astype(np.int32), aux=np.zeros(40, np.int32))
     extra = {k: np.concatenate([v, v[:7]]) for k, v in extra.items()}        # with duplicates: the rebuild drops them
 
+    seg_base = [seg_of(t, 0) for t in ("DEL", "INS", "DUP", "INV", "TRA")]   # by candidate kind
     # ---- through host memory
     rows = {k: [] for k in ("seg", "a", "b", "read", "aux")}
+    n_split = 0
     for t in tasks:
         sig = extract.cigar_signatures(ctx, t["off"], t["cigar"], t["start"], t["use"])
         ql = t["qlen"][sig["ins_read"]].astype(np.int64)
@@ -679,10 +681,15 @@ def test_extraction_rows_stay_on_the_device_until_they_are_clustered(ctx):
         rows["seg"] += [np.full(len(seq), seg_of("INS", t["chrom"])), np.full(len(sig["del_read"]), seg_of("DEL", t["chrom"]))]
         rows["a"] += [sig["ins_pos"], sig["del_pos"]]; rows["b"] += [sig["ins_len"], sig["del_len"]]
         rows["read"] += [t["base"] + sig["ins_read"], t["base"] + sig["del_read"]]; rows["aux"] += [seq, np.zeros(len(sig["del_read"]), np.int64)]
+        sp = extract.pool_rows_of_split(extract.split_signatures(ctx, t["enc"]), seg_base, t["base"], t["qlen"])      # the split-read candidates of the task
+        for k in rows:
+            rows[k].append(sp[k])
+        n_split += len(sp["a"])
+    assert n_split > 500
     for k in rows:
         rows[k].append(extra[k])
     cat = {k: np.concatenate(v) for k, v in rows.items()}
-    assert (cat["aux"][: len(cat["aux"]) - 47] != cat["b"][: len(cat["b"]) - 47]).sum() > 10        # clipped sequences exist
+    assert ((cat["seg"] // n_chrom == TYPES.index("INS")) & (cat["aux"] != cat["b"])).sum() > 10   # clipped sequences exist
     want = rebuild.rebuild_columns(ctx, cat["seg"], cat["a"], cat["b"], rank[cat["read"]], cat["aux"], major, nodedup)
 
     # ---- on the device
@@ -690,6 +697,7 @@ def test_extraction_rows_stay_on_the_device_until_they_are_clustered(ctx):
     for t in tasks:
         extract.cigar_signatures(ctx, t["off"], t["cigar"], t["start"], t["use"],
                                  pool=dict(seg_ins=seg_of("INS", t["chrom"]), seg_del=seg_of("DEL", t["chrom"]), read_base=t["base"], query_len=t["qlen"]))
+        extract.split_signatures(ctx, t["enc"], pool=dict(seg_base=seg_base, read_base=t["base"], query_len=t["qlen"]))
     rebuild.pool_append(ctx, extra["seg"], extra["a"], extra["b"], extra["read"], extra["aux"])
     assert rebuild.pool_rows(ctx) == len(cat["a"])
     got = rebuild.rebuild_pool(ctx, rank, major, nodedup, keep_on_device=False)
