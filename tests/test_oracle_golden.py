@@ -200,3 +200,36 @@ def test_single_pipe_task_gates_and_reads_table_vs_reference():
     from oracle import oracle
     for case in load_json("single_pipe.json.gz"):
         assert_single_pipe_case(case, oracle.cigar_signatures, oracle.split_signatures)
+
+
+def test_pool_rows_of_the_split_candidates_encode_the_reference_tuples():
+    """the rows the split-read kernel appends to the device-resident pool (restated on the host by extract.pool_rows_of_split)
+    carry exactly what the rebuild sorts of the reference's candidate tuples (split_sigs.json.gz: organize_split_signal's own
+    output): positions, lengths / second positions, the INS sequence length, the INV strand code, the TRA mate and type"""
+    from cutesv_amd import extract
+    from cutesv_amd.columns import BND_CODE
+    from helpers import split_case_inputs
+    n = 0
+    for case in load_json("split_sigs.json.gz"):
+        enc, names, queries, chroms, kw = split_case_inputs(case)
+        sig = oracle.split_signatures(enc, **kw)
+        rows = extract.pool_rows_of_split(sig, [0, 100, 200, 300, 400], 5000, [len(q) for q in queries])
+        cand = extract.split_candidates(sig, names, queries, chroms)
+        at = {t: 0 for t in cand}
+        rank = {c: i for i, c in enumerate(chroms)}
+        for i, kind in enumerate(sig["kind"].tolist()):
+            t = ("DEL", "INS", "DUP", "INV", "TRA")[kind]
+            x = cand[t][at[t]]; at[t] += 1
+            a, b, aux, seg, read = (int(rows[k][i]) for k in ("a", "b", "aux", "seg", "read"))
+            assert read == 5000 + int(sig["read"][i]) and names[read - 5000] == (x[2] if t == "INS" else x[-3])
+            assert seg == kind * 100 + rank[x[-1]]
+            if t in ("DEL", "DUP"):
+                assert (a, b, aux) == (x[0], x[1], 0)
+            elif t == "INS":
+                assert (a, b, aux) == (int(x[0]), x[1], len(x[3]))
+            elif t == "INV":
+                assert (aux, a, b) == ({"++": 0, "--": 1}[x[0]], x[1], x[2])
+            else:
+                assert (aux, a, b) == (rank[x[2]] * 8 + BND_CODE[x[0]], x[1], x[3])
+            n += 1
+    assert n > 1000
