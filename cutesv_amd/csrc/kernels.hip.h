@@ -952,12 +952,89 @@ template <int E, class KP> __device__ __forceinline__ void bitonic_wave_mem(KP K
     for (int e = 0; e < E; e++) if (e * 64 + lane < P) K[e * 64 + lane] = k[e];
 }
 
-template <int BLOCK, class KP> __device__ void bitonic_sort(KP K, int P)
+// The same network on 32-bit keys: half the instructions per compare-exchange (one DPP / bpermute, one compare, one select
+// instead of two, three and two).  Both sort keys of the refine kernels are (value << S) | small index: when every value of a
+// cluster fits 32 - LB bits (read ids below 2^24, lengths below 2^24: nearly always) the keys are packed, sorted and unpacked
+// in registers.  Returns false (nothing done) when they do not fit.
+template <int J> __device__ __forceinline__ unsigned xor_lane_u32(unsigned v)
+{
+    if (J == 1) return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xf, 0xf, false);
+    if (J == 2) return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xf, 0xf, false);
+    if (J == 8) return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x128, 0xf, 0xf, false);
+    return (unsigned)__shfl_xor((int)v, J);
+}
+template <int E, int J> __device__ __forceinline__ void bitonic_step_lanes32(unsigned (&k)[E], int kk)
+{
+    const int lane = lane_id();
+    const bool lower = (lane & J) == 0;
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const unsigned other = xor_lane_u32<J>(k[e]);
+        const bool asc = ((e * 64 + lane) & kk) == 0;
+        const unsigned mn = k[e] < other ? k[e] : other, mx = k[e] < other ? other : k[e];
+        k[e] = (lower == asc) ? mn : mx;
+    }
+}
+template <int E> __device__ __forceinline__ void bitonic_wave32(unsigned (&k)[E])
+{
+    const int lane = lane_id();
+    for (int kk = 2; kk <= 64 * E; kk <<= 1) {
+        for (int j = kk >> 1; j >= 64; j >>= 1) {            // same-lane partners
+            const int de = j >> 6;
+#pragma unroll
+            for (int e = 0; e < E; e++)
+                if ((e & de) == 0 && (e | de) < E) {
+                    const bool asc = ((e * 64 + lane) & kk) == 0;
+                    const unsigned x = k[e], y = k[e | de];
+                    if ((x > y) == asc) { k[e] = y; k[e | de] = x; }
+                }
+        }
+        const int j0 = kk >> 1 < 32 ? kk >> 1 : 32;
+        if (j0 >= 32) bitonic_step_lanes32<E, 32>(k, kk);
+        if (j0 >= 16) bitonic_step_lanes32<E, 16>(k, kk);
+        if (j0 >= 8) bitonic_step_lanes32<E, 8>(k, kk);
+        if (j0 >= 4) bitonic_step_lanes32<E, 4>(k, kk);
+        if (j0 >= 2) bitonic_step_lanes32<E, 2>(k, kk);
+        bitonic_step_lanes32<E, 1>(k, kk);
+    }
+}
+template <int E, class KP> __device__ __forceinline__ bool bitonic_wave_mem32(KP K, int P, int S)
+{
+    constexpr int LB = 8;                                   // the index of at most 256 elements
+    const int lane = lane_id();
+    u64 k[E];
+    bool fits = true;
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        k[e] = (e * 64 + lane < P) ? K[e * 64 + lane] : PAD_KEY;
+        if (k[e] != PAD_KEY && (((k[e] >> S) + 1) >> (32 - LB)) != 0) fits = false;      // (the all-ones word is the padding key)
+    }
+    if (__ballot(!fits)) return false;
+    unsigned k32[E];
+#pragma unroll
+    for (int e = 0; e < E; e++) k32[e] = k[e] == PAD_KEY ? 0xffffffffu : (((unsigned)(k[e] >> S) << LB) | ((unsigned)k[e] & 0xffu));
+    bitonic_wave32<E>(k32);
+#pragma unroll
+    for (int e = 0; e < E; e++)
+        if (e * 64 + lane < P) K[e * 64 + lane] = k32[e] == 0xffffffffu ? PAD_KEY : (((u64)(k32[e] >> LB) << S) | (u64)(k32[e] & 0xffu));
+    return true;
+}
+
+// S: the keys are (value << S) | index, index < P (S = 0: unknown layout, always the 64-bit network)
+template <int BLOCK, class KP> __device__ void bitonic_sort(KP K, int P, int S = 0)
 {
     if (BLOCK == 64 && P <= 256) {                    // callers synchronised before; the results are visible after this barrier
-        if (P <= 64) bitonic_wave_mem<1>(K, P);
-        else if (P <= 128) bitonic_wave_mem<2>(K, P);
-        else bitonic_wave_mem<4>(K, P);
+        bool done = false;
+        if (S > 0 && !CSV_ABL(19)) {
+            if (P <= 64) done = bitonic_wave_mem32<1>(K, P, S);
+            else if (P <= 128) done = bitonic_wave_mem32<2>(K, P, S);
+            else done = bitonic_wave_mem32<4>(K, P, S);
+        }
+        if (!done) {
+            if (P <= 64) bitonic_wave_mem<1>(K, P);
+            else if (P <= 128) bitonic_wave_mem<2>(K, P);
+            else bitonic_wave_mem<4>(K, P);
+        }
         __syncthreads();
         return;
     }
@@ -1131,7 +1208,7 @@ template <int BLOCK, bool LDS> __device__ int sort_by_read(const DevBatch& B, co
     for (int i = threadIdx.x; i < it.P; i += BLOCK)
         A.K[i] = i < it.m ? (((u64)(unsigned)B.rid[it.s + i]) << 32) | (unsigned)i : PAD_KEY;
     __syncthreads();
-    bitonic_sort<BLOCK>(A.K, it.P);
+    bitonic_sort<BLOCK>(A.K, it.P, 32);
     int runs = 0;
     for (int q = threadIdx.x; q < it.m; q += BLOCK) {
         const u64 k = A.K[q];
@@ -1187,7 +1264,7 @@ template <int BLOCK, bool LDS, bool SMALLN> __device__ void refine_indel(const D
     __syncthreads();
     for (int q = threadIdx.x; q < P; q += BLOCK) A.K[q] = (u64)A.X[q];
     __syncthreads();
-    bitonic_sort<BLOCK>(A.K, P);        // == stable sort by length over first-appearance order (INDEL:136)
+    bitonic_sort<BLOCK>(A.K, P, ib);    // == stable sort by length over first-appearance order (INDEL:136)
 
     // rank order: a-values -> K, lengths -> X, kept local index -> V1
     i64 lsum = 0;
@@ -1359,7 +1436,7 @@ template <int BLOCK, bool LDS> __device__ void refine_pair(const DevBatch& B, co
         A.K[i] = key;
     }
     __syncthreads();
-    bitonic_sort<BLOCK>(A.K, P);
+    bitonic_sort<BLOCK>(A.K, P, ib);
     for (int r = threadIdx.x; r < m; r += BLOCK) {
         const u64 key = A.K[r];
         const int i = (int)(key & imask);
