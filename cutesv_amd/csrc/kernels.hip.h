@@ -1009,14 +1009,27 @@ template <int E, class KP> __device__ __forceinline__ bool bitonic_wave_mem32(KP
         k[e] = (e * 64 + lane < P) ? K[e * 64 + lane] : PAD_KEY;
         if (k[e] != PAD_KEY && (((k[e] >> S) + 1) >> (32 - LB)) != 0) fits = false;      // (the all-ones word is the padding key)
     }
-    if (__ballot(!fits)) return false;
+    u64 base = 0;
+    if (__ballot(!fits)) {
+        // not as they are: relative to the smallest value of the cluster (second positions of DUP / INV / TRA signatures are
+        // genome coordinates, but those of one cluster lie close together)
+        u64 mn = ~0ull;
+#pragma unroll
+        for (int e = 0; e < E; e++) if (k[e] != PAD_KEY && (k[e] >> S) < mn) mn = k[e] >> S;
+        for (int d = 32; d > 0; d >>= 1) { const u64 o = (u64)shfl_xor_i64((i64)mn, d); mn = o < mn ? o : mn; }
+        fits = true;
+#pragma unroll
+        for (int e = 0; e < E; e++) if (k[e] != PAD_KEY && ((((k[e] >> S) - mn) + 1) >> (32 - LB)) != 0) fits = false;
+        if (__ballot(!fits)) return false;
+        base = mn;
+    }
     unsigned k32[E];
 #pragma unroll
-    for (int e = 0; e < E; e++) k32[e] = k[e] == PAD_KEY ? 0xffffffffu : (((unsigned)(k[e] >> S) << LB) | ((unsigned)k[e] & 0xffu));
+    for (int e = 0; e < E; e++) k32[e] = k[e] == PAD_KEY ? 0xffffffffu : (((unsigned)((k[e] >> S) - base) << LB) | ((unsigned)k[e] & 0xffu));
     bitonic_wave32<E>(k32);
 #pragma unroll
     for (int e = 0; e < E; e++)
-        if (e * 64 + lane < P) K[e * 64 + lane] = k32[e] == 0xffffffffu ? PAD_KEY : (((u64)(k32[e] >> LB) << S) | (u64)(k32[e] & 0xffu));
+        if (e * 64 + lane < P) K[e * 64 + lane] = k32[e] == 0xffffffffu ? PAD_KEY : ((((u64)(k32[e] >> LB) + base) << S) | (u64)(k32[e] & 0xffu));
     return true;
 }
 
