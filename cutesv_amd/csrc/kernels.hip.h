@@ -1167,6 +1167,28 @@ __device__ __forceinline__ void item_done(const DevBatch& B, int j, int nslots, 
 // summed by an 8-lane group (lane j = accumulator j of numpy's 8-way unrolled loop), then numpy's fixed combine
 // tree and sequential tail.  Every lane returns the result.  No private arrays, no call: the one-wavefront tiers
 // stay free of scratch.
+// cal_CIPOS from the exact integer variance, as in the register tier (indel_unit): int(1.96 * std / n ** 0.5) through
+// N = n * sum(d^2) - sum(d)^2 (d = x - x[0]), one float32 square root and the table factor 1.96 / (n * n ** 0.5).  false: the
+// values are too far apart for the integers, or the result lies within 2e-6 of an integer - the caller replays numpy then.
+template <class VP> __device__ __forceinline__ bool cipos_fast(VP v, int n, i64 sum, const float* cipk_tab, int& out)
+{
+    const i64 x0 = v[0];
+    i64 s2 = 0;
+    bool small = (u64)x0 < (1ull << 31);
+    for (int i = lane_id(); i < n; i += 64) {
+        const i64 d = v[i] - x0;
+        small = small && d > -(1 << 20) && d < (1 << 20);
+        s2 += d * d;
+    }
+    if (__ballot(!small)) return false;
+    s2 = wave_sum_i64(s2);
+    const i64 s1 = sum - (i64)n * x0;
+    const i64 N = (i64)n * s2 - s1 * s1;                    // n^2 * variance, exact (< 2^57)
+    const float vf = __builtin_amdgcn_sqrtf((float)(double)N) * cipk_tab[n & (SQRT_TAB - 1)];
+    if (N < 0 || (vf > 0.5f && fabsf(vf - rintf(vf)) <= 2e-6f * vf)) return false;
+    out = (int)vf;
+    return true;
+}
 template <class VP> __device__ __forceinline__ int cipos_wave(VP v, int n, i64 sum, const double* sqrt_tab)
 {
     const int lane = lane_id(), g = lane >> 3, j = lane & 7;
@@ -1376,8 +1398,8 @@ template <int BLOCK, bool LDS, bool SMALLN> __device__ void refine_indel(const D
         }
         int cip = 0, cil = 0;
         if (SMALLN) {                                                       // n <= 256: whole wavefront, no scratch
-            cip = cipos_wave(PA + r0, n, sp, B.sqrt_tab);                    // INDEL:191
-            cil = cipos_wave(PB + r0, n, sl, B.sqrt_tab);                    // INDEL:194
+            if (CSV_ABL(20) || !cipos_fast(PA + r0, n, sp, B.cipk_tab, cip)) cip = cipos_wave(PA + r0, n, sp, B.sqrt_tab);      // INDEL:191
+            if (CSV_ABL(20) || !cipos_fast(PB + r0, n, sl, B.cipk_tab, cil)) cil = cipos_wave(PB + r0, n, sl, B.sqrt_tab);      // INDEL:194
         } else if (lane_id() == 0) {                                          // V5 is free on the DEL/INS path: per-wavefront stack
             const typename MemT<LDS>::intp stk = A.V5 + (threadIdx.x >> 6) * CIPOS_STACK_INTS;
             cip = cipos_of(PA + r0, n, sp, B.sqrt_tab, stk);
