@@ -106,7 +106,8 @@ def test_cipos_on_integer_boundaries(ctx):
     from cutesv_amd.columns import SigStore
     per = {t: [] for t in ("DEL", "INS", "DUP", "INV", "TRA")}
     pos, rid = 100_000, 0
-    for n, step in ((4, 50), (16, 100), (64, 200)):
+    # (n = 100 .. 256: the one-wavefront-per-cluster tier, whose exact-variance form has the same fallback)
+    for n, step in ((4, 50), (16, 100), (64, 200), (100, 250), (144, 300), (196, 50), (256, 400)):
         for j in range(1, 13):
             k = step * j
             for i in range(n):
@@ -117,7 +118,7 @@ def test_cipos_on_integer_boundaries(ctx):
             pos += 100_000
     st = SigStore.from_tuple_lists(per)
     got = _compare_soa(ctx, st, Params(min_support=3, max_size=-1, max_cluster_bias_DEL=20000, diff_ratio_merging_DEL=50.0))
-    assert len(got["bp1"]) == 36 and (got["cipos"] > 0).all()
+    assert len(got["bp1"]) == 84 and (got["cipos"] > 0).all()
 
 
 def test_register_tiers_fallback_routes(ctx):
