@@ -1312,7 +1312,7 @@ template <int BLOCK, bool LDS, bool SMALLN> __device__ void refine_indel(const D
     }
     lsum = block_sum_i64<BLOCK>(lsum, red);
     __syncthreads();
-    const double thr = sg.diff_ratio * ((double)lsum / (double)U);          // INDEL:138
+    const double thr = sg.diff_ratio * div_by((double)lsum, (double)U, B.rcp_tab[U]);          // INDEL:138 (exact division by table reciprocal: div_by)
 
     // allele split on consecutive length gaps (INDEL:153-162): V2[a] = first rank of allele a
     int carry = 0;
@@ -1362,7 +1362,8 @@ template <int BLOCK, bool LDS, bool SMALLN> __device__ void refine_indel(const D
         for (int i = lane_id(); i < n; i += 64) { sp += PA[r0 + i]; sl += PB[r0 + i]; }
         sp = wave_sum_i64(sp); sl = wave_sum_i64(sl);
         int keep = (int)(rr * (double)n); if (keep < 1) keep = 1;           // INDEL:169
-        const double pmean = (double)sp / (double)n, lmean = (double)sl / (double)n;
+        const double rcp_n = B.rcp_tab[n];
+        const double pmean = div_by((double)sp, (double)n, rcp_n), lmean = div_by((double)sl, (double)n, rcp_n);
         double bp, siglen; i64 search;
         if (keep >= n) {
             // every member kept: mean of the kept values == mean of all (exact integer sums);
