@@ -123,7 +123,8 @@ struct csv_ctx {
     Buf sc_k, sc_x, sc_v1, sc_v2, sc_v3, sc_v4, sc_v5;
     Buf o_rec, o_supsig, o_suprid, allele_id;
     Buf reads_off, r_start, r_end, r_primary, r_id, s_start, s_end, s_idp, cmax, cfirst, bfirst, span_len, maxlen, gt_over, gt_huge, gt_pool, contig_len;
-    Buf ro_tcnt, ro_ent, ro_table;
+    Buf ro_tcnt, ro_ent, ro_table, ro_tblk;
+    std::vector<int> h_tblk;                   // per tile of the reads table: the first chromosome block that begins at or after it
     // stand-alone
     Buf sqrt_tab, rcp_tab, cipk_tab, cnt, rstate;
     Buf gs_chrom, gs_perm0, gs_perm1, gs_hist, gs_tot;          // general reads sort (fallback), allocated on first use
@@ -532,7 +533,7 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
         PL(s_start, (R + 64) * cw); PL(s_end, (R + 64) * cw); PL(s_idp, (R + 64) * 4);      // (whole chunks of 64 rows are read)
         PL(cmax, (div_up(R, 64) + 136) * 8); PL(span_len, (div_up(R, 512) + 8) * 8); PL(cfirst, (div_up(R, 64) + 136) * 8); PL(bfirst, (div_up(R, 4096) + 136) * 8);      // (+ two steps of padding: k_genotype reads 128 entries from any valid one)
         PL(maxlen, (in->n_chrom + 1) * 8);
-        if (reorder) { PL(ro_tcnt, (div_up(R, RO_TILE) + 1) * 4); PL(ro_ent, (div_up(R, RO_TILE) + 1) * (size_t)RO_TCAP * 16); PL(ro_table, RO_CAP * 16); }
+        if (reorder) { PL(ro_tcnt, (div_up(R, RO_TILE) + 1) * 4); PL(ro_ent, (div_up(R, RO_TILE) + 1) * (size_t)RO_TCAP * 16); PL(ro_tblk, (div_up(R, RO_TILE) + 2) * 4); PL(ro_table, RO_CAP * 16); }
     }
 #undef PL
     {
@@ -640,6 +641,19 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
         HIP_TRY(c, hipMemcpyAsync(c->reads_off.p, in->reads_off, (size_t)(in->n_chrom + 1) * 8, hipMemcpyHostToDevice, sr));
         if (c->any_tra_gt && in->n_chrom > 0) HIP_TRY(c, hipMemcpyAsync(c->contig_len.p, in->contig_len, (size_t)in->n_chrom * 8, hipMemcpyHostToDevice, sr));
     }
+    if (R > 0 && reorder) {
+        // which chromosome blocks begin inside every tile of RO_TILE rows: k_reads_runs leaves a descent AT a block start out of
+        // its lists (k_reads_plan adds every block start anyway; a reference with hundreds of small contigs has dozens of them
+        // per tile)
+        const int ntl = div_up(R, RO_TILE);
+        c->h_tblk.assign((size_t)ntl + 1, 0);
+        int k = 0;
+        for (int t = 0; t <= ntl; t++) {
+            while (k < in->n_chrom && in->reads_off[k] < (i64)t * RO_TILE) k++;
+            c->h_tblk[(size_t)t] = k;
+        }
+        HIP_TRY(c, hipMemcpyAsync(c->ro_tblk.p, c->h_tblk.data(), ((size_t)ntl + 1) * 4, hipMemcpyHostToDevice, sr));
+    }
     if (R > 0) {
         const size_t cw = rd32 ? 4 : 8;
         HIP_TRY(c, hipMemcpyAsync(c->r_start.p, in->r_start, R * cw, hipMemcpyHostToDevice, sr));
@@ -701,7 +715,7 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
         B.gt_pool = dp<int>(c->gt_pool); B.gt_pool_n = pool_n;
         B.ro_mode = reorder ? 1 : 0;
         if (reorder) {
-            B.ro_tcnt = dp<int>(c->ro_tcnt); B.ro_ent = dp<int4>(c->ro_ent); B.ro_table = dp<int4>(c->ro_table); B.ro_cap = RO_CAP;
+            B.ro_tcnt = dp<int>(c->ro_tcnt); B.ro_ent = dp<int4>(c->ro_ent); B.ro_tblk = dp<int>(c->ro_tblk); B.ro_table = dp<int4>(c->ro_table); B.ro_cap = RO_CAP;
             B.ro_gap = env_int("CSV_READS_GAP", 1000000);      // (tests shrink it together with their task regions)
         }
     }

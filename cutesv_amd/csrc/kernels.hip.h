@@ -186,6 +186,7 @@ struct DevBatch {
     i64*           maxlen;           // ... and per chromosome (k_reads_maxlen): bounds how far before a window a covering read can start
     int            ro_mode;          // 0: caller promised sorted blocks; 1: run-level reorder on the device; 2: general radix sort (fallback)
     int*           ro_tcnt;          // per tile of RO_TILE rows: run starts found by k_reads_runs ...
+    const int*     ro_tblk;          // per tile: the first chromosome block that begins at or after its first row (host-built)
     int4*          ro_ent;           // ... and their records {row, its start, the start of the row before, out of range}, RO_TCAP per tile
     int4*          ro_table;         // runs in start order: {source begin, length, destination begin, chromosome}
     int            ro_cap;           // capacity of both
@@ -2497,25 +2498,27 @@ __device__ __forceinline__ int chrom_of_read(const DevBatch& B, i64 i, int hint)
 constexpr i64 READ_END_MAX = 1ll << 40;             // ends are doubled in window arithmetic: anything beyond is a broken table
 
 constexpr int RO_TILE = 256 * 8;
-constexpr int RO_TCAP = 8;                          // run starts a tile of RO_TILE rows may hold (more: the general sort)
+constexpr int RO_TCAP = 32;                         // run starts a tile of RO_TILE rows may hold (more: the general sort)
 // A row starts a run when its start is smaller than its predecessor's (a descent) or jumps ahead by more than ro_gap.
 // The second rule cuts the runs the extraction step glued together: a worker that processed the task regions 3 and then 7
 // of a chromosome leaves them back to back without a descent, although the regions 4-6 (in other workers' files)
 // belong in between; such a seam is at least one task region wide (--batches, 10 Mbp by default), ro_gap is 1 Mbp.
 // The rule is only a heuristic for WHERE to cut - k_reads_plan verifies that the pieces do not interleave once
 // ordered, and anything else goes to the general sort.  (Block starts are added by k_reads_plan.)
-// Every tile keeps its own short list {row, its start, the start of the row before, out of range} + a count: no device
-// atomics (a few hundred appends to ONE counter were a third of this kernel), and k_reads_plan needs no look-up of the
-// starts - its critical path is two round trips.
+// Every tile keeps its own short list {row, its start, the start of the row before, out of range} in row order + a count: no
+// device atomics, and k_reads_plan needs no look-up of the starts - its critical path is two round trips.
 template <bool RN> __global__ __launch_bounds__(256) void k_reads_runs(DevBatch B)
 {
-    __shared__ int s_cnt;
-    if (threadIdx.x == 0) s_cnt = 0;
-    __syncthreads();
+    __shared__ int s_w[4];
+    __shared__ u64 s_blk[RO_TILE / 64];                      // rows of the tile at which a chromosome block begins
+    const int c0 = B.ro_tblk[blockIdx.x], c1 = B.ro_tblk[blockIdx.x + 1];
+    if (threadIdx.x < RO_TILE / 64) s_blk[threadIdx.x] = 0;
     // a lane owns 8 consecutive rows (16-byte loads); the start before its first row comes from the lane to the left
     const i64 base = (i64)blockIdx.x * RO_TILE + (threadIdx.x >> 6) * 512, i0 = base + lane_id() * 8;
+    i64 v[8];
+    i64 prev0 = INT64_MIN;
+    unsigned flags = 0;
     if (base < B.n_reads) {
-        i64 v[8];
         if (i0 + 8 <= B.n_reads) {
             if constexpr (RN) {
                 const int4 x0 = *(const int4*)(B.r_start.p32 + i0), x1 = *(const int4*)(B.r_start.p32 + i0 + 4);
@@ -2528,23 +2531,46 @@ template <bool RN> __global__ __launch_bounds__(256) void k_reads_runs(DevBatch 
 #pragma unroll
             for (int r = 0; r < 8; r++) v[r] = i0 + r < B.n_reads ? col_at<RN>(B.r_start, i0 + r) : INT64_MAX;
         }
-        i64 prev = (lane_id() == 0 && base > 0) ? col_at<RN>(B.r_start, base - 1) : INT64_MIN;
+        prev0 = (lane_id() == 0 && base > 0) ? col_at<RN>(B.r_start, base - 1) : INT64_MIN;
         const i64 left = wave_shr1_i64(v[7]);
-        if (lane_id() != 0) prev = left;
+        if (lane_id() != 0) prev0 = left;
+        i64 prev = prev0;
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             const i64 i = i0 + r;
-            const bool st = i < B.n_reads && i > 0 && prev != INT64_MIN && (v[r] < prev || v[r] - prev > B.ro_gap);
-            if (st) {
-                const int slot = atomicAdd(&s_cnt, 1);
+            if (i < B.n_reads && i > 0 && prev != INT64_MIN && (v[r] < prev || v[r] - prev > B.ro_gap)) flags |= 1u << r;
+            prev = v[r];
+        }
+    }
+    if (c1 > c0) {                                          // (wave-uniform, and rare in a genome of a few long chromosomes)
+        __syncthreads();
+        for (int c = c0 + threadIdx.x; c < c1; c += 256) {
+            const i64 o = B.reads_off[c] - (i64)blockIdx.x * RO_TILE;
+            if (o >= 0 && o < RO_TILE) atomicOr((unsigned long long*)&s_blk[o >> 6], 1ull << (o & 63));
+        }
+        __syncthreads();
+        flags &= ~(unsigned)((const uint8_t*)s_blk)[((threadIdx.x >> 6) * 512 + lane_id() * 8) >> 3];       // a descent AT a block start is the plan's business
+    }
+    // the tile's records in row order: exclusive prefix of the per-thread counts (a tile has a handful)
+    const int cnt = __popc(flags);
+    const int inc = wave_incl_scan_i32(cnt);
+    if (lane_id() == 63) s_w[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    int slot = inc - cnt, tot = 0;
+    for (int q = 0; q < 4; q++) { if (q < (int)(threadIdx.x >> 6)) slot += s_w[q]; tot += s_w[q]; }
+    if (flags) {
+        i64 prev = prev0;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            if ((flags >> r) & 1) {
                 const int bad = (v[r] < 0 || v[r] >= (1ll << 32) || prev < 0 || prev >= (1ll << 32)) ? 1 : 0;
-                if (slot < RO_TCAP) B.ro_ent[(i64)blockIdx.x * RO_TCAP + slot] = make_int4((int)i, (int)(unsigned)v[r], (int)(unsigned)prev, bad);
+                if (slot < RO_TCAP) B.ro_ent[(i64)blockIdx.x * RO_TCAP + slot] = make_int4((int)(i0 + r), (int)(unsigned)v[r], (int)(unsigned)prev, bad);
+                slot++;
             }
             prev = v[r];
         }
     }
-    __syncthreads();
-    if (threadIdx.x == 0) B.ro_tcnt[blockIdx.x] = s_cnt;
+    if (threadIdx.x == 0) B.ro_tcnt[blockIdx.x] = tot;
 }
 
 // one workgroup: the tiles' run starts + one start per chromosome block -> runs by (chromosome, first start, position);
@@ -2618,13 +2644,11 @@ template <bool RN> __global__ __launch_bounds__(RP_THREADS) void k_reads_plan(De
     int4 e8[8];
 #pragma unroll
     for (int r = 0; r < 8; r++) e8[r] = (cnt8[r] > 0 && !over) ? B.ro_ent[(i64)(t0 + r) * RO_TCAP] : make_int4(0, 0, 0, 0);
-    auto tile_records = [&](int t, int k) {                     // (a tile with several records: ranked among themselves)
+    auto tile_records = [&](int t, int k) {                     // (a tile with several records: they are in row order)
         const int4* E = B.ro_ent + (i64)t * RO_TCAP;
         for (int j = 0; j < k; j++) {
             const int4 e = E[j];
-            int r = 0;
-            for (int jj = 0; jj < k; jj++) r += E[jj].x < e.x;
-            fpos[at + r] = e.x; ffv[at + r] = (unsigned)e.y; fpv[at + r] = (unsigned)e.z;
+            fpos[at + j] = e.x; ffv[at + j] = (unsigned)e.y; fpv[at + j] = (unsigned)e.z;
             if (e.w) atomicOr(&s_bad, 1);
         }
     };

@@ -965,6 +965,20 @@ def test_single_pipe_on_the_gpu(ctx):
         assert_single_pipe_case(case, lambda *a, **k: extract.cigar_signatures(ctx, *a, **k), lambda enc, **k: extract.split_signatures(ctx, enc, **k))
 
 
+def test_hundreds_of_chromosomes_with_genotyping(ctx, monkeypatch):
+    """an assembly with 400 contigs, genotyped: more chromosomes than k_genotype keeps block offsets for in LDS, 400 block starts
+    for the reads-order plan to merge with the runs it finds (reads in extraction order), segments of a few dozen signatures"""
+    st = synth.small_mixed(seed=77, n_sites=1000, coverage=14, n_contigs=400, contig_len=120_000, n_noise=3000, n_loci=300)
+    p = Params.ont(genotype=True, genotype_tra=True, min_support=3)
+    got = _compare_soa(ctx, st, p)
+    assert len(got["bp1"]) > 3000 and (got["dr"] >= 0).sum() > 3000 and len(st.tasks()) > 1500
+    runs, _ = synth.extraction_order(st, region=60_000, workers=3)           # two task regions per contig
+    assert (np.diff(runs.r_start) < 0).sum() > 500                           # descents at the 399 block starts and inside the blocks
+    monkeypatch.setenv("CSV_READS_GAP", "20000")
+    got2 = _compare_soa(ctx, runs, p)
+    assert ctx.last_reads_mode() == 1 and len(got2["bp1"]) == len(got["bp1"])
+
+
 def test_thousands_of_small_segments(ctx):
     """a reference with thousands of small contigs: 3000 (contig, type) segments of a few dozen signatures each, so that
     every chain tile spans dozens of segments (the per-row path, the segment search bounded by the tile's range, the
