@@ -387,35 +387,45 @@ class SigStore:
         n = len(sigs)
         reads = reads or []
         name_col = {"DEL": 2, "INS": 2, "DUP": 2, "INV": 3, "TRA": 4}[svtype]
-        names = [x[name_col] for x in sigs]
+        col = lambda k: [x[k] for x in sigs]                  # noqa: E731  (one list per field)
+        names = col(name_col)
         rnames = [r[3] for r in reads]
-        uniq = sorted(set(names).union(rnames))
-        rank = dict(zip(uniq, range(len(uniq))))
-        rid = np.fromiter((rank[q] for q in names), np.int32, n)
+        # The list is already in the rebuild's order, so the ids only have to tell reads apart: numbered by first appearance
+        # (sorting 10^5 names and looking every one up again was more than half of this function; `from_tuple_lists`, which
+        # sorts rows BY name, interns rank-preservingly).
+        rank = {}
+        setd = rank.setdefault
+        rid = np.fromiter((setd(q, len(rank)) for q in names), np.int32, n)
+        for q in rnames:
+            setd(q, len(rank))
+        uniq = list(rank)
         if chroms is None:
             cs = {chrom}
             if svtype == "TRA":
-                cs.update(x[2] for x in sigs)
+                cs.update(col(2))
             cs.update(r[4] for r in reads)
             chroms = sorted(cs)
         crank = {c: i for i, c in enumerate(chroms)}
+
+        def ints(k):                                          # int(x) per element: positions may be x.5 floats (main script :228)
+            v = np.array(col(k)) if n else np.zeros(0, np.int64)
+            return v.astype(np.int64) if v.dtype.kind in "iuf" else np.fromiter((int(x[k]) for x in sigs), np.int64, n)
         aux = np.zeros(n, np.int32)
         ins_seq, strands = {}, ("++", "--")
         if svtype in ("DEL", "INS", "DUP"):
-            a = np.fromiter((int(x[0]) for x in sigs), np.int64, n)
-            b = np.fromiter((int(x[1]) for x in sigs), np.int64, n)
+            a, b = ints(0), ints(1)
             if svtype == "INS":
-                aux = np.fromiter((len(x[3]) for x in sigs), np.int32, n)
-                ins_seq = {i: x[3] for i, x in enumerate(sigs)}
+                seqs = col(3)
+                aux = np.fromiter(map(len, seqs), np.int32, n)
+                ins_seq = dict(enumerate(seqs))
         elif svtype == "INV":
-            strands = tuple(sorted(set(x[0] for x in sigs))) or ("++", "--")
+            st_col = col(0)
+            strands = tuple(sorted(set(st_col))) or ("++", "--")
             code = {s_: i for i, s_ in enumerate(strands)}
-            a = np.fromiter((int(x[1]) for x in sigs), np.int64, n)
-            b = np.fromiter((int(x[2]) for x in sigs), np.int64, n)
-            aux = np.fromiter((code[x[0]] for x in sigs), np.int32, n)
+            a, b = ints(1), ints(2)
+            aux = np.fromiter(map(code.__getitem__, st_col), np.int32, n)
         else:
-            a = np.fromiter((int(x[1]) for x in sigs), np.int64, n)
-            b = np.fromiter((int(x[3]) for x in sigs), np.int64, n)
+            a, b = ints(1), ints(3)
             aux = np.fromiter((crank[x[2]] * 8 + BND_CODE.get(x[0], 4) for x in sigs), np.int32, n)
         kw = {}
         if reads:
