@@ -142,7 +142,8 @@ struct csv_ctx {
     // page-locked host staging: small tables on the way in, counters + call records + support lists on the way out
     char*  h_pin = nullptr;
     size_t h_pin_cap = 0;
-    // two page-locked words the device writes and the host peeks at during a run (which big tiers have work)
+    // two page-locked 64-bit words the device writes {run sequence, count}: items above 64 signatures (k_chain_apply), calls that
+    // overflowed the first genotype pass (k_genotype<8192>); read when a LATER run of the same upload is planned
     volatile int* h_flag = nullptr;
     int*          d_flag = nullptr;
     int           run_seq = 0;

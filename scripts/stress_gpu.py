@@ -63,8 +63,11 @@ for it in range(n_it):
         want = oracle.cluster_batch(hb, per_sig=True).trimmed()
         if rng.integers(0, 2):                            # the one-shot call, results copied out or published in place ...
             got = ctx.cluster_batch(hb, per_sig=True, reuse=bool(rng.integers(0, 2))).trimmed()
-        else:                                             # ... or upload / run (twice: the tier peek, idempotence) / download
+        else:                                             # ... or upload / run (twice: tiers on demand, idempotence) / download
             ctx.upload(hb, per_sig=True)
+            ctx.run()
+            if rng.integers(0, 2):
+                ctx.sync()                                # (the first run's answers are on the host when the next is planned)
             ctx.run(); ctx.run()
             got = ctx.download(per_sig=True).trimmed()
         assert_soa_equal(got, want, store=st, set_order_segments=())
