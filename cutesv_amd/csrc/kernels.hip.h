@@ -2890,15 +2890,23 @@ __global__ __launch_bounds__(256) void k_reads_chromcol(DevBatch B, int* out)
 // list; k_genotype<8192, 1> (one wavefront per workgroup, 32 KB) finishes those up to ~6000 reads; what is deeper
 // still (chrM, rDNA and centromeric pile-ups) gets a table in GLOBAL memory sized from the scan extent: a slice of
 // the pool per workgroup, and the whole pool - which holds any call of the batch - for the last workgroup standing.
-template <int HASH> __device__ __forceinline__ int hash_insert(int* tab, int id)
+// Insert `id` into the open-addressing set for the lanes that `want` it; 1: the id was new.  ONE wave-uniform loop whose per-lane
+// state lives in vector registers (integers, not lane masks): a per-lane probe loop entered under a divergent branch costs ~19
+// SCALAR instructions per probe round for
+// its exec-mask bookkeeping, and the genotype kernel issued 1.75 scalar instructions per vector one: 27.5 M per 90x launch, which at
+// one scalar instruction per SIMD every four cycles is 45 of its 60 us.  (cfg5: 60 -> 53 us; cfg4: 21 -> 19 us.)
+template <int HASH> __device__ __forceinline__ int hash_insert_v(int* tab, int id, int want)
 {
     unsigned h = ((unsigned)id * 2654435761u) >> (32 - __builtin_ctz(HASH));
-    for (;;) {
-        const int old = atomicCAS(&tab[h], -1, id);
-        if (old == -1) return 1;
-        if (old == id) return 0;
-        h = (h + 1) & (HASH - 1);
+    int ins = 0, pend = want;
+    while (__ballot(pend != 0)) {
+        int old = -2;
+        if (pend) old = atomicCAS(&tab[h], -1, id);
+        ins |= (old == -1) ? 1 : 0;
+        pend = (old == -2 || old == -1 || old == id) ? 0 : 1;
+        h = (h + (unsigned)pend) & (HASH - 1);
     }
+    return ins;
 }
 __device__ __forceinline__ int hash_insert_n(int* tab, int bits, int id)      // runtime size 2^bits (global-memory tables)
 {
@@ -3033,9 +3041,7 @@ template <int HASH, bool RN> __device__ __forceinline__ int cover_window(const D
             for (int u = 0; u < GT_UNROLL; u++) {
                 if (filled + 64 > HASH * 3 / 4) { overflow = true; return dr; }
                 const bool cov = ok[u] && idp[u] < 0 && st[u] <= Lh && en[u] >= Rh;          // primary (bit 31), starts at or before L, reaches R
-                int ins = 0;
-                if (cov && !CSV_ABL(17)) ins = hash_insert<HASH>(tab, idp[u] & 0x7fffffff);
-                if (CSV_ABL(17)) ins = cov;
+                const int ins = CSV_ABL(17) ? (int)cov : hash_insert_v<HASH>(tab, idp[u] & 0x7fffffff, cov ? 1 : 0);
                 const int k = __popcll(__ballot(ins));
                 dr += k; filled += k;
             }
@@ -3197,7 +3203,7 @@ template <int HASH, int WPB, bool SECOND, bool RN> __global__ __launch_bounds__(
             if (filled + 64 > HASH * 3 / 4) { overflow = true; break; }
             const i64 i = base + lane_id();
             int ins = 0;
-            if (i < ns && !CSV_ABL(18)) ins = hash_insert<HASH>(tab, base == 0 ? sup0 : B.o_suprid[s0 + i]);
+            if (!CSV_ABL(18)) ins = hash_insert_v<HASH>(tab, base == 0 ? sup0 : (i < ns ? B.o_suprid[s0 + i] : 0), i < ns ? 1 : 0);
             filled += __popcll(__ballot(ins));
         }
         int dr = 0;
