@@ -1944,7 +1944,7 @@ template <int SW> __device__ __forceinline__ int indel_unit(const DevBatch& B, c
         const int pax = __shfl(aux, hb | (ch & (SW - 1)));
 
         // ---- stable sort of the kept signatures by length (INDEL:136): rank by (len, first appearance)
-        int rank = 0;
+        int rank = 0, src_lane = -1;
         if (CSV_ABL(1)) rank = sl;
         else if (SW < 64) {
             if (!__ballot(rep && (bl >> 26) != 0)) {
@@ -1961,8 +1961,13 @@ template <int SW> __device__ __forceinline__ int indel_unit(const DevBatch& B, c
                 }
             }
         } else if (!__ballot(rep && (bl >> 25) != 0)) {                  // same one-word key, 6 bits of first appearance
-            const int key = rep ? (((int)bl << 6) | sl) : 0x7fffffff;
-            for (u64 mk = __ballot(rep); mk; mk &= mk - 1) rank += __builtin_amdgcn_readlane(key, __ffsll((long long)mk) - 1) < key;
+            // one cluster per wavefront: the keys (kept ones by (length, lane), the others behind them in lane order) go through
+            // the 64-lane sorting network (21 compare-exchanges in DPP / bpermute, no scalar work), and sorted position p then
+            // PULLS its row from the lane the key came from.  (A rank by counting - one v_readlane, compare and add per kept
+            // signature - was 3 vector + 6 scalar instructions times up to 64.)
+            unsigned ks[1] = {rep ? (((unsigned)bl << 6) | (unsigned)sl) : (0x80000000u | (unsigned)sl)};
+            bitonic_wave32<1>(ks);
+            src_lane = (int)(ks[0] & 63u);
         } else {
             for (u64 mk = __ballot(rep); mk; mk &= mk - 1) {
                 const int t = __ffsll((long long)mk) - 1;
@@ -1970,12 +1975,18 @@ template <int SW> __device__ __forceinline__ int indel_unit(const DevBatch& B, c
                 rank += (lt < bl) || (lt == bl && t < sl);
             }
         }
-        const int dest = hb | (rep ? rank : U + __popcll(~rm & sl_lt & SUBMASK));
-        const i64 pos = permute_i64(dest, pa);
-        const i64 len = permute_i64(dest, bl);
-        const int chp = __builtin_amdgcn_ds_permute(dest << 2, ch);
-        const int axp = __builtin_amdgcn_ds_permute(dest << 2, pax);
-        const int ridp = __builtin_amdgcn_ds_permute(dest << 2, rid);      // (every signature of a read's group carries the group's read id)
+        i64 pos, len; int chp, axp, ridp;
+        if (SW == 64 && src_lane >= 0) {                                     // (wave-uniform: all lanes or none)
+            pos = shfl_i64(pa, src_lane); len = shfl_i64(bl, src_lane);
+            chp = __shfl(ch, src_lane); axp = __shfl(pax, src_lane); ridp = __shfl(rid, src_lane);
+        } else {
+            const int dest = hb | (rep ? rank : U + __popcll(~rm & sl_lt & SUBMASK));
+            pos = permute_i64(dest, pa);
+            len = permute_i64(dest, bl);
+            chp = __builtin_amdgcn_ds_permute(dest << 2, ch);
+            axp = __builtin_amdgcn_ds_permute(dest << 2, pax);
+            ridp = __builtin_amdgcn_ds_permute(dest << 2, rid);              // (every signature of a read's group carries the group's read id)
+        }
         const int r = sl;
         const bool live = ok && r < U;
         const int last = hb | (SW - 1);
