@@ -2867,7 +2867,8 @@ template <bool RN> __global__ __launch_bounds__(256) void k_reads_gather(DevBatc
 
 // longest read per chromosome from the spans' maxima (a span of 512 rows that straddles two blocks counts for both: the bound
 // may only be too generous).  (One atomic maximum per span from the gather itself was tried: 12 000 atomics on two dozen
-// addresses took the gather from 48 to 137 us.)
+// addresses took the gather from 48 to 137 us; one chromosome per 128-byte line and an atomic only when a value read first is
+// smaller - a few hundred per line, at the start of the kernel - still cost it 12 us, six times this kernel and its boundary.)
 __global__ __launch_bounds__(256) void k_reads_maxlen(DevBatch B)
 {
     if (reads_pending(B)) return;
