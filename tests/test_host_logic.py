@@ -235,3 +235,24 @@ def test_legacy_sigs_text_files_round_trip(tmp_path):
     for k in ("a", "b", "read_id", "aux", "reads_off", "r_start", "r_end", "r_primary", "r_id"):
         assert np.array_equal(getattr(got, k), getattr(want, k)), k
     assert got.ins_seq == want.ins_seq and got.names.names == want.names.names
+
+
+def test_vcf_text_is_the_same_on_one_thread_and_on_a_team(monkeypatch):
+    """csv_vcf_emit formats slices of 1024 calls on a team of worker threads that outlives the call (asleep in between): the
+    text and the SVID counters of a few thousand calls do not depend on the number of threads, nor on the team having been
+    used, resized and used again (no GPU needed: the calls come from the oracle)"""
+    from cutesv_amd import synth, vcf
+    from oracle import oracle
+    st = synth.ont30(seed=5, scale=0.12)
+    p = Params.ont()
+    hb = st.host_batch(st.tasks(), p)
+    res = oracle.cluster_batch(hb, per_sig=False)
+    assert res.n_calls > 2 * 1024
+
+    def emit(threads):
+        monkeypatch.setenv("CSV_VCF_THREADS", str(threads))
+        out = vcf.emit_records(st, hb.segments, res, {}, min_size=p.min_size, max_size=p.max_size, genotype=False, ignore_sequence=True)
+        return (out[0], list(out[1])) if isinstance(out, tuple) else out
+    want = emit(1)
+    for threads in (4, 4, 7, 2, 4):
+        assert emit(threads) == want
