@@ -118,8 +118,8 @@ struct csv_ctx {
     // batch buffers (slices of `arena`)
     Buf seg, woff, seg_drop, a, b, rid, aux, a32, b32;
     Buf cluster_id, partial, tile_cnt, item_rec, list_small, list_big, list_tiny, list_wide, seg_gate, tile_info, ch_masks, tile_items, seg_err;
-    Buf item_nslots, item_cnt, item_base, item_chunk, sup_tmp;
-    Buf t_rec;
+    Buf item_cnt, item_base, item_chunk, sup_tmp;
+    Buf t_rec, t_rec0;
     Buf sc_k, sc_x, sc_v1, sc_v2, sc_v3, sc_v4, sc_v5;
     Buf o_rec, o_supsig, o_suprid, allele_id;
     Buf reads_off, r_start, r_end, r_primary, r_id, s_start, s_end, s_idp, cmax, cfirst, bfirst, span_len, maxlen, gt_over, gt_huge, gt_pool, contig_len;
@@ -520,9 +520,9 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
     if (per_sig) PL(ch_masks, nt * CT_WORDS * 8);
     PL(tile_items, nt * (size_t)TI_STRIDE * 16);
     PL(item_rec, cap_items * 16); PL(list_small, cap_items * 16); PL(list_big, cap_items * 4); PL(list_tiny, cap_items * 16); PL(list_wide, cap_items * 16);
-    PL(item_nslots, cap_items * 4); PL(item_cnt, cap_items * 8); PL(item_base, (cap_items + 8) * 8); PL(item_chunk, (cap_items / IS_CHUNK + 2) * 8);
+    PL(item_cnt, cap_items * 8); PL(item_base, (cap_items + 8) * 8); PL(item_chunk, (cap_items / IS_CHUNK + 2) * 8);
     // temp call records are indexed by w (a cluster's slots live in its own signature range)
-    PL(t_rec, (W + 1) * sizeof(TmpRec));
+    PL(t_rec, (W + 1) * sizeof(TmpRec)); PL(t_rec0, (cap_items + 1) * sizeof(TmpRec));
     PL(sc_k, SC * 8); PL(sc_x, SC * 8); PL(sc_v1, SC * 4); PL(sc_v2, SC * 4); PL(sc_v3, SC * 4); PL(sc_v4, SC * 4); PL(sc_v5, SC * 4);
     PL(o_rec, (cap_tmp + 1) * sizeof(CallRec)); PL(o_supsig, (W + 1) * 8); PL(o_suprid, (W + 1) * 4);
     if (have_tab) { PL(reads_off, (in->n_chrom + 1) * 8); PL(contig_len, (in->n_chrom + 1) * 8); }
@@ -699,9 +699,9 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
     B.ch_masks = per_sig ? dp<u64>(c->ch_masks) : nullptr; B.tile_items = dp<int4>(c->tile_items);
     B.seg_err = dp<int>(c->seg_err);
     B.tiny_max = getenv("CSV_NO_TINY") ? 0 : 16;               // (timing aid: 0 sends every DEL/INS cluster of m <= 32 through the paired path)
-    B.item_nslots = dp<int>(c->item_nslots); B.item_cnt = dp<i64>(c->item_cnt); B.item_base = dp<i64>(c->item_base); B.item_chunk = dp<i64>(c->item_chunk);
+    B.item_cnt = dp<i64>(c->item_cnt); B.item_base = dp<i64>(c->item_base); B.item_chunk = dp<i64>(c->item_chunk);
     B.sup_tmp = dp<int2>(c->sup_tmp);
-    B.t_rec = dp<TmpRec>(c->t_rec);
+    B.t_rec = dp<TmpRec>(c->t_rec); B.t_rec0 = dp<TmpRec>(c->t_rec0);
     B.cap_tmp = (int)cap_tmp; B.cap_items = (int)cap_items;
     B.sc_k = dp<u64>(c->sc_k); B.sc_x = dp<i64>(c->sc_x); B.sc_v1 = dp<int>(c->sc_v1); B.sc_v2 = dp<int>(c->sc_v2); B.sc_v3 = dp<int>(c->sc_v3); B.sc_v4 = dp<int>(c->sc_v4); B.sc_v5 = dp<int>(c->sc_v5);
     B.o_rec = dp<CallRec>(c->o_rec); B.o_supsig = dp<i64>(c->o_supsig); B.o_suprid = dp<int>(c->o_suprid);
@@ -992,17 +992,6 @@ int read_counters(csv_ctx* c)
             fprintf(stderr, "[csv] counters: clusters %d items %d calls %d error %d | reads: mode %d runs %d state %d | gt_over %d gt_huge %d tra_huge %d\n",
                     c->h_cnt.n_clusters, c->h_cnt.n_items, c->h_cnt.n_calls, c->h_cnt.error, c->B.ro_mode, c->h_cnt.n_runs, c->h_cnt.ro_state,
                     c->h_cnt.n_gt_over, c->h_cnt.n_gt_huge, c->h_cnt.n_tra_huge);
-        if (const char* dump = getenv("CSV_DUMP_ITEMS")) {                    // debug aid: the work-item tables of the last run
-            const int n = c->h_cnt.n_items;
-            std::vector<char> buf((size_t)n * (16 + 8 + 4 + 16 + 4 + 16) + 64);
-            char* q = buf.data();
-            int hdr[4] = {n, c->h_cnt.n_items_big, c->h_cnt.n_items_tiny, c->h_cnt.n_calls};
-            memcpy(q, hdr, 16); q += 16;
-            const void* src[6] = {c->item_rec.p, c->item_cnt.p, c->item_nslots.p, c->list_small.p, c->list_big.p, c->list_tiny.p};
-            const size_t w[6] = {16, 8, 4, 16, 4, 16};
-            for (int k = 0; k < 6; k++) { if (n) (void)hipMemcpy(q, src[k], (size_t)n * w[k], hipMemcpyDeviceToHost); q += (size_t)n * w[k]; }
-            if (FILE* f = fopen(dump, "wb")) { fwrite(buf.data(), 1, (size_t)(q - buf.data()), f); fclose(f); }
-        }
         if (c->B.ro_mode == 1 && c->B.n_reads > 0 && c->any_genotype && c->h_cnt.ro_state == RO_NEED_GENERAL && attempt == 0) {
             c->reads_general = true;
             c->B.ro_mode = 2;

@@ -66,23 +66,29 @@ struct __attribute__((aligned(16))) CallRec {
 };
 static_assert(sizeof(CallRec) == 96, "CallRec layout");
 
-// A temp call record (one per allele / sub-cluster, at t_rec[first w of the cluster + slot]): written by the refine
-// kernels with three 16-byte stores and a 4-byte one, read by k_emit as one 64-byte line.  (Nine separate arrays made k_emit
-// fetch nine lines per slot: 9.6x its algorithmic bytes.)
+// A temp call record (one per allele / sub-cluster): written by the refine kernels with four 16-byte stores (the whole
+// 64-byte line: nothing to merge), read by k_emit as one line.  Slot 0 of item j lives in the DENSE, item-indexed array
+// t_rec0[j] - 99 % of the items have exactly one slot, so neighbouring items' records share 128-byte lines on the write and
+// on the read side, and k_emit's load of it depends on nothing but the item index (r03: every record sat alone in its
+// cluster's own signature range, t_rec[first w + slot]: one 64-byte line touched per 128-byte fetch, and a dependent round
+// trip behind the item record).  Slots >= 1 (a second allele) stay at t_rec[first w + slot].  Slot 0 also carries what
+// k_emit needs to know about the ITEM: its slot count and the aux word of the cluster's first signature.
+// (Nine separate arrays made k_emit fetch nine lines per slot: 9.6x its algorithmic bytes.)
 struct __attribute__((aligned(16))) TmpRec {
     i64 bp1, bp2;                     //  0
     i64 search, pick;                 // 16
     int support, cipos, cilen, supoff;   // 32
-    int valid, pad0, pad1, pad2;      // 48
+    int valid, nslots, aux0, pad2;    // 48 (nslots / aux0: slot 0 only)
 };
 static_assert(sizeof(TmpRec) == 64, "TmpRec layout");
-__device__ __forceinline__ void tmp_write(TmpRec* t, i64 bp1, i64 bp2, i64 search, i64 pick, int support, int cipos, int cilen, int supoff, int valid)
+__device__ __forceinline__ void tmp_write(TmpRec* t, i64 bp1, i64 bp2, i64 search, i64 pick, int support, int cipos, int cilen, int supoff, int valid,
+                                          int nslots = 0, int aux0 = 0)
 {
     int4* r = (int4*)t;
     r[0] = make_int4((int)(bp1 & 0xffffffffll), (int)(bp1 >> 32), (int)(bp2 & 0xffffffffll), (int)(bp2 >> 32));
     r[1] = make_int4((int)(search & 0xffffffffll), (int)(search >> 32), (int)(pick & 0xffffffffll), (int)(pick >> 32));
     r[2] = make_int4(support, cipos, cilen, supoff);
-    ((int*)t)[12] = valid;
+    r[3] = make_int4(valid, nslots, aux0, 0);
 }
 
 struct DevCounters {          // one small struct in device memory, zeroed at the start of every run
@@ -156,13 +162,13 @@ struct DevBatch {
     const int4*    seg_gate;         // per segment {read_count, dropped, svtype, -}: one 16-byte load for the size gate
     const int4*    tile_info;        // per chain tile, built by the host: TILE_REC int4 words (see TILE_REC below)
     // refine outputs
-    int*           item_nslots;      // temp slots the item filled (t_*[s + slot])
+    TmpRec*        t_rec0;           // cap_items: slot 0 of every item (+ its slot count and first aux word), item-indexed
     i64*           item_cnt;         // packed (valid calls << 32 | supports of valid calls)
     i64*           item_base;        // exclusive prefix of item_cnt per tile of EM_TILE items, inside the tile's chunk of IS_CHUNK items
     i64*           item_chunk;       // total of item_cnt per chunk
     int2*          sup_tmp;          // W: support lists {signature w, its read id}, stored inside the cluster's own [s, e) range (the read id
                                      // rides along so that k_emit needs no dependent gather for it)
-    TmpRec*        t_rec;            // W temp call records (a cluster's slots live in its own signature range)
+    TmpRec*        t_rec;            // W temp call records: slots >= 1 of an item live in its own signature range, t_rec[first w + slot]
     int            cap_tmp;
     int            cap_items;
     // big-cluster scratch (2 * W + 16 elements each)
@@ -1158,11 +1164,12 @@ template <class VP, class IP> __device__ int cipos_of(VP v, int n, i64 sum, cons
 // one thread publishes an item's result: slot count and packed (valid calls << 32 | their supports).
 // (Accumulating tile sums here with atomics was tried: even non-returning adds on ~n/8 words doubled
 // the kernel time, so the prefix is a separate, single-workgroup sweep: k_items_scan.)
-__device__ __forceinline__ void item_done(const DevBatch& B, int j, int nslots, int ncalls, int nsup)
+__device__ __forceinline__ void item_done(const DevBatch& B, int j, int ncalls, int nsup)
 {
-    B.item_nslots[j] = nslots;
     B.item_cnt[j] = ((i64)ncalls << 32) + (i64)nsup;
 }
+// where slot `slot` of item j (first signature s) keeps its temp record
+__device__ __forceinline__ TmpRec* tmp_slot(const DevBatch& B, int j, int s, int slot) { return slot == 0 ? &B.t_rec0[j] : &B.t_rec[s + slot]; }
 // The same np.std / cal_CIPOS for n <= 256, computed by a whole wavefront from values held in LDS: numpy's
 // recursion has at most three leaves there (n -> n2 = (n/2) & ~7 and n - n2 <= 135 -> 64 + <= 71); each leaf is
 // summed by an 8-lane group (lane j = accumulator j of numpy's 8-way unrolled loop), then numpy's fixed combine
@@ -1229,7 +1236,7 @@ template <class VP> __device__ __forceinline__ int cipos_wave(VP v, int n, i64 s
 
 __device__ __forceinline__ void item_none(const DevBatch& B, int j)
 {
-    if (threadIdx.x == 0) item_done(B, j, 0, 0, 0);
+    if (threadIdx.x == 0) item_done(B, j, 0, 0);
 }
 
 // Temp call slots need no allocation: a cluster of m signatures yields at most m calls (every allele /
@@ -1348,7 +1355,7 @@ template <int BLOCK, bool LDS, bool SMALLN> __device__ void refine_indel(const D
         A.V3[a] = rank; A.V4[a] = soff;
     }
     npass = (int)block_sum_i64<BLOCK>(npass, red);
-    const int tbase = s;
+    const int tbase = s, aux0 = B.aux[s];
 
     // per allele statistics: one wavefront per allele
     double rr = sg.remain_reads_ratio; if (rr > 1) rr = 1;                  // INDEL:46-47
@@ -1428,15 +1435,13 @@ template <int BLOCK, bool LDS, bool SMALLN> __device__ void refine_indel(const D
         // supports: the allele's kept signatures in allele order (INDEL:205, 416)
         for (int i = lane_id(); i < n; i += 64) { const int w = s + A.V1[r0 + i]; B.sup_tmp[s + soff + i] = make_int2(w, B.rid[w]); }
         if (lane_id() == 0) {
-            const int t = tbase + rank;
-            tmp_write(&B.t_rec[t], (i64)bp, (i64)siglen, search, pick, n, cip, cil, soff, valid);
+            tmp_write(tmp_slot(B, it.j, tbase, rank), (i64)bp, (i64)siglen, search, pick, n, cip, cil, soff, valid, npass, aux0);
             if (valid) { ncalls++; nsup += n; }
         }
     }
     ncalls = (int)block_sum_i64<BLOCK>(ncalls, red);
     nsup = (int)block_sum_i64<BLOCK>(nsup, red);
-    (void)tbase;
-    if (threadIdx.x == 0) item_done(B, it.j, npass, ncalls, nsup);
+    if (threadIdx.x == 0) item_done(B, it.j, ncalls, nsup);
 }
 
 // compacted write of the first-seen signatures of ranks [r0, r1) to sup_tmp[dst...]; one wavefront
@@ -1564,13 +1569,11 @@ template <int BLOCK, bool LDS> __device__ void refine_pair(const DevBatch& B, co
             int cnt = r1 - r0;
             if (k == 0) { s1 += PA[0]; s2 += PB[0]; cnt += 1; }             // element 0 is visited twice, TRA:114-124
             write_first_seen<LDS>(B, A, s, r0, r1, s + soff);
-            if (lane_id() == 0) {
-                const int t = tbase + q;
-                tmp_write(&B.t_rec[t], (i64)((double)s1 / (double)cnt), (i64)((double)s2 / (double)cnt), 0, -1, u, 0, 0, soff, 1);   // TRA:173, 175
-            }
+            if (lane_id() == 0)
+                tmp_write(tmp_slot(B, it.j, tbase, q), (i64)((double)s1 / (double)cnt), (i64)((double)s2 / (double)cnt), 0, -1, u, 0, 0, soff, 1, ne, B.aux[s]);   // TRA:173, 175
             soff += u;
         }
-        if (lane_id() == 0) item_done(B, it.j, ne, ne, soff);
+        if (lane_id() == 0) item_done(B, it.j, ne, soff);
         return;
     }
 
@@ -1592,7 +1595,7 @@ template <int BLOCK, bool LDS> __device__ void refine_pair(const DevBatch& B, co
         carry_slot += tot; carry_sup += tots;
     }
     const int nslots = carry_slot;
-    const int tbase = s;
+    const int tbase = s, aux0 = B.aux[s];
     int ncalls = 0, nsup = 0;
     __syncthreads();                                                        // V4 / V5 of sub k were written by thread k
     for (int k = threadIdx.x >> 6; k < nsub; k += BLOCK / 64) {
@@ -1621,14 +1624,13 @@ template <int BLOCK, bool LDS> __device__ void refine_pair(const DevBatch& B, co
         const int valid = (d >= sg.sv_size) && (d <= sg.max_size || sg.max_size == -1); // DUP:112; INV:132-134
         write_first_seen<LDS>(B, A, s, r0, r1, s + A.V5[k]);
         if (lane_id() == 0) {
-            const int t = tbase + slot;
-            tmp_write(&B.t_rec[t], bp1, bp2, 0, -1, u, 0, 0, A.V5[k], valid);
+            tmp_write(tmp_slot(B, it.j, tbase, slot), bp1, bp2, 0, -1, u, 0, 0, A.V5[k], valid, nslots, aux0);
             if (valid) { ncalls++; nsup += u; }
         }
     }
     ncalls = (int)block_sum_i64<BLOCK>(ncalls, red);
     nsup = (int)block_sum_i64<BLOCK>(nsup, red);
-    if (threadIdx.x == 0) item_done(B, it.j, nslots, ncalls, nsup);
+    if (threadIdx.x == 0) item_done(B, it.j, ncalls, nsup);
 }
 
 // The arrays are reached through FLAT pointers (they may also live in global scratch).  hipcc folds
@@ -1821,11 +1823,14 @@ template <int N> struct RankSwz<N, N> { static __device__ __forceinline__ void r
 // What a unit reads from memory, in two rounds: the list entries of its clusters (one per sub-wave), then - addresses
 // known from the entry alone - the rows and the segment scalars together.  (The first version walked list -> item
 // record -> segment -> rows: four dependent round trips per unit, and with ~10 k units on ~5 k resident wavefronts the
-// kernel's time is a small multiple of one unit's latency.)  k_refine_indel_wave loads the inputs of a wavefront's
-// first two units before it computes anything.
-struct UnitIn {
+// kernel's time is a small multiple of one unit's latency.)
+// Positions and lengths stay in the width of the caller's columns (crd_t): a batch of int32 columns (CSV_IN_SIG_I32, what
+// SigStore.pinned() and bench.py send) is refined in 32-bit registers - every cross-lane move of a coordinate is one
+// ds_permute / ds_bpermute / DPP instead of two, every select one v_cndmask (r03 widened at the load: 80 VGPRs + spills).
+template <bool NARROW> using crd_t = typename std::conditional<NARROW, int, i64>::type;
+template <bool NARROW> struct UnitIn {
     int4 e;                       // list entry {item, segment | svtype << 24, first w, size}; svtype -1: no item (per lane, uniform inside a sub-wave)
-    i64  a, b;
+    crd_t<NARROW> a, b;
     int  rid, aux;
 };
 // entry of the sub-wave's cluster: unit p of a list whose units hold 64 / sw clusters (sw = 1 << sw_log2, wave-uniform)
@@ -1835,57 +1840,80 @@ __device__ __forceinline__ int4 unit_entry(const int4* list, int p, int nlist, i
     return (p >= 0 && q < nlist) ? list[q] : make_int4(0, (int)0xff000000u, 0, 0);
 }
 // rows of the entry's cluster, one signature per lane of the sub-wave; m_lo < size <= sw or the lanes stay empty
-template <bool NARROW> __device__ __forceinline__ void unit_rows(const DevBatch& B, const int4 e, int sw_log2, int m_lo, UnitIn& U)
+template <bool NARROW> __device__ __forceinline__ void unit_rows(const DevBatch& B, const int4 e, int sw_log2, int m_lo, UnitIn<NARROW>& U)
 {
     const int sl = lane_id() & ((1 << sw_log2) - 1), type = e.y >> 24, s = e.z, m = e.w;
     const bool in = (type == CSV_DEL || type == CSV_INS) && m > m_lo && m <= (1 << sw_log2) && sl < m;
     U.e = e;
-    U.a = in ? col_at<NARROW>(B.a, s + sl) : 0;
-    U.b = in ? col_at<NARROW>(B.b, s + sl) : 0;
+    if constexpr (NARROW) { U.a = in ? B.a.p32[s + sl] : 0; U.b = in ? B.b.p32[s + sl] : 0; }
+    else { U.a = in ? B.a.p64[s + sl] : 0; U.b = in ? B.b.p64[s + sl] : 0; }
     U.rid = in ? B.rid[s + sl] : -1 - lane_id();
     U.aux = (in && type == CSV_INS) ? B.aux[s + sl] : 0;
 }
 
+// cross-lane moves of a coordinate in either width; the ds_(b)permute forms take a READY byte address (lane << 2): the
+// handful of source lanes a unit keeps going back to (rank 0 of its sub-wave, the first and last rank of its allele) are
+// shifted once, not at every use (HIP's __shfl recomputes (src & 63) + (self & ~63) << 2 each time)
+__device__ __forceinline__ int bperm(int addr4, int v) { return __builtin_amdgcn_ds_bpermute(addr4, v); }
+__device__ __forceinline__ i64 bperm(int addr4, i64 v)
+{
+    const int lo = __builtin_amdgcn_ds_bpermute(addr4, (int)(v & 0xffffffffll)), hi = __builtin_amdgcn_ds_bpermute(addr4, (int)(v >> 32));
+    return ((i64)hi << 32) | (unsigned)lo;
+}
+__device__ __forceinline__ int fperm(int addr4, int v) { return __builtin_amdgcn_ds_permute(addr4, v); }      // lane i SENDS v to lane addr4 >> 2 (a bijection)
+__device__ __forceinline__ i64 fperm(int addr4, i64 v)
+{
+    const int lo = __builtin_amdgcn_ds_permute(addr4, (int)(v & 0xffffffffll)), hi = __builtin_amdgcn_ds_permute(addr4, (int)(v >> 32));
+    return ((i64)hi << 32) | (unsigned)lo;
+}
+__device__ __forceinline__ int rdlane(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ i64 rdlane(i64 v, int l) { return readlane_i64(v, l); }
+// value of the lane to the left (DPP wave_shr:1).  The move must stay an instruction of its own: left alone, hipcc folds it
+// into the consumer - `v_subrev_u32_dpp v11, v14, v14 wave_shr:1 bound_ctrl:1` for len - lprev, the same register as both
+// operands - and that instruction returned 0 in every lane on gfx950 (no allele was ever split; r04, found by
+// test_narrow_input_columns).  The empty asm makes the moved value opaque to the DPP combiner.
+__device__ __forceinline__ int shr1(int v) { int r = dpp_i32<0x138, 0xf>(0, v); asm volatile("" : "+v"(r)); return r; }
+__device__ __forceinline__ i64 shr1(i64 v) { return wave_shr1_i64(v); }
+template <int SW> __device__ __forceinline__ i64 sub_rlc(i64 x, int t, int g) { return sub_rl64<SW>(x, t, g); }
+template <int SW> __device__ __forceinline__ int sub_rlc(int x, int t, int g) { return sub_rl<SW>(x, t, g); }
+template <class T> struct crd_min;
+template <> struct crd_min<int> { static constexpr int v = INT32_MIN; };
+template <> struct crd_min<i64> { static constexpr i64 v = INT64_MIN; };
+
 #ifndef CSV_IW_WAVES
 #define CSV_IW_WAVES 6
 #endif
-// one unit of work: SW = 32 -> the pair of items (2p, 2p + 1), each handled if m <= 32;
-//                   SW = 64 -> the single item p, handled if 32 < m <= 64.  Returns (SW = 32 only) a 2-bit mask
-//                   of pair members that are DEL/INS clusters of 32 < m <= 64 and still need the wide pass.
-template <int SW> __device__ __forceinline__ int indel_unit(const DevBatch& B, const UnitIn& U)
+// one unit of work: SW = 16 -> four clusters of m <= 16; SW = 32 -> the pair of items (2p, 2p + 1), each handled if m <= 32;
+//                   SW = 64 -> the single item p, handled if 32 < m <= 64.
+template <int SW, bool NARROW> __device__ __forceinline__ void indel_unit(const DevBatch& B, const UnitIn<NARROW>& U)
 {
-    constexpr bool HALF = SW == 32;
+    typedef crd_t<NARROW> C;
     constexpr int NSUB = 64 / SW;                      // clusters per wavefront
     constexpr int MLO = SW == 64 ? 32 : 0;
     constexpr u64 SUBMASK = SW == 64 ? ~0ull : (1ull << SW) - 1ull;
     const int lane = lane_id(), sl = lane & (SW - 1), hb = lane & ~(SW - 1), g = lane / SW;
-    const u64 sl_lt = (1ull << sl) - 1ull, sl_le = sl_lt | (1ull << sl);        // masks in sub-lane positions
-    int wide = 0;
+    const int hb4 = hb << 2, last4 = (hb | (SW - 1)) << 2;                       // byte addresses of the sub-wave's first / last lane
     do {
         const int j = U.e.x, k = U.e.y & 0xffffff, type = U.e.y >> 24, s = U.e.z, m = U.e.w;
         // other types go to k_refine<64,64>, the other size class to the other instantiation
         const bool indel = type == CSV_DEL || type == CSV_INS;
         const bool act = indel && m > MLO && m <= SW;
-        if (HALF) {
-            const u64 wm = __ballot(indel && m > 32 && sl == 0);
-            wide = (int)(wm & 1) | (int)((wm >> 32) & 1) << 1;
-        }
         if (!__ballot(act)) break;
-        if (CSV_ABL(6)) { if (act && sl == 0) item_done(B, j, 0, 0, (int)(U.a + U.b + U.rid + U.aux)); break; }      // loads only
+        if (CSV_ABL(6)) { if (act && sl == 0) item_done(B, j, 0, (int)(U.a + U.b + U.rid + U.aux)); break; }      // loads only
         // segment scalars: issued here, first needed after the de-duplication (the table is a few KB and cache resident)
         int rc = 0x7fffffff, msr = 0;
-        double ratio = 0.0, rr = 1.0;
-        i64 gsig0 = 0;
+        double ratio = 0.0;
         if (act) {
             const csv_segment& sg = B.seg[k];
             rc = sg.read_count; msr = sg.min_support_reads; ratio = sg.diff_ratio;
-            rr = sg.remain_reads_ratio; if (rr > 1) rr = 1;                       // INDEL:46-47
-            gsig0 = sg.sig_begin + ((i64)s - B.woff[k]);
         }
         const bool in = act && sl < m;
-        const i64 a = U.a, b = U.b;
+        const C a = U.a, b = U.b;
         const int rid = U.rid, aux = U.aux;
-        const bool badk = sub_ballot<SW>(in && (((u64)b) >> (63 - IDX_BITS)) != 0, g) != 0;   // out-of-range length: the cluster emits nothing
+        // out-of-range length (negative, or beyond the sort keys of the other tiers): the cluster emits nothing
+        bool bad;
+        if constexpr (NARROW) bad = in && b < 0; else bad = in && (((u64)b) >> (63 - IDX_BITS)) != 0;
+        const bool badk = sub_ballot<SW>(bad, g) != 0;
         if (badk && sl == 0) atomicOr(&B.seg_err[k], CSV_SEG_KEY_RANGE);
         const int mact = act ? m : 0;
         int mmax = __builtin_amdgcn_readlane(mact, 0);
@@ -1894,7 +1922,7 @@ template <int SW> __device__ __forceinline__ int indel_unit(const DevBatch& B, c
 
         // ---- per-read de-duplication (INDEL:125-131): first appearance F, kept signature = strictly longest
         int F = sl, ch = sl;
-        i64 bl = b;
+        C bl = b;
         // which lanes hold my read id?  One ballot per id bit, AND of the agreeing sides: the whole wavefront
         // (both sub-waves) in ~6 instructions per bit, independent of m.
         bool dup_any = false;
@@ -1923,11 +1951,11 @@ template <int SW> __device__ __forceinline__ int indel_unit(const DevBatch& B, c
         // not a rare path: walk only the lanes that have a partner (two to four per wavefront, in lane order = order of
         // appearance), each broadcast with plain v_readlane, instead of all mmax sub-lanes through the 4-way select.
         if (const u64 dm0 = __ballot(dup_any)) {
-            if (dup_any) { F = -1; ch = -1; bl = INT64_MIN; }
+            if (dup_any) { F = -1; ch = -1; bl = crd_min<C>::v; }
             for (u64 dm = dm0; dm; dm &= dm - 1) {
                 const int t = __ffsll((long long)dm) - 1;
                 const int rt = __builtin_amdgcn_readlane(rid, t);
-                const i64 bt = readlane_i64(b, t);
+                const C bt = rdlane(b, t);
                 if (dup_any && (t & ~(SW - 1)) == hb && rt == rid) {          // same cluster, same read (a folded-id false match fails here)
                     if (F < 0) F = t & (SW - 1);
                     if (bt > bl) { bl = bt; ch = t & (SW - 1); }
@@ -1936,12 +1964,14 @@ template <int SW> __device__ __forceinline__ int indel_unit(const DevBatch& B, c
         }
         const bool rep = in && (F == sl);
         const u64 rm = sub_ballot<SW>(rep, g);
-        const int U = __popcll(rm);
-        const bool ok = act && !badk && U >= rc;                                 // INDEL:133-134
-        if (act && !ok && sl == 0) item_done(B, j, 0, 0, 0);
+        const int U_ = __popcll(rm);
+        const bool ok = act && !badk && U_ >= rc;                                // INDEL:133-134
+        if (act && !ok && sl == 0) item_done(B, j, 0, 0);
         if (!__ballot(ok)) break;
-        const i64 pa = shfl_i64(a, hb | (ch & (SW - 1)));
-        const int pax = __shfl(aux, hb | (ch & (SW - 1)));
+        const int ch4 = (hb | (ch & (SW - 1))) << 2;
+        const C pa = bperm(ch4, a);
+        const int pax = bperm(ch4, aux);
+        const int aux0 = bperm(hb4, aux);                                         // aux word of the cluster's first signature (k_emit: call_aux)
 
         // ---- stable sort of the kept signatures by length (INDEL:136): rank by (len, first appearance)
         int rank = 0, src_lane = -1;
@@ -1955,8 +1985,9 @@ template <int SW> __device__ __forceinline__ int indel_unit(const DevBatch& B, c
                 // sub-waves in one LDS-crossbar instruction; the pattern is an immediate, hence the unrolled loop
                 RankSwz<0, SW>::run(key, mmax, rank);
             } else {
+                const u64 sl_lt0 = (1ull << sl) - 1ull; (void)sl_lt0;
                 for (int t = 0; t < mmax; t++) {
-                    const i64 lt = sub_rl64<SW>(bl, t, g);
+                    const C lt = sub_rlc<SW>(bl, t, g);
                     rank += ((rm >> t) & 1) && ((lt < bl) || (lt == bl && t < sl));
                 }
             }
@@ -1971,34 +2002,40 @@ template <int SW> __device__ __forceinline__ int indel_unit(const DevBatch& B, c
         } else {
             for (u64 mk = __ballot(rep); mk; mk &= mk - 1) {
                 const int t = __ffsll((long long)mk) - 1;
-                const i64 lt = readlane_i64(bl, t);
+                const C lt = rdlane(bl, t);
                 rank += (lt < bl) || (lt == bl && t < sl);
             }
         }
-        i64 pos, len; int chp, axp, ridp;
+        C pos, len; int chp, axp, ridp;
         if (SW == 64 && src_lane >= 0) {                                     // (wave-uniform: all lanes or none)
-            pos = shfl_i64(pa, src_lane); len = shfl_i64(bl, src_lane);
-            chp = __shfl(ch, src_lane); axp = __shfl(pax, src_lane); ridp = __shfl(rid, src_lane);
+            const int s4 = src_lane << 2;
+            pos = bperm(s4, pa); len = bperm(s4, bl);
+            chp = bperm(s4, ch); axp = bperm(s4, pax); ridp = bperm(s4, rid);
         } else {
-            const int dest = hb | (rep ? rank : U + __popcll(~rm & sl_lt & SUBMASK));
-            pos = permute_i64(dest, pa);
-            len = permute_i64(dest, bl);
-            chp = __builtin_amdgcn_ds_permute(dest << 2, ch);
-            axp = __builtin_amdgcn_ds_permute(dest << 2, pax);
-            ridp = __builtin_amdgcn_ds_permute(dest << 2, rid);              // (every signature of a read's group carries the group's read id)
+            const u64 sl_lt = (1ull << sl) - 1ull;
+            const int dest4 = (hb | (rep ? rank : U_ + __popcll(~rm & sl_lt & SUBMASK))) << 2;
+            pos = fperm(dest4, pa);
+            len = fperm(dest4, bl);
+            chp = fperm(dest4, ch);
+            axp = fperm(dest4, pax);
+            ridp = fperm(dest4, rid);                                        // (every signature of a read's group carries the group's read id)
         }
         const int r = sl;
-        const bool live = ok && r < U;
-        const int last = hb | (SW - 1);
+        const bool live = ok && r < U_;
 
         // ---- sums.  A cluster whose positions and lengths all lie within 2^18 of its first member's (every ordinary one)
         // takes the FAST form: both deltas, biased to be non-negative, share ONE 64-bit scan (sums < 2^25 per half), and what
         // follows - allele sums, the member closest to the mean, the variances - works on these small exact integers.
         constexpr int DB = 18;
-        const i64 bpos = shfl_i64(pos, hb), blen = shfl_i64(len, hb);             // rank 0 of the sub-wave: the origin of the deltas
+        const C bpos = bperm(hb4, pos), blen = bperm(hb4, len);                   // rank 0 of the sub-wave: the origin of the deltas
         int dp32, dl32;                                                           // the deltas (meaningful when `fast`)
         bool small;
-        {
+        if constexpr (NARROW) {
+            // (coordinates of an int32 column; a live length is >= 0 - `bad` - and the difference of two non-negative ints cannot wrap)
+            const int dpi = (int)((unsigned)pos - (unsigned)bpos), dli = (int)((unsigned)len - (unsigned)blen);
+            small = !live || ((pos | bpos) >= 0 && dpi > -(1 << DB) && dpi < (1 << DB) && dli > -(1 << DB) && dli < (1 << DB));
+            dp32 = live ? dpi : 0; dl32 = live ? dli : 0;
+        } else {
             const i64 dpi = pos - bpos, dli = len - blen;
             small = !live || ((u64)pos < (1ull << 31) && (u64)len < (1ull << 31) && dpi > -(1 << DB) && dpi < (1 << DB) && dli > -(1 << DB) && dli < (1 << DB));
             dp32 = live ? (int)dpi : 0; dl32 = live ? (int)dli : 0;
@@ -2008,35 +2045,38 @@ template <int SW> __device__ __forceinline__ int indel_unit(const DevBatch& B, c
         if (fast) {
             const unsigned dpb = live ? (unsigned)(dp32 + (1 << DB)) : 0u, dlb = live ? (unsigned)(dl32 + (1 << DB)) : 0u;
             PK = sub_scan_i64<SW>((i64)(((u64)dlb << 32) | dpb));
-            lsum = (i64)U * (blen - (1 << DB)) + (i64)((u64)shfl_i64(PK, last) >> 32);
-        } else lsum = shfl_i64(sub_scan_i64<SW>(live ? len : 0), last);
+            lsum = (i64)U_ * ((i64)blen - (1 << DB)) + (i64)((u64)bperm(last4, PK) >> 32);
+        } else lsum = bperm(last4, sub_scan_i64<SW>(live ? (i64)len : 0));
         // ---- allele split on consecutive length gaps (INDEL:138, 153-162)
-        const double thr = ratio * div_by((double)lsum, (double)U, B.rcp_tab[U & (SQRT_TAB - 1)]);
-        const i64 lprev = wave_shr1_i64(len);
-        const bool f = live && r > 0 && ((double)(len - lprev) > thr);
+        const double thr = ratio * div_by((double)lsum, (double)U_, B.rcp_tab[U_ & (SQRT_TAB - 1)]);
+        const C lprev = shr1(len);
+        bool f;
+        if constexpr (NARROW) f = live && r > 0 && ((double)(int)((unsigned)len - (unsigned)lprev) > thr);
+        else f = live && r > 0 && ((double)(len - lprev) > thr);
         const u64 fmask = __ballot(f);
         const u64 S = ((fmask >> hb) & SUBMASK) | 1ull;                           // allele start ranks (sub-lane positions)
+        const u64 sl_le = (2ull << sl) - 1ull;
         const u64 below = S & sl_le, above = S & ~sl_le & SUBMASK;
         const int r0 = 63 - __clzll((long long)below);
-        int r1 = above ? (__ffsll((long long)above) - 1) : U;
-        if (r1 > U) r1 = U;
+        int r1 = above ? (__ffsll((long long)above) - 1) : U_;
+        if (r1 > U_) r1 = U_;
         const int n = live ? r1 - r0 : 1, i = r - r0;
 
-        const int e1 = hb | ((r1 - 1) & (SW - 1)), e0 = hb | ((r0 - 1) & (SW - 1));
+        const int e14 = (hb | ((r1 - 1) & (SW - 1))) << 2, e04 = (hb | ((r0 - 1) & (SW - 1))) << 2;     // last rank of the allele / of the one before
         // NB: every cross-lane op sits in wave-uniform control flow; only the selects are per lane
         i64 sp, sln;
         int s1p = 0, s1l = 0;                                                     // fast: sums of the deltas over the allele
         if (fast) {
-            const i64 k1 = shfl_i64(PK, e1), k0 = shfl_i64(PK, e0);
+            const i64 k1 = bperm(e14, PK), k0 = bperm(e04, PK);
             const u64 seg = (u64)(k1 - (r0 > 0 ? k0 : 0));                        // (both halves ascend: no borrow across them)
             s1p = (int)(unsigned)(seg & 0xffffffffull) - n * (1 << DB);
             s1l = (int)(unsigned)(seg >> 32) - n * (1 << DB);
-            sp = (i64)n * bpos + s1p; sln = (i64)n * blen + s1l;
+            sp = (i64)n * (i64)bpos + s1p; sln = (i64)n * (i64)blen + s1l;
         } else {
-            const i64 Ppos = sub_scan_i64<SW>(live ? pos : 0), Plen = sub_scan_i64<SW>(live ? len : 0);
-            const i64 pp0 = shfl_i64(Ppos, e0), pl0 = shfl_i64(Plen, e0);
-            sp = shfl_i64(Ppos, e1) - (r0 > 0 ? pp0 : 0);
-            sln = shfl_i64(Plen, e1) - (r0 > 0 ? pl0 : 0);
+            const i64 Ppos = sub_scan_i64<SW>(live ? (i64)pos : 0), Plen = sub_scan_i64<SW>(live ? (i64)len : 0);
+            const i64 pp0 = bperm(e04, Ppos), pl0 = bperm(e04, Plen);
+            sp = bperm(e14, Ppos) - (r0 > 0 ? pp0 : 0);
+            sln = bperm(e14, Plen) - (r0 > 0 ? pl0 : 0);
         }
 
         // ---- emission order: stable ascending by support among alleles with n >= minimum_support_reads (INDEL:163-166)
@@ -2054,11 +2094,13 @@ template <int SW> __device__ __forceinline__ int indel_unit(const DevBatch& B, c
         }
 
         // ---- statistics, all alleles at once
+        double rr = 1.0;
+        if (act) { rr = B.seg[k].remain_reads_ratio; if (rr > 1) rr = 1; }        // INDEL:46-47 (cache resident; loaded here, not held since the top)
         int keep = (int)(rr * (double)n); if (keep < 1) keep = 1;                 // INDEL:169
         const double rcp_n = B.rcp_tab[n & (SQRT_TAB - 1)];
         const double pmean = div_by((double)sp, (double)n, rcp_n), lmean = div_by((double)sln, (double)n, rcp_n);
         double bp = pmean, siglen = lmean;
-        i64 search;
+        C search;
         if (CSV_ABL(3)) search = pos;
         else if (!__ballot(pass && keep < n) && fast) {
             // every member kept: search_threshold = first member with the smallest |pos - mean| (INDEL:171-177), in integers:
@@ -2076,9 +2118,10 @@ template <int SW> __device__ __forceinline__ int indel_unit(const DevBatch& B, c
                 CSV_MINSTEP(0x111, 1) CSV_MINSTEP(0x112, 2) CSV_MINSTEP(0x114, 4) CSV_MINSTEP(0x118, 8)
 #undef CSV_MINSTEP
             } else {
-                for (int d = 1; d < SW; d <<= 1) { const unsigned o = (unsigned)__shfl((int)bk, (lane - d) & 63); if (i >= d && o < bk) bk = o; }
+                const int l4 = lane << 2;
+                for (int d = 1; d < SW; d <<= 1) { const unsigned o = (unsigned)bperm((l4 - 4 * d) & 252, (int)bk); if (i >= d && o < bk) bk = o; }
             }
-            search = shfl_i64(pos, hb | (__shfl((int)bk, e1) & (SW - 1)));
+            search = bperm((hb | (bperm(e14, (int)bk) & (SW - 1))) << 2, pos);
         } else if (!__ballot(pass && keep < n)) {
             // the same on the doubles themselves (clusters that span more than 2^18 bases)
             double bd = fabs((double)pos - pmean); int bi = r;
@@ -2086,7 +2129,7 @@ template <int SW> __device__ __forceinline__ int indel_unit(const DevBatch& B, c
                 const double od = shfl_f64(bd, (lane - d) & 63); const int oi = __shfl(bi, (lane - d) & 63);
                 if (r - d >= r0 && (od < bd || (od == bd && oi < bi))) { bd = od; bi = oi; }
             }
-            search = shfl_i64(pos, hb | (__shfl(bi, e1) & (SW - 1)));
+            search = bperm((hb | (bperm(e14, bi) & (SW - 1))) << 2, pos);
         } else {
             // keep the `keep` members closest to the mean, ties in allele order (INDEL:171-176, 182-187)
             const double dp = fabs((double)pos - pmean), dl = fabs((double)len - lmean);
@@ -2095,17 +2138,17 @@ template <int SW> __device__ __forceinline__ int indel_unit(const DevBatch& B, c
                 const int r0t = sub_rl<SW>(r0, t, g);
                 const double tp = __longlong_as_double(sub_rl64<SW>(__double_as_longlong(dp), t, g));
                 const double tl = __longlong_as_double(sub_rl64<SW>(__double_as_longlong(dl), t, g));
-                if (t < U && r0t == r0) {
+                if (t < U_ && r0t == r0) {
                     rp += (tp < dp) || (tp == dp && t < r);
                     rl += (tl < dl) || (tl == dl && t < r);
                 }
             }
-            const i64 Kp = sub_scan_i64<SW>((live && rp < keep) ? pos : 0), Kl = sub_scan_i64<SW>((live && rl < keep) ? len : 0);
-            const i64 Ks = sub_scan_i64<SW>((live && rp == 0) ? pos : 0);
-            const i64 kp0 = shfl_i64(Kp, e0), kl0 = shfl_i64(Kl, e0), ks0 = shfl_i64(Ks, e0);
-            const i64 ks = shfl_i64(Kp, e1) - (r0 > 0 ? kp0 : 0);
-            const i64 kl = shfl_i64(Kl, e1) - (r0 > 0 ? kl0 : 0);
-            search = shfl_i64(Ks, e1) - (r0 > 0 ? ks0 : 0);
+            const i64 Kp = sub_scan_i64<SW>((live && rp < keep) ? (i64)pos : 0), Kl = sub_scan_i64<SW>((live && rl < keep) ? (i64)len : 0);
+            const i64 Ks = sub_scan_i64<SW>((live && rp == 0) ? (i64)pos : 0);
+            const i64 kp0 = bperm(e04, Kp), kl0 = bperm(e04, Kl), ks0 = bperm(e04, Ks);
+            const i64 ks = bperm(e14, Kp) - (r0 > 0 ? kp0 : 0);
+            const i64 kl = bperm(e14, Kl) - (r0 > 0 ? kl0 : 0);
+            search = (C)(bperm(e14, Ks) - (r0 > 0 ? ks0 : 0));
             const double rcp_k = B.rcp_tab[keep & (SQRT_TAB - 1)];
             bp = div_by((double)ks, (double)keep, rcp_k); siglen = div_by((double)kl, (double)keep, rcp_k);   // INDEL:176-177, 187
         }
@@ -2114,17 +2157,28 @@ template <int SW> __device__ __forceinline__ int indel_unit(const DevBatch& B, c
         // int(1.96 * std / n ** 0.5) leaves the stage.  numpy's sum of (x - mean)^2 differs from the exact variance
         // (n * sum(d^2) - sum(d)^2) / n^2 (integers, d = x - x0) by a relative error below 4e-12 for coordinates under 2^31 (the
         // mean's rounding error e enters only as n e^2: the first-order term 2 e sum(x - mean) vanishes).  So: the exact integer
-        // variance through two more scans, the value 1.96 * sqrt(N) / (n * n ** 0.5) in float32 (one v_sqrt_f32, a table factor;
-        // relative error < 5e-7), and the replay only for a wavefront in which some allele's value lies within 2e-6 (relative)
-        // of an integer: about one unit in a thousand.  (Replay, four float64 divisions and two square roots per unit were 28 %
-        // of this kernel's instructions.)
+        // variance through one or two more scans, the value 1.96 * sqrt(N) / (n * n ** 0.5) in float32 (one v_sqrt_f32, a table
+        // factor; relative error < 5e-7), and the replay only for a wavefront in which some allele's value lies within 2e-6
+        // (relative) of an integer: about one unit in a thousand.  (Replay, four float64 divisions and two square roots per unit
+        // were 28 % of this kernel's instructions.)
         int cip = 0, cil = 0;
         if (!CSV_ABL(2)) {
             bool exact_ok = fast;
             if (exact_ok) {
-                const i64 Q2p = sub_scan_i64<SW>((i64)dp32 * dp32), Q2l = sub_scan_i64<SW>((i64)dl32 * dl32);      // squares < 2^36, sums < 2^42
-                const i64 qp0 = shfl_i64(Q2p, e0), ql0 = shfl_i64(Q2l, e0);
-                const i64 s2p = shfl_i64(Q2p, e1) - (r0 > 0 ? qp0 : 0), s2l = shfl_i64(Q2l, e1) - (r0 > 0 ? ql0 : 0);
+                i64 s2p, s2l;
+                const int adp = dp32 < 0 ? -dp32 : dp32, adl = dl32 < 0 ? -dl32 : dl32;
+                if (!__ballot((adp | adl) >> 12)) {
+                    // every delta below 2^12 (all but clusters with two far-apart alleles): the squares are below 2^24, their sums
+                    // over a sub-wave below 2^30, so both series share one scan like the deltas themselves
+                    const i64 Q = sub_scan_i64<SW>((i64)(((u64)(unsigned)(adl * adl) << 32) | (unsigned)(adp * adp)));
+                    const i64 q1 = bperm(e14, Q), q0 = bperm(e04, Q);
+                    const u64 seg = (u64)(q1 - (r0 > 0 ? q0 : 0));
+                    s2p = (i64)(seg & 0xffffffffull); s2l = (i64)(seg >> 32);
+                } else {
+                    const i64 Q2p = sub_scan_i64<SW>((i64)dp32 * dp32), Q2l = sub_scan_i64<SW>((i64)dl32 * dl32);      // squares < 2^36, sums < 2^42
+                    const i64 qp0 = bperm(e04, Q2p), ql0 = bperm(e04, Q2l);
+                    s2p = bperm(e14, Q2p) - (r0 > 0 ? qp0 : 0); s2l = bperm(e14, Q2l) - (r0 > 0 ? ql0 : 0);
+                }
                 const i64 np_ = (i64)n * s2p - (i64)s1p * s1p, nl_ = (i64)n * s2l - (i64)s1l * s1l;          // n^2 * variance, exact, < 2^48
                 const float ck = B.cipk_tab[n & (SQRT_TAB - 1)];                     // 1.96 / (n * n ** 0.5)
                 const float vp = __builtin_amdgcn_sqrtf((float)(double)np_) * ck, vl = __builtin_amdgcn_sqrtf((float)(double)nl_) * ck;
@@ -2148,29 +2202,30 @@ template <int SW> __device__ __forceinline__ int indel_unit(const DevBatch& B, c
         const u64 range = ((n >= 64) ? ~0ull : ((1ull << n) - 1ull)) << r0;
         const u64 mm = okm & range;
         const int pr = mm ? (__ffsll((long long)mm) - 1) : r0;
-        const int pick_ch = __shfl(chp, hb | pr);
-        const i64 pick_pos = shfl_i64(pos, hb | pr);
+        const int pr4 = (hb | pr) << 2;
+        const int pick_ch = bperm(pr4, chp);
+        const C pick_pos = bperm(pr4, pos);
         i64 pick = -1; bool valid = true;
+        i64 bp_i = (i64)bp, search_i = (i64)search;
         if (type == CSV_INS) {
             valid = mm != 0;
-            pick = gsig0 + pick_ch;
-            bp = (double)pick_pos;
-            search = (i64)bp;                                                     // INDEL:415
+            bp_i = (i64)pick_pos;                                                 // (the reference's float(pos) -> int() round trip is exact below 2^53)
+            search_i = bp_i;                                                      // INDEL:415
         }
         if (pass && !CSV_ABL(4)) B.sup_tmp[s + soff + i] = make_int2(s + chp, ridp);   // INDEL:205, 416
         const bool head = pass && i == 0;
         if (head && !CSV_ABL(4)) {
-            const int t = s + erank;
-            tmp_write(&B.t_rec[t], (i64)bp, (i64)siglen, search, valid ? pick : -1, n, cip, cil, soff, valid ? 1 : 0);
+            if (type == CSV_INS && valid) pick = B.seg[k].sig_begin + ((i64)s - B.woff[k]) + pick_ch;      // global signature index (w -> caller's row)
+            tmp_write(tmp_slot(B, j, s, erank), bp_i, (i64)siglen, search_i, pick, n, cip, cil, soff, valid ? 1 : 0, npass, aux0);
         }
         const int ncalls = __popcll(sub_ballot<SW>(head && valid, g));
-        const int nsup = __shfl(sub_scan_i32<SW>((head && valid) ? n : 0), last);
-        if (ok && sl == 0) item_done(B, j, npass, ncalls, nsup);
+        const int nsup = bperm(last4, sub_scan_i32<SW>((head && valid) ? n : 0));
+        if (ok && sl == 0) item_done(B, j, ncalls, nsup);
     } while (0);
-    return wide;
 }
 
-template <bool NARROW> __global__ __launch_bounds__(256, CSV_IW_WAVES) void k_refine_indel_wave(DevBatch B)
+// (int64 columns keep their coordinates in register pairs: one wavefront per SIMD fewer, and no spills either)
+template <bool NARROW> __global__ __launch_bounds__(256, NARROW ? CSV_IW_WAVES : CSV_IW_WAVES - 1) void k_refine_indel_wave(DevBatch B)
 {
     const int ntiny = B.cnt->n_items_tiny, nsmall = B.cnt->n_items - B.cnt->n_items_big - ntiny;
     const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * 256 + threadIdx.x) >> 6), nwaves = (gridDim.x * 256) >> 6;
@@ -2183,24 +2238,24 @@ template <bool NARROW> __global__ __launch_bounds__(256, CSV_IW_WAVES) void k_re
     // wavefronts, so that a wavefront that already has a wide item is not also the one that gets a second unit when there
     // are more units than wavefronts.  (More wide items than wavefronts - deep coverage - : everything over all of them.)
     for (int p = wave; p < n_wide; p += nwaves) {
-        UnitIn U;
+        UnitIn<NARROW> U;
         unit_rows<NARROW>(B, unit_entry(B.list_wide, p, n_wide, 6), 6, 32, U);
-        indel_unit<64>(B, U);
+        indel_unit<64, NARROW>(B, U);
     }
     const int skip = n_wide < nwaves ? n_wide : 0, M = nwaves - skip;
     if (wave < skip) return;
     const int slot = wave - skip;
     for (int p = slot; p < n_pair; p += M) {
-        UnitIn U;
+        UnitIn<NARROW> U;
         unit_rows<NARROW>(B, unit_entry(B.list_small, p, nsmall, 5), 5, 0, U);
-        indel_unit<32>(B, U);                              // (members with 32 < m <= 64 are skipped here: they are units of their own)
+        indel_unit<32, NARROW>(B, U);                      // (members with 32 < m <= 64 are skipped here: they are units of their own)
     }
     int q0 = slot - n_pair % M;                            // the quads continue the round-robin where the pairs stopped
     if (q0 < 0) q0 += M;
     for (int p = q0; p < n_quad; p += M) {
-        UnitIn U;
+        UnitIn<NARROW> U;
         unit_rows<NARROW>(B, unit_entry(B.list_tiny, p, ntiny, 4), 4, 0, U);
-        indel_unit<16>(B, U);
+        indel_unit<16, NARROW>(B, U);
     }
 }
 
@@ -2292,20 +2347,18 @@ __device__ __forceinline__ void write_call(const DevBatch& B, int c, i64 bp1, i6
 __device__ __forceinline__ void emit_item_serial(const DevBatch& B, int j, i64 base)
 {
     const int lane = lane_id();
-    const int nslots = B.item_nslots[j];
+    const int nslots = B.t_rec0[j].nslots, aux0 = B.t_rec0[j].aux0;
     const int4 rec = B.item_rec[j];
     const int cid = rec.x, k = rec.y, s = rec.z;
     const csv_segment& sgk = B.seg[k];
     const i64 gs = sgk.sig_begin + ((i64)s - B.woff[k]) - s;           // w -> global signature index
     const int4 ghdr = make_int4(sgk.chrom, sgk.svtype | (sgk.genotype ? 0x100 : 0), (int)(sgk.gt_bias & 0xffffffffll), (int)(sgk.gt_bias >> 32));
     int cb = (int)(base >> 32); i64 sb = base & 0xffffffffll;
-    const int aux0 = B.aux[s];
     for (int c0 = 0; c0 < nslots; c0 += 64) {
-        const int t = s + c0 + lane;
         const int in = (c0 + lane) < nslots;
         TmpRec tr;
         tr.valid = 0;
-        if (in) tr = B.t_rec[t];
+        if (in) tr = *tmp_slot(B, j, s, c0 + lane);
         const int valid = in ? tr.valid : 0;
         const int nsup = valid ? tr.support : 0;
         const int tso = valid ? tr.supoff : 0;
@@ -2352,8 +2405,11 @@ __global__ __launch_bounds__(256) void k_emit(DevBatch B)
         // AFTER the others: a scalar load of it is hoisted to the top of the kernel and waited for there.)
         const int jj = j < jmax ? j : jmax, tt = tile < jmax / EM_TILE ? tile : jmax / EM_TILE;
         const i64 cnt_raw = B.item_cnt[jj];
-        const int nslots_raw = B.item_nslots[jj];
         const int4 rec_raw = B.item_rec[jj];
+        // slot 0 of the item: dense and item-indexed, so it travels with round 1 (the 8 records of a tile are 512 contiguous
+        // bytes; the group's first lane takes its item's four 16-byte words)
+        int4 q0 = make_int4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0;
+        if (l8 == 0) { const int4* r = (const int4*)&B.t_rec0[jj]; q0 = r[0]; q1 = r[1]; q2 = r[2]; q3 = r[3]; }
         const int nchunk = tt / (IS_CHUNK / EM_TILE);
         i64 cb_raw = B.item_chunk[lane < nchunk ? lane : 0];
         i64 tile_base = B.item_base[tt];
@@ -2372,7 +2428,8 @@ __global__ __launch_bounds__(256) void k_emit(DevBatch B)
             const i64 t = tile_base + ginc;
             B.cnt->n_calls = (int)(t >> 32); B.cnt->n_support = t & 0xffffffffll;
         }
-        const int nslots = cnt ? nslots_raw : 0;
+        const int ns0 = __shfl(q3.y, g * 8);                // (cross-lane moves stay outside per-lane selects)
+        const int nslots = cnt ? ns0 : 0;
         if (__ballot(nslots > 8)) {                         // wave-uniform
             for (int q = 0; q < EM_TILE; q++) {
                 const i64 cq = shfl_i64(cnt, q * 8), bq = shfl_i64(base, q * 8);
@@ -2382,26 +2439,28 @@ __global__ __launch_bounds__(256) void k_emit(DevBatch B)
         }
         const int cid = rec.x, k = rec.y, s = rec.z;
         const bool mine = l8 < nslots;
-        const int t = s + l8;
-        // ... round 2: the slot records of all 8 items (one lane per temp slot), valid or not, and the segment scalars
+        // ... round 2: the records of the slots >= 1 (one lane per temp slot; one item in a hundred has any), valid or not, and
+        // the segment scalars
+        if (mine && l8 > 0) { const int4* r = (const int4*)&B.t_rec[s + l8]; q0 = r[0]; q1 = r[1]; q2 = r[2]; q3 = r[3]; }
         int valid = 0, nsup = 0, tso = 0, ci = 0, cl = 0;
         i64 bp1 = 0, bp2 = 0, srch = 0, pick = 0;
         if (mine) {
-            const TmpRec tr = B.t_rec[t];
-            valid = tr.valid; nsup = tr.support; tso = tr.supoff;
-            bp1 = tr.bp1; bp2 = tr.bp2; ci = tr.cipos; cl = tr.cilen; srch = tr.search; pick = tr.pick;
+            valid = q3.x; nsup = q2.x; tso = q2.w; ci = q2.y; cl = q2.z;
+            bp1 = ((i64)q0.y << 32) | (unsigned)q0.x; bp2 = ((i64)q0.w << 32) | (unsigned)q0.z;
+            srch = ((i64)q1.y << 32) | (unsigned)q1.x; pick = ((i64)q1.w << 32) | (unsigned)q1.z;
         }
+        const int aux0 = __shfl(q3.z, g * 8);               // (slot 0 carries the cluster's first aux word: no gather of B.aux[s])
         // (... and, before the slot records say how long the lists are, the first 32 supports of the item's first slot, whose list
         // always begins at the cluster's own first row: most items have one call with fewer supports than that, and their third
         // round trip disappears)
         int2 pre[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) { const i64 x = (i64)s + l8 + 8 * u; pre[u] = B.sup_tmp[x < B.W ? x : B.W]; }
-        i64 gs = 0; int aux0 = 0;
+        i64 gs = 0;
         int4 ghdr = make_int4(0, 0, 0, 0);
         if (nslots) {
             const csv_segment& sgk = B.seg[k];
-            gs = sgk.sig_begin + ((i64)s - B.woff[k]) - s; aux0 = B.aux[s];
+            gs = sgk.sig_begin + ((i64)s - B.woff[k]) - s;
             ghdr = make_int4(sgk.chrom, sgk.svtype | (sgk.genotype ? 0x100 : 0), (int)(sgk.gt_bias & 0xffffffffll), (int)(sgk.gt_bias >> 32));
         }
         if (!valid) { nsup = 0; tso = 0; }
