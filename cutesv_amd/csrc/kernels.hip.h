@@ -1807,18 +1807,44 @@ __device__ __forceinline__ void np_sum_allele2(double sq1, double sq2, int n, in
     out1 = res1; out2 = res2;
 }
 
-// rank += #{t < mmax : key[t] < key} with key[t] = the key of sub-lane t of the caller's own sub-wave of 32 / 16 lanes
-// (ds_swizzle wants its pattern as an immediate: compile-time recursion instead of a loop)
-// (N = sub-wave width: 32 -> and_mask 0, 16 -> and_mask 0x10 keeps the 16-lane row inside the half)
-template <int T, int N> struct RankSwz {
-    static __device__ __forceinline__ void run(int key, int mmax, int& rank)
-    {
-        if ((T & 3) == 0 && T >= mmax) return;             // (sub-lanes past the cluster hold the largest key: harmless, so the test runs every 4th step)
-        rank += __builtin_amdgcn_ds_swizzle(key, (N == 16 ? 0x10 : 0) | (T << 5)) < key;
-        RankSwz<T + 1, N>::run(key, mmax, rank);
+// Sorting network inside sub-waves of SW = 16 / 32 lanes (every sub-wave of the wavefront at once, all ascending): the
+// bitonic network's 10 / 15 compare-exchanges on one-word keys, three vector instructions each.  Which side keeps the
+// smaller key is a compile-time lane mask (inverse_ballot hands it to the select as an SGPR pair).  Partners 1, 2 and 8 lanes
+// away sit in the same DPP row: v_min_u32_dpp, v_max_u32_dpp, v_cndmask.  Partners 4 and 16 lanes away come through a
+// ds_swizzle with an xor mask: swizzle, compare, select, and "keep mine" = the compare's mask XNOR the constant (scalar).
+// (r03 ranked by counting: a ds_swizzle broadcast, a compare and an add for each of the up to 32 sub-lanes = 96 vector
+// instructions per pair of clusters; this is 45.)
+constexpr u64 cx_keepmin_mask(int SW, int KK, int J)
+{
+    u64 m = 0;
+    for (int l = 0; l < 64; l++) { const bool lower = (l & J) == 0, asc = ((l & (SW - 1)) & KK) == 0; if (lower == asc) m |= 1ull << l; }
+    return m;
+}
+template <int SW, int KK, int J> __device__ __forceinline__ unsigned cx_step(unsigned k)
+{
+    constexpr u64 KEEPMIN = cx_keepmin_mask(SW, KK, J);
+    if constexpr (J == 1 || J == 2 || J == 8) {
+        // partner inside the DPP row: hipcc folds the move into v_min_u32_dpp / v_max_u32_dpp, the select takes the constant mask
+        constexpr int CTRL = J == 1 ? 0xB1 : (J == 2 ? 0x4E : 0x128);                                      // quad_perm [1,0,3,2] / [2,3,0,1] / row_ror:8
+        const unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)k, (int)k, CTRL, 0xf, 0xf, true);
+        const unsigned mn = k < o ? k : o, mx = k < o ? o : k;
+        return __builtin_amdgcn_inverse_ballot_w64(KEEPMIN) ? mn : mx;
+    } else {
+        const unsigned o = (unsigned)__builtin_amdgcn_ds_swizzle((int)k, 0x1f | (J << 10));               // bit mode: lane ^ J (J = 4, 16)
+        const u64 lt = __ballot(k < o);
+        return __builtin_amdgcn_inverse_ballot_w64(~(lt ^ KEEPMIN)) ? k : o;                                // (keys are distinct)
     }
-};
-template <int N> struct RankSwz<N, N> { static __device__ __forceinline__ void run(int, int, int&) {} };
+}
+template <int SW> __device__ __forceinline__ unsigned sort_sub(unsigned k)
+{
+    static_assert(SW == 16 || SW == 32, "sub-wave width");
+    k = cx_step<SW, 2, 1>(k);
+    k = cx_step<SW, 4, 2>(k); k = cx_step<SW, 4, 1>(k);
+    k = cx_step<SW, 8, 4>(k); k = cx_step<SW, 8, 2>(k); k = cx_step<SW, 8, 1>(k);
+    k = cx_step<SW, 16, 8>(k); k = cx_step<SW, 16, 4>(k); k = cx_step<SW, 16, 2>(k); k = cx_step<SW, 16, 1>(k);
+    if (SW == 32) { k = cx_step<SW, 32, 16>(k); k = cx_step<SW, 32, 8>(k); k = cx_step<SW, 32, 4>(k); k = cx_step<SW, 32, 2>(k); k = cx_step<SW, 32, 1>(k); }
+    return k;
+}
 
 // What a unit reads from memory, in two rounds: the list entries of its clusters (one per sub-wave), then - addresses
 // known from the entry alone - the rows and the segment scalars together.  (The first version walked list -> item
@@ -1936,13 +1962,17 @@ template <int SW, bool NARROW> __device__ __forceinline__ void indel_unit(const 
             // straight-line: a bit that no id has set costs one ballot and changes nothing.
             const bool wide_ids = ((unsigned)__builtin_amdgcn_readlane(orv, 63) >> 12) != 0;
             const int hid = wide_ids ? ((rid ^ (rid >> 12) ^ (rid >> 24)) & 0xfff) : rid;
-            u64 match = inmask;
+            // lanes whose (folded) id differs from mine in some bit: per bit one sign-extending field extract (all ones when
+            // my bit is set), one ballot, and acc |= ballot ^ mine for each half - v_bitop3 - : 4 instructions
+            // (r03 selected between the ballot and its complement: 7.5)
+            u64 differ = 0;
 #pragma unroll
             for (int bit = 0; bit < 12; bit++) {
-                const bool set = (hid >> bit) & 1;
-                const u64 mk = __ballot(set);
-                match &= set ? mk : ~mk;
+                const int ones = (int)((unsigned)hid << (31 - bit)) >> 31;
+                const u64 mk = __ballot(ones != 0);
+                differ |= mk ^ (u64)(i64)ones;
             }
+            const u64 match = inmask & ~differ;
             const u64 mine = SUBMASK << hb;
             dup_any = in && __popcll(match & mine) > 1;
             if (CSV_ABL(0)) dup_any = false;
@@ -1976,16 +2006,14 @@ template <int SW, bool NARROW> __device__ __forceinline__ void indel_unit(const 
         // ---- stable sort of the kept signatures by length (INDEL:136): rank by (len, first appearance)
         int rank = 0, src_lane = -1;
         if (CSV_ABL(1)) rank = sl;
-        else if (SW < 64) {
+        else if constexpr (SW < 64) {
             if (!__ballot(rep && (bl >> 26) != 0)) {
-                // every kept length fits 26 bits: (length, first appearance) packs into ONE word, so a step is a
-                // broadcast, a compare and an add.  Lanes that are not kept never count as smaller.
-                const int key = rep ? (((int)bl << 5) | sl) : 0x7fffffff;
-                // ds_swizzle (bit mode: lane' = (lane & and) | or, inside each half of 32) broadcasts sub-lane t of BOTH
-                // sub-waves in one LDS-crossbar instruction; the pattern is an immediate, hence the unrolled loop
-                RankSwz<0, SW>::run(key, mmax, rank);
+                // every kept length fits 26 bits: (length, first appearance) packs into ONE word; the kept ones by that key, the
+                // others behind them in lane order, through the sub-wave's sorting network; sorted position p then PULLS its row
+                // from the lane its key came from
+                const unsigned ks = sort_sub<SW>(rep ? (((unsigned)bl << 5) | (unsigned)sl) : (0x80000000u | (unsigned)sl));
+                src_lane = hb | (int)(ks & (SW - 1));
             } else {
-                const u64 sl_lt0 = (1ull << sl) - 1ull; (void)sl_lt0;
                 for (int t = 0; t < mmax; t++) {
                     const C lt = sub_rlc<SW>(bl, t, g);
                     rank += ((rm >> t) & 1) && ((lt < bl) || (lt == bl && t < sl));
@@ -2007,7 +2035,7 @@ template <int SW, bool NARROW> __device__ __forceinline__ void indel_unit(const 
             }
         }
         C pos, len; int chp, axp, ridp;
-        if (SW == 64 && src_lane >= 0) {                                     // (wave-uniform: all lanes or none)
+        if (src_lane >= 0) {                                                 // (wave-uniform: all lanes or none)
             const int s4 = src_lane << 2;
             pos = bperm(s4, pa); len = bperm(s4, bl);
             chp = bperm(s4, ch); axp = bperm(s4, pax); ridp = bperm(s4, rid);
