@@ -4,18 +4,25 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg2|cfg4|cfg5|rebuild|extract] [--scale S] [--mode replica|shard]
 
 A "step" is one pass of the whole hot path (chain -> refine -> order [-> reads order -> genotype]) over one synthetic
-signature batch that is already resident in HBM when the timed region starts.  At N = 1 the workload is BASELINE
-config 3 (synthetic HG002-shaped ONT 30x, ~2.8 M INS+DEL signatures, ONT preset): the metric is quoted "on 30x WGS",
-and this is the 30x whole-genome configuration that names one MI355X.  The reads table of the genotyping workloads
-(cfg4 / cfg5) is fed in the order cuteSV's extraction leaves it (synth.extraction_order), so the device-side reads
-ordering is inside every step.
+signature batch that is already resident in HBM when the timed region starts, AND the delivery of its result - the calls'
+structure-of-arrays and the support lists - into the caller's host memory: the region of SURVEY.md 8(d) ("flat arrays ->
+rows SoA in host RAM") with the inputs resident as the bench contract asks.  `value` = signatures / that step.  The same
+line carries the two neighbouring regions: `kernel_only` (the launch sequence alone, results left in HBM: what r01-r03
+reported as value) and `boundary.one_shot_call_ms` (page-locked host columns -> host SoA, PCIe both ways).
+At N = 1 the workload is BASELINE config 3 (synthetic HG002-shaped ONT 30x, ~2.8 M INS+DEL signatures, ONT preset): the
+metric is quoted "on 30x WGS", and this is the 30x whole-genome configuration that names one MI355X; the other configs
+(cfg2, cfg4, cfg5) are measured in the same run in compact form (`other_workloads`).  The reads table of the genotyping
+workloads (cfg4 / cfg5) is fed in the order cuteSV's extraction leaves it (synth.extraction_order), so the device-side
+reads ordering is inside every step.
 
 N > 1: one process per GPU.  Launched by torch.distributed.run the ranks come from the environment; plain
 `python bench.py --gpus N` spawns the N ranks itself (127.0.0.1 rendezvous).  The path shards with no data-path
 collective; the only communication is the timing barrier / max-reduce (gloo, CPU tensors).
-  --mode replica (default)  every rank clusters its own genome of the workload's shape (seed + rank): "weak" scaling.
+  --mode replica (default for cfg3)  every rank clusters its own genome of the workload's shape (seed + rank): "weak"
+                            scaling; the line ALSO carries a `sharded` object: BASELINE config 4 (one HiFi genome with
+                            --genotype) split over the N ranks, measured right after the replica loop.
   --mode shard              ONE genome (BASELINE configs 4 and 5: "chromosomes sharded over 8 MI355X"): the ranks split
-                            its chromosomes with shard.tasks_of_rank; a step is the rank's whole csv_cluster_batch call
+                            its chromosomes with shard.plan; a step is the rank's whole csv_cluster_batch call
                             (H2D + kernels + D2H); rank 0 then merges the ranks' rows and checks them against the
                             unsharded run: "strong" scaling.
 
@@ -267,6 +274,319 @@ def digest_rows(rows_by_chr):
     return {c: hashlib.sha256("\n".join("\t".join(r) for r in rows).encode()).hexdigest() for c, rows in rows_by_chr.items()}
 
 
+def vcf_leg(ctx, pstore, params, tasks):
+    """native VCF record emit straight from the SoA (no Python rows).  ignore_sequence: REF/ALT are 'N' / '<TYPE>' as with
+    cuteSV's --ignore_sequence; pair types (which always look up one base) are left out of this timing"""
+    from cutesv_amd import vcf as vcf_mod
+    try:
+        keep = [i for i, (t, c) in enumerate(tasks) if t in ("DEL", "INS")]
+        hb2 = pstore.host_batch([tasks[i] for i in keep], params)
+        r3 = ctx.cluster_batch(hb2)
+        tv = []
+        text = b""
+        for _ in range(5):
+            t0 = time.perf_counter()
+            text, _ = vcf_mod.emit_records(pstore, hb2.segments, r3, None, min_size=params.min_size, max_size=params.max_size,
+                                           genotype=params.genotype, ignore_sequence=True, as_bytes=True)
+            tv.append(time.perf_counter() - t0)
+        # pinned columns -> VCF text: the boundary call + the native emitter, no Python rows in between
+        ts = timed(lambda: vcf_mod.emit_records(pstore, hb2.segments, ctx.cluster_batch(hb2, reuse=True), None, min_size=params.min_size,
+                                                 max_size=params.max_size, genotype=params.genotype, ignore_sequence=True, as_bytes=True), 5)
+        return dict(ms=float(np.median(tv)) * 1e3, records=text.count(b"\n"), bytes=len(text), threads=min(16, os.cpu_count() or 1),
+                    stage_wall_vcf_ms=float(np.median(ts)) * 1e3, ignore_sequence=True)
+    except Exception as e:          # noqa: BLE001  (never let the optional leg break the benchmark line)
+        return dict(error=str(e))
+
+
+def per_task_leg(ctx, store, params, tasks):
+    """INTEGRATION.md mode 1: the reference's own task interface, one (chromosome, type) task per call from ITS files
+    (<TYPE>.pickle at sigs_index offsets): unpickle + columnar conversion + the boundary call + rows, for the largest task"""
+    try:
+        import pickle
+        import tempfile
+        ins_tasks = [(t, c) for (t, c) in tasks if t == "INS"] or tasks
+        tt, tc = max(ins_tasks, key=lambda k: store.seg_index[k][1] - store.seg_index[k][0])
+        b0, e0 = store.seg_index[(tt, tc)]
+        nm = store.names.take(store.read_id[b0:e0])
+        if tt == "INS":
+            lst = [(int(store.a[i]), int(store.b[i]), nm[i - b0], store.sequence(i), "INS", tc) for i in range(b0, e0)]
+        else:
+            lst = [(int(store.a[i]), int(store.b[i]), nm[i - b0], tt, tc) for i in range(b0, e0)]
+        with tempfile.TemporaryDirectory() as wd:
+            wd += "/"
+            with open(wd + tt + ".pickle", "wb") as f:
+                pickle.dump(lst, f)
+            idx = {t_: {} for t_ in ("DEL", "INS", "INV", "DUP", "TRA")}
+            idx[tt][tc] = 0
+            bias = params.max_cluster_bias_INS if tt == "INS" else params.max_cluster_bias_DEL
+            ratio = params.diff_ratio_merging_INS if tt == "INS" else params.diff_ratio_merging_DEL
+            args = (wd, tc, tt, params.min_support, ratio, bias, min(params.min_support, 5), "bam", False, params.gt_round, params.remain_reads_ratio, idx)
+            fn = resolve.run_ins if tt == "INS" else resolve.run_del
+            resolve._ctx = ctx
+            ts_ = timed(lambda: fn(args), 4)
+            t0 = time.perf_counter()
+            with open(wd + tt + ".pickle", "rb") as f:
+                pickle.load(f)
+            t_unpickle = time.perf_counter() - t0
+        return dict(task="%s chr%s" % (tt, tc), signatures=e0 - b0, ms=float(np.median(ts_)) * 1e3, unpickle_ms=t_unpickle * 1e3,
+                    signatures_per_s=(e0 - b0) / float(np.median(ts_)),
+                    note="resolve.run_ins(args) with the reference's argument tuple on its pickle layout: pickle.load + columnar conversion + csv_cluster_batch + rows")
+    except Exception as e:           # noqa: BLE001  (optional leg)
+        return dict(error=repr(e))
+
+
+PARITY_FIELDS = ("call_seg", "call_cluster", "bp1", "bp2", "support", "cipos", "cilen", "search_pos", "seq_pick", "dr", "dv", "gl_idx",
+                 "support_off", "support_sig", "cluster_id", "allele_id")
+GT_PARTS = ("k_reads_order", "k_reads_gather", "k_reads_maxlen", "k_genotype")        # stage slots (HIP events)
+GT_KERNELS = ("k_reads_runs", "k_reads_plan", "k_reads_gather", "k_reads_maxlen", "k_genotype")   # kernel names (PMC)
+
+
+def timed(fn, reps):
+    """wall time of fn() to the moment its result exists (the result is released after the clock stops: tearing down
+    the previous call's 350 k row strings is the consumer's time, not the producer's)"""
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        out = fn()
+        ts.append(time.perf_counter() - t0)
+        del out
+    return ts
+
+
+def per_kernel_us(v, names):
+    """A stage slot is the time between two hipEventRecord calls on the library's stream; the records themselves occupy the
+    stream (a slot that launches nothing still reads 4-5 us).  The library records one slot that is empty BY CONSTRUCTION
+    ("event_floor", after the last kernel); that reading is subtracted, so that kernel_us is the kernel's own duration (it
+    then agrees with rocprofv3's begin-to-end average: profiles/).  Raw slots are kept in `_raw`."""
+    raw = {names[i]: float(v[i]) * 1e3 for i in range(_abi.N_STAGES) if names[i]}
+    gap = raw.pop("event_floor", 0.0)
+    if gap <= 0.5:                                           # (a library without the explicit slot)
+        gap = min([x for x in raw.values() if x > 0.5] or [0.0])
+    d = {k: round(max(0.0, x - gap), 2) if x > 0.5 else 0.0 for k, x in raw.items()}
+    d["genotype_stage"] = round(sum(d.get(k, 0.0) for k in GT_PARTS), 2)
+    d["_event_floor"] = round(gap, 2)
+    d["_raw"] = {k: round(x, 2) for k, x in raw.items() if x > 0.5}
+    return d
+
+
+def cpu_legs(name, store, params, tasks, hb, n_sig, procs, py_pool, full_pool):
+    """CPU baselines of one workload (rank 0, N = 1; before any HIP state exists in the process: the pool forks).
+    py_pool: oracle/py_restatement.py under a fork Pool (the reference's execution model); full_pool: on every task of the
+    workload (else the segments of every 3rd chromosome when the workload has > 4 M signatures)."""
+    from oracle import oracle, py_restatement as pr
+    cpu = None
+    if py_pool:
+        sample = tasks if (full_pool or n_sig <= 4_000_000) else [t for i, t in enumerate(tasks) if (i % 24) % 3 == 0]
+        tl = pr.tasks_from_store(store, params, sample)
+        ns = sum(len(t[2]) for t in tl)
+        t0 = time.perf_counter()
+        r = pr.run_pool_forked(tl, procs)
+        dt = time.perf_counter() - t0
+        cpu = dict(value=ns / dt, unit="signatures/s", cores=procs, kind="port", wall_s=dt, full_workload=len(sample) == len(tasks),
+                   sample="%d of %d (chr,type) tasks, %d signatures, %.2f s wall; oracle/py_restatement.py in a fork "
+                          "Pool(%d): the reference's pool model (Python per-signature loop, numpy scalar calls)"
+                          % (len(sample), len(tasks), ns, dt, procs),
+                   rows=sum(len(x[1]) for x in r))
+        del tl, r
+    t0 = time.perf_counter()
+    ores = oracle.cluster_batch(hb, per_sig=True)
+    dtc = time.perf_counter() - t0
+    cpu_c = dict(value=n_sig / dtc, unit="signatures/s", cores=1, kind="port",
+                 sample="full workload, oracle/cutesv_oracle.c single thread, %.3f s" % dtc)
+    # the same C restatement over the (chr, type) tasks on all host cores, one task per call like the reference's pool:
+    # the parallelism a task pool can reach is bounded by the task count and by the largest task (chr1 INS)
+    nthr = min(len(tasks), procs)
+    dtm, mt_calls = min((oracle.cluster_tasks_mt(store, tasks, params, nthr) for _ in range(3)), key=lambda x: x[0])
+    cpu_c_mt = dict(value=n_sig / dtm, unit="signatures/s", cores=nthr, kind="port", wall_s=dtm, calls=mt_calls,
+                    sample="full workload, oracle/cutesv_oracle.c, one (chr,type) task per call on %d threads (host has %d cores; "
+                           "%d tasks), largest first, best of 3: %.4f s" % (nthr, os.cpu_count() or 1, len(tasks), dtm))
+    return cpu, cpu_c, cpu_c_mt, ores
+
+
+def resident_loops(ctx, phb, steps, warmup, dist=None):
+    """The two resident timed loops of an uploaded batch.  Returns (seconds of `steps` steps WITH the result delivered to
+    page-locked host arrays each step, seconds of the launch sequences alone, the last delivered result)."""
+    ctx.upload(phb, per_sig=False)
+    # every step does the whole stage, the ordering / packing of the reads table included (the library would keep the
+    # ordered table of an upload across runs: CSV_OPT_REUSE_READS_ORDER, measured separately)
+    ctx.option(1, 0)
+    ctx.run(); ctx.sync()
+    probe = ctx.download()
+    res = ctx.result_buffers(cap_calls=probe.n_calls + 64, cap_support=probe.n_support + 64)
+    for _ in range(warmup):
+        ctx.run(); ctx.download(into=res)
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ctx.run()
+        ctx.download(into=res)                               # k_publish into the page-locked arrays + ONE stream synchronisation
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    for _ in range(warmup):
+        ctx.run()
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ctx.run()
+    ctx.sync()
+    dt_k = time.perf_counter() - t0
+    return dt, dt_k, res
+
+
+def instrumented(ctx, phb, steps):
+    """per-kernel HIP-event durations on the library's stream (per_sig on: kernel_units needs cluster_id); returns
+    (mean stage ms with the per-signature outputs, the same without them, the run's stats, the downloaded result)"""
+    names = engine.stage_names()
+    ctx.upload(phb, per_sig=True)
+    acc = np.zeros(_abi.N_STAGES)
+    st = None
+    for _ in range(steps):
+        st = ctx.run(stats=True)
+        acc += np.array(list(st.ms_stage))
+    acc /= steps
+    res = ctx.download(per_sig=True)
+    ctx.upload(phb, per_sig=False)
+    plain = np.zeros(_abi.N_STAGES)
+    tot = 0.0
+    n2 = max(3, min(steps, 10))
+    for _ in range(n2):
+        s2 = ctx.run(stats=True)
+        plain += np.array(list(s2.ms_stage))
+        tot += s2.ms_total
+    plain /= n2
+    return per_kernel_us(acc, names), per_kernel_us(plain, names), st, res, tot / n2 * 1e3
+
+
+def dominant(per_kernel_nps, kbytes):
+    """the longest kernel of the plain pass; kernels within 5 % of the longest count as tied and the one that moves the most
+    algorithmic bytes is named (so that the choice does not flip between runs on a 0.1 us difference)"""
+    cand = [n for n in per_kernel_nps if n in kbytes and kbytes[n] > 0 and per_kernel_nps[n] > 0 and n not in ("k_chain_apply", "k_items_scan")]
+    longest = max(per_kernel_nps[n] for n in cand)
+    return max((n for n in cand if per_kernel_nps[n] >= 0.95 * longest), key=lambda n: kbytes[n])
+
+
+def traffic_of(workload, scale):
+    """L2 <-> fabric bytes per launch from the rocprofv3 PMC passes of the SAME command committed under profiles/
+    (scripts/refresh_profiles.sh; counters calibrated in profiles/r04_pmc_calibration.txt)"""
+    tf = os.path.join(ROOT, "profiles", "traffic_%s.json" % workload)
+    if not os.path.exists(tf) or scale != 1.0:
+        return None
+    with open(tf) as f:
+        return {k: v for k, v in json.load(f).items() if k.startswith("k_") and "." not in k and "[" not in k}
+
+
+def compact_workload(ctx, name, a, cpu):
+    """cfg2 / cfg4 / cfg5 in the N = 1 line, compact: the same two resident loops, the dominant kernel and its roofline
+    fraction, parity of the int32-column device path against the C oracle at full size, the boundary call, the C all-threads
+    baseline (and, where it was run, the Python pool on the FULL workload)."""
+    store, params, wl_name, tasks, hb, n_sig = cpu["store"], cpu["params"], cpu["wl_name"], cpu["tasks"], cpu["hb"], cpu["n_sig"]
+    pstore = store.pinned()
+    phb = pstore.host_batch(tasks, params)
+    steps = max(5, min(a.steps, 20))
+    dt, dt_k, _ = resident_loops(ctx, phb, steps, 3)
+    pk_sig, pk, st, res, _ = instrumented(ctx, phb, 5)
+    kbytes, total_bytes, units = kernel_units(store, hb, res, st, per_sig_step=False)
+    if units["reads"]:
+        pk["genotype_stage"] = round(sum(pk.get(k, 0.0) for k in GT_PARTS), 2)
+    dom = dominant(pk, kbytes)
+    w, g = cpu["ores"].trimmed(), res.trimmed()
+    parity = all(np.array_equal(g[k], w[k]) for k in PARITY_FIELDS)
+    t_one = timed(lambda: ctx.cluster_batch(phb, reuse=True), 4)
+    tr = traffic_of(name, 1.0)
+    dom_traffic = None if tr is None else (sum(tr.get(k, 0) for k in GT_KERNELS) if dom == "genotype_stage" else tr.get(dom))
+    ms, ms_k, one = dt / steps * 1e3, dt_k / steps * 1e3, float(np.min(t_one)) * 1e3
+    out = {"workload": wl_name, "signatures": n_sig, "reads": units["reads"], "calls": units["calls"],
+           "ms_per_step": ms, "value": n_sig / (ms * 1e-3), "kernel_only_ms_per_step": ms_k, "kernel_only_value": n_sig / (ms_k * 1e-3),
+           "one_shot_call_ms": one,
+           "dominant_kernel": {"kernel": dom, "us": pk[dom], "algorithmic_bytes": kbytes[dom],
+                               "frac": round(kbytes[dom] / (pk[dom] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "traffic": dom_traffic},
+           "pipeline": {"algorithmic_bytes": total_bytes, "frac": round(total_bytes / (ms_k * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+           "kernel_us": {k: v for k, v in pk.items() if isinstance(v, float) and v > 0.3 and not k.startswith("_")},
+           "parity_vs_oracle": bool(parity), "parity_columns": "int32 (SigStore.pinned())",
+           "cpu_baseline_c_mt": {k: cpu["cpu_c_mt"][k] for k in ("value", "cores", "wall_s")},
+           "one_shot_speedup_vs_c_mt": cpu["cpu_c_mt"]["wall_s"] * 1e3 / one}
+    if cpu["cpu"] is not None:
+        out["cpu_baseline"] = {k: cpu["cpu"][k] for k in ("value", "cores", "wall_s", "full_workload", "sample")}
+        out["step_speedup_vs_cpu_baseline"] = cpu["cpu"]["wall_s"] * 1e3 / ms if cpu["cpu"]["full_workload"] else None
+        out["one_shot_speedup_vs_cpu_baseline"] = cpu["cpu"]["wall_s"] * 1e3 / one if cpu["cpu"]["full_workload"] else None
+    return out
+
+
+def measure_sharded(ctx, dist, rank, world, workload, scale, steps, warmup):
+    """ONE genome over `world` ranks (BASELINE configs 4 / 5): every rank computes the same plan without communicating, a step
+    is the rank's whole boundary call (H2D + kernels + D2H); rank 0 merges the ranks' rows exactly as main_ctrl concatenates
+    task results and compares them with the unsharded run.  Returns (dict on rank 0 / None, seconds, signatures of the genome)."""
+    from cutesv_amd.columns import SigStore
+    shared = "/dev/shm/cutesv_amd_bench_%s_%s" % (os.environ.get("MASTER_PORT", "0"), workload)
+    if world > 1:
+        if rank == 0:
+            store, params, wl_name = make_workload(workload, scale, 0)
+            store.save(shared)
+        dist.barrier()
+        if rank != 0:
+            _, params, wl_name = make_workload(workload, 0.001, 0)
+            store = SigStore.load(shared)
+        dist.barrier()
+        if rank == 0:
+            import shutil
+            shutil.rmtree(shared, ignore_errors=True)          # (the mappings stay valid)
+    else:
+        store, params, wl_name = make_workload(workload, scale, 0)
+    all_tasks = store.tasks()
+    plan = shard.plan(store, world, params, genotype=params.genotype)
+    units = plan[rank]
+    pstore = store.pinned()
+    phb, unit_keys = shard.host_batch(pstore, params, units, pin=engine.pinned_copy)
+    n_sig = int((phb.segments["sig_end"] - phb.segments["sig_begin"]).sum())
+    for _ in range(warmup):
+        ctx.cluster_batch(phb, reuse=True)
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ctx.cluster_batch(phb, reuse=True)
+    t_rank = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    loads = [n_sig]
+    total_sig = n_sig
+    if dist is not None:
+        import torch
+        tt = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt[0])
+        gl = [None] * world
+        dist.all_gather_object(gl, (n_sig, t_rank / steps * 1e3, 0 if phb.r_start is None else int(phb.r_start.shape[0])))
+        loads = gl
+        total_sig = sum(x[0] for x in gl)
+    per_seg = rows_mod.rows_by_segment(pstore, phb.segments, ctx.cluster_batch(phb))
+    mine = {k: per_seg[i] for i, k in enumerate(unit_keys)}
+    gathered = [mine]
+    if dist is not None:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+    out = None
+    if rank == 0:
+        merged = digest_rows(shard.merge_rows(gathered))
+        full = digest_rows(resolve.cluster_stage(pstore, params, tasks=all_tasks, ctx=ctx))
+        ok = merged == full
+        assert ok, "sharded rows differ from the unsharded run"
+        ms = dt / steps * 1e3
+        out = {"workload": wl_name, "mode": "one genome split over the ranks: chromosomes longest-first, the largest cut at gaps wider than "
+                                            "max_cluster_bias until the heaviest rank is within 3 % of the mean; no collective; a step is the rank's "
+                                            "whole boundary call (H2D + kernels + D2H)",
+               "ranks": world, "signatures_total": total_sig, "ms_per_step": ms, "value": total_sig / (ms * 1e-3), "scaling": "strong",
+               "shard_merge_equals_unsharded": bool(ok), "pieces": sum(len(u) for u in plan),
+               "per_rank": [{"signatures": x[0], "ms_per_step": round(x[1], 4), "reads": x[2]} for x in loads] if dist is not None else None,
+               "signature_load_max_over_mean": (max(x[0] for x in loads) / (total_sig / world)) if dist is not None else 1.0}
+    tasks = list(dict.fromkeys((t, c) for (t, c, _) in unit_keys))
+    hb_plain, _ = shard.host_batch(store, params, units)          # (the same pieces from the pageable store: the one-shot-pageable leg, kernel_units)
+    return out, dt, total_sig, store, params, wl_name, pstore, phb, tasks, hb_plain
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -276,6 +596,7 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--mode", default="auto", choices=["auto", "replica", "shard"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-others", action="store_true", help="skip the compact cfg2 / cfg4 / cfg5 objects of the default N = 1 line")
     ap.add_argument("--cpu-procs", type=int, default=0)
     a = ap.parse_args()
 
@@ -310,125 +631,66 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)     # timing barrier only: no data-path collective
-    if shard_mode and world > 1:
-        # one genome for all ranks: rank 0 generates it, the others map the flat column files
-        from cutesv_amd.columns import SigStore
-        shared = "/dev/shm/cutesv_amd_bench_%s_%s" % (os.environ.get("MASTER_PORT", "0"), a.workload)
-        if rank == 0:
-            store, params, wl_name = make_workload(a.workload, a.scale, 0)
-            store.save(shared)
-        dist.barrier()
-        if rank != 0:
-            _, params, wl_name = make_workload(a.workload, 0.001, 0)
-            store = SigStore.load(shared)
-        dist.barrier()
-        if rank == 0:
-            import shutil
-            shutil.rmtree(shared, ignore_errors=True)          # (the mappings stay valid)
-    else:
-        store, params, wl_name = make_workload(a.workload, a.scale, 0 if shard_mode else rank)
-    all_tasks = store.tasks()
-    tasks = all_tasks
-    units = shard.plan(store, world, params, genotype=params.genotype)[rank] if shard_mode else None
-    if shard_mode:
-        hb, unit_keys = shard.host_batch(store, params, units)
-    else:
-        hb = store.host_batch(tasks, params)
-    n_sig = int((hb.segments["sig_end"] - hb.segments["sig_begin"]).sum())
 
-    # ---------------- CPU baseline first (fork pool before any HIP state exists in this process)
-    cpu = None
-    cpu_c = None
-    cpu_c_mt = None
-    ores = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        from oracle import oracle, py_restatement as pr
+    sharded_obj = None
+    if shard_mode:
+        if ctx is None:
+            ctx = engine.Context(local_rank % max(1, engine.device_count()))
+        sharded_obj, dt, total_sig, store, params, wl_name, pstore, phb, tasks, hb = measure_sharded(ctx, dist, rank, world, a.workload, a.scale, a.steps, a.warmup)
+        n_sig = int((phb.segments["sig_end"] - phb.segments["sig_begin"]).sum())
+        dt_k = None
+        t_upload = t_pin = None
+    else:
+        store, params, wl_name = make_workload(a.workload, a.scale, rank)
+        tasks = store.tasks()
+        hb = store.host_batch(tasks, params)
+        n_sig = int((hb.segments["sig_end"] - hb.segments["sig_begin"]).sum())
+
+    # ---------------- CPU baselines first (fork pools before any HIP state exists in this process)
+    cpu = cpu_c = cpu_c_mt = ores = None
+    others = {}
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and not shard_mode:
         procs = a.cpu_procs or os.cpu_count() or 1
-        # bounded sample: all tasks of the workload when it has <= 4 M signatures (a few seconds of pool time),
-        # else the segments of every 3rd chromosome (same flags)
-        sample = tasks if n_sig <= 4_000_000 else [t for i, t in enumerate(tasks) if (i % 24) % 3 == 0]
-        tl = pr.tasks_from_store(store, params, sample)
-        ns = sum(len(t[2]) for t in tl)
-        t0 = time.perf_counter()
-        r = pr.run_pool_forked(tl, procs)
-        dt = time.perf_counter() - t0
-        cpu = dict(value=ns / dt, unit="signatures/s", cores=procs, kind="port", wall_s=dt, full_workload=len(sample) == len(tasks),
-                   sample="%d of %d (chr,type) tasks, %d signatures, %.2f s wall; oracle/py_restatement.py in a fork "
-                          "Pool(%d): the reference's pool model (Python per-signature loop, numpy scalar calls)"
-                          % (len(sample), len(tasks), ns, dt, procs),
-                   rows=sum(len(x[1]) for x in r))
-        del tl, r
-        t0 = time.perf_counter()
-        ores = oracle.cluster_batch(hb, per_sig=True)
-        dtc = time.perf_counter() - t0
-        cpu_c = dict(value=n_sig / dtc, unit="signatures/s", cores=1, kind="port",
-                     sample="full workload, oracle/cutesv_oracle.c single thread, %.3f s" % dtc)
-        # the same C restatement over the (chr, type) tasks on all host cores, one task per call like the reference's pool:
-        # the parallelism a task pool can reach is bounded by the task count and by the largest task (chr1 INS)
-        nthr = min(len(tasks), procs)
-        dtm, mt_calls = min((oracle.cluster_tasks_mt(store, tasks, params, nthr) for _ in range(3)), key=lambda x: x[0])
-        cpu_c_mt = dict(value=n_sig / dtm, unit="signatures/s", cores=nthr, kind="port", wall_s=dtm, calls=mt_calls,
-                        sample="full workload, oracle/cutesv_oracle.c, one (chr,type) task per call on %d threads (host has %d cores; "
-                               "%d tasks), largest first, best of 3: %.4f s" % (nthr, os.cpu_count() or 1, len(tasks), dtm))
+        cpu, cpu_c, cpu_c_mt, ores = cpu_legs(a.workload, store, params, tasks, hb, n_sig, procs, py_pool=True, full_pool=False)
         cal = os.path.join(ROOT, "profiles", "calibration_py_restatement.json")
         if os.path.exists(cal):
             with open(cal) as f:
                 cpu["calibration_vs_reference"] = json.load(f)
+        if a.workload == "cfg3" and a.scale == 1.0 and not a.no_others:
+            for name in ("cfg2", "cfg4", "cfg5"):
+                try:
+                    st_o, p_o, wl_o = make_workload(name, 1.0, 0)
+                    tk_o = st_o.tasks()
+                    hb_o = st_o.host_batch(tk_o, p_o)
+                    ns_o = int((hb_o.segments["sig_end"] - hb_o.segments["sig_begin"]).sum())
+                    # the Python pool (the reference's execution model) on the FULL 90x workload; cfg2 / cfg4: the C legs only
+                    c0, c1, c2, o_o = cpu_legs(name, st_o, p_o, tk_o, hb_o, ns_o, procs, py_pool=(name == "cfg5"), full_pool=True)
+                    others[name] = dict(store=st_o, params=p_o, wl_name=wl_o, tasks=tk_o, hb=hb_o, n_sig=ns_o, cpu=c0, cpu_c=c1, cpu_c_mt=c2, ores=o_o)
+                except Exception as e:          # noqa: BLE001  (never let a compact leg break the benchmark line)
+                    others[name] = dict(error=repr(e))
 
     # ---------------- GPU
     if ctx is None:
         ctx = engine.Context(local_rank % max(1, engine.device_count()))
-    # the columns as a worker process holds them: in page-locked host memory
-    t0 = time.perf_counter()
-    pstore = store.pinned()
-    t_pin = time.perf_counter() - t0
-    if shard_mode:
-        phb, unit_keys = shard.host_batch(pstore, params, units, pin=engine.pinned_copy)
-    else:
-        phb = pstore.host_batch(tasks, params)
-
-    def timed(fn, reps):
-        """wall time of fn() to the moment its result exists (the result is released after the clock stops: tearing down
-        the previous call's 350 k row strings is the consumer's time, not the producer's)"""
-        ts = []
-        for _ in range(reps):
-            t0 = time.perf_counter()
-            out = fn()
-            ts.append(time.perf_counter() - t0)
-            del out
-        return ts
-
-    if shard_mode:
-        # one genome over `world` GPUs: a step is this rank's whole boundary call
-        for _ in range(a.warmup):
-            ctx.cluster_batch(phb)
-        if dist is not None:
-            dist.barrier()
+    if not shard_mode:
+        # the columns as a worker process holds them: in page-locked host memory
         t0 = time.perf_counter()
-        for _ in range(a.steps):
-            sres = ctx.cluster_batch(phb)
-        if dist is not None:
-            dist.barrier()
-        dt = time.perf_counter() - t0
-    else:
+        pstore = store.pinned()
+        t_pin = time.perf_counter() - t0
+        phb = pstore.host_batch(tasks, params)
         t0 = time.perf_counter()
         ctx.upload(phb, per_sig=False)
         t_upload = time.perf_counter() - t0
-        # every step does the whole stage, the ordering / packing of the reads table included (the library would keep the
-        # ordered table of an upload across runs: CSV_OPT_REUSE_READS_ORDER, measured separately below)
-        ctx.option(1, 0)
-        for _ in range(a.warmup):
-            ctx.run()
-        ctx.sync()
+        dt, dt_k, _ = resident_loops(ctx, phb, a.steps, a.warmup, dist)
+        total_sig = n_sig
         if dist is not None:
-            dist.barrier()
-        t0 = time.perf_counter()
-        for _ in range(a.steps):
-            ctx.run()
-        ctx.sync()
-        if dist is not None:
-            dist.barrier()
-        dt = time.perf_counter() - t0
+            import torch
+            tt = torch.tensor([dt, dt_k], dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt, dt_k = float(tt[0]), float(tt[1])
+            ts = torch.tensor([n_sig], dtype=torch.float64)
+            dist.all_reduce(ts, op=dist.ReduceOp.SUM)
+            total_sig = int(ts[0])
     ms_reads_kept = None
     if not shard_mode and phb.r_start is not None:
         ctx.option(1, 1)
@@ -441,53 +703,24 @@ def main():
         ctx.sync()
         ms_reads_kept = (time.perf_counter() - t0) / a.steps * 1e3
         ctx.option(1, 0)
-    total_sig = n_sig
-    if dist is not None:
-        import torch
-        tt = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt[0])
-        ts = torch.tensor([n_sig], dtype=torch.float64)
-        dist.all_reduce(ts, op=dist.ReduceOp.SUM)
-        total_sig = int(ts[0])
     ms_per_step = dt / a.steps * 1e3
     value = total_sig * a.steps / dt
+    ms_kernel_only = None if dt_k is None else dt_k / a.steps * 1e3
 
-    shard_check = None
-    if shard_mode:
-        # merge the ranks' rows exactly as main_ctrl concatenates task results (pieces of a chromosome in coordinate order)
-        # and compare with the unsharded run
-        per_seg = rows_mod.rows_by_segment(pstore, phb.segments, ctx.cluster_batch(phb))
-        mine = {k: per_seg[i] for i, k in enumerate(unit_keys)}
-        gathered = [mine]
-        if dist is not None:
-            gathered = [None] * world
-            dist.all_gather_object(gathered, mine)
-        if rank == 0:
-            merged = digest_rows(shard.merge_rows(gathered))
-            full = digest_rows(resolve.cluster_stage(pstore, params, tasks=all_tasks, ctx=ctx))
-            shard_check = merged == full
-            assert shard_check, "sharded rows differ from the unsharded run"
-            # the shards rank 0 measured below are its own: the per-kernel pass describes one rank's share
-        tasks = list(dict.fromkeys((t, c) for (t, c, _) in unit_keys))
+    # world > 1, replica mode: the un-parameterised command also measures ONE genome sharded over the ranks (BASELINE config 4)
+    if world > 1 and not shard_mode and a.workload == "cfg3":
+        try:
+            sharded_obj = measure_sharded(ctx, dist, rank, world, "cfg4", a.scale, max(5, min(a.steps, 20)), 2)[0]
+        except Exception as e:          # noqa: BLE001
+            sharded_obj = {"error": repr(e)}
+            if dist is not None:
+                raise
 
     out = None
     if rank == 0:
-        # ---------------- instrumented pass: per-kernel HIP-event durations on the library's stream (per_sig on: the units
-        # below need cluster_id; the plain timed loop above ran without the optional per-signature stores)
-        ctx.upload(phb, per_sig=True)
-        acc = np.zeros(_abi.N_STAGES)
-        tot = 0.0
-        st = None
-        for _ in range(a.steps):
-            st = ctx.run(stats=True)
-            acc += np.array(list(st.ms_stage))
-            tot += st.ms_total
-        acc /= a.steps
         names = engine.stage_names()
-        res = ctx.download(per_sig=True)
+        per_kernel, per_kernel_nps, st, res, kernel_time_us = instrumented(ctx, phb, a.steps)
         # cold: caches evicted before every step (the flush is outside the event-timed region of csv_batch_run)
-        ctx.upload(phb, per_sig=False)
         cold_acc = np.zeros(_abi.N_STAGES)
         cold_tot = 0.0
         ncold = min(a.steps, 10)
@@ -496,12 +729,7 @@ def main():
             s2 = ctx.run(stats=True)
             cold_acc += np.array(list(s2.ms_stage))
             cold_tot += s2.ms_total
-        cold_acc /= ncold
-        warm_plain = np.zeros(_abi.N_STAGES)
-        for _ in range(ncold):
-            s2 = ctx.run(stats=True)
-            warm_plain += np.array(list(s2.ms_stage))
-        warm_plain /= ncold
+        per_kernel_cold = per_kernel_us(cold_acc / ncold, names)
 
         # ---------------- the boundary as a drop-in sees it
         t_one = timed(lambda: ctx.cluster_batch(phb, reuse=True), 7)          # (caller-owned result arrays, allocated once)
@@ -513,63 +741,8 @@ def main():
         # (bytes per signature / read as the ABI defines the columns; positions and lengths travel as int32 when the store
         # keeps narrow twins - CSV_IN_SIG_I32 / CSV_IN_READS_I32)
         h2d_bytes = (2 * phb.a.dtype.itemsize + 8) * n_sig + ((2 * phb.r_start.dtype.itemsize + 5) * int(phb.r_start.shape[0]) if phb.r_start is not None else 0)
-        # native VCF record emit straight from the SoA (no Python rows).  ignore_sequence: a 3.1 Gbp synthetic reference is
-        # not materialised for the benchmark, so REF/ALT are 'N' / '<TYPE>' as with cuteSV's --ignore_sequence; pair types
-        # (which always look up one base) are left out of this timing
-        t_vcf = None
-        from cutesv_amd import vcf as vcf_mod
-        try:
-            keep = [i for i, (t, c) in enumerate(tasks) if t in ("DEL", "INS")]
-            hb2 = pstore.host_batch([tasks[i] for i in keep], params)
-            r3 = ctx.cluster_batch(hb2)
-            tv = []
-            for _ in range(5):
-                t0 = time.perf_counter()
-                text, _ = vcf_mod.emit_records(pstore, hb2.segments, r3, None, min_size=params.min_size, max_size=params.max_size,
-                                               genotype=params.genotype, ignore_sequence=True, as_bytes=True)
-                tv.append(time.perf_counter() - t0)
-            # pinned columns -> VCF text: the boundary call + the native emitter, no Python rows in between
-            ts = timed(lambda: vcf_mod.emit_records(pstore, hb2.segments, ctx.cluster_batch(hb2, reuse=True), None, min_size=params.min_size,
-                                                     max_size=params.max_size, genotype=params.genotype, ignore_sequence=True, as_bytes=True), 5)
-            t_vcf = dict(ms=float(np.median(tv)) * 1e3, records=text.count(b"\n"), bytes=len(text), threads=min(16, os.cpu_count() or 1),
-                         stage_wall_vcf_ms=float(np.median(ts)) * 1e3)
-        except Exception as e:          # never let the optional leg break the benchmark line
-            t_vcf = dict(error=str(e))
-
-        # INTEGRATION.md mode 1: the reference's own task interface, one (chromosome, type) task per call from ITS files
-        # (<TYPE>.pickle at sigs_index offsets): unpickle + columnar conversion + the boundary call + rows, for the largest task
-        t_task = None
-        try:
-            import pickle, tempfile
-            ins_tasks = [(t, c) for (t, c) in tasks if t == "INS"] or tasks
-            tt, tc = max(ins_tasks, key=lambda k: store.seg_index[k][1] - store.seg_index[k][0])
-            b0, e0 = store.seg_index[(tt, tc)]
-            nm = store.names.take(store.read_id[b0:e0])
-            if tt == "INS":
-                lst = [(int(store.a[i]), int(store.b[i]), nm[i - b0], store.sequence(i), "INS", tc) for i in range(b0, e0)]
-            else:
-                lst = [(int(store.a[i]), int(store.b[i]), nm[i - b0], tt, tc) for i in range(b0, e0)]
-            with tempfile.TemporaryDirectory() as wd:
-                wd += "/"
-                with open(wd + tt + ".pickle", "wb") as f:
-                    pickle.dump(lst, f)
-                idx = {t_: {} for t_ in ("DEL", "INS", "INV", "DUP", "TRA")}
-                idx[tt][tc] = 0
-                bias = params.max_cluster_bias_INS if tt == "INS" else params.max_cluster_bias_DEL
-                ratio = params.diff_ratio_merging_INS if tt == "INS" else params.diff_ratio_merging_DEL
-                args = (wd, tc, tt, params.min_support, ratio, bias, min(params.min_support, 5), "bam", False, params.gt_round, params.remain_reads_ratio, idx)
-                fn = resolve.run_ins if tt == "INS" else resolve.run_del
-                resolve._ctx = ctx
-                ts_ = timed(lambda: fn(args), 4)
-                t0 = time.perf_counter()
-                with open(wd + tt + ".pickle", "rb") as f:
-                    pickle.load(f)
-                t_unpickle = time.perf_counter() - t0
-            t_task = dict(task="%s chr%s" % (tt, tc), signatures=e0 - b0, ms=float(np.median(ts_)) * 1e3, unpickle_ms=t_unpickle * 1e3,
-                          signatures_per_s=(e0 - b0) / float(np.median(ts_)),
-                          note="resolve.run_ins(args) with the reference's argument tuple on its pickle layout: pickle.load + SigStore.from_task_lists + csv_cluster_batch + rows")
-        except Exception as e:           # noqa: BLE001  (optional leg)
-            t_task = dict(error=repr(e))
+        t_vcf = vcf_leg(ctx, pstore, params, tasks)
+        t_task = per_task_leg(ctx, store, params, tasks)
 
         # measured device-to-device copy ceiling of this box (report the fraction of the vendor peak AND of
         # the copy ceiling): 512 MiB hipMemcpy device to device, read + write bytes over the best of 10 runs
@@ -584,97 +757,95 @@ def main():
             if not os.environ.get("CSV_BENCH_LENIENT"):
                 raise
             kbytes, total_bytes, units = {n: 1 for n in names if n}, 1, {}
-        gt_parts = ("k_reads_order", "k_reads_gather", "k_reads_maxlen", "k_genotype")        # stage slots (HIP events)
-        gt_kernels = ("k_reads_runs", "k_reads_plan", "k_reads_gather", "k_reads_maxlen", "k_genotype")   # kernel names (PMC)
-
-        # A stage slot is the time between two hipEventRecord calls on the library's stream; the records themselves occupy the
-        # stream (slots that launch nothing - a tier without work, the reads stage of a batch without reads - still read
-        # 4-5 us).  That floor, taken as the smallest slot of the pass, is subtracted, so that kernel_us is the kernel's own
-        # duration (it then agrees with rocprofv3's begin-to-end average: profiles/); the raw slots are kept in *_raw.
-        def per_kernel_us(v):
-            raw = {names[i]: float(v[i]) * 1e3 for i in range(_abi.N_STAGES) if names[i]}
-            gap = min([x for x in raw.values() if x > 0.5] or [0.0])        # (slots that were never recorded read 0)
-            d = {k: round(max(0.0, x - gap), 2) if x > 0.5 else 0.0 for k, x in raw.items()}
-            d["genotype_stage"] = round(sum(d.get(k, 0.0) for k in gt_parts), 2)
-            d["_event_gap"] = round(gap, 2)
-            return d
-        per_kernel, per_kernel_cold, per_kernel_nps = per_kernel_us(acc), per_kernel_us(cold_acc), per_kernel_us(warm_plain)
-        # dominant kernel = the longest of the plain pass; kernels within 5 % of the longest count as tied and the one that
-        # moves the most algorithmic bytes is named (so that the choice does not flip between runs on a 0.1 us difference)
-        cand = [n for n in per_kernel_nps if n in kbytes and kbytes[n] > 0 and per_kernel_nps[n] > 0 and n not in ("k_chain_apply", "k_items_scan")]
-        longest = max(per_kernel_nps[n] for n in cand)
-        dom = max((n for n in cand if per_kernel_nps[n] >= 0.95 * longest), key=lambda n: kbytes[n])
+        dom = dominant(per_kernel_nps, kbytes)
         # kernel_us (net) is the kernel's own time between two event records; what rocprofv3 --kernel-trace calls its duration -
         # and what the kernel costs the step - also holds one kernel boundary (dispatch to dispatch, ~1.6 us here).  When the
         # whole step is one chain on one stream (no side streams: no pair types, no reads stage) the boundary follows from the
-        # plain loop itself: (step - sum of the kernels) / kernels launched, and the roofline is priced on kernel + boundary, so
-        # that it agrees with the committed trace (profiles/*_kernel_trace.txt).
-        launched = [n for n in per_kernel_nps if n.startswith("k_") and per_kernel_nps[n] > 0.6]
+        # plain kernel-only loop itself: (step - sum of the kernels) / kernels launched, and the roofline is priced on kernel +
+        # boundary, so that it agrees with the committed trace (profiles/*_kernel_trace.txt).
+        launched = [n for n in per_kernel_nps if n.startswith("k_") and isinstance(per_kernel_nps[n], float) and per_kernel_nps[n] > 0.6]
         one_chain = not shard_mode and all(per_kernel_nps.get(n, 0.0) < 0.6 for n in ("k_refine_wave", "k_reads_order", "k_reads_gather", "k_genotype_tra"))
         boundary_us = None
-        if one_chain and launched:
-            boundary_us = max(0.0, (ms_per_step * 1e3 - sum(per_kernel_nps[n] for n in launched)) / len(launched))
+        if one_chain and launched and ms_kernel_only is not None:
+            boundary_us = max(0.0, (ms_kernel_only * 1e3 - sum(per_kernel_nps[n] for n in launched)) / len(launched))
         dom_us = per_kernel_nps[dom] + (boundary_us or 0.0)
-        dom_s = dom_us * 1e-6
-        achieved = kbytes[dom] / dom_s / 1e9
-        cold_achieved = kbytes[dom] / (per_kernel_cold[dom] * 1e-6) / 1e9
-        # HBM traffic per launch from the rocprofv3 PMC passes of the SAME command (scripts/refresh_profiles.sh writes
-        # profiles/traffic_<workload>.json from the FETCH_SIZE / WRITE_SIZE databases next to the kernel trace)
-        traffic, traffic_all = None, None
-        tf = os.path.join(ROOT, "profiles", "traffic_%s.json" % a.workload)
-        if os.path.exists(tf) and a.scale == 1.0:
-            with open(tf) as f:
-                tj = json.load(f)
-            traffic_all = {k: v for k, v in tj.items() if k.startswith("k_")}
-            traffic = sum(tj.get(k, 0) for k in gt_kernels) if dom == "genotype_stage" else tj.get(dom)
+        achieved = kbytes[dom] / (dom_us * 1e-6) / 1e9
+        cold_achieved = kbytes[dom] / (per_kernel_cold[dom] * 1e-6) / 1e9 if per_kernel_cold[dom] > 0 else None
+        traffic_all = traffic_of(a.workload, a.scale)
+        traffic = None if traffic_all is None else (sum(traffic_all.get(k, 0) for k in GT_KERNELS) if dom == "genotype_stage" else traffic_all.get(dom))
         roof_all = {n: {"us": per_kernel_nps[n], "algorithmic_bytes": kbytes[n], "gbs": round(kbytes[n] / (per_kernel_nps[n] * 1e-6) / 1e9, 1),
                         "frac": round(kbytes[n] / (per_kernel_nps[n] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
-                    for n in per_kernel_nps if n in kbytes and kbytes[n] > 0 and per_kernel_nps[n] > 0}
+                    for n in per_kernel_nps if n in kbytes and kbytes[n] > 0 and isinstance(per_kernel_nps[n], float) and per_kernel_nps[n] > 0}
         parity = None
         if ores is not None:
             w, g = ores.trimmed(), res.trimmed()
-            parity = all(np.array_equal(g[k], w[k]) for k in ("call_seg", "call_cluster", "bp1", "bp2", "support", "cipos", "cilen",
-                                                             "search_pos", "seq_pick", "dr", "dv", "gl_idx", "support_off",
-                                                             "support_sig", "cluster_id", "allele_id"))
+            parity = all(np.array_equal(g[k], w[k]) for k in PARITY_FIELDS)
         stage_ms = float(np.median(t_stage)) * 1e3
         one_ms = float(np.min(t_one)) * 1e3
+        ko_ms = ms_kernel_only if ms_kernel_only is not None else None
+        other_out = {}
+        for name, cpu_o in others.items():
+            if "error" in cpu_o:
+                other_out[name] = cpu_o
+                continue
+            try:
+                other_out[name] = compact_workload(ctx, name, a, cpu_o)
+            except Exception as e:      # noqa: BLE001
+                other_out[name] = {"error": repr(e)}
+            cpu_o.clear()
         out = {
             "metric": "SV signatures clustered/sec (whole node)", "value": value, "unit": "signatures/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
+            "timed_region": ("the rank's whole boundary call: page-locked host columns -> kernels -> host SoA" if shard_mode else
+                             "inputs resident in HBM -> all kernels -> calls + support lists delivered into page-locked host arrays (k_publish + one "
+                             "stream synchronisation per step)"),
+            "kernel_only": None if ko_ms is None else {"ms_per_step": ko_ms, "value": total_sig / (ko_ms * 1e-3),
+                                                       "note": "the launch sequence alone, results left in HBM (the region r01-r03 reported as value)"},
             "ms_per_step_reads_order_kept": ms_reads_kept,
             "higher_is_better": True, "scaling": "strong" if shard_mode else "weak", "vs_baseline": None, "dtype": "int64+f64", "data": "synthetic",
             "config": {"workload": wl_name, "signatures_per_gpu": n_sig, "signatures_total": total_sig, "segments": len(tasks),
                        "preset": "ONT" if a.workload in ("cfg2", "cfg3", "cfg5") else "HiFi",
-                       "genotype": bool(params.genotype), "mode": a.mode,
-                       "sharding": ("one genome split over the GPUs: chromosomes longest-first, the largest cut at gaps wider than max_cluster_bias until the "
-                                    "heaviest rank is within 3 % of the mean; no collective; a step is the rank's H2D + kernels + D2H"
-                                    if shard_mode else "one genome per GPU, no collective")},
+                       "genotype": bool(params.genotype), "mode": a.mode, "columns": "int32 positions / lengths (SigStore.pinned())",
+                       "sharding": (sharded_obj["mode"] if (shard_mode and sharded_obj) else "one genome per GPU, no collective")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_note": "L2 <-> fabric bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, rocprofv3 PMC passes of this command, calibrated on "
+                                         "known byte counts: profiles/r04_pmc_calibration.txt); includes requests the Infinity Cache answers",
                          "algorithmic_bytes": kbytes[dom], "kernel_us": round(dom_us, 2), "kernel_us_net": per_kernel_nps[dom],
                          "boundary_us": None if boundary_us is None else round(boundary_us, 2),
                          "copy_ceiling": copy_gbs, "frac_of_copy_ceiling": (achieved / copy_gbs) if copy_gbs else None,
-                         "cold": {"kernel_us": per_kernel_cold[dom], "achieved": cold_achieved, "frac": cold_achieved / HBM_PEAK_GBS,
+                         "cold": {"kernel_us": per_kernel_cold[dom], "achieved": cold_achieved, "frac": None if cold_achieved is None else cold_achieved / HBM_PEAK_GBS,
                                   "pipeline_us": round(cold_tot / ncold * 1e3, 2),
                                   "note": "L2 + Infinity Cache evicted before every step (csv_cache_flush, 1 GiB)"}},
-            "roofline_pipeline": {"algorithmic_bytes": total_bytes, "kernel_time_us": round(tot / a.steps * 1e3, 2),
-                                  "achieved": total_bytes / (ms_per_step * 1e-3) / 1e9 if not shard_mode else None, "unit": "GB/s",
-                                  "frac": total_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS if not shard_mode else None},
+            # one denominator: the kernel-only loop (the algorithmic bytes are the kernels'; the host delivery is not HBM traffic)
+            "roofline_pipeline": {"algorithmic_bytes": total_bytes, "step_us": None if ko_ms is None else round(ko_ms * 1e3, 2),
+                                  "achieved": total_bytes / (ko_ms * 1e-3) / 1e9 if ko_ms else None, "unit": "GB/s",
+                                  "frac": total_bytes / (ko_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ko_ms else None,
+                                  "instrumented_pass_us": round(kernel_time_us, 2),
+                                  "note": "achieved / frac on the plain kernel-only loop; instrumented_pass_us is the event-per-kernel pass (each record occupies the stream) and is NOT a denominator"},
             "roofline_per_kernel": roof_all, "traffic_per_kernel": traffic_all,
             "kernel_us": per_kernel_nps, "kernel_us_per_sig_outputs": per_kernel, "kernel_us_cold": per_kernel_cold, "units": units,
             "cpu_baseline": cpu, "cpu_baseline_c": cpu_c, "cpu_baseline_c_mt": cpu_c_mt,
-            "speedup_vs_cpu_baseline": (value / world / cpu["value"]) if cpu else None,
-            "boundary": {"pin_ms": t_pin * 1e3,
+            # speed-ups, each over ONE named pair of regions (r03's speedup_vs_cpu_baseline divided the kernel-only loop by a Python pool)
+            "speedups": {
+                "stage_wall_vs_reference_model": (cpu["wall_s"] * 1e3 / stage_ms) if (cpu and cpu.get("full_workload")) else None,
+                "step_vs_reference_model": (cpu["wall_s"] * 1e3 / ms_per_step) if (cpu and cpu.get("full_workload") and world == 1) else None,
+                "one_shot_vs_c_all_threads": (cpu_c_mt["wall_s"] * 1e3 / one_ms) if cpu_c_mt else None,
+                "step_vs_c_all_threads": (cpu_c_mt["wall_s"] * 1e3 / ms_per_step) if (cpu_c_mt and world == 1) else None,
+                "note": "reference_model = oracle/py_restatement.py in a fork Pool at all host cores (cuteSV's execution model, the north_star target); "
+                        "c_all_threads = the C oracle, one (chr,type) task per thread; stage_wall = page-locked columns -> the reference's row lists"},
+            "boundary": {"pin_ms": None if t_pin is None else t_pin * 1e3,
                          "one_shot_call_ms": one_ms, "one_shot_call_ms_all": [round(x * 1e3, 3) for x in t_one],
                          "one_shot_pageable_ms": float(np.min(t_one_pageable)) * 1e3,
                          "h2d_bytes": h2d_bytes, "pcie_gbs": h2d_bytes / (one_ms * 1e-3) / 1e9, "pcie_frac_of_gen5_x16": h2d_bytes / (one_ms * 1e-3) / 1e9 / PCIE_PEAK_GBS,
                          "rows_ms": float(np.median(t_rows)) * 1e3, "rows": n_rows,
                          "stage_wall_ms": stage_ms, "stage_wall_ms_all": [round(x * 1e3, 3) for x in t_stage],
-                         "stage_speedup_vs_cpu_baseline": (cpu["wall_s"] * 1e3 / stage_ms) if (cpu and cpu.get("full_workload")) else None,
                          "vcf_emit_native": t_vcf, "per_task_drop_in": t_task,
                          "pcie_inclusive_signatures_per_s": n_sig / (one_ms * 1e-3),
                          "stage_signatures_per_s": n_sig / (stage_ms * 1e-3)},
-            "parity_vs_oracle": parity, "shard_merge_equals_unsharded": shard_check,
+            "other_workloads": other_out or None,
+            "sharded": sharded_obj if not shard_mode else None,
+            "parity_vs_oracle": parity, "shard_merge_equals_unsharded": (sharded_obj or {}).get("shard_merge_equals_unsharded") if shard_mode else None,
         }
         if not shard_mode:
             out["boundary"]["upload_ms"] = t_upload * 1e3

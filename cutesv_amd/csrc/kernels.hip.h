@@ -166,8 +166,8 @@ struct DevBatch {
     i64*           item_cnt;         // packed (valid calls << 32 | supports of valid calls)
     i64*           item_base;        // exclusive prefix of item_cnt per tile of EM_TILE items, inside the tile's chunk of IS_CHUNK items
     i64*           item_chunk;       // total of item_cnt per chunk
-    int2*          sup_tmp;          // W: support lists {signature w, its read id}, stored inside the cluster's own [s, e) range (the read id
-                                     // rides along so that k_emit needs no dependent gather for it)
+    int*           sup_tmp;          // W: support lists (signature w), stored inside the cluster's own [s, e) range.  (r03 carried the read id along:
+                                     // 8 B per entry written and read back for a word only genotyped segments need - k_emit gathers it there)
     TmpRec*        t_rec;            // W temp call records: slots >= 1 of an item live in its own signature range, t_rec[first w + slot]
     int            cap_tmp;
     int            cap_items;
@@ -1433,7 +1433,7 @@ template <int BLOCK, bool LDS, bool SMALLN> __device__ void refine_indel(const D
             search = (i64)bp;                                               // INDEL:415
         }
         // supports: the allele's kept signatures in allele order (INDEL:205, 416)
-        for (int i = lane_id(); i < n; i += 64) { const int w = s + A.V1[r0 + i]; B.sup_tmp[s + soff + i] = make_int2(w, B.rid[w]); }
+        for (int i = lane_id(); i < n; i += 64) { const int w = s + A.V1[r0 + i]; B.sup_tmp[s + soff + i] = w; }
         if (lane_id() == 0) {
             tmp_write(tmp_slot(B, it.j, tbase, rank), (i64)bp, (i64)siglen, search, pick, n, cip, cil, soff, valid, npass, aux0);
             if (valid) { ncalls++; nsup += n; }
@@ -1452,7 +1452,7 @@ template <bool LDS> __device__ __forceinline__ void write_first_seen(const DevBa
         const int r = base + lane_id();
         const int f = (r < r1) && (A.V1[r < r1 ? r : r0] < 0);
         const u64 mk = __ballot(f);
-        if (f) { const int w = s + (A.V1[r] & 0x7fffffff); B.sup_tmp[dst + run + __popcll(mk & lanemask_lt())] = make_int2(w, B.rid[w]); }
+        if (f) { const int w = s + (A.V1[r] & 0x7fffffff); B.sup_tmp[dst + run + __popcll(mk & lanemask_lt())] = w; }
         run += __popcll(mk);
     }
 }
@@ -2034,11 +2034,11 @@ template <int SW, bool NARROW> __device__ __forceinline__ void indel_unit(const 
                 rank += (lt < bl) || (lt == bl && t < sl);
             }
         }
-        C pos, len; int chp, axp, ridp;
+        C pos, len; int chp, axp;
         if (src_lane >= 0) {                                                 // (wave-uniform: all lanes or none)
             const int s4 = src_lane << 2;
             pos = bperm(s4, pa); len = bperm(s4, bl);
-            chp = bperm(s4, ch); axp = bperm(s4, pax); ridp = bperm(s4, rid);
+            chp = bperm(s4, ch); axp = bperm(s4, pax);
         } else {
             const u64 sl_lt = (1ull << sl) - 1ull;
             const int dest4 = (hb | (rep ? rank : U_ + __popcll(~rm & sl_lt & SUBMASK))) << 2;
@@ -2046,7 +2046,6 @@ template <int SW, bool NARROW> __device__ __forceinline__ void indel_unit(const 
             len = fperm(dest4, bl);
             chp = fperm(dest4, ch);
             axp = fperm(dest4, pax);
-            ridp = fperm(dest4, rid);                                        // (every signature of a read's group carries the group's read id)
         }
         const int r = sl;
         const bool live = ok && r < U_;
@@ -2240,7 +2239,7 @@ template <int SW, bool NARROW> __device__ __forceinline__ void indel_unit(const 
             bp_i = (i64)pick_pos;                                                 // (the reference's float(pos) -> int() round trip is exact below 2^53)
             search_i = bp_i;                                                      // INDEL:415
         }
-        if (pass && !CSV_ABL(4)) B.sup_tmp[s + soff + i] = make_int2(s + chp, ridp);   // INDEL:205, 416
+        if (pass && !CSV_ABL(4)) B.sup_tmp[s + soff + i] = s + chp;                     // INDEL:205, 416
         const bool head = pass && i == 0;
         if (head && !CSV_ABL(4)) {
             if (type == CSV_INS && valid) pick = B.seg[k].sig_begin + ((i64)s - B.woff[k]) + pick_ch;      // global signature index (w -> caller's row)
@@ -2285,6 +2284,9 @@ template <bool NARROW> __global__ __launch_bounds__(256, NARROW ? CSV_IW_WAVES :
         unit_rows<NARROW>(B, unit_entry(B.list_tiny, p, ntiny, 4), 4, 0, U);
         indel_unit<16, NARROW>(B, U);
     }
+    // (r04, rejected: loading the next unit's entry two units ahead and its rows one unit ahead - 12 more VGPRs, so five
+    // wavefronts per SIMD or spills at six - was 17.4 / 19.1 us against 15.0 on the 30x genome: occupancy hides more latency
+    // than the prefetch saves, because only two wavefronts in three have a second unit at all)
 }
 
 // ------------------------------------------------------------------------------------ order
@@ -2403,11 +2405,10 @@ __device__ __forceinline__ void emit_item_serial(const DevBatch& B, int j, i64 b
             const i64 dst = shfl_i64(so, l);
             const int src = s + __shfl(tso, l);
             for (int i = lane; i < nn; i += 64) {
-                const int2 sr = B.sup_tmp[src + i];
-                B.o_supsig[dst + i] = gs + sr.x;
-                B.o_suprid[dst + i] = sr.y;
-                if (sr.y < 0) atomicOr(&B.cnt->error, ERR_KEY_RANGE);
-                if (B.per_sig) B.allele_id[sr.x] = cc;
+                const int w = B.sup_tmp[src + i];
+                B.o_supsig[dst + i] = gs + w;
+                if (sgk.genotype) { const int r = B.rid[w]; B.o_suprid[dst + i] = r; if (r < 0) atomicOr(&B.cnt->error, ERR_KEY_RANGE); }
+                if (B.per_sig) B.allele_id[w] = cc;
             }
         }
         cb += __popcll(mk);
@@ -2481,7 +2482,7 @@ __global__ __launch_bounds__(256) void k_emit(DevBatch B)
         // (... and, before the slot records say how long the lists are, the first 32 supports of the item's first slot, whose list
         // always begins at the cluster's own first row: most items have one call with fewer supports than that, and their third
         // round trip disappears)
-        int2 pre[4];
+        int pre[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) { const i64 x = (i64)s + l8 + 8 * u; pre[u] = B.sup_tmp[x < B.W ? x : B.W]; }
         i64 gs = 0;
@@ -2491,6 +2492,7 @@ __global__ __launch_bounds__(256) void k_emit(DevBatch B)
             gs = sgk.sig_begin + ((i64)s - B.woff[k]) - s;
             ghdr = make_int4(sgk.chrom, sgk.svtype | (sgk.genotype ? 0x100 : 0), (int)(sgk.gt_bias & 0xffffffffll), (int)(sgk.gt_bias >> 32));
         }
+        const bool gtseg = (ghdr.y & 0x100) != 0;
         if (!valid) { nsup = 0; tso = 0; }
         const u64 mk = __ballot(valid);
         const u64 gmask = 0xffull << (g * 8);
@@ -2508,19 +2510,25 @@ __global__ __launch_bounds__(256) void k_emit(DevBatch B)
             if (!__ballot(nn > 0)) continue;                // wave-uniform
             // 4 strides per step, loads issued together (lists are 15-90 long)
             for (int i = l8; i < nn; i += 32) {
-                int2 sr[4];
+                int sr[4], rd[4];
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
-                    if (sl == 0 && i == l8 && ts == 0) sr[u] = (i + 8 * u < nn) ? pre[u] : make_int2(-1, 0);
-                    else sr[u] = (i + 8 * u < nn) ? B.sup_tmp[s + ts + i + 8 * u] : make_int2(-1, 0);
+                    if (sl == 0 && i == l8 && ts == 0) sr[u] = (i + 8 * u < nn) ? pre[u] : -1;
+                    else sr[u] = (i + 8 * u < nn) ? B.sup_tmp[s + ts + i + 8 * u] : -1;
                 }
+                // the supports' read ids seed the cover sets of the genotype kernels: gathered here, for genotyped segments only
+                // (the rows were read by the refine kernel a moment ago)
+#pragma unroll
+                for (int u = 0; u < 4; u++) rd[u] = (gtseg && sr[u] >= 0) ? B.rid[sr[u]] : 0;
 #pragma unroll
                 for (int u = 0; u < 4; u++)
-                    if (sr[u].x >= 0) {
-                        B.o_supsig[dst + i + 8 * u] = gs + sr[u].x;
-                        B.o_suprid[dst + i + 8 * u] = sr[u].y;
-                        if (sr[u].y < 0) atomicOr(&B.cnt->error, ERR_KEY_RANGE);      // (a negative id would pass for an empty hash slot)
-                        if (B.per_sig) B.allele_id[sr[u].x] = cc;
+                    if (sr[u] >= 0) {
+                        B.o_supsig[dst + i + 8 * u] = gs + sr[u];
+                        if (gtseg) {
+                            B.o_suprid[dst + i + 8 * u] = rd[u];
+                            if (rd[u] < 0) atomicOr(&B.cnt->error, ERR_KEY_RANGE);      // (a negative id would pass for an empty hash slot)
+                        }
+                        if (B.per_sig) B.allele_id[sr[u]] = cc;
                     }
             }
         }

@@ -90,7 +90,17 @@ class Context:
         """evict L2 / Infinity Cache (a measurement aid: the next run reads its columns from HBM)"""
         self._check(lib().csv_cache_flush(self._h, int(nbytes)))
 
-    def download(self, per_sig=False, cap_calls=None, cap_support=None):
+    def result_buffers(self, per_sig=False, cap_calls=None, cap_support=None, pinned=True):
+        """caller-owned result arrays for the uploaded batch, to be handed to download(into=...) again and again; page-locked by
+        default: the device then writes the calls straight into them (k_publish) and a download is one synchronisation"""
+        n = self._batch.n_sig
+        return _abi.HostResult(n, cap_calls or max(64, n // 16 + 16), cap_support or max(64, n + 16), per_sig=per_sig,
+                               n_seg=len(self._batch.segments), alloc=pinned_empty if pinned else None)
+
+    def download(self, per_sig=False, cap_calls=None, cap_support=None, into=None):
+        if into is not None:
+            self._check(lib().csv_batch_download(self._h, C.byref(into.c)))       # (E_CAPACITY: the caller sized `into`; it is raised)
+            return into
         n = self._batch.n_sig
         cap_calls = cap_calls or max(64, n // 16 + 16)
         cap_support = cap_support or max(64, n + 16)

@@ -316,13 +316,17 @@ def tasks_from_store(store, params, tasks=None):
         a = store.a[beg:end].tolist(); b = store.b[beg:end].tolist(); ax = store.aux[beg:end].tolist()
         nm = names.take(store.read_id[beg:end])
         if svtype == "INS":
-            sigs = [(a[i], b[i], nm[i], store.sequence(beg + i)) for i in range(end - beg)]
+            if store.ins_seq is None and names.names is None:       # synthetic stores: 'ACGT' repeated to the aux length (SigStore.sequence)
+                base = "ACGT" * (max(ax, default=0) // 4 + 1)
+                sigs = list(zip(a, b, nm, [base[:n] for n in ax]))
+            else:
+                sigs = [(a[i], b[i], nm[i], store.sequence(beg + i)) for i in range(end - beg)]
         elif svtype == "INV":
             sigs = [(a[i], b[i], nm[i], store.strands[ax[i]]) for i in range(end - beg)]
         elif svtype == "TRA":
             sigs = [(a[i], b[i], nm[i], "ABCDXXXX"[ax[i] & 7], store.chroms[ax[i] >> 3]) for i in range(end - beg)]
         else:
-            sigs = [(a[i], b[i], nm[i]) for i in range(end - beg)]
+            sigs = list(zip(a, b, nm))
         reads = None
         if params.genotype and svtype != "TRA" and store.has_reads(chrom):
             if chrom not in reads_cache:

@@ -10,6 +10,6 @@ for spec in "$@"; do
   echo "$line" | python -c "
 import sys, json
 d = json.loads(sys.stdin.read()); k = d['kernel_us']
-print('%-10s ms/step %.4f  ' % ('$label', d['ms_per_step']) + ' '.join('%s=%.1f' % (n[2:], v) for n, v in k.items() if v > 0 and n.startswith('k_')) + '  one_shot %.3f stage %.2f rows %.2f' % (d['boundary']['one_shot_call_ms'], d['boundary']['stage_wall_ms'], d['boundary']['rows_ms']))"
+print('%-10s ms/step %.4f kernels %.4f  ' % ('$label', d['ms_per_step'], (d.get('kernel_only') or {}).get('ms_per_step', 0)) + ' '.join('%s=%.1f' % (n[2:], v) for n, v in k.items() if n.startswith('k_') and v > 0) + '  one_shot %.3f stage %.2f rows %.2f' % (d['boundary']['one_shot_call_ms'], d['boundary']['stage_wall_ms'], d['boundary']['rows_ms']))"
 done
 done

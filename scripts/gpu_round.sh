@@ -20,8 +20,8 @@ try:
 except Exception as e:
     print("no bench line:", e); sys.exit(0)
 print("ms/step %.4f value %.3g" % (d["ms_per_step"], d["value"]))
-print("kernel_us", {k[2:]: v for k, v in d["kernel_us"].items() if v})
-print("cold", {k[2:]: v for k, v in d["kernel_us_cold"].items() if v})
+print("kernel_us", {k[2:]: v for k, v in d["kernel_us"].items() if k.startswith("k_") and v})
+print("cold", {k[2:]: v for k, v in d["kernel_us_cold"].items() if k.startswith("k_") and v})
 print("roofline", {k: d["roofline"][k] for k in ("kernel", "achieved", "frac", "kernel_us")}, "cold", d["roofline"]["cold"])
 b = d["boundary"]; print("boundary", {k: (round(v, 3) if isinstance(v, float) else v) for k, v in b.items() if k not in ("vcf_emit_native",)})
 print("cpu", d.get("cpu_baseline") and d["cpu_baseline"]["wall_s"], "parity", d["parity_vs_oracle"])
