@@ -889,7 +889,10 @@ int run_impl(csv_ctx* c, csv_run_stats* stats)
         // the tiers run side by side only in a large batch: a fork and a join cost 6-10 us each, more than the overlap of short
         // kernels is worth (five simulation beds, 0.56 M signatures: 110 us in a row, 115-133 us forked; 90x ONT, 11 M: 367 vs 335)
         const bool tier_fork = fork && W >= (i64)env_int("CSV_TIER_FORK_MIN", 4 << 20);
-        const bool side_b = tier_fork && need_big, side_c = tier_fork && c->any_pair;
+        // with clusters above 64 signatures in the batch, the one-wavefront tier for 65 .. 256 also takes the DUP / INV / TRA clusters
+        // of at most 64 (its second phase): one grid, the long clusters first, instead of two kernels in a row
+        B.pair_in_mid = (need_big && c->any_pair && !getenv("CSV_NO_PAIR_IN_MID")) ? 1 : 0;
+        const bool side_b = tier_fork && need_big, side_c = tier_fork && c->any_pair && !B.pair_in_mid;
         if (!tier_fork) { sB = st; sC = st; }
         if (side_b || side_c) {
             HIP_TRY(c, hipEventRecord(c->ev_sel, st));
@@ -898,7 +901,7 @@ int run_impl(csv_ctx* c, csv_run_stats* stats)
         }
         if (B.a.p32) LAUNCH("refine_indel_wave", k_refine_indel_wave<true>, g_iw, 256, 0, B);
         else LAUNCH("refine_indel_wave", k_refine_indel_wave<false>, g_iw, 256, 0, B);
-        if (c->any_pair) LAUNCH_ON(sC, "refine_wave", (k_refine<64, 64, false>), g_small, 64, LDS_SMALL, B, 0, 64);
+        if (c->any_pair && !B.pair_in_mid) LAUNCH_ON(sC, "refine_wave", (k_refine<64, 64, false>), g_small, 64, LDS_SMALL, B, 0, 64);
         else HIP_TRY(c, mark());
         int g_mid = B.cap_items < 8192 ? B.cap_items : 8192;
         if (g_mid < 1) g_mid = 1;

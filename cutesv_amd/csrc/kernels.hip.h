@@ -151,6 +151,8 @@ struct DevBatch {
     int4*          list_wide;        // DEL/INS items with 32 < m <= 64 (same entries, any order): their own units, so that no
                                      // wavefront runs a pair and then its wide members one after the other
     int            tiny_max;         // 16 (0 switches the class off)
+    int            pair_in_mid;      // this run's k_refine<64,256> launch also refines the DUP / INV / TRA clusters of at most 64 signatures
+                                     // (second phase; k_refine<64,64> is not launched then)
     u64*           ch_masks;         // per chain tile: its 32 flag words (written only for CSV_IN_PER_SIG: k_chain_ids)
     int4*          tile_items;       // per chain tile, TI_STRIDE slots: the clusters that passed the size gate, in order:
                                      // {first w, size, segment | svtype << 24 | tier << 28, cluster index inside the tile}
@@ -1659,12 +1661,17 @@ template <int BLOCK, int CAP, bool BIG> __global__ __launch_bounds__(BLOCK, (BLO
     i64* red = (i64*)(smem_raw + LDS_LEAD + 36 * N);
     int* ired = (int*)(red + 6);
     const int n = big ? B.cnt->n_items_big : (B.cnt->n_items - B.cnt->n_items_big - B.cnt->n_items_tiny);
+    // (r04, rejected: "tier by occupancy" - when a batch has fewer clusters of 65 .. 256 signatures than two per CU, hand each
+    // to a whole 256-thread workgroup of the tier below instead of one wavefront: 29 us against 23 for the ~100 such clusters of
+    // the simulation beds.  The LDS network's 2 x 36 barriers and the serial np.std replay cost more than three more wavefronts
+    // save.  What pays is not waiting for the tiers one after the other: see the second phase below.)
+    const int lo = m_lo;
     for (int q = blockIdx.x; q < n; q += gridDim.x) {
         ItemCtx it;
         it.j = big ? B.list_big[q] : B.list_small[q].x;
         const int4 rec = B.item_rec[it.j];
         it.cid = rec.x; it.k = rec.y; it.s = rec.z; it.m = rec.w;
-        if (it.m <= m_lo || it.m > m_hi) continue;
+        if (it.m <= lo || it.m > m_hi) continue;
         if (!big) { const int ty = B.seg[it.k].svtype; if (ty == CSV_DEL || ty == CSV_INS) continue; }
         it.gsig0 = B.seg[it.k].sig_begin + ((i64)it.s - B.woff[it.k]);
         int P = 1;
@@ -1695,6 +1702,32 @@ template <int BLOCK, int CAP, bool BIG> __global__ __launch_bounds__(BLOCK, (BLO
             G.V4 = B.sc_v4 + o; G.V5 = B.sc_v5 + o;
             if (indel) refine_indel<BLOCK, false, false>(B, it, G, red, ired);
             else refine_pair<BLOCK, false>(B, it, G, red, ired);
+        }
+    }
+    // Second phase of the one-wavefront tier for 65 .. 256 signatures (pair_too: the launch that also stands in for
+    // k_refine<64,64>): the DUP / INV / TRA clusters of at most 64 signatures, dealt round-robin over the workgroups where the
+    // first phase stopped.  The two kernels used to run one after the other, each lasting as long as its slowest cluster (five
+    // simulation beds: 11.5 + 23 us with ~100 and ~1500 busy wavefronts); as ONE grid the long clusters start first and the
+    // short ones fill the rest of the chip beside them.
+    if constexpr (BIG && BLOCK == 64) {
+        if (m_hi < 0) return;                             // (never: keeps the parameter list of the instantiations alike)
+        if (!B.pair_in_mid) return;
+        const int ns = B.cnt->n_items - B.cnt->n_items_big - B.cnt->n_items_tiny;
+        int q0 = (int)blockIdx.x - n % (int)gridDim.x;
+        if (q0 < 0) q0 += gridDim.x;
+        for (int q = q0; q < ns; q += gridDim.x) {
+            ItemCtx it;
+            const int4 e = B.list_small[q];               // {item, segment | svtype << 24, first w, size}
+            const int ty = e.y >> 24;
+            if (ty == CSV_DEL || ty == CSV_INS || e.w > 64) continue;
+            it.j = e.x; it.k = e.y & 0xffffff; it.s = e.z; it.m = e.w;
+            it.cid = B.item_rec[it.j].x;
+            it.gsig0 = B.seg[it.k].sig_begin + ((i64)it.s - B.woff[it.k]);
+            int P = 1;
+            while (P < it.m) P <<= 1;
+            it.P = P; it.ib = IDX_BITS;
+            __syncthreads();
+            refine_pair<BLOCK, true>(B, it, L, red, ired);
         }
     }
 }
