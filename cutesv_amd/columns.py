@@ -93,6 +93,22 @@ def intern_names(*name_lists):
     return uniq, [np.fromiter((rank[n] for n in lst), dtype=np.int32, count=len(lst)) for lst in name_lists]
 
 
+def _sparse_blob(table, picks, n=None):
+    """(blob, offsets[n + 1]) holding only table[i] for i in picks (a list, or a dict keyed by index); every other entry empty"""
+    n = len(table) if n is None else n
+    picks = np.asarray(picks, np.int64)
+    picks = np.unique(picks[picks >= 0])
+    if isinstance(table, dict):
+        picks = picks[np.fromiter((int(i) in table for i in picks.tolist()), bool, len(picks))] if len(picks) else picks
+    vals = [table[i].encode() for i in picks.tolist()]
+    lens = np.zeros(n, np.int64)
+    if len(picks):
+        lens[picks] = [len(v) for v in vals]
+    off = np.zeros(n + 1, np.int64)
+    np.cumsum(lens, out=off[1:])
+    return b"".join(vals), off
+
+
 @dataclass
 class SigStore:
     chroms: list                                  # chromosome names; index = chrom id (also the chr2 rank for TRA)
@@ -164,42 +180,56 @@ class SigStore:
         return dataclasses.replace(self, narrow=narrow or None, **cols)
 
     # ------------------------------------------------------------------ string tables for the native row / VCF emitters
-    def names_blob(self):
+    def names_blob(self, picks=None):
         """read names as csv_rows_emit takes them: (blob, offsets, n_names, prefix, width); an explicit table, or
-        (None, None, 0, prefix, width) for the synthetic '<prefix>%0<width>d' scheme.  Cached on the store."""
+        (None, None, 0, prefix, width) for the synthetic '<prefix>%0<width>d' scheme.  The full table is cached on the store.
+        picks (read ids, any order, duplicates allowed): only THESE names are put into the blob - every other id gets an empty
+        string - and nothing is cached: a task's rows name ~20 k of its 110 k reads, and encoding all of them cost more than
+        the rows themselves (resolve.run_* builds one store per task)."""
         nb = getattr(self, "_names_blob", None)
-        if nb is None:
-            if self.names.names is not None:
-                enc = [x.encode() for x in self.names.names]
-                off = np.zeros(len(enc) + 1, np.int64)
-                if enc:
-                    np.cumsum([len(x) for x in enc], out=off[1:])
-                nb = (b"".join(enc), off, len(enc), None, 0)
-            else:
-                import re
-                m = re.fullmatch(r"([^%]*)%0(\d+)d", self.names.fmt)
-                if not m:
-                    raise ValueError("synthetic read-name format %r is not '<prefix>%%0<width>d'" % self.names.fmt)
-                nb = (None, None, 0, m.group(1).encode(), int(m.group(2)))
-            self._names_blob = nb
+        if nb is not None:
+            return nb
+        if self.names.names is None:
+            import re
+            m = re.fullmatch(r"([^%]*)%0(\d+)d", self.names.fmt)
+            if not m:
+                raise ValueError("synthetic read-name format %r is not '<prefix>%%0<width>d'" % self.names.fmt)
+            nb = self._names_blob = (None, None, 0, m.group(1).encode(), int(m.group(2)))
+            return nb
+        names = self.names.names
+        if picks is not None:
+            return _sparse_blob(names, picks) + (len(names), None, 0)
+        enc = [x.encode() for x in names]
+        off = np.zeros(len(enc) + 1, np.int64)
+        if enc:
+            np.cumsum([len(x) for x in enc], out=off[1:])
+        nb = self._names_blob = (b"".join(enc), off, len(enc), None, 0)
         return nb
 
-    def ins_blob(self):
+    def ins_blob(self, picks=None):
         """inserted sequences by global signature index as (blob, offsets[n_sig + 1]); (None, None) when the store is
-        synthetic ('ACGT' repeated to the aux length).  Cached on the store."""
+        synthetic ('ACGT' repeated to the aux length).  The full blob is cached on the store; picks (signature indices, -1
+        entries ignored): only those sequences, nothing cached (see names_blob)."""
         ib = getattr(self, "_ins_blob", None)
-        if ib is None:
-            if self.ins_seq is None:
-                ib = (None, None)
-            else:
-                lens = np.zeros(self.n_sig, np.int64)
-                keys = sorted(self.ins_seq)
-                if keys:
-                    lens[np.array(keys, np.int64)] = [len(self.ins_seq[k]) for k in keys]
-                off = np.zeros(self.n_sig + 1, np.int64)
-                np.cumsum(lens, out=off[1:])
-                ib = ("".join(self.ins_seq[k] for k in keys).encode(), off)
-            self._ins_blob = ib
+        if ib is not None:
+            return ib
+        if self.ins_seq is None:
+            ib = self._ins_blob = (None, None)
+            return ib
+        seqs = self.ins_seq
+        if picks is not None:
+            return _sparse_blob(seqs, picks, n=self.n_sig)
+        if isinstance(seqs, dict):
+            keys = sorted(seqs)
+            vals = [seqs[k] for k in keys]
+        else:                                                  # a list by signature index (from_task_lists: the task's own objects)
+            keys, vals = list(range(len(seqs))), seqs
+        lens = np.zeros(self.n_sig, np.int64)
+        if keys:
+            lens[np.array(keys, np.int64)] = [len(v) for v in vals]
+        off = np.zeros(self.n_sig + 1, np.int64)
+        np.cumsum(lens, out=off[1:])
+        ib = self._ins_blob = ("".join(vals).encode(), off)
         return ib
 
     # ------------------------------------------------------------------ segments / batches
@@ -268,7 +298,7 @@ class SigStore:
         meta = dict(chroms=self.chroms, strands=list(self.strands),
                     seg_index=[[t, c, int(b), int(e)] for (t, c), (b, e) in self.seg_index.items()],
                     names=self.names.names, name_fmt=self.names.fmt,
-                    ins_seq=None if self.ins_seq is None else {str(k): v for k, v in self.ins_seq.items()})
+                    ins_seq=None if self.ins_seq is None else {str(k): v for k, v in (self.ins_seq.items() if isinstance(self.ins_seq, dict) else enumerate(self.ins_seq))})
         with open(os.path.join(path, "sigindex.json"), "w") as f:
             json.dump(meta, f)
 
@@ -382,60 +412,60 @@ class SigStore:
     def from_task_lists(cls, svtype, chrom, sigs, reads=None, chroms=None):
         """One reference task - the list `pickle.load` returns at sigs_index[svtype][chrom] (already in the rebuild order
         and de-duplicated: main script :764-802, :958-969 wrote it) and, when the task genotypes, its chromosome's reads list
-        - as a flat store, column by column (list comprehensions + numpy; `from_tuple_lists` re-sorts and walks tuple by
-        tuple: ~3x the time for a chr1-sized task).  What a pool worker pays per task in the drop-in (resolve.run_*)."""
+        - as a flat store.  What a pool worker pays per task in the drop-in (resolve.run_*): ONE pass over the tuples in C
+        (`_cols_native.walk`, csrc/cols_py.cpp: integer fields - int() of an x.5 float included, main script :228 - straight
+        into the column buffers, names numbered by first appearance, len() of the inserted sequences).  (r03 did it with list
+        comprehensions and numpy.fromiter: ~50 ms for the 110 862 signatures of INS chr2.)"""
+        from . import _cols_native as cn                     # (built by the same make as the library; no Python fallback)
         n = len(sigs)
         reads = reads or []
-        name_col = {"DEL": 2, "INS": 2, "DUP": 2, "INV": 3, "TRA": 4}[svtype]
-        col = lambda k: [x[k] for x in sigs]                  # noqa: E731  (one list per field)
-        names = col(name_col)
-        rnames = [r[3] for r in reads]
+        nr = len(reads)
         # The list is already in the rebuild's order, so the ids only have to tell reads apart: numbered by first appearance
-        # (sorting 10^5 names and looking every one up again was more than half of this function; `from_tuple_lists`, which
-        # sorts rows BY name, interns rank-preservingly).
-        rank = {}
-        setd = rank.setdefault
-        rid = np.fromiter((setd(q, len(rank)) for q in names), np.int32, n)
-        for q in rnames:
-            setd(q, len(rank))
-        uniq = list(rank)
+        # (`from_tuple_lists`, which sorts rows BY name, interns rank-preservingly).
+        a, b = np.empty(n, np.int64), np.empty(n, np.int64)
+        rid, aux = np.empty(n, np.int32), np.zeros(n, np.int32)
+        ins_seq, strands = [], ("++", "--")
+        name_col = {"DEL": 2, "INS": 2, "DUP": 2, "INV": 3, "TRA": 4}[svtype]
+        if svtype in ("DEL", "DUP"):
+            cn.walk(sigs, ((0, a), (1, b)), (), ())
+        elif svtype == "INS":
+            cn.walk(sigs, ((0, a), (1, b)), (), ((3, aux),))
+            ins_seq = cn.column(sigs, 3)                      # (the objects of the task list, shared: SigStore.sequence indexes it)
+        elif svtype == "INV":
+            sd = {}
+            cn.walk(sigs, ((1, a), (2, b)), ((0, aux, sd),), ())
+            strands = tuple(sorted(sd)) or ("++", "--")
+            if n:
+                aux = np.array([strands.index(s_) for s_ in sd], np.int32)[aux]     # first-appearance id -> rank of the strand string
+        else:                                                 # TRA: (bnd type, pos1, chr2, pos2, read, "TRA", chr1)
+            td, cd = {}, {}
+            t_id, c_id = np.empty(n, np.int32), np.empty(n, np.int32)
+            cn.walk(sigs, ((1, a), (3, b)), ((0, t_id, td), (2, c_id, cd)), ())
+        rd = {}
+        r_chr = np.empty(nr, np.int32)
+        r_start, r_end = np.empty(nr, np.int64), np.empty(nr, np.int64)
+        r_primary, r_id = np.empty(nr, np.uint8), np.empty(nr, np.int32)
+        if nr:                                                # (start, end, is_primary, read, chr), main script :733
+            cn.walk(reads, ((0, r_start), (1, r_end), (2, r_primary)), ((4, r_chr, rd),), ())
+        # read names of the signatures, then of the reads table, in ONE id space (first appearance)
+        uniq = cn.intern(((sigs, name_col, rid), (reads, 3, r_id)) if nr else ((sigs, name_col, rid),))
         if chroms is None:
             cs = {chrom}
             if svtype == "TRA":
-                cs.update(col(2))
-            cs.update(r[4] for r in reads)
+                cs.update(cd)
+            cs.update(rd)
             chroms = sorted(cs)
         crank = {c: i for i, c in enumerate(chroms)}
-
-        def ints(k):                                          # int(x) per element: positions may be x.5 floats (main script :228)
-            v = np.array(col(k)) if n else np.zeros(0, np.int64)
-            return v.astype(np.int64) if v.dtype.kind in "iuf" else np.fromiter((int(x[k]) for x in sigs), np.int64, n)
-        aux = np.zeros(n, np.int32)
-        ins_seq, strands = {}, ("++", "--")
-        if svtype in ("DEL", "INS", "DUP"):
-            a, b = ints(0), ints(1)
-            if svtype == "INS":
-                seqs = col(3)
-                aux = np.fromiter(map(len, seqs), np.int32, n)
-                ins_seq = dict(enumerate(seqs))
-        elif svtype == "INV":
-            st_col = col(0)
-            strands = tuple(sorted(set(st_col))) or ("++", "--")
-            code = {s_: i for i, s_ in enumerate(strands)}
-            a, b = ints(1), ints(2)
-            aux = np.fromiter(map(code.__getitem__, st_col), np.int32, n)
-        else:
-            a, b = ints(1), ints(3)
-            aux = np.fromiter((crank[x[2]] * 8 + BND_CODE.get(x[0], 4) for x in sigs), np.int32, n)
+        if svtype == "TRA" and n:
+            clut = np.array([crank[c] for c in cd], np.int32)
+            tlut = np.array([BND_CODE.get(t, 4) for t in td], np.int32)
+            aux = clut[c_id] * 8 + tlut[t_id]
         kw = {}
-        if reads:
-            rc = np.fromiter((crank[r[4]] for r in reads), np.int64, len(reads))
+        if nr:
+            rc = np.array([crank[c] for c in rd], np.int64)[r_chr]
             o = np.argsort(rc, kind="stable")                # blocks by chromosome; the device orders every block by start
             kw = dict(reads_off=np.searchsorted(rc[o], np.arange(len(chroms) + 1)).astype(np.int64),
-                      r_start=np.fromiter((int(r[0]) for r in reads), np.int64, len(reads))[o],
-                      r_end=np.fromiter((int(r[1]) for r in reads), np.int64, len(reads))[o],
-                      r_primary=np.fromiter((int(r[2]) for r in reads), np.uint8, len(reads))[o],
-                      r_id=np.fromiter((rank[q] for q in rnames), np.int32, len(reads))[o])
+                      r_start=r_start[o], r_end=r_end[o], r_primary=r_primary[o], r_id=r_id[o])
         return cls(chroms=list(chroms), a=a, b=b, read_id=rid, aux=aux, seg_index={(svtype, chrom): (0, n)} if n else {},
                    names=NameTable(uniq), ins_seq=ins_seq if svtype == "INS" else {}, strands=strands, **kw)
 

@@ -49,9 +49,11 @@ def _rows_in(store, segments, res):
     nch = len(store.chroms)
     names = (C.c_char_p * max(1, nch))(*[c.encode() for c in store.chroms])
     strands = (C.c_char_p * max(1, len(store.strands)))(*[s.encode() for s in store.strands])
-    nb = store.names_blob()
-    ib = store.ins_blob()
     n = res.n_calls
+    # (an explicit name table / explicit sequences: only the entries these calls mention are encoded, unless the store already
+    # holds its full blobs - see SigStore.names_blob)
+    nb = store.names_blob(picks=store.read_id[res.arrays["support_sig"][:res.n_support]])
+    ib = store.ins_blob(picks=res.arrays["seq_pick"][:n])
     gl = res.arrays["gl_idx"][:n]
     glb, glo = gl_table_blob(np.unique(gl[gl >= 0]) if n else ())
     rid = np.ascontiguousarray(store.read_id, np.int32)
