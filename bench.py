@@ -274,28 +274,94 @@ def digest_rows(rows_by_chr):
     return {c: hashlib.sha256("\n".join("\t".join(r) for r in rows).encode()).hexdigest() for c, rows in rows_by_chr.items()}
 
 
+_REF = {}
+
+
+def synthetic_reference(store):
+    """A synthetic reference genome ON DISK for the VCF leg (a FASTA file with 60-base lines + its .fai, in /dev/shm when there is
+    room): contigs as long as the workload's coordinates need.  The emitter reads REF / ALT bases out of the memory-mapped file
+    (cutesv_amd/fasta.py Reference) exactly as it would out of a real hg38.fa.  Built once per process, removed at exit."""
+    import atexit
+    import shutil
+    import tempfile
+    from cutesv_amd.fasta import Reference
+    lens = []
+    for i, c in enumerate(store.chroms):
+        need = 0
+        for t in ("DEL", "INS", "DUP", "INV", "TRA"):
+            if (t, c) in store.seg_index:
+                b0, e0 = store.seg_index[(t, c)]
+                if e0 > b0:
+                    need = max(need, int(store.a[b0:e0].max()), int(store.b[b0:e0].max()) if t in ("DUP", "INV") else 0)
+        if store.contig_len is not None:
+            need = max(need, int(store.contig_len[i]))
+        lens.append(need + 200_000)
+    if store.chroms and "TRA" in {t for t, _ in store.seg_index}:       # mate positions live on other contigs
+        m = max(lens)
+        lens = [m] * len(lens)
+    key = (tuple(store.chroms), tuple(lens))
+    if key in _REF:
+        return _REF[key]
+    t0 = time.perf_counter()
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > sum(lens) * 1.1 + (1 << 28) else None
+    d = tempfile.mkdtemp(prefix="cutesv_amd_ref_", dir=base)
+    atexit.register(shutil.rmtree, d, ignore_errors=True)
+    path = os.path.join(d, "ref.fa")
+    line = b"ACGTTGCAAGCTTAGCCATGGATCCGTAACGTTAGCATGCCGATTACGGCTAAGTCCATG\n"     # 60 bases
+    assert len(line) == 61
+    block = line * 17189                                                         # ~1 MiB
+    fai = []
+    with open(path, "wb") as f:
+        off = 0
+        for c, n in zip(store.chroms, lens):
+            hdr = (">%s synthetic\n" % c).encode()
+            f.write(hdr); off += len(hdr)
+            full, rem = divmod(n, 60)
+            fai.append("%s\t%d\t%d\t60\t61\n" % (c, n, off))
+            k = full
+            while k > 0:
+                w = min(k, 17189)
+                f.write(block[:61 * w]); k -= w
+            if rem:
+                f.write(line[:rem] + b"\n")
+            off += full * 61 + (rem + 1 if rem else 0)
+    with open(path + ".fai", "w") as f:
+        f.writelines(fai)
+    ref = Reference(path)
+    _REF[key] = (ref, dict(path=path, bytes=os.path.getsize(path), contigs=len(lens), build_s=round(time.perf_counter() - t0, 2)))
+    return _REF[key]
+
+
 def vcf_leg(ctx, pstore, params, tasks):
-    """native VCF record emit straight from the SoA (no Python rows).  ignore_sequence: REF/ALT are 'N' / '<TYPE>' as with
-    cuteSV's --ignore_sequence; pair types (which always look up one base) are left out of this timing"""
+    """native VCF record emit straight from the SoA (no Python rows): EVERY type of the workload, REF / ALT bases fetched from an
+    on-disk reference through fasta.Reference (mmap + .fai) as generate_output does through pysam (GT:254-262, 297-309, 334,
+    360-365, 431-448).  (r03 timed it with ignore_sequence and without the pair types.)"""
     from cutesv_amd import vcf as vcf_mod
     try:
-        keep = [i for i, (t, c) in enumerate(tasks) if t in ("DEL", "INS")]
-        hb2 = pstore.host_batch([tasks[i] for i in keep], params)
+        ref, ref_info = synthetic_reference(pstore)
+        hb2 = pstore.host_batch(tasks, params)
         r3 = ctx.cluster_batch(hb2)
+        kw = dict(min_size=params.min_size, max_size=params.max_size, genotype=params.genotype, ignore_sequence=False, as_view=True)
         tv = []
         text = b""
         for _ in range(5):
             t0 = time.perf_counter()
-            text, _ = vcf_mod.emit_records(pstore, hb2.segments, r3, None, min_size=params.min_size, max_size=params.max_size,
-                                           genotype=params.genotype, ignore_sequence=True, as_bytes=True)
+            text, _ = vcf_mod.emit_records(pstore, hb2.segments, r3, ref, **kw)
             tv.append(time.perf_counter() - t0)
         # pinned columns -> VCF text: the boundary call + the native emitter, no Python rows in between
-        ts = timed(lambda: vcf_mod.emit_records(pstore, hb2.segments, ctx.cluster_batch(hb2, reuse=True), None, min_size=params.min_size,
-                                                 max_size=params.max_size, genotype=params.genotype, ignore_sequence=True, as_bytes=True), 5)
-        return dict(ms=float(np.median(tv)) * 1e3, records=text.count(b"\n"), bytes=len(text), threads=min(16, os.cpu_count() or 1),
-                    stage_wall_vcf_ms=float(np.median(ts)) * 1e3, ignore_sequence=True)
+        ts = timed(lambda: vcf_mod.emit_records(pstore, hb2.segments, ctx.cluster_batch(hb2, reuse=True), ref, **kw), 5)
+        tn = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            vcf_mod.emit_records(pstore, hb2.segments, r3, ref, **dict(kw, ignore_sequence=True))      # (pair types look one base up regardless)
+            tn.append(time.perf_counter() - t0)
+        types = sorted({t for t, _ in tasks})
+        return dict(ms=float(np.median(tv)) * 1e3, records=int(np.count_nonzero(np.frombuffer(text, np.uint8) == 10)), bytes=len(text), threads=min(16, os.cpu_count() or 1),
+                    stage_wall_vcf_ms=float(np.median(ts)) * 1e3, ignore_sequence=False, types=types, reference=ref_info,
+                    ms_ignore_sequence=float(np.median(tn)) * 1e3)
     except Exception as e:          # noqa: BLE001  (never let the optional leg break the benchmark line)
-        return dict(error=str(e))
+        import traceback
+        return dict(error=repr(e), trace=traceback.format_exc()[-600:])
 
 
 def per_task_leg(ctx, store, params, tasks):
@@ -507,6 +573,8 @@ def compact_workload(ctx, name, a, cpu):
            "parity_vs_oracle": bool(parity), "parity_columns": "int32 (SigStore.pinned())",
            "cpu_baseline_c_mt": {k: cpu["cpu_c_mt"][k] for k in ("value", "cores", "wall_s")},
            "one_shot_speedup_vs_c_mt": cpu["cpu_c_mt"]["wall_s"] * 1e3 / one}
+    if name == "cfg5":
+        out["vcf_emit_native"] = vcf_leg(ctx, pstore, params, tasks)
     if cpu["cpu"] is not None:
         out["cpu_baseline"] = {k: cpu["cpu"][k] for k in ("value", "cores", "wall_s", "full_workload", "sample")}
         out["step_speedup_vs_cpu_baseline"] = cpu["cpu"]["wall_s"] * 1e3 / ms if cpu["cpu"]["full_workload"] else None

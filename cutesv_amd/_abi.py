@@ -8,7 +8,7 @@ import ctypes as C
 
 import numpy as np
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 DEL, INS, DUP, INV, TRA = 0, 1, 2, 3, 4
 SVTYPE_CODE = {"DEL": DEL, "INS": INS, "DUP": DUP, "INV": INV, "TRA": TRA}
 SVTYPE_NAME = {v: k for k, v in SVTYPE_CODE.items()}

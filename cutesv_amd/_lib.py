@@ -42,6 +42,7 @@ SYMBOLS = [
     ("csv_pool_rows", C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     ("csv_pool_append", C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("csv_vcf_emit", C.c_int, None),           # prototype set in cutesv_amd/vcf.py (needs its struct)
+    ("csv_fasta_index", C.c_int64, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
 ]
 
 

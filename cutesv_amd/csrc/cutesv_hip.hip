@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <chrono>
 #include <map>
 #include <mutex>
@@ -131,7 +132,7 @@ struct csv_ctx {
     Buf flush;                                                   // csv_cache_flush scratch
     // rebuild step (slices of `arena_rb`)
     Buf rb_seg, rb_a, rb_b, rb_rid, rb_aux, rb_auxk, rb_major, rb_nodedup, rb_perm0, rb_perm1, rb_hist, rb_tot, rb_partial;
-    Buf rb_oseg, rb_oa, rb_ob, rb_orid, rb_oaux, rb_osrc, rb_segcnt, rb_rank, rb_mx;
+    Buf rb_oseg, rb_oa, rb_ob, rb_orid, rb_oaux, rb_osrc, rb_segcnt, rb_rank, rb_mx, rb_drop;
     // the device-resident signature pool (stand-alone allocations: it outlives the per-call arenas)
     Buf pool_seg, pool_a, pool_b, pool_read, pool_aux, sp_qlen;
     i64 pool_n = 0, pool_cap = 0;
@@ -1280,6 +1281,7 @@ int csv_rebuild_signatures(csv_ctx* c, const csv_rebuild_in* in, csv_rebuild_out
     PL(rb_tot, 256 * 4); PL(rb_partial, (ntile + 2) * 4);
     PL(rb_oseg, n * 4); PL(rb_oa, n * 8); PL(rb_ob, n * 8); PL(rb_orid, n * 4); PL(rb_oaux, n * 4); PL(rb_osrc, n * 4); PL(rb_segcnt, ((size_t)in->n_seg + 2) * 8);
     if (from_pool) { PL(rb_rank, (size_t)in->n_rank * 4); PL(rb_mx, 64); }
+    if (in->tie_order && in->seg_nodedup) PL(rb_drop, n + 64);
 #undef PL
     {
         if (P.total > c->arena_rb.cap) HIP_TRY(c, hipDeviceSynchronize());
@@ -1336,6 +1338,60 @@ int csv_rebuild_signatures(csv_ctx* c, const csv_rebuild_in* in, csv_rebuild_out
     R.nodedup = in->seg_nodedup ? dp<uint8_t>(c->rb_nodedup) : nullptr;
     R.o_seg = dp<int>(c->rb_oseg); R.o_a = dp<i64>(c->rb_oa); R.o_b = dp<i64>(c->rb_ob); R.o_rid = dp<int>(c->rb_orid);
     R.o_aux = dp<int>(c->rb_oaux); R.o_src = dp<int>(c->rb_osrc); R.n_out = (int*)c->cnt.p;
+    R.drop = nullptr;
+    out->n_tie_rows = 0; out->n_tie_dropped = 0;
+    bool ties_settled = false;
+    if (in->tie_order && R.nodedup) {
+        // INS rows that tie on their integer keys: the caller orders them (by sequence) and names the duplicates; the answer is
+        // written into the permutation / a drop map on the device, and the gather below never knows.  The output buffers are
+        // free until the gather: rb_oa holds the list, rb_oseg / rb_orid / rb_ob the answer on its way back.
+        int* d_n = (int*)c->cnt.p;
+        HIP_TRY(c, hipMemsetAsync(d_n, 0, 4, st));
+        HIP_TRY(c, hipMemsetAsync(c->rb_drop.p, 0, (size_t)n, st));
+        hipLaunchKernelGGL(k_rebuild_ties, dim3(div_up(n, 256)), dim3(256), 0, st, R, (int2*)c->rb_oa.p, d_n);
+        int n_list = 0;
+        HIP_TRY(c, hipMemcpyAsync(&n_list, d_n, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipStreamSynchronize(st));
+        if (n_list > 0) {
+            std::vector<int2> lst((size_t)n_list);
+            HIP_TRY(c, hipMemcpy(lst.data(), c->rb_oa.p, (size_t)n_list * 8, hipMemcpyDeviceToHost));
+            std::sort(lst.begin(), lst.end(), [](const int2& x, const int2& y) { return (x.x & 0x7fffffff) < (y.x & 0x7fffffff); });
+            std::vector<int64_t> goff;
+            std::vector<int> src((size_t)n_list), pos((size_t)n_list), order((size_t)n_list, -1);
+            std::vector<uint8_t> drop((size_t)n_list, 0);
+            for (int k = 0; k < n_list; k++) {
+                if (!(lst[k].x & (int)0x80000000)) goff.push_back(k);               // a group's head
+                pos[k] = lst[k].x & 0x7fffffff; src[k] = lst[k].y;
+            }
+            goff.push_back(n_list);
+            const int rc = in->tie_order(in->tie_user, (int64_t)goff.size() - 1, goff.data(), src.data(), order.data(), drop.data());
+            if (rc != 0) return fail(c, CSV_E_INVALID, "tie_order returned %d", rc);
+            // order[] must be a permutation inside every group
+            std::vector<int> nsrc((size_t)n_list);
+            std::vector<uint8_t> nflag((size_t)n_list);
+            std::vector<uint8_t> seen((size_t)n_list, 0);
+            i64 dropped = 0;
+            for (size_t g = 0; g + 1 < goff.size(); g++) {
+                const int64_t g0 = goff[g], g1 = goff[g + 1];
+                for (int64_t k = g0; k < g1; k++) {
+                    const int64_t o = order[k];
+                    if (o < 0 || o >= g1 - g0 || seen[g0 + o]) return fail(c, CSV_E_INVALID, "tie_order: order[] is not a permutation inside group %zu", g);
+                    seen[g0 + o] = 1;
+                    nsrc[g0 + o] = src[k]; nflag[g0 + o] = drop[k] ? 1 : 0;
+                    dropped += drop[k] ? 1 : 0;
+                }
+            }
+            HIP_TRY(c, hipMemcpyAsync(c->rb_oseg.p, pos.data(), (size_t)n_list * 4, hipMemcpyHostToDevice, st));
+            HIP_TRY(c, hipMemcpyAsync(c->rb_orid.p, nsrc.data(), (size_t)n_list * 4, hipMemcpyHostToDevice, st));
+            HIP_TRY(c, hipMemcpyAsync(c->rb_ob.p, nflag.data(), (size_t)n_list, hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(k_rebuild_tie_apply, dim3(div_up(n_list, 256)), dim3(256), 0, st, n_list, dp<int>(c->rb_oseg), dp<int>(c->rb_orid),
+                               dp<uint8_t>(c->rb_ob), const_cast<int*>(R.perm), dp<uint8_t>(c->rb_drop));
+            HIP_TRY(c, hipStreamSynchronize(st));                                       // (the host vectors are the copies' sources)
+            out->n_tie_rows = n_list; out->n_tie_dropped = dropped;
+        }
+        R.drop = dp<uint8_t>(c->rb_drop);
+        ties_settled = true;
+    }
     hipLaunchKernelGGL(k_rebuild_count, dim3(ntile), dim3(256), 0, st, R);
     hipLaunchKernelGGL(k_rebuild_apply, dim3(ntile), dim3(256), 0, st, R);
     // rows per segment and the INS tie count ([n_seg] = ties), from the sorted output
@@ -1351,7 +1407,7 @@ int csv_rebuild_signatures(csv_ctx* c, const csv_rebuild_in* in, csv_rebuild_out
     HIP_TRY(c, hipStreamSynchronize(st));
     HIP_TRY(c, hipEventElapsedTime(&out->ms_device, c->ev[0], c->ev[1]));
     out->n_out = n_out; out->n_passes = npass;
-    out->n_ins_ties = segcnt[(size_t)in->n_seg];
+    out->n_ins_ties = ties_settled ? 0 : segcnt[(size_t)in->n_seg];
     if (out->seg_count) memcpy(out->seg_count, segcnt.data(), (size_t)in->n_seg * 8);
     const bool keep_dev = (in->flags & CSV_RB_KEEP_ON_DEVICE) != 0;
     out->dev_seg_id = out->dev_a = out->dev_b = out->dev_read_id = out->dev_aux = out->dev_src_row = nullptr;

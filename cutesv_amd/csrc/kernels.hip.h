@@ -1775,7 +1775,7 @@ template <int SW> __device__ __forceinline__ u64 sub_ballot(bool p, int g)
 {
     const u64 m = __ballot(p);
     if (SW == 64) return m;
-    return (m >> (g * SW)) & ((1ull << SW) - 1ull);
+    return (m >> (g * SW)) & ((1ull << (SW & 63)) - 1ull);
 }
 // inclusive scans inside a sub-wave: the DPP network simply stops early (16 lanes = one DPP row: row_shr only;
 // 32 lanes: before row_bcast:31)
@@ -1949,7 +1949,7 @@ template <int SW, bool NARROW> __device__ __forceinline__ void indel_unit(const 
     typedef crd_t<NARROW> C;
     constexpr int NSUB = 64 / SW;                      // clusters per wavefront
     constexpr int MLO = SW == 64 ? 32 : 0;
-    constexpr u64 SUBMASK = SW == 64 ? ~0ull : (1ull << SW) - 1ull;
+    constexpr u64 SUBMASK = SW == 64 ? ~0ull : (1ull << (SW & 63)) - 1ull;
     const int lane = lane_id(), sl = lane & (SW - 1), hb = lane & ~(SW - 1), g = lane / SW;
     const int hb4 = hb << 2, last4 = (hb | (SW - 1)) << 2;                       // byte addresses of the sub-wave's first / last lane
     do {

@@ -139,6 +139,7 @@ struct RebuildArgs {
     const int* perm;
     const int* seg; const i64* a; const i64* b; const int* rid; const int* aux; const int* auxk;
     const uint8_t* nodedup;     // per segment: keep every row (nullable)
+    const uint8_t* drop;        // per sorted position, keep-every-row segments only: the caller's tie_order said "duplicate" (nullable)
     int* keep;             // 1 when the sorted row differs from its predecessor
     int* partial;          // per 2048-row tile counts
     int* o_seg; i64* o_a; i64* o_b; int* o_rid; int* o_aux; int* o_src;
@@ -150,7 +151,7 @@ __device__ __forceinline__ int rebuild_keep(const RebuildArgs& R, i64 i)
     if (i >= R.n) return 0;
     if (i == 0) return 1;
     const int p = R.perm ? R.perm[i] : (int)i, q = R.perm ? R.perm[i - 1] : (int)(i - 1);
-    if (R.nodedup && R.nodedup[R.seg[p]]) return 1;
+    if (R.nodedup && R.nodedup[R.seg[p]]) return R.drop ? !R.drop[i] : 1;
     return !(R.seg[p] == R.seg[q] && R.a[p] == R.a[q] && R.b[p] == R.b[q] && R.rid[p] == R.rid[q] && R.aux[p] == R.aux[q]);
 }
 
@@ -188,6 +189,31 @@ __global__ __launch_bounds__(256) void k_rebuild_apply(RebuildArgs R)
         run += __popcll(m);
     }
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) *R.n_out = run;
+}
+
+// The tie groups of the keep-every-row segments in the sorted permutation: position i ties with i - 1 when (segment, a, b, read
+// id) agree.  Every position that belongs to a group is appended to `list` as {i | continues << 31, source row}; the order of
+// the appends does not matter (a few rows per genome: the host sorts them by position).
+__global__ __launch_bounds__(256) void k_rebuild_ties(RebuildArgs R, int2* list, int* n_list)
+{
+    const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (i >= R.n) return;
+    auto ties = [&](i64 x) -> bool {                        // position x continues the group of x - 1
+        if (x <= 0 || x >= R.n) return false;
+        const int p = R.perm ? R.perm[x] : (int)x, q = R.perm ? R.perm[x - 1] : (int)(x - 1);
+        return R.nodedup[R.seg[p]] && R.seg[p] == R.seg[q] && R.a[p] == R.a[q] && R.b[p] == R.b[q] && R.rid[p] == R.rid[q];
+    };
+    const bool cont = ties(i), head = !cont && ties(i + 1);
+    if (cont || head) {
+        const int k = atomicAdd(n_list, 1);
+        list[k] = make_int2((int)i | (cont ? (int)0x80000000 : 0), R.perm ? R.perm[i] : (int)i);
+    }
+}
+// the caller's answer: perm[pos[k]] = src[k], drop[pos[k]] = flag[k]
+__global__ __launch_bounds__(256) void k_rebuild_tie_apply(int n, const int* pos, const int* src, const uint8_t* flag, int* perm, uint8_t* drop)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k < n) { perm[pos[k]] = src[k]; drop[pos[k]] = flag[k]; }
 }
 
 // rows per segment of the sorted, de-duplicated output (o_seg ascends): one thread per segment, two binary searches; and the

@@ -49,6 +49,9 @@ inline char iupac(char c)
     }
 }
 
+struct IupacTable { char t[256]; IupacTable() { for (int c = 0; c < 256; c++) t[c] = iupac((char)c); } };
+const IupacTable kIupac;
+
 // str(round(dv / (dv + dr), 4))  (cuteSV_genotype.py:284): correctly rounded to 4 decimals, then Python's
 // shortest repr, which for such a value is the 4-decimal string without trailing zeros (one decimal kept).
 void put_af(Sink& o, long long dv, long long dr)
@@ -255,7 +258,11 @@ int emit_slice(const csv_vcf_in* in, const int64_t* v, int64_t nv, int ch, int64
         const char* seq = in->chrom_seq ? in->chrom_seq[ch] : nullptr;
         const int64_t slen = in->chrom_len ? in->chrom_len[ch] : 0;
         const char* cname = in->chrom_name[ch];
-        auto base = [&](int64_t i, char& c) -> bool { if (!seq || i < 0 || i >= slen) return false; c = seq[i]; return true; };
+        // a contig read straight from a FASTA file (mmap): line_bases bases, then the line break, per line of line_width bytes
+        const int64_t lb = (in->chrom_line_bases && in->chrom_line_width) ? in->chrom_line_bases[ch] : 0;
+        const int64_t lw = lb > 0 ? in->chrom_line_width[ch] : 0;
+        auto at = [&](int64_t i) -> char { return lb > 0 ? seq[(i / lb) * lw + i % lb] : seq[i]; };
+        auto base = [&](int64_t i, char& c) -> bool { if (!seq || i < 0 || i >= slen) return false; c = at(i); return true; };
         for (int64_t qi = 0; qi < nv; qi++) {
             const int64_t c = v[qi];
             const csv_segment& sg = in->seg[R.call_seg[c]];
@@ -306,7 +313,24 @@ int emit_slice(const csv_vcf_in* in, const int64_t* v, int64_t nv, int ch, int64
                 } else {
                     long long r1 = pos + len;                                           // slice end, clamped like Python
                     if (r1 > slen) r1 = slen;
-                    for (long long i = r0; i < r1; i++) o.put(iupac(seq[i]));
+                    if (!seq && r1 > r0) return CSV_E_INVALID;
+                    // the deleted bases: whole runs of a FASTA line at a time (memcpy), then the IUPAC table over the copy
+                    // (a call, a division and a push_back per base made this slice 95 % of the emitter's time on a 30x genome)
+                    if (r1 > r0) {
+                        const size_t w0 = o.buf.size();
+                        o.buf.resize(w0 + (size_t)(r1 - r0));
+                        char* dst = &o.buf[w0];
+                        if (lb > 0) {
+                            long long i = r0;
+                            while (i < r1) {
+                                const long long in_line = i % lb, run = std::min<long long>(lb - in_line, r1 - i);
+                                memcpy(dst, seq + (i / lb) * lw + in_line, (size_t)run);
+                                dst += run; i += run;
+                            }
+                        } else memcpy(dst, seq + r0, (size_t)(r1 - r0));
+                        char* p = &o.buf[w0];
+                        for (long long k = 0; k < r1 - r0; k++) p[k] = kIupac.t[(unsigned char)p[k]];
+                    }
                     o.put('\t');
                     char b0;
                     if (!base(r0, b0)) return CSV_E_INVALID;
@@ -390,3 +414,58 @@ int emit_slice(const csv_vcf_in* in, const int64_t* v, int64_t nv, int ch, int64
     return CSV_OK;
 }
 }  // namespace
+
+// ---------------------------------------------------------------------------------------- FASTA index
+// The `.fai` of a FASTA file held in memory (mmap): per contig its name (up to the first white space of the header), length,
+// byte offset of the first base, bases per line and bytes per line - what `samtools faidx` writes and pysam.FastaFile reads
+// (generate_output opens the reference with it, cuteSV_genotype.py:254-259).  One memchr-driven pass; lines of a contig must
+// have one length (the last may be shorter), like faidx demands.  Returns the number of contigs (may exceed max_contigs: call
+// again with larger arrays), or -CSV_E_INVALID for a file that cannot be indexed.  name_off / name_len address the header text inside `data`.
+extern "C" int64_t csv_fasta_index(const char* data, int64_t size, int64_t max_contigs, int64_t* name_off, int32_t* name_len,
+                                   int64_t* length, int64_t* offset, int32_t* line_bases, int32_t* line_width)
+{
+    if (!data || size < 0) return -(int64_t)CSV_E_INVALID;
+    int64_t n = 0, p = 0;
+    while (p < size) {
+        if (data[p] != '>') {                                       // (blank lines between records are tolerated)
+            const char* nl = (const char*)memchr(data + p, '\n', (size_t)(size - p));
+            if (!nl) break;
+            if (nl != data + p && !(nl == data + p + 1 && data[p] == '\r')) return -(int64_t)CSV_E_INVALID;      // sequence before any header
+            p = nl - data + 1;
+            continue;
+        }
+        const char* nl = (const char*)memchr(data + p, '\n', (size_t)(size - p));
+        const int64_t hdr_end = nl ? nl - data : size;
+        int64_t e = p + 1;
+        while (e < hdr_end && data[e] != ' ' && data[e] != '\t' && data[e] != '\r') e++;
+        const int64_t seq0 = nl ? hdr_end + 1 : size;
+        int64_t q = seq0, len = 0;
+        int32_t lb = 0, lw = 0;
+        bool last_short = false;
+        while (q < size && data[q] != '>') {
+            const char* l2 = (const char*)memchr(data + q, '\n', (size_t)(size - q));
+            const int64_t le = l2 ? l2 - data : size;                  // end of the line's text
+            int64_t bases = le - q;
+            if (bases > 0 && data[le - 1] == '\r') bases--;
+            const int64_t width = (l2 ? le + 1 : le) - q;
+            if (bases == 0) { q = l2 ? le + 1 : size; last_short = true; continue; }      // an empty line ends the contig's regular part
+            if (last_short) return -(int64_t)CSV_E_INVALID;                     // a longer line after a short one: not indexable
+            if (lb == 0) { if (bases > INT32_MAX || width > INT32_MAX) return -(int64_t)CSV_E_INVALID; lb = (int32_t)bases; lw = (int32_t)width; }
+            else if (bases > lb) return -(int64_t)CSV_E_INVALID;
+            if (bases < lb || (l2 && width != lw)) last_short = true;
+            len += bases;
+            q = l2 ? le + 1 : size;
+        }
+        if (n < max_contigs) {
+            if (name_off) name_off[n] = p + 1;
+            if (name_len) name_len[n] = (int32_t)(e - (p + 1));
+            if (length) length[n] = len;
+            if (offset) offset[n] = seq0;
+            if (line_bases) line_bases[n] = lb;
+            if (line_width) line_width[n] = lw;
+        }
+        n++;
+        p = q;
+    }
+    return n;
+}

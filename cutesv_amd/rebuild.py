@@ -22,18 +22,48 @@ from .columns import SigStore, NameTable, TYPES
 class RebuildIn(C.Structure):
     _fields_ = [("n", C.c_int64), ("n_seg", C.c_int32), ("flags", C.c_int32), ("seg_aux_major", C.c_void_p),
                 ("seg_id", C.c_void_p), ("a", C.c_void_p), ("b", C.c_void_p), ("read_id", C.c_void_p), ("aux", C.c_void_p),
-                ("seg_nodedup", C.c_void_p), ("read_rank", C.c_void_p), ("n_rank", C.c_int64)]
+                ("seg_nodedup", C.c_void_p), ("read_rank", C.c_void_p), ("n_rank", C.c_int64), ("tie_order", C.c_void_p), ("tie_user", C.c_void_p)]
+
+
+# csv_tie_order_fn (include/cutesv_hip.h): int (*)(void* user, int64 n_groups, const int64* group_off, const int32* src_row, int32* order, uint8* drop)
+TIE_ORDER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_uint8))
 
 
 class RebuildOut(C.Structure):
     _fields_ = [("n_out", C.c_int64), ("seg_id", C.c_void_p), ("a", C.c_void_p), ("b", C.c_void_p), ("read_id", C.c_void_p),
                 ("aux", C.c_void_p), ("src_row", C.c_void_p), ("ms_device", C.c_float), ("n_passes", C.c_int32),
                 ("seg_count", C.c_void_p), ("n_ins_ties", C.c_int64), ("dev_seg_id", C.c_void_p), ("dev_a", C.c_void_p), ("dev_b", C.c_void_p),
-                ("dev_read_id", C.c_void_p), ("dev_aux", C.c_void_p), ("dev_src_row", C.c_void_p)]
+                ("dev_read_id", C.c_void_p), ("dev_aux", C.c_void_p), ("dev_src_row", C.c_void_p), ("n_tie_rows", C.c_int64), ("n_tie_dropped", C.c_int64)]
 
 
-def rebuild_columns(ctx, seg_id, a, b, read_id, aux, seg_aux_major, seg_nodedup=None, keep_on_device=False):
+def tie_callback(seq_of_src, half_of_src):
+    """csv_tie_order_fn for INS rows (include/cutesv_hip.h): every tie group - rows that agree in (segment, int(pos), len, read)
+    - ordered by its sequences (Python's stable sort, like the reference's list.sort with the sequence as the last key, main
+    script :774-775) and adjacent rows whose sequence AND x.5 flag are equal too dropped (:958-969).  seq_of_src(row) /
+    half_of_src(row): the caller's data by input row.  Returns the ctypes callback (keep a reference while it is in use)."""
+    def fn(_user, n_groups, group_off, src_row, order, drop):
+        try:
+            for g in range(n_groups):
+                g0, g1 = group_off[g], group_off[g + 1]
+                rows = list(range(g0, g1))
+                rows.sort(key=lambda i: seq_of_src(src_row[i]))
+                prev = None
+                for pos, i in enumerate(rows):
+                    order[i] = pos
+                    cur = (seq_of_src(src_row[i]), int(half_of_src(src_row[i])))
+                    drop[i] = 1 if (prev is not None and cur == prev) else 0
+                    prev = cur
+            return 0
+        except Exception:                      # noqa: BLE001  (an exception must not cross the C frame)
+            import traceback
+            traceback.print_exc()
+            return 1
+    return TIE_ORDER_FN(fn)
+
+
+def rebuild_columns(ctx, seg_id, a, b, read_id, aux, seg_aux_major, seg_nodedup=None, keep_on_device=False, tie_order=None):
     """-> dict(seg_id, a, b, read_id, aux, src_row, ms_device, n_passes, seg_count, n_ins_ties): sorted, de-duplicated rows.
+    tie_order: a `tie_callback(...)`: the tie groups of the keep-every-row segments are settled inside the call (n_ins_ties 0).
     keep_on_device: the sorted columns stay in device memory (CSV_RB_KEEP_ON_DEVICE): the dict then holds `dev` (device
     addresses of a / b / read_id / aux, valid until the context's next rebuild / extraction call) and, from the host side,
     only src_row and seg_count - 4 instead of 28 bytes per row cross PCIe."""
@@ -50,7 +80,8 @@ def rebuild_columns(ctx, seg_id, a, b, read_id, aux, seg_aux_major, seg_nodedup=
     seg_count = np.zeros(len(major), np.int64)
     rin = RebuildIn(n=n, n_seg=len(major), flags=_abi.RB_KEEP_ON_DEVICE if keep_on_device else 0, seg_aux_major=major.ctypes.data,
                     seg_id=seg_id.ctypes.data, a=a.ctypes.data, b=b.ctypes.data, read_id=read_id.ctypes.data, aux=aux.ctypes.data,
-                    seg_nodedup=None if nodedup is None else nodedup.ctypes.data)
+                    seg_nodedup=None if nodedup is None else nodedup.ctypes.data,
+                    tie_order=None if tie_order is None else C.cast(tie_order, C.c_void_p))
     if keep_on_device:
         rout = RebuildOut(src_row=o["src_row"].ctypes.data, seg_count=seg_count.ctypes.data)
     else:
@@ -63,6 +94,7 @@ def rebuild_columns(ctx, seg_id, a, b, read_id, aux, seg_aux_major, seg_nodedup=
     out["n_passes"] = int(rout.n_passes)
     out["seg_count"] = seg_count
     out["n_ins_ties"] = int(rout.n_ins_ties)
+    out["n_tie_rows"], out["n_tie_dropped"] = int(rout.n_tie_rows), int(rout.n_tie_dropped)
     out["n_out"] = k
     if keep_on_device:
         out["dev"] = dict(a=rout.dev_a, b=rout.dev_b, read_id=rout.dev_read_id, aux=rout.dev_aux, seg_id=rout.dev_seg_id, src_row=rout.dev_src_row)
@@ -71,12 +103,15 @@ def rebuild_columns(ctx, seg_id, a, b, read_id, aux, seg_aux_major, seg_nodedup=
 
 def rebuild_to_device_batch(ctx, chroms, per_type, params_segment, reads=None):
     """The rebuild -> cluster hand-off without a host round trip (the reference's dataflow main script :750-857 -> :1113-1199):
-    unsorted per-type rows (as store_from_unsorted takes them; no INS sequences: the integer columns decide) are sorted and
-    de-duplicated on the device and STAY there; returns (batch, tasks, src_row) where `batch` is an `_abi.HostBatch.on_device`
-    whose columns are the rebuild's device buffers, `tasks` the (type, chromosome) pairs of its segments in the reference's
-    order and `src_row` the input row of every sorted row (to carry read names / sequences on the host).
+    unsorted per-type rows (as store_from_unsorted takes them) are sorted and de-duplicated on the device and STAY there;
+    returns (batch, tasks, src_row) where `batch` is an `_abi.HostBatch.on_device` whose columns are the rebuild's device
+    buffers, `tasks` the (type, chromosome) pairs of its segments in the reference's order and `src_row` the input row of every
+    sorted row (to carry read names / sequences on the host).
     params_segment(svtype, chrom_index, begin, end) -> csv_segment record.
-    Raises when INS rows tie on their integer columns (their order depends on the sequences: use store_from_unsorted)."""
+    INS rows with `seq` (and `half`): rows that tie on (chromosome, int(pos), len, read) are ordered by their sequences and
+    de-duplicated on the whole tuple as the reference does - the few tie rows' indices visit the host through the library's
+    tie_order callback, the columns do not (r03 raised on the first tie and sent the whole genome through host memory).
+    Without `seq` the integer columns decide."""
     order = sorted(range(len(chroms)), key=lambda i: chroms[i])
     crank = np.zeros(len(chroms), np.int64)
     crank[order] = np.arange(len(chroms))
@@ -96,11 +131,16 @@ def rebuild_to_device_batch(ctx, chroms, per_type, params_segment, reads=None):
         if t in ("INV", "TRA"):
             major[ti * len(chroms):(ti + 1) * len(chroms)] = 1
     ti_ins = TYPES.index("INS")
-    nodedup[ti_ins * len(chroms):(ti_ins + 1) * len(chroms)] = 1
-    r = rebuild_columns(ctx, cat["seg"], cat["a"], cat["b"], cat["rid"], cat["aux"], major, nodedup, keep_on_device=True)
-    if r["n_ins_ties"]:
-        raise ValueError("%d INS rows tie on (chromosome, position, length, read): their order depends on the inserted sequences; "
-                         "finish them on the host (rebuild.store_from_unsorted)" % r["n_ins_ties"])
+    cb = None
+    ins = per_type.get("INS")
+    if ins is not None and ins.get("seq") is not None and len(ins["a"]):
+        nodedup[ti_ins * len(chroms):(ti_ins + 1) * len(chroms)] = 1
+        ins_base = sum(len(per_type[t]["a"]) for t in TYPES[:ti_ins] if t in per_type)
+        seqs = ins["seq"]
+        half = ins.get("half")
+        cb = tie_callback(lambda s_: seqs[s_ - ins_base], (lambda s_: half[s_ - ins_base]) if half is not None else (lambda s_: 0))
+    r = rebuild_columns(ctx, cat["seg"], cat["a"], cat["b"], cat["rid"], cat["aux"], major, nodedup, keep_on_device=True, tie_order=cb)
+    assert r["n_ins_ties"] == 0
     off = np.r_[0, np.cumsum(r["seg_count"])]
     segs, tasks = [], []
     for s in range(n_seg):
@@ -137,7 +177,7 @@ def pool_append(ctx, seg_id, a, b, read, aux):
     ctx._check(lib().csv_pool_append(ctx._h, len(a), seg_id.ctypes.data, a.ctypes.data, b.ctypes.data, read.ctypes.data, aux.ctypes.data))
 
 
-def rebuild_pool(ctx, read_rank, seg_aux_major, seg_nodedup=None, keep_on_device=True):
+def rebuild_pool(ctx, read_rank, seg_aux_major, seg_nodedup=None, keep_on_device=True, tie_order=None):
     """csv_rebuild_signatures over the context's pool (CSV_RB_FROM_POOL): the rows the extraction kernels left on the device
     (extract.cigar_signatures(pool=...)) and those appended with pool_append, sorted and de-duplicated; a row's read index is
     replaced by read_rank[index] (rank of the read's name in Python string order).  Same result dict as rebuild_columns;
@@ -154,12 +194,14 @@ def rebuild_pool(ctx, read_rank, seg_aux_major, seg_nodedup=None, keep_on_device
         o.update(seg_id=np.empty(n, np.int32), a=np.empty(n, np.int64), b=np.empty(n, np.int64), read_id=np.empty(n, np.int32), aux=np.empty(n, np.int32))
     seg_count = np.zeros(len(major), np.int64)
     rin = RebuildIn(n=0, n_seg=len(major), flags=_abi.RB_FROM_POOL | (_abi.RB_KEEP_ON_DEVICE if keep_on_device else 0), seg_aux_major=major.ctypes.data,
-                    seg_nodedup=None if nodedup is None else nodedup.ctypes.data, read_rank=rank.ctypes.data, n_rank=len(rank))
+                    seg_nodedup=None if nodedup is None else nodedup.ctypes.data, read_rank=rank.ctypes.data, n_rank=len(rank),
+                    tie_order=None if tie_order is None else C.cast(tie_order, C.c_void_p))
     rout = RebuildOut(seg_count=seg_count.ctypes.data, **{k: v.ctypes.data for k, v in o.items()})
     ctx._check(L.csv_rebuild_signatures(ctx._h, C.byref(rin), C.byref(rout)))
     k = int(rout.n_out)
     r = {name: v[:k] for name, v in o.items()}
-    r.update(ms_device=float(rout.ms_device), n_passes=int(rout.n_passes), seg_count=seg_count, n_ins_ties=int(rout.n_ins_ties), n_out=k)
+    r.update(ms_device=float(rout.ms_device), n_passes=int(rout.n_passes), seg_count=seg_count, n_ins_ties=int(rout.n_ins_ties), n_out=k,
+             n_tie_rows=int(rout.n_tie_rows), n_tie_dropped=int(rout.n_tie_dropped))
     if keep_on_device:
         r["dev"] = dict(a=rout.dev_a, b=rout.dev_b, read_id=rout.dev_read_id, aux=rout.dev_aux, seg_id=rout.dev_seg_id, src_row=rout.dev_src_row)
     return r

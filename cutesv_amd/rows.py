@@ -52,7 +52,7 @@ def _rows_in(store, segments, res):
     n = res.n_calls
     # (an explicit name table / explicit sequences: only the entries these calls mention are encoded, unless the store already
     # holds its full blobs - see SigStore.names_blob)
-    nb = store.names_blob(picks=store.read_id[res.arrays["support_sig"][:res.n_support]])
+    nb = store.names_blob(picks=store.read_id[res.arrays["support_sig"][:res.n_support]] if store.names.names is not None else None)
     ib = store.ins_blob(picks=res.arrays["seq_pick"][:n])
     gl = res.arrays["gl_idx"][:n]
     glb, glo = gl_table_blob(np.unique(gl[gl >= 0]) if n else ())

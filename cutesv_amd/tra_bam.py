@@ -41,9 +41,14 @@ def window_status(alignments, s, e, names, up_bound, itround, chunk=2048):
         if not block:
             return 0
         flag = np.fromiter((a.flag for a in block), np.int64, len(block))
-        start = np.fromiter((a.reference_start for a in block), np.int64, len(block))
-        end = np.fromiter((a.reference_end for a in block), np.int64, len(block))
         primary = (flag == 0) | (flag == 16)
+        # coordinates of the primary records only: fetch() also yields records without an end (an unmapped mate placed at its
+        # partner's position has reference_end None), and the reference never looks at theirs either (`flag not in (0, 16)`)
+        start = np.zeros(len(block), np.int64)
+        end = np.zeros(len(block), np.int64)
+        for i in np.flatnonzero(primary).tolist():
+            start[i] = block[i].reference_start or 0
+            end[i] = block[i].reference_end or 0
         spanning = primary & (start < s) & (end > e)
         k = seen + 1 + np.arange(len(block))                                # position in the stream
         n_primary = primary_seen + np.cumsum(primary)

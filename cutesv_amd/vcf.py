@@ -25,6 +25,7 @@ class VcfIn(C.Structure):
         ("gl_key", C.c_void_p), ("gl_str", C.POINTER(C.c_char_p)), ("n_gl", C.c_int32),
         ("min_size", C.c_int64), ("max_size", C.c_int64),
         ("genotype", C.c_int32), ("report_readid", C.c_int32), ("ignore_sequence", C.c_int32), ("reserved", C.c_int32),
+        ("chrom_line_bases", C.c_void_p), ("chrom_line_width", C.c_void_p),
     ]
 
 
@@ -36,20 +37,25 @@ def _csr(strings):
     return blob, off
 
 
-_OUT_BUF = None
+import threading
+
+_TLS = threading.local()          # the recycled output buffer is per thread: csv_vcf_emit runs with the GIL released and supports
+                                  # concurrent callers (a second caller gets a worker team of its own), so must its caller's buffer
 
 
 def emit_records(store, segments, res, reference, min_size=30, max_size=100000, genotype=False, report_readid=False,
-                 ignore_sequence=False, svid=None, as_bytes=False):
+                 ignore_sequence=False, svid=None, as_bytes=False, as_view=False):
     """calls of one batch -> (VCF body text, svid counters).
 
     segments   the csv_segment records the batch was run with (HostBatch.segments)
     res        _abi.HostResult of that batch
-    reference  {chromosome name: sequence (str or bytes)}; may miss chromosomes without calls
+    reference  a fasta.Reference (memory-mapped FASTA + .fai: bases are read in C straight from the mapping), or
+               {chromosome name: sequence (str or bytes)}; may miss chromosomes without calls
     svid       running counters [INS, DEL, BND, DUP, INV] (main script :1209-1213), advanced in place
     as_bytes   return the text as `bytes` (what a file is written from) instead of decoding it to `str`
+    as_view    return a memoryview of this thread's output buffer instead (valid until the thread's next emit_records call):
+               `f.write(view)` needs no copy of the text - with real REF sequences a 30x genome's records are ~30 MB
     """
-    global _OUT_BUF
     L = lib()
     L.csv_vcf_emit.restype = C.c_int
     L.csv_vcf_emit.argtypes = [C.POINTER(VcfIn), C.c_char_p, C.c_int64, C.POINTER(C.c_int64), C.c_void_p]
@@ -59,10 +65,20 @@ def emit_records(store, segments, res, reference, min_size=30, max_size=100000, 
     call_type = segs["svtype"][t["call_seg"]] if n else np.zeros(0, np.int32)
     nch = len(store.chroms)
     names = (C.c_char_p * nch)(*[c.encode() for c in store.chroms])
-    seq_bytes = [None if reference is None or c not in reference else
-                 (reference[c] if isinstance(reference[c], bytes) else reference[c].encode()) for c in store.chroms]
-    seqs = (C.c_char_p * nch)(*seq_bytes)
-    clen = np.array([0 if s is None else len(s) for s in seq_bytes], np.int64)
+    from .fasta import Reference
+    line_bases = line_width = None
+    if isinstance(reference, Reference):
+        ent = [reference.contig(c) if c in reference else (0, 0, 0, 0) for c in store.chroms]
+        seqs = (C.c_void_p * nch)(*[e[0] or None for e in ent])
+        clen = np.array([e[1] for e in ent], np.int64)
+        line_bases = np.array([e[2] for e in ent], np.int32)
+        line_width = np.array([e[3] for e in ent], np.int32)
+        seq_bytes = reference                              # (kept alive below)
+    else:
+        seq_bytes = [None if reference is None or c not in reference else
+                     (reference[c] if isinstance(reference[c], bytes) else reference[c].encode()) for c in store.chroms]
+        seqs = (C.c_char_p * nch)(*seq_bytes)
+        clen = np.array([0 if s is None else len(s) for s in seq_bytes], np.int64)
     order = sorted(range(nch), key=lambda i: store.chroms[i])
     rank = np.zeros(nch, np.int32)
     rank[order] = np.arange(nch, dtype=np.int32)
@@ -83,7 +99,9 @@ def emit_records(store, segments, res, reference, min_size=30, max_size=100000, 
     if svid is None:
         svid = np.zeros(5, np.int64)
     vin = VcfIn(res=C.pointer(res.c), seg=segs.ctypes.data, n_seg=len(segs), n_chrom=nch,
-                chrom_name=names, chrom_seq=seqs, chrom_len=clen.ctypes.data, chrom_rank=rank.ctypes.data,
+                chrom_name=names, chrom_seq=C.cast(seqs, C.POINTER(C.c_char_p)), chrom_len=clen.ctypes.data, chrom_rank=rank.ctypes.data,
+                chrom_line_bases=None if line_bases is None else line_bases.ctypes.data,
+                chrom_line_width=None if line_width is None else line_width.ctypes.data,
                 ins_alt=alt_blob, ins_alt_off=None if alt_off is None else alt_off.ctypes.data,
                 rnames=rn_blob, rnames_off=None if rn_off is None else rn_off.ctypes.data,
                 strand_name=strands, gl_key=keys.ctypes.data, gl_str=gl_strs, n_gl=len(keys),
@@ -91,17 +109,20 @@ def emit_records(store, segments, res, reference, min_size=30, max_size=100000, 
                 ignore_sequence=int(bool(ignore_sequence)))
     cap = 256 * max(n, 1) + (len(alt_blob) if alt_blob else 0) + (len(rn_blob) if rn_blob else 0) + 4096
     for _ in range(2):
-        if _OUT_BUF is None or len(_OUT_BUF) < cap:       # (recycled: a fresh zero-filled buffer per call costs as much as the emitter)
-            _OUT_BUF = np.empty(cap, np.uint8)
+        buf = getattr(_TLS, "buf", None)
+        if buf is None or len(buf) < cap:                 # (recycled: a fresh zero-filled buffer per call costs as much as the emitter)
+            buf = _TLS.buf = np.empty(cap, np.uint8)
         need = C.c_int64(0)
         sv = svid.copy()
-        rc = L.csv_vcf_emit(C.byref(vin), C.cast(_OUT_BUF.ctypes.data, C.c_char_p), len(_OUT_BUF), C.byref(need), sv.ctypes.data)
+        rc = L.csv_vcf_emit(C.byref(vin), C.cast(buf.ctypes.data, C.c_char_p), len(buf), C.byref(need), sv.ctypes.data)
         if rc == _abi.E_CAPACITY:
             cap = need.value + 16
             continue
         if rc != _abi.OK:
             raise RuntimeError("csv_vcf_emit: %s (a reference sequence is missing or too short?)" % _abi.ERR_NAME.get(rc, rc))
         svid[:] = sv
-        raw = _OUT_BUF[:need.value].tobytes()
+        if as_view:
+            return memoryview(buf)[:need.value], svid
+        raw = buf[:need.value].tobytes()
         return (raw if as_bytes else raw.decode()), svid
     raise RuntimeError("csv_vcf_emit: capacity retry failed")

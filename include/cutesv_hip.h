@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CSV_ABI_VERSION 5
+#define CSV_ABI_VERSION 6
 
 /* SV types: one (chromosome, type) pair is one segment == one reference pool task
  * (MAIN:1116-1189).  Order of the enum is irrelevant to results. */
@@ -283,6 +283,18 @@ enum {
                                         aux of csv_rebuild_in are ignored; a row's read index is replaced by read_rank[index] (the
                                         rank of the read's NAME: string order is the caller's business); src_row numbers pool rows */
 };
+/* The rows of the keep-every-row segments (seg_nodedup) whose integer keys tie - (segment, a, b, read_id) equal - are ordered
+ * by data only the caller has: the reference sorts INS rows by (chr, int(pos), len, read, SEQUENCE) and drops a row only when
+ * the whole tuple repeats, the x.5 of a split-read position included (MAIN:774-775, :958-969).  csv_rebuild_signatures sorts on
+ * the integer columns on the device, hands the tie groups - a few rows per genome - to this function ONCE, on the calling
+ * thread, and applies the answer to the device-resident permutation before the rows are gathered: the columns never come to
+ * the host for it (CSV_RB_KEEP_ON_DEVICE -> CSV_IN_DEVICE_COLUMNS stays intact).
+ *   rows [group_off[g], group_off[g + 1]) of src_row are group g, in the device's stable order (= input order);
+ *   order[i]  the callee's position of row i INSIDE its group (a permutation of 0 .. size - 1 per group),
+ *   drop[i]   1: the row is a duplicate and is removed.
+ * Return 0; anything else fails the call with CSV_E_INVALID. */
+typedef int (*csv_tie_order_fn)(void* user, int64_t n_groups, const int64_t* group_off, const int32_t* src_row, int32_t* order, uint8_t* drop);
+
 typedef struct csv_rebuild_in {
     int64_t        n;
     int32_t        n_seg;
@@ -295,9 +307,11 @@ typedef struct csv_rebuild_in {
     const int32_t* aux;
     const uint8_t* seg_nodedup;     /* n_seg or NULL: 1 = sort this segment but keep every row.  INS rows are equal only when
                                        their sequences and the x.5 of a split-read position are equal too (MAIN:228, :774-775):
-                                       the caller finishes those few tie groups on the host (cutesv_amd/rebuild.py) */
+                                       tie_order (below) settles those few groups; without it the caller finishes them on the host */
     const int32_t* read_rank;       /* CSV_RB_FROM_POOL: n_rank ranks, indexed by the pool rows' read index */
     int64_t        n_rank;
+    csv_tie_order_fn tie_order;     /* nullable (ABI v6): see csv_tie_order_fn */
+    void*          tie_user;
 } csv_rebuild_in;
 
 typedef struct csv_rebuild_out {
@@ -312,14 +326,17 @@ typedef struct csv_rebuild_out {
     int32_t  n_passes;              /* out: radix passes executed */
     int64_t* seg_count;             /* n_seg or NULL: rows of every segment after the de-duplication (the csv_segment ranges of the
                                        sorted columns follow from these by a prefix sum) */
-    int64_t  n_ins_ties;            /* out: rows of seg_nodedup segments that agree with their predecessor in (segment, a, b, read_id):
-                                       0 means the device order is final, otherwise the caller finishes those groups on the host */
+    int64_t  n_ins_ties;            /* out: rows of seg_nodedup segments that agree with their predecessor in (segment, a, b, read_id) and
+                                       were NOT settled by tie_order: 0 means the device order is final, otherwise (no tie_order given)
+                                       the caller finishes those groups on the host */
     void*    dev_seg_id;            /* out (CSV_RB_KEEP_ON_DEVICE): device addresses of the sorted columns, n_out rows each: */
     void*    dev_a;                 /*   int32 seg_id, int64 a, int64 b, int32 read_id, int32 aux, int32 src_row */
     void*    dev_b;
     void*    dev_read_id;
     void*    dev_aux;
     void*    dev_src_row;
+    int64_t  n_tie_rows;            /* out (ABI v6): rows handed to tie_order, and how many of them it dropped */
+    int64_t  n_tie_dropped;
 } csv_rebuild_out;
 
 int csv_rebuild_signatures(csv_ctx* ctx, const csv_rebuild_in* in, csv_rebuild_out* out);
@@ -469,12 +486,24 @@ typedef struct csv_vcf_in {
     int32_t              report_readid;
     int32_t              ignore_sequence;
     int32_t              reserved;
+    /* (ABI v6) chrom_seq[c] may point INTO a FASTA file (mmap) instead of at a contiguous string: per chromosome the bases per
+     * line and the bytes per line (bases + line break) of its `.fai` entry; NULL arrays or a 0 entry = contiguous */
+    const int32_t*       chrom_line_bases;
+    const int32_t*       chrom_line_width;
 } csv_vcf_in;
 
 /* Writes the records into `out` (capacity `cap` bytes) and returns CSV_OK, or CSV_E_CAPACITY with
  * *n_written = the needed size.  svid[5] = running record counters in the order INS, DEL, BND, DUP, INV
  * (main script :1209-1213); pass zeros for a fresh file, they are advanced in place. */
 int csv_vcf_emit(const csv_vcf_in* in, char* out, int64_t cap, int64_t* n_written, int64_t* svid);
+
+/* The `.fai` of a FASTA file held in memory (e.g. mmap): what pysam.FastaFile / `samtools faidx` give generate_output
+ * (GT:254-259) - per contig its name (name_off / name_len address the header text inside `data`, up to the first white space),
+ * length, byte offset of the first base, bases per line and bytes per line.  Returns the number of contigs found (call again
+ * with larger arrays when it exceeds max_contigs; NULL arrays are skipped), or -CSV_E_INVALID for a file that cannot
+ * be indexed (sequence before a header, lines of unequal length inside a contig).  No GPU work. */
+int64_t csv_fasta_index(const char* data, int64_t size, int64_t max_contigs, int64_t* name_off, int32_t* name_len,
+                        int64_t* length, int64_t* offset, int32_t* line_bases, int32_t* line_width);
 
 /* ---------------------------------------------------------------------------------------------
  * Host-side row builder: the structure-of-arrays result -> the row lists the reference's resolvers return

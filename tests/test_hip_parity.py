@@ -761,6 +761,79 @@ def test_gpu_rebuild_identical_to_reference_rebuild(ctx):
             assert [x for x in got[t] if x[-1] == ch] == rows, (case["name"], t, ch)
 
 
+def _rebuild_case_columns(case):
+    """the raw candidates of a rebuild_order.json.gz case as unsorted per-type columns (+ names, strands, chromosomes)"""
+    from cutesv_amd.columns import intern_names, BND_CODE
+    from helpers import rebuild_case_inputs
+    per, reads = rebuild_case_inputs(case)
+    chroms = sorted({x[-1] for t in per for x in per[t]} | {x[2] for x in per["TRA"]} | {r[-1] for r in reads})
+    cidx = {c: i for i, c in enumerate(chroms)}
+    npos = {"DEL": 2, "INS": 2, "DUP": 2, "INV": 3, "TRA": 4}
+    uniq, _ = intern_names([x[npos[t]] for t in per for x in per[t]] + [r[3] for r in reads])
+    rank = {n: i for i, n in enumerate(uniq)}
+    strands = sorted({x[0] for x in per["INV"]})
+    cols = {}
+    for t, lst in per.items():
+        d = dict(chrom=[cidx[x[-1]] for x in lst], read_id=[rank[x[npos[t]]] for x in lst])
+        if t in ("DEL", "DUP"):
+            d.update(a=[int(x[0]) for x in lst], b=[int(x[1]) for x in lst], aux=[0] * len(lst))
+        elif t == "INS":
+            d.update(a=[int(x[0]) for x in lst], b=[int(x[1]) for x in lst], aux=[len(x[3]) for x in lst],
+                     seq=[x[3] for x in lst], half=[int(x[0] != int(x[0])) for x in lst])
+        elif t == "INV":
+            d.update(a=[int(x[1]) for x in lst], b=[int(x[2]) for x in lst], aux=[strands.index(x[0]) for x in lst])
+        else:
+            d.update(a=[int(x[1]) for x in lst], b=[int(x[3]) for x in lst], aux=[cidx[x[2]] * 8 + BND_CODE[x[0]] for x in lst])
+        cols[t] = d
+    return per, cols, chroms, uniq, strands
+
+
+def test_ins_ties_are_settled_without_the_columns_leaving_the_device(ctx):
+    """main script :774-775, :958-969 through CSV_RB_KEEP_ON_DEVICE -> CSV_IN_DEVICE_COLUMNS: INS rows that agree in
+    (chr, int(pos), len, read) are ordered by their sequences and de-duplicated on the whole tuple by the library's tie_order
+    callback - only those rows' indices visit the host.  The sorted order (read back through src_row) is the reference's own
+    (rebuild_order.json.gz, whose cases hold sequence-only and x.5-only differences), and clustering the device-resident
+    columns gives the calls of the store the host-finished path builds.  r03 raised ValueError on the first tie."""
+    from cutesv_amd import rebuild
+    from cutesv_amd.columns import NameTable, TYPES
+    from helpers import rebuild_expected
+    p = Params.ont(min_support=2)
+    tie_rows = 0
+    for case in load_json("rebuild_order.json.gz"):
+        per, cols, chroms, uniq, strands = _rebuild_case_columns(case)
+        st, _ = rebuild.store_from_unsorted(ctx, chroms, cols, names=NameTable(uniq), strands=tuple(strands))     # host finish (r03)
+
+        def seg_of(t, ci, beg, end):
+            rec = st.segment(t, chroms[ci], p).copy()
+            rec["sig_begin"], rec["sig_end"] = beg, end
+            return rec
+        batch, tasks, src_row = rebuild.rebuild_to_device_batch(ctx, chroms, cols, seg_of)
+        # the device order, read back through src_row, is the reference's list for every (type, chromosome)
+        base, flat = {}, []
+        for t in TYPES:
+            base[t] = len(flat)
+            flat.extend((t, x) for x in per.get(t, []))
+        want = rebuild_expected(case)
+        got = {}
+        for sr in src_row.tolist():
+            t, x = flat[sr]
+            row = tuple([int(x[0])] + list(x[1:])) if t in ("DEL", "INS", "DUP") else tuple(x)
+            got.setdefault((t, x[-1]), []).append(row)
+        assert set(got) == set(want), case["name"]
+        for k, rows in want.items():
+            assert got[k] == rows, (case["name"], k)
+        # ... and the cluster stage reads those columns where they are
+        assert batch.n_sig == st.n_sig
+        a = ctx.cluster_batch(batch).trimmed()
+        b = ctx.cluster_batch(st.host_batch(tasks, p)).trimmed()
+        for f in ("call_seg", "bp1", "bp2", "support", "cipos", "cilen", "search_pos", "seq_pick", "support_off", "support_sig"):
+            assert np.array_equal(a[f], b[f]), (case["name"], f)
+        ins = cols["INS"]
+        key = list(zip(ins["chrom"], ins["a"], ins["b"], ins["read_id"]))
+        tie_rows += len(key) - len(set(key))
+    assert tie_rows > 0                                                 # (the fixture does hold tie groups)
+
+
 def test_cigar_scan_identical_to_reference_and_oracle(ctx):
     """csv_cigar_signatures (8f row 4): the reference's candidate lists on the golden reads, and the oracle's arrays bit for
     bit on a large random batch (reads of 1 .. 5000 operations, so that the 64-operation steps, the carried merge state

@@ -81,3 +81,65 @@ def test_fasta_reader(tmp_path):
     p.write_text(">chr1 desc\nACGT\nNNAC\n>chr2\nGG\n\n>chr3\n")
     assert read_fasta(str(p)) == {"chr1": "ACGTNNAC", "chr2": "GG", "chr3": ""}
     assert read_fasta(str(p), only={"chr2"}) == {"chr2": "GG"}
+
+
+def _write_fasta(path, seqs, width, newline="\n"):
+    with open(path, "w", newline="") as f:
+        for name, s in seqs.items():
+            f.write(">%s some description%s" % (name, newline))
+            for i in range(0, len(s), width):
+                f.write(s[i:i + width] + newline)
+
+
+def test_fasta_index_and_mapped_reference(tmp_path):
+    """fasta.Reference: the native indexer (csv_fasta_index) gives what `samtools faidx` would (name, length, offset, bases per
+    line, bytes per line), an existing .fai is read instead, and fetch() returns the contigs' bases; files that cannot be
+    indexed are refused"""
+    import pytest
+    from cutesv_amd.fasta import Reference, read_fasta
+    seqs = {"chr1": synth.reference_sequence(1000, seed=1), "chr2": synth.reference_sequence(61, seed=2), "chrE": "", "chr3": "ACGTN" * 24}
+    for width, nl in ((60, "\n"), (7, "\n"), (50, "\r\n")):
+        fa = tmp_path / ("w%d%d.fa" % (width, len(nl)))
+        _write_fasta(fa, seqs, width, nl)
+        ref = Reference(str(fa), write_fai=True)
+        assert ref.names == list(seqs)
+        assert ref.length.tolist() == [len(s) for s in seqs.values()]
+        for i, (n, s) in enumerate(seqs.items()):
+            if s:
+                assert int(ref.line_bases[i]) == min(width, len(s)) and int(ref.line_width[i]) == min(width, len(s)) + len(nl)
+            assert ref.fetch(n) == s and ref.fetch(n, 5, 70) == s[5:70]
+        again = Reference(str(fa))                               # through the .fai this time
+        assert again.names == ref.names and again.offset.tolist() == ref.offset.tolist() and again.fetch("chr1", 900) == seqs["chr1"][900:]
+        assert read_fasta(str(fa)) == seqs
+    bad = tmp_path / "bad.fa"
+    bad.write_text(">c\nACGT\nAC\nACGT\n")
+    with pytest.raises(ValueError):
+        Reference(str(bad))
+
+
+def test_vcf_text_from_a_mapped_fasta_is_the_text_from_strings(tmp_path):
+    """REF / ALT bases read in C straight from a memory-mapped FASTA (line_bases / line_width arithmetic) give the records the
+    whole-contig strings give - the reference's text (vcf_lines.json.gz) - DEL slices across line breaks and pair types included"""
+    from cutesv_amd.fasta import Reference
+    small = {c["name"]: c for c in load_json("small_cases.json.gz")}
+    golden = load_json("vcf_lines.json.gz")
+    done = 0
+    for g in golden:
+        if g["flags"].get("ignore_sequence"):
+            continue
+        case = small[g["case"]]
+        st = store_from_json(case["store"])
+        p = Params(**case["params"])
+        ref = {c: synth.reference_sequence(g["ref_len"], seed=g["ref_seed0"] + i) for i, c in enumerate(st.chroms)}
+        fa = tmp_path / ("ref%d.fa" % done)
+        _write_fasta(fa, ref, 60 if done % 2 == 0 else 17)
+        mapped = Reference(str(fa))
+        tasks = [(t, c) for t, c, _ in case["rows"]]
+        hb = st.host_batch(tasks, p)
+        res = oracle.cluster_batch(hb, per_sig=False)
+        text, _ = vcf.emit_records(st, hb.segments, res, mapped, min_size=p.min_size, max_size=p.max_size, genotype=p.genotype, **g["flags"])
+        assert _canon(text) == _canon(g["text"]), "%s %s: %s" % (g["case"], g["flags"], _first_diff(_canon(text), _canon(g["text"])))
+        done += 1
+        if done >= 8:
+            break
+    assert done >= 4
