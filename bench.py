@@ -348,6 +348,7 @@ def vcf_leg(ctx, pstore, params, tasks):
             t0 = time.perf_counter()
             text, _ = vcf_mod.emit_records(pstore, hb2.segments, r3, ref, **kw)
             tv.append(time.perf_counter() - t0)
+        n_rec, n_bytes = int(np.count_nonzero(np.frombuffer(text, np.uint8) == 10)), len(text)      # (the view is this thread's buffer: read it now)
         # pinned columns -> VCF text: the boundary call + the native emitter, no Python rows in between
         ts = timed(lambda: vcf_mod.emit_records(pstore, hb2.segments, ctx.cluster_batch(hb2, reuse=True), ref, **kw), 5)
         tn = []
@@ -356,7 +357,7 @@ def vcf_leg(ctx, pstore, params, tasks):
             vcf_mod.emit_records(pstore, hb2.segments, r3, ref, **dict(kw, ignore_sequence=True))      # (pair types look one base up regardless)
             tn.append(time.perf_counter() - t0)
         types = sorted({t for t, _ in tasks})
-        return dict(ms=float(np.median(tv)) * 1e3, records=int(np.count_nonzero(np.frombuffer(text, np.uint8) == 10)), bytes=len(text), threads=min(16, os.cpu_count() or 1),
+        return dict(ms=float(np.median(tv)) * 1e3, records=n_rec, bytes=n_bytes, threads=min(16, os.cpu_count() or 1),
                     stage_wall_vcf_ms=float(np.median(ts)) * 1e3, ignore_sequence=False, types=types, reference=ref_info,
                     ms_ignore_sequence=float(np.median(tn)) * 1e3)
     except Exception as e:          # noqa: BLE001  (never let the optional leg break the benchmark line)

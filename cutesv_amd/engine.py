@@ -207,16 +207,35 @@ class Registered:
         return self.ok
 
 
+_REGISTERED = {}                   # address -> Registered: registrations made through host_register live until host_unregister
+
+
 def host_register(arr):
-    """page-lock an existing contiguous numpy array in place; returns a `Registered` handle (truthy on success) that owns
-    the registration: drop it, or call .close(), before the array's memory is released"""
+    """page-lock an existing contiguous numpy array in place (csv_host_register).  The registration (and the array) stays alive
+    until `host_unregister(arr)` - the contract of rounds 1-2: `if host_register(a): ... host_unregister(a)` - whatever
+    the caller does with the returned handle (truthy on success).  For a registration that ends with a scope use
+    `host_register_scoped`."""
+    h = Registered(arr)
+    if h.ok:
+        _REGISTERED[int(arr.ctypes.data)] = h
+    return h
+
+
+def host_register_scoped(arr):
+    """like host_register, but the returned `Registered` handle OWNS the registration: dropping it (or .close()) unregisters"""
     return Registered(arr)
 
 
 def host_unregister(arr):
-    """`arr`: the handle host_register returned, or (legacy) the array itself"""
+    """`arr`: the array that was registered, or the handle host_register / host_register_scoped returned"""
     if isinstance(arr, Registered):
+        _REGISTERED.pop(int(arr.arr.ctypes.data), None)
         ok = arr.ok
         arr.close()
+        return ok
+    h = _REGISTERED.pop(int(arr.ctypes.data), None)
+    if h is not None:
+        ok = h.ok
+        h.close()
         return ok
     return lib().csv_host_unregister(C.c_void_p(arr.ctypes.data)) == _abi.OK

@@ -35,12 +35,21 @@ def _bias_of(svtype, params):
             "DUP": params.max_cluster_bias_DUP}[svtype]
 
 
+def _runs(store, svtype, b, e):
+    """position-sorted runs of a segment's rows: the whole range, except INV, whose rows are ordered (strand, pos) (main script
+    :792): one run per strand (the chain breaks at a strand change anyway, INV:56)"""
+    if svtype != "INV" or e - b < 2:
+        return [(b, e)]
+    cut = (b + 1 + np.flatnonzero(store.aux[b + 1:e] != store.aux[b:e - 1])).tolist()
+    return list(zip([b] + cut, cut + [e]))
+
+
 def _cuts(store, chrom, params, n_pieces):
     """coordinates x_1 < ... < x_{k-1} that cut `chrom` into ~equal pieces: piece i holds, of every cuttable segment, the
     signatures with x_i <= pos < x_{i+1}; a coordinate is admissible for a segment when the signatures on either side of it
     are more than the segment's max_cluster_bias apart (INV: two neighbours with a position gap that large break the chain
     whatever their strands are, INV:56).  Returns a sorted list (possibly shorter than asked)."""
-    segs = [(t, store.seg_index[(t, chrom)]) for t in CUT_TYPES if (t, chrom) in store.seg_index]
+    segs = [(t, r) for t in CUT_TYPES if (t, chrom) in store.seg_index for r in _runs(store, t, *store.seg_index[(t, chrom)])]
     if not segs or n_pieces < 2:
         return []
     pos_all = np.sort(np.concatenate([store.a[b:e] for _, (b, e) in segs]))
@@ -62,7 +71,7 @@ def _cuts(store, chrom, params, n_pieces):
                 x = int(a0[j])                                   # cut in front of signature j of the densest segment
                 ok = True
                 for t, (b, e) in segs:
-                    if t == t0:
+                    if (t, (b, e)) == (t0, (b0, e0)):
                         continue
                     a = store.a[b:e]
                     m = int(np.searchsorted(a, x))
@@ -101,9 +110,9 @@ def plan(store, world_size, params=None, genotype=False, max_imbalance=0.03):
             n = 0
             for t in CUT_TYPES:
                 if (t, c) in store.seg_index:
-                    b, e = store.seg_index[(t, c)]
-                    a = store.a[b:e]
-                    n += int(np.searchsorted(a, hi) if hi is not None else len(a)) - int(np.searchsorted(a, lo) if lo is not None else 0)
+                    for b, e in _runs(store, t, *store.seg_index[(t, c)]):
+                        a = store.a[b:e]
+                        n += int(np.searchsorted(a, hi) if hi is not None else len(a)) - int(np.searchsorted(a, lo) if lo is not None else 0)
             if i == 0 and ("TRA", c) in store.seg_index:
                 b, e = store.seg_index[("TRA", c)]
                 n += e - b
@@ -157,10 +166,12 @@ def tasks_of_rank(store, rank, world_size, genotype=False, types=TYPES):
 
 
 def rank_batch(store, params, units):
-    """The batch of one rank: (segments, keys, reads kwargs).  keys[i] = (type, chrom, piece) of segment i; the segments of a
-    piece are sub-ranges of the store's segments with the segment's own scalars; the reads table holds, per chromosome, only
-    the reads that can reach a genotyping window of the rank's pieces (windows lie within gt_bias of a signature position,
-    pair types also around pos2)."""
+    """The batch of one rank: (segments, keys, reads kwargs).  keys[i] = (type, chrom, order) of segment i; the segments of a
+    piece are sub-ranges of the store's segments with the segment's own scalars - ONE per position-sorted run: an INV piece is
+    a sub-range of every strand's run, keyed strand-major (order = run * n_pieces + piece) so that merge_rows puts the rows back
+    in the reference's order (all of '++', then all of '--'); the reads table holds, per chromosome, only the reads that can
+    reach a genotyping window of the rank's pieces (windows lie within gt_bias of a signature position, pair types also around
+    pos2)."""
     segs, keys = [], []
     need = {}                                                     # chrom -> [lo, hi] coordinate range the rank genotypes in
     for t in TYPES:
@@ -169,24 +180,27 @@ def rank_batch(store, params, units):
                 continue
             if t == "TRA" and piece != 0:
                 continue
-            rec = store.segment(t, c, params).copy()
-            b, e = int(rec["sig_begin"]), int(rec["sig_end"])
-            if t != "TRA" and n_pieces > 1:
-                a = store.a[b:e]
-                b2 = b + (int(np.searchsorted(a, lo)) if lo is not None else 0)
-                e2 = b + (int(np.searchsorted(a, hi)) if hi is not None else e - b)
-                rec["sig_begin"], rec["sig_end"] = b2, e2
-                b, e = b2, e2
-            if e <= b:
-                continue
-            segs.append(rec); keys.append((t, c, piece))
-            if rec["genotype"] and t != "TRA":
-                x0 = int(store.a[b:e].min()); x1 = int(max(store.a[b:e].max(), store.b[b:e].max() if t in ("DUP", "INV") else 0))
-                g = int(rec["gt_bias"]) + 2
-                cur = need.get(c)
-                need[c] = [min(x0 - g, cur[0]) if cur else x0 - g, max(x1 + g, cur[1]) if cur else x1 + g]
-            elif rec["genotype"]:
-                need[c] = [-(1 << 62), 1 << 62]                   # TRA windows sit on two chromosomes: keep whole blocks
+            rec0 = store.segment(t, c, params)
+            b0, e0 = int(rec0["sig_begin"]), int(rec0["sig_end"])
+            runs = _runs(store, t, b0, e0) if (t != "TRA" and n_pieces > 1) else [(b0, e0)]
+            for ri, (rb, re_) in enumerate(runs):
+                rec = rec0.copy()
+                b, e = rb, re_
+                if t != "TRA" and n_pieces > 1:
+                    a = store.a[rb:re_]
+                    b = rb + (int(np.searchsorted(a, lo)) if lo is not None else 0)
+                    e = rb + (int(np.searchsorted(a, hi)) if hi is not None else re_ - rb)
+                    rec["sig_begin"], rec["sig_end"] = b, e
+                if e <= b:
+                    continue
+                segs.append(rec); keys.append((t, c, ri * n_pieces + piece))
+                if rec["genotype"] and t != "TRA":
+                    x0 = int(store.a[b:e].min()); x1 = int(max(store.a[b:e].max(), store.b[b:e].max() if t in ("DUP", "INV") else 0))
+                    g = int(rec["gt_bias"]) + 2
+                    cur = need.get(c)
+                    need[c] = [min(x0 - g, cur[0]) if cur else x0 - g, max(x1 + g, cur[1]) if cur else x1 + g]
+                elif rec["genotype"]:
+                    need[c] = [-(1 << 62), 1 << 62]               # TRA windows sit on two chromosomes: keep whole blocks
     kw = {}
     if store.reads_off is not None and any(s["genotype"] for s in segs):
         tra = any(s["genotype"] and s["svtype"] == _abi.TRA for s in segs)
@@ -223,8 +237,9 @@ def host_batch(store, params, units, pin=None):
 
 
 def merge_rows(per_rank):
-    """[{(type, chrom, piece): rows}] of all ranks -> {chrom: rows} in the order main_ctrl concatenates task results
-    (main script :1191-1197: DEL, INS, INV, DUP, TRA per chromosome), the pieces of a segment in coordinate order."""
+    """[{(type, chrom, order): rows}] of all ranks -> {chrom: rows} in the order main_ctrl concatenates task results
+    (main script :1191-1197: DEL, INS, INV, DUP, TRA per chromosome), the pieces of a segment in the segment's own row order
+    (coordinate order; INV: strand-major, rank_batch)."""
     every = {}
     for d in per_rank:
         for k, rows in d.items():

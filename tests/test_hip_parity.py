@@ -352,6 +352,32 @@ def test_full_size_cfg4_cfg5_vs_oracle(ctx, cfg, order):
     assert (got["gl_idx"] >= 0).sum() > min_calls // 2
 
 
+@pytest.mark.parametrize("cfg", ["cfg3", "cfg4", "cfg5"])
+def test_full_size_int32_columns_vs_oracle(ctx, cfg):
+    """The path bench.py and SigStore.pinned() actually use - int32 position / length columns (CSV_IN_SIG_I32), int32 reads
+    (CSV_IN_READS_I32), page-locked, results published straight into page-locked arrays - at FULL size against the C oracle on
+    the int64 columns: every SoA field, the support lists, the per-signature outputs.  (r03 compared this path with the oracle
+    only on a small mixed workload; the register tier now keeps int32 coordinates in 32-bit registers, a different
+    instantiation from the int64 one.)"""
+    from helpers import assert_soa_equal
+    st, p = {"cfg3": (lambda: (synth.ont30(), Params.ont())),
+             "cfg4": (lambda: (synth.extraction_order(synth.hifi30_gt())[0], Params.hifi(genotype=True, min_support=3))),
+             "cfg5": (lambda: (synth.extraction_order(synth.ont90_all())[0], Params.ont(genotype=True)))}[cfg]()
+    pst = st.pinned()
+    hb = pst.host_batch(pst.tasks(), p)
+    assert hb.a.dtype == np.int32 and hb.c.flags & _abi.IN_SIG_I32
+    if hb.r_start is not None:
+        assert hb.r_start.dtype == np.int32 and hb.c.flags & _abi.IN_READS_I32
+    want = _oracle().cluster_batch(st.host_batch(st.tasks(), p), per_sig=True).trimmed()
+    got = ctx.cluster_batch(hb, per_sig=True, reuse=True).trimmed()
+    assert_soa_equal(got, want, st)
+    # ... and resident: upload once, run twice (tiers on demand), deliver into the same page-locked arrays
+    ctx.upload(hb, per_sig=True)
+    ctx.run(); ctx.run()
+    res = ctx.result_buffers(per_sig=True)
+    assert_soa_equal(ctx.download(per_sig=True, into=res).trimmed(), want, st)
+
+
 @pytest.mark.parametrize("cfg", ["cfg4", "cfg5"])
 def test_full_size_partition_and_rerun_properties(ctx, cfg):
     """BASELINE configs 4 (HiFi 30x, 6.2 M reads, genotyping) and 5 (ONT 90x, 11 M signatures, all five types,

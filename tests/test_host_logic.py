@@ -122,6 +122,68 @@ def test_lpt_sharding_is_a_balanced_partition():
         assert max(loads) <= 1.03 * sum(loads) / n, (n, loads)
 
 
+def test_inv_dominated_chromosome_is_cut_per_strand_run():
+    """INV rows are ordered (strand, pos) (main script :792): a coordinate cut is a sub-range of EVERY strand's run, the gap
+    test holds at the exact index used, and the pieces' rows go back strand-major.  A store whose densest cuttable segment is
+    INV, worlds 2 .. 8 with forced cuts, through the oracle engine: merged rows == unsharded rows, loads balanced."""
+    import dataclasses
+    from cutesv_amd.columns import Params, SigStore, NameTable
+    from cutesv_amd import rows as rows_mod
+    from oracle import oracle
+    rng = np.random.default_rng(5)
+    n_sites, per = 300, 15
+    site = np.sort(rng.integers(10_000, 40_000_000, n_sites))
+    a, b, rid, aux = [], [], [], []
+    for strand in (0, 1):                                        # '++' rows first, then '--' (the rebuild's order)
+        pos = np.repeat(site, per) + rng.integers(-40, 40, n_sites * per)
+        o = np.argsort(pos, kind="stable")
+        a.append(pos[o]); b.append((pos + 5000 + rng.integers(-40, 40, len(pos)))[o])
+        rid.append((np.repeat(np.arange(n_sites), per) * per + np.tile(np.arange(per), n_sites))[o] + strand * 1_000_000)
+        aux.append(np.full(len(pos), strand))
+    n_inv = 2 * n_sites * per
+    d_pos = np.sort(rng.integers(10_000, 40_000_000, 400))       # a sparse DEL segment on the same chromosome
+    st = SigStore(chroms=["1"], a=np.concatenate([d_pos] + a).astype(np.int64), b=np.concatenate([np.full(400, 50)] + b).astype(np.int64),
+                  read_id=np.concatenate([np.arange(400) + 5_000_000] + rid).astype(np.int32),
+                  aux=np.concatenate([np.zeros(400)] + aux).astype(np.int32),
+                  seg_index={("DEL", "1"): (0, 400), ("INV", "1"): (400, 400 + n_inv)}, names=NameTable(), strands=("++", "--"))
+    p = Params.ont(min_support=5)
+
+    def stage(units):
+        hb, keys = shard.host_batch(st, p, units)
+        per_seg = rows_mod.rows_by_segment(st, hb.segments, oracle.cluster_batch(hb))
+        return {k: per_seg[i] for i, k in enumerate(keys)}
+    full = shard.merge_rows([stage(shard.plan(st, 1, p)[0])])
+    assert len(full["1"]) > 500
+    for world in (2, 3, 8):
+        plan = shard.plan(st, world, p, max_imbalance=0.0)
+        assert any(u[2] > 1 for us in plan for u in us)
+        loads = []
+        parts = []
+        for units in plan:
+            segs, keys, _ = shard.rank_batch(st, p, units)
+            loads.append(int((segs["sig_end"] - segs["sig_begin"]).sum()))
+            parts.append(stage(units))
+        assert sum(loads) == st.n_sig
+        assert max(loads) <= 1.25 * st.n_sig / world, (world, loads)
+        assert shard.merge_rows(parts) == full, world
+
+
+def test_tra_window_status_skips_records_without_an_end():
+    """fetch() also yields records that have no reference_end (an unmapped mate placed at its partner's position, flag 69);
+    count_coverage never looks at their coordinates (`flag not in (0, 16)`, cuteSV_genotype.py:72-93) and neither may the
+    chunked form: they only count towards the iteration total"""
+    import types
+    from cutesv_amd.tra_bam import window_status
+    rec = lambda flag, s, e, q: types.SimpleNamespace(flag=flag, reference_start=s, reference_end=e, query_name=q)   # noqa: E731
+    al = [rec(0, 100, 900, "a"), rec(69, 150, None, "u1"), rec(16, 120, 950, "b"), rec(256, 0, 2000, "sec"), rec(69, None, None, "u2"), rec(0, 90, 1000, "c")]
+    names = set()
+    assert window_status(al, 200, 800, names, up_bound=10, itround=500) == 0 and names == {"a", "b", "c"}
+    names = set()
+    assert window_status(al, 200, 800, names, up_bound=2, itround=500) == 1 and names == {"a", "b"}
+    names = set()
+    assert window_status(al, 200, 800, names, up_bound=10, itround=3, chunk=2) == -1 and names == {"a", "b"}     # 2 of 3 primary > 0.2
+
+
 def test_shims_follow_the_reference_argument_contract():
     from cutesv_amd import resolve
     idx = {"DEL": {}, "INS": {}, "INV": {}, "DUP": {}, "TRA": {}}
