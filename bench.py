@@ -131,8 +131,9 @@ def kernel_units(store, hb, res, stats, per_sig_step):
 
 def bench_rebuild(a):
     """--workload rebuild: SURVEY.md 8f row 2 (main script :750-857): the cfg3 genome's rows in random order + 5 % duplicates
-    -> the order contract, on the device.  Roofline: one radix pass reads a key byte column entry and moves a 4-byte
-    permutation entry twice (histogram + scatter: ~24 B per row and pass incl. the gathers), the final gather 56 B per row."""
+    -> the order contract, on the device.  Roofline (composite-key sort, sort.hip.h): pack reads the 28-byte row and writes a
+    16-byte element; a radix pass reads the elements twice (histogram, scatter) and writes them once = 48 B per row and pass;
+    the tail reads the elements and writes the six output columns (16 + 32 B per row)."""
     from cutesv_amd import rebuild
     store, params, _ = make_workload("cfg3", a.scale, 0)
     per = synth.unsorted_rows(store, seed=1, dup_frac=0.05)
@@ -168,7 +169,7 @@ def bench_rebuild(a):
     t0 = time.perf_counter()
     tl.sort(key=lambda x: (x[0], x[1], x[2], x[3]))
     t_py = time.perf_counter() - t0
-    bytes_alg = n_in * (24 * info["n_passes"] + 56)
+    bytes_alg = n_in * (44 + 48 * info["n_passes"] + 48)
     out = {"metric": "signature rows rebuilt/sec (sort + de-duplication, main script :750-857)", "value": n_in / (ms * 1e-3), "unit": "rows/s", "n_gpus": 1,
            "steps": min(a.steps, 10), "warmup": a.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "int64 keys", "data": "synthetic",

@@ -132,7 +132,7 @@ struct csv_ctx {
     Buf flush;                                                   // csv_cache_flush scratch
     // rebuild step (slices of `arena_rb`)
     Buf rb_seg, rb_a, rb_b, rb_rid, rb_aux, rb_auxk, rb_major, rb_nodedup, rb_perm0, rb_perm1, rb_hist, rb_tot, rb_partial;
-    Buf rb_oseg, rb_oa, rb_ob, rb_orid, rb_oaux, rb_osrc, rb_segcnt, rb_rank, rb_mx, rb_drop;
+    Buf rb_oseg, rb_oa, rb_ob, rb_orid, rb_oaux, rb_osrc, rb_segcnt, rb_rank, rb_mx, rb_drop, rb_el0, rb_el1;
     // the device-resident signature pool (stand-alone allocations: it outlives the per-call arenas)
     Buf pool_seg, pool_a, pool_b, pool_read, pool_aux, sp_qlen;
     i64 pool_n = 0, pool_cap = 0;
@@ -1261,7 +1261,7 @@ int csv_rebuild_signatures(csv_ctx* c, const csv_rebuild_in* in, csv_rebuild_out
     if (from_pool && (!in->read_rank || in->n_rank <= 0 || !in->seg_aux_major)) return fail(c, CSV_E_INVALID, "CSV_RB_FROM_POOL needs read_rank");
     if (n == 0) return CSV_OK;
     // key widths (bytes that are non-zero somewhere) from one host pass over the columns (pool rows: from the device, below)
-    i64 mx_a = 0, mx_b = 0; int mx_rid = 0, mx_aux = 0, mx_seg = 0;
+    i64 mx_a = 0, mx_b = 0; int mx_rid = 0, mx_aux = 0, mx_seg = 0, mx_aux_all = 0;
     for (i64 i = 0; i < n && !from_pool; i++) {
         const int sg = in->seg_id[i];
         if (sg < 0 || sg >= in->n_seg || in->a[i] < 0 || in->b[i] < 0 || in->read_id[i] < 0 || in->aux[i] < 0)
@@ -1270,15 +1270,18 @@ int csv_rebuild_signatures(csv_ctx* c, const csv_rebuild_in* in, csv_rebuild_out
         if (in->b[i] > mx_b) mx_b = in->b[i];
         if (in->read_id[i] > mx_rid) mx_rid = in->read_id[i];
         if (in->seg_aux_major[sg] && in->aux[i] > mx_aux) mx_aux = in->aux[i];
+        if (in->aux[i] > mx_aux_all) mx_aux_all = in->aux[i];
         if (sg > mx_seg) mx_seg = sg;
     }
     auto nbytes = [](u64 v) { int k = 0; while (v) { k++; v >>= 8; } return k; };
+    auto nbits = [](u64 v) { int k = 0; while (v) { k++; v >>= 1; } return k; };
     const int nunits = div_up(n, SORT_WTILE), nblk = div_up(nunits, 4), ntile = div_up(n, 2048);
     Plan P;
 #define PL(buf, bytes) P.add(c->buf, (size_t)(bytes))
     PL(rb_seg, n * 4); PL(rb_a, n * 8); PL(rb_b, n * 8); PL(rb_rid, n * 4); PL(rb_aux, n * 4); PL(rb_auxk, n * 4);
-    PL(rb_major, in->n_seg); PL(rb_nodedup, in->n_seg); PL(rb_perm0, n * 4); PL(rb_perm1, n * 4); PL(rb_hist, (size_t)256 * nunits * 4);
-    PL(rb_tot, 256 * 4); PL(rb_partial, (ntile + 2) * 4);
+    PL(rb_major, in->n_seg); PL(rb_nodedup, in->n_seg); PL(rb_perm0, n * 4); PL(rb_perm1, n * 4); PL(rb_hist, (size_t)RS_RADIX * nunits * 4);
+    PL(rb_tot, RS_RADIX * 4); PL(rb_partial, (ntile + 2) * 4);
+    PL(rb_el0, (size_t)n * 32); PL(rb_el1, (size_t)n * 32);          // composite-key elements (16 or 32 bytes each; sized for either)
     PL(rb_oseg, n * 4); PL(rb_oa, n * 8); PL(rb_ob, n * 8); PL(rb_orid, n * 4); PL(rb_oaux, n * 4); PL(rb_osrc, n * 4); PL(rb_segcnt, ((size_t)in->n_seg + 2) * 8);
     if (from_pool) { PL(rb_rank, (size_t)in->n_rank * 4); PL(rb_mx, 64); }
     if (in->tie_order && in->seg_nodedup) PL(rb_drop, n + 64);
@@ -1305,34 +1308,23 @@ int csv_rebuild_signatures(csv_ctx* c, const csv_rebuild_in* in, csv_rebuild_out
                            dp<int>(c->pool_read), dp<int>(c->pool_aux), n, dp<int>(c->rb_rank), (i64)in->n_rank, in->n_seg, dp<uint8_t>(c->rb_major),
                            dp<int>(c->rb_seg), dp<i64>(c->rb_a), dp<i64>(c->rb_b), dp<int>(c->rb_rid), dp<int>(c->rb_aux), dp<unsigned long long>(c->rb_mx));
         unsigned long long mx[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        HIP_TRY(c, hipMemcpyAsync(mx, c->rb_mx.p, 48, hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipMemcpyAsync(mx, c->rb_mx.p, 56, hipMemcpyDeviceToHost, st));
         HIP_TRY(c, hipStreamSynchronize(st));
         if (mx[5]) return fail(c, CSV_E_INVALID, "a pool row has a negative key, a segment out of range or a read without a rank");
-        mx_a = (i64)mx[0]; mx_b = (i64)mx[1]; mx_rid = (int)mx[2]; mx_aux = (int)mx[3]; mx_seg = (int)mx[4];
+        mx_a = (i64)mx[0]; mx_b = (i64)mx[1]; mx_rid = (int)mx[2]; mx_aux = (int)mx[3]; mx_seg = (int)mx[4]; mx_aux_all = (int)mx[6];
     }
     HIP_TRY(c, hipEventRecord(c->ev[0], st));
-    hipLaunchKernelGGL(k_rebuild_auxkey, dim3(div_up(n, 256)), dim3(256), 0, st, n, dp<int>(c->rb_seg), dp<int>(c->rb_aux),
-                       dp<uint8_t>(c->rb_major), dp<int>(c->rb_auxk));
-    // least significant key first: read_id, b, a, [aux], segment
-    struct Field { const void* col; int elem64; int bytes; };
-    const Field fields[5] = {{c->rb_rid.p, 0, nbytes((u64)mx_rid)}, {c->rb_b.p, 1, nbytes((u64)mx_b)}, {c->rb_a.p, 1, nbytes((u64)mx_a)},
-                             {c->rb_auxk.p, 0, nbytes((u64)mx_aux)}, {c->rb_seg.p, 0, nbytes((u64)mx_seg) > 0 ? nbytes((u64)mx_seg) : 1}};
-    const int* pin = nullptr;
-    int* pout = dp<int>(c->rb_perm0);
-    int npass = 0;
-    for (const Field& f : fields)
-        for (int byte = 0; byte < f.bytes; byte++) {
-            SortPass SP{f.col, f.elem64, byte * 8, n, nunits, pin, pout, dp<int>(c->rb_hist)};
-            hipLaunchKernelGGL(k_sort_hist, dim3(nblk), dim3(256), 0, st, SP);
-            hipLaunchKernelGGL(k_sort_rowsum, dim3(256), dim3(256), 0, st, dp<int>(c->rb_hist), nunits, dp<int>(c->rb_tot));
-            hipLaunchKernelGGL(k_sort_rowscan, dim3(256), dim3(256), 0, st, dp<int>(c->rb_hist), nunits, dp<int>(c->rb_tot));
-            hipLaunchKernelGGL(k_sort_scatter, dim3(nblk), dim3(256), 0, st, SP);
-            pin = pout;
-            pout = (pout == dp<int>(c->rb_perm0)) ? dp<int>(c->rb_perm1) : dp<int>(c->rb_perm0);
-            npass++;
-        }
+    // the composite-key sort (sort.hip.h) whenever the key fits 128 bits; CSV_RB_PERM_SORT=1 forces the permutation sort
+    KeyLayout KL{};
+    KL.ib = nbits((u64)(n - 1)) > 0 ? nbits((u64)(n - 1)) : 1;
+    KL.rb = nbits((u64)mx_rid) > 0 ? nbits((u64)mx_rid) : 1; KL.bb = nbits((u64)mx_b) > 0 ? nbits((u64)mx_b) : 1;
+    KL.ab = nbits((u64)mx_a) > 0 ? nbits((u64)mx_a) : 1; KL.xb = nbits((u64)mx_aux); KL.sb = nbits((u64)mx_seg) > 0 ? nbits((u64)mx_seg) : 1;
+    KL.pb = nbits((u64)mx_aux_all);
+    KL.T = KL.rb + KL.bb + KL.ab + KL.xb + KL.sb;
+    KL.wide = (KL.ib + KL.T + KL.pb <= 128) ? 0 : 1;
+    const bool composite = KL.T <= 128 && !getenv("CSV_RB_PERM_SORT");
     RebuildArgs R{};
-    R.n = n; R.perm = pin;
+    R.n = n;
     R.seg = dp<int>(c->rb_seg); R.a = dp<i64>(c->rb_a); R.b = dp<i64>(c->rb_b); R.rid = dp<int>(c->rb_rid); R.aux = dp<int>(c->rb_aux);
     R.auxk = dp<int>(c->rb_auxk); R.keep = nullptr; R.partial = dp<int>(c->rb_partial);
     R.nodedup = in->seg_nodedup ? dp<uint8_t>(c->rb_nodedup) : nullptr;
@@ -1341,62 +1333,142 @@ int csv_rebuild_signatures(csv_ctx* c, const csv_rebuild_in* in, csv_rebuild_out
     R.drop = nullptr;
     out->n_tie_rows = 0; out->n_tie_dropped = 0;
     bool ties_settled = false;
-    if (in->tie_order && R.nodedup) {
-        // INS rows that tie on their integer keys: the caller orders them (by sequence) and names the duplicates; the answer is
-        // written into the permutation / a drop map on the device, and the gather below never knows.  The output buffers are
-        // free until the gather: rb_oa holds the list, rb_oseg / rb_orid / rb_ob the answer on its way back.
-        int* d_n = (int*)c->cnt.p;
-        HIP_TRY(c, hipMemsetAsync(d_n, 0, 4, st));
-        HIP_TRY(c, hipMemsetAsync(c->rb_drop.p, 0, (size_t)n, st));
-        hipLaunchKernelGGL(k_rebuild_ties, dim3(div_up(n, 256)), dim3(256), 0, st, R, (int2*)c->rb_oa.p, d_n);
-        int n_list = 0;
-        HIP_TRY(c, hipMemcpyAsync(&n_list, d_n, 4, hipMemcpyDeviceToHost, st));
-        HIP_TRY(c, hipStreamSynchronize(st));
-        if (n_list > 0) {
-            std::vector<int2> lst((size_t)n_list);
-            HIP_TRY(c, hipMemcpy(lst.data(), c->rb_oa.p, (size_t)n_list * 8, hipMemcpyDeviceToHost));
-            std::sort(lst.begin(), lst.end(), [](const int2& x, const int2& y) { return (x.x & 0x7fffffff) < (y.x & 0x7fffffff); });
-            std::vector<int64_t> goff;
-            std::vector<int> src((size_t)n_list), pos((size_t)n_list), order((size_t)n_list, -1);
-            std::vector<uint8_t> drop((size_t)n_list, 0);
-            for (int k = 0; k < n_list; k++) {
-                if (!(lst[k].x & (int)0x80000000)) goff.push_back(k);               // a group's head
-                pos[k] = lst[k].x & 0x7fffffff; src[k] = lst[k].y;
-            }
-            goff.push_back(n_list);
-            const int rc = in->tie_order(in->tie_user, (int64_t)goff.size() - 1, goff.data(), src.data(), order.data(), drop.data());
-            if (rc != 0) return fail(c, CSV_E_INVALID, "tie_order returned %d", rc);
-            // order[] must be a permutation inside every group
-            std::vector<int> nsrc((size_t)n_list);
-            std::vector<uint8_t> nflag((size_t)n_list);
-            std::vector<uint8_t> seen((size_t)n_list, 0);
-            i64 dropped = 0;
-            for (size_t g = 0; g + 1 < goff.size(); g++) {
-                const int64_t g0 = goff[g], g1 = goff[g + 1];
-                for (int64_t k = g0; k < g1; k++) {
-                    const int64_t o = order[k];
-                    if (o < 0 || o >= g1 - g0 || seen[g0 + o]) return fail(c, CSV_E_INVALID, "tie_order: order[] is not a permutation inside group %zu", g);
-                    seen[g0 + o] = 1;
-                    nsrc[g0 + o] = src[k]; nflag[g0 + o] = drop[k] ? 1 : 0;
-                    dropped += drop[k] ? 1 : 0;
-                }
-            }
-            HIP_TRY(c, hipMemcpyAsync(c->rb_oseg.p, pos.data(), (size_t)n_list * 4, hipMemcpyHostToDevice, st));
-            HIP_TRY(c, hipMemcpyAsync(c->rb_orid.p, nsrc.data(), (size_t)n_list * 4, hipMemcpyHostToDevice, st));
-            HIP_TRY(c, hipMemcpyAsync(c->rb_ob.p, nflag.data(), (size_t)n_list, hipMemcpyHostToDevice, st));
-            hipLaunchKernelGGL(k_rebuild_tie_apply, dim3(div_up(n_list, 256)), dim3(256), 0, st, n_list, dp<int>(c->rb_oseg), dp<int>(c->rb_orid),
-                               dp<uint8_t>(c->rb_ob), const_cast<int*>(R.perm), dp<uint8_t>(c->rb_drop));
-            HIP_TRY(c, hipStreamSynchronize(st));                                       // (the host vectors are the copies' sources)
-            out->n_tie_rows = n_list; out->n_tie_dropped = dropped;
+    int npass = 0;
+    // the tie groups' round trip to the caller (csv_tie_order_fn): `lst` = {position | continues << 31, source row}, any order
+    std::vector<int> tie_pos, tie_src; std::vector<uint8_t> tie_flag;
+    auto ask_caller = [&](std::vector<int2>& lst) -> int {
+        const int n_list = (int)lst.size();
+        std::sort(lst.begin(), lst.end(), [](const int2& x, const int2& y) { return (x.x & 0x7fffffff) < (y.x & 0x7fffffff); });
+        std::vector<int64_t> goff;
+        std::vector<int> src((size_t)n_list), order((size_t)n_list, -1);
+        std::vector<uint8_t> drop((size_t)n_list, 0);
+        tie_pos.assign((size_t)n_list, 0); tie_src.assign((size_t)n_list, 0); tie_flag.assign((size_t)n_list, 0);
+        for (int k = 0; k < n_list; k++) {
+            if (!(lst[k].x & (int)0x80000000)) goff.push_back(k);               // a group's head
+            tie_pos[k] = lst[k].x & 0x7fffffff; src[k] = lst[k].y;
         }
-        R.drop = dp<uint8_t>(c->rb_drop);
-        ties_settled = true;
+        goff.push_back(n_list);
+        const int rc = in->tie_order(in->tie_user, (int64_t)goff.size() - 1, goff.data(), src.data(), order.data(), drop.data());
+        if (rc != 0) return fail(c, CSV_E_INVALID, "tie_order returned %d", rc);
+        std::vector<uint8_t> seen((size_t)n_list, 0);
+        int64_t dropped = 0;
+        for (size_t g = 0; g + 1 < goff.size(); g++) {                            // order[] must be a permutation inside every group
+            const int64_t g0 = goff[g], g1 = goff[g + 1];
+            for (int64_t k = g0; k < g1; k++) {
+                const int64_t o = order[k];
+                if (o < 0 || o >= g1 - g0 || seen[g0 + o]) return fail(c, CSV_E_INVALID, "tie_order: order[] is not a permutation inside group %zu", g);
+                seen[g0 + o] = 1;
+                tie_src[g0 + o] = src[k]; tie_flag[g0 + o] = drop[k] ? 1 : 0;
+                dropped += drop[k] ? 1 : 0;
+            }
+        }
+        out->n_tie_rows = n_list; out->n_tie_dropped = dropped;
+        return CSV_OK;
+    };
+    if (composite) {
+        RsCols C{dp<int>(c->rb_seg), dp<i64>(c->rb_a), dp<i64>(c->rb_b), dp<int>(c->rb_rid), dp<int>(c->rb_aux), dp<uint8_t>(c->rb_major)};
+        void* e_in = c->rb_el0.p; void* e_out = c->rb_el1.p;
+        auto run_sort = [&](auto wide_tag) -> int {
+            constexpr bool W = decltype(wide_tag)::value;
+            typedef RsElem<W> E;
+            hipLaunchKernelGGL(k_rs_pack<W>, dim3(div_up(n, 256)), dim3(256), 0, st, C, n, KL, (E*)e_in);
+            for (int shift = 0; shift < KL.T; shift += RS_BITS) {
+                const int dbits = KL.T - shift < RS_BITS ? KL.T - shift : RS_BITS;
+                hipLaunchKernelGGL(k_rs_hist<W>, dim3(nblk), dim3(256), 0, st, (const E*)e_in, n, nunits, KL, shift, dbits, dp<int>(c->rb_hist));
+                hipLaunchKernelGGL(k_sort_rowsum, dim3(RS_RADIX), dim3(256), 0, st, dp<int>(c->rb_hist), nunits, dp<int>(c->rb_tot));
+                hipLaunchKernelGGL(k_sort_rowscan, dim3(RS_RADIX), dim3(256), 0, st, dp<int>(c->rb_hist), nunits, dp<int>(c->rb_tot));
+                hipLaunchKernelGGL(k_rs_scatter<W>, dim3(nblk), dim3(256), 0, st, (const E*)e_in, (E*)e_out, n, nunits, KL, shift, dbits, dp<int>(c->rb_hist));
+                std::swap(e_in, e_out);
+                npass++;
+            }
+            RsTail T{};
+            T.n = n; T.L = KL; T.nodedup = R.nodedup; T.drop = nullptr; T.partial = R.partial;
+            T.o_seg = R.o_seg; T.o_a = R.o_a; T.o_b = R.o_b; T.o_rid = R.o_rid; T.o_aux = R.o_aux; T.o_src = R.o_src; T.n_out = R.n_out;
+            if (in->tie_order && R.nodedup) {
+                int* d_n = (int*)c->cnt.p;
+                HIP_TRY(c, hipMemsetAsync(d_n, 0, 4, st));
+                HIP_TRY(c, hipMemsetAsync(c->rb_drop.p, 0, (size_t)n, st));
+                hipLaunchKernelGGL(k_rs_ties<W>, dim3(div_up(n, 256)), dim3(256), 0, st, T, (const E*)e_in, (int2*)c->rb_oa.p, d_n);
+                int n_list = 0;
+                HIP_TRY(c, hipMemcpyAsync(&n_list, d_n, 4, hipMemcpyDeviceToHost, st));
+                HIP_TRY(c, hipStreamSynchronize(st));
+                if (n_list > 0) {
+                    std::vector<int2> lst((size_t)n_list);
+                    HIP_TRY(c, hipMemcpy(lst.data(), c->rb_oa.p, (size_t)n_list * 8, hipMemcpyDeviceToHost));
+                    const int rc = ask_caller(lst);
+                    if (rc) return rc;
+                    HIP_TRY(c, hipMemcpyAsync(c->rb_oseg.p, tie_pos.data(), (size_t)n_list * 4, hipMemcpyHostToDevice, st));
+                    HIP_TRY(c, hipMemcpyAsync(c->rb_orid.p, tie_src.data(), (size_t)n_list * 4, hipMemcpyHostToDevice, st));
+                    HIP_TRY(c, hipMemcpyAsync(c->rb_ob.p, tie_flag.data(), (size_t)n_list, hipMemcpyHostToDevice, st));
+                    hipLaunchKernelGGL(k_rs_tie_apply<W>, dim3(div_up(n_list, 256)), dim3(256), 0, st, n_list, dp<int>(c->rb_oseg), dp<int>(c->rb_orid),
+                                       dp<uint8_t>(c->rb_ob), dp<int>(c->rb_aux), KL, (E*)e_in, dp<uint8_t>(c->rb_drop));
+                    HIP_TRY(c, hipStreamSynchronize(st));                                   // (the host vectors are the copies' sources)
+                }
+                T.drop = dp<uint8_t>(c->rb_drop);
+                ties_settled = true;
+            }
+            hipLaunchKernelGGL(k_rs_count<W>, dim3(ntile), dim3(256), 0, st, T, (const E*)e_in);
+            hipLaunchKernelGGL(k_rs_apply<W>, dim3(ntile), dim3(256), 0, st, T, (const E*)e_in);
+            return CSV_OK;
+        };
+        const int rc = KL.wide ? run_sort(std::true_type{}) : run_sort(std::false_type{});
+        if (rc) return rc;
+    } else {
+        hipLaunchKernelGGL(k_rebuild_auxkey, dim3(div_up(n, 256)), dim3(256), 0, st, n, dp<int>(c->rb_seg), dp<int>(c->rb_aux),
+                           dp<uint8_t>(c->rb_major), dp<int>(c->rb_auxk));
+        // least significant key first: read_id, b, a, [aux], segment
+        struct Field { const void* col; int elem64; int bytes; };
+        const Field fields[5] = {{c->rb_rid.p, 0, nbytes((u64)mx_rid)}, {c->rb_b.p, 1, nbytes((u64)mx_b)}, {c->rb_a.p, 1, nbytes((u64)mx_a)},
+                                 {c->rb_auxk.p, 0, nbytes((u64)mx_aux)}, {c->rb_seg.p, 0, nbytes((u64)mx_seg) > 0 ? nbytes((u64)mx_seg) : 1}};
+        const int* pin = nullptr;
+        int* pout = dp<int>(c->rb_perm0);
+        for (const Field& f : fields)
+            for (int byte = 0; byte < f.bytes; byte++) {
+                SortPass SP{f.col, f.elem64, byte * 8, n, nunits, pin, pout, dp<int>(c->rb_hist)};
+                hipLaunchKernelGGL(k_sort_hist, dim3(nblk), dim3(256), 0, st, SP);
+                hipLaunchKernelGGL(k_sort_rowsum, dim3(256), dim3(256), 0, st, dp<int>(c->rb_hist), nunits, dp<int>(c->rb_tot));
+                hipLaunchKernelGGL(k_sort_rowscan, dim3(256), dim3(256), 0, st, dp<int>(c->rb_hist), nunits, dp<int>(c->rb_tot));
+                hipLaunchKernelGGL(k_sort_scatter, dim3(nblk), dim3(256), 0, st, SP);
+                pin = pout;
+                pout = (pout == dp<int>(c->rb_perm0)) ? dp<int>(c->rb_perm1) : dp<int>(c->rb_perm0);
+                npass++;
+            }
+        R.perm = pin;
+        if (in->tie_order && R.nodedup) {
+            // INS rows that tie on their integer keys: the caller orders them (by sequence) and names the duplicates; the answer is
+            // written into the permutation / a drop map on the device, and the gather below never knows.  The output buffers are
+            // free until the gather: rb_oa holds the list, rb_oseg / rb_orid / rb_ob the answer on its way back.
+            int* d_n = (int*)c->cnt.p;
+            HIP_TRY(c, hipMemsetAsync(d_n, 0, 4, st));
+            HIP_TRY(c, hipMemsetAsync(c->rb_drop.p, 0, (size_t)n, st));
+            hipLaunchKernelGGL(k_rebuild_ties, dim3(div_up(n, 256)), dim3(256), 0, st, R, (int2*)c->rb_oa.p, d_n);
+            int n_list = 0;
+            HIP_TRY(c, hipMemcpyAsync(&n_list, d_n, 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(c, hipStreamSynchronize(st));
+            if (n_list > 0) {
+                std::vector<int2> lst((size_t)n_list);
+                HIP_TRY(c, hipMemcpy(lst.data(), c->rb_oa.p, (size_t)n_list * 8, hipMemcpyDeviceToHost));
+                const int rc = ask_caller(lst);
+                if (rc) return rc;
+                HIP_TRY(c, hipMemcpyAsync(c->rb_oseg.p, tie_pos.data(), (size_t)n_list * 4, hipMemcpyHostToDevice, st));
+                HIP_TRY(c, hipMemcpyAsync(c->rb_orid.p, tie_src.data(), (size_t)n_list * 4, hipMemcpyHostToDevice, st));
+                HIP_TRY(c, hipMemcpyAsync(c->rb_ob.p, tie_flag.data(), (size_t)n_list, hipMemcpyHostToDevice, st));
+                hipLaunchKernelGGL(k_rebuild_tie_apply, dim3(div_up(n_list, 256)), dim3(256), 0, st, n_list, dp<int>(c->rb_oseg), dp<int>(c->rb_orid),
+                                   dp<uint8_t>(c->rb_ob), const_cast<int*>(R.perm), dp<uint8_t>(c->rb_drop));
+                HIP_TRY(c, hipStreamSynchronize(st));                                       // (the host vectors are the copies' sources)
+            }
+            R.drop = dp<uint8_t>(c->rb_drop);
+            ties_settled = true;
+        }
+        hipLaunchKernelGGL(k_rebuild_count, dim3(ntile), dim3(256), 0, st, R);
+        hipLaunchKernelGGL(k_rebuild_apply, dim3(ntile), dim3(256), 0, st, R);
     }
-    hipLaunchKernelGGL(k_rebuild_count, dim3(ntile), dim3(256), 0, st, R);
-    hipLaunchKernelGGL(k_rebuild_apply, dim3(ntile), dim3(256), 0, st, R);
     // rows per segment and the INS tie count ([n_seg] = ties), from the sorted output
     HIP_TRY(c, hipMemsetAsync(dp<i64>(c->rb_segcnt) + in->n_seg, 0, 8, st));
-    hipLaunchKernelGGL(k_rebuild_segcount, dim3(div_up(in->n_seg, 256) > 64 ? div_up(in->n_seg, 256) : 64), dim3(256), 0, st, R, in->n_seg,
+    // (the tie count is a grid-stride loop over the sorted rows: enough workgroups for ~4 rows per thread)
+    const int g_sc = std::max(div_up(in->n_seg, 256), std::min(div_up(n, 1024), 8192));
+    if (ties_settled) R.nodedup = nullptr;                  // (nothing left to count)
+    hipLaunchKernelGGL(k_rebuild_segcount, dim3(g_sc), dim3(256), 0, st, R, in->n_seg,
                        dp<i64>(c->rb_segcnt), dp<i64>(c->rb_segcnt) + in->n_seg);
     HIP_TRY(c, hipEventRecord(c->ev[1], st));
     HIP_TRY(c, hipGetLastError());

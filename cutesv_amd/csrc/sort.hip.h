@@ -17,8 +17,14 @@
 
 namespace csv {
 
-constexpr int SORT_CHUNKS = 32;                      // 64-row chunks per wavefront tile
-constexpr int SORT_WTILE = 64 * SORT_CHUNKS;         // rows per wavefront tile (2048)
+// 64-row chunks per wavefront tile.  Measured on the 2.85 M rows of a 30x genome (composite-key sort, one box, ms per rebuild):
+// 8: 1.09, 16: 0.71, 32: 0.58, 64: 0.53, 128: 0.66 - a longer tile keeps more rows of a digit together, so the scatter writes
+// longer runs (it is bound by its scattered 16-byte stores, not by the ~700 wavefronts' latency); beyond 64 the chip runs dry.
+#ifndef CSV_SORT_CHUNKS
+#define CSV_SORT_CHUNKS 64
+#endif
+constexpr int SORT_CHUNKS = CSV_SORT_CHUNKS;
+constexpr int SORT_WTILE = 64 * SORT_CHUNKS;         // rows per wavefront tile (4096)
 
 struct SortPass {
     const void* col;       // key column (device)
@@ -131,6 +137,228 @@ __global__ __launch_bounds__(256) void k_sort_scatter(SortPass P)
         if (in && (match >> lane) <= 1ull) cnt[wv][dig] += __popcll(match);
         __builtin_amdgcn_wave_barrier();
     }
+}
+
+// ---------------------------------------------------------------------------------------- composite-key sort (round 4)
+// The sort above moves a permutation and GATHERS the digit of every row through it in both kernels of every pass: 64 lanes,
+// 64 cache lines, 8 useful bytes each - 173 us per pass on the 2.85 M rows of a 30x genome, 10 passes, and the final gather
+// + de-duplication chase the permutation through five columns again (r03: 1.73 ms in all, 6 % of the HBM roofline).
+// Here the whole order contract is ONE integer per row.  Field widths come from the columns' maxima (host pass or
+// k_pool_to_rows): key = seg | aux of aux-major segments | a | b | read id, most significant first, T bits; the row index
+// (ib bits) and the row's aux word ride along.  When idx + key + aux fit 128 bits (a 30x genome: 22 + 70 + 13) an element
+// is 16 bytes {lo, hi} = aux << (ib + T) | key << ib | idx; otherwise 32 bytes {key lo, key hi, idx | aux << 32, 0}
+// (keys up to 128 bits; beyond that the permutation sort above takes the batch).  A pass is an LSD step on a 10-bit digit of
+// the key bits - 7 passes for 70 bits - that MOVES the elements: every load is coalesced, the hist kernel reads 16 bytes per
+// row, the scatter kernel reads 16 and writes 16.  The tail needs no gather either: duplicates are equal keys with equal aux
+// words, ties of the keep-every-row segments are equal keys, and the output columns are fields of the key.
+constexpr int RS_BITS = 10, RS_RADIX = 1 << RS_BITS;
+typedef unsigned __int128 u128;
+struct KeyLayout {
+    int ib, rb, bb, ab, xb, sb, pb;      // bits of: row index, read id, b, a, aux-as-key, segment, aux payload (compact form)
+    int T;                               // key bits = rb + bb + ab + xb + sb
+    int wide;                            // 1: 32-byte elements
+};
+template <bool WIDE> struct RsElem;
+template <> struct RsElem<false> { ulonglong2 v; };
+template <> struct RsElem<true>  { ulonglong4 v; };
+__device__ __forceinline__ u128 rs_u128(u64 lo, u64 hi) { return ((u128)hi << 64) | lo; }
+__device__ __forceinline__ u64 rs_mask(int bits) { return bits >= 64 ? ~0ull : ((1ull << bits) - 1ull); }
+// the key (T bits, right-aligned), the row index and the aux word of an element
+template <bool WIDE> __device__ __forceinline__ u128 rs_key(const RsElem<WIDE>& e, const KeyLayout& L)
+{
+    if constexpr (WIDE) return rs_u128(e.v.x, e.v.y);
+    else { const u128 w = rs_u128(e.v.x, e.v.y) >> L.ib; return L.T >= 128 ? w : (w & (((u128)1 << L.T) - 1)); }
+}
+template <bool WIDE> __device__ __forceinline__ int rs_idx(const RsElem<WIDE>& e, const KeyLayout& L)
+{
+    if constexpr (WIDE) return (int)(e.v.z & 0xffffffffull); else return (int)(e.v.x & rs_mask(L.ib));
+}
+template <bool WIDE> __device__ __forceinline__ int rs_aux(const RsElem<WIDE>& e, const KeyLayout& L)
+{
+    if constexpr (WIDE) return (int)(e.v.z >> 32); else return (int)(u64)(rs_u128(e.v.x, e.v.y) >> (L.ib + L.T));
+}
+template <bool WIDE> __device__ __forceinline__ void rs_set_row(RsElem<WIDE>& e, const KeyLayout& L, int idx, int aux)
+{
+    if constexpr (WIDE) e.v.z = (u64)(unsigned)idx | ((u64)(unsigned)aux << 32);
+    else {
+        u128 w = rs_u128(e.v.x, e.v.y);
+        const u128 keep = (((u128)1 << L.T) - 1) << L.ib;
+        w = (w & keep) | (u128)(unsigned)idx | ((u128)(unsigned)aux << (L.ib + L.T));
+        e.v.x = (u64)w; e.v.y = (u64)(w >> 64);
+    }
+}
+// digit of `dbits` key bits at `shift` (inside the key; the last digit of a key is narrower: the bits above it are not key)
+template <bool WIDE> __device__ __forceinline__ int rs_digit(const RsElem<WIDE>& e, const KeyLayout& L, int shift, int dbits)
+{
+    const int s = shift + (WIDE ? 0 : L.ib);
+    const u64 lo = e.v.x, hi = e.v.y;
+    const u64 w = s >= 64 ? (hi >> (s - 64)) : (s == 0 ? lo : ((lo >> s) | (hi << (64 - s))));
+    return (int)(w & ((1u << dbits) - 1u));
+}
+struct RsCols { const int* seg; const i64* a; const i64* b; const int* rid; const int* aux; const uint8_t* major; };
+
+template <bool WIDE> __global__ __launch_bounds__(256) void k_rs_pack(RsCols C, i64 n, KeyLayout L, RsElem<WIDE>* out)
+{
+    const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int sg = C.seg[i], ax = C.aux[i];
+    u128 k = (u128)(unsigned)sg;
+    k = (k << L.xb) | (u128)(unsigned)(C.major[sg] ? ax : 0);
+    k = (k << L.ab) | (u128)(u64)C.a[i];
+    k = (k << L.bb) | (u128)(u64)C.b[i];
+    k = (k << L.rb) | (u128)(unsigned)C.rid[i];
+    RsElem<WIDE> e;
+    if constexpr (WIDE) { e.v.x = (u64)k; e.v.y = (u64)(k >> 64); e.v.z = (u64)(unsigned)i | ((u64)(unsigned)ax << 32); e.v.w = 0; }
+    else { const u128 w = ((u128)(unsigned)ax << (L.ib + L.T)) | (k << L.ib) | (u128)(u64)i; e.v.x = (u64)w; e.v.y = (u64)(w >> 64); }
+    out[i] = e;
+}
+// one wavefront per tile of 2048 elements: LDS histogram per wavefront, written digit-major
+template <bool WIDE> __global__ __launch_bounds__(256) void k_rs_hist(const RsElem<WIDE>* in, i64 n, int nunits, KeyLayout L, int shift, int dbits, int* hist)
+{
+    __shared__ int h[4][RS_RADIX];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int unit = blockIdx.x * 4 + wv;
+    for (int d = lane; d < RS_RADIX; d += 64) h[wv][d] = 0;
+    __syncthreads();
+    if (unit < nunits) {
+        // (the tile's loads eight chunks at a time: with ~1.4 wavefronts per SIMD - 2.85 M rows are 1392 tiles - a loop of
+        // dependent load -> atomic steps is a chain of 32 round trips)
+        const i64 base = (i64)unit * SORT_WTILE;
+        for (int c0 = 0; c0 < SORT_CHUNKS; c0 += 8) {
+            RsElem<WIDE> e[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const i64 row = base + (c0 + u) * 64 + lane; e[u] = in[row < n ? row : n - 1]; }
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const i64 row = base + (c0 + u) * 64 + lane; if (row < n) atomicAdd(&h[wv][rs_digit<WIDE>(e[u], L, shift, dbits)], 1); }
+        }
+    }
+    __syncthreads();
+    if (unit < nunits)
+        for (int d = lane; d < RS_RADIX; d += 64) hist[(i64)d * nunits + unit] = h[wv][d];
+}
+// stable scatter of the elements: every wavefront walks its tile chunk by chunk, in row order
+template <bool WIDE> __global__ __launch_bounds__(256) void k_rs_scatter(const RsElem<WIDE>* in, RsElem<WIDE>* out, i64 n, int nunits, KeyLayout L, int shift, int dbits, const int* hist)
+{
+    __shared__ int cnt[4][RS_RADIX];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int unit = blockIdx.x * 4 + wv;
+    if (unit < nunits)
+        for (int d = lane; d < RS_RADIX; d += 64) cnt[wv][d] = hist[(i64)d * nunits + unit];
+    __syncthreads();
+    if (unit >= nunits) return;
+    const i64 base = (i64)unit * SORT_WTILE;
+    const u64 lt = (1ull << lane) - 1ull;
+    constexpr int PF = WIDE ? 4 : 8;                                  // chunks loaded ahead (registers: 4 words per 16-byte element)
+    for (int c0 = 0; c0 < SORT_CHUNKS; c0 += PF) {
+        RsElem<WIDE> pre[PF];
+#pragma unroll
+        for (int u = 0; u < PF; u++) { const i64 r2 = base + (c0 + u) * 64 + lane; pre[u] = in[r2 < n ? r2 : n - 1]; }
+#pragma unroll
+        for (int u = 0; u < PF; u++) {
+            const i64 row = base + (c0 + u) * 64 + lane;
+            const bool in_ = row < n;
+            const RsElem<WIDE> e = pre[u];
+            const int dig = in_ ? rs_digit<WIDE>(e, L, shift, dbits) : 0;
+            u64 differ = ~__ballot(in_);
+#pragma unroll
+            for (int bit = 0; bit < RS_BITS; bit++) {
+                const int ones = (int)((unsigned)dig << (31 - bit)) >> 31;
+                const u64 mk = __ballot(ones != 0);
+                differ |= mk ^ (u64)(i64)ones;
+            }
+            const u64 match = ~differ;                                    // lanes of this chunk with my digit
+            if (in_) {
+                const int before = cnt[wv][dig];                          // same value for the whole match group
+                out[before + __popcll(match & lt)] = e;
+            }
+            // the highest lane of each group advances the group's counter (after everyone read it: LDS ops of a wavefront execute in order)
+            if (in_ && (match >> lane) <= 1ull) cnt[wv][dig] += __popcll(match);
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+struct RsTail {
+    i64 n;
+    KeyLayout L;
+    const uint8_t* nodedup;     // per segment: keep every row (nullable)
+    const uint8_t* drop;        // per sorted position: the caller's tie_order said "duplicate" (nullable)
+    int* partial;               // per 2048-row tile counts
+    int* o_seg; i64* o_a; i64* o_b; int* o_rid; int* o_aux; int* o_src;
+    int* n_out;
+};
+template <bool WIDE> __device__ __forceinline__ int rs_seg_of(u128 key, const KeyLayout& L) { return (int)(u64)(key >> (L.rb + L.bb + L.ab + L.xb)); }
+template <bool WIDE> __device__ __forceinline__ int rs_keep(const RsTail& R, const RsElem<WIDE>* el, i64 i)
+{
+    if (i >= R.n) return 0;
+    if (i == 0) return 1;
+    const RsElem<WIDE> e = el[i], q = el[i - 1];
+    const u128 k = rs_key<WIDE>(e, R.L);
+    if (R.nodedup && R.nodedup[rs_seg_of<WIDE>(k, R.L)]) return R.drop ? !R.drop[i] : 1;
+    return !(k == rs_key<WIDE>(q, R.L) && rs_aux<WIDE>(e, R.L) == rs_aux<WIDE>(q, R.L));
+}
+template <bool WIDE> __global__ __launch_bounds__(256) void k_rs_count(RsTail R, const RsElem<WIDE>* el)
+{
+    const i64 base = (i64)blockIdx.x * 2048 + (threadIdx.x >> 6) * 512;
+    int cnt = 0;
+    for (int r = 0; r < 8; r++) cnt += __popcll(__ballot(rs_keep<WIDE>(R, el, base + r * 64 + (threadIdx.x & 63))));
+    __shared__ int s[4];
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) R.partial[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+}
+template <bool WIDE> __global__ __launch_bounds__(256) void k_rs_apply(RsTail R, const RsElem<WIDE>* el)
+{
+    __shared__ i64 sh[4];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const i64 base = (i64)blockIdx.x * 2048 + wv * 512;
+    u64 masks[8]; int cnt = 0;
+    for (int r = 0; r < 8; r++) { masks[r] = __ballot(rs_keep<WIDE>(R, el, base + r * 64 + lane)); cnt += __popcll(masks[r]); }
+    int run = (int)block_prefix_of(R.partial, blockIdx.x, sh);
+    __shared__ int s[4];
+    if (lane == 0) s[wv] = cnt;
+    __syncthreads();
+    for (int k = 0; k < wv; k++) run += s[k];
+    const KeyLayout& L = R.L;
+    for (int r = 0; r < 8; r++) {
+        const i64 i = base + r * 64 + lane;
+        const u64 m = masks[r];
+        if ((m >> lane) & 1) {
+            const int o = run + __popcll(m & ((1ull << lane) - 1ull));
+            const RsElem<WIDE> e = el[i];
+            const u128 k = rs_key<WIDE>(e, L);
+            R.o_rid[o] = (int)((u64)k & rs_mask(L.rb));
+            R.o_b[o] = (i64)((u64)(k >> L.rb) & rs_mask(L.bb));
+            R.o_a[o] = (i64)((u64)(k >> (L.rb + L.bb)) & rs_mask(L.ab));
+            R.o_seg[o] = rs_seg_of<WIDE>(k, L);
+            R.o_aux[o] = rs_aux<WIDE>(e, L);
+            R.o_src[o] = rs_idx<WIDE>(e, L);
+        }
+        run += __popcll(m);
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) *R.n_out = run;
+}
+// tie groups of the keep-every-row segments (equal keys), as {position | continues << 31, source row}
+template <bool WIDE> __global__ __launch_bounds__(256) void k_rs_ties(RsTail R, const RsElem<WIDE>* el, int2* list, int* n_list)
+{
+    const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (i >= R.n) return;
+    const u128 k = rs_key<WIDE>(el[i], R.L);
+    if (!R.nodedup[rs_seg_of<WIDE>(k, R.L)]) return;
+    const bool cont = i > 0 && rs_key<WIDE>(el[i - 1], R.L) == k;
+    const bool head = !cont && i + 1 < R.n && rs_key<WIDE>(el[i + 1], R.L) == k;
+    if (cont || head) list[atomicAdd(n_list, 1)] = make_int2((int)i | (cont ? (int)0x80000000 : 0), rs_idx<WIDE>(el[i], R.L));
+}
+// the caller's answer: the element at pos[k] becomes source row src[k] (same key: only the row and its aux word change)
+template <bool WIDE> __global__ __launch_bounds__(256) void k_rs_tie_apply(int n, const int* pos, const int* src, const uint8_t* flag, const int* aux_col,
+                                                                           KeyLayout L, RsElem<WIDE>* el, uint8_t* drop)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    RsElem<WIDE> e = el[pos[k]];
+    rs_set_row<WIDE>(e, L, src[k], aux_col[src[k]]);
+    el[pos[k]] = e;
+    drop[pos[k]] = flag[k];
 }
 
 // ---------------------------------------------------------------------------------------- gather + de-dup
@@ -255,8 +483,8 @@ __global__ __launch_bounds__(256) void k_pool_to_rows(const int* p_seg, const i6
                                                       const int* rank, i64 n_rank, int n_seg, const uint8_t* seg_aux_major,
                                                       int* o_seg, i64* o_a, i64* o_b, int* o_rid, int* o_aux, unsigned long long* mx)
 {
-    __shared__ unsigned long long sh[4][6];
-    unsigned long long m[6] = {0, 0, 0, 0, 0, 0};
+    __shared__ unsigned long long sh[4][7];
+    unsigned long long m[7] = {0, 0, 0, 0, 0, 0, 0};                 // [6]: aux of every row (rides along with the composite key)
     for (i64 i = (i64)blockIdx.x * 2048 + threadIdx.x; i < n && i < (i64)(blockIdx.x + 1) * 2048; i += 256) {
         const int sg = p_seg[i], rd = p_read[i], ax = p_aux[i];
         const i64 a = p_a[i], b = p_b[i];
@@ -271,10 +499,11 @@ __global__ __launch_bounds__(256) void k_pool_to_rows(const int* p_seg, const i6
             m[2] = (unsigned long long)rk > m[2] ? (unsigned long long)rk : m[2];
             if (seg_aux_major[sg]) m[3] = (unsigned long long)ax > m[3] ? (unsigned long long)ax : m[3];
             m[4] = (unsigned long long)sg > m[4] ? (unsigned long long)sg : m[4];
+            m[6] = (unsigned long long)ax > m[6] ? (unsigned long long)ax : m[6];
         }
     }
 #pragma unroll
-    for (int k = 0; k < 6; k++) {
+    for (int k = 0; k < 7; k++) {
         for (int d = 32; d > 0; d >>= 1) {
             const unsigned lo = __shfl_xor((unsigned)(m[k] & 0xffffffffull), d), hi = __shfl_xor((unsigned)(m[k] >> 32), d);
             const unsigned long long o = ((unsigned long long)hi << 32) | lo;
@@ -283,7 +512,7 @@ __global__ __launch_bounds__(256) void k_pool_to_rows(const int* p_seg, const i6
         if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6][k] = m[k];
     }
     __syncthreads();
-    if (threadIdx.x < 6) {
+    if (threadIdx.x < 7) {
         unsigned long long v = sh[0][threadIdx.x];
         for (int w = 1; w < 4; w++) v = sh[w][threadIdx.x] > v ? sh[w][threadIdx.x] : v;
         if (v) atomicMax(&mx[threadIdx.x], v);
