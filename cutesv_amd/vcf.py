@@ -85,9 +85,19 @@ def emit_records(store, segments, res, reference, min_size=30, max_size=100000, 
     # inserted sequences of INS calls, sliced to SVLEN
     alt_blob, alt_off = None, None
     if n and not ignore_sequence and (call_type == _abi.INS).any():
-        pick, ln = t["seq_pick"].tolist(), t["bp2"].tolist()
-        alt = [store.sequence(pick[c])[:ln[c]] if call_type[c] == _abi.INS else "" for c in range(n)]
-        alt_blob, alt_off = _csr(alt)
+        ins = np.flatnonzero(call_type == _abi.INS)
+        pick, ln = t["seq_pick"][ins].tolist(), t["bp2"][ins].tolist()
+        if store.ins_seq is None and store.names.names is None:           # synthetic stores: 'ACGT' repeated to the aux length (SigStore.sequence)
+            sl = np.minimum(store.aux[t["seq_pick"][ins]], t["bp2"][ins]).tolist()
+            base = "ACGT" * (max(sl, default=0) // 4 + 1)
+            parts = [base[:k] for k in sl]
+        else:
+            seq = store.sequence
+            parts = [seq(pick[i])[:ln[i]] for i in range(len(ins))]
+        alt_off = np.zeros(n + 1, np.int64)
+        alt_off[ins + 1] = [len(x) for x in parts]
+        np.cumsum(alt_off, out=alt_off)
+        alt_blob = "".join(parts).encode()
     rn_blob, rn_off = None, None
     if n and report_readid:
         nm = store.names.take(store.read_id[t["support_sig"]])

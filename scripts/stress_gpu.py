@@ -56,8 +56,8 @@ for it in range(n_it):
             lo, hi = int(st.reads_off[c]), int(st.reads_off[c + 1])
             perm[lo:hi] = lo + rng.permutation(hi - lo)
         st = dataclasses.replace(st, r_start=st.r_start[perm], r_end=st.r_end[perm], r_primary=st.r_primary[perm], r_id=st.r_id[perm])
-    if rng.integers(0, 3) == 0:
-        st = st.pinned()                                  # page-locked columns, int32 twins of the positions / lengths
+    if rng.integers(0, 2) == 0:
+        st = st.pinned()                                  # page-locked columns, int32 twins of the positions / lengths (half of the runs)
     hb = st.host_batch(tasks, p)
     try:
         want = oracle.cluster_batch(hb, per_sig=True).trimmed()
