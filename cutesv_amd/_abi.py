@@ -65,7 +65,7 @@ _OUT_ARRAYS = [  # (name, dtype, which capacity)
 class BatchOut(C.Structure):
     _fields_ = ([("cap_calls", C.c_int64), ("cap_support", C.c_int64),
                  ("n_calls", C.c_int64), ("n_support", C.c_int64), ("n_clusters", C.c_int64)]
-                + [(name, C.c_void_p) for name, _, _ in _OUT_ARRAYS])
+                + [(name, C.c_void_p) for name, _, _ in _OUT_ARRAYS] + [("support_sig32", C.c_void_p)])
 
 
 class RunStats(C.Structure):
@@ -169,9 +169,10 @@ class HostBatch:
 class HostResult:
     """Caller-allocated csv_batch_out plus numpy views on it."""
 
-    def __init__(self, n_sig, cap_calls, cap_support, per_sig=False, n_seg=0, alloc=None):
+    def __init__(self, n_sig, cap_calls, cap_support, per_sig=False, n_seg=0, alloc=None, narrow_support=False):
         """alloc(shape, dtype) -> array: where the result arrays live (default numpy; engine.pinned_empty puts them in
-        page-locked memory, so that the device-to-host copies land in them by DMA)"""
+        page-locked memory, so that the device-to-host copies land in them by DMA).  narrow_support: the support list as int32
+        (csv_batch_out.support_sig32): `arrays["support_sig"]` is then an int32 array - every consumer indexes with it"""
         empty = alloc or (lambda n, dt: np.empty(n, dtype=dt))
         self.cap_calls = int(cap_calls)
         self.cap_support = int(cap_support)
@@ -189,9 +190,12 @@ class HostResult:
                 arr = empty(self.cap_calls + 1, dt)
                 arr[:] = 0
             else:
-                arr = empty(self.cap_support, dt)
+                arr = empty(self.cap_support, np.int32 if narrow_support else dt)
             self.arrays[name] = arr
             kw[name] = _ptr(arr)
+        if narrow_support:
+            kw["support_sig32"], kw["support_sig"] = kw["support_sig"], None
+        self.narrow_support = bool(narrow_support)
         self.c = BatchOut(cap_calls=self.cap_calls, cap_support=self.cap_support, **kw)
 
     @property

@@ -525,7 +525,7 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
     // temp call records are indexed by w (a cluster's slots live in its own signature range)
     PL(t_rec, (W + 1) * sizeof(TmpRec)); PL(t_rec0, (cap_items + 1) * sizeof(TmpRec));
     PL(sc_k, SC * 8); PL(sc_x, SC * 8); PL(sc_v1, SC * 4); PL(sc_v2, SC * 4); PL(sc_v3, SC * 4); PL(sc_v4, SC * 4); PL(sc_v5, SC * 4);
-    PL(o_rec, (cap_tmp + 1) * sizeof(CallRec)); PL(o_supsig, (W + 1) * 8); PL(o_suprid, (W + 1) * 4);
+    PL(o_rec, (cap_tmp + 1) * sizeof(CallRec)); PL(o_supsig, (W + 1) * 4); PL(o_suprid, (W + 1) * 4);
     if (have_tab) { PL(reads_off, (in->n_chrom + 1) * 8); PL(contig_len, (in->n_chrom + 1) * 8); }
     if (R > 0) {
         PL(gt_over, (cap_tmp + 2) * 4); PL(gt_huge, (cap_tmp + 2) * 4); PL(gt_pool, pool_n * 4);
@@ -705,7 +705,7 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
     B.t_rec = dp<TmpRec>(c->t_rec); B.t_rec0 = dp<TmpRec>(c->t_rec0);
     B.cap_tmp = (int)cap_tmp; B.cap_items = (int)cap_items;
     B.sc_k = dp<u64>(c->sc_k); B.sc_x = dp<i64>(c->sc_x); B.sc_v1 = dp<int>(c->sc_v1); B.sc_v2 = dp<int>(c->sc_v2); B.sc_v3 = dp<int>(c->sc_v3); B.sc_v4 = dp<int>(c->sc_v4); B.sc_v5 = dp<int>(c->sc_v5);
-    B.o_rec = dp<CallRec>(c->o_rec); B.o_supsig = dp<i64>(c->o_supsig); B.o_suprid = dp<int>(c->o_suprid);
+    B.o_rec = dp<CallRec>(c->o_rec); B.o_supsig = dp<int>(c->o_supsig); B.o_suprid = dp<int>(c->o_suprid);
     B.n_reads = R;
     if (have_tab) { B.reads_off = dp<i64>(c->reads_off); B.contig_len = dp<i64>(c->contig_len); }
     if (R > 0) {
@@ -1087,9 +1087,10 @@ bool publish_targets(csv_ctx* c, const csv_batch_out* out, PublishArgs& P)
     (void)c;
     if (getenv("CSV_NO_PUBLISH") || out->cap_calls < 0 || out->cap_support < 0) return false;
     const size_t nc = (size_t)out->cap_calls, ns = (size_t)out->cap_support;
+    const bool sup32 = out->support_sig32 != nullptr;
     const void* host[15] = {out->call_seg, out->call_cluster, out->call_aux, out->support, out->cipos, out->cilen, out->dr, out->dv, out->gl_idx,
-                            out->bp1, out->bp2, out->search_pos, out->seq_pick, out->support_off, out->support_sig};
-    const size_t bytes[15] = {nc * 4, nc * 4, nc * 4, nc * 4, nc * 4, nc * 4, nc * 4, nc * 4, nc * 4, nc * 8, nc * 8, nc * 8, nc * 8, (nc + 1) * 8, ns * 8};
+                            out->bp1, out->bp2, out->search_pos, out->seq_pick, out->support_off, sup32 ? (const void*)out->support_sig32 : (const void*)out->support_sig};
+    const size_t bytes[15] = {nc * 4, nc * 4, nc * 4, nc * 4, nc * 4, nc * 4, nc * 4, nc * 4, nc * 4, nc * 8, nc * 8, nc * 8, nc * 8, (nc + 1) * 8, ns * (sup32 ? 4 : 8)};
     void* dev[15];
     for (int i = 0; i < 15; i++) {
         if (!host[i]) return false;
@@ -1099,7 +1100,7 @@ bool publish_targets(csv_ctx* c, const csv_batch_out* out, PublishArgs& P)
     P.call_seg = (int*)dev[0]; P.call_cluster = (int*)dev[1]; P.call_aux = (int*)dev[2]; P.support = (int*)dev[3]; P.cipos = (int*)dev[4];
     P.cilen = (int*)dev[5]; P.dr = (int*)dev[6]; P.dv = (int*)dev[7]; P.gl_idx = (int*)dev[8];
     P.bp1 = (i64*)dev[9]; P.bp2 = (i64*)dev[10]; P.search_pos = (i64*)dev[11]; P.seq_pick = (i64*)dev[12]; P.support_off = (i64*)dev[13];
-    P.support_sig = (i64*)dev[14];
+    P.support_sig = sup32 ? nullptr : (i64*)dev[14]; P.support_sig32 = sup32 ? (int*)dev[14] : nullptr;
     return true;
 }
 
@@ -1107,6 +1108,8 @@ int csv_batch_download(csv_ctx* c, csv_batch_out* out)
 {
     if (!c || !out) return CSV_E_INVALID;
     if (!c->ran) return fail(c, CSV_E_STATE, "csv_batch_download before csv_batch_run");
+    if ((out->support_sig != nullptr) == (out->support_sig32 != nullptr))
+        return fail(c, CSV_E_INVALID, "csv_batch_out: exactly one of support_sig / support_sig32 must be given");
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t st = c->stream;
     const int S0 = (int)c->h_seg.size();
@@ -1159,12 +1162,15 @@ int csv_batch_download(csv_ctx* c, csv_batch_out* out)
     const DevBatch& B = c->B;
     const int S = (int)c->h_seg.size();
     const size_t o_rec = 256, o_err = published ? 256 : o_rec + ((nc * sizeof(CallRec) + 255) & ~(size_t)255), o_end = o_err + (size_t)(S + 1) * 4;
+    int* sup_stage = nullptr;
     if (!published) {
-    if (o_end > c->h_pin_cap) { const int rc = pin_reserve(c, o_end); if (rc) return rc; }
+    if (o_end + (out->support_sig32 ? 0 : ns * 4) + 64 > c->h_pin_cap) { const int rc = pin_reserve(c, o_end + (out->support_sig32 ? 0 : ns * 4) + 64); if (rc) return rc; }
     // the call records first: they are unpacked on the host while the (larger) support list is still on its way
     if (nc) HIP_TRY(c, hipMemcpyAsync(c->h_pin + o_rec, B.o_rec, nc * sizeof(CallRec), hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipEventRecord(c->ev_sel, st));
-    if (ns) HIP_TRY(c, hipMemcpyAsync(out->support_sig, B.o_supsig, ns * 8, hipMemcpyDeviceToHost, st));    // (already in its final layout)
+    // the support list is int32 on the device: straight into the caller's int32 array, or widened on the host behind the copy
+    if (ns && out->support_sig32) HIP_TRY(c, hipMemcpyAsync(out->support_sig32, B.o_supsig, ns * 4, hipMemcpyDeviceToHost, st));
+    else if (ns) { sup_stage = (int*)(c->h_pin + o_end); HIP_TRY(c, hipMemcpyAsync(sup_stage, B.o_supsig, ns * 4, hipMemcpyDeviceToHost, st)); }
     if (S) HIP_TRY(c, hipMemcpyAsync(c->h_pin + o_err, B.seg_err, (size_t)S * 4, hipMemcpyDeviceToHost, st));
     }
     if (out->cluster_id) memset(out->cluster_id, 0xff, (size_t)c->n_sig_host * 4);
@@ -1192,6 +1198,7 @@ int csv_batch_download(csv_ctx* c, csv_batch_out* out)
         if (out->support_off) out->support_off[nc] = (int64_t)ns;
     }
     if (!published || out->cluster_id || out->allele_id) HIP_TRY(c, hipStreamSynchronize(st));
+    if (sup_stage) for (size_t i = 0; i < ns; i++) out->support_sig[i] = sup_stage[i];
     if (out->seg_status && S) memcpy(out->seg_status, c->h_pin + o_err, (size_t)S * 4);
     return CSV_OK;
 }

@@ -177,7 +177,7 @@ struct DevBatch {
     u64*           sc_k; i64* sc_x; int* sc_v1; int* sc_v2; int* sc_v3; int* sc_v4; int* sc_v5;
     // final outputs: one 96-byte record per call (the host unpacks it into csv_batch_out's arrays after ONE copy)
     CallRec*       o_rec;
-    i64*           o_supsig;         // global signature index
+    int*           o_supsig;         // global signature index (a batch holds fewer than 2^31 signatures)
     int*           o_suprid;         // read id of the support (genotype)
     int*           allele_id;        // W
     // reads
@@ -2439,7 +2439,7 @@ __device__ __forceinline__ void emit_item_serial(const DevBatch& B, int j, i64 b
             const int src = s + __shfl(tso, l);
             for (int i = lane; i < nn; i += 64) {
                 const int w = B.sup_tmp[src + i];
-                B.o_supsig[dst + i] = gs + w;
+                B.o_supsig[dst + i] = (int)(gs + w);
                 if (sgk.genotype) { const int r = B.rid[w]; B.o_suprid[dst + i] = r; if (r < 0) atomicOr(&B.cnt->error, ERR_KEY_RANGE); }
                 if (B.per_sig) B.allele_id[w] = cc;
             }
@@ -2556,7 +2556,7 @@ __global__ __launch_bounds__(256) void k_emit(DevBatch B)
 #pragma unroll
                 for (int u = 0; u < 4; u++)
                     if (sr[u] >= 0) {
-                        B.o_supsig[dst + i + 8 * u] = gs + sr[u];
+                        B.o_supsig[dst + i + 8 * u] = (int)(gs + sr[u]);
                         if (gtseg) {
                             B.o_suprid[dst + i + 8 * u] = rd[u];
                             if (rd[u] < 0) atomicOr(&B.cnt->error, ERR_KEY_RANGE);      // (a negative id would pass for an empty hash slot)
@@ -2581,6 +2581,7 @@ struct PublishArgs {
     int n_seg;
     int *call_seg, *call_cluster, *call_aux, *support, *cipos, *cilen, *dr, *dv, *gl_idx;
     i64 *bp1, *bp2, *search_pos, *seq_pick, *support_off, *support_sig;
+    int *support_sig32;      // the caller's int32 support list (then support_sig is NULL)
 };
 __global__ __launch_bounds__(256) void k_publish(DevBatch B, PublishArgs P)
 {
@@ -2605,7 +2606,8 @@ __global__ __launch_bounds__(256) void k_publish(DevBatch B, PublishArgs P)
         P.dr[i] = r4.x; P.dv[i] = r4.y; P.gl_idx[i] = r4.z;
     }
     if (tid == 0) P.support_off[nc] = ns;
-    for (i64 i = tid; i < ns; i += nth) P.support_sig[i] = B.o_supsig[i];
+    if (P.support_sig32) { for (i64 i = tid; i < ns; i += nth) P.support_sig32[i] = B.o_supsig[i]; }
+    else for (i64 i = tid; i < ns; i += nth) P.support_sig[i] = (i64)B.o_supsig[i];
 }
 
 // ------------------------------------------------------------------------------------ reads: order + pack

@@ -92,13 +92,13 @@ template <class Sink> int layout(const csv_rows_in* in, Sink& S, int64_t c_begin
             int64_t total = s1 > s0 ? s1 - s0 - 1 : 0;      // commas
             if (in->name_blob) {
                 for (int64_t i = s0; i < s1; i++) {
-                    const int32_t id = in->read_id[R.support_sig[i]];
+                    const int32_t id = in->read_id[R.support_sig ? R.support_sig[i] : (int64_t)R.support_sig32[i]];
                     if (id < 0 || id >= in->n_names) return false;
                     total += in->name_off[id + 1] - in->name_off[id];
                 }
             } else {
                 for (int64_t i = s0; i < s1; i++) {
-                    const int32_t id = in->read_id[R.support_sig[i]];
+                    const int32_t id = in->read_id[R.support_sig ? R.support_sig[i] : (int64_t)R.support_sig32[i]];
                     if (id < 0) return false;
                     const int d = id < 1000000000 && in->name_width >= 9 ? 0 : dec_len((uint32_t)id);
                     total += name_prefix_len + (d > in->name_width ? d : in->name_width);
@@ -109,7 +109,7 @@ template <class Sink> int layout(const csv_rows_in* in, Sink& S, int64_t c_begin
             if (d) {
                 for (int64_t i = s0; i < s1; i++) {
                     if (i > s0) *d++ = ',';
-                    const int32_t id = in->read_id[R.support_sig[i]];
+                    const int32_t id = in->read_id[R.support_sig ? R.support_sig[i] : (int64_t)R.support_sig32[i]];
                     if (in->name_blob) { const int64_t n = in->name_off[id + 1] - in->name_off[id]; memcpy(d, in->name_blob + in->name_off[id], (size_t)n); d += n; }
                     else { if (name_prefix_len) { memcpy(d, in->name_prefix, (size_t)name_prefix_len); d += name_prefix_len; } d = put_padded_u32(d, (uint32_t)id, in->name_width); }
                 }

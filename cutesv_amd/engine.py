@@ -95,7 +95,7 @@ class Context:
         default: the device then writes the calls straight into them (k_publish) and a download is one synchronisation"""
         n = self._batch.n_sig
         return _abi.HostResult(n, cap_calls or max(64, n // 16 + 16), cap_support or max(64, n + 16), per_sig=per_sig,
-                               n_seg=len(self._batch.segments), alloc=pinned_empty if pinned else None)
+                               n_seg=len(self._batch.segments), alloc=pinned_empty if pinned else None, narrow_support=True)
 
     def download(self, per_sig=False, cap_calls=None, cap_support=None, into=None):
         if into is not None:
@@ -129,7 +129,7 @@ class Context:
                     or res.per_sig != per_sig or (per_sig and res.n_sig != n)):
                 # (recycled arrays are worth page-locking: the result copies then land in them by DMA)
                 res = _abi.HostResult(n, cap_calls, cap_support, per_sig=per_sig, n_seg=len(batch.segments),
-                                      alloc=pinned_empty if reuse else None)
+                                      alloc=pinned_empty if reuse else None, narrow_support=bool(reuse))
                 if reuse:
                     self._res_cache = res
             rc = lib().csv_cluster_batch(self._h, C.byref(batch.c), C.byref(res.c))

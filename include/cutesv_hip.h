@@ -178,6 +178,9 @@ typedef struct csv_batch_out {
     int32_t* cluster_id;    /* n_sig or NULL */
     int32_t* allele_id;     /* n_sig or NULL */
     int32_t* seg_status;    /* n_seg or NULL */
+    int32_t* support_sig32; /* (ABI v6) cap_support or NULL: the support list as int32 - a batch holds fewer than 2^31 signatures -
+                               INSTEAD of support_sig (exactly one of the two is given): half the bytes of the largest result
+                               array on the link */
 } csv_batch_out;
 
 /* Per-kernel device timings of one csv_batch_run, measured with HIP events recorded on the
