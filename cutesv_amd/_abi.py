@@ -196,6 +196,7 @@ class HostResult:
         if narrow_support:
             kw["support_sig32"], kw["support_sig"] = kw["support_sig"], None
         self.narrow_support = bool(narrow_support)
+        self.n_seg_used = self.n_seg                 # segments of the batch the arrays were last filled for (a recycled result may be larger)
         self.c = BatchOut(cap_calls=self.cap_calls, cap_support=self.cap_support, **kw)
 
     @property
@@ -224,6 +225,8 @@ class HostResult:
                 out[name] = arr[:nc + 1]
             elif cap == "support":
                 out[name] = arr[:ns]
+            elif cap == "seg":
+                out[name] = arr[:max(1, self.n_seg_used)]
             else:
                 out[name] = arr
         out["n_clusters"] = self.n_clusters

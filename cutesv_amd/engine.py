@@ -100,6 +100,7 @@ class Context:
     def download(self, per_sig=False, cap_calls=None, cap_support=None, into=None):
         if into is not None:
             self._check(lib().csv_batch_download(self._h, C.byref(into.c)))       # (E_CAPACITY: the caller sized `into`; it is raised)
+            into.n_seg_used = len(self._batch.segments)
             return into
         n = self._batch.n_sig
         cap_calls = cap_calls or max(64, n // 16 + 16)
@@ -137,6 +138,7 @@ class Context:
                 cap_calls, cap_support = max(cap_calls, res.n_calls + 1), max(cap_support, res.n_support + 1)
                 continue
             self._check(rc)
+            res.n_seg_used = len(batch.segments)
             return res
         raise CsvError(_abi.E_CAPACITY, "capacity retry failed")
 
