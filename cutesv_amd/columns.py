@@ -100,13 +100,14 @@ def _sparse_blob(table, picks, n=None):
     picks = np.unique(picks[picks >= 0])
     if isinstance(table, dict):
         picks = picks[np.fromiter((int(i) in table for i in picks.tolist()), bool, len(picks))] if len(picks) else picks
-    vals = [table[i].encode() for i in picks.tolist()]
+    from . import _cols_native as cn                     # (built by the same make as the library; no Python fallback)
+    took = np.empty(len(picks), np.int64)
+    blob = cn.clip_join(table, np.ascontiguousarray(picks), np.full(len(picks), np.iinfo(np.int64).max, np.int64), took)
     lens = np.zeros(n, np.int64)
-    if len(picks):
-        lens[picks] = [len(v) for v in vals]
+    lens[picks] = took
     off = np.zeros(n + 1, np.int64)
     np.cumsum(lens, out=off[1:])
-    return b"".join(vals), off
+    return blob, off
 
 
 @dataclass

@@ -18,6 +18,7 @@
 #define PY_SSIZE_T_CLEAN
 #include <Python.h>
 #include <stdint.h>
+#include <string.h>
 #include <vector>
 
 namespace {
@@ -216,10 +217,101 @@ PyObject* column(PyObject*, PyObject* args)
     return out;
 }
 
+// clip_join(table, picks, lens, out_len) -> bytes: b"".join(table[picks[i]][:lens[i]].encode() for i ...), the lengths actually
+// taken written to out_len - the ALT strings of a batch's INS calls (cuteSV_genotype.py:297-309: the inserted sequence sliced
+// to SVLEN) as csv_vcf_in.ins_alt takes them, in two C passes over the picked strings instead of four Python-level ones.
+//   table    list / tuple by index, dict keyed by int, or None: the synthetic stores' "ACGT" repeated (lens is then the length)
+//   picks    int64 buffer (indices / keys); lens: int64 buffer (Python slice ends: negative counts from the end); out_len: int64, writable
+// A string that is not ASCII takes the Python slice itself (code points, not bytes).
+PyObject* clip_join(PyObject*, PyObject* args)
+{
+    PyObject *table, *opicks, *olens, *oout;
+    if (!PyArg_ParseTuple(args, "OOOO", &table, &opicks, &olens, &oout)) return nullptr;
+    Py_buffer pk{}, ln{};
+    if (PyObject_GetBuffer(opicks, &pk, PyBUF_C_CONTIGUOUS) != 0) return nullptr;
+    if (PyObject_GetBuffer(olens, &ln, PyBUF_C_CONTIGUOUS) != 0) { PyBuffer_Release(&pk); return nullptr; }
+    Buf out;
+    PyObject* res = nullptr;
+    PyObject* fast = nullptr;
+    std::vector<PyObject*> owned;                 // slices of non-ASCII strings (kept until the copy is done)
+    struct Piece { const char* p; Py_ssize_t n; };
+    std::vector<Piece> pieces;
+    do {
+        if (pk.itemsize != 8 || ln.itemsize != 8 || pk.len != ln.len) { PyErr_SetString(PyExc_ValueError, "clip_join: picks and lens must be int64 buffers of one length"); break; }
+        const Py_ssize_t n = pk.len / 8;
+        if (!out.get(oout, n, "clip_join out_len") || out.v.itemsize != 8) { if (!PyErr_Occurred()) PyErr_SetString(PyExc_ValueError, "clip_join: out_len must be int64"); break; }
+        const int64_t* picks = (const int64_t*)pk.buf;
+        const int64_t* lens = (const int64_t*)ln.buf;
+        int64_t* ol = (int64_t*)out.v.buf;
+        const bool synthetic = table == Py_None, is_dict = PyDict_Check(table);
+        PyObject** items = nullptr; Py_ssize_t n_items = 0;
+        if (!synthetic && !is_dict) {
+            fast = PySequence_Fast(table, "clip_join: table must be a list, a tuple, a dict or None");
+            if (!fast) break;
+            items = PySequence_Fast_ITEMS(fast); n_items = PySequence_Fast_GET_SIZE(fast);
+        }
+        pieces.resize((size_t)n);
+        int64_t total = 0, longest = 0;
+        bool ok = true;
+        for (Py_ssize_t i = 0; i < n && ok; i++) {
+            if (synthetic) {
+                const int64_t k = lens[i] > 0 ? lens[i] : 0;
+                pieces[(size_t)i] = {nullptr, (Py_ssize_t)k};
+                ol[i] = k; total += k; if (k > longest) longest = k;
+                continue;
+            }
+            PyObject* s;
+            if (is_dict) {
+                PyObject* key = PyLong_FromLongLong(picks[i]);
+                if (!key) { ok = false; break; }
+                s = PyDict_GetItemWithError(table, key);
+                Py_DECREF(key);
+                if (!s) { if (!PyErr_Occurred()) PyErr_Format(PyExc_KeyError, "%lld", (long long)picks[i]); ok = false; break; }
+            } else {
+                if (picks[i] < 0 || picks[i] >= n_items) { PyErr_Format(PyExc_IndexError, "clip_join: index %lld outside the table", (long long)picks[i]); ok = false; break; }
+                s = items[picks[i]];
+            }
+            if (!PyUnicode_Check(s)) { PyErr_SetString(PyExc_TypeError, "clip_join: the table must hold str"); ok = false; break; }
+            Py_ssize_t len = PyUnicode_GET_LENGTH(s);
+            int64_t end = lens[i] < 0 ? lens[i] + len : lens[i];
+            if (end < 0) end = 0;
+            if (end > len) end = len;
+            if (!PyUnicode_IS_ASCII(s)) {
+                s = PyUnicode_Substring(s, 0, (Py_ssize_t)end);
+                if (!s) { ok = false; break; }
+                owned.push_back(s);
+                Py_ssize_t nb;
+                const char* p = PyUnicode_AsUTF8AndSize(s, &nb);
+                if (!p) { ok = false; break; }
+                pieces[(size_t)i] = {p, nb};
+                ol[i] = nb; total += nb;
+                continue;
+            }
+            pieces[(size_t)i] = {(const char*)PyUnicode_1BYTE_DATA(s), (Py_ssize_t)end};
+            ol[i] = end; total += end;
+        }
+        if (!ok) break;
+        res = PyBytes_FromStringAndSize(nullptr, (Py_ssize_t)total);
+        if (!res) break;
+        char* dst = PyBytes_AS_STRING(res);
+        std::vector<char> pattern;
+        if (synthetic) { pattern.resize((size_t)longest + 4); for (size_t k = 0; k < pattern.size(); k++) pattern[k] = "ACGT"[k & 3]; }
+        for (const Piece& q : pieces) {
+            memcpy(dst, synthetic ? pattern.data() : q.p, (size_t)q.n);
+            dst += q.n;
+        }
+    } while (false);
+    for (PyObject* o : owned) Py_DECREF(o);
+    Py_XDECREF(fast);
+    PyBuffer_Release(&pk); PyBuffer_Release(&ln);
+    return res;
+}
+
 PyMethodDef kMethods[] = {
     {"walk", walk, METH_VARARGS, "walk(seq, ints, interns, lens): fill column buffers from a list of tuples"},
     {"intern", intern, METH_VARARGS, "intern(((seq, field, int32 buffer), ...)) -> distinct values by first appearance; ids into the buffers"},
     {"column", column, METH_VARARGS, "column(seq, field) -> [x[field] for x in seq]"},
+    {"clip_join", clip_join, METH_VARARGS, "clip_join(table, picks, lens, out_len) -> bytes of table[picks[i]][:lens[i]] joined"},
     {nullptr, nullptr, 0, nullptr}};
 PyModuleDef kModule = {PyModuleDef_HEAD_INIT, "_cols_native", "task lists -> flat columns (cutesv_amd/columns.py)", -1, kMethods, nullptr, nullptr, nullptr, nullptr};
 

@@ -85,19 +85,20 @@ def emit_records(store, segments, res, reference, min_size=30, max_size=100000, 
     # inserted sequences of INS calls, sliced to SVLEN
     alt_blob, alt_off = None, None
     if n and not ignore_sequence and (call_type == _abi.INS).any():
+        from . import _cols_native as cn                     # (built by the same make as the library; no Python fallback)
         ins = np.flatnonzero(call_type == _abi.INS)
-        pick, ln = t["seq_pick"][ins].tolist(), t["bp2"][ins].tolist()
-        if store.ins_seq is None and store.names.names is None:           # synthetic stores: 'ACGT' repeated to the aux length (SigStore.sequence)
-            sl = np.minimum(store.aux[t["seq_pick"][ins]], t["bp2"][ins]).tolist()
-            base = "ACGT" * (max(sl, default=0) // 4 + 1)
-            parts = [base[:k] for k in sl]
-        else:
-            seq = store.sequence
-            parts = [seq(pick[i])[:ln[i]] for i in range(len(ins))]
+        pick = np.ascontiguousarray(t["seq_pick"][ins], np.int64)
+        ln = np.ascontiguousarray(t["bp2"][ins], np.int64)
+        table = store.ins_seq
+        if table is None:
+            if store.names.names is not None:
+                store.sequence(0)                             # (raises: real read names but no inserted sequences)
+            ln = np.minimum(store.aux[pick].astype(np.int64), ln)      # synthetic stores: 'ACGT' repeated to the aux length
+        took = np.empty(len(ins), np.int64)
+        alt_blob = cn.clip_join(table, pick, ln, took)        # b"".join(sequence(pick)[:SVLEN]) in C (GT:297-309)
         alt_off = np.zeros(n + 1, np.int64)
-        alt_off[ins + 1] = [len(x) for x in parts]
+        alt_off[ins + 1] = took
         np.cumsum(alt_off, out=alt_off)
-        alt_blob = "".join(parts).encode()
     rn_blob, rn_off = None, None
     if n and report_readid:
         nm = store.names.take(store.read_id[t["support_sig"]])

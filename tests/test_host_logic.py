@@ -318,3 +318,30 @@ def test_vcf_text_is_the_same_on_one_thread_and_on_a_team(monkeypatch):
     want = emit(1)
     for threads in (4, 4, 7, 2, 4):
         assert emit(threads) == want
+
+
+def test_clip_join_is_the_python_slice_and_join():
+    """_cols_native.clip_join (the ALT strings of INS calls for csv_vcf_in.ins_alt) == b"".join(seq[pick][:SVLEN].encode()),
+    for the three shapes a store keeps its inserted sequences in (cuteSV_genotype.py:297-309)."""
+    from cutesv_amd import _cols_native as cn
+    rng = np.random.default_rng(5)
+    table = ["".join("ACGTN"[k] for k in rng.integers(0, 5, int(m))) for m in rng.integers(0, 90, 300)]
+    table[7] = "ACéGT中NN"                                  # not ASCII: sliced by code point
+    picks = rng.integers(0, len(table), 1000).astype(np.int64)
+    picks[:3] = 7
+    lens = rng.integers(-5, 120, 1000).astype(np.int64)
+    lens[:3] = (3, 6, 100)
+    want = [table[p][:k].encode() for p, k in zip(picks.tolist(), lens.tolist())]
+    for tab in (table, tuple(table), dict(enumerate(table))):
+        took = np.full(1000, -1, np.int64)
+        blob = cn.clip_join(tab, picks, lens, took)
+        assert blob == b"".join(want) and took.tolist() == [len(w) for w in want]
+    took = np.empty(1000, np.int64)
+    blob = cn.clip_join(None, picks, lens, took)
+    want = [("ACGT" * 40)[:max(0, k)].encode() for k in lens.tolist()]
+    assert blob == b"".join(want) and took.tolist() == [len(w) for w in want]
+    with pytest.raises(IndexError):
+        cn.clip_join(table, np.array([len(table)], np.int64), np.array([1], np.int64), np.empty(1, np.int64))
+    with pytest.raises(KeyError):
+        cn.clip_join({1: "A"}, np.array([2], np.int64), np.array([1], np.int64), np.empty(1, np.int64))
+    assert cn.clip_join(table, np.zeros(0, np.int64), np.zeros(0, np.int64), np.empty(0, np.int64)) == b""
