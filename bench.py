@@ -503,58 +503,6 @@ def resident_loops(ctx, phb, steps, warmup, dist=None):
     return dt, dt_k, res
 
 
-def two_in_flight(ctx, phb, steps, device):
-    """The `value` region with two batches in flight: a second context (own stream, own resident copy of the columns and
-    own page-locked result arrays) driven from a second host thread, so that one context's delivery over PCIe overlaps the
-    other's kernels.  A reported figure beside `value` (what a worker that streams samples sees), not `value` itself."""
-    import threading
-    ctx2 = engine.Context(device)
-    try:
-        pair = []
-        for c in (ctx, ctx2):
-            c.upload(phb, per_sig=False)
-            c.option(1, 0)
-            c.run(); c.sync()
-            p = c.download()
-            pair.append((c, c.result_buffers(cap_calls=p.n_calls + 64, cap_support=p.n_support + 64)))
-        gate = threading.Barrier(3)
-        err = []
-
-        def drive(c, res, n):
-            try:
-                for _ in range(3):
-                    c.run(); c.download(into=res)
-                gate.wait()
-                for _ in range(n):
-                    c.run(); c.download(into=res)
-                gate.wait()
-            except Exception as e:      # noqa: BLE001
-                err.append(repr(e))
-                gate.abort()
-
-        n = max(1, steps // 2)
-        th = [threading.Thread(target=drive, args=(c, r, n)) for c, r in pair]
-        for t in th:
-            t.start()
-        try:
-            gate.wait()
-            t0 = time.perf_counter()
-            gate.wait()
-            dt = time.perf_counter() - t0
-        except threading.BrokenBarrierError:
-            dt = None
-        for t in th:
-            t.join()
-        if err or dt is None:
-            return {"error": (err or ["barrier broken"])[0]}
-        same = all(np.array_equal(pair[0][1].trimmed()[k], pair[1][1].trimmed()[k]) for k in ("bp1", "bp2", "support", "support_sig"))
-        return {"steps": 2 * n, "ms_per_step": dt / (2 * n) * 1e3, "results_equal": bool(same),
-                "note": "two contexts (streams) alternate on one device, each step still = all kernels + delivery into page-locked host arrays"}
-    finally:
-        ctx2.close()
-        ctx.upload(phb, per_sig=False)
-
-
 def instrumented(ctx, phb, steps):
     """per-kernel HIP-event durations on the library's stream (per_sig on: kernel_units needs cluster_id); returns
     (mean stage ms with the per-signature outputs, the same without them, the run's stats, the downloaded result)"""
@@ -865,12 +813,6 @@ def main():
         h2d_bytes = (2 * phb.a.dtype.itemsize + 8) * n_sig + ((2 * phb.r_start.dtype.itemsize + 5) * int(phb.r_start.shape[0]) if phb.r_start is not None else 0)
         t_vcf = vcf_leg(ctx, pstore, params, tasks)
         t_task = per_task_leg(ctx, store, params, tasks)
-        try:
-            t_two = two_in_flight(ctx, phb, a.steps, local_rank % max(1, engine.device_count())) if world == 1 else None
-        except Exception as e:           # noqa: BLE001  (optional leg)
-            t_two = {"error": repr(e)}
-        if t_two and "ms_per_step" in t_two:
-            t_two["value"] = n_sig / (t_two["ms_per_step"] * 1e-3)
 
         # measured device-to-device copy ceiling of this box (report the fraction of the vendor peak AND of
         # the copy ceiling): 512 MiB hipMemcpy device to device, read + write bytes over the best of 10 runs
@@ -929,7 +871,6 @@ def main():
                              "stream synchronisation per step)"),
             "kernel_only": None if ko_ms is None else {"ms_per_step": ko_ms, "value": total_sig / (ko_ms * 1e-3),
                                                        "note": "the launch sequence alone, results left in HBM (the region r01-r03 reported as value)"},
-            "two_in_flight": t_two,
             "ms_per_step_reads_order_kept": ms_reads_kept,
             "higher_is_better": True, "scaling": "strong" if shard_mode else "weak", "vs_baseline": None, "dtype": "int64+f64", "data": "synthetic",
             "config": {"workload": wl_name, "signatures_per_gpu": n_sig, "signatures_total": total_sig, "segments": len(tasks),

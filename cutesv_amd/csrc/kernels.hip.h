@@ -1278,17 +1278,116 @@ template <int BLOCK> __device__ bool keys_out_of_range(const DevBatch& B, const 
 }
 
 // ---- DEL / INS: generate_del_cluster / generate_ins_cluster (INDEL:110-219, 319-432)
-template <int BLOCK, bool LDS, bool SMALLN> __device__ void refine_indel(const DevBatch& B, const ItemCtx& it, const ArraysT<LDS>& A, i64* red, int* ired)
+// STAGED (the one-wavefront tier, m <= 256): the cluster's four columns are read ONCE, in one round trip at the head - lengths
+// into X, sequence lengths into V5 (free on this path), positions kept in registers until the lengths are dead, then into X -
+// and every later step indexes LDS.  The unstaged form goes back to global memory for the lengths (twice), the positions and
+// the sequence lengths, each a dependent round trip of a kernel that is a chain of ~10 of them per cluster.
+template <int BLOCK, bool LDS, bool SMALLN, bool STAGED = false> __device__ void refine_indel(const DevBatch& B, const ItemCtx& it, const ArraysT<LDS>& A, i64* red, int* ired)
 {
+    static_assert(!STAGED || (BLOCK == 64 && LDS && SMALLN), "the staged form is the one-wavefront LDS tier");
+    constexpr int E = 4;                                                    // elements per lane of the staged form (m <= 256)
     const csv_segment& sg = B.seg[it.k];
     const int m = it.m, P = it.P, s = it.s, ib = it.ib;
     const u64 imask = (1ull << ib) - 1ull;
-    if (keys_out_of_range<BLOCK>(B, it, red)) { item_none(B, it.j); return; }
-    const int U = sort_by_read<BLOCK, LDS>(B, it, A, red);
+    i64 st_a[E];
+    int U;
+    if constexpr (STAGED) {
+        i64 st_b[E]; int st_r[E], st_x[E];
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            st_a[e] = 0; st_b[e] = 0; st_r[e] = 0; st_x[e] = 0;
+            if (64 * e < m) {                                               // (wave-uniform)
+                const int i = 64 * e + lane_id();
+                const i64 w = s + (i < m ? i : 0);
+                st_b[e] = B.b[w]; st_r[e] = B.rid[w]; st_a[e] = B.a[w]; st_x[e] = B.aux[w];
+            }
+        }
+        int bad = 0;
+#pragma unroll
+        for (int e = 0; e < E; e++) bad |= (64 * e + lane_id() < m) && ((((u64)st_b[e]) >> (63 - ib)) != 0);
+        if (__ballot(bad)) {                                                // keys_out_of_range
+            if (threadIdx.x == 0) atomicOr(&B.seg_err[it.k], CSV_SEG_KEY_RANGE);
+            item_none(B, it.j);
+            return;
+        }
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const int i = 64 * e + lane_id();
+            if (i < P) A.K[i] = i < m ? (((u64)(unsigned)st_r[e]) << 32) | (unsigned)i : PAD_KEY;
+            if (i < m) { A.X[i] = st_b[e]; A.V5[i] = st_x[e]; }
+        }
+        __syncthreads();
+        bitonic_sort<BLOCK>(A.K, P, 32);
+        int runs = 0;
+        for (int q = threadIdx.x; q < m; q += BLOCK) {
+            const u64 k = A.K[q];
+            A.V2[q] = (int)(k & 0xffffffffull);
+            runs += (q == 0) || ((A.K[q - 1] >> 32) != (k >> 32));
+        }
+        U = wave_sum_i32(runs);
+        __syncthreads();
+    } else {
+        if (keys_out_of_range<BLOCK>(B, it, red)) { item_none(B, it.j); return; }
+        U = sort_by_read<BLOCK, LDS>(B, it, A, red);
+    }
     if (U < sg.read_count) { item_none(B, it.j); return; }                  // INDEL:133-134
 
     // per run of equal read id: first appearance F (smallest index) and the kept signature
     // (strictly longest, earliest among equals)  INDEL:125-131.  New key = (len, F), staged in X.
+    i64 lsum = 0;
+    if constexpr (STAGED) {
+        u64 nk[E];
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const int q = 64 * e + lane_id();
+            u64 key = PAD_KEY;
+            if (q < m) {
+                const unsigned r = (unsigned)(A.K[q] >> 32);
+                if (q == 0 || (unsigned)(A.K[q - 1] >> 32) != r) {
+                    const int F = A.V2[q];
+                    int best = F; i64 bl = A.X[F];
+                    for (int t = q + 1; t < m && (unsigned)(A.K[t] >> 32) == r; t++) {
+                        const int i2 = A.V2[t]; const i64 l2 = A.X[i2];
+                        if (l2 > bl) { bl = l2; best = i2; }
+                    }
+                    A.V3[F] = best;
+                    key = ((u64)bl << ib) | (u64)F;
+                }
+            }
+            nk[e] = key;
+        }
+        __syncthreads();                                                    // the read-ordered keys and the lengths are dead
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const int q = 64 * e + lane_id();
+            if (q < P) A.K[q] = nk[e];
+            if (q < m) A.X[q] = st_a[e];                                    // positions by local index
+        }
+        __syncthreads();
+        bitonic_sort<BLOCK>(A.K, P, ib);    // == stable sort by length over first-appearance order (INDEL:136)
+        // rank order: a-values -> K, lengths -> X, kept local index -> V1
+        i64 av[E], lv[E]; int cv[E];
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const int r = 64 * e + lane_id();
+            av[e] = 0; lv[e] = 0; cv[e] = 0;
+            if (r < U) {
+                const u64 key = A.K[r];
+                cv[e] = A.V3[(int)(key & imask)];
+                lv[e] = (i64)(key >> ib);
+                av[e] = A.X[cv[e]];
+                lsum += lv[e];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const int r = 64 * e + lane_id();
+            if (r < U) { A.K[r] = (u64)av[e]; A.X[r] = lv[e]; A.V1[r] = cv[e]; }
+        }
+        lsum = wave_sum_i64(lsum);
+        __syncthreads();
+    } else {
     for (int q = threadIdx.x; q < P; q += BLOCK) {
         u64 key = PAD_KEY;
         if (q < m) {
@@ -1312,7 +1411,6 @@ template <int BLOCK, bool LDS, bool SMALLN> __device__ void refine_indel(const D
     bitonic_sort<BLOCK>(A.K, P, ib);    // == stable sort by length over first-appearance order (INDEL:136)
 
     // rank order: a-values -> K, lengths -> X, kept local index -> V1
-    i64 lsum = 0;
     for (int r = threadIdx.x; r < U; r += BLOCK) {
         const u64 key = A.K[r];
         const int ch = A.V3[(int)(key & imask)];
@@ -1322,6 +1420,7 @@ template <int BLOCK, bool LDS, bool SMALLN> __device__ void refine_indel(const D
     }
     lsum = block_sum_i64<BLOCK>(lsum, red);
     __syncthreads();
+    }
     const double thr = sg.diff_ratio * div_by((double)lsum, (double)U, B.rcp_tab[U]);          // INDEL:138 (exact division by table reciprocal: div_by)
 
     // allele split on consecutive length gaps (INDEL:153-162): V2[a] = first rank of allele a
@@ -1357,7 +1456,9 @@ template <int BLOCK, bool LDS, bool SMALLN> __device__ void refine_indel(const D
         A.V3[a] = rank; A.V4[a] = soff;
     }
     npass = (int)block_sum_i64<BLOCK>(npass, red);
-    const int tbase = s, aux0 = B.aux[s];
+    int aux0;
+    if constexpr (STAGED) aux0 = A.V5[0]; else aux0 = B.aux[s];
+    const int tbase = s;
 
     // per allele statistics: one wavefront per allele
     double rr = sg.remain_reads_ratio; if (rr > 1) rr = 1;                  // INDEL:46-47
@@ -1422,7 +1523,9 @@ template <int BLOCK, bool LDS, bool SMALLN> __device__ void refine_indel(const D
             valid = 0;
             for (int base = 0; base < n; base += 64) {
                 const int i = base + lane_id();
-                const int ok = (i < n) && ((i64)B.aux[s + A.V1[r0 + (i < n ? i : 0)]] >= want);
+                int sl;                                                      // len(seq) of the allele's i-th member
+                if constexpr (STAGED) sl = A.V5[A.V1[r0 + (i < n ? i : 0)]]; else sl = B.aux[s + A.V1[r0 + (i < n ? i : 0)]];
+                const int ok = (i < n) && ((i64)sl >= want);
                 const u64 mk = __ballot(ok);
                 if (mk) {
                     const int i0 = base + __ffsll((long long)mk) - 1;
@@ -1666,10 +1769,21 @@ template <int BLOCK, int CAP, bool BIG> __global__ __launch_bounds__(BLOCK, (BLO
     // the simulation beds.  The LDS network's 2 x 36 barriers and the serial np.std replay cost more than three more wavefronts
     // save.  What pays is not waiting for the tiers one after the other: see the second phase below.)
     const int lo = m_lo;
+    // (one-wavefront tiers: the list entry and the item record of the NEXT cluster are fetched while this one is refined - two
+    // dependent round trips off the head of every cluster.  Not in the workgroup tier: 10.3 -> 12.3 us on the 90x workload.)
+    constexpr bool AHEAD = BLOCK == 64;
+    int j_nx = 0; int4 rec_nx = make_int4(0, 0, 0, 0);
+    if (AHEAD && (int)blockIdx.x < n) { j_nx = big ? B.list_big[blockIdx.x] : B.list_small[blockIdx.x].x; rec_nx = B.item_rec[j_nx]; }
     for (int q = blockIdx.x; q < n; q += gridDim.x) {
         ItemCtx it;
-        it.j = big ? B.list_big[q] : B.list_small[q].x;
-        const int4 rec = B.item_rec[it.j];
+        int4 rec;
+        if constexpr (AHEAD) {
+            it.j = j_nx; rec = rec_nx;
+            if (q + (int)gridDim.x < n) { j_nx = big ? B.list_big[q + gridDim.x] : B.list_small[q + gridDim.x].x; rec_nx = B.item_rec[j_nx]; }
+        } else {
+            it.j = big ? B.list_big[q] : B.list_small[q].x;
+            rec = B.item_rec[it.j];
+        }
         it.cid = rec.x; it.k = rec.y; it.s = rec.z; it.m = rec.w;
         if (it.m <= lo || it.m > m_hi) continue;
         if (!big) { const int ty = B.seg[it.k].svtype; if (ty == CSV_DEL || ty == CSV_INS) continue; }
@@ -1687,7 +1801,7 @@ template <int BLOCK, int CAP, bool BIG> __global__ __launch_bounds__(BLOCK, (BLO
         const int t = B.seg[it.k].svtype;
         const bool indel = t == CSV_DEL || t == CSV_INS;
         if (P <= CAP) {
-            if constexpr (BIG) { if (indel) { refine_indel<BLOCK, true, (CAP <= 256)>(B, it, L, red, ired); continue; } }
+            if constexpr (BIG) { if (indel) { refine_indel<BLOCK, true, (CAP <= 256), (BLOCK == 64 && CAP <= 256 && !CSV_ABL(24))>(B, it, L, red, ired); continue; } }
             refine_pair<BLOCK, true>(B, it, L, red, ired);
         } else if constexpr (CAP <= 256) {
             // the one-wavefront tiers are only launched for m <= CAP; keeping the global-scratch path (and its
