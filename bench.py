@@ -183,7 +183,7 @@ def bench_rebuild(a):
                      "rebuild_on_device_then_cluster_ms": float(np.median(wall_dev[a.warmup:])) * 1e3,
                      "same_calls": bool(same),
                      "note": "wall clock of rebuild + csv_cluster_batch from unsorted host rows; second form: CSV_RB_KEEP_ON_DEVICE + CSV_IN_DEVICE_COLUMNS"}}
-    print(json.dumps(out))
+    emit(out)
     ctx.close()
 
 
@@ -250,7 +250,7 @@ def bench_extract(a):
                            "us_per_read_vs_cigar_scan": ms_s / ms_c,
                            "cpu_c_oracle_reads_per_s": n / t_s},
            "signatures": {"ins": int(len(got["ins_pos"])), "del": int(len(got["del_pos"]))}, "chain_extract_rebuild": chain, "parity_vs_oracle": bool(parity)}
-    print(json.dumps(out))
+    emit(out)
     ctx.close()
 
 
@@ -657,6 +657,28 @@ def measure_sharded(ctx, dist, rank, world, workload, scale, steps, warmup):
     return out, dt, total_sig, store, params, wl_name, pstore, phb, tasks, hb_plain
 
 
+_OUT_FD = None
+
+
+def quiet_stdout():
+    """Everything a library writes to file descriptor 1 from here on goes to stderr (gloo announces "[Gloo] Rank 0 is connected
+    to N peer ranks" on stdout); the benchmark line itself is written to the real stdout by emit()."""
+    global _OUT_FD
+    if _OUT_FD is None:
+        sys.stdout.flush()
+        _OUT_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(out):
+    line = (json.dumps(out) + "\n").encode()
+    if _OUT_FD is None:
+        sys.stdout.write(line.decode()); sys.stdout.flush()
+    else:
+        sys.stdout.flush()
+        os.write(_OUT_FD, line)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -669,6 +691,8 @@ def main():
     ap.add_argument("--no-others", action="store_true", help="skip the compact cfg2 / cfg4 / cfg5 objects of the default N = 1 line")
     ap.add_argument("--cpu-procs", type=int, default=0)
     a = ap.parse_args()
+    if "WORLD_SIZE" in os.environ or a.gpus == 1:
+        quiet_stdout()
 
     if a.workload == "rebuild":
         return bench_rebuild(a)
@@ -919,7 +943,7 @@ def main():
         }
         if not shard_mode:
             out["boundary"]["upload_ms"] = t_upload * 1e3
-        print(json.dumps(out))
+        emit(out)
     if dist is not None:
         dist.barrier()
     ctx.close()

@@ -909,8 +909,8 @@ int run_impl(csv_ctx* c, csv_run_stats* stats)
         int g_big = B.cap_items < 512 ? B.cap_items : 512;
         if (g_big < 1) g_big = 1;
         if (need_big) {
-            LAUNCH_ON(sB, "refine_mid", (k_refine<64, 256, true>), g_mid, 64, LDS_MID, B, 64, 256);
-            LAUNCH_ON(sB, "refine_block", (k_refine<256, 2048, true>), g_big, 256, LDS_BIG, B, 256, 0x7fffffff);
+            LAUNCH_ON(sB, "refine_mid", (k_refine<64, 256, true>), g_mid, 64, LDS_MID, B, 64, MID_CAP);
+            LAUNCH_ON(sB, "refine_block", (k_refine<256, 2048, true>), g_big, 256, LDS_BIG, B, MID_CAP, 0x7fffffff);
         } else { HIP_TRY(c, mark()); HIP_TRY(c, mark()); }
         if (side_b) { HIP_TRY(c, hipEventRecord(c->ev_aux[0], sB)); HIP_TRY(c, hipStreamWaitEvent(st, c->ev_aux[0], 0)); }
         if (side_c) { HIP_TRY(c, hipEventRecord(c->ev_aux[1], sC)); HIP_TRY(c, hipStreamWaitEvent(st, c->ev_aux[1], 0)); }

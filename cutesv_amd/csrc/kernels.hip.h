@@ -108,6 +108,7 @@ struct DevCounters {          // one small struct in device memory, zeroed at th
     int gt_ticket;            // workgroups of the second genotype pass that have finished
     int n_tra_huge;           // the same two for k_genotype_tra
     int tra_ticket;
+    int n_items_huge;         // work items above 256 signatures (the workgroup tier's; counted by k_chain_apply)
 };
 enum { RO_REORDER = 0, RO_IDENTITY = 1, RO_NEED_GENERAL = 2 };
 // What the reads-order stage found out about the reads table of the UPLOAD: unlike DevCounters it is not zeroed by every run (a
@@ -325,6 +326,7 @@ __device__ __forceinline__ int seg_of(const DevBatch& B, i64 w)
 // sentinel (see oracle csvo_cluster_batch).
 constexpr int CH_ITEMS = 8;                         // rows of 64 per wavefront
 constexpr int CH_TILE = 256 * CH_ITEMS;             // signatures per workgroup
+constexpr int MID_CAP = 256;                        // largest cluster of the one-wavefront tiers (k_refine<64,256>); above: the workgroup tier
 constexpr int CT_WORDS = CH_TILE / WAVE;            // flag words (64 signatures each) per tile
 constexpr int TI_STRIDE = CH_TILE + 8;              // work-item slots per tile (at most one per signature)
 
@@ -813,6 +815,10 @@ __global__ __launch_bounds__(256) void k_chain_apply(DevBatch B)
             if (wide) B.list_wide[bw + __popcll(m_wide & lanemask_lt())] = ent;
         }
         bb += __popcll(m_big); bt += __popcll(m_tiny); bw += __popcll(m_wide);
+        // (rare: the workgroup tier looks at this count before it walks the list of the items above 64 - on a 90x genome that
+        // list has 15 k entries, none of them its own, and the walk alone was 10 us)
+        const u64 m_huge = __ballot(act && (tier & 1) && rec.y > MID_CAP);
+        if (m_huge && lane_id() == 0) atomicAdd(&B.cnt->n_items_huge, __popcll(m_huge));
     }
     if (tile == ntile - 1 && lane_id() == 63) {             // its running counts now cover the whole batch
         B.cnt->n_clusters = run + (int)own0;
@@ -1764,6 +1770,7 @@ template <int BLOCK, int CAP, bool BIG> __global__ __launch_bounds__(BLOCK, (BLO
     i64* red = (i64*)(smem_raw + LDS_LEAD + 36 * N);
     int* ired = (int*)(red + 6);
     const int n = big ? B.cnt->n_items_big : (B.cnt->n_items - B.cnt->n_items_big - B.cnt->n_items_tiny);
+    if constexpr (BIG && BLOCK > 64) { if (B.cnt->n_items_huge == 0) return; }        // (nothing above MID_CAP signatures in this batch)
     // (r04, rejected: "tier by occupancy" - when a batch has fewer clusters of 65 .. 256 signatures than two per CU, hand each
     // to a whole 256-thread workgroup of the tier below instead of one wavefront: 29 us against 23 for the ~100 such clusters of
     // the simulation beds.  The LDS network's 2 x 36 barriers and the serial np.std replay cost more than three more wavefronts
