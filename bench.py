@@ -545,6 +545,28 @@ def traffic_of(workload, scale):
         return {k: v for k, v in json.load(f).items() if k.startswith("k_") and "." not in k and "[" not in k}
 
 
+def valu_issue_of(workload, scale, kernel, kernel_us, n_cu=256, clock_mhz=2400.0):
+    """How busy the kernel keeps the vector ALUs, from the SQ counter passes of the SAME command committed under profiles/
+    (scripts/profile_insts.sh -> profiles/insts_<workload>.json).  SQ_ACTIVE_INST_VALU counts, summed over all wavefronts, the
+    quad-cycles (4 clocks) in which a wavefront's VALU instruction occupies its SIMD; busy = that / (SIMDs x the kernel's own
+    duration).  The HBM roofline is what the bench contract asks for; THIS is the ceiling these integer kernels run against
+    (DESIGN.md section 5): a fraction near 1 means only fewer instructions make the kernel faster."""
+    f = os.path.join(ROOT, "profiles", "insts_%s.json" % workload)
+    if not os.path.exists(f) or scale != 1.0 or not kernel_us:
+        return None
+    with open(f) as fh:
+        r = json.load(fh).get(kernel)
+    if not r or not r.get("SQ_ACTIVE_INST_VALU"):
+        return None
+    simd_cycles = 4.0 * n_cu * kernel_us * clock_mhz
+    return {"kernel": kernel, "valu_insts_per_launch": r["SQ_INSTS_VALU"], "salu_insts_per_launch": r["SQ_INSTS_SALU"], "lds_insts_per_launch": r["SQ_INSTS_LDS"],
+            "waves": r["SQ_WAVES"], "valu_active_quad_cycles": r["SQ_ACTIVE_INST_VALU"],
+            "valu_busy_frac": 4.0 * r["SQ_ACTIVE_INST_VALU"] / simd_cycles, "clock_mhz_assumed": clock_mhz, "kernel_us": kernel_us,
+            "wave_share_issuing_valu": r["SQ_ACTIVE_INST_VALU"] / r["SQ_WAVE_CYCLES"] if r.get("SQ_WAVE_CYCLES") else None,
+            "wave_share_issue_stalled": r["SQ_WAIT_INST_ANY"] / r["SQ_WAVE_CYCLES"] if r.get("SQ_WAVE_CYCLES") else None,
+            "source": "profiles/insts_%s.json (rocprofv3 --pmc, two passes)" % workload}
+
+
 def compact_workload(ctx, name, a, cpu):
     """cfg2 / cfg4 / cfg5 in the N = 1 line, compact: the same two resident loops, the dominant kernel and its roofline
     fraction, parity of the int32-column device path against the C oracle at full size, the boundary call, the C all-threads
@@ -907,6 +929,8 @@ def main():
                                          "known byte counts: profiles/r04_pmc_calibration.txt); includes requests the Infinity Cache answers",
                          "algorithmic_bytes": kbytes[dom], "kernel_us": round(dom_us, 2), "kernel_us_net": per_kernel_nps[dom],
                          "boundary_us": None if boundary_us is None else round(boundary_us, 2),
+                         "valu_issue": valu_issue_of(a.workload, a.scale, "k_genotype" if dom == "genotype_stage" else dom,
+                                                     per_kernel_nps.get("k_genotype") if dom == "genotype_stage" else per_kernel_nps[dom]),
                          "copy_ceiling": copy_gbs, "frac_of_copy_ceiling": (achieved / copy_gbs) if copy_gbs else None,
                          "cold": {"kernel_us": per_kernel_cold[dom], "achieved": cold_achieved, "frac": None if cold_achieved is None else cold_achieved / HBM_PEAK_GBS,
                                   "pipeline_us": round(cold_tot / ncold * 1e3, 2),

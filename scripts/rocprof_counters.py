@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""rocprofv3 PMC passes (any counters, one or more rocpd databases) -> one table, per kernel and launch.
+
+    python scripts/rocprof_counters.py <pass1.db> [<pass2.db> ...] > profiles/<tag>_insts.txt
+
+Per-launch averages of every counter found; the int64-column instantiations are kept apart like rocprof_traffic.py does.
+Derived columns when their inputs are there: valu_per_wave = SQ_INSTS_VALU / SQ_WAVES;  valu_busy = SQ_ACTIVE_INST_VALU /
+SQ_BUSY_CYCLES / 4 (four SIMDs per CU share one busy-cycle count: the fraction of the kernel's CU-cycles in which a SIMD
+issued a vector instruction - a wave64 VALU instruction occupies its SIMD for 4 cycles)."""
+import sqlite3
+import sys
+
+from rocprof_traffic import short
+
+
+def main():
+    table, counters, launches = {}, [], {}
+    for db in sys.argv[1:]:
+        cur = sqlite3.connect(db).cursor()
+        for name, cname, n, avg in cur.execute("select kernel_name, counter_name, count(*), avg(value) from counters_collection "
+                                               "group by kernel_name, counter_name"):
+            k = short(name)
+            if cname not in counters:
+                counters.append(cname)
+            row = table.setdefault(k, {})
+            row[cname] = row.get(cname, 0.0) + avg           # (the two passes of k_genotype: summed)
+            launches[k] = max(launches.get(k, 0), n)
+    der = []
+    if "SQ_INSTS_VALU" in counters and "SQ_WAVES" in counters:
+        der.append("valu_per_wave")
+    if "SQ_ACTIVE_INST_VALU" in counters and "SQ_BUSY_CYCLES" in counters:
+        der.append("valu_busy")
+    print("# per launch, averaged over the launches of the run")
+    print("# %-26s %8s " % ("kernel", "launches") + " ".join("%18s" % c for c in counters + der))
+    key = "SQ_INSTS_VALU" if "SQ_INSTS_VALU" in counters else counters[0]
+    for k in sorted(table, key=lambda k: -table[k].get(key, 0.0)):
+        r = table[k]
+        d = []
+        if "valu_per_wave" in der:
+            d.append(r.get("SQ_INSTS_VALU", 0.0) / r["SQ_WAVES"] if r.get("SQ_WAVES") else 0.0)
+        if "valu_busy" in der:
+            d.append(r.get("SQ_ACTIVE_INST_VALU", 0.0) / r["SQ_BUSY_CYCLES"] / 4.0 if r.get("SQ_BUSY_CYCLES") else 0.0)
+        print("%-28s %8d " % (k, launches[k]) + " ".join("%18.1f" % r.get(c, 0.0) for c in counters) + " " + " ".join("%18.3f" % x for x in d))
+
+
+if __name__ == "__main__":
+    main()
