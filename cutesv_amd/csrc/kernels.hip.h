@@ -262,14 +262,36 @@ template <int CTRL, int RM> __device__ __forceinline__ i64 dpp_i64(i64 old, i64 
     const int hi = dpp_i32<CTRL, RM>((int)(old >> 32), (int)(v >> 32));
     return ((i64)hi << 32) | (unsigned)lo;
 }
+// One step of a 64-bit DPP scan: v + (v moved by the pattern; lanes without a source and rows outside the mask add nothing),
+// as the carry pair the hardware has for it - v_add_co_u32_dpp / v_addc_co_u32_dpp.  Written through dpp_i64 the compiler
+// builds the moved value as two 64-bit numbers (lo | 0 and 0 | hi), each from a zeroed register and a v_mov_b32_dpp, and adds
+// them with two v_lshl_add_u64: seven vector instructions a step where two do - and these kernels run at 60 - 86 % of the vector
+// ALUs' issue rate (profiles/r04_cfg3_insts.txt), so the count is the time.  s_nop 1: a DPP read needs two wait states after
+// the VALU write of its source, and the hazard recogniser does not look inside an asm block.
+template <int CTRL, int RM> __device__ __forceinline__ i64 dpp_add_i64(i64 v);
+#define CSV_DPP_ADD64(CTRL, RM, TXT)                                                                                              \
+    template <> __device__ __forceinline__ i64 dpp_add_i64<CTRL, RM>(i64 v)                                                       \
+    {                                                                                                                             \
+        unsigned lo = (unsigned)((u64)v & 0xffffffffull), hi = (unsigned)((u64)v >> 32);                                          \
+        asm volatile("s_nop 1\n\tv_add_co_u32_dpp %0, vcc, %0, %0 " TXT "\n\tv_addc_co_u32_dpp %1, vcc, %1, %1, vcc " TXT         \
+                     : "+v"(lo), "+v"(hi) : : "vcc");                                                                             \
+        return (i64)(((u64)hi << 32) | lo);                                                                                       \
+    }
+CSV_DPP_ADD64(0x111, 0xf, "row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+CSV_DPP_ADD64(0x112, 0xf, "row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+CSV_DPP_ADD64(0x114, 0xf, "row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+CSV_DPP_ADD64(0x118, 0xf, "row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+CSV_DPP_ADD64(0x142, 0xa, "row_bcast:15 row_mask:0xa bank_mask:0xf")
+CSV_DPP_ADD64(0x143, 0xc, "row_bcast:31 row_mask:0xc bank_mask:0xf")
+#undef CSV_DPP_ADD64
 __device__ __forceinline__ i64 wave_incl_scan_i64(i64 v)
 {
-    v += dpp_i64<0x111, 0xf>(0, v);     // row_shr:1
-    v += dpp_i64<0x112, 0xf>(0, v);     // row_shr:2
-    v += dpp_i64<0x114, 0xf>(0, v);     // row_shr:4
-    v += dpp_i64<0x118, 0xf>(0, v);     // row_shr:8
-    v += dpp_i64<0x142, 0xa>(0, v);     // row_bcast:15 into rows 1 and 3
-    v += dpp_i64<0x143, 0xc>(0, v);     // row_bcast:31 into rows 2 and 3
+    v = dpp_add_i64<0x111, 0xf>(v);     // row_shr:1
+    v = dpp_add_i64<0x112, 0xf>(v);     // row_shr:2
+    v = dpp_add_i64<0x114, 0xf>(v);     // row_shr:4
+    v = dpp_add_i64<0x118, 0xf>(v);     // row_shr:8
+    v = dpp_add_i64<0x142, 0xa>(v);     // row_bcast:15 into rows 1 and 3
+    v = dpp_add_i64<0x143, 0xc>(v);     // row_bcast:31 into rows 2 and 3
     return v;
 }
 __device__ __forceinline__ int wave_incl_scan_i32(int v)
@@ -1902,12 +1924,12 @@ template <int SW> __device__ __forceinline__ u64 sub_ballot(bool p, int g)
 // 32 lanes: before row_bcast:31)
 template <int SW> __device__ __forceinline__ i64 sub_scan_i64(i64 v)
 {
-    v += dpp_i64<0x111, 0xf>(0, v);
-    v += dpp_i64<0x112, 0xf>(0, v);
-    v += dpp_i64<0x114, 0xf>(0, v);
-    v += dpp_i64<0x118, 0xf>(0, v);
-    if (SW >= 32) v += dpp_i64<0x142, 0xa>(0, v);
-    if (SW == 64) v += dpp_i64<0x143, 0xc>(0, v);
+    v = dpp_add_i64<0x111, 0xf>(v);
+    v = dpp_add_i64<0x112, 0xf>(v);
+    v = dpp_add_i64<0x114, 0xf>(v);
+    v = dpp_add_i64<0x118, 0xf>(v);
+    if (SW >= 32) v = dpp_add_i64<0x142, 0xa>(v);
+    if (SW == 64) v = dpp_add_i64<0x143, 0xc>(v);
     return v;
 }
 template <int SW> __device__ __forceinline__ int sub_scan_i32(int v)

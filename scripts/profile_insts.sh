@@ -14,6 +14,7 @@ timeout -k 5 150 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_I
 echo "pass 1 rc=$?"
 timeout -k 5 150 rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAVE_CYCLES -d $OUT/${TAG}_${WL}_i2 -o pmc -- python $ARGS > $OUT/${TAG}_${WL}_i2.log 2>&1
 echo "pass 2 rc=$?"
-cd $R/scripts && python rocprof_counters.py $(ls $OUT/${TAG}_${WL}_i1/*.db | head -1) $(ls $OUT/${TAG}_${WL}_i2/*.db | head -1) > $F/${TAG}_${WL}_insts.txt
+cd $R/scripts && python rocprof_counters.py --json $F/insts_${WL}.json $(ls $OUT/${TAG}_${WL}_i1/*.db | head -1) $(ls $OUT/${TAG}_${WL}_i2/*.db | head -1) > $F/${TAG}_${WL}_insts.txt
 rm -rf $OUT/${TAG}_${WL}_i1 $OUT/${TAG}_${WL}_i2
+cp $F/insts_${WL}.json $R/profiles/insts_${WL}.json          # (the bench lines of this run pick it up)
 head -16 $F/${TAG}_${WL}_insts.txt | cut -c1-250

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """rocprofv3 PMC passes (any counters, one or more rocpd databases) -> one table, per kernel and launch.
 
-    python scripts/rocprof_counters.py <pass1.db> [<pass2.db> ...] > profiles/<tag>_insts.txt
+    python scripts/rocprof_counters.py [--json out.json] <pass1.db> [<pass2.db> ...] > profiles/<tag>_insts.txt
 
 Per-launch averages of every counter found; the int64-column instantiations are kept apart like rocprof_traffic.py does.
 Derived columns when their inputs are there: valu_per_wave = SQ_INSTS_VALU / SQ_WAVES;  valu_busy = SQ_ACTIVE_INST_VALU /
@@ -15,7 +15,11 @@ from rocprof_traffic import short
 
 def main():
     table, counters, launches = {}, [], {}
-    for db in sys.argv[1:]:
+    argv = sys.argv[1:]
+    out_json = None
+    if argv and argv[0] == "--json":
+        out_json, argv = argv[1], argv[2:]
+    for db in argv:
         cur = sqlite3.connect(db).cursor()
         for name, cname, n, avg in cur.execute("select kernel_name, counter_name, count(*), avg(value) from counters_collection "
                                                "group by kernel_name, counter_name"):
@@ -41,6 +45,10 @@ def main():
         if "valu_busy" in der:
             d.append(r.get("SQ_ACTIVE_INST_VALU", 0.0) / r["SQ_BUSY_CYCLES"] / 4.0 if r.get("SQ_BUSY_CYCLES") else 0.0)
         print("%-28s %8d " % (k, launches[k]) + " ".join("%18.1f" % r.get(c, 0.0) for c in counters) + " " + " ".join("%18.3f" % x for x in d))
+    if out_json:
+        import json
+        with open(out_json, "w") as fh:
+            json.dump({k: dict(table[k], launches=launches[k]) for k in table}, fh, indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":

@@ -5,6 +5,7 @@ TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
 F=$R/gpurun_out/final; mkdir -p $F
 timeout -k 10 900 python -m pytest tests -m gpu -x -q > $F/${TAG}_pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -2 $F/${TAG}_pytest_gpu.log
+for wl in cfg3 cfg5; do scripts/profile_insts.sh $wl $TAG > $F/${TAG}_${wl}_insts.log 2>&1; done
 scripts/refresh_profiles.sh $TAG "cfg3 cfg4 cfg5" > $F/${TAG}_refresh.log 2>&1
 timeout 300 python bench.py --workload rebuild > $F/${TAG}_bench_rebuild.json 2>/dev/null
 timeout 300 python bench.py --workload extract > $F/${TAG}_bench_extract.json 2>/dev/null
