@@ -345,3 +345,17 @@ def test_clip_join_is_the_python_slice_and_join():
     with pytest.raises(KeyError):
         cn.clip_join({1: "A"}, np.array([2], np.int64), np.array([1], np.int64), np.empty(1, np.int64))
     assert cn.clip_join(table, np.zeros(0, np.int64), np.zeros(0, np.int64), np.empty(0, np.int64)) == b""
+
+
+def test_bench_reads_its_committed_counter_files():
+    """bench.py attaches the PMC traffic and the VALU-issue figures of the dominant kernel from files committed under profiles/
+    (collected by scripts/refresh_profiles.sh / profile_insts.sh on the same command): they must parse and make sense."""
+    sys.path.insert(0, ROOT)
+    import bench
+    tr = bench.traffic_of("cfg3", 1.0)
+    assert tr and tr["k_refine_indel_wave"] > 8_000_000 and all("." not in k and "[" not in k for k in tr)
+    vi = bench.valu_issue_of("cfg3", 1.0, "k_refine_indel_wave", 13.6)
+    assert vi and 0.3 < vi["valu_busy_frac"] < 1.05 and vi["valu_insts_per_launch"] > 1e6
+    assert 0.05 < vi["wave_share_issuing_valu"] < 0.5
+    assert bench.valu_issue_of("cfg3", 0.5, "k_refine_indel_wave", 13.6) is None        # (counters are of the full-size workload only)
+    assert bench.valu_issue_of("cfg3", 1.0, "k_no_such_kernel", 1.0) is None
