@@ -368,7 +368,7 @@ def vcf_leg(ctx, pstore, params, tasks):
 
 def per_task_leg(ctx, store, params, tasks):
     """INTEGRATION.md mode 1: the reference's own task interface, one (chromosome, type) task per call from ITS files
-    (<TYPE>.pickle at sigs_index offsets): unpickle + columnar conversion + the boundary call + rows, for the largest task"""
+    (<TYPE>.pickle at sigs_index offsets): the pickle -> columns (walked in C) + the boundary call + rows, for the largest task"""
     try:
         import pickle
         import tempfile
@@ -398,7 +398,8 @@ def per_task_leg(ctx, store, params, tasks):
             t_unpickle = time.perf_counter() - t0
         return dict(task="%s chr%s" % (tt, tc), signatures=e0 - b0, ms=float(np.median(ts_)) * 1e3, unpickle_ms=t_unpickle * 1e3,
                     signatures_per_s=(e0 - b0) / float(np.median(ts_)),
-                    note="resolve.run_ins(args) with the reference's argument tuple on its pickle layout: pickle.load + columnar conversion + csv_cluster_batch + rows")
+                    note="resolve.run_ins(args) with the reference's argument tuple on its pickle layout: the pickle walked in C out of the mapped file "
+                         "(_cols_native.pickle_table: no Python object per tuple) + csv_cluster_batch + rows; unpickle_ms = pickle.load of the same block alone")
     except Exception as e:           # noqa: BLE001  (optional leg)
         return dict(error=repr(e))
 

@@ -307,10 +307,387 @@ PyObject* clip_join(PyObject*, PyObject* args)
     return res;
 }
 
+// ------------------------------------------------------------------------------------------ the task pickles without the objects
+// A pool worker of the reference starts every task with pickle.load at sigs_index[type][chr] (cuteSV_resolveINDEL.py:52-58,
+// cuteSV_resolveDUP.py:25-27, cuteSV_resolveINV.py:42-44, cuteSV_resolveTRA.py:36-38): a list of tuples of ints, x.5 floats and
+// strings that the main script wrote with pickle.dumps (:817-857).  For the 110 862 signatures of INS chr2 that is ~450 k Python
+// objects and 21-24 ms before the first of them is looked at - and the drop-in wants columns, not objects.  pickle_table() walks
+// the opcode stream itself: integer fields go straight into int64 columns (int() of a float: truncation, main script :228),
+// string fields become (offset, length) spans of their UTF-8 bytes inside the buffer (a 26 MB block of inserted sequences is
+// never touched), memo references are followed.  It understands exactly what pickle emits for such lists - protocols 2 to 5:
+// PROTO FRAME EMPTY_LIST MARK APPEND(S) TUPLE/1/2/3 EMPTY_TUPLE BININT/1/2 LONG1 BINFLOAT (SHORT_)BINUNICODE(8) MEMOIZE BINPUT
+// LONG_BINPUT BINGET LONG_BINGET NEWTRUE NEWFALSE NONE STOP - and returns None for anything else (the caller then uses pickle).
+//
+//   pickle_table(buf, offset, width, int_fields, str_fields) -> None | (n_rows, end_offset, [int64 bytes per int field],
+//                                                                      [(offsets int64 bytes, lengths int32 bytes) per str field])
+//   span_intern(((buf, offsets, lengths, ids int32 out), ...)) -> (blob bytes, offsets int64 bytes, lengths int32 bytes) of the
+//                 distinct strings by first appearance, ONE id space over all specs
+//   span_join(buf, offsets, lengths, picks int64, clips int64 | None, out_len int64) -> bytes     (clip_join for a span table)
+//   span_cplen(buf, offsets, lengths, out int32)       len() of every string (code points; bytes when the text is ASCII)
+namespace pk {
+enum Kind : uint8_t { LIST, MARKER, ROW, INT, FLOAT, STR, OTHER };
+struct Cell { Kind kind; int32_t len; int64_t a; };
+
+struct Reader {
+    const unsigned char* p; int64_t n, i;
+    bool need(int64_t k) const { return i + k <= n; }
+    uint64_t le(int k) { uint64_t v = 0; for (int b = 0; b < k; b++) v |= (uint64_t)p[i + b] << (8 * b); i += k; return v; }
+};
+}   // namespace pk
+
+PyObject* pickle_table(PyObject*, PyObject* args)
+{
+    PyObject *obuf, *oints, *ostrs; Py_ssize_t offset, width;
+    if (!PyArg_ParseTuple(args, "OnnO!O!", &obuf, &offset, &width, &PyTuple_Type, &oints, &PyTuple_Type, &ostrs)) return nullptr;
+    Py_buffer view{};
+    if (PyObject_GetBuffer(obuf, &view, PyBUF_SIMPLE) != 0) return nullptr;
+    struct Rel { Py_buffer* v; ~Rel() { PyBuffer_Release(v); } } rel{&view};
+    if (offset < 0 || offset > view.len) { PyErr_SetString(PyExc_ValueError, "pickle_table: offset outside the buffer"); return nullptr; }
+    std::vector<Py_ssize_t> fi, fs;
+    for (Py_ssize_t k = 0; k < PyTuple_GET_SIZE(oints); k++) { fi.push_back(PyLong_AsSsize_t(PyTuple_GET_ITEM(oints, k))); }
+    for (Py_ssize_t k = 0; k < PyTuple_GET_SIZE(ostrs); k++) { fs.push_back(PyLong_AsSsize_t(PyTuple_GET_ITEM(ostrs, k))); }
+    if (PyErr_Occurred()) return nullptr;
+    for (Py_ssize_t f : fi) if (f < 0) { PyErr_SetString(PyExc_ValueError, "pickle_table: negative field"); return nullptr; }
+    for (Py_ssize_t f : fs) if (f < 0) { PyErr_SetString(PyExc_ValueError, "pickle_table: negative field"); return nullptr; }
+
+    using namespace pk;
+    Reader R{(const unsigned char*)view.buf, (int64_t)view.len, (int64_t)offset};
+    std::vector<Cell> st, memo;
+    std::vector<std::vector<int64_t>> ci(fi.size()), so(fs.size());
+    std::vector<std::vector<int32_t>> sl(fs.size());
+    int64_t n_rows = 0;
+    bool done = false, unsupported = false;
+    const char* corrupt = nullptr;
+    auto memo_put = [&](uint64_t k) {
+        if (st.empty()) { corrupt = "memo of an empty stack"; return; }
+        if (k > (1ull << 31)) { unsupported = true; return; }
+        if (memo.size() <= k) memo.resize((size_t)k + 1, Cell{OTHER, 0, 0});
+        memo[(size_t)k] = st.back();
+    };
+    auto make_row = [&](size_t first) {              // the cells st[first ..] are the fields of one tuple
+        const size_t c = st.size() - first;
+        // a row must be an element of THE list: [LIST, row] (APPEND form) or [LIST, MARKER, row, row, ...] (APPENDS batches)
+        const bool placed = (first == 1 && st[0].kind == LIST) ||
+                            (first >= 2 && st[0].kind == LIST && st[1].kind == MARKER && (first == 2 || st[first - 1].kind == ROW));
+        if (!placed || (width >= 0 && (Py_ssize_t)c != width)) { unsupported = true; return; }
+        for (size_t k = 0; k < fi.size(); k++) {
+            if ((size_t)fi[k] >= c) { unsupported = true; return; }
+            const Cell& x = st[first + (size_t)fi[k]];
+            int64_t v;
+            if (x.kind == INT) v = x.a;
+            else if (x.kind == FLOAT) {
+                double d; memcpy(&d, &x.a, 8);
+                if (!(d > -9.2e18 && d < 9.2e18)) { unsupported = true; return; }        // (nan / inf / beyond int64: let pickle + int() say it)
+                v = (int64_t)d;                                                          // int(x): truncation toward zero
+            } else { unsupported = true; return; }
+            ci[k].push_back(v);
+        }
+        for (size_t k = 0; k < fs.size(); k++) {
+            if ((size_t)fs[k] >= c) { unsupported = true; return; }
+            const Cell& x = st[first + (size_t)fs[k]];
+            if (x.kind != STR) { unsupported = true; return; }
+            so[k].push_back(x.a); sl[k].push_back(x.len);
+        }
+        st.resize(first);
+        st.push_back(Cell{ROW, 0, n_rows});
+        n_rows++;
+    };
+    auto top_marker = [&]() -> long {
+        for (long q = (long)st.size() - 1; q >= 0; q--) if (st[(size_t)q].kind == MARKER) return q;
+        return -1;
+    };
+    while (!done && !unsupported && !corrupt) {
+        if (!R.need(1)) { corrupt = "truncated"; break; }
+        const unsigned char op = R.p[R.i++];
+        switch (op) {
+        case 0x80: if (!R.need(1)) { corrupt = "truncated"; break; } if (R.p[R.i] < 2 || R.p[R.i] > 5) unsupported = true; R.i += 1; break;     // PROTO
+        case 0x95: if (!R.need(8)) { corrupt = "truncated"; break; } R.i += 8; break;                                                        // FRAME
+        case ']': st.push_back(Cell{LIST, 0, 0}); break;
+        case '(': st.push_back(Cell{MARKER, 0, 0}); break;
+        case 'K': if (!R.need(1)) { corrupt = "truncated"; break; } st.push_back(Cell{INT, 0, (int64_t)R.le(1)}); break;
+        case 'M': if (!R.need(2)) { corrupt = "truncated"; break; } st.push_back(Cell{INT, 0, (int64_t)R.le(2)}); break;
+        case 'J': if (!R.need(4)) { corrupt = "truncated"; break; } st.push_back(Cell{INT, 0, (int64_t)(int32_t)(uint32_t)R.le(4)}); break;
+        case 0x8a: {                                                                                                                         // LONG1
+            if (!R.need(1)) { corrupt = "truncated"; break; }
+            const int k = R.p[R.i++];
+            if (k > 8) { unsupported = true; break; }
+            if (!R.need(k)) { corrupt = "truncated"; break; }
+            uint64_t v = k ? R.le(k) : 0;
+            if (k && k < 8 && (v >> (8 * k - 1)) & 1) v |= ~0ull << (8 * k);             // sign extension
+            st.push_back(Cell{INT, 0, (int64_t)v});
+            break;
+        }
+        case 'G': {                                                                                                                          // BINFLOAT (big endian)
+            if (!R.need(8)) { corrupt = "truncated"; break; }
+            uint64_t v = 0; for (int b = 0; b < 8; b++) v = (v << 8) | R.p[R.i + b];
+            R.i += 8;
+            st.push_back(Cell{FLOAT, 0, (int64_t)v});
+            break;
+        }
+        case 0x8c: case 'X': case 0x8d: {                                                                                                    // (SHORT_)BINUNICODE(8)
+            const int k = op == 0x8c ? 1 : (op == 'X' ? 4 : 8);
+            if (!R.need(k)) { corrupt = "truncated"; break; }
+            const uint64_t len = R.le(k);
+            if (len > (uint64_t)INT32_MAX) { unsupported = true; break; }
+            if (!R.need((int64_t)len)) { corrupt = "truncated"; break; }
+            st.push_back(Cell{STR, (int32_t)len, R.i});
+            R.i += (int64_t)len;
+            break;
+        }
+        case 0x94: memo_put(memo.size()); break;                                                                                             // MEMOIZE
+        case 'q': if (!R.need(1)) { corrupt = "truncated"; break; } memo_put(R.le(1)); break;                                               // BINPUT
+        case 'r': if (!R.need(4)) { corrupt = "truncated"; break; } memo_put(R.le(4)); break;                                               // LONG_BINPUT
+        case 'h': case 'j': {                                                                                                                // BINGET / LONG_BINGET
+            const int k = op == 'h' ? 1 : 4;
+            if (!R.need(k)) { corrupt = "truncated"; break; }
+            const uint64_t id = R.le(k);
+            if (id >= memo.size()) { corrupt = "memo reference before its definition"; break; }
+            const Cell c = memo[(size_t)id];
+            if (c.kind == ROW || c.kind == LIST || c.kind == MARKER) { unsupported = true; break; }     // a shared tuple / list: objects matter
+            st.push_back(c);
+            break;
+        }
+        case 0x88: st.push_back(Cell{INT, 0, 1}); break;                                                                                     // NEWTRUE (int(True))
+        case 0x89: st.push_back(Cell{INT, 0, 0}); break;
+        case 'N': st.push_back(Cell{OTHER, 0, 0}); break;
+        case ')': make_row(st.size()); break;                                                                                                // EMPTY_TUPLE
+        case 0x85: case 0x86: case 0x87: {
+            const size_t c = (size_t)(op - 0x84);
+            if (st.size() < c) { corrupt = "tuple of a short stack"; break; }
+            make_row(st.size() - c);
+            break;
+        }
+        case 't': {
+            const long m = top_marker();
+            if (m < 0) { corrupt = "TUPLE without MARK"; break; }
+            st.erase(st.begin() + m);                                                    // the fields slide down over their marker
+            make_row((size_t)m);
+            break;
+        }
+        case 'e': {                                                                                                                          // APPENDS
+            const long m = top_marker();
+            if (m != 1 || st[0].kind != LIST) { if (m < 0) corrupt = "APPENDS without MARK"; else unsupported = true; break; }
+            for (size_t q = 2; q < st.size(); q++) if (st[q].kind != ROW) unsupported = true;
+            st.resize(1);
+            break;
+        }
+        case 'a':                                                                                                                            // APPEND
+            if (st.size() != 2 || st[0].kind != LIST || st[1].kind != ROW) { unsupported = true; break; }
+            st.resize(1);
+            break;
+        case '.': if (st.size() != 1 || st[0].kind != LIST) unsupported = true; done = true; break;                                          // STOP
+        default: unsupported = true; break;
+        }
+    }
+    if (corrupt) { PyErr_Format(PyExc_ValueError, "pickle_table: %s at byte %lld", corrupt, (long long)R.i); return nullptr; }
+    if (unsupported) Py_RETURN_NONE;
+    PyObject* ints = PyList_New((Py_ssize_t)fi.size());
+    PyObject* strs = PyList_New((Py_ssize_t)fs.size());
+    if (!ints || !strs) { Py_XDECREF(ints); Py_XDECREF(strs); return nullptr; }
+    for (size_t k = 0; k < fi.size(); k++) {
+        PyObject* b = PyBytes_FromStringAndSize((const char*)ci[k].data(), (Py_ssize_t)(ci[k].size() * 8));
+        if (!b) { Py_DECREF(ints); Py_DECREF(strs); return nullptr; }
+        PyList_SET_ITEM(ints, (Py_ssize_t)k, b);
+    }
+    for (size_t k = 0; k < fs.size(); k++) {
+        PyObject* o = PyBytes_FromStringAndSize((const char*)so[k].data(), (Py_ssize_t)(so[k].size() * 8));
+        PyObject* l = PyBytes_FromStringAndSize((const char*)sl[k].data(), (Py_ssize_t)(sl[k].size() * 4));
+        PyObject* t = (o && l) ? PyTuple_Pack(2, o, l) : nullptr;
+        Py_XDECREF(o); Py_XDECREF(l);
+        if (!t) { Py_DECREF(ints); Py_DECREF(strs); return nullptr; }
+        PyList_SET_ITEM(strs, (Py_ssize_t)k, t);
+    }
+    return Py_BuildValue("(LLNN)", (long long)n_rows, (long long)R.i, ints, strs);
+}
+
+// read-only views of (buffer, int64 offsets, int32 lengths)
+struct SpanArgs {
+    Py_buffer buf{}, off{}, len{};
+    bool hb = false, ho = false, hl = false;
+    ~SpanArgs() { if (hb) PyBuffer_Release(&buf); if (ho) PyBuffer_Release(&off); if (hl) PyBuffer_Release(&len); }
+    bool get(PyObject* b, PyObject* o, PyObject* l)
+    {
+        if (PyObject_GetBuffer(b, &buf, PyBUF_SIMPLE) != 0) return false;
+        hb = true;
+        if (PyObject_GetBuffer(o, &off, PyBUF_C_CONTIGUOUS) != 0) return false;
+        ho = true;
+        if (PyObject_GetBuffer(l, &len, PyBUF_C_CONTIGUOUS) != 0) return false;
+        hl = true;
+        if (off.itemsize != 8 || len.itemsize != 4 || off.len / 8 != len.len / 4) { PyErr_SetString(PyExc_ValueError, "spans: int64 offsets and int32 lengths of one length are expected"); return false; }
+        return true;
+    }
+    Py_ssize_t n() const { return off.len / 8; }
+    bool span(Py_ssize_t i, const char*& p, int32_t& k) const
+    {
+        const int64_t o = ((const int64_t*)off.buf)[i]; k = ((const int32_t*)len.buf)[i];
+        if (o < 0 || k < 0 || o + k > buf.len) { PyErr_Format(PyExc_ValueError, "span %zd lies outside the buffer", i); return false; }
+        p = (const char*)buf.buf + o;
+        return true;
+    }
+};
+
+inline uint64_t hash_bytes(const char* p, int32_t n)
+{
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t)n;
+    while (n >= 8) { uint64_t w; memcpy(&w, p, 8); h = (h ^ w) * 0xFF51AFD7ED558CCDull; h ^= h >> 32; p += 8; n -= 8; }
+    uint64_t w = 0;
+    if (n) memcpy(&w, p, (size_t)n);
+    h = (h ^ w) * 0xC4CEB9FE1A85EC53ull;
+    return h ^ (h >> 29);
+}
+
+PyObject* span_intern(PyObject*, PyObject* args)
+{
+    PyObject* specs;
+    if (!PyArg_ParseTuple(args, "O!", &PyTuple_Type, &specs)) return nullptr;
+    const Py_ssize_t ns = PyTuple_GET_SIZE(specs);
+    std::vector<SpanArgs> sp((size_t)ns);
+    std::vector<Buf> ids((size_t)ns);
+    Py_ssize_t total = 0;
+    for (Py_ssize_t k = 0; k < ns; k++) {
+        PyObject *b, *o, *l, *out;
+        if (!PyArg_ParseTuple(PyTuple_GET_ITEM(specs, k), "OOOO", &b, &o, &l, &out) || !sp[(size_t)k].get(b, o, l)) return nullptr;
+        if (!ids[(size_t)k].get(out, sp[(size_t)k].n(), "span_intern ids") || ids[(size_t)k].v.itemsize != 4) { if (!PyErr_Occurred()) PyErr_SetString(PyExc_ValueError, "span_intern: ids must be int32"); return nullptr; }
+        total += sp[(size_t)k].n();
+    }
+    size_t cap = 64;
+    while (cap < (size_t)total * 2 + 8) cap <<= 1;
+    std::vector<int32_t> slot(cap, -1);
+    struct U { const char* p; int32_t n; uint64_t h; };
+    std::vector<U> uniq;
+    uniq.reserve((size_t)total / 2 + 8);
+    int64_t blob_bytes = 0;
+    for (Py_ssize_t k = 0; k < ns; k++) {
+        const SpanArgs& S = sp[(size_t)k];
+        int32_t* out = (int32_t*)ids[(size_t)k].v.buf;
+        for (Py_ssize_t i = 0; i < S.n(); i++) {
+            const char* p; int32_t n;
+            if (!S.span(i, p, n)) return nullptr;
+            const uint64_t h = hash_bytes(p, n);
+            size_t q = (size_t)(h >> 7) & (cap - 1);
+            int32_t id = -1;
+            for (;; q = (q + 1) & (cap - 1)) {
+                const int32_t u = slot[q];
+                if (u < 0) break;
+                const U& x = uniq[(size_t)u];
+                if (x.h == h && x.n == n && memcmp(x.p, p, (size_t)n) == 0) { id = u; break; }
+            }
+            if (id < 0) {
+                if (uniq.size() >= (size_t)INT32_MAX) { PyErr_SetString(PyExc_OverflowError, "span_intern: more than 2^31 distinct values"); return nullptr; }
+                slot[q] = id = (int32_t)uniq.size();
+                uniq.push_back(U{p, n, h});
+                blob_bytes += n;
+            }
+            out[i] = id;
+        }
+    }
+    PyObject* blob = PyBytes_FromStringAndSize(nullptr, (Py_ssize_t)blob_bytes);
+    PyObject* off = PyBytes_FromStringAndSize(nullptr, (Py_ssize_t)(uniq.size() * 8));
+    PyObject* len = PyBytes_FromStringAndSize(nullptr, (Py_ssize_t)(uniq.size() * 4));
+    if (!blob || !off || !len) { Py_XDECREF(blob); Py_XDECREF(off); Py_XDECREF(len); return nullptr; }
+    char* d = PyBytes_AS_STRING(blob);
+    int64_t* po = (int64_t*)PyBytes_AS_STRING(off);
+    int32_t* pl = (int32_t*)PyBytes_AS_STRING(len);
+    int64_t at = 0;
+    for (size_t u = 0; u < uniq.size(); u++) {
+        memcpy(d + at, uniq[u].p, (size_t)uniq[u].n);
+        po[u] = at; pl[u] = uniq[u].n; at += uniq[u].n;
+    }
+    return Py_BuildValue("(NNN)", blob, off, len);
+}
+
+// bytes of the first `ncp` code points of the UTF-8 text p[0 .. n)
+inline int32_t utf8_prefix(const char* p, int32_t n, int64_t ncp)
+{
+    int32_t i = 0;
+    while (i < n && ncp > 0) { i++; while (i < n && ((unsigned char)p[i] & 0xC0) == 0x80) i++; ncp--; }
+    return i;
+}
+inline bool is_ascii(const char* p, int32_t n)
+{
+    uint64_t acc = 0;
+    while (n >= 8) { uint64_t w; memcpy(&w, p, 8); acc |= w; p += 8; n -= 8; }
+    while (n > 0) { acc |= (unsigned char)*p++; n--; }
+    return (acc & 0x8080808080808080ull) == 0;
+}
+inline int64_t utf8_cplen(const char* p, int32_t n)
+{
+    if (is_ascii(p, n)) return n;
+    int64_t c = 0;
+    for (int32_t i = 0; i < n; i++) c += ((unsigned char)p[i] & 0xC0) != 0x80;
+    return c;
+}
+
+PyObject* span_join(PyObject*, PyObject* args)
+{
+    PyObject *b, *o, *l, *opicks, *oclips, *oout;
+    if (!PyArg_ParseTuple(args, "OOOOOO", &b, &o, &l, &opicks, &oclips, &oout)) return nullptr;
+    SpanArgs S;
+    if (!S.get(b, o, l)) return nullptr;
+    Py_buffer pk{}, cl{};
+    if (PyObject_GetBuffer(opicks, &pk, PyBUF_C_CONTIGUOUS) != 0) return nullptr;
+    struct R1 { Py_buffer* v; ~R1() { PyBuffer_Release(v); } } r1{&pk};
+    const bool clipped = oclips != Py_None;
+    if (clipped && PyObject_GetBuffer(oclips, &cl, PyBUF_C_CONTIGUOUS) != 0) return nullptr;
+    struct R2 { Py_buffer* v; bool on; ~R2() { if (on) PyBuffer_Release(v); } } r2{&cl, clipped};
+    if (pk.itemsize != 8 || (clipped && (cl.itemsize != 8 || cl.len != pk.len))) { PyErr_SetString(PyExc_ValueError, "span_join: picks / clips must be int64 buffers of one length"); return nullptr; }
+    const Py_ssize_t n = pk.len / 8;
+    Buf out;
+    if (!out.get(oout, n, "span_join out_len") || out.v.itemsize != 8) { if (!PyErr_Occurred()) PyErr_SetString(PyExc_ValueError, "span_join: out_len must be int64"); return nullptr; }
+    const int64_t* picks = (const int64_t*)pk.buf;
+    const int64_t* clips = clipped ? (const int64_t*)cl.buf : nullptr;
+    int64_t* ol = (int64_t*)out.v.buf;
+    struct Piece { const char* p; int32_t n; };
+    std::vector<Piece> pieces((size_t)n);
+    int64_t total = 0;
+    for (Py_ssize_t i = 0; i < n; i++) {
+        if (picks[i] < 0 || picks[i] >= S.n()) { PyErr_Format(PyExc_IndexError, "span_join: index %lld outside the table", (long long)picks[i]); return nullptr; }
+        const char* p; int32_t k;
+        if (!S.span((Py_ssize_t)picks[i], p, k)) return nullptr;
+        if (clipped) {                                                                   // the Python slice [:clip] (code points)
+            int64_t end = clips[i];
+            if (end < 0 || !is_ascii(p, k)) {
+                const int64_t cps = utf8_cplen(p, k);
+                if (end < 0) end += cps;
+                if (end < 0) end = 0;
+                k = utf8_prefix(p, k, end);
+            } else if (end < k) k = (int32_t)end;
+        }
+        pieces[(size_t)i] = Piece{p, k};
+        ol[i] = k; total += k;
+    }
+    PyObject* res = PyBytes_FromStringAndSize(nullptr, (Py_ssize_t)total);
+    if (!res) return nullptr;
+    char* d = PyBytes_AS_STRING(res);
+    for (const Piece& q : pieces) { memcpy(d, q.p, (size_t)q.n); d += q.n; }
+    return res;
+}
+
+PyObject* span_cplen(PyObject*, PyObject* args)
+{
+    PyObject *b, *o, *l, *oout;
+    if (!PyArg_ParseTuple(args, "OOOO", &b, &o, &l, &oout)) return nullptr;
+    SpanArgs S;
+    if (!S.get(b, o, l)) return nullptr;
+    Buf out;
+    if (!out.get(oout, S.n(), "span_cplen out") || out.v.itemsize != 4) { if (!PyErr_Occurred()) PyErr_SetString(PyExc_ValueError, "span_cplen: out must be int32"); return nullptr; }
+    int32_t* d = (int32_t*)out.v.buf;
+    for (Py_ssize_t i = 0; i < S.n(); i++) {
+        const char* p; int32_t k;
+        if (!S.span(i, p, k)) return nullptr;
+        d[i] = (int32_t)utf8_cplen(p, k);
+    }
+    Py_RETURN_NONE;
+}
+
 PyMethodDef kMethods[] = {
     {"walk", walk, METH_VARARGS, "walk(seq, ints, interns, lens): fill column buffers from a list of tuples"},
     {"intern", intern, METH_VARARGS, "intern(((seq, field, int32 buffer), ...)) -> distinct values by first appearance; ids into the buffers"},
     {"column", column, METH_VARARGS, "column(seq, field) -> [x[field] for x in seq]"},
+    {"pickle_table", pickle_table, METH_VARARGS, "pickle_table(buf, offset, width, int_fields, str_fields) -> None | (n, end, [int64 bytes], [(off bytes, len bytes)])"},
+    {"span_intern", span_intern, METH_VARARGS, "span_intern(((buf, off, len, ids), ...)) -> (blob, off, len) of the distinct strings by first appearance"},
+    {"span_join", span_join, METH_VARARGS, "span_join(buf, off, len, picks, clips | None, out_len) -> bytes"},
+    {"span_cplen", span_cplen, METH_VARARGS, "span_cplen(buf, off, len, out int32): len() of every string"},
     {"clip_join", clip_join, METH_VARARGS, "clip_join(table, picks, lens, out_len) -> bytes of table[picks[i]][:lens[i]] joined"},
     {nullptr, nullptr, 0, nullptr}};
 PyModuleDef kModule = {PyModuleDef_HEAD_INIT, "_cols_native", "task lists -> flat columns (cutesv_amd/columns.py)", -1, kMethods, nullptr, nullptr, nullptr, nullptr};

@@ -38,6 +38,29 @@ def context():
     return _ctx
 
 
+_maps = {}
+
+
+def _mapped(path):
+    """the file, memory-mapped read-only (kept for the life of the process: a pool worker runs many tasks on the same files);
+    None for a file that cannot be mapped (empty, missing)"""
+    import mmap
+    try:
+        stt = os.stat(path)
+        key = (path, stt.st_size, stt.st_mtime_ns)
+        m = _maps.get(path)
+        if m is not None and m[0] == key:
+            return m[1]
+        if stt.st_size == 0:
+            return None
+        with open(path, "rb") as f:
+            mm = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)
+        _maps[path] = (key, mm)
+        return mm
+    except (OSError, ValueError):
+        return None
+
+
 def _store_for(work_dir, sigs_index, svtype, chrom, need_reads):
     """Signatures of ONE task as flat columns: the mmap'ed `<work_dir>cutesv_amd.cols/` if our rebuild step wrote it
     (shared by every task of the process), otherwise just this task's pickled list - and, when it genotypes, its
@@ -50,11 +73,22 @@ def _store_for(work_dir, sigs_index, svtype, chrom, need_reads):
             st = _stores[work_dir] = SigStore.load(cols)
         return st
     import pickle
+    want_reads = need_reads and chrom in sigs_index.get("reads", {})
+    if not os.environ.get("CUTESV_AMD_UNPICKLE"):      # (set: always through pickle.load, the r03 path)
+        # the pickles walked in C straight out of the mapped files (no Python object per tuple); None: something in the stream
+        # that the walker does not know - then pickle itself reads it
+        sig_map = _mapped("%s%s.pickle" % (work_dir, svtype))
+        reads_map = _mapped("%sreads.pickle" % work_dir) if want_reads else None
+        if sig_map is not None and (reads_map is not None or not want_reads):
+            st = SigStore.from_task_pickles(svtype, chrom, sig_map, sigs_index[svtype][chrom],
+                                            reads_map, sigs_index["reads"][chrom] if want_reads else None)
+            if st is not None:
+                return st
     with open("%s%s.pickle" % (work_dir, svtype), "rb") as f:
         f.seek(sigs_index[svtype][chrom])
         sigs = pickle.load(f)
     reads = []
-    if need_reads and chrom in sigs_index.get("reads", {}):
+    if want_reads:
         with open("%sreads.pickle" % work_dir, "rb") as f:
             f.seek(sigs_index["reads"][chrom])
             reads = pickle.load(f)

@@ -94,8 +94,12 @@ def emit_records(store, segments, res, reference, min_size=30, max_size=100000, 
             if store.names.names is not None:
                 store.sequence(0)                             # (raises: real read names but no inserted sequences)
             ln = np.minimum(store.aux[pick].astype(np.int64), ln)      # synthetic stores: 'ACGT' repeated to the aux length
-        took = np.empty(len(ins), np.int64)
-        alt_blob = cn.clip_join(table, pick, ln, took)        # b"".join(sequence(pick)[:SVLEN]) in C (GT:297-309)
+        from .columns import SpanList
+        if isinstance(table, SpanList):                       # (a task store built from the reference's pickle: spans of the mapped file)
+            alt_blob, took = table.join(pick, ln)
+        else:
+            took = np.empty(len(ins), np.int64)
+            alt_blob = cn.clip_join(table, pick, ln, took)    # b"".join(sequence(pick)[:SVLEN]) in C (GT:297-309)
         alt_off = np.zeros(n + 1, np.int64)
         alt_off[ins + 1] = took
         np.cumsum(alt_off, out=alt_off)

@@ -359,3 +359,116 @@ def test_bench_reads_its_committed_counter_files():
     assert 0.05 < vi["wave_share_issuing_valu"] < 0.5
     assert bench.valu_issue_of("cfg3", 0.5, "k_refine_indel_wave", 13.6) is None        # (counters are of the full-size workload only)
     assert bench.valu_issue_of("cfg3", 1.0, "k_no_such_kernel", 1.0) is None
+
+
+def _same_store(x, y):
+    assert x.chroms == y.chroms and x.seg_index == y.seg_index and tuple(x.strands) == tuple(y.strands)
+    for k in ("a", "b", "read_id", "aux", "reads_off", "r_start", "r_end", "r_primary", "r_id"):
+        u, v = getattr(x, k), getattr(y, k)
+        assert (u is None) == (v is None), k
+        if u is not None:
+            assert np.array_equal(u, v), k
+    assert list(x.names.names) == list(y.names.names)
+    if isinstance(y.ins_seq, dict):
+        assert not len(x.ins_seq) and not len(y.ins_seq)
+    else:
+        assert list(x.ins_seq) == list(y.ins_seq)
+
+
+def test_task_pickles_walked_in_c_give_the_store_pickle_load_gives(tmp_path):
+    """SigStore.from_task_pickles (the reference's <TYPE>.pickle / reads.pickle blocks walked in C out of the mapped files:
+    INDEL:52-58, DUP:25-27, INV:42-44, TRA:36-38 read them with pickle.load) == from_task_lists(pickle.load(...)), for every
+    type, every protocol pickle can have written, shared objects (memo references), x.5 positions, big and negative ints,
+    booleans, non-ASCII text; and None for streams that need real unpickling."""
+    import mmap
+    from cutesv_amd.columns import SigStore, SpanList
+    from cutesv_amd import _cols_native as cn
+    rng = np.random.default_rng(11)
+    names = ["read/%d/ccs" % i for i in range(300)] + ["ré中d%d" % i for i in range(5)]
+
+    def lists(svtype, n):
+        out = []
+        chr1 = "chr1"                                         # ONE object: pickle writes memo references to it
+        for i in range(n):
+            nm = names[int(rng.integers(0, len(names)))]
+            pos = int(rng.integers(0, 1 << 31)) + (0.5 if rng.random() < 0.2 else 0)
+            if rng.random() < 0.05:
+                pos = int(rng.integers(1 << 33, 1 << 40))     # LONG1
+            ln = int(rng.integers(1, 70000))
+            if svtype == "DEL":
+                out.append((pos, ln, nm, "DEL", chr1))
+            elif svtype == "INS":
+                seq = "ACGT" * int(rng.integers(0, 80)) + ("é" if rng.random() < 0.02 else "")
+                out.append((pos, ln, nm, seq, "INS", chr1))
+            elif svtype == "DUP":
+                out.append((int(pos), int(pos) + ln, nm, "DUP", chr1))
+            elif svtype == "INV":
+                out.append((("++", "--")[i & 1], int(pos), int(pos) + ln, nm, "INV", chr1))
+            else:
+                out.append(("ABCDE"[int(rng.integers(0, 5))], int(pos), "chr%d" % int(rng.integers(2, 6)), ln, nm, "TRA", chr1))
+        return out
+
+    reads = [(int(rng.integers(0, 1 << 28)), int(rng.integers(1 << 28, 1 << 29)), bool(i & 1) if i % 3 else int(i & 1),
+              names[int(rng.integers(0, len(names)))], "chr1" if i % 4 else "chr2") for i in range(700)]
+    for proto in (2, 3, 4, 5):
+        for svtype in ("DEL", "INS", "DUP", "INV", "TRA"):
+            for n in (0, 1, 3, 2500):                         # (APPEND form, one APPENDS batch, several batches and frames)
+                sigs = lists(svtype, n)
+                path, rpath = str(tmp_path / "s.pickle"), str(tmp_path / "r.pickle")
+                with open(path, "wb") as f:
+                    f.write(b"junk before the block")
+                    off = f.tell()
+                    pickle.dump(sigs, f, protocol=proto)
+                    f.write(b"the next block")
+                with open(rpath, "wb") as f:
+                    pickle.dump(reads, f, protocol=proto)
+                with open(path, "rb") as f, open(rpath, "rb") as g:
+                    sm = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)
+                    rm = mmap.mmap(g.fileno(), 0, access=mmap.ACCESS_READ)
+                with_reads = svtype != "TRA" and n > 1
+                got = SigStore.from_task_pickles(svtype, "chr1", sm, off, rm if with_reads else None, 0 if with_reads else None)
+                chroms = sorted({"chr1"} | {x[2] for x in sigs}) if svtype == "TRA" else None
+                want = SigStore.from_task_lists(svtype, "chr1", sigs, reads if with_reads else [], chroms=chroms)
+                assert got is not None, (proto, svtype, n)
+                _same_store(got, want)
+                if svtype == "INS" and n:
+                    picks = rng.integers(0, n, 40).astype(np.int64)
+                    clips = rng.integers(-3, 400, 40).astype(np.int64)
+                    blob, took = got.ins_seq.join(picks, clips)
+                    ref = [sigs[int(p)][3][:int(c)].encode() for p, c in zip(picks, clips)]
+                    assert blob == b"".join(ref) and took.tolist() == [len(r) for r in ref]
+                    assert got.ins_blob(picks=picks)[0] == want.ins_blob(picks=picks)[0]
+                    assert np.array_equal(got.ins_blob(picks=picks)[1], want.ins_blob(picks=picks)[1])
+                if n:
+                    pk = rng.integers(0, len(got.names.names), 50)
+                    assert got.names_blob(picks=pk)[0] == want.names_blob(picks=pk)[0]
+    # streams the walker must hand back to pickle: a nested tuple, a list element, a shared tuple object, bytes, a wrong width
+    t = (1, 2, "r", "DEL", "chr1")
+    for bad in ([(1, 2, ("r",), "DEL", "chr1")], [[1, 2, "r", "DEL", "chr1"]], [t, t], [(1, 2, b"r", "DEL", "chr1")],
+                [(1, 2, "r", "DEL")], [(None, 2, "r", "DEL", "chr1")], {"a": 1}, [(float("nan"), 2, "r", "DEL", "chr1")],
+                [(1 << 70, 2, "r", "DEL", "chr1")]):
+        assert cn.pickle_table(pickle.dumps(bad), 0, 5, (0, 1), (2,)) is None, bad
+    with pytest.raises(ValueError):
+        cn.pickle_table(pickle.dumps([(i, 2, "r", "DEL", "chr1") for i in range(10)])[:-9], 0, 5, (0, 1), (2,))          # truncated
+    assert isinstance(SpanList(b"abcd", [0, 2], [2, 2])[-1], str) and SpanList(b"abcd", [0, 2], [2, 2])[0:2] == ["ab", "cd"]
+
+
+def test_store_for_reads_a_reference_workdir_the_same_with_and_without_the_walker(tmp_path, monkeypatch):
+    """resolve._store_for on the reference's file layout (helpers.write_reference_workdir): the C walk of the mapped pickles and
+    the pickle.load path (CUTESV_AMD_UNPICKLE=1) build the same task stores, reads blocks included."""
+    from cutesv_amd import resolve
+    from helpers import write_reference_workdir
+    for case in [c for c in load_json("small_cases.json.gz") if c["name"] in ("realnames_gt", "ont_gt", "hifi")]:
+        st = store_from_json(case["store"])
+        d = str(tmp_path / case["name"]) + "/"
+        os.makedirs(d)
+        idx = write_reference_workdir(st, d)
+        for t in ("DEL", "INS", "INV", "DUP", "TRA"):
+            for c in idx[t]:
+                need_reads = t != "TRA"
+                monkeypatch.delenv("CUTESV_AMD_UNPICKLE", raising=False)
+                got = resolve._store_for(d, idx, t, c, need_reads)
+                assert got.ins_seq is None or not isinstance(got.ins_seq, list)            # (the walker's spans, not pickle's objects)
+                monkeypatch.setenv("CUTESV_AMD_UNPICKLE", "1")
+                want = resolve._store_for(d, idx, t, c, need_reads)
+                _same_store(got, want)
