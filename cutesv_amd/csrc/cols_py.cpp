@@ -360,9 +360,8 @@ PyObject* pickle_table(PyObject*, PyObject* args)
     const char* corrupt = nullptr;
     auto memo_put = [&](uint64_t k) {
         if (st.empty()) { corrupt = "memo of an empty stack"; return; }
-        if (k > (1ull << 31)) { unsupported = true; return; }
-        if (memo.size() <= k) memo.resize((size_t)k + 1, Cell{OTHER, 0, 0});
-        memo[(size_t)k] = st.back();
+        if (k > memo.size()) { unsupported = true; return; }                         // (pickle numbers its memo densely; anything else: not ours)
+        if (k == memo.size()) memo.push_back(st.back()); else memo[(size_t)k] = st.back();
     };
     auto make_row = [&](size_t first) {              // the cells st[first ..] are the fields of one tuple
         const size_t c = st.size() - first;
