@@ -693,7 +693,17 @@ def quiet_stdout():
         os.dup2(2, 1)
 
 
+LINE_LIMIT = 20000       # bytes: the driver reads the line from a bounded tail of stdout (24 000 bytes measured)
+BULKY = ("kernel_us_per_sig_outputs", "kernel_us_cold", "traffic_per_kernel", "roofline_per_kernel", "units", "other_workloads")
+
+
 def emit(out):
+    for k in BULKY:                                          # (never needed so far: the longest line is 13 KB)
+        if len(json.dumps(out)) + 1 <= LINE_LIMIT:
+            break
+        if isinstance(out, dict) and out.get(k) is not None:
+            out[k] = None
+            out.setdefault("trimmed_to_fit_the_line", []).append(k)
     line = (json.dumps(out) + "\n").encode()
     if _OUT_FD is None:
         sys.stdout.write(line.decode()); sys.stdout.flush()

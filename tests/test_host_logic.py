@@ -1,5 +1,6 @@
 """CPU tests of the host side: C-ABI surface, column store round trips, sharding, drop-in shims' argument handling."""
 import ctypes as C
+import json
 import os
 import pickle
 import re
@@ -359,6 +360,22 @@ def test_bench_reads_its_committed_counter_files():
     assert 0.05 < vi["wave_share_issuing_valu"] < 0.5
     assert bench.valu_issue_of("cfg3", 0.5, "k_refine_indel_wave", 13.6) is None        # (counters are of the full-size workload only)
     assert bench.valu_issue_of("cfg3", 1.0, "k_no_such_kernel", 1.0) is None
+    # the one JSON line stays inside the bounded tail of stdout the driver reads: the committed line does, an oversized one is trimmed
+    with open(os.path.join(ROOT, "profiles", "r04_bench_cfg3.json")) as f:
+        assert len(f.read()) < bench.LINE_LIMIT
+    big = {"metric": "m", "value": 1.0, "units": {"x": "y" * 30000}, "other_workloads": {"a": 1}}
+    r, w = os.pipe()
+    saved = bench._OUT_FD
+    try:
+        bench._OUT_FD = w
+        bench.emit(big)
+    finally:
+        bench._OUT_FD = saved
+        os.close(w)
+    line = os.read(r, 1 << 20)
+    os.close(r)
+    d = json.loads(line)
+    assert len(line) <= bench.LINE_LIMIT and d["value"] == 1.0 and d["units"] is None and d["trimmed_to_fit_the_line"] == ["units"] and d["other_workloads"] == {"a": 1}
 
 
 def _same_store(x, y):
