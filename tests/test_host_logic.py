@@ -489,3 +489,33 @@ def test_store_for_reads_a_reference_workdir_the_same_with_and_without_the_walke
                 monkeypatch.setenv("CUTESV_AMD_UNPICKLE", "1")
                 want = resolve._store_for(d, idx, t, c, need_reads)
                 _same_store(got, want)
+
+
+def test_random_workloads_sharded_over_2_to_8_ranks_merge_to_the_unsharded_rows():
+    """random all-type workloads (genotyped or not, reads in extraction order or sorted, ONT / HiFi presets), cut into pieces for
+    2, 3, 5 and 8 ranks with and without forced cuts, every rank's batch through the oracle engine: the merged rows are the
+    unsharded rows (the N > 1 path the driver runs on hardware).  A 600-workload campaign of the same loop (43 k
+    cut pieces) found nothing."""
+    from cutesv_amd import rows as rows_mod
+    from cutesv_amd.columns import Params
+    from oracle import oracle
+    cuts = 0
+    for it in range(24):
+        rng = np.random.default_rng(7000 + it)
+        gt = bool(rng.integers(0, 2))
+        st = synth.small_mixed(seed=9000 + it, n_sites=int(rng.integers(5, 400)), coverage=int(rng.choice([4, 9, 20, 45, 90])), genotype=gt,
+                               n_contigs=int(rng.integers(2, 5)))
+        if gt and rng.random() < 0.5:
+            st, _ = synth.extraction_order(st, seed=it, region=int(rng.choice([100_000, 250_000])), workers=int(rng.integers(2, 9)))
+        p = Params.ont(genotype=gt, min_support=int(rng.integers(2, 8))) if rng.random() < 0.5 else Params.hifi(genotype=gt, min_support=int(rng.integers(2, 5)))
+
+        def stage(units):
+            hb, keys = shard.host_batch(st, p, units)
+            per_seg = rows_mod.rows_by_segment(st, hb.segments, oracle.cluster_batch(hb))
+            return {k: per_seg[i] for i, k in enumerate(keys)}
+        full = shard.merge_rows([stage(shard.plan(st, 1, p, genotype=gt)[0])])
+        for world in (2, 3, 5, 8):
+            plan = shard.plan(st, world, p, genotype=gt, max_imbalance=float(rng.choice([0.0, 0.03])))
+            cuts += sum(1 for us in plan for u in us if u[2] > 1)
+            assert shard.merge_rows([stage(u) for u in plan]) == full, (it, world)
+    assert cuts > 500
