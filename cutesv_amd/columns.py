@@ -85,7 +85,7 @@ class SpanList:
         if i < 0:
             i += len(self)
         o = int(self.off[i])
-        return bytes(self._mv[o:o + int(self.len[i])]).decode()
+        return bytes(self._mv[o:o + int(self.len[i])]).decode("utf-8", "surrogatepass")      # (as pickle decodes its own strings)
 
     def __iter__(self):
         return (self[i] for i in range(len(self)))
