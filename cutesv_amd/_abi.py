@@ -8,7 +8,7 @@ import ctypes as C
 
 import numpy as np
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 DEL, INS, DUP, INV, TRA = 0, 1, 2, 3, 4
 SVTYPE_CODE = {"DEL": DEL, "INS": INS, "DUP": DUP, "INV": INV, "TRA": TRA}
 SVTYPE_NAME = {v: k for k, v in SVTYPE_CODE.items()}
@@ -23,6 +23,9 @@ RB_KEEP_ON_DEVICE = 1
 RB_FROM_POOL = 2                        # ... the rows are the context's device-resident signature pool
 CG_TO_POOL = 1                         # csv_cigar_in.flags: the signatures also become pool rows                         # csv_rebuild_in.flags
 SEG_KEY_RANGE = 1                             # csv_batch_out.seg_status bits
+OUT_NO_SUPPORT_LIST, OUT_COORD_I32 = 1, 2     # csv_batch_out.flags (ABI v7)
+OPTIONAL_CALL_FIELDS = ("call_cluster", "call_aux", "cipos", "cilen", "search_pos", "seq_pick", "dr", "dv", "gl_idx")
+COORD_FIELDS = ("bp1", "bp2", "search_pos", "seq_pick")
 
 # numpy dtype with exactly the C layout of `csv_segment` (all members naturally aligned)
 SEGMENT_DTYPE = np.dtype([
@@ -65,7 +68,7 @@ _OUT_ARRAYS = [  # (name, dtype, which capacity)
 class BatchOut(C.Structure):
     _fields_ = ([("cap_calls", C.c_int64), ("cap_support", C.c_int64),
                  ("n_calls", C.c_int64), ("n_support", C.c_int64), ("n_clusters", C.c_int64)]
-                + [(name, C.c_void_p) for name, _, _ in _OUT_ARRAYS] + [("support_sig32", C.c_void_p)])
+                + [(name, C.c_void_p) for name, _, _ in _OUT_ARRAYS] + [("support_sig32", C.c_void_p), ("flags", C.c_int32), ("reserved", C.c_int32)])
 
 
 class RunStats(C.Structure):
@@ -169,23 +172,35 @@ class HostBatch:
 class HostResult:
     """Caller-allocated csv_batch_out plus numpy views on it."""
 
-    def __init__(self, n_sig, cap_calls, cap_support, per_sig=False, n_seg=0, alloc=None, narrow_support=False):
+    def __init__(self, n_sig, cap_calls, cap_support, per_sig=False, n_seg=0, alloc=None, narrow_support=False,
+                 no_support=False, coord32=False, fields=None):
         """alloc(shape, dtype) -> array: where the result arrays live (default numpy; engine.pinned_empty puts them in
         page-locked memory, so that the device-to-host copies land in them by DMA).  narrow_support: the support list as int32
-        (csv_batch_out.support_sig32): `arrays["support_sig"]` is then an int32 array - every consumer indexes with it"""
+        (csv_batch_out.support_sig32): `arrays["support_sig"]` is then an int32 array - every consumer indexes with it.
+        ABI v7: no_support - CSV_OUT_NO_SUPPORT_LIST (support_off / support_sig are None); coord32 - CSV_OUT_COORD_I32 (bp1, bp2,
+        search_pos, seq_pick are int32 arrays; needs int32 input columns); fields - the OPTIONAL_CALL_FIELDS to carry (None: all),
+        the others stay None and are not written."""
         empty = alloc or (lambda n, dt: np.empty(n, dtype=dt))
         self.cap_calls = int(cap_calls)
         self.cap_support = int(cap_support)
         self.n_sig, self.n_seg, self.per_sig = int(n_sig), int(n_seg), bool(per_sig)
+        self.no_support, self.coord32 = bool(no_support), bool(coord32)
+        self.fields = None if fields is None else frozenset(fields)
         self.arrays = {}
         kw = {}
         for name, dt, cap in _OUT_ARRAYS:
-            if cap == "sig":
+            if name in COORD_FIELDS and coord32:
+                dt = np.int32
+            if self.fields is not None and name in OPTIONAL_CALL_FIELDS and name not in self.fields:
+                arr = None
+            elif cap == "sig":
                 arr = empty(n_sig, dt) if per_sig else None
             elif cap == "seg":
                 arr = np.zeros(max(1, n_seg), dtype=dt)
             elif cap == "calls":
                 arr = empty(self.cap_calls, dt)
+            elif no_support:
+                arr = None
             elif cap == "calls+1":
                 arr = empty(self.cap_calls + 1, dt)
                 arr[:] = 0
@@ -197,7 +212,12 @@ class HostResult:
             kw["support_sig32"], kw["support_sig"] = kw["support_sig"], None
         self.narrow_support = bool(narrow_support)
         self.n_seg_used = self.n_seg                 # segments of the batch the arrays were last filled for (a recycled result may be larger)
-        self.c = BatchOut(cap_calls=self.cap_calls, cap_support=self.cap_support, **kw)
+        self.c = BatchOut(cap_calls=self.cap_calls, cap_support=self.cap_support,
+                          flags=(OUT_NO_SUPPORT_LIST if no_support else 0) | (OUT_COORD_I32 if coord32 else 0), **kw)
+
+    def shape_key(self):
+        """what a recycled result must agree on with a request besides its capacities"""
+        return (self.per_sig, self.no_support, self.coord32, self.fields, self.narrow_support)
 
     @property
     def n_calls(self):

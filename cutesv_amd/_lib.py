@@ -28,6 +28,7 @@ SYMBOLS = [
     ("csv_ctx_sync", C.c_int, [C.c_void_p]),
     ("csv_batch_reads_mode", C.c_int, [C.c_void_p]),
     ("csv_batch_validate", C.c_int, [C.c_void_p]),
+    ("csv_batch_info", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64)]),
     ("csv_batch_option", C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     ("csv_gl_index", C.c_int32, [C.c_int64, C.c_int64]),
     ("csv_host_alloc", C.c_int, [C.c_int64, C.POINTER(C.c_void_p)]),

@@ -118,6 +118,7 @@ struct csv_ctx {
     Arena       arena, arena_rb;
     // batch buffers (slices of `arena`)
     Buf seg, woff, seg_drop, a, b, rid, aux, a32, b32;
+    Buf tile_lead;
     Buf cluster_id, partial, tile_cnt, item_rec, list_small, list_big, list_tiny, list_wide, seg_gate, tile_info, ch_masks, tile_items, seg_err;
     Buf item_cnt, item_base, item_chunk, sup_tmp;
     Buf t_rec, t_rec0;
@@ -160,6 +161,9 @@ struct csv_ctx {
     bool     reads_general = false;            // this batch's reads table needs the general sort (found out by a first run)
     i64      sqrt_n = 0;                       // entries of sqrt_tab (grown to the longest segment seen: an allele is never larger)
     bool     copies_pending = false;           // csv_cluster_batch: the column copies are still in flight behind ev_copy[0] / [1]
+    bool     lazy_pending = false;             // gate-first call: this upload's first run still has to fetch the gated rows from the caller's columns
+    bool     partial_cols = false;             // ... and its device columns hold only the rows the kernels read (csv_batch_validate refuses)
+    i64      lazy_bytes = 0;                   // bytes the bulk copy of this upload did NOT send (measurement aid: csv_batch_lazy_info)
     i64      n_sig_host = 0, n_reads = 0;
     DevBatch B;
     DevCounters h_cnt;
@@ -231,7 +235,7 @@ int env_int(const char* name, int dflt)
     return v && *v ? atoi(v) : dflt;
 }
 
-int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sync);
+int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sync, bool lazy_ok);
 int read_counters(csv_ctx* c);
 
 // `num ** 0.5` of cal_CIPOS is libm pow(), not sqrt() (GT:59; the two differ for 271 integers below 300 000): the device reads
@@ -409,9 +413,18 @@ int csv_ctx_sync(csv_ctx* c)
     return CSV_OK;
 }
 
-int csv_batch_upload(csv_ctx* c, const csv_batch_in* in) { return upload_impl(c, in, false, true); }
+int csv_batch_upload(csv_ctx* c, const csv_batch_in* in) { return upload_impl(c, in, false, true, false); }
 
 int csv_batch_reads_mode(const csv_ctx* c) { return (c && c->uploaded && c->n_reads > 0) ? c->B.ro_mode : -1; }
+
+int csv_batch_info(const csv_ctx* c, int which, int64_t* value)
+{
+    if (!c || !value) return CSV_E_INVALID;
+    if (which == 0) *value = c->partial_cols ? 1 : 0;
+    else if (which == 1) *value = c->lazy_bytes;
+    else return CSV_E_INVALID;
+    return CSV_OK;
+}
 
 int csv_batch_option(csv_ctx* c, int option, int value)
 {
@@ -428,15 +441,18 @@ namespace {
 // to four copy streams (one DMA engine each), the reads table on its own so that the clustering kernels never wait
 // for it.  `sync` = false (csv_cluster_batch): nothing waits here, the kernels are ordered behind the copies by events
 // and the final download synchronises before the call returns.
-int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sync)
+int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sync, bool lazy_ok)
 {
     if (!c || !in) return CSV_E_INVALID;
     c->uploaded = c->ran = false;
+    c->lazy_pending = c->partial_cols = false; c->lazy_bytes = 0;
     c->reads_general = false;
     c->reads_ready = false;
     c->upload_seq0 = c->run_seq;                      // (tier answers of earlier sequence numbers belong to other columns)
     HIP_TRY(c, hipSetDevice(c->device));
     if (in->n_seg < 0 || in->n_sig < 0 || (in->n_seg > 0 && !in->seg)) return fail(c, CSV_E_INVALID, "bad batch header");
+    // (support lists and seq_pick name signatures by their global index in 32 bits on the device)
+    if (in->n_sig >= (1ll << 31)) return fail(c, CSV_E_INVALID, "n_sig = %lld: a batch indexes at most 2^31 - 1 signature rows (split the store)", (long long)in->n_sig);
     const int S = in->n_seg;
     c->h_seg.assign(in->seg, in->seg + S);
     c->h_woff.assign(S + 1, 0);
@@ -493,6 +509,20 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
     const bool per_sig = per_sig_forced || (in->flags & CSV_IN_PER_SIG);
     const bool dev_cols = (in->flags & CSV_IN_DEVICE_COLUMNS) != 0;       // a / b / read_id / aux are device pointers: device-to-device copies
     const hipMemcpyKind col_kind = dev_cols ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    // Gate-first (one-shot calls only: the caller's columns are valid until the call returns): when b / read_id / aux live in
+    // page-locked memory the device can read, only the position column travels in bulk and k_lazy_fetch pulls the rows of the
+    // clusters that pass the size gate (kernels.hip.h).  Small batches are cheaper in one piece (CSV_LAZY_MIN signatures,
+    // default 64 Ki: below that the extra kernel and its PCIe round trips cost more than the bytes they save).
+    const bool sig32_ = (in->flags & CSV_IN_SIG_I32) != 0;
+    const void *lz_b = nullptr, *lz_rid = nullptr, *lz_aux = nullptr;
+    bool lazy = lazy_ok && !dev_cols && W > 0 && !getenv("CSV_NO_LAZY") && W >= (i64)env_int("CSV_LAZY_MIN", 64 << 10) && in->b && in->read_id && in->aux;
+    if (lazy) {
+        const size_t nb = (size_t)in->n_sig;
+        lz_b = pinned_device_address(in->b, nb * (sig32_ ? 4 : 8));
+        lz_rid = lz_b ? pinned_device_address(in->read_id, nb * 4) : nullptr;
+        lz_aux = lz_rid ? pinned_device_address(in->aux, nb * 4) : nullptr;
+        lazy = lz_aux != nullptr;
+    }
 
     // ---- device memory: one plan, one arena
     const i64 R = (c->any_genotype && in->reads_off) ? in->n_reads : 0;
@@ -518,6 +548,7 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
     PL(sup_tmp, (W + 1) * 4);
     if (per_sig) { PL(cluster_id, (W + 1) * 4); PL(allele_id, (W + 1) * 4); }
     PL(partial, nt * 4); PL(tile_cnt, nt * 16);
+    if (lazy) PL(tile_lead, nt * 4);
     if (per_sig) PL(ch_masks, nt * CT_WORDS * 8);
     PL(tile_items, nt * (size_t)TI_STRIDE * 16);
     PL(item_rec, cap_items * 16); PL(list_small, cap_items * 16); PL(list_big, cap_items * 4); PL(list_tiny, cap_items * 16); PL(list_wide, cap_items * 16);
@@ -612,17 +643,27 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
             if (n > 0) {
                 if (group == 1 && sig32) {
                     HIP_TRY(c, hipMemcpyAsync(dp<int>(c->a32) + dst, (const int32_t*)in->a + src, n * 4, col_kind, cs));
-                    HIP_TRY(c, hipMemcpyAsync(dp<int>(c->b32) + dst, (const int32_t*)in->b + src, n * 4, col_kind, cs));
+                    if (!lazy) HIP_TRY(c, hipMemcpyAsync(dp<int>(c->b32) + dst, (const int32_t*)in->b + src, n * 4, col_kind, cs));
                 } else if (group == 1) {
                     HIP_TRY(c, hipMemcpyAsync(dp<i64>(c->a) + dst, in->a + src, n * 8, col_kind, cs));
-                    HIP_TRY(c, hipMemcpyAsync(dp<i64>(c->b) + dst, in->b + src, n * 8, col_kind, cs));
-                } else HIP_TRY(c, hipMemcpyAsync(dp<int>(c->rid) + dst, in->read_id + src, n * 4, col_kind, cs));
+                    if (!lazy) HIP_TRY(c, hipMemcpyAsync(dp<i64>(c->b) + dst, in->b + src, n * 8, col_kind, cs));
+                } else if (!lazy) HIP_TRY(c, hipMemcpyAsync(dp<int>(c->rid) + dst, in->read_id + src, n * 4, col_kind, cs));
+                if (lazy) c->lazy_bytes += n * (sig32 ? 4 : 8) + n * 4;
                 for (int q = k; q <= e;) {                  // aux: runs of segments of this group's kind
                     int q2 = q;
                     while (q2 + 1 <= e && aux_kind(q2 + 1) == aux_kind(q)) q2++;
                     const i64 na = c->h_woff[q2 + 1] - c->h_woff[q];
-                    if (aux_kind(q) == group && na > 0)
-                        HIP_TRY(c, hipMemcpyAsync(dp<int>(c->aux) + c->h_woff[q], in->aux + c->h_seg[q].sig_begin, na * 4, col_kind, cs));
+                    if (aux_kind(q) == group && na > 0) {
+                        if (!(lazy && group == 2)) HIP_TRY(c, hipMemcpyAsync(dp<int>(c->aux) + c->h_woff[q], in->aux + c->h_seg[q].sig_begin, na * 4, col_kind, cs));
+                        else c->lazy_bytes += na * 4;
+                    }
+                    // gate-first: the chain predicates of INV / TRA segments read b (kernels.hip.h sig_flag): those ranges travel whole
+                    if (lazy && group == 1 && aux_kind(q) == 1 && na > 0) {
+                        const i64 sb = c->h_seg[q].sig_begin;
+                        if (sig32) HIP_TRY(c, hipMemcpyAsync(dp<int>(c->b32) + c->h_woff[q], (const int32_t*)in->b + sb, na * 4, col_kind, cs));
+                        else HIP_TRY(c, hipMemcpyAsync(dp<i64>(c->b) + c->h_woff[q], in->b + sb, na * 8, col_kind, cs));
+                        c->lazy_bytes -= na * (sig32 ? 4 : 8);
+                    }
                     q = q2 + 1;
                 }
             }
@@ -697,6 +738,7 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
     B.partial = dp<int>(c->partial); B.tile_cnt = dp<int4>(c->tile_cnt);
     B.item_rec = dp<int4>(c->item_rec); B.list_small = dp<int4>(c->list_small); B.list_big = dp<int>(c->list_big); B.list_tiny = dp<int4>(c->list_tiny); B.list_wide = dp<int4>(c->list_wide);
     B.seg_gate = dp<int4>(c->seg_gate); B.tile_info = dp<int4>(c->tile_info);
+    if (lazy) { B.h_b = lz_b; B.h_rid = (const int*)lz_rid; B.h_aux = (const int*)lz_aux; B.tile_lead = dp<int>(c->tile_lead); c->lazy_pending = c->partial_cols = true; }
     B.ch_masks = per_sig ? dp<u64>(c->ch_masks) : nullptr; B.tile_items = dp<int4>(c->tile_items);
     B.seg_err = dp<int>(c->seg_err);
     B.tiny_max = getenv("CSV_NO_TINY") ? 0 : 16;               // (timing aid: 0 sends every DEL/INS cluster of m <= 32 through the paired path)
@@ -863,10 +905,25 @@ int run_impl(csv_ctx* c, csv_run_stats* stats)
             if (rc) return rc;
             if (!swap) HIP_TRY(c, hipEventRecord(c->ev_aux[2], sD));
         }
+        const bool lazy = c->lazy_pending;                 // (the first run of a gate-first upload; stats are never taken on one)
+        if (lazy) {
+            const int gz = nb < 2048 ? nb : 2048;
+            if (B.a.p32) hipLaunchKernelGGL(k_lazy_zero<true>, dim3(gz), dim3(256), 0, st, B);
+            else hipLaunchKernelGGL(k_lazy_zero<false>, dim3(gz), dim3(256), 0, st, B);
+        }
         if (B.a.p32) LAUNCH("chain_count", k_chain_count<true>, nb, 256, 0, B);
         else LAUNCH("chain_count", k_chain_count<false>, nb, 256, 0, B);
         LAUNCH("chain_apply", k_chain_apply, div_up(nb, 4), 256, 0, B);
         if (B.per_sig) hipLaunchKernelGGL(k_chain_ids, dim3(nb), dim3(256), 0, st, B);      // (optional outputs; timed with whatever follows)
+        if (lazy) {
+            if (B.a.p32) hipLaunchKernelGGL(k_lazy_fetch<true>, dim3(nb), dim3(256), 0, st, B);
+            else hipLaunchKernelGGL(k_lazy_fetch<false>, dim3(nb), dim3(256), 0, st, B);
+            DBG("lazy_fetch");
+            // the device columns now hold every row a kernel reads: later runs of this upload (the general-sort re-run of a reads
+            // table, a caller's csv_batch_run) take them as they are - the caller's host columns are not touched again
+            c->lazy_pending = false;
+            B.h_b = nullptr; B.h_rid = nullptr; B.h_aux = nullptr; B.tile_lead = nullptr;
+        }
         if (c->copies_pending) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_copy[1], 0));   // read ids, INS sequence lengths
         int g_small = B.cap_items < 8192 ? B.cap_items : 8192;
         if (g_small < 1) g_small = 1;
@@ -1064,6 +1121,7 @@ int csv_batch_validate(csv_ctx* c)
 {
     if (!c) return CSV_E_INVALID;
     if (!c->uploaded) return fail(c, CSV_E_STATE, "csv_batch_validate before csv_batch_upload");
+    if (c->partial_cols) return fail(c, CSV_E_STATE, "csv_batch_validate needs a csv_batch_upload: a csv_cluster_batch call from page-locked columns keeps only the rows its kernels read");
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t st = c->stream;
     HIP_TRY(c, hipMemsetAsync(c->cnt.p, 0, sizeof(DevCounters), st));
@@ -1087,20 +1145,26 @@ bool publish_targets(csv_ctx* c, const csv_batch_out* out, PublishArgs& P)
     (void)c;
     if (getenv("CSV_NO_PUBLISH") || out->cap_calls < 0 || out->cap_support < 0) return false;
     const size_t nc = (size_t)out->cap_calls, ns = (size_t)out->cap_support;
-    const bool sup32 = out->support_sig32 != nullptr;
+    const bool sup32 = out->support_sig32 != nullptr, nosup = (out->flags & CSV_OUT_NO_SUPPORT_LIST) != 0;
+    const size_t cw = (out->flags & CSV_OUT_COORD_I32) ? 4 : 8;
     const void* host[15] = {out->call_seg, out->call_cluster, out->call_aux, out->support, out->cipos, out->cilen, out->dr, out->dv, out->gl_idx,
                             out->bp1, out->bp2, out->search_pos, out->seq_pick, out->support_off, sup32 ? (const void*)out->support_sig32 : (const void*)out->support_sig};
-    const size_t bytes[15] = {nc * 4, nc * 4, nc * 4, nc * 4, nc * 4, nc * 4, nc * 4, nc * 4, nc * 4, nc * 8, nc * 8, nc * 8, nc * 8, (nc + 1) * 8, ns * (sup32 ? 4 : 8)};
+    const size_t bytes[15] = {nc * 4, nc * 4, nc * 4, nc * 4, nc * 4, nc * 4, nc * 4, nc * 4, nc * 4, nc * cw, nc * cw, nc * cw, nc * cw, (nc + 1) * 8, ns * (sup32 ? 4 : 8)};
+    // (ABI v7) optional fields may be NULL: not written; every array that IS given must be page-locked
+    const bool required[15] = {true, false, false, true, false, false, false, false, false, true, true, false, false, !nosup, !nosup};
     void* dev[15];
     for (int i = 0; i < 15; i++) {
-        if (!host[i]) return false;
-        dev[i] = pinned_device_address(host[i], bytes[i]);
+        dev[i] = nullptr;
+        if (nosup && i >= 13) continue;
+        if (!host[i]) { if (required[i]) return false; continue; }
+        dev[i] = pinned_device_address(host[i], bytes[i] ? bytes[i] : 1);
         if (!dev[i]) return false;
     }
     P.call_seg = (int*)dev[0]; P.call_cluster = (int*)dev[1]; P.call_aux = (int*)dev[2]; P.support = (int*)dev[3]; P.cipos = (int*)dev[4];
     P.cilen = (int*)dev[5]; P.dr = (int*)dev[6]; P.dv = (int*)dev[7]; P.gl_idx = (int*)dev[8];
-    P.bp1 = (i64*)dev[9]; P.bp2 = (i64*)dev[10]; P.search_pos = (i64*)dev[11]; P.seq_pick = (i64*)dev[12]; P.support_off = (i64*)dev[13];
+    P.bp1 = dev[9]; P.bp2 = dev[10]; P.search_pos = dev[11]; P.seq_pick = dev[12]; P.support_off = (i64*)dev[13];
     P.support_sig = sup32 ? nullptr : (i64*)dev[14]; P.support_sig32 = sup32 ? (int*)dev[14] : nullptr;
+    P.coord32 = cw == 4; P.no_support = nosup;
     return true;
 }
 
@@ -1108,8 +1172,11 @@ int csv_batch_download(csv_ctx* c, csv_batch_out* out)
 {
     if (!c || !out) return CSV_E_INVALID;
     if (!c->ran) return fail(c, CSV_E_STATE, "csv_batch_download before csv_batch_run");
-    if ((out->support_sig != nullptr) == (out->support_sig32 != nullptr))
-        return fail(c, CSV_E_INVALID, "csv_batch_out: exactly one of support_sig / support_sig32 must be given");
+    const bool nosup = (out->flags & CSV_OUT_NO_SUPPORT_LIST) != 0, coord32 = (out->flags & CSV_OUT_COORD_I32) != 0;
+    if (!nosup && ((out->support_sig != nullptr) == (out->support_sig32 != nullptr) || !out->support_off))
+        return fail(c, CSV_E_INVALID, "csv_batch_out: support_off and exactly one of support_sig / support_sig32 must be given (or CSV_OUT_NO_SUPPORT_LIST)");
+    if (!out->call_seg || !out->bp1 || !out->bp2 || !out->support) return fail(c, CSV_E_INVALID, "csv_batch_out: call_seg, bp1, bp2 and support are required");
+    if (coord32 && !c->B.a.p32) return fail(c, CSV_E_INVALID, "CSV_OUT_COORD_I32 needs a batch of CSV_IN_SIG_I32 columns");
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t st = c->stream;
     const int S0 = (int)c->h_seg.size();
@@ -1156,14 +1223,15 @@ int csv_batch_download(csv_ctx* c, csv_batch_out* out)
     if (k.error & ERR_TMP_OVERFLOW) return fail(c, CSV_E_INVALID, "internal: temp call capacity exceeded");
     if ((out->cluster_id || out->allele_id) && !c->B.per_sig)
         return fail(c, CSV_E_STATE, "cluster_id / allele_id requested but the batch was uploaded without CSV_IN_PER_SIG");
-    if (k.n_calls > out->cap_calls || k.n_support > out->cap_support)
+    if (k.n_calls > out->cap_calls || (!nosup && k.n_support > out->cap_support))
         return fail(c, CSV_E_CAPACITY, "need %d calls / %lld supports", k.n_calls, (long long)k.n_support);
-    const size_t nc = (size_t)k.n_calls, ns = (size_t)k.n_support;
+    const size_t nc = (size_t)k.n_calls; size_t ns = (size_t)k.n_support;
     const DevBatch& B = c->B;
     const int S = (int)c->h_seg.size();
     const size_t o_rec = 256, o_err = published ? 256 : o_rec + ((nc * sizeof(CallRec) + 255) & ~(size_t)255), o_end = o_err + (size_t)(S + 1) * 4;
     int* sup_stage = nullptr;
     if (!published) {
+    if (nosup) ns = 0;                                       // (the staging path below moves no support list then)
     if (o_end + (out->support_sig32 ? 0 : ns * 4) + 64 > c->h_pin_cap) { const int rc = pin_reserve(c, o_end + (out->support_sig32 ? 0 : ns * 4) + 64); if (rc) return rc; }
     // the call records first: they are unpacked on the host while the (larger) support list is still on its way
     if (nc) HIP_TRY(c, hipMemcpyAsync(c->h_pin + o_rec, B.o_rec, nc * sizeof(CallRec), hipMemcpyDeviceToHost, st));
@@ -1190,12 +1258,26 @@ int csv_batch_download(csv_ctx* c, csv_batch_out* out)
         const CallRec* r = (const CallRec*)(c->h_pin + o_rec);
         for (size_t i = 0; i < nc; i++) {
             const CallRec& x = r[i];
-            out->call_seg[i] = x.seg; out->call_cluster[i] = x.cluster; out->call_aux[i] = x.aux;
-            out->bp1[i] = x.bp1; out->bp2[i] = x.bp2; out->support[i] = x.support; out->cipos[i] = x.cipos; out->cilen[i] = x.cilen;
-            out->search_pos[i] = x.search; out->seq_pick[i] = x.pick; out->dr[i] = x.dr; out->dv[i] = x.dv; out->gl_idx[i] = x.gl;
-            out->support_off[i] = x.supoff;
+            out->call_seg[i] = x.seg; out->support[i] = x.support;
+            if (out->call_cluster) out->call_cluster[i] = x.cluster;
+            if (out->call_aux) out->call_aux[i] = x.aux;
+            if (out->cipos) out->cipos[i] = x.cipos;
+            if (out->cilen) out->cilen[i] = x.cilen;
+            if (coord32) {
+                ((int32_t*)out->bp1)[i] = (int32_t)x.bp1; ((int32_t*)out->bp2)[i] = (int32_t)x.bp2;
+                if (out->search_pos) ((int32_t*)out->search_pos)[i] = (int32_t)x.search;
+                if (out->seq_pick) ((int32_t*)out->seq_pick)[i] = (int32_t)x.pick;
+            } else {
+                out->bp1[i] = x.bp1; out->bp2[i] = x.bp2;
+                if (out->search_pos) out->search_pos[i] = x.search;
+                if (out->seq_pick) out->seq_pick[i] = x.pick;
+            }
+            if (out->dr) out->dr[i] = x.dr;
+            if (out->dv) out->dv[i] = x.dv;
+            if (out->gl_idx) out->gl_idx[i] = x.gl;
+            if (!nosup) out->support_off[i] = x.supoff;
         }
-        if (out->support_off) out->support_off[nc] = (int64_t)ns;
+        if (!nosup) out->support_off[nc] = (int64_t)ns;
     }
     if (!published || out->cluster_id || out->allele_id) HIP_TRY(c, hipStreamSynchronize(st));
     if (sup_stage) for (size_t i = 0; i < ns; i++) out->support_sig[i] = sup_stage[i];
@@ -1686,7 +1768,7 @@ int csv_cluster_batch(csv_ctx* c, const csv_batch_in* in, csv_batch_out* out)
     const bool tm = getenv("CSV_DEBUG_TIMING") != nullptr;
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = tm ? now() : 0;
-    int rc = upload_impl(c, in, out->cluster_id != nullptr || out->allele_id != nullptr, false);
+    int rc = upload_impl(c, in, out->cluster_id != nullptr || out->allele_id != nullptr, false, true);
     const double t1 = tm ? now() : 0;
     if (rc == CSV_OK) rc = run_impl(c, nullptr);
     const double t2 = tm ? now() : 0;

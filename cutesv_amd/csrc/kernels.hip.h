@@ -164,6 +164,15 @@ struct DevBatch {
     int*           seg_err;          // n_seg words of CSV_SEG_* bits
     const int4*    seg_gate;         // per segment {read_count, dropped, svtype, -}: one 16-byte load for the size gate
     const int4*    tile_info;        // per chain tile, built by the host: TILE_REC int4 words (see TILE_REC below)
+    // gate-first one-shot call (csv_cluster_batch from page-locked columns): only the position column crosses PCIe in bulk; what
+    // the refine kernels read of the OTHER columns - the rows of the clusters that pass the size gate, ~18 % of a 30x genome -
+    // is fetched by k_lazy_fetch straight out of the caller's host columns (device-visible addresses, indexed by the caller's
+    // global signature index) after the chain kernels have said which rows those are.  NULL: the columns were copied whole.
+    const void*    h_b;              // int32 / int64 like `b`
+    const int*     h_rid;
+    const int*     h_aux;
+    int*           tile_lead;        // per chain tile: tile-relative position of its first cluster start (CH_TILE: none) - the rows
+                                     // before it belong to a cluster that started in an earlier tile
     // refine outputs
     TmpRec*        t_rec0;           // cap_items: slot 0 of every item (+ its slot count and first aux word), item-indexed
     i64*           item_cnt;         // packed (valid calls << 32 | supports of valid calls)
@@ -717,6 +726,12 @@ template <bool NARROW> __global__ __launch_bounds__(256, 6) void k_chain_count(D
     }
     __syncthreads();
     if (CSV_UNLIKELY(nin == 0)) rcmin = min(min(s_rc[0], s_rc[1]), min(s_rc[2], s_rc[3]));
+    if (B.tile_lead && wv == 1) {                           // (gate-first calls only) where the tile's first cluster starts
+        const u64 nzw = __ballot(lane < CT_WORDS && s_F[lane < CT_WORDS ? lane : 0] != 0);
+        int lead = CH_TILE;
+        if (nzw) { const int fw = __ffsll((long long)nzw) - 1; lead = fw * 64 + __ffsll((long long)s_F[fw]) - 1; }
+        if (lane == 0) B.tile_lead[blockIdx.x] = lead < nvalid ? lead : CH_TILE;
+    }
     if (CSV_ABL(9)) { if (threadIdx.x == 0) B.partial[blockIdx.x] = (int)s_F[3]; return; }       // flags + barrier only
     // ---- every thread: the 8 flags [8 t, 8 t + 8) of the tile and the 64-flag window that begins with them
     const int t = threadIdx.x, wi = t >> 3, sh8 = (t & 7) * 8;
@@ -876,6 +891,104 @@ __global__ __launch_bounds__(256) void k_chain_ids(DevBatch B)
         const i64 w = base + r * WAVE + lane_id();
         if (w < B.W) { B.cluster_id[w] = run + __popcll(m & (lanemask_lt() | (1ull << lane_id()))) - 1; B.allele_id[w] = -1; }
         run += __popcll(m);
+    }
+}
+
+// ------------------------------------------------------------------------------------ gate-first fetch
+// A one-shot call from page-locked columns (csv_cluster_batch) sends only the POSITION column across PCIe in bulk (plus b / aux
+// of INV / TRA segments, whose chain predicates read them): 82 % of a 30x genome's signatures sit in clusters that fail the size
+// gate (INDEL:62-64, 86) and no kernel ever reads their lengths, read ids or sequence lengths - 27 of the 44.5 MB a bulk upload
+// moves.  Once k_chain_count / k_chain_apply have listed the clusters that pass, k_lazy_fetch reads exactly their rows out of the
+// caller's host columns (the device sees page-locked host memory; a load from it is a PCIe read) into the device columns, at
+// the positions a bulk copy would have put them: every later kernel is unchanged.
+// source row (the caller's global signature index) of compact row w of segment k
+__device__ __forceinline__ i64 lazy_src(const DevBatch& B, int k, i64 w) { return B.seg[k].sig_begin + (w - B.woff[k]); }
+
+// Before the chain kernels: the (0,0) look-alike rule (INDEL:62-64: an element equal to the reference's [0,0,''] sentinel ends
+// its cluster) is the one place where a chain predicate of a DEL / INS / DUP segment looks at a length - and only where the
+// position is 0.  Those rows (a handful per genome, at the head of a segment) get their `b` now.
+template <bool NARROW> __global__ __launch_bounds__(256) void k_lazy_zero(DevBatch B)
+{
+    for (i64 w = (i64)blockIdx.x * 256 + threadIdx.x; w < B.W; w += (i64)gridDim.x * 256) {
+        const bool z = NARROW ? (B.a.p32[w] == 0) : (B.a.p64[w] == 0);
+        if (CSV_UNLIKELY(z)) {
+            const i64 src = lazy_src(B, seg_of(B, w), w);
+            if constexpr (NARROW) const_cast<int*>(B.b.p32)[w] = ((const int*)B.h_b)[src];
+            else const_cast<i64*>(B.b.p64)[w] = ((const i64*)B.h_b)[src];
+        }
+    }
+}
+
+// One workgroup per chain tile.  Which rows: those of the tile's work items (tile_items, clipped to the tile) and the rows
+// before the tile's first cluster start, which continue a cluster of an earlier tile - fetched whether that cluster passed
+// the gate or not (two rows per tile boundary on average; a pile-up of a million signatures is fetched by all the tiles it
+// covers at once, not by the one wavefront that owns the item).  The rows become a bit mask in LDS, then every thread takes 8
+// rows, all loads of a thread issued before its first store: consecutive lanes, consecutive rows, consecutive host addresses.
+template <bool NARROW> __global__ __launch_bounds__(256) void k_lazy_fetch(DevBatch B)
+{
+    __shared__ u64 s_G[CT_WORDS];
+    const int tile = blockIdx.x, t = threadIdx.x;
+    const i64 tile0 = (i64)tile * CH_TILE;
+    const int4 tc = B.tile_cnt[tile];
+    const int lead = B.tile_lead[tile];
+    const int4* trp = B.tile_info + (i64)TILE_REC * tile;
+    const int4 t0 = trp[0], t1 = trp[1], t2 = trp[2], t3 = trp[3];
+    const int k0 = __builtin_amdgcn_readfirstlane(t0.x), k1 = __builtin_amdgcn_readfirstlane(t0.y), nin = __builtin_amdgcn_readfirstlane(t0.z);
+    const TileSegI g0 = tile_seg(t1), g1 = tile_seg(t2), g2 = tile_seg(t3);
+    // source offsets of the inline segments (w -> the caller's row): issued with the first round
+    i64 d0 = 0, d1 = 0, d2 = 0;
+    if (nin >= 1) d0 = B.seg[g0.k].sig_begin - B.woff[g0.k];
+    if (nin >= 2) d1 = B.seg[g1.k].sig_begin - B.woff[g1.k];
+    if (nin >= 3) d2 = B.seg[g2.k].sig_begin - B.woff[g2.k];
+    if (t < CT_WORDS) {
+        const int lo = t * 64;
+        s_G[t] = lead >= lo + 64 ? ~0ull : (lead > lo ? (1ull << (lead - lo)) - 1ull : 0ull);
+    }
+    __syncthreads();
+    const int n_it = tc.y;
+    for (int i = t; i < n_it; i += 256) {
+        const int4 it = B.tile_items[(i64)tile * TI_STRIDE + i];
+        const int p0 = it.x - (int)tile0;
+        const int p1 = it.y > CH_TILE - p0 ? CH_TILE : p0 + it.y;
+        for (int wd = p0 >> 6; wd <= (p1 - 1) >> 6; wd++) {
+            const int lo = wd * 64, x = p0 > lo ? p0 - lo : 0, y = p1 - lo < 64 ? p1 - lo : 64;
+            atomicOr(&s_G[wd], (y >= 64 ? ~0ull : (1ull << y) - 1ull) & ~((1ull << x) - 1ull));
+        }
+    }
+    __syncthreads();
+    typedef typename std::conditional<NARROW, int, i64>::type raw_t;
+    raw_t vb[CH_ITEMS]; int vr[CH_ITEMS], vx[CH_ITEMS];
+    unsigned on = 0, wb = 0, wx = 0;                        // per row: fetched at all / b fetched / aux fetched
+#pragma unroll
+    for (int r = 0; r < CH_ITEMS; r++) {
+        const int p = r * 256 + t;
+        const i64 w = tile0 + p;
+        vb[r] = 0; vr[r] = 0; vx[r] = 0;
+        if (((s_G[p >> 6] >> (p & 63)) & 1ull) && w < B.W) {
+            int type; i64 src;
+            if (CSV_LIKELY(nin >= 1)) {
+                const bool i2 = nin > 2 && (int)w >= g2.sf, i1 = nin > 1 && (int)w >= g1.sf;
+                type = i2 ? g2.type : (i1 ? g1.type : g0.type);
+                src = w + (i2 ? d2 : (i1 ? d1 : d0));
+            } else {
+                const int k = seg_in_tile(B, w, k0, k1);
+                type = B.seg[k].svtype; src = lazy_src(B, k, w);
+            }
+            on |= 1u << r;
+            vr[r] = B.h_rid[src];
+            if (!pair_type(type)) {                         // (INV / TRA: b and aux came with the bulk copy - the chain kernels read them)
+                wb |= 1u << r;
+                vb[r] = ((const raw_t*)B.h_b)[src];
+                if (type == CSV_INS) { wx |= 1u << r; vx[r] = B.h_aux[src]; }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < CH_ITEMS; r++) {
+        const i64 w = tile0 + r * 256 + t;
+        if ((on >> r) & 1) const_cast<int*>(B.rid)[w] = vr[r];
+        if ((wb >> r) & 1) { if constexpr (NARROW) const_cast<int*>(B.b.p32)[w] = vb[r]; else const_cast<i64*>(B.b.p64)[w] = vb[r]; }
+        if ((wx >> r) & 1) const_cast<int*>(B.aux)[w] = vx[r];
     }
 }
 
@@ -2722,10 +2835,17 @@ struct PublishArgs {
     DevCounters* h_cnt;      // page-locked landing zone of the counters
     int* h_seg_err;          // n_seg words (staging block)
     int n_seg;
-    int *call_seg, *call_cluster, *call_aux, *support, *cipos, *cilen, *dr, *dv, *gl_idx;
-    i64 *bp1, *bp2, *search_pos, *seq_pick, *support_off, *support_sig;
+    int *call_seg, *call_cluster, *call_aux, *support, *cipos, *cilen, *dr, *dv, *gl_idx;      // (NULL: the caller does not want the field)
+    void *bp1, *bp2, *search_pos, *seq_pick;    // i64, or int when coord32 (CSV_OUT_COORD_I32)
+    i64 *support_off, *support_sig;
     int *support_sig32;      // the caller's int32 support list (then support_sig is NULL)
+    int coord32, no_support; // CSV_OUT_COORD_I32 / CSV_OUT_NO_SUPPORT_LIST
 };
+__device__ __forceinline__ void publish_coord(void* p, int c32, i64 i, int lo, int hi)
+{
+    if (!p) return;
+    if (c32) ((int*)p)[i] = lo; else ((i64*)p)[i] = ((i64)hi << 32) | (unsigned)lo;
+}
 __global__ __launch_bounds__(256) void k_publish(DevBatch B, PublishArgs P)
 {
     const i64 tid = (i64)blockIdx.x * 256 + threadIdx.x, nth = (i64)gridDim.x * 256;
@@ -2738,16 +2858,24 @@ __global__ __launch_bounds__(256) void k_publish(DevBatch B, PublishArgs P)
         ((int*)P.h_cnt)[tid] = v;
     }
     for (i64 k = tid; k < P.n_seg; k += nth) P.h_seg_err[k] = B.seg_err[k];
-    if (nc > P.cap_calls || ns > P.cap_support) return;
+    if (nc > P.cap_calls || (!P.no_support && ns > P.cap_support)) return;
     for (i64 i = tid; i < nc; i += nth) {
         const int4* r = (const int4*)&B.o_rec[i];
         const int4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4];
-        P.bp1[i] = ((i64)r0.y << 32) | (unsigned)r0.x; P.bp2[i] = ((i64)r0.w << 32) | (unsigned)r0.z;
-        P.search_pos[i] = ((i64)r1.y << 32) | (unsigned)r1.x; P.seq_pick[i] = ((i64)r1.w << 32) | (unsigned)r1.z;
-        P.support_off[i] = ((i64)r2.y << 32) | (unsigned)r2.x; P.support[i] = r2.z; P.cipos[i] = r2.w;
-        P.cilen[i] = r3.x; P.call_seg[i] = r3.y; P.call_cluster[i] = r3.z; P.call_aux[i] = r3.w;
-        P.dr[i] = r4.x; P.dv[i] = r4.y; P.gl_idx[i] = r4.z;
+        // (which fields travel is wave-uniform: kernel arguments)
+        publish_coord(P.bp1, P.coord32, i, r0.x, r0.y); publish_coord(P.bp2, P.coord32, i, r0.z, r0.w);
+        publish_coord(P.search_pos, P.coord32, i, r1.x, r1.y); publish_coord(P.seq_pick, P.coord32, i, r1.z, r1.w);
+        if (!P.no_support) P.support_off[i] = ((i64)r2.y << 32) | (unsigned)r2.x;
+        P.support[i] = r2.z; P.call_seg[i] = r3.y;
+        if (P.cipos) P.cipos[i] = r2.w;
+        if (P.cilen) P.cilen[i] = r3.x;
+        if (P.call_cluster) P.call_cluster[i] = r3.z;
+        if (P.call_aux) P.call_aux[i] = r3.w;
+        if (P.dr) P.dr[i] = r4.x;
+        if (P.dv) P.dv[i] = r4.y;
+        if (P.gl_idx) P.gl_idx[i] = r4.z;
     }
+    if (P.no_support) return;
     if (tid == 0) P.support_off[nc] = ns;
     if (P.support_sig32) { for (i64 i = tid; i < ns; i += nth) P.support_sig32[i] = B.o_supsig[i]; }
     else for (i64 i = tid; i < ns; i += nth) P.support_sig[i] = (i64)B.o_supsig[i];

@@ -18,6 +18,7 @@
 #include <string.h>
 
 #include "../../include/cutesv_hip.h"
+#include "soa_access.h"
 
 namespace csv_rows {
 
@@ -55,6 +56,7 @@ template <class Sink> int layout(const csv_rows_in* in, Sink& S, int64_t c_begin
 {
     if (!in || !in->res || (in->n_seg > 0 && !in->seg) || !in->chrom_name) return CSV_E_INVALID;
     const csv_batch_out& R = *in->res;
+    if (!csv_soa::has_support_list(R)) return CSV_E_INVALID;      // (a row's read list: not a CSV_OUT_NO_SUPPORT_LIST result)
     const int64_t nc = (c_end < 0 || c_end > R.n_calls) ? R.n_calls : c_end;
     static const char* kTraAlt[4][2] = {{"N[", "["}, {"N]", "]"}, {"[", "[N"}, {"]", "]N"}};     // cuteSV_resolveTRA.py:142-153
     static const char* kType[4] = {"DEL", "INS", "DUP", "INV"};
@@ -66,16 +68,16 @@ template <class Sink> int layout(const csv_rows_in* in, Sink& S, int64_t c_begin
         if (sg.chrom < 0 || sg.chrom >= in->n_chrom) return CSV_E_INVALID;
         const int t = sg.svtype;
         const char* chrom = in->chrom_name[sg.chrom];
-        const int64_t bp1 = R.bp1[c], bp2 = R.bp2[c];
+        const int64_t bp1 = csv_soa::bp1(R, c), bp2 = csv_soa::bp2(R, c);
         // genotype fields: str(DR), GT, PL, GQ, QUAL (cuteSV_resolveINDEL.py:471-475); '.' fields when the task was not
         // genotyped or count_coverage gave up (cuteSV_resolveTRA.py:276-281)
-        const bool gt_on = sg.genotype != 0 && R.gl_idx[c] >= 0;
+        const bool gt_on = sg.genotype != 0 && csv_soa::gl_idx(R, c) >= 0;
         const char* g[4] = {"./.", ".,.,.", ".", "."};
         int64_t gn[4] = {3, 5, 1, 1};
         if (gt_on) {                                         // table row "GT \t PL \t GQ \t QUAL"
-            if (!in->gl_blob || !in->gl_off || R.gl_idx[c] >= CSV_GL_TABLE_SIZE) return CSV_E_INVALID;
-            const char* p = in->gl_blob + in->gl_off[R.gl_idx[c]];
-            const char* e = in->gl_blob + in->gl_off[R.gl_idx[c] + 1];
+            if (!in->gl_blob || !in->gl_off || csv_soa::gl_idx(R, c) >= CSV_GL_TABLE_SIZE) return CSV_E_INVALID;
+            const char* p = in->gl_blob + in->gl_off[csv_soa::gl_idx(R, c)];
+            const char* e = in->gl_blob + in->gl_off[csv_soa::gl_idx(R, c) + 1];
             for (int q = 0; q < 4; q++) {
                 const char* tb = q < 3 ? (const char*)memchr(p, '\t', (size_t)(e - p)) : e;
                 if (!tb) return CSV_E_INVALID;
@@ -85,7 +87,7 @@ template <class Sink> int layout(const csv_rows_in* in, Sink& S, int64_t c_begin
         auto f_str = [&](const char* s, int64_t n) { S.field_begin(0); S.raw(s, n); S.field_end(); };
         auto f_num = [&](int64_t v) { S.field_begin(0); S.num(v); S.field_end(); };
         auto f_ci = [&](int32_t v) { S.field_begin(0); S.ch('-'); S.num(v); S.ch(','); S.num(v); S.field_end(); };   // cal_CIPOS, GT:60
-        auto f_dr = [&]() { S.field_begin(0); if (gt_on) S.num(R.dr[c]); else S.ch('.'); S.field_end(); };
+        auto f_dr = [&]() { S.field_begin(0); if (gt_on) S.num(csv_soa::dr(R, c)); else S.ch('.'); S.field_end(); };
         auto f_gl = [&](int q) { f_str(g[q], gn[q]); };
         auto f_reads = [&]() -> bool {
             const int64_t s0 = R.support_off[c], s1 = R.support_off[c + 1];
@@ -122,11 +124,11 @@ template <class Sink> int layout(const csv_rows_in* in, Sink& S, int64_t c_begin
         S.row_begin(nf);
         f_str(chrom, (int64_t)strlen(chrom));
         if (t == CSV_DEL || t == CSV_INS) {
-            f_str(kType[t], 3); f_num(bp1); f_num(t == CSV_DEL ? -bp2 : bp2); f_num(R.support[c]); f_ci(R.cipos[c]); f_ci(R.cilen[c]);
+            f_str(kType[t], 3); f_num(bp1); f_num(t == CSV_DEL ? -bp2 : bp2); f_num(R.support[c]); f_ci(csv_soa::cipos(R, c)); f_ci(csv_soa::cilen(R, c));
             f_dr(); f_gl(0); f_gl(1); f_gl(2); f_gl(3);
             if (!f_reads()) return CSV_E_INVALID;
             if (t == CSV_INS) {                              // the inserted sequence sliced to SVLEN (INDEL:402)
-                const int64_t sig = R.seq_pick[c];
+                const int64_t sig = csv_soa::seq_pick(R, c);
                 if (sig < 0) return CSV_E_INVALID;
                 int64_t n = in->ins_blob ? in->ins_off[sig + 1] - in->ins_off[sig] : (in->aux ? in->aux[sig] : 0);
                 if (bp2 < n) n = bp2 < 0 ? 0 : bp2;
@@ -139,13 +141,13 @@ template <class Sink> int layout(const csv_rows_in* in, Sink& S, int64_t c_begin
             f_dr(); f_gl(0); f_gl(1); f_gl(2); f_gl(3);
             if (!f_reads()) return CSV_E_INVALID;
         } else if (t == CSV_INV) {
-            if (R.call_aux[c] < 0 || R.call_aux[c] >= in->n_strand) return CSV_E_INVALID;
-            const char* sn = in->strand_name[R.call_aux[c]];
+            if (csv_soa::call_aux(R, c) < 0 || csv_soa::call_aux(R, c) >= in->n_strand) return CSV_E_INVALID;
+            const char* sn = in->strand_name[csv_soa::call_aux(R, c)];
             f_str("INV", 3); f_num(bp1); f_num(bp2 - bp1); f_num(R.support[c]);
             f_dr(); f_gl(0); f_str(sn, (int64_t)strlen(sn)); f_gl(1); f_gl(2); f_gl(3);
             if (!f_reads()) return CSV_E_INVALID;
         } else {
-            const int code = R.call_aux[c] & 7, c2 = R.call_aux[c] >> 3;
+            const int code = csv_soa::call_aux(R, c) & 7, c2 = csv_soa::call_aux(R, c) >> 3;
             if (code > 3 || c2 < 0 || c2 >= in->n_chrom) return CSV_E_INVALID;
             const char* chr2 = in->chrom_name[c2];
             const int64_t n2 = (int64_t)strlen(chr2);

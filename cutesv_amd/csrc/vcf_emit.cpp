@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "../../include/cutesv_hip.h"
+#include "soa_access.h"
 
 namespace {
 
@@ -92,12 +93,12 @@ inline int emitted_id(const csv_vcf_in* in, const csv_batch_out& R, int64_t c)
 {
     const int type = in->seg[R.call_seg[c]].svtype;
     if (type == CSV_DEL || type == CSV_INS) {
-        const long long len = R.bp2[c];
+        const long long len = csv_soa::bp2(R, c);
         if ((len > in->max_size && in->max_size != -1) || len < in->min_size) return -1;
         return type == CSV_INS ? ID_INS : ID_DEL;
     }
     if (type == CSV_DUP || type == CSV_INV) {
-        const long long len = R.bp2[c] - R.bp1[c];
+        const long long len = csv_soa::bp2(R, c) - csv_soa::bp1(R, c);
         if (llabs(len) > in->max_size && in->max_size != -1) return -1;
         return type == CSV_DUP ? ID_DUP : ID_INV;
     }
@@ -214,7 +215,7 @@ extern "C" int csv_vcf_emit(const csv_vcf_in* in, char* out, int64_t cap, int64_
     std::sort(order.begin(), order.end(), [&](int x, int y) { return in->chrom_rank[x] < in->chrom_rank[y]; });
     // generate_output's stable sort by int(row[2]) per chromosome (cuteSV_genotype.py:252)
     team.run(in->n_chrom, [&](int64_t ch) {
-        std::stable_sort(idx.begin() + coff[(size_t)ch], idx.begin() + coff[(size_t)ch + 1], [&](int64_t x, int64_t y) { return R.bp1[x] < R.bp1[y]; });
+        std::stable_sort(idx.begin() + coff[(size_t)ch], idx.begin() + coff[(size_t)ch + 1], [&](int64_t x, int64_t y) { return csv_soa::bp1(R, x) < csv_soa::bp1(R, y); });
     });
     // slices in emission order
     struct Slice { int ch; int64_t lo, hi; int64_t cnt[5]; int64_t start[5]; int rc; const std::string* buf; size_t off, len; };
@@ -277,11 +278,11 @@ int emit_slice(const csv_vcf_in* in, const int64_t* v, int64_t nv, int ch, int64
             const csv_segment& sg = in->seg[R.call_seg[c]];
             const int type = sg.svtype;
             // TRA calls whose count_coverage gave up carry the '.' fields too (cuteSV_resolveTRA.py:276-281)
-            const bool gt_on = sg.genotype != 0 && R.gl_idx[c] >= 0;
+            const bool gt_on = sg.genotype != 0 && csv_soa::gl_idx(R, c) >= 0;
             // genotype strings of the row ('.' fields when the task was not genotyped)
             GlRow g{"./.", 3, ".,.,.", 5, ".", 1, ".", 1};
             if (gt_on) {
-                const int32_t key = R.gl_idx[c];
+                const int32_t key = csv_soa::gl_idx(R, c);
                 const int32_t* it = std::lower_bound(in->gl_key, in->gl_key + in->n_gl, key);
                 if (it == in->gl_key + in->n_gl || *it != key || !split_gl(in->gl_str[it - in->gl_key], g)) return CSV_E_INVALID;
             }
@@ -289,23 +290,23 @@ int emit_slice(const csv_vcf_in* in, const int64_t* v, int64_t nv, int ch, int64
             // filter label (cuteSV_genotype.py:289-292)
             const char* filt = "PASS";
             if (!(g.qual_n == 1 && g.qual[0] == '.')) filt = strtod(std::string(g.qual, g.qual_n).c_str(), nullptr) >= 5.0 ? "PASS" : "q5";
-            const long long pos = R.bp1[c], re = R.support[c];
+            const long long pos = csv_soa::bp1(R, c), re = R.support[c];
             auto put_rnames = [&]() {
                 if (in->report_readid) { o.put(";RNAMES="); if (in->rnames) o.put(in->rnames + in->rnames_off[c], (size_t)(in->rnames_off[c + 1] - in->rnames_off[c])); }
             };
             auto put_af_field = [&](bool numeric) {
                 if (!in->genotype) return;
                 o.put(";AF=");
-                if (numeric) put_af(o, re, R.dr[c]); else o.put('.');
+                if (numeric) put_af(o, re, csv_soa::dr(R, c)); else o.put('.');
             };
             auto put_tail = [&]() {           // QUAL FILTER INFO are written by the caller; this is FORMAT + sample
                 o.put('\t'); o.put(kFormat); o.put('\t');
                 o.put(g.gt, g.gt_n); o.put(':');
-                if (gt_on) o.num(R.dr[c]); else o.put('.');
+                if (gt_on) o.num(csv_soa::dr(R, c)); else o.put('.');
                 o.put(':'); o.num(re); o.put(':'); o.put(g.pl, g.pl_n); o.put(':'); o.put(g.gq, g.gq_n); o.put('\n');
             };
             if (type == CSV_DEL || type == CSV_INS) {
-                const long long len = R.bp2[c];                                         // |SVLEN|
+                const long long len = csv_soa::bp2(R, c);                                         // |SVLEN|
                 if (len > in->max_size && in->max_size != -1) continue;                   // :265-266
                 if (len < in->min_size) continue;                                       // :267-268
                 const long long end = type == CSV_INS ? pos : pos + len;
@@ -350,15 +351,15 @@ int emit_slice(const csv_vcf_in* in, const int64_t* v, int64_t nv, int ch, int64
                 o.put(type == CSV_INS ? ";SVTYPE=INS;SVLEN=" : ";SVTYPE=DEL;SVLEN=");
                 o.num(type == CSV_INS ? len : -len);
                 o.put(";END="); o.num(end);
-                o.put(";CIPOS=-"); o.num(R.cipos[c]); o.put(','); o.num(R.cipos[c]);
-                o.put(";CILEN=-"); o.num(R.cilen[c]); o.put(','); o.num(R.cilen[c]);
+                o.put(";CIPOS=-"); o.num(csv_soa::cipos(R, c)); o.put(','); o.num(csv_soa::cipos(R, c));
+                o.put(";CILEN=-"); o.num(csv_soa::cilen(R, c)); o.put(','); o.num(csv_soa::cilen(R, c));
                 o.put(";RE="); o.num(re);
                 put_rnames();
                 put_af_field(gt_on);
                 if (type == CSV_DEL) o.put(";STRAND=+-");
                 put_tail();
             } else if (type == CSV_DUP) {
-                const long long len = R.bp2[c] - R.bp1[c];
+                const long long len = csv_soa::bp2(R, c) - csv_soa::bp1(R, c);
                 if (llabs(len) > in->max_size && in->max_size != -1) continue;            // :315-316
                 char b0;
                 if (!base(pos, b0)) return CSV_E_INVALID;                                // ref_chrom[int(i[2])] (:334)
@@ -374,9 +375,9 @@ int emit_slice(const csv_vcf_in* in, const int64_t* v, int64_t nv, int ch, int64
                 put_af_field(gt_on);
                 put_tail();
             } else if (type == CSV_INV) {
-                const long long len = R.bp2[c] - R.bp1[c];
+                const long long len = csv_soa::bp2(R, c) - csv_soa::bp1(R, c);
                 if (llabs(len) > in->max_size && in->max_size != -1) continue;            // :351-352
-                const char* strand = in->strand_name[R.call_aux[c]];
+                const char* strand = in->strand_name[csv_soa::call_aux(R, c)];
                 const bool pp = strcmp(strand, "++") == 0;                              // :360-365
                 const long long pinv = pp ? pos : pos + 1;
                 const long long ridx = pp ? (pos - 1 > 0 ? pos - 1 : 0) : pos;
@@ -394,9 +395,9 @@ int emit_slice(const csv_vcf_in* in, const int64_t* v, int64_t nv, int ch, int64
                 put_af_field(gt_on);
                 put_tail();
             } else {                                                                    // BND (:400-458)
-                const int code = R.call_aux[c] & 7;
-                const char* chr2 = in->chrom_name[R.call_aux[c] >> 3];
-                const long long mate = R.bp2[c] + ((code == 0 || code == 2) ? 1 : 0);    // TRA:140
+                const int code = csv_soa::call_aux(R, c) & 7;
+                const char* chr2 = in->chrom_name[csv_soa::call_aux(R, c) >> 3];
+                const long long mate = csv_soa::bp2(R, c) + ((code == 0 || code == 2) ? 1 : 0);    // TRA:140
                 const bool nfirst = code < 2;                                           // ALT starts with 'N' (types A/B)
                 const long long pbnd = nfirst ? pos : pos + 1;
                 char b0 = 'N';

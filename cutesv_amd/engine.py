@@ -90,15 +90,31 @@ class Context:
         """evict L2 / Infinity Cache (a measurement aid: the next run reads its columns from HBM)"""
         self._check(lib().csv_cache_flush(self._h, int(nbytes)))
 
-    def result_buffers(self, per_sig=False, cap_calls=None, cap_support=None, pinned=True):
+    def result_buffers(self, per_sig=False, cap_calls=None, cap_support=None, pinned=True, no_support=False, coord32=False, fields=None):
         """caller-owned result arrays for the uploaded batch, to be handed to download(into=...) again and again; page-locked by
-        default: the device then writes the calls straight into them (k_publish) and a download is one synchronisation"""
+        default: the device then writes the calls straight into them (k_publish) and a download is one synchronisation.
+        no_support / coord32 / fields: the slim forms of ABI v7 (_abi.HostResult)"""
         n = self._batch.n_sig
         return _abi.HostResult(n, cap_calls or max(64, n // 16 + 16), cap_support or max(64, n + 16), per_sig=per_sig,
-                               n_seg=len(self._batch.segments), alloc=pinned_empty if pinned else None, narrow_support=True)
+                               n_seg=len(self._batch.segments), alloc=pinned_empty if pinned else None, narrow_support=True,
+                               no_support=no_support, coord32=coord32, fields=fields)
+
+    def lazy_info(self):
+        """(gate-first?, signature-column bytes the bulk copy of the last upload did not send): csv_batch_info"""
+        a, b = C.c_int64(0), C.c_int64(0)
+        self._check(lib().csv_batch_info(self._h, 0, C.byref(a)))
+        self._check(lib().csv_batch_info(self._h, 1, C.byref(b)))
+        return bool(a.value), int(b.value)
 
     def download(self, per_sig=False, cap_calls=None, cap_support=None, into=None):
         if into is not None:
+            # the library checks cap_calls / cap_support (E_CAPACITY); the arrays it fills WITHOUT a capacity of their own are
+            # sized by the batch: seg_status (one word per segment), cluster_id / allele_id (one per signature)
+            if into.n_seg < len(self._batch.segments):
+                raise ValueError("download(into=...): the result has room for %d segments, the uploaded batch has %d"
+                                 % (into.n_seg, len(self._batch.segments)))
+            if into.per_sig and into.n_sig != self._batch.n_sig:
+                raise ValueError("download(into=...): per-signature arrays of %d rows, the uploaded batch has %d" % (into.n_sig, self._batch.n_sig))
             self._check(lib().csv_batch_download(self._h, C.byref(into.c)))       # (E_CAPACITY: the caller sized `into`; it is raised)
             into.n_seg_used = len(self._batch.segments)
             return into
@@ -116,21 +132,24 @@ class Context:
         raise CsvError(_abi.E_CAPACITY, "capacity retry failed")
 
     # ---- one shot: csv_cluster_batch (H2D, kernels and D2H overlap inside the one call)
-    def cluster_batch(self, batch, per_sig=False, cap_calls=None, cap_support=None, reuse=False):
+    def cluster_batch(self, batch, per_sig=False, cap_calls=None, cap_support=None, reuse=False, no_support=False, coord32=False, fields=None):
         """reuse=True hands the C call the result arrays of this context's previous reuse=True call when they are large
         enough (a caller that consumes a result before asking for the next one, like resolve.run_batch, saves the
-        page faults of ~20 MB of fresh arrays per call); the previous result is overwritten."""
+        page faults of ~20 MB of fresh arrays per call); the previous result is overwritten.
+        no_support / coord32 / fields: the slim result forms of ABI v7 (what does not cross PCIe: _abi.HostResult)."""
         n = batch.n_sig
         cap_calls = cap_calls or max(64, n // 16 + 16)
         cap_support = cap_support or max(64, n + 16)         # (a signature supports at most one call)
         self._batch = batch
         for _ in range(2):
             res = self._res_cache if reuse else None
+            key = (bool(per_sig), bool(no_support), bool(coord32), None if fields is None else frozenset(fields), bool(reuse))
             if (res is None or res.cap_calls < cap_calls or res.cap_support < cap_support or res.n_seg < len(batch.segments)
-                    or res.per_sig != per_sig or (per_sig and res.n_sig != n)):
+                    or res.shape_key() != key or (per_sig and res.n_sig != n)):
                 # (recycled arrays are worth page-locking: the result copies then land in them by DMA)
                 res = _abi.HostResult(n, cap_calls, cap_support, per_sig=per_sig, n_seg=len(batch.segments),
-                                      alloc=pinned_empty if reuse else None, narrow_support=bool(reuse))
+                                      alloc=pinned_empty if reuse else None, narrow_support=bool(reuse),
+                                      no_support=no_support, coord32=coord32, fields=fields)
                 if reuse:
                     self._res_cache = res
             rc = lib().csv_cluster_batch(self._h, C.byref(batch.c), C.byref(res.c))

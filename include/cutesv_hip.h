@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CSV_ABI_VERSION 6
+#define CSV_ABI_VERSION 7
 
 /* SV types: one (chromosome, type) pair is one segment == one reference pool task
  * (MAIN:1116-1189).  Order of the enum is irrelevant to results. */
@@ -152,8 +152,15 @@ typedef struct csv_batch_in {
  *   (INDEL:110-136, GT:95-159) and neither has this library; the only per-segment condition left is a length / pos2
  *   value outside [0, 2^42) (the clusters holding one emit nothing, every other cluster of the batch is unaffected;
  *   main_ctrl swallows a failing task the same way, MAIN:1193-1199).
+ * (ABI v7) A caller that does not need a field does not pay for its trip across PCIe: call_cluster, call_aux, cipos, cilen,
+ *   search_pos, seq_pick, dr, dv and gl_idx may each be NULL (not written); call_seg, bp1, bp2 and support are always required.
+ *   `flags`: CSV_OUT_NO_SUPPORT_LIST - support_off / support_sig / support_sig32 are not written and may be NULL (`support` still
+ *   holds every call's read count, n_support the total): read names reach the VCF only under --report_readid (GT:263-458), and
+ *   the list is half of a discovery run's result bytes.  CSV_OUT_COORD_I32 - bp1, bp2, search_pos and seq_pick point to int32_t
+ *   arrays (only with CSV_IN_SIG_I32 columns, whose coordinates fit by construction; CSV_E_INVALID otherwise).
  */
 enum { CSV_SEG_KEY_RANGE = 1 };
+enum { CSV_OUT_NO_SUPPORT_LIST = 1, CSV_OUT_COORD_I32 = 2 };
 typedef struct csv_batch_out {
     int64_t  cap_calls;
     int64_t  cap_support;
@@ -181,6 +188,8 @@ typedef struct csv_batch_out {
     int32_t* support_sig32; /* (ABI v6) cap_support or NULL: the support list as int32 - a batch holds fewer than 2^31 signatures -
                                INSTEAD of support_sig (exactly one of the two is given): half the bytes of the largest result
                                array on the link */
+    int32_t  flags;         /* (ABI v7) CSV_OUT_* */
+    int32_t  reserved;
 } csv_batch_out;
 
 /* Per-kernel device timings of one csv_batch_run, measured with HIP events recorded on the
@@ -230,6 +239,11 @@ int csv_ctx_sync(csv_ctx* ctx);
 /* How the reads table of the last completed run was brought into start order: 0 = the caller promised sorted blocks,
  * 1 = whole sorted runs were moved (or nothing had to move), 2 = the general stable radix sort; -1 = no reads table. */
 int csv_batch_reads_mode(const csv_ctx* ctx);
+/* (ABI v7) What the last upload of this context did at the PCIe boundary: which = 0: 1 when csv_cluster_batch took the
+ * gate-first form (page-locked b / read_id / aux columns: only the position column travels in bulk, the rows of the clusters
+ * that pass the size gate - INDEL:62-64, 86 - are read out of the caller's columns by the device), else 0; which = 1: the
+ * bytes of signature columns the bulk copy therefore did not send.  A measurement aid (bench.py's pcie object). */
+int csv_batch_info(const csv_ctx* ctx, int which, int64_t* value);
 /* Context options.  CSV_OPT_REUSE_READS_ORDER (default 1): the start-ordered, packed copy of the reads table that the first
  * csv_batch_run after an upload builds is kept for later runs of the SAME upload (a resident caller that re-runs a batch,
  * e.g. with other segment scalars, does not re-order millions of reads every time); 0 rebuilds it in every run.
@@ -238,7 +252,9 @@ enum { CSV_OPT_REUSE_READS_ORDER = 1 };
 int csv_batch_option(csv_ctx* ctx, int option, int value);
 
 /* Page-locked host memory.  Columns that live in it (or in a registered caller buffer) are copied asynchronously, so the
- * kernels start while the later columns are still on the link; RESULT arrays that live in it are filled in place by the
+ * kernels start while the later columns are still on the link; a csv_cluster_batch call whose b / read_id / aux columns live in
+ * it copies only the position column and lets the device read the rows it needs from the others (gate-first; batches of at
+ * least CSV_LAZY_MIN = 65 536 signatures, CSV_NO_LAZY=1 in the environment switches it off); RESULT arrays that live in it are filled in place by the
  * device (csv_batch_download / csv_cluster_batch then cost one synchronisation: no staging copy, no host-side unpack) -
  * all of bp1 ... support_sig must be page-locked for that, seg_status and the per-signature arrays may be anywhere.
  * Memory from csv_host_alloc / csv_host_register must be released through csv_host_free / csv_host_unregister.  No

@@ -59,10 +59,17 @@ for it in range(n_it):
     if rng.integers(0, 2) == 0:
         st = st.pinned()                                  # page-locked columns, int32 twins of the positions / lengths (half of the runs)
     hb = st.host_batch(tasks, p)
+    # one-shot calls from page-locked columns: the gate-first form (only the positions travel in bulk) for two runs in three
+    os.environ["CSV_LAZY_MIN"] = "0" if rng.integers(0, 3) else "1000000000"
     try:
         want = oracle.cluster_batch(hb, per_sig=True).trimmed()
         if rng.integers(0, 2):                            # the one-shot call, results copied out or published in place ...
             got = ctx.cluster_batch(hb, per_sig=True, reuse=bool(rng.integers(0, 2))).trimmed()
+            if rng.integers(0, 4) == 0 and hb.a.dtype == np.int32:       # ... and a slim result of the same batch (ABI v7)
+                fields = tuple(f for f in ("call_aux", "cipos", "cilen", "seq_pick", "dr", "dv", "gl_idx", "search_pos", "call_cluster") if rng.integers(0, 2))
+                slim = ctx.cluster_batch(hb, reuse=bool(rng.integers(0, 2)), no_support=bool(rng.integers(0, 2)), coord32=bool(rng.integers(0, 2)), fields=fields).trimmed()
+                for name in ("call_seg", "bp1", "bp2", "support") + fields:
+                    assert np.array_equal(slim[name].astype(np.int64), got[name].astype(np.int64)), "slim " + name
         else:                                             # ... or upload / run (twice: tiers on demand, idempotence) / download
             ctx.upload(hb, per_sig=True)
             ctx.run()

@@ -1121,3 +1121,182 @@ def test_narrow_input_columns(ctx):
     hb = pbig.host_batch(pbig.tasks(), p)
     assert hb.a.dtype == np.int64 and hb.r_start.dtype == np.int32
     assert_soa_equal(ctx.cluster_batch(hb, per_sig=True).trimmed(), _oracle().cluster_batch(hb, per_sig=True).trimmed(), big)
+
+
+# ---------------------------------------------------------------------------------------------- gate-first calls, slim results (ABI v7)
+def _pinned_batch(hb):
+    """the same batch with every column in page-locked memory (what csv_cluster_batch needs to take the gate-first form)"""
+    pc = engine.pinned_copy
+    kw = {}
+    if hb.reads_off is not None:
+        kw = dict(reads_off=hb.reads_off, r_start=pc(hb.r_start), r_end=pc(hb.r_end), r_primary=pc(hb.r_primary), r_id=pc(hb.r_id))
+    return _abi.HostBatch(hb.segments, pc(hb.a), pc(hb.b), pc(hb.read_id), pc(hb.aux), n_chrom=hb.n_chrom, contig_len=hb.contig_len,
+                          per_sig=bool(hb.c.flags & _abi.IN_PER_SIG), reads_sorted=bool(hb.c.flags & _abi.IN_READS_SORTED), **kw)
+
+
+def _gate_first_engine(ctx):
+    def run(hb):
+        res = ctx.cluster_batch(_pinned_batch(hb), per_sig=True)
+        assert ctx.lazy_info()[0], "the call did not take the gate-first form"
+        return res
+    return run
+
+
+def test_gate_first_rows_identical_to_reference(ctx, monkeypatch):
+    """csv_cluster_batch from page-locked columns copies only the position column and fetches the rows of the clusters that pass
+    the size gate out of the caller's columns (k_lazy_zero / k_lazy_fetch): every golden case of the reference - the (0,0)
+    sentinel look-alikes, INV / TRA chains, genotyping - gives the reference's rows through that form too"""
+    monkeypatch.setenv("CSV_LAZY_MIN", "0")
+    for fixture in ("small_cases.json.gz", "known_answers.json"):
+        for case in load_json(fixture):
+            st = store_from_json(case["store"])
+            p = Params(**case["params"])
+            want = {(t, c): r for t, c, r in case["rows"]}
+            got, res, hb = rows_by_task(st, p, _gate_first_engine(ctx), tasks=list(want.keys()))
+            for key in want:
+                assert_rows_equal(key[0], got[key], want[key], where="gate-first %s %s" % (case["name"], key))
+
+
+def _gate_first_vs_oracle(ctx, st, p):
+    hb = st.host_batch(st.tasks(), p)
+    want = _oracle().cluster_batch(hb, per_sig=True).trimmed()
+    phb = _pinned_batch(hb)
+    got = ctx.cluster_batch(phb, per_sig=True)
+    assert ctx.lazy_info()[0]
+    assert_soa_equal(got.trimmed(), want, store=st)
+    # a resident re-run of the same upload takes the device columns as the fetch left them (the host columns are not read again)
+    ctx.run()
+    assert_soa_equal(ctx.download(per_sig=True).trimmed(), want, store=st)
+    with pytest.raises(engine.CsvError):
+        ctx.validate()                                    # (the order check needs whole columns: a csv_batch_upload)
+    return got.trimmed()
+
+
+def test_gate_first_vs_oracle_every_tier(ctx, monkeypatch):
+    from cutesv_amd.columns import SigStore
+    monkeypatch.setenv("CSV_LAZY_MIN", "0")
+    # all five types with genotyping, three presets
+    for seed, p in ((101, Params(genotype=True)), (102, Params.ont(genotype=True)), (103, Params.hifi(genotype=True, min_support=3))):
+        _gate_first_vs_oracle(ctx, synth.small_mixed(seed=seed, dup_frac=0.2, n_loci=200), p)
+    # clusters of thousands of signatures (the LDS and the global-scratch tiers): fetched by every chain tile they cover
+    st = synth.small_mixed(seed=77, n_sites=30, coverage=60, n_noise=30000, n_loci=3000, contig_len=400_000, dup_frac=0.3)
+    got = _gate_first_vs_oracle(ctx, st, Params(max_cluster_bias_DEL=3000, max_cluster_bias_INS=3000, max_cluster_bias_DUP=20000,
+                                                 max_cluster_bias_INV=20000, max_cluster_bias_TRA=5000, min_support=3, genotype=False))
+    assert np.bincount(got["cluster_id"][got["cluster_id"] >= 0]).max() > 2048
+    # a 12 000x pile-up next to 30x loci, genotyped
+    base = synth.small_mixed(seed=5, coverage=30, n_contigs=2, contig_len=1_000_000)
+    pile = synth.small_mixed(seed=6, coverage=12000, n_sites=3, n_contigs=2, contig_len=40_000, n_noise=0, n_loci=0, dup_frac=0.02)
+    _gate_first_vs_oracle(ctx, synth.concat_stores(base, pile), Params(genotype=True, min_support=10, max_cluster_bias_DEL=200))
+    # batch sizes on / next to the chain tile boundary; the last cluster is long
+    for n in (2048, 4096, 4097, 6143, 64, 1):
+        rng = np.random.default_rng(n)
+        per = {t: [] for t in ("DEL", "INS", "DUP", "INV", "TRA")}
+        pos, i = 1000, 0
+        while i < n:
+            m = min(int(rng.choice([1, 2, 5, 12, 20, 40, 70, 300])) if n - i > 400 else n - i, n - i)
+            for j in range(m):
+                per["DEL"].append((pos + int(rng.integers(0, 30)), int(rng.integers(40, 60)), "q%06d" % (i + j), "DEL", "1"))
+            pos += 5000
+            i += m
+        _gate_first_vs_oracle(ctx, SigStore.from_tuple_lists(per), Params.ont(min_support=3))
+    # thousands of small segments: chain tiles that span dozens of segments (the per-row source mapping)
+    rng = np.random.default_rng(12)
+    per = {"DEL": [], "INS": []}
+    for c in range(700):
+        ch = "ctg%05d" % c
+        for site in range(int(rng.integers(1, 4))):
+            pos = 1000 + site * 5000
+            for r in range(int(rng.integers(3, 14))):
+                per["DEL"].append((pos + int(rng.integers(-5, 5)), 300 + int(rng.integers(-3, 3)), "d%d_%d_%d" % (c, site, r), "DEL", ch))
+                per["INS"].append((pos + 2000 + int(rng.integers(-5, 5)), 200 + int(rng.integers(-3, 3)), "i%d_%d_%d" % (c, site, r), "ACGT" * 50, "INS", ch))
+    _gate_first_vs_oracle(ctx, SigStore.from_tuple_lists(per, []), Params.ont(min_support=3))
+    # int64 columns (a length beyond 31 bits keeps the wide columns): the other instantiation of the fetch
+    big = synth.small_mixed(seed=21, genotype=True)
+    big.b[5] = 1 << 33
+    hb = big.host_batch(big.tasks(), Params.ont(genotype=True))
+    assert hb.a.dtype == np.int64
+    _gate_first_vs_oracle(ctx, big, Params.ont(genotype=True))
+
+
+def test_gate_first_zero_positions(ctx, monkeypatch):
+    """the one chain predicate of a DEL / INS / DUP segment that reads a length: an element equal to the reference's [0, 0, '']
+    sentinel (INDEL:62-64) - position 0 AND length 0 - starts a new cluster behind it and silences the cluster it ends.  The
+    gate-first form fetches `b` of the rows at position 0 before the chain kernels run (k_lazy_zero)."""
+    from cutesv_amd.columns import SigStore
+    monkeypatch.setenv("CSV_LAZY_MIN", "0")
+    per = {t: [] for t in ("DEL", "INS", "DUP", "INV", "TRA")}
+    for ch, zero_len in (("1", 0), ("2", 7), ("3", 0)):
+        n0 = 0
+        for i in range(6):                                  # position 0: lengths 0 (the look-alike) or not
+            per["DEL"].append((0, zero_len if i < 4 else 35, "z%s_%d" % (ch, i), "DEL", ch)); n0 += 1
+            per["INS"].append((0, zero_len if i < 3 else 40, "y%s_%d" % (ch, i), "ACGT" * 10, "INS", ch))
+        for i in range(12):
+            per["DEL"].append((3 + i, 50 + i % 3, "a%s_%d" % (ch, i), "DEL", ch))
+            per["INS"].append((2 + i, 60 + i % 2, "b%s_%d" % (ch, i), "ACGT" * 20, "INS", ch))
+        for i in range(10):
+            per["DEL"].append((5000 + i, 80, "c%s_%d" % (ch, i), "DEL", ch))
+    st = SigStore.from_tuple_lists(per)
+    for p in (Params.ont(min_support=3), Params(min_support=2, max_cluster_bias_DEL=10, max_cluster_bias_INS=10)):
+        got = _gate_first_vs_oracle(ctx, st, p)
+        monkeypatch.setenv("CSV_NO_LAZY", "1")
+        hb = st.host_batch(st.tasks(), p)
+        bulk = ctx.cluster_batch(_pinned_batch(hb), per_sig=True)
+        assert not ctx.lazy_info()[0]
+        assert_soa_equal(bulk.trimmed(), got, store=st)
+        monkeypatch.delenv("CSV_NO_LAZY")
+
+
+@pytest.mark.parametrize("genotype", [False, True])
+def test_slim_results_equal_the_full_ones(ctx, genotype, monkeypatch):
+    """ABI v7: CSV_OUT_NO_SUPPORT_LIST, CSV_OUT_COORD_I32 and NULL optional fields change what crosses PCIe, not a value: every
+    array that is asked for equals the full result's, through k_publish (page-locked arrays) and through the copy path"""
+    st = synth.small_mixed(seed=41, genotype=genotype, n_loci=150)
+    p = Params.ont(genotype=genotype)
+    pst = st.pinned()
+    hb = pst.host_batch(pst.tasks(), p)
+    assert hb.a.dtype == np.int32
+    full = ctx.cluster_batch(hb).trimmed()
+    forms = [dict(no_support=True), dict(coord32=True), dict(no_support=True, coord32=True, fields=("call_aux", "cipos", "cilen", "seq_pick")),
+             dict(fields=()), dict(no_support=True, coord32=True, fields=("dr", "dv", "gl_idx"))]
+    for kw in forms:
+        for reuse in (True, False):                         # page-locked (published in place) / pageable (copied and unpacked)
+            ctx._res_cache = None
+            r = ctx.cluster_batch(hb, reuse=reuse, **kw)
+            t = r.trimmed()
+            assert r.n_calls == len(full["bp1"]) and r.n_support == len(full["support_sig"])
+            for name in ("call_seg", "bp1", "bp2", "support") + tuple(kw.get("fields", _abi.OPTIONAL_CALL_FIELDS)):
+                assert t[name] is not None and np.array_equal(t[name].astype(np.int64), full[name].astype(np.int64)), (kw, reuse, name)
+                if kw.get("coord32") and name in _abi.COORD_FIELDS:
+                    assert t[name].dtype == np.int32
+            for name in _abi.OPTIONAL_CALL_FIELDS:
+                if "fields" in kw and name not in kw["fields"]:
+                    assert t[name] is None
+            if kw.get("no_support"):
+                assert t["support_off"] is None and t["support_sig"] is None
+            else:
+                assert np.array_equal(t["support_off"], full["support_off"]) and np.array_equal(t["support_sig"], full["support_sig"])
+    # int32 coordinates need int32 columns
+    wide = st.host_batch(st.tasks(), p)
+    with pytest.raises(engine.CsvError):
+        ctx.cluster_batch(wide, coord32=True)
+    # resident: deliver slim into recycled page-locked arrays
+    ctx.upload(hb); ctx.run()
+    res = ctx.result_buffers(no_support=True, coord32=True, fields=("call_aux", "cipos", "cilen", "seq_pick", "dr", "gl_idx"))
+    t = ctx.download(into=res).trimmed()
+    for name in ("call_seg", "bp1", "bp2", "support", "call_aux", "cipos", "cilen", "seq_pick", "dr", "gl_idx"):
+        assert np.array_equal(t[name].astype(np.int64), full[name].astype(np.int64)), name
+
+
+def test_download_into_checks_the_batch_shape(ctx):
+    """recycled result arrays that are too small for the uploaded batch's segments / signatures are refused (seg_status and the
+    per-signature arrays have no capacity field of their own)"""
+    small = synth.small_mixed(seed=3, n_contigs=2)
+    large = synth.small_mixed(seed=4, n_contigs=4)
+    p = Params.ont()
+    ctx.upload(small.host_batch(small.tasks(), p), per_sig=True)
+    res = ctx.result_buffers(per_sig=True)
+    ctx.run(); ctx.download(per_sig=True, into=res)
+    ctx.upload(large.host_batch(large.tasks(), p), per_sig=True)
+    ctx.run()
+    with pytest.raises(ValueError):
+        ctx.download(per_sig=True, into=res)
