@@ -118,7 +118,7 @@ struct csv_ctx {
     Arena       arena, arena_rb;
     // batch buffers (slices of `arena`)
     Buf seg, woff, seg_drop, a, b, rid, aux, a32, b32;
-    Buf tile_lead;
+    Buf tile_lead, tabs;
     Buf cluster_id, partial, tile_cnt, item_rec, list_small, list_big, list_tiny, list_wide, seg_gate, tile_info, ch_masks, tile_items, seg_err;
     Buf item_cnt, item_base, item_chunk, sup_tmp;
     Buf t_rec, t_rec0;
@@ -538,8 +538,13 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
     if (R > 0) while (pool_n < 2 * (2 * rc_max + maxseg_gt) + 4096 || pool_n < 64 * tra_gt_len + 8192) { pool_n <<= 1; if (pool_n >= (1ll << 32)) break; }
     Plan P;
 #define PL(buf, bytes) P.add(c->buf, (size_t)(bytes))
-    PL(seg, (S + 1) * sizeof(csv_segment)); PL(woff, (S + 2) * sizeof(i64)); PL(seg_drop, S + 1); PL(seg_gate, (S + 1) * 16); PL(seg_err, (S + 1) * 4);
-    PL(tile_info, nt * TILE_REC * 16);
+    // the small tables (segments, prefix, drop marks, gate records, status words, chain tile records) are ONE block laid out like
+    // their page-locked staging copy: one DMA copy brings them all (r04: five blit kernels of ~5 us each in front of the columns)
+    const size_t o_seg = 0, o_woff = o_seg + (size_t)(S + 1) * sizeof(csv_segment), o_drop = o_woff + (size_t)(S + 2) * 8,
+                 o_gate = (o_drop + (size_t)S + 1 + 15) & ~(size_t)15, o_serr = o_gate + (size_t)(S + 1) * 16,
+                 o_tiles = (o_serr + (size_t)(S + 1) * 4 + 15) & ~(size_t)15, o_end = o_tiles + (size_t)nt * TILE_REC * 16,
+                 o_ones = (o_end + 255) & ~(size_t)255, ones_bytes = (size_t)(CH_TILE + 64) * 8, o_stage_end = o_ones + ones_bytes;
+    PL(tabs, o_end);
     // positions and lengths stay in the width they arrive in: the kernels read int32 columns as they are (kernels.hip.h Col)
     const bool sig32 = (in->flags & CSV_IN_SIG_I32) != 0, rd32 = (in->flags & CSV_IN_READS_I32) != 0;
     // (the position column is followed by a tile of padding, so that the chain kernel can read any span that begins inside the batch)
@@ -577,12 +582,24 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
     }
 
     // ---- small tables: staged in page-locked memory, one copy
-    const size_t o_seg = 0, o_woff = o_seg + (size_t)(S + 1) * sizeof(csv_segment), o_drop = o_woff + (size_t)(S + 2) * 8,
-                 o_gate = (o_drop + (size_t)S + 1 + 15) & ~(size_t)15, o_tiles = o_gate + (size_t)(S + 1) * 16, o_end = o_tiles + (size_t)nt * TILE_REC * 16;
+    {
+        char* tb = (char*)c->tabs.p;
+        c->seg.p = tb + o_seg; c->woff.p = tb + o_woff; c->seg_drop.p = tb + o_drop; c->seg_gate.p = tb + o_gate; c->seg_err.p = tb + o_serr; c->tile_info.p = tb + o_tiles;
+    }
     // (the staging block is also the landing zone of the results: never smaller than one counters struct)
-    { const int rc = pin_reserve(c, o_end + sizeof(DevCounters) + 256); if (rc) return rc; }
+    { const int rc = pin_reserve(c, o_stage_end + sizeof(DevCounters) + 256); if (rc) return rc; }
     hipStream_t st = c->stream;
+    // The column copies go out on the kernels' OWN stream: the kernels that wait for them then wait on a barrier packet in
+    // their queue.  On a copy stream of their own (r01-r04, CSV_COPY_STREAM=1) the dependency was an event across queues, which
+    // this runtime resolves late: ~90 us between the end of the copy and the first kernel in a one-shot call (cfg3 gate-first
+    // 0.64 -> 0.55 ms) - more than the chain kernels (~15 us) ever overlapped with the second copy group.
+    hipStream_t cs = env_int("CSV_COPY_STREAM", 0) ? c->copy[0] : st;
     HIP_TRY(c, hipStreamSynchronize(st));                   // the staging block may still be the source of an earlier copy
+    // whatever ran before (a resident caller's kernels still reading the columns this upload rewrites) is over before the
+    // column copies start - and nothing else: they do not wait for the tables or the zero fills below
+    HIP_TRY(c, hipEventRecord(c->ev_init, st));
+    HIP_TRY(c, hipStreamWaitEvent(cs, c->ev_init, 0));
+    memset(c->h_pin + o_serr, 0, (size_t)(S + 1) * 4);
     memcpy(c->h_pin + o_seg, c->h_seg.data(), (size_t)S * sizeof(csv_segment));
     memcpy(c->h_pin + o_woff, c->h_woff.data(), (size_t)(S + 1) * 8);
     memcpy(c->h_pin + o_drop, drop.data(), (size_t)S + 1);
@@ -616,13 +633,8 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
             }
             r[2] = (nin <= 3 && !wide_bias) ? nin : 0;
         }
-        HIP_TRY(c, hipMemcpyAsync(c->tile_info.p, ti, (size_t)nt * TILE_REC * 16, hipMemcpyHostToDevice, st));
     }
-    HIP_TRY(c, hipMemcpyAsync(c->seg.p, c->h_pin + o_seg, (size_t)S * sizeof(csv_segment), hipMemcpyHostToDevice, st));
-    HIP_TRY(c, hipMemcpyAsync(c->woff.p, c->h_pin + o_woff, (size_t)(S + 1) * 8, hipMemcpyHostToDevice, st));
-    HIP_TRY(c, hipMemcpyAsync(c->seg_drop.p, c->h_pin + o_drop, (size_t)S + 1, hipMemcpyHostToDevice, st));
-    HIP_TRY(c, hipMemcpyAsync(c->seg_gate.p, c->h_pin + o_gate, (size_t)(S + 1) * 16, hipMemcpyHostToDevice, st));
-    HIP_TRY(c, hipMemsetAsync(c->seg_err.p, 0, (size_t)(S + 1) * 4, st));
+    HIP_TRY(c, hipMemcpyAsync(c->tabs.p, c->h_pin, o_end, hipMemcpyHostToDevice, st));
 
     // ---- columns, on the copy stream, in two groups: what the chain kernels read (positions, lengths / pos2, the strand
     // and chr2 words of INV / TRA segments), then what only the refine kernels read (read ids, INS sequence lengths).  In a
@@ -630,10 +642,15 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
     // source ranges are adjacent travel as one copy; aux is not read for DEL / DUP segments (include/cutesv_hip.h) and is
     // zero-filled on the device instead of crossing PCIe.  (One stream: a second DMA engine adds nothing on this link -
     // scripts/micro/h2d_bw.hip measures 57 GB/s with 1, 2, 4 or 8 streams, from page-locked and pageable memory alike.)
-    hipStream_t cs = c->copy[0];
-    HIP_TRY(c, hipMemsetAsync(c->aux.p, 0, (size_t)(W + 1) * 4, st));
-    HIP_TRY(c, hipEventRecord(c->ev_init, st));
-    HIP_TRY(c, hipStreamWaitEvent(cs, c->ev_init, 0));      // (the memset above, and whatever ran before)
+    // The padding behind the position column (positive values) is a DMA copy of a block of ones out of the staging area, in
+    // FRONT of the column: a fill kernel behind the DMA copy cost the stream an engine switch (~40 us in the trace) right
+    // where the chain kernels wait.
+    {
+        int* ones = (int*)(c->h_pin + o_ones);
+        for (size_t i = 0; i < ones_bytes / 4; i++) ones[i] = 1;
+        if (sig32) HIP_TRY(c, hipMemcpyAsync(dp<int>(c->a32) + W, ones, (size_t)(CH_TILE + 64) * 4, hipMemcpyHostToDevice, cs));
+        else HIP_TRY(c, hipMemcpyAsync(dp<i64>(c->a) + W, ones, (size_t)(CH_TILE + 64) * 8, hipMemcpyHostToDevice, cs));
+    }
     auto aux_kind = [&](int q) { const int t = c->h_seg[q].svtype; return t == CSV_INS ? 2 : (t == CSV_INV || t == CSV_TRA) ? 1 : 0; };
     for (int group = 1; group <= 2; group++) {
         for (int k = 0; k < S;) {
@@ -648,7 +665,7 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
                     HIP_TRY(c, hipMemcpyAsync(dp<i64>(c->a) + dst, in->a + src, n * 8, col_kind, cs));
                     if (!lazy) HIP_TRY(c, hipMemcpyAsync(dp<i64>(c->b) + dst, in->b + src, n * 8, col_kind, cs));
                 } else if (!lazy) HIP_TRY(c, hipMemcpyAsync(dp<int>(c->rid) + dst, in->read_id + src, n * 4, col_kind, cs));
-                if (lazy) c->lazy_bytes += n * (sig32 ? 4 : 8) + n * 4;
+                if (lazy && group == 2) c->lazy_bytes += n * (sig32 ? 4 : 8) + n * 4;      // b and read_id of the range stay behind
                 for (int q = k; q <= e;) {                  // aux: runs of segments of this group's kind
                     int q2 = q;
                     while (q2 + 1 <= e && aux_kind(q2 + 1) == aux_kind(q)) q2++;
@@ -657,6 +674,10 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
                         if (!(lazy && group == 2)) HIP_TRY(c, hipMemcpyAsync(dp<int>(c->aux) + c->h_woff[q], in->aux + c->h_seg[q].sig_begin, na * 4, col_kind, cs));
                         else c->lazy_bytes += na * 4;
                     }
+                    // aux of DEL / DUP segments is not the caller's to define (include/cutesv_hip.h): zero on the device.  Their own
+                    // ranges only, on the main stream - nothing a copy writes, so the copies wait for no fill (gate-first: k_lazy_fetch
+                    // writes the zeros of the rows it fetches)
+                    if (group == 1 && aux_kind(q) == 0 && na > 0 && !lazy) HIP_TRY(c, hipMemsetAsync(dp<int>(c->aux) + c->h_woff[q], 0, (size_t)na * 4, st));
                     // gate-first: the chain predicates of INV / TRA segments read b (kernels.hip.h sig_flag): those ranges travel whole
                     if (lazy && group == 1 && aux_kind(q) == 1 && na > 0) {
                         const i64 sb = c->h_seg[q].sig_begin;
@@ -668,10 +689,6 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
                 }
             }
             k = e + 1;
-        }
-        if (group == 1) {                                   // the padding behind the position column: positive values
-            if (sig32) HIP_TRY(c, hipMemsetD32Async((hipDeviceptr_t)(dp<int>(c->a32) + W), 1, CH_TILE + 64, cs));
-            else HIP_TRY(c, hipMemsetD32Async((hipDeviceptr_t)(dp<i64>(c->a) + W), 1, 2 * (size_t)(CH_TILE + 64), cs));
         }
         HIP_TRY(c, hipEventRecord(c->ev_copy[group - 1], cs));
     }

@@ -979,7 +979,8 @@ template <bool NARROW> __global__ __launch_bounds__(256) void k_lazy_fetch(DevBa
             if (!pair_type(type)) {                         // (INV / TRA: b and aux came with the bulk copy - the chain kernels read them)
                 wb |= 1u << r;
                 vb[r] = ((const raw_t*)B.h_b)[src];
-                if (type == CSV_INS) { wx |= 1u << r; vx[r] = B.h_aux[src]; }
+                wx |= 1u << r;                              // (aux of a DEL / DUP row is zero on the device: include/cutesv_hip.h)
+                if (type == CSV_INS) vx[r] = B.h_aux[src];
             }
         }
     }

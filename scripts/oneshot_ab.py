@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""A/B of the one-shot boundary call on the GPU box: python scripts/oneshot_ab.py [cfg3 cfg4 cfg5 ...]
+csv_cluster_batch from page-locked columns to page-locked results: bulk upload vs the gate-first form, full vs slim results."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench                                              # noqa: E402
+from cutesv_amd import engine                             # noqa: E402
+
+SLIM = dict(no_support=True, coord32=True, fields=("call_aux", "cipos", "cilen", "seq_pick", "dr", "gl_idx"))
+ctx = engine.Context(0)
+for wl in (sys.argv[1:] or ["cfg3"]):
+    store, params, name = bench.make_workload(wl, 1.0, 0)
+    pst = store.pinned()
+    phb = pst.host_batch(pst.tasks(), params)
+    n = phb.n_sig
+    for label, env, kw in (("bulk/full", {"CSV_NO_LAZY": "1"}, {}), ("gate-first/full", {}, {}), ("bulk/slim", {"CSV_NO_LAZY": "1"}, SLIM),
+                           ("gate-first/nosup", {}, dict(no_support=True)), ("gate-first/slim", {}, SLIM),
+                           ("gf/slim/copystream", {"CSV_COPY_STREAM": "1"}, SLIM), ("gate-first/slim", {}, SLIM)):
+        for k in ("CSV_NO_LAZY", "CSV_COPY_STREAM"):
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        ctx._res_cache = None
+        ts = []
+        for _ in range(12):
+            t0 = time.perf_counter()
+            r = ctx.cluster_batch(phb, reuse=True, **kw)
+            ts.append((time.perf_counter() - t0) * 1e3)
+        lazy, saved = ctx.lazy_info()
+        ts = ts[2:]
+        print("%s %-18s min %.3f med %.3f ms  (%.2e sig/s)  lazy=%d bytes_not_sent=%.1f MB calls=%d" %
+              (wl, label, min(ts), float(np.median(ts)), n / (min(ts) * 1e-3), lazy, saved / 1e6, r.n_calls), flush=True)
+ctx.close()
