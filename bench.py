@@ -472,9 +472,13 @@ def cpu_legs(name, store, params, tasks, hb, n_sig, procs, py_pool, full_pool):
     return cpu, cpu_c, cpu_c_mt, ores
 
 
+SLIM = dict(no_support=True, coord32=True, fields=("call_aux", "cipos", "cilen", "seq_pick", "dr", "gl_idx"))
+
+
 def resident_loops(ctx, phb, steps, warmup, dist=None):
-    """The two resident timed loops of an uploaded batch.  Returns (seconds of `steps` steps WITH the result delivered to
-    page-locked host arrays each step, seconds of the launch sequences alone, the last delivered result)."""
+    """The resident timed loops of an uploaded batch.  Returns (seconds of `steps` steps WITH the full result - calls + support
+    lists - delivered to page-locked host arrays each step, seconds of the launch sequences alone, the last delivered result,
+    seconds of `steps` steps with the SLIM result delivered: what a run without --report_readid consumes, ABI v7)."""
     ctx.upload(phb, per_sig=False)
     # every step does the whole stage, the ordering / packing of the reads table included (the library would keep the
     # ordered table of an upload across runs: CSV_OPT_REUSE_READS_ORDER, measured separately)
@@ -501,7 +505,17 @@ def resident_loops(ctx, phb, steps, warmup, dist=None):
         ctx.run()
     ctx.sync()
     dt_k = time.perf_counter() - t0
-    return dt, dt_k, res
+    dt_slim = None
+    if phb.a.dtype == np.int32:
+        slim = ctx.result_buffers(cap_calls=probe.n_calls + 64, cap_support=64, **SLIM)
+        for _ in range(warmup):
+            ctx.run(); ctx.download(into=slim)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ctx.run()
+            ctx.download(into=slim)
+        dt_slim = time.perf_counter() - t0
+    return dt, dt_k, res, dt_slim
 
 
 def instrumented(ctx, phb, steps):
@@ -576,7 +590,7 @@ def compact_workload(ctx, name, a, cpu):
     pstore = store.pinned()
     phb = pstore.host_batch(tasks, params)
     steps = max(5, min(a.steps, 20))
-    dt, dt_k, _ = resident_loops(ctx, phb, steps, 3)
+    dt, dt_k, _, dt_s = resident_loops(ctx, phb, steps, 3)
     pk_sig, pk, st, res, _ = instrumented(ctx, phb, 5)
     kbytes, total_bytes, units = kernel_units(store, hb, res, st, per_sig_step=False)
     if units["reads"]:
@@ -585,12 +599,14 @@ def compact_workload(ctx, name, a, cpu):
     w, g = cpu["ores"].trimmed(), res.trimmed()
     parity = all(np.array_equal(g[k], w[k]) for k in PARITY_FIELDS)
     t_one = timed(lambda: ctx.cluster_batch(phb, reuse=True), 4)
+    t_one_slim = timed(lambda: ctx.cluster_batch(phb, reuse=True, **SLIM), 4)
     tr = traffic_of(name, 1.0)
     dom_traffic = None if tr is None else (sum(tr.get(k, 0) for k in GT_KERNELS) if dom == "genotype_stage" else tr.get(dom))
     ms, ms_k, one = dt / steps * 1e3, dt_k / steps * 1e3, float(np.min(t_one)) * 1e3
     out = {"workload": wl_name, "signatures": n_sig, "reads": units["reads"], "calls": units["calls"],
            "ms_per_step": ms, "value": n_sig / (ms * 1e-3), "kernel_only_ms_per_step": ms_k, "kernel_only_value": n_sig / (ms_k * 1e-3),
-           "one_shot_call_ms": one,
+           "one_shot_call_ms": one, "one_shot_slim_ms": float(np.min(t_one_slim)) * 1e3,
+           "slim_ms_per_step": None if dt_s is None else dt_s / steps * 1e3,
            "dominant_kernel": {"kernel": dom, "us": pk[dom], "algorithmic_bytes": kbytes[dom],
                                "frac": round(kbytes[dom] / (pk[dom] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "traffic": dom_traffic},
            "pipeline": {"algorithmic_bytes": total_bytes, "frac": round(total_bytes / (ms_k * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
@@ -693,17 +709,103 @@ def quiet_stdout():
         os.dup2(2, 1)
 
 
-LINE_LIMIT = 20000       # bytes: the driver reads the line from a bounded tail of stdout (24 000 bytes measured)
-BULKY = ("kernel_us_per_sig_outputs", "kernel_us_cold", "traffic_per_kernel", "roofline_per_kernel", "units", "other_workloads")
+LINE_LIMIT = 7600        # bytes: the driver keeps an 8 000-byte tail of stdout (BENCH_r04.json): the whole line must fit it
+FULL_LINE = False         # --full: print every object (the scripts under scripts/ read kernel_us_cold, traffic_per_kernel, ...)
+
+
+def _num(x, nd=4):
+    return round(x, nd) if isinstance(x, float) else x
+
+
+def compact(out):
+    """The line the driver parses: the contract's keys in full, everything else as short named numbers.  The full objects go
+    to stderr and to gpurun_out/bench_detail_<workload>.json (`detail`)."""
+    if "roofline" not in out or "config" not in out or not isinstance(out.get("roofline"), dict):
+        return out
+    r = out["roofline"]
+    c = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data") if k in out}
+    c["config"] = {k: (v[:200] if isinstance(v, str) else v) for k, v in out["config"].items()}
+    keep = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes", "kernel_us", "kernel_us_net", "boundary_us", "copy_ceiling", "frac_of_copy_ceiling")
+    c["roofline"] = {k: _num(r.get(k)) for k in keep if k in r}
+    if isinstance(r.get("valu_issue"), dict):
+        c["roofline"]["valu_busy_frac"] = _num(r["valu_issue"].get("valu_busy_frac"))
+        c["roofline"]["valu_insts_per_wave"] = _num(r["valu_issue"]["valu_insts_per_launch"] / max(1, r["valu_issue"]["waves"]), 1)
+    if isinstance(r.get("cold"), dict):
+        c["roofline"]["cold_frac"] = _num(r["cold"].get("frac"))
+    if isinstance(out.get("roofline_pipeline"), dict):
+        c["roofline"]["pipeline_frac"] = _num(out["roofline_pipeline"].get("frac"))
+    h = out.get("host_to_host")
+    if isinstance(h, dict):
+        c["roofline"]["pcie"] = {k: _num(v) for k, v in h["pcie"].items()}
+        c["host_to_host"] = {k: _num(h.get(k)) for k in ("gate_first", "ms", "value", "slim_ms", "slim_value", "bulk_upload_ms", "pageable_columns_ms", "bytes_all_columns")}
+        c["host_to_host"]["region"] = "page-locked host columns -> host SoA (H2D + kernels + D2H), SURVEY 8d (ii)"
+    cb = out.get("cpu_baseline")
+    if isinstance(cb, dict):
+        c["cpu_baseline"] = {k: (cb[k][:170] if isinstance(cb[k], str) else _num(cb[k])) for k in ("value", "unit", "cores", "kind", "wall_s", "full_workload", "sample", "rows") if k in cb}
+    else:
+        c["cpu_baseline"] = cb
+    b = out.get("boundary") or {}
+    vcf = b.get("vcf_emit_native") or {}
+    c["regions_ms"] = {"kernel_only": _num((out.get("kernel_only") or {}).get("ms_per_step")), "resident_delivered": _num(out.get("ms_per_step")),
+                       "resident_delivered_slim": _num((out.get("resident_delivered_slim") or {}).get("ms_per_step")),
+                       "host_to_host": _num((h or {}).get("ms")), "host_to_host_slim": _num((h or {}).get("slim_ms")),
+                       "stage_wall_rows": _num(b.get("stage_wall_ms")), "stage_wall_lazy_rows": _num(b.get("stage_wall_lazy_ms")),
+                       "stage_wall_vcf_text": _num(vcf.get("stage_wall_vcf_ms")),
+                       "per_task_drop_in": _num((b.get("per_task_drop_in") or {}).get("ms"))}
+    if isinstance(out.get("kernel_us"), dict):
+        c["kernel_us"] = {k[2:] if k.startswith("k_") else k: v for k, v in out["kernel_us"].items() if isinstance(v, float) and v > 0.3 and not k.startswith("_")}
+    if isinstance(out.get("cpu_baseline_c_mt"), dict):
+        c["cpu_baseline_c_mt"] = {k: _num(out["cpu_baseline_c_mt"][k]) for k in ("value", "cores", "wall_s")}
+    if isinstance(out.get("speedups"), dict):
+        c["speedups"] = {k: _num(v, 1) for k, v in out["speedups"].items() if k != "note"}
+    c["parity_vs_oracle"] = out.get("parity_vs_oracle")
+    ow = out.get("other_workloads")
+    if isinstance(ow, dict):
+        c["other_workloads"] = {}
+        for name, o in ow.items():
+            if "error" in o:
+                c["other_workloads"][name] = {"error": o["error"][:120]}
+                continue
+            d = o["dominant_kernel"]
+            e = {"signatures": o["signatures"], "reads": o["reads"], "calls": o["calls"], "ms_per_step": _num(o["ms_per_step"]),
+                 "slim_ms_per_step": _num(o.get("slim_ms_per_step")), "kernel_only_ms": _num(o["kernel_only_ms_per_step"]), "host_to_host_ms": _num(o["one_shot_call_ms"]),
+                 "host_to_host_slim_ms": _num(o.get("one_shot_slim_ms")), "dominant": [d["kernel"], d["us"], d["frac"]],
+                 "pipeline_frac": o["pipeline"]["frac"], "parity_vs_oracle": o["parity_vs_oracle"], "c_mt_wall_ms": _num(o["cpu_baseline_c_mt"]["wall_s"] * 1e3, 2)}
+            if "cpu_baseline" in o:
+                e["py_pool_wall_s"] = _num(o["cpu_baseline"]["wall_s"], 2)
+            if isinstance(o.get("vcf_emit_native"), dict) and "stage_wall_vcf_ms" in o["vcf_emit_native"]:
+                e["stage_wall_vcf_ms"] = _num(o["vcf_emit_native"]["stage_wall_vcf_ms"], 2)
+            c["other_workloads"][name] = e
+    sh = out.get("sharded")
+    if isinstance(sh, dict):
+        c["sharded"] = {k: _num(sh.get(k)) for k in ("ranks", "signatures_total", "ms_per_step", "value", "scaling", "shard_merge_equals_unsharded", "pieces", "signature_load_max_over_mean", "error") if k in sh}
+        c["sharded"]["workload"] = (sh.get("workload") or "")[:60]
+        if sh.get("per_rank"):
+            c["sharded"]["per_rank_ms"] = [x["ms_per_step"] for x in sh["per_rank"]]
+    for k in ("per_rank", "shard_merge_equals_unsharded", "timed_region", "detail"):
+        if out.get(k) is not None:
+            c[k] = out[k]
+    for k in ("per_rank", "other_workloads", "kernel_us", "speedups"):            # (a last resort: never needed at N <= 8)
+        if len(json.dumps(c)) + 1 <= LINE_LIMIT:
+            break
+        c.pop(k, None)
+        c.setdefault("trimmed_to_fit_the_line", []).append(k)
+    return c
 
 
 def emit(out):
-    for k in BULKY:                                          # (never needed so far: the longest line is 13 KB)
-        if len(json.dumps(out)) + 1 <= LINE_LIMIT:
-            break
-        if isinstance(out, dict) and out.get(k) is not None:
-            out[k] = None
-            out.setdefault("trimmed_to_fit_the_line", []).append(k)
+    if not FULL_LINE and isinstance(out, dict) and "roofline" in out and "kernel_us" in out:
+        try:
+            d = os.path.join(ROOT, "gpurun_out")
+            os.makedirs(d, exist_ok=True)
+            path = os.path.join(d, "bench_detail_%s_n%s.json" % (str(out["config"]["workload"]).split(":")[0], out.get("n_gpus")))
+            with open(path, "w") as f:
+                json.dump(out, f)
+            out["detail"] = os.path.relpath(path, ROOT)
+        except OSError:
+            pass
+        sys.stderr.write("[bench detail] " + json.dumps(out) + "\n")
+        out = compact(out)
     line = (json.dumps(out) + "\n").encode()
     if _OUT_FD is None:
         sys.stdout.write(line.decode()); sys.stdout.flush()
@@ -723,7 +825,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-others", action="store_true", help="skip the compact cfg2 / cfg4 / cfg5 objects of the default N = 1 line")
     ap.add_argument("--cpu-procs", type=int, default=0)
+    ap.add_argument("--full", action="store_true", help="print every object on the one line (default: the compact line, full objects on stderr and in gpurun_out/)")
     a = ap.parse_args()
+    global FULL_LINE
+    FULL_LINE = a.full
     if "WORLD_SIZE" in os.environ or a.gpus == 1:
         quiet_stdout()
 
@@ -765,7 +870,7 @@ def main():
             ctx = engine.Context(local_rank % max(1, engine.device_count()))
         sharded_obj, dt, total_sig, store, params, wl_name, pstore, phb, tasks, hb = measure_sharded(ctx, dist, rank, world, a.workload, a.scale, a.steps, a.warmup)
         n_sig = int((phb.segments["sig_end"] - phb.segments["sig_begin"]).sum())
-        dt_k = None
+        dt_k = dt_slim = None
         t_upload = t_pin = None
     else:
         store, params, wl_name = make_workload(a.workload, a.scale, rank)
@@ -808,8 +913,9 @@ def main():
         t0 = time.perf_counter()
         ctx.upload(phb, per_sig=False)
         t_upload = time.perf_counter() - t0
-        dt, dt_k, _ = resident_loops(ctx, phb, a.steps, a.warmup, dist)
+        dt, dt_k, _, dt_slim = resident_loops(ctx, phb, a.steps, a.warmup, dist)
         total_sig = n_sig
+        dt_own = dt
         if dist is not None:
             import torch
             tt = torch.tensor([dt, dt_k], dtype=torch.float64)
@@ -818,6 +924,18 @@ def main():
             ts = torch.tensor([n_sig], dtype=torch.float64)
             dist.all_reduce(ts, op=dist.ReduceOp.SUM)
             total_sig = int(ts[0])
+    # which device every rank sat on (a SCALE record can then show N distinct GPUs) and what it measured by itself
+    try:
+        bus, ncu = engine.device_info(ctx.device)
+    except Exception:            # noqa: BLE001
+        bus, ncu = None, None
+    own_ms = (dt_own if not shard_mode else dt) / a.steps * 1e3
+    per_rank = [dict(rank=rank, device=ctx.device, devices_visible=engine.device_count(), pci_bus_id=bus, compute_units=ncu,
+                     signatures=n_sig, ms_per_step=round(own_ms, 5), value=round(n_sig / (own_ms * 1e-3)))]
+    if dist is not None:
+        gl = [None] * world
+        dist.all_gather_object(gl, per_rank[0])
+        per_rank = gl
     ms_reads_kept = None
     if not shard_mode and phb.r_start is not None:
         ctx.option(1, 1)
@@ -859,7 +977,12 @@ def main():
         per_kernel_cold = per_kernel_us(cold_acc / ncold, names)
 
         # ---------------- the boundary as a drop-in sees it
-        t_one = timed(lambda: ctx.cluster_batch(phb, reuse=True), 7)          # (caller-owned result arrays, allocated once)
+        t_one = timed(lambda: ctx.cluster_batch(phb, reuse=True), 9)          # (caller-owned result arrays, allocated once)
+        gate_first, bytes_not_sent = ctx.lazy_info()
+        t_one_slim = timed(lambda: ctx.cluster_batch(phb, reuse=True, **SLIM), 9) if phb.a.dtype == np.int32 else None
+        os.environ["CSV_NO_LAZY"] = "1"                                       # the whole columns in one piece (r04's form)
+        t_one_bulk = timed(lambda: ctx.cluster_batch(phb, reuse=True), 5)
+        del os.environ["CSV_NO_LAZY"]
         t_one_pageable = timed(lambda: ctx.cluster_batch(hb, reuse=True), 5)
         r2 = ctx.cluster_batch(phb)
         t_rows = timed(lambda: rows_mod.rows_by_segment(pstore, phb.segments, r2), 3)
@@ -909,6 +1032,34 @@ def main():
             parity = all(np.array_equal(g[k], w[k]) for k in PARITY_FIELDS)
         stage_ms = float(np.median(t_stage)) * 1e3
         one_ms = float(np.min(t_one)) * 1e3
+        one_slim_ms = None if t_one_slim is None else float(np.min(t_one_slim)) * 1e3
+        one_bulk_ms = float(np.min(t_one_bulk)) * 1e3
+        # what crosses PCIe in the host -> host call: the bulk copies (all the columns, or the position column alone in the
+        # gate-first form), the rows the device then reads out of the caller's columns (useful bytes: 12 B per signature of a
+        # gated cluster + 4 B for INS; the link moves whole 64-byte lines of them), the reads table, and the result coming back
+        down_full = 76 * r2.n_calls + 4 * r2.n_support + 8
+        down_slim = 4 * (4 + len(SLIM["fields"])) * r2.n_calls
+        refine_alg = sum(kbytes.get(k, 0) for k in ("k_refine_indel_wave", "k_refine_wave", "k_refine_mid", "k_refine_block"))
+        fetched_useful = (refine_alg - (4 if phb.a.dtype == np.int32 else 0) * units.get("sig_in_gated_clusters", 0)) if gate_first else 0
+        up_bulk = h2d_bytes - (bytes_not_sent if gate_first else 0)
+
+        def pcie(ms, down):
+            moved = up_bulk + fetched_useful + down
+            return {"bytes_up_bulk": int(up_bulk), "bytes_up_fetched_useful": int(fetched_useful), "bytes_down": int(down), "ms": ms,
+                    "achieved_gbs": moved / (ms * 1e-3) / 1e9, "frac_of_63": moved / (ms * 1e-3) / 1e9 / PCIE_PEAK_GBS}
+        host_to_host = {
+            "region": "csv_cluster_batch: page-locked host columns -> kernels -> result SoA in page-locked host memory (SURVEY 8d region (ii); the "
+                      "reference's timed region MAIN:1113-1199 minus the rows)",
+            "gate_first": bool(gate_first),
+            "ms": one_ms, "value": n_sig / (one_ms * 1e-3), "ms_all": [round(x * 1e3, 3) for x in t_one],
+            "slim_ms": one_slim_ms, "slim_value": None if one_slim_ms is None else n_sig / (one_slim_ms * 1e-3),
+            "bulk_upload_ms": one_bulk_ms, "pageable_columns_ms": float(np.min(t_one_pageable)) * 1e3,
+            "pcie": pcie(one_ms, down_full), "pcie_slim": None if one_slim_ms is None else pcie(one_slim_ms, down_slim),
+            "bytes_all_columns": int(h2d_bytes),
+            "note": "gate-first: only the position column (+ the reads table) is copied in bulk; the device reads b / read_id / aux of the clusters "
+                    "that pass the size gate out of the caller's columns (whole 64-byte lines cross the link: bytes_up_fetched_useful is the "
+                    "rows' own bytes).  slim = CSV_OUT_NO_SUPPORT_LIST | CSV_OUT_COORD_I32, fields %s: what the VCF emitter reads without "
+                    "--report_readid" % (SLIM["fields"],)}
         ko_ms = ms_kernel_only if ms_kernel_only is not None else None
         other_out = {}
         for name, cpu_o in others.items():
@@ -929,7 +1080,7 @@ def main():
             "kernel_only": None if ko_ms is None else {"ms_per_step": ko_ms, "value": total_sig / (ko_ms * 1e-3),
                                                        "note": "the launch sequence alone, results left in HBM (the region r01-r03 reported as value)"},
             "ms_per_step_reads_order_kept": ms_reads_kept,
-            "higher_is_better": True, "scaling": "strong" if shard_mode else "weak", "vs_baseline": None, "dtype": "int64+f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if shard_mode else "weak", "vs_baseline": None, "dtype": "int32 columns, int64+f64 arithmetic" if phb.a.dtype == np.int32 else "int64+f64", "data": "synthetic",
             "config": {"workload": wl_name, "signatures_per_gpu": n_sig, "signatures_total": total_sig, "segments": len(tasks),
                        "preset": "ONT" if a.workload in ("cfg2", "cfg3", "cfg5") else "HiFi",
                        "genotype": bool(params.genotype), "mode": a.mode, "columns": "int32 positions / lengths (SigStore.pinned())",
@@ -958,21 +1109,21 @@ def main():
             # speed-ups, each over ONE named pair of regions (r03's speedup_vs_cpu_baseline divided the kernel-only loop by a Python pool)
             "speedups": {
                 "stage_wall_vs_reference_model": (cpu["wall_s"] * 1e3 / stage_ms) if (cpu and cpu.get("full_workload")) else None,
-                "step_vs_reference_model": (cpu["wall_s"] * 1e3 / ms_per_step) if (cpu and cpu.get("full_workload") and world == 1) else None,
-                "one_shot_vs_c_all_threads": (cpu_c_mt["wall_s"] * 1e3 / one_ms) if cpu_c_mt else None,
-                "step_vs_c_all_threads": (cpu_c_mt["wall_s"] * 1e3 / ms_per_step) if (cpu_c_mt and world == 1) else None,
+                "host_to_host_vs_c_all_threads": (cpu_c_mt["wall_s"] * 1e3 / one_ms) if cpu_c_mt else None,
+                "resident_step_vs_c_all_threads": (cpu_c_mt["wall_s"] * 1e3 / ms_per_step) if (cpu_c_mt and world == 1) else None,
                 "note": "reference_model = oracle/py_restatement.py in a fork Pool at all host cores (cuteSV's execution model, the north_star target); "
                         "c_all_threads = the C oracle, one (chr,type) task per thread; stage_wall = page-locked columns -> the reference's row lists"},
+            "host_to_host": host_to_host,
+            "resident_delivered_slim": None if dt_slim is None else {"ms_per_step": dt_slim / a.steps * 1e3, "value": n_sig * a.steps / dt_slim,
+                                                                     "note": "as value, with the slim result (no support lists, int32 coordinates)"},
             "boundary": {"pin_ms": None if t_pin is None else t_pin * 1e3,
-                         "one_shot_call_ms": one_ms, "one_shot_call_ms_all": [round(x * 1e3, 3) for x in t_one],
-                         "one_shot_pageable_ms": float(np.min(t_one_pageable)) * 1e3,
-                         "h2d_bytes": h2d_bytes, "pcie_gbs": h2d_bytes / (one_ms * 1e-3) / 1e9, "pcie_frac_of_gen5_x16": h2d_bytes / (one_ms * 1e-3) / 1e9 / PCIE_PEAK_GBS,
+                         "one_shot_call_ms": one_ms,
                          "rows_ms": float(np.median(t_rows)) * 1e3, "rows": n_rows,
                          "stage_wall_ms": stage_ms, "stage_wall_ms_all": [round(x * 1e3, 3) for x in t_stage],
                          "vcf_emit_native": t_vcf, "per_task_drop_in": t_task,
-                         "pcie_inclusive_signatures_per_s": n_sig / (one_ms * 1e-3),
                          "stage_signatures_per_s": n_sig / (stage_ms * 1e-3)},
             "other_workloads": other_out or None,
+            "per_rank": per_rank,
             "sharded": sharded_obj if not shard_mode else None,
             "parity_vs_oracle": parity, "shard_merge_equals_unsharded": (sharded_obj or {}).get("shard_merge_equals_unsharded") if shard_mode else None,
         }

@@ -17,6 +17,7 @@ SYMBOLS = [
     ("csv_measure_copy_bandwidth", C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_double)]),
     ("csv_cache_flush", C.c_int, [C.c_void_p, C.c_int64]),
     ("csv_device_count", C.c_int, [C.POINTER(C.c_int)]),
+    ("csv_device_info", C.c_int, [C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int)]),
     ("csv_ctx_create", C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     ("csv_ctx_destroy", None, [C.c_void_p]),
     ("csv_last_error", C.c_char_p, [C.c_void_p]),

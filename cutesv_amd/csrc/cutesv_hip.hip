@@ -301,6 +301,15 @@ int csv_device_count(int* n)
     return e == hipSuccess ? CSV_OK : CSV_E_HIP;
 }
 
+int csv_device_info(int device_id, char* pci_bus_id, int cap, int* n_cu)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device_id < 0 || device_id >= n) return CSV_E_HIP;
+    if (pci_bus_id && cap > 0) { pci_bus_id[0] = 0; if (hipDeviceGetPCIBusId(pci_bus_id, cap, device_id) != hipSuccess) return CSV_E_HIP; }
+    if (n_cu && hipDeviceGetAttribute(n_cu, hipDeviceAttributeMultiprocessorCount, device_id) != hipSuccess) return CSV_E_HIP;
+    return CSV_OK;
+}
+
 int32_t csv_gl_index(int64_t c0, int64_t c1)
 {
     if (c0 == 3 && c1 == 1) return 101 * 101;

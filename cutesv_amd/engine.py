@@ -18,6 +18,16 @@ def device_count():
     return n.value
 
 
+def device_info(device=0):
+    """(PCI bus id, compute units) of a device: csv_device_info"""
+    buf = C.create_string_buffer(64)
+    ncu = C.c_int(0)
+    rc = lib().csv_device_info(int(device), buf, 64, C.byref(ncu))
+    if rc != _abi.OK:
+        raise CsvError(rc, "csv_device_info(%d) failed" % device)
+    return buf.value.decode(), ncu.value
+
+
 class Context:
     def __init__(self, device=0):
         self._h = C.c_void_p()

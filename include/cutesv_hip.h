@@ -215,6 +215,9 @@ int         csv_abi_version(void);
  * check its own mirror of the layouts at load time. */
 int         csv_struct_size(int which);
 int         csv_device_count(int* n);
+/* (ABI v7) PCI bus id of a device ("0000:c1:00.0") and its compute-unit count: what a multi-process launcher logs per rank to show
+ * that N ranks sit on N distinct GPUs (the reference's pool workers have no placement: MAIN:1113).  Returns CSV_OK. */
+int         csv_device_info(int device_id, char* pci_bus_id, int cap, int* n_cu);
 int         csv_ctx_create(int device_id, csv_ctx** out);
 void        csv_ctx_destroy(csv_ctx* ctx);
 const char* csv_last_error(const csv_ctx* ctx);

@@ -6,7 +6,7 @@ WL=${WL:-cfg3}
 for rep in 1 2; do
 for spec in "$@"; do
   label=${spec%%=*}; envs=${spec#*=}
-  line=$(env $envs timeout 300 python bench.py --workload $WL --steps 200 --warmup 10 --no-cpu-baseline 2>/dev/null | tail -1)
+  line=$(env $envs timeout 300 python bench.py --workload $WL --steps 200 --warmup 10 --no-cpu-baseline --full 2>/dev/null | tail -1)
   echo "$line" | python -c "
 import sys, json
 d = json.loads(sys.stdin.read()); k = d['kernel_us']

@@ -11,7 +11,7 @@ if [ "$MODE" = tests ]; then
 fi
 for wl in $WLS; do
   extra=""; [ $wl != cfg3 ] && extra="--no-cpu-baseline"
-  timeout -k 10 600 python bench.py --workload $wl $extra > $O/bench_$wl.json 2> $O/bench_$wl.err
+  timeout -k 10 600 python bench.py --full --workload $wl $extra > $O/bench_$wl.json 2> $O/bench_$wl.err
   echo "bench $wl rc=$?"; tail -c 1500 $O/bench_$wl.err
   python - $O/bench_$wl.json <<'PY'
 import json, sys

@@ -14,8 +14,8 @@ for wl in $WLS; do
   rm -rf $P/${TAG}_${wl}_kt $P/${TAG}_${wl}_fetch $P/${TAG}_${wl}_write
 done
 for wl in $WLS cfg2; do
-  if [ $wl = cfg3 ]; then timeout 900 python bench.py --workload $wl > $F/${TAG}_bench_${wl}.json 2> $F/${TAG}_bench_${wl}.err
-  else timeout 900 python bench.py --workload $wl --steps 50 --warmup 5 > $F/${TAG}_bench_${wl}.json 2> $F/${TAG}_bench_${wl}.err; fi
+  if [ $wl = cfg3 ]; then timeout 900 python bench.py --full --workload $wl > $F/${TAG}_bench_${wl}.json 2> $F/${TAG}_bench_${wl}.err
+  else timeout 900 python bench.py --full --workload $wl --steps 50 --warmup 5 > $F/${TAG}_bench_${wl}.json 2> $F/${TAG}_bench_${wl}.err; fi
   tail -c 300 $F/${TAG}_bench_${wl}.json
 done
 ls -la $F

@@ -9,8 +9,8 @@ for wl in cfg3 cfg5; do scripts/profile_insts.sh $wl $TAG > $F/${TAG}_${wl}_inst
 scripts/refresh_profiles.sh $TAG "cfg3 cfg4 cfg5" > $F/${TAG}_refresh.log 2>&1
 timeout 300 python bench.py --workload rebuild > $F/${TAG}_bench_rebuild.json 2>/dev/null
 timeout 300 python bench.py --workload extract > $F/${TAG}_bench_extract.json 2>/dev/null
-timeout 600 python bench.py --gpus 8 --steps 10 --warmup 2 > $F/${TAG}_bench_cfg3_replica_plus_cfg4_sharded_8ranks_one_device.json 2>/dev/null; echo "8 ranks rc=$?"
-timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 5 --warmup 2 2>/dev/null | tail -1 > $F/${TAG}_bench_torchrun_2ranks_one_device.json; echo "torchrun rc=$?"
+timeout 600 python bench.py --full --gpus 8 --steps 10 --warmup 2 > $F/${TAG}_bench_cfg3_replica_plus_cfg4_sharded_8ranks_one_device.json 2>/dev/null; echo "8 ranks rc=$?"
+timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --full --gpus 2 --steps 5 --warmup 2 2>/dev/null | tail -1 > $F/${TAG}_bench_torchrun_2ranks_one_device.json; echo "torchrun rc=$?"
 timeout 700 python scripts/stress_gpu.py ${STRESS_N:-30000} 1200000 > $F/${TAG}_stress.log 2>&1; tail -2 $F/${TAG}_stress.log
 timeout 300 python scripts/stress_gpu.py ${STRESS_BIG:-3000} 1300000 big > $F/${TAG}_stress_big.log 2>&1; tail -2 $F/${TAG}_stress_big.log
 ls $F | wc -l
