@@ -351,7 +351,8 @@ def vcf_leg(ctx, pstore, params, tasks):
             tv.append(time.perf_counter() - t0)
         n_rec, n_bytes = int(np.count_nonzero(np.frombuffer(text, np.uint8) == 10)), len(text)      # (the view is this thread's buffer: read it now)
         # pinned columns -> VCF text: the boundary call + the native emitter, no Python rows in between
-        ts = timed(lambda: vcf_mod.emit_records(pstore, hb2.segments, ctx.cluster_batch(hb2, reuse=True), ref, **kw), 5)
+        slim = SLIM if hb2.a.dtype == np.int32 else {}      # (the emitter reads no support list unless --report_readid is on)
+        ts = timed(lambda: vcf_mod.emit_records(pstore, hb2.segments, ctx.cluster_batch(hb2, reuse=True, **slim), ref, **kw), 5)
         tn = []
         for _ in range(3):
             t0 = time.perf_counter()
@@ -987,6 +988,8 @@ def main():
         r2 = ctx.cluster_batch(phb)
         t_rows = timed(lambda: rows_mod.rows_by_segment(pstore, phb.segments, r2), 3)
         t_stage = timed(lambda: resolve.cluster_stage(pstore, params, tasks=tasks, ctx=ctx), 5)
+        # the same stage handing out lazy row sequences (rows.LazyRows: a row's strings are created when somebody reads it)
+        t_stage_lazy = timed(lambda: resolve.cluster_stage(pstore, params, tasks=tasks, ctx=ctx, lazy=True), 7)
         n_rows = sum(len(v) for v in resolve.cluster_stage(pstore, params, tasks=tasks, ctx=ctx).values())
         # (bytes per signature / read as the ABI defines the columns; positions and lengths travel as int32 when the store
         # keeps narrow twins - CSV_IN_SIG_I32 / CSV_IN_READS_I32)
@@ -1120,6 +1123,7 @@ def main():
                          "one_shot_call_ms": one_ms,
                          "rows_ms": float(np.median(t_rows)) * 1e3, "rows": n_rows,
                          "stage_wall_ms": stage_ms, "stage_wall_ms_all": [round(x * 1e3, 3) for x in t_stage],
+                         "stage_wall_lazy_ms": float(np.median(t_stage_lazy)) * 1e3,
                          "vcf_emit_native": t_vcf, "per_task_drop_in": t_task,
                          "stage_signatures_per_s": n_sig / (stage_ms * 1e-3)},
             "other_workloads": other_out or None,

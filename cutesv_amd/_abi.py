@@ -215,6 +215,19 @@ class HostResult:
         self.c = BatchOut(cap_calls=self.cap_calls, cap_support=self.cap_support,
                           flags=(OUT_NO_SUPPORT_LIST if no_support else 0) | (OUT_COORD_I32 if coord32 else 0), **kw)
 
+    def snapshot(self):
+        """a private copy cut to the produced sizes (ordinary memory): what outlives the recycled, page-locked arrays of a
+        reuse=True call (rows.LazyRows keeps one)"""
+        out = HostResult(self.n_sig, max(1, self.n_calls), max(1, self.n_support), per_sig=False, n_seg=max(1, self.n_seg_used),
+                         narrow_support=self.narrow_support, no_support=self.no_support, coord32=self.coord32, fields=self.fields)
+        t = self.trimmed()
+        for name, _, cap in _OUT_ARRAYS:
+            if cap != "sig" and out.arrays.get(name) is not None and t.get(name) is not None:
+                out.arrays[name][:len(t[name])] = t[name]
+        out.c.n_calls, out.c.n_support, out.c.n_clusters = self.n_calls, self.n_support, self.n_clusters
+        out.n_seg_used = self.n_seg_used
+        return out
+
     def shape_key(self):
         """what a recycled result must agree on with a request besides its capacities"""
         return (self.per_sig, self.no_support, self.coord32, self.fields, self.narrow_support)

@@ -327,6 +327,34 @@ PyObject* build(PyObject*, PyObject* arg)
     return S.rows;
 }
 
+// build_some(addr_of_csv_rows_in, int64 call indices) -> the rows of exactly those calls, in the order given: what a lazy row
+// sequence (cutesv_amd/rows.py LazyRows) materialises when a consumer indexes or iterates it
+PyObject* build_some(PyObject*, PyObject* args)
+{
+    PyObject* addr;
+    Py_buffer view;
+    if (!PyArg_ParseTuple(args, "Oy*", &addr, &view)) return nullptr;
+    const csv_rows_in* in = (const csv_rows_in*)PyLong_AsVoidPtr(addr);
+    if (!in || !in->res) { PyBuffer_Release(&view); if (!PyErr_Occurred()) PyErr_SetString(PyExc_ValueError, "null csv_rows_in"); return nullptr; }
+    const int64_t n = (int64_t)(view.len / 8), nc = in->res->n_calls;
+    const int64_t* idx = (const int64_t*)view.buf;
+    const int gc_was_on = PyGC_Disable();
+    PySink S(n);
+    int rc = S.ok ? CSV_OK : CSV_E_NOMEM;
+    for (int64_t i = 0; i < n && rc == CSV_OK && S.ok; i++) {
+        if (idx[i] < 0 || idx[i] >= nc) { rc = CSV_E_INVALID; break; }
+        rc = csv_rows::layout(in, S, idx[i], idx[i] + 1);
+    }
+    if (gc_was_on) PyGC_Enable();
+    PyBuffer_Release(&view);
+    if (rc != CSV_OK || !S.ok || S.r != n) {
+        Py_XDECREF(S.rows);
+        if (!PyErr_Occurred()) PyErr_Format(PyExc_RuntimeError, "row builder failed (code %d)", rc ? rc : CSV_E_NOMEM);
+        return nullptr;
+    }
+    return S.rows;
+}
+
 // split(buffer, n_rows) -> list of n_rows lists of str from csv_rows_emit's text (rows end with '\n', fields are
 // separated by '\t'): the generic way in for hosts that only have the blob
 PyObject* split(PyObject*, PyObject* args)
@@ -364,6 +392,7 @@ PyObject* split(PyObject*, PyObject* args)
 }
 
 PyMethodDef methods[] = {{"build", build, METH_O, "build(address of a csv_rows_in) -> list[list[str]]"},
+                         {"build_some", build_some, METH_VARARGS, "build_some(address of a csv_rows_in, int64 call indices) -> list[list[str]]"},
                          {"split", split, METH_VARARGS, "split(buffer, n_rows) -> list[list[str]]"},
                          {nullptr, nullptr, 0, nullptr}};
 PyModuleDef moddef = {PyModuleDef_HEAD_INIT, "_rows_native", "row builder of cutesv_amd", -1, methods, nullptr, nullptr, nullptr, nullptr};

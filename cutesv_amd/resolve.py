@@ -115,16 +115,48 @@ def run_batch(store, segments, tasks, ctx=None):
     return {t: per_seg[k] for k, t in enumerate(tasks)}
 
 
-def cluster_stage(store, params, tasks=None, ctx=None):
-    """The whole phase 3 for the tasks of `store` this process owns -> {chr: rows}."""
+def cluster_stage(store, params, tasks=None, ctx=None, lazy=False):
+    """The whole phase 3 for the tasks of `store` this process owns -> {chr: rows}.
+    lazy=True: the per-chromosome values are rows.LazyRows - list-like (extend / sort by int(row[2]) / iterate / index, what
+    main_ctrl and generate_output do with them: main script :1191-1197, GT:242-252) but backed by the structure of arrays: a
+    row's strings exist only once somebody reads the row, and a consumer that takes the arrays themselves
+    (`vcf.emit_stage(results, ...)`) never creates one (a 30x genome: ~11 ms of CPython str creation for 25 k rows)."""
     tasks = tasks or store.tasks()
     segs = [store.segment(t, ch, params) for t, ch in tasks]
+    if lazy:
+        return _cluster_stage_lazy(store, segs, tasks, ctx)
     by_task = run_batch(store, segs, tasks, ctx)
     results = {}
     for t in TYPES:                                   # main script :1191-1197 extends in submission order
         for (tt, ch) in tasks:
             if tt == t:
                 results.setdefault(ch, []).extend(by_task[(tt, ch)])
+    return results
+
+
+def _batch_of(store, segments):
+    import numpy as np
+    segs = np.array(segments, dtype=_abi.SEGMENT_DTYPE)
+    kw = {}
+    if len(segs) and segs["genotype"].any() and store.reads_off is not None:
+        kw = dict(reads_off=store.reads_off, r_start=store.r_start, r_end=store.r_end, r_primary=store.r_primary, r_id=store.r_id)
+        if ((segs["svtype"] == _abi.TRA) & (segs["genotype"] != 0)).any():
+            kw["contig_len"] = store.contig_len
+    return _abi.HostBatch(segs, store.a, store.b, store.read_id, store.aux, n_chrom=len(store.chroms), **kw)
+
+
+def _cluster_stage_lazy(store, segs, tasks, ctx):
+    import numpy as np
+    ctx = ctx or context()
+    hb = _batch_of(store, segs)
+    res = ctx.cluster_batch(hb, reuse=True)
+    backing, ranges = rows_mod.lazy_rows_by_segment(store, hb.segments, res)      # (a private copy of the arrays: `res` is recycled)
+    results = {}
+    for t in TYPES:                                   # main script :1191-1197 extends in submission order
+        for k, (tt, ch) in enumerate(tasks):
+            if tt == t:
+                lo, hi = ranges[k]
+                results.setdefault(ch, rows_mod.LazyRows()).extend(rows_mod.LazyRows(backing, np.arange(lo, hi, dtype=np.int64)))
     return results
 
 

@@ -141,3 +141,14 @@ def emit_records(store, segments, res, reference, min_size=30, max_size=100000, 
         raw = buf[:need.value].tobytes()
         return (raw if as_bytes else raw.decode()), svid
     raise RuntimeError("csv_vcf_emit: capacity retry failed")
+
+
+def emit_stage(results, reference, **kw):
+    """VCF body text of a `resolve.cluster_stage(..., lazy=True)` result ({chr: rows.LazyRows}): the native emitter reads the
+    structure of arrays the lazy rows are backed by - no row strings are created on the way (GT:242-467, main script
+    :1208-1237).  Keyword arguments as emit_records."""
+    backs = {id(b): b for b in (v.backing() if hasattr(v, "backing") else None for v in results.values()) if b is not None}
+    if len(backs) != 1 or any(not hasattr(v, "backing") or v.backing() is None for v in results.values()):
+        raise ValueError("emit_stage needs the untouched result of ONE cluster_stage(lazy=True) call")
+    b = next(iter(backs.values()))
+    return emit_records(b.store, b.segments, b.res, reference, **kw)

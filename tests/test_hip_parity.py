@@ -1300,3 +1300,29 @@ def test_download_into_checks_the_batch_shape(ctx):
     ctx.run()
     with pytest.raises(ValueError):
         ctx.download(per_sig=True, into=res)
+
+
+def test_lazy_stage_equals_the_row_lists(ctx):
+    """resolve.cluster_stage(lazy=True) on the HIP path: the same rows as the materialised stage, and the native emitter gives the
+    same VCF text from the lazy objects' arrays (vcf.emit_stage) as from the result itself"""
+    from cutesv_amd import resolve, vcf
+    st = synth.small_mixed(seed=52, genotype=True).pinned()
+    p = Params.ont(genotype=True)
+    eager = resolve.cluster_stage(st, p, ctx=ctx)
+    lazy = resolve.cluster_stage(st, p, ctx=ctx, lazy=True)
+    again = resolve.cluster_stage(st, p, ctx=ctx, lazy=True)          # (the first result's private arrays survive the recycled ones)
+    assert set(lazy) == set(eager) and sum(len(v) for v in eager.values()) > 100
+    for ch in eager:
+        assert lazy[ch] == eager[ch] and again[ch] == eager[ch]
+        a = list(eager[ch]); a.sort(key=lambda x: int(x[2]))
+        lazy[ch].sort(key=lambda x: int(x[2]))
+        assert lazy[ch] == a and lazy[ch].backing() is not None
+    ref = {c: synth.reference_sequence(3_200_000, seed=9 + i) for i, c in enumerate(st.chroms)}
+    hb = st.host_batch(st.tasks(), p)
+    kw = dict(min_size=p.min_size, max_size=p.max_size, genotype=True)
+    want, _ = vcf.emit_records(st, hb.segments, ctx.cluster_batch(hb), ref, **kw)
+    got, _ = vcf.emit_stage(again, ref, **kw)
+    assert got == want and got.count("\n") > 50
+    slim, _ = vcf.emit_records(st, hb.segments, ctx.cluster_batch(hb, reuse=True, no_support=True, coord32=True,
+                                                                  fields=("call_aux", "cipos", "cilen", "seq_pick", "dr", "gl_idx")), ref, **kw)
+    assert slim == want

@@ -1,8 +1,11 @@
 """CPU test: the native VCF record emitter (cutesv_amd/csrc/vcf_emit.cpp, no GPU work) against the lines the
 reference's generate_output + main_ctrl numbering produce for the same calls (tests/golden/vcf_lines.json.gz)."""
-import numpy as np
+import os
 
-from cutesv_amd import synth, vcf
+import numpy as np
+import pytest
+
+from cutesv_amd import synth, vcf, rows as rows_mod
 from cutesv_amd.columns import Params
 from oracle import oracle
 from helpers import load_json, store_from_json
@@ -143,3 +146,151 @@ def test_vcf_text_from_a_mapped_fasta_is_the_text_from_strings(tmp_path):
         if done >= 8:
             break
     assert done >= 4
+
+
+# ---------------------------------------------------------------------------------------------- lazy rows (rows.LazyRows)
+class _OracleCtx:
+    """stands in for engine.Context where only csv_cluster_batch's result matters (the row side is host code)"""
+
+    def cluster_batch(self, hb, reuse=False, **kw):
+        return oracle.cluster_batch(hb, per_sig=False)
+
+
+def _lazy_and_eager(st, p, tasks):
+    from cutesv_amd import resolve
+    from cutesv_amd.columns import TYPES
+    lazy = resolve.cluster_stage(st, p, tasks=tasks, ctx=_OracleCtx(), lazy=True)
+    hb = st.host_batch(tasks, p)
+    per_seg = rows_mod.rows_by_segment(st, hb.segments, oracle.cluster_batch(hb, per_sig=False))
+    eager = {}
+    for t in TYPES:
+        for k, (tt, ch) in enumerate(tasks):
+            if tt == t:
+                eager.setdefault(ch, []).extend(per_seg[k])
+    return lazy, eager
+
+
+def test_lazy_rows_are_the_row_lists():
+    """cluster_stage(lazy=True) hands out list-like objects backed by the structure of arrays: same rows, same order, and
+    everything main_ctrl / generate_output do with a task's rows (extend, sort by int(row[2]), iterate, index: main script
+    :1191-1197, GT:242-252) gives what the plain lists give - the str objects just do not exist until somebody looks"""
+    from cutesv_amd.rows import LazyRows
+    n_checked = 0
+    for case in load_json("small_cases.json.gz"):
+        st = store_from_json(case["store"])
+        p = Params(**case["params"])
+        tasks = [(t, c) for t, c, _ in case["rows"]]
+        lazy, eager = _lazy_and_eager(st, p, tasks)
+        assert set(lazy) == set(eager)
+        for ch in eager:
+            lz, ea = lazy[ch], eager[ch]
+            assert isinstance(lz, LazyRows) and len(lz) == len(ea) and lz.backing() is not None
+            assert lz == ea and list(lz) == ea and lz.materialise() == ea
+            if ea:
+                assert lz[0] == ea[0] and lz[-1] == ea[-1] and lz[len(ea) // 2] == ea[len(ea) // 2] and lz[1:3] == ea[1:3]
+                with pytest.raises(IndexError):
+                    lz[len(ea)]
+            # generate_output's sort: stable, by int(row[2]); from the bp1 column, no strings
+            a, b = LazyRows(), list(ea)
+            a.extend(lz)
+            a.sort(key=lambda x: int(x[2])); b.sort(key=lambda x: int(x[2]))
+            assert a.backing() is lz.backing() and a == b
+            a.sort(key=lambda x: int(x[2]), reverse=True); b.sort(key=lambda x: int(x[2]), reverse=True)
+            assert a == b
+            # any other key: the rows are materialised and sorted like a list
+            a.sort(key=lambda x: (x[1], len(x))); b.sort(key=lambda x: (x[1], len(x)))
+            assert a == b and a.backing() is None
+            # mixing with plain rows (tra_bam.genotype_rows returns lists)
+            c, d = LazyRows(), []
+            c.extend(lz); d.extend(ea)
+            extra = [["9", "DEL", "5", "-40", "3", "-1,1", "-2,2", ".", "./.", ".,.,.", ".", ".", "r1,r2"]]
+            c.extend(extra); d.extend(extra)
+            c.extend(lz); d.extend(ea)
+            assert c == d and len(c) == len(d)
+            c.sort(key=lambda x: int(x[2])); d.sort(key=lambda x: int(x[2]))
+            assert c == d
+            n_checked += len(ea)
+    assert n_checked > 500
+
+
+def test_native_emitter_reads_the_lazy_stage_without_rows():
+    small = {c["name"]: c for c in load_json("small_cases.json.gz")}
+    for g in load_json("vcf_lines.json.gz")[:9]:
+        case = small[g["case"]]
+        st = store_from_json(case["store"])
+        p = Params(**case["params"])
+        ref = {c: synth.reference_sequence(g["ref_len"], seed=g["ref_seed0"] + i) for i, c in enumerate(st.chroms)}
+        tasks = [(t, c) for t, c, _ in case["rows"]]
+        from cutesv_amd import resolve
+        lazy = resolve.cluster_stage(st, p, tasks=tasks, ctx=_OracleCtx(), lazy=True)
+        text, svid = vcf.emit_stage(lazy, ref, min_size=p.min_size, max_size=p.max_size, genotype=p.genotype, **g["flags"])
+        assert _canon(text) == _canon(g["text"]), "%s %s" % (g["case"], g["flags"])
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/src/cuteSV"), reason="the reference tree is only present in the build container")
+def test_reference_generate_output_consumes_lazy_rows(tmp_path):
+    """the reference's OWN generate_output (cuteSV_genotype.py:242-467), imported from /root/reference with the pysam stub the
+    golden generator uses, run on LazyRows objects: sorts them, iterates them, indexes their rows - and writes the text the
+    golden fixture holds for plain row lists"""
+    import argparse
+    import pickle
+    import sys
+    import types
+    seqs = {}
+
+    class _FastaFile:
+        def __init__(self, path):
+            pass
+
+        def fetch(self, chrom):
+            return seqs[chrom]
+
+        def close(self):
+            pass
+    stub = types.ModuleType("pysam")
+    stub.FastaFile = _FastaFile
+    saved = sys.modules.get("pysam")
+    sys.modules["pysam"] = stub
+    sys.path.insert(0, "/root/reference/src")
+    try:
+        for m in [k for k in sys.modules if k.startswith("cuteSV")]:
+            del sys.modules[m]
+        import cuteSV.cuteSV_genotype as R_GT
+        small = {c["name"]: c for c in load_json("small_cases.json.gz")}
+        from cutesv_amd import resolve
+        n = 0
+        for g in load_json("vcf_lines.json.gz"):
+            case = small[g["case"]]
+            st = store_from_json(case["store"])
+            p = Params(**case["params"])
+            seqs.clear()
+            seqs.update({c: synth.reference_sequence(g["ref_len"], seed=g["ref_seed0"] + i) for i, c in enumerate(st.chroms)})
+            tasks = [(t, c) for t, c, _ in case["rows"]]
+            results = resolve.cluster_stage(st, p, tasks=tasks, ctx=_OracleCtx(), lazy=True)
+            args = argparse.Namespace(genotype=p.genotype, max_size=p.max_size, min_size=p.min_size, **g["flags"])
+            d = str(tmp_path / ("w%d" % n)) + "/"
+            os.makedirs(d + "results")
+            svid = {"INS": 0, "DEL": 0, "BND": 0, "DUP": 0, "INV": 0}
+            text = []
+            for c in sorted(results):
+                R_GT.generate_output(args, results[c], "ref.fa", c, d)
+            for c in sorted(results):
+                with open("%sresults/%s.pickle" % (d, c), "rb") as f:
+                    while True:
+                        try:
+                            for svtype, line in pickle.load(f):
+                                text.append(line.replace("<SVID>", str(svid[svtype])))
+                                svid[svtype] += 1
+                        except EOFError:
+                            break
+            assert _canon("".join(text)) == _canon(g["text"]), "%s %s" % (g["case"], g["flags"])
+            n += 1
+        assert n >= 21
+    finally:
+        sys.path.remove("/root/reference/src")
+        for m in [k for k in sys.modules if k.startswith("cuteSV")]:
+            del sys.modules[m]
+        if saved is not None:
+            sys.modules["pysam"] = saved
+        else:
+            del sys.modules["pysam"]
