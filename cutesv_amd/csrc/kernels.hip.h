@@ -619,10 +619,8 @@ __device__ __forceinline__ int4 chain_gate_of(const i64* woff, const int4* seg_g
     return seg_gate[lo];
 }
 
-template <bool NARROW> __global__ __launch_bounds__(256, 6) void k_chain_count(DevBatch B)
+template <bool NARROW> __global__ __launch_bounds__(256, NARROW ? 6 : 5) void k_chain_count(DevBatch B)
 {
-    // first kernel of a run: nothing in this kernel reads the counters, every later kernel is stream-ordered behind it
-    if (blockIdx.x == 0 && threadIdx.x < (int)(sizeof(DevCounters) / 4)) ((int*)B.cnt)[threadIdx.x] = 0;
     // flags / (0,0)-predecessor marks of the tile, one bit per signature (word w = signatures 64 w .. 64 w + 63, also addressed
     // as bytes of 8 signatures); [32] = the row after the tile
     __shared__ __attribute__((aligned(16))) u64 s_F[CT_WORDS + 2], s_Z[CT_WORDS + 2];
@@ -789,6 +787,10 @@ template <bool NARROW> __global__ __launch_bounds__(256, 6) void k_chain_count(D
             B.tile_items[(i64)blockIdx.x * TI_STRIDE + ji] = make_int4((int)tile0 + pos, m, kseg | (g.z << 24) | ((fl >> 1) << 28), ci);
         }
     }
+    // first kernel of a run: nothing in this kernel reads the counters, every later kernel is stream-ordered behind it.  (At the
+    // END: a store in front of the loads made every load of the kernel "possibly clobbered", so the tile records - one address
+    // per workgroup - came through vector loads into 32 VGPRs instead of scalar loads into SGPRs.)
+    if (blockIdx.x == 0 && threadIdx.x < (int)(sizeof(DevCounters) / 4)) ((int*)B.cnt)[threadIdx.x] = 0;
     if (threadIdx.x == 0) {
         const int tot = s_w[0] + s_w[1] + s_w[2] + s_w[3], tt = s_t[0] + s_t[1] + s_t[2] + s_t[3];
         B.partial[blockIdx.x] = tot & 0xffff;                 // (k_chain_ids reads the starts alone)
@@ -1057,40 +1059,67 @@ template <int J> __device__ __forceinline__ u64 xor_lane_u64(u64 v)
     else { lo = __shfl_xor(lo, J); hi = __shfl_xor(hi, J); }
     return ((u64)(unsigned)hi << 32) | (unsigned)lo;
 }
-template <int E, int J> __device__ __forceinline__ void bitonic_step_lanes(u64 (&k)[E], int kk)
+template <int J> __device__ __forceinline__ unsigned xor_lane_u32(unsigned v)
 {
-    const int lane = lane_id();
-    const bool lower = (lane & J) == 0;
-#pragma unroll
-    for (int e = 0; e < E; e++) {
-        const u64 other = xor_lane_u64<J>(k[e]);
-        const bool asc = ((e * 64 + lane) & kk) == 0;
-        const u64 mn = k[e] < other ? k[e] : other, mx = k[e] < other ? other : k[e];
-        k[e] = (lower == asc) ? mn : mx;
+    if (J == 1) return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xf, 0xf, false);
+    if (J == 2) return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xf, 0xf, false);
+    if (J == 8) return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x128, 0xf, 0xf, false);
+    return (unsigned)__shfl_xor((int)v, J);
+}
+// Which lanes of register e keep the SMALLER key of a compare-exchange with the partner J lanes away in stage KK of the network
+// over 64 * E elements (element index = e * 64 + lane): a compile-time constant.  Written with the lane id at run time -
+// (lane & J) == 0, ((e * 64 + lane) & kk) == 0 - the compiler computed every one of these masks once, in front of the kernel's
+// loop, and held them in SGPR pairs for the whole kernel: 49 SGPR spills (v_writelane / v_readlane pairs) in k_refine<64,256>,
+// 22 in k_refine_indel_wave.  As literals they cost one s_mov_b64 where they are used.
+constexpr u64 keepmin_mask_e(int e, int KK, int J)
+{
+    u64 m = 0;
+    for (int l = 0; l < 64; l++) { const bool lower = (l & J) == 0, asc = ((e * 64 + l) & KK) == 0; if (lower == asc) m |= 1ull << l; }
+    return m;
+}
+template <int e, int E, int J, int KK, class T> __device__ __forceinline__ void bitonic_lanes_e(T (&k)[E])
+{
+    if constexpr (e < E) {
+        constexpr u64 KEEPMIN = keepmin_mask_e(e, KK, J);
+        T other;
+        if constexpr (sizeof(T) == 8) other = (T)xor_lane_u64<J>((u64)k[e]); else other = (T)xor_lane_u32<J>((unsigned)k[e]);
+        const T mn = k[e] < other ? k[e] : other, mx = k[e] < other ? other : k[e];
+        k[e] = __builtin_amdgcn_inverse_ballot_w64(KEEPMIN) ? mn : mx;
+        bitonic_lanes_e<e + 1, E, J, KK, T>(k);
+    }
+}
+// same-lane partners (distance j >= 64): registers e and e | de, direction from the element index - compile-time per register
+template <int e, int E, int DE, int KK, class T> __device__ __forceinline__ void bitonic_regs_e(T (&k)[E])
+{
+    if constexpr (e < E) {
+        if constexpr ((e & DE) == 0 && (e | DE) < E) {
+            constexpr bool asc = ((e * 64) & KK) == 0;      // (KK >= 128 here: the lane bits do not reach it)
+            const T x = k[e], y = k[e | DE];
+            const bool sw = (x > y) == asc;
+            k[e] = sw ? y : x; k[e | DE] = sw ? x : y;
+        }
+        bitonic_regs_e<e + 1, E, DE, KK, T>(k);
+    }
+}
+template <int E, int KK, class T> __device__ __forceinline__ void bitonic_stage(T (&k)[E])
+{
+    if constexpr (KK <= 64 * E) {
+        if constexpr (KK >= 512) bitonic_regs_e<0, E, 4, KK, T>(k);
+        if constexpr (KK >= 256) bitonic_regs_e<0, E, 2, KK, T>(k);
+        if constexpr (KK >= 128) bitonic_regs_e<0, E, 1, KK, T>(k);
+        if constexpr (KK >= 64) bitonic_lanes_e<0, E, 32, KK, T>(k);
+        if constexpr (KK >= 32) bitonic_lanes_e<0, E, 16, KK, T>(k);
+        if constexpr (KK >= 16) bitonic_lanes_e<0, E, 8, KK, T>(k);
+        if constexpr (KK >= 8) bitonic_lanes_e<0, E, 4, KK, T>(k);
+        if constexpr (KK >= 4) bitonic_lanes_e<0, E, 2, KK, T>(k);
+        bitonic_lanes_e<0, E, 1, KK, T>(k);
+        bitonic_stage<E, KK * 2, T>(k);
     }
 }
 template <int E> __device__ __forceinline__ void bitonic_wave(u64 (&k)[E])
 {
-    const int lane = lane_id();
-    for (int kk = 2; kk <= 64 * E; kk <<= 1) {
-        for (int j = kk >> 1; j >= 64; j >>= 1) {            // same-lane partners
-            const int de = j >> 6;
-#pragma unroll
-            for (int e = 0; e < E; e++)
-                if ((e & de) == 0 && (e | de) < E) {
-                    const bool asc = ((e * 64 + lane) & kk) == 0;
-                    const u64 x = k[e], y = k[e | de];
-                    if ((x > y) == asc) { k[e] = y; k[e | de] = x; }
-                }
-        }
-        const int j0 = kk >> 1 < 32 ? kk >> 1 : 32;
-        if (j0 >= 32) bitonic_step_lanes<E, 32>(k, kk);
-        if (j0 >= 16) bitonic_step_lanes<E, 16>(k, kk);
-        if (j0 >= 8) bitonic_step_lanes<E, 8>(k, kk);
-        if (j0 >= 4) bitonic_step_lanes<E, 4>(k, kk);
-        if (j0 >= 2) bitonic_step_lanes<E, 2>(k, kk);
-        bitonic_step_lanes<E, 1>(k, kk);
-    }
+    static_assert(E <= 8, "register pairs up to distance 4");
+    bitonic_stage<E, 2, u64>(k);
 }
 template <int E, class KP> __device__ __forceinline__ void bitonic_wave_mem(KP K, int P)
 {
@@ -1107,47 +1136,10 @@ template <int E, class KP> __device__ __forceinline__ void bitonic_wave_mem(KP K
 // instead of two, three and two).  Both sort keys of the refine kernels are (value << S) | small index: when every value of a
 // cluster fits 32 - LB bits (read ids below 2^24, lengths below 2^24: nearly always) the keys are packed, sorted and unpacked
 // in registers.  Returns false (nothing done) when they do not fit.
-template <int J> __device__ __forceinline__ unsigned xor_lane_u32(unsigned v)
-{
-    if (J == 1) return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xf, 0xf, false);
-    if (J == 2) return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xf, 0xf, false);
-    if (J == 8) return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x128, 0xf, 0xf, false);
-    return (unsigned)__shfl_xor((int)v, J);
-}
-template <int E, int J> __device__ __forceinline__ void bitonic_step_lanes32(unsigned (&k)[E], int kk)
-{
-    const int lane = lane_id();
-    const bool lower = (lane & J) == 0;
-#pragma unroll
-    for (int e = 0; e < E; e++) {
-        const unsigned other = xor_lane_u32<J>(k[e]);
-        const bool asc = ((e * 64 + lane) & kk) == 0;
-        const unsigned mn = k[e] < other ? k[e] : other, mx = k[e] < other ? other : k[e];
-        k[e] = (lower == asc) ? mn : mx;
-    }
-}
 template <int E> __device__ __forceinline__ void bitonic_wave32(unsigned (&k)[E])
 {
-    const int lane = lane_id();
-    for (int kk = 2; kk <= 64 * E; kk <<= 1) {
-        for (int j = kk >> 1; j >= 64; j >>= 1) {            // same-lane partners
-            const int de = j >> 6;
-#pragma unroll
-            for (int e = 0; e < E; e++)
-                if ((e & de) == 0 && (e | de) < E) {
-                    const bool asc = ((e * 64 + lane) & kk) == 0;
-                    const unsigned x = k[e], y = k[e | de];
-                    if ((x > y) == asc) { k[e] = y; k[e | de] = x; }
-                }
-        }
-        const int j0 = kk >> 1 < 32 ? kk >> 1 : 32;
-        if (j0 >= 32) bitonic_step_lanes32<E, 32>(k, kk);
-        if (j0 >= 16) bitonic_step_lanes32<E, 16>(k, kk);
-        if (j0 >= 8) bitonic_step_lanes32<E, 8>(k, kk);
-        if (j0 >= 4) bitonic_step_lanes32<E, 4>(k, kk);
-        if (j0 >= 2) bitonic_step_lanes32<E, 2>(k, kk);
-        bitonic_step_lanes32<E, 1>(k, kk);
-    }
+    static_assert(E <= 8, "register pairs up to distance 4");
+    bitonic_stage<E, 2, unsigned>(k);
 }
 template <int E, class KP> __device__ __forceinline__ bool bitonic_wave_mem32(KP K, int P, int S)
 {
@@ -2057,6 +2049,21 @@ template <int SW> __device__ __forceinline__ int sub_scan_i32(int v)
     return v;
 }
 
+// ds_bpermute with an immediate byte offset on top of the address register (lane addr4 / 4 + OFF / 4, mod 64).  The builtin has
+// no offset operand and the compiler does not fold an added constant into the field; the wait is in the block because the
+// compiler's counter bookkeeping does not look inside it.
+template <int OFF> __device__ __forceinline__ int bperm_off(int addr4, int v)
+{
+    int r;
+    asm volatile("ds_bpermute_b32 %0, %1, %2 offset:%3\n\ts_waitcnt lgkmcnt(0)" : "=v"(r) : "v"(addr4), "v"(v), "n"(OFF));
+    return r;
+}
+template <int OFF> __device__ __forceinline__ double bperm_off_f64(int addr4, double v)
+{
+    const i64 b = __double_as_longlong(v);
+    const int lo = bperm_off<OFF>(addr4, (int)(b & 0xffffffffll)), hi = bperm_off<OFF>(addr4, (int)(b >> 32));
+    return __longlong_as_double(((i64)hi << 32) | (unsigned)lo);
+}
 // ds_bpermute with a ready byte address (lane << 2): no per-call index arithmetic
 __device__ __forceinline__ double bperm_f64(int addr4, double v)
 {
@@ -2077,18 +2084,22 @@ __device__ __forceinline__ void np_sum_allele2(double sq1, double sq2, int n, in
     const int lane = lane_id();
     const int nfull = n - (n & 7);
     double acc1 = sq1, acc2 = sq2;
+    // (byte addresses of other lanes: the lane's own address plus a constant - the immediate offset of ds_bpermute - or plus a
+    // wave-uniform step; the hardware ignores the bits above the lane.  Spelled ((lane + k) & 63) << 2 they were loop invariants
+    // that the compiler computed in front of the kernel's unit loop and kept in VGPRs for its whole life - for a path that one
+    // unit in a thousand takes.)
+    const int l4 = lane << 2;
     for (int t = 1; t < rows; t++) {
-        const int addr = ((lane + 8 * t) & 63) << 2;
+        const int addr = l4 + 32 * t;
         const double v1 = bperm_f64(addr, sq1), v2 = bperm_f64(addr, sq2);
         if (i < 8 && i + 8 * t < nfull) { acc1 += v1; acc2 += v2; }
     }
-    const int ad1 = ((lane + 1) & 63) << 2, ad2 = ((lane + 2) & 63) << 2, ad4 = ((lane + 4) & 63) << 2;
-    const double p1 = acc1 + bperm_f64(ad1, acc1), q1 = acc2 + bperm_f64(ad1, acc2);
-    const double p2 = p1 + bperm_f64(ad2, p1), q2 = q1 + bperm_f64(ad2, q1);
-    const double p3 = p2 + bperm_f64(ad4, p2), q3 = q2 + bperm_f64(ad4, q2);
+    const double p1 = acc1 + bperm_off_f64<4>(l4, acc1), q1 = acc2 + bperm_off_f64<4>(l4, acc2);
+    const double p2 = p1 + bperm_off_f64<8>(l4, p1), q2 = q1 + bperm_off_f64<8>(l4, q1);
+    const double p3 = p2 + bperm_off_f64<16>(l4, p2), q3 = q2 + bperm_off_f64<16>(l4, q2);
     double res1 = (n >= 8) ? p3 : 0.0, res2 = (n >= 8) ? q3 : 0.0;
     const int start = (n >= 8) ? nfull : 0;
-    const int adt = ((lane + start) & 63) << 2;               // lane L now holds element start + (L - r0) of its allele
+    const int adt = l4 + 4 * start;                            // lane L now holds element start + (L - r0) of its allele
     double t1 = bperm_f64(adt, sq1), t2 = bperm_f64(adt, sq2);
     for (int e = 0; e < tail; e++) {
         if (start + e < n) { res1 += t1; res2 += t2; }
@@ -2119,6 +2130,12 @@ template <int SW, int KK, int J> __device__ __forceinline__ unsigned cx_step(uns
         const unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)k, (int)k, CTRL, 0xf, 0xf, true);
         const unsigned mn = k < o ? k : o, mx = k < o ? o : k;
         return __builtin_amdgcn_inverse_ballot_w64(KEEPMIN) ? mn : mx;
+    } else if constexpr (J == 32) {
+        // the other half of the wavefront: ds_bpermute with an immediate offset of 32 lanes on the lane's own address (no address
+        // arithmetic, nothing for the compiler to hoist into a long-lived register)
+        const unsigned o = (unsigned)bperm_off<128>(lane_id() << 2, (int)k);
+        const u64 lt = __ballot(k < o);
+        return __builtin_amdgcn_inverse_ballot_w64(~(lt ^ KEEPMIN)) ? k : o;
     } else {
         const unsigned o = (unsigned)__builtin_amdgcn_ds_swizzle((int)k, 0x1f | (J << 10));               // bit mode: lane ^ J (J = 4, 16)
         const u64 lt = __ballot(k < o);
@@ -2127,12 +2144,16 @@ template <int SW, int KK, int J> __device__ __forceinline__ unsigned cx_step(uns
 }
 template <int SW> __device__ __forceinline__ unsigned sort_sub(unsigned k)
 {
-    static_assert(SW == 16 || SW == 32, "sub-wave width");
+    static_assert(SW == 16 || SW == 32 || SW == 64, "sub-wave width");
     k = cx_step<SW, 2, 1>(k);
     k = cx_step<SW, 4, 2>(k); k = cx_step<SW, 4, 1>(k);
     k = cx_step<SW, 8, 4>(k); k = cx_step<SW, 8, 2>(k); k = cx_step<SW, 8, 1>(k);
     k = cx_step<SW, 16, 8>(k); k = cx_step<SW, 16, 4>(k); k = cx_step<SW, 16, 2>(k); k = cx_step<SW, 16, 1>(k);
-    if (SW == 32) { k = cx_step<SW, 32, 16>(k); k = cx_step<SW, 32, 8>(k); k = cx_step<SW, 32, 4>(k); k = cx_step<SW, 32, 2>(k); k = cx_step<SW, 32, 1>(k); }
+    if (SW >= 32) { k = cx_step<SW, 32, 16>(k); k = cx_step<SW, 32, 8>(k); k = cx_step<SW, 32, 4>(k); k = cx_step<SW, 32, 2>(k); k = cx_step<SW, 32, 1>(k); }
+    // (one cluster per wavefront: the select masks are compile-time constants here too.  The generic 64-lane network -
+    // bitonic_wave32 - derives them from the lane id at run time, and the compiler kept a dozen of them in SGPR pairs across
+    // the whole kernel: most of its 22 SGPR spills)
+    if (SW == 64) { k = cx_step<SW, 64, 32>(k); k = cx_step<SW, 64, 16>(k); k = cx_step<SW, 64, 8>(k); k = cx_step<SW, 64, 4>(k); k = cx_step<SW, 64, 2>(k); k = cx_step<SW, 64, 1>(k); }
     return k;
 }
 
@@ -2201,7 +2222,10 @@ template <> struct crd_min<i64> { static constexpr i64 v = INT64_MIN; };
 #endif
 // one unit of work: SW = 16 -> four clusters of m <= 16; SW = 32 -> the pair of items (2p, 2p + 1), each handled if m <= 32;
 //                   SW = 64 -> the single item p, handled if 32 < m <= 64.
-template <int SW, bool NARROW> __device__ __forceinline__ void indel_unit(const DevBatch& B, const UnitIn<NARROW>& U)
+// LDS of one wavefront of k_refine_indel_wave: the tag table of the per-read de-duplication (below) and one mark byte per lane
+constexpr int IW_TAG_BITS = 12;                     // 4096 one-byte slots per wavefront
+struct IwLds { unsigned char tag[1 << IW_TAG_BITS]; unsigned char mark[64]; };
+template <int SW, bool NARROW> __device__ __forceinline__ void indel_unit(const DevBatch& B, const UnitIn<NARROW>& U, CSV_LDS IwLds* L)
 {
     typedef crd_t<NARROW> C;
     constexpr int NSUB = 64 / SW;                      // clusters per wavefront
@@ -2239,32 +2263,25 @@ template <int SW, bool NARROW> __device__ __forceinline__ void indel_unit(const 
         // ---- per-read de-duplication (INDEL:125-131): first appearance F, kept signature = strictly longest
         int F = sl, ch = sl;
         C bl = b;
-        // which lanes hold my read id?  One ballot per id bit, AND of the agreeing sides: the whole wavefront
-        // (both sub-waves) in ~6 instructions per bit, independent of m.
+        // Which lanes hold a read id that some other lane of their cluster holds too?  A last-writer-wins table in LDS: every lane
+        // writes its lane number at hash(read id) inside its cluster's part of the wavefront's 4096 one-byte slots and reads the
+        // slot back; whoever does not find itself there lost to a lane with the same id (or, one time in a hundred, to a hash
+        // collision) and marks the winner.  Lost or marked = "has a partner": a superset of the truth, and the exact loop below
+        // compares the ids themselves.  ~12 vector instructions and four LDS operations, whatever the ids look like (r04: twelve
+        // ballots over the id bits, 6 vector instructions each - 72 of a unit's ~680).
         bool dup_any = false;
         {
-            const u64 inmask = __ballot(in);
-            int orv = in ? rid : 0;
-            orv |= dpp_i32<0x111, 0xf>(0, orv); orv |= dpp_i32<0x112, 0xf>(0, orv); orv |= dpp_i32<0x114, 0xf>(0, orv);
-            orv |= dpp_i32<0x118, 0xf>(0, orv); orv |= dpp_i32<0x142, 0xa>(0, orv); orv |= dpp_i32<0x143, 0xc>(0, orv);
-            // more than 12 id bits: compare a 12-bit fold instead.  Equal ids still always match; a false match only
-            // sends the wavefront through the exact loop below (probability ~m^2 / 8192 per cluster).  Always 12 steps,
-            // straight-line: a bit that no id has set costs one ballot and changes nothing.
-            const bool wide_ids = ((unsigned)__builtin_amdgcn_readlane(orv, 63) >> 12) != 0;
-            const int hid = wide_ids ? ((rid ^ (rid >> 12) ^ (rid >> 24)) & 0xfff) : rid;
-            // lanes whose (folded) id differs from mine in some bit: per bit one sign-extending field extract (all ones when
-            // my bit is set), one ballot, and acc |= ballot ^ mine for each half - v_bitop3 - : 4 instructions
-            // (r03 selected between the ballot and its complement: 7.5)
-            u64 differ = 0;
-#pragma unroll
-            for (int bit = 0; bit < 12; bit++) {
-                const int ones = (int)((unsigned)hid << (31 - bit)) >> 31;
-                const u64 mk = __ballot(ones != 0);
-                differ |= mk ^ (u64)(i64)ones;
-            }
-            const u64 match = inmask & ~differ;
-            const u64 mine = SUBMASK << hb;
-            dup_any = in && __popcll(match & mine) > 1;
+            constexpr int HB = IW_TAG_BITS - (NSUB == 4 ? 2 : NSUB == 2 ? 1 : 0);     // hash bits inside a cluster's part
+            const unsigned h = (unsigned)rid ^ ((unsigned)rid >> HB) ^ ((unsigned)rid >> (2 * HB));
+            const int slot = (int)(h & ((1u << HB) - 1u)) | (g << HB);
+            L->mark[lane] = 0;
+            if (in) L->tag[slot] = (unsigned char)lane;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int w = in ? (int)L->tag[slot] : lane;
+            const bool lost = w != lane;
+            if (lost) L->mark[w] = 1;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            dup_any = lost || (in && L->mark[lane] != 0);
             if (CSV_ABL(0)) dup_any = false;
         }
         // Reads with more than one signature in a cluster are common (a 30x cluster has one in ~40 % of the cases), so this is
@@ -2314,9 +2331,8 @@ template <int SW, bool NARROW> __device__ __forceinline__ void indel_unit(const 
             // the 64-lane sorting network (21 compare-exchanges in DPP / bpermute, no scalar work), and sorted position p then
             // PULLS its row from the lane the key came from.  (A rank by counting - one v_readlane, compare and add per kept
             // signature - was 3 vector + 6 scalar instructions times up to 64.)
-            unsigned ks[1] = {rep ? (((unsigned)bl << 6) | (unsigned)sl) : (0x80000000u | (unsigned)sl)};
-            bitonic_wave32<1>(ks);
-            src_lane = (int)(ks[0] & 63u);
+            const unsigned ks = sort_sub<64>(rep ? (((unsigned)bl << 6) | (unsigned)sl) : (0x80000000u | (unsigned)sl));
+            src_lane = (int)(ks & 63u);
         } else {
             for (u64 mk = __ballot(rep); mk; mk &= mk - 1) {
                 const int t = __ffsll((long long)mk) - 1;
@@ -2435,17 +2451,24 @@ template <int SW, bool NARROW> __device__ __forceinline__ void indel_unit(const 
                 CSV_MINSTEP(0x111, 1) CSV_MINSTEP(0x112, 2) CSV_MINSTEP(0x114, 4) CSV_MINSTEP(0x118, 8)
 #undef CSV_MINSTEP
             } else {
+                // value of lane - d: ds_bpermute adds its immediate offset to the byte address and ignores the bits above the lane
+                // (ISA: src_lane = (addr + offset) / 4 mod 64), so ONE address register serves every distance.  (Computed
+                // addresses - (lane - d) * 4 & 252 - were hoisted out of the unit loop by the compiler: six VGPRs held for the
+                // whole kernel, three of them spilled to scratch at six wavefronts per SIMD.)
                 const int l4 = lane << 2;
-                for (int d = 1; d < SW; d <<= 1) { const unsigned o = (unsigned)bperm((l4 - 4 * d) & 252, (int)bk); if (i >= d && o < bk) bk = o; }
+#define CSV_MINB(D) if (D < SW) { const unsigned o = (unsigned)bperm_off<256 - 4 * D>(l4, (int)bk); if (i >= D && o < bk) bk = o; }
+                CSV_MINB(1) CSV_MINB(2) CSV_MINB(4) CSV_MINB(8) CSV_MINB(16) CSV_MINB(32)
+#undef CSV_MINB
             }
             search = bperm((hb | (bperm(e14, (int)bk) & (SW - 1))) << 2, pos);
         } else if (!__ballot(pass && keep < n)) {
             // the same on the doubles themselves (clusters that span more than 2^18 bases)
             double bd = fabs((double)pos - pmean); int bi = r;
-            for (int d = 1; d < SW; d <<= 1) {
-                const double od = shfl_f64(bd, (lane - d) & 63); const int oi = __shfl(bi, (lane - d) & 63);
-                if (r - d >= r0 && (od < bd || (od == bd && oi < bi))) { bd = od; bi = oi; }
-            }
+            const int l4 = lane << 2;                        // (lane - d through ds_bpermute's immediate offset: see the integer form above)
+#define CSV_MIND(D) if (D < SW) { const double od = bperm_off_f64<256 - 4 * D>(l4, bd); const int oi = bperm_off<256 - 4 * D>(l4, bi); \
+                                  if (r - D >= r0 && (od < bd || (od == bd && oi < bi))) { bd = od; bi = oi; } }
+            CSV_MIND(1) CSV_MIND(2) CSV_MIND(4) CSV_MIND(8) CSV_MIND(16) CSV_MIND(32)
+#undef CSV_MIND
             search = bperm((hb | (bperm(e14, bi) & (SW - 1))) << 2, pos);
         } else {
             // keep the `keep` members closest to the mean, ties in allele order (INDEL:171-176, 182-187)
@@ -2544,12 +2567,19 @@ template <int SW, bool NARROW> __device__ __forceinline__ void indel_unit(const 
 // (int64 columns keep their coordinates in register pairs: one wavefront per SIMD fewer, and no spills either)
 template <bool NARROW> __global__ __launch_bounds__(256, NARROW ? CSV_IW_WAVES : CSV_IW_WAVES - 1) void k_refine_indel_wave(DevBatch B)
 {
+    __shared__ IwLds s_iw[4];
+    CSV_LDS IwLds* L = (CSV_LDS IwLds*)&s_iw[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))];       // (a scalar: not a VGPR held across the kernel)
     const int ntiny = B.cnt->n_items_tiny, nsmall = B.cnt->n_items - B.cnt->n_items_big - ntiny;
     const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * 256 + threadIdx.x) >> 6), nwaves = (gridDim.x * 256) >> 6;
     // Units: the wide items (one cluster of 33 .. 64 signatures per wavefront), the pairs of the small list, the quads of the
     // tiny list (clusters of at most 16 signatures: four per wavefront, a sub-wave is one DPP row); unit u goes to wavefront
     // u mod nwaves.  A unit costs two dependent round trips: its list entries, then its rows.
     const int n_pair = (nsmall + 1) / 2, n_quad = (ntiny + 3) / 4, n_wide = B.cnt->n_items_wide;
+    // (r05, rejected with a measurement: handing the units out on demand - every wavefront's first unit its own index, further
+    // ones from ticket counters drawn one unit ahead, 32 counters by residue class - made this kernel 63 us instead of 12.5 on
+    // the 30x genome and 260 instead of 41 on the 90x one: ~10 k device-scope atomics on 32 addresses are served one after the
+    // other at 150-200 ns each.  The static deal below is balanced in COUNT per SIMD already - workgroups go round-robin over
+    // XCDs and CUs, so the waves that get a second unit are spread evenly - and the remaining spread is the units' own cost.)
     // Longest first: the wide items (32 < m <= 64, the one-cluster-per-wavefront form, about twice a pair's latency) go to
     // the wavefronts that are dispatched first; the pairs and then the quads are dealt round-robin over the OTHER
     // wavefronts, so that a wavefront that already has a wide item is not also the one that gets a second unit when there
@@ -2557,7 +2587,7 @@ template <bool NARROW> __global__ __launch_bounds__(256, NARROW ? CSV_IW_WAVES :
     for (int p = wave; p < n_wide; p += nwaves) {
         UnitIn<NARROW> U;
         unit_rows<NARROW>(B, unit_entry(B.list_wide, p, n_wide, 6), 6, 32, U);
-        indel_unit<64, NARROW>(B, U);
+        indel_unit<64, NARROW>(B, U, L);
     }
     const int skip = n_wide < nwaves ? n_wide : 0, M = nwaves - skip;
     if (wave < skip) return;
@@ -2565,14 +2595,14 @@ template <bool NARROW> __global__ __launch_bounds__(256, NARROW ? CSV_IW_WAVES :
     for (int p = slot; p < n_pair; p += M) {
         UnitIn<NARROW> U;
         unit_rows<NARROW>(B, unit_entry(B.list_small, p, nsmall, 5), 5, 0, U);
-        indel_unit<32, NARROW>(B, U);                      // (members with 32 < m <= 64 are skipped here: they are units of their own)
+        indel_unit<32, NARROW>(B, U, L);                      // (members with 32 < m <= 64 are skipped here: they are units of their own)
     }
     int q0 = slot - n_pair % M;                            // the quads continue the round-robin where the pairs stopped
     if (q0 < 0) q0 += M;
     for (int p = q0; p < n_quad; p += M) {
         UnitIn<NARROW> U;
         unit_rows<NARROW>(B, unit_entry(B.list_tiny, p, ntiny, 4), 4, 0, U);
-        indel_unit<16, NARROW>(B, U);
+        indel_unit<16, NARROW>(B, U, L);
     }
     // (r04, rejected: loading the next unit's entry two units ahead and its rows one unit ahead - 12 more VGPRs, so five
     // wavefronts per SIMD or spills at six - was 17.4 / 19.1 us against 15.0 on the 30x genome: occupancy hides more latency
