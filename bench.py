@@ -169,13 +169,18 @@ def bench_rebuild(a):
     t0 = time.perf_counter()
     tl.sort(key=lambda x: (x[0], x[1], x[2], x[3]))
     t_py = time.perf_counter() - t0
-    bytes_alg = n_in * (44 + 48 * info["n_passes"] + 48)
+    # algorithmic bytes: the row in (28 B: seg 4 + a 8 + b 8 + read 4 + aux 4) and the row out (28 B).  The radix passes are
+    # TRAFFIC, not algorithmic bytes: 16 B packed + per pass 16 read (histogram) + 16 read + 16 written (scatter)
+    bytes_alg = n_in * 56
+    bytes_traffic = n_in * (28 + 16 + 48 * info["n_passes"] + 16 + 32)
     out = {"metric": "signature rows rebuilt/sec (sort + de-duplication, main script :750-857)", "value": n_in / (ms * 1e-3), "unit": "rows/s", "n_gpus": 1,
            "steps": min(a.steps, 10), "warmup": a.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "int64 keys", "data": "synthetic",
            "config": {"workload": "rebuild: cfg3 rows in random order + 5 %% exact duplicates (%d rows in, %d out, %d radix passes)" % (n_in, got.n_sig, info["n_passes"])},
            "roofline": {"bound": "hbm", "kernel": "k_sort_* + k_rebuild_*", "achieved": bytes_alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": bytes_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": bytes_alg},
+                        "frac": bytes_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": bytes_traffic, "algorithmic_bytes": bytes_alg,
+                        "traffic_note": "computed, not measured: pack 28 + 16 B, %d radix passes x 48 B, tail 16 + 32 B per row" % info["n_passes"],
+                        "traffic_gbs": bytes_traffic / (ms * 1e-3) / 1e9},
            "cpu_baseline": {"value": smp / t_py, "unit": "rows/s", "cores": 1, "kind": "port",
                             "sample": "Python list.sort with the reference's tuple key on %d DEL rows (%.2f s): the reference's rebuild is this per type" % (smp, t_py)},
            "cpu_baseline_numpy": {"value": n_in / t_np, "unit": "rows/s", "cores": 1, "sample": "numpy lexsort of all rows, %.3f s" % t_np},
@@ -574,10 +579,15 @@ def valu_issue_of(workload, scale, kernel, kernel_us, n_cu=256, clock_mhz=2400.0
         r = json.load(fh).get(kernel)
     if not r or not r.get("SQ_ACTIVE_INST_VALU"):
         return None
-    simd_cycles = 4.0 * n_cu * kernel_us * clock_mhz
+    # busy share of the chip's SIMDs as a pure counter ratio: SQ_BUSY_CYCLES is summed over the 32 shader engines, so the
+    # kernel lasted SQ_BUSY_CYCLES / 32 clocks IN THE COUNTER RUN; 4 * ACTIVE / (4 * n_cu * BUSY / 32) = 32 * ACTIVE / (n_cu * BUSY)
+    # (scripts/rocprof_counters.py prints the same column; no clock is assumed - r04 priced the counter run's instructions
+    # on the bench run's duration at an assumed 2.4 GHz)
+    busy = r.get("SQ_BUSY_CYCLES")
     return {"kernel": kernel, "valu_insts_per_launch": r["SQ_INSTS_VALU"], "salu_insts_per_launch": r["SQ_INSTS_SALU"], "lds_insts_per_launch": r["SQ_INSTS_LDS"],
             "waves": r["SQ_WAVES"], "valu_active_quad_cycles": r["SQ_ACTIVE_INST_VALU"],
-            "valu_busy_frac": 4.0 * r["SQ_ACTIVE_INST_VALU"] / simd_cycles, "clock_mhz_assumed": clock_mhz, "kernel_us": kernel_us,
+            "valu_busy_frac": (32.0 * r["SQ_ACTIVE_INST_VALU"] / (n_cu * busy)) if busy else None, "kernel_us": kernel_us,
+            "kernel_us_in_the_counter_run_at_2p4_ghz": (busy / 32.0 / 2400.0) if busy else None,
             "wave_share_issuing_valu": r["SQ_ACTIVE_INST_VALU"] / r["SQ_WAVE_CYCLES"] if r.get("SQ_WAVE_CYCLES") else None,
             "wave_share_issue_stalled": r["SQ_WAIT_INST_ANY"] / r["SQ_WAVE_CYCLES"] if r.get("SQ_WAVE_CYCLES") else None,
             "source": "profiles/insts_%s.json (rocprofv3 --pmc, two passes)" % workload}

@@ -328,6 +328,31 @@ namespace pk {
 enum Kind : uint8_t { LIST, MARKER, ROW, INT, FLOAT, STR, OTHER };
 struct Cell { Kind kind; int32_t len; int64_t a; };
 
+// what PyUnicode_DecodeUTF8(.., "surrogatepass") - pickle's decoder of BINUNICODE payloads - accepts: well-formed UTF-8 (no
+// overlong forms, nothing above U+10FFFF) plus three-byte encoded surrogates
+inline bool utf8_ok(const unsigned char* s, int64_t n)
+{
+    int64_t i = 0;
+    while (i < n) {
+        if (i + 8 <= n) { uint64_t w; memcpy(&w, s + i, 8); if (!(w & 0x8080808080808080ull)) { i += 8; continue; } }
+        const unsigned c = s[i];
+        if (c < 0x80) { i++; continue; }
+        if (c < 0xC2) return false;
+        if (c < 0xE0) { if (i + 1 >= n || (s[i + 1] & 0xC0) != 0x80) return false; i += 2; continue; }
+        if (c < 0xF0) {
+            if (i + 2 >= n || (s[i + 1] & 0xC0) != 0x80 || (s[i + 2] & 0xC0) != 0x80) return false;
+            if (c == 0xE0 && s[i + 1] < 0xA0) return false;
+            i += 3; continue;
+        }
+        if (c < 0xF5) {
+            if (i + 3 >= n || (s[i + 1] & 0xC0) != 0x80 || (s[i + 2] & 0xC0) != 0x80 || (s[i + 3] & 0xC0) != 0x80) return false;
+            if ((c == 0xF0 && s[i + 1] < 0x90) || (c == 0xF4 && s[i + 1] > 0x8F)) return false;
+            i += 4; continue;
+        }
+        return false;
+    }
+    return true;
+}
 struct Reader {
     const unsigned char* p; int64_t n, i;
     bool need(int64_t k) const { return i + k <= n; }
@@ -400,7 +425,14 @@ PyObject* pickle_table(PyObject*, PyObject* args)
         const unsigned char op = R.p[R.i++];
         switch (op) {
         case 0x80: if (!R.need(1)) { corrupt = "truncated"; break; } if (R.p[R.i] < 2 || R.p[R.i] > 5) unsupported = true; R.i += 1; break;     // PROTO
-        case 0x95: if (!R.need(8)) { corrupt = "truncated"; break; } R.i += 8; break;                                                        // FRAME
+        case 0x95: {                                                                                                                         // FRAME
+            // pickle reads the whole frame before it goes on (load_frame: "pickle data was truncated" when the announced bytes are
+            // not there): a frame that runs past the buffer is not ours to accept
+            if (!R.need(8)) { corrupt = "truncated"; break; }
+            const uint64_t flen = R.le(8);
+            if (flen > (uint64_t)INT64_MAX || !R.need((int64_t)flen)) unsupported = true;
+            break;
+        }
         case ']': st.push_back(Cell{LIST, 0, 0}); break;
         case '(': st.push_back(Cell{MARKER, 0, 0}); break;
         case 'K': if (!R.need(1)) { corrupt = "truncated"; break; } st.push_back(Cell{INT, 0, (int64_t)R.le(1)}); break;
@@ -429,6 +461,9 @@ PyObject* pickle_table(PyObject*, PyObject* args)
             const uint64_t len = R.le(k);
             if (len > (uint64_t)INT32_MAX) { unsupported = true; break; }
             if (!R.need((int64_t)len)) { corrupt = "truncated"; break; }
+            // (pickle decodes the payload as it reads it - UTF-8, surrogatepass - and raises on anything else; the spans handed out
+            // here are decoded later, or never: the check is made now, 8 bytes at a time for ASCII)
+            if (!utf8_ok(R.p + R.i, (int64_t)len)) { unsupported = true; break; }
             st.push_back(Cell{STR, (int32_t)len, R.i});
             R.i += (int64_t)len;
             break;

@@ -1436,7 +1436,8 @@ int csv_rebuild_signatures(csv_ctx* c, const csv_rebuild_in* in, csv_rebuild_out
     KL.ab = nbits((u64)mx_a) > 0 ? nbits((u64)mx_a) : 1; KL.xb = nbits((u64)mx_aux); KL.sb = nbits((u64)mx_seg) > 0 ? nbits((u64)mx_seg) : 1;
     KL.pb = nbits((u64)mx_aux_all);
     KL.T = KL.rb + KL.bb + KL.ab + KL.xb + KL.sb;
-    KL.wide = (KL.ib + KL.T + KL.pb <= 128) ? 0 : 1;
+    // (the compact element holds aux | key | index in 128 bits; with no aux bits and ib + T == 128 its shifts would be by 128: wide then)
+    KL.wide = (KL.ib + KL.T + KL.pb <= 128 && KL.ib + KL.T < 128) ? 0 : 1;
     const bool composite = KL.T <= 128 && !getenv("CSV_RB_PERM_SORT");
     RebuildArgs R{};
     R.n = n;

@@ -275,14 +275,15 @@ template <int CTRL, int RM> __device__ __forceinline__ i64 dpp_i64(i64 old, i64 
 // as the carry pair the hardware has for it - v_add_co_u32_dpp / v_addc_co_u32_dpp.  Written through dpp_i64 the compiler
 // builds the moved value as two 64-bit numbers (lo | 0 and 0 | hi), each from a zeroed register and a v_mov_b32_dpp, and adds
 // them with two v_lshl_add_u64: seven vector instructions a step where two do - and these kernels run at 60 - 86 % of the vector
-// ALUs' issue rate (profiles/r04_cfg3_insts.txt), so the count is the time.  s_nop 1: a DPP read needs two wait states after
-// the VALU write of its source, and the hazard recogniser does not look inside an asm block.
+// ALUs' issue rate (profiles/r04_cfg3_insts.txt), so the count is the time.  s_nop 4: a DPP read needs two wait states after
+// the VALU write of its source and FIVE after a VALU write of EXEC (v_cmpx), and the hazard recogniser does not look inside an
+// asm block: the wait covers the longer of the two whatever precedes the block.
 template <int CTRL, int RM> __device__ __forceinline__ i64 dpp_add_i64(i64 v);
 #define CSV_DPP_ADD64(CTRL, RM, TXT)                                                                                              \
     template <> __device__ __forceinline__ i64 dpp_add_i64<CTRL, RM>(i64 v)                                                       \
     {                                                                                                                             \
         unsigned lo = (unsigned)((u64)v & 0xffffffffull), hi = (unsigned)((u64)v >> 32);                                          \
-        asm volatile("s_nop 1\n\tv_add_co_u32_dpp %0, vcc, %0, %0 " TXT "\n\tv_addc_co_u32_dpp %1, vcc, %1, %1, vcc " TXT         \
+        asm volatile("s_nop 4\n\tv_add_co_u32_dpp %0, vcc, %0, %0 " TXT "\n\tv_addc_co_u32_dpp %1, vcc, %1, %1, vcc " TXT         \
                      : "+v"(lo), "+v"(hi) : : "vcc");                                                                             \
         return (i64)(((u64)hi << 32) | lo);                                                                                       \
     }

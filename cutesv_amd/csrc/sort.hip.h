@@ -248,11 +248,16 @@ template <bool WIDE> __global__ __launch_bounds__(256) void k_rs_scatter(const R
     if (unit >= nunits) return;
     const i64 base = (i64)unit * SORT_WTILE;
     const u64 lt = (1ull << lane) - 1ull;
-    constexpr int PF = WIDE ? 4 : 8;                                  // chunks loaded ahead (registers: 4 words per 16-byte element)
+    constexpr int PF = WIDE ? 4 : 8;                                  // chunks loaded ahead (registers: 4 words per 16-byte element; 8 per 32-byte one)
     for (int c0 = 0; c0 < SORT_CHUNKS; c0 += PF) {
         RsElem<WIDE> pre[PF];
 #pragma unroll
-        for (int u = 0; u < PF; u++) { const i64 r2 = base + (c0 + u) * 64 + lane; pre[u] = in[r2 < n ? r2 : n - 1]; }
+        for (int u = 0; u < PF; u++) {
+            const i64 r2 = base + (c0 + u) * 64 + lane;
+            // (a 32-byte element as two 16-byte words: copied as one aggregate it went through a stack slot - 64 B of scratch per lane)
+            if constexpr (WIDE) { const ulonglong2* q = (const ulonglong2*)&in[r2 < n ? r2 : n - 1]; const ulonglong2 q0 = q[0], q1 = q[1]; pre[u].v.x = q0.x; pre[u].v.y = q0.y; pre[u].v.z = q1.x; pre[u].v.w = q1.y; }
+            else pre[u] = in[r2 < n ? r2 : n - 1];
+        }
 #pragma unroll
         for (int u = 0; u < PF; u++) {
             const i64 row = base + (c0 + u) * 64 + lane;
@@ -269,7 +274,9 @@ template <bool WIDE> __global__ __launch_bounds__(256) void k_rs_scatter(const R
             const u64 match = ~differ;                                    // lanes of this chunk with my digit
             if (in_) {
                 const int before = cnt[wv][dig];                          // same value for the whole match group
-                out[before + __popcll(match & lt)] = e;
+                const i64 dst = before + __popcll(match & lt);
+                if constexpr (WIDE) { ulonglong2* o = (ulonglong2*)&out[dst]; o[0] = make_ulonglong2(e.v.x, e.v.y); o[1] = make_ulonglong2(e.v.z, e.v.w); }
+                else out[dst] = e;
             }
             // the highest lane of each group advances the group's counter (after everyone read it: LDS ops of a wavefront execute in order)
             if (in_ && (match >> lane) <= 1ull) cnt[wv][dig] += __popcll(match);

@@ -56,7 +56,10 @@ class Reference:
         # a stale or foreign index must not send the emitter past the mapping
         last = self.offset + np.where(self.line_bases > 0, (np.maximum(self.length, 1) - 1) // np.maximum(self.line_bases, 1) * self.line_width
                                       + (np.maximum(self.length, 1) - 1) % np.maximum(self.line_bases, 1), 0)
-        if len(t) and (int(last.max()) >= self.size or int(self.offset.min()) < 0):
+        # (a contig without sequence - a header at the end of the file, length 0: samtools writes the same entry - has nothing to
+        # read: its offset may equal the file size)
+        has = self.length > 0
+        if len(t) and ((has.any() and int(last[has].max()) >= self.size) or int(self.offset.min()) < 0 or int(self.offset.max()) > self.size):
             raise ValueError("%s does not describe %s (offsets beyond the file)" % (fai, self.path))
 
     def _build(self):

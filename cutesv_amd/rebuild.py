@@ -46,11 +46,12 @@ def tie_callback(seq_of_src, half_of_src):
             for g in range(n_groups):
                 g0, g1 = group_off[g], group_off[g + 1]
                 rows = list(range(g0, g1))
-                rows.sort(key=lambda i: seq_of_src(src_row[i]))
+                seq = {i: seq_of_src(src_row[i]) for i in rows}        # (one look-up per row)
+                rows.sort(key=seq.__getitem__)
                 prev = None
                 for pos, i in enumerate(rows):
                     order[i] = pos
-                    cur = (seq_of_src(src_row[i]), int(half_of_src(src_row[i])))
+                    cur = (seq[i], int(half_of_src(src_row[i])))
                     drop[i] = 1 if (prev is not None and cur == prev) else 0
                     prev = cur
             return 0
@@ -140,7 +141,9 @@ def rebuild_to_device_batch(ctx, chroms, per_type, params_segment, reads=None):
         half = ins.get("half")
         cb = tie_callback(lambda s_: seqs[s_ - ins_base], (lambda s_: half[s_ - ins_base]) if half is not None else (lambda s_: 0))
     r = rebuild_columns(ctx, cat["seg"], cat["a"], cat["b"], cat["rid"], cat["aux"], major, nodedup, keep_on_device=True, tie_order=cb)
-    assert r["n_ins_ties"] == 0
+    if r["n_ins_ties"]:                                     # (with a tie callback the device order is final; never with `assert`: -O strips it)
+        raise ValueError("%d INS rows tie on (position, length, read) and were not settled on the device: the batch is not in the "
+                         "reference's order" % r["n_ins_ties"])
     off = np.r_[0, np.cumsum(r["seg_count"])]
     segs, tasks = [], []
     for s in range(n_seg):

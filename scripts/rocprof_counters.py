@@ -43,7 +43,13 @@ def main():
         if "valu_per_wave" in der:
             d.append(r.get("SQ_INSTS_VALU", 0.0) / r["SQ_WAVES"] if r.get("SQ_WAVES") else 0.0)
         if "valu_busy" in der:
-            d.append(r.get("SQ_ACTIVE_INST_VALU", 0.0) / r["SQ_BUSY_CYCLES"] / 4.0 if r.get("SQ_BUSY_CYCLES") else 0.0)
+            # SQ_ACTIVE_INST_VALU: quad-cycles (4 clocks) in which a wavefront's VALU instruction occupies its SIMD, summed over
+            # the chip; SQ_BUSY_CYCLES: clocks an SQ is busy, summed over the chip's 32 shader engines (8 XCDs x 4) - so
+            # SQ_BUSY_CYCLES / 32 is the kernel's duration in clocks (checked against the trace: 1 006 854 / 32 = 31 464 clocks
+            # = 13.1 us at 2.4 GHz for a 13.1 us kernel).  Busy share of the 1024 SIMDs = 4 * ACTIVE / (1024 * BUSY / 32)
+            # = ACTIVE / (8 * BUSY): a pure counter ratio, no clock assumed.  (r04 divided by 4 instead of 8: the column read
+            # 1.49 for a kernel at 0.74.)
+            d.append(r.get("SQ_ACTIVE_INST_VALU", 0.0) / r["SQ_BUSY_CYCLES"] / 8.0 if r.get("SQ_BUSY_CYCLES") else 0.0)
         print("%-28s %8d " % (k, launches[k]) + " ".join("%18.1f" % r.get(c, 0.0) for c in counters) + " " + " ".join("%18.3f" % x for x in d))
     if out_json:
         import json

@@ -360,22 +360,29 @@ def test_bench_reads_its_committed_counter_files():
     assert 0.05 < vi["wave_share_issuing_valu"] < 0.5
     assert bench.valu_issue_of("cfg3", 0.5, "k_refine_indel_wave", 13.6) is None        # (counters are of the full-size workload only)
     assert bench.valu_issue_of("cfg3", 1.0, "k_no_such_kernel", 1.0) is None
-    # the one JSON line stays inside the bounded tail of stdout the driver reads: the committed line does, an oversized one is trimmed
+    # the one JSON line stays inside the 8 000-byte tail of stdout the driver keeps: the full objects of a run are compacted
+    # to named numbers (every key of the contract survives), the detail goes to stderr / gpurun_out
     with open(os.path.join(ROOT, "profiles", "r04_bench_cfg3.json")) as f:
-        assert len(f.read()) < bench.LINE_LIMIT
-    big = {"metric": "m", "value": 1.0, "units": {"x": "y" * 30000}, "other_workloads": {"a": 1}}
+        full = json.load(f)
+    c = bench.compact(dict(full))
+    assert len(json.dumps(c)) + 1 <= bench.LINE_LIMIT
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert c[k] == full[k] or k == "config", k
+    assert c["roofline"]["frac"] == pytest.approx(full["roofline"]["frac"], rel=1e-3) and c["roofline"]["bound"] == "hbm" and c["roofline"]["traffic"] == full["roofline"]["traffic"]
+    assert c["cpu_baseline"]["value"] == pytest.approx(full["cpu_baseline"]["value"], rel=1e-3) and c["cpu_baseline"]["cores"] == full["cpu_baseline"]["cores"]
+    assert set(c["other_workloads"]) == set(full["other_workloads"]) and c["parity_vs_oracle"] is True
     r, w = os.pipe()
     saved = bench._OUT_FD
     try:
         bench._OUT_FD = w
-        bench.emit(big)
+        bench.emit(dict(full))
     finally:
         bench._OUT_FD = saved
         os.close(w)
     line = os.read(r, 1 << 20)
     os.close(r)
     d = json.loads(line)
-    assert len(line) <= bench.LINE_LIMIT and d["value"] == 1.0 and d["units"] is None and d["trimmed_to_fit_the_line"] == ["units"] and d["other_workloads"] == {"a": 1}
+    assert len(line) <= bench.LINE_LIMIT and d["value"] == full["value"] and d["roofline"]["kernel"] == full["roofline"]["kernel"]
 
 
 def _same_store(x, y):
@@ -465,8 +472,14 @@ def test_task_pickles_walked_in_c_give_the_store_pickle_load_gives(tmp_path):
                 [(1, 2, "r", "DEL")], [(None, 2, "r", "DEL", "chr1")], {"a": 1}, [(float("nan"), 2, "r", "DEL", "chr1")],
                 [(1 << 70, 2, "r", "DEL", "chr1")]):
         assert cn.pickle_table(pickle.dumps(bad), 0, 5, (0, 1), (2,)) is None, bad
-    with pytest.raises(ValueError):
-        cn.pickle_table(pickle.dumps([(i, 2, "r", "DEL", "chr1") for i in range(10)])[:-9], 0, 5, (0, 1), (2,))          # truncated
+    # a truncated stream is never accepted: declined (its FRAME runs past the buffer: pickle.load then says what is wrong) or refused
+    for proto in (2, 4):
+        trunc = pickle.dumps([(i, 2, "r", "DEL", "chr1") for i in range(10)], protocol=proto)[:-9]
+        try:
+            got = cn.pickle_table(trunc, 0, 5, (0, 1), (2,))
+        except ValueError:
+            got = None
+        assert got is None
     assert isinstance(SpanList(b"abcd", [0, 2], [2, 2])[-1], str) and SpanList(b"abcd", [0, 2], [2, 2])[0:2] == ["ab", "cd"]
 
 
@@ -519,3 +532,45 @@ def test_random_workloads_sharded_over_2_to_8_ranks_merge_to_the_unsharded_rows(
             cuts += sum(1 for us in plan for u in us if u[2] > 1)
             assert shard.merge_rows([stage(u) for u in plan]) == full, (it, world)
     assert cuts > 500
+
+
+def test_pickle_walker_accepts_nothing_that_pickle_rejects():
+    """differential fuzz of _cols_native.pickle_table against pickle.loads: single-byte corruptions of a task's pickled list in
+    protocols 2 / 4 / 5.  The walker may decline (None: resolve._store_for then lets pickle.load read the block), it must never
+    ACCEPT a stream that pickle itself rejects - a FRAME that runs past the buffer, a string payload that is not UTF-8 (r04: the
+    walker ignored frame lengths and decoded strings late or never)."""
+    import random
+    import signal
+    from cutesv_amd import _cols_native as cn
+    rng = random.Random(11)
+    rows = [(1000 + i * 7, 40 + i % 13, ("read_%d_é" % i) if i % 50 == 0 else "read_%d" % i, "ACGT" * (i % 9 + 1), "INS", "1") for i in range(200)]
+
+    def on_alarm(*_):
+        raise TimeoutError()
+    old = signal.signal(signal.SIGALRM, on_alarm)
+    both = walker_only = 0
+    try:
+        for proto in (2, 4, 5):
+            blob = pickle.dumps(rows, protocol=proto)
+            for _ in range(1500):
+                b = bytearray(blob)
+                b[rng.randrange(len(b))] = rng.randrange(256)
+                b = bytes(b)
+                try:
+                    ok_w = cn.pickle_table(b, 0, 6, (0, 1), (2, 3, 4, 5)) is not None
+                except ValueError:
+                    ok_w = False
+                if not ok_w:
+                    continue                                   # (declined: nothing to compare)
+                signal.alarm(5)
+                try:
+                    ok_p = isinstance(pickle.loads(b), list)
+                except BaseException:                          # noqa: BLE001  (whatever pickle raises on garbage, a time-out included)
+                    ok_p = False
+                finally:
+                    signal.alarm(0)
+                both += ok_p
+                walker_only += not ok_p
+    finally:
+        signal.signal(signal.SIGALRM, old)
+    assert walker_only == 0 and both > 500, (walker_only, both)
