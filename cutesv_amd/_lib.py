@@ -27,6 +27,8 @@ SYMBOLS = [
     ("csv_batch_run", C.c_int, [C.c_void_p, C.POINTER(_abi.RunStats)]),
     ("csv_batch_download", C.c_int, [C.c_void_p, C.POINTER(_abi.BatchOut)]),
     ("csv_ctx_sync", C.c_int, [C.c_void_p]),
+    ("csv_batch_publish_async", C.c_int, [C.c_void_p, C.POINTER(_abi.BatchOut)]),
+    ("csv_batch_publish_wait", C.c_int, [C.c_void_p, C.POINTER(C.POINTER(_abi.BatchOut))]),
     ("csv_batch_reads_mode", C.c_int, [C.c_void_p]),
     ("csv_batch_validate", C.c_int, [C.c_void_p]),
     ("csv_batch_info", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64)]),

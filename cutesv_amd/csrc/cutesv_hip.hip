@@ -124,6 +124,7 @@ struct csv_ctx {
     Buf t_rec, t_rec0;
     Buf sc_k, sc_x, sc_v1, sc_v2, sc_v3, sc_v4, sc_v5;
     Buf o_rec, o_supsig, o_suprid, allele_id;
+    Buf o_rec2, o_supsig2;                     // the second result arena (runs alternate: a publish may still read the other one)
     Buf reads_off, r_start, r_end, r_primary, r_id, s_start, s_end, s_idp, cmax, cfirst, bfirst, span_len, maxlen, gt_over, gt_huge, gt_pool, contig_len;
     Buf ro_tcnt, ro_ent, ro_table, ro_tblk;
     std::vector<int> h_tblk;                   // per tile of the reads table: the first chromosome block that begins at or after it
@@ -161,6 +162,16 @@ struct csv_ctx {
     bool     reads_general = false;            // this batch's reads table needs the general sort (found out by a first run)
     i64      sqrt_n = 0;                       // entries of sqrt_tab (grown to the longest segment seen: an allele is never larger)
     bool     copies_pending = false;           // csv_cluster_batch: the column copies are still in flight behind ev_copy[0] / [1]
+    // pipelined delivery (csv_batch_publish_async): runs alternate between two result arenas {call records, support list,
+    // counters}; the k_publish of run k reads arena k & 1 on its own stream while run k + 1 fills the other one
+    hipStream_t pub = nullptr;
+    hipEvent_t  ev_run[2] = {}, ev_pub[2] = {};
+    int         parity = 0;                    // arena of the last run
+    struct Pend { csv_batch_out* out = nullptr; bool live = false; } pend[2];
+    int         pend_order[2] = {0, 0}, n_pend = 0;      // arenas with a publish in flight, oldest first
+    bool        settled = false;               // a run of this upload has been downloaded synchronously (reads mode final, capacities known)
+    char*       h_pub = nullptr;               // page-locked landing zones of the asynchronous publishes: 2 x {counters 256 B, status words}
+    size_t      h_pub_cap = 0;
     bool     lazy_pending = false;             // gate-first call: this upload's first run still has to fetch the gated rows from the caller's columns
     bool     partial_cols = false;             // ... and its device columns hold only the rows the kernels read (csv_batch_validate refuses)
     i64      lazy_bytes = 0;                   // bytes the bulk copy of this upload did NOT send (measurement aid: csv_batch_lazy_info)
@@ -368,6 +379,9 @@ int csv_ctx_create(int device_id, csv_ctx** out)
         }
     }
     for (auto& s2 : c->copy) if (hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) != hipSuccess) { delete c; return CSV_E_HIP; }
+    if (hipStreamCreateWithFlags(&c->pub, hipStreamNonBlocking) != hipSuccess) { delete c; return CSV_E_HIP; }
+    for (int q = 0; q < 2; q++)
+        if (hipEventCreateWithFlags(&c->ev_run[q], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_pub[q], hipEventDisableTiming) != hipSuccess) { delete c; return CSV_E_HIP; }
     if (hipEventCreateWithFlags(&c->ev_init, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_sel, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_reads, hipEventDisableTiming) != hipSuccess) { delete c; return CSV_E_HIP; }
@@ -381,7 +395,7 @@ int csv_ctx_create(int device_id, csv_ctx** out)
             else (void)hipHostFree(hf);
         }
     }
-    if (reserve(c, c->cnt, sizeof(DevCounters)) || reserve(c, c->rstate, sizeof(ReadsState)) || pin_reserve(c, 1 << 20) || sqrt_table(c, SQRT_TAB)) {
+    if (reserve(c, c->cnt, 512) || reserve(c, c->rstate, sizeof(ReadsState)) || pin_reserve(c, 1 << 20) || sqrt_table(c, SQRT_TAB)) {
         delete c;
         return CSV_E_HIP;
     }
@@ -400,6 +414,9 @@ void csv_ctx_destroy(csv_ctx* c)
     if (c->arena_rb.base) (void)hipFree(c->arena_rb.base);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     if (c->h_flag) (void)hipHostFree((void*)c->h_flag);
+    if (c->h_pub) (void)hipHostFree(c->h_pub);
+    for (int q = 0; q < 2; q++) { if (c->ev_run[q]) (void)hipEventDestroy(c->ev_run[q]); if (c->ev_pub[q]) (void)hipEventDestroy(c->ev_pub[q]); }
+    if (c->pub) (void)hipStreamDestroy(c->pub);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->ev_aux) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->ev_copy) if (e) (void)hipEventDestroy(e);
@@ -453,7 +470,8 @@ namespace {
 int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sync, bool lazy_ok)
 {
     if (!c || !in) return CSV_E_INVALID;
-    c->uploaded = c->ran = false;
+    if (c->n_pend) { (void)hipStreamSynchronize(c->pub); c->n_pend = 0; c->pend[0].live = c->pend[1].live = false; }      // (results nobody waited for)
+    c->uploaded = c->ran = false; c->settled = false; c->parity = 0;
     c->lazy_pending = c->partial_cols = false; c->lazy_bytes = 0;
     c->reads_general = false;
     c->reads_ready = false;
@@ -571,6 +589,7 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
     PL(t_rec, (W + 1) * sizeof(TmpRec)); PL(t_rec0, (cap_items + 1) * sizeof(TmpRec));
     PL(sc_k, SC * 8); PL(sc_x, SC * 8); PL(sc_v1, SC * 4); PL(sc_v2, SC * 4); PL(sc_v3, SC * 4); PL(sc_v4, SC * 4); PL(sc_v5, SC * 4);
     PL(o_rec, (cap_tmp + 1) * sizeof(CallRec)); PL(o_supsig, (W + 1) * 4); PL(o_suprid, (W + 1) * 4);
+    PL(o_rec2, (cap_tmp + 1) * sizeof(CallRec)); PL(o_supsig2, (W + 1) * 4);
     if (have_tab) { PL(reads_off, (in->n_chrom + 1) * 8); PL(contig_len, (in->n_chrom + 1) * 8); }
     if (R > 0) {
         PL(gt_over, (cap_tmp + 2) * 4); PL(gt_huge, (cap_tmp + 2) * 4); PL(gt_pool, pool_n * 4);
@@ -857,8 +876,17 @@ int run_impl(csv_ctx* c, csv_run_stats* stats)
             fprintf(stderr, " %s\n", hipGetErrorString(e_)); fflush(stderr);                               \
         }                                                                                                  \
     } while (0)
+    // this run's result arena: the other one than the last run's (whose publish may still be reading it on the publish stream)
+    {
+        const int p = c->parity ^ 1;
+        if (c->pend[p].live) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_pub[p], 0));       // (launched two runs ago)
+        c->parity = p;
+        B.cnt = (DevCounters*)((char*)c->cnt.p + 256 * p);
+        B.o_rec = p ? dp<CallRec>(c->o_rec2) : dp<CallRec>(c->o_rec);
+        B.o_supsig = p ? dp<int>(c->o_supsig2) : dp<int>(c->o_supsig);
+    }
     HIP_TRY(c, mark());
-    if (W == 0) HIP_TRY(c, hipMemsetAsync(c->cnt.p, 0, sizeof(DevCounters), st));      // otherwise k_chain_count zeroes them
+    if (W == 0) HIP_TRY(c, hipMemsetAsync(B.cnt, 0, sizeof(DevCounters), st));      // otherwise k_chain_count zeroes them
     HIP_TRY(c, mark());                                                              // slot 0: init (empty batch only)
     // Plain runs fork the independent kernels onto side streams (joined again before k_items_scan /
     // k_genotype); instrumented runs (stats != NULL) and CSV_DEBUG keep everything on the main stream so
@@ -1070,7 +1098,7 @@ int read_counters(csv_ctx* c)
 {
     hipStream_t st = c->stream;
     for (int attempt = 0; attempt < 2; attempt++) {
-        HIP_TRY(c, hipMemcpyAsync(c->h_pin, c->cnt.p, sizeof(DevCounters), hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipMemcpyAsync(c->h_pin, c->B.cnt, sizeof(DevCounters), hipMemcpyDeviceToHost, st));
         HIP_TRY(c, hipStreamSynchronize(st));
         memcpy(&c->h_cnt, c->h_pin, sizeof(DevCounters));
         {   // the reads-order state of the upload lives outside the per-run counters
@@ -1198,6 +1226,7 @@ int csv_batch_download(csv_ctx* c, csv_batch_out* out)
 {
     if (!c || !out) return CSV_E_INVALID;
     if (!c->ran) return fail(c, CSV_E_STATE, "csv_batch_download before csv_batch_run");
+    if (c->n_pend) return fail(c, CSV_E_STATE, "csv_batch_download while %d asynchronous publish(es) are in flight: csv_batch_publish_wait first", c->n_pend);
     const bool nosup = (out->flags & CSV_OUT_NO_SUPPORT_LIST) != 0, coord32 = (out->flags & CSV_OUT_COORD_I32) != 0;
     if (!nosup && ((out->support_sig != nullptr) == (out->support_sig32 != nullptr) || !out->support_off))
         return fail(c, CSV_E_INVALID, "csv_batch_out: support_off and exactly one of support_sig / support_sig32 must be given (or CSV_OUT_NO_SUPPORT_LIST)");
@@ -1239,6 +1268,7 @@ int csv_batch_download(csv_ctx* c, csv_batch_out* out)
         const int rc = read_counters(c);
         if (rc) return rc;
     }
+    c->settled = true;
     const DevCounters& k = c->h_cnt;
     out->n_calls = k.n_calls; out->n_support = k.n_support; out->n_clusters = k.n_clusters;
     if (k.error & ERR_READS_UNSORTED) return fail(c, CSV_E_UNSORTED, "a reads block is not sorted by start although CSV_IN_READS_SORTED was set");
@@ -1309,6 +1339,82 @@ int csv_batch_download(csv_ctx* c, csv_batch_out* out)
     if (sup_stage) for (size_t i = 0; i < ns; i++) out->support_sig[i] = sup_stage[i];
     if (out->seg_status && S) memcpy(out->seg_status, c->h_pin + o_err, (size_t)S * 4);
     return CSV_OK;
+}
+
+// ---- pipelined delivery: the result of run k crosses PCIe while run k + 1 computes
+static int result_status(csv_ctx* c, const DevCounters& k, csv_batch_out* out, bool nosup)
+{
+    out->n_calls = k.n_calls; out->n_support = k.n_support; out->n_clusters = k.n_clusters;
+    if (k.error & ERR_READS_UNSORTED) return fail(c, CSV_E_UNSORTED, "a reads block is not sorted by start although CSV_IN_READS_SORTED was set");
+    if (k.error & ERR_CLUSTER_TOO_BIG) return fail(c, CSV_E_INVALID, "a chained cluster has more than %lld signatures", (long long)MAX_CLUSTER);
+    if (k.error & ERR_KEY_RANGE) return fail(c, CSV_E_INVALID, "a read id is negative, or a read end is negative or >= 2^40");
+    if (k.error & ERR_COVER_OVERFLOW) return fail(c, CSV_E_INVALID, "internal: the genotype hash pool was too small");
+    if (k.error & ERR_TRA_CHROM) return fail(c, CSV_E_INVALID, "a TRA call names a mate chromosome outside the reads table");
+    if (k.error & ERR_TMP_OVERFLOW) return fail(c, CSV_E_INVALID, "internal: temp call capacity exceeded");
+    if (k.n_calls > out->cap_calls || (!nosup && k.n_support > out->cap_support))
+        return fail(c, CSV_E_CAPACITY, "need %d calls / %lld supports", k.n_calls, (long long)k.n_support);
+    return CSV_OK;
+}
+
+int csv_batch_publish_async(csv_ctx* c, csv_batch_out* out)
+{
+    if (!c || !out) return CSV_E_INVALID;
+    if (!c->ran) return fail(c, CSV_E_STATE, "csv_batch_publish_async before csv_batch_run");
+    if (!c->settled) return fail(c, CSV_E_STATE, "csv_batch_publish_async needs one csv_batch_download of this upload first (it settles how the reads table is ordered and what the result needs)");
+    if (c->B.per_sig || out->cluster_id || out->allele_id) return fail(c, CSV_E_INVALID, "csv_batch_publish_async delivers no per-signature outputs");
+    if (c->pend[c->parity].live) return fail(c, CSV_E_STATE, "this run's result is already being published");
+    if (c->n_pend >= 2) return fail(c, CSV_E_STATE, "two publishes in flight: csv_batch_publish_wait first");
+    const bool nosup = (out->flags & CSV_OUT_NO_SUPPORT_LIST) != 0, coord32 = (out->flags & CSV_OUT_COORD_I32) != 0;
+    if (!nosup && ((out->support_sig != nullptr) == (out->support_sig32 != nullptr) || !out->support_off))
+        return fail(c, CSV_E_INVALID, "csv_batch_out: support_off and exactly one of support_sig / support_sig32 must be given (or CSV_OUT_NO_SUPPORT_LIST)");
+    if (!out->call_seg || !out->bp1 || !out->bp2 || !out->support) return fail(c, CSV_E_INVALID, "csv_batch_out: call_seg, bp1, bp2 and support are required");
+    if (coord32 && !c->B.a.p32) return fail(c, CSV_E_INVALID, "CSV_OUT_COORD_I32 needs a batch of CSV_IN_SIG_I32 columns");
+    HIP_TRY(c, hipSetDevice(c->device));
+    PublishArgs P{};
+    if (!publish_targets(c, out, P)) return fail(c, CSV_E_INVALID, "csv_batch_publish_async writes the result in place: every array of csv_batch_out must be page-locked (csv_host_alloc / csv_host_register)");
+    const int S0 = (int)c->h_seg.size(), p = c->parity;
+    const size_t zone = (256 + (size_t)(S0 + 1) * 4 + 255) & ~(size_t)255;
+    if (2 * zone > c->h_pub_cap) {
+        if (c->n_pend) return fail(c, CSV_E_STATE, "internal: landing zones in use");
+        if (c->h_pub) { HIP_TRY(c, hipHostFree(c->h_pub)); c->h_pub = nullptr; c->h_pub_cap = 0; }
+        void* hp = nullptr;
+        if (hipHostMalloc(&hp, 2 * zone + 4096, hipHostMallocDefault) != hipSuccess) return fail(c, CSV_E_NOMEM, "hipHostMalloc for the publish landing zones failed");
+        c->h_pub = (char*)hp; c->h_pub_cap = 2 * zone + 4096;
+    }
+    void* dpub = nullptr;
+    HIP_TRY(c, hipHostGetDevicePointer(&dpub, c->h_pub, 0));
+    const size_t half = c->h_pub_cap / 2 & ~(size_t)255;
+    P.cap_calls = out->cap_calls; P.cap_support = out->cap_support; P.n_seg = S0;
+    P.h_cnt = (DevCounters*)((char*)dpub + half * p); P.h_seg_err = (int*)((char*)dpub + half * p + 256);
+    // (the run's kernels are all in the main stream's queue: an event recorded now marks their end - a plain run pays nothing for it)
+    HIP_TRY(c, hipEventRecord(c->ev_run[p], c->stream));
+    HIP_TRY(c, hipStreamWaitEvent(c->pub, c->ev_run[p], 0));
+    hipLaunchKernelGGL(k_publish, dim3(512), dim3(256), 0, c->pub, c->B, P);       // (c->B points at arena p: the last run's)
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventRecord(c->ev_pub[p], c->pub));
+    c->pend[p].out = out; c->pend[p].live = true;
+    c->pend_order[c->n_pend++] = p;
+    return CSV_OK;
+}
+
+int csv_batch_publish_wait(csv_ctx* c, csv_batch_out** done)
+{
+    if (!c) return CSV_E_INVALID;
+    if (done) *done = nullptr;
+    if (!c->n_pend) return fail(c, CSV_E_STATE, "csv_batch_publish_wait: nothing in flight");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int p = c->pend_order[0];
+    HIP_TRY(c, hipEventSynchronize(c->ev_pub[p]));
+    c->pend_order[0] = c->pend_order[1]; c->n_pend--;
+    csv_batch_out* out = c->pend[p].out;
+    c->pend[p].live = false; c->pend[p].out = nullptr;
+    if (done) *done = out;
+    const size_t half = c->h_pub_cap / 2 & ~(size_t)255;
+    DevCounters k;
+    memcpy(&k, c->h_pub + half * p, sizeof k);
+    const int S = (int)c->h_seg.size();
+    if (out->seg_status && S) memcpy(out->seg_status, c->h_pub + half * p + 256, (size_t)S * 4);
+    return result_status(c, k, out, (out->flags & CSV_OUT_NO_SUPPORT_LIST) != 0);
 }
 
 // room for `extra` more rows in the pool (grows by copying: the pool is not in an arena)

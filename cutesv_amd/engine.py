@@ -141,6 +141,25 @@ class Context:
             return res
         raise CsvError(_abi.E_CAPACITY, "capacity retry failed")
 
+    # ---- pipelined delivery (csv_batch_publish_async / _wait): run k's result crosses PCIe while run k + 1 computes
+    def publish_async(self, into):
+        """start delivering the LAST run's result into `into` (page-locked HostResult, e.g. result_buffers()); returns at once"""
+        if into.n_seg < len(self._batch.segments):
+            raise ValueError("publish_async: the result has room for %d segments, the uploaded batch has %d" % (into.n_seg, len(self._batch.segments)))
+        self._check(lib().csv_batch_publish_async(self._h, C.byref(into.c)))
+        self._inflight = getattr(self, "_inflight", [])
+        self._inflight.append(into)
+
+    def publish_wait(self):
+        """wait for the oldest delivery in flight; returns its HostResult (raises on its error status, e.g. E_CAPACITY)"""
+        done = C.POINTER(_abi.BatchOut)()
+        rc = lib().csv_batch_publish_wait(self._h, C.byref(done))
+        res = self._inflight.pop(0) if getattr(self, "_inflight", None) else None
+        self._check(rc)
+        if res is not None:
+            res.n_seg_used = len(self._batch.segments)
+        return res
+
     # ---- one shot: csv_cluster_batch (H2D, kernels and D2H overlap inside the one call)
     def cluster_batch(self, batch, per_sig=False, cap_calls=None, cap_support=None, reuse=False, no_support=False, coord32=False, fields=None):
         """reuse=True hands the C call the result arrays of this context's previous reuse=True call when they are large

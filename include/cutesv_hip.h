@@ -239,6 +239,17 @@ int csv_batch_upload(csv_ctx* ctx, const csv_batch_in* in);
 int csv_batch_run(csv_ctx* ctx, csv_run_stats* stats /* nullable */);
 int csv_batch_download(csv_ctx* ctx, csv_batch_out* out);
 int csv_ctx_sync(csv_ctx* ctx);
+/* (ABI v7) Pipelined delivery for a resident caller that runs batch after batch (or one batch again and again): the result of run
+ * k is written into the caller's page-locked arrays by the device (as csv_batch_download does) on a stream of its own WHILE run
+ * k + 1 computes - consecutive runs alternate between two result arenas on the device.  csv_batch_publish_async starts the
+ * delivery of the LAST run's result into `out` and returns at once; csv_batch_publish_wait blocks until the OLDEST delivery in
+ * flight is complete, fills n_calls / n_support / n_clusters / seg_status of its result struct - returned through `done` - and
+ * returns its status (CSV_E_CAPACITY etc.).  At most two deliveries in flight, each into arrays of its own; every array must be
+ * page-locked; no per-signature outputs; the upload must have been downloaded once synchronously before (that settles how its
+ * reads table is ordered).  The sequence  run, async(A), run, async(B), wait -> A, run, async(A), wait -> B ...  keeps the link
+ * busy under the kernels.  No counterpart in the reference (its workers return pickled rows through a pipe, MAIN:1191-1197). */
+int csv_batch_publish_async(csv_ctx* ctx, csv_batch_out* out);
+int csv_batch_publish_wait(csv_ctx* ctx, csv_batch_out** done /* nullable */);
 /* How the reads table of the last completed run was brought into start order: 0 = the caller promised sorted blocks,
  * 1 = whole sorted runs were moved (or nothing had to move), 2 = the general stable radix sort; -1 = no reads table. */
 int csv_batch_reads_mode(const csv_ctx* ctx);

@@ -1326,3 +1326,56 @@ def test_lazy_stage_equals_the_row_lists(ctx):
     slim, _ = vcf.emit_records(st, hb.segments, ctx.cluster_batch(hb, reuse=True, no_support=True, coord32=True,
                                                                   fields=("call_aux", "cipos", "cilen", "seq_pick", "dr", "gl_idx")), ref, **kw)
     assert slim == want
+
+
+@pytest.mark.parametrize("genotype", [False, True])
+def test_pipelined_delivery_equals_the_serial_download(ctx, genotype):
+    """csv_batch_publish_async / _wait: run k's result is written into the caller's page-locked arrays on a stream of its own while
+    run k + 1 computes (two result arenas on the device).  Every delivered result equals the synchronous download, whatever
+    the interleaving; the state errors are errors"""
+    st = synth.small_mixed(seed=61, genotype=genotype, n_loci=300).pinned()
+    p = Params.ont(genotype=genotype)
+    hb = st.host_batch(st.tasks(), p)
+    want = _oracle().cluster_batch(hb, per_sig=False).trimmed()
+    ctx.upload(hb, per_sig=False)
+    ctx.run()
+    a, b = ctx.result_buffers(), ctx.result_buffers()
+    with pytest.raises(engine.CsvError):
+        ctx.publish_async(a)                               # (not before one synchronous download of the upload)
+    assert_soa_equal(ctx.download().trimmed(), want, store=st)
+    with pytest.raises(engine.CsvError):
+        ctx.publish_wait()                                 # (nothing in flight)
+    bufs = [a, b]
+    ctx.run(); ctx.publish_async(bufs[0])
+    for k in range(1, 12):
+        ctx.run(); ctx.publish_async(bufs[k & 1])
+        done = ctx.publish_wait()
+        assert done is bufs[(k - 1) & 1]
+        assert_soa_equal(done.trimmed(), want, store=st)
+        for arr in done.arrays.values():                   # (the next delivery into these arrays must really write them)
+            if arr is not None and arr.dtype != np.uint8:
+                arr[...] = -7
+    with pytest.raises(engine.CsvError):
+        ctx.download()                                     # (a delivery is in flight)
+    assert_soa_equal(ctx.publish_wait().trimmed(), want, store=st)
+    # three in a row without waiting: the third is refused; slim results travel the same way
+    slim = [ctx.result_buffers(no_support=True, coord32=True, fields=("cipos", "cilen", "dr", "gl_idx")) for _ in range(2)]
+    ctx.run(); ctx.publish_async(slim[0]); ctx.run(); ctx.publish_async(slim[1])
+    ctx.run()
+    with pytest.raises(engine.CsvError):
+        ctx.publish_async(a)
+    for q in range(2):
+        t = ctx.publish_wait().trimmed()
+        for name in ("call_seg", "bp1", "bp2", "support", "cipos", "cilen", "dr", "gl_idx"):
+            assert np.array_equal(t[name].astype(np.int64), want[name].astype(np.int64)), name
+    # too small a result: the status of THAT delivery
+    tiny = ctx.result_buffers(cap_calls=4, cap_support=4)
+    ctx.run(); ctx.publish_async(tiny)
+    with pytest.raises(engine.CsvError) as e:
+        ctx.publish_wait()
+    assert e.value.code == _abi.E_CAPACITY
+    # pageable arrays cannot be written in place
+    ctx.run()
+    with pytest.raises(engine.CsvError):
+        ctx.publish_async(ctx.result_buffers(pinned=False))
+    assert_soa_equal(ctx.download().trimmed(), want, store=st)
