@@ -2417,7 +2417,10 @@ template <int SW, bool NARROW> __device__ __forceinline__ void indel_unit(const 
         const bool pass = live && n >= msr;
         int erank = 0, soff = 0, npass = 0;
         const u64 starts = fmask | (NSUB == 4 ? 0x0001000100010001ull : NSUB == 2 ? 0x0000000100000001ull : 1ull);   // allele starts of every sub-wave, absolute lanes
-        for (u64 mk = CSV_ABL(5) ? 0ull : starts; mk; mk &= mk - 1) {
+        // (no allele split anywhere in the wavefront - three units in four on a 30x genome -: every cluster's one allele is
+        // first in line, nothing in front of it: the walk over the allele starts has nothing to find)
+        if (fmask == 0) npass = 1;
+        else for (u64 mk = CSV_ABL(5) ? 0ull : starts; mk; mk &= mk - 1) {
             const int t = __ffsll((long long)mk) - 1;
             const int nt = __builtin_amdgcn_readlane(n, t);
             const int tl = t & (SW - 1);
@@ -2447,19 +2450,17 @@ template <int SW, bool NARROW> __device__ __forceinline__ void indel_unit(const 
             const double resid = fma(-(double)n, pmean, (double)sp);              // sum - n * fl(sum / n): < 0 <=> the mean was rounded up
             const unsigned t = resid < 0.0 ? (nd < 0) : (resid > 0.0 ? (nd > 0) : 0);
             unsigned bk = ((2u * an + t) << 6) | (unsigned)r;                    // (distance, side, rank): one 32-bit minimum
-            if (SW == 16) {                                  // a sub-wave is one DPP row: row_shr moves, no LDS round trips
-#define CSV_MINSTEP(CTRL, D) { const unsigned o = (unsigned)dpp_i32<CTRL, 0xf>((int)bk, (int)bk); if (i >= D && o < bk) bk = o; }
+            // segmented prefix minimum over the allele (the minimum of the whole allele arrives at its last rank): inside a DPP row
+            // of 16 lanes with row_shr moves, then the row before through row_bcast:15 / row_bcast:31 - a lane whose allele began
+            // before its row takes the (complete) value of that row's last lane, which belongs to the same allele.  All DPP: no
+            // LDS round trip in a chain of five or six dependent steps (r04: ds_bpermute per step for the 32- and 64-lane units).
+            {
+                const int q = lane & 15;
+#define CSV_MINSTEP(CTRL, D) { const unsigned o = (unsigned)dpp_i32<CTRL, 0xf>((int)bk, (int)bk); if (i >= D && q >= D && o < bk) bk = o; }
                 CSV_MINSTEP(0x111, 1) CSV_MINSTEP(0x112, 2) CSV_MINSTEP(0x114, 4) CSV_MINSTEP(0x118, 8)
 #undef CSV_MINSTEP
-            } else {
-                // value of lane - d: ds_bpermute adds its immediate offset to the byte address and ignores the bits above the lane
-                // (ISA: src_lane = (addr + offset) / 4 mod 64), so ONE address register serves every distance.  (Computed
-                // addresses - (lane - d) * 4 & 252 - were hoisted out of the unit loop by the compiler: six VGPRs held for the
-                // whole kernel, three of them spilled to scratch at six wavefronts per SIMD.)
-                const int l4 = lane << 2;
-#define CSV_MINB(D) if (D < SW) { const unsigned o = (unsigned)bperm_off<256 - 4 * D>(l4, (int)bk); if (i >= D && o < bk) bk = o; }
-                CSV_MINB(1) CSV_MINB(2) CSV_MINB(4) CSV_MINB(8) CSV_MINB(16) CSV_MINB(32)
-#undef CSV_MINB
+                if (SW >= 32) { const unsigned o = (unsigned)dpp_i32<0x142, 0xa>((int)bk, (int)bk); if ((lane & 16) && i > q && o < bk) bk = o; }
+                if (SW == 64) { const unsigned o = (unsigned)dpp_i32<0x143, 0xc>((int)bk, (int)bk); if ((lane & 32) && i > (lane & 31) && o < bk) bk = o; }
             }
             search = bperm((hb | (bperm(e14, (int)bk) & (SW - 1))) << 2, pos);
         } else if (!__ballot(pass && keep < n)) {
