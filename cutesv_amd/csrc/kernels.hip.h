@@ -78,7 +78,7 @@ struct __attribute__((aligned(16))) TmpRec {
     i64 bp1, bp2;                     //  0
     i64 search, pick;                 // 16
     int support, cipos, cilen, supoff;   // 32
-    int valid, nslots, aux0, pad2;    // 48 (nslots / aux0: slot 0 only)
+    int valid, nslots, aux0, pad2;    // 48 (valid: bit 0 the call exists, bit 1 `pick` is a row in w space - k_emit adds the segment's offset; nslots / aux0: slot 0 only)
 };
 static_assert(sizeof(TmpRec) == 64, "TmpRec layout");
 __device__ __forceinline__ void tmp_write(TmpRec* t, i64 bp1, i64 bp2, i64 search, i64 pick, int support, int cipos, int cilen, int supoff, int valid,
@@ -2243,10 +2243,10 @@ template <int SW, bool NARROW> __device__ __forceinline__ void indel_unit(const 
         if (CSV_ABL(6)) { if (act && sl == 0) item_done(B, j, 0, (int)(U.a + U.b + U.rid + U.aux)); break; }      // loads only
         // segment scalars: issued here, first needed after the de-duplication (the table is a few KB and cache resident)
         int rc = 0x7fffffff, msr = 0;
-        double ratio = 0.0;
+        double ratio = 0.0, rr0 = 1.0;
         if (act) {
             const csv_segment& sg = B.seg[k];
-            rc = sg.read_count; msr = sg.min_support_reads; ratio = sg.diff_ratio;
+            rc = sg.read_count; msr = sg.min_support_reads; ratio = sg.diff_ratio; rr0 = sg.remain_reads_ratio;
         }
         const bool in = act && sl < m;
         const C a = U.a, b = U.b;
@@ -2300,6 +2300,9 @@ template <int SW, bool NARROW> __device__ __forceinline__ void indel_unit(const 
                 }
             }
         }
+        // remain_reads_ratio (INDEL:46-47, 169) is 1 unless the caller said otherwise: then every member of an allele is kept and
+        // the ratio itself is never needed again - one flag instead of a double held (or a dependent load issued) mid-unit
+        const bool rr_full = !(rr0 < 1.0);
         const bool rep = in && (F == sl);
         const u64 rm = sub_ballot<SW>(rep, g);
         const int U_ = __popcll(rm);
@@ -2431,9 +2434,12 @@ template <int SW, bool NARROW> __device__ __forceinline__ void indel_unit(const 
         }
 
         // ---- statistics, all alleles at once
-        double rr = 1.0;
-        if (act) { rr = B.seg[k].remain_reads_ratio; if (rr > 1) rr = 1; }        // INDEL:46-47 (cache resident; loaded here, not held since the top)
-        int keep = (int)(rr * (double)n); if (keep < 1) keep = 1;                 // INDEL:169
+        int keep = n;
+        if (__ballot(act && !rr_full)) {                                          // (a --remain_reads_ratio below 1: the ratio, now)
+            double rr = 1.0;
+            if (act) { rr = B.seg[k].remain_reads_ratio; if (rr > 1) rr = 1; }    // INDEL:46-47
+            keep = (int)(rr * (double)n); if (keep < 1) keep = 1;                 // INDEL:169
+        }
         const double rcp_n = B.rcp_tab[n & (SQRT_TAB - 1)];
         const double pmean = div_by((double)sp, (double)n, rcp_n), lmean = div_by((double)sln, (double)n, rcp_n);
         double bp = pmean, siglen = lmean;
@@ -2557,8 +2563,12 @@ template <int SW, bool NARROW> __device__ __forceinline__ void indel_unit(const 
         if (pass && !CSV_ABL(4)) B.sup_tmp[s + soff + i] = s + chp;                     // INDEL:205, 416
         const bool head = pass && i == 0;
         if (head && !CSV_ABL(4)) {
-            if (type == CSV_INS && valid) pick = B.seg[k].sig_begin + ((i64)s - B.woff[k]) + pick_ch;      // global signature index (w -> caller's row)
-            tmp_write(tmp_slot(B, j, s, erank), bp_i, (i64)siglen, search_i, pick, n, cip, cil, soff, valid ? 1 : 0, npass, aux0);
+            // the picked signature as its row in w space; k_emit, which has the segment's offsets at hand for the support lists anyway,
+            // turns it into the caller's global index (bit 1 of `valid`).  (Here that was two dependent loads - the segment's
+            // sig_begin, its woff - and 64-bit sums at the very end of a unit, with every lane of the wavefront waiting.)
+            int vflag = valid ? 1 : 0;
+            if (type == CSV_INS && valid) { pick = (i64)(s + pick_ch); vflag |= 2; }
+            tmp_write(tmp_slot(B, j, s, erank), bp_i, (i64)siglen, search_i, pick, n, cip, cil, soff, vflag, npass, aux0);
         }
         const int ncalls = __popcll(sub_ballot<SW>(head && valid, g));
         const int nsup = bperm(last4, sub_scan_i32<SW>((head && valid) ? n : 0));
@@ -2711,7 +2721,8 @@ __device__ __forceinline__ void emit_item_serial(const DevBatch& B, int j, i64 b
         TmpRec tr;
         tr.valid = 0;
         if (in) tr = *tmp_slot(B, j, s, c0 + lane);
-        const int valid = in ? tr.valid : 0;
+        const int valid = in ? (tr.valid & 1) : 0;
+        if (in && (tr.valid & 2)) tr.pick += gs;                            // (a w-space pick of the register tier -> the caller's row)
         const int nsup = valid ? tr.support : 0;
         const int tso = valid ? tr.supoff : 0;
         const u64 mk = __ballot(valid);
@@ -2794,9 +2805,10 @@ __global__ __launch_bounds__(256) void k_emit(DevBatch B)
         // the segment scalars
         if (mine && l8 > 0) { const int4* r = (const int4*)&B.t_rec[s + l8]; q0 = r[0]; q1 = r[1]; q2 = r[2]; q3 = r[3]; }
         int valid = 0, nsup = 0, tso = 0, ci = 0, cl = 0;
+        bool pick_w = false;
         i64 bp1 = 0, bp2 = 0, srch = 0, pick = 0;
         if (mine) {
-            valid = q3.x; nsup = q2.x; tso = q2.w; ci = q2.y; cl = q2.z;
+            valid = q3.x & 1; pick_w = (q3.x & 2) != 0; nsup = q2.x; tso = q2.w; ci = q2.y; cl = q2.z;
             bp1 = ((i64)q0.y << 32) | (unsigned)q0.x; bp2 = ((i64)q0.w << 32) | (unsigned)q0.z;
             srch = ((i64)q1.y << 32) | (unsigned)q1.x; pick = ((i64)q1.w << 32) | (unsigned)q1.z;
         }
@@ -2815,6 +2827,7 @@ __global__ __launch_bounds__(256) void k_emit(DevBatch B)
             ghdr = make_int4(sgk.chrom, sgk.svtype | (sgk.genotype ? 0x100 : 0), (int)(sgk.gt_bias & 0xffffffffll), (int)(sgk.gt_bias >> 32));
         }
         const bool gtseg = (ghdr.y & 0x100) != 0;
+        if (pick_w) pick += gs;                               // (the register tier's picks are rows in w space: gs + w = the caller's row)
         if (!valid) { nsup = 0; tso = 0; }
         const u64 mk = __ballot(valid);
         const u64 gmask = 0xffull << (g * 8);
