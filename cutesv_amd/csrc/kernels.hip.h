@@ -1178,19 +1178,20 @@ template <int E, class KP> __device__ __forceinline__ bool bitonic_wave_mem32(KP
 }
 
 // S: the keys are (value << S) | index, index < P (S = 0: unknown layout, always the 64-bit network)
-template <int BLOCK, class KP> __device__ void bitonic_sort(KP K, int P, int S = 0)
+// ME: the largest P / 64 the caller can have (one-wavefront tiers: their CAP / 64) - the wider instantiations are not compiled in
+template <int BLOCK, class KP, int ME = 4> __device__ void bitonic_sort(KP K, int P, int S = 0)
 {
     if (BLOCK == 64 && P <= 256) {                    // callers synchronised before; the results are visible after this barrier
         bool done = false;
         if (S > 0 && !CSV_ABL(19)) {
             if (P <= 64) done = bitonic_wave_mem32<1>(K, P, S);
-            else if (P <= 128) done = bitonic_wave_mem32<2>(K, P, S);
-            else done = bitonic_wave_mem32<4>(K, P, S);
+            else if (ME >= 2 && P <= 128) done = bitonic_wave_mem32<(ME >= 2 ? 2 : 1)>(K, P, S);
+            else if (ME >= 4) done = bitonic_wave_mem32<(ME >= 4 ? 4 : 1)>(K, P, S);
         }
         if (!done) {
             if (P <= 64) bitonic_wave_mem<1>(K, P);
-            else if (P <= 128) bitonic_wave_mem<2>(K, P);
-            else bitonic_wave_mem<4>(K, P);
+            else if (ME >= 2 && P <= 128) bitonic_wave_mem<(ME >= 2 ? 2 : 1)>(K, P);
+            else if (ME >= 4) bitonic_wave_mem<(ME >= 4 ? 4 : 1)>(K, P);
         }
         __syncthreads();
         return;
@@ -1383,12 +1384,12 @@ __device__ __forceinline__ void item_none(const DevBatch& B, int j)
 
 // phase A: sort by (read id, local index); returns the number of distinct reads.
 // Leaves K sorted and V2[q] = local index at sorted position q.
-template <int BLOCK, bool LDS> __device__ int sort_by_read(const DevBatch& B, const ItemCtx& it, const ArraysT<LDS>& A, i64* red)
+template <int BLOCK, bool LDS, int ME = 4> __device__ int sort_by_read(const DevBatch& B, const ItemCtx& it, const ArraysT<LDS>& A, i64* red)
 {
     for (int i = threadIdx.x; i < it.P; i += BLOCK)
         A.K[i] = i < it.m ? (((u64)(unsigned)B.rid[it.s + i]) << 32) | (unsigned)i : PAD_KEY;
     __syncthreads();
-    bitonic_sort<BLOCK>(A.K, it.P, 32);
+    bitonic_sort<BLOCK, decltype(A.K), ME>(A.K, it.P, 32);
     int runs = 0;
     for (int q = threadIdx.x; q < it.m; q += BLOCK) {
         const u64 k = A.K[q];
@@ -1417,10 +1418,10 @@ template <int BLOCK> __device__ bool keys_out_of_range(const DevBatch& B, const 
 // into X, sequence lengths into V5 (free on this path), positions kept in registers until the lengths are dead, then into X -
 // and every later step indexes LDS.  The unstaged form goes back to global memory for the lengths (twice), the positions and
 // the sequence lengths, each a dependent round trip of a kernel that is a chain of ~10 of them per cluster.
-template <int BLOCK, bool LDS, bool SMALLN, bool STAGED = false> __device__ void refine_indel(const DevBatch& B, const ItemCtx& it, const ArraysT<LDS>& A, i64* red, int* ired)
+template <int BLOCK, bool LDS, bool SMALLN, bool STAGED = false, int ME = 4> __device__ void refine_indel(const DevBatch& B, const ItemCtx& it, const ArraysT<LDS>& A, i64* red, int* ired)
 {
     static_assert(!STAGED || (BLOCK == 64 && LDS && SMALLN), "the staged form is the one-wavefront LDS tier");
-    constexpr int E = 4;                                                    // elements per lane of the staged form (m <= 256)
+    constexpr int E = ME;                                                   // elements per lane of the staged form (m <= 64 ME: the tier's capacity)
     const csv_segment& sg = B.seg[it.k];
     const int m = it.m, P = it.P, s = it.s, ib = it.ib;
     const u64 imask = (1ull << ib) - 1ull;
@@ -1452,7 +1453,7 @@ template <int BLOCK, bool LDS, bool SMALLN, bool STAGED = false> __device__ void
             if (i < m) { A.X[i] = st_b[e]; A.V5[i] = st_x[e]; }
         }
         __syncthreads();
-        bitonic_sort<BLOCK>(A.K, P, 32);
+        bitonic_sort<BLOCK, decltype(A.K), ME>(A.K, P, 32);
         int runs = 0;
         for (int q = threadIdx.x; q < m; q += BLOCK) {
             const u64 k = A.K[q];
@@ -1463,7 +1464,7 @@ template <int BLOCK, bool LDS, bool SMALLN, bool STAGED = false> __device__ void
         __syncthreads();
     } else {
         if (keys_out_of_range<BLOCK>(B, it, red)) { item_none(B, it.j); return; }
-        U = sort_by_read<BLOCK, LDS>(B, it, A, red);
+        U = sort_by_read<BLOCK, LDS, ME>(B, it, A, red);
     }
     if (U < sg.read_count) { item_none(B, it.j); return; }                  // INDEL:133-134
 
@@ -1499,7 +1500,7 @@ template <int BLOCK, bool LDS, bool SMALLN, bool STAGED = false> __device__ void
             if (q < m) A.X[q] = st_a[e];                                    // positions by local index
         }
         __syncthreads();
-        bitonic_sort<BLOCK>(A.K, P, ib);    // == stable sort by length over first-appearance order (INDEL:136)
+        bitonic_sort<BLOCK, decltype(A.K), ME>(A.K, P, ib);    // == stable sort by length over first-appearance order (INDEL:136)
         // rank order: a-values -> K, lengths -> X, kept local index -> V1
         i64 av[E], lv[E]; int cv[E];
 #pragma unroll
@@ -1543,7 +1544,7 @@ template <int BLOCK, bool LDS, bool SMALLN, bool STAGED = false> __device__ void
     __syncthreads();
     for (int q = threadIdx.x; q < P; q += BLOCK) A.K[q] = (u64)A.X[q];
     __syncthreads();
-    bitonic_sort<BLOCK>(A.K, P, ib);    // == stable sort by length over first-appearance order (INDEL:136)
+    bitonic_sort<BLOCK, decltype(A.K), ME>(A.K, P, ib);    // == stable sort by length over first-appearance order (INDEL:136)
 
     // rank order: a-values -> K, lengths -> X, kept local index -> V1
     for (int r = threadIdx.x; r < U; r += BLOCK) {
@@ -1699,13 +1700,13 @@ template <bool LDS> __device__ __forceinline__ void write_first_seen(const DevBa
 
 // ---- DUP / INV / TRA: generate_dup_cluster (DUP:79-131), generate_semi_inv_cluster (INV:101-203),
 //      generate_semi_tra_cluster (TRA:106-254)
-template <int BLOCK, bool LDS> __device__ void refine_pair(const DevBatch& B, const ItemCtx& it, const ArraysT<LDS>& A, i64* red, int* ired)
+template <int BLOCK, bool LDS, int ME = 4> __device__ void refine_pair(const DevBatch& B, const ItemCtx& it, const ArraysT<LDS>& A, i64* red, int* ired)
 {
     const csv_segment& sg = B.seg[it.k];
     const int m = it.m, P = it.P, s = it.s, type = sg.svtype, ib = it.ib;
     const u64 imask = (1ull << ib) - 1ull;
     if (keys_out_of_range<BLOCK>(B, it, red)) { item_none(B, it.j); return; }
-    const int U = sort_by_read<BLOCK, LDS>(B, it, A, red);                       // V2 = (read id, index) order
+    const int U = sort_by_read<BLOCK, LDS, ME>(B, it, A, red);                   // V2 = (read id, index) order
     if (U < sg.read_count) { item_none(B, it.j); return; }                  // DUP:82-84, INV:106-109, TRA:128-129
 
     // stable sort by pos2 (DUP:86, INV:111, TRA:109): key = (pos2, local index)
@@ -1718,7 +1719,7 @@ template <int BLOCK, bool LDS> __device__ void refine_pair(const DevBatch& B, co
         A.K[i] = key;
     }
     __syncthreads();
-    bitonic_sort<BLOCK>(A.K, P, ib);
+    bitonic_sort<BLOCK, decltype(A.K), ME>(A.K, P, ib);
     for (int r = threadIdx.x; r < m; r += BLOCK) {
         const u64 key = A.K[r];
         const int i = (int)(key & imask);
@@ -1890,6 +1891,11 @@ template <int CAP> constexpr int refine_lds_bytes() { return LDS_LEAD + (CAP + A
 template <int BLOCK, int CAP, bool BIG> __global__ __launch_bounds__(BLOCK, (BLOCK == 64 ? CSV_RF_WAVES : 1)) void k_refine(DevBatch B, int m_lo, int m_hi)
 {
     constexpr int big = BIG ? 1 : 0;
+    // 64-key registers of the one-wavefront sorts: the tier's capacity.  (r05, rejected with a measurement: a second capacity - a
+    // <64,128> launch at five wavefronts per SIMD for 65 .. 128 signatures next to <64,256> for the rest - made the tier 75 us
+    // instead of 60 on the 90x genome and 36 instead of 19 on the simulation beds: two kernels in a row each last as long as
+    // their slowest cluster.)
+    constexpr int ME_ = (BLOCK == 64 && CAP <= 256) ? (CAP + 63) / 64 : 4;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     CSV_LDS char* smem = (CSV_LDS char*)smem_raw + LDS_LEAD;
     constexpr int N = CAP + ARR_PAD;
@@ -1937,8 +1943,8 @@ template <int BLOCK, int CAP, bool BIG> __global__ __launch_bounds__(BLOCK, (BLO
         const int t = B.seg[it.k].svtype;
         const bool indel = t == CSV_DEL || t == CSV_INS;
         if (P <= CAP) {
-            if constexpr (BIG) { if (indel) { refine_indel<BLOCK, true, (CAP <= 256), (BLOCK == 64 && CAP <= 256 && !CSV_ABL(24))>(B, it, L, red, ired); continue; } }
-            refine_pair<BLOCK, true>(B, it, L, red, ired);
+            if constexpr (BIG) { if (indel) { refine_indel<BLOCK, true, (CAP <= 256), (BLOCK == 64 && CAP <= 256 && !CSV_ABL(24)), ME_>(B, it, L, red, ired); continue; } }
+            refine_pair<BLOCK, true, ME_>(B, it, L, red, ired);
         } else if constexpr (CAP <= 256) {
             // the one-wavefront tiers are only launched for m <= CAP; keeping the global-scratch path (and its
             // serial np.std routine with a private stack) out of them keeps these kernels free of scratch
@@ -1977,7 +1983,7 @@ template <int BLOCK, int CAP, bool BIG> __global__ __launch_bounds__(BLOCK, (BLO
             while (P < it.m) P <<= 1;
             it.P = P; it.ib = IDX_BITS;
             __syncthreads();
-            refine_pair<BLOCK, true>(B, it, L, red, ired);
+            refine_pair<BLOCK, true, ME_>(B, it, L, red, ired);
         }
     }
 }
