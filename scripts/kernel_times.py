@@ -26,7 +26,10 @@ acc = np.zeros(_abi.N_STAGES)
 for _ in range(steps):
     acc += np.array(list(ctx.run(stats=True).ms_stage))
 pk = bench.per_kernel_us(acc / steps, names)
-ctx.run(); ctx.sync()
+ctx.run(); ctx.download()
+for _ in range(4):
+    ctx.run()
+ctx.sync()
 import time
 t0 = time.perf_counter()
 for _ in range(steps):
