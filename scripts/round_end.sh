@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-end evidence on the GPU box (through gpurun): tests, profiles (kernel trace + calibrated PMC traffic), every bench line,
 # the N-ranks-on-one-device rehearsal and a stress campaign.  scripts/round_end.sh r04   -> gpurun_out/final/
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
 F=$R/gpurun_out/final; mkdir -p $F
 timeout -k 10 900 python -m pytest tests -m gpu -x -q > $F/${TAG}_pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -2 $F/${TAG}_pytest_gpu.log
@@ -14,3 +14,8 @@ timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --mast
 timeout 700 python scripts/stress_gpu.py ${STRESS_N:-30000} 1200000 > $F/${TAG}_stress.log 2>&1; tail -2 $F/${TAG}_stress.log
 timeout 300 python scripts/stress_gpu.py ${STRESS_BIG:-3000} 1300000 big > $F/${TAG}_stress_big.log 2>&1; tail -2 $F/${TAG}_stress_big.log
 ls $F | wc -l
+# the host -> host call: bulk vs gate-first, full vs slim results; its kernels + copies on a timeline (no counters)
+timeout 300 python scripts/oneshot_ab.py cfg3 cfg4 cfg5 cfg2 > $F/${TAG}_oneshot_ab.txt 2>&1; tail -4 $F/${TAG}_oneshot_ab.txt
+( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/os_tl && cd $R && timeout -k 5 300 rocprofv3 --kernel-trace --memory-copy-trace -d /tmp/os_tl -o tl -- python scripts/oneshot_ab.py cfg3 > $F/${TAG}_oneshot_tl.log 2>&1 )
+python scripts/rocprof_oneshot_timeline.py $(ls /tmp/os_tl/*.db /tmp/os_tl/*/*.db 2>/dev/null | head -1) 2 > $F/${TAG}_oneshot_timeline.txt 2>&1
+python scripts/resource_usage.py > $F/${TAG}_resource_usage.txt 2>/dev/null
