@@ -496,7 +496,8 @@ __global__ __launch_bounds__(256) void k_pool_to_rows(const int* p_seg, const i6
         const int sg = p_seg[i], rd = p_read[i], ax = p_aux[i];
         const i64 a = p_a[i], b = p_b[i];
         int rk = -1;
-        if (rd >= 0 && rd < n_rank) rk = rank[rd];
+        if (rank) { if (rd >= 0 && rd < n_rank) rk = rank[rd]; }
+        else rk = rd;                                       // (rows from the host: the read column is the rank already)
         const bool bad = sg < 0 || sg >= n_seg || a < 0 || b < 0 || rk < 0 || ax < 0;
         o_seg[i] = bad ? 0 : sg; o_a[i] = a; o_b[i] = b; o_rid[i] = rk; o_aux[i] = ax;
         if (bad) m[5] = 1;

@@ -121,9 +121,9 @@ def rebuild_to_device_batch(ctx, chroms, per_type, params_segment, reads=None):
         if t not in per_type or len(per_type[t]["a"]) == 0:
             continue
         d = per_type[t]
-        cols["seg"].append(ti * len(chroms) + crank[np.asarray(d["chrom"], np.int64)])
+        cols["seg"].append((ti * len(chroms) + crank[np.asarray(d["chrom"], np.int64)]).astype(np.int32))
         cols["a"].append(np.asarray(d["a"], np.int64)); cols["b"].append(np.asarray(d["b"], np.int64))
-        cols["rid"].append(np.asarray(d["read_id"], np.int64)); cols["aux"].append(np.asarray(d["aux"], np.int64))
+        cols["rid"].append(np.asarray(d["read_id"], np.int32)); cols["aux"].append(np.asarray(d["aux"], np.int32))       # (the ABI's widths: no conversion pass later)
     cat = {k: np.concatenate(v) if v else np.zeros(0, np.int64) for k, v in cols.items()}
     n_seg = len(TYPES) * len(chroms)
     major = np.zeros(n_seg, np.uint8)
@@ -266,9 +266,9 @@ def store_from_unsorted(ctx, chroms, per_type, names=None, strands=("++", "--"),
         ch = np.asarray(d["chrom"], np.int64)
         if t == "INS":
             ins_base, ins_n = n_rows, len(ch)
-        cols["seg"].append(ti * len(chroms) + crank[ch])
+        cols["seg"].append((ti * len(chroms) + crank[ch]).astype(np.int32))
         cols["a"].append(np.asarray(d["a"], np.int64)); cols["b"].append(np.asarray(d["b"], np.int64))
-        cols["rid"].append(np.asarray(d["read_id"], np.int64)); cols["aux"].append(np.asarray(d["aux"], np.int64))
+        cols["rid"].append(np.asarray(d["read_id"], np.int32)); cols["aux"].append(np.asarray(d["aux"], np.int32))       # (the ABI's widths: no conversion pass later)
         n_rows += len(ch)
     cat = {k: np.concatenate(v) if v else np.zeros(0, np.int64) for k, v in cols.items()}
     n_seg = len(TYPES) * len(chroms)
