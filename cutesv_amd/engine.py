@@ -66,6 +66,7 @@ class Context:
             batch.c.flags = (batch.c.flags & ~_abi.IN_PER_SIG) | (_abi.IN_PER_SIG if per_sig else 0)
         self._check(lib().csv_batch_upload(self._h, C.byref(batch.c)))
         self._batch = batch
+        self._inflight = []                       # (an upload drains the deliveries nobody waited for)
 
     def run(self, stats=False):
         if stats:
@@ -170,6 +171,7 @@ class Context:
         cap_calls = cap_calls or max(64, n // 16 + 16)
         cap_support = cap_support or max(64, n + 16)         # (a signature supports at most one call)
         self._batch = batch
+        self._inflight = []
         for _ in range(2):
             res = self._res_cache if reuse else None
             key = (bool(per_sig), bool(no_support), bool(coord32), None if fields is None else frozenset(fields), bool(reuse))

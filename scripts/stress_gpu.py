@@ -77,6 +77,15 @@ for it in range(n_it):
                 ctx.sync()                                # (the first run's answers are on the host when the next is planned)
             ctx.run(); ctx.run()
             got = ctx.download(per_sig=True).trimmed()
+            if rng.integers(0, 4) == 0 and not os.environ.get("CSV_STRESS_NO_PIPE"):      # ... and the pipelined delivery of two more runs
+                ctx.upload(hb, per_sig=False)
+                ctx.run(); ctx.download()
+                bufs = [ctx.result_buffers(cap_calls=len(got["bp1"]) + 8, cap_support=len(got["support_sig"]) + 8) for _ in range(2)]
+                ctx.run(); ctx.publish_async(bufs[0]); ctx.run(); ctx.publish_async(bufs[1])
+                for _ in range(2):
+                    d = ctx.publish_wait().trimmed()
+                    for name in ("call_seg", "bp1", "bp2", "support", "cipos", "cilen", "seq_pick", "dr", "dv", "gl_idx", "support_off", "support_sig"):
+                        assert np.array_equal(np.asarray(d[name]).astype(np.int64), np.asarray(got[name]).astype(np.int64)), "pipelined " + name
         assert_soa_equal(got, want, store=st, set_order_segments=())
     except Exception as e:                                # noqa: BLE001
         bad.append((seed0 + it, repr(e)[:200]))
