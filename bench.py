@@ -491,7 +491,10 @@ def resident_loops(ctx, phb, steps, warmup, dist=None):
     ctx.option(1, 0)
     ctx.run(); ctx.sync()
     probe = ctx.download()
-    res = ctx.result_buffers(cap_calls=probe.n_calls + 64, cap_support=probe.n_support + 64)
+    # (the full result: every call field + the support lists; coordinates as int32 when the columns are - CSV_OUT_COORD_I32: the same
+    # numbers in 60 instead of 76 bytes per call)
+    c32 = phb.a.dtype == np.int32
+    res = ctx.result_buffers(cap_calls=probe.n_calls + 64, cap_support=probe.n_support + 64, coord32=c32)
     for _ in range(warmup):
         ctx.run(); ctx.download(into=res)
     if dist is not None:
@@ -536,7 +539,7 @@ def resident_loops(ctx, phb, steps, warmup, dist=None):
         if dist is not None:
             dist.barrier()
         return time.perf_counter() - t0
-    res_b = ctx.result_buffers(cap_calls=probe.n_calls + 64, cap_support=probe.n_support + 64)
+    res_b = ctx.result_buffers(cap_calls=probe.n_calls + 64, cap_support=probe.n_support + 64, coord32=c32)
     dt_pipe = pipelined([res, res_b])
     dt_pipe_slim = None
     if dt_slim is not None:
@@ -1113,7 +1116,7 @@ def main():
             "metric": "SV signatures clustered/sec (whole node)", "value": value, "unit": "signatures/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
             "timed_region": ("the rank's whole boundary call: page-locked host columns -> kernels -> host SoA" if shard_mode else
-                             "inputs resident in HBM -> all kernels -> calls + support lists delivered into page-locked host arrays, every step's full "
+                             "inputs resident in HBM -> all kernels -> every call field + the int32 support lists delivered into page-locked host arrays (int32 coordinates with int32 columns), every step's full "
                              "result; the delivery of step k (k_publish on its own stream) runs under the kernels of step k + 1 (csv_batch_publish_async)"),
             "kernel_only": None if ko_ms is None else {"ms_per_step": ko_ms, "value": total_sig / (ko_ms * 1e-3),
                                                        "note": "the launch sequence alone, results left in HBM (the region r01-r03 reported as value)"},

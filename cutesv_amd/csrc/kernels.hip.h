@@ -2384,14 +2384,21 @@ template <int SW, bool NARROW> __device__ __forceinline__ void indel_unit(const 
             dp32 = live ? (int)dpi : 0; dl32 = live ? (int)dli : 0;
         }
         const bool fast = !__ballot(!small) && !CSV_ABL(15);
-        i64 PK = 0, lsum;
+        // (the sums are needed as doubles only.  On the fast path they are n x origin + a small exact integer: with int32 columns
+        // both factors and the product are exact in float64 - n <= 64, |origin| < 2^31 - so the double is built from two 32-bit
+        // conversions, a multiply and an add instead of a 64-bit multiply-add and a 64-bit integer -> float64 conversion, which has
+        // no instruction of its own; the result is the same number either way)
+        i64 PK = 0;
+        double d_lsum;
         if (fast) {
             const unsigned dpb = live ? (unsigned)(dp32 + (1 << DB)) : 0u, dlb = live ? (unsigned)(dl32 + (1 << DB)) : 0u;
             PK = sub_scan_i64<SW>((i64)(((u64)dlb << 32) | dpb));
-            lsum = (i64)U_ * ((i64)blen - (1 << DB)) + (i64)((u64)bperm(last4, PK) >> 32);
-        } else lsum = bperm(last4, sub_scan_i64<SW>(live ? (i64)len : 0));
+            const int hi = (int)(unsigned)((u64)bperm(last4, PK) >> 32);                // sum of the biased deltas: < 2^25
+            if constexpr (NARROW) d_lsum = (double)U_ * ((double)(int)blen - (double)(1 << DB)) + (double)hi;
+            else d_lsum = (double)((i64)U_ * ((i64)blen - (1 << DB)) + (i64)hi);
+        } else d_lsum = (double)bperm(last4, sub_scan_i64<SW>(live ? (i64)len : 0));
         // ---- allele split on consecutive length gaps (INDEL:138, 153-162)
-        const double thr = ratio * div_by((double)lsum, (double)U_, B.rcp_tab[U_ & (SQRT_TAB - 1)]);
+        const double thr = ratio * div_by(d_lsum, (double)U_, B.rcp_tab[U_ & (SQRT_TAB - 1)]);
         const C lprev = shr1(len);
         bool f;
         if constexpr (NARROW) f = live && r > 0 && ((double)(int)((unsigned)len - (unsigned)lprev) > thr);
@@ -2407,19 +2414,20 @@ template <int SW, bool NARROW> __device__ __forceinline__ void indel_unit(const 
 
         const int e14 = (hb | ((r1 - 1) & (SW - 1))) << 2, e04 = (hb | ((r0 - 1) & (SW - 1))) << 2;     // last rank of the allele / of the one before
         // NB: every cross-lane op sits in wave-uniform control flow; only the selects are per lane
-        i64 sp, sln;
+        double d_sp, d_sln;                                                       // the allele's position / length sums, as doubles (exact)
         int s1p = 0, s1l = 0;                                                     // fast: sums of the deltas over the allele
         if (fast) {
             const i64 k1 = bperm(e14, PK), k0 = bperm(e04, PK);
             const u64 seg = (u64)(k1 - (r0 > 0 ? k0 : 0));                        // (both halves ascend: no borrow across them)
             s1p = (int)(unsigned)(seg & 0xffffffffull) - n * (1 << DB);
             s1l = (int)(unsigned)(seg >> 32) - n * (1 << DB);
-            sp = (i64)n * (i64)bpos + s1p; sln = (i64)n * (i64)blen + s1l;
+            if constexpr (NARROW) { d_sp = (double)n * (double)(int)bpos + (double)s1p; d_sln = (double)n * (double)(int)blen + (double)s1l; }
+            else { d_sp = (double)((i64)n * (i64)bpos + s1p); d_sln = (double)((i64)n * (i64)blen + s1l); }
         } else {
             const i64 Ppos = sub_scan_i64<SW>(live ? (i64)pos : 0), Plen = sub_scan_i64<SW>(live ? (i64)len : 0);
             const i64 pp0 = bperm(e04, Ppos), pl0 = bperm(e04, Plen);
-            sp = bperm(e14, Ppos) - (r0 > 0 ? pp0 : 0);
-            sln = bperm(e14, Plen) - (r0 > 0 ? pl0 : 0);
+            d_sp = (double)(bperm(e14, Ppos) - (r0 > 0 ? pp0 : 0));
+            d_sln = (double)(bperm(e14, Plen) - (r0 > 0 ? pl0 : 0));
         }
 
         // ---- emission order: stable ascending by support among alleles with n >= minimum_support_reads (INDEL:163-166)
@@ -2447,7 +2455,7 @@ template <int SW, bool NARROW> __device__ __forceinline__ void indel_unit(const 
             keep = (int)(rr * (double)n); if (keep < 1) keep = 1;                 // INDEL:169
         }
         const double rcp_n = B.rcp_tab[n & (SQRT_TAB - 1)];
-        const double pmean = div_by((double)sp, (double)n, rcp_n), lmean = div_by((double)sln, (double)n, rcp_n);
+        const double pmean = div_by(d_sp, (double)n, rcp_n), lmean = div_by(d_sln, (double)n, rcp_n);
         double bp = pmean, siglen = lmean;
         C search;
         if (CSV_ABL(3)) search = pos;
@@ -2459,7 +2467,7 @@ template <int SW, bool NARROW> __device__ __forceinline__ void indel_unit(const 
             // rounded is the nearer one - the sign of the division's residual, which one fma gives exactly.
             const int nd = n * dp32 - s1p;                                      // |nd| < 2^25
             const unsigned an = (unsigned)(nd < 0 ? -nd : nd);
-            const double resid = fma(-(double)n, pmean, (double)sp);              // sum - n * fl(sum / n): < 0 <=> the mean was rounded up
+            const double resid = fma(-(double)n, pmean, d_sp);                    // sum - n * fl(sum / n): < 0 <=> the mean was rounded up
             const unsigned t = resid < 0.0 ? (nd < 0) : (resid > 0.0 ? (nd > 0) : 0);
             unsigned bk = ((2u * an + t) << 6) | (unsigned)r;                    // (distance, side, rank): one 32-bit minimum
             // segmented prefix minimum over the allele (the minimum of the whole allele arrives at its last rank): inside a DPP row
@@ -2551,7 +2559,10 @@ template <int SW, bool NARROW> __device__ __forceinline__ void indel_unit(const 
         }
 
         // ---- INS: first member (allele order) whose sequence is long enough gives POS and ALT (INDEL:398-405)
-        const i64 want = (i64)siglen;
+        // (int32 columns: a mean of values inside the int32 range is inside it too - one v_cvt_i32_f64 instead of the dozen
+        // instructions of a float64 -> int64 conversion; both truncate toward zero)
+        i64 want, bp_t;
+        if constexpr (NARROW) { want = (i64)(int)siglen; bp_t = (i64)(int)bp; } else { want = (i64)siglen; bp_t = (i64)bp; }
         const u64 okm = sub_ballot<SW>(live && type == CSV_INS && (i64)axp >= want, g);
         const u64 range = ((n >= 64) ? ~0ull : ((1ull << n) - 1ull)) << r0;
         const u64 mm = okm & range;
@@ -2560,7 +2571,7 @@ template <int SW, bool NARROW> __device__ __forceinline__ void indel_unit(const 
         const int pick_ch = bperm(pr4, chp);
         const C pick_pos = bperm(pr4, pos);
         i64 pick = -1; bool valid = true;
-        i64 bp_i = (i64)bp, search_i = (i64)search;
+        i64 bp_i = bp_t, search_i = (i64)search;
         if (type == CSV_INS) {
             valid = mm != 0;
             bp_i = (i64)pick_pos;                                                 // (the reference's float(pos) -> int() round trip is exact below 2^53)
@@ -2574,7 +2585,7 @@ template <int SW, bool NARROW> __device__ __forceinline__ void indel_unit(const 
             // sig_begin, its woff - and 64-bit sums at the very end of a unit, with every lane of the wavefront waiting.)
             int vflag = valid ? 1 : 0;
             if (type == CSV_INS && valid) { pick = (i64)(s + pick_ch); vflag |= 2; }
-            tmp_write(tmp_slot(B, j, s, erank), bp_i, (i64)siglen, search_i, pick, n, cip, cil, soff, vflag, npass, aux0);
+            tmp_write(tmp_slot(B, j, s, erank), bp_i, want, search_i, pick, n, cip, cil, soff, vflag, npass, aux0);
         }
         const int ncalls = __popcll(sub_ballot<SW>(head && valid, g));
         const int nsup = bperm(last4, sub_scan_i32<SW>((head && valid) ? n : 0));
