@@ -362,9 +362,11 @@ def test_bench_reads_its_committed_counter_files():
     assert bench.valu_issue_of("cfg3", 1.0, "k_no_such_kernel", 1.0) is None
     # the one JSON line stays inside the 8 000-byte tail of stdout the driver keeps: the full objects of a run are compacted
     # to named numbers (every key of the contract survives), the detail goes to stderr / gpurun_out
-    with open(os.path.join(ROOT, "profiles", "r04_bench_cfg3.json")) as f:
-        full = json.load(f)
+    with open(os.path.join(ROOT, "profiles", "r05_bench_cfg3.json")) as f:
+        full = json.loads(f.read().strip().splitlines()[-1])          # (`bench.py --full`: every object on the line)
     c = bench.compact(dict(full))
+    assert c["host_to_host"]["ms"] == pytest.approx(full["host_to_host"]["ms"], rel=1e-3) and c["roofline"]["pcie"]["bytes_up_bulk"] > 0
+    assert c["regions_ms"]["stage_wall_lazy_rows"] < c["regions_ms"]["stage_wall_rows"]
     assert len(json.dumps(c)) + 1 <= bench.LINE_LIMIT
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
         assert c[k] == full[k] or k == "config", k
