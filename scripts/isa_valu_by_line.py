@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Static vector-instruction count of one kernel per source line (no GPU needed).
 
-    python scripts/isa_valu_by_line.py k_refine_indel_waveILb1E [top]
+    python scripts/isa_valu_by_line.py k_refine_indel_waveILb1E [top] [v|s]
 
 Compiles cutesv_amd/csrc/cutesv_hip.hip for gfx950 with line tables (-gline-tables-only -S), walks the kernel's assembly and
 charges every v_* instruction to the source line of the last .loc directive.  The kernels of this library run at 55 - 86 % of the
@@ -22,6 +22,7 @@ CSRC = os.path.join(ROOT, "cutesv_amd", "csrc")
 def main():
     want = sys.argv[1]
     top = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+    unit = sys.argv[3] if len(sys.argv) > 3 else "v"          # "s": the scalar unit's instructions instead (s_waitcnt / s_nop excluded)
     with tempfile.TemporaryDirectory() as d:
         asm = os.path.join(d, "k.s")
         subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math",
@@ -46,11 +47,11 @@ def main():
         if m:
             cur = (files.get(int(m.group(1)), "?"), int(m.group(2)))
             continue
-        m = re.match(r"\s+(v_\w+)", l)
-        if m:
+        m = re.match(r"\s+(%s_\w+)" % unit, l)
+        if m and not m.group(1).startswith(("s_waitcnt", "s_nop", "s_endpgm")):
             cnt[cur] += 1
             ops[m.group(1)] += 1
-    print("%s: %d vector instructions (static)" % (lines[starts[0]].split(":")[0], sum(cnt.values())))
+    print("%s: %d %s instructions (static)" % (lines[starts[0]].split(":")[0], sum(cnt.values()), "scalar" if unit == "s" else "vector"))
     print("by opcode:", ", ".join("%s %d" % kv for kv in ops.most_common(12)))
     for (f, ln), c in cnt.most_common(top):
         if f not in src:
