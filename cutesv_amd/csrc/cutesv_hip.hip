@@ -1051,6 +1051,9 @@ int run_impl(csv_ctx* c, csv_run_stats* stats)
                 hipLaunchKernelGGL((k_genotype<1024, 4, false, false>), dim3(env_int("CSV_GT_GRID", GT_GRID)), dim3(256), 0, st, B);
                 if (need_second) hipLaunchKernelGGL((k_genotype<8192, 4, true, false>), dim3(256), dim3(256), 0, st, B);
             }
+#ifdef CSV_GT_PROF
+            hipLaunchKernelGGL(k_gt_prof_print, dim3(1), dim3(1), 0, st, B);
+#endif
             DBG("genotype");
             HIP_TRY(c, mark());
         } else if (stats) { for (int q = 0; q < 4; q++) HIP_TRY(c, mark()); }

@@ -3371,17 +3371,21 @@ __global__ __launch_bounds__(256) void k_reads_chromcol(DevBatch B, int* out)
 // SCALAR instructions per probe round for
 // its exec-mask bookkeeping, and the genotype kernel issued 1.75 scalar instructions per vector one: 27.5 M per 90x launch, which at
 // one scalar instruction per SIMD every four cycles is 45 of its 60 us.  (cfg5: 60 -> 53 us; cfg4: 21 -> 19 us.)
+__device__ __forceinline__ unsigned umin32(unsigned a, unsigned b) { return a < b ? a : b; }
+// (`id` is never negative, also in the lanes that do not `want`)
 template <int HASH> __device__ __forceinline__ int hash_insert_v(int* tab, int id, int want)
 {
     unsigned h = ((unsigned)id * 2654435761u) >> (32 - __builtin_ctz(HASH));
     int ins = 0, pend = want;
-    while (__ballot(pend != 0)) {
-        int old = -2;
+    // (first round unconditionally: a loop that tests before it probes pays its scalar bookkeeping twice for the common single
+    // round; a lane that sits a round out sees "the id is there", so that neither `ins` nor `pend` needs its mask AND-ed in)
+    do {
+        int old = id;
         if (pend) old = atomicCAS(&tab[h], -1, id);
         ins |= (old == -1) ? 1 : 0;
-        pend = (old == -2 || old == -1 || old == id) ? 0 : 1;
-        h = (h + (unsigned)pend) & (HASH - 1);
-    }
+        pend = (int)umin32((unsigned)old + 1u, (unsigned)(old ^ id));       // 0: inserted (old == -1) or present (old == id)
+        h = (h + (pend ? 1u : 0u)) & (HASH - 1);
+    } while (__ballot(pend != 0));
     return ins;
 }
 __device__ __forceinline__ int hash_insert_n(int* tab, int bits, int id)      // runtime size 2^bits (global-memory tables)
@@ -3446,12 +3450,45 @@ template <bool RN> __device__ __forceinline__ void bfirst_probe(const DevBatch& 
 // Rows, chunks and blocks are 32-bit numbers (a table has fewer than 2^31 reads), and the window tests run on HALVED bounds
 // in the table's own width: 2 start <= L2 <=> start <= L2 >> 1, 2 end >= R2 <=> end >= (R2 + 1) >> 1 - the kernel was
 // bound by the issue of 64-bit compares and address arithmetic, not by memory (0.4 k vector instructions per call).
+// -DCSV_GT_PROF (a measurement build, never the product): per-phase shader-clock sums of k_genotype's first pass, one add per
+// wavefront and phase into the first words of the (then idle) global pool; k_gt_prof_print reports and clears them.
+#ifdef CSV_GT_PROF
+#define GT_TICK(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t__ = __builtin_readcyclecounter(); gt_prof[k] += t__ - gt_t; gt_t = t__; } while (0)
+#define GT_PROF_ARGS , unsigned long long* gt_prof, unsigned long long& gt_t
+#define GT_PROF_PASS , gt_prof, gt_t
+__global__ void k_gt_prof_print(DevBatch B)
+{
+    unsigned long long* g = (unsigned long long*)B.gt_pool;     // (one 128-byte slot per workgroup modulo 1024: same-address atomics
+    unsigned long long p[16];                                    // from 16 k wavefronts queue up at one L2 channel and slow every load)
+    for (int k = 0; k < 16; k++) { p[k] = 0; for (int b = 0; b < 1024; b++) { p[k] += g[16 * b + k]; g[16 * b + k] = 0; } }
+    printf("gt_prof waves %llu calls %llu chunks %llu steps2 %llu windows %llu | ticks: lifetime %llu = loop %llu next_head %llu chrom %llu probes+clear %llu supports %llu step1 %llu step2_wait %llu step2_alu %llu rows %llu result %llu\n",
+           p[15], p[8], p[9], p[10], p[11], p[14], p[7], p[12], p[13], p[0], p[1], p[2], p[3], p[4], p[5], p[6]);
+
+}
+#else
+#define GT_TICK(k) do { } while (0)
+#define GT_PROF_ARGS
+#define GT_PROF_PASS
+#endif
+// lowest set bit of a wave-uniform mask, cleared in place; -1 when the mask is empty (`m &= m - 1` is three scalar instructions
+// and a compare on top of the find)
+__device__ __forceinline__ int pick_bit(u64& m)
+{
+    int j;
+    asm("s_ff1_i32_b64 %0, %1\n\ts_bitset0_b64 %1, %0" : "=&s"(j), "+s"(m));
+    return j;
+}
+// a negative number unless a <= b (the sign of a saturating difference in the table's 32-bit form)
+template <bool RN> __device__ __forceinline__ int neg_unless_le(rd_t<RN> a, rd_t<RN> b)
+{
+    if constexpr (RN) return __builtin_elementwise_sub_sat(b, a); else return a <= b ? 0 : -1;
+}
 template <int HASH, bool RN> __device__ __forceinline__ int cover_window(const DevBatch& B, int* tab, int r0, int r1, i64 L2, i64 R2, i64 maxlen, int& filled, bool& overflow,
-                                                                         rd_t<RN> fa0, rd_t<RN> fc0)
+                                                                         rd_t<RN> fa0, rd_t<RN> fc0 GT_PROF_ARGS)
 {
     using CT = rd_t<RN>;
     const CT* bf = (const CT*)B.bfirst; const CT* cf = (const CT*)B.cfirst; const CT* cx = (const CT*)B.cmax;
-    int dr = 0;
+    const int filled0 = filled;                             // (every insert below is one DR)
     const int lane = lane_id();
     const i64 Lh64 = L2 >> 1, Rh64 = (R2 + 1) >> 1, Fh64 = (R2 - 2 * maxlen + 1) >> 1;      // a covering read starts at or after Fh
     CT Lh, Rh, Fh;
@@ -3462,69 +3499,109 @@ template <int HASH, bool RN> __device__ __forceinline__ int cover_window(const D
         Fh = (int)(Fh64 < INT32_MIN ? INT32_MIN : Fh64);   // (Fh <= Rh)
     } else { Lh = Lh64; Rh = Rh64; Fh = Fh64; }
     const int c0 = r0 >> 6, c1 = (r1 - 1) >> 6, k0 = c0 >> 6, k1 = c1 >> 6;
+    // The range and order tests of (1) and (2) are sign bits: a term is negative where its condition fails, terms are OR-ed (all
+    // must hold) or AND-ed (one must hold) in the vector unit, and one compare per ballot reaches the scalar unit - written as
+    // boolean expressions each ballot cost three to five scalar mask operations.
     // (1) last block whose first start is <= L (the block that holds the chromosome's first read counts as such: its own
     // first read may belong to the previous chromosome)
     int ktop = k0;
     for (int kb = k0; kb <= k1; kb += 128) {
-        const int ka = kb + lane, kc = kb + 64 + lane;
+        const int ka = kb + lane, kc = ka + 64;
         CT fa = fa0, fc = fc0;
         if (kb != k0) { fa = (bf + kb)[lane]; fc = (bf + kb)[64 + lane]; }
-        const int na = __popcll(__ballot(ka <= k1 && (ka == k0 || fa <= Lh))), nc = __popcll(__ballot(kc <= k1 && (kc == k0 || fc <= Lh)));
-        if (na + nc > 0) ktop = kb + na + nc - 1;           // (the predicate is true on a prefix: starts ascend inside a chromosome)
-        if (na + nc < 128) break;
+        // k <= k1 and (k == k0 or first <= L); k >= k0 here, so k0 - k is zero at k0 and negative after it
+        const int ta = (k1 - ka) | ((k0 - ka) & neg_unless_le<RN>(fa, Lh)), tc = (k1 - kc) | ((k0 - kc) & neg_unless_le<RN>(fc, Lh));
+        const int nn = __popcll(__ballot(ta >= 0)) + __popcll(__ballot(tc >= 0));
+        if (nn == 0) break;                                 // (the predicate is true on a prefix: starts ascend inside a chromosome)
+        ktop = kb + nn - 1;
+        if (nn < 128) break;
     }
+    GT_TICK(2);
+#ifdef CSV_GT_PROF
+    gt_prof[11]++;
+#endif
     // (2) chunks, two blocks per step, walking towards the chromosome's first chunk until the scan range is closed
-    bool first_step = true;
     int top_chunk = -1;
     for (int kk = ktop; kk >= k0; kk -= 2) {
-        const int cb = (kk > k0 ? kk - 1 : kk) << 6;        // first chunk of the step
-        const int ca = cb + lane, cc = cb + 64 + lane;
-        const bool ina = ca >= c0 && ca <= c1, inc = cc >= c0 && cc <= c1 && (kk > k0);
-        const CT fa = (cf + cb)[lane], fc = (cf + cb)[64 + lane];
-        const CT ma = (cx + cb)[lane], mc = (cx + cb)[64 + lane];
-        if (first_step) {                                   // the chunk of the last read with start <= L lies in this step
-            const int na = __popcll(__ballot(ina && (ca == c0 || fa <= Lh))), nc = __popcll(__ballot(inc && (cc == c0 || fc <= Lh)));
-            const int lo_c = cb > c0 ? cb : c0;
-            top_chunk = lo_c + na + nc - 1;
-            first_step = false;
-            if (top_chunk < lo_c) return 0;                 // no read of the chromosome starts at or before L
-        }
-        // chunks of this step that lie at or before top_chunk, may hold a read with start >= F (their successor's first read
-        // starts at or after F, or they are the last such) and hold a read that reaches R
-        const u64 before_a = __ballot(ina && ca != c0 && fa < Fh), before_c = __ballot(inc && cc != c0 && fc < Fh);   // chunk begins before F
-        // the scan's first chunk is the LAST chunk that begins before F (it may still hold later reads); every chunk after it qualifies
-        const int nb_a = __popcll(before_a), nb_c = __popcll(before_c);
+        const int two = kk > k0 ? 1 : 0;                    // blocks kk - 1 and kk, or the chromosome's first block alone
+        const int cb = (kk - two) << 6;                     // first chunk of the step
         const int lo_c = cb > c0 ? cb : c0;
-        const bool closed = (nb_a + nb_c > 0) || lo_c == c0;
-        const int bot_chunk = (nb_a + nb_c > 0) ? (nb_c ? cb + 64 + (63 - __clzll((long long)before_c)) : cb + (63 - __clzll((long long)before_a))) : lo_c;
-        u64 todo_a = __ballot(ina && ca >= bot_chunk && ca <= top_chunk && ma >= Rh);
-        u64 todo_c = __ballot(inc && cc >= bot_chunk && cc <= top_chunk && mc >= Rh);
-        // (3) the reads of the flagged chunks
-        while (todo_a | todo_c) {
-            CT st[GT_UNROLL], en[GT_UNROLL]; int idp[GT_UNROLL]; bool ok[GT_UNROLL];
+        int hi_c = cb + 63 + (two << 6); if (hi_c > c1) hi_c = c1;
+        const int ca = cb + lane, cc = ca + 64;
+        // (a chunk number is below 2^25: its byte offset fits 32 bits, and the column's base stays one scalar pair)
+        const unsigned oa = (unsigned)ca * (unsigned)sizeof(CT), oc = oa + 64u * (unsigned)sizeof(CT);
+        const CT fa = *(const CT*)((const char*)cf + oa), fc = *(const CT*)((const char*)cf + oc);
+        const CT ma = *(const CT*)((const char*)cx + oa), mc = *(const CT*)((const char*)cx + oc);
+        GT_TICK(3);
+#ifdef CSV_GT_PROF
+        gt_prof[10]++;
+#endif
+        if (kk == ktop) {                                   // the chunk of the last read with start <= L lies in this step
+            const int ta = (ca - lo_c) | (hi_c - ca) | ((c0 - ca) & neg_unless_le<RN>(fa, Lh));
+            const int tc = (cc - lo_c) | (hi_c - cc) | ((c0 - cc) & neg_unless_le<RN>(fc, Lh));
+            const int nn = __popcll(__ballot(ta >= 0)) + __popcll(__ballot(tc >= 0));
+            if (nn == 0) return 0;                          // no read of the chromosome starts at or before L
+            top_chunk = lo_c + nn - 1;
+        }
+        // The scan's first chunk is the LAST chunk that begins before F (it may still hold later reads; the chromosome's first
+        // chunk may begin in its predecessor): chunks of the step other than c0 whose first start is below F ...
+        const int ba = (ca - lo_c) | (hi_c - ca) | (ca - c0 - 1) | ~neg_unless_le<RN>(Fh, fa);
+        const int bc = (cc - lo_c) | (hi_c - cc) | (cc - c0 - 1) | ~neg_unless_le<RN>(Fh, fc);
+        const u64 before_a = __ballot(ba >= 0), before_c = __ballot(bc >= 0);
+        const bool any_before = (before_a | before_c) != 0;
+        const bool closed = any_before || lo_c == c0;
+        const int bot_chunk = before_c ? cb + 127 - __clzll((long long)before_c) : (before_a ? cb + 63 - __clzll((long long)before_a) : lo_c);
+        // ... and every chunk from there to top_chunk that holds a read reaching R
+        const int lo_t = bot_chunk, hi_t = top_chunk < hi_c ? top_chunk : hi_c;            // (bot_chunk >= lo_c)
+        const int qa = (ca - lo_t) | (hi_t - ca) | neg_unless_le<RN>(Rh, ma), qc = (cc - lo_t) | (hi_t - cc) | neg_unless_le<RN>(Rh, mc);
+        const u64 todo_a = CSV_ABL(26) ? 0ull : __ballot(qa >= 0), todo_c = CSV_ABL(26) ? (u64)(__popcll(__ballot(qc >= 0) | __ballot(qa >= 0)) == 64) : __ballot(qc >= 0);
+        // (3) the reads of the flagged chunks, four chunks in flight.  The scalar unit was this kernel's busiest (1.1 scalar
+        // instructions per vector one, ~43 per chunk here): a chunk is now picked by two scalar instructions, a column is read at
+        // ONE base per step of (2) plus a 32-bit byte offset, the row tests are sign bits of differences OR-ed together in the
+        // vector unit instead of five lane masks AND-ed in the scalar unit.
+        GT_TICK(4);
+#ifdef CSV_GT_PROF
+        gt_prof[9] += __popcll(todo_a) + __popcll(todo_c);
+#endif
+        const char* st_b; const char* en_b;
+        if constexpr (RN) { st_b = (const char*)(B.s_start32 + ((i64)cb << 6)); en_b = (const char*)(B.s_end32 + ((i64)cb << 6)); }
+        else { st_b = (const char*)(B.s_start64 + ((i64)cb << 6)); en_b = (const char*)(B.s_end64 + ((i64)cb << 6)); }
+        const char* id_b = (const char*)(B.s_idp + ((i64)cb << 6));
+        const int nrow1 = r1 - r0 - 1;
+#pragma unroll 1
+        for (int half = 0; half < 2; half++) {
+            u64 m = half ? todo_c : todo_a;
+            if (!m) continue;
+            const int rel_h = lane + (cb << 6) - r0 + (half << 12);        // row - r0 of this lane in chunk 0 of the half
+            const unsigned off_h = ((unsigned)lane << 2) + ((unsigned)half << 14);
+            while (m) {
+                CT st[GT_UNROLL], en[GT_UNROLL]; int idp[GT_UNROLL], jj[GT_UNROLL];
+                const int ng = __popcll(m);                  // chunks left in this half: the group's slots past them are skipped
 #pragma unroll
-            for (int u = 0; u < GT_UNROLL; u++) {
-                int chunk = -1;
-                if (todo_a) { chunk = cb + __ffsll((long long)todo_a) - 1; todo_a &= todo_a - 1; }
-                else if (todo_c) { chunk = cb + 64 + __ffsll((long long)todo_c) - 1; todo_c &= todo_c - 1; }
-                const int row = (chunk << 6) + lane;
-                ok[u] = chunk >= 0 && row >= r0 && row < r1;
-                const i64 cbase = (i64)(chunk >= 0 ? chunk : c0) << 6;      // wave-uniform: base + lane (rows past the table are padding)
-                if constexpr (RN) { st[u] = (B.s_start32 + cbase)[lane]; en[u] = (B.s_end32 + cbase)[lane]; } else { st[u] = (B.s_start64 + cbase)[lane]; en[u] = (B.s_end64 + cbase)[lane]; }
-                idp[u] = (B.s_idp + cbase)[lane];
-            }
+                for (int u = 0; u < GT_UNROLL; u++) {
+                    if (u > 0 && u >= ng) break;
+                    jj[u] = pick_bit(m);
+                    const unsigned o4 = ((unsigned)jj[u] << 8) + off_h;
+                    st[u] = *(const CT*)(st_b + (RN ? o4 : 2u * o4)); en[u] = *(const CT*)(en_b + (RN ? o4 : 2u * o4));
+                    idp[u] = *(const int*)(id_b + o4);
+                }
 #pragma unroll
-            for (int u = 0; u < GT_UNROLL; u++) {
-                if (filled + 64 > HASH * 3 / 4) { overflow = true; return dr; }
-                const bool cov = ok[u] && idp[u] < 0 && st[u] <= Lh && en[u] >= Rh;          // primary (bit 31), starts at or before L, reaches R
-                const int ins = CSV_ABL(17) ? (int)cov : hash_insert_v<HASH>(tab, idp[u] & 0x7fffffff, cov ? 1 : 0);
-                const int k = __popcll(__ballot(ins));
-                dr += k; filled += k;
+                for (int u = 0; u < GT_UNROLL; u++) {
+                    if (u > 0 && u >= ng) break;
+                    if (filled + 64 > HASH * 3 / 4) { overflow = true; return 0; }
+                    const int rowrel = (jj[u] << 6) + rel_h;
+                    // negative unless: the row is one of the chromosome's, primary (bit 31 of idp), starts at or before L, reaches R
+                    const int t = rowrel | __builtin_elementwise_sub_sat(nrow1, rowrel) | ~idp[u] | neg_unless_le<RN>(st[u], Lh) | neg_unless_le<RN>(Rh, en[u]);
+                    const int cov = t >= 0 ? 1 : 0;
+                    const int ins = CSV_ABL(17) ? cov : hash_insert_v<HASH>(tab, idp[u] & 0x7fffffff, cov);
+                    filled += __popcll(__ballot(ins));
+                }
             }
         }
+        GT_TICK(5);
         if (closed) break;
     }
-    return dr;
+    return filled - filled0;
 }
 
 __device__ __forceinline__ int gl_index_dev(i64 c0, i64 c1)
@@ -3543,11 +3620,18 @@ __device__ __forceinline__ int gl_index_dev(i64 c0, i64 c1)
 // what one call needs before it touches the reads table; loaded one call ahead (the per-call work is a chain of
 // dependent round trips, this takes the first ones off it)
 struct GtHead { int c; int4 h; i64 s0, s1, search, b1, b2; };
+// The record is read through the CONSTANT address space: the fields read here were written by earlier kernels and do not change
+// while this one runs (its own result goes to bytes 64-79 of the record, which nothing reads this way), `c` is wave-uniform, and
+// the kernel is bound by the vector unit's issue rate - as ordinary loads these come back in vector registers (the kernel's own
+// stores could alias them, so the compiler may not use the scalar cache) and everything derived from them - windows, halved
+// bounds, block and chunk ranges: ~50 instructions of 64-bit arithmetic per call - runs on the vector unit with 64 equal lanes.
+typedef int gt_v4i __attribute__((ext_vector_type(4)));
+typedef const gt_v4i __attribute__((address_space(4))) * gt_rec_cptr;
 __device__ __forceinline__ void gt_load_call(const DevBatch& B, int c, GtHead& H)
 {
-    const int4* r = (const int4*)&B.o_rec[c];
-    const int4 r0 = r[0], r1 = r[1], r2 = r[2];
-    H.c = c; H.h = r[5];
+    gt_rec_cptr r = (gt_rec_cptr)(uintptr_t)&B.o_rec[c];
+    const gt_v4i r0 = r[0], r1 = r[1], r2 = r[2], r5 = r[5];
+    H.c = c; H.h = make_int4(r5.x, r5.y, r5.z, r5.w);
     H.b1 = ((i64)r0.y << 32) | (unsigned)r0.x; H.b2 = ((i64)r0.w << 32) | (unsigned)r0.z;
     H.search = ((i64)r1.y << 32) | (unsigned)r1.x;
     H.s0 = ((i64)r2.y << 32) | (unsigned)r2.x; H.s1 = H.s0 + r2.z;
@@ -3621,20 +3705,23 @@ template <bool RN> __device__ bool genotype_global(const DevBatch& B, const GtHe
 // SECOND is a template parameter so that the first pass - the one every call goes through - does not carry the code and the
 // registers of the global-pool path (as a run-time argument: 28 scalar spills and 16 bytes of scratch per lane in the hot
 // kernel; cfg-4 56.7 -> 40.6 us, cfg-5 136 -> 116 us)
-template <int HASH, int WPB, bool SECOND, bool RN> __global__ __launch_bounds__(64 * WPB) void k_genotype(DevBatch B)
+template <int HASH, int WPB, bool SECOND, bool RN> __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_num_sgpr(96))) void k_genotype(DevBatch B)
 {
     constexpr int second = SECOND ? 1 : 0;
     __shared__ int tabs[WPB][HASH];
     __shared__ int s_red[WPB], s_last;
     // the chromosomes' blocks of the reads table and their longest reads, once per workgroup (a dependent look-up per call otherwise)
     __shared__ int s_off[GT_NC + 1];
-    __shared__ i64 s_ml[GT_NC];
+    __shared__ int s_ml[GT_NC][2];                   // (as two words: read as an i64 the compiler merges this read and the global one of the
+                                                     // other branch into ONE flat load through a selected pointer)
     int* tab = tabs[threadIdx.x >> 6];
     const bool in_lds = B.n_chrom <= GT_NC;
     if (in_lds) {
         for (int i = threadIdx.x; i <= B.n_chrom; i += 64 * WPB) s_off[i] = (int)B.reads_off[i];
-        for (int i = threadIdx.x; i < B.n_chrom; i += 64 * WPB) s_ml[i] = B.maxlen[i];
+        for (int i = threadIdx.x; i < B.n_chrom; i += 64 * WPB) { const i64 ml = B.maxlen[i]; s_ml[i][0] = (int)ml; s_ml[i][1] = (int)(ml >> 32); }
     }
+    // (calls dealt to the XCDs in bands of 256 neighbours instead of launch order - one L2 per XCD - changed neither the time nor,
+    // with it, the story: 50.3 vs 50.5 us)
     const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * (64 * WPB) + threadIdx.x) >> 6), nwaves = (gridDim.x * (64 * WPB)) >> 6;
     GtHead cur, nxt;
     // (the first call's record is fetched before the number of calls is known - the index is clamped to the table -: one round
@@ -3652,40 +3739,56 @@ template <int HASH, int WPB, bool SECOND, bool RN> __global__ __launch_bounds__(
     }
     if (second && n == 0) return;                                   // (nothing overflowed the first pass: no list, no hand-over)
     if constexpr (SECOND) { if (wave < n) gt_load_head(B, second, wave, cur); }
+#ifdef CSV_GT_PROF
+    unsigned long long gt_prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long gt_t0 = __builtin_readcyclecounter();
+    unsigned long long gt_t = gt_t0;
+#endif
     for (int q = wave; q < n; q += nwaves, cur = nxt) {
+        GT_TICK(7);
         nxt = cur;
         if (q + nwaves < n) gt_load_head(B, second, q + nwaves, nxt);
         const int c = cur.c, svtype = cur.h.y & 0xff, chrom = cur.h.x;
         if (!(cur.h.y & 0x100) || svtype == CSV_TRA) continue;    // TRA: k_genotype_tra
+#ifdef CSV_GT_PROF
+        gt_prof[8]++;
+#endif
+        GT_TICK(12);
         int r0, r1; i64 maxlen;
-        if (in_lds) { r0 = s_off[chrom]; r1 = s_off[chrom + 1]; maxlen = s_ml[chrom]; }
+        if (in_lds) { r0 = s_off[chrom]; r1 = s_off[chrom + 1]; maxlen = ((i64)s_ml[chrom][1] << 32) | (unsigned)s_ml[chrom][0]; }
         else { r0 = (int)B.reads_off[chrom]; r1 = (int)B.reads_off[chrom + 1]; maxlen = B.maxlen[chrom]; }
-        // one round trip: the first supports and the block probes of the window(s); the table is cleared while they fly
+        // one round trip: the first 128 supports and the block probes of the window(s); the table is cleared while they fly.
+        // (Issuing this trip one call ahead, under the previous call's chunk loads, was measured twice - before and after the
+        // instruction diet - and changed nothing: 50.0 vs 50.5 us on the 90x workload; see DESIGN.md on what bounds the kernel.)
         const GtWin W = gt_windows(cur);
-        const i64 s0 = cur.s0, ns = cur.s1 - s0;
+        const i64 s0 = cur.s0; const int ns = (int)(cur.s1 - s0);       // (a call's support count is an int: gt_load_call)
         rd_t<RN> fa = 0, fc = 0;
+        GT_TICK(13);
         if (r1 > r0) bfirst_probe<RN>(B, r0, r1, fa, fc);
-        int sup0 = lane_id() < ns ? B.o_suprid[s0 + lane_id()] : -1;
+        int sup0 = lane_id() < ns ? B.o_suprid[s0 + lane_id()] : 0;
+        int sup1 = lane_id() + 64 < ns ? B.o_suprid[s0 + 64 + lane_id()] : 0;       // (90x: most calls have more than 64 supports)
         {
             int4* t4 = (int4*)tab;
 #pragma unroll
             for (int k = 0; k < HASH / 256; k++) t4[k * 64 + lane_id()] = make_int4(-1, -1, -1, -1);
         }
         // (the loaded values are first looked at here: without this the compiler waits for each load right where it is issued)
-        if constexpr (RN) asm volatile("" : "+v"(fa), "+v"(fc), "+v"(sup0)); else asm volatile("" : "+v"(fa), "+v"(fc), "+v"(sup0));
+        asm volatile("" : "+v"(fa), "+v"(fc), "+v"(sup0), "+v"(sup1));
         int filled = 0;
         bool overflow = false;
-        for (i64 base = 0; base < ns; base += 64) {
+        GT_TICK(0);
+        for (int base = 0; base < ns; base += 64) {
             if (filled + 64 > HASH * 3 / 4) { overflow = true; break; }
-            const i64 i = base + lane_id();
+            const int i = base + lane_id();
             int ins = 0;
-            if (!CSV_ABL(18)) ins = hash_insert_v<HASH>(tab, base == 0 ? sup0 : (i < ns ? B.o_suprid[s0 + i] : 0), i < ns ? 1 : 0);
+            if (!CSV_ABL(18)) ins = hash_insert_v<HASH>(tab, base == 0 ? sup0 : (base == 64 ? sup1 : (i < ns ? B.o_suprid[s0 + i] : 0)), i < ns ? 1 : 0);
             filled += __popcll(__ballot(ins));
         }
         int dr = 0;
+        GT_TICK(1);
         if (!overflow && !CSV_ABL(16) && r1 > r0) {
-            dr = cover_window<HASH, RN>(B, tab, r0, r1, W.La, W.Ra, maxlen, filled, overflow, fa, fc);
-            if (W.n == 2 && !overflow) dr += cover_window<HASH, RN>(B, tab, r0, r1, W.Lb, W.Rb, maxlen, filled, overflow, fa, fc);      // (same chromosome: same probes)
+            dr = cover_window<HASH, RN>(B, tab, r0, r1, W.La, W.Ra, maxlen, filled, overflow, fa, fc GT_PROF_PASS);
+            if (W.n == 2 && !overflow) dr += cover_window<HASH, RN>(B, tab, r0, r1, W.Lb, W.Rb, maxlen, filled, overflow, fa, fc GT_PROF_PASS);      // (same chromosome: same probes)
         }
         if (overflow) {                                                       // wave-uniform
             if constexpr (!SECOND) { if (lane_id() == 0) B.gt_over[atomicAdd(&B.cnt->n_gt_over, 1)] = c; continue; }
@@ -3698,7 +3801,11 @@ template <int HASH, int WPB, bool SECOND, bool RN> __global__ __launch_bounds__(
             }
         }
         if (lane_id() == 0) ((int4*)&B.o_rec[c])[4] = make_int4(dr, (int)ns, gl_index_dev(dr, ns), 0);
+        GT_TICK(6);
     }
+#ifdef CSV_GT_PROF
+    if constexpr (!SECOND) { if (lane_id() == 0) { gt_prof[14] = __builtin_readcyclecounter() - gt_t0; gt_prof[15] = 1; for (int k = 0; k < 16; k++) atomicAdd((unsigned long long*)B.gt_pool + 16 * (blockIdx.x & 1023) + k, gt_prof[k]); } }
+#endif
     if constexpr (!SECOND) return;
     // the last workgroup to get here owns the whole pool (every other one is done with its slice) and finishes the
     // calls that needed more than a slice, one at a time

@@ -162,6 +162,18 @@ class Context:
         return res
 
     # ---- one shot: csv_cluster_batch (H2D, kernels and D2H overlap inside the one call)
+    # ---- a reuse=True result that its consumer keeps (rows.RowsBacking reads the arrays in place instead of copying them)
+    def lend(self, res):
+        """take `res` out of recycling until give_back(res); False if it is not this context's recycled result"""
+        if res is not self._res_cache:
+            return False
+        self._res_cache = None
+        return True
+
+    def give_back(self, res):
+        if self._res_cache is None:
+            self._res_cache = res                # (otherwise it is simply dropped: a newer one took the slot)
+
     def cluster_batch(self, batch, per_sig=False, cap_calls=None, cap_support=None, reuse=False, no_support=False, coord32=False, fields=None):
         """reuse=True hands the C call the result arrays of this context's previous reuse=True call when they are large
         enough (a caller that consumes a result before asking for the next one, like resolve.run_batch, saves the

@@ -150,7 +150,7 @@ def _cluster_stage_lazy(store, segs, tasks, ctx):
     ctx = ctx or context()
     hb = _batch_of(store, segs)
     res = ctx.cluster_batch(hb, reuse=True)
-    backing, ranges = rows_mod.lazy_rows_by_segment(store, hb.segments, res)      # (a private copy of the arrays: `res` is recycled)
+    backing, ranges = rows_mod.lazy_rows_by_segment(store, hb.segments, res, ctx)     # (`res` is lent to the rows, or copied)
     results = {}
     for t in TYPES:                                   # main script :1191-1197 extends in submission order
         for k, (tt, ch) in enumerate(tasks):

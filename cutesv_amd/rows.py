@@ -15,6 +15,7 @@ that are not CPython.  `materialise_py` is the per-call Python loop it
 replaced (round 1: ~90 ms); it is kept as the readable statement of the layouts and the tests compare the two.
 """
 import ctypes as C
+import weakref
 
 import numpy as np
 
@@ -112,8 +113,14 @@ class RowsBacking:
     """What a LazyRows sequence is made from: the store, the batch's segments and a private copy of the result's structure of
     arrays.  The csv_rows_in block (name / sequence tables) is built on the first row anyone asks for."""
 
-    def __init__(self, store, segments, res):
-        self.store, self.segments, self.res = store, np.ascontiguousarray(segments, dtype=_abi.SEGMENT_DTYPE), res.snapshot()
+    def __init__(self, store, segments, res, ctx=None):
+        # a recycled (reuse=True) result is overwritten by the context's next call: either the context lends it for the life of
+        # this object (no copy: the 0.6 ms of a 30x genome's stage), or a private copy is cut to the produced sizes
+        if ctx is not None and getattr(ctx, "lend", None) is not None and ctx.lend(res):
+            weakref.finalize(self, ctx.give_back, res)
+        else:
+            res = res.snapshot()
+        self.store, self.segments, self.res = store, np.ascontiguousarray(segments, dtype=_abi.SEGMENT_DTYPE), res
         self._rin = None
         n = self.res.n_calls
         self.key = np.asarray(self.res.arrays["bp1"][:n], dtype=np.int64)        # int(row[2]) of every call: what generate_output sorts by
@@ -252,9 +259,10 @@ class LazyRows:
         self._parts = new
 
 
-def lazy_rows_by_segment(store, segments, res):
-    """-> (RowsBacking, list (per segment) of call-index ranges [lo, hi)): the lazy counterpart of rows_by_segment"""
-    b = RowsBacking(store, segments, res)
+def lazy_rows_by_segment(store, segments, res, ctx=None):
+    """-> (RowsBacking, list (per segment) of call-index ranges [lo, hi)): the lazy counterpart of rows_by_segment.
+    ctx: the engine.Context `res` came from with reuse=True (its arrays are then kept, not copied)."""
+    b = RowsBacking(store, segments, res, ctx)
     n = b.res.n_calls
     cut = np.searchsorted(b.res.arrays["call_seg"][:n], np.arange(len(b.segments) + 1)).tolist()
     return b, [(cut[k], cut[k + 1]) for k in range(len(b.segments))]

@@ -1317,6 +1317,16 @@ def test_lazy_stage_equals_the_row_lists(ctx):
         a = list(eager[ch]); a.sort(key=lambda x: int(x[2]))
         lazy[ch].sort(key=lambda x: int(x[2]))
         assert lazy[ch] == a and lazy[ch].backing() is not None
+    # the rows read the context's recycled result in place (Context.lend): it is out of recycling while they live, back after
+    held = next(iter(again.values())).backing().res
+    assert held is not ctx._res_cache
+    del lazy
+    import gc
+    gc.collect()
+    third = resolve.cluster_stage(st, p, ctx=ctx, lazy=True)
+    for ch in eager:
+        assert again[ch] == eager[ch] and third[ch] == eager[ch]
+    assert next(iter(again.values())).backing().res is held
     ref = {c: synth.reference_sequence(3_200_000, seed=9 + i) for i, c in enumerate(st.chroms)}
     hb = st.host_batch(st.tasks(), p)
     kw = dict(min_size=p.min_size, max_size=p.max_size, genotype=True)

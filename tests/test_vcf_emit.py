@@ -213,6 +213,56 @@ def test_lazy_rows_are_the_row_lists():
     assert n_checked > 500
 
 
+class _RecyclingCtx(_OracleCtx):
+    """... and recycles ONE result object the way engine.Context does with reuse=True (overwriting it), with the same lend /
+    give_back protocol"""
+
+    def __init__(self):
+        self._res_cache, self.made = None, 0
+
+    def cluster_batch(self, hb, reuse=False, **kw):
+        fresh = oracle.cluster_batch(hb, per_sig=False)
+        if self._res_cache is None:
+            self._res_cache, self.made = fresh, self.made + 1
+            return fresh
+        old = self._res_cache                         # overwrite the recycled arrays in place
+        for k, v in fresh.arrays.items():
+            if v is not None and old.arrays.get(k) is not None and len(old.arrays[k]) >= len(v):
+                old.arrays[k][:len(v)] = v
+        old.c.n_calls, old.c.n_support, old.c.n_clusters = fresh.n_calls, fresh.n_support, fresh.n_clusters
+        return old
+
+
+
+def test_lazy_rows_keep_a_lent_result_instead_of_copying_it():
+    """rows.RowsBacking asks the context to lend its recycled result (engine.Context.lend / give_back): the rows then read
+    the arrays in place, the context's next call gets other arrays, and a dead backing returns its result"""
+    import gc
+    from cutesv_amd import resolve, engine
+    st = synth.small_mixed(seed=77, genotype=False)
+    p = Params.ont()
+    tasks = st.tasks()
+    ctx = _RecyclingCtx()
+    ctx.lend = lambda res: engine.Context.lend(ctx, res)
+    ctx.give_back = lambda res: engine.Context.give_back(ctx, res)
+    _, eager = _lazy_and_eager(st, p, tasks)
+    a = resolve.cluster_stage(st, p, tasks=tasks, ctx=ctx, lazy=True)
+    held = next(iter(a.values())).backing().res
+    assert ctx._res_cache is None and ctx.made == 1             # lent: no copy was made, the slot is empty
+    st2 = synth.small_mixed(seed=78, genotype=False)              # another batch through the same context ...
+    b = resolve.cluster_stage(st2, p, tasks=st2.tasks(), ctx=ctx, lazy=True)
+    assert ctx.made == 2 and next(iter(b.values())).backing().res is not held
+    for ch in eager:                                              # ... leaves the first rows alone
+        assert a[ch] == eager[ch]
+    del a
+    gc.collect()
+    assert ctx._res_cache is held                                 # given back
+    # a context without the protocol: the rows take a private copy, as before
+    c = resolve.cluster_stage(st, p, tasks=tasks, ctx=_OracleCtx(), lazy=True)
+    for ch in eager:
+        assert c[ch] == eager[ch]
+
+
 def test_native_emitter_reads_the_lazy_stage_without_rows():
     small = {c["name"]: c for c in load_json("small_cases.json.gz")}
     for g in load_json("vcf_lines.json.gz")[:9]:
