@@ -19,3 +19,5 @@ timeout 300 python scripts/oneshot_ab.py cfg3 cfg4 cfg5 cfg2 > $F/${TAG}_oneshot
 ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/os_tl && cd $R && timeout -k 5 300 rocprofv3 --kernel-trace --memory-copy-trace -d /tmp/os_tl -o tl -- python scripts/oneshot_ab.py cfg3 > $F/${TAG}_oneshot_tl.log 2>&1 )
 python scripts/rocprof_oneshot_timeline.py $(ls /tmp/os_tl/*.db /tmp/os_tl/*/*.db 2>/dev/null | head -1) 2 > $F/${TAG}_oneshot_timeline.txt 2>&1
 python scripts/resource_usage.py > $F/${TAG}_resource_usage.txt 2>/dev/null
+# where k_genotype's wavefronts spend their cycles (measurement build: make -C cutesv_amd/csrc gt-prof)
+if [ -f $R/build/lib_prof.so ]; then for wl in cfg5 cfg4; do echo "# $wl"; CUTESV_AMD_LIB=$R/build/lib_prof.so timeout 300 python scripts/gt_prof.py $wl 2>&1 | grep gt_prof | tail -1; done > $F/${TAG}_gt_prof.txt; fi
