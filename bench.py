@@ -236,8 +236,17 @@ def bench_extract(a):
         for k in range(n_task):
             extract.cigar_signatures(ctx, off, cigar, start + k, use, pool=dict(seg_ins=1, seg_del=0, read_base=k * n), host_outputs=False)
         return rebuild.rebuild_pool(ctx, rank, major, nodedup, keep_on_device=True)
-    chain = {}
-    for name, fn in (("through_host_ms", via_host), ("on_device_ms", via_pool)):
+    # ... and the same with the reads' CIGAR words in page-locked memory (a driver decodes the BAM records into such a buffer):
+    # the hand-off's floor is then the words themselves over PCIe (n_task x 73 MB at 55 GB/s)
+    p_off, p_cigar = engine.pinned_copy(off), engine.pinned_copy(cigar)
+
+    def via_pool_pinned():
+        rebuild.pool_reset(ctx)
+        for k in range(n_task):
+            extract.cigar_signatures(ctx, p_off, p_cigar, start + k, use, pool=dict(seg_ins=1, seg_del=0, read_base=k * n), host_outputs=False)
+        return rebuild.rebuild_pool(ctx, rank, major, nodedup, keep_on_device=True)
+    chain = {"cigar_bytes_per_task": int(cigar.nbytes), "pcie_floor_ms": n_task * cigar.nbytes / 55e9 * 1e3}
+    for name, fn in (("through_host_ms", via_host), ("on_device_ms", via_pool), ("on_device_pinned_cigars_ms", via_pool_pinned)):
         fn()
         t0 = time.perf_counter(); r = fn(); chain[name] = (time.perf_counter() - t0) * 1e3
         chain[name.replace("_ms", "_rows")] = int(r["n_out"])

@@ -62,12 +62,13 @@ def tie_callback(seq_of_src, half_of_src):
     return TIE_ORDER_FN(fn)
 
 
-def rebuild_columns(ctx, seg_id, a, b, read_id, aux, seg_aux_major, seg_nodedup=None, keep_on_device=False, tie_order=None):
+def rebuild_columns(ctx, seg_id, a, b, read_id, aux, seg_aux_major, seg_nodedup=None, keep_on_device=False, tie_order=None, src_row_out=None):
     """-> dict(seg_id, a, b, read_id, aux, src_row, ms_device, n_passes, seg_count, n_ins_ties): sorted, de-duplicated rows.
     tie_order: a `tie_callback(...)`: the tie groups of the keep-every-row segments are settled inside the call (n_ins_ties 0).
     keep_on_device: the sorted columns stay in device memory (CSV_RB_KEEP_ON_DEVICE): the dict then holds `dev` (device
     addresses of a / b / read_id / aux, valid until the context's next rebuild / extraction call) and, from the host side,
-    only src_row and seg_count - 4 instead of 28 bytes per row cross PCIe."""
+    only src_row and seg_count - 4 instead of 28 bytes per row cross PCIe.
+    src_row_out: an int32 array of at least n entries to receive src_row (a page-locked one lands by DMA)."""
     L = lib()
     L.csv_rebuild_signatures.restype = C.c_int
     L.csv_rebuild_signatures.argtypes = [C.c_void_p, C.POINTER(RebuildIn), C.POINTER(RebuildOut)]
@@ -76,8 +77,13 @@ def rebuild_columns(ctx, seg_id, a, b, read_id, aux, seg_aux_major, seg_nodedup=
     major = np.ascontiguousarray(seg_aux_major, np.uint8)
     nodedup = None if seg_nodedup is None else np.ascontiguousarray(seg_nodedup, np.uint8)
     n = len(a)
-    o = dict(seg_id=np.empty(n, np.int32), a=np.empty(n, np.int64), b=np.empty(n, np.int64), read_id=np.empty(n, np.int32),
-             aux=np.empty(n, np.int32), src_row=np.empty(n, np.int32))
+    if src_row_out is not None and (src_row_out.dtype != np.int32 or len(src_row_out) < n or not src_row_out.flags.c_contiguous):
+        raise ValueError("src_row_out must be a contiguous int32 array of at least %d entries" % n)
+    if keep_on_device:                                    # (the five sorted columns stay on the device: no host arrays for them)
+        o = dict(src_row=src_row_out if src_row_out is not None else np.empty(n, np.int32))
+    else:
+        o = dict(seg_id=np.empty(n, np.int32), a=np.empty(n, np.int64), b=np.empty(n, np.int64), read_id=np.empty(n, np.int32),
+                 aux=np.empty(n, np.int32), src_row=src_row_out if src_row_out is not None else np.empty(n, np.int32))
     seg_count = np.zeros(len(major), np.int64)
     rin = RebuildIn(n=n, n_seg=len(major), flags=_abi.RB_KEEP_ON_DEVICE if keep_on_device else 0, seg_aux_major=major.ctypes.data,
                     seg_id=seg_id.ctypes.data, a=a.ctypes.data, b=b.ctypes.data, read_id=read_id.ctypes.data, aux=aux.ctypes.data,
@@ -102,12 +108,41 @@ def rebuild_columns(ctx, seg_id, a, b, read_id, aux, seg_aux_major, seg_nodedup=
     return out
 
 
+_STAGE = (("seg", np.int32), ("a", np.int64), ("b", np.int64), ("rid", np.int32), ("aux", np.int32), ("src_row", np.int32))
+
+
+_FILL_CHUNK = 1 << 19                                   # rows per copy job
+_POOL = []
+
+
+def _fill_pool():
+    if not _POOL:
+        import concurrent.futures
+        import os
+        _POOL.append(concurrent.futures.ThreadPoolExecutor(max_workers=max(2, min(8, (os.cpu_count() or 2) // 2)), thread_name_prefix="csv-stage"))
+    return _POOL[0]
+
+
+def _staging(ctx, n):
+    """views [:n] of the context's page-locked staging columns (grown by half when too small)"""
+    from .engine import pinned_empty
+    st = getattr(ctx, "_rb_stage", None)
+    if st is None or st["cap"] < n:
+        cap = max(1024, n + n // 2 if st is not None else n)
+        st = {"cap": cap}
+        for k, dt in _STAGE:
+            st[k] = pinned_empty(cap, dt)
+        ctx._rb_stage = st
+    return {k: st[k][:n] for k, _ in _STAGE}
+
+
 def rebuild_to_device_batch(ctx, chroms, per_type, params_segment, reads=None):
     """The rebuild -> cluster hand-off without a host round trip (the reference's dataflow main script :750-857 -> :1113-1199):
     unsorted per-type rows (as store_from_unsorted takes them) are sorted and de-duplicated on the device and STAY there;
     returns (batch, tasks, src_row) where `batch` is an `_abi.HostBatch.on_device` whose columns are the rebuild's device
     buffers, `tasks` the (type, chromosome) pairs of its segments in the reference's order and `src_row` the input row of every
-    sorted row (to carry read names / sequences on the host).
+    sorted row (to carry read names / sequences on the host).  Like the batch's device columns, `src_row` lives in the
+    context's staging memory: both are valid until the context's next rebuild call (copy src_row to keep it longer).
     params_segment(svtype, chrom_index, begin, end) -> csv_segment record.
     INS rows with `seq` (and `half`): rows that tie on (chromosome, int(pos), len, read) are ordered by their sequences and
     de-duplicated on the whole tuple as the reference does - the few tie rows' indices visit the host through the library's
@@ -116,15 +151,35 @@ def rebuild_to_device_batch(ctx, chroms, per_type, params_segment, reads=None):
     order = sorted(range(len(chroms)), key=lambda i: chroms[i])
     crank = np.zeros(len(chroms), np.int64)
     crank[order] = np.arange(len(chroms))
-    cols = {k: [] for k in ("seg", "a", "b", "rid", "aux")}
-    for ti, t in enumerate(TYPES):
-        if t not in per_type or len(per_type[t]["a"]) == 0:
-            continue
+    # The five columns are written ONCE, in the ABI's widths, into page-locked staging arrays the context keeps (no per-type
+    # temporaries, no concatenate pass, and the upload is a DMA at the link's rate instead of a staged copy of pageable memory:
+    # the 80 MB of a 30x genome's rows took 4 of the chain's 8.6 ms)
+    live = [(ti, t) for ti, t in enumerate(TYPES) if t in per_type and len(per_type[t]["a"])]
+    n_rows = sum(len(per_type[t]["a"]) for _, t in live)
+    cat = _staging(ctx, n_rows)
+    # (one core copies ~20 GB/s: the pieces go to a few threads - numpy's copy / take loops run without the interpreter lock)
+    jobs = []
+    lo = 0
+    for ti, t in live:
         d = per_type[t]
-        cols["seg"].append((ti * len(chroms) + crank[np.asarray(d["chrom"], np.int64)]).astype(np.int32))
-        cols["a"].append(np.asarray(d["a"], np.int64)); cols["b"].append(np.asarray(d["b"], np.int64))
-        cols["rid"].append(np.asarray(d["read_id"], np.int32)); cols["aux"].append(np.asarray(d["aux"], np.int32))       # (the ABI's widths: no conversion pass later)
-    cat = {k: np.concatenate(v) if v else np.zeros(0, np.int64) for k, v in cols.items()}
+        hi = lo + len(d["a"])
+        ch = np.asarray(d["chrom"])
+        if len(ch) and (int(ch.min()) < 0 or int(ch.max()) >= len(chroms)):
+            raise ValueError("%s rows: chromosome index outside [0, %d)" % (t, len(chroms)))
+        seg_of_chrom = (ti * len(chroms) + crank).astype(np.int32)
+        src = {"a": np.asarray(d["a"]), "b": np.asarray(d["b"]), "rid": np.asarray(d["read_id"]), "aux": np.asarray(d["aux"])}
+        for c0 in range(0, hi - lo, _FILL_CHUNK):
+            c1 = min(hi - lo, c0 + _FILL_CHUNK)
+            jobs.append((np.take, (seg_of_chrom, ch[c0:c1]), dict(out=cat["seg"][lo + c0:lo + c1], mode="clip")))
+            for k, v in src.items():
+                jobs.append((np.copyto, (cat[k][lo + c0:lo + c1], v[c0:c1]), dict(casting="unsafe")))
+        lo = hi
+    if len(jobs) > 8:
+        for f in [_fill_pool().submit(fn, *args, **kw) for fn, args, kw in jobs]:
+            f.result()
+    else:
+        for fn, args, kw in jobs:
+            fn(*args, **kw)
     n_seg = len(TYPES) * len(chroms)
     major = np.zeros(n_seg, np.uint8)
     nodedup = np.zeros(n_seg, np.uint8)
@@ -140,7 +195,8 @@ def rebuild_to_device_batch(ctx, chroms, per_type, params_segment, reads=None):
         seqs = ins["seq"]
         half = ins.get("half")
         cb = tie_callback(lambda s_: seqs[s_ - ins_base], (lambda s_: half[s_ - ins_base]) if half is not None else (lambda s_: 0))
-    r = rebuild_columns(ctx, cat["seg"], cat["a"], cat["b"], cat["rid"], cat["aux"], major, nodedup, keep_on_device=True, tie_order=cb)
+    r = rebuild_columns(ctx, cat["seg"], cat["a"], cat["b"], cat["rid"], cat["aux"], major, nodedup, keep_on_device=True, tie_order=cb,
+                        src_row_out=cat["src_row"])
     if r["n_ins_ties"]:                                     # (with a tie callback the device order is final; never with `assert`: -O strips it)
         raise ValueError("%d INS rows tie on (position, length, read) and were not settled on the device: the batch is not in the "
                          "reference's order" % r["n_ins_ties"])

@@ -15,21 +15,25 @@ for rep in range(3):
     r2 = ctx.cluster_batch(batch)
     t2=time.perf_counter()
     print("rebuild_to_device_batch %.2f ms, cluster_batch(device columns) %.2f ms" % ((t1-t0)*1e3,(t2-t1)*1e3))
-# pieces
-chroms=store.chroms
-t0=time.perf_counter()
-order = sorted(range(len(chroms)), key=lambda i: chroms[i]); crank=np.zeros(len(chroms),np.int64); crank[order]=np.arange(len(chroms))
-cols = {k: [] for k in ("seg","a","b","rid","aux")}
-for ti,t in enumerate(TYPES):
-    if t not in per or len(per[t]["a"])==0: continue
-    d=per[t]
-    cols["seg"].append(ti*len(chroms)+crank[np.asarray(d["chrom"],np.int64)])
-    cols["a"].append(np.asarray(d["a"],np.int64)); cols["b"].append(np.asarray(d["b"],np.int64))
-    cols["rid"].append(np.asarray(d["read_id"],np.int64)); cols["aux"].append(np.asarray(d["aux"],np.int64))
-t1=time.perf_counter()
-cat={k: np.concatenate(v) for k,v in cols.items()}
-t2=time.perf_counter()
-major=np.zeros(len(TYPES)*len(chroms),np.uint8)
-r=rebuild.rebuild_columns(ctx, cat["seg"],cat["a"],cat["b"],cat["rid"],cat["aux"],major,None,keep_on_device=True)
-t3=time.perf_counter()
-print("per-type numpy %.2f ms, concatenate %.2f ms, rebuild_columns %.2f ms (device %.2f ms) dtypes %s" % ((t1-t0)*1e3,(t2-t1)*1e3,(t3-t2)*1e3,r["ms_device"], {k:str(v.dtype) for k,v in per["DEL"].items() if hasattr(v,'dtype')}))
+# pieces of rebuild_to_device_batch: the staging fill (numpy, page-locked destination), the library call, the segment records
+chroms = store.chroms
+live = [(ti, t) for ti, t in enumerate(TYPES) if t in per and len(per[t]["a"])]
+n_rows = sum(len(per[t]["a"]) for _, t in live)
+for rep in range(3):
+    t0 = time.perf_counter()
+    cat = rebuild._staging(ctx, n_rows)
+    lo = 0
+    for ti, t in live:
+        d = per[t]; hi = lo + len(d["a"])
+        np.take(np.arange(len(chroms), dtype=np.int32), np.asarray(d["chrom"]), out=cat["seg"][lo:hi], mode="clip")
+        np.copyto(cat["a"][lo:hi], d["a"], casting="unsafe"); np.copyto(cat["b"][lo:hi], d["b"], casting="unsafe")
+        np.copyto(cat["rid"][lo:hi], d["read_id"], casting="unsafe"); np.copyto(cat["aux"][lo:hi], d["aux"], casting="unsafe")
+        lo = hi
+    t1 = time.perf_counter()
+    major = np.zeros(len(TYPES) * len(chroms), np.uint8)
+    r = rebuild.rebuild_columns(ctx, cat["seg"], cat["a"], cat["b"], cat["rid"], cat["aux"], major, None, keep_on_device=True)
+    t2 = time.perf_counter()
+    segs = [seg_of(t, 0, 0, 1) for _ in range(48)]
+    t3 = time.perf_counter()
+    print("staging fill %.2f ms (%d rows, %.0f MB), rebuild_columns %.2f ms (device %.2f ms), 48 segment records %.2f ms; input dtypes %s" %
+          ((t1 - t0) * 1e3, n_rows, n_rows * 28 / 1e6, (t2 - t1) * 1e3, r["ms_device"], (t3 - t2) * 1e3, {k: str(v.dtype) for k, v in per["DEL"].items() if hasattr(v, "dtype")}))

@@ -576,3 +576,46 @@ def test_pickle_walker_accepts_nothing_that_pickle_rejects():
     finally:
         signal.signal(signal.SIGALRM, old)
     assert walker_only == 0 and both > 500, (walker_only, both)
+
+
+def test_rebuild_staging_fill_equals_the_concatenated_columns(monkeypatch):
+    """rebuild.rebuild_to_device_batch writes the per-type rows once, in the ABI's widths, into the context's staging columns
+    (threads, chunks of 2^19 rows): the same columns as the per-type conversions + np.concatenate they replaced"""
+    from cutesv_amd import rebuild, engine
+    from cutesv_amd.columns import TYPES
+    monkeypatch.setattr(engine, "pinned_empty", lambda n, dt: np.empty(n, dt))
+    rng = np.random.default_rng(1)
+    chroms = ["2", "10", "1", "X"]
+    per = {}
+    for t, m in (("DEL", 1_300_000), ("INS", 700_001), ("TRA", 5)):
+        per[t] = dict(chrom=rng.integers(0, 4, m), a=rng.integers(0, 1 << 40, m), b=rng.integers(0, 1 << 20, m),
+                      read_id=rng.integers(0, 1 << 30, m).astype(np.int32), aux=rng.integers(0, 1000, m))
+    seen = {}
+
+    class Stop(Exception):
+        pass
+
+    def capture(ctx, seg, a, b, rid, aux, major, nodedup, **kw):
+        seen.update(seg=seg.copy(), a=a.copy(), b=b.copy(), rid=rid.copy(), aux=aux.copy(), src_row_out=kw.get("src_row_out"))
+        raise Stop()
+    monkeypatch.setattr(rebuild, "rebuild_columns", capture)
+
+    class Ctx:
+        pass
+    with pytest.raises(Stop):
+        rebuild.rebuild_to_device_batch(Ctx(), chroms, per, None)
+    order = sorted(range(len(chroms)), key=lambda i: chroms[i])
+    crank = np.zeros(len(chroms), np.int64)
+    crank[order] = np.arange(len(chroms))
+    want = {k: [] for k in ("seg", "a", "b", "rid", "aux")}
+    for ti, t in enumerate(TYPES):
+        if t in per:
+            d = per[t]
+            want["seg"].append((ti * len(chroms) + crank[d["chrom"]]).astype(np.int32))
+            want["a"].append(d["a"]); want["b"].append(d["b"]); want["rid"].append(d["read_id"]); want["aux"].append(d["aux"].astype(np.int32))
+    for k, v in want.items():
+        assert np.array_equal(seen[k], np.concatenate(v)) and seen[k].dtype == np.concatenate(v).dtype, k
+    assert seen["src_row_out"] is not None and len(seen["src_row_out"]) == len(seen["a"])
+    per["DEL"]["chrom"][7] = 4                                         # a chromosome index outside the table is an error, not a clip
+    with pytest.raises(ValueError):
+        rebuild.rebuild_to_device_batch(Ctx(), chroms, per, None)
