@@ -546,7 +546,10 @@ class SigStore:
         name_span = spans[{"DEL": 0, "DUP": 0, "INS": 0, "INV": 1, "TRA": 2}[svtype]]
         cd = []
         if svtype == "INS":
-            cn.span_cplen(sig_buf, spans[1][0], spans[1][1], aux)
+            if t[4]:                                      # every string of the stream is ASCII (the walker validated them): len = bytes
+                aux[:] = spans[1][1]
+            else:
+                cn.span_cplen(sig_buf, spans[1][0], spans[1][1], aux)
             ins_seq = SpanList(sig_buf, spans[1][0], spans[1][1])
         elif svtype == "INV":
             sd, sid = small(sig_buf, spans[0])

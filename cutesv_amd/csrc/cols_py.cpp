@@ -319,7 +319,8 @@ PyObject* clip_join(PyObject*, PyObject* args)
 // LONG_BINPUT BINGET LONG_BINGET NEWTRUE NEWFALSE NONE STOP - and returns None for anything else (the caller then uses pickle).
 //
 //   pickle_table(buf, offset, width, int_fields, str_fields) -> None | (n_rows, end_offset, [int64 bytes per int field],
-//                                                                      [(offsets int64 bytes, lengths int32 bytes) per str field])
+//                                                                      [(offsets int64 bytes, lengths int32 bytes) per str field],
+//                                                                      all_ascii: no string payload of the stream has a byte >= 0x80)
 //   span_intern(((buf, offsets, lengths, ids int32 out), ...)) -> (blob bytes, offsets int64 bytes, lengths int32 bytes) of the
 //                 distinct strings by first appearance, ONE id space over all specs
 //   span_join(buf, offsets, lengths, picks int64, clips int64 | None, out_len int64) -> bytes     (clip_join for a span table)
@@ -330,7 +331,7 @@ struct Cell { Kind kind; int32_t len; int64_t a; };
 
 // what PyUnicode_DecodeUTF8(.., "surrogatepass") - pickle's decoder of BINUNICODE payloads - accepts: well-formed UTF-8 (no
 // overlong forms, nothing above U+10FFFF) plus three-byte encoded surrogates
-inline bool utf8_ok(const unsigned char* s, int64_t n)
+inline bool utf8_ok(const unsigned char* s, int64_t n, bool* not_ascii = nullptr)
 {
     {   // all ASCII - every read name and sequence of a real file - is one OR over the payload, 32 bytes a step (memory speed)
         uint64_t acc = 0;
@@ -339,6 +340,7 @@ inline bool utf8_ok(const unsigned char* s, int64_t n)
         for (; j < n; j++) acc |= s[j];
         if (!(acc & 0x8080808080808080ull)) return true;
     }
+    if (not_ascii) *not_ascii = true;
     int64_t i = 0;
     while (i < n) {
         if (i + 8 <= n) { uint64_t w; memcpy(&w, s + i, 8); if (!(w & 0x8080808080808080ull)) { i += 8; continue; } }
@@ -388,7 +390,7 @@ PyObject* pickle_table(PyObject*, PyObject* args)
     std::vector<std::vector<int64_t>> ci(fi.size()), so(fs.size());
     std::vector<std::vector<int32_t>> sl(fs.size());
     int64_t n_rows = 0;
-    bool done = false, unsupported = false;
+    bool done = false, unsupported = false, any_non_ascii = false;       // (all-ASCII text: len() of a string is its byte count)
     const char* corrupt = nullptr;
     auto memo_put = [&](uint64_t k) {
         if (st.empty()) { corrupt = "memo of an empty stack"; return; }
@@ -470,7 +472,7 @@ PyObject* pickle_table(PyObject*, PyObject* args)
             if (!R.need((int64_t)len)) { corrupt = "truncated"; break; }
             // (pickle decodes the payload as it reads it - UTF-8, surrogatepass - and raises on anything else; the spans handed out
             // here are decoded later, or never: the check is made now, 8 bytes at a time for ASCII)
-            if (!utf8_ok(R.p + R.i, (int64_t)len)) { unsupported = true; break; }
+            if (!utf8_ok(R.p + R.i, (int64_t)len, &any_non_ascii)) { unsupported = true; break; }
             st.push_back(Cell{STR, (int32_t)len, R.i});
             R.i += (int64_t)len;
             break;
@@ -538,7 +540,7 @@ PyObject* pickle_table(PyObject*, PyObject* args)
         if (!t) { Py_DECREF(ints); Py_DECREF(strs); return nullptr; }
         PyList_SET_ITEM(strs, (Py_ssize_t)k, t);
     }
-    return Py_BuildValue("(LLNN)", (long long)n_rows, (long long)R.i, ints, strs);
+    return Py_BuildValue("(LLNNO)", (long long)n_rows, (long long)R.i, ints, strs, any_non_ascii ? Py_False : Py_True);
 }
 
 // read-only views of (buffer, int64 offsets, int32 lengths)
@@ -725,7 +727,7 @@ PyMethodDef kMethods[] = {
     {"walk", walk, METH_VARARGS, "walk(seq, ints, interns, lens): fill column buffers from a list of tuples"},
     {"intern", intern, METH_VARARGS, "intern(((seq, field, int32 buffer), ...)) -> distinct values by first appearance; ids into the buffers"},
     {"column", column, METH_VARARGS, "column(seq, field) -> [x[field] for x in seq]"},
-    {"pickle_table", pickle_table, METH_VARARGS, "pickle_table(buf, offset, width, int_fields, str_fields) -> None | (n, end, [int64 bytes], [(off bytes, len bytes)])"},
+    {"pickle_table", pickle_table, METH_VARARGS, "pickle_table(buf, offset, width, int_fields, str_fields) -> None | (n, end, [int64 bytes], [(off bytes, len bytes)], all_ascii)"},
     {"span_intern", span_intern, METH_VARARGS, "span_intern(((buf, off, len, ids), ...)) -> (blob, off, len) of the distinct strings by first appearance"},
     {"span_join", span_join, METH_VARARGS, "span_join(buf, off, len, picks, clips | None, out_len) -> bytes"},
     {"span_cplen", span_cplen, METH_VARARGS, "span_cplen(buf, off, len, out int32): len() of every string"},

@@ -436,6 +436,16 @@ def test_task_pickles_walked_in_c_give_the_store_pickle_load_gives(tmp_path):
 
     reads = [(int(rng.integers(0, 1 << 28)), int(rng.integers(1 << 28, 1 << 29)), bool(i & 1) if i % 3 else int(i & 1),
               names[int(rng.integers(0, len(names)))], "chr1" if i % 4 else "chr2") for i in range(700)]
+    # the walker says whether every string of a stream was ASCII (a string's len() is then its byte count and the store skips
+    # the code-point pass over the sequences): both answers
+    ascii_rows = [(10 + i, 50, "read%d" % (i % 7), "ACGT" * (i % 5), "INS", "chr1") for i in range(40)]
+    for rows_, flag in ((ascii_rows, True), (ascii_rows[:20] + [(31, 50, "read1", "ACé", "INS", "chr1")] + ascii_rows[20:], False),
+                        (ascii_rows[:20] + [(31, 50, "ré", "AC", "INS", "chr1")], False)):
+        blob = pickle.dumps(rows_, protocol=4)
+        t = cn.pickle_table(blob, 0, 6, (0, 1), (2, 3))
+        assert t is not None and t[4] is flag
+        got = SigStore.from_task_pickles("INS", "chr1", blob, 0)
+        assert got.aux.tolist() == [len(r[3]) for r in rows_]
     for proto in (2, 3, 4, 5):
         for svtype in ("DEL", "INS", "DUP", "INV", "TRA"):
             for n in (0, 1, 3, 2500):                         # (APPEND form, one APPENDS batch, several batches and frames)
