@@ -1,0 +1,183 @@
+"""bench.py's `mode1_stage` leg (also runnable by itself): the clustering stage the way cuteSV runs it.
+
+The reference's phase 3 (main script :1113-1199) is a forked `Pool(processes=threads)` with one `map_async(run_X, [tuple])`
+per (chromosome, type); its workers read their task from `<TYPE>.pickle` / `reads.pickle`.  This leg writes a workload as
+exactly those files (outside every timed region) and times, from `Pool(...)` to the merged `results` dict:
+
+  * the drop-in - `cutesv_amd.resolve.run_*` under that pool, T workers sharing ONE GPU through its broker
+    (`cutesv_amd/broker.py`); `warm`: the broker was started ahead of the stage (`resolve.warm_up()`, as a cuteSV run would do
+    at start-up: the HIP runtime's start overlaps the extraction phase); `cold`: the first worker starts it inside the
+    timed region; `direct`: one HIP context per worker, created after fork (CUTESV_AMD_BROKER=0);
+  * the reference's execution model - `oracle/py_restatement.py`'s five callables under the same pool, the same T, reading
+    the SAME pickles (both sides pay for `pickle`).
+
+    python bench_stage.py --workload cfg4 --workers 1,8,32
+"""
+import argparse
+import hashlib
+import json
+import os
+import shutil
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from cutesv_amd import resolve, broker                 # noqa: E402
+
+READS_FIELD = {"DEL": 12, "INS": 12, "DUP": 10, "INV": 11}
+
+
+def rows_digest(results):
+    """order-independent over chromosomes, order-dependent inside one; DUP / TRA read lists as sets (the reference builds them
+    from Python sets: DUP:82, TRA:182)"""
+    h = hashlib.sha256()
+    n = 0
+    for ch in sorted(results):
+        for r in results[ch]:
+            r = list(r)
+            k = READS_FIELD.get(r[1], 11)
+            if r[1] == "DUP" or r[1] not in READS_FIELD:
+                r[k] = ",".join(sorted(r[k].split(",")))
+            h.update("\t".join(r).encode())
+            h.update(b"\n")
+            n += 1
+    return n, h.hexdigest()
+
+
+def _stage(wd, idx, params, T, fns=None):
+    t0 = time.perf_counter()
+    res = resolve.main_ctrl_phase3(wd, idx, params, T, fns=fns)
+    return time.perf_counter() - t0, res
+
+
+def _broker_info(shutdown=False):
+    try:
+        with broker.Client.connect(resolve.device_index(), owner_pid=os.getpid(), spawn=False) as cl:
+            info = cl.info()
+            if shutdown:
+                cl.shutdown()
+        return info
+    except broker.BrokerError:
+        return None
+
+
+def _wait_gone(timeout=20.0):
+    t_end = time.monotonic() + timeout
+    name = broker.socket_name(os.getpid(), resolve.device_index())
+    while broker._try_connect(name) is not None and time.monotonic() < t_end:
+        time.sleep(0.02)
+
+
+def mode1_stage(name, store, params, workers=(1, 8, 32), reference=True, cold_and_direct_at=8, reps=2, keep_dir=None, log=None):
+    """-> dict for the bench line.  Must run before this process holds any HIP state (the pools fork)."""
+    from oracle import py_restatement as pr                       # (the CPU baseline of this leg)
+    say = log or (lambda s: sys.stderr.write("[mode1_stage %s] %s\n" % (name, s)))
+    wd = (keep_dir or tempfile.mkdtemp(prefix="cutesv_amd_stage_")) + "/"
+    os.makedirs(wd, exist_ok=True)
+    out = {"workload": name, "signatures": int(store.n_sig), "reads": int(store.n_reads),
+           "region": "Pool(processes=T) -> one map_async(run_X, [tuple]) per (chr, type) on the reference's pickles -> merged results dict "
+                     "(main script :1113-1199); pickles written outside the timed region"}
+    try:
+        t0 = time.perf_counter()
+        idx = store.write_reference_workdir(wd)
+        out["tasks"] = sum(len(idx[t]) for t in ("DEL", "INS", "INV", "DUP", "TRA"))
+        out["write_workdir_s"] = round(time.perf_counter() - t0, 2)
+        out["pickle_bytes"] = sum(os.path.getsize(os.path.join(wd, f)) for f in os.listdir(wd))
+        os.environ.setdefault("CUTESV_AMD_TRA_GT", "off")         # (the synthetic work dirs have no BAM to re-open, TRA:258-309)
+        n_sig = out["signatures"]
+        legs = []
+        os.environ["CUTESV_AMD_BROKER"] = "1"
+        t0 = time.perf_counter()
+        resolve.warm_up()
+        # a worker's first request waits for the broker's context anyway; make "warm" mean warm
+        deadline = time.monotonic() + 180
+        info = None
+        while info is None and time.monotonic() < deadline:
+            info = _broker_info()
+            if info is None:
+                time.sleep(0.02)
+        out["broker_start_s"] = round(time.perf_counter() - t0, 3)
+        out["broker_engine_start_s"] = None if info is None else info.get("engine_start_s")
+        ref_digest = None
+        for T in workers:
+            walls = []
+            for _ in range(reps):
+                dt, res = _stage(wd, idx, params, T)
+                walls.append(dt)
+            dg = rows_digest(res)
+            leg = {"workers": T, "wall_ms": round(min(walls) * 1e3, 2), "wall_ms_all": [round(w * 1e3, 1) for w in walls], "rows": dg[0],
+                   "signatures_per_s": round(n_sig / min(walls))}
+            say("drop-in warm broker T=%d: %s ms" % (T, leg["wall_ms_all"]))
+            if reference:
+                dtr, ref = _stage(wd, idx, params, T, fns=pr.REF_FNS)
+                rd = rows_digest(ref)
+                ref_digest = ref_digest or rd
+                leg.update(reference_pool_wall_ms=round(dtr * 1e3, 1), vs_reference_pool=round(dtr / min(walls), 1), rows_equal_reference_model=(rd == dg))
+                say("reference model T=%d: %.1f ms (x%.1f), rows equal: %s" % (T, dtr * 1e3, dtr / min(walls), rd == dg))
+            legs.append(leg)
+        info = _broker_info(shutdown=True)
+        _wait_gone()
+        resolve.shut_down()
+        out["legs"] = legs
+        out["broker"] = None if info is None else {k: info.get(k) for k in ("calls", "batches", "merged_calls", "max_batch", "busy_s", "maps", "bus", "engine")}
+        if cold_and_direct_at:
+            T = cold_and_direct_at
+            os.environ.pop("CUTESV_AMD_BROKER_NAME", None)
+            dt, res = _stage(wd, idx, params, T)                   # cold: the first worker starts the broker
+            out["cold_broker"] = {"workers": T, "wall_ms": round(dt * 1e3, 1), "rows": rows_digest(res)[0]}
+            say("drop-in cold broker T=%d: %.1f ms" % (T, dt * 1e3))
+            _broker_info(shutdown=True)
+            _wait_gone()
+            os.environ["CUTESV_AMD_BROKER"] = "0"                  # direct: a HIP context per worker, created after fork
+            walls = []
+            for _ in range(2):
+                dt, res = _stage(wd, idx, params, T)
+                walls.append(dt)
+            out["context_per_worker"] = {"workers": T, "wall_ms": round(min(walls) * 1e3, 1), "wall_ms_all": [round(w * 1e3, 1) for w in walls],
+                                         "rows": rows_digest(res)[0]}
+            say("drop-in context per worker T=%d: %s ms" % (T, out["context_per_worker"]["wall_ms_all"]))
+    finally:
+        os.environ.pop("CUTESV_AMD_BROKER", None)
+        os.environ.pop("CUTESV_AMD_BROKER_NAME", None)
+        if keep_dir is None:
+            shutil.rmtree(wd, ignore_errors=True)
+    return out
+
+
+def compact(m):
+    """what fits the driver's line: {workers, wall_ms, signatures_per_s, vs_reference_pool} per T"""
+    if not isinstance(m, dict) or "legs" not in m:
+        return m
+    c = {"tasks": m.get("tasks"), "legs": [{k: leg.get(k) for k in ("workers", "wall_ms", "signatures_per_s", "reference_pool_wall_ms", "vs_reference_pool",
+                                                                       "rows_equal_reference_model")} for leg in m["legs"]]}
+    for k in ("cold_broker", "context_per_worker"):
+        if m.get(k):
+            c[k] = {"workers": m[k]["workers"], "wall_ms": m[k]["wall_ms"]}
+    c["broker_start_s"] = m.get("broker_start_s")
+    if m.get("broker"):
+        c["merged_calls"] = m["broker"].get("merged_calls")
+    return c
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="cfg3")
+    ap.add_argument("--scale", type=float, default=1.0)
+    ap.add_argument("--workers", default="1,8,32")
+    ap.add_argument("--no-reference", action="store_true")
+    ap.add_argument("--reps", type=int, default=2)
+    ap.add_argument("--keep-dir", default=None)
+    a = ap.parse_args()
+    import bench
+    store, params, wl = bench.make_workload(a.workload, a.scale, 0)
+    m = mode1_stage(a.workload, store, params, workers=tuple(int(x) for x in a.workers.split(",")), reference=not a.no_reference,
+                    reps=a.reps, keep_dir=a.keep_dir)
+    print(json.dumps(m))
+
+
+if __name__ == "__main__":
+    main()

@@ -173,13 +173,14 @@ class HostResult:
     """Caller-allocated csv_batch_out plus numpy views on it."""
 
     def __init__(self, n_sig, cap_calls, cap_support, per_sig=False, n_seg=0, alloc=None, narrow_support=False,
-                 no_support=False, coord32=False, fields=None):
+                 no_support=False, coord32=False, fields=None, seg_alloc=None):
         """alloc(shape, dtype) -> array: where the result arrays live (default numpy; engine.pinned_empty puts them in
         page-locked memory, so that the device-to-host copies land in them by DMA).  narrow_support: the support list as int32
         (csv_batch_out.support_sig32): `arrays["support_sig"]` is then an int32 array - every consumer indexes with it.
         ABI v7: no_support - CSV_OUT_NO_SUPPORT_LIST (support_off / support_sig are None); coord32 - CSV_OUT_COORD_I32 (bp1, bp2,
         search_pos, seq_pick are int32 arrays; needs int32 input columns); fields - the OPTIONAL_CALL_FIELDS to carry (None: all),
-        the others stay None and are not written."""
+        the others stay None and are not written.  seg_alloc: where `seg_status` lives (default: an ordinary numpy array even
+        under `alloc` - one word per segment is not worth a page-locked block of its own; broker.Client puts it in its shared region)."""
         empty = alloc or (lambda n, dt: np.empty(n, dtype=dt))
         self.cap_calls = int(cap_calls)
         self.cap_support = int(cap_support)
@@ -196,7 +197,8 @@ class HostResult:
             elif cap == "sig":
                 arr = empty(n_sig, dt) if per_sig else None
             elif cap == "seg":
-                arr = np.zeros(max(1, n_seg), dtype=dt)
+                arr = np.zeros(max(1, n_seg), dtype=dt) if seg_alloc is None else seg_alloc(max(1, n_seg), dt)
+                arr[:] = 0
             elif cap == "calls":
                 arr = empty(self.cap_calls, dt)
             elif no_support:

@@ -642,6 +642,62 @@ class SigStore:
                     reads.append((int(x[1]), int(x[2]), int(x[3]), x[4], x[0]))
         return cls.from_tuple_lists(per_type, reads, contig_len=contig_len)
 
+    # ------------------------------------------------------------------ the inverse, as files (tests / bench: the drop-in's input)
+    def write_reference_workdir(self, work_dir, types=TYPES):
+        """Lay the store out as the reference's own work directory (main script :817-857, 1085-1093): `<TYPE>.pickle` - one
+        pickled list of the reference's tuples per chromosome at a recorded byte offset - `reads.pickle` likewise, and the index
+        dict {TYPE: {chr: offset}, "reads": {...}} (also written as `sigindex.pickle`).  The inverse of from_reference_workdir,
+        column-wise (no Python loop per signature: a 30x genome in seconds).  Returns the index."""
+        import pickle
+        if not work_dir.endswith("/"):
+            work_dir += "/"
+        index = {}
+        for t in TYPES:
+            index[t] = {}
+            with open(work_dir + t + ".pickle", "wb") as f:
+                if t not in types:
+                    continue
+                for ch in self.chroms:
+                    if (t, ch) not in self.seg_index:
+                        continue
+                    beg, end = self.seg_index[(t, ch)]
+                    if end <= beg:
+                        continue
+                    n = end - beg
+                    a, b = self.a[beg:end].tolist(), self.b[beg:end].tolist()
+                    nm = self.names.take(self.read_id[beg:end])
+                    ax = self.aux[beg:end].tolist()
+                    tt, cc = [t] * n, [ch] * n
+                    if t in ("DEL", "DUP"):
+                        blk = list(zip(a, b, nm, tt, cc))
+                    elif t == "INS":
+                        if self.ins_seq is None and self.names.names is None:
+                            base = "ACGT" * (max(ax, default=0) // 4 + 1)
+                            seqs = [base[:k] for k in ax]
+                        else:
+                            seqs = [self.sequence(i) for i in range(beg, end)]
+                        blk = list(zip(a, b, nm, seqs, tt, cc))
+                    elif t == "INV":
+                        blk = list(zip([self.strands[k] for k in ax], a, b, nm, tt, cc))
+                    else:
+                        blk = list(zip([BND_NAME[k & 7] if (k & 7) < 4 else "X" for k in ax], a, [self.chroms[k >> 3] for k in ax], b, nm, tt, cc))
+                    index[t][ch] = f.tell()
+                    pickle.dump(blk, f)
+        index["reads"] = {}
+        with open(work_dir + "reads.pickle", "wb") as f:
+            if self.reads_off is not None:
+                for c, ch in enumerate(self.chroms):
+                    lo, hi = int(self.reads_off[c]), int(self.reads_off[c + 1])
+                    if hi <= lo:
+                        continue
+                    blk = list(zip(self.r_start[lo:hi].tolist(), self.r_end[lo:hi].tolist(), self.r_primary[lo:hi].tolist(),
+                                   self.names.take(self.r_id[lo:hi]), [ch] * (hi - lo)))
+                    index["reads"][ch] = f.tell()
+                    pickle.dump(blk, f)
+        with open(work_dir + "sigindex.pickle", "wb") as f:
+            pickle.dump(index, f)
+        return index
+
     # ------------------------------------------------------------------ the inverse (tests / golden generation)
     def tuple_lists(self):
         """Reference-format tuple lists per type and the reads list (inverse of from_tuple_lists)."""

@@ -11,7 +11,14 @@ to a multiprocessing pool; each call returns `(chr, rows)`.  This module offers
     (:1191-1197: DEL, INS, INV, DUP, TRA per chromosome).
 
 There is no CPU path: the work is done by libcutesv_hip.so; a missing library raises on first use.
-Each process owns one `engine.Context` (one HIP device, created lazily AFTER fork).
+
+Who owns the GPU.  Called in the process that imported this module (a script, a test, one process per GPU running
+`cluster_stage`), a task runs on that process's own `engine.Context` (one HIP device, created lazily).  Called in a worker
+of the reference's forked `Pool` (main script :1113) the tasks of ALL workers run on ONE context per GPU, owned by a broker
+process (`broker.py`): a worker walks its pickle, hands the columns over in shared memory and builds its rows from the
+structure of arrays it gets back.  N contexts on a device would each pay the runtime's start (and their arenas, tables and
+page-locked landing zones) inside the stage.  CUTESV_AMD_BROKER = auto (default) | 1 (always) | 0 (a context per worker,
+created after fork).  `warm_up()` in the pool's parent starts the broker ahead of the stage.
 """
 import logging
 import os
@@ -20,22 +27,111 @@ from . import _abi, engine, rows as rows_mod
 from .columns import SigStore, Params, TYPES
 
 _ctx = None
+_ctx_pid = None
 _stores = {}
+_brokers = []                      # warm_up(): the broker processes this (parent) process started
+
+# what the row builders read of a result (rows_layout.h; `search_pos`, `dv`, `call_cluster` stay on the device)
+ROW_FIELDS = ("call_aux", "cipos", "cilen", "seq_pick", "dr", "gl_idx")
+
+
+def device_list():
+    """GPUs the stage may use: CUTESV_AMD_DEVICES = "0,2,3" or a count "8" (default: one device, see device_index)"""
+    v = os.environ.get("CUTESV_AMD_DEVICES", "").strip()
+    if not v:
+        return None
+    if "," in v:
+        return [int(x) for x in v.split(",") if x.strip() != ""]
+    return list(range(int(v)))
+
+
+def _worker_number():
+    """1-based index of this process among its pool's workers (multiprocessing numbers them); 0 outside a pool"""
+    import multiprocessing as mp
+    ident = getattr(mp.current_process(), "_identity", ())
+    return int(ident[0]) if ident else 0
 
 
 def device_index():
-    """GPU of this worker: CUTESV_AMD_DEVICE, else LOCAL_RANK, else 0."""
-    for k in ("CUTESV_AMD_DEVICE", "LOCAL_RANK"):
-        if os.environ.get(k, "") != "":
-            return int(os.environ[k])
+    """GPU of this process: CUTESV_AMD_DEVICE; else the pool worker's share of CUTESV_AMD_DEVICES (worker k of the pool ->
+    device list[(k - 1) mod n]: the pool hands a task to whichever worker is free, so the devices fill evenly); else
+    LOCAL_RANK; else 0."""
+    if os.environ.get("CUTESV_AMD_DEVICE", "") != "":
+        return int(os.environ["CUTESV_AMD_DEVICE"])
+    devs = device_list()
+    if devs:
+        return devs[(max(_worker_number(), 1) - 1) % len(devs)]
+    if os.environ.get("LOCAL_RANK", "") != "":
+        return int(os.environ["LOCAL_RANK"])
     return 0
 
 
+def in_pool_worker():
+    import multiprocessing as mp
+    return mp.parent_process() is not None
+
+
+def use_broker():
+    mode = os.environ.get("CUTESV_AMD_BROKER", "auto").lower()
+    if mode in ("0", "off", "no"):
+        return False
+    if mode in ("1", "on", "yes"):
+        return True
+    return in_pool_worker()
+
+
 def context():
-    global _ctx
+    """this process's engine: an `engine.Context`, or - in a pool worker - a `broker.Client` of the GPU's broker (same
+    `cluster_batch`).  Never inherited across a fork: a context created by the parent is not used by its children."""
+    global _ctx, _ctx_pid
+    if _ctx is not None and _ctx_pid not in (None, os.getpid()):
+        _ctx = None                                   # (forked with a parent's engine: HIP state does not survive a fork)
     if _ctx is None:
-        _ctx = engine.Context(device_index())
+        if use_broker():
+            from . import broker
+            _ctx = broker.Client.connect(device_index())
+        else:
+            _ctx = engine.Context(device_index())
+        _ctx_pid = os.getpid()
     return _ctx
+
+
+def warm_up(devices=None, linger=None):
+    """Start the GPU broker(s) of the pool THIS process is about to fork (main script :1113), so that the HIP runtime's start
+    and the context's first allocations overlap whatever the caller does until the first task arrives (in cuteSV: the whole
+    extraction phase).  Optional: without it the first worker to need a broker starts it.  Returns the broker names."""
+    from . import broker
+    devs = devices if devices is not None else (device_list() or [device_index()])
+    prefix = "cutesv_amd-%d-%d" % (os.getuid(), os.getpid())
+    os.environ["CUTESV_AMD_BROKER_NAME"] = prefix    # (inherited by the workers: they look for exactly these sockets)
+    names = []
+    for d in devs:
+        name = broker.socket_name(os.getpid(), d)
+        if broker._try_connect(name) is None:
+            _brokers.append(broker.spawn(name, d, os.getpid(), linger=linger))
+        names.append(name)
+    return names
+
+
+def shut_down(devices=None):
+    """stop the brokers warm_up() started (they also leave by themselves when this process ends)"""
+    from . import broker
+    devs = devices if devices is not None else (device_list() or [device_index()])
+    for d in devs:
+        s = broker._try_connect(broker.socket_name(os.getpid(), d))
+        if s is not None:
+            try:
+                broker.Client(s, d, "").shutdown()
+            except broker.BrokerError:
+                pass
+            s.close()
+    for p in _brokers:
+        try:
+            p.wait(timeout=10)
+        except Exception:          # noqa: BLE001
+            pass
+    del _brokers[:]
+    os.environ.pop("CUTESV_AMD_BROKER_NAME", None)
 
 
 _maps = {}
@@ -110,7 +206,7 @@ def run_batch(store, segments, tasks, ctx=None):
         if ((segs["svtype"] == _abi.TRA) & (segs["genotype"] != 0)).any():
             kw["contig_len"] = store.contig_len
     hb = _abi.HostBatch(segs, store.a, store.b, store.read_id, store.aux, n_chrom=len(store.chroms), **kw)
-    res = ctx.cluster_batch(hb, reuse=True)           # (consumed right here: the arrays may be recycled by the next call)
+    res = ctx.cluster_batch(hb, reuse=True, fields=ROW_FIELDS)     # (consumed right here: the arrays may be recycled by the next call)
     per_seg = rows_mod.rows_by_segment(store, hb.segments, res)
     return {t: per_seg[k] for k, t in enumerate(tasks)}
 
@@ -280,3 +376,46 @@ def _one_tra_reads_table(work_dir, chrom, sigs_index, seg_of_store):
     rows = run_batch(store, [seg_of_store(store)], [("TRA", chrom)])[("TRA", chrom)]
     logging.info("Finished %s:TRA." % chrom)
     return (chrom, rows)
+
+
+# ------------------------------------------------------------------------------------------------ the caller, restated
+def main_ctrl_phase3(work_dir, sigs_index, params, threads, fns=None, bam="bam", start_method="fork", on_error=None):
+    """The reference's phase 3 as `main_ctrl` runs it (main script :1113-1199), for tests and bench.py: a
+    `Pool(processes=threads)`, one `map_async(run_X, [tuple])` per (chromosome, type) in DEL, INS, INV, DUP, TRA order with the
+    reference's argument tuples, `res.get()[0]`, `results[chr].extend(rows)`; an exception of a task is swallowed after
+    logging, as the reference does (:1198-1199).  fns: the five callables (default: this module's - the drop-in);
+    params: columns.Params (the argparse values).  Returns {chr: rows}."""
+    import multiprocessing as mp
+    p = params
+    fns = fns or dict(DEL=run_del, INS=run_ins, INV=run_inv, DUP=run_dup, TRA=run_tra)
+    result = []
+    with mp.get_context(start_method).Pool(processes=int(threads)) as analysis_pools:
+        for chrom in sigs_index["DEL"]:
+            para = [(work_dir, chrom, "DEL", p.min_support, p.diff_ratio_merging_DEL, p.max_cluster_bias_DEL, min(p.min_support, 5),
+                     bam, p.genotype, p.gt_round, p.remain_reads_ratio, sigs_index)]
+            result.append(analysis_pools.map_async(fns["DEL"], para))
+        for chrom in sigs_index["INS"]:
+            para = [(work_dir, chrom, "INS", p.min_support, p.diff_ratio_merging_INS, p.max_cluster_bias_INS, min(p.min_support, 5),
+                     bam, p.genotype, p.gt_round, p.remain_reads_ratio, sigs_index)]
+            result.append(analysis_pools.map_async(fns["INS"], para))
+        for chrom in sigs_index["INV"]:
+            para = [(work_dir, chrom, "INV", p.min_support, p.max_cluster_bias_INV, p.min_size, bam, p.genotype, p.max_size, p.gt_round, sigs_index)]
+            result.append(analysis_pools.map_async(fns["INV"], para))
+        for chrom in sigs_index["DUP"]:
+            para = [(work_dir, chrom, p.min_support, p.max_cluster_bias_DUP, p.min_size, bam, p.genotype, p.max_size, p.gt_round, sigs_index)]
+            result.append(analysis_pools.map_async(fns["DUP"], para))
+        for chrom in sigs_index["TRA"]:
+            para = [(work_dir, chrom, p.min_support, p.diff_ratio_filtering_TRA, p.max_cluster_bias_TRA, bam, p.genotype, p.gt_round, sigs_index)]
+            result.append(analysis_pools.map_async(fns["TRA"], para))
+        results = {}
+        for res in result:
+            try:
+                chrom, svs = res.get()[0]
+                if chrom not in results:
+                    results[chrom] = []
+                results[chrom].extend(svs)
+            except Exception as e:          # noqa: BLE001  (main script :1198-1199 logs and carries on)
+                logging.info("LocalError: %r" % (e,))
+                if on_error is not None:
+                    on_error(e)
+    return results

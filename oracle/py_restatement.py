@@ -371,3 +371,84 @@ def run_pool_forked(task_list, processes):
         res = [h.get()[0] for h in handles]
     _TASKS = None
     return res
+
+
+# ---------------------------------------------------------------------------------------- the five task callables, on the reference's files
+# The reference's workers receive the argument tuples of main script :1117-1188 and read their task from `<TYPE>.pickle` /
+# `reads.pickle` at the offsets of `sigs_index` (INDEL:52-58, 445-448; DUP:25-27; INV:42-44; TRA:36-38).  These five do the
+# same for the restatement, so that bench.py's `mode1_stage` leg times both sides on the SAME files: both pay `pickle.load`.
+def _block(work_dir, name, offset):
+    import pickle
+    with open("%s%s.pickle" % (work_dir, name), "rb") as f:
+        f.seek(offset)
+        return pickle.load(f)
+
+
+def _reads_of(work_dir, chrom, sigs_index, genotype):
+    if not genotype or chrom not in sigs_index.get("reads", {}):
+        return None
+    return _block(work_dir, "reads", sigs_index["reads"][chrom])       # (start, end, is_primary, read, chr): a prefix of what sweep_cover reads
+
+
+def _indel_task(args, svtype):
+    (work_dir, chrom, _t, read_count, ratio, bias, _msr, _bam, genotype, gt_round, keep, sigs_index) = args
+    if chrom not in sigs_index[svtype]:
+        return chrom, []
+    sigs = [(int(e[0]),) + tuple(e[1:4]) for e in _block(work_dir, svtype, sigs_index[svtype][chrom])]     # int(pos): INDEL:271
+    p = {"min_support": read_count, "genotype": genotype, "max_cluster_bias_" + svtype: bias, "diff_ratio_merging_" + svtype: ratio,
+         "remain_reads_ratio": keep, "gt_round": gt_round}
+    return run_task((svtype, chrom, sigs, _reads_of(work_dir, chrom, sigs_index, genotype), p))
+
+
+def ref_run_del(args):
+    return _indel_task(args, "DEL")
+
+
+def ref_run_ins(args):
+    return _indel_task(args, "INS")
+
+
+def ref_run_inv(args):
+    work_dir, chrom, _t, read_count, bias, min_size, _bam, genotype, max_size, gt_round, sigs_index = args
+    if chrom not in sigs_index["INV"]:
+        return chrom, []
+    sigs = [(e[1], e[2], e[3], e[0]) for e in _block(work_dir, "INV", sigs_index["INV"][chrom])]          # (strand, pos1, pos2, read, ..)
+    p = {"min_support": read_count, "genotype": genotype, "max_cluster_bias_INV": bias, "min_size": min_size, "max_size": max_size}
+    return run_task(("INV", chrom, sigs, _reads_of(work_dir, chrom, sigs_index, genotype), p))
+
+
+def ref_run_dup(args):
+    work_dir, chrom, read_count, bias, min_size, _bam, genotype, max_size, gt_round, sigs_index = args
+    if chrom not in sigs_index["DUP"]:
+        return chrom, []
+    sigs = [(int(e[0]), e[1], e[2]) for e in _block(work_dir, "DUP", sigs_index["DUP"][chrom])]
+    p = {"min_support": read_count, "genotype": genotype, "max_cluster_bias_DUP": bias, "min_size": min_size, "max_size": max_size}
+    return run_task(("DUP", chrom, sigs, _reads_of(work_dir, chrom, sigs_index, genotype), p))
+
+
+def ref_run_tra(args):
+    work_dir, chrom, read_count, overlap, bias, _bam, _genotype, gt_round, sigs_index = args
+    if chrom not in sigs_index["TRA"]:
+        return chrom, []
+    sigs = [(e[1], e[3], e[4], e[0], e[2]) for e in _block(work_dir, "TRA", sigs_index["TRA"][chrom])]    # (type, pos1, chr2, pos2, read, ..)
+    p = {"min_support": read_count, "genotype": False, "max_cluster_bias_TRA": bias, "diff_ratio_filtering_TRA": overlap}
+    return run_task(("TRA", chrom, sigs, None, p))
+
+
+REF_FNS = dict(DEL=ref_run_del, INS=ref_run_ins, INV=ref_run_inv, DUP=ref_run_dup, TRA=ref_run_tra)
+
+
+def _noop(_):
+    return None
+
+
+def pool_startup_seconds(processes, n_tasks):
+    """what the pool itself costs: the same fork Pool, `n_tasks` no-op tasks, torn down - no signature is looked at"""
+    import multiprocessing as mp
+    import time
+    t0 = time.perf_counter()
+    with mp.get_context("fork").Pool(processes=processes) as pool:
+        hs = [pool.map_async(_noop, [i]) for i in range(n_tasks)]
+        for h in hs:
+            h.get()
+    return time.perf_counter() - t0
