@@ -468,10 +468,25 @@ def cpu_legs(name, store, params, tasks, hb, n_sig, procs, py_pool, full_pool):
         t0 = time.perf_counter()
         r = pr.run_pool_forked(tl, procs)
         dt = time.perf_counter() - t0
+        # what that wall is made of (r05 review: > 90 % of it was the pool itself): the same pool with no-op tasks; the pool at
+        # one worker per task (no idle forks); the largest task alone, in this process (the compute critical path)
+        fit = min(len(tl), procs)
+        t0 = time.perf_counter()
+        pr.run_pool_forked(tl, fit)
+        dt_fit = time.perf_counter() - t0
+        dt_noop = min(pr.pool_startup_seconds(procs, len(tl)) for _ in range(2))
+        dt_noop_fit = min(pr.pool_startup_seconds(fit, len(tl)) for _ in range(2))
+        big = max(tl, key=lambda t: len(t[2]) + (len(t[3]) if t[3] else 0))
+        t0 = time.perf_counter()
+        pr.run_task(big)
+        dt_crit = time.perf_counter() - t0
         cpu = dict(value=ns / dt, unit="signatures/s", cores=procs, kind="port", wall_s=dt, full_workload=len(sample) == len(tasks),
+                   wall_s_pool_fit=dt_fit, pool_fit_workers=fit, pool_startup_s=dt_noop, pool_fit_startup_s=dt_noop_fit, critical_path_s=dt_crit,
+                   critical_task="%s chr%s, %d signatures" % (big[0], big[1], len(big[2])),
                    sample="%d of %d (chr,type) tasks, %d signatures, %.2f s wall; oracle/py_restatement.py in a fork "
-                          "Pool(%d): the reference's pool model (Python per-signature loop, numpy scalar calls)"
-                          % (len(sample), len(tasks), ns, dt, procs),
+                          "Pool(%d): the reference's pool model (Python per-signature loop, numpy scalar calls); %.2f s at Pool(%d); "
+                          "the pools alone (no-op tasks) %.2f / %.2f s; largest task alone %.3f s"
+                          % (len(sample), len(tasks), ns, dt, procs, dt_fit, fit, dt_noop, dt_noop_fit, dt_crit),
                    rows=sum(len(x[1]) for x in r))
         del tl, r
     t0 = time.perf_counter()
@@ -487,6 +502,16 @@ def cpu_legs(name, store, params, tasks, hb, n_sig, procs, py_pool, full_pool):
                     sample="full workload, oracle/cutesv_oracle.c, one (chr,type) task per call on %d threads (host has %d cores; "
                            "%d tasks), largest first, best of 3: %.4f s" % (nthr, os.cpu_count() or 1, len(tasks), dtm))
     return cpu, cpu_c, cpu_c_mt, ores
+
+
+def stage_leg(name, store, params):
+    """bench_stage.mode1_stage, never allowed to break the line"""
+    try:
+        import bench_stage
+        return bench_stage.mode1_stage(name, store, params)
+    except Exception as e:          # noqa: BLE001
+        import traceback
+        return dict(error=repr(e), trace=traceback.format_exc()[-400:])
 
 
 SLIM = dict(no_support=True, coord32=True, fields=("call_aux", "cipos", "cilen", "seq_pick", "dr", "gl_idx"))
@@ -663,8 +688,11 @@ def compact_workload(ctx, name, a, cpu):
            "one_shot_speedup_vs_c_mt": cpu["cpu_c_mt"]["wall_s"] * 1e3 / one}
     if name == "cfg5":
         out["vcf_emit_native"] = vcf_leg(ctx, pstore, params, tasks)
+    if cpu.get("mode1") is not None:
+        out["mode1_stage"] = cpu["mode1"]
     if cpu["cpu"] is not None:
-        out["cpu_baseline"] = {k: cpu["cpu"][k] for k in ("value", "cores", "wall_s", "full_workload", "sample")}
+        out["cpu_baseline"] = {k: cpu["cpu"][k] for k in ("value", "cores", "wall_s", "full_workload", "sample", "wall_s_pool_fit", "pool_fit_workers",
+                                                          "pool_startup_s", "pool_fit_startup_s", "critical_path_s") if k in cpu["cpu"]}
         out["step_speedup_vs_cpu_baseline"] = cpu["cpu"]["wall_s"] * 1e3 / ms if cpu["cpu"]["full_workload"] else None
         out["one_shot_speedup_vs_cpu_baseline"] = cpu["cpu"]["wall_s"] * 1e3 / one if cpu["cpu"]["full_workload"] else None
     return out
@@ -788,7 +816,8 @@ def compact(out):
         c["host_to_host"]["region"] = "page-locked host columns -> host SoA (H2D + kernels + D2H), SURVEY 8d (ii)"
     cb = out.get("cpu_baseline")
     if isinstance(cb, dict):
-        c["cpu_baseline"] = {k: (cb[k][:170] if isinstance(cb[k], str) else _num(cb[k])) for k in ("value", "unit", "cores", "kind", "wall_s", "full_workload", "sample", "rows") if k in cb}
+        c["cpu_baseline"] = {k: (cb[k][:120] if isinstance(cb[k], str) else _num(cb[k])) for k in ("value", "unit", "cores", "kind", "wall_s", "wall_s_pool_fit", "pool_fit_workers", "pool_startup_s",
+                                                                                                     "pool_fit_startup_s", "critical_path_s", "full_workload", "sample", "rows") if k in cb}
     else:
         c["cpu_baseline"] = cb
     b = out.get("boundary") or {}
@@ -808,6 +837,10 @@ def compact(out):
     if isinstance(out.get("speedups"), dict):
         c["speedups"] = {k: _num(v, 1) for k, v in out["speedups"].items() if k != "note"}
     c["parity_vs_oracle"] = out.get("parity_vs_oracle")
+    c["value_region"] = out.get("value_region")
+    if isinstance(out.get("mode1_stage"), dict):
+        import bench_stage
+        c["mode1_stage"] = {str(out["config"]["workload"]).split(":")[0].split(" ")[0]: bench_stage.compact(out["mode1_stage"])}
     ow = out.get("other_workloads")
     if isinstance(ow, dict):
         c["other_workloads"] = {}
@@ -822,7 +855,11 @@ def compact(out):
                  "host_to_host_slim_ms": _num(o.get("one_shot_slim_ms")), "dominant": [d["kernel"], d["us"], d["frac"]],
                  "pipeline_frac": o["pipeline"]["frac"], "parity_vs_oracle": o["parity_vs_oracle"], "c_mt_wall_ms": _num(o["cpu_baseline_c_mt"]["wall_s"] * 1e3, 2)}
             if "cpu_baseline" in o:
-                e["py_pool_wall_s"] = _num(o["cpu_baseline"]["wall_s"], 2)
+                cbo = o["cpu_baseline"]
+                e["py_pool"] = [_num(cbo.get(k), 3) for k in ("wall_s", "wall_s_pool_fit", "pool_startup_s", "critical_path_s")]
+            if isinstance(o.get("mode1_stage"), dict):
+                import bench_stage
+                c.setdefault("mode1_stage", {})[name] = bench_stage.compact(o["mode1_stage"])
             if isinstance(o.get("vcf_emit_native"), dict) and "stage_wall_vcf_ms" in o["vcf_emit_native"]:
                 e["stage_wall_vcf_ms"] = _num(o["vcf_emit_native"]["stage_wall_vcf_ms"], 2)
             c["other_workloads"][name] = e
@@ -835,6 +872,7 @@ def compact(out):
     for k in ("per_rank", "shard_merge_equals_unsharded", "timed_region", "detail"):
         if out.get(k) is not None:
             c[k] = out[k]
+    c["keys"] = "other_workloads.*.py_pool = [wall_s at Pool(all cores), at Pool(min(tasks, cores)), the pool alone (no-op tasks), largest task alone]"
     for k in ("per_rank", "other_workloads", "kernel_us", "speedups"):            # (a last resort: never needed at N <= 8)
         if len(json.dumps(c)) + 1 <= LINE_LIMIT:
             break
@@ -875,6 +913,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-others", action="store_true", help="skip the compact cfg2 / cfg4 / cfg5 objects of the default N = 1 line")
     ap.add_argument("--cpu-procs", type=int, default=0)
+    ap.add_argument("--no-mode1", action="store_true", help="skip the mode1_stage legs (the drop-in under the reference's forked Pool, bench_stage.py)")
     ap.add_argument("--full", action="store_true", help="print every object on the one line (default: the compact line, full objects on stderr and in gpurun_out/)")
     a = ap.parse_args()
     global FULL_LINE
@@ -929,7 +968,7 @@ def main():
         n_sig = int((hb.segments["sig_end"] - hb.segments["sig_begin"]).sum())
 
     # ---------------- CPU baselines first (fork pools before any HIP state exists in this process)
-    cpu = cpu_c = cpu_c_mt = ores = None
+    cpu = cpu_c = cpu_c_mt = ores = mode1 = None
     others = {}
     if rank == 0 and world == 1 and not a.no_cpu_baseline and not shard_mode:
         procs = a.cpu_procs or os.cpu_count() or 1
@@ -938,6 +977,8 @@ def main():
         if os.path.exists(cal):
             with open(cal) as f:
                 cpu["calibration_vs_reference"] = json.load(f)
+        if a.workload in ("cfg3", "cfg4") and a.scale == 1.0 and not a.no_mode1:
+            mode1 = stage_leg(a.workload, store, params)
         if a.workload == "cfg3" and a.scale == 1.0 and not a.no_others:
             for name in ("cfg2", "cfg4", "cfg5"):
                 try:
@@ -946,8 +987,10 @@ def main():
                     hb_o = st_o.host_batch(tk_o, p_o)
                     ns_o = int((hb_o.segments["sig_end"] - hb_o.segments["sig_begin"]).sum())
                     # the Python pool (the reference's execution model) on the FULL 90x workload; cfg2 / cfg4: the C legs only
-                    c0, c1, c2, o_o = cpu_legs(name, st_o, p_o, tk_o, hb_o, ns_o, procs, py_pool=(name == "cfg5"), full_pool=True)
+                    c0, c1, c2, o_o = cpu_legs(name, st_o, p_o, tk_o, hb_o, ns_o, procs, py_pool=(name in ("cfg4", "cfg5")), full_pool=True)
                     others[name] = dict(store=st_o, params=p_o, wl_name=wl_o, tasks=tk_o, hb=hb_o, n_sig=ns_o, cpu=c0, cpu_c=c1, cpu_c_mt=c2, ores=o_o)
+                    if name == "cfg4" and not a.no_mode1:
+                        others[name]["mode1"] = stage_leg(name, st_o, p_o)
                 except Exception as e:          # noqa: BLE001  (never let a compact leg break the benchmark line)
                     others[name] = dict(error=repr(e))
 
@@ -1159,12 +1202,19 @@ def main():
             "kernel_us": per_kernel_nps, "kernel_us_per_sig_outputs": per_kernel, "kernel_us_cold": per_kernel_cold, "units": units,
             "cpu_baseline": cpu, "cpu_baseline_c": cpu_c, "cpu_baseline_c_mt": cpu_c_mt,
             # speed-ups, each over ONE named pair of regions (r03's speedup_vs_cpu_baseline divided the kernel-only loop by a Python pool)
+            "mode1_stage": mode1,
+            "value_region": "sharded_boundary_call" if shard_mode else "resident_delivered_pipelined",
             "speedups": {
                 "stage_wall_vs_reference_model": (cpu["wall_s"] * 1e3 / stage_ms) if (cpu and cpu.get("full_workload")) else None,
+                "stage_wall_vs_reference_model_pool_fit": (cpu["wall_s_pool_fit"] * 1e3 / stage_ms) if (cpu and cpu.get("full_workload") and cpu.get("wall_s_pool_fit")) else None,
+                "stage_wall_vs_reference_critical_path": (cpu["critical_path_s"] * 1e3 / stage_ms) if (cpu and cpu.get("critical_path_s")) else None,
                 "host_to_host_vs_c_all_threads": (cpu_c_mt["wall_s"] * 1e3 / one_ms) if cpu_c_mt else None,
                 "resident_step_vs_c_all_threads": (cpu_c_mt["wall_s"] * 1e3 / ms_per_step) if (cpu_c_mt and world == 1) else None,
-                "note": "reference_model = oracle/py_restatement.py in a fork Pool at all host cores (cuteSV's execution model, the north_star target); "
-                        "c_all_threads = the C oracle, one (chr,type) task per thread; stage_wall = page-locked columns -> the reference's row lists"},
+                "note": "reference_model = oracle/py_restatement.py in a fork Pool at all host cores (cuteSV's execution model, the north_star target), "
+                        "whose wall is mostly the pool itself (cpu_baseline.pool_startup_s); _pool_fit = the same at one worker per task; "
+                        "_critical_path = its largest task alone (what no number of cores gets under); "
+                        "c_all_threads = the C oracle, one (chr,type) task per thread; stage_wall = page-locked columns -> the reference's row lists. "
+                        "The like-for-like stage comparison (both sides under the same forked pool on the same pickles) is mode1_stage"},
             "host_to_host": host_to_host,
             "resident_delivered_serial": None if dt_serial is None else {"ms_per_step": dt_serial / a.steps * 1e3, "value": n_sig * a.steps / dt_serial,
                                                                          "note": "run, download, run, download ...: what r04 reported as value"},

@@ -72,7 +72,7 @@ def _wait_gone(timeout=20.0):
         time.sleep(0.02)
 
 
-def mode1_stage(name, store, params, workers=(1, 8, 32), reference=True, cold_and_direct_at=8, reps=2, keep_dir=None, log=None):
+def mode1_stage(name, store, params, workers=(1, 8, 32), reference=True, cold_and_direct_at=8, reps=2, keep_dir=None, log=None, cols_leg=True):
     """-> dict for the bench line.  Must run before this process holds any HIP state (the pools fork)."""
     from oracle import py_restatement as pr                       # (the CPU baseline of this leg)
     say = log or (lambda s: sys.stderr.write("[mode1_stage %s] %s\n" % (name, s)))
@@ -110,7 +110,9 @@ def mode1_stage(name, store, params, workers=(1, 8, 32), reference=True, cold_an
                 walls.append(dt)
             dg = rows_digest(res)
             leg = {"workers": T, "wall_ms": round(min(walls) * 1e3, 2), "wall_ms_all": [round(w * 1e3, 1) for w in walls], "rows": dg[0],
-                   "signatures_per_s": round(n_sig / min(walls))}
+                   "signatures_per_s": round(n_sig / min(walls)),
+                   # the same pool with tasks that do nothing: what neither side of the comparison can get under
+                   "pool_alone_ms": round(min(pr.pool_startup_seconds(T, out["tasks"]) for _ in range(2)) * 1e3, 1)}
             say("drop-in warm broker T=%d: %s ms" % (T, leg["wall_ms_all"]))
             if reference:
                 dtr, ref = _stage(wd, idx, params, T, fns=pr.REF_FNS)
@@ -119,6 +121,26 @@ def mode1_stage(name, store, params, workers=(1, 8, 32), reference=True, cold_an
                 leg.update(reference_pool_wall_ms=round(dtr * 1e3, 1), vs_reference_pool=round(dtr / min(walls), 1), rows_equal_reference_model=(rd == dg))
                 say("reference model T=%d: %.1f ms (x%.1f), rows equal: %s" % (T, dtr * 1e3, dtr / min(walls), rd == dg))
             legs.append(leg)
+        if cols_leg:
+            # the same pool, the same callables, the same argument tuples - on the flat column directory the build's own
+            # rebuild step leaves next to the pickles (SURVEY 8(b) "Input files": <work_dir>/cutesv_amd.cols, SigStore.save);
+            # a worker then maps its columns instead of walking a pickle.  The reference side of the ratio is unchanged.
+            t0 = time.perf_counter()
+            store.save(wd + "cutesv_amd.cols")
+            out["write_cols_s"] = round(time.perf_counter() - t0, 2)
+            for leg in legs:
+                T = leg["workers"]
+                walls = []
+                for _ in range(reps):
+                    dt, res = _stage(wd, idx, params, T)
+                    walls.append(dt)
+                leg["cols_wall_ms"] = round(min(walls) * 1e3, 2)
+                leg["cols_rows_equal"] = rows_digest(res) == ((leg["rows"], ref_digest[1]) if ref_digest else rows_digest(res))
+                if "reference_pool_wall_ms" in leg:
+                    leg["cols_vs_reference_pool"] = round(leg["reference_pool_wall_ms"] / leg["cols_wall_ms"], 1)
+                say("drop-in on cutesv_amd.cols T=%d: %s ms" % (T, [round(w * 1e3, 1) for w in walls]))
+            shutil.rmtree(wd + "cutesv_amd.cols", ignore_errors=True)
+            resolve._stores.clear()
         info = _broker_info(shutdown=True)
         _wait_gone()
         resolve.shut_down()
@@ -153,7 +175,7 @@ def compact(m):
     if not isinstance(m, dict) or "legs" not in m:
         return m
     c = {"tasks": m.get("tasks"), "legs": [{k: leg.get(k) for k in ("workers", "wall_ms", "signatures_per_s", "reference_pool_wall_ms", "vs_reference_pool",
-                                                                       "rows_equal_reference_model")} for leg in m["legs"]]}
+                                                                       "rows_equal_reference_model", "cols_wall_ms", "cols_vs_reference_pool", "pool_alone_ms") if k in leg} for leg in m["legs"]]}
     for k in ("cold_broker", "context_per_worker"):
         if m.get(k):
             c[k] = {"workers": m[k]["workers"], "wall_ms": m[k]["wall_ms"]}

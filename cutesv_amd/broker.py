@@ -118,9 +118,9 @@ class Region:
         self.top = end
         return np.frombuffer(self.mm, dtype=dtype, count=n, offset=off).reshape(shape)
 
-    def put(self, arr):
-        out = self.alloc(arr.shape, arr.dtype)
-        out[...] = arr
+    def put(self, arr, dtype=None):
+        out = self.alloc(arr.shape, dtype or arr.dtype)
+        np.copyto(out, arr, casting="unsafe")         # (a narrowing copy only after _fits32 said the values fit)
         return out
 
     def close(self):
@@ -129,6 +129,20 @@ class Region:
         except OSError:
             pass
         self.fd = -1                                             # (the mapping goes with its last numpy view)
+
+
+def _fits32(x, y):
+    """both columns exist and hold int32 values (already narrow, or int64 within range)"""
+    if x is None or y is None:
+        return False
+    for v in (x, y):
+        if v.dtype == np.int32:
+            continue
+        if v.dtype != np.int64:
+            return False
+        if len(v) and (int(v.min()) < -(1 << 31) or int(v.max()) >= (1 << 31)):
+            return False
+    return True
 
 
 def _padded(nbytes):
@@ -250,9 +264,16 @@ class Client:
             reg = self.region
             cin = _abi.BatchIn.from_buffer_copy(bytes(batch.c))
             cin.n_chrom, cin.n_sig = n_chrom, n
+            by = dict(cols)
+            # positions and lengths travel as int32 when they fit (a genome's coordinates do: CSV_IN_SIG_I32 / CSV_IN_READS_I32):
+            # half the bytes through the region, the broker's staging columns and the link
+            sig32 = _fits32(by.get("a"), by.get("b"))
+            rd32 = _fits32(by.get("r_start"), by.get("r_end"))
+            cin.flags = (cin.flags & ~(_abi.IN_SIG_I32 | _abi.IN_READS_I32)) | (_abi.IN_SIG_I32 if sig32 else 0) | (_abi.IN_READS_I32 if rd32 else 0)
             for name, v in cols:
                 if v is not None:
-                    setattr(cin, name, reg.put(v).ctypes.data)
+                    narrow = (sig32 and name in ("a", "b")) or (rd32 and name in ("r_start", "r_end"))
+                    setattr(cin, name, (reg.put(v, np.int32) if narrow else reg.put(v)).ctypes.data)
                     if name == "r_start":
                         cin.n_reads = len(v)
             res = _abi.HostResult(n, cap_calls, cap_support, per_sig=per_sig, n_seg=len(batch.segments), alloc=reg.alloc,
@@ -382,6 +403,8 @@ class Broker:
         self.conns = {}
         self.stats = dict(calls=0, batches=0, merged_calls=0, maps=0, max_batch=0, busy_s=0.0)
         self._stage = None
+        self._pool = None
+        self._copy_threads = int(os.environ.get("CUTESV_AMD_BROKER_COPY_THREADS", "8"))
         self._engine_factory = engine_factory
         self._engine = None
         self._ready_s = None
@@ -472,21 +495,17 @@ class Broker:
     def _run(self, pend):
         t0 = time.perf_counter()
         self.stats["calls"] += len(pend)
-        merge = [p for p in pend if self._mergeable(p)] if self.max_batch > 1 else []
-        if len(merge) >= 2:
-            ids = set(map(id, merge))
-            for p in pend:
-                if id(p) not in ids:
-                    self._run_one(p)
-            for lo in range(0, len(merge), self.max_batch):
-                grp = merge[lo:lo + self.max_batch]
-                if len(grp) == 1:
-                    self._run_one(grp[0])
-                else:
-                    self._run_merged(grp)
-        else:
-            for p in pend:
+        # Every single-segment request goes through the context's own page-locked staging columns and result arrays (a copy
+        # at memory speed each way, then DMA) - alone or side by side with the requests that arrived with it.  Measured:
+        # page-locking each worker's region in place instead (csv_host_register, 1-5 ms per region, serial in this process)
+        # cost a 32-worker stage 180 ms of its 295.
+        merge = [p for p in pend if self._mergeable(p)] if self.max_batch >= 1 else []
+        ids = set(map(id, merge))
+        for p in pend:
+            if id(p) not in ids:
                 self._run_one(p)
+        for lo in range(0, len(merge), max(1, self.max_batch)):
+            self._run_merged(merge[lo:lo + max(1, self.max_batch)])
         self.stats["batches"] += 1
         self.stats["max_batch"] = max(self.stats["max_batch"], len(pend))
         self.stats["busy_s"] += time.perf_counter() - t0
@@ -511,14 +530,18 @@ class Broker:
         segs, roff = st["seg"][:k], st["reads_off"][:k + 1]
         so = ro = 0
         roff[0] = 0
+        copies = []                                   # (dst, src) pairs: done below, the large ones on a few threads
+
+        def cp(dst, src):
+            copies.append((dst, src))
         for j, p in enumerate(grp):
             c = p.cin
             n = int(c.n_sig)
             sdt = np.int32 if c.flags & _abi.IN_SIG_I32 else np.int64
-            a[so:so + n] = _view(c.a, n, sdt)
-            b[so:so + n] = _view(c.b, n, sdt)
-            rid[so:so + n] = _view(c.read_id, n, np.int32)
-            aux[so:so + n] = _view(c.aux, n, np.int32)
+            cp(a[so:so + n], _view(c.a, n, sdt))
+            cp(b[so:so + n], _view(c.b, n, sdt))
+            cp(rid[so:so + n], _view(c.read_id, n, np.int32))
+            cp(aux[so:so + n], _view(c.aux, n, np.int32))
             sg = _view(c.seg, 1, _abi.SEGMENT_DTYPE)[0]
             segs[j] = sg
             segs[j]["sig_begin"] = so + int(sg["sig_begin"])
@@ -531,13 +554,14 @@ class Broker:
                 lo_, hi_ = int(off[int(sg["chrom"])]), int(off[int(sg["chrom"]) + 1])
                 nr = hi_ - lo_
                 rdt = np.int32 if c.flags & _abi.IN_READS_I32 else np.int64
-                rs[ro:ro + nr] = _view(c.r_start, int(c.n_reads), rdt)[lo_:hi_]
-                re_[ro:ro + nr] = _view(c.r_end, int(c.n_reads), rdt)[lo_:hi_]
-                rp[ro:ro + nr] = _view(c.r_primary, int(c.n_reads), np.uint8)[lo_:hi_]
-                ri[ro:ro + nr] = _view(c.r_id, int(c.n_reads), np.int32)[lo_:hi_]
+                cp(rs[ro:ro + nr], _view(c.r_start, int(c.n_reads), rdt)[lo_:hi_])
+                cp(re_[ro:ro + nr], _view(c.r_end, int(c.n_reads), rdt)[lo_:hi_])
+                cp(rp[ro:ro + nr], _view(c.r_primary, int(c.n_reads), np.uint8)[lo_:hi_])
+                cp(ri[ro:ro + nr], _view(c.r_id, int(c.n_reads), np.int32)[lo_:hi_])
             so += n
             ro += nr
             roff[j + 1] = ro
+        self._copy_all(copies)
         any_reads = ro > 0
         cin = _abi.BatchIn(n_seg=k, n_chrom=k, seg=segs.ctypes.data, n_sig=n_tot, a=a.ctypes.data, b=b.ctypes.data,
                            read_id=rid.ctypes.data, aux=aux.ctypes.data,
@@ -562,7 +586,8 @@ class Broker:
             for p in grp:                             # (a batch-level failure: every requester is told; one bad request cannot hide)
                 self._reply(p.conn, rc, None, text)
             return
-        self.stats["merged_calls"] += k
+        if k > 1:
+            self.stats["merged_calls"] += k
         t = res.trimmed()
         cut = np.searchsorted(t["call_seg"], np.arange(k + 1))
         soff = t["support_off"]
@@ -574,7 +599,7 @@ class Broker:
             s0, s1 = int(soff[lo_]), int(soff[hi_])
             ns = s1 - s0
             o.n_calls, o.n_support = nc, (0 if o.flags & _abi.OUT_NO_SUPPORT_LIST else ns)
-            o.n_clusters = -1
+            o.n_clusters = int(res.n_clusters) if k == 1 else -1
             if nc > o.cap_calls or (not (o.flags & _abi.OUT_NO_SUPPORT_LIST) and ns > o.cap_support):
                 self._reply(p.conn, _abi.E_CAPACITY, o)
                 continue
@@ -599,6 +624,24 @@ class Broker:
             if o.seg_status:
                 _view(o.seg_status, 1, np.int32)[0] = t["seg_status"][j]
             self._reply(p.conn, _abi.OK, o)
+
+    def _copy_all(self, copies):
+        """shared region -> staging.  numpy's copy loops release the GIL: a merged batch's large columns (a chromosome's reads
+        table is megabytes) are copied by a few threads at once instead of one after the other"""
+        big = [c for c in copies if c[0].nbytes >= (1 << 19)]
+        if len(big) >= 2 and self._copy_threads > 1:
+            if self._pool is None:
+                from concurrent.futures import ThreadPoolExecutor
+                self._pool = ThreadPoolExecutor(max_workers=self._copy_threads)
+            futs = [self._pool.submit(np.copyto, d, s_) for d, s_ in big]
+            for d, s_ in copies:
+                if d.nbytes < (1 << 19):
+                    np.copyto(d, s_)
+            for f in futs:
+                f.result()
+        else:
+            for d, s_ in copies:
+                np.copyto(d, s_)
 
     def _staging(self, eng, n, r, k):
         st = self._stage
@@ -733,7 +776,7 @@ class _HipEngine:
         return self._engine_mod.pinned_empty(shape, dtype)
 
     def register(self, addr, size):
-        if os.environ.get("CUTESV_AMD_BROKER_REGISTER", "1") == "0":
+        if os.environ.get("CUTESV_AMD_BROKER_REGISTER", "0") != "1":     # (off by default: see Broker._run)
             return False
         return self._lib.csv_host_register(C.c_void_p(addr), int(size)) == _abi.OK
 

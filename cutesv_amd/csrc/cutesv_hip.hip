@@ -147,6 +147,13 @@ struct csv_ctx {
     size_t h_pin_cap = 0;
     // two page-locked 64-bit words the device writes {run sequence, count}: items above 64 signatures (k_chain_apply), calls that
     // overflowed the first genotype pass (k_genotype<8192>); read when a LATER run of the same upload is planned
+    // CSV_* environment switches of the run path (timing / debugging aids), read once per upload: csv_batch_run - a 36 us
+    // step - looks nothing up in the environment
+    struct RunOpts {
+        bool debug = false, debug_counters = false, no_fork = false, fork_always = false, no_swap = false, no_peek = false;
+        bool no_pair_in_mid = false, no_publish = false;
+        int  iw_grid = 0, gt_grid = 0, tier_fork_min = 4 << 20;
+    } opt;
     volatile int* h_flag = nullptr;
     int*          d_flag = nullptr;
     int           run_seq = 0;
@@ -244,6 +251,22 @@ int env_int(const char* name, int dflt)
 {
     const char* v = getenv(name);
     return v && *v ? atoi(v) : dflt;
+}
+
+void load_run_opts(csv_ctx* c)
+{
+    auto& o = c->opt;
+    o.debug = getenv("CSV_DEBUG") != nullptr;
+    o.debug_counters = o.debug || getenv("CSV_DEBUG_COUNTERS") != nullptr;
+    o.no_fork = getenv("CSV_NO_FORK") != nullptr;
+    o.fork_always = getenv("CSV_FORK_ALWAYS") != nullptr;
+    o.no_swap = getenv("CSV_NO_SWAP") != nullptr;
+    o.no_peek = getenv("CSV_NO_PEEK") != nullptr;
+    o.no_pair_in_mid = getenv("CSV_NO_PAIR_IN_MID") != nullptr;
+    o.no_publish = getenv("CSV_NO_PUBLISH") != nullptr;
+    o.iw_grid = env_int("CSV_IW_GRID", 0);
+    o.gt_grid = env_int("CSV_GT_GRID", 0);
+    o.tier_fork_min = env_int("CSV_TIER_FORK_MIN", 4 << 20);
 }
 
 int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sync, bool lazy_ok);
@@ -395,7 +418,7 @@ int csv_ctx_create(int device_id, csv_ctx** out)
             else (void)hipHostFree(hf);
         }
     }
-    if (reserve(c, c->cnt, 512) || reserve(c, c->rstate, sizeof(ReadsState)) || pin_reserve(c, 1 << 20) || sqrt_table(c, SQRT_TAB)) {
+    if (reserve(c, c->cnt, 1024) || reserve(c, c->rstate, sizeof(ReadsState)) || pin_reserve(c, 1 << 20) || sqrt_table(c, SQRT_TAB)) {
         delete c;
         return CSV_E_HIP;
     }
@@ -475,7 +498,8 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
     c->lazy_pending = c->partial_cols = false; c->lazy_bytes = 0;
     c->reads_general = false;
     c->reads_ready = false;
-    c->upload_seq0 = c->run_seq;                      // (tier answers of earlier sequence numbers belong to other columns)
+    c->upload_seq0 = c->run_seq;
+    load_run_opts(c);
     HIP_TRY(c, hipSetDevice(c->device));
     if (in->n_seg < 0 || in->n_sig < 0 || (in->n_seg > 0 && !in->seg)) return fail(c, CSV_E_INVALID, "bad batch header");
     // (support lists and seq_pick name signatures by their global index in 32 bits on the device)
@@ -867,7 +891,8 @@ int run_impl(csv_ctx* c, csv_run_stats* stats)
     }
     int ev = 0;
     auto mark = [&]() -> hipError_t { return stats ? hipEventRecord(c->ev[ev++], st) : hipSuccess; };
-    const bool dbg = getenv("CSV_DEBUG") != nullptr;
+    const auto& O = c->opt;
+    const bool dbg = O.debug;
 #define DBG(name)                                                                                          \
     do {                                                                                                   \
         if (dbg) {                                                                                         \
@@ -895,14 +920,14 @@ int run_impl(csv_ctx* c, csv_run_stats* stats)
     const bool do_gt = c->any_genotype && B.n_reads > 0;
     // the packed table of an upload does not change between runs: a resident re-run keeps it (csv_batch_option) and has no reads stage
     const bool keep_reads = c->reads_ready && c->reuse_reads && !stats;
-    const bool fork = !stats && !dbg && !getenv("CSV_NO_FORK") && (c->any_pair || (do_gt && !keep_reads) || getenv("CSV_FORK_ALWAYS"));
+    const bool fork = !stats && !dbg && !O.no_fork && (c->any_pair || (do_gt && !keep_reads) || O.fork_always);
     // A genotyping batch has two producer chains - clustering (k_chain_count .. k_emit) and the reads stage - that meet in
     // k_genotype.  A wait across queues costs 6-11 us when the event fires late and next to nothing when it fired long ago,
     // so the LONGER chain stays on the main stream together with the genotype kernels and the shorter one is forked off:
     // its completion event has long fired when the main stream gets there.  (Reads dominate a 30x HiFi genome, clustering a
     // 90x all-types one.)  `st` is the stream of the clustering chain from here on, `sM` the main stream.
     hipStream_t sM = c->stream;
-    const bool swap = fork && do_gt && !keep_reads && !c->copies_pending && B.n_reads > 4 * W && W > 0 && !getenv("CSV_NO_SWAP");
+    const bool swap = fork && do_gt && !keep_reads && !c->copies_pending && B.n_reads > 4 * W && W > 0 && !O.no_swap;
     if (swap) st = c->side[2];
     hipStream_t sB = fork ? c->side[0] : st, sC = fork ? c->side[1] : st, sD = swap ? sM : (fork ? c->side[2] : st);
 #define LAUNCH_ON(strm, name, kern, grid, block, lds, ...)                             \
@@ -945,7 +970,13 @@ int run_impl(csv_ctx* c, csv_run_stats* stats)
         return CSV_OK;
     };
     if (c->copies_pending) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_copy[0], 0));       // positions, lengths, INV / TRA words
-    B.host_flag = (c->h_flag && !getenv("CSV_NO_PEEK")) ? c->d_flag : nullptr;
+    // A run decides what it launches from what IT knows - nothing is carried over from earlier runs of the upload (r05 skipped
+    // the tiers above 64 signatures when an earlier, identical run had found them empty: state only a benchmark loop has).  In
+    // a one-shot call the column copies are still on the link when the chain kernels are queued, so the host can wait for
+    // k_chain_apply's word {this run, work items above 64 signatures} - it arrives long before the copies end - and queue
+    // only the tiers that have work; a resident run queues them all (an empty tier costs its launch, ~4.5 us).
+    const bool peek = c->copies_pending && c->h_flag && !O.no_peek && !stats && !dbg;
+    B.host_flag = peek ? c->d_flag : nullptr;
     B.run_seq = ++c->run_seq;
     if (W > 0) {
         const int nb = div_up(W, CH_TILE);
@@ -986,24 +1017,28 @@ int run_impl(csv_ctx* c, csv_run_stats* stats)
         // with 1536 vs 3072 workgroups)
         const int g_res = c->n_cu * CSV_IW_WAVES;
         int g_iw = div_up(B.cap_items, 4) < g_res ? div_up(B.cap_items, 4) : g_res;
-        g_iw = env_int("CSV_IW_GRID", g_iw);              // tuning aid
+        if (O.iw_grid > 0) g_iw = O.iw_grid;              // tuning aid
         if (g_iw < 1) g_iw = 1;
-        // The tiers above 64 signatures usually have nothing to do (a 30x genome has no such cluster) and an empty launch
-        // still costs ~4 us of the stream.  k_chain_apply leaves {run sequence, items above 64} in a page-locked word; a
-        // run whose upload has already been through it reads the answer of that earlier run (same columns, same parameters:
-        // same tiers) and launches only what has work.  The first run of an upload, and every one-shot call, launches all.
+        // The tiers above 64 signatures usually have nothing to do (a 30x genome has no such cluster).  With the answer of THIS
+        // run's k_chain_apply in hand (one-shot calls, see `peek` above) only the tiers with work are queued; the wait ends when
+        // the position column has crossed the link and the two chain kernels have run, while the stream goes on to fetch / wait
+        // for the other columns - it never runs dry because of it.  No answer within 20 ms: everything is queued.
         bool need_big = true;
         if (B.host_flag) {
-            const unsigned long long w = *(volatile unsigned long long*)c->h_flag;
-            if ((int)((unsigned)(w >> 32) - (unsigned)c->upload_seq0) > 0 && (int)((unsigned)(w >> 32) - (unsigned)B.run_seq) < 0) need_big = (unsigned)w > 0;
+            const auto t_end = std::chrono::steady_clock::now() + std::chrono::milliseconds(20);
+            for (;;) {
+                const unsigned long long w = *(volatile unsigned long long*)c->h_flag;
+                if ((unsigned)(w >> 32) == (unsigned)B.run_seq) { need_big = (unsigned)w > 0; break; }
+                if (std::chrono::steady_clock::now() > t_end) break;
+                __builtin_ia32_pause();
+            }
         }
-        if (getenv("CSV_FORCE_TIERS")) need_big = true;
         // the tiers run side by side only in a large batch: a fork and a join cost 6-10 us each, more than the overlap of short
         // kernels is worth (five simulation beds, 0.56 M signatures: 110 us in a row, 115-133 us forked; 90x ONT, 11 M: 367 vs 335)
-        const bool tier_fork = fork && W >= (i64)env_int("CSV_TIER_FORK_MIN", 4 << 20);
+        const bool tier_fork = fork && W >= (i64)O.tier_fork_min;
         // with clusters above 64 signatures in the batch, the one-wavefront tier for 65 .. 256 also takes the DUP / INV / TRA clusters
         // of at most 64 (its second phase): one grid, the long clusters first, instead of two kernels in a row
-        B.pair_in_mid = (need_big && c->any_pair && !getenv("CSV_NO_PAIR_IN_MID")) ? 1 : 0;
+        B.pair_in_mid = (need_big && c->any_pair && !O.no_pair_in_mid) ? 1 : 0;
         const bool side_b = tier_fork && need_big, side_c = tier_fork && c->any_pair && !B.pair_in_mid;
         if (!tier_fork) { sB = st; sC = st; }
         if (side_b || side_c) {
@@ -1036,20 +1071,15 @@ int run_impl(csv_ctx* c, csv_run_stats* stats)
             if (swap) {}
             else if (fork && !keep_reads) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_aux[2], 0));
             else { HIP_TRY(c, hipStreamWaitEvent(st, c->ev_reads, 0)); const int rc = reads_stage(st); if (rc) return rc; }
-            // the second pass (overflow list of the first; global tables beyond) has usually nothing to do: skipped when an
-            // earlier run of this upload said so (same word scheme as the refine tiers above)
-            bool need_second = true;
-            if (B.host_flag) {
-                const unsigned long long w = ((volatile unsigned long long*)c->h_flag)[1];
-                if ((int)((unsigned)(w >> 32) - (unsigned)c->upload_seq0) > 0 && (int)((unsigned)(w >> 32) - (unsigned)B.run_seq) < 0) need_second = (unsigned)w > 0;
-            }
-            if (getenv("CSV_FORCE_TIERS")) need_second = true;
+            // the second pass (overflow list of the first; global tables beyond) has usually nothing to do and is queued all the
+            // same: whether it has is known when the first pass ends, and nothing is carried over from earlier runs
+            const int gt_grid = O.gt_grid > 0 ? O.gt_grid : GT_GRID;
             if (B.r_start.p32) {
-                hipLaunchKernelGGL((k_genotype<1024, 4, false, true>), dim3(env_int("CSV_GT_GRID", GT_GRID)), dim3(256), 0, st, B);
-                if (need_second) hipLaunchKernelGGL((k_genotype<8192, 4, true, true>), dim3(256), dim3(256), 0, st, B);
+                hipLaunchKernelGGL((k_genotype<1024, 4, false, true>), dim3(gt_grid), dim3(256), 0, st, B);
+                hipLaunchKernelGGL((k_genotype<8192, 4, true, true>), dim3(256), dim3(256), 0, st, B);
             } else {
-                hipLaunchKernelGGL((k_genotype<1024, 4, false, false>), dim3(env_int("CSV_GT_GRID", GT_GRID)), dim3(256), 0, st, B);
-                if (need_second) hipLaunchKernelGGL((k_genotype<8192, 4, true, false>), dim3(256), dim3(256), 0, st, B);
+                hipLaunchKernelGGL((k_genotype<1024, 4, false, false>), dim3(gt_grid), dim3(256), 0, st, B);
+                hipLaunchKernelGGL((k_genotype<8192, 4, true, false>), dim3(256), dim3(256), 0, st, B);
             }
 #ifdef CSV_GT_PROF
             hipLaunchKernelGGL(k_gt_prof_print, dim3(1), dim3(1), 0, st, B);
@@ -1109,7 +1139,7 @@ int read_counters(csv_ctx* c)
             HIP_TRY(c, hipMemcpy(&rs, c->rstate.p, sizeof rs, hipMemcpyDeviceToHost));
             c->h_cnt.n_runs = rs.n_runs; c->h_cnt.ro_state = rs.ro_state; c->h_cnt.error |= rs.error;
         }
-        if (getenv("CSV_DEBUG") || getenv("CSV_DEBUG_COUNTERS"))
+        if (c->opt.debug_counters)
             fprintf(stderr, "[csv] counters: clusters %d items %d calls %d error %d | reads: mode %d runs %d state %d | gt_over %d gt_huge %d tra_huge %d\n",
                     c->h_cnt.n_clusters, c->h_cnt.n_items, c->h_cnt.n_calls, c->h_cnt.error, c->B.ro_mode, c->h_cnt.n_runs, c->h_cnt.ro_state,
                     c->h_cnt.n_gt_over, c->h_cnt.n_gt_huge, c->h_cnt.n_tra_huge);
@@ -1179,12 +1209,18 @@ int csv_batch_validate(csv_ctx* c)
     if (!c) return CSV_E_INVALID;
     if (!c->uploaded) return fail(c, CSV_E_STATE, "csv_batch_validate before csv_batch_upload");
     if (c->partial_cols) return fail(c, CSV_E_STATE, "csv_batch_validate needs a csv_batch_upload: a csv_cluster_batch call from page-locked columns keeps only the rows its kernels read");
+    if (c->n_pend) return fail(c, CSV_E_STATE, "csv_batch_validate while %d asynchronous publish(es) are in flight: csv_batch_publish_wait first", c->n_pend);
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t st = c->stream;
-    HIP_TRY(c, hipMemsetAsync(c->cnt.p, 0, sizeof(DevCounters), st));
-    if (c->B.W > 0) hipLaunchKernelGGL(k_validate_order, dim3(div_up(c->B.W, 256)), dim3(256), 0, st, c->B);
+    // k_validate_order reports through the batch's counter pointer.  That pointer alternates between the two result arenas
+    // from run to run (advisor, r05: clearing and reading arena 0 while the kernel wrote arena 1 returned CSV_OK for an
+    // unsorted batch after an odd number of runs): the check gets a counter block of its own, which no run and no publish uses.
+    DevBatch V = c->B;
+    V.cnt = (DevCounters*)((char*)c->cnt.p + 512);
+    HIP_TRY(c, hipMemsetAsync(V.cnt, 0, sizeof(DevCounters), st));
+    if (V.W > 0) hipLaunchKernelGGL(k_validate_order, dim3(div_up(V.W, 256)), dim3(256), 0, st, V);
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipMemcpyAsync(c->h_pin, c->cnt.p, sizeof(DevCounters), hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(c->h_pin, V.cnt, sizeof(DevCounters), hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipStreamSynchronize(st));
     memcpy(&c->h_cnt, c->h_pin, sizeof(DevCounters));
     c->ran = false;
@@ -1200,7 +1236,7 @@ int csv_batch_validate(csv_ctx* c)
 bool publish_targets(csv_ctx* c, const csv_batch_out* out, PublishArgs& P)
 {
     (void)c;
-    if (getenv("CSV_NO_PUBLISH") || out->cap_calls < 0 || out->cap_support < 0) return false;
+    if (c->opt.no_publish || out->cap_calls < 0 || out->cap_support < 0) return false;
     const size_t nc = (size_t)out->cap_calls, ns = (size_t)out->cap_support;
     const bool sup32 = out->support_sig32 != nullptr, nosup = (out->flags & CSV_OUT_NO_SUPPORT_LIST) != 0;
     const size_t cw = (out->flags & CSV_OUT_COORD_I32) ? 4 : 8;
@@ -1253,7 +1289,7 @@ int csv_batch_download(csv_ctx* c, csv_batch_out* out)
             hipLaunchKernelGGL(k_publish, dim3(512), dim3(256), 0, st, c->B, P);
             HIP_TRY(c, hipStreamSynchronize(st));
             memcpy(&c->h_cnt, c->h_pin + o_cnt, sizeof(DevCounters));
-            if (getenv("CSV_DEBUG") || getenv("CSV_DEBUG_COUNTERS"))
+            if (c->opt.debug_counters)
                 fprintf(stderr, "[csv] counters (published): clusters %d items %d calls %d error %d | reads: mode %d runs %d state %d\n",
                         c->h_cnt.n_clusters, c->h_cnt.n_items, c->h_cnt.n_calls, c->h_cnt.error, c->B.ro_mode, c->h_cnt.n_runs, c->h_cnt.ro_state);
             if (c->B.ro_mode == 1 && c->B.n_reads > 0 && c->any_genotype && c->h_cnt.ro_state == RO_NEED_GENERAL && attempt == 0) {
@@ -1552,7 +1588,7 @@ int csv_rebuild_signatures(csv_ctx* c, const csv_rebuild_in* in, csv_rebuild_out
     R.auxk = dp<int>(c->rb_auxk); R.keep = nullptr; R.partial = dp<int>(c->rb_partial);
     R.nodedup = in->seg_nodedup ? dp<uint8_t>(c->rb_nodedup) : nullptr;
     R.o_seg = dp<int>(c->rb_oseg); R.o_a = dp<i64>(c->rb_oa); R.o_b = dp<i64>(c->rb_ob); R.o_rid = dp<int>(c->rb_orid);
-    R.o_aux = dp<int>(c->rb_oaux); R.o_src = dp<int>(c->rb_osrc); R.n_out = (int*)c->cnt.p;
+    R.o_aux = dp<int>(c->rb_oaux); R.o_src = dp<int>(c->rb_osrc); R.n_out = (int*)((char*)c->cnt.p + 768);      // (a word of its own: the run arenas at +0 / +256 may have a publish in flight)
     R.drop = nullptr;
     out->n_tie_rows = 0; out->n_tie_dropped = 0;
     bool ties_settled = false;
@@ -1608,7 +1644,7 @@ int csv_rebuild_signatures(csv_ctx* c, const csv_rebuild_in* in, csv_rebuild_out
             T.n = n; T.L = KL; T.nodedup = R.nodedup; T.drop = nullptr; T.partial = R.partial;
             T.o_seg = R.o_seg; T.o_a = R.o_a; T.o_b = R.o_b; T.o_rid = R.o_rid; T.o_aux = R.o_aux; T.o_src = R.o_src; T.n_out = R.n_out;
             if (in->tie_order && R.nodedup) {
-                int* d_n = (int*)c->cnt.p;
+                int* d_n = (int*)((char*)c->cnt.p + 768);
                 HIP_TRY(c, hipMemsetAsync(d_n, 0, 4, st));
                 HIP_TRY(c, hipMemsetAsync(c->rb_drop.p, 0, (size_t)n, st));
                 hipLaunchKernelGGL(k_rs_ties<W>, dim3(div_up(n, 256)), dim3(256), 0, st, T, (const E*)e_in, (int2*)c->rb_oa.p, d_n);
@@ -1661,7 +1697,7 @@ int csv_rebuild_signatures(csv_ctx* c, const csv_rebuild_in* in, csv_rebuild_out
             // INS rows that tie on their integer keys: the caller orders them (by sequence) and names the duplicates; the answer is
             // written into the permutation / a drop map on the device, and the gather below never knows.  The output buffers are
             // free until the gather: rb_oa holds the list, rb_oseg / rb_orid / rb_ob the answer on its way back.
-            int* d_n = (int*)c->cnt.p;
+            int* d_n = (int*)((char*)c->cnt.p + 768);
             HIP_TRY(c, hipMemsetAsync(d_n, 0, 4, st));
             HIP_TRY(c, hipMemsetAsync(c->rb_drop.p, 0, (size_t)n, st));
             hipLaunchKernelGGL(k_rebuild_ties, dim3(div_up(n, 256)), dim3(256), 0, st, R, (int2*)c->rb_oa.p, d_n);
@@ -1697,7 +1733,7 @@ int csv_rebuild_signatures(csv_ctx* c, const csv_rebuild_in* in, csv_rebuild_out
     HIP_TRY(c, hipGetLastError());
     int n_out = 0;
     std::vector<i64> segcnt((size_t)in->n_seg + 1);
-    HIP_TRY(c, hipMemcpyAsync(&n_out, c->cnt.p, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(&n_out, (char*)c->cnt.p + 768, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipMemcpyAsync(segcnt.data(), c->rb_segcnt.p, ((size_t)in->n_seg + 1) * 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipStreamSynchronize(st));
     HIP_TRY(c, hipEventElapsedTime(&out->ms_device, c->ev[0], c->ev[1]));

@@ -22,6 +22,7 @@ created after fork).  `warm_up()` in the pool's parent starts the broker ahead o
 """
 import logging
 import os
+import time
 
 from . import _abi, engine, rows as rows_mod
 from .columns import SigStore, Params, TYPES
@@ -102,6 +103,11 @@ def warm_up(devices=None, linger=None):
     extraction phase).  Optional: without it the first worker to need a broker starts it.  Returns the broker names."""
     from . import broker
     devs = devices if devices is not None else (device_list() or [device_index()])
+    # what every forked worker would otherwise do in its first task (~10 ms each, on the stage's critical path when the pool
+    # has as many workers as tasks): the CPU-side extension modules and the whole cal_GL table - inherited through fork.
+    # (Never the HIP library: a parent that has touched the runtime cannot fork workers that use it.)
+    from . import _rows_native, _cols_native, genotype          # noqa: F401
+    genotype.fill_table()
     prefix = "cutesv_amd-%d-%d" % (os.getuid(), os.getpid())
     os.environ["CUTESV_AMD_BROKER_NAME"] = prefix    # (inherited by the workers: they look for exactly these sockets)
     names = []
@@ -194,7 +200,10 @@ def _store_for(work_dir, sigs_index, svtype, chrom, need_reads):
     return SigStore.from_task_lists(svtype, chrom, sigs, reads, chroms=chroms)
 
 
-def run_batch(store, segments, tasks, ctx=None):
+_last_marks = [0.0, 0.0]
+
+
+def run_batch(store, segments, tasks, ctx=None, timeline=None):
     """segments: csv_segment records for `tasks` [(type, chr)] -> {(type, chr): rows}"""
     import numpy as np
     ctx = ctx or context()
@@ -206,7 +215,11 @@ def run_batch(store, segments, tasks, ctx=None):
         if ((segs["svtype"] == _abi.TRA) & (segs["genotype"] != 0)).any():
             kw["contig_len"] = store.contig_len
     hb = _abi.HostBatch(segs, store.a, store.b, store.read_id, store.aux, n_chrom=len(store.chroms), **kw)
+    if timeline:
+        _last_marks[0] = time.time()
     res = ctx.cluster_batch(hb, reuse=True, fields=ROW_FIELDS)     # (consumed right here: the arrays may be recycled by the next call)
+    if timeline:
+        _last_marks[1] = time.time()
     per_seg = rows_mod.rows_by_segment(store, hb.segments, res)
     return {t: per_seg[k] for k, t in enumerate(tasks)}
 
@@ -261,12 +274,18 @@ def _one(work_dir, chrom, svtype, sigs_index, seg_of_store, need_reads=False):
         return (chrom, [])
     if not work_dir.endswith("/"):
         work_dir += "/"                               # (main_ctrl normalises it, main script :993-996)
+    tl = os.environ.get("CUTESV_AMD_TIMELINE")        # (a directory: one line per task with its phases' clock readings)
+    t0 = time.time() if tl else 0.0
     store = _store_for(work_dir, sigs_index, svtype, chrom, need_reads)
     if (svtype, chrom) not in store.seg_index:
         return (chrom, [])
     seg = seg_of_store(store)
-    rows = run_batch(store, [seg], [(svtype, chrom)])[(svtype, chrom)]
+    t1 = time.time() if tl else 0.0
+    rows = run_batch(store, [seg], [(svtype, chrom)], timeline=tl)[(svtype, chrom)]
     logging.info("Finished %s:%s." % (chrom, svtype))
+    if tl:
+        with open(os.path.join(tl, "w%d.tl" % os.getpid()), "a") as f:
+            f.write("%s %s %d %d %.6f %.6f %.6f %.6f %.6f\n" % (svtype, chrom, store.n_sig, store.n_reads, t0, t1, _last_marks[0], _last_marks[1], time.time()))
     return (chrom, rows)
 
 

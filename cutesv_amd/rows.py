@@ -196,6 +196,72 @@ class LazyRows:
         self.extend(other)
         return self
 
+    # ---- the rest of the list protocol (advisor, r05): anything that changes single rows turns the sequence into plain rows
+    def __reduce__(self):
+        """pickles as a plain list (main_ctrl hands results[chrom] to Pool.starmap_async(generate_output, ...), which pickles
+        it; the backing holds ctypes pointers that cannot travel)"""
+        return (list, (self.materialise(),))
+
+    def _plain(self):
+        if not (len(self._parts) == 1 and isinstance(self._parts[0], list)):
+            self._parts = [self.materialise()]
+        return self._parts[0]
+
+    def append(self, row):
+        if self._parts and isinstance(self._parts[-1], list):
+            self._parts[-1].append(row)
+        else:
+            self._parts.append([row])
+
+    def insert(self, i, row):
+        self._plain().insert(i, row)
+
+    def pop(self, i=-1):
+        return self._plain().pop(i)
+
+    def remove(self, row):
+        self._plain().remove(row)
+
+    def reverse(self):
+        self._plain().reverse()
+
+    def clear(self):
+        self._parts = []
+
+    def copy(self):
+        out = LazyRows()
+        out._parts = [list(p) if isinstance(p, list) else (p[0], p[1].copy()) for p in self._parts]
+        return out
+
+    def index(self, row, *a):
+        return self.materialise().index(row, *a)
+
+    def count(self, row):
+        return self.materialise().count(row)
+
+    def __contains__(self, row):
+        return row in self.materialise()
+
+    def __setitem__(self, i, row):
+        self._plain()[i] = row
+
+    def __delitem__(self, i):
+        del self._plain()[i]
+
+    def __add__(self, other):
+        out = self.copy()
+        out.extend(other)
+        return out
+
+    def __radd__(self, other):
+        out = LazyRows()
+        out.extend(other)
+        out.extend(self)
+        return out
+
+    def __bool__(self):
+        return len(self) > 0
+
     def __eq__(self, other):
         return self.materialise() == (other.materialise() if isinstance(other, LazyRows) else other)
 
@@ -223,20 +289,31 @@ class LazyRows:
         return np.concatenate(ks) if ks else np.zeros(0, np.int64)
 
     def sort(self, key=None, reverse=False):
-        """list.sort.  A key that is `int(row[2])` - the only one the reference uses on rows (GT:252) - is recognised on a sample
-        of rows and answered from the bp1 column (a stable argsort of integers); anything else sorts the materialised rows."""
+        """list.sort.  `key=rows.BY_POS` (or sort_by_pos()) is answered from the bp1 column: a stable argsort of integers, no
+        row is built.  Any other key that is `int(row[2])` on a sample of rows - the reference's own lambda (GT:252) - takes the
+        same path AFTER the key has been checked against the column on every row it can be evaluated on cheaply: the sample
+        first, and, when the rows exist anyway (plain parts), all of them; a key that disagrees anywhere sorts the materialised
+        rows with list.sort (advisor, r05: a sampled probe alone could silently replace a key that differs elsewhere)."""
         n = len(self)
         if n < 2:
             return
-        vector = key is not None
-        if vector:
-            step = max(1, n // 8)
+        vector = key is BY_POS
+        if not vector and key is not None:
+            vector = True
+            step = max(1, n // 64)
             try:
                 for i in range(0, n, step):
                     r = self[i]
-                    if key(r) != int(r[2]) or type(key(r)) is not int:
+                    kv = key(r)
+                    if type(kv) is not int or kv != int(r[2]):
                         vector = False
                         break
+                if vector:                    # the key as a function of the row's fields: a row the sample did not hold cannot
+                    probe = list(self[0])     # differ unless the key reads other fields - try it on a row whose other fields moved
+                    for f in range(len(probe)):
+                        if f != 2:
+                            probe[f] = "0"
+                    vector = key(probe) == int(probe[2])
             except Exception:                 # noqa: BLE001  (a key this probe cannot evaluate: let list.sort raise what it raises)
                 vector = False
         if not vector:
@@ -257,6 +334,16 @@ class LazyRows:
             sel = lo[a0:a1]
             new.append([p[int(q)] for q in sel] if isinstance(p, list) else (p[0], p[1][sel]))
         self._parts = new
+
+
+    def sort_by_pos(self, reverse=False):
+        """the reference's `semi_result.sort(key=lambda x: int(x[2]))` (GT:252), explicitly"""
+        self.sort(key=BY_POS, reverse=reverse)
+
+
+def BY_POS(row):
+    """sort key of the reference's VCF writer: int(row[2]) (cuteSV_genotype.py:252); LazyRows.sort recognises it by identity"""
+    return int(row[2])
 
 
 def lazy_rows_by_segment(store, segments, res, ctx=None):

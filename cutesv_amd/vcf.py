@@ -84,6 +84,10 @@ def emit_records(store, segments, res, reference, min_size=30, max_size=100000, 
     rank[order] = np.arange(nch, dtype=np.int32)
     # inserted sequences of INS calls, sliced to SVLEN
     alt_blob, alt_off = None, None
+    if n and not ignore_sequence and (call_type == _abi.INS).any() and t["seq_pick"] is None:
+        raise ValueError("emit_records: the result carries no seq_pick (a slim result without that field): INS records need it unless ignore_sequence")
+    if n and report_readid and (t["support_sig"] is None or t["support_off"] is None):
+        raise ValueError("emit_records: report_readid needs the support lists (the result was made with CSV_OUT_NO_SUPPORT_LIST)")
     if n and not ignore_sequence and (call_type == _abi.INS).any():
         from . import _cols_native as cn                     # (built by the same make as the library; no Python fallback)
         ins = np.flatnonzero(call_type == _abi.INS)
@@ -108,7 +112,8 @@ def emit_records(store, segments, res, reference, min_size=30, max_size=100000, 
         nm = store.names.take(store.read_id[t["support_sig"]])
         so = t["support_off"].tolist()
         rn_blob, rn_off = _csr([",".join(nm[so[c]:so[c + 1]]) for c in range(n)])
-    keys = np.unique(t["gl_idx"][t["gl_idx"] >= 0]).astype(np.int32) if n else np.zeros(0, np.int32)
+    gl = t["gl_idx"]                                      # (a slim result may leave it out: no call is genotyped then)
+    keys = np.unique(gl[gl >= 0]).astype(np.int32) if (n and gl is not None) else np.zeros(0, np.int32)
     gl_strs = (C.c_char_p * max(1, len(keys)))(*["\t".join(gl_fields(int(k))).encode() for k in keys])
     strands = (C.c_char_p * len(store.strands))(*[s.encode() for s in store.strands])
     if svid is None:
@@ -151,4 +156,11 @@ def emit_stage(results, reference, **kw):
     if len(backs) != 1 or any(not hasattr(v, "backing") or v.backing() is None for v in results.values()):
         raise ValueError("emit_stage needs the untouched result of ONE cluster_stage(lazy=True) call")
     b = next(iter(backs.values()))
+    # "untouched" is checked, not assumed (advisor, r05): the emitter writes EVERY call of the backing's result, so the rows
+    # on offer must be exactly those calls - each once, none dropped with a chromosome, a task or a filtered row
+    idx = np.concatenate([v.call_indices() for v in results.values()]) if results else np.zeros(0, np.int64)
+    n = b.res.n_calls
+    if len(idx) != n or (n and not np.array_equal(np.sort(idx), np.arange(n))):
+        raise ValueError("emit_stage: the rows on offer are not exactly the calls of the stage's result (%d rows, %d calls): rows were "
+                         "removed, repeated or filtered - write those with emit_records on a result of their own, or from the row lists" % (len(idx), n))
     return emit_records(b.store, b.segments, b.res, reference, **kw)

@@ -581,6 +581,30 @@ def test_input_order_contract_is_checked(ctx):
         with pytest.raises(engine.CsvError) as e:
             ctx.validate()
         assert e.value.code == _abi.E_UNSORTED
+        # ... and after any number of runs: the runs alternate between two counter arenas, the check has its own block
+        # (advisor, r05: after an odd number of runs the error bit was written to one arena and read from the other)
+        for runs in (1, 2, 3):
+            ctx.upload(bad.host_batch(bad.tasks(), Params.ont()))
+            for _ in range(runs):
+                ctx.run()
+            with pytest.raises(engine.CsvError) as e:
+                ctx.validate()
+            assert e.value.code == _abi.E_UNSORTED
+    good = st.host_batch(st.tasks(), Params.ont())
+    ctx.upload(good)
+    ctx.run()
+    ctx.validate()
+    # a pipelined delivery in flight: the check refuses instead of touching counters a publish may be reading
+    res = ctx.result_buffers()
+    ctx.run()
+    ctx.download(into=res)                                # (the pipelined delivery needs one synchronous download of the upload first)
+    ctx.run()
+    ctx.publish_async(res)
+    with pytest.raises(engine.CsvError) as e:
+        ctx.validate()
+    assert e.value.code == _abi.E_STATE
+    ctx.publish_wait()
+    ctx.validate()
 
 
 def test_gpu_rebuild_reproduces_the_reference_order_contract(ctx):
@@ -925,12 +949,16 @@ def test_run_tra_shim_genotypes_like_the_reference(ctx, tmp_path, monkeypatch):
                 assert_rows_equal("TRA", got[1], want, where="run_tra %s %s %s" % (mode, case["name"], c))
 
 
-def test_resident_runs_with_and_without_the_tier_peek(ctx, monkeypatch):
-    """upload / run / download: the host's peek at the big-tier counts (which skips empty k_refine<64,256> /
-    k_refine<256,2048> launches) must not change a byte, with clusters above 64 signatures present or not"""
+def test_runs_with_and_without_the_tier_peek(ctx, monkeypatch):
+    """A one-shot call whose column copies are still on the link waits for THIS run's k_chain_apply to say whether the tiers
+    above 64 signatures have work and queues k_refine<64,256> / k_refine<256,2048> only then (r06: nothing is carried over
+    from earlier runs; a resident run queues every tier).  Must not change a byte - with clusters above 64 signatures present
+    or not, with the peek or without (CSV_NO_PEEK), one-shot from page-locked columns (bulk and gate-first), one-shot from
+    pageable columns, resident."""
     for st, p in ((synth.small_mixed(seed=3), Params.ont(genotype=True)),
                   (synth.small_mixed(seed=4, coverage=150, n_sites=20), Params.ont(genotype=True, min_support=3))):
         hb = st.host_batch(st.tasks(), p)
+        phb = _pinned_batch(hb)
         want = _oracle().cluster_batch(hb, per_sig=True).trimmed()
         for env in (None, "1"):
             if env:
@@ -941,6 +969,12 @@ def test_resident_runs_with_and_without_the_tier_peek(ctx, monkeypatch):
             for _ in range(3):
                 ctx.run()
             assert_soa_equal(ctx.download(per_sig=True).trimmed(), want)
+            for lazy_min in ("0", "1000000000"):
+                monkeypatch.setenv("CSV_LAZY_MIN", lazy_min)
+                for _ in range(2):
+                    assert_soa_equal(ctx.cluster_batch(phb, per_sig=True, reuse=True).trimmed(), want)
+            monkeypatch.delenv("CSV_LAZY_MIN", raising=False)
+            assert_soa_equal(ctx.cluster_batch(hb, per_sig=True).trimmed(), want)
     sizes = np.bincount(want["cluster_id"][want["cluster_id"] >= 0])
     assert sizes.max() > 64                                   # the second workload does exercise the big tiers
 
@@ -1032,10 +1066,10 @@ def test_resident_reruns_keep_the_reads_order_state(ctx):
     ctx.option(1, 1)
 
 
-def test_resident_reruns_launch_what_an_earlier_run_asked_for(ctx):
-    """the refine tiers above 64 signatures and the genotype overflow pass are launched in a re-run only if an earlier run of the
-    same upload reported work for them: a deep batch (every tier, cover sets beyond the small hash tables) and a shallow one,
-    uploaded alternately and run several times each, must give the oracle's result every time"""
+def test_resident_reruns_of_deep_and_shallow_batches(ctx):
+    """a deep batch (every refine tier, cover sets beyond the small hash tables: the genotype overflow pass has work) and a
+    shallow one, uploaded alternately and run several times each, must give the oracle's result every time (r05 launched the
+    upper tiers and the overflow pass only when an earlier run had asked for them; r06 launches them in every resident run)"""
     p = Params.ont(genotype=True, min_support=3)
     deep = synth.small_mixed(seed=4711, n_sites=6, coverage=900, genotype=True)
     shallow = synth.small_mixed(seed=4712, n_sites=40, coverage=12, genotype=True)

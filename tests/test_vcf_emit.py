@@ -344,3 +344,56 @@ def test_reference_generate_output_consumes_lazy_rows(tmp_path):
             sys.modules["pysam"] = saved
         else:
             del sys.modules["pysam"]
+
+
+def _count_rows(rows):
+    return len(rows), rows[0][2] if len(rows) else None
+
+
+def test_lazy_rows_pickle_and_the_rest_of_the_list_protocol():
+    """main_ctrl hands results[chrom] to Pool.starmap_async(generate_output, ...) (main script :1208-1237), which pickles it: a
+    LazyRows travels as the plain list of its rows.  append / insert / + / item assignment / deletion turn it into plain
+    rows and behave like a list's (advisor, r05)."""
+    import multiprocessing as mp
+    import pickle
+    from cutesv_amd.rows import LazyRows, BY_POS
+    case = next(c for c in load_json("small_cases.json.gz") if c["name"] == "ont_gt")
+    st = store_from_json(case["store"])
+    p = Params(**case["params"])
+    tasks = [(t, c) for t, c, _ in case["rows"]]
+    lazy, eager = _lazy_and_eager(st, p, tasks)
+    ch = max(eager, key=lambda c: len(eager[c]))
+    lz, ea = lazy[ch], eager[ch]
+    assert len(ea) > 5
+    back = pickle.loads(pickle.dumps(lz))
+    assert type(back) is list and back == ea
+    with mp.get_context("fork").Pool(2) as pool:                       # the hand-off itself
+        got = pool.starmap(_count_rows, [(lz,), (lazy[next(iter(lazy))],)])
+    assert got[0] == (len(ea), ea[0][2])
+    extra = ["9", "DEL", "5", "-40", "3", "-1,1", "-2,2", ".", "./.", ".,.,.", ".", ".", "r1,r2"]
+    a, b = lz.copy(), list(ea)
+    assert (a + [extra]) == (b + [extra]) and ([extra] + a) == ([extra] + b) and isinstance(a + [extra], LazyRows)
+    a.append(extra); b.append(extra)
+    assert a == b and len(a) == len(b) and extra in a and a.index(extra) == b.index(extra) and a.count(extra) == 1
+    a.insert(1, extra); b.insert(1, extra)
+    a[0] = extra; b[0] = extra
+    del a[2]; del b[2]
+    assert a == b
+    assert a.pop() == b.pop() and a.pop(0) == b.pop(0) and a == b
+    a.reverse(); b.reverse()
+    assert a == b and bool(a)
+    a.remove(extra); b.remove(extra)
+    assert a == b
+    a.clear()
+    assert len(a) == 0 and not a and lz == ea                          # (the copy was the one that changed)
+    # the explicit position key: from the bp1 column, no row built; a look-alike key that reads another field as well is not
+    # mistaken for it
+    c, d = lz.copy(), list(ea)
+    c.sort(key=BY_POS); d.sort(key=lambda x: int(x[2]))
+    assert c == d and c.backing() is not None
+    c.sort_by_pos(reverse=True); d.sort(key=lambda x: int(x[2]), reverse=True)
+    assert c == d
+    tricky = lambda x: int(x[2]) + (0 if x[4] != "0" else 10 ** 9)      # noqa: E731  (int(row[2]) on every real row)
+    c, d = lz.copy(), list(ea)
+    c.sort(key=tricky); d.sort(key=tricky)
+    assert c == d and c.backing() is None
