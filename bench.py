@@ -505,10 +505,16 @@ def cpu_legs(name, store, params, tasks, hb, n_sig, procs, py_pool, full_pool):
 
 
 def stage_leg(name, store, params):
-    """bench_stage.mode1_stage, never allowed to break the line"""
+    """bench_stage.mode1_stage in a process of its own, never allowed to break the line.  A cuteSV main process is small when it
+    forks its phase-3 pool; this one holds gigabytes of workloads and oracle results by then, and every fork copies its page
+    tables (measured: the 32-worker cfg4 stage 322 ms from a fresh process, 915-1130 ms forked from here)."""
+    import subprocess
     try:
-        import bench_stage
-        return bench_stage.mode1_stage(name, store, params)
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench_stage.py"), "--workload", name], stdout=subprocess.PIPE, stderr=None, timeout=900)
+        lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+        if p.returncode != 0 or not lines:
+            return dict(error="bench_stage.py exited with %d" % p.returncode)
+        return json.loads(lines[-1])
     except Exception as e:          # noqa: BLE001
         import traceback
         return dict(error=repr(e), trace=traceback.format_exc()[-400:])

@@ -8,7 +8,7 @@ import ctypes as C
 
 import numpy as np
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 DEL, INS, DUP, INV, TRA = 0, 1, 2, 3, 4
 SVTYPE_CODE = {"DEL": DEL, "INS": INS, "DUP": DUP, "INV": INV, "TRA": TRA}
 SVTYPE_NAME = {v: k for k, v in SVTYPE_CODE.items()}
@@ -18,7 +18,7 @@ ERR_NAME = {OK: "CSV_OK", E_INVALID: "CSV_E_INVALID", E_CAPACITY: "CSV_E_CAPACIT
             E_NOMEM: "CSV_E_NOMEM", E_UNSORTED: "CSV_E_UNSORTED", E_STATE: "CSV_E_STATE"}
 N_STAGES = 24
 GL_TABLE_SIZE = 101 * 101 + 2
-IN_PER_SIG, IN_READS_SORTED, IN_SIG_I32, IN_READS_I32, IN_DEVICE_COLUMNS = 1, 2, 4, 8, 16            # csv_batch_in.flags
+IN_PER_SIG, IN_READS_SORTED, IN_SIG_I32, IN_READS_I32, IN_DEVICE_COLUMNS, IN_SIG_DELTA16 = 1, 2, 4, 8, 16, 32            # csv_batch_in.flags
 RB_KEEP_ON_DEVICE = 1
 RB_FROM_POOL = 2                        # ... the rows are the context's device-resident signature pool
 CG_TO_POOL = 1                         # csv_cigar_in.flags: the signatures also become pool rows                         # csv_rebuild_in.flags
@@ -51,6 +51,7 @@ class BatchIn(C.Structure):
         ("r_start", C.c_void_p), ("r_end", C.c_void_p), ("r_primary", C.c_void_p), ("r_id", C.c_void_p),
         ("contig_len", C.c_void_p),
         ("flags", C.c_int32), ("reserved", C.c_int32),
+        ("a_delta", C.c_void_p), ("n_esc", C.c_int64), ("a_esc_row", C.c_void_p), ("a_esc_val", C.c_void_p),      # ABI v8: CSV_IN_SIG_DELTA16
     ]
 
 
@@ -89,7 +90,9 @@ class HostBatch:
     """Host-side buffers of one csv_batch_in.  Keeps the numpy arrays alive for the C call."""
 
     def __init__(self, segments, a, b, read_id, aux, n_chrom=0, reads_off=None,
-                 r_start=None, r_end=None, r_primary=None, r_id=None, contig_len=None, per_sig=False, reads_sorted=False):
+                 r_start=None, r_end=None, r_primary=None, r_id=None, contig_len=None, per_sig=False, reads_sorted=False, a_delta=None):
+        """a_delta: (delta uint16[n_sig], escape rows int64[], escape values int32[]) of `a` - delta16_of(a) - when the position
+        column may cross the link as 16-bit gaps (CSV_IN_SIG_DELTA16; int32 columns only)"""
         self.segments = np.ascontiguousarray(segments, dtype=SEGMENT_DTYPE)
         # positions / lengths may come as int32 columns (CSV_IN_SIG_I32: a third less data on the link); both alike
         sig32 = getattr(a, "dtype", None) == np.int32 and getattr(b, "dtype", None) == np.int32
@@ -115,6 +118,12 @@ class HostBatch:
         self.contig_len = None if contig_len is None else _col(contig_len, np.int64)
         if self.contig_len is not None and self.contig_len.shape[0] != self.n_chrom:
             raise ValueError("contig_len must have n_chrom entries")
+        self.a_delta = None
+        if a_delta is not None and self.a.dtype == np.int32:
+            d, er, ev = a_delta
+            self.a_delta = (_col(d, np.uint16), _col(er, np.int64), _col(ev, np.int32))
+            if self.a_delta[0].shape[0] != n or self.a_delta[1].shape[0] != self.a_delta[2].shape[0]:
+                raise ValueError("a_delta: one gap per signature and one value per escape row are expected")
         self.c = BatchIn(
             n_seg=len(self.segments), n_chrom=self.n_chrom, seg=_ptr(self.segments),
             n_sig=n, a=_ptr(self.a), b=_ptr(self.b), read_id=_ptr(self.read_id), aux=_ptr(self.aux),
@@ -123,7 +132,9 @@ class HostBatch:
             r_start=_ptr(self.r_start), r_end=_ptr(self.r_end), r_primary=_ptr(self.r_primary), r_id=_ptr(self.r_id),
             contig_len=_ptr(self.contig_len),
             flags=(IN_PER_SIG if per_sig else 0) | (IN_READS_SORTED if reads_sorted else 0) | (IN_SIG_I32 if self.a.dtype == np.int32 else 0)
-            | (IN_READS_I32 if self.r_start is not None and self.r_start.dtype == np.int32 else 0))
+            | (IN_READS_I32 if self.r_start is not None and self.r_start.dtype == np.int32 else 0) | (IN_SIG_DELTA16 if self.a_delta is not None else 0),
+            a_delta=None if self.a_delta is None else _ptr(self.a_delta[0]), n_esc=0 if self.a_delta is None else self.a_delta[1].shape[0],
+            a_esc_row=None if self.a_delta is None else _ptr(self.a_delta[1]), a_esc_val=None if self.a_delta is None else _ptr(self.a_delta[2]))
 
     @classmethod
     def on_device(cls, segments, dev, n_sig, n_chrom=0, keep=None, **reads):
@@ -266,6 +277,23 @@ class HostResult:
                 out[name] = arr
         out["n_clusters"] = self.n_clusters
         return out
+
+
+def delta16_of(a, alloc=None):
+    """The position column as CSV_IN_SIG_DELTA16 takes it: (gaps uint16[n], escape rows int64[], escape values int32[]).
+    gap[i] = a[i] - a[i - 1] where that lies in [0, 0xFFFF) (i > 0), else 0xFFFF with (i, a[i]) in the escape list.
+    alloc(shape, dtype): where the gap array lives (engine.pinned_empty for a page-locked one)."""
+    a = np.ascontiguousarray(a, np.int32)
+    n = a.shape[0]
+    d = np.empty(n, np.int64)
+    if n:
+        d[0] = -1
+        np.subtract(a[1:], a[:-1], out=d[1:], dtype=np.int64)
+    esc = (d < 0) | (d >= 0xFFFF)
+    out = (alloc or (lambda s_, dt: np.empty(s_, dt)))(n, np.uint16)
+    np.copyto(out, np.where(esc, 0xFFFF, d), casting="unsafe")
+    rows = np.flatnonzero(esc).astype(np.int64)
+    return out, rows, a[rows].astype(np.int32)
 
 
 def make_segment(svtype, chrom, sig_begin, sig_end, max_cluster_bias, read_count, diff_ratio=0.0,

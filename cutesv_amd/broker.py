@@ -264,6 +264,9 @@ class Client:
             reg = self.region
             cin = _abi.BatchIn.from_buffer_copy(bytes(batch.c))
             cin.n_chrom, cin.n_sig = n_chrom, n
+            cin.a_delta = cin.a_esc_row = cin.a_esc_val = None      # (the gap form of a whole store's column does not travel with a task)
+            cin.n_esc = 0
+            cin.flags &= ~_abi.IN_SIG_DELTA16
             by = dict(cols)
             # positions and lengths travel as int32 when they fit (a genome's coordinates do: CSV_IN_SIG_I32 / CSV_IN_READS_I32):
             # half the bytes through the region, the broker's staging columns and the link

@@ -220,6 +220,9 @@ class SigStore:
                     narrow[k] = engine.pinned_copy(v.astype(np.int32))
                 else:
                     cols[k] = engine.pinned_copy(v)
+        if "a" in narrow:
+            # ... and the position column once more as 16-bit gaps (CSV_IN_SIG_DELTA16): half of the largest transfer of a call
+            narrow["a_delta"] = _abi.delta16_of(narrow["a"], alloc=engine.pinned_empty)
         return dataclasses.replace(self, narrow=narrow or None, **cols)
 
     # ------------------------------------------------------------------ string tables for the native row / VCF emitters
@@ -325,7 +328,8 @@ class SigStore:
                       r_primary=self.r_primary, r_id=self.r_id)
             if bool(((segs["svtype"] == _abi.TRA) & (segs["genotype"] != 0)).any()):
                 kw["contig_len"] = self.contig_len
-        return _abi.HostBatch(segs, nw.get("a", self.a), nw.get("b", self.b), self.read_id, self.aux, n_chrom=len(self.chroms), **kw)
+        return _abi.HostBatch(segs, nw.get("a", self.a), nw.get("b", self.b), self.read_id, self.aux, n_chrom=len(self.chroms),
+                              a_delta=nw.get("a_delta") if os.environ.get("CUTESV_AMD_NO_DELTA16") is None else None, **kw)
 
     # ------------------------------------------------------------------ persistence (flat .cols directory)
     def save(self, path):

@@ -119,6 +119,8 @@ struct csv_ctx {
     // batch buffers (slices of `arena`)
     Buf seg, woff, seg_drop, a, b, rid, aux, a32, b32;
     Buf tile_lead, tabs;
+    Buf ad16, anc;                             // CSV_IN_SIG_DELTA16: the gaps in w space; the anchor tables {per-tile offsets, w, value}
+    bool delta16 = false;                      // the last upload rebuilt its position column from gaps (csv_batch_info 2)
     Buf cluster_id, partial, tile_cnt, item_rec, list_small, list_big, list_tiny, list_wide, seg_gate, tile_info, ch_masks, tile_items, seg_err;
     Buf item_cnt, item_base, item_chunk, sup_tmp;
     Buf t_rec, t_rec0;
@@ -471,6 +473,7 @@ int csv_batch_info(const csv_ctx* c, int which, int64_t* value)
     if (!c || !value) return CSV_E_INVALID;
     if (which == 0) *value = c->partial_cols ? 1 : 0;
     else if (which == 1) *value = c->lazy_bytes;
+    else if (which == 2) *value = c->delta16 ? 1 : 0;
     else return CSV_E_INVALID;
     return CSV_OK;
 }
@@ -575,6 +578,20 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
         lazy = lz_aux != nullptr;
     }
 
+    // CSV_IN_SIG_DELTA16: the position column as 16-bit gaps + anchors (kernels.hip.h k_unpack_a16).  Needs disjoint segments (an
+    // escape row belongs to one w): anything else takes the column itself.
+    bool delta16 = sig32_ && !dev_cols && W > 0 && (in->flags & CSV_IN_SIG_DELTA16) && in->a_delta && in->a && in->n_esc >= 0 &&
+                   (in->n_esc == 0 || (in->a_esc_row && in->a_esc_val)) && !getenv("CSV_NO_DELTA16") && W >= (i64)env_int("CSV_DELTA16_MIN", 32 << 10);
+    std::vector<std::pair<i64, int>> by_begin;            // non-empty segments by their first source row
+    if (delta16) {
+        for (int k = 0; k < S; k++) if (c->h_woff[k + 1] > c->h_woff[k]) by_begin.emplace_back(c->h_seg[k].sig_begin, k);
+        std::sort(by_begin.begin(), by_begin.end());
+        for (size_t i = 0; i + 1 < by_begin.size(); i++)
+            if (c->h_seg[by_begin[i].second].sig_end > by_begin[i + 1].first) { delta16 = false; break; }
+    }
+    const i64 n_anc_cap = delta16 ? (div_up(W, CH_TILE) + S + in->n_esc + 8) : 0;
+    c->delta16 = delta16;
+
     // ---- device memory: one plan, one arena
     const i64 R = (c->any_genotype && in->reads_off) ? in->n_reads : 0;
     const bool reorder = R > 0 && !(in->flags & CSV_IN_READS_SORTED);
@@ -594,13 +611,15 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
     const size_t o_seg = 0, o_woff = o_seg + (size_t)(S + 1) * sizeof(csv_segment), o_drop = o_woff + (size_t)(S + 2) * 8,
                  o_gate = (o_drop + (size_t)S + 1 + 15) & ~(size_t)15, o_serr = o_gate + (size_t)(S + 1) * 16,
                  o_tiles = (o_serr + (size_t)(S + 1) * 4 + 15) & ~(size_t)15, o_end = o_tiles + (size_t)nt * TILE_REC * 16,
-                 o_ones = (o_end + 255) & ~(size_t)255, ones_bytes = (size_t)(CH_TILE + 64) * 8, o_stage_end = o_ones + ones_bytes;
+                 o_ones = (o_end + 255) & ~(size_t)255, ones_bytes = (size_t)(CH_TILE + 64) * 8, o_anc = o_ones + ones_bytes,
+                 anc_bytes = delta16 ? (size_t)(div_up(W, CH_TILE) + 2 + 2 * n_anc_cap) * 4 : 0, o_stage_end = o_anc + ((anc_bytes + 255) & ~(size_t)255);
     PL(tabs, o_end);
     // positions and lengths stay in the width they arrive in: the kernels read int32 columns as they are (kernels.hip.h Col)
     const bool sig32 = (in->flags & CSV_IN_SIG_I32) != 0, rd32 = (in->flags & CSV_IN_READS_I32) != 0;
     // (the position column is followed by a tile of padding, so that the chain kernel can read any span that begins inside the batch)
     if (sig32) { PL(a32, (W + CH_TILE + 64) * 4); PL(b32, (W + 1) * 4); } else { PL(a, (W + CH_TILE + 64) * 8); PL(b, (W + 1) * 8); }
     PL(rid, (W + 1) * 4); PL(aux, (W + 1) * 4);
+    if (delta16) { PL(ad16, (W + CH_TILE + 64) * 2); PL(anc, (size_t)(div_up(W, CH_TILE) + 2 + 2 * n_anc_cap) * 4); }
     PL(sup_tmp, (W + 1) * 4);
     if (per_sig) { PL(cluster_id, (W + 1) * 4); PL(allele_id, (W + 1) * 4); }
     PL(partial, nt * 4); PL(tile_cnt, nt * 16);
@@ -711,7 +730,8 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
             const i64 src = c->h_seg[k].sig_begin, n = c->h_woff[e + 1] - c->h_woff[k], dst = c->h_woff[k];
             if (n > 0) {
                 if (group == 1 && sig32) {
-                    HIP_TRY(c, hipMemcpyAsync(dp<int>(c->a32) + dst, (const int32_t*)in->a + src, n * 4, col_kind, cs));
+                    if (delta16) { HIP_TRY(c, hipMemcpyAsync(dp<uint16_t>(c->ad16) + dst, in->a_delta + src, n * 2, col_kind, cs)); c->lazy_bytes += n * 2; }
+                    else HIP_TRY(c, hipMemcpyAsync(dp<int>(c->a32) + dst, (const int32_t*)in->a + src, n * 4, col_kind, cs));
                     if (!lazy) HIP_TRY(c, hipMemcpyAsync(dp<int>(c->b32) + dst, (const int32_t*)in->b + src, n * 4, col_kind, cs));
                 } else if (group == 1) {
                     HIP_TRY(c, hipMemcpyAsync(dp<i64>(c->a) + dst, in->a + src, n * 8, col_kind, cs));
@@ -741,6 +761,47 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
                 }
             }
             k = e + 1;
+        }
+        if (group == 1 && delta16) {
+            // the anchors, built while the gaps are on the link: the first row of every chain tile, the first row of every
+            // segment, the caller's escape rows that lie in a segment - {w, a[source row of w]} by ascending w, one slice per tile
+            const int32_t* ha = (const int32_t*)in->a;
+            const i64 ntile = div_up(W, CH_TILE);
+            std::vector<std::pair<i64, int>> anc;
+            anc.reserve((size_t)n_anc_cap);
+            {
+                int k = 0;
+                for (i64 t = 0; t < ntile; t++) {
+                    const i64 w = t * (i64)CH_TILE;
+                    while (k + 1 < S && c->h_woff[k + 1] <= w) k++;
+                    anc.emplace_back(w, ha[c->h_seg[k].sig_begin + (w - c->h_woff[k])]);
+                }
+            }
+            for (auto& bk : by_begin) anc.emplace_back(c->h_woff[bk.second], ha[bk.first]);
+            for (i64 e = 0; e < in->n_esc; e++) {
+                const i64 g = in->a_esc_row[e];
+                auto it = std::upper_bound(by_begin.begin(), by_begin.end(), std::make_pair(g, INT32_MAX));
+                if (it == by_begin.begin()) continue;
+                --it;
+                const csv_segment& sg = c->h_seg[it->second];
+                if (g >= sg.sig_end) continue;                      // (a row no segment of this batch holds)
+                anc.emplace_back(c->h_woff[it->second] + (g - sg.sig_begin), in->a_esc_val[e]);
+            }
+            std::sort(anc.begin(), anc.end());
+            anc.erase(std::unique(anc.begin(), anc.end(), [](const std::pair<i64, int>& x, const std::pair<i64, int>& y) { return x.first == y.first; }), anc.end());
+            int* h_off = (int*)(c->h_pin + o_anc);
+            int* h_w = h_off + ntile + 2;
+            int* h_v = h_w + n_anc_cap;
+            size_t q = 0;
+            for (i64 t = 0; t <= ntile; t++) {
+                while (q < anc.size() && anc[q].first < t * (i64)CH_TILE) q++;
+                h_off[t] = (int)q;
+            }
+            h_off[ntile + 1] = (int)anc.size();
+            for (size_t i = 0; i < anc.size(); i++) { h_w[i] = (int)anc[i].first; h_v[i] = anc[i].second; }
+            HIP_TRY(c, hipMemcpyAsync(c->anc.p, c->h_pin + o_anc, anc_bytes, hipMemcpyHostToDevice, cs));
+            UnpackArgs UA{dp<uint16_t>(c->ad16), dp<int>(c->a32), W, dp<int>(c->anc), dp<int>(c->anc) + ntile + 2, dp<int>(c->anc) + ntile + 2 + n_anc_cap};
+            hipLaunchKernelGGL(k_unpack_a16, dim3((unsigned)ntile), dim3(256), 0, cs, UA);
         }
         HIP_TRY(c, hipEventRecord(c->ev_copy[group - 1], cs));
     }

@@ -897,6 +897,63 @@ __global__ __launch_bounds__(256) void k_chain_ids(DevBatch B)
     }
 }
 
+// ------------------------------------------------------------------------------------ the position column from 16-bit gaps
+// CSV_IN_SIG_DELTA16 (ABI v8): the rebuild order (main script :764-802) makes the position column non-decreasing inside a
+// segment and a genome's neighbouring signatures lie ~1 kb apart, so the column - the largest transfer of a gate-first call -
+// crosses the link as 16-bit gaps and is rebuilt here, in front of the chain kernels.  Wherever a gap does not exist or does
+// not fit (the first row of a chain tile, the first row of a segment, the caller's escape rows) the host side lists an
+// ANCHOR {w, a[w]}; a row's position is its last anchor plus the gaps since: a segmented inclusive scan, one workgroup per
+// chain tile, eight consecutive rows per thread (one 16-byte load).  Every tile begins with an anchor, so tiles are independent.
+struct UnpackArgs {
+    const uint16_t* d;          // gaps in w space (+ a tile of slack)
+    int*            a;          // the int32 position column
+    i64             W;
+    const int*      anc_off;    // per chain tile: first anchor; [ntiles]: the end
+    const int*      anc_w;      // ascending
+    const int*      anc_val;
+};
+__global__ __launch_bounds__(256) void k_unpack_a16(UnpackArgs A)
+{
+    __shared__ int s_f[4], s_s[4];
+    const int tile = blockIdx.x, t = threadIdx.x, lane = lane_id(), wv = t >> 6;
+    const i64 w0 = (i64)tile * CH_TILE + t * 8;
+    const uint4 raw = *(const uint4*)(A.d + w0);
+    const unsigned g[8] = {raw.x & 0xffffu, raw.x >> 16, raw.y & 0xffffu, raw.y >> 16, raw.z & 0xffffu, raw.z >> 16, raw.w & 0xffffu, raw.w >> 16};
+    const int o1 = A.anc_off[tile + 1];
+    int lo = A.anc_off[tile], hi = o1;                      // first anchor at or behind this thread's first row
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if ((i64)A.anc_w[mid] < w0) lo = mid + 1; else hi = mid; }
+    int ai = lo;
+    i64 aw = ai < o1 ? (i64)A.anc_w[ai] : (i64)INT64_MAX;
+    int loc[8];
+    unsigned since = 0;                                     // bit r: an anchor at or before row r inside this thread
+    int sum = 0, F = 0;
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        if (w0 + r == aw) { sum = A.anc_val[ai]; F = 1; ai++; aw = ai < o1 ? (i64)A.anc_w[ai] : (i64)INT64_MAX; }
+        else sum += (int)g[r];
+        loc[r] = sum;
+        if (F) since |= 1u << r;
+    }
+    // segmented inclusive scan of the threads' (F, sum): (F1, S1) + (F2, S2) = (F1 | F2, F2 ? S2 : S1 + S2)
+    int fs = F, ss = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int fo = __shfl_up(fs, off), so = __shfl_up(ss, off);
+        if (lane >= off) { if (!fs) ss += so; fs |= fo; }
+    }
+    if (lane == 63) { s_f[wv] = fs; s_s[wv] = ss; }
+    __syncthreads();
+    int pf = 0, ps = 0;                                     // what the earlier wavefronts carry in
+    for (int q = 0; q < wv; q++) { if (s_f[q]) { pf = 1; ps = s_s[q]; } else ps += s_s[q]; }
+    int ef = __shfl_up(fs, 1), es = __shfl_up(ss, 1);       // the lanes before this one, inside the wavefront
+    if (lane == 0) { ef = 0; es = 0; }
+    const int carry = ef ? es : ps + es;                    // (a tile's first row is an anchor: the carry is always defined by one)
+    (void)pf;
+#pragma unroll
+    for (int r = 0; r < 8; r++)
+        if (w0 + r < A.W) A.a[w0 + r] = ((since >> r) & 1) ? loc[r] : loc[r] + carry;
+}
+
 // ------------------------------------------------------------------------------------ gate-first fetch
 // A one-shot call from page-locked columns (csv_cluster_batch) sends only the POSITION column across PCIe in bulk (plus b / aux
 // of INV / TRA segments, whose chain predicates read them): 82 % of a 30x genome's signatures sit in clusters that fail the size

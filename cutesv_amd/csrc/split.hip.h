@@ -49,7 +49,7 @@ template <bool EMIT> struct SpSink {
 __device__ __forceinline__ SpSeg sp_flip(SpSeg x, i64 L) { SpSeg y = x; y.rs = L - x.re; y.re = L - x.rs; return y; }    // [RLength - x[1], RLength - x[0]] + x[2:]
 __device__ __forceinline__ double sp_max(i64 a, i64 delta) { const double q = (double)delta / 5.0; return (double)a > q ? (double)a : q; }   // max(a, delta / 5)
 
-template <bool EMIT> __device__ void sp_inv(SpSink<EMIT>& S, const SpSeg& e1, const SpSeg& e2, i64 SV)      // analysis_inv :50-95
+template <bool EMIT> __device__ __forceinline__ void sp_inv(SpSink<EMIT>& S, const SpSeg& e1, const SpSeg& e2, i64 SV)      // analysis_inv :50-95
 {
     if (e1.st == 0) {
         if (e1.fe - e2.fe >= SV && 2 * e2.rs + (e1.fe - e2.fe) >= 2 * e1.re) S.put(3, e1.chr, 0, e2.fe, e1.fe, 0, 0);
@@ -59,7 +59,7 @@ template <bool EMIT> __device__ void sp_inv(SpSink<EMIT>& S, const SpSeg& e1, co
         if (e1.fs - e2.fs >= SV && 2 * e2.rs + (e1.fs - e2.fs) >= 2 * e1.re) S.put(3, e1.chr, 1, e2.fs, e1.fs, 0, 0);
     }
 }
-template <bool EMIT> __device__ void sp_bnd(SpSink<EMIT>& S, const SpSeg& e1, const SpSeg& e2)                // analysis_bnd :97-188
+template <bool EMIT> __device__ __forceinline__ void sp_bnd(SpSink<EMIT>& S, const SpSeg& e1, const SpSeg& e2)                // analysis_bnd :97-188
 {
     if (e2.rs - e1.re > 100) return;
     const bool lt = e1.chr < e2.chr;                   // (chromosome ids are ranks in Python string order)
@@ -71,7 +71,7 @@ template <bool EMIT> __device__ void sp_bnd(SpSink<EMIT>& S, const SpSeg& e1, co
 }
 // the INS / DEL pair of rules on two consecutive same-strand segments (:241-259, :358-376, :382-399, :411-428); `gate` is
 // the extra ele_3[2] >= ele_2[3] test of :361 / :371 (true where the reference has none)
-template <bool EMIT> __device__ void sp_indel(SpSink<EMIT>& S, const SpSeg& e1, const SpSeg& e2, i64 SV, i64 Max, int rc, bool gate)
+template <bool EMIT> __device__ __forceinline__ void sp_indel(SpSink<EMIT>& S, const SpSeg& e1, const SpSeg& e2, i64 SV, i64 Max, int rc, bool gate)
 {
     i64 delta = e2.rs + e1.fe - e2.fs - e1.re;
     if ((double)(e1.fe - e2.fs) < sp_max(SV, delta) && delta >= SV)
@@ -83,7 +83,7 @@ template <bool EMIT> __device__ void sp_indel(SpSink<EMIT>& S, const SpSeg& e1, 
             if (gate) S.put(0, e2.chr, 0, e1.fe, delta, 0, 0);
 }
 
-template <bool EMIT> __device__ int split_read(const SplitArgs& A, i64 r, i64 out_base)
+template <bool EMIT> __device__ __forceinline__ int split_read(const SplitArgs& A, i64 r, i64 out_base)
 {
     const i64 e0 = A.ent_off[r], e1o = A.ent_off[r + 1], L = A.read_len[r];
     const i64 SV = A.sv, Max = A.max_size;
@@ -96,7 +96,10 @@ template <bool EMIT> __device__ int split_read(const SplitArgs& A, i64 r, i64 ou
         if (A.primary[k]) { x.rs = A.c0[k]; x.re = A.c1[k]; x.fs = A.f0[k]; x.fe = A.f1[k]; min_mapq = 0; }
         else {
             if (A.mapq[k] < min_mapq) continue;                                                      // :501
-            if (x.st == 0) { x.rs = A.c0[k]; x.re = L - A.c1[k]; } else { x.rs = A.c1[k]; x.re = L - A.c0[k]; }    // :503-510
+            // (both words loaded, then chosen: written as two branches that read c0 / c1 crosswise, the compiler builds a table
+            // of the two POINTERS in scratch and indexes it by the strand - 24 bytes of scratch per lane for a select)
+            const i64 v0 = A.c0[k], v1 = A.c1[k];
+            x.rs = x.st == 0 ? v0 : v1; x.re = L - (x.st == 0 ? v1 : v0);                             // :503-510
             x.fs = A.f0[k]; x.fe = A.f0[k] + A.f1[k];
         }
         int p = n++;

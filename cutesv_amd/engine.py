@@ -117,6 +117,12 @@ class Context:
         self._check(lib().csv_batch_info(self._h, 1, C.byref(b)))
         return bool(a.value), int(b.value)
 
+    def delta16_info(self):
+        """did the last upload send its position column as 16-bit gaps (CSV_IN_SIG_DELTA16)?  csv_batch_info(2)"""
+        a = C.c_int64(0)
+        self._check(lib().csv_batch_info(self._h, 2, C.byref(a)))
+        return bool(a.value)
+
     def download(self, per_sig=False, cap_calls=None, cap_support=None, into=None):
         if into is not None:
             # the library checks cap_calls / cap_support (E_CAPACITY); the arrays it fills WITHOUT a capacity of their own are

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CSV_ABI_VERSION 7
+#define CSV_ABI_VERSION 8
 
 /* SV types: one (chromosome, type) pair is one segment == one reference pool task
  * (MAIN:1116-1189).  Order of the enum is irrelevant to results. */
@@ -96,10 +96,15 @@ enum {
     CSV_IN_SIG_I32 = 4,       /* a and b point to int32_t columns (positions and lengths of a genome fit 31 bits; a third
                                  less data on the link: 67 -> 45 MB for a 30x genome); widened on the device */
     CSV_IN_READS_I32 = 8,     /* r_start and r_end point to int32_t columns */
-    CSV_IN_DEVICE_COLUMNS = 16 /* a, b, read_id and aux are DEVICE pointers (memory of this context's GPU, e.g. csv_rebuild_out.dev_* of
+    CSV_IN_DEVICE_COLUMNS = 16, /* a, b, read_id and aux are DEVICE pointers (memory of this context's GPU, e.g. csv_rebuild_out.dev_* of
                                  a csv_rebuild_signatures call with CSV_RB_KEEP_ON_DEVICE): the columns move device to device
                                  (HBM rate) instead of crossing PCIe twice; the reference's dataflow rebuild -> cluster
                                  (MAIN:750-857 -> 1113-1199) without a host round trip */
+    CSV_IN_SIG_DELTA16 = 32   /* (ABI v8, with CSV_IN_SIG_I32, host columns) a_delta / a_esc_* are given: the position column crosses
+                                 the link as 16-bit gaps - the rebuild order (MAIN:764-802) makes it non-decreasing inside a segment,
+                                 a 30x genome's neighbours are ~1 kb apart - and is rebuilt on the device (k_unpack_a16): 11.1 -> 5.6 MB
+                                 for a 30x genome, the largest single transfer of a gate-first call.  `a` must still be given (the
+                                 library reads a few rows of it on the host; every other path uses it as before) */
 };
 typedef struct csv_batch_in {
     int32_t            n_seg;
@@ -120,6 +125,13 @@ typedef struct csv_batch_in {
                                        TRA segment genotypes */
     int32_t            flags;       /* CSV_IN_* */
     int32_t            reserved;
+    /* (ABI v8) CSV_IN_SIG_DELTA16: a_delta[i] = a[i] - a[i - 1] where that lies in [0, 0xFFFF) and i > 0, else 0xFFFF and row i is listed
+     * in a_esc_row (ascending) with a_esc_val = a[i].  n_sig entries; built once per store (SigStore.pinned()).  Rows that begin a
+     * segment or a chain tile need no escape: the library anchors them itself.  NULL / 0 without the flag. */
+    const uint16_t*    a_delta;
+    int64_t            n_esc;
+    const int64_t*     a_esc_row;
+    const int32_t*     a_esc_val;
 } csv_batch_in;
 
 /*
@@ -256,7 +268,9 @@ int csv_batch_reads_mode(const csv_ctx* ctx);
 /* (ABI v7) What the last upload of this context did at the PCIe boundary: which = 0: 1 when csv_cluster_batch took the
  * gate-first form (page-locked b / read_id / aux columns: only the position column travels in bulk, the rows of the clusters
  * that pass the size gate - INDEL:62-64, 86 - are read out of the caller's columns by the device), else 0; which = 1: the
- * bytes of signature columns the bulk copy therefore did not send.  A measurement aid (bench.py's pcie object). */
+ * bytes of signature columns the bulk copy therefore did not send (ABI v8: including the half of the position column that
+ * CSV_IN_SIG_DELTA16 saves); which = 2 (ABI v8): 1 when the position column crossed as 16-bit gaps.  A measurement aid
+ * (bench.py's pcie object). */
 int csv_batch_info(const csv_ctx* ctx, int which, int64_t* value);
 /* Context options.  CSV_OPT_REUSE_READS_ORDER (default 1): the start-ordered, packed copy of the reads table that the first
  * csv_batch_run after an upload builds is kept for later runs of the SAME upload (a resident caller that re-runs a batch,

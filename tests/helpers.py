@@ -250,3 +250,21 @@ def assert_single_pipe_case(case, cigar_fn, split_fn):
         assert got == case[t], (case["name"], t, len(got), len(case[t]))
     assert [list(x) for x in reads_info] == case["reads_table"], (case["name"], len(reads_info), len(case["reads_table"]))
     assert len(reads_info) > 20
+
+
+# ------------------------------------------------------------------------------------------------ zero-width genotype windows
+def zero_width_window_case():
+    """max_cluster_bias_DEL = 0 with --genotype: every DEL window is (p, p).  The reference RAISES there (KeyError inside
+    overlap_cover's sweep, cuteSV_genotype.py:95-159: the window's right end is processed before its left end) and main_ctrl
+    swallows the exception, so the whole task's rows are lost (main script :1198-1199; checked against the reference itself
+    in the build container).  The build does not reproduce the crash: it returns the calls, genotyped by the rule the sweep
+    implements wherever it returns - cover = primary reads with start <= L and end >= R.  -> (store, params, expected rows)"""
+    per = {"DEL": [(1000, 50 + (i % 3), "r%d" % i, "DEL", "1") for i in range(8)] + [(5000, 80, "q%d" % i, "DEL", "1") for i in range(6)]}
+    reads = ([(900 - 10 * i, 1200 + 10 * i, 1, "r%d" % i, "1") for i in range(8)] +
+             [(400, 6000, 1, "x1", "1"), (990, 1001, 1, "x2", "1"), (1000, 1000, 1, "x3", "1"), (1001, 2000, 1, "x4", "1"),
+              (4000, 5000, 1, "x5", "1"), (5000, 7000, 0, "x6", "1")] + [(4900, 5100, 1, "q%d" % i, "1") for i in range(6)])
+    st = SigStore.from_tuple_lists(per, reads)
+    p = Params(min_support=3, genotype=True, max_cluster_bias_DEL=0)
+    want = [['1', 'DEL', '1000', '-50', '8', '-0,0', '-0,0', '3', '0/1', '51,3,3', '3', '51.0', 'r0,r3,r6,r1,r4,r7,r2,r5'],
+            ['1', 'DEL', '5000', '-80', '6', '-0,0', '-0,0', '2', '1/1', '41,4,2', '3', '40.6', 'q0,q1,q2,q3,q4,q5']]
+    return st, p, want

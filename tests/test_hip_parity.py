@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from cutesv_amd import synth, engine, _abi
-from cutesv_amd.columns import Params
+from cutesv_amd.columns import Params, SigStore
 from helpers import (load_json, store_from_json, rows_by_task, assert_rows_equal, assert_soa_equal, digest)
 
 pytestmark = pytest.mark.gpu
@@ -438,6 +438,16 @@ def test_full_size_partition_and_rerun_properties(ctx, cfg):
     assert sum(n for n, _ in whole.values()) > min_calls
     for t in tasks:
         assert parts[t] == whole[t], t
+
+
+def test_zero_width_genotype_windows(ctx):
+    """max_cluster_bias 0 with genotyping: the reference raises inside overlap_cover and its main_ctrl drops the task; the
+    build returns the calls (helpers.zero_width_window_case says why and what)"""
+    from helpers import zero_width_window_case
+    st, p, want = zero_width_window_case()
+    got, res, hb = rows_by_task(st, p, _hip_engine(ctx))
+    assert got[("DEL", "1")] == want
+    _compare_soa(ctx, st, p)
 
 
 def test_empty_and_ragged(ctx):
@@ -1423,3 +1433,81 @@ def test_pipelined_delivery_equals_the_serial_download(ctx, genotype):
     with pytest.raises(engine.CsvError):
         ctx.publish_async(ctx.result_buffers(pinned=False))
     assert_soa_equal(ctx.download().trimmed(), want, store=st)
+
+
+def test_position_column_as_16_bit_gaps(ctx, monkeypatch):
+    """CSV_IN_SIG_DELTA16 (ABI v8): the position column crosses the link as 16-bit gaps + the caller's escape list and is rebuilt
+    on the device (k_unpack_a16) - bit for bit what the column itself gives: every golden-shaped workload, gaps that do not fit
+    (> 65534, negative across segments, equal neighbours), 1 400 small segments (several anchors per tile), a subset of
+    non-adjacent segments, segments that begin inside a source segment, one-shot (gate-first and bulk), resident, and with the
+    reads table; a batch whose segments overlap falls back to the column itself."""
+    monkeypatch.setenv("CSV_DELTA16_MIN", "0")
+    rng = np.random.default_rng(8)
+
+    def both(pst, hb, st_plain, p, tasks=None):
+        assert hb.c.flags & _abi.IN_SIG_DELTA16 and hb.a_delta is not None
+        want = _oracle().cluster_batch(st_plain.host_batch(tasks or st_plain.tasks(), p), per_sig=True).trimmed()
+        for lazy_min in ("0", "1000000000"):
+            monkeypatch.setenv("CSV_LAZY_MIN", lazy_min)
+            got = ctx.cluster_batch(hb, per_sig=True, reuse=True).trimmed()
+            assert ctx.delta16_info()
+            assert_soa_equal(got, want, st_plain)
+        monkeypatch.delenv("CSV_LAZY_MIN")
+        ctx.upload(hb, per_sig=True)
+        assert ctx.delta16_info()
+        ctx.run(); ctx.run()
+        assert_soa_equal(ctx.download(per_sig=True).trimmed(), want, st_plain)
+        monkeypatch.setenv("CSV_NO_DELTA16", "1")
+        got = ctx.cluster_batch(hb, per_sig=True, reuse=True).trimmed()
+        assert not ctx.delta16_info()
+        assert_soa_equal(got, want, st_plain)
+        monkeypatch.delenv("CSV_NO_DELTA16")
+        return want
+
+    for seed, kw, p in ((61, dict(), Params.ont(genotype=True)), (62, dict(n_sites=80, coverage=40, n_noise=3000), Params.hifi(genotype=True, min_support=3)),
+                        (63, dict(n_sites=10, coverage=300, n_noise=50), Params.ont(min_support=3))):
+        st = synth.small_mixed(seed=seed, **kw)
+        pst = st.pinned()
+        both(pst, pst.host_batch(pst.tasks(), p), st, p)
+        sub = [t for i, t in enumerate(st.tasks()) if i % 3 != 1]          # non-adjacent segments
+        both(pst, pst.host_batch(sub, p), st, p, tasks=sub)
+    # gaps that do not fit, equal neighbours, positions near 2^31
+    n = 6000
+    pos = np.sort(np.concatenate([rng.integers(0, 2_000_000_000, 40), np.repeat(rng.integers(0, 2_000_000_000, 300), rng.integers(1, 40, 300))]))[:n]
+    per = {"DEL": [(int(x), int(50 + (i % 7)), "r%d" % (i % 977), "DEL", "1") for i, x in enumerate(pos)],
+           "INS": [(int(x) + 3, int(60 + (i % 5)), "q%d" % (i % 911), "A" * int(60 + (i % 5)), "INS", "1") for i, x in enumerate(pos)]}
+    st = SigStore.from_tuple_lists(per)
+    pst = st.pinned()
+    assert len(pst.narrow["a_delta"][1]) > 30
+    both(pst, pst.host_batch(pst.tasks(), Params.ont(min_support=3)), st, Params.ont(min_support=3))
+    # thousands of small segments: many anchors per chain tile
+    st = synth.small_mixed(seed=64, n_sites=30, coverage=20, n_contigs=24, contig_len=60_000, n_noise=2000)
+    pst = st.pinned()
+    p = Params.ont(min_support=3)
+    hb = pst.host_batch(pst.tasks(), p)
+    pieces = []
+    for sg in hb.segments:                                               # every segment cut into pieces of ~40 rows at gaps wider than the bias
+        b0, e0 = int(sg["sig_begin"]), int(sg["sig_end"])
+        cuts = [b0]
+        for i in range(b0 + 1, e0):
+            if i - cuts[-1] >= 40 and sg["svtype"] in (_abi.DEL, _abi.INS, _abi.DUP) and st.a[i] - st.a[i - 1] > sg["max_cluster_bias"]:
+                cuts.append(i)
+        cuts.append(e0)
+        for x, y in zip(cuts[:-1], cuts[1:]):
+            q = sg.copy(); q["sig_begin"], q["sig_end"] = x, y
+            pieces.append(q)
+    segs = np.array(pieces, dtype=_abi.SEGMENT_DTYPE)
+    assert len(segs) > 3 * len(hb.segments)
+    nw = pst.narrow
+    hb2 = _abi.HostBatch(segs, nw["a"], nw["b"], pst.read_id, pst.aux, n_chrom=len(pst.chroms), a_delta=nw["a_delta"])
+    plain = _abi.HostBatch(segs, st.a, st.b, st.read_id, st.aux, n_chrom=len(st.chroms))
+    want = _oracle().cluster_batch(plain, per_sig=True).trimmed()
+    got = ctx.cluster_batch(hb2, per_sig=True, reuse=True).trimmed()
+    assert ctx.delta16_info()
+    assert_soa_equal(got, want, st)
+    # overlapping segments: the library takes the column itself
+    segs2 = np.concatenate([segs[:5], segs[:5]])
+    hb3 = _abi.HostBatch(segs2, nw["a"], nw["b"], pst.read_id, pst.aux, n_chrom=len(pst.chroms), a_delta=nw["a_delta"])
+    got = ctx.cluster_batch(hb3, per_sig=True, reuse=True).trimmed()
+    assert not ctx.delta16_info()
+    assert_soa_equal(got, _oracle().cluster_batch(_abi.HostBatch(segs2, st.a, st.b, st.read_id, st.aux, n_chrom=len(st.chroms)), per_sig=True).trimmed(), st)

@@ -233,3 +233,16 @@ def test_pool_rows_of_the_split_candidates_encode_the_reference_tuples():
                 assert (aux, a, b) == (rank[x[2]] * 8 + BND_CODE[x[0]], x[1], x[3])
             n += 1
     assert n > 1000
+
+
+def test_zero_width_genotype_windows_return_calls():
+    """where the reference raises and loses the task (helpers.zero_width_window_case), the oracle - and with it the build -
+    returns the calls with the cover rule's DR: x1 (400..6000), x2 (990..1001) and x3 (1000..1000) cover (1000, 1000); x4 starts
+    behind it; the support reads do not count"""
+    from helpers import zero_width_window_case
+    from cutesv_amd import rows as rows_mod
+    from oracle import oracle
+    st, p, want = zero_width_window_case()
+    hb = st.host_batch(st.tasks(), p)
+    got = rows_mod.rows_by_segment(st, hb.segments, oracle.cluster_batch(hb, per_sig=False))
+    assert got == [want]
