@@ -818,7 +818,7 @@ def compact(out):
     h = out.get("host_to_host")
     if isinstance(h, dict):
         c["roofline"]["pcie"] = {k: _num(v) for k, v in h["pcie"].items()}
-        c["host_to_host"] = {k: _num(h.get(k)) for k in ("gate_first", "ms", "value", "slim_ms", "slim_value", "bulk_upload_ms", "pageable_columns_ms", "bytes_all_columns")}
+        c["host_to_host"] = {k: _num(h.get(k)) for k in ("gate_first", "delta16", "ms", "value", "slim_ms", "slim_value", "bulk_upload_ms", "pageable_columns_ms", "bytes_all_columns")}
         c["host_to_host"]["region"] = "page-locked host columns -> host SoA (H2D + kernels + D2H), SURVEY 8d (ii)"
     cb = out.get("cpu_baseline")
     if isinstance(cb, dict):
@@ -1078,6 +1078,7 @@ def main():
         # ---------------- the boundary as a drop-in sees it
         t_one = timed(lambda: ctx.cluster_batch(phb, reuse=True), 9)          # (caller-owned result arrays, allocated once)
         gate_first, bytes_not_sent = ctx.lazy_info()
+        delta16 = ctx.delta16_info()
         t_one_slim = timed(lambda: ctx.cluster_batch(phb, reuse=True, **SLIM), 9) if phb.a.dtype == np.int32 else None
         os.environ["CSV_NO_LAZY"] = "1"                                       # the whole columns in one piece (r04's form)
         t_one_bulk = timed(lambda: ctx.cluster_batch(phb, reuse=True), 5)
@@ -1142,7 +1143,7 @@ def main():
         down_slim = 4 * (4 + len(SLIM["fields"])) * r2.n_calls
         refine_alg = sum(kbytes.get(k, 0) for k in ("k_refine_indel_wave", "k_refine_wave", "k_refine_mid", "k_refine_block"))
         fetched_useful = (refine_alg - (4 if phb.a.dtype == np.int32 else 0) * units.get("sig_in_gated_clusters", 0)) if gate_first else 0
-        up_bulk = h2d_bytes - (bytes_not_sent if gate_first else 0)
+        up_bulk = h2d_bytes - bytes_not_sent                    # (gate-first: b / read_id / aux stay behind; CSV_IN_SIG_DELTA16: half of the position column)
 
         def pcie(ms, down):
             moved = up_bulk + fetched_useful + down
@@ -1151,7 +1152,7 @@ def main():
         host_to_host = {
             "region": "csv_cluster_batch: page-locked host columns -> kernels -> result SoA in page-locked host memory (SURVEY 8d region (ii); the "
                       "reference's timed region MAIN:1113-1199 minus the rows)",
-            "gate_first": bool(gate_first),
+            "gate_first": bool(gate_first), "delta16": bool(delta16),
             "ms": one_ms, "value": n_sig / (one_ms * 1e-3), "ms_all": [round(x * 1e3, 3) for x in t_one],
             "slim_ms": one_slim_ms, "slim_value": None if one_slim_ms is None else n_sig / (one_slim_ms * 1e-3),
             "bulk_upload_ms": one_bulk_ms, "pageable_columns_ms": float(np.min(t_one_pageable)) * 1e3,

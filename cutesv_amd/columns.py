@@ -222,7 +222,9 @@ class SigStore:
                     cols[k] = engine.pinned_copy(v)
         if "a" in narrow:
             # ... and the position column once more as 16-bit gaps (CSV_IN_SIG_DELTA16): half of the largest transfer of a call
-            narrow["a_delta"] = _abi.delta16_of(narrow["a"], alloc=engine.pinned_empty)
+            ad = _abi.delta16_of(narrow["a"], alloc=engine.pinned_empty)
+            if len(ad[1]) * 64 <= len(ad[0]) or os.environ.get("CSV_DELTA16_ESC"):      # (a sparse column is mostly escapes: the column itself travels)
+                narrow["a_delta"] = ad
         return dataclasses.replace(self, narrow=narrow or None, **cols)
 
     # ------------------------------------------------------------------ string tables for the native row / VCF emitters

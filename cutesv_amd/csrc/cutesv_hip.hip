@@ -121,6 +121,7 @@ struct csv_ctx {
     Buf tile_lead, tabs;
     Buf ad16, anc;                             // CSV_IN_SIG_DELTA16: the gaps in w space; the anchor tables {per-tile offsets, w, value}
     bool delta16 = false;                      // the last upload rebuilt its position column from gaps (csv_batch_info 2)
+    bool unpack_pending = false; UnpackArgs unpack_args{}; int unpack_tiles = 0;      // ... and k_unpack_a16 is still to be queued (one-shot calls: by the run)
     Buf cluster_id, partial, tile_cnt, item_rec, list_small, list_big, list_tiny, list_wide, seg_gate, tile_info, ch_masks, tile_items, seg_err;
     Buf item_cnt, item_base, item_chunk, sup_tmp;
     Buf t_rec, t_rec0;
@@ -581,7 +582,10 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
     // CSV_IN_SIG_DELTA16: the position column as 16-bit gaps + anchors (kernels.hip.h k_unpack_a16).  Needs disjoint segments (an
     // escape row belongs to one w): anything else takes the column itself.
     bool delta16 = sig32_ && !dev_cols && W > 0 && (in->flags & CSV_IN_SIG_DELTA16) && in->a_delta && in->a && in->n_esc >= 0 &&
-                   (in->n_esc == 0 || (in->a_esc_row && in->a_esc_val)) && !getenv("CSV_NO_DELTA16") && W >= (i64)env_int("CSV_DELTA16_MIN", 32 << 10);
+                   (in->n_esc == 0 || (in->a_esc_row && in->a_esc_val)) && !getenv("CSV_NO_DELTA16") && W >= (i64)env_int("CSV_DELTA16_MIN", 32 << 10) &&
+                   // a sparse column (sites far apart: a HiFi call set, the simulation beds) is mostly escapes: each costs the host an
+                   // anchor (search + sort: 50 k of them 1.1 ms, measured on cfg4) and saves nothing - the column itself then
+                   in->n_esc * (i64)env_int("CSV_DELTA16_ESC", 64) <= in->n_sig;
     std::vector<std::pair<i64, int>> by_begin;            // non-empty segments by their first source row
     if (delta16) {
         for (int k = 0; k < S; k++) if (c->h_woff[k + 1] > c->h_woff[k]) by_begin.emplace_back(c->h_seg[k].sig_begin, k);
@@ -800,8 +804,6 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
             h_off[ntile + 1] = (int)anc.size();
             for (size_t i = 0; i < anc.size(); i++) { h_w[i] = (int)anc[i].first; h_v[i] = anc[i].second; }
             HIP_TRY(c, hipMemcpyAsync(c->anc.p, c->h_pin + o_anc, anc_bytes, hipMemcpyHostToDevice, cs));
-            UnpackArgs UA{dp<uint16_t>(c->ad16), dp<int>(c->a32), W, dp<int>(c->anc), dp<int>(c->anc) + ntile + 2, dp<int>(c->anc) + ntile + 2 + n_anc_cap};
-            hipLaunchKernelGGL(k_unpack_a16, dim3((unsigned)ntile), dim3(256), 0, cs, UA);
         }
         HIP_TRY(c, hipEventRecord(c->ev_copy[group - 1], cs));
     }
@@ -836,6 +838,22 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
     }
     // (the main stream does not wait for the reads table: the kernels that read it are ordered behind this event)
     if (have_tab) HIP_TRY(c, hipEventRecord(c->ev_reads, sr));
+    c->unpack_pending = false;
+    if (delta16) {
+        // The position column out of its gaps (k_unpack_a16) is queued behind EVERY copy of the upload, as the first kernel of
+        // the run (a resident upload: right here).  Measured on cfg4 (80 MB of reads table on its own stream): the kernel queued
+        // between the column copies delayed the copies behind it until the reads table had left the copy engine (1.77 -> 2.82 ms);
+        // queued from here in a one-shot call, after the last copy, the launch itself blocked the host for 1.1 ms.
+        const i64 ntile = div_up(W, CH_TILE);
+        c->unpack_args = UnpackArgs{dp<uint16_t>(c->ad16), dp<int>(c->a32), W, dp<int>(c->anc), dp<int>(c->anc) + ntile + 2, dp<int>(c->anc) + ntile + 2 + n_anc_cap};
+        c->unpack_tiles = (int)ntile;
+        c->unpack_pending = true;
+        if (sync) {
+            HIP_TRY(c, hipStreamWaitEvent(st, c->ev_copy[0], 0));
+            hipLaunchKernelGGL(k_unpack_a16, dim3((unsigned)ntile), dim3(256), 0, st, c->unpack_args);
+            c->unpack_pending = false;
+        }
+    }
     c->have_tab = have_tab;
     if (sync) {
         HIP_TRY(c, hipStreamSynchronize(st)); HIP_TRY(c, hipStreamSynchronize(cs));
@@ -1031,6 +1049,10 @@ int run_impl(csv_ctx* c, csv_run_stats* stats)
         return CSV_OK;
     };
     if (c->copies_pending) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_copy[0], 0));       // positions, lengths, INV / TRA words
+    if (c->unpack_pending) {                               // CSV_IN_SIG_DELTA16: the position column out of its gaps, first kernel of the call
+        hipLaunchKernelGGL(k_unpack_a16, dim3((unsigned)c->unpack_tiles), dim3(256), 0, st, c->unpack_args);
+        c->unpack_pending = false;
+    }
     // A run decides what it launches from what IT knows - nothing is carried over from earlier runs of the upload (r05 skipped
     // the tiers above 64 signatures when an earlier, identical run had found them empty: state only a benchmark loop has).  In
     // a one-shot call the column copies are still on the link when the chain kernels are queued, so the host can wait for

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A/B of the one-shot boundary call on the GPU box: python scripts/oneshot_ab.py [cfg3 cfg4 cfg5 ...]
+"""A/B of the one-shot boundary call on the GPU box: python scripts/oneshot_ab.py [cfg3 cfg4 cfg5 ...] [only=label,label]
 csv_cluster_batch from page-locked columns to page-locked results: bulk upload vs the gate-first form, full vs slim results."""
 import os
 import sys
@@ -14,15 +14,20 @@ from cutesv_amd import engine                             # noqa: E402
 
 SLIM = dict(no_support=True, coord32=True, fields=("call_aux", "cipos", "cilen", "seq_pick", "dr", "gl_idx"))
 ctx = engine.Context(0)
-for wl in (sys.argv[1:] or ["cfg3"]):
+ONLY = [x[5:].split(",") for x in sys.argv[1:] if x.startswith("only=")]
+ONLY = ONLY[0] if ONLY else None
+for wl in ([x for x in sys.argv[1:] if not x.startswith("only=")] or ["cfg3"]):
     store, params, name = bench.make_workload(wl, 1.0, 0)
     pst = store.pinned()
     phb = pst.host_batch(pst.tasks(), params)
     n = phb.n_sig
-    for label, env, kw in (("bulk/full", {"CSV_NO_LAZY": "1"}, {}), ("gate-first/full", {}, {}), ("bulk/slim", {"CSV_NO_LAZY": "1"}, SLIM),
-                           ("gate-first/nosup", {}, dict(no_support=True)), ("gate-first/slim", {}, SLIM),
-                           ("gf/slim/copystream", {"CSV_COPY_STREAM": "1"}, SLIM), ("gate-first/slim", {}, SLIM)):
-        for k in ("CSV_NO_LAZY", "CSV_COPY_STREAM"):
+    for label, env, kw in (("bulk/full/no-delta16", {"CSV_NO_LAZY": "1", "CSV_NO_DELTA16": "1"}, {}), ("bulk/full", {"CSV_NO_LAZY": "1"}, {}),
+                           ("gate-first/full/no-delta16", {"CSV_NO_DELTA16": "1"}, {}), ("gate-first/full", {}, {}),
+                           ("gate-first/slim/no-delta16", {"CSV_NO_DELTA16": "1"}, SLIM), ("gate-first/slim", {}, SLIM),
+                           ("gate-first/full/no-peek", {"CSV_NO_PEEK": "1"}, {}), ("gate-first/full", {}, {})):
+        if ONLY is not None and label not in ONLY:
+            continue
+        for k in ("CSV_NO_LAZY", "CSV_COPY_STREAM", "CSV_NO_DELTA16", "CSV_NO_PEEK"):
             os.environ.pop(k, None)
         os.environ.update(env)
         ctx._res_cache = None
@@ -33,6 +38,6 @@ for wl in (sys.argv[1:] or ["cfg3"]):
             ts.append((time.perf_counter() - t0) * 1e3)
         lazy, saved = ctx.lazy_info()
         ts = ts[2:]
-        print("%s %-18s min %.3f med %.3f ms  (%.2e sig/s)  lazy=%d bytes_not_sent=%.1f MB calls=%d" %
-              (wl, label, min(ts), float(np.median(ts)), n / (min(ts) * 1e-3), lazy, saved / 1e6, r.n_calls), flush=True)
+        print("%s %-28s min %.3f med %.3f ms  (%.2e sig/s)  lazy=%d delta16=%d bytes_not_sent=%.1f MB calls=%d" %
+              (wl, label, min(ts), float(np.median(ts)), n / (min(ts) * 1e-3), lazy, ctx.delta16_info(), saved / 1e6, r.n_calls), flush=True)
 ctx.close()
