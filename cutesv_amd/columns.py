@@ -152,6 +152,37 @@ def _sparse_blob(table, picks, n=None):
     return blob, off
 
 
+def _reads_near(pos1, pos2, r_start, r_end, margin, shift=10):
+    """Which reads of a chromosome's block can matter to ONE task's genotyping?  A call's window is [p - h, p + h] around a
+    point p that lies inside the span of its cluster's positions (a member's position for DEL / INS - INDEL:177, 399-403, 450-451 -
+    a mean of member positions for DUP / INV, for either coordinate - DUP:99-109, 146-151; INV:129-130, 218-221) with h <=
+    `margin`; neighbouring members of a cluster are at most max_cluster_bias <= margin apart (the chain and sub-cluster rules),
+    so every window lies inside the union of [x - margin, x + margin] over the task's signature coordinates x.  A read that COVERS
+    a window (start <= L and end >= R, GT:95-159) contains it, hence intersects that union.  The union is kept as a bit per
+    1024-bp bin; a read stays iff a marked bin lies in [start, end].  Everything else in the block - 90 % and more of a genome's
+    reads for a 30x call set - is never interned, never uploaded and never sorted.  -> bool mask, or None (keep all)."""
+    n = len(pos1)
+    if n == 0 or len(r_start) == 0:
+        return None
+    xs = pos1 if pos2 is None else np.concatenate([pos1, pos2])
+    hi = int(max(int(xs.max()), int(r_end.max()))) + margin + (2 << shift)
+    lo_ok = int(xs.min()) >= 0 and int(r_start.min()) >= 0
+    if not lo_ok or hi >= (1 << 40):
+        return None
+    nb = (hi >> shift) + 2
+    lo_b = np.maximum(xs - margin, 0) >> shift
+    hi_b = (xs + margin) >> shift
+    d = np.zeros(nb + 1, np.int64)                           # +1 at the first bin of a marked range, -1 behind its last
+    np.add.at(d, lo_b, 1)
+    np.add.at(d, hi_b + 1, -1)
+    marked = np.cumsum(d[:-1]) > 0
+    cum = np.zeros(nb + 1, np.int64)
+    np.cumsum(marked, out=cum[1:])
+    rb0 = np.minimum(r_start >> shift, nb - 1)
+    rb1 = np.minimum(np.maximum(r_end, r_start) >> shift, nb - 1)
+    return (cum[rb1 + 1] - cum[rb0]) > 0
+
+
 @dataclass
 class SigStore:
     chroms: list                                  # chromosome names; index = chrom id (also the chr2 rank for TRA)
@@ -519,12 +550,14 @@ class SigStore:
                    names=NameTable(uniq), ins_seq=ins_seq if svtype == "INS" else {}, strands=strands, **kw)
 
     @classmethod
-    def from_task_pickles(cls, svtype, chrom, sig_buf, sig_off, reads_buf=None, reads_off=None):
+    def from_task_pickles(cls, svtype, chrom, sig_buf, sig_off, reads_buf=None, reads_off=None, gt_margin=None):
         """from_task_lists without the lists: the task's pickle (and its chromosome's reads pickle) walked in C straight out of
         the mapped files (`_cols_native.pickle_table`): integer fields into the columns, strings as spans of the file - the
         read names interned by their bytes, the inserted sequences never touched unless a call picks one.  The 110 862
         signatures of INS chr2: ~6 ms instead of 21-24 ms of pickle.load + 5 ms over its objects.  Returns None when the
-        stream holds anything pickle_table does not know (the caller unpickles then)."""
+        stream holds anything pickle_table does not know (the caller unpickles then).
+        gt_margin (the task's genotyping half-window: max_cluster_bias, 1000 for INS - INDEL:450-451, DUP:146-151, INV:218-221):
+        only the reads that can cover a window of THIS task are kept - see _reads_near."""
         from . import _cols_native as cn                     # (built by the same make as the library; no Python fallback)
         ints, strs, width = {"DEL": ((0, 1), (2,), 5), "DUP": ((0, 1), (2,), 5), "INS": ((0, 1), (2, 3), 6),
                              "INV": ((1, 2), (0, 3), 6), "TRA": ((1, 3), (0, 2, 4), 7)}[svtype]
@@ -572,6 +605,14 @@ class SigStore:
         if nr:
             r_start, r_end, r_primary = (np.frombuffer(x, np.int64) for x in rt[2])
             rsp = [(np.frombuffer(o, np.int64), np.frombuffer(l, np.int32)) for o, l in rt[3]]
+            if gt_margin is not None and n:
+                keep = _reads_near(a, b if svtype in ("DUP", "INV") else None, r_start, r_end, int(gt_margin))
+                if keep is not None:
+                    if not keep.any():
+                        keep[0] = True                      # (a block with reads stays a block with reads: DR = 0, not "no reads block")
+                    r_start, r_end, r_primary = r_start[keep], r_end[keep], r_primary[keep]
+                    rsp = [(o[keep], l[keep]) for o, l in rsp]
+                    nr = len(r_start)
             r_id = np.empty(nr, np.int32)
             spec.append((reads_buf, rsp[0][0], rsp[0][1], r_id))
             rd, r_chr = small(reads_buf, rsp[1])
@@ -588,9 +629,18 @@ class SigStore:
             aux = clut[c_id] * 8 + tlut[t_id]
         if nr:
             rc = np.array([crank[c] for c in rd], np.int64)[r_chr]
-            o = np.argsort(rc, kind="stable")
-            kw = dict(reads_off=np.searchsorted(rc[o], np.arange(len(chroms) + 1)).astype(np.int64),
-                      r_start=r_start[o], r_end=r_end[o], r_primary=r_primary[o].astype(np.uint8), r_id=r_id[o])
+            if len(rd) == 1:                                # (the usual block: one chromosome - nothing to regroup)
+                kw = dict(reads_off=np.array([0, nr] if crank[rd[0]] == 0 else [0] * (crank[rd[0]] + 1) + [nr] * (len(chroms) - crank[rd[0]]), np.int64),
+                          r_start=r_start, r_end=r_end, r_primary=r_primary.astype(np.uint8), r_id=r_id)
+            else:
+                o = np.argsort(rc, kind="stable")
+                kw = dict(reads_off=np.searchsorted(rc[o], np.arange(len(chroms) + 1)).astype(np.int64),
+                          r_start=r_start[o], r_end=r_end[o], r_primary=r_primary[o].astype(np.uint8), r_id=r_id[o])
+        elif reads_buf is not None and int(rt[0]) > 0:
+            # every read of the block was out of reach of the task's windows: an empty block, still a reads table (a task
+            # WITHOUT a reads block loses its calls, INDEL:443-444; one whose reads cover nothing keeps them with DR = 0)
+            kw = dict(reads_off=np.zeros(len(chroms) + 1, np.int64), r_start=np.zeros(0, np.int64), r_end=np.zeros(0, np.int64),
+                      r_primary=np.zeros(0, np.uint8), r_id=np.zeros(0, np.int32))
         return cls(chroms=chroms, a=a, b=b, read_id=rid, aux=aux, seg_index={(svtype, chrom): (0, n)} if n else {},
                    names=NameTable(uniq), ins_seq=ins_seq if svtype == "INS" else {}, strands=strands, **kw)
 

@@ -163,7 +163,7 @@ def _mapped(path):
         return None
 
 
-def _store_for(work_dir, sigs_index, svtype, chrom, need_reads):
+def _store_for(work_dir, sigs_index, svtype, chrom, need_reads, gt_margin=None):
     """Signatures of ONE task as flat columns: the mmap'ed `<work_dir>cutesv_amd.cols/` if our rebuild step wrote it
     (shared by every task of the process), otherwise just this task's pickled list - and, when it genotypes, its
     chromosome's reads block - converted from the reference's files (main script :817-857).  A pool worker therefore
@@ -183,7 +183,8 @@ def _store_for(work_dir, sigs_index, svtype, chrom, need_reads):
         reads_map = _mapped("%sreads.pickle" % work_dir) if want_reads else None
         if sig_map is not None and (reads_map is not None or not want_reads):
             st = SigStore.from_task_pickles(svtype, chrom, sig_map, sigs_index[svtype][chrom],
-                                            reads_map, sigs_index["reads"][chrom] if want_reads else None)
+                                            reads_map, sigs_index["reads"][chrom] if want_reads else None,
+                                            gt_margin=None if os.environ.get("CUTESV_AMD_ALL_READS") else gt_margin)
             if st is not None:
                 return st
     with open("%s%s.pickle" % (work_dir, svtype), "rb") as f:
@@ -269,14 +270,14 @@ def _cluster_stage_lazy(store, segs, tasks, ctx):
     return results
 
 
-def _one(work_dir, chrom, svtype, sigs_index, seg_of_store, need_reads=False):
+def _one(work_dir, chrom, svtype, sigs_index, seg_of_store, need_reads=False, gt_margin=None):
     if chrom not in sigs_index.get(svtype, {}):       # INDEL:44-45, DUP:19-20, INV:33-34, TRA:31-32
         return (chrom, [])
     if not work_dir.endswith("/"):
         work_dir += "/"                               # (main_ctrl normalises it, main script :993-996)
     tl = os.environ.get("CUTESV_AMD_TIMELINE")        # (a directory: one line per task with its phases' clock readings)
     t0 = time.time() if tl else 0.0
-    store = _store_for(work_dir, sigs_index, svtype, chrom, need_reads)
+    store = _store_for(work_dir, sigs_index, svtype, chrom, need_reads, gt_margin)
     if (svtype, chrom) not in store.seg_index:
         return (chrom, [])
     seg = seg_of_store(store)
@@ -299,7 +300,7 @@ def _indel(args, svtype):
                                  diff_ratio=threshold_gloab, remain_reads_ratio=remain_reads_ratio,
                                  gt_bias=max_cluster_bias if svtype == "DEL" else 1000,       # INDEL:103 / :312
                                  min_support_reads=minimum_support_reads, genotype=bool(action))
-    return _one(path, chrom, svtype, sigs_index, seg, need_reads=bool(action))
+    return _one(path, chrom, svtype, sigs_index, seg, need_reads=bool(action), gt_margin=max_cluster_bias if svtype == "DEL" else 1000)
 
 
 def run_del(args):
@@ -317,7 +318,7 @@ def run_inv(args):
         beg, end = store.seg_index[("INV", chrom)]
         return _abi.make_segment("INV", store.chroms.index(chrom), beg, end, max_cluster_bias, read_count,
                                  sv_size=sv_size, max_size=MaxSize, gt_bias=max_cluster_bias, genotype=bool(action))
-    return _one(path, chrom, "INV", sigs_index, seg, need_reads=bool(action))
+    return _one(path, chrom, "INV", sigs_index, seg, need_reads=bool(action), gt_margin=max_cluster_bias)
 
 
 def run_dup(args):
@@ -327,7 +328,7 @@ def run_dup(args):
         beg, end = store.seg_index[("DUP", chrom)]
         return _abi.make_segment("DUP", store.chroms.index(chrom), beg, end, max_cluster_bias, read_count,
                                  sv_size=sv_size, max_size=MaxSize, gt_bias=max_cluster_bias, genotype=bool(action))
-    return _one(path, chrom, "DUP", sigs_index, seg, need_reads=bool(action))
+    return _one(path, chrom, "DUP", sigs_index, seg, need_reads=bool(action), gt_margin=max_cluster_bias)
 
 
 _warned_tra = False

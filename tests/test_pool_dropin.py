@@ -267,3 +267,63 @@ def test_forked_pool_stage_on_one_device(tmp_path, cfg, threads, mode):
         assert r["broker"]["engine"] == "libcutesv_hip.so" and r["broker"]["pid"] not in r["worker_pids"] + [r["parent_pid"]]
         assert r["broker"]["calls"] >= r["tasks"] - 1
     assert r["leftover_brokers"] == 0
+
+
+class _OracleCtx:
+    """stands in for the engine where only csv_cluster_batch's result matters (the task-store side is host code)"""
+
+    def cluster_batch(self, hb, reuse=False, **kw):
+        from oracle import oracle
+        return oracle.cluster_batch(hb, per_sig=False)
+
+
+def test_a_task_keeps_only_the_reads_that_can_reach_its_windows(tmp_path, monkeypatch):
+    """SigStore.from_task_pickles(gt_margin=...) drops the reads of the chromosome's block that cannot cover any genotyping
+    window of the task (columns._reads_near): the rows - DR, GT, PL, GQ, QUAL of every call, all types - must equal the rows
+    from the whole block, and most of the block must be gone on a genome-like layout"""
+    from cutesv_amd.columns import SigStore
+    monkeypatch.setattr(resolve, "_ctx", _OracleCtx())
+    monkeypatch.setattr(resolve, "_ctx_pid", None)
+    monkeypatch.setenv("CUTESV_AMD_TRA_GT", "off")
+    kept_share = []
+    for seed, kw, p in ((201, dict(n_sites=40, coverage=30, contig_len=3_000_000, n_contigs=2, n_noise=40), Params.ont(genotype=True, min_support=3)),
+                        (202, dict(n_sites=25, coverage=20, contig_len=2_000_000, n_contigs=3, n_noise=200, n_loci=10), Params.hifi(genotype=True, min_support=3)),
+                        (203, dict(n_sites=60, coverage=12, contig_len=800_000, n_contigs=2), Params(genotype=True, min_support=2, max_cluster_bias_DEL=50, max_cluster_bias_INV=2000))):
+        st = synth.small_mixed(seed=seed, genotype=True, **kw)
+        wd = str(tmp_path / ("w%d" % seed)) + "/"
+        os.makedirs(wd)
+        idx = st.write_reference_workdir(wd)
+
+        def stage():
+            out = {}
+            for t, c in st.tasks():
+                if t == "DEL":
+                    r = resolve.run_del((wd, c, "DEL", p.min_support, p.diff_ratio_merging_DEL, p.max_cluster_bias_DEL, min(p.min_support, 5), "bam", True, p.gt_round, p.remain_reads_ratio, idx))
+                elif t == "INS":
+                    r = resolve.run_ins((wd, c, "INS", p.min_support, p.diff_ratio_merging_INS, p.max_cluster_bias_INS, min(p.min_support, 5), "bam", True, p.gt_round, p.remain_reads_ratio, idx))
+                elif t == "INV":
+                    r = resolve.run_inv((wd, c, "INV", p.min_support, p.max_cluster_bias_INV, p.min_size, "bam", True, p.max_size, p.gt_round, idx))
+                elif t == "DUP":
+                    r = resolve.run_dup((wd, c, p.min_support, p.max_cluster_bias_DUP, p.min_size, "bam", True, p.max_size, p.gt_round, idx))
+                else:
+                    continue
+                out[(t, c)] = [helpers_canonical(t, x) for x in r[1]]
+            return out
+        near = stage()
+        monkeypatch.setenv("CUTESV_AMD_ALL_READS", "1")
+        whole = stage()
+        monkeypatch.delenv("CUTESV_AMD_ALL_READS")
+        assert near == whole and sum(len(v) for v in near.values()) > 20
+        assert any(row[7] not in (".", "0") for rows in near.values() for row in rows if row[1] in ("DEL", "INS"))      # some DR > 0: reads do cover
+        for t, c in st.tasks():
+            if t in ("DEL", "INS"):
+                m = resolve._mapped(wd + t + ".pickle"), resolve._mapped(wd + "reads.pickle")
+                a = SigStore.from_task_pickles(t, c, m[0], idx[t][c], m[1], idx["reads"][c], gt_margin=1000)
+                b = SigStore.from_task_pickles(t, c, m[0], idx[t][c], m[1], idx["reads"][c])
+                kept_share.append(a.n_reads / max(1, b.n_reads))
+    assert min(kept_share) < 0.5, kept_share
+
+
+def helpers_canonical(t, row):
+    from helpers import canonical_row
+    return canonical_row(t, row)
