@@ -155,7 +155,7 @@ struct csv_ctx {
     struct RunOpts {
         bool debug = false, debug_counters = false, no_fork = false, fork_always = false, no_swap = false, no_peek = false;
         bool no_pair_in_mid = false, no_publish = false;
-        int  iw_grid = 0, gt_grid = 0, tier_fork_min = 4 << 20;
+        int  iw_grid = 0, gt_grid = 0, tier_fork_min = 4 << 20, mid_grid = 0, big_grid = 0;
     } opt;
     volatile int* h_flag = nullptr;
     int*          d_flag = nullptr;
@@ -270,6 +270,8 @@ void load_run_opts(csv_ctx* c)
     o.iw_grid = env_int("CSV_IW_GRID", 0);
     o.gt_grid = env_int("CSV_GT_GRID", 0);
     o.tier_fork_min = env_int("CSV_TIER_FORK_MIN", 4 << 20);
+    o.mid_grid = env_int("CSV_MID_GRID", 0);
+    o.big_grid = env_int("CSV_BIG_GRID", 0);
 }
 
 int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sync, bool lazy_ok);
@@ -1133,9 +1135,10 @@ int run_impl(csv_ctx* c, csv_run_stats* stats)
         else LAUNCH("refine_indel_wave", k_refine_indel_wave<false>, g_iw, 256, 0, B);
         if (c->any_pair && !B.pair_in_mid) LAUNCH_ON(sC, "refine_wave", (k_refine<64, 64, false>), g_small, 64, LDS_SMALL, B, 0, 64);
         else HIP_TRY(c, mark());
-        int g_mid = B.cap_items < 8192 ? B.cap_items : 8192;
+        const int mid_cap = O.mid_grid > 0 ? O.mid_grid : 8192, big_cap = O.big_grid > 0 ? O.big_grid : 512;
+        int g_mid = B.cap_items < mid_cap ? B.cap_items : mid_cap;
         if (g_mid < 1) g_mid = 1;
-        int g_big = B.cap_items < 512 ? B.cap_items : 512;
+        int g_big = B.cap_items < big_cap ? B.cap_items : big_cap;
         if (g_big < 1) g_big = 1;
         if (need_big) {
             LAUNCH_ON(sB, "refine_mid", (k_refine<64, 256, true>), g_mid, 64, LDS_MID, B, 64, MID_CAP);

@@ -1,15 +1,20 @@
 #!/bin/bash
 # Round-end evidence on the GPU box (through gpurun): tests, profiles (kernel trace + calibrated PMC traffic), every bench line,
 # the N-ranks-on-one-device rehearsal and a stress campaign.  scripts/round_end.sh r04   -> gpurun_out/final/
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
 F=$R/gpurun_out/final; mkdir -p $F
 timeout -k 10 900 python -m pytest tests -m gpu -x -q > $F/${TAG}_pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -2 $F/${TAG}_pytest_gpu.log
 for wl in cfg3 cfg5; do scripts/profile_insts.sh $wl $TAG > $F/${TAG}_${wl}_insts.log 2>&1; done
 scripts/refresh_profiles.sh $TAG "cfg3 cfg4 cfg5" > $F/${TAG}_refresh.log 2>&1
+# the drop-in under the reference's forked pool (bench_stage.py, a process of its own) and where its wall time goes
+for wl in cfg3 cfg4; do timeout 600 python bench_stage.py --workload $wl > $F/${TAG}_stage_${wl}.json 2> $F/${TAG}_stage_${wl}.log; done
+timeout 300 python scripts/stage_timeline.py --workload cfg4 --workers 1,8,32 2>/dev/null | grep -v "^\[" > $F/${TAG}_stage_timeline_cfg4_pickles.txt
+timeout 300 python scripts/stage_timeline.py --workload cfg4 --workers 1,8,32 --cols 2>/dev/null | grep -v "^\[" > $F/${TAG}_stage_timeline_cfg4_cols.txt
 timeout 300 python bench.py --workload rebuild > $F/${TAG}_bench_rebuild.json 2>/dev/null
 timeout 300 python bench.py --workload extract > $F/${TAG}_bench_extract.json 2>/dev/null
 timeout 600 python bench.py --full --gpus 8 --steps 10 --warmup 2 > $F/${TAG}_bench_cfg3_replica_plus_cfg4_sharded_8ranks_one_device.json 2>/dev/null; echo "8 ranks rc=$?"
+timeout 600 python bench.py --full --workload cfg5 --mode shard --gpus 8 --steps 5 --warmup 2 > $F/${TAG}_bench_cfg5_sharded_8ranks_one_device.json 2>/dev/null; echo "cfg5 8 ranks rc=$?"
 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --full --gpus 2 --steps 5 --warmup 2 2>/dev/null | tail -1 > $F/${TAG}_bench_torchrun_2ranks_one_device.json; echo "torchrun rc=$?"
 timeout 700 python scripts/stress_gpu.py ${STRESS_N:-30000} 1200000 > $F/${TAG}_stress.log 2>&1; tail -2 $F/${TAG}_stress.log
 timeout 300 python scripts/stress_gpu.py ${STRESS_BIG:-3000} 1300000 big > $F/${TAG}_stress_big.log 2>&1; tail -2 $F/${TAG}_stress_big.log

@@ -56,6 +56,14 @@ for it in range(n_it):
             lo, hi = int(st.reads_off[c]), int(st.reads_off[c + 1])
             perm[lo:hi] = lo + rng.permutation(hi - lo)
         st = dataclasses.replace(st, r_start=st.r_start[perm], r_end=st.r_end[perm], r_primary=st.r_primary[perm], r_id=st.r_id[perm])
+    # (r06) the position column as 16-bit gaps for two pinned runs in three - whatever the share of escapes and the batch size -
+    # and the same-run tier peek of the one-shot calls on or off
+    os.environ["CSV_DELTA16_ESC"] = "0"
+    os.environ["CSV_DELTA16_MIN"] = "0" if rng.integers(0, 3) else "1000000000"
+    if rng.integers(0, 4) == 0:
+        os.environ["CSV_NO_PEEK"] = "1"
+    else:
+        os.environ.pop("CSV_NO_PEEK", None)
     if rng.integers(0, 2) == 0:
         st = st.pinned()                                  # page-locked columns, int32 twins of the positions / lengths (half of the runs)
     hb = st.host_batch(tasks, p)
