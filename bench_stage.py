@@ -54,31 +54,46 @@ def _stage(wd, idx, params, T, fns=None):
     return time.perf_counter() - t0, res
 
 
+def _devices():
+    return resolve.device_list() or [resolve.device_index()]
+
+
 def _broker_info(shutdown=False):
+    """report of the first device's broker (None if any device's broker is missing); shutdown=True stops them all"""
+    first = None
     try:
-        with broker.Client.connect(resolve.device_index(), owner_pid=os.getpid(), spawn=False) as cl:
-            info = cl.info()
-            if shutdown:
-                cl.shutdown()
-        return info
+        for d in _devices():
+            with broker.Client.connect(d, owner_pid=os.getpid(), spawn=False) as cl:
+                info = cl.info()
+                first = first or info
+                if first is not info:
+                    for k in ("calls", "batches", "merged_calls", "busy_s", "maps"):
+                        first[k] = first.get(k, 0) + info.get(k, 0)
+                if shutdown:
+                    cl.shutdown()
+        return first
     except broker.BrokerError:
         return None
 
 
 def _wait_gone(timeout=20.0):
     t_end = time.monotonic() + timeout
-    name = broker.socket_name(os.getpid(), resolve.device_index())
-    while broker._try_connect(name) is not None and time.monotonic() < t_end:
-        time.sleep(0.02)
+    for d in _devices():
+        name = broker.socket_name(os.getpid(), d)
+        while broker._try_connect(name) is not None and time.monotonic() < t_end:
+            time.sleep(0.02)
 
 
-def mode1_stage(name, store, params, workers=(1, 8, 32), reference=True, cold_and_direct_at=8, reps=2, keep_dir=None, log=None, cols_leg=True):
-    """-> dict for the bench line.  Must run before this process holds any HIP state (the pools fork)."""
+def mode1_stage(name, store, params, workers=(1, 8, 32), reference=True, cold_and_direct_at=8, reps=2, keep_dir=None, log=None, cols_leg=True, devices=1):
+    """-> dict for the bench line.  Must run before this process holds any HIP state (the pools fork).
+    devices > 1: the pool's workers share that many GPUs (CUTESV_AMD_DEVICES), one broker each."""
+    if devices and int(devices) > 1:
+        os.environ["CUTESV_AMD_DEVICES"] = str(int(devices))
     from oracle import py_restatement as pr                       # (the CPU baseline of this leg)
     say = log or (lambda s: sys.stderr.write("[mode1_stage %s] %s\n" % (name, s)))
     wd = (keep_dir or tempfile.mkdtemp(prefix="cutesv_amd_stage_")) + "/"
     os.makedirs(wd, exist_ok=True)
-    out = {"workload": name, "signatures": int(store.n_sig), "reads": int(store.n_reads),
+    out = {"workload": name, "signatures": int(store.n_sig), "reads": int(store.n_reads), "devices": len(_devices()),
            "region": "Pool(processes=T) -> one map_async(run_X, [tuple]) per (chr, type) on the reference's pickles -> merged results dict "
                      "(main script :1113-1199); pickles written outside the timed region"}
     try:
@@ -163,6 +178,7 @@ def mode1_stage(name, store, params, workers=(1, 8, 32), reference=True, cold_an
                                          "rows": rows_digest(res)[0]}
             say("drop-in context per worker T=%d: %s ms" % (T, out["context_per_worker"]["wall_ms_all"]))
     finally:
+        os.environ.pop("CUTESV_AMD_DEVICES", None) if devices and int(devices) > 1 else None
         os.environ.pop("CUTESV_AMD_BROKER", None)
         os.environ.pop("CUTESV_AMD_BROKER_NAME", None)
         if keep_dir is None:
@@ -193,11 +209,12 @@ def main():
     ap.add_argument("--no-reference", action="store_true")
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--keep-dir", default=None)
+    ap.add_argument("--devices", type=int, default=1, help="GPUs the pool's workers share (one broker each)")
     a = ap.parse_args()
     import bench
     store, params, wl = bench.make_workload(a.workload, a.scale, 0)
     m = mode1_stage(a.workload, store, params, workers=tuple(int(x) for x in a.workers.split(",")), reference=not a.no_reference,
-                    reps=a.reps, keep_dir=a.keep_dir)
+                    reps=a.reps, keep_dir=a.keep_dir, devices=a.devices)
     print(json.dumps(m))
 
 
