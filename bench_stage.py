@@ -49,6 +49,15 @@ def rows_digest(results):
 
 
 def _stage(wd, idx, params, T, fns=None):
+    if fns is None:
+        # a timed stage starts with an empty broker: the walked reads blocks its workers share (the second task of a chromosome
+        # finds what the first one left) must be ITS OWN, not those of the repetition before
+        try:
+            for d in _devices():
+                with broker.Client.connect(d, owner_pid=os.getpid(), spawn=False) as cl:
+                    cl.reads_flush()
+        except broker.BrokerError:
+            pass
     t0 = time.perf_counter()
     res = resolve.main_ctrl_phase3(wd, idx, params, T, fns=fns)
     return time.perf_counter() - t0, res

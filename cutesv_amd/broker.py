@@ -36,7 +36,7 @@ from . import _abi
 
 MAGIC = 0x42565343                                   # "CSVB"
 HDR = struct.Struct("<IIQ")                          # magic, kind, payload bytes
-K_MAP, K_CALL, K_INFO, K_SHUTDOWN, K_REPLY, K_STATS = 1, 2, 3, 4, 5, 6
+K_MAP, K_CALL, K_INFO, K_SHUTDOWN, K_REPLY, K_STATS, K_PUT, K_GET, K_FLUSH = 1, 2, 3, 4, 5, 6, 7, 8, 9
 REPLY = struct.Struct("<iqqqqq")                     # rc, cap_calls, cap_support, n_calls, n_support, n_clusters  (+ error text)
 ALIGN = 256
 
@@ -207,6 +207,47 @@ class Client:
 
     def shutdown(self):
         self._request(K_SHUTDOWN)
+
+    # ---- a chromosome's walked reads block, shared between the pool's workers (columns.WalkedReads)
+    def reads_get(self, key):
+        """the block another worker walked and left with the broker, or None"""
+        from .columns import WalkedReads
+        try:
+            _send_msg(self.sock, K_GET, repr(key).encode())
+            k, data, fds = _recv_msg(self.sock)
+        except (OSError, EOFError) as e:
+            raise BrokerError("the GPU broker %r went away (%s); there is no CPU path" % (self.name, e)) from e
+        if k != K_REPLY or not fds:
+            for fd in fds:
+                os.close(fd)
+            return None
+        try:
+            size = struct.unpack("<Q", data[:8])[0]
+            mm = mmap.mmap(fds[0], size, prot=mmap.PROT_READ)
+            return WalkedReads.from_buffer(mm)             # (the arrays keep the mapping alive)
+        except (OSError, ValueError):
+            return None
+        finally:
+            for fd in fds:
+                os.close(fd)
+
+    def reads_flush(self):
+        """forget every walked block (bench_stage.py: a timed stage must not find the blocks of the one before)"""
+        self._request(K_FLUSH)
+
+    def reads_put(self, key, wr):
+        """leave a walked block with the broker (an anonymous shared-memory file; the broker only keeps the descriptor)"""
+        size = wr.nbytes()
+        fd = os.memfd_create("cutesv_amd_reads", 0)
+        try:
+            os.ftruncate(fd, size)
+            with mmap.mmap(fd, size) as mm:
+                wr.write_into(mm)
+            self._request(K_PUT, struct.pack("<Q", size) + repr(key).encode(), fds=(fd,))
+        except OSError:
+            pass                                          # (a cache: failing to share a block loses nothing but time)
+        finally:
+            os.close(fd)
 
     # ---- the call
     def _ensure(self, need):
@@ -406,6 +447,9 @@ class Broker:
         self.conns = {}
         self.stats = dict(calls=0, batches=0, merged_calls=0, maps=0, max_batch=0, busy_s=0.0)
         self._stage = None
+        self.blocks = {}                              # walked reads blocks the workers share: key -> (memfd, bytes)
+        self.block_bytes = 0
+        self.block_cap = int(os.environ.get("CUTESV_AMD_BROKER_BLOCKS_MB", "8192")) << 20
         self._pool = None
         self._copy_threads = int(os.environ.get("CUTESV_AMD_BROKER_COPY_THREADS", "8"))
         self._engine_factory = engine_factory
@@ -688,6 +732,32 @@ class Broker:
                 self._reply(conn, _abi.E_INVALID, None, "broker: a request whose pointers do not lie in its shared region")
             else:
                 pend.append(p)
+        elif kind == K_PUT:
+            try:
+                size = struct.unpack("<Q", payload[:8])[0]
+                key = payload[8:]
+                if fds and key not in self.blocks and self.block_bytes + size <= self.block_cap:
+                    self.blocks[key] = (fds[0], size)
+                    self.block_bytes += size
+                    fds = fds[1:]
+                    self.stats["blocks"] = len(self.blocks)
+            finally:
+                for fd in fds:
+                    os.close(fd)
+            self._reply(conn, _abi.OK)
+        elif kind == K_FLUSH:
+            self._forget_blocks()
+            self._reply(conn, _abi.OK)
+        elif kind == K_GET:
+            ent = self.blocks.get(payload)
+            try:
+                if ent is None:
+                    _send_msg(s, K_REPLY, b"")
+                else:
+                    self.stats["block_hits"] = self.stats.get("block_hits", 0) + 1
+                    _send_msg(s, K_REPLY, struct.pack("<Q", ent[1]), fds=(ent[0],))
+            except OSError:
+                self._drop(conn)
         elif kind == K_INFO:
             d = dict(self.stats, pid=os.getpid(), device=self.device, name=self.name, clients=len(self.conns),
                      engine_start_s=self._ready_s, **self.engine().describe())
@@ -737,9 +807,19 @@ class Broker:
             if self.conns:
                 idle_since = time.monotonic()
 
+    def _forget_blocks(self):
+        for fd, _ in self.blocks.values():
+            try:
+                os.close(fd)
+            except OSError:
+                pass
+        self.blocks, self.block_bytes = {}, 0
+        self.stats["blocks"] = 0
+
     def close(self):
         for c in list(self.conns.values()):
             self._drop(c)
+        self._forget_blocks()
         self.listener.close()
         if self._engine is not None:
             self._engine.close()

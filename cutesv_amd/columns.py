@@ -152,6 +152,45 @@ def _sparse_blob(table, picks, n=None):
     return blob, off
 
 
+class WalkedReads:
+    """A chromosome's reads block (main script :733: (start, end, is_primary, read, chr) per row) as `pickle_table` leaves it:
+    three integer columns and the (offset, length) spans of the two strings inside the mapped `reads.pickle`.  Flat arrays only,
+    so that one worker's walk can be handed to the others through shared memory (`to_bytes_views` / `from_buffer`)."""
+    FIELDS = (("start", np.int64), ("end", np.int64), ("primary", np.int64), ("name_off", np.int64), ("name_len", np.int32),
+              ("chr_off", np.int64), ("chr_len", np.int32))
+
+    def __init__(self, n, **cols):
+        self.n = int(n)
+        for k, _ in self.FIELDS:
+            setattr(self, k, cols[k])
+
+    @classmethod
+    def from_table(cls, rt):
+        ints = [np.frombuffer(x, np.int64) for x in rt[2]]
+        sp = [(np.frombuffer(o, np.int64), np.frombuffer(l, np.int32)) for o, l in rt[3]]
+        return cls(int(rt[0]), start=ints[0], end=ints[1], primary=ints[2], name_off=sp[0][0], name_len=sp[0][1], chr_off=sp[1][0], chr_len=sp[1][1])
+
+    def nbytes(self):
+        return 64 + sum((self.n * np.dtype(dt).itemsize + 63) // 64 * 64 for _, dt in self.FIELDS)
+
+    def write_into(self, buf):
+        """lay the columns out in `buf` (a writable buffer of nbytes()): [n, 0...] then the columns, 64-byte aligned"""
+        np.frombuffer(buf, np.int64, 8)[:] = [self.n, 0, 0, 0, 0, 0, 0, 0]
+        off = 64
+        for k, dt in self.FIELDS:
+            np.frombuffer(buf, dt, self.n, off)[:] = getattr(self, k)
+            off += (self.n * np.dtype(dt).itemsize + 63) // 64 * 64
+
+    @classmethod
+    def from_buffer(cls, buf):
+        n = int(np.frombuffer(buf, np.int64, 1)[0])
+        off, cols = 64, {}
+        for k, dt in cls.FIELDS:
+            cols[k] = np.frombuffer(buf, dt, n, off)
+            off += (n * np.dtype(dt).itemsize + 63) // 64 * 64
+        return cls(n, **cols)
+
+
 def _reads_near(pos1, pos2, r_start, r_end, margin, shift=10):
     """Which reads of a chromosome's block can matter to ONE task's genotyping?  A call's window is [p - h, p + h] around a
     point p that lies inside the span of its cluster's positions (a member's position for DEL / INS - INDEL:177, 399-403, 450-451 -
@@ -550,14 +589,18 @@ class SigStore:
                    names=NameTable(uniq), ins_seq=ins_seq if svtype == "INS" else {}, strands=strands, **kw)
 
     @classmethod
-    def from_task_pickles(cls, svtype, chrom, sig_buf, sig_off, reads_buf=None, reads_off=None, gt_margin=None):
+    def from_task_pickles(cls, svtype, chrom, sig_buf, sig_off, reads_buf=None, reads_off=None, gt_margin=None, reads_cache=None, reads_key=None):
         """from_task_lists without the lists: the task's pickle (and its chromosome's reads pickle) walked in C straight out of
         the mapped files (`_cols_native.pickle_table`): integer fields into the columns, strings as spans of the file - the
         read names interned by their bytes, the inserted sequences never touched unless a call picks one.  The 110 862
         signatures of INS chr2: ~6 ms instead of 21-24 ms of pickle.load + 5 ms over its objects.  Returns None when the
         stream holds anything pickle_table does not know (the caller unpickles then).
         gt_margin (the task's genotyping half-window: max_cluster_bias, 1000 for INS - INDEL:450-451, DUP:146-151, INV:218-221):
-        only the reads that can cover a window of THIS task are kept - see _reads_near."""
+        only the reads that can cover a window of THIS task are kept - see _reads_near.
+        reads_cache / reads_key: the walked form of a chromosome's reads block is shared between the tasks of the chromosome - DEL,
+        INS, INV, DUP each walk the same block in the reference (INDEL:445-448) - through anything that offers
+        `reads_get(key) -> WalkedReads | None` and `reads_put(key, WalkedReads)` (broker.Client: the GPU's broker keeps the blocks
+        in shared memory for the pool's workers)."""
         from . import _cols_native as cn                     # (built by the same make as the library; no Python fallback)
         ints, strs, width = {"DEL": ((0, 1), (2,), 5), "DUP": ((0, 1), (2,), 5), "INS": ((0, 1), (2, 3), 6),
                              "INV": ((1, 2), (0, 3), 6), "TRA": ((1, 3), (0, 2, 4), 7)}[svtype]
@@ -567,13 +610,20 @@ class SigStore:
         n = int(t[0])
         a, b = (np.frombuffer(x, np.int64).copy() for x in t[2])     # (writable, like every other store's columns)
         spans = [(np.frombuffer(o, np.int64), np.frombuffer(l, np.int32)) for o, l in t[3]]
-        rt = None
+        wr = None                                             # the chromosome's reads block, walked (WalkedReads)
         nr = 0
         if reads_buf is not None:
-            rt = cn.pickle_table(reads_buf, int(reads_off), 5, (0, 1, 2), (3, 4))      # (start, end, is_primary, read, chr), main script :733
-            if rt is None:
-                return None
-            nr = int(rt[0])
+            if reads_cache is not None and reads_key is not None:
+                wr = reads_cache.reads_get(reads_key)
+            if wr is None:
+                rt = cn.pickle_table(reads_buf, int(reads_off), 5, (0, 1, 2), (3, 4))      # (start, end, is_primary, read, chr), main script :733
+                if rt is None:
+                    return None
+                wr = WalkedReads.from_table(rt)
+                if reads_cache is not None and reads_key is not None and wr.n:
+                    reads_cache.reads_put(reads_key, wr)
+            nr = wr.n
+            n_block = wr.n
 
         def small(buf, sp):                                   # a field with a handful of distinct values -> (values, ids)
             ids = np.empty(len(sp[0]), np.int32)
@@ -603,8 +653,8 @@ class SigStore:
         kw = {}
         rd = []
         if nr:
-            r_start, r_end, r_primary = (np.frombuffer(x, np.int64) for x in rt[2])
-            rsp = [(np.frombuffer(o, np.int64), np.frombuffer(l, np.int32)) for o, l in rt[3]]
+            r_start, r_end, r_primary = wr.start, wr.end, wr.primary
+            rsp = [(wr.name_off, wr.name_len), (wr.chr_off, wr.chr_len)]
             if gt_margin is not None and n:
                 keep = _reads_near(a, b if svtype in ("DUP", "INV") else None, r_start, r_end, int(gt_margin))
                 if keep is not None:
@@ -636,7 +686,7 @@ class SigStore:
                 o = np.argsort(rc, kind="stable")
                 kw = dict(reads_off=np.searchsorted(rc[o], np.arange(len(chroms) + 1)).astype(np.int64),
                           r_start=r_start[o], r_end=r_end[o], r_primary=r_primary[o].astype(np.uint8), r_id=r_id[o])
-        elif reads_buf is not None and int(rt[0]) > 0:
+        elif reads_buf is not None and n_block > 0:
             # every read of the block was out of reach of the task's windows: an empty block, still a reads table (a task
             # WITHOUT a reads block loses its calls, INDEL:443-444; one whose reads cover nothing keeps them with DR = 0)
             kw = dict(reads_off=np.zeros(len(chroms) + 1, np.int64), r_start=np.zeros(0, np.int64), r_end=np.zeros(0, np.int64),

@@ -182,9 +182,16 @@ def _store_for(work_dir, sigs_index, svtype, chrom, need_reads, gt_margin=None):
         sig_map = _mapped("%s%s.pickle" % (work_dir, svtype))
         reads_map = _mapped("%sreads.pickle" % work_dir) if want_reads else None
         if sig_map is not None and (reads_map is not None or not want_reads):
+            cache = key = None
+            if want_reads and not os.environ.get("CUTESV_AMD_NO_READS_CACHE"):
+                eng = _ctx if _ctx is not None else (context() if use_broker() else None)
+                if eng is not None and hasattr(eng, "reads_get"):          # (a pool worker: the GPU's broker hands walked blocks round)
+                    k_ = _maps["%sreads.pickle" % work_dir][0]
+                    cache, key = eng, (k_[0], k_[1], k_[2], int(sigs_index["reads"][chrom]))
             st = SigStore.from_task_pickles(svtype, chrom, sig_map, sigs_index[svtype][chrom],
                                             reads_map, sigs_index["reads"][chrom] if want_reads else None,
-                                            gt_margin=None if os.environ.get("CUTESV_AMD_ALL_READS") else gt_margin)
+                                            gt_margin=None if os.environ.get("CUTESV_AMD_ALL_READS") else gt_margin,
+                                            reads_cache=cache, reads_key=key)
             if st is not None:
                 return st
     with open("%s%s.pickle" % (work_dir, svtype), "rb") as f:

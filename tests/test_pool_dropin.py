@@ -159,6 +159,11 @@ def test_phase3_pool_through_the_broker_returns_the_reference_rows(oracle_broker
         assert len(results[c]) == len(want)
         for g, (t, w) in zip(results[c], want):
             assert_rows_equal(t, [g], [w], where="pool %s" % c)
+    if p.genotype:
+        # the tasks of a chromosome shared its walked reads block through the broker (the first one left it there)
+        with broker.Client.connect(0, owner_pid=os.getpid(), spawn=False) as cl:
+            info = cl.info()
+        assert info.get("blocks", 0) >= 1 and info.get("block_hits", 0) >= 1, info
     # the restatement's five callables on the same files, under the same harness (bench.py's mode1_stage baseline)
     from oracle import py_restatement as pr
     ref = resolve.main_ctrl_phase3(wd, idx, p, threads, fns=pr.REF_FNS)
