@@ -155,7 +155,7 @@ struct csv_ctx {
     struct RunOpts {
         bool debug = false, debug_counters = false, no_fork = false, fork_always = false, no_swap = false, no_peek = false;
         bool no_pair_in_mid = false, no_publish = false;
-        int  iw_grid = 0, gt_grid = 0, tier_fork_min = 4 << 20, mid_grid = 0, big_grid = 0;
+        int  iw_grid = 0, gt_grid = 0, tier_fork_min = 1 << 30, mid_grid = 0, big_grid = 0;
     } opt;
     volatile int* h_flag = nullptr;
     int*          d_flag = nullptr;
@@ -269,7 +269,7 @@ void load_run_opts(csv_ctx* c)
     o.no_publish = getenv("CSV_NO_PUBLISH") != nullptr;
     o.iw_grid = env_int("CSV_IW_GRID", 0);
     o.gt_grid = env_int("CSV_GT_GRID", 0);
-    o.tier_fork_min = env_int("CSV_TIER_FORK_MIN", 4 << 20);
+    o.tier_fork_min = env_int("CSV_TIER_FORK_MIN", 1 << 30);
     o.mid_grid = env_int("CSV_MID_GRID", 0);
     o.big_grid = env_int("CSV_BIG_GRID", 0);
 }
@@ -1118,8 +1118,10 @@ int run_impl(csv_ctx* c, csv_run_stats* stats)
                 __builtin_ia32_pause();
             }
         }
-        // the tiers run side by side only in a large batch: a fork and a join cost 6-10 us each, more than the overlap of short
-        // kernels is worth (five simulation beds, 0.56 M signatures: 110 us in a row, 115-133 us forked; 90x ONT, 11 M: 367 vs 335)
+        // The tiers run one after the other.  Side by side (CSV_TIER_FORK_MIN=<signatures>; the default for >= 4 Mi until r05) the
+        // register tier and the one-wavefront tier - both bound by vector issue - share the CUs and finish when their sum would
+        // have (r06 timeline of the 90x genome: 45 + 90 us overlapped = 99 us, against 37 + 61 in a row), and the fork and the
+        // join add 8 + 14 us of event waits: 256.5 -> 246 us for the step without it.
         const bool tier_fork = fork && W >= (i64)O.tier_fork_min;
         // with clusters above 64 signatures in the batch, the one-wavefront tier for 65 .. 256 also takes the DUP / INV / TRA clusters
         // of at most 64 (its second phase): one grid, the long clusters first, instead of two kernels in a row
