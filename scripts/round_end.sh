@@ -18,6 +18,7 @@ timeout 600 python bench.py --full --workload cfg5 --mode shard --gpus 8 --steps
 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --full --gpus 2 --steps 5 --warmup 2 2>/dev/null | tail -1 > $F/${TAG}_bench_torchrun_2ranks_one_device.json; echo "torchrun rc=$?"
 timeout 700 python scripts/stress_gpu.py ${STRESS_N:-30000} 1200000 > $F/${TAG}_stress.log 2>&1; tail -2 $F/${TAG}_stress.log
 timeout 300 python scripts/stress_gpu.py ${STRESS_BIG:-3000} 1300000 big > $F/${TAG}_stress_big.log 2>&1; tail -2 $F/${TAG}_stress_big.log
+timeout 600 python scripts/stress_pool.py ${STRESS_POOL:-400} 70000 > $F/${TAG}_stress_pool.log 2>&1; tail -2 $F/${TAG}_stress_pool.log
 ls $F | wc -l
 # the host -> host call: bulk vs gate-first, full vs slim results; its kernels + copies on a timeline (no counters)
 timeout 300 python scripts/oneshot_ab.py cfg3 cfg4 cfg5 cfg2 > $F/${TAG}_oneshot_ab.txt 2>&1; tail -4 $F/${TAG}_oneshot_ab.txt
