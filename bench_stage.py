@@ -76,7 +76,7 @@ def _broker_info(shutdown=False):
                 info = cl.info()
                 first = first or info
                 if first is not info:
-                    for k in ("calls", "batches", "merged_calls", "busy_s", "maps"):
+                    for k in ("calls", "batches", "merged_calls", "busy_s", "maps", "stage_in_s", "engine_s", "slice_out_s", "blocks", "block_hits"):
                         first[k] = first.get(k, 0) + info.get(k, 0)
                 if shutdown:
                     cl.shutdown()
@@ -169,7 +169,7 @@ def mode1_stage(name, store, params, workers=(1, 8, 32), reference=True, cold_an
         _wait_gone()
         resolve.shut_down()
         out["legs"] = legs
-        out["broker"] = None if info is None else {k: info.get(k) for k in ("calls", "batches", "merged_calls", "max_batch", "busy_s", "maps", "bus", "engine")}
+        out["broker"] = None if info is None else {k: info.get(k) for k in ("calls", "batches", "merged_calls", "max_batch", "busy_s", "stage_in_s", "engine_s", "slice_out_s", "maps", "blocks", "block_hits", "bus", "engine")}
         if cold_and_direct_at:
             T = cold_and_direct_at
             os.environ.pop("CUTESV_AMD_BROKER_NAME", None)

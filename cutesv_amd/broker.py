@@ -560,9 +560,9 @@ class Broker:
     def _run_merged(self, grp):
         """k single-segment requests -> one csv_cluster_batch.  Request j becomes segment j and "chromosome" j of the batch (its
         reads block, in its own read-id space: ids only have to tell reads apart inside a chromosome)."""
-        from . import engine as eng_mod
         eng = self.engine()
         k = len(grp)
+        t_0 = time.perf_counter()
         wide_sig = any(not (p.cin.flags & _abi.IN_SIG_I32) for p in grp)
         wide_rd = any(p.cin.n_reads and not (p.cin.flags & _abi.IN_READS_I32) for p in grp)
         n_tot = sum(p.cin.n_sig for p in grp)
@@ -609,6 +609,7 @@ class Broker:
             ro += nr
             roff[j + 1] = ro
         self._copy_all(copies)
+        t_1 = time.perf_counter()
         any_reads = ro > 0
         cin = _abi.BatchIn(n_seg=k, n_chrom=k, seg=segs.ctypes.data, n_sig=n_tot, a=a.ctypes.data, b=b.ctypes.data,
                            read_id=rid.ctypes.data, aux=aux.ctypes.data,
@@ -628,6 +629,9 @@ class Broker:
                 res = None
                 continue
             break
+        t_2 = time.perf_counter()
+        self.stats["stage_in_s"] = self.stats.get("stage_in_s", 0.0) + (t_1 - t_0)
+        self.stats["engine_s"] = self.stats.get("engine_s", 0.0) + (t_2 - t_1)
         if rc != _abi.OK:
             text = eng.last_error()
             for p in grp:                             # (a batch-level failure: every requester is told; one bad request cannot hide)
@@ -671,6 +675,7 @@ class Broker:
             if o.seg_status:
                 _view(o.seg_status, 1, np.int32)[0] = t["seg_status"][j]
             self._reply(p.conn, _abi.OK, o)
+        self.stats["slice_out_s"] = self.stats.get("slice_out_s", 0.0) + (time.perf_counter() - t_2)
 
     def _copy_all(self, copies):
         """shared region -> staging.  numpy's copy loops release the GIL: a merged batch's large columns (a chromosome's reads

@@ -414,6 +414,15 @@ class SigStore:
             cols.update(contig_len=self.contig_len)
         for k, v in cols.items():
             np.save(os.path.join(path, k + ".npy"), v)
+        # int32 twins of the positions / lengths when they fit (a genome's do): what travels to the GPU (CSV_IN_SIG_I32 /
+        # CSV_IN_READS_I32) - a worker that maps the directory then neither scans the columns for their range nor narrows them
+        for pair in (("a", "b"), ("r_start", "r_end")):
+            vs = [cols.get(k) for k in pair]
+            if vs[0] is None:
+                continue
+            if all(len(v) == 0 or (int(v.min()) >= -(1 << 31) and int(v.max()) < (1 << 31)) for v in vs):
+                for k, v in zip(pair, vs):
+                    np.save(os.path.join(path, k + "32.npy"), np.ascontiguousarray(v, np.int32))
         meta = dict(chroms=self.chroms, strands=list(self.strands),
                     seg_index=[[t, c, int(b), int(e)] for (t, c), (b, e) in self.seg_index.items()],
                     names=None if self.names.names is None else list(self.names.names), name_fmt=self.names.fmt,
@@ -431,10 +440,14 @@ class SigStore:
             kw = {k: ld(k) for k in ("reads_off", "r_start", "r_end", "r_primary", "r_id")}
         if os.path.exists(os.path.join(path, "contig_len.npy")):
             kw["contig_len"] = ld("contig_len")
+        narrow = {k: ld(k + "32") for k in ("a", "b", "r_start", "r_end") if os.path.exists(os.path.join(path, k + "32.npy"))}
+        if ("a" in narrow) != ("b" in narrow) or ("r_start" in narrow) != ("r_end" in narrow):
+            narrow = {}
         return cls(chroms=meta["chroms"], a=ld("a"), b=ld("b"), read_id=ld("read_id"), aux=ld("aux"),
                    seg_index={(t, c): (b, e) for t, c, b, e in meta["seg_index"]},
                    names=NameTable(meta["names"], meta["name_fmt"]), strands=tuple(meta["strands"]),
-                   ins_seq=None if meta["ins_seq"] is None else {int(k): v for k, v in meta["ins_seq"].items()}, **kw)
+                   ins_seq=None if meta["ins_seq"] is None else {int(k): v for k, v in meta["ins_seq"].items()},
+                   narrow=narrow or None, **kw)
 
     # ------------------------------------------------------------------ conversion from the reference's layout
     @classmethod

@@ -215,14 +215,7 @@ def run_batch(store, segments, tasks, ctx=None, timeline=None):
     """segments: csv_segment records for `tasks` [(type, chr)] -> {(type, chr): rows}"""
     import numpy as np
     ctx = ctx or context()
-    segs = np.array(segments, dtype=_abi.SEGMENT_DTYPE)
-    kw = {}
-    if len(segs) and segs["genotype"].any() and store.reads_off is not None:
-        kw = dict(reads_off=store.reads_off, r_start=store.r_start, r_end=store.r_end,
-                  r_primary=store.r_primary, r_id=store.r_id)
-        if ((segs["svtype"] == _abi.TRA) & (segs["genotype"] != 0)).any():
-            kw["contig_len"] = store.contig_len
-    hb = _abi.HostBatch(segs, store.a, store.b, store.read_id, store.aux, n_chrom=len(store.chroms), **kw)
+    hb = _batch_of(store, segments)
     if timeline:
         _last_marks[0] = time.time()
     res = ctx.cluster_batch(hb, reuse=True, fields=ROW_FIELDS)     # (consumed right here: the arrays may be recycled by the next call)
@@ -254,12 +247,14 @@ def cluster_stage(store, params, tasks=None, ctx=None, lazy=False):
 def _batch_of(store, segments):
     import numpy as np
     segs = np.array(segments, dtype=_abi.SEGMENT_DTYPE)
+    nw = store.narrow or {}                           # (int32 twins of the positions / lengths: SigStore.pinned(), a mapped .cols directory)
     kw = {}
     if len(segs) and segs["genotype"].any() and store.reads_off is not None:
-        kw = dict(reads_off=store.reads_off, r_start=store.r_start, r_end=store.r_end, r_primary=store.r_primary, r_id=store.r_id)
+        kw = dict(reads_off=store.reads_off, r_start=nw.get("r_start", store.r_start), r_end=nw.get("r_end", store.r_end),
+                  r_primary=store.r_primary, r_id=store.r_id)
         if ((segs["svtype"] == _abi.TRA) & (segs["genotype"] != 0)).any():
             kw["contig_len"] = store.contig_len
-    return _abi.HostBatch(segs, store.a, store.b, store.read_id, store.aux, n_chrom=len(store.chroms), **kw)
+    return _abi.HostBatch(segs, nw.get("a", store.a), nw.get("b", store.b), store.read_id, store.aux, n_chrom=len(store.chroms), **kw)
 
 
 def _cluster_stage_lazy(store, segs, tasks, ctx):
