@@ -213,12 +213,28 @@ _last_marks = [0.0, 0.0]
 
 def run_batch(store, segments, tasks, ctx=None, timeline=None):
     """segments: csv_segment records for `tasks` [(type, chr)] -> {(type, chr): rows}"""
-    import numpy as np
+    global _ctx
+    own = ctx is None
     ctx = ctx or context()
     hb = _batch_of(store, segments)
     if timeline:
         _last_marks[0] = time.time()
-    res = ctx.cluster_batch(hb, reuse=True, fields=ROW_FIELDS)     # (consumed right here: the arrays may be recycled by the next call)
+    try:
+        res = ctx.cluster_batch(hb, reuse=True, fields=ROW_FIELDS)     # (consumed right here: the arrays may be recycled by the next call)
+    except Exception as e:                              # noqa: BLE001
+        from . import broker
+        if not (own and isinstance(e, broker.BrokerError)):
+            raise
+        # the GPU's broker went away under this worker (killed, crashed): the task is tried once more on a fresh connection -
+        # which starts a new broker if nobody listens - instead of failing every later task of the worker on a dead socket
+        logging.warning("cutesv_amd: %s - reconnecting" % (e,))
+        try:
+            _ctx.close()
+        except Exception:                               # noqa: BLE001
+            pass
+        _ctx = None
+        ctx = context()
+        res = ctx.cluster_batch(hb, reuse=True, fields=ROW_FIELDS)
     if timeline:
         _last_marks[1] = time.time()
     per_seg = rows_mod.rows_by_segment(store, hb.segments, res)

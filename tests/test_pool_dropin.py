@@ -332,3 +332,35 @@ def test_a_task_keeps_only_the_reads_that_can_reach_its_windows(tmp_path, monkey
 def helpers_canonical(t, row):
     from helpers import canonical_row
     return canonical_row(t, row)
+
+
+def test_a_worker_survives_its_brokers_death(oracle_broker, tmp_path, monkeypatch):
+    """the broker is killed between two tasks of one worker: the next task raises once at most and the worker reconnects (here: to a
+    broker started again under the same name) instead of failing every later task on a dead socket"""
+    import signal
+    monkeypatch.setenv("CUTESV_AMD_TRA_GT", "off")
+    monkeypatch.setenv("CUTESV_AMD_BROKER", "1")
+    monkeypatch.setattr(resolve, "_ctx", None)
+    monkeypatch.setattr(broker, "spawn", lambda name, device, watch_pid, linger=None, log=None: subprocess.Popen(
+        [sys.executable, os.path.join(HERE, "broker_oracle.py"), "--name", name, "--device", str(device), "--watch-pid", str(watch_pid), "--linger", "5"],
+        env=dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))))
+    oracle_broker()
+    st, p, case = _golden_case("ont_gt")
+    wd = str(tmp_path) + "/"
+    idx = st.write_reference_workdir(wd)
+    c = next(iter(idx["DEL"]))
+    args = (wd, c, "DEL", p.min_support, p.diff_ratio_merging_DEL, p.max_cluster_bias_DEL, min(p.min_support, 5), "bam", p.genotype, p.gt_round, p.remain_reads_ratio, idx)
+    want = resolve.run_del(args)
+    with broker.Client.connect(0, owner_pid=os.getpid(), spawn=False) as cl:
+        pid = cl.info()["pid"]
+    os.kill(pid, signal.SIGKILL)
+    t_end = time.monotonic() + 10
+    while broker._try_connect(broker.socket_name(os.getpid(), 0)) is not None and time.monotonic() < t_end:
+        time.sleep(0.02)
+    again = resolve.run_del(args)                       # the dead socket is noticed, a new broker is started, the task is redone
+    assert again == want and len(want[1]) > 0
+    with broker.Client.connect(0, owner_pid=os.getpid(), spawn=False) as cl:
+        assert cl.info()["pid"] != pid
+        cl.shutdown()
+    resolve._ctx.close()
+    resolve._ctx = None
