@@ -474,8 +474,11 @@ def cpu_legs(name, store, params, tasks, hb, n_sig, procs, py_pool, full_pool):
         t0 = time.perf_counter()
         pr.run_pool_forked(tl, fit)
         dt_fit = time.perf_counter() - t0
-        dt_noop = min(pr.pool_startup_seconds(procs, len(tl)) for _ in range(2))
-        dt_noop_fit = min(pr.pool_startup_seconds(fit, len(tl)) for _ in range(2))
+        # (the no-op pools are forked from THIS process, whose size sets their cost - tens of seconds at 256 workers once the
+        # 90x workload's tuple lists are in memory: measured for the workloads up to 4 M signatures, once for the others' fit)
+        small = n_sig <= 4_000_000
+        dt_noop = min(pr.pool_startup_seconds(procs, len(tl)) for _ in range(2 if name == "cfg3" else 1)) if small else None
+        dt_noop_fit = min(pr.pool_startup_seconds(fit, len(tl)) for _ in range(2 if name == "cfg3" else 1))
         big = max(tl, key=lambda t: len(t[2]) + (len(t[3]) if t[3] else 0))
         t0 = time.perf_counter()
         pr.run_task(big)
@@ -485,8 +488,8 @@ def cpu_legs(name, store, params, tasks, hb, n_sig, procs, py_pool, full_pool):
                    critical_task="%s chr%s, %d signatures" % (big[0], big[1], len(big[2])),
                    sample="%d of %d (chr,type) tasks, %d signatures, %.2f s wall; oracle/py_restatement.py in a fork "
                           "Pool(%d): the reference's pool model (Python per-signature loop, numpy scalar calls); %.2f s at Pool(%d); "
-                          "the pools alone (no-op tasks) %.2f / %.2f s; largest task alone %.3f s"
-                          % (len(sample), len(tasks), ns, dt, procs, dt_fit, fit, dt_noop, dt_noop_fit, dt_crit),
+                          "the pools alone (no-op tasks) %s / %.2f s; largest task alone %.3f s"
+                          % (len(sample), len(tasks), ns, dt, procs, dt_fit, fit, "-" if dt_noop is None else "%.2f" % dt_noop, dt_noop_fit, dt_crit),
                    rows=sum(len(x[1]) for x in r))
         del tl, r
     t0 = time.perf_counter()
