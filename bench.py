@@ -1121,7 +1121,8 @@ def main():
         # (r06: a resident run queues the two tiers above 64 signatures whether they have work or not; an empty launch is all
         # boundary, so its whole slot is charged to the boundaries of the kernels that do work - which lands within 1-2 % of the
         # dominant kernel's rocprofv3 average: 14.5 vs 14.46 us on cfg3)
-        launched = [n for n in per_kernel_nps if n.startswith("k_") and isinstance(per_kernel_nps[n], float) and per_kernel_nps[n] > 2.0]
+        launched = [n for n in per_kernel_nps if n.startswith("k_") and isinstance(per_kernel_nps[n], float) and per_kernel_nps[n] > 0.6
+                    and not (n in ("k_refine_mid", "k_refine_block", "k_refine_wave") and per_kernel_nps[n] < 2.0)]
         one_chain = not shard_mode and all(per_kernel_nps.get(n, 0.0) < 0.6 for n in ("k_refine_wave", "k_reads_order", "k_reads_gather", "k_genotype_tra"))
         boundary_us = None
         if one_chain and launched and ms_kernel_only is not None:
