@@ -717,6 +717,7 @@ class Broker:
             if _peer_uid(c) != os.getuid():
                 c.close()
                 return False
+            c.settimeout(10.0)                        # (a message is sent in one piece: a peer that stalls mid-message is dropped, not waited for)
             self.conns[c.fileno()] = _Conn(c)
             self.sel.register(c, selectors.EVENT_READ)
             self._served = True
