@@ -712,6 +712,9 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
         }
     }
     HIP_TRY(c, hipMemcpyAsync(c->tabs.p, c->h_pin, o_end, hipMemcpyHostToDevice, st));
+    // (the upload's reads-order state is cleared here, in FRONT of the column copies: behind them the fill kernel was one more
+    // switch between the copy engine and the compute queue on the one-shot call's critical path)
+    HIP_TRY(c, hipMemsetAsync(c->rstate.p, 0, sizeof(ReadsState), st));
 
     // ---- columns, on the copy stream, in two groups: what the chain kernels read (positions, lengths / pos2, the strand
     // and chr2 words of INV / TRA segments), then what only the refine kernels read (read ids, INS sequence lengths).  In a
@@ -724,8 +727,9 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
     // where the chain kernels wait.
     {
         int* ones = (int*)(c->h_pin + o_ones);
-        for (size_t i = 0; i < ones_bytes / 4; i++) ones[i] = 1;
-        if (sig32) HIP_TRY(c, hipMemcpyAsync(dp<int>(c->a32) + W, ones, (size_t)(CH_TILE + 64) * 4, hipMemcpyHostToDevice, cs));
+        if (!delta16) for (size_t i = 0; i < ones_bytes / 4; i++) ones[i] = 1;
+        if (delta16) {}                                   // (k_unpack_a16 writes the padding together with the column)
+        else if (sig32) HIP_TRY(c, hipMemcpyAsync(dp<int>(c->a32) + W, ones, (size_t)(CH_TILE + 64) * 4, hipMemcpyHostToDevice, cs));
         else HIP_TRY(c, hipMemcpyAsync(dp<i64>(c->a) + W, ones, (size_t)(CH_TILE + 64) * 8, hipMemcpyHostToDevice, cs));
     }
     auto aux_kind = [&](int q) { const int t = c->h_seg[q].svtype; return t == CSV_INS ? 2 : (t == CSV_INV || t == CSV_TRA) ? 1 : 0; };
@@ -812,7 +816,6 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
     c->copies_pending = true;                               // run_impl orders the kernels behind the two events
     // reads table: its own stream (side[2] runs the reads_order / prefix-max kernels behind it)
     hipStream_t sr = c->side[2];
-    HIP_TRY(c, hipMemsetAsync(c->rstate.p, 0, sizeof(ReadsState), st));
     if (have_tab) {
         HIP_TRY(c, hipStreamWaitEvent(sr, c->ev_init, 0));
         HIP_TRY(c, hipMemcpyAsync(c->reads_off.p, in->reads_off, (size_t)(in->n_chrom + 1) * 8, hipMemcpyHostToDevice, sr));
@@ -847,12 +850,14 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
         // between the column copies delayed the copies behind it until the reads table had left the copy engine (1.77 -> 2.82 ms);
         // queued from here in a one-shot call, after the last copy, the launch itself blocked the host for 1.1 ms.
         const i64 ntile = div_up(W, CH_TILE);
-        c->unpack_args = UnpackArgs{dp<uint16_t>(c->ad16), dp<int>(c->a32), W, dp<int>(c->anc), dp<int>(c->anc) + ntile + 2, dp<int>(c->anc) + ntile + 2 + n_anc_cap};
+        c->unpack_args = UnpackArgs{dp<uint16_t>(c->ad16), dp<int>(c->a32), W, dp<int>(c->anc), dp<int>(c->anc) + ntile + 2, dp<int>(c->anc) + ntile + 2 + n_anc_cap, (int)ntile, 0};
         c->unpack_tiles = (int)ntile;
         c->unpack_pending = true;
         if (sync) {
             HIP_TRY(c, hipStreamWaitEvent(st, c->ev_copy[0], 0));
-            hipLaunchKernelGGL(k_unpack_a16, dim3((unsigned)ntile), dim3(256), 0, st, c->unpack_args);
+            DevBatch none;                                // (a resident upload is never gate-first: nothing of the batch is read)
+            memset(&none, 0, sizeof none);
+            hipLaunchKernelGGL(k_unpack_a16, dim3((unsigned)ntile + 1), dim3(256), 0, st, c->unpack_args, none);
             c->unpack_pending = false;
         }
     }
@@ -1051,8 +1056,12 @@ int run_impl(csv_ctx* c, csv_run_stats* stats)
         return CSV_OK;
     };
     if (c->copies_pending) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_copy[0], 0));       // positions, lengths, INV / TRA words
+    bool zero_done = false;
     if (c->unpack_pending) {                               // CSV_IN_SIG_DELTA16: the position column out of its gaps, first kernel of the call
-        hipLaunchKernelGGL(k_unpack_a16, dim3((unsigned)c->unpack_tiles), dim3(256), 0, st, c->unpack_args);
+        // (a gate-first call: the same kernel fetches `b` of the rows at position 0 - k_lazy_zero's whole job - as it writes them)
+        c->unpack_args.zero_b = (c->lazy_pending && W > 0) ? 1 : 0;
+        zero_done = c->unpack_args.zero_b != 0;
+        hipLaunchKernelGGL(k_unpack_a16, dim3((unsigned)c->unpack_tiles + 1), dim3(256), 0, st, c->unpack_args, B);
         c->unpack_pending = false;
     }
     // A run decides what it launches from what IT knows - nothing is carried over from earlier runs of the upload (r05 skipped
@@ -1076,7 +1085,7 @@ int run_impl(csv_ctx* c, csv_run_stats* stats)
             if (!swap) HIP_TRY(c, hipEventRecord(c->ev_aux[2], sD));
         }
         const bool lazy = c->lazy_pending;                 // (the first run of a gate-first upload; stats are never taken on one)
-        if (lazy) {
+        if (lazy && !zero_done) {
             const int gz = nb < 2048 ? nb : 2048;
             if (B.a.p32) hipLaunchKernelGGL(k_lazy_zero<true>, dim3(gz), dim3(256), 0, st, B);
             else hipLaunchKernelGGL(k_lazy_zero<false>, dim3(gz), dim3(256), 0, st, B);

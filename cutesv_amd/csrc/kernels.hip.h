@@ -911,11 +911,22 @@ struct UnpackArgs {
     const int*      anc_off;    // per chain tile: first anchor; [ntiles]: the end
     const int*      anc_w;      // ascending
     const int*      anc_val;
+    int             ntile;      // chain tiles; workgroup `ntile` only writes padding
+    int             zero_b;     // gate-first call: also fetch `b` of the rows at position 0 (what k_lazy_zero does, below)
 };
-__global__ __launch_bounds__(256) void k_unpack_a16(UnpackArgs A)
+__device__ __forceinline__ i64 lazy_src(const DevBatch& B, int k, i64 w);
+__global__ __launch_bounds__(256) void k_unpack_a16(UnpackArgs A, DevBatch B)
 {
     __shared__ int s_f[4], s_s[4];
     const int tile = blockIdx.x, t = threadIdx.x, lane = lane_id(), wv = t >> 6;
+    // the padding behind the column (positive values: the chain kernel reads any span that begins inside the batch without a
+    // range test) is written here too - a DMA copy of a block of ones in front of the column was a blit kernel and an engine
+    // switch of its own (5 + 8 us of the one-shot call's timeline)
+    const i64 pad_end = A.W + CH_TILE + 64;
+    if (tile >= A.ntile) {
+        for (i64 w = (i64)A.ntile * CH_TILE + t; w < pad_end; w += 256) A.a[w] = 1;
+        return;
+    }
     const i64 w0 = (i64)tile * CH_TILE + t * 8;
     const uint4 raw = *(const uint4*)(A.d + w0);
     const unsigned g[8] = {raw.x & 0xffffu, raw.x >> 16, raw.y & 0xffffu, raw.y >> 16, raw.z & 0xffffu, raw.z >> 16, raw.w & 0xffffu, raw.w >> 16};
@@ -943,15 +954,21 @@ __global__ __launch_bounds__(256) void k_unpack_a16(UnpackArgs A)
     }
     if (lane == 63) { s_f[wv] = fs; s_s[wv] = ss; }
     __syncthreads();
-    int pf = 0, ps = 0;                                     // what the earlier wavefronts carry in
-    for (int q = 0; q < wv; q++) { if (s_f[q]) { pf = 1; ps = s_s[q]; } else ps += s_s[q]; }
+    int ps = 0;                                             // what the earlier wavefronts carry in
+    for (int q = 0; q < wv; q++) { if (s_f[q]) ps = s_s[q]; else ps += s_s[q]; }
     int ef = __shfl_up(fs, 1), es = __shfl_up(ss, 1);       // the lanes before this one, inside the wavefront
     if (lane == 0) { ef = 0; es = 0; }
     const int carry = ef ? es : ps + es;                    // (a tile's first row is an anchor: the carry is always defined by one)
-    (void)pf;
 #pragma unroll
-    for (int r = 0; r < 8; r++)
-        if (w0 + r < A.W) A.a[w0 + r] = ((since >> r) & 1) ? loc[r] : loc[r] + carry;
+    for (int r = 0; r < 8; r++) {
+        const i64 w = w0 + r;
+        const int v = ((since >> r) & 1) ? loc[r] : loc[r] + carry;
+        if (w < A.W) {
+            A.a[w] = v;
+            // (gate-first: the (0,0) look-alike rule reads the length of a row at position 0 - see k_lazy_zero)
+            if (CSV_UNLIKELY(A.zero_b && v == 0)) const_cast<int*>(B.b.p32)[w] = ((const int*)B.h_b)[lazy_src(B, seg_of(B, w), w)];
+        } else if (w < pad_end) A.a[w] = 1;
+    }
 }
 
 // ------------------------------------------------------------------------------------ gate-first fetch
