@@ -112,7 +112,7 @@ struct csv_ctx {
     hipStream_t stream = nullptr;
     hipStream_t side[3] = {};         // side streams: [0] mid + workgroup tier, [1] DUP/INV/TRA wavefront tier, [2] reads order + prefix max
     hipStream_t copy[N_COPY_STREAMS] = {};    // host -> device column copies (one DMA engine each)
-    hipEvent_t  ev_init = nullptr, ev_sel = nullptr, ev_aux[3] = {}, ev_copy[N_COPY_STREAMS] = {}, ev_reads = nullptr;
+    hipEvent_t  ev_init = nullptr, ev_sel = nullptr, ev_aux[3] = {}, ev_copy[N_COPY_STREAMS] = {}, ev_reads = nullptr, ev_anc = nullptr;
     std::string err;
     hipEvent_t  ev[CSV_N_STAGES + 2] = {};
     Arena       arena, arena_rb;
@@ -121,6 +121,7 @@ struct csv_ctx {
     Buf tile_lead, tabs;
     Buf ad16, anc;                             // CSV_IN_SIG_DELTA16: the gaps in w space; the anchor tables {per-tile offsets, w, value}
     bool delta16 = false;                      // the last upload rebuilt its position column from gaps (csv_batch_info 2)
+    bool rstate_dirty = true;                  // the reads-order state may hold an earlier upload's verdict
     bool unpack_pending = false; UnpackArgs unpack_args{}; int unpack_tiles = 0;      // ... and k_unpack_a16 is still to be queued (one-shot calls: by the run)
     Buf cluster_id, partial, tile_cnt, item_rec, list_small, list_big, list_tiny, list_wide, seg_gate, tile_info, ch_masks, tile_items, seg_err;
     Buf item_cnt, item_base, item_chunk, sup_tmp;
@@ -412,7 +413,8 @@ int csv_ctx_create(int device_id, csv_ctx** out)
         if (hipEventCreateWithFlags(&c->ev_run[q], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_pub[q], hipEventDisableTiming) != hipSuccess) { delete c; return CSV_E_HIP; }
     if (hipEventCreateWithFlags(&c->ev_init, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_sel, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_reads, hipEventDisableTiming) != hipSuccess) { delete c; return CSV_E_HIP; }
+        hipEventCreateWithFlags(&c->ev_reads, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_anc, hipEventDisableTiming) != hipSuccess) { delete c; return CSV_E_HIP; }
     for (auto& e : c->ev_aux) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { delete c; return CSV_E_HIP; }
     for (auto& e : c->ev_copy) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { delete c; return CSV_E_HIP; }
     {
@@ -451,6 +453,7 @@ void csv_ctx_destroy(csv_ctx* c)
     if (c->ev_init) (void)hipEventDestroy(c->ev_init);
     if (c->ev_sel) (void)hipEventDestroy(c->ev_sel);
     if (c->ev_reads) (void)hipEventDestroy(c->ev_reads);
+    if (c->ev_anc) (void)hipEventDestroy(c->ev_anc);
     for (auto& s2 : c->side) if (s2) (void)hipStreamDestroy(s2);
     for (auto& s2 : c->copy) if (s2) (void)hipStreamDestroy(s2);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -711,10 +714,11 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
             r[2] = (nin <= 3 && !wide_bias) ? nin : 0;
         }
     }
+    // (the upload's reads-order state is cleared here, in FRONT of every copy - behind the column copies the fill kernel was one
+    // more switch between the copy engine and the compute queue on the one-shot call's critical path - and only when there is a
+    // reads table to order)
+    if (have_tab || c->rstate_dirty) { HIP_TRY(c, hipMemsetAsync(c->rstate.p, 0, sizeof(ReadsState), st)); c->rstate_dirty = have_tab; }
     HIP_TRY(c, hipMemcpyAsync(c->tabs.p, c->h_pin, o_end, hipMemcpyHostToDevice, st));
-    // (the upload's reads-order state is cleared here, in FRONT of the column copies: behind them the fill kernel was one more
-    // switch between the copy engine and the compute queue on the one-shot call's critical path)
-    HIP_TRY(c, hipMemsetAsync(c->rstate.p, 0, sizeof(ReadsState), st));
 
     // ---- columns, on the copy stream, in two groups: what the chain kernels read (positions, lengths / pos2, the strand
     // and chr2 words of INV / TRA segments), then what only the refine kernels read (read ids, INS sequence lengths).  In a
@@ -809,7 +813,11 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
             }
             h_off[ntile + 1] = (int)anc.size();
             for (size_t i = 0; i < anc.size(); i++) { h_w[i] = (int)anc[i].first; h_v[i] = anc[i].second; }
-            HIP_TRY(c, hipMemcpyAsync(c->anc.p, c->h_pin + o_anc, anc_bytes, hipMemcpyHostToDevice, cs));
+            // (on a copy stream of its own: behind the gaps on the kernels' stream it was 7 us of copy + 9 us of hand-over between
+            // two copies on the call's critical path; here it lands while the gaps are still on the link, and the event has long
+            // fired when k_unpack_a16 - queued behind the gaps - gets to wait for it)
+            HIP_TRY(c, hipMemcpyAsync(c->anc.p, c->h_pin + o_anc, anc_bytes, hipMemcpyHostToDevice, c->copy[0]));
+            HIP_TRY(c, hipEventRecord(c->ev_anc, c->copy[0]));
         }
         HIP_TRY(c, hipEventRecord(c->ev_copy[group - 1], cs));
     }
@@ -855,6 +863,7 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
         c->unpack_pending = true;
         if (sync) {
             HIP_TRY(c, hipStreamWaitEvent(st, c->ev_copy[0], 0));
+            HIP_TRY(c, hipStreamWaitEvent(st, c->ev_anc, 0));
             DevBatch none;                                // (a resident upload is never gate-first: nothing of the batch is read)
             memset(&none, 0, sizeof none);
             hipLaunchKernelGGL(k_unpack_a16, dim3((unsigned)ntile + 1), dim3(256), 0, st, c->unpack_args, none);
@@ -1059,6 +1068,7 @@ int run_impl(csv_ctx* c, csv_run_stats* stats)
     bool zero_done = false;
     if (c->unpack_pending) {                               // CSV_IN_SIG_DELTA16: the position column out of its gaps, first kernel of the call
         // (a gate-first call: the same kernel fetches `b` of the rows at position 0 - k_lazy_zero's whole job - as it writes them)
+        HIP_TRY(c, hipStreamWaitEvent(st, c->ev_anc, 0));
         c->unpack_args.zero_b = (c->lazy_pending && W > 0) ? 1 : 0;
         zero_done = c->unpack_args.zero_b != 0;
         hipLaunchKernelGGL(k_unpack_a16, dim3((unsigned)c->unpack_tiles + 1), dim3(256), 0, st, c->unpack_args, B);
