@@ -52,6 +52,7 @@ class BatchIn(C.Structure):
         ("contig_len", C.c_void_p),
         ("flags", C.c_int32), ("reserved", C.c_int32),
         ("a_delta", C.c_void_p), ("n_esc", C.c_int64), ("a_esc_row", C.c_void_p), ("a_esc_val", C.c_void_p),      # ABI v8: CSV_IN_SIG_DELTA16
+        ("rows8", C.c_void_p),                                                                                      # ABI v8: {b, read_id} interleaved
     ]
 
 
@@ -90,7 +91,7 @@ class HostBatch:
     """Host-side buffers of one csv_batch_in.  Keeps the numpy arrays alive for the C call."""
 
     def __init__(self, segments, a, b, read_id, aux, n_chrom=0, reads_off=None,
-                 r_start=None, r_end=None, r_primary=None, r_id=None, contig_len=None, per_sig=False, reads_sorted=False, a_delta=None):
+                 r_start=None, r_end=None, r_primary=None, r_id=None, contig_len=None, per_sig=False, reads_sorted=False, a_delta=None, rows8=None):
         """a_delta: (delta uint16[n_sig], escape rows int64[], escape values int32[]) of `a` - delta16_of(a) - when the position
         column may cross the link as 16-bit gaps (CSV_IN_SIG_DELTA16; int32 columns only)"""
         self.segments = np.ascontiguousarray(segments, dtype=SEGMENT_DTYPE)
@@ -118,6 +119,12 @@ class HostBatch:
         self.contig_len = None if contig_len is None else _col(contig_len, np.int64)
         if self.contig_len is not None and self.contig_len.shape[0] != self.n_chrom:
             raise ValueError("contig_len must have n_chrom entries")
+        # rows8: the (n, 2) int32 array {b, read_id} per signature (page-locked: SigStore.pinned()) for the gate-first fetch
+        self.rows8 = None
+        if rows8 is not None and self.a.dtype == np.int32:
+            self.rows8 = _col(rows8, np.int32)
+            if self.rows8.shape != (n, 2):
+                raise ValueError("rows8: one {b, read_id} pair per signature is expected")
         self.a_delta = None
         if a_delta is not None and self.a.dtype == np.int32:
             d, er, ev = a_delta
@@ -134,7 +141,8 @@ class HostBatch:
             flags=(IN_PER_SIG if per_sig else 0) | (IN_READS_SORTED if reads_sorted else 0) | (IN_SIG_I32 if self.a.dtype == np.int32 else 0)
             | (IN_READS_I32 if self.r_start is not None and self.r_start.dtype == np.int32 else 0) | (IN_SIG_DELTA16 if self.a_delta is not None else 0),
             a_delta=None if self.a_delta is None else _ptr(self.a_delta[0]), n_esc=0 if self.a_delta is None else self.a_delta[1].shape[0],
-            a_esc_row=None if self.a_delta is None else _ptr(self.a_delta[1]), a_esc_val=None if self.a_delta is None else _ptr(self.a_delta[2]))
+            a_esc_row=None if self.a_delta is None else _ptr(self.a_delta[1]), a_esc_val=None if self.a_delta is None else _ptr(self.a_delta[2]),
+            rows8=_ptr(self.rows8))
 
     @classmethod
     def on_device(cls, segments, dev, n_sig, n_chrom=0, keep=None, **reads):

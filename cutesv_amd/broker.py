@@ -305,7 +305,7 @@ class Client:
             reg = self.region
             cin = _abi.BatchIn.from_buffer_copy(bytes(batch.c))
             cin.n_chrom, cin.n_sig = n_chrom, n
-            cin.a_delta = cin.a_esc_row = cin.a_esc_val = None      # (the gap form of a whole store's column does not travel with a task)
+            cin.a_delta = cin.a_esc_row = cin.a_esc_val = cin.rows8 = None      # (the gap / interleaved forms of a whole store's columns do not travel with a task)
             cin.n_esc = 0
             cin.flags &= ~_abi.IN_SIG_DELTA16
             by = dict(cols)

@@ -290,6 +290,12 @@ class SigStore:
                     narrow[k] = engine.pinned_copy(v.astype(np.int32))
                 else:
                     cols[k] = engine.pinned_copy(v)
+        if "b" in narrow and self.n_sig:
+            # ... the lengths and read ids once more, interleaved {b, read_id}: what a gate-first call's device-side fetch reads
+            r8 = engine.pinned_empty((self.n_sig, 2), np.int32)
+            r8[:, 0] = narrow["b"]
+            r8[:, 1] = self.read_id
+            narrow["rows8"] = r8
         if "a" in narrow:
             # ... and the position column once more as 16-bit gaps (CSV_IN_SIG_DELTA16): half of the largest transfer of a call
             ad = _abi.delta16_of(narrow["a"], alloc=engine.pinned_empty)
@@ -401,7 +407,8 @@ class SigStore:
             if bool(((segs["svtype"] == _abi.TRA) & (segs["genotype"] != 0)).any()):
                 kw["contig_len"] = self.contig_len
         return _abi.HostBatch(segs, nw.get("a", self.a), nw.get("b", self.b), self.read_id, self.aux, n_chrom=len(self.chroms),
-                              a_delta=nw.get("a_delta") if os.environ.get("CUTESV_AMD_NO_DELTA16") is None else None, **kw)
+                              a_delta=nw.get("a_delta") if os.environ.get("CUTESV_AMD_NO_DELTA16") is None else None,
+                              rows8=nw.get("rows8") if os.environ.get("CUTESV_AMD_NO_ROWS8") is None else None, **kw)
 
     # ------------------------------------------------------------------ persistence (flat .cols directory)
     def save(self, path):

@@ -574,13 +574,17 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
     // clusters that pass the size gate (kernels.hip.h).  Small batches are cheaper in one piece (CSV_LAZY_MIN signatures,
     // default 64 Ki: below that the extra kernel and its PCIe round trips cost more than the bytes they save).
     const bool sig32_ = (in->flags & CSV_IN_SIG_I32) != 0;
-    const void *lz_b = nullptr, *lz_rid = nullptr, *lz_aux = nullptr;
+    const void *lz_b = nullptr, *lz_rid = nullptr, *lz_aux = nullptr, *lz_rows8 = nullptr;
     bool lazy = lazy_ok && !dev_cols && W > 0 && !getenv("CSV_NO_LAZY") && W >= (i64)env_int("CSV_LAZY_MIN", 64 << 10) && in->b && in->read_id && in->aux;
     if (lazy) {
         const size_t nb = (size_t)in->n_sig;
-        lz_b = pinned_device_address(in->b, nb * (sig32_ ? 4 : 8));
-        lz_rid = lz_b ? pinned_device_address(in->read_id, nb * 4) : nullptr;
-        lz_aux = lz_rid ? pinned_device_address(in->aux, nb * 4) : nullptr;
+        // (ABI v8) {b, read_id} interleaved, page-locked: the fetch reads one array instead of two
+        if (sig32_ && in->rows8 && !getenv("CSV_NO_ROWS8")) lz_rows8 = pinned_device_address(in->rows8, nb * 8);
+        if (!lz_rows8) {
+            lz_b = pinned_device_address(in->b, nb * (sig32_ ? 4 : 8));
+            lz_rid = lz_b ? pinned_device_address(in->read_id, nb * 4) : nullptr;
+        }
+        lz_aux = (lz_rows8 || lz_rid) ? pinned_device_address(in->aux, nb * 4) : nullptr;
         lazy = lz_aux != nullptr;
     }
 
@@ -902,7 +906,7 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
     B.partial = dp<int>(c->partial); B.tile_cnt = dp<int4>(c->tile_cnt);
     B.item_rec = dp<int4>(c->item_rec); B.list_small = dp<int4>(c->list_small); B.list_big = dp<int>(c->list_big); B.list_tiny = dp<int4>(c->list_tiny); B.list_wide = dp<int4>(c->list_wide);
     B.seg_gate = dp<int4>(c->seg_gate); B.tile_info = dp<int4>(c->tile_info);
-    if (lazy) { B.h_b = lz_b; B.h_rid = (const int*)lz_rid; B.h_aux = (const int*)lz_aux; B.tile_lead = dp<int>(c->tile_lead); c->lazy_pending = c->partial_cols = true; }
+    if (lazy) { B.h_b = lz_b; B.h_rid = (const int*)lz_rid; B.h_aux = (const int*)lz_aux; B.h_rows8 = (const int2*)lz_rows8; B.tile_lead = dp<int>(c->tile_lead); c->lazy_pending = c->partial_cols = true; }
     B.ch_masks = per_sig ? dp<u64>(c->ch_masks) : nullptr; B.tile_items = dp<int4>(c->tile_items);
     B.seg_err = dp<int>(c->seg_err);
     B.tiny_max = getenv("CSV_NO_TINY") ? 0 : 16;               // (timing aid: 0 sends every DEL/INS cluster of m <= 32 through the paired path)
@@ -1111,7 +1115,7 @@ int run_impl(csv_ctx* c, csv_run_stats* stats)
             // the device columns now hold every row a kernel reads: later runs of this upload (the general-sort re-run of a reads
             // table, a caller's csv_batch_run) take them as they are - the caller's host columns are not touched again
             c->lazy_pending = false;
-            B.h_b = nullptr; B.h_rid = nullptr; B.h_aux = nullptr; B.tile_lead = nullptr;
+            B.h_b = nullptr; B.h_rid = nullptr; B.h_aux = nullptr; B.h_rows8 = nullptr; B.tile_lead = nullptr;
         }
         if (c->copies_pending) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_copy[1], 0));   // read ids, INS sequence lengths
         int g_small = B.cap_items < 8192 ? B.cap_items : 8192;

@@ -171,6 +171,7 @@ struct DevBatch {
     const void*    h_b;              // int32 / int64 like `b`
     const int*     h_rid;
     const int*     h_aux;
+    const int2*    h_rows8;          // {b, read_id} interleaved (csv_batch_in.rows8) or NULL: then h_b / h_rid
     int*           tile_lead;        // per chain tile: tile-relative position of its first cluster start (CH_TILE: none) - the rows
                                      // before it belong to a cluster that started in an earlier tile
     // refine outputs
@@ -966,7 +967,10 @@ __global__ __launch_bounds__(256) void k_unpack_a16(UnpackArgs A, DevBatch B)
         if (w < A.W) {
             A.a[w] = v;
             // (gate-first: the (0,0) look-alike rule reads the length of a row at position 0 - see k_lazy_zero)
-            if (CSV_UNLIKELY(A.zero_b && v == 0)) const_cast<int*>(B.b.p32)[w] = ((const int*)B.h_b)[lazy_src(B, seg_of(B, w), w)];
+            if (CSV_UNLIKELY(A.zero_b && v == 0)) {
+                const i64 src = lazy_src(B, seg_of(B, w), w);
+                const_cast<int*>(B.b.p32)[w] = B.h_rows8 ? B.h_rows8[src].x : ((const int*)B.h_b)[src];
+            }
         } else if (w < pad_end) A.a[w] = 1;
     }
 }
@@ -990,7 +994,7 @@ template <bool NARROW> __global__ __launch_bounds__(256) void k_lazy_zero(DevBat
         const bool z = NARROW ? (B.a.p32[w] == 0) : (B.a.p64[w] == 0);
         if (CSV_UNLIKELY(z)) {
             const i64 src = lazy_src(B, seg_of(B, w), w);
-            if constexpr (NARROW) const_cast<int*>(B.b.p32)[w] = ((const int*)B.h_b)[src];
+            if constexpr (NARROW) const_cast<int*>(B.b.p32)[w] = B.h_rows8 ? B.h_rows8[src].x : ((const int*)B.h_b)[src];
             else const_cast<i64*>(B.b.p64)[w] = ((const i64*)B.h_b)[src];
         }
     }
@@ -1052,10 +1056,17 @@ template <bool NARROW> __global__ __launch_bounds__(256) void k_lazy_fetch(DevBa
                 type = B.seg[k].svtype; src = lazy_src(B, k, w);
             }
             on |= 1u << r;
-            vr[r] = B.h_rid[src];
+            bool have_b = false;
+            if constexpr (NARROW) {
+                if (B.h_rows8) {                            // one 8-byte load: {b, read_id} of the row (b is simply not stored for INV / TRA)
+                    const int2 br = B.h_rows8[src];
+                    vr[r] = br.y; vb[r] = br.x; have_b = true;
+                }
+            }
+            if (!have_b) vr[r] = B.h_rid[src];
             if (!pair_type(type)) {                         // (INV / TRA: b and aux came with the bulk copy - the chain kernels read them)
                 wb |= 1u << r;
-                vb[r] = ((const raw_t*)B.h_b)[src];
+                if (!have_b) vb[r] = ((const raw_t*)B.h_b)[src];
                 wx |= 1u << r;                              // (aux of a DEL / DUP row is zero on the device: include/cutesv_hip.h)
                 if (type == CSV_INS) vx[r] = B.h_aux[src];
             }

@@ -132,6 +132,11 @@ typedef struct csv_batch_in {
     int64_t            n_esc;
     const int64_t*     a_esc_row;
     const int32_t*     a_esc_val;
+    /* (ABI v8, optional, with CSV_IN_SIG_I32) the length and read-id columns once more, interleaved: rows8[2 * i] = b[i],
+     * rows8[2 * i + 1] = read_id[i], in page-locked memory.  A gate-first csv_cluster_batch (csv_batch_info 0) then reads the rows of
+     * the clusters that pass the size gate (INDEL:62-64, 86) out of THIS array: a run of ~20 rows is 3-4 PCIe lines of 64 bytes
+     * instead of 2-3 in each of two columns (the fetch is the largest item of such a call).  b and read_id must still be given. */
+    const int32_t*     rows8;
 } csv_batch_in;
 
 /*

@@ -60,6 +60,10 @@ for it in range(n_it):
     # and the same-run tier peek of the one-shot calls on or off
     os.environ["CSV_DELTA16_ESC"] = "0"
     os.environ["CSV_DELTA16_MIN"] = "0" if rng.integers(0, 3) else "1000000000"
+    if rng.integers(0, 3) == 0:
+        os.environ["CSV_NO_ROWS8"] = "1"                  # the gate-first fetch out of the two columns instead of the interleaved rows
+    else:
+        os.environ.pop("CSV_NO_ROWS8", None)
     if rng.integers(0, 4) == 0:
         os.environ["CSV_NO_PEEK"] = "1"
     else:

@@ -1448,11 +1448,16 @@ def test_position_column_as_16_bit_gaps(ctx, monkeypatch):
     def both(pst, hb, st_plain, p, tasks=None):
         assert hb.c.flags & _abi.IN_SIG_DELTA16 and hb.a_delta is not None
         want = _oracle().cluster_batch(st_plain.host_batch(tasks or st_plain.tasks(), p), per_sig=True).trimmed()
+        assert hb.rows8 is not None and hb.c.rows8
         for lazy_min in ("0", "1000000000"):
             monkeypatch.setenv("CSV_LAZY_MIN", lazy_min)
-            got = ctx.cluster_batch(hb, per_sig=True, reuse=True).trimmed()
-            assert ctx.delta16_info()
-            assert_soa_equal(got, want, st_plain)
+            for no_rows8 in (None, "1"):                  # the fetch out of the interleaved {b, read_id} array, or out of the two columns
+                if no_rows8:
+                    monkeypatch.setenv("CSV_NO_ROWS8", no_rows8)
+                got = ctx.cluster_batch(hb, per_sig=True, reuse=True).trimmed()
+                assert ctx.delta16_info() and ctx.lazy_info()[0] == (lazy_min == "0")
+                assert_soa_equal(got, want, st_plain)
+                monkeypatch.delenv("CSV_NO_ROWS8", raising=False)
         monkeypatch.delenv("CSV_LAZY_MIN")
         ctx.upload(hb, per_sig=True)
         assert ctx.delta16_info()
