@@ -1168,19 +1168,26 @@ def test_narrow_input_columns(ctx):
 
 
 # ---------------------------------------------------------------------------------------------- gate-first calls, slim results (ABI v7)
-def _pinned_batch(hb):
-    """the same batch with every column in page-locked memory (what csv_cluster_batch needs to take the gate-first form)"""
+def _pinned_batch(hb, rows8=False):
+    """the same batch with every column in page-locked memory (what csv_cluster_batch needs to take the gate-first form);
+    rows8: int32 positions / lengths and the interleaved {b, read_id} array next to them (ABI v8: the fetch reads that one)"""
     pc = engine.pinned_copy
     kw = {}
     if hb.reads_off is not None:
         kw = dict(reads_off=hb.reads_off, r_start=pc(hb.r_start), r_end=pc(hb.r_end), r_primary=pc(hb.r_primary), r_id=pc(hb.r_id))
-    return _abi.HostBatch(hb.segments, pc(hb.a), pc(hb.b), pc(hb.read_id), pc(hb.aux), n_chrom=hb.n_chrom, contig_len=hb.contig_len,
+    a, b = pc(hb.a), pc(hb.b)
+    if rows8 and hb.n_sig and hb.a.dtype == np.int64 and np.abs(hb.a).max() < (1 << 31) and np.abs(hb.b).max() < (1 << 31):
+        a, b = pc(hb.a.astype(np.int32)), pc(hb.b.astype(np.int32))
+        r8 = engine.pinned_empty((hb.n_sig, 2), np.int32)
+        r8[:, 0], r8[:, 1] = b, hb.read_id
+        kw["rows8"] = r8
+    return _abi.HostBatch(hb.segments, a, b, pc(hb.read_id), pc(hb.aux), n_chrom=hb.n_chrom, contig_len=hb.contig_len,
                           per_sig=bool(hb.c.flags & _abi.IN_PER_SIG), reads_sorted=bool(hb.c.flags & _abi.IN_READS_SORTED), **kw)
 
 
-def _gate_first_engine(ctx):
+def _gate_first_engine(ctx, rows8=False):
     def run(hb):
-        res = ctx.cluster_batch(_pinned_batch(hb), per_sig=True)
+        res = ctx.cluster_batch(_pinned_batch(hb, rows8=rows8), per_sig=True)
         assert ctx.lazy_info()[0], "the call did not take the gate-first form"
         return res
     return run
@@ -1196,14 +1203,18 @@ def test_gate_first_rows_identical_to_reference(ctx, monkeypatch):
             st = store_from_json(case["store"])
             p = Params(**case["params"])
             want = {(t, c): r for t, c, r in case["rows"]}
-            got, res, hb = rows_by_task(st, p, _gate_first_engine(ctx), tasks=list(want.keys()))
-            for key in want:
-                assert_rows_equal(key[0], got[key], want[key], where="gate-first %s %s" % (case["name"], key))
+            for rows8 in (False, True):                    # the fetch out of the columns / out of the interleaved {b, read_id} rows
+                got, res, hb = rows_by_task(st, p, _gate_first_engine(ctx, rows8=rows8), tasks=list(want.keys()))
+                for key in want:
+                    assert_rows_equal(key[0], got[key], want[key], where="gate-first %s %s" % (case["name"], key))
 
 
 def _gate_first_vs_oracle(ctx, st, p):
     hb = st.host_batch(st.tasks(), p)
     want = _oracle().cluster_batch(hb, per_sig=True).trimmed()
+    got8 = ctx.cluster_batch(_pinned_batch(hb, rows8=True), per_sig=True)
+    assert ctx.lazy_info()[0]
+    assert_soa_equal(got8.trimmed(), want, store=st)
     phb = _pinned_batch(hb)
     got = ctx.cluster_batch(phb, per_sig=True)
     assert ctx.lazy_info()[0]
