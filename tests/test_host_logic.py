@@ -362,7 +362,7 @@ def test_bench_reads_its_committed_counter_files():
     assert bench.valu_issue_of("cfg3", 1.0, "k_no_such_kernel", 1.0) is None
     # the one JSON line stays inside the 8 000-byte tail of stdout the driver keeps: the full objects of a run are compacted
     # to named numbers (every key of the contract survives), the detail goes to stderr / gpurun_out
-    with open(os.path.join(ROOT, "profiles", "r05_bench_cfg3.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r06_bench_cfg3.json")) as f:
         full = json.loads(f.read().strip().splitlines()[-1])          # (`bench.py --full`: every object on the line)
     c = bench.compact(dict(full))
     assert c["host_to_host"]["ms"] == pytest.approx(full["host_to_host"]["ms"], rel=1e-3) and c["roofline"]["pcie"]["bytes_up_bulk"] > 0
@@ -373,6 +373,14 @@ def test_bench_reads_its_committed_counter_files():
     assert c["roofline"]["frac"] == pytest.approx(full["roofline"]["frac"], rel=1e-3) and c["roofline"]["bound"] == "hbm" and c["roofline"]["traffic"] == full["roofline"]["traffic"]
     assert c["cpu_baseline"]["value"] == pytest.approx(full["cpu_baseline"]["value"], rel=1e-3) and c["cpu_baseline"]["cores"] == full["cpu_baseline"]["cores"]
     assert set(c["other_workloads"]) == set(full["other_workloads"]) and c["parity_vs_oracle"] is True
+    # round 6: the stage under cuteSV's forked pool for cfg3 and cfg4, what the pool baseline is made of, the name of value's region
+    assert c["value_region"] == "resident_delivered_pipelined"
+    for wl in ("cfg3", "cfg4"):
+        legs = c["mode1_stage"][wl]["legs"]
+        assert [leg["workers"] for leg in legs] == [1, 8, 32]
+        assert all(leg["rows_equal_reference_model"] and leg["wall_ms"] > 0 and leg["vs_reference_pool"] > 1 and leg["pool_alone_ms"] > 0 for leg in legs)
+    assert all(c["cpu_baseline"][k] > 0 for k in ("wall_s", "wall_s_pool_fit", "pool_startup_s", "critical_path_s"))
+    assert c["host_to_host"]["delta16"] is True and c["host_to_host"]["ms"] < 0.5
     r, w = os.pipe()
     saved = bench._OUT_FD
     try:
