@@ -364,3 +364,40 @@ def test_a_worker_survives_its_brokers_death(oracle_broker, tmp_path, monkeypatc
         cl.shutdown()
     resolve._ctx.close()
     resolve._ctx = None
+
+
+def test_warm_up_starts_the_brokers_and_shut_down_stops_them(tmp_path, monkeypatch):
+    """resolve.warm_up() in the pool's parent: one broker per device, named after this process, found by the forked workers through
+    the inherited CUTESV_AMD_BROKER_NAME; the CPU-side state the workers would build in their first task (extension modules, the
+    cal_GL table) is in place before the fork; shut_down() stops the brokers"""
+    from cutesv_amd import genotype
+    monkeypatch.setenv("CUTESV_AMD_TRA_GT", "off")
+    monkeypatch.setenv("CUTESV_AMD_BROKER", "1")
+    monkeypatch.setenv("CUTESV_AMD_DEVICES", "2")
+    monkeypatch.delenv("CUTESV_AMD_BROKER_NAME", raising=False)
+    monkeypatch.setattr(resolve, "_ctx", None)
+    monkeypatch.setattr(broker, "spawn", lambda name, device, watch_pid, linger=None, log=None: subprocess.Popen(
+        [sys.executable, os.path.join(HERE, "broker_oracle.py"), "--name", name, "--device", str(device), "--watch-pid", str(watch_pid), "--linger", "5"],
+        env=dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))))
+    names = resolve.warm_up()
+    try:
+        assert len(names) == 2 and os.environ["CUTESV_AMD_BROKER_NAME"].endswith("-%d" % os.getpid())
+        assert len(genotype._table) >= 5151                               # the whole cal_GL table, inherited by the workers
+        t_end = time.monotonic() + 30
+        while any(broker._try_connect(n) is None for n in names):
+            assert time.monotonic() < t_end
+            time.sleep(0.02)
+        st, p, case = _golden_case("ont_gt")
+        wd = str(tmp_path) + "/"
+        idx = st.write_reference_workdir(wd)
+        results = resolve.main_ctrl_phase3(wd, idx, p, 4)
+        assert sum(len(v) for v in results.values()) == sum(len(rows) for _, _, rows in case["rows"])
+        used = []
+        for d in (0, 1):
+            with broker.Client.connect(d, owner_pid=os.getpid(), spawn=False) as cl:
+                used.append(cl.info()["calls"])
+        assert all(u > 0 for u in used), used
+    finally:
+        resolve.shut_down()
+    assert all(broker._try_connect(n) is None for n in names)
+    assert "CUTESV_AMD_BROKER_NAME" not in os.environ
