@@ -352,8 +352,9 @@ def _try_connect(name):
         return None
 
 
-def spawn(name, device, watch_pid, linger=None, log=None):
-    """start the broker process of `name` (a fresh interpreter: no HIP state is inherited); returns the Popen object"""
+def spawn(name, device, watch_pid, linger=None, log=None, prealloc=None):
+    """start the broker process of `name` (a fresh interpreter: no HIP state is inherited); returns the Popen object.
+    prealloc: "signatures,reads" - staging page-locked before the first request (resolve.warm_up passes it)"""
     import subprocess
     env = dict(os.environ)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -361,6 +362,8 @@ def spawn(name, device, watch_pid, linger=None, log=None):
     cmd = [sys.executable, "-m", "cutesv_amd.broker", "--name", name, "--device", str(device), "--watch-pid", str(watch_pid)]
     if linger is not None:
         cmd += ["--linger", str(linger)]
+    if prealloc:
+        cmd += ["--prealloc", str(prealloc)]
     log = log or os.environ.get("CUTESV_AMD_BROKER_LOG")
     err = open(log, "ab") if log else None
     try:
@@ -438,7 +441,7 @@ class Broker:
     """The serving loop.  `call(handle, cin, cout) -> rc` and `last_error()` come from the engine: libcutesv_hip.so through an
     `engine.Context` in the product; the tests hand in the oracle's entry point to exercise the protocol without a GPU."""
 
-    def __init__(self, name, device=0, watch_pid=0, linger=30.0, engine_factory=None, max_batch=64):
+    def __init__(self, name, device=0, watch_pid=0, linger=30.0, engine_factory=None, max_batch=64, prealloc=None):
         self.name, self.device, self.watch_pid, self.linger = name, int(device), int(watch_pid), float(linger)
         self.max_batch = int(os.environ.get("CUTESV_AMD_BROKER_BATCH", max_batch))
         self.listener = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
@@ -447,6 +450,7 @@ class Broker:
         self.conns = {}
         self.stats = dict(calls=0, batches=0, merged_calls=0, maps=0, max_batch=0, busy_s=0.0)
         self._stage = None
+        self.prealloc = prealloc                      # (signatures, reads): staging and result arrays made before the first request
         self.blocks = {}                              # walked reads blocks the workers share: key -> (memfd, bytes)
         self.block_bytes = 0
         self.block_cap = int(os.environ.get("CUTESV_AMD_BROKER_BLOCKS_MB", "8192")) << 20
@@ -785,7 +789,17 @@ class Broker:
         self.sel = selectors.DefaultSelector()
         self.sel.register(self.listener, selectors.EVENT_READ)
         self._served = False
-        self.engine()                                 # (clients are already queueing on the listening socket)
+        eng = self.engine()                           # (clients are already queueing on the listening socket)
+        if self.prealloc:
+            # a broker started ahead of the stage (resolve.warm_up) also page-locks its staging columns and result arrays now:
+            # grown on demand they cost the FIRST batches of a stage 50-100 ms (hipHostMalloc of a few hundred MB), which a
+            # pool of 32 workers - all of whose first requests arrive together - pays in full
+            try:
+                n, r = int(self.prealloc[0]), int(self.prealloc[1])
+                st = self._staging(eng, n, r, self.max_batch)
+                st["res"] = _abi.HostResult(n, max(64, n // 16 + 16), max(64, n + 16), n_seg=self.max_batch, alloc=eng.alloc, narrow_support=True)
+            except Exception as e:                      # noqa: BLE001  (an optimisation: the broker serves without it)
+                sys.stderr.write("cutesv_amd.broker: staging not pre-allocated (%r)\n" % (e,))
         idle_since = time.monotonic()
         # CUTESV_AMD_BROKER_GATHER_MS: after a request arrives, wait this long for the other workers' requests before
         # launching (0: take what is there - the requests that piled up behind the previous batch are merged anyway)
@@ -887,9 +901,11 @@ def main(argv=None, engine_factory=None):
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--watch-pid", type=int, default=0)
     ap.add_argument("--linger", type=float, default=float(os.environ.get("CUTESV_AMD_BROKER_LINGER", "30")))
+    ap.add_argument("--prealloc", default="", help="signatures,reads: page-lock staging for batches of that size before the first request")
     a = ap.parse_args(argv)
+    pre = tuple(int(x) for x in a.prealloc.split(",")) if a.prealloc else None
     try:
-        b = Broker(a.name, a.device, a.watch_pid, a.linger, engine_factory=engine_factory)
+        b = Broker(a.name, a.device, a.watch_pid, a.linger, engine_factory=engine_factory, prealloc=pre if pre and len(pre) == 2 else None)
     except OSError as e:                              # (somebody else bound the name between our starter's probe and now: fine)
         sys.stderr.write("cutesv_amd.broker: %s is taken (%s)\n" % (a.name, e))
         return 0

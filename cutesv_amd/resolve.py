@@ -114,7 +114,8 @@ def warm_up(devices=None, linger=None):
     for d in devs:
         name = broker.socket_name(os.getpid(), d)
         if broker._try_connect(name) is None:
-            _brokers.append(broker.spawn(name, d, os.getpid(), linger=linger))
+            # (started ahead of the stage, the broker also page-locks staging for batches of this size - signatures, reads - now)
+            _brokers.append(broker.spawn(name, d, os.getpid(), linger=linger, prealloc=os.environ.get("CUTESV_AMD_BROKER_PREALLOC", "4000000,8000000")))
         names.append(name)
     return names
 

@@ -341,7 +341,7 @@ def test_a_worker_survives_its_brokers_death(oracle_broker, tmp_path, monkeypatc
     monkeypatch.setenv("CUTESV_AMD_TRA_GT", "off")
     monkeypatch.setenv("CUTESV_AMD_BROKER", "1")
     monkeypatch.setattr(resolve, "_ctx", None)
-    monkeypatch.setattr(broker, "spawn", lambda name, device, watch_pid, linger=None, log=None: subprocess.Popen(
+    monkeypatch.setattr(broker, "spawn", lambda name, device, watch_pid, linger=None, log=None, prealloc=None: subprocess.Popen(
         [sys.executable, os.path.join(HERE, "broker_oracle.py"), "--name", name, "--device", str(device), "--watch-pid", str(watch_pid), "--linger", "5"],
         env=dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))))
     oracle_broker()
@@ -376,7 +376,7 @@ def test_warm_up_starts_the_brokers_and_shut_down_stops_them(tmp_path, monkeypat
     monkeypatch.setenv("CUTESV_AMD_DEVICES", "2")
     monkeypatch.delenv("CUTESV_AMD_BROKER_NAME", raising=False)
     monkeypatch.setattr(resolve, "_ctx", None)
-    monkeypatch.setattr(broker, "spawn", lambda name, device, watch_pid, linger=None, log=None: subprocess.Popen(
+    monkeypatch.setattr(broker, "spawn", lambda name, device, watch_pid, linger=None, log=None, prealloc=None: subprocess.Popen(
         [sys.executable, os.path.join(HERE, "broker_oracle.py"), "--name", name, "--device", str(device), "--watch-pid", str(watch_pid), "--linger", "5"],
         env=dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))))
     names = resolve.warm_up()
