@@ -18,7 +18,7 @@ ERR_NAME = {OK: "CSV_OK", E_INVALID: "CSV_E_INVALID", E_CAPACITY: "CSV_E_CAPACIT
             E_NOMEM: "CSV_E_NOMEM", E_UNSORTED: "CSV_E_UNSORTED", E_STATE: "CSV_E_STATE"}
 N_STAGES = 24
 GL_TABLE_SIZE = 101 * 101 + 2
-IN_PER_SIG, IN_READS_SORTED, IN_SIG_I32, IN_READS_I32, IN_DEVICE_COLUMNS, IN_SIG_DELTA16 = 1, 2, 4, 8, 16, 32            # csv_batch_in.flags
+IN_PER_SIG, IN_READS_SORTED, IN_SIG_I32, IN_READS_I32, IN_DEVICE_COLUMNS, IN_SIG_DELTA16, IN_READS_DELTA16 = 1, 2, 4, 8, 16, 32, 64     # csv_batch_in.flags
 RB_KEEP_ON_DEVICE = 1
 RB_FROM_POOL = 2                        # ... the rows are the context's device-resident signature pool
 CG_TO_POOL = 1                         # csv_cigar_in.flags: the signatures also become pool rows                         # csv_rebuild_in.flags
@@ -53,6 +53,8 @@ class BatchIn(C.Structure):
         ("flags", C.c_int32), ("reserved", C.c_int32),
         ("a_delta", C.c_void_p), ("n_esc", C.c_int64), ("a_esc_row", C.c_void_p), ("a_esc_val", C.c_void_p),      # ABI v8: CSV_IN_SIG_DELTA16
         ("rows8", C.c_void_p),                                                                                      # ABI v8: {b, read_id} interleaved
+        ("r_delta", C.c_void_p), ("n_r_esc", C.c_int64), ("r_esc_row", C.c_void_p), ("r_esc_val", C.c_void_p),      # ABI v8: CSV_IN_READS_DELTA16
+        ("r_len16", C.c_void_p), ("n_l_esc", C.c_int64), ("l_esc_row", C.c_void_p), ("l_esc_val", C.c_void_p),
     ]
 
 
@@ -91,7 +93,7 @@ class HostBatch:
     """Host-side buffers of one csv_batch_in.  Keeps the numpy arrays alive for the C call."""
 
     def __init__(self, segments, a, b, read_id, aux, n_chrom=0, reads_off=None,
-                 r_start=None, r_end=None, r_primary=None, r_id=None, contig_len=None, per_sig=False, reads_sorted=False, a_delta=None, rows8=None):
+                 r_start=None, r_end=None, r_primary=None, r_id=None, contig_len=None, per_sig=False, reads_sorted=False, a_delta=None, rows8=None, r_delta=None, r_len16=None):
         """a_delta: (delta uint16[n_sig], escape rows int64[], escape values int32[]) of `a` - delta16_of(a) - when the position
         column may cross the link as 16-bit gaps (CSV_IN_SIG_DELTA16; int32 columns only)"""
         self.segments = np.ascontiguousarray(segments, dtype=SEGMENT_DTYPE)
@@ -131,15 +133,31 @@ class HostBatch:
             self.a_delta = (_col(d, np.uint16), _col(er, np.int64), _col(ev, np.int32))
             if self.a_delta[0].shape[0] != n or self.a_delta[1].shape[0] != self.a_delta[2].shape[0]:
                 raise ValueError("a_delta: one gap per signature and one value per escape row are expected")
+        # r_delta / r_len16: (uint16[n_reads], escape rows int64[], escape values int32[]) - delta16_of(r_start), len16_of(r_start, r_end)
+        self.r_delta = self.r_len16 = None
+        if self.r_start is not None and self.r_start.dtype == np.int32:
+            nr = self.r_start.shape[0]
+            for name, v in (("r_delta", r_delta), ("r_len16", r_len16)):
+                if v is not None:
+                    t3 = (_col(v[0], np.uint16), _col(v[1], np.int64), _col(v[2], np.int32))
+                    if t3[0].shape[0] != nr or t3[1].shape[0] != t3[2].shape[0]:
+                        raise ValueError("%s: one entry per read and one value per escape row are expected" % name)
+                    setattr(self, name, t3)
+        rdx = {}
+        if self.r_delta is not None:
+            rdx.update(r_delta=_ptr(self.r_delta[0]), n_r_esc=self.r_delta[1].shape[0], r_esc_row=_ptr(self.r_delta[1]), r_esc_val=_ptr(self.r_delta[2]))
+        if self.r_len16 is not None:
+            rdx.update(r_len16=_ptr(self.r_len16[0]), n_l_esc=self.r_len16[1].shape[0], l_esc_row=_ptr(self.r_len16[1]), l_esc_val=_ptr(self.r_len16[2]))
         self.c = BatchIn(
             n_seg=len(self.segments), n_chrom=self.n_chrom, seg=_ptr(self.segments),
             n_sig=n, a=_ptr(self.a), b=_ptr(self.b), read_id=_ptr(self.read_id), aux=_ptr(self.aux),
-            reads_off=_ptr(self.reads_off),
+            reads_off=_ptr(self.reads_off), **rdx,
             n_reads=0 if self.r_start is None else self.r_start.shape[0],
             r_start=_ptr(self.r_start), r_end=_ptr(self.r_end), r_primary=_ptr(self.r_primary), r_id=_ptr(self.r_id),
             contig_len=_ptr(self.contig_len),
             flags=(IN_PER_SIG if per_sig else 0) | (IN_READS_SORTED if reads_sorted else 0) | (IN_SIG_I32 if self.a.dtype == np.int32 else 0)
-            | (IN_READS_I32 if self.r_start is not None and self.r_start.dtype == np.int32 else 0) | (IN_SIG_DELTA16 if self.a_delta is not None else 0),
+            | (IN_READS_I32 if self.r_start is not None and self.r_start.dtype == np.int32 else 0) | (IN_SIG_DELTA16 if self.a_delta is not None else 0)
+            | (IN_READS_DELTA16 if (self.r_delta is not None or self.r_len16 is not None) else 0),
             a_delta=None if self.a_delta is None else _ptr(self.a_delta[0]), n_esc=0 if self.a_delta is None else self.a_delta[1].shape[0],
             a_esc_row=None if self.a_delta is None else _ptr(self.a_delta[1]), a_esc_val=None if self.a_delta is None else _ptr(self.a_delta[2]),
             rows8=_ptr(self.rows8))
@@ -302,6 +320,18 @@ def delta16_of(a, alloc=None):
     np.copyto(out, np.where(esc, 0xFFFF, d), casting="unsafe")
     rows = np.flatnonzero(esc).astype(np.int64)
     return out, rows, a[rows].astype(np.int32)
+
+
+def len16_of(start, end, alloc=None):
+    """The reads table's end column as CSV_IN_READS_DELTA16 takes it: (lengths uint16[n], escape rows int64[], escape values int32[]);
+    length[i] = end[i] - start[i] where that lies in [0, 0xFFFF), else 0xFFFF with (i, end[i]) in the escape list."""
+    start, end = np.ascontiguousarray(start, np.int32), np.ascontiguousarray(end, np.int32)
+    d = end.astype(np.int64) - start
+    esc = (d < 0) | (d >= 0xFFFF)
+    out = (alloc or (lambda s_, dt: np.empty(s_, dt)))(len(d), np.uint16)
+    np.copyto(out, np.where(esc, 0xFFFF, d), casting="unsafe")
+    rows = np.flatnonzero(esc).astype(np.int64)
+    return out, rows, end[rows].astype(np.int32)
 
 
 def make_segment(svtype, chrom, sig_begin, sig_end, max_cluster_bias, read_count, diff_ratio=0.0,

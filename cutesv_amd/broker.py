@@ -306,8 +306,9 @@ class Client:
             cin = _abi.BatchIn.from_buffer_copy(bytes(batch.c))
             cin.n_chrom, cin.n_sig = n_chrom, n
             cin.a_delta = cin.a_esc_row = cin.a_esc_val = cin.rows8 = None      # (the gap / interleaved forms of a whole store's columns do not travel with a task)
-            cin.n_esc = 0
-            cin.flags &= ~_abi.IN_SIG_DELTA16
+            cin.r_delta = cin.r_esc_row = cin.r_esc_val = cin.r_len16 = cin.l_esc_row = cin.l_esc_val = None
+            cin.n_esc = cin.n_r_esc = cin.n_l_esc = 0
+            cin.flags &= ~(_abi.IN_SIG_DELTA16 | _abi.IN_READS_DELTA16)
             by = dict(cols)
             # positions and lengths travel as int32 when they fit (a genome's coordinates do: CSV_IN_SIG_I32 / CSV_IN_READS_I32):
             # half the bytes through the region, the broker's staging columns and the link

@@ -296,6 +296,16 @@ class SigStore:
             r8[:, 0] = narrow["b"]
             r8[:, 1] = self.read_id
             narrow["rows8"] = r8
+        if "r_start" in narrow and self.n_reads:
+            # ... the reads table's starts as 16-bit gaps and its ends as 16-bit lengths (CSV_IN_READS_DELTA16), each where the
+            # column is not mostly escapes (a shuffled block; ultra-long reads)
+            keep_all = bool(os.environ.get("CSV_DELTA16_ESC"))
+            rd = _abi.delta16_of(narrow["r_start"], alloc=engine.pinned_empty)
+            if keep_all or len(rd[1]) * 64 <= len(rd[0]):
+                narrow["r_delta"] = rd
+            rl = _abi.len16_of(narrow["r_start"], narrow["r_end"], alloc=engine.pinned_empty)
+            if keep_all or len(rl[1]) * 64 <= len(rl[0]):
+                narrow["r_len16"] = rl
         if "a" in narrow:
             # ... and the position column once more as 16-bit gaps (CSV_IN_SIG_DELTA16): half of the largest transfer of a call
             ad = _abi.delta16_of(narrow["a"], alloc=engine.pinned_empty)
@@ -404,6 +414,8 @@ class SigStore:
         if need_reads and self.reads_off is not None:
             kw = dict(reads_off=self.reads_off, r_start=nw.get("r_start", self.r_start), r_end=nw.get("r_end", self.r_end),
                       r_primary=self.r_primary, r_id=self.r_id)
+            if os.environ.get("CUTESV_AMD_NO_DELTA16") is None:
+                kw.update(r_delta=nw.get("r_delta"), r_len16=nw.get("r_len16"))
             if bool(((segs["svtype"] == _abi.TRA) & (segs["genotype"] != 0)).any()):
                 kw["contig_len"] = self.contig_len
         return _abi.HostBatch(segs, nw.get("a", self.a), nw.get("b", self.b), self.read_id, self.aux, n_chrom=len(self.chroms),

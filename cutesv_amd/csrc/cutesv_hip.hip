@@ -120,6 +120,8 @@ struct csv_ctx {
     Buf seg, woff, seg_drop, a, b, rid, aux, a32, b32;
     Buf tile_lead, tabs;
     Buf ad16, anc;                             // CSV_IN_SIG_DELTA16: the gaps in w space; the anchor tables {per-tile offsets, w, value}
+    Buf rd16, ranc, rl16, rlesc;               // CSV_IN_READS_DELTA16: start gaps + their anchors, lengths + their escape rows / values
+    int  reads_delta = 0;                      // bit 0: the last upload's reads starts crossed as gaps, bit 1: its ends as lengths (csv_batch_info 3)
     bool delta16 = false;                      // the last upload rebuilt its position column from gaps (csv_batch_info 2)
     bool rstate_dirty = true;                  // the reads-order state may hold an earlier upload's verdict
     bool unpack_pending = false; UnpackArgs unpack_args{}; int unpack_tiles = 0;      // ... and k_unpack_a16 is still to be queued (one-shot calls: by the run)
@@ -480,6 +482,7 @@ int csv_batch_info(const csv_ctx* c, int which, int64_t* value)
     if (which == 0) *value = c->partial_cols ? 1 : 0;
     else if (which == 1) *value = c->lazy_bytes;
     else if (which == 2) *value = c->delta16 ? 1 : 0;
+    else if (which == 3) *value = c->reads_delta;
     else return CSV_E_INVALID;
     return CSV_OK;
 }
@@ -619,16 +622,25 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
     if (R > 0) while (pool_n < 2 * (2 * rc_max + maxseg_gt) + 4096 || pool_n < 64 * tra_gt_len + 8192) { pool_n <<= 1; if (pool_n >= (1ll << 32)) break; }
     Plan P;
 #define PL(buf, bytes) P.add(c->buf, (size_t)(bytes))
+    const bool sig32 = (in->flags & CSV_IN_SIG_I32) != 0, rd32 = (in->flags & CSV_IN_READS_I32) != 0;
+    // CSV_IN_READS_DELTA16: starts as gaps / ends as lengths, each only where escapes are rare (host work per escape, nothing saved)
+    const bool rdz = rd32 && R > (i64)env_int("CSV_DELTA16_MIN", 32 << 10) && (in->flags & CSV_IN_READS_DELTA16) && !getenv("CSV_NO_DELTA16");
+    const i64 esc_per = (i64)env_int("CSV_DELTA16_ESC", 64);
+    const bool r_gaps = rdz && in->r_delta && in->r_start && in->n_r_esc >= 0 && (in->n_r_esc == 0 || (in->r_esc_row && in->r_esc_val)) && in->n_r_esc * esc_per <= R;
+    const bool r_lens = rdz && in->r_len16 && in->n_l_esc >= 0 && (in->n_l_esc == 0 || (in->l_esc_row && in->l_esc_val)) && in->n_l_esc * esc_per <= R;
+    const i64 r_ntile = div_up(R, CH_TILE), r_anc_cap = r_gaps ? (r_ntile + in->n_chrom + in->n_r_esc + 8) : 0;
+    c->reads_delta = (r_gaps ? 1 : 0) | (r_lens ? 2 : 0);
     // the small tables (segments, prefix, drop marks, gate records, status words, chain tile records) are ONE block laid out like
     // their page-locked staging copy: one DMA copy brings them all (r04: five blit kernels of ~5 us each in front of the columns)
     const size_t o_seg = 0, o_woff = o_seg + (size_t)(S + 1) * sizeof(csv_segment), o_drop = o_woff + (size_t)(S + 2) * 8,
                  o_gate = (o_drop + (size_t)S + 1 + 15) & ~(size_t)15, o_serr = o_gate + (size_t)(S + 1) * 16,
                  o_tiles = (o_serr + (size_t)(S + 1) * 4 + 15) & ~(size_t)15, o_end = o_tiles + (size_t)nt * TILE_REC * 16,
                  o_ones = (o_end + 255) & ~(size_t)255, ones_bytes = (size_t)(CH_TILE + 64) * 8, o_anc = o_ones + ones_bytes,
-                 anc_bytes = delta16 ? (size_t)(div_up(W, CH_TILE) + 2 + 2 * n_anc_cap) * 4 : 0, o_stage_end = o_anc + ((anc_bytes + 255) & ~(size_t)255);
+                 anc_bytes = delta16 ? (size_t)(div_up(W, CH_TILE) + 2 + 2 * n_anc_cap) * 4 : 0, o_ranc = o_anc + ((anc_bytes + 255) & ~(size_t)255),
+                 ranc_bytes = r_gaps ? (size_t)(r_ntile + 2 + 2 * r_anc_cap) * 4 : 0, o_lesc = o_ranc + ((ranc_bytes + 255) & ~(size_t)255),
+                 lesc_bytes = r_lens ? (size_t)(in->n_l_esc + 1) * 12 : 0, o_stage_end = o_lesc + ((lesc_bytes + 255) & ~(size_t)255);
     PL(tabs, o_end);
     // positions and lengths stay in the width they arrive in: the kernels read int32 columns as they are (kernels.hip.h Col)
-    const bool sig32 = (in->flags & CSV_IN_SIG_I32) != 0, rd32 = (in->flags & CSV_IN_READS_I32) != 0;
     // (the position column is followed by a tile of padding, so that the chain kernel can read any span that begins inside the batch)
     if (sig32) { PL(a32, (W + CH_TILE + 64) * 4); PL(b32, (W + 1) * 4); } else { PL(a, (W + CH_TILE + 64) * 8); PL(b, (W + 1) * 8); }
     PL(rid, (W + 1) * 4); PL(aux, (W + 1) * 4);
@@ -652,6 +664,8 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
         // the table as uploaded and its packed start-ordered form, both in the caller's width (int32: 13 + 12 bytes per read)
         const size_t cw = rd32 ? 4 : 8;
         PL(r_start, R * cw); PL(r_end, R * cw); PL(r_primary, R); PL(r_id, R * 4);
+        if (r_gaps) { PL(rd16, (R + CH_TILE + 64) * 2); PL(ranc, (size_t)(r_ntile + 2 + 2 * r_anc_cap) * 4); }
+        if (r_lens) { PL(rl16, (R + 64) * 2); PL(rlesc, (size_t)(in->n_l_esc + 1) * 12); }
         PL(s_start, (R + 64) * cw); PL(s_end, (R + 64) * cw); PL(s_idp, (R + 64) * 4);      // (whole chunks of 64 rows are read)
         PL(cmax, (div_up(R, 64) + 136) * 8); PL(span_len, (div_up(R, 512) + 8) * 8); PL(cfirst, (div_up(R, 64) + 136) * 8); PL(bfirst, (div_up(R, 4096) + 136) * 8);      // (+ two steps of padding: k_genotype reads 128 entries from any valid one)
         PL(maxlen, (in->n_chrom + 1) * 8);
@@ -848,10 +862,49 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
     }
     if (R > 0) {
         const size_t cw = rd32 ? 4 : 8;
-        HIP_TRY(c, hipMemcpyAsync(c->r_start.p, in->r_start, R * cw, hipMemcpyHostToDevice, sr));
-        HIP_TRY(c, hipMemcpyAsync(c->r_end.p, in->r_end, R * cw, hipMemcpyHostToDevice, sr));
+        if (r_gaps) HIP_TRY(c, hipMemcpyAsync(c->rd16.p, in->r_delta, (size_t)R * 2, hipMemcpyHostToDevice, sr));
+        else HIP_TRY(c, hipMemcpyAsync(c->r_start.p, in->r_start, R * cw, hipMemcpyHostToDevice, sr));
+        if (r_lens) HIP_TRY(c, hipMemcpyAsync(c->rl16.p, in->r_len16, (size_t)R * 2, hipMemcpyHostToDevice, sr));
+        else HIP_TRY(c, hipMemcpyAsync(c->r_end.p, in->r_end, R * cw, hipMemcpyHostToDevice, sr));
         HIP_TRY(c, hipMemcpyAsync(c->r_primary.p, in->r_primary, R, hipMemcpyHostToDevice, sr));
         HIP_TRY(c, hipMemcpyAsync(c->r_id.p, in->r_id, R * 4, hipMemcpyHostToDevice, sr));
+        if (r_gaps) {
+            // anchors of the start column, built while the table is on the link: the first row of every tile of 2048 rows, the
+            // first row of every chromosome block, the caller's escape rows (the first row of every sorted run is one) - rows of
+            // the table itself: no w space here.  They follow the table on its own stream (page-locked staging: h_ranc).
+            const int32_t* hs = (const int32_t*)in->r_start;
+            std::vector<std::pair<i64, int>> anc;
+            anc.reserve((size_t)r_anc_cap);
+            for (i64 t = 0; t < r_ntile; t++) anc.emplace_back(t * (i64)CH_TILE, hs[t * (i64)CH_TILE]);
+            for (int k = 0; k < in->n_chrom; k++) { const i64 r0 = in->reads_off[k]; if (r0 >= 0 && r0 < R) anc.emplace_back(r0, hs[r0]); }
+            for (i64 e = 0; e < in->n_r_esc; e++) { const i64 r0 = in->r_esc_row[e]; if (r0 >= 0 && r0 < R) anc.emplace_back(r0, in->r_esc_val[e]); }
+            std::sort(anc.begin(), anc.end());
+            anc.erase(std::unique(anc.begin(), anc.end(), [](const std::pair<i64, int>& x, const std::pair<i64, int>& y) { return x.first == y.first; }), anc.end());
+            int* h_off = (int*)(c->h_pin + o_ranc);          // (page-locked staging: a copy out of pageable memory would block the host
+                                                             // until the table in front of it on this stream has crossed the link)
+            int* h_w = h_off + r_ntile + 2;
+            int* h_v = h_w + r_anc_cap;
+            size_t q = 0;
+            for (i64 t = 0; t <= r_ntile; t++) { while (q < anc.size() && anc[q].first < t * (i64)CH_TILE) q++; h_off[t] = (int)q; }
+            h_off[r_ntile + 1] = (int)anc.size();
+            for (size_t i = 0; i < anc.size(); i++) { h_w[i] = (int)anc[i].first; h_v[i] = anc[i].second; }
+            HIP_TRY(c, hipMemcpyAsync(c->ranc.p, h_off, ranc_bytes, hipMemcpyHostToDevice, sr));
+            UnpackArgs UA{dp<uint16_t>(c->rd16), dp<int>(c->r_start), R, dp<int>(c->ranc), dp<int>(c->ranc) + r_ntile + 2, dp<int>(c->ranc) + r_ntile + 2 + r_anc_cap, (int)r_ntile, 0, 0};
+            DevBatch none;
+            memset(&none, 0, sizeof none);
+            hipLaunchKernelGGL(k_unpack_a16, dim3((unsigned)r_ntile), dim3(256), 0, sr, UA, none);
+        }
+        if (r_lens) {
+            hipLaunchKernelGGL(k_reads_end16, dim3(div_up(R, 256)), dim3(256), 0, sr, (const int*)dp<int>(c->r_start), (const uint16_t*)dp<uint16_t>(c->rl16), dp<int>(c->r_end), R);
+            if (in->n_l_esc > 0) {
+                char* base = (char*)c->rlesc.p;
+                char* hst = c->h_pin + o_lesc;                // (through the page-locked staging, as above)
+                memcpy(hst, in->l_esc_row, (size_t)in->n_l_esc * 8);
+                memcpy(hst + (size_t)in->n_l_esc * 8, in->l_esc_val, (size_t)in->n_l_esc * 4);
+                HIP_TRY(c, hipMemcpyAsync(base, hst, (size_t)in->n_l_esc * 12, hipMemcpyHostToDevice, sr));
+                hipLaunchKernelGGL(k_scatter_rows_i32, dim3(div_up(in->n_l_esc, 256)), dim3(256), 0, sr, (const i64*)base, (const int*)(base + (size_t)in->n_l_esc * 8), dp<int>(c->r_end), in->n_l_esc, R);
+            }
+        }
     }
     // (the main stream does not wait for the reads table: the kernels that read it are ordered behind this event)
     if (have_tab) HIP_TRY(c, hipEventRecord(c->ev_reads, sr));
@@ -862,7 +915,7 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
         // between the column copies delayed the copies behind it until the reads table had left the copy engine (1.77 -> 2.82 ms);
         // queued from here in a one-shot call, after the last copy, the launch itself blocked the host for 1.1 ms.
         const i64 ntile = div_up(W, CH_TILE);
-        c->unpack_args = UnpackArgs{dp<uint16_t>(c->ad16), dp<int>(c->a32), W, dp<int>(c->anc), dp<int>(c->anc) + ntile + 2, dp<int>(c->anc) + ntile + 2 + n_anc_cap, (int)ntile, 0};
+        c->unpack_args = UnpackArgs{dp<uint16_t>(c->ad16), dp<int>(c->a32), W, dp<int>(c->anc), dp<int>(c->anc) + ntile + 2, dp<int>(c->anc) + ntile + 2 + n_anc_cap, (int)ntile, 0, 1};
         c->unpack_tiles = (int)ntile;
         c->unpack_pending = true;
         if (sync) {

@@ -914,6 +914,8 @@ struct UnpackArgs {
     const int*      anc_val;
     int             ntile;      // chain tiles; workgroup `ntile` only writes padding
     int             zero_b;     // gate-first call: also fetch `b` of the rows at position 0 (what k_lazy_zero does, below)
+    int             pad;        // 1: the column is followed by a tile + 64 rows of padding (ones); 0: nothing is written past W (the
+                                // reads table's start column, CSV_IN_READS_DELTA16)
 };
 __device__ __forceinline__ i64 lazy_src(const DevBatch& B, int k, i64 w);
 __global__ __launch_bounds__(256) void k_unpack_a16(UnpackArgs A, DevBatch B)
@@ -923,7 +925,7 @@ __global__ __launch_bounds__(256) void k_unpack_a16(UnpackArgs A, DevBatch B)
     // the padding behind the column (positive values: the chain kernel reads any span that begins inside the batch without a
     // range test) is written here too - a DMA copy of a block of ones in front of the column was a blit kernel and an engine
     // switch of its own (5 + 8 us of the one-shot call's timeline)
-    const i64 pad_end = A.W + CH_TILE + 64;
+    const i64 pad_end = A.pad ? A.W + CH_TILE + 64 : A.W;
     if (tile >= A.ntile) {
         for (i64 w = (i64)A.ntile * CH_TILE + t; w < pad_end; w += 256) A.a[w] = 1;
         return;
@@ -973,6 +975,19 @@ __global__ __launch_bounds__(256) void k_unpack_a16(UnpackArgs A, DevBatch B)
             }
         } else if (w < pad_end) A.a[w] = 1;
     }
+}
+
+// CSV_IN_READS_DELTA16: the reads table's end column from 16-bit lengths (behind k_unpack_a16 for the starts, or on the starts
+// as they were copied), then the few rows whose length does not fit - their ends travel as they are
+__global__ __launch_bounds__(256) void k_reads_end16(const int* start, const uint16_t* len16, int* end, i64 n)
+{
+    const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) end[i] = start[i] + (int)len16[i];
+}
+__global__ __launch_bounds__(256) void k_scatter_rows_i32(const i64* row, const int* val, int* out, i64 n_esc, i64 n)
+{
+    const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (i < n_esc) { const i64 r = row[i]; if (r >= 0 && r < n) out[r] = val[i]; }
 }
 
 // ------------------------------------------------------------------------------------ gate-first fetch

@@ -117,6 +117,12 @@ class Context:
         self._check(lib().csv_batch_info(self._h, 1, C.byref(b)))
         return bool(a.value), int(b.value)
 
+    def reads_delta_info(self):
+        """bit 0: the last upload's reads starts crossed as 16-bit gaps, bit 1: its ends as 16-bit lengths (CSV_IN_READS_DELTA16)"""
+        a = C.c_int64(0)
+        self._check(lib().csv_batch_info(self._h, 3, C.byref(a)))
+        return int(a.value)
+
     def delta16_info(self):
         """did the last upload send its position column as 16-bit gaps (CSV_IN_SIG_DELTA16)?  csv_batch_info(2)"""
         a = C.c_int64(0)

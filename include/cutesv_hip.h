@@ -100,6 +100,10 @@ enum {
                                  a csv_rebuild_signatures call with CSV_RB_KEEP_ON_DEVICE): the columns move device to device
                                  (HBM rate) instead of crossing PCIe twice; the reference's dataflow rebuild -> cluster
                                  (MAIN:750-857 -> 1113-1199) without a host round trip */
+    CSV_IN_READS_DELTA16 = 64, /* (ABI v8, with CSV_IN_READS_I32) r_delta / r_len16 (either or both) are given: the reads table's start column
+                                 crosses the link as 16-bit gaps (a block is a concatenation of start-sorted runs, MAIN:697-735, 810: a 30x
+                                 genome's neighbours are ~0.5 kb apart) and its end column as 16-bit lengths (HiFi reads are < 64 kb), both
+                                 rebuilt on the device: 13 -> 9 bytes per read, the bulk of a genotyping call's upload */
     CSV_IN_SIG_DELTA16 = 32   /* (ABI v8, with CSV_IN_SIG_I32, host columns) a_delta / a_esc_* are given: the position column crosses
                                  the link as 16-bit gaps - the rebuild order (MAIN:764-802) makes it non-decreasing inside a segment,
                                  a 30x genome's neighbours are ~1 kb apart - and is rebuilt on the device (k_unpack_a16): 11.1 -> 5.6 MB
@@ -137,6 +141,19 @@ typedef struct csv_batch_in {
      * the clusters that pass the size gate (INDEL:62-64, 86) out of THIS array: a run of ~20 rows is 3-4 PCIe lines of 64 bytes
      * instead of 2-3 in each of two columns (the fetch is the largest item of such a call).  b and read_id must still be given. */
     const int32_t*     rows8;
+    /* (ABI v8) CSV_IN_READS_DELTA16.  r_delta[i] = r_start[i] - r_start[i - 1] where that lies in [0, 0xFFFF) and i > 0, else 0xFFFF and
+     * row i is listed in r_esc_row (ascending) with r_esc_val = r_start[i] (the first row of every sorted run is one).  r_len16[i] =
+     * r_end[i] - r_start[i] where that lies in [0, 0xFFFF), else 0xFFFF and row i is listed in l_esc_row (ascending) with l_esc_val =
+     * r_end[i].  n_reads entries each; r_start / r_end must still be given (the library reads a few rows of r_start on the host).
+     * Either pointer may be NULL.  A column that is mostly escapes (shuffled blocks; ultra-long reads for r_len16) travels as itself. */
+    const uint16_t*    r_delta;
+    int64_t            n_r_esc;
+    const int64_t*     r_esc_row;
+    const int32_t*     r_esc_val;
+    const uint16_t*    r_len16;
+    int64_t            n_l_esc;
+    const int64_t*     l_esc_row;
+    const int32_t*     l_esc_val;
 } csv_batch_in;
 
 /*
@@ -274,7 +291,8 @@ int csv_batch_reads_mode(const csv_ctx* ctx);
  * gate-first form (page-locked b / read_id / aux columns: only the position column travels in bulk, the rows of the clusters
  * that pass the size gate - INDEL:62-64, 86 - are read out of the caller's columns by the device), else 0; which = 1: the
  * bytes of signature columns the bulk copy therefore did not send (ABI v8: including the half of the position column that
- * CSV_IN_SIG_DELTA16 saves); which = 2 (ABI v8): 1 when the position column crossed as 16-bit gaps.  A measurement aid
+ * CSV_IN_SIG_DELTA16 saves); which = 2 (ABI v8): 1 when the position column crossed as 16-bit gaps; which = 3 (ABI v8): bit 0 / bit 1 when the reads table's
+ * starts / ends crossed as 16-bit gaps / lengths.  A measurement aid
  * (bench.py's pcie object). */
 int csv_batch_info(const csv_ctx* ctx, int which, int64_t* value);
 /* Context options.  CSV_OPT_REUSE_READS_ORDER (default 1): the start-ordered, packed copy of the reads table that the first

@@ -1528,3 +1528,57 @@ def test_position_column_as_16_bit_gaps(ctx, monkeypatch):
     got = ctx.cluster_batch(hb3, per_sig=True, reuse=True).trimmed()
     assert not ctx.delta16_info()
     assert_soa_equal(got, _oracle().cluster_batch(_abi.HostBatch(segs2, st.a, st.b, st.read_id, st.aux, n_chrom=len(st.chroms)), per_sig=True).trimmed(), st)
+
+
+@pytest.mark.parametrize("order", ["sorted", "extraction", "shuffled"])
+def test_reads_table_as_16_bit_gaps_and_lengths(ctx, monkeypatch, order):
+    """CSV_IN_READS_DELTA16 (ABI v8): the reads table's start column as 16-bit gaps (+ the escape rows: the first row of every sorted
+    run, any gap that does not fit) and its end column as 16-bit lengths (+ the reads of 64 kb and more), rebuilt on the device
+    before the reads are ordered - bit for bit what the columns themselves give, whatever the order of the table (a shuffled block
+    is all escapes), with long reads, one-shot and resident, next to the signature column's own gap form"""
+    monkeypatch.setenv("CSV_DELTA16_MIN", "0")
+    monkeypatch.setenv("CSV_DELTA16_ESC", "0")
+    monkeypatch.setenv("CSV_READS_GAP", "30000")
+    import dataclasses
+    rng = np.random.default_rng(17)
+    for seed, kw, p in ((71, dict(n_sites=40, coverage=30), Params.ont(genotype=True, min_support=3)),
+                        (72, dict(n_sites=25, coverage=60, contig_len=2_000_000, n_contigs=4, n_noise=500), Params.hifi(genotype=True, min_support=3)),
+                        (73, dict(n_sites=30, coverage=25, n_contigs=5), Params(genotype=True, min_support=2, max_cluster_bias_INV=2000))):
+        st = synth.small_mixed(seed=seed, genotype=True, **kw)
+        # a share of very long reads: lengths that do not fit 16 bits
+        long_ = rng.random(st.n_reads) < 0.07
+        r_end = st.r_end.copy()
+        r_end[long_] = st.r_start[long_] + rng.integers(65_535, 900_000, int(long_.sum()))
+        st = dataclasses.replace(st, r_end=r_end)
+        if order == "extraction":
+            st, _ = synth.extraction_order(st, seed=seed, region=150_000, workers=5)
+        elif order == "shuffled":
+            perm = np.arange(st.n_reads)
+            for c in range(len(st.chroms)):
+                lo, hi = int(st.reads_off[c]), int(st.reads_off[c + 1])
+                perm[lo:hi] = lo + rng.permutation(hi - lo)
+            st = dataclasses.replace(st, r_start=st.r_start[perm], r_end=st.r_end[perm], r_primary=st.r_primary[perm], r_id=st.r_id[perm])
+        pst = st.pinned()
+        hb = pst.host_batch(pst.tasks(), p)
+        assert hb.r_delta is not None and hb.r_len16 is not None and hb.c.flags & _abi.IN_READS_DELTA16
+        assert len(hb.r_len16[1]) > 0                                        # some ends travel as escapes
+        want = _oracle().cluster_batch(st.host_batch(st.tasks(), p), per_sig=True).trimmed()
+        got = ctx.cluster_batch(hb, per_sig=True, reuse=True).trimmed()
+        assert ctx.reads_delta_info() == 3
+        assert_soa_equal(got, want, st)
+        assert (got["dr"] > 0).any()
+        ctx.upload(hb, per_sig=True)
+        assert ctx.reads_delta_info() == 3
+        ctx.run(); ctx.run()
+        assert_soa_equal(ctx.download(per_sig=True).trimmed(), want, st)
+        # only one of the two columns in its 16-bit form; neither
+        for drop in ("r_delta", "r_len16"):
+            hb1 = _abi.HostBatch(hb.segments, hb.a, hb.b, hb.read_id, hb.aux, n_chrom=hb.n_chrom, reads_off=hb.reads_off, r_start=hb.r_start, r_end=hb.r_end,
+                                 r_primary=hb.r_primary, r_id=hb.r_id, contig_len=hb.contig_len,
+                                 r_delta=None if drop == "r_delta" else hb.r_delta, r_len16=None if drop == "r_len16" else hb.r_len16)
+            assert_soa_equal(ctx.cluster_batch(hb1, per_sig=True, reuse=True).trimmed(), want, st)
+            assert ctx.reads_delta_info() == (2 if drop == "r_delta" else 1)
+        monkeypatch.setenv("CSV_NO_DELTA16", "1")
+        assert_soa_equal(ctx.cluster_batch(hb, per_sig=True, reuse=True).trimmed(), want, st)
+        assert ctx.reads_delta_info() == 0
+        monkeypatch.delenv("CSV_NO_DELTA16")
