@@ -55,6 +55,7 @@ class BatchIn(C.Structure):
         ("rows8", C.c_void_p),                                                                                      # ABI v8: {b, read_id} interleaved
         ("r_delta", C.c_void_p), ("n_r_esc", C.c_int64), ("r_esc_row", C.c_void_p), ("r_esc_val", C.c_void_p),      # ABI v8: CSV_IN_READS_DELTA16
         ("r_len16", C.c_void_p), ("n_l_esc", C.c_int64), ("l_esc_row", C.c_void_p), ("l_esc_val", C.c_void_p),
+        ("r_idp", C.c_void_p),                                                                                      # ABI v8: r_id | r_primary << 31
     ]
 
 
@@ -93,7 +94,7 @@ class HostBatch:
     """Host-side buffers of one csv_batch_in.  Keeps the numpy arrays alive for the C call."""
 
     def __init__(self, segments, a, b, read_id, aux, n_chrom=0, reads_off=None,
-                 r_start=None, r_end=None, r_primary=None, r_id=None, contig_len=None, per_sig=False, reads_sorted=False, a_delta=None, rows8=None, r_delta=None, r_len16=None):
+                 r_start=None, r_end=None, r_primary=None, r_id=None, contig_len=None, per_sig=False, reads_sorted=False, a_delta=None, rows8=None, r_delta=None, r_len16=None, r_idp=None):
         """a_delta: (delta uint16[n_sig], escape rows int64[], escape values int32[]) of `a` - delta16_of(a) - when the position
         column may cross the link as 16-bit gaps (CSV_IN_SIG_DELTA16; int32 columns only)"""
         self.segments = np.ascontiguousarray(segments, dtype=SEGMENT_DTYPE)
@@ -144,6 +145,12 @@ class HostBatch:
                         raise ValueError("%s: one entry per read and one value per escape row are expected" % name)
                     setattr(self, name, t3)
         rdx = {}
+        self.r_idp = None
+        if r_idp is not None and self.r_id is not None:
+            self.r_idp = _col(r_idp, np.uint32)
+            if self.r_idp.shape[0] != self.r_id.shape[0]:
+                raise ValueError("r_idp: one word per read is expected")
+            rdx["r_idp"] = _ptr(self.r_idp)
         if self.r_delta is not None:
             rdx.update(r_delta=_ptr(self.r_delta[0]), n_r_esc=self.r_delta[1].shape[0], r_esc_row=_ptr(self.r_delta[1]), r_esc_val=_ptr(self.r_delta[2]))
         if self.r_len16 is not None:

@@ -306,7 +306,7 @@ class Client:
             cin = _abi.BatchIn.from_buffer_copy(bytes(batch.c))
             cin.n_chrom, cin.n_sig = n_chrom, n
             cin.a_delta = cin.a_esc_row = cin.a_esc_val = cin.rows8 = None      # (the gap / interleaved forms of a whole store's columns do not travel with a task)
-            cin.r_delta = cin.r_esc_row = cin.r_esc_val = cin.r_len16 = cin.l_esc_row = cin.l_esc_val = None
+            cin.r_delta = cin.r_esc_row = cin.r_esc_val = cin.r_len16 = cin.l_esc_row = cin.l_esc_val = cin.r_idp = None
             cin.n_esc = cin.n_r_esc = cin.n_l_esc = 0
             cin.flags &= ~(_abi.IN_SIG_DELTA16 | _abi.IN_READS_DELTA16)
             by = dict(cols)

@@ -296,6 +296,11 @@ class SigStore:
             r8[:, 0] = narrow["b"]
             r8[:, 1] = self.read_id
             narrow["rows8"] = r8
+        if self.r_id is not None and self.n_reads and int(self.r_id.min()) >= 0:
+            # ... the read id and the primary flag in one word (the form the device keeps them in): 5 -> 4 bytes per read on the link
+            idp = engine.pinned_empty(self.n_reads, np.uint32)
+            np.copyto(idp, self.r_id.astype(np.uint32) | (self.r_primary.astype(np.uint32) << np.uint32(31)), casting="unsafe")
+            narrow["r_idp"] = idp
         if "r_start" in narrow and self.n_reads:
             # ... the reads table's starts as 16-bit gaps and its ends as 16-bit lengths (CSV_IN_READS_DELTA16), each where the
             # column is not mostly escapes (a shuffled block; ultra-long reads)
@@ -415,7 +420,7 @@ class SigStore:
             kw = dict(reads_off=self.reads_off, r_start=nw.get("r_start", self.r_start), r_end=nw.get("r_end", self.r_end),
                       r_primary=self.r_primary, r_id=self.r_id)
             if os.environ.get("CUTESV_AMD_NO_DELTA16") is None:
-                kw.update(r_delta=nw.get("r_delta"), r_len16=nw.get("r_len16"))
+                kw.update(r_delta=nw.get("r_delta"), r_len16=nw.get("r_len16"), r_idp=nw.get("r_idp"))
             if bool(((segs["svtype"] == _abi.TRA) & (segs["genotype"] != 0)).any()):
                 kw["contig_len"] = self.contig_len
         return _abi.HostBatch(segs, nw.get("a", self.a), nw.get("b", self.b), self.read_id, self.aux, n_chrom=len(self.chroms),

@@ -866,8 +866,17 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
         else HIP_TRY(c, hipMemcpyAsync(c->r_start.p, in->r_start, R * cw, hipMemcpyHostToDevice, sr));
         if (r_lens) HIP_TRY(c, hipMemcpyAsync(c->rl16.p, in->r_len16, (size_t)R * 2, hipMemcpyHostToDevice, sr));
         else HIP_TRY(c, hipMemcpyAsync(c->r_end.p, in->r_end, R * cw, hipMemcpyHostToDevice, sr));
-        HIP_TRY(c, hipMemcpyAsync(c->r_primary.p, in->r_primary, R, hipMemcpyHostToDevice, sr));
-        HIP_TRY(c, hipMemcpyAsync(c->r_id.p, in->r_id, R * 4, hipMemcpyHostToDevice, sr));
+        const bool r_packed = in->r_idp != nullptr && rd32 && !getenv("CSV_NO_DELTA16");
+        if (r_packed) {
+            // (the packed word lands where the packed start-ordered table will be built - s_idp is not written before k_reads_gather -
+            // and is split into the two columns the reads stage reads)
+            HIP_TRY(c, hipMemcpyAsync(c->s_idp.p, in->r_idp, (size_t)R * 4, hipMemcpyHostToDevice, sr));
+            hipLaunchKernelGGL(k_reads_split_idp, dim3(div_up(R, 256)), dim3(256), 0, sr, (const unsigned*)c->s_idp.p, dp<int>(c->r_id), dp<uint8_t>(c->r_primary), R);
+            c->reads_delta |= 4;
+        } else {
+            HIP_TRY(c, hipMemcpyAsync(c->r_primary.p, in->r_primary, R, hipMemcpyHostToDevice, sr));
+            HIP_TRY(c, hipMemcpyAsync(c->r_id.p, in->r_id, R * 4, hipMemcpyHostToDevice, sr));
+        }
         if (r_gaps) {
             // anchors of the start column, built while the table is on the link: the first row of every tile of 2048 rows, the
             // first row of every chromosome block, the caller's escape rows (the first row of every sorted run is one) - rows of

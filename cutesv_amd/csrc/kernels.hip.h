@@ -984,6 +984,12 @@ __global__ __launch_bounds__(256) void k_reads_end16(const int* start, const uin
     const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
     if (i < n) end[i] = start[i] + (int)len16[i];
 }
+// csv_batch_in.r_idp: the read id and the primary flag arrive as one word; the kernels of the reads stage read two columns
+__global__ __launch_bounds__(256) void k_reads_split_idp(const unsigned* idp, int* id, uint8_t* primary, i64 n)
+{
+    const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) { const unsigned v = idp[i]; id[i] = (int)(v & 0x7fffffffu); primary[i] = (uint8_t)(v >> 31); }
+}
 __global__ __launch_bounds__(256) void k_scatter_rows_i32(const i64* row, const int* val, int* out, i64 n_esc, i64 n)
 {
     const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;

@@ -154,6 +154,10 @@ typedef struct csv_batch_in {
     int64_t            n_l_esc;
     const int64_t*     l_esc_row;
     const int32_t*     l_esc_val;
+    /* (ABI v8, optional) r_idp[i] = r_id[i] | r_primary[i] << 31: the read id and the primary flag in one word (the form the device
+     * keeps them in anyway).  When given, r_primary / r_id do not cross the link (5 -> 4 bytes per read); both must still be valid
+     * pointers for the paths that read them on the host. */
+    const uint32_t*    r_idp;
 } csv_batch_in;
 
 /*

@@ -1563,12 +1563,13 @@ def test_reads_table_as_16_bit_gaps_and_lengths(ctx, monkeypatch, order):
         assert hb.r_delta is not None and hb.r_len16 is not None and hb.c.flags & _abi.IN_READS_DELTA16
         assert len(hb.r_len16[1]) > 0                                        # some ends travel as escapes
         want = _oracle().cluster_batch(st.host_batch(st.tasks(), p), per_sig=True).trimmed()
+        assert hb.r_idp is not None and hb.c.r_idp                       # ... and the id | primary << 31 word instead of two columns
         got = ctx.cluster_batch(hb, per_sig=True, reuse=True).trimmed()
-        assert ctx.reads_delta_info() == 3
+        assert ctx.reads_delta_info() == 7
         assert_soa_equal(got, want, st)
         assert (got["dr"] > 0).any()
         ctx.upload(hb, per_sig=True)
-        assert ctx.reads_delta_info() == 3
+        assert ctx.reads_delta_info() == 7
         ctx.run(); ctx.run()
         assert_soa_equal(ctx.download(per_sig=True).trimmed(), want, st)
         # only one of the two columns in its 16-bit form; neither
