@@ -1095,7 +1095,11 @@ def main():
         n_rows = sum(len(v) for v in resolve.cluster_stage(pstore, params, tasks=tasks, ctx=ctx).values())
         # (bytes per signature / read as the ABI defines the columns; positions and lengths travel as int32 when the store
         # keeps narrow twins - CSV_IN_SIG_I32 / CSV_IN_READS_I32)
-        h2d_bytes = (2 * phb.a.dtype.itemsize + 8) * n_sig + ((2 * phb.r_start.dtype.itemsize + 5) * int(phb.r_start.shape[0]) if phb.r_start is not None else 0)
+        # (reads: CSV_IN_READS_DELTA16 sends the starts as 16-bit gaps / the ends as 16-bit lengths, r_idp the id and the primary flag
+        # as one word - whichever of them the last call took: csv_batch_info 3)
+        rbits = ctx.reads_delta_info() if phb.r_start is not None else 0
+        per_read = (2 if rbits & 1 else phb.r_start.dtype.itemsize) + (2 if rbits & 2 else phb.r_start.dtype.itemsize) + (4 if rbits & 4 else 5) if phb.r_start is not None else 0
+        h2d_bytes = (2 * phb.a.dtype.itemsize + 8) * n_sig + (per_read * int(phb.r_start.shape[0]) if phb.r_start is not None else 0)
         t_vcf = vcf_leg(ctx, pstore, params, tasks)
         t_task = per_task_leg(ctx, store, params, tasks)
 
