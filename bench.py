@@ -1082,6 +1082,7 @@ def main():
         t_one = timed(lambda: ctx.cluster_batch(phb, reuse=True), 9)          # (caller-owned result arrays, allocated once)
         gate_first, bytes_not_sent = ctx.lazy_info()
         delta16 = ctx.delta16_info()
+        rbits = ctx.reads_delta_info() if phb.r_start is not None else 0        # (of THIS call: later legs go through other faces)
         t_one_slim = timed(lambda: ctx.cluster_batch(phb, reuse=True, **SLIM), 9) if phb.a.dtype == np.int32 else None
         os.environ["CSV_NO_LAZY"] = "1"                                       # the whole columns in one piece (r04's form)
         t_one_bulk = timed(lambda: ctx.cluster_batch(phb, reuse=True), 5)
@@ -1097,7 +1098,6 @@ def main():
         # keeps narrow twins - CSV_IN_SIG_I32 / CSV_IN_READS_I32)
         # (reads: CSV_IN_READS_DELTA16 sends the starts as 16-bit gaps / the ends as 16-bit lengths, r_idp the id and the primary flag
         # as one word - whichever of them the last call took: csv_batch_info 3)
-        rbits = ctx.reads_delta_info() if phb.r_start is not None else 0
         per_read = (2 if rbits & 1 else phb.r_start.dtype.itemsize) + (2 if rbits & 2 else phb.r_start.dtype.itemsize) + (4 if rbits & 4 else 5) if phb.r_start is not None else 0
         h2d_bytes = (2 * phb.a.dtype.itemsize + 8) * n_sig + (per_read * int(phb.r_start.shape[0]) if phb.r_start is not None else 0)
         t_vcf = vcf_leg(ctx, pstore, params, tasks)
@@ -1163,7 +1163,7 @@ def main():
         host_to_host = {
             "region": "csv_cluster_batch: page-locked host columns -> kernels -> result SoA in page-locked host memory (SURVEY 8d region (ii); the "
                       "reference's timed region MAIN:1113-1199 minus the rows)",
-            "gate_first": bool(gate_first), "delta16": bool(delta16),
+            "gate_first": bool(gate_first), "delta16": bool(delta16), "reads_16bit_forms": int(rbits),
             "ms": one_ms, "value": n_sig / (one_ms * 1e-3), "ms_all": [round(x * 1e3, 3) for x in t_one],
             "slim_ms": one_slim_ms, "slim_value": None if one_slim_ms is None else n_sig / (one_slim_ms * 1e-3),
             "bulk_upload_ms": one_bulk_ms, "pageable_columns_ms": float(np.min(t_one_pageable)) * 1e3,

@@ -266,12 +266,17 @@ def _batch_of(store, segments):
     segs = np.array(segments, dtype=_abi.SEGMENT_DTYPE)
     nw = store.narrow or {}                           # (int32 twins of the positions / lengths: SigStore.pinned(), a mapped .cols directory)
     kw = {}
+    slim16 = os.environ.get("CUTESV_AMD_NO_DELTA16") is None      # (the 16-bit / interleaved / packed forms SigStore.pinned() keeps: ABI v8)
     if len(segs) and segs["genotype"].any() and store.reads_off is not None:
         kw = dict(reads_off=store.reads_off, r_start=nw.get("r_start", store.r_start), r_end=nw.get("r_end", store.r_end),
                   r_primary=store.r_primary, r_id=store.r_id)
+        if slim16:
+            kw.update(r_delta=nw.get("r_delta"), r_len16=nw.get("r_len16"), r_idp=nw.get("r_idp"))
         if ((segs["svtype"] == _abi.TRA) & (segs["genotype"] != 0)).any():
             kw["contig_len"] = store.contig_len
-    return _abi.HostBatch(segs, nw.get("a", store.a), nw.get("b", store.b), store.read_id, store.aux, n_chrom=len(store.chroms), **kw)
+    return _abi.HostBatch(segs, nw.get("a", store.a), nw.get("b", store.b), store.read_id, store.aux, n_chrom=len(store.chroms),
+                          a_delta=nw.get("a_delta") if slim16 else None,
+                          rows8=nw.get("rows8") if os.environ.get("CUTESV_AMD_NO_ROWS8") is None else None, **kw)
 
 
 def _cluster_stage_lazy(store, segs, tasks, ctx):
