@@ -217,15 +217,19 @@ class HostResult:
     """Caller-allocated csv_batch_out plus numpy views on it."""
 
     def __init__(self, n_sig, cap_calls, cap_support, per_sig=False, n_seg=0, alloc=None, narrow_support=False,
-                 no_support=False, coord32=False, fields=None, seg_alloc=None):
+                 no_support=False, coord32=False, fields=None, seg_alloc=None, block=None):
         """alloc(shape, dtype) -> array: where the result arrays live (default numpy; engine.pinned_empty puts them in
         page-locked memory, so that the device-to-host copies land in them by DMA).  narrow_support: the support list as int32
         (csv_batch_out.support_sig32): `arrays["support_sig"]` is then an int32 array - every consumer indexes with it.
         ABI v7: no_support - CSV_OUT_NO_SUPPORT_LIST (support_off / support_sig are None); coord32 - CSV_OUT_COORD_I32 (bp1, bp2,
         search_pos, seq_pick are int32 arrays; needs int32 input columns); fields - the OPTIONAL_CALL_FIELDS to carry (None: all),
         the others stay None and are not written.  seg_alloc: where `seg_status` lives (default: an ordinary numpy array even
-        under `alloc` - one word per segment is not worth a page-locked block of its own; broker.Client puts it in its shared region)."""
+        under `alloc` - one word per segment is not worth a page-locked block of its own; broker.Client puts it in its shared region).
+        block(nbytes) -> writable buffer: the per-call arrays and the support list are carved back to back out of ONE buffer (widest
+        elements first, no gaps) - csv_batch_publish_async then moves them with the copy engine in one piece (engine.pinned_block)"""
         empty = alloc or (lambda n, dt: np.empty(n, dtype=dt))
+        if block is not None:
+            empty = self._carver(block, cap_calls, cap_support, no_support, coord32, fields, narrow_support)
         self.cap_calls = int(cap_calls)
         self.cap_support = int(cap_support)
         self.n_sig, self.n_seg, self.per_sig = int(n_sig), int(n_seg), bool(per_sig)
@@ -260,6 +264,35 @@ class HostResult:
         self.n_seg_used = self.n_seg                 # segments of the batch the arrays were last filled for (a recycled result may be larger)
         self.c = BatchOut(cap_calls=self.cap_calls, cap_support=self.cap_support,
                           flags=(OUT_NO_SUPPORT_LIST if no_support else 0) | (OUT_COORD_I32 if coord32 else 0), **kw)
+
+    @staticmethod
+    def _carver(block, cap_calls, cap_support, no_support, coord32, fields, narrow_support):
+        """alloc(n, dtype) over one buffer: the arrays __init__ is about to ask for, in its order, each at a fixed place"""
+        want = []
+        for name, dt, cap in _OUT_ARRAYS:
+            if name in COORD_FIELDS and coord32:
+                dt = np.int32
+            if fields is not None and name in OPTIONAL_CALL_FIELDS and name not in frozenset(fields):
+                continue
+            if cap == "calls":
+                want.append((name, np.dtype(dt), int(cap_calls)))
+            elif cap == "calls+1" and not no_support:
+                want.append((name, np.dtype(dt), int(cap_calls) + 1))
+            elif cap == "support" and not no_support:
+                want.append((name, np.dtype(np.int32 if narrow_support else dt), int(cap_support)))
+        order = sorted(range(len(want)), key=lambda i: (-want[i][1].itemsize, want[i][0] == "support_sig", i))
+        off, place = 0, {}
+        for i in order:
+            place[i] = off
+            off += want[i][1].itemsize * want[i][2]
+        buf = block(max(8, off))
+        seq = iter(range(len(want)))
+
+        def empty(n, dt):
+            i = next(seq)
+            assert want[i][2] == int(n) and want[i][1] == np.dtype(dt), (want[i], n, dt)
+            return np.frombuffer(buf, dtype=dt, count=int(n), offset=place[i])
+        return empty
 
     def snapshot(self):
         """a private copy cut to the produced sizes (ordinary memory): what outlives the recycled, page-locked arrays of a

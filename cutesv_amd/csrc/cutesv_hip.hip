@@ -159,6 +159,7 @@ struct csv_ctx {
         bool debug = false, debug_counters = false, no_fork = false, fork_always = false, no_swap = false, no_peek = false;
         bool no_pair_in_mid = false, no_publish = false;
         int  iw_grid = 0, gt_grid = 0, tier_fork_min = 1 << 30, mid_grid = 0, big_grid = 0;
+        bool pub_inplace = false;
     } opt;
     volatile int* h_flag = nullptr;
     int*          d_flag = nullptr;
@@ -185,6 +186,10 @@ struct csv_ctx {
     bool        settled = false;               // a run of this upload has been downloaded synchronously (reads mode final, capacities known)
     char*       h_pub = nullptr;               // page-locked landing zones of the asynchronous publishes: 2 x {counters 256 B, status words}
     size_t      h_pub_cap = 0;
+    // block delivery: when the caller's result arrays sit back to back in page-locked memory (at most PUB_MAX_SPANS runs of
+    // adjacent arrays), k_publish writes them into a device image of those runs and the copy engine moves each run in one piece
+    void*       pub_stage[2] = {nullptr, nullptr};
+    size_t      pub_stage_cap[2] = {0, 0};
     bool     lazy_pending = false;             // gate-first call: this upload's first run still has to fetch the gated rows from the caller's columns
     bool     partial_cols = false;             // ... and its device columns hold only the rows the kernels read (csv_batch_validate refuses)
     i64      lazy_bytes = 0;                   // bytes the bulk copy of this upload did NOT send (measurement aid: csv_batch_lazy_info)
@@ -275,6 +280,7 @@ void load_run_opts(csv_ctx* c)
     o.tier_fork_min = env_int("CSV_TIER_FORK_MIN", 1 << 30);
     o.mid_grid = env_int("CSV_MID_GRID", 0);
     o.big_grid = env_int("CSV_BIG_GRID", 0);
+    o.pub_inplace = getenv("CSV_PUB_INPLACE") != nullptr;
 }
 
 int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sync, bool lazy_ok);
@@ -447,6 +453,7 @@ void csv_ctx_destroy(csv_ctx* c)
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     if (c->h_flag) (void)hipHostFree((void*)c->h_flag);
     if (c->h_pub) (void)hipHostFree(c->h_pub);
+    for (auto& ps : c->pub_stage) if (ps) (void)hipFree(ps);
     for (int q = 0; q < 2; q++) { if (c->ev_run[q]) (void)hipEventDestroy(c->ev_run[q]); if (c->ev_pub[q]) (void)hipEventDestroy(c->ev_pub[q]); }
     if (c->pub) (void)hipStreamDestroy(c->pub);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -1406,7 +1413,33 @@ int csv_batch_validate(csv_ctx* c)
 // block, unpacked into the caller's arrays on the host (a few MB; the per-signature outputs only when they were asked
 // for at upload).
 // Are all of the caller's call arrays page-locked (device addressable)?  Then fill `P` with their device addresses.
-bool publish_targets(csv_ctx* c, const csv_batch_out* out, PublishArgs& P)
+constexpr int PUB_MAX_SPANS = 3;
+struct PubLayout {                                   // the result arrays as the caller laid them out: runs of exactly adjacent arrays
+    const char* host[15]; size_t bytes[15]; size_t stage_off[15];
+    struct Span { const char* host; size_t bytes, stage_off; } span[15];
+    int n_span = 0; size_t stage_bytes = 0;
+};
+static void publish_spans(PubLayout& L)
+{
+    int idx[15], n = 0;
+    for (int i = 0; i < 15; i++) if (L.host[i] && L.bytes[i]) idx[n++] = i;
+    std::sort(idx, idx + n, [&](int x, int y) { return L.host[x] < L.host[y]; });
+    L.n_span = 0; L.stage_bytes = 0;
+    for (int q = 0; q < n; q++) {
+        const int i = idx[q];
+        if (L.n_span && L.span[L.n_span - 1].host + L.span[L.n_span - 1].bytes == L.host[i]) {
+            auto& sp = L.span[L.n_span - 1];
+            L.stage_off[i] = sp.stage_off + sp.bytes; sp.bytes += L.bytes[i];
+        } else {
+            // (a run starts at the same offset modulo 256 as on the host: every array keeps its alignment in the image)
+            const size_t off = ((L.stage_bytes + 255) & ~(size_t)255) + ((uintptr_t)L.host[i] & 255);
+            L.span[L.n_span++] = {L.host[i], L.bytes[i], off};
+            L.stage_off[i] = off;
+        }
+        L.stage_bytes = L.span[L.n_span - 1].stage_off + L.span[L.n_span - 1].bytes;
+    }
+}
+bool publish_targets(csv_ctx* c, const csv_batch_out* out, PublishArgs& P, PubLayout* L = nullptr, char* stage = nullptr)
 {
     (void)c;
     if (c->opt.no_publish || out->cap_calls < 0 || out->cap_support < 0) return false;
@@ -1423,8 +1456,13 @@ bool publish_targets(csv_ctx* c, const csv_batch_out* out, PublishArgs& P)
         dev[i] = nullptr;
         if (nosup && i >= 13) continue;
         if (!host[i]) { if (required[i]) return false; continue; }
+        if (stage) { dev[i] = stage + L->stage_off[i]; continue; }          // (second pass: the device image of a laid-out result)
         dev[i] = pinned_device_address(host[i], bytes[i] ? bytes[i] : 1);
         if (!dev[i]) return false;
+    }
+    if (L && !stage) {
+        for (int i = 0; i < 15; i++) { L->host[i] = dev[i] ? (const char*)host[i] : nullptr; L->bytes[i] = dev[i] ? bytes[i] : 0; L->stage_off[i] = 0; }
+        publish_spans(*L);
     }
     P.call_seg = (int*)dev[0]; P.call_cluster = (int*)dev[1]; P.call_aux = (int*)dev[2]; P.support = (int*)dev[3]; P.cipos = (int*)dev[4];
     P.cilen = (int*)dev[5]; P.dr = (int*)dev[6]; P.dv = (int*)dev[7]; P.gl_idx = (int*)dev[8];
@@ -1583,7 +1621,8 @@ int csv_batch_publish_async(csv_ctx* c, csv_batch_out* out)
     if (coord32 && !c->B.a.p32) return fail(c, CSV_E_INVALID, "CSV_OUT_COORD_I32 needs a batch of CSV_IN_SIG_I32 columns");
     HIP_TRY(c, hipSetDevice(c->device));
     PublishArgs P{};
-    if (!publish_targets(c, out, P)) return fail(c, CSV_E_INVALID, "csv_batch_publish_async writes the result in place: every array of csv_batch_out must be page-locked (csv_host_alloc / csv_host_register)");
+    PubLayout L;
+    if (!publish_targets(c, out, P, &L)) return fail(c, CSV_E_INVALID, "csv_batch_publish_async writes the result in place: every array of csv_batch_out must be page-locked (csv_host_alloc / csv_host_register)");
     const int S0 = (int)c->h_seg.size(), p = c->parity;
     const size_t zone = (256 + (size_t)(S0 + 1) * 4 + 255) & ~(size_t)255;
     if (2 * zone > c->h_pub_cap) {
@@ -1596,14 +1635,39 @@ int csv_batch_publish_async(csv_ctx* c, csv_batch_out* out)
     void* dpub = nullptr;
     HIP_TRY(c, hipHostGetDevicePointer(&dpub, c->h_pub, 0));
     const size_t half = c->h_pub_cap / 2 & ~(size_t)255;
+    // Block delivery (arrays back to back in page-locked memory: engine.result_buffers lays them out so).  A kernel that stores
+    // across PCIe holds up every kernel BOUNDARY of the next run beside it - the end-of-kernel cache write-back waits for the
+    // posted writes in flight, whoever issued them (measured: k_chain_apply 6 -> 62 us next to a k_publish of 3.4 MB, a step 110 us
+    // = run + delivery, nothing overlapped) - while a copy-engine transfer leaves the kernels alone.  So: the image is written into
+    // device memory behind the run's own kernels (main stream, ~4 us) and the copy engine moves it under the next run.
+    const bool block = L.n_span > 0 && L.n_span <= PUB_MAX_SPANS && !c->opt.pub_inplace;
+    if (block) {
+        if (L.stage_bytes + 256 > c->pub_stage_cap[p]) {
+            if (c->pub_stage[p]) { HIP_TRY(c, hipStreamSynchronize(c->pub)); HIP_TRY(c, hipFree(c->pub_stage[p])); c->pub_stage[p] = nullptr; c->pub_stage_cap[p] = 0; }
+            const size_t cap = L.stage_bytes + L.stage_bytes / 8 + 4096;
+            if (hipMalloc(&c->pub_stage[p], cap) != hipSuccess) return fail(c, CSV_E_NOMEM, "hipMalloc(%zu) for the result image failed", cap);
+            c->pub_stage_cap[p] = cap;
+        }
+        if (!publish_targets(c, out, P, &L, (char*)c->pub_stage[p])) return fail(c, CSV_E_INVALID, "internal: result image");
+    }
     P.cap_calls = out->cap_calls; P.cap_support = out->cap_support; P.n_seg = S0;
     P.h_cnt = (DevCounters*)((char*)dpub + half * p); P.h_seg_err = (int*)((char*)dpub + half * p + 256);
-    // (the run's kernels are all in the main stream's queue: an event recorded now marks their end - a plain run pays nothing for it)
-    HIP_TRY(c, hipEventRecord(c->ev_run[p], c->stream));
-    HIP_TRY(c, hipStreamWaitEvent(c->pub, c->ev_run[p], 0));
-    hipLaunchKernelGGL(k_publish, dim3(512), dim3(256), 0, c->pub, c->B, P);       // (c->B points at arena p: the last run's)
-    HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipEventRecord(c->ev_pub[p], c->pub));
+    const hipStream_t ps = c->pub;
+    if (block) {
+        hipLaunchKernelGGL(k_publish, dim3(512), dim3(256), 0, c->stream, c->B, P);       // (c->B points at arena p: the last run's)
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipEventRecord(c->ev_run[p], c->stream));
+        HIP_TRY(c, hipStreamWaitEvent(ps, c->ev_run[p], 0));
+        for (int q = 0; q < L.n_span; q++)
+            HIP_TRY(c, hipMemcpyAsync((void*)L.span[q].host, (char*)c->pub_stage[p] + L.span[q].stage_off, L.span[q].bytes, hipMemcpyDeviceToHost, ps));
+    } else {
+        // (the run's kernels are all in the main stream's queue: an event recorded now marks their end - a plain run pays nothing for it)
+        HIP_TRY(c, hipEventRecord(c->ev_run[p], c->stream));
+        HIP_TRY(c, hipStreamWaitEvent(c->pub, c->ev_run[p], 0));
+        hipLaunchKernelGGL(k_publish, dim3(512), dim3(256), 0, c->pub, c->B, P);
+        HIP_TRY(c, hipGetLastError());
+    }
+    HIP_TRY(c, hipEventRecord(c->ev_pub[p], ps));
     c->pend[p].out = out; c->pend[p].live = true;
     c->pend_order[c->n_pend++] = p;
     return CSV_OK;

@@ -101,14 +101,15 @@ class Context:
         """evict L2 / Infinity Cache (a measurement aid: the next run reads its columns from HBM)"""
         self._check(lib().csv_cache_flush(self._h, int(nbytes)))
 
-    def result_buffers(self, per_sig=False, cap_calls=None, cap_support=None, pinned=True, no_support=False, coord32=False, fields=None):
+    def result_buffers(self, per_sig=False, cap_calls=None, cap_support=None, pinned=True, no_support=False, coord32=False, fields=None, block=True):
         """caller-owned result arrays for the uploaded batch, to be handed to download(into=...) again and again; page-locked by
         default: the device then writes the calls straight into them (k_publish) and a download is one synchronisation.
-        no_support / coord32 / fields: the slim forms of ABI v7 (_abi.HostResult)"""
+        no_support / coord32 / fields: the slim forms of ABI v7 (_abi.HostResult).  block: the per-call arrays and the support list
+        back to back in ONE page-locked block (what csv_batch_publish_async's copy-engine delivery wants)"""
         n = self._batch.n_sig
         return _abi.HostResult(n, cap_calls or max(64, n // 16 + 16), cap_support or max(64, n + 16), per_sig=per_sig,
                                n_seg=len(self._batch.segments), alloc=pinned_empty if pinned else None, narrow_support=True,
-                               no_support=no_support, coord32=coord32, fields=fields)
+                               no_support=no_support, coord32=coord32, fields=fields, block=pinned_block if (pinned and block and not per_sig) else None)
 
     def lazy_info(self):
         """(gate-first?, signature-column bytes the bulk copy of the last upload did not send): csv_batch_info"""
@@ -248,6 +249,14 @@ def pinned_empty(shape, dtype):
     buf = (C.c_char * blk.nbytes).from_address(blk.ptr)
     buf._csv_block = blk                      # the array's base is `buf`; the block lives exactly as long
     return np.frombuffer(buf, dtype=dtype, count=n).reshape(shape)
+
+
+def pinned_block(nbytes):
+    """a writable page-locked buffer of nbytes (freed with the last array carved out of it)"""
+    blk = _PinnedBlock(max(1, int(nbytes)))
+    buf = (C.c_char * blk.nbytes).from_address(blk.ptr)
+    buf._csv_block = blk
+    return buf
 
 
 def pinned_copy(arr):

@@ -92,7 +92,8 @@ for it in range(n_it):
             if rng.integers(0, 4) == 0 and not os.environ.get("CSV_STRESS_NO_PIPE"):      # ... and the pipelined delivery of two more runs
                 ctx.upload(hb, per_sig=False)
                 ctx.run(); ctx.download()
-                bufs = [ctx.result_buffers(cap_calls=len(got["bp1"]) + 8, cap_support=len(got["support_sig"]) + 8) for _ in range(2)]
+                blk = bool(rng.integers(0, 2))                # (one page-locked block: the copy engine delivers; scattered arrays: k_publish in place)
+                bufs = [ctx.result_buffers(cap_calls=len(got["bp1"]) + 8, cap_support=len(got["support_sig"]) + 8, block=blk) for _ in range(2)]
                 ctx.run(); ctx.publish_async(bufs[0]); ctx.run(); ctx.publish_async(bufs[1])
                 for _ in range(2):
                     d = ctx.publish_wait().trimmed()

@@ -1393,18 +1393,20 @@ def test_lazy_stage_equals_the_row_lists(ctx):
     assert slim == want
 
 
+@pytest.mark.parametrize("block", [True, False])
 @pytest.mark.parametrize("genotype", [False, True])
-def test_pipelined_delivery_equals_the_serial_download(ctx, genotype):
-    """csv_batch_publish_async / _wait: run k's result is written into the caller's page-locked arrays on a stream of its own while
-    run k + 1 computes (two result arenas on the device).  Every delivered result equals the synchronous download, whatever
-    the interleaving; the state errors are errors"""
+def test_pipelined_delivery_equals_the_serial_download(ctx, genotype, block):
+    """csv_batch_publish_async / _wait: run k's result reaches the caller's page-locked arrays while run k + 1 computes (two result
+    arenas on the device) - moved by the copy engine when the arrays sit back to back in one block (block=True: result_buffers'
+    layout), written in place by k_publish on a stream of its own when they are scattered.  Every delivered result equals the
+    synchronous download, whatever the interleaving; the state errors are errors"""
     st = synth.small_mixed(seed=61, genotype=genotype, n_loci=300).pinned()
     p = Params.ont(genotype=genotype)
     hb = st.host_batch(st.tasks(), p)
     want = _oracle().cluster_batch(hb, per_sig=False).trimmed()
     ctx.upload(hb, per_sig=False)
     ctx.run()
-    a, b = ctx.result_buffers(), ctx.result_buffers()
+    a, b = ctx.result_buffers(block=block), ctx.result_buffers(block=block)
     with pytest.raises(engine.CsvError):
         ctx.publish_async(a)                               # (not before one synchronous download of the upload)
     assert_soa_equal(ctx.download().trimmed(), want, store=st)
@@ -1424,7 +1426,7 @@ def test_pipelined_delivery_equals_the_serial_download(ctx, genotype):
         ctx.download()                                     # (a delivery is in flight)
     assert_soa_equal(ctx.publish_wait().trimmed(), want, store=st)
     # three in a row without waiting: the third is refused; slim results travel the same way
-    slim = [ctx.result_buffers(no_support=True, coord32=True, fields=("cipos", "cilen", "dr", "gl_idx")) for _ in range(2)]
+    slim = [ctx.result_buffers(no_support=True, coord32=True, fields=("cipos", "cilen", "dr", "gl_idx"), block=block) for _ in range(2)]
     ctx.run(); ctx.publish_async(slim[0]); ctx.run(); ctx.publish_async(slim[1])
     ctx.run()
     with pytest.raises(engine.CsvError):
@@ -1434,7 +1436,7 @@ def test_pipelined_delivery_equals_the_serial_download(ctx, genotype):
         for name in ("call_seg", "bp1", "bp2", "support", "cipos", "cilen", "dr", "gl_idx"):
             assert np.array_equal(t[name].astype(np.int64), want[name].astype(np.int64)), name
     # too small a result: the status of THAT delivery
-    tiny = ctx.result_buffers(cap_calls=4, cap_support=4)
+    tiny = ctx.result_buffers(cap_calls=4, cap_support=4, block=block)
     ctx.run(); ctx.publish_async(tiny)
     with pytest.raises(engine.CsvError) as e:
         ctx.publish_wait()
