@@ -1189,7 +1189,7 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
             "timed_region": ("the rank's whole boundary call: page-locked host columns -> kernels -> host SoA" if shard_mode else
                              "inputs resident in HBM -> all kernels -> every call field + the int32 support lists delivered into page-locked host arrays (int32 coordinates with int32 columns), every step's full "
-                             "result; the delivery of step k (k_publish on its own stream) runs under the kernels of step k + 1 (csv_batch_publish_async)"),
+                             "result; the delivery of step k (one copy-engine transfer of the result block, written as a device image behind the run) runs under the kernels of step k + 1 (csv_batch_publish_async)"),
             "kernel_only": None if ko_ms is None else {"ms_per_step": ko_ms, "value": total_sig / (ko_ms * 1e-3),
                                                        "note": "the launch sequence alone, results left in HBM (the region r01-r03 reported as value)"},
             "ms_per_step_reads_order_kept": ms_reads_kept,

@@ -285,7 +285,13 @@ int csv_ctx_sync(csv_ctx* ctx);
  * returns its status (CSV_E_CAPACITY etc.).  At most two deliveries in flight, each into arrays of its own; every array must be
  * page-locked; no per-signature outputs; the upload must have been downloaded once synchronously before (that settles how its
  * reads table is ordered).  The sequence  run, async(A), run, async(B), wait -> A, run, async(A), wait -> B ...  keeps the link
- * busy under the kernels.  No counterpart in the reference (its workers return pickled rows through a pipe, MAIN:1191-1197). */
+ * busy under the kernels.  HOW the result crosses depends on where the caller put the arrays: arrays that sit exactly back to back
+ * in page-locked memory (at most three such runs: e.g. every per-call array and the support list carved out of ONE csv_host_alloc
+ * block, no gaps) are written as a device image behind the run's kernels and moved by the copy engine, one transfer per run of
+ * arrays - in full, i.e. cap_calls / cap_support elements each: size them from the first download; scattered arrays are written in
+ * place by a kernel on a stream of its own.  The first form is the one that overlaps: a kernel storing across PCIe holds up every
+ * kernel boundary of the run beside it.  Elements beyond n_calls / n_support are unspecified in both forms.
+ * No counterpart in the reference (its workers return pickled rows through a pipe, MAIN:1191-1197). */
 int csv_batch_publish_async(csv_ctx* ctx, csv_batch_out* out);
 int csv_batch_publish_wait(csv_ctx* ctx, csv_batch_out** done /* nullable */);
 /* How the reads table of the last completed run was brought into start order: 0 = the caller promised sorted blocks,

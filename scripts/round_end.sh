@@ -27,3 +27,9 @@ python scripts/rocprof_oneshot_timeline.py $(ls /tmp/os_tl/*.db /tmp/os_tl/*/*.d
 python scripts/resource_usage.py > $F/${TAG}_resource_usage.txt 2>/dev/null
 # where k_genotype's wavefronts spend their cycles (measurement build: make -C cutesv_amd/csrc gt-prof)
 if [ -f $R/build/lib_prof.so ]; then for wl in cfg5 cfg4; do echo "# $wl"; CUTESV_AMD_LIB=$R/build/lib_prof.so timeout 300 python scripts/gt_prof.py $wl 2>&1 | grep gt_prof | tail -1; done > $F/${TAG}_gt_prof.txt; fi
+# the pipelined resident loop: host time per call, and both queues + the copy engine on a timeline, block delivery vs k_publish in place
+timeout 200 python scripts/pipe_ab.py cfg3 300 > $F/${TAG}_pipe_ab.txt 2>&1; CSV_PUB_INPLACE=1 timeout 200 python scripts/pipe_ab.py cfg3 300 2>&1 | grep pipelined | sed 's/^/in place: /' >> $F/${TAG}_pipe_ab.txt
+for form in block inplace; do
+  ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/pp_$form && cd $R && if [ $form = inplace ]; then export CSV_PUB_INPLACE=1; fi; timeout -k 5 200 rocprofv3 --kernel-trace --memory-copy-trace -d /tmp/pp_$form -o pp -- python scripts/pipe_ab.py cfg3 40 > /dev/null 2>&1 )
+  python scripts/pipe_timeline.py $(ls /tmp/pp_$form/*.db /tmp/pp_$form/*/*.db 2>/dev/null | head -1) 3 > $F/${TAG}_pipe_timeline_$form.txt 2>&1
+done
