@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--workers", default="8,32")
     ap.add_argument("--cols", action="store_true", help="also write the flat cutesv_amd.cols directory (the build's own input format)")
+    ap.add_argument("--all", action="store_true", help="every task of the last repetition, worker by worker, and the broker's counters for that stage")
     a = ap.parse_args()
     store, params, _ = bench.make_workload(a.workload, a.scale, 0)
     wd = tempfile.mkdtemp(prefix="cutesv_amd_tl_") + "/"
@@ -42,6 +43,7 @@ def main():
         for rep in range(2):
             tl = tempfile.mkdtemp(prefix="tl_")
             os.environ["CUTESV_AMD_TIMELINE"] = tl
+            b0 = bench_stage._broker_info() or {}
             t0 = time.time()
             res = resolve.main_ctrl_phase3(wd, idx, params, T)
             t1 = time.time()
@@ -61,6 +63,13 @@ def main():
             big = sorted(rows, key=lambda r: -(r[8] - r[4]))[:4]
             for r in big:
                 print("      %s %s n=%d reads=%d: start %.1f store %.1f call %.1f rows %.1f ms" % (r[0], r[1], r[2], r[3], r[4] * 1e3, (r[5] - r[4]) * 1e3, (r[7] - r[6]) * 1e3, (r[8] - r[7]) * 1e3))
+            if a.all and rep == 1:
+                b1 = bench_stage._broker_info() or {}
+                print("      broker, this stage: %s" % {k: round(b1.get(k, 0) - b0.get(k, 0), 4) for k in ("calls", "batches", "merged_calls", "busy_s", "stage_in_s", "engine_s", "slice_out_s", "block_hits")})
+                for w in sorted({r[9] for r in rows}):
+                    mine = [r for r in rows if r[9] == w]
+                    print("      %s: %s" % (w, "  ".join("%s%s %.1f [s %.1f c %.1f r %.1f] -> %.1f" % (r[0][0], r[1], r[4] * 1e3, (r[5] - r[4]) * 1e3, (r[7] - r[6]) * 1e3,
+                                                                                                        (r[8] - r[7]) * 1e3, r[8] * 1e3) for r in mine)))
     bench_stage._broker_info(shutdown=True)
 
 
