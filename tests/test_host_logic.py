@@ -637,3 +637,34 @@ def test_rebuild_staging_fill_equals_the_concatenated_columns(monkeypatch):
     per["DEL"]["chrom"][7] = 4                                         # a chromosome index outside the table is an error, not a clip
     with pytest.raises(ValueError):
         rebuild.rebuild_to_device_batch(Ctx(), chroms, per, None)
+
+
+@pytest.mark.parametrize("kw", [dict(narrow_support=True), dict(narrow_support=True, coord32=True), dict(),
+                                dict(no_support=True, coord32=True, fields=("call_aux", "cipos", "cilen", "seq_pick", "dr", "gl_idx")),
+                                dict(narrow_support=True, fields=())])
+def test_block_result_arrays_sit_back_to_back(kw):
+    """HostResult(block=...): the per-call arrays and the support list are carved out of ONE buffer, widest elements first, with
+    no gap between neighbours and every array aligned to its element - what csv_batch_publish_async (include/cutesv_hip.h) needs to
+    hand the result to the copy engine as one run of arrays; seg_status and the per-signature arrays stay outside"""
+    bufs = []
+
+    def block(nbytes):
+        bufs.append(bytearray(nbytes))
+        return bufs[-1]
+    for cap_calls, cap_support in ((1, 1), (77, 501), (4096, 12345)):
+        r = _abi.HostResult(1000, cap_calls, cap_support, n_seg=3, block=block, **kw)
+        inside = sorted((a.__array_interface__["data"][0], a.nbytes, name) for name, a in r.arrays.items()
+                        if a is not None and name not in ("seg_status", "cluster_id", "allele_id"))
+        base = np.frombuffer(bufs[-1], np.uint8).__array_interface__["data"][0]
+        assert inside[0][0] == base
+        for (ad, nb, name), (ad2, _, name2) in zip(inside, inside[1:]):
+            assert ad + nb == ad2, (name, name2)                   # exactly adjacent: one run for the copy engine
+        assert inside[-1][0] + inside[-1][1] - base == sum(nb for _, nb, _ in inside) <= len(bufs[-1])
+        for ad, _, name in inside:
+            assert ad % r.arrays[name].dtype.itemsize == 0, name
+        want = _abi.HostResult(1000, cap_calls, cap_support, n_seg=3, **kw)
+        assert {k: (None if v is None else (v.dtype, v.shape)) for k, v in r.arrays.items()} == \
+               {k: (None if v is None else (v.dtype, v.shape)) for k, v in want.arrays.items()}
+        for name, a in r.arrays.items():                          # the struct carries the carved addresses
+            if a is not None and name != "support_sig":
+                assert getattr(r.c, name) == a.__array_interface__["data"][0], name
