@@ -169,7 +169,7 @@ def mode1_stage(name, store, params, workers=(1, 8, 32), reference=True, cold_an
         _wait_gone()
         resolve.shut_down()
         out["legs"] = legs
-        out["broker"] = None if info is None else {k: info.get(k) for k in ("calls", "batches", "merged_calls", "max_batch", "busy_s", "stage_in_s", "engine_s", "slice_out_s", "maps", "blocks", "block_hits", "bus", "engine")}
+        out["broker"] = None if info is None else {k: info.get(k) for k in ("calls", "batches", "merged_calls", "max_batch", "busy_s", "stage_in_s", "engine_s", "slice_out_s", "maps", "blocks", "block_hits", "stage_grows", "bus", "engine")}
         if cold_and_direct_at:
             T = cold_and_direct_at
             os.environ.pop("CUTESV_AMD_BROKER_NAME", None)

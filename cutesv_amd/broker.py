@@ -556,11 +556,40 @@ class Broker:
         for p in pend:
             if id(p) not in ids:
                 self._run_one(p)
-        for lo in range(0, len(merge), max(1, self.max_batch)):
-            self._run_merged(merge[lo:lo + max(1, self.max_batch)])
+        for grp in self._groups(merge):
+            self._run_merged(grp)
         self.stats["batches"] += 1
         self.stats["max_batch"] = max(self.stats["max_batch"], len(pend))
         self.stats["busy_s"] += time.perf_counter() - t0
+
+    @staticmethod
+    def _reads_block(c):
+        """rows of the reads block a single-segment request's batch will carry (its segment's chromosome, if it genotypes)"""
+        if not (c.n_reads and c.reads_off):
+            return 0
+        sg = _view(c.seg, 1, _abi.SEGMENT_DTYPE)[0]
+        if not sg["genotype"]:
+            return 0
+        off = _view(c.reads_off, int(c.n_chrom) + 1, np.int64)
+        return int(off[int(sg["chrom"]) + 1]) - int(off[int(sg["chrom"])])
+
+    def _groups(self, merge):
+        """the waiting requests cut into batches: at most max_batch side by side, and no more than the page-locked staging columns
+        hold as they are - two batches cost one more call (~0.3 ms), growing a few hundred MB of page-locked memory in the middle of
+        a stage costs a hundred (32 workers' reads blocks arriving at once)"""
+        st, cap = self._stage, max(1, self.max_batch)
+        out, cur, n, r = [], [], 0, 0
+        for p in merge:
+            pn, pr = int(p.cin.n_sig), self._reads_block(p.cin)
+            if cur and (len(cur) >= cap or (st is not None and (n + pn > st["n"] or r + pr > st["r"]))):
+                out.append(cur)
+                cur, n, r = [], 0, 0
+            cur.append(p)
+            n += pn
+            r += pr
+        if cur:
+            out.append(cur)
+        return out
 
     def _run_merged(self, grp):
         """k single-segment requests -> one csv_cluster_batch.  Request j becomes segment j and "chromosome" j of the batch (its
@@ -703,6 +732,7 @@ class Broker:
     def _staging(self, eng, n, r, k):
         st = self._stage
         if st is None or st["n"] < n or st["r"] < r or st["k"] < k:
+            self.stats["stage_grows"] = self.stats.get("stage_grows", 0) + 1
             n2, r2, k2 = max(n * 5 // 4, 1 << 16), max(r * 5 // 4, 1 << 16), max(k, self.max_batch)
             st = self._stage = dict(n=n2, r=r2, k=k2,
                                     a=eng.alloc(n2, np.int64), b=eng.alloc(n2, np.int64), read_id=eng.alloc(n2, np.int32), aux=eng.alloc(n2, np.int32),
@@ -895,7 +925,25 @@ class _HipEngine:
         self.ctx.close()
 
 
+def _reserve_fd_table(n=4096):
+    """Grow this process's descriptor table ONCE, now, while it has one thread.  The kernel enlarges the table in powers of two and, in
+    a process with several threads (the HIP runtime's, the copy pool's), waits for an RCU grace period each time: a pool of 32
+    workers connecting for the first time - 32 sockets, 32 region descriptors - crossed 64 / 128 / 256 descriptors inside the stage
+    and the broker sat 150-180 ms in accept / recvmsg (measured: one K_MAP message 176 ms, a 32-worker stage 263 instead of 151 ms;
+    the next stage, its table already large, was fast)."""
+    try:
+        import resource
+        soft, _hard = resource.getrlimit(resource.RLIMIT_NOFILE)
+        hi = min(int(n), int(soft) - 1)
+        if hi > 64:
+            os.dup2(0, hi, inheritable=False)
+            os.close(hi)
+    except (OSError, ValueError, ImportError):
+        pass
+
+
 def main(argv=None, engine_factory=None):
+    _reserve_fd_table()
     import argparse
     ap = argparse.ArgumentParser(description="cutesv_amd GPU broker: one HIP context per GPU for a pool of cuteSV workers")
     ap.add_argument("--name", required=True)

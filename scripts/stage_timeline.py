@@ -63,10 +63,10 @@ def main():
             big = sorted(rows, key=lambda r: -(r[8] - r[4]))[:4]
             for r in big:
                 print("      %s %s n=%d reads=%d: start %.1f store %.1f call %.1f rows %.1f ms" % (r[0], r[1], r[2], r[3], r[4] * 1e3, (r[5] - r[4]) * 1e3, (r[7] - r[6]) * 1e3, (r[8] - r[7]) * 1e3))
-            if a.all and rep == 1:
+            if a.all:
                 b1 = bench_stage._broker_info() or {}
-                print("      broker, this stage: %s" % {k: round(b1.get(k, 0) - b0.get(k, 0), 4) for k in ("calls", "batches", "merged_calls", "busy_s", "stage_in_s", "engine_s", "slice_out_s", "block_hits")})
-                for w in sorted({r[9] for r in rows}):
+                print("      broker, this stage: %s" % {k: round(b1.get(k, 0) - b0.get(k, 0), 4) for k in ("calls", "batches", "merged_calls", "busy_s", "stage_in_s", "engine_s", "slice_out_s", "block_hits", "stage_grows")})
+                for w in (sorted({r[9] for r in rows}) if rep == 1 else ()):
                     mine = [r for r in rows if r[9] == w]
                     print("      %s: %s" % (w, "  ".join("%s%s %.1f [s %.1f c %.1f r %.1f] -> %.1f" % (r[0][0], r[1], r[4] * 1e3, (r[5] - r[4]) * 1e3, (r[7] - r[6]) * 1e3,
                                                                                                         (r[8] - r[7]) * 1e3, r[8] * 1e3) for r in mine)))
