@@ -16,6 +16,7 @@ exactly those files (outside every timed region) and times, from `Pool(...)` to 
 import argparse
 import hashlib
 import json
+import gc
 import os
 import shutil
 import sys
@@ -58,6 +59,9 @@ def _stage(wd, idx, params, T, fns=None):
                     cl.reads_flush()
         except broker.BrokerError:
             pass
+    # every timed stage - either side's - starts from a collected heap: the rows of the stage before (350 000 lists and strings) make
+    # the parent's collector passes, which run while it unpickles the workers' rows, 40-50 ms longer for whichever stage comes second
+    gc.collect()
     t0 = time.perf_counter()
     res = resolve.main_ctrl_phase3(wd, idx, params, T, fns=fns)
     return time.perf_counter() - t0, res
@@ -128,11 +132,13 @@ def mode1_stage(name, store, params, workers=(1, 8, 32), reference=True, cold_an
         out["broker_engine_start_s"] = None if info is None else info.get("engine_start_s")
         ref_digest = None
         for T in workers:
-            walls = []
+            walls, res = [], None
             for _ in range(reps):
+                res = None                                # (the rows of the repetition before are gone before this one is timed)
                 dt, res = _stage(wd, idx, params, T)
                 walls.append(dt)
             dg = rows_digest(res)
+            res = None
             leg = {"workers": T, "wall_ms": round(min(walls) * 1e3, 2), "wall_ms_all": [round(w * 1e3, 1) for w in walls], "rows": dg[0],
                    "signatures_per_s": round(n_sig / min(walls)),
                    # the same pool with tasks that do nothing: what neither side of the comparison can get under
@@ -141,6 +147,7 @@ def mode1_stage(name, store, params, workers=(1, 8, 32), reference=True, cold_an
             if reference:
                 dtr, ref = _stage(wd, idx, params, T, fns=pr.REF_FNS)
                 rd = rows_digest(ref)
+                ref = None
                 ref_digest = ref_digest or rd
                 leg.update(reference_pool_wall_ms=round(dtr * 1e3, 1), vs_reference_pool=round(dtr / min(walls), 1), rows_equal_reference_model=(rd == dg))
                 say("reference model T=%d: %.1f ms (x%.1f), rows equal: %s" % (T, dtr * 1e3, dtr / min(walls), rd == dg))
@@ -154,12 +161,15 @@ def mode1_stage(name, store, params, workers=(1, 8, 32), reference=True, cold_an
             out["write_cols_s"] = round(time.perf_counter() - t0, 2)
             for leg in legs:
                 T = leg["workers"]
-                walls = []
+                walls, res = [], None
                 for _ in range(reps):
+                    res = None
                     dt, res = _stage(wd, idx, params, T)
                     walls.append(dt)
                 leg["cols_wall_ms"] = round(min(walls) * 1e3, 2)
+                leg["cols_wall_ms_all"] = [round(w * 1e3, 1) for w in walls]
                 leg["cols_rows_equal"] = rows_digest(res) == ((leg["rows"], ref_digest[1]) if ref_digest else rows_digest(res))
+                res = None
                 if "reference_pool_wall_ms" in leg:
                     leg["cols_vs_reference_pool"] = round(leg["reference_pool_wall_ms"] / leg["cols_wall_ms"], 1)
                 say("drop-in on cutesv_amd.cols T=%d: %s ms" % (T, [round(w * 1e3, 1) for w in walls]))
