@@ -577,7 +577,9 @@ class Broker:
         """the waiting requests cut into batches: at most max_batch side by side, and no more than the page-locked staging columns
         hold as they are - two batches cost one more call (~0.3 ms), growing a few hundred MB of page-locked memory in the middle of
         a stage costs a hundred (32 workers' reads blocks arriving at once)"""
-        st, cap = self._stage, max(1, self.max_batch)
+        # (only a staging block that was sized on purpose - resolve.warm_up's prealloc - is a limit; one that grew out of the first
+        # small request keeps growing, or nothing would ever be merged behind a broker started cold)
+        st, cap = (self._stage if self.prealloc else None), max(1, self.max_batch)
         out, cur, n, r = [], [], 0, 0
         for p in merge:
             pn, pr = int(p.cin.n_sig), self._reads_block(p.cin)
@@ -931,6 +933,8 @@ def _reserve_fd_table(n=4096):
     workers connecting for the first time - 32 sockets, 32 region descriptors - crossed 64 / 128 / 256 descriptors inside the stage
     and the broker sat 150-180 ms in accept / recvmsg (measured: one K_MAP message 176 ms, a 32-worker stage 263 instead of 151 ms;
     the next stage, its table already large, was fast)."""
+    if os.environ.get("CUTESV_AMD_BROKER_FD_TABLE", "1") == "0":           # (diagnostic: the table grows on demand again)
+        return
     try:
         import resource
         soft, _hard = resource.getrlimit(resource.RLIMIT_NOFILE)

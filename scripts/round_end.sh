@@ -12,6 +12,7 @@ for wl in cfg3 cfg4; do timeout 600 python bench_stage.py --workload $wl > $F/${
 timeout 300 python scripts/stage_timeline.py --workload cfg4 --workers 1,8,32 2>/dev/null | grep -v "^\[" > $F/${TAG}_stage_timeline_cfg4_pickles.txt
 timeout 300 python scripts/stage_timeline.py --workload cfg4 --workers 1,8,32 --cols 2>/dev/null | grep -v "^\[" > $F/${TAG}_stage_timeline_cfg4_cols.txt
 for wl in cfg3 cfg4; do timeout 300 python scripts/stage_timeline.py --workload $wl --workers 8 --cols --all 2>/dev/null | grep -v "^\[" | cut -c1-1200 > $F/${TAG}_stage_timeline_${wl}_cols_all.txt; done
+( echo "# the first 32-worker stage of a broker (after one 8-worker stage): descriptor table grown on demand, then grown once at start"; for v in 0 1; do echo "## CUTESV_AMD_BROKER_FD_TABLE=$v"; CUTESV_AMD_BROKER_FD_TABLE=$v timeout 300 python scripts/stage_timeline.py --workload cfg3 --workers 8,32 --all 2>/dev/null | grep -v "^\[" | awk '/== T=32/{f=1} f' | cut -c1-400 | head -42; done ) > $F/${TAG}_stage_timeline_cfg3_first_t32.txt
 timeout 300 python bench.py --workload rebuild > $F/${TAG}_bench_rebuild.json 2>/dev/null
 timeout 300 python bench.py --workload extract > $F/${TAG}_bench_extract.json 2>/dev/null
 timeout 600 python bench.py --full --gpus 8 --steps 10 --warmup 2 > $F/${TAG}_bench_cfg3_replica_plus_cfg4_sharded_8ranks_one_device.json 2>/dev/null; echo "8 ranks rc=$?"
