@@ -401,3 +401,28 @@ def test_warm_up_starts_the_brokers_and_shut_down_stops_them(tmp_path, monkeypat
         resolve.shut_down()
     assert all(broker._try_connect(n) is None for n in names)
     assert "CUTESV_AMD_BROKER_NAME" not in os.environ
+
+
+def test_merged_batches_stay_inside_preallocated_staging():
+    """Broker._groups: waiting single-segment requests are laid side by side - at most max_batch of them, and, behind a broker whose
+    staging was page-locked on purpose (resolve.warm_up's prealloc), never more signatures / reads-table rows than that staging
+    holds: the batch is cut instead of a few hundred MB of page-locked memory growing in the middle of a stage.  A staging block
+    that grew out of the first request of a cold broker is no limit (it keeps growing)"""
+    import types
+    from cutesv_amd import broker as bk
+
+    def req(n_sig, n_reads=0):
+        seg = np.zeros(1, _abi.SEGMENT_DTYPE)
+        seg["genotype"], seg["chrom"] = (1 if n_reads else 0), 0
+        off = np.array([0, n_reads], np.int64)
+        cin = _abi.BatchIn(n_seg=1, n_chrom=1, seg=seg.ctypes.data, n_sig=n_sig, n_reads=n_reads, reads_off=off.ctypes.data if n_reads else None)
+        return types.SimpleNamespace(cin=cin, _keep=(seg, off))
+    b = bk.Broker.__new__(bk.Broker)
+    b.max_batch, b.prealloc, b._stage = 4, (1000, 5000), dict(n=1000, r=5000, k=4)
+    sizes = lambda groups: [[(int(p.cin.n_sig), int(p.cin.n_reads)) for p in g] for g in groups]     # noqa: E731
+    pend = [req(300), req(300), req(300), req(300), req(50), req(50), req(50), req(50), req(50)]
+    assert sizes(b._groups(pend)) == [[(300, 0)] * 3, [(300, 0), (50, 0), (50, 0), (50, 0)], [(50, 0)] * 2]      # signatures, then max_batch
+    pend = [req(10, 3000), req(10, 3000), req(10, 1000), req(2000, 100)]
+    assert sizes(b._groups(pend)) == [[(10, 3000)], [(10, 3000), (10, 1000)], [(2000, 100)]]                 # reads rows; an oversize request alone
+    b.prealloc = None                                                                                       # a cold broker: only max_batch
+    assert [len(g) for g in b._groups([req(300) for _ in range(9)])] == [4, 4, 1]
