@@ -45,6 +45,4 @@ for rep in range(2):
     dt = pc() - t0
     print("%s pipelined         %.1f us/step: host in run %.1f, publish_async %.1f, publish_wait %.1f" %
           (wl, dt / steps * 1e6, tr / steps * 1e6, tp / steps * 1e6, tw / steps * 1e6), flush=True)
-# the same with the wait of step k - 1 BEFORE the run of step k + 1 is queued two deep: run, run, publish ... (what a caller with
-# three arenas could do is not offered; this only shows what the queue depth is worth)
 ctx.close()
