@@ -112,7 +112,7 @@ struct csv_ctx {
     hipStream_t stream = nullptr;
     hipStream_t side[3] = {};         // side streams: [0] mid + workgroup tier, [1] DUP/INV/TRA wavefront tier, [2] reads order + prefix max
     hipStream_t copy[N_COPY_STREAMS] = {};    // host -> device column copies (one DMA engine each)
-    hipEvent_t  ev_init = nullptr, ev_sel = nullptr, ev_aux[3] = {}, ev_copy[N_COPY_STREAMS] = {}, ev_reads = nullptr, ev_anc = nullptr;
+    hipEvent_t  ev_init = nullptr, ev_sel = nullptr, ev_aux[3] = {}, ev_copy[N_COPY_STREAMS] = {}, ev_reads = nullptr, ev_anc = nullptr, ev_rd[4] = {};
     std::string err;
     hipEvent_t  ev[CSV_N_STAGES + 2] = {};
     Arena       arena, arena_rb;
@@ -159,7 +159,7 @@ struct csv_ctx {
         bool debug = false, debug_counters = false, no_fork = false, fork_always = false, no_swap = false, no_peek = false;
         bool no_pair_in_mid = false, no_publish = false;
         int  iw_grid = 0, gt_grid = 0, tier_fork_min = 1 << 30, mid_grid = 0, big_grid = 0;
-        bool pub_inplace = false;
+        bool pub_inplace = false, no_reads_overlap = false;
     } opt;
     volatile int* h_flag = nullptr;
     int*          d_flag = nullptr;
@@ -281,6 +281,7 @@ void load_run_opts(csv_ctx* c)
     o.mid_grid = env_int("CSV_MID_GRID", 0);
     o.big_grid = env_int("CSV_BIG_GRID", 0);
     o.pub_inplace = getenv("CSV_PUB_INPLACE") != nullptr;
+    o.no_reads_overlap = getenv("CSV_NO_READS_OVERLAP") != nullptr;
 }
 
 int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sync, bool lazy_ok);
@@ -424,6 +425,7 @@ int csv_ctx_create(int device_id, csv_ctx** out)
         hipEventCreateWithFlags(&c->ev_reads, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_anc, hipEventDisableTiming) != hipSuccess) { delete c; return CSV_E_HIP; }
     for (auto& e : c->ev_aux) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { delete c; return CSV_E_HIP; }
+    for (auto& e : c->ev_rd) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { delete c; return CSV_E_HIP; }
     for (auto& e : c->ev_copy) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { delete c; return CSV_E_HIP; }
     {
         void* hf = nullptr;
@@ -463,6 +465,7 @@ void csv_ctx_destroy(csv_ctx* c)
     if (c->ev_sel) (void)hipEventDestroy(c->ev_sel);
     if (c->ev_reads) (void)hipEventDestroy(c->ev_reads);
     if (c->ev_anc) (void)hipEventDestroy(c->ev_anc);
+    for (auto& e : c->ev_rd) if (e) (void)hipEventDestroy(e);
     for (auto& s2 : c->side) if (s2) (void)hipStreamDestroy(s2);
     for (auto& s2 : c->copy) if (s2) (void)hipStreamDestroy(s2);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -867,13 +870,80 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
         }
         HIP_TRY(c, hipMemcpyAsync(c->ro_tblk.p, c->h_tblk.data(), ((size_t)ntl + 1) * 4, hipMemcpyHostToDevice, sr));
     }
-    if (R > 0) {
+    const bool r_packed = R > 0 && in->r_idp != nullptr && rd32 && !getenv("CSV_NO_DELTA16");
+    // all three 16-bit / packed forms on offer: the decode of one column runs (on a side stream, behind an event) while the next
+    // column is on the link - id | primary first (the largest), the start gaps + their anchors, the lengths last, so that only
+    // k_reads_end16 is left when the last byte has landed.  In one stream, in the order copies - copies - kernels, the three
+    // decode kernels and the anchors' copy (95 us with their hand-overs) all followed the last byte.
+    const bool r_overlap = r_packed && r_gaps && r_lens && !c->opt.no_reads_overlap;
+    auto reads_anchors = [&]() {
+        // anchors of the start column, built while the table is on the link: the first row of every tile of 2048 rows, the
+        // first row of every chromosome block, the caller's escape rows (the first row of every sorted run is one) - rows of
+        // the table itself: no w space here.  They follow the table on its own stream (page-locked staging: h_ranc).
+        const int32_t* hs = (const int32_t*)in->r_start;
+        std::vector<std::pair<i64, int>> anc;
+        anc.reserve((size_t)r_anc_cap);
+        for (i64 t = 0; t < r_ntile; t++) anc.emplace_back(t * (i64)CH_TILE, hs[t * (i64)CH_TILE]);
+        for (int k = 0; k < in->n_chrom; k++) { const i64 r0 = in->reads_off[k]; if (r0 >= 0 && r0 < R) anc.emplace_back(r0, hs[r0]); }
+        for (i64 e = 0; e < in->n_r_esc; e++) { const i64 r0 = in->r_esc_row[e]; if (r0 >= 0 && r0 < R) anc.emplace_back(r0, in->r_esc_val[e]); }
+        std::sort(anc.begin(), anc.end());
+        anc.erase(std::unique(anc.begin(), anc.end(), [](const std::pair<i64, int>& x, const std::pair<i64, int>& y) { return x.first == y.first; }), anc.end());
+        int* h_off = (int*)(c->h_pin + o_ranc);          // (page-locked staging: a copy out of pageable memory would block the host
+                                                         // until the table in front of it on this stream has crossed the link)
+        int* h_w = h_off + r_ntile + 2;
+        int* h_v = h_w + r_anc_cap;
+        size_t q = 0;
+        for (i64 t = 0; t <= r_ntile; t++) { while (q < anc.size() && anc[q].first < t * (i64)CH_TILE) q++; h_off[t] = (int)q; }
+        h_off[r_ntile + 1] = (int)anc.size();
+        for (size_t i = 0; i < anc.size(); i++) { h_w[i] = (int)anc[i].first; h_v[i] = anc[i].second; }
+        return h_off;
+    };
+    auto reads_unpack = [&](hipStream_t s) {
+        UnpackArgs UA{dp<uint16_t>(c->rd16), dp<int>(c->r_start), R, dp<int>(c->ranc), dp<int>(c->ranc) + r_ntile + 2, dp<int>(c->ranc) + r_ntile + 2 + r_anc_cap, (int)r_ntile, 0, 0};
+        DevBatch none;
+        memset(&none, 0, sizeof none);
+        hipLaunchKernelGGL(k_unpack_a16, dim3((unsigned)r_ntile), dim3(256), 0, s, UA, none);
+    };
+    auto reads_ends = [&](hipStream_t s) -> int {
+        hipLaunchKernelGGL(k_reads_end16, dim3(div_up(R, 256)), dim3(256), 0, s, (const int*)dp<int>(c->r_start), (const uint16_t*)dp<uint16_t>(c->rl16), dp<int>(c->r_end), R);
+        if (in->n_l_esc > 0) {
+            char* base = (char*)c->rlesc.p;
+            char* hst = c->h_pin + o_lesc;                // (through the page-locked staging, as above)
+            memcpy(hst, in->l_esc_row, (size_t)in->n_l_esc * 8);
+            memcpy(hst + (size_t)in->n_l_esc * 8, in->l_esc_val, (size_t)in->n_l_esc * 4);
+            HIP_TRY(c, hipMemcpyAsync(base, hst, (size_t)in->n_l_esc * 12, hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(k_scatter_rows_i32, dim3(div_up(in->n_l_esc, 256)), dim3(256), 0, s, (const i64*)base, (const int*)(base + (size_t)in->n_l_esc * 8), dp<int>(c->r_end), in->n_l_esc, R);
+        }
+        return CSV_OK;
+    };
+    if (R > 0 && r_overlap) {
+        hipStream_t sk = c->side[1];
+        // (the packed word lands where the packed start-ordered table will be built - s_idp is not written before k_reads_gather)
+        HIP_TRY(c, hipMemcpyAsync(c->s_idp.p, in->r_idp, (size_t)R * 4, hipMemcpyHostToDevice, sr));
+        HIP_TRY(c, hipEventRecord(c->ev_rd[0], sr));
+        HIP_TRY(c, hipMemcpyAsync(c->rd16.p, in->r_delta, (size_t)R * 2, hipMemcpyHostToDevice, sr));
+        HIP_TRY(c, hipEventRecord(c->ev_rd[1], sr));
+        HIP_TRY(c, hipMemcpyAsync(c->rl16.p, in->r_len16, (size_t)R * 2, hipMemcpyHostToDevice, sr));
+        // (the anchors travel on another copy stream: between two columns in this one they cost the link 34 us of turn-arounds)
+        int* h_off = reads_anchors();
+        HIP_TRY(c, hipStreamWaitEvent(c->copy[1], c->ev_init, 0));
+        HIP_TRY(c, hipMemcpyAsync(c->ranc.p, h_off, ranc_bytes, hipMemcpyHostToDevice, c->copy[1]));
+        HIP_TRY(c, hipEventRecord(c->ev_rd[3], c->copy[1]));
+        HIP_TRY(c, hipStreamWaitEvent(sk, c->ev_rd[0], 0));
+        hipLaunchKernelGGL(k_reads_split_idp, dim3(div_up(R, 256)), dim3(256), 0, sk, (const unsigned*)c->s_idp.p, dp<int>(c->r_id), dp<uint8_t>(c->r_primary), R);
+        HIP_TRY(c, hipStreamWaitEvent(sk, c->ev_rd[1], 0));
+        HIP_TRY(c, hipStreamWaitEvent(sk, c->ev_rd[3], 0));
+        reads_unpack(sk);
+        HIP_TRY(c, hipEventRecord(c->ev_rd[2], sk));
+        HIP_TRY(c, hipStreamWaitEvent(sr, c->ev_rd[2], 0));          // (long fired when the lengths have crossed)
+        { const int rc = reads_ends(sr); if (rc) return rc; }
+        c->reads_delta |= 4;
+    } else if (R > 0) {
         const size_t cw = rd32 ? 4 : 8;
         if (r_gaps) HIP_TRY(c, hipMemcpyAsync(c->rd16.p, in->r_delta, (size_t)R * 2, hipMemcpyHostToDevice, sr));
         else HIP_TRY(c, hipMemcpyAsync(c->r_start.p, in->r_start, R * cw, hipMemcpyHostToDevice, sr));
         if (r_lens) HIP_TRY(c, hipMemcpyAsync(c->rl16.p, in->r_len16, (size_t)R * 2, hipMemcpyHostToDevice, sr));
         else HIP_TRY(c, hipMemcpyAsync(c->r_end.p, in->r_end, R * cw, hipMemcpyHostToDevice, sr));
-        const bool r_packed = in->r_idp != nullptr && rd32 && !getenv("CSV_NO_DELTA16");
         if (r_packed) {
             // (the packed word lands where the packed start-ordered table will be built - s_idp is not written before k_reads_gather -
             // and is split into the two columns the reads stage reads)
@@ -885,42 +955,11 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
             HIP_TRY(c, hipMemcpyAsync(c->r_id.p, in->r_id, R * 4, hipMemcpyHostToDevice, sr));
         }
         if (r_gaps) {
-            // anchors of the start column, built while the table is on the link: the first row of every tile of 2048 rows, the
-            // first row of every chromosome block, the caller's escape rows (the first row of every sorted run is one) - rows of
-            // the table itself: no w space here.  They follow the table on its own stream (page-locked staging: h_ranc).
-            const int32_t* hs = (const int32_t*)in->r_start;
-            std::vector<std::pair<i64, int>> anc;
-            anc.reserve((size_t)r_anc_cap);
-            for (i64 t = 0; t < r_ntile; t++) anc.emplace_back(t * (i64)CH_TILE, hs[t * (i64)CH_TILE]);
-            for (int k = 0; k < in->n_chrom; k++) { const i64 r0 = in->reads_off[k]; if (r0 >= 0 && r0 < R) anc.emplace_back(r0, hs[r0]); }
-            for (i64 e = 0; e < in->n_r_esc; e++) { const i64 r0 = in->r_esc_row[e]; if (r0 >= 0 && r0 < R) anc.emplace_back(r0, in->r_esc_val[e]); }
-            std::sort(anc.begin(), anc.end());
-            anc.erase(std::unique(anc.begin(), anc.end(), [](const std::pair<i64, int>& x, const std::pair<i64, int>& y) { return x.first == y.first; }), anc.end());
-            int* h_off = (int*)(c->h_pin + o_ranc);          // (page-locked staging: a copy out of pageable memory would block the host
-                                                             // until the table in front of it on this stream has crossed the link)
-            int* h_w = h_off + r_ntile + 2;
-            int* h_v = h_w + r_anc_cap;
-            size_t q = 0;
-            for (i64 t = 0; t <= r_ntile; t++) { while (q < anc.size() && anc[q].first < t * (i64)CH_TILE) q++; h_off[t] = (int)q; }
-            h_off[r_ntile + 1] = (int)anc.size();
-            for (size_t i = 0; i < anc.size(); i++) { h_w[i] = (int)anc[i].first; h_v[i] = anc[i].second; }
+            int* h_off = reads_anchors();
             HIP_TRY(c, hipMemcpyAsync(c->ranc.p, h_off, ranc_bytes, hipMemcpyHostToDevice, sr));
-            UnpackArgs UA{dp<uint16_t>(c->rd16), dp<int>(c->r_start), R, dp<int>(c->ranc), dp<int>(c->ranc) + r_ntile + 2, dp<int>(c->ranc) + r_ntile + 2 + r_anc_cap, (int)r_ntile, 0, 0};
-            DevBatch none;
-            memset(&none, 0, sizeof none);
-            hipLaunchKernelGGL(k_unpack_a16, dim3((unsigned)r_ntile), dim3(256), 0, sr, UA, none);
+            reads_unpack(sr);
         }
-        if (r_lens) {
-            hipLaunchKernelGGL(k_reads_end16, dim3(div_up(R, 256)), dim3(256), 0, sr, (const int*)dp<int>(c->r_start), (const uint16_t*)dp<uint16_t>(c->rl16), dp<int>(c->r_end), R);
-            if (in->n_l_esc > 0) {
-                char* base = (char*)c->rlesc.p;
-                char* hst = c->h_pin + o_lesc;                // (through the page-locked staging, as above)
-                memcpy(hst, in->l_esc_row, (size_t)in->n_l_esc * 8);
-                memcpy(hst + (size_t)in->n_l_esc * 8, in->l_esc_val, (size_t)in->n_l_esc * 4);
-                HIP_TRY(c, hipMemcpyAsync(base, hst, (size_t)in->n_l_esc * 12, hipMemcpyHostToDevice, sr));
-                hipLaunchKernelGGL(k_scatter_rows_i32, dim3(div_up(in->n_l_esc, 256)), dim3(256), 0, sr, (const i64*)base, (const int*)(base + (size_t)in->n_l_esc * 8), dp<int>(c->r_end), in->n_l_esc, R);
-            }
-        }
+        if (r_lens) { const int rc = reads_ends(sr); if (rc) return rc; }
     }
     // (the main stream does not wait for the reads table: the kernels that read it are ordered behind this event)
     if (have_tab) HIP_TRY(c, hipEventRecord(c->ev_reads, sr));

@@ -25,10 +25,11 @@ for wl in ([x for x in sys.argv[1:] if not x.startswith("only=")] or ["cfg3"]):
                            ("gate-first/full/no-delta16", {"CSV_NO_DELTA16": "1"}, {}), ("gate-first/full", {}, {}),
                            ("gate-first/slim/no-delta16", {"CSV_NO_DELTA16": "1"}, SLIM), ("gate-first/slim", {}, SLIM),
                            ("gate-first/full/no-peek", {"CSV_NO_PEEK": "1"}, {}), ("gate-first/full/no-rows8", {"CSV_NO_ROWS8": "1"}, {}),
-                           ("gate-first/slim/no-rows8", {"CSV_NO_ROWS8": "1"}, SLIM), ("gate-first/slim", {}, SLIM), ("gate-first/full", {}, {})):
+                           ("gate-first/slim/no-rows8", {"CSV_NO_ROWS8": "1"}, SLIM), ("gate-first/full/no-reads-overlap", {"CSV_NO_READS_OVERLAP": "1"}, {}),
+                           ("gate-first/slim", {}, SLIM), ("gate-first/full", {}, {})):
         if ONLY is not None and label not in ONLY:
             continue
-        for k in ("CSV_NO_LAZY", "CSV_COPY_STREAM", "CSV_NO_DELTA16", "CSV_NO_PEEK", "CSV_NO_ROWS8"):
+        for k in ("CSV_NO_LAZY", "CSV_COPY_STREAM", "CSV_NO_DELTA16", "CSV_NO_PEEK", "CSV_NO_ROWS8", "CSV_NO_READS_OVERLAP"):
             os.environ.pop(k, None)
         os.environ.update(env)
         ctx._res_cache = None

@@ -26,6 +26,8 @@ ls $F | wc -l
 timeout 300 python scripts/oneshot_ab.py cfg3 cfg4 cfg5 cfg2 > $F/${TAG}_oneshot_ab.txt 2>&1; tail -4 $F/${TAG}_oneshot_ab.txt
 ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/os_tl && cd $R && timeout -k 5 300 rocprofv3 --kernel-trace --memory-copy-trace -d /tmp/os_tl -o tl -- python scripts/oneshot_ab.py cfg3 > $F/${TAG}_oneshot_tl.log 2>&1 )
 python scripts/rocprof_oneshot_timeline.py $(ls /tmp/os_tl/*.db /tmp/os_tl/*/*.db 2>/dev/null | head -1) 2 > $F/${TAG}_oneshot_timeline.txt 2>&1
+( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/os_tl4 && cd $R && timeout -k 5 300 rocprofv3 --kernel-trace --memory-copy-trace -d /tmp/os_tl4 -o tl -- python scripts/oneshot_ab.py cfg4 only=gate-first/full > /dev/null 2>&1 )
+python scripts/rocprof_oneshot_timeline.py $(ls /tmp/os_tl4/*.db /tmp/os_tl4/*/*.db 2>/dev/null | head -1) 1 > $F/${TAG}_oneshot_timeline_cfg4.txt 2>&1
 python scripts/resource_usage.py > $F/${TAG}_resource_usage.txt 2>/dev/null
 # where k_genotype's wavefronts spend their cycles (measurement build: make -C cutesv_amd/csrc gt-prof)
 if [ -f $R/build/lib_prof.so ]; then for wl in cfg5 cfg4; do echo "# $wl"; CUTESV_AMD_LIB=$R/build/lib_prof.so timeout 300 python scripts/gt_prof.py $wl 2>&1 | grep gt_prof | tail -1; done > $F/${TAG}_gt_prof.txt; fi
