@@ -112,7 +112,7 @@ struct csv_ctx {
     hipStream_t stream = nullptr;
     hipStream_t side[3] = {};         // side streams: [0] mid + workgroup tier, [1] DUP/INV/TRA wavefront tier, [2] reads order + prefix max
     hipStream_t copy[N_COPY_STREAMS] = {};    // host -> device column copies (one DMA engine each)
-    hipEvent_t  ev_init = nullptr, ev_sel = nullptr, ev_aux[3] = {}, ev_copy[N_COPY_STREAMS] = {}, ev_reads = nullptr, ev_anc = nullptr, ev_rd[4] = {};
+    hipEvent_t  ev_init = nullptr, ev_sel = nullptr, ev_aux[3] = {}, ev_copy[N_COPY_STREAMS] = {}, ev_reads = nullptr, ev_anc = nullptr, ev_rd[5] = {};
     std::string err;
     hipEvent_t  ev[CSV_N_STAGES + 2] = {};
     Arena       arena, arena_rb;
@@ -124,6 +124,7 @@ struct csv_ctx {
     int  reads_delta = 0;                      // bit 0: the last upload's reads starts crossed as gaps, bit 1: its ends as lengths (csv_batch_info 3)
     bool delta16 = false;                      // the last upload rebuilt its position column from gaps (csv_batch_info 2)
     bool rstate_dirty = true;                  // the reads-order state may hold an earlier upload's verdict
+    bool reads_early = false;                  // the last upload decoded the reads table's start column on side[1] (upload_impl)
     bool unpack_pending = false; UnpackArgs unpack_args{}; int unpack_tiles = 0;      // ... and k_unpack_a16 is still to be queued (one-shot calls: by the run)
     Buf cluster_id, partial, tile_cnt, item_rec, list_small, list_big, list_tiny, list_wide, seg_gate, tile_info, ch_masks, tile_items, seg_err;
     Buf item_cnt, item_base, item_chunk, sup_tmp;
@@ -640,6 +641,7 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
     const bool r_lens = rdz && in->r_len16 && in->n_l_esc >= 0 && (in->n_l_esc == 0 || (in->l_esc_row && in->l_esc_val)) && in->n_l_esc * esc_per <= R;
     const i64 r_ntile = div_up(R, CH_TILE), r_anc_cap = r_gaps ? (r_ntile + in->n_chrom + in->n_r_esc + 8) : 0;
     c->reads_delta = (r_gaps ? 1 : 0) | (r_lens ? 2 : 0);
+    c->reads_early = false;
     // the small tables (segments, prefix, drop marks, gate records, status words, chain tile records) are ONE block laid out like
     // their page-locked staging copy: one DMA copy brings them all (r04: five blit kernels of ~5 us each in front of the columns)
     const size_t o_seg = 0, o_woff = o_seg + (size_t)(S + 1) * sizeof(csv_segment), o_drop = o_woff + (size_t)(S + 2) * 8,
@@ -938,6 +940,7 @@ int upload_impl(csv_ctx* c, const csv_batch_in* in, bool per_sig_forced, bool sy
         HIP_TRY(c, hipStreamWaitEvent(sr, c->ev_rd[2], 0));          // (long fired when the lengths have crossed)
         { const int rc = reads_ends(sr); if (rc) return rc; }
         c->reads_delta |= 4;
+        c->reads_early = true;                              // (the first run may order the table on the decode stream)
     } else if (R > 0) {
         const size_t cw = rd32 ? 4 : 8;
         if (r_gaps) HIP_TRY(c, hipMemcpyAsync(c->rd16.p, in->r_delta, (size_t)R * 2, hipMemcpyHostToDevice, sr));
@@ -1144,7 +1147,10 @@ int run_impl(csv_ctx* c, csv_run_stats* stats)
         HIP_TRY(c, mark());                                                            \
     } while (0)
 #define LAUNCH(name, kern, grid, block, lds, ...) LAUNCH_ON(st, name, kern, grid, block, lds, __VA_ARGS__)
-    auto reads_stage = [&](hipStream_t s2) -> int {       // reads order + pack + longest read per chromosome on stream s2
+    // s_early: the stream the upload decoded the start column on (a one-shot call whose reads table came in its 16-bit forms):
+    // k_reads_runs / k_reads_plan read the starts and nothing else of the table, so they run there, behind the decode, while the
+    // end column is still on the link; s2 waits for their event before it packs the table
+    auto reads_stage = [&](hipStream_t s2, hipStream_t s_early = nullptr) -> int {       // reads order + pack + longest read per chromosome on stream s2
         const int nr = div_up(B.n_reads, 2048);
         const bool rn = B.r_start.p32 != nullptr;
         const bool keep = keep_reads;
@@ -1153,13 +1159,15 @@ int run_impl(csv_ctx* c, csv_run_stats* stats)
                 const int rc = general_reads_sort(c, s2);
                 if (rc) return rc;
             } else if (B.ro_mode == 1) {
+                const hipStream_t so = s_early ? s_early : s2;
                 if (rn) {
-                    hipLaunchKernelGGL(k_reads_runs<true>, dim3(div_up(B.n_reads, RO_TILE)), dim3(256), 0, s2, B);
-                    hipLaunchKernelGGL(k_reads_plan<true>, dim3(1), dim3(RP_THREADS), LDS_PLAN, s2, B);
+                    hipLaunchKernelGGL(k_reads_runs<true>, dim3(div_up(B.n_reads, RO_TILE)), dim3(256), 0, so, B);
+                    hipLaunchKernelGGL(k_reads_plan<true>, dim3(1), dim3(RP_THREADS), LDS_PLAN, so, B);
                 } else {
-                    hipLaunchKernelGGL(k_reads_runs<false>, dim3(div_up(B.n_reads, RO_TILE)), dim3(256), 0, s2, B);
-                    hipLaunchKernelGGL(k_reads_plan<false>, dim3(1), dim3(RP_THREADS), LDS_PLAN, s2, B);
+                    hipLaunchKernelGGL(k_reads_runs<false>, dim3(div_up(B.n_reads, RO_TILE)), dim3(256), 0, so, B);
+                    hipLaunchKernelGGL(k_reads_plan<false>, dim3(1), dim3(RP_THREADS), LDS_PLAN, so, B);
                 }
+                if (s_early) { HIP_TRY(c, hipEventRecord(c->ev_rd[4], so)); HIP_TRY(c, hipStreamWaitEvent(s2, c->ev_rd[4], 0)); }
             }
         }
         DBG("reads_order");
@@ -1202,7 +1210,10 @@ int run_impl(csv_ctx* c, csv_run_stats* stats)
             // verdict on the table goes to the upload's state, not to the run's counters (which k_chain_count zeroes).
             HIP_TRY(c, hipEventRecord(c->ev_init, sM));
             HIP_TRY(c, hipStreamWaitEvent(swap ? st : sD, c->ev_init, 0));
-            const int rc = reads_stage(sD);
+            const bool early = c->reads_early && c->copies_pending && !swap && !O.no_reads_overlap;
+            if (early) HIP_TRY(c, hipStreamWaitEvent(c->side[1], c->ev_init, 0));
+            const int rc = reads_stage(sD, early ? c->side[1] : nullptr);
+            c->reads_early = false;
             if (rc) return rc;
             if (!swap) HIP_TRY(c, hipEventRecord(c->ev_aux[2], sD));
         }
