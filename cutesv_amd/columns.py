@@ -197,29 +197,15 @@ def _reads_near(pos1, pos2, r_start, r_end, margin, shift=10):
     a mean of member positions for DUP / INV, for either coordinate - DUP:99-109, 146-151; INV:129-130, 218-221) with h <=
     `margin`; neighbouring members of a cluster are at most max_cluster_bias <= margin apart (the chain and sub-cluster rules),
     so every window lies inside the union of [x - margin, x + margin] over the task's signature coordinates x.  A read that COVERS
-    a window (start <= L and end >= R, GT:95-159) contains it, hence intersects that union.  The union is kept as a bit per
-    1024-bp bin; a read stays iff a marked bin lies in [start, end].  Everything else in the block - 90 % and more of a genome's
-    reads for a 30x call set - is never interned, never uploaded and never sorted.  -> bool mask, or None (keep all)."""
-    n = len(pos1)
-    if n == 0 or len(r_start) == 0:
-        return None
-    xs = pos1 if pos2 is None else np.concatenate([pos1, pos2])
-    hi = int(max(int(xs.max()), int(r_end.max()))) + margin + (2 << shift)
-    lo_ok = int(xs.min()) >= 0 and int(r_start.min()) >= 0
-    if not lo_ok or hi >= (1 << 40):
-        return None
-    nb = (hi >> shift) + 2
-    lo_b = np.maximum(xs - margin, 0) >> shift
-    hi_b = (xs + margin) >> shift
-    d = np.zeros(nb + 1, np.int64)                           # +1 at the first bin of a marked range, -1 behind its last
-    np.add.at(d, lo_b, 1)
-    np.add.at(d, hi_b + 1, -1)
-    marked = np.cumsum(d[:-1]) > 0
-    cum = np.zeros(nb + 1, np.int64)
-    np.cumsum(marked, out=cum[1:])
-    rb0 = np.minimum(r_start >> shift, nb - 1)
-    rb1 = np.minimum(np.maximum(r_end, r_start) >> shift, nb - 1)
-    return (cum[rb1 + 1] - cum[rb0]) > 0
+    a window (start <= L and end >= R, GT:95-159) contains it, hence intersects that union.  The union is kept as a flag per
+    1024-bp bin; a read stays iff a flagged bin lies in [start, end].  Everything else in the block - 90 % and more of a genome's
+    reads for a 30x call set - is never interned, never uploaded and never sorted.  -> bool mask, or None (keep all).
+    One pass over the signatures and one over the block in C (`_cols_native.reads_near`; the numpy statement of the same rule is
+    kept by tests/test_host_logic.py)."""
+    from . import _cols_native as cn
+    i64 = lambda x: np.ascontiguousarray(x, np.int64)          # noqa: E731
+    m = cn.reads_near(i64(pos1), None if pos2 is None else i64(pos2), i64(r_start), i64(r_end), int(margin), int(shift))
+    return None if m is None else np.frombuffer(bytearray(m), np.bool_)
 
 
 @dataclass
@@ -626,7 +612,8 @@ class SigStore:
                    names=NameTable(uniq), ins_seq=ins_seq if svtype == "INS" else {}, strands=strands, **kw)
 
     @classmethod
-    def from_task_pickles(cls, svtype, chrom, sig_buf, sig_off, reads_buf=None, reads_off=None, gt_margin=None, reads_cache=None, reads_key=None):
+    def from_task_pickles(cls, svtype, chrom, sig_buf, sig_off, reads_buf=None, reads_off=None, gt_margin=None, reads_cache=None, reads_key=None,
+                          sig_end=None, reads_end=None):
         """from_task_lists without the lists: the task's pickle (and its chromosome's reads pickle) walked in C straight out of
         the mapped files (`_cols_native.pickle_table`): integer fields into the columns, strings as spans of the file - the
         read names interned by their bytes, the inserted sequences never touched unless a call picks one.  The 110 862
@@ -637,11 +624,13 @@ class SigStore:
         reads_cache / reads_key: the walked form of a chromosome's reads block is shared between the tasks of the chromosome - DEL,
         INS, INV, DUP each walk the same block in the reference (INDEL:445-448) - through anything that offers
         `reads_get(key) -> WalkedReads | None` and `reads_put(key, WalkedReads)` (broker.Client: the GPU's broker keeps the blocks
-        in shared memory for the pool's workers)."""
+        in shared memory for the pool's workers).
+        sig_end / reads_end: where the block ends in its file, if the caller knows (the next offset of `sigindex.pickle`): the walker
+        then sizes its columns once instead of doubling them (a hint - a wrong one costs memory or time, never a row)."""
         from . import _cols_native as cn                     # (built by the same make as the library; no Python fallback)
         ints, strs, width = {"DEL": ((0, 1), (2,), 5), "DUP": ((0, 1), (2,), 5), "INS": ((0, 1), (2, 3), 6),
                              "INV": ((1, 2), (0, 3), 6), "TRA": ((1, 3), (0, 2, 4), 7)}[svtype]
-        t = cn.pickle_table(sig_buf, int(sig_off), width, ints, strs)
+        t = cn.pickle_table(sig_buf, int(sig_off), width, ints, strs, -1 if sig_end is None else int(sig_end))
         if t is None:
             return None
         n = int(t[0])
@@ -653,7 +642,8 @@ class SigStore:
             if reads_cache is not None and reads_key is not None:
                 wr = reads_cache.reads_get(reads_key)
             if wr is None:
-                rt = cn.pickle_table(reads_buf, int(reads_off), 5, (0, 1, 2), (3, 4))      # (start, end, is_primary, read, chr), main script :733
+                rt = cn.pickle_table(reads_buf, int(reads_off), 5, (0, 1, 2), (3, 4),      # (start, end, is_primary, read, chr), main script :733
+                                     -1 if reads_end is None else int(reads_end))
                 if rt is None:
                     return None
                 wr = WalkedReads.from_table(rt)
@@ -697,8 +687,9 @@ class SigStore:
                 if keep is not None:
                     if not keep.any():
                         keep[0] = True                      # (a block with reads stays a block with reads: DR = 0, not "no reads block")
-                    r_start, r_end, r_primary = r_start[keep], r_end[keep], r_primary[keep]
-                    rsp = [(o[keep], l[keep]) for o, l in rsp]
+                    sel = np.flatnonzero(keep)                # (one index list, seven takes: a boolean mask is re-scanned by every column)
+                    r_start, r_end, r_primary = r_start.take(sel), r_end.take(sel), r_primary.take(sel)
+                    rsp = [(o.take(sel), l.take(sel)) for o, l in rsp]
                     nr = len(r_start)
             r_id = np.empty(nr, np.int32)
             spec.append((reads_buf, rsp[0][0], rsp[0][1], r_id))

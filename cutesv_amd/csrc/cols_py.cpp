@@ -19,6 +19,7 @@
 #include <Python.h>
 #include <stdint.h>
 #include <string.h>
+#include <sys/mman.h>
 #include <vector>
 
 namespace {
@@ -318,7 +319,7 @@ PyObject* clip_join(PyObject*, PyObject* args)
 // PROTO FRAME EMPTY_LIST MARK APPEND(S) TUPLE/1/2/3 EMPTY_TUPLE BININT/1/2 LONG1 BINFLOAT (SHORT_)BINUNICODE(8) MEMOIZE BINPUT
 // LONG_BINPUT BINGET LONG_BINGET NEWTRUE NEWFALSE NONE STOP - and returns None for anything else (the caller then uses pickle).
 //
-//   pickle_table(buf, offset, width, int_fields, str_fields) -> None | (n_rows, end_offset, [int64 bytes per int field],
+//   pickle_table(buf, offset, width, int_fields, str_fields[, end_hint]) -> None | (n_rows, end_offset, [int64 bytes per int field],
 //                                                                      [(offsets int64 bytes, lengths int32 bytes) per str field],
 //                                                                      all_ascii: no string payload of the stream has a byte >= 0x80)
 //   span_intern(((buf, offsets, lengths, ids int32 out), ...)) -> (blob bytes, offsets int64 bytes, lengths int32 bytes) of the
@@ -337,7 +338,11 @@ inline bool utf8_ok(const unsigned char* s, int64_t n, bool* not_ascii = nullptr
         uint64_t acc = 0;
         int64_t j = 0;
         for (; j + 32 <= n; j += 32) { uint64_t w[4]; memcpy(w, s + j, 32); acc |= (w[0] | w[1]) | (w[2] | w[3]); }
-        for (; j < n; j++) acc |= s[j];
+        for (; j + 8 <= n; j += 8) { uint64_t w; memcpy(&w, s + j, 8); acc |= w; }
+        if (j < n) {                                      // (a read name: one or two words and the word that ends at its last byte)
+            if (n >= 8) { uint64_t w; memcpy(&w, s + n - 8, 8); acc |= w; }
+            else for (; j < n; j++) acc |= s[j];
+        }
         if (!(acc & 0x8080808080808080ull)) return true;
     }
     if (not_ascii) *not_ascii = true;
@@ -367,12 +372,68 @@ struct Reader {
     bool need(int64_t k) const { return i + k <= n; }
     uint64_t le(int k) { uint64_t v = 0; for (int b = 0; b < k; b++) v |= (uint64_t)p[i + b] << (8 * b); i += k; return v; }
 };
+inline uint32_t le32(const unsigned char* q) { return (uint32_t)q[0] | (uint32_t)q[1] << 8 | (uint32_t)q[2] << 16 | (uint32_t)q[3] << 24; }
+inline uint64_t le64(const unsigned char* q) { return (uint64_t)le32(q) | (uint64_t)le32(q + 4) << 32; }
+
+// the memo (and nothing else): plain records in a block that grows by realloc - for the 12 M entries of a HiFi chromosome's reads
+// block that is a remap of pages, not the copy a std::vector makes at every doubling
+// A block that has just grown by megabytes and is about to be written front to back: have the kernel map its new pages in one
+// call (MADV_POPULATE_WRITE, Linux 5.14) instead of taking a fault per 4 KB page - ~1.4 us apiece on the pool's (virtual) machines,
+// 170 ms for the 0.5 GB of columns and memo of a HiFi chromosome's reads block.  Advice only: an older kernel refuses, nothing changes.
+#ifndef MADV_POPULATE_WRITE
+#define MADV_POPULATE_WRITE 23
+#endif
+inline void grown(void* p, size_t old_bytes, size_t bytes)
+{
+    if (bytes < old_bytes + (4u << 20)) return;
+    const uintptr_t a = ((uintptr_t)p + old_bytes + 4095) & ~(uintptr_t)4095, e = ((uintptr_t)p + bytes) & ~(uintptr_t)4095;
+    if (e > a) (void)madvise((void*)a, e - a, MADV_POPULATE_WRITE);
+}
+
+template <class T> struct Pod {
+    T* p = nullptr; size_t n = 0, cap = 0;
+    ~Pod() { free(p); }
+    bool push(const T& x)
+    {
+        if (n == cap) {
+            const size_t c = cap ? cap * 2 : 4096;
+            T* q = (T*)realloc(p, c * sizeof(T));
+            if (!q) return false;
+            grown(q, cap * sizeof(T), c * sizeof(T));
+            p = q; cap = c;
+        }
+        p[n++] = x;
+        return true;
+    }
+};
+
+// The table's columns ARE the bytes objects pickle_table returns: written in place, grown together (one capacity check per row)
+// through _PyBytes_Resize - realloc underneath - and cut to the row count at the end.  (r05: a std::vector per column, copied at
+// every doubling and once more into its bytes object - 0.3 GB of extra traffic for a 6 M-row reads block.)
+struct Columns {
+    std::vector<PyObject*> o; std::vector<int> item; std::vector<char*> base;
+    size_t cap = 0;
+    ~Columns() { for (PyObject* x : o) Py_XDECREF(x); }
+    void add(int itemsize) { o.push_back(nullptr); item.push_back(itemsize); base.push_back(nullptr); }
+    bool reserve(size_t rows)
+    {
+        for (size_t k = 0; k < o.size(); k++) {
+            if (!o[k]) { o[k] = PyBytes_FromStringAndSize(nullptr, (Py_ssize_t)(rows * (size_t)item[k])); if (!o[k]) return false; }
+            else if (_PyBytes_Resize(&o[k], (Py_ssize_t)(rows * (size_t)item[k])) != 0) return false;      // (o[k] is NULL then, the error set)
+            base[k] = PyBytes_AS_STRING(o[k]);
+            grown(base[k], cap * (size_t)item[k], rows * (size_t)item[k]);
+        }
+        cap = rows;
+        return true;
+    }
+    PyObject* take(size_t k) { PyObject* x = o[k]; o[k] = nullptr; return x; }
+};
 }   // namespace pk
 
 PyObject* pickle_table(PyObject*, PyObject* args)
 {
-    PyObject *obuf, *oints, *ostrs; Py_ssize_t offset, width;
-    if (!PyArg_ParseTuple(args, "OnnO!O!", &obuf, &offset, &width, &PyTuple_Type, &oints, &PyTuple_Type, &ostrs)) return nullptr;
+    PyObject *obuf, *oints, *ostrs; Py_ssize_t offset, width, end_hint = -1;
+    if (!PyArg_ParseTuple(args, "OnnO!O!|n", &obuf, &offset, &width, &PyTuple_Type, &oints, &PyTuple_Type, &ostrs, &end_hint)) return nullptr;
     Py_buffer view{};
     if (PyObject_GetBuffer(obuf, &view, PyBUF_SIMPLE) != 0) return nullptr;
     struct Rel { Py_buffer* v; ~Rel() { PyBuffer_Release(v); } } rel{&view};
@@ -386,41 +447,62 @@ PyObject* pickle_table(PyObject*, PyObject* args)
 
     using namespace pk;
     Reader R{(const unsigned char*)view.buf, (int64_t)view.len, (int64_t)offset};
-    std::vector<Cell> st, memo;
-    std::vector<std::vector<int64_t>> ci(fi.size()), so(fs.size());
-    std::vector<std::vector<int32_t>> sl(fs.size());
+    std::vector<Cell> st;
+    Pod<Cell> memo;
+    Columns C;                                                           // int fields (int64), then (offset int64, length int32) per string field
+    const size_t NI = fi.size(), NS = fs.size();
+    for (size_t k = 0; k < NI; k++) C.add(8);
+    for (size_t k = 0; k < NS; k++) { C.add(8); C.add(4); }
+    if (!C.reserve(1024)) return nullptr;
     int64_t n_rows = 0;
-    bool done = false, unsupported = false, any_non_ascii = false;       // (all-ASCII text: len() of a string is its byte count)
+    bool done = false, unsupported = false, oom = false, any_non_ascii = false;       // (all-ASCII text: len() of a string is its byte count)
     const char* corrupt = nullptr;
     auto memo_put = [&](uint64_t k) {
         if (st.empty()) { corrupt = "memo of an empty stack"; return; }
-        if (k > memo.size()) { unsupported = true; return; }                         // (pickle numbers its memo densely; anything else: not ours)
-        if (k == memo.size()) memo.push_back(st.back()); else memo[(size_t)k] = st.back();
+        if (k > memo.n) { unsupported = true; return; }                              // (pickle numbers its memo densely; anything else: not ours)
+        if (k == memo.n) { if (!memo.push(st.back())) oom = true; } else memo.p[(size_t)k] = st.back();
+    };
+    // the fields x[0 .. c) of one tuple -> row n_rows of the columns; false: not a row of ours (nothing is written then)
+    constexpr size_t MAXF = 16;
+    auto put_row = [&](const Cell* x, size_t c) -> bool {
+        if (NI > MAXF || NS > MAXF) return false;
+        int64_t iv[MAXF];
+        for (size_t k = 0; k < NI; k++) {
+            if ((size_t)fi[k] >= c) return false;
+            const Cell& y = x[(size_t)fi[k]];
+            if (y.kind == INT) iv[k] = y.a;
+            else if (y.kind == FLOAT) {
+                double d; memcpy(&d, &y.a, 8);
+                if (!(d > -9.2e18 && d < 9.2e18)) return false;                       // (nan / inf / beyond int64: let pickle + int() say it)
+                iv[k] = (int64_t)d;                                                   // int(x): truncation toward zero
+            } else return false;
+        }
+        for (size_t k = 0; k < NS; k++) if ((size_t)fs[k] >= c || x[(size_t)fs[k]].kind != STR) return false;
+        if ((size_t)n_rows == C.cap) {
+            // full: twice the rows - or, when the caller has said where the block ends (the next offset of the index), the rows the
+            // rest of it will hold at the bytes per row seen so far (+ 3 %): ONE growth, no copy of a column at every doubling
+            size_t want = C.cap * 2;
+            if (end_hint > R.i && end_hint <= R.n && n_rows >= 1024 && R.i > (int64_t)offset) {
+                const double per_row = (double)(R.i - (int64_t)offset) / (double)n_rows;
+                const double est = (double)n_rows + (double)(end_hint - R.i) / per_row * 1.03 + 1024.0;
+                if (est > (double)want && est < 4e9) want = (size_t)est;
+            }
+            if (!C.reserve(want)) { oom = true; return false; }                       // (what the block needs is what doubling would reach, too)
+        }
+        for (size_t k = 0; k < NI; k++) ((int64_t*)C.base[k])[n_rows] = iv[k];
+        for (size_t k = 0; k < NS; k++) {
+            const Cell& y = x[(size_t)fs[k]];
+            ((int64_t*)C.base[NI + 2 * k])[n_rows] = y.a;
+            ((int32_t*)C.base[NI + 2 * k + 1])[n_rows] = y.len;
+        }
+        return true;
     };
     auto make_row = [&](size_t first) {              // the cells st[first ..] are the fields of one tuple
         const size_t c = st.size() - first;
         // a row must be an element of THE list: [LIST, row] (APPEND form) or [LIST, MARKER, row, row, ...] (APPENDS batches)
         const bool placed = (first == 1 && st[0].kind == LIST) ||
                             (first >= 2 && st[0].kind == LIST && st[1].kind == MARKER && (first == 2 || st[first - 1].kind == ROW));
-        if (!placed || (width >= 0 && (Py_ssize_t)c != width)) { unsupported = true; return; }
-        for (size_t k = 0; k < fi.size(); k++) {
-            if ((size_t)fi[k] >= c) { unsupported = true; return; }
-            const Cell& x = st[first + (size_t)fi[k]];
-            int64_t v;
-            if (x.kind == INT) v = x.a;
-            else if (x.kind == FLOAT) {
-                double d; memcpy(&d, &x.a, 8);
-                if (!(d > -9.2e18 && d < 9.2e18)) { unsupported = true; return; }        // (nan / inf / beyond int64: let pickle + int() say it)
-                v = (int64_t)d;                                                          // int(x): truncation toward zero
-            } else { unsupported = true; return; }
-            ci[k].push_back(v);
-        }
-        for (size_t k = 0; k < fs.size(); k++) {
-            if ((size_t)fs[k] >= c) { unsupported = true; return; }
-            const Cell& x = st[first + (size_t)fs[k]];
-            if (x.kind != STR) { unsupported = true; return; }
-            so[k].push_back(x.a); sl[k].push_back(x.len);
-        }
+        if (!placed || (width >= 0 && (Py_ssize_t)c != width) || !put_row(st.data() + first, c)) { unsupported = true; return; }
         st.resize(first);
         st.push_back(Cell{ROW, 0, n_rows});
         n_rows++;
@@ -429,7 +511,88 @@ PyObject* pickle_table(PyObject*, PyObject* args)
         for (long q = (long)st.size() - 1; q >= 0; q--) if (st[(size_t)q].kind == MARKER) return q;
         return -1;
     };
-    while (!done && !unsupported && !corrupt) {
+    // One row in one go: MARK <fields> TUPLE as the pickler writes an element of the list - the whole of a task's stream but
+    // for a few bytes per batch of 1000.  Same opcodes, same checks as the loop below, the fields in a local array instead of on
+    // the stack, one bounds check per opcode (16 bytes of slack) instead of one per operand.  Anything else - an opcode the rows
+    // of the main script's lists do not have, the last bytes of the buffer, a row the columns cannot take - and the row is handed
+    // back untouched (false: R.i and the memo as they were) for the loop below to read, and to judge.
+    auto fast_row = [&]() -> bool {
+        const unsigned char* const p = R.p;
+        const int64_t n = R.n;
+        int64_t i = R.i;
+        const size_t memo0 = memo.n;
+        Cell f[MAXF];
+        size_t nf = 0;
+        for (;;) {
+            if (n - i < 16) break;
+            const unsigned char op = p[i++];
+            Cell c;
+            switch (op) {
+            case 'K': c = Cell{INT, 0, (int64_t)p[i]}; i += 1; goto field;
+            case 'M': c = Cell{INT, 0, (int64_t)(p[i] | p[i + 1] << 8)}; i += 2; goto field;
+            case 'J': c = Cell{INT, 0, (int64_t)(int32_t)le32(p + i)}; i += 4; goto field;
+            case 0x8a: {                                                                                                                     // LONG1
+                const int k = p[i++];
+                if (k > 8) goto bail;
+                uint64_t v = 0;
+                for (int b = 0; b < k; b++) v |= (uint64_t)p[i + b] << (8 * b);
+                i += k;
+                if (k && k < 8 && (v >> (8 * k - 1)) & 1) v |= ~0ull << (8 * k);
+                c = Cell{INT, 0, (int64_t)v};
+                goto field;
+            }
+            case 'G': c = Cell{FLOAT, 0, (int64_t)__builtin_bswap64(le64(p + i))}; i += 8; goto field;                                       // BINFLOAT (big endian)
+            case 0x88: c = Cell{INT, 0, 1}; goto field;
+            case 0x89: c = Cell{INT, 0, 0}; goto field;
+            case 'N': c = Cell{OTHER, 0, 0}; goto field;
+            case 0x8c: case 'X': case 0x8d: {
+                uint64_t len;
+                if (op == 0x8c) { len = p[i]; i += 1; } else if (op == 'X') { len = le32(p + i); i += 4; } else { len = le64(p + i); i += 8; }
+                if (len > (uint64_t)INT32_MAX || (uint64_t)(n - i) < len) goto bail;
+                if (!utf8_ok(p + i, (int64_t)len, &any_non_ascii)) goto bail;
+                c = Cell{STR, (int32_t)len, i};
+                i += (int64_t)len;
+                goto field;
+            }
+            case 0x94: if (!nf) goto bail; if (!memo.push(f[nf - 1])) { oom = true; goto bail; } continue;                                  // MEMOIZE
+            case 'q': case 'r': {                                                                                                            // (LONG_)BINPUT
+                uint64_t k;
+                if (op == 'q') { k = p[i]; i += 1; } else { k = le32(p + i); i += 4; }
+                if (!nf || k != memo.n) goto bail;
+                if (!memo.push(f[nf - 1])) { oom = true; goto bail; }
+                continue;
+            }
+            case 'h': case 'j': {                                                                                                            // (LONG_)BINGET
+                uint64_t id;
+                if (op == 'h') { id = p[i]; i += 1; } else { id = le32(p + i); i += 4; }
+                if (id >= memo.n) goto bail;
+                c = memo.p[(size_t)id];
+                if (c.kind == ROW || c.kind == LIST || c.kind == MARKER) goto bail;
+                goto field;
+            }
+            case 0x95: {                                                                                                                     // FRAME
+                const uint64_t flen = le64(p + i); i += 8;
+                if (flen > (uint64_t)INT64_MAX || (uint64_t)(n - i) < flen) goto bail;
+                continue;
+            }
+            case 't': {
+                if ((width >= 0 && (Py_ssize_t)nf != width) || !put_row(f, nf)) goto bail;
+                st.push_back(Cell{ROW, 0, n_rows});
+                n_rows++;
+                R.i = i;
+                return true;
+            }
+            default: goto bail;
+            }
+        field:
+            if (nf == MAXF) goto bail;
+            f[nf++] = c;
+        }
+    bail:
+        memo.n = memo0;
+        return false;
+    };
+    while (!done && !unsupported && !corrupt && !oom) {
         if (!R.need(1)) { corrupt = "truncated"; break; }
         const unsigned char op = R.p[R.i++];
         switch (op) {
@@ -443,7 +606,12 @@ PyObject* pickle_table(PyObject*, PyObject* args)
             break;
         }
         case ']': st.push_back(Cell{LIST, 0, 0}); break;
-        case '(': st.push_back(Cell{MARKER, 0, 0}); break;
+        case '(':
+            // the MARK of a row - of the APPEND form, or inside an APPENDS batch - opens the fast path; the MARK of a batch does not
+            if (((st.size() == 1 && st[0].kind == LIST) || (st.size() >= 2 && st[0].kind == LIST && st[1].kind == MARKER && (st.size() == 2 || st.back().kind == ROW)))
+                && fast_row()) break;
+            st.push_back(Cell{MARKER, 0, 0});
+            break;
         case 'K': if (!R.need(1)) { corrupt = "truncated"; break; } st.push_back(Cell{INT, 0, (int64_t)R.le(1)}); break;
         case 'M': if (!R.need(2)) { corrupt = "truncated"; break; } st.push_back(Cell{INT, 0, (int64_t)R.le(2)}); break;
         case 'J': if (!R.need(4)) { corrupt = "truncated"; break; } st.push_back(Cell{INT, 0, (int64_t)(int32_t)(uint32_t)R.le(4)}); break;
@@ -477,15 +645,15 @@ PyObject* pickle_table(PyObject*, PyObject* args)
             R.i += (int64_t)len;
             break;
         }
-        case 0x94: memo_put(memo.size()); break;                                                                                             // MEMOIZE
+        case 0x94: memo_put(memo.n); break;                                                                                             // MEMOIZE
         case 'q': if (!R.need(1)) { corrupt = "truncated"; break; } memo_put(R.le(1)); break;                                               // BINPUT
         case 'r': if (!R.need(4)) { corrupt = "truncated"; break; } memo_put(R.le(4)); break;                                               // LONG_BINPUT
         case 'h': case 'j': {                                                                                                                // BINGET / LONG_BINGET
             const int k = op == 'h' ? 1 : 4;
             if (!R.need(k)) { corrupt = "truncated"; break; }
             const uint64_t id = R.le(k);
-            if (id >= memo.size()) { corrupt = "memo reference before its definition"; break; }
-            const Cell c = memo[(size_t)id];
+            if (id >= memo.n) { corrupt = "memo reference before its definition"; break; }
+            const Cell c = memo.p[(size_t)id];
             if (c.kind == ROW || c.kind == LIST || c.kind == MARKER) { unsupported = true; break; }     // a shared tuple / list: objects matter
             st.push_back(c);
             break;
@@ -522,21 +690,19 @@ PyObject* pickle_table(PyObject*, PyObject* args)
         default: unsupported = true; break;
         }
     }
+    if (oom) { if (!PyErr_Occurred()) PyErr_NoMemory(); return nullptr; }
     if (corrupt) { PyErr_Format(PyExc_ValueError, "pickle_table: %s at byte %lld", corrupt, (long long)R.i); return nullptr; }
     if (unsupported) Py_RETURN_NONE;
-    PyObject* ints = PyList_New((Py_ssize_t)fi.size());
-    PyObject* strs = PyList_New((Py_ssize_t)fs.size());
+    if (!C.reserve((size_t)n_rows)) return nullptr;                       // cut to the rows there are
+    PyObject* ints = PyList_New((Py_ssize_t)NI);
+    PyObject* strs = PyList_New((Py_ssize_t)NS);
     if (!ints || !strs) { Py_XDECREF(ints); Py_XDECREF(strs); return nullptr; }
-    for (size_t k = 0; k < fi.size(); k++) {
-        PyObject* b = PyBytes_FromStringAndSize((const char*)ci[k].data(), (Py_ssize_t)(ci[k].size() * 8));
-        if (!b) { Py_DECREF(ints); Py_DECREF(strs); return nullptr; }
-        PyList_SET_ITEM(ints, (Py_ssize_t)k, b);
-    }
-    for (size_t k = 0; k < fs.size(); k++) {
-        PyObject* o = PyBytes_FromStringAndSize((const char*)so[k].data(), (Py_ssize_t)(so[k].size() * 8));
-        PyObject* l = PyBytes_FromStringAndSize((const char*)sl[k].data(), (Py_ssize_t)(sl[k].size() * 4));
-        PyObject* t = (o && l) ? PyTuple_Pack(2, o, l) : nullptr;
-        Py_XDECREF(o); Py_XDECREF(l);
+    for (size_t k = 0; k < NI; k++) PyList_SET_ITEM(ints, (Py_ssize_t)k, C.take(k));
+    for (size_t k = 0; k < NS; k++) {
+        PyObject* o = C.take(NI + 2 * k);
+        PyObject* l = C.take(NI + 2 * k + 1);
+        PyObject* t = PyTuple_Pack(2, o, l);
+        Py_DECREF(o); Py_DECREF(l);
         if (!t) { Py_DECREF(ints); Py_DECREF(strs); return nullptr; }
         PyList_SET_ITEM(strs, (Py_ssize_t)k, t);
     }
@@ -603,9 +769,18 @@ PyObject* span_intern(PyObject*, PyObject* args)
     for (Py_ssize_t k = 0; k < ns; k++) {
         const SpanArgs& S = sp[(size_t)k];
         int32_t* out = (int32_t*)ids[(size_t)k].v.buf;
+        const char* prev_p = nullptr; int32_t prev_n = -1, prev_id = -1;
+        const Py_ssize_t AHEAD = 12;                                 // (the kept reads of a task lie scattered over a 0.2 GB file: a miss per name)
         for (Py_ssize_t i = 0; i < S.n(); i++) {
             const char* p; int32_t n;
+            if (i + AHEAD < S.n()) {
+                const int64_t o = ((const int64_t*)S.off.buf)[i + AHEAD];
+                if (o >= 0 && o < S.buf.len) __builtin_prefetch((const char*)S.buf.buf + o);
+            }
             if (!S.span(i, p, n)) return nullptr;
+            // the SAME bytes as the row before - a memo reference of the pickle: the chromosome of every row of a reads block, the
+            // "DEL" of every signature - need no hash
+            if (p == prev_p && n == prev_n) { out[i] = prev_id; continue; }
             const uint64_t h = hash_bytes(p, n);
             size_t q = (size_t)(h >> 7) & (cap - 1);
             int32_t id = -1;
@@ -622,6 +797,7 @@ PyObject* span_intern(PyObject*, PyObject* args)
                 blob_bytes += n;
             }
             out[i] = id;
+            prev_p = p; prev_n = n; prev_id = id;
         }
     }
     PyObject* blob = PyBytes_FromStringAndSize(nullptr, (Py_ssize_t)blob_bytes);
@@ -637,6 +813,69 @@ PyObject* span_intern(PyObject*, PyObject* args)
         po[u] = at; pl[u] = uniq[u].n; at += uniq[u].n;
     }
     return Py_BuildValue("(NNN)", blob, off, len);
+}
+
+// reads_near(pos1 int64, pos2 int64 | None, r_start int64, r_end int64, margin, shift) -> None | bytes (one 0 / 1 byte per read)
+// Which reads of a chromosome's block can cover a genotyping window of ONE task (columns.SigStore.from_task_pickles, where the
+// argument is made: every window lies in the union of [x - margin, x + margin] over the task's signature coordinates x, and a read
+// that covers a window intersects that union).  The union as a flag per 2^shift-bp bin, a running count of flagged bins, and one
+// subtraction per read - a pass over the signatures and a pass over the block instead of the dozen numpy passes (and their
+// temporaries: 240 ms over the 48 tasks of a HiFi genome) this replaces.  None: nothing to decide on (no signatures, no reads),
+// or coordinates outside [0, 2^40) - the caller keeps every read then.
+struct I64View {
+    Py_buffer v{}; bool held = false;
+    ~I64View() { if (held) PyBuffer_Release(&v); }
+    bool get(PyObject* o, const char* what)
+    {
+        if (PyObject_GetBuffer(o, &v, PyBUF_C_CONTIGUOUS | PyBUF_FORMAT) != 0) return false;
+        held = true;
+        if (v.itemsize != 8 || !v.format || (strcmp(v.format, "l") != 0 && strcmp(v.format, "q") != 0)) { PyErr_Format(PyExc_ValueError, "reads_near: %s must be a contiguous int64 array", what); return false; }
+        return true;
+    }
+    const int64_t* p() const { return (const int64_t*)v.buf; }
+    Py_ssize_t n() const { return v.len / 8; }
+};
+
+PyObject* reads_near(PyObject*, PyObject* args)
+{
+    PyObject *o1, *o2, *os, *oe; long long margin; int shift;
+    if (!PyArg_ParseTuple(args, "OOOOLi", &o1, &o2, &os, &oe, &margin, &shift)) return nullptr;
+    I64View x1, x2, rs, re;
+    if (!x1.get(o1, "pos1") || (o2 != Py_None && !x2.get(o2, "pos2")) || !rs.get(os, "r_start") || !re.get(oe, "r_end")) return nullptr;
+    if (rs.n() != re.n()) { PyErr_SetString(PyExc_ValueError, "reads_near: r_start and r_end differ in length"); return nullptr; }
+    if (margin < 0 || shift < 0 || shift > 30) { PyErr_SetString(PyExc_ValueError, "reads_near: margin >= 0 and 0 <= shift <= 30"); return nullptr; }
+    const Py_ssize_t nx = x1.n(), nr = rs.n();
+    if (nx == 0 || nr == 0) Py_RETURN_NONE;
+    int64_t xmin = INT64_MAX, xmax = INT64_MIN, smin = INT64_MAX, emax = INT64_MIN;
+    for (const I64View* X : {&x1, &x2}) for (Py_ssize_t i = 0; i < (X->held ? X->n() : 0); i++) { const int64_t v = X->p()[i]; xmin = v < xmin ? v : xmin; xmax = v > xmax ? v : xmax; }
+    for (Py_ssize_t i = 0; i < nr; i++) { const int64_t s = rs.p()[i], e = re.p()[i]; smin = s < smin ? s : smin; emax = e > emax ? e : emax; }
+    const int64_t lim = (int64_t)1 << 40;
+    if (xmin < 0 || smin < 0 || xmax >= lim || emax >= lim || margin >= lim) Py_RETURN_NONE;
+    const int64_t hi = (xmax > emax ? xmax : emax) + margin + ((int64_t)2 << shift);
+    if (hi >= lim) Py_RETURN_NONE;
+    const int64_t nb = (hi >> shift) + 2;
+    std::vector<int32_t> d;
+    try { d.assign((size_t)nb + 1, 0); } catch (...) { return PyErr_NoMemory(); }
+    // +1 at the first bin of a flagged range, -1 behind its last (a task has fewer than 2^31 signatures: csv_segment's int32 counts)
+    for (const I64View* X : {&x1, &x2}) for (Py_ssize_t i = 0; i < (X->held ? X->n() : 0); i++) {
+        const int64_t v = X->p()[i], lo = v - margin;
+        d[(size_t)((lo > 0 ? lo : 0) >> shift)] += 1;
+        d[(size_t)(((v + margin) >> shift) + 1)] -= 1;
+    }
+    // d[k] becomes the number of flagged bins in front of bin k
+    int32_t open = 0, count = 0;
+    for (int64_t k = 0; k < nb; k++) { open += d[(size_t)k]; d[(size_t)k] = count; count += open > 0; }
+    d[(size_t)nb] = count;
+    PyObject* out = PyBytes_FromStringAndSize(nullptr, nr);
+    if (!out) return nullptr;
+    unsigned char* m = (unsigned char*)PyBytes_AS_STRING(out);
+    for (Py_ssize_t i = 0; i < nr; i++) {
+        const int64_t s = rs.p()[i], e = re.p()[i] > s ? re.p()[i] : s;
+        int64_t b0 = s >> shift, b1 = e >> shift;
+        b0 = b0 < nb - 1 ? b0 : nb - 1; b1 = b1 < nb - 1 ? b1 : nb - 1;
+        m[i] = d[(size_t)b1 + 1] - d[(size_t)b0] > 0;
+    }
+    return out;
 }
 
 // bytes of the first `ncp` code points of the UTF-8 text p[0 .. n)
@@ -729,6 +968,7 @@ PyMethodDef kMethods[] = {
     {"column", column, METH_VARARGS, "column(seq, field) -> [x[field] for x in seq]"},
     {"pickle_table", pickle_table, METH_VARARGS, "pickle_table(buf, offset, width, int_fields, str_fields) -> None | (n, end, [int64 bytes], [(off bytes, len bytes)], all_ascii)"},
     {"span_intern", span_intern, METH_VARARGS, "span_intern(((buf, off, len, ids), ...)) -> (blob, off, len) of the distinct strings by first appearance"},
+    {"reads_near", reads_near, METH_VARARGS, "reads_near(pos1, pos2 | None, r_start, r_end, margin, shift) -> None | bytes: which reads can cover a window near a signature"},
     {"span_join", span_join, METH_VARARGS, "span_join(buf, off, len, picks, clips | None, out_len) -> bytes"},
     {"span_cplen", span_cplen, METH_VARARGS, "span_cplen(buf, off, len, out int32): len() of every string"},
     {"clip_join", clip_join, METH_VARARGS, "clip_join(table, picks, lens, out_len) -> bytes of table[picks[i]][:lens[i]] joined"},

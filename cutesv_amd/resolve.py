@@ -164,6 +164,18 @@ def _mapped(path):
         return None
 
 
+def _block_end(offsets, chrom, file_len):
+    """where the pickled block of `chrom` ends in its file: the blocks lie back to back (main script :817-857 dumps them one after
+    another and records where each begins), so the next larger offset of the index, or the end of the file.  A hint for the
+    walker's buffers, nothing more."""
+    try:
+        off = int(offsets[chrom])
+        later = [int(o) for o in offsets.values() if int(o) > off]
+        return min(later) if later else int(file_len)
+    except (TypeError, ValueError, KeyError):
+        return None
+
+
 def _store_for(work_dir, sigs_index, svtype, chrom, need_reads, gt_margin=None):
     """Signatures of ONE task as flat columns: the mmap'ed `<work_dir>cutesv_amd.cols/` if our rebuild step wrote it
     (shared by every task of the process), otherwise just this task's pickled list - and, when it genotypes, its
@@ -192,7 +204,9 @@ def _store_for(work_dir, sigs_index, svtype, chrom, need_reads, gt_margin=None):
             st = SigStore.from_task_pickles(svtype, chrom, sig_map, sigs_index[svtype][chrom],
                                             reads_map, sigs_index["reads"][chrom] if want_reads else None,
                                             gt_margin=None if os.environ.get("CUTESV_AMD_ALL_READS") else gt_margin,
-                                            reads_cache=cache, reads_key=key)
+                                            reads_cache=cache, reads_key=key,
+                                            sig_end=_block_end(sigs_index[svtype], chrom, len(sig_map)),
+                                            reads_end=_block_end(sigs_index["reads"], chrom, len(reads_map)) if want_reads else None)
             if st is not None:
                 return st
     with open("%s%s.pickle" % (work_dir, svtype), "rb") as f:

@@ -591,9 +591,140 @@ def test_pickle_walker_accepts_nothing_that_pickle_rejects():
                     signal.alarm(0)
                 both += ok_p
                 walker_only += not ok_p
+                if ok_p:                                       # accepted by both: the SAME table (the row-at-a-time path of the walker
+                    want = pickle.loads(b)                     # hands anything unusual back to its opcode loop - and must then agree)
+                    t = cn.pickle_table(b, 0, 6, (0, 1), (2, 3, 4, 5))
+                    assert t[0] == len(want)
+                    assert np.frombuffer(t[2][0], np.int64).tolist() == [int(r[0]) for r in want]
+                    assert np.frombuffer(t[2][1], np.int64).tolist() == [int(r[1]) for r in want]
+                    for k, (o, l) in zip((2, 3, 4, 5), t[3]):
+                        o, l = np.frombuffer(o, np.int64), np.frombuffer(l, np.int32)
+                        assert [b[int(x):int(x) + int(y)].decode("utf-8", "surrogatepass") for x, y in zip(o, l)] == [r[k] for r in want]
     finally:
         signal.signal(signal.SIGALRM, old)
     assert walker_only == 0 and both > 500, (walker_only, both)
+
+
+def test_pickle_walker_row_at_a_time_path_and_its_edges():
+    """pickle_table reads a row - MARK, fields, TUPLE - in one go and hands anything else back to its opcode loop: the table must
+    not depend on which of the two read a row.  Streams built by hand around the hand-over points: the last rows of a buffer (the
+    fast path wants 16 bytes of slack), a FRAME between two fields, BINPUT / LONG_BINPUT memo numbering (protocol 2), a name that
+    is a memo reference, LONG1 / BININT / BINFLOAT fields, a row of the wrong width in the middle, and every value of the end
+    hint (none, exact, short, far too long, beyond the buffer) - same table, byte for byte."""
+    import struct
+    from cutesv_amd import _cols_native as cn
+
+    def table(blob, width=5, ints=(0, 1), strs=(2, 3, 4), off=0, hint=None):
+        t = cn.pickle_table(blob, off, width, ints, strs) if hint is None else cn.pickle_table(blob, off, width, ints, strs, hint)
+        if t is None:
+            return None
+        return (t[0], t[1], [np.frombuffer(x, np.int64).tolist() for x in t[2]],
+                [[blob[int(o):int(o) + int(n)] for o, n in zip(np.frombuffer(a, np.int64), np.frombuffer(b, np.int32))] for a, b in t[3]], t[4])
+
+    def expect(rows, blob, strs=(2, 3, 4)):
+        return (len(rows), len(blob), [[int(r[0]) for r in rows], [int(r[1]) for r in rows]], [[r[k].encode("utf-8", "surrogatepass") for r in rows] for k in strs], True)
+
+    rng = np.random.default_rng(5)
+    chr1, kind = "chr1", "DEL"
+    rows = []
+    for i in range(5000):
+        pos = int(rng.integers(0, 1 << 31))
+        if i % 7 == 0:
+            pos = pos + 0.5                                       # BINFLOAT
+        if i % 11 == 0:
+            pos = int(rng.integers(1 << 33, 1 << 45))             # LONG1
+        rows.append((pos, int(rng.integers(-70000, 70000)), "read%d" % (i // 2), kind, chr1))
+    for i in range(0, 5000, 2):                                   # the same str OBJECT twice: the second row's name is a memo reference
+        rows[i + 1] = rows[i + 1][:2] + (rows[i][2],) + rows[i + 1][3:]
+    for proto in (2, 3, 4, 5):
+        blob = pickle.dumps(rows, protocol=proto)
+        want = expect(rows, blob)
+        assert table(blob) == want
+        for hint in (len(blob), len(blob) // 3, 10, len(blob) * 50, -5, 0):
+            assert table(blob, hint=hint) == want, (proto, hint)
+        pad = b"x" * 40
+        assert table(pad + blob + pad, off=40, hint=40 + len(blob))[2] == want[2]
+        # a list element that is not one of our rows, far into the stream: declined whichever path meets it
+        for bad in ((1, 2, "r", kind), (1, 2, 3, kind, chr1), (1, "x", "r", kind, chr1), (None, 2, "r", kind, chr1), (1, 2, ("r",), kind, chr1)):
+            assert table(pickle.dumps(rows[:3000] + [bad] + rows[3000:], protocol=proto)) is None, (proto, bad)
+    # by hand (protocol 2 opcodes): ] q0 ( rows... e .   with a FRAME between two fields, LONG_BINPUT, and a buffer that ends right
+    # behind STOP - the last rows of every buffer are read by the opcode loop
+    head = b"\x80\x02]q\x00("                                     # memo 0: the list; then the batch's MARK
+    first = b"(K\x07K\x08X\x02\x00\x00\x00r0q\x01X\x03\x00\x00\x00DELq\x02X\x01\x00\x00\x001q\x03tq\x04"      # memo 1 the name, 2 "DEL", 3 "1", 4 the tuple
+    stream, names, memo = head + first, [b"r0"], 5
+    for i in range(1, 300):
+        nm = b"name%d" % i
+        stream += b"(" + b"J" + struct.pack("<i", 100 + i) + (b"\x95" + struct.pack("<Q", 0) if i % 5 == 0 else b"") + b"M" + struct.pack("<H", i) + \
+                  b"X" + struct.pack("<I", len(nm)) + nm + ((b"r" + struct.pack("<I", memo)) if i % 3 == 0 else (b"q" + bytes([memo]))) + b"h\x02h\x03t"
+        memo += 1
+        if memo < 250 and i % 2:
+            stream += b"q" + bytes([memo])                        # the tuple memoized too (every other row)
+            memo += 1
+        names.append(nm)
+        if memo >= 250:
+            break
+    stream += b"e."
+    got = table(stream, strs=(2,))
+    ref = pickle.loads(stream)
+    assert got is not None and got[0] == len(ref) == len(names)
+    assert got[2] == [[r[0] for r in ref], [r[1] for r in ref]] and got[3] == [[r[2].encode() for r in ref]]
+    assert all(r[3] == "DEL" and r[4] == "1" for r in ref)
+    for cut in range(1, 40):                                      # truncated anywhere near the end: refused or declined, never a table
+        try:
+            assert cn.pickle_table(stream[:-cut], 0, 5, (0, 1), (2,)) is None
+        except ValueError:
+            pass
+
+
+def test_reads_near_is_its_numpy_statement():
+    """columns._reads_near (one C pass, `_cols_native.reads_near`) against the rule written out in numpy - the form it replaced:
+    a flag per 2^shift-bp bin of the union of [x - margin, x + margin] over the task's coordinates, a read stays iff a flagged bin
+    lies in [start, end]; None (keep every read) for empty inputs and for coordinates outside [0, 2^40)."""
+    from cutesv_amd.columns import _reads_near
+
+    def statement(pos1, pos2, r_start, r_end, margin, shift=10):
+        n = len(pos1)
+        if n == 0 or len(r_start) == 0:
+            return None
+        xs = pos1 if pos2 is None else np.concatenate([pos1, pos2])
+        hi = int(max(int(xs.max()), int(r_end.max()))) + margin + (2 << shift)
+        if not (int(xs.min()) >= 0 and int(r_start.min()) >= 0) or hi >= (1 << 40):
+            return None
+        nb = (hi >> shift) + 2
+        d = np.zeros(nb + 1, np.int64)
+        np.add.at(d, np.maximum(xs - margin, 0) >> shift, 1)
+        np.add.at(d, ((xs + margin) >> shift) + 1, -1)
+        cum = np.zeros(nb + 1, np.int64)
+        np.cumsum(np.cumsum(d[:-1]) > 0, out=cum[1:])
+        rb0 = np.minimum(r_start >> shift, nb - 1)
+        rb1 = np.minimum(np.maximum(r_end, r_start) >> shift, nb - 1)
+        return (cum[rb1 + 1] - cum[rb0]) > 0
+
+    rng = np.random.default_rng(3)
+    kept = []
+    for it in range(300):
+        span = (1 << 32) if it % 60 == 59 else int(rng.choice([5_000, 200_000, 3_000_000]))
+        n, nr = int(rng.integers(1, 400)), int(rng.integers(1, 3000))
+        pos1 = rng.integers(0, span, n)
+        pos2 = None if it % 3 else pos1 + rng.integers(0, 50_000, n)
+        r_start = rng.integers(0, span, nr)
+        r_end = r_start + rng.integers(-10, 40_000, nr)           # (an end in front of its start: counted as the start)
+        margin = int(rng.choice([0, 1, 50, 1000, 5000]))
+        shift = int(rng.choice([0, 4, 10, 13])) if span < (1 << 30) else 10
+        got, want = _reads_near(pos1, pos2, r_start, r_end, margin, shift), statement(pos1, pos2, r_start, r_end, margin, shift)
+        assert (got is None) == (want is None)
+        if want is not None:
+            assert got.dtype == np.bool_ and np.array_equal(got, want), it
+            kept.append(got.mean())
+    assert min(kept) < 0.05 and max(kept) > 0.95
+    z = np.zeros(0, np.int64)
+    one = np.array([5], np.int64)
+    assert _reads_near(z, None, one, one, 10) is None and _reads_near(one, None, z, z, 10) is None
+    assert _reads_near(np.array([-1]), None, one, one, 10) is None and _reads_near(one, None, np.array([-3]), one, 10) is None
+    assert _reads_near(np.array([1 << 40]), None, one, one, 10) is None and _reads_near(one, None, one, np.array([(1 << 40) - 5]), 10) is None
+    got = _reads_near(one, None, np.array([0, 5000]), np.array([10, 6000]), 100)
+    assert got.tolist() == [True, False]
+    got[0] = False                                                # (writable: from_task_pickles keeps one read of a block it would empty)
 
 
 def test_rebuild_staging_fill_equals_the_concatenated_columns(monkeypatch):
