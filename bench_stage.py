@@ -229,11 +229,12 @@ def main():
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--keep-dir", default=None)
     ap.add_argument("--devices", type=int, default=1, help="GPUs the pool's workers share (one broker each)")
+    ap.add_argument("--no-cold", action="store_true", help="skip the cold-broker and context-per-worker legs")
     a = ap.parse_args()
     import bench
     store, params, wl = bench.make_workload(a.workload, a.scale, 0)
     m = mode1_stage(a.workload, store, params, workers=tuple(int(x) for x in a.workers.split(",")), reference=not a.no_reference,
-                    reps=a.reps, keep_dir=a.keep_dir, devices=a.devices)
+                    reps=a.reps, keep_dir=a.keep_dir, devices=a.devices, cold_and_direct_at=0 if a.no_cold else 8)
     print(json.dumps(m))
 
 

@@ -155,40 +155,63 @@ def _sparse_blob(table, picks, n=None):
 class WalkedReads:
     """A chromosome's reads block (main script :733: (start, end, is_primary, read, chr) per row) as `pickle_table` leaves it:
     three integer columns and the (offset, length) spans of the two strings inside the mapped `reads.pickle`.  Flat arrays only,
-    so that one worker's walk can be handed to the others through shared memory (`to_bytes_views` / `from_buffer`)."""
-    FIELDS = (("start", np.int64), ("end", np.int64), ("primary", np.int64), ("name_off", np.int64), ("name_len", np.int32),
+    so that one worker's walk can be handed to the others through shared memory (`write_into` / `from_buffer`).  What is handed
+    over is no wider than it has to be: the primary flag as a byte (every consumer casts it to one), and the chromosome's span
+    ONCE when every row carries the same one - the block of a chromosome, as the main script writes it: 29 bytes a row, not 48."""
+    FIELDS = (("start", np.int64), ("end", np.int64), ("primary", np.uint8), ("name_off", np.int64), ("name_len", np.int32),
               ("chr_off", np.int64), ("chr_len", np.int32))
+    PER_BLOCK = ("chr_off", "chr_len")                        # one row instead of n when `one_chr`
 
-    def __init__(self, n, **cols):
+    def __init__(self, n, one_chr=False, **cols):
         self.n = int(n)
+        self.one_chr = bool(one_chr)
         for k, _ in self.FIELDS:
             setattr(self, k, cols[k])
+
+    def rows_of(self, k):
+        return min(self.n, 1) if (self.one_chr and k in self.PER_BLOCK) else self.n
 
     @classmethod
     def from_table(cls, rt):
         ints = [np.frombuffer(x, np.int64) for x in rt[2]]
         sp = [(np.frombuffer(o, np.int64), np.frombuffer(l, np.int32)) for o, l in rt[3]]
-        return cls(int(rt[0]), start=ints[0], end=ints[1], primary=ints[2], name_off=sp[0][0], name_len=sp[0][1], chr_off=sp[1][0], chr_len=sp[1][1])
+        n = int(rt[0])
+        co, cl = sp[1]
+        one = n > 0 and bool((co == co[0]).all()) and bool((cl == cl[0]).all())       # (a memo reference per row: the same bytes)
+        if one:
+            co, cl = co[:1], cl[:1]
+        return cls(n, one, start=ints[0], end=ints[1], primary=ints[2].astype(np.uint8), name_off=sp[0][0], name_len=sp[0][1], chr_off=co, chr_len=cl)
+
+    def chr_spans(self, sel=None):
+        """(offsets, lengths) of the chromosome field, a span per row (of the rows `sel`)"""
+        if self.one_chr:
+            m = self.n if sel is None else len(sel)
+            return np.repeat(self.chr_off, m), np.repeat(self.chr_len, m)
+        return (self.chr_off, self.chr_len) if sel is None else (self.chr_off.take(sel), self.chr_len.take(sel))
 
     def nbytes(self):
-        return 64 + sum((self.n * np.dtype(dt).itemsize + 63) // 64 * 64 for _, dt in self.FIELDS)
+        return 64 + sum((self.rows_of(k) * np.dtype(dt).itemsize + 63) // 64 * 64 for k, dt in self.FIELDS)
 
     def write_into(self, buf):
-        """lay the columns out in `buf` (a writable buffer of nbytes()): [n, 0...] then the columns, 64-byte aligned"""
-        np.frombuffer(buf, np.int64, 8)[:] = [self.n, 0, 0, 0, 0, 0, 0, 0]
+        """lay the columns out in `buf` (a writable buffer of nbytes()): [n, one_chr, 0...] then the columns, 64-byte aligned"""
+        np.frombuffer(buf, np.int64, 8)[:] = [self.n, int(self.one_chr), 0, 0, 0, 0, 0, 0]
         off = 64
         for k, dt in self.FIELDS:
-            np.frombuffer(buf, dt, self.n, off)[:] = getattr(self, k)
-            off += (self.n * np.dtype(dt).itemsize + 63) // 64 * 64
+            m = self.rows_of(k)
+            np.frombuffer(buf, dt, m, off)[:] = getattr(self, k)
+            off += (m * np.dtype(dt).itemsize + 63) // 64 * 64
 
     @classmethod
     def from_buffer(cls, buf):
-        n = int(np.frombuffer(buf, np.int64, 1)[0])
-        off, cols = 64, {}
+        n, one = (int(x) for x in np.frombuffer(buf, np.int64, 2))
+        self = cls.__new__(cls)
+        self.n, self.one_chr = n, bool(one)
+        off = 64
         for k, dt in cls.FIELDS:
-            cols[k] = np.frombuffer(buf, dt, n, off)
-            off += (n * np.dtype(dt).itemsize + 63) // 64 * 64
-        return cls(n, **cols)
+            m = self.rows_of(k)
+            setattr(self, k, np.frombuffer(buf, dt, m, off))
+            off += (m * np.dtype(dt).itemsize + 63) // 64 * 64
+        return self
 
 
 def _reads_near(pos1, pos2, r_start, r_end, margin, shift=10):
@@ -681,19 +704,24 @@ class SigStore:
         rd = []
         if nr:
             r_start, r_end, r_primary = wr.start, wr.end, wr.primary
-            rsp = [(wr.name_off, wr.name_len), (wr.chr_off, wr.chr_len)]
+            r_name = (wr.name_off, wr.name_len)
+            sel = None
             if gt_margin is not None and n:
                 keep = _reads_near(a, b if svtype in ("DUP", "INV") else None, r_start, r_end, int(gt_margin))
                 if keep is not None:
                     if not keep.any():
                         keep[0] = True                      # (a block with reads stays a block with reads: DR = 0, not "no reads block")
-                    sel = np.flatnonzero(keep)                # (one index list, seven takes: a boolean mask is re-scanned by every column)
+                    sel = np.flatnonzero(keep)                # (one index list, a take per column: a boolean mask is re-scanned by every column)
                     r_start, r_end, r_primary = r_start.take(sel), r_end.take(sel), r_primary.take(sel)
-                    rsp = [(o.take(sel), l.take(sel)) for o, l in rsp]
+                    r_name = (r_name[0].take(sel), r_name[1].take(sel))
                     nr = len(r_start)
             r_id = np.empty(nr, np.int32)
-            spec.append((reads_buf, rsp[0][0], rsp[0][1], r_id))
-            rd, r_chr = small(reads_buf, rsp[1])
+            spec.append((reads_buf, r_name[0], r_name[1], r_id))
+            if wr.one_chr:                                    # (the block of one chromosome: its name read once)
+                o0, l0 = int(wr.chr_off[0]), int(wr.chr_len[0])
+                rd, r_chr = [bytes(memoryview(reads_buf)[o0:o0 + l0]).decode("utf-8", "surrogatepass")], None
+            else:
+                rd, r_chr = small(reads_buf, wr.chr_spans(sel))
         blob, uo, ul = cn.span_intern(tuple(spec))          # read names of the signatures, then of the reads, ONE id space
         uniq = SpanList(blob, np.frombuffer(uo, np.int64), np.frombuffer(ul, np.int32))
         cs = {chrom}
@@ -706,11 +734,11 @@ class SigStore:
             tlut = np.array([BND_CODE.get(t_, 4) for t_ in td], np.int32)
             aux = clut[c_id] * 8 + tlut[t_id]
         if nr:
-            rc = np.array([crank[c] for c in rd], np.int64)[r_chr]
             if len(rd) == 1:                                # (the usual block: one chromosome - nothing to regroup)
                 kw = dict(reads_off=np.array([0, nr] if crank[rd[0]] == 0 else [0] * (crank[rd[0]] + 1) + [nr] * (len(chroms) - crank[rd[0]]), np.int64),
                           r_start=r_start, r_end=r_end, r_primary=r_primary.astype(np.uint8), r_id=r_id)
             else:
+                rc = np.array([crank[c] for c in rd], np.int64)[r_chr]
                 o = np.argsort(rc, kind="stable")
                 kw = dict(reads_off=np.searchsorted(rc[o], np.arange(len(chroms) + 1)).astype(np.int64),
                           r_start=r_start[o], r_end=r_end[o], r_primary=r_primary[o].astype(np.uint8), r_id=r_id[o])

@@ -676,6 +676,61 @@ def test_pickle_walker_row_at_a_time_path_and_its_edges():
             pass
 
 
+def test_walked_reads_block_round_trips_through_shared_memory(tmp_path):
+    """columns.WalkedReads - a chromosome's reads block as the workers of a pool hand it round (broker.Client.reads_put / reads_get):
+    laid out in a buffer and read back it is the same block, with the chromosome span kept once when every row carries the same
+    one (29 bytes a row) and per row otherwise; a task store built from a block that went through the buffer is the store built
+    from the walk itself, with and without the reads-near-a-window filter."""
+    from cutesv_amd import _cols_native as cn
+    from cutesv_amd.columns import WalkedReads
+    rng = np.random.default_rng(9)
+    names = ["read%d" % i for i in range(300)]
+    sigs = [(int(p_), 50 + i % 7, names[int(rng.integers(0, 300))], "DEL", "chr1") for i, p_ in enumerate(np.sort(rng.integers(1000, 900_000, 400)))]
+    for n_chr in (1, 2):
+        c = ["chr1", "chr2"]
+        reads = [(int(s_), int(s_) + int(rng.integers(100, 30_000)), bool(i % 5), names[int(rng.integers(0, 300))], c[(i % 4 == 0) * (n_chr - 1)])
+                 for i, s_ in enumerate(np.sort(rng.integers(0, 1_000_000, 3000)))]
+        rblob, sblob = pickle.dumps(reads, protocol=4), pickle.dumps(sigs, protocol=4)
+        wr = WalkedReads.from_table(cn.pickle_table(rblob, 0, 5, (0, 1, 2), (3, 4)))
+        assert wr.n == 3000 and wr.one_chr == (n_chr == 1) and len(wr.chr_off) == (1 if n_chr == 1 else 3000)
+        assert wr.nbytes() < 3000 * (30 if n_chr == 1 else 42) + 64 * 8
+        buf = bytearray(wr.nbytes())
+        wr.write_into(buf)
+        back = WalkedReads.from_buffer(bytes(buf))
+        assert back.n == wr.n and back.one_chr == wr.one_chr
+        for k, dt in WalkedReads.FIELDS:
+            assert getattr(back, k).dtype == dt and np.array_equal(getattr(back, k), getattr(wr, k)), k
+        sel = np.array([0, 5, 2999])
+        o, l = back.chr_spans(sel)
+        assert [rblob[int(x):int(x) + int(y)].decode() for x, y in zip(o, l)] == [reads[int(i)][4] for i in sel]
+        assert [len(x) for x in back.chr_spans()] == [3000, 3000]
+
+        class Shelf:                                             # what broker.Client offers: the block comes back out of a buffer
+            def __init__(self):
+                self.d = {}
+
+            def reads_get(self, key):
+                return WalkedReads.from_buffer(self.d[key]) if key in self.d else None
+
+            def reads_put(self, key, w):
+                b = bytearray(w.nbytes())
+                w.write_into(b)
+                self.d[key] = bytes(b)
+        for margin in (None, 1000):
+            shelf = Shelf()
+            direct = SigStore.from_task_pickles("DEL", "chr1", sblob, 0, rblob, 0, gt_margin=margin)
+            first = SigStore.from_task_pickles("DEL", "chr1", sblob, 0, rblob, 0, gt_margin=margin, reads_cache=shelf, reads_key="k")
+            again = SigStore.from_task_pickles("DEL", "chr1", sblob, 0, rblob, 0, gt_margin=margin, reads_cache=shelf, reads_key="k")
+            assert list(shelf.d) == ["k"]
+            _same_store(first, direct)
+            _same_store(again, direct)
+            want = SigStore.from_task_lists("DEL", "chr1", sigs, reads)
+            if margin is None:
+                _same_store(direct, want)
+            else:
+                assert 0 < direct.n_reads < want.n_reads
+
+
 def test_reads_near_is_its_numpy_statement():
     """columns._reads_near (one C pass, `_cols_native.reads_near`) against the rule written out in numpy - the form it replaced:
     a flag per 2^shift-bp bin of the union of [x - margin, x + margin] over the task's coordinates, a read stays iff a flagged bin
