@@ -19,7 +19,6 @@
 #include <Python.h>
 #include <stdint.h>
 #include <string.h>
-#include <sys/mman.h>
 #include <vector>
 
 namespace {
@@ -377,19 +376,6 @@ inline uint64_t le64(const unsigned char* q) { return (uint64_t)le32(q) | (uint6
 
 // the memo (and nothing else): plain records in a block that grows by realloc - for the 12 M entries of a HiFi chromosome's reads
 // block that is a remap of pages, not the copy a std::vector makes at every doubling
-// A block that has just grown by megabytes and is about to be written front to back: have the kernel map its new pages in one
-// call (MADV_POPULATE_WRITE, Linux 5.14) instead of taking a fault per 4 KB page - ~1.4 us apiece on the pool's (virtual) machines,
-// 170 ms for the 0.5 GB of columns and memo of a HiFi chromosome's reads block.  Advice only: an older kernel refuses, nothing changes.
-#ifndef MADV_POPULATE_WRITE
-#define MADV_POPULATE_WRITE 23
-#endif
-inline void grown(void* p, size_t old_bytes, size_t bytes)
-{
-    if (bytes < old_bytes + (4u << 20)) return;
-    const uintptr_t a = ((uintptr_t)p + old_bytes + 4095) & ~(uintptr_t)4095, e = ((uintptr_t)p + bytes) & ~(uintptr_t)4095;
-    if (e > a) (void)madvise((void*)a, e - a, MADV_POPULATE_WRITE);
-}
-
 template <class T> struct Pod {
     T* p = nullptr; size_t n = 0, cap = 0;
     ~Pod() { free(p); }
@@ -399,7 +385,6 @@ template <class T> struct Pod {
             const size_t c = cap ? cap * 2 : 4096;
             T* q = (T*)realloc(p, c * sizeof(T));
             if (!q) return false;
-            grown(q, cap * sizeof(T), c * sizeof(T));
             p = q; cap = c;
         }
         p[n++] = x;
@@ -421,7 +406,6 @@ struct Columns {
             if (!o[k]) { o[k] = PyBytes_FromStringAndSize(nullptr, (Py_ssize_t)(rows * (size_t)item[k])); if (!o[k]) return false; }
             else if (_PyBytes_Resize(&o[k], (Py_ssize_t)(rows * (size_t)item[k])) != 0) return false;      // (o[k] is NULL then, the error set)
             base[k] = PyBytes_AS_STRING(o[k]);
-            grown(base[k], cap * (size_t)item[k], rows * (size_t)item[k]);
         }
         cap = rows;
         return true;
@@ -761,39 +745,67 @@ PyObject* span_intern(PyObject*, PyObject* args)
     }
     size_t cap = 64;
     while (cap < (size_t)total * 2 + 8) cap <<= 1;
-    std::vector<int32_t> slot(cap, -1);
-    struct U { const char* p; int32_t n; uint64_t h; };
-    std::vector<U> uniq;
-    uniq.reserve((size_t)total / 2 + 8);
+    // a slot keeps 32 bits of the hash beside the id: a probe that passes somebody else's entry never leaves the table
+    struct Slot { uint32_t tag; int32_t id; };
+    struct U { const char* p; int32_t n; };
+    // the scratch outlives the call (one call at a time, under the interpreter lock): a worker interns task after task of about
+    // the same size, and fresh pages cost more than the probes (1.4 us a page on the pool's virtual machines; ~5 MB a task).
+    // What has grown beyond 64 MB is given back at the end.
+    static std::vector<Slot> slot;
+    static std::vector<U> uniq;
+    static std::vector<uint64_t> hs;
+    struct Trim {
+        ~Trim()
+        {
+            if (slot.capacity() * sizeof(Slot) > (64u << 20)) std::vector<Slot>().swap(slot);
+            if (uniq.capacity() * sizeof(U) > (64u << 20)) std::vector<U>().swap(uniq);
+            if (hs.capacity() * 8 > (64u << 20)) std::vector<uint64_t>().swap(hs);
+        }
+    } trim;
+    slot.assign(cap, Slot{0, -1});
+    uniq.clear();
     int64_t blob_bytes = 0;
     for (Py_ssize_t k = 0; k < ns; k++) {
         const SpanArgs& S = sp[(size_t)k];
         int32_t* out = (int32_t*)ids[(size_t)k].v.buf;
-        const char* prev_p = nullptr; int32_t prev_n = -1, prev_id = -1;
-        const Py_ssize_t AHEAD = 12;                                 // (the kept reads of a task lie scattered over a 0.2 GB file: a miss per name)
-        for (Py_ssize_t i = 0; i < S.n(); i++) {
-            const char* p; int32_t n;
-            if (i + AHEAD < S.n()) {
-                const int64_t o = ((const int64_t*)S.off.buf)[i + AHEAD];
+        const Py_ssize_t m = S.n();
+        // Two passes, each with its misses asked for ahead of time: the hashes (the payloads - the kept reads of a task lie
+        // scattered over a 0.2 GB file - fetched 12 names ahead), then the table (a name's first slot fetched 8 names ahead).
+        // One name at a time, miss after miss, this was 60-75 ns a name; a task of a 30x genome has 10^5 of them.
+        hs.resize((size_t)m);
+        for (Py_ssize_t i = 0; i < m; i++) {
+            if (i + 12 < m) {
+                const int64_t o = ((const int64_t*)S.off.buf)[i + 12];
                 if (o >= 0 && o < S.buf.len) __builtin_prefetch((const char*)S.buf.buf + o);
             }
+            const char* p; int32_t n;
+            if (!S.span(i, p, n)) return nullptr;
+            hs[(size_t)i] = hash_bytes(p, n);
+        }
+        const char* prev_p = nullptr; int32_t prev_n = -1, prev_id = -1;
+        for (Py_ssize_t i = 0; i < m; i++) {
+            if (i + 8 < m) __builtin_prefetch(&slot[(size_t)(hs[(size_t)i + 8] >> 7) & (cap - 1)]);
+            const char* p; int32_t n;
             if (!S.span(i, p, n)) return nullptr;
             // the SAME bytes as the row before - a memo reference of the pickle: the chromosome of every row of a reads block, the
-            // "DEL" of every signature - need no hash
+            // "DEL" of every signature - need no probe
             if (p == prev_p && n == prev_n) { out[i] = prev_id; continue; }
-            const uint64_t h = hash_bytes(p, n);
+            const uint64_t h = hs[(size_t)i];
+            const uint32_t tag = (uint32_t)(h >> 32);
             size_t q = (size_t)(h >> 7) & (cap - 1);
             int32_t id = -1;
             for (;; q = (q + 1) & (cap - 1)) {
-                const int32_t u = slot[q];
-                if (u < 0) break;
-                const U& x = uniq[(size_t)u];
-                if (x.h == h && x.n == n && memcmp(x.p, p, (size_t)n) == 0) { id = u; break; }
+                const Slot e = slot[q];
+                if (e.id < 0) break;
+                if (e.tag != tag) continue;
+                const U& x = uniq[(size_t)e.id];
+                if (x.n == n && memcmp(x.p, p, (size_t)n) == 0) { id = e.id; break; }
             }
             if (id < 0) {
                 if (uniq.size() >= (size_t)INT32_MAX) { PyErr_SetString(PyExc_OverflowError, "span_intern: more than 2^31 distinct values"); return nullptr; }
-                slot[q] = id = (int32_t)uniq.size();
-                uniq.push_back(U{p, n, h});
+                id = (int32_t)uniq.size();
+                slot[q] = Slot{tag, id};
+                uniq.push_back(U{p, n});
                 blob_bytes += n;
             }
             out[i] = id;
