@@ -731,6 +731,17 @@ def test_walked_reads_block_round_trips_through_shared_memory(tmp_path):
                 assert 0 < direct.n_reads < want.n_reads
 
 
+def test_block_end_is_the_next_offset_of_the_index():
+    """resolve._block_end: the walker's size hint - where a chromosome's pickled block ends in its file (the blocks lie back to
+    back, main script :817-857): the next larger offset of the index, the file's end for the last block, None when the index does
+    not hold integers (the walker then doubles its buffers as before)"""
+    from cutesv_amd import resolve
+    idx = {"2": 700, "1": 0, "X": 1900, "10": 1200}                # (in file order: 1, 2, 10, X - not in key order)
+    assert [resolve._block_end(idx, c, 2500) for c in ("1", "2", "10", "X")] == [700, 1200, 1900, 2500]
+    assert resolve._block_end({"1": 0}, "1", 0) == 0 and resolve._block_end(idx, "nope", 10) is None
+    assert resolve._block_end({"1": "zero"}, "1", 10) is None and resolve._block_end({"1": 0, "2": None}, "1", 10) is None
+
+
 def test_reads_near_is_its_numpy_statement():
     """columns._reads_near (one C pass, `_cols_native.reads_near`) against the rule written out in numpy - the form it replaced:
     a flag per 2^shift-bp bin of the union of [x - margin, x + margin] over the task's coordinates, a read stays iff a flagged bin
