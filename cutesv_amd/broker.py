@@ -241,8 +241,7 @@ class Client:
         fd = os.memfd_create("cutesv_amd_reads", 0)
         try:
             os.ftruncate(fd, size)
-            with mmap.mmap(fd, size) as mm:
-                wr.write_into(mm)
+            wr.write_fd(fd)
             self._request(K_PUT, struct.pack("<Q", size) + repr(key).encode(), fds=(fd,))
         except (OSError, BrokerError):
             pass                                          # (a cache: failing to share a block loses nothing but time)

@@ -201,6 +201,19 @@ class WalkedReads:
             np.frombuffer(buf, dt, m, off)[:] = getattr(self, k)
             off += (m * np.dtype(dt).itemsize + 63) // 64 * 64
 
+    def write_fd(self, fd):
+        """the same layout written into a file of nbytes() (a fresh memfd: the gaps between the columns stay holes, i.e. zeros) with
+        one pwrite per column: the kernel copies straight into new pages, where a store through a mapping first takes a fault per
+        4 KB page and zeroes it (8 blocks of a HiFi genome, 89 MB: 39 ms against 90)"""
+        import os
+        os.pwrite(fd, np.array([self.n, int(self.one_chr), 0, 0, 0, 0, 0, 0], np.int64), 0)
+        off = 64
+        for k, dt in self.FIELDS:
+            m = self.rows_of(k)
+            if m:
+                os.pwrite(fd, memoryview(np.ascontiguousarray(getattr(self, k), dt)).cast("B"), off)
+            off += (m * np.dtype(dt).itemsize + 63) // 64 * 64
+
     @classmethod
     def from_buffer(cls, buf):
         n, one = (int(x) for x in np.frombuffer(buf, np.int64, 2))

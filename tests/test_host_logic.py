@@ -698,6 +698,13 @@ def test_walked_reads_block_round_trips_through_shared_memory(tmp_path):
         wr.write_into(buf)
         back = WalkedReads.from_buffer(bytes(buf))
         assert back.n == wr.n and back.one_chr == wr.one_chr
+        fd = os.memfd_create("walked", 0)                         # what reads_put does: the same bytes, written column by column
+        try:
+            os.ftruncate(fd, wr.nbytes())
+            wr.write_fd(fd)
+            assert os.pread(fd, wr.nbytes() + 1, 0) == bytes(buf)
+        finally:
+            os.close(fd)
         for k, dt in WalkedReads.FIELDS:
             assert getattr(back, k).dtype == dt and np.array_equal(getattr(back, k), getattr(wr, k)), k
         sel = np.array([0, 5, 2999])
