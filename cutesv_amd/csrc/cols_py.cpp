@@ -464,12 +464,14 @@ PyObject* pickle_table(PyObject*, PyObject* args)
         for (size_t k = 0; k < NS; k++) if ((size_t)fs[k] >= c || x[(size_t)fs[k]].kind != STR) return false;
         if ((size_t)n_rows == C.cap) {
             // full: twice the rows - or, when the caller has said where the block ends (the next offset of the index), the rows the
-            // rest of it will hold at the bytes per row seen so far (+ 3 %): ONE growth, no copy of a column at every doubling
+            // rest of it will hold at the bytes per row seen so far (+ 3 %), in steps of at most eight times what is already there:
+            // a few growths instead of one per doubling, and a hint that is wrong (the end of a 50 GB file for a block in its
+            // middle) can ask for eight times too much address space, never for more than the machine has
             size_t want = C.cap * 2;
             if (end_hint > R.i && end_hint <= R.n && n_rows >= 1024 && R.i > (int64_t)offset) {
                 const double per_row = (double)(R.i - (int64_t)offset) / (double)n_rows;
                 const double est = (double)n_rows + (double)(end_hint - R.i) / per_row * 1.03 + 1024.0;
-                if (est > (double)want && est < 4e9) want = (size_t)est;
+                if (est > (double)want) want = est < (double)(C.cap * 8) ? (size_t)est : C.cap * 8;
             }
             if (!C.reserve(want)) { oom = true; return false; }                       // (what the block needs is what doubling would reach, too)
         }
