@@ -662,7 +662,7 @@ class SigStore:
         `reads_get(key) -> WalkedReads | None` and `reads_put(key, WalkedReads)` (broker.Client: the GPU's broker keeps the blocks
         in shared memory for the pool's workers).
         sig_end / reads_end: where the block ends in its file, if the caller knows (the next offset of `sigindex.pickle`): the walker
-        then sizes its columns once instead of doubling them (a hint - a wrong one costs memory or time, never a row)."""
+        then sizes its columns in a few steps instead of doubling them (a hint - a wrong one costs memory or time, never a row)."""
         from . import _cols_native as cn                     # (built by the same make as the library; no Python fallback)
         ints, strs, width = {"DEL": ((0, 1), (2,), 5), "DUP": ((0, 1), (2,), 5), "INS": ((0, 1), (2, 3), 6),
                              "INV": ((1, 2), (0, 3), 6), "TRA": ((1, 3), (0, 2, 4), 7)}[svtype]

@@ -393,7 +393,7 @@ template <class T> struct Pod {
 };
 
 // The table's columns ARE the bytes objects pickle_table returns: written in place, grown together (one capacity check per row)
-// through _PyBytes_Resize - realloc underneath - and cut to the row count at the end.  (r05: a std::vector per column, copied at
+// through _PyBytes_Resize - realloc underneath - in a few steps when the caller knows where the block ends, and cut to the row count.  (r05: a std::vector per column, copied at
 // every doubling and once more into its bytes object - 0.3 GB of extra traffic for a 6 M-row reads block.)
 struct Columns {
     std::vector<PyObject*> o; std::vector<int> item; std::vector<char*> base;
