@@ -41,6 +41,16 @@ def main():
     for T in [int(x) for x in a.workers.split(",")]:
         print("== T=%d: no-op pool of %d tasks %.1f ms" % (T, n_tasks, min(pr.pool_startup_seconds(T, n_tasks) for _ in range(3)) * 1e3))
         for rep in range(2):
+            if rep == 0:
+                # the first repetition of every T is the stage a cuteSV run has: nothing on the broker's shelf; the second one finds
+                # every walked reads block there (what the tasks cost when nobody has to walk a block)
+                try:
+                    from cutesv_amd import broker
+                    for d in bench_stage._devices():
+                        with broker.Client.connect(d, owner_pid=os.getpid(), spawn=False) as cl:
+                            cl.reads_flush()
+                except Exception:                          # noqa: BLE001  (no broker to flush: the stage will say so itself)
+                    pass
             tl = tempfile.mkdtemp(prefix="tl_")
             os.environ["CUTESV_AMD_TIMELINE"] = tl
             b0 = bench_stage._broker_info() or {}
@@ -58,8 +68,8 @@ def main():
             store_ms = sum(r[5] - r[4] for r in rows) * 1e3
             call_ms = sum(r[7] - r[6] for r in rows) * 1e3
             rows_ms = sum(r[8] - r[7] for r in rows) * 1e3
-            print("   wall %.1f ms | first task starts %.1f, last ends %.1f | sum over tasks: store %.1f, call %.1f, rows %.1f ms | workers used %d"
-                  % ((t1 - t0) * 1e3, rows[0][4] * 1e3, max(r[8] for r in rows) * 1e3, store_ms, call_ms, rows_ms, len({r[9] for r in rows})))
+            print("   [%s] wall %.1f ms | first task starts %.1f, last ends %.1f | sum over tasks: store %.1f, call %.1f, rows %.1f ms | workers used %d"
+                  % ("empty shelf" if rep == 0 else "blocks shared", (t1 - t0) * 1e3, rows[0][4] * 1e3, max(r[8] for r in rows) * 1e3, store_ms, call_ms, rows_ms, len({r[9] for r in rows})))
             big = sorted(rows, key=lambda r: -(r[8] - r[4]))[:4]
             for r in big:
                 print("      %s %s n=%d reads=%d: start %.1f store %.1f call %.1f rows %.1f ms" % (r[0], r[1], r[2], r[3], r[4] * 1e3, (r[5] - r[4]) * 1e3, (r[7] - r[6]) * 1e3, (r[8] - r[7]) * 1e3))
